@@ -1,0 +1,274 @@
+"""ctypes binding of oracle/liboracle.so — TEST INFRASTRUCTURE ONLY (never imported by the product)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from stvo_amd.ctypes_types import Cam, GridWindow, MatchParams, OptParams, PoseResult
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+
+u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+
+
+class Matched(C.Structure):
+    _fields_ = [("np", C.c_int), ("P", C.c_void_p), ("pl_obs", C.c_void_p), ("sigma2p", C.c_void_p),
+                ("inlier_p", C.c_void_p), ("nl", C.c_int), ("sP", C.c_void_p), ("eP", C.c_void_p),
+                ("le_obs", C.c_void_p), ("spl", C.c_void_p), ("epl", C.c_void_p), ("sigma2l", C.c_void_p),
+                ("inlier_l", C.c_void_p)]
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Oracle:
+    def __init__(self, lib):
+        self.lib = lib
+        L = lib
+        L.orc_distance.argtypes = [u8p, u8p]; L.orc_distance.restype = C.c_int
+        L.orc_knn2.argtypes = [u8p, C.c_int, u8p, C.c_int, i32p, i32p, i32p]; L.orc_knn2.restype = None
+        L.orc_match_nnr.argtypes = [u8p, C.c_int, u8p, C.c_int, C.c_float, i32p]; L.orc_match_nnr.restype = C.c_int
+        L.orc_match.argtypes = [u8p, C.c_int, u8p, C.c_int, C.c_float, C.c_int, i32p]; L.orc_match.restype = C.c_int
+        L.orc_grid_build.argtypes = [i32p, C.c_void_p, C.c_int, i32p, i32p]; L.orc_grid_build.restype = None
+        L.orc_line_coords.argtypes = [C.c_double] * 4 + [i32p, C.c_int]; L.orc_line_coords.restype = C.c_int
+        L.orc_grid_window_gather.argtypes = [i32p, i32p, C.c_int, C.c_int, C.POINTER(GridWindow), i32p, u8p]
+        L.orc_grid_window_gather.restype = C.c_int
+        L.orc_match_grid_points.argtypes = [i32p, u8p, C.c_int, i32p, i32p, u8p, C.c_int, C.POINTER(GridWindow),
+                                            C.c_double, C.c_int, i32p]
+        L.orc_match_grid_points.restype = C.c_int
+        L.orc_match_grid_lines.argtypes = [i32p, u8p, C.c_int, i32p, i32p, u8p, C.c_int, f64p, C.POINTER(GridWindow),
+                                           C.c_double, C.c_double, C.c_int, i32p]
+        L.orc_match_grid_lines.restype = C.c_int
+        L.orc_stereo_points.argtypes = [f32p, i32p, u8p, C.c_int, f32p, u8p, C.c_int, C.c_int, C.c_int, C.POINTER(Cam),
+                                        C.POINTER(MatchParams), i32p, f64p, f64p, f64p, f64p, C.c_void_p]
+        L.orc_stereo_points.restype = C.c_int
+        L.orc_stereo_lines.argtypes = [f32p, f32p, i32p, u8p, C.c_int, f32p, u8p, C.c_int, C.c_int, C.c_int,
+                                       C.POINTER(Cam), C.POINTER(MatchParams), i32p, f64p, f64p, f64p, f64p, f64p, f64p,
+                                       f64p, f64p, C.c_void_p]
+        L.orc_stereo_lines.restype = C.c_int
+        for name, nin, nout in [("orc_expmap_se3", 6, 16), ("orc_logmap_se3", 16, 6), ("orc_inverse_se3", 16, 16),
+                                ("orc_adjoint_se3", 16, 36), ("orc_inverse6", 36, 36), ("orc_eig6", 36, 6)]:
+            getattr(L, name).argtypes = [f64p, f64p]; getattr(L, name).restype = None
+        L.orc_unccomp_se3.argtypes = [f64p, f64p, f64p, f64p]; L.orc_unccomp_se3.restype = None
+        L.orc_solve6.argtypes = [f64p, f64p, f64p, C.POINTER(C.c_double)]; L.orc_solve6.restype = C.c_int
+        L.orc_mean_stdv_mad.argtypes = [f64p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.orc_mean_stdv_mad.restype = None
+        L.orc_stdv_mad.argtypes = [f64p, C.c_int]; L.orc_stdv_mad.restype = C.c_double
+        L.orc_line_overlap.argtypes = [f64p] * 4; L.orc_line_overlap.restype = C.c_double
+        L.orc_line_overlap_stereo.argtypes = [C.c_double] * 5; L.orc_line_overlap_stereo.restype = C.c_double
+        L.orc_is_good_solution.argtypes = [f64p, f64p, C.c_double]; L.orc_is_good_solution.restype = C.c_int
+        L.orc_optimize_functions.argtypes = [f64p, C.POINTER(Cam), C.POINTER(OptParams), C.POINTER(Matched), C.c_int,
+                                             f64p, f64p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
+        L.orc_optimize_functions.restype = None
+        L.orc_remove_outliers.argtypes = [f64p, C.POINTER(Cam), C.POINTER(OptParams), C.POINTER(Matched),
+                                          C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.orc_remove_outliers.restype = None
+        L.orc_optimize_pose.argtypes = [f64p, C.POINTER(Cam), C.POINTER(OptParams), C.POINTER(Matched),
+                                        C.POINTER(PoseResult)]
+        L.orc_optimize_pose.restype = None
+
+    # ---- matching ----
+    def distance(self, a, b):
+        return self.lib.orc_distance(np.ascontiguousarray(a), np.ascontiguousarray(b))
+
+    def knn2(self, q, t):
+        nq = len(q)
+        i0 = np.empty(nq, np.int32); d0 = np.empty(nq, np.int32); d1 = np.empty(nq, np.int32)
+        self.lib.orc_knn2(q, nq, t, len(t), i0, d0, d1)
+        return i0, d0, d1
+
+    def match_nnr(self, d1, d2, nnr):
+        m12 = np.empty(max(len(d1), 1), np.int32)
+        n = self.lib.orc_match_nnr(d1, len(d1), d2, len(d2), nnr, m12)
+        return m12[:len(d1)], n
+
+    def match(self, d1, d2, nnr, best_lr=1):
+        m12 = np.empty(max(len(d1), 1), np.int32)
+        n = self.lib.orc_match(d1, len(d1), d2, len(d2), nnr, best_lr, m12)
+        return m12[:len(d1)], n
+
+    def grid_build(self, cell_xy, owner=None):
+        cell_xy = np.ascontiguousarray(cell_xy, np.int32).reshape(-1, 2)
+        n = len(cell_xy)
+        start = np.empty(64 * 48 + 1, np.int32)
+        items = np.empty(max(n, 1), np.int32)
+        own = None if owner is None else np.ascontiguousarray(owner, np.int32)
+        self.lib.orc_grid_build(cell_xy, None if own is None else _ptr(own), n, start, items)
+        return start, items[:start[-1]].copy()
+
+    def line_coords(self, x1, y1, x2, y2, cap=256):
+        out = np.empty((cap, 2), np.int32)
+        n = self.lib.orc_line_coords(x1, y1, x2, y2, out.reshape(-1), cap)
+        return out[:n].copy()
+
+    def window_gather(self, start, items, x, y, w, n2):
+        out = np.empty(max(len(items), 1), np.int32)
+        seen = np.zeros(n2 + 1, np.uint8)
+        gw = GridWindow(*w)
+        items_ = items if len(items) else np.zeros(1, np.int32)
+        n = self.lib.orc_grid_window_gather(start, items_, x, y, C.byref(gw), out, seen)
+        return out[:n].copy()
+
+    def match_grid_points(self, cell_xy1, d1, start, items, d2, w, ratio, best_lr=1):
+        n1 = len(d1)
+        m12 = np.empty(max(n1, 1), np.int32)
+        gw = GridWindow(*w)
+        items_ = items if len(items) else np.zeros(1, np.int32)
+        n = self.lib.orc_match_grid_points(np.ascontiguousarray(cell_xy1, np.int32).reshape(-1), d1, n1, start, items_,
+                                           d2, len(d2), C.byref(gw), ratio, best_lr, m12)
+        return m12[:n1], n
+
+    def match_grid_lines(self, cell_xy1, d1, start, items, d2, dir2, w, ratio, line_sim_th, best_lr=1):
+        n1 = len(d1)
+        m12 = np.empty(max(n1, 1), np.int32)
+        gw = GridWindow(*w)
+        items_ = items if len(items) else np.zeros(1, np.int32)
+        n = self.lib.orc_match_grid_lines(np.ascontiguousarray(cell_xy1, np.int32).reshape(-1), d1, n1, start, items_,
+                                          d2, len(d2), np.ascontiguousarray(dir2, np.float64).reshape(-1),
+                                          C.byref(gw), ratio, line_sim_th, best_lr, m12)
+        return m12[:n1], n
+
+    def stereo_points(self, kp_l, oct_l, desc_l, kp_r, desc_r, cols, rows, cam, mp):
+        nl = len(kp_l)
+        src = np.empty(max(nl, 1), np.int32); pl = np.empty((max(nl, 1), 2)); disp = np.empty(max(nl, 1))
+        P = np.empty((max(nl, 1), 3)); s2 = np.empty(max(nl, 1)); raw = np.empty(max(nl, 1), np.int32)
+        camc = Cam.from_dict(cam)
+        k = self.lib.orc_stereo_points(np.ascontiguousarray(kp_l, np.float32).reshape(-1), np.ascontiguousarray(oct_l, np.int32),
+                                       desc_l, nl, np.ascontiguousarray(kp_r, np.float32).reshape(-1), desc_r, len(kp_r),
+                                       cols, rows, C.byref(camc), C.byref(mp), src, pl.reshape(-1), disp, P.reshape(-1),
+                                       s2, _ptr(raw))
+        return dict(src_idx=src[:k].copy(), pl=pl[:k].copy(), disp=disp[:k].copy(), P=P[:k].copy(), sigma2=s2[:k].copy(),
+                    m12_raw=raw[:nl].copy())
+
+    def stereo_lines(self, kl_l, angle_l, oct_l, desc_l, kl_r, desc_r, cols, rows, cam, mp):
+        nl = len(kl_l); c = max(nl, 1)
+        src = np.empty(c, np.int32); spl = np.empty((c, 2)); epl = np.empty((c, 2)); sd = np.empty(c); ed = np.empty(c)
+        sP = np.empty((c, 3)); eP = np.empty((c, 3)); le = np.empty((c, 3)); s2 = np.empty(c); raw = np.empty(c, np.int32)
+        camc = Cam.from_dict(cam)
+        k = self.lib.orc_stereo_lines(np.ascontiguousarray(kl_l, np.float32).reshape(-1), np.ascontiguousarray(angle_l, np.float32),
+                                      np.ascontiguousarray(oct_l, np.int32), desc_l, nl,
+                                      np.ascontiguousarray(kl_r, np.float32).reshape(-1), desc_r, len(kl_r), cols, rows,
+                                      C.byref(camc), C.byref(mp), src, spl.reshape(-1), epl.reshape(-1), sd, ed,
+                                      sP.reshape(-1), eP.reshape(-1), le.reshape(-1), s2, _ptr(raw))
+        return dict(src_idx=src[:k].copy(), spl=spl[:k].copy(), epl=epl[:k].copy(), sdisp=sd[:k].copy(), edisp=ed[:k].copy(),
+                    sP=sP[:k].copy(), eP=eP[:k].copy(), le=le[:k].copy(), sigma2=s2[:k].copy(), m12_raw=raw[:nl].copy())
+
+    # ---- small algebra ----
+    def _v(self, name, x, nout):
+        out = np.empty(nout)
+        getattr(self.lib, name)(np.ascontiguousarray(x, np.float64).reshape(-1), out)
+        return out
+
+    def expmap(self, x): return self._v("orc_expmap_se3", x, 16).reshape(4, 4)
+    def logmap(self, T): return self._v("orc_logmap_se3", T, 6)
+    def inverse_se3(self, T): return self._v("orc_inverse_se3", T, 16).reshape(4, 4)
+    def adjoint(self, T): return self._v("orc_adjoint_se3", T, 36).reshape(6, 6)
+    def inverse6(self, A): return self._v("orc_inverse6", A, 36).reshape(6, 6)
+    def eig6(self, A): return self._v("orc_eig6", A, 6)
+
+    def unccomp(self, T1, c1, cinc):
+        out = np.empty(36)
+        self.lib.orc_unccomp_se3(np.ascontiguousarray(T1).reshape(-1), np.ascontiguousarray(c1).reshape(-1),
+                                 np.ascontiguousarray(cinc).reshape(-1), out)
+        return out.reshape(6, 6)
+
+    def solve6(self, H, g):
+        x = np.empty(6); lad = C.c_double()
+        rank = self.lib.orc_solve6(np.ascontiguousarray(H, np.float64).reshape(-1), np.ascontiguousarray(g, np.float64), x, C.byref(lad))
+        return x, lad.value, rank
+
+    def mean_stdv_mad(self, r):
+        m = C.c_double(); s = C.c_double()
+        r = np.ascontiguousarray(r, np.float64)
+        self.lib.orc_mean_stdv_mad(r if len(r) else np.zeros(1), len(r), C.byref(m), C.byref(s))
+        return m.value, s.value
+
+    def stdv_mad(self, r):
+        r = np.ascontiguousarray(r, np.float64)
+        return self.lib.orc_stdv_mad(r if len(r) else np.zeros(1), len(r))
+
+    def line_overlap(self, so, eo, sp, ep):
+        a = [np.ascontiguousarray(v, np.float64) for v in (so, eo, sp, ep)]
+        return self.lib.orc_line_overlap(*a)
+
+    def line_overlap_stereo(self, a, b, c, d, th):
+        return self.lib.orc_line_overlap_stereo(a, b, c, d, th)
+
+    def is_good(self, DT, cov, err):
+        return bool(self.lib.orc_is_good_solution(np.ascontiguousarray(DT).reshape(-1), np.ascontiguousarray(cov).reshape(-1), err))
+
+    # ---- optimizer ----
+    @staticmethod
+    def _matched(rec):
+        keep = {}
+        for k in ("P", "pl_obs", "sigma2p", "sP", "eP", "le_obs", "spl", "epl", "sigma2l"):
+            keep[k] = np.ascontiguousarray(rec[k], np.float64)
+        keep["inlier_p"] = np.ascontiguousarray(rec["inlier_p"], np.int32).copy()
+        keep["inlier_l"] = np.ascontiguousarray(rec["inlier_l"], np.int32).copy()
+        m = Matched(len(keep["sigma2p"]), _ptr(keep["P"]), _ptr(keep["pl_obs"]), _ptr(keep["sigma2p"]), _ptr(keep["inlier_p"]),
+                    len(keep["sigma2l"]), _ptr(keep["sP"]), _ptr(keep["eP"]), _ptr(keep["le_obs"]), _ptr(keep["spl"]),
+                    _ptr(keep["epl"]), _ptr(keep["sigma2l"]), _ptr(keep["inlier_l"]))
+        return m, keep
+
+    def optimize_functions(self, DT, cam, params, rec, robust=0):
+        m, keep = self._matched(rec)
+        H = np.empty(36); g = np.empty(6); e = C.c_double(); n = C.c_int32()
+        camc = Cam.from_dict(cam)
+        self.lib.orc_optimize_functions(np.ascontiguousarray(DT, np.float64).reshape(-1), C.byref(camc), C.byref(params),
+                                        C.byref(m), robust, H, g, C.byref(e), C.byref(n))
+        return H.reshape(6, 6), g, e.value, n.value
+
+    def remove_outliers(self, DT, cam, params, rec):
+        m, keep = self._matched(rec)
+        npt = C.c_int32(int(keep["inlier_p"].sum())); nls = C.c_int32(int(keep["inlier_l"].sum()))
+        camc = Cam.from_dict(cam)
+        self.lib.orc_remove_outliers(np.ascontiguousarray(DT, np.float64).reshape(-1), C.byref(camc), C.byref(params),
+                                     C.byref(m), C.byref(npt), C.byref(nls))
+        return keep["inlier_p"], keep["inlier_l"], npt.value, nls.value
+
+    def optimize_pose(self, init_T, cam, params, rec):
+        m, keep = self._matched(rec)
+        res = PoseResult()
+        camc = Cam.from_dict(cam)
+        self.lib.orc_optimize_pose(np.ascontiguousarray(init_T, np.float64).reshape(-1), C.byref(camc), C.byref(params),
+                                   C.byref(m), C.byref(res))
+        d = res.as_dict()
+        d["inlier_p"] = keep["inlier_p"]; d["inlier_l"] = keep["inlier_l"]
+        return d
+
+
+_cached = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR], stdout=subprocess.DEVNULL)
+
+
+def load():
+    global _cached
+    if _cached is None:
+        so = os.path.join(ORACLE_DIR, "liboracle.so")
+        src = os.path.join(ORACLE_DIR, "stvo_oracle.c")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            build()
+        _cached = Oracle(C.CDLL(so))
+    return _cached
+
+
+def load_ref():
+    """The reference's own grid/Bresenham code (oracle/_ref), or None when it was never built."""
+    so = os.path.join(ORACLE_DIR, "_ref", "libstvo_ref.so")
+    if not os.path.exists(so):
+        return None
+    lib = C.CDLL(so)
+    lib.ref_line_coords.argtypes = [C.c_double] * 4 + [i32p, C.c_int]; lib.ref_line_coords.restype = C.c_int
+    lib.ref_grid_get.argtypes = [i32p, C.c_void_p, C.c_int, C.c_int, C.c_int, i32p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.c_int, i32p, i32p, C.c_int]
+    lib.ref_grid_get.restype = C.c_int
+    return lib
