@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""bench.py — stereo frame-pairs/s through the hot path {f2f brute-force match + optimizePose} on MI355X.
+
+One "step" = one pass of the hot path over one batch of B synthetic frame pairs that are already
+resident in HBM (BASELINE.json configs[1]: synthetic 1241x376 stereo, ~2000 ORB key-points per frame,
+brute-force point match + optimizePose, KITTI parameters).  Prints ONE JSON line (rank 0).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Multi-GPU: independent sequences are sharded one batch per rank (weak scaling); the only collective
+is the timing barrier / max-reduction over RCCL — the path itself has no exchange step.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "stvo-pl_amd", "python"))
+
+HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+VALU_PEAK_LANE_OPS = 78.6e12  # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (32-bit integer VALU lane-ops/s)
+K1_LANE_OPS_PER_PAIR = 19     # 8 xor + 8 bcnt + lshl_or + med3 + min  
+
+
+def cpu_baseline(frames, prm, budget_s=15.0):
+    """The oracle (scalar C port of the reference path) timed on this box's host cores, 1 thread,
+    on a bounded sample of the same workload.  Checker code: used here ONLY as the CPU baseline."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    from stvo_amd import synth
+    orc = oracle_lib.load()
+    z3, z2 = np.zeros((0, 3)), np.zeros((0, 2))
+    done, t0 = 0, time.perf_counter()
+    for fr in frames:
+        m12, _ = orc.match(fr["prev_desc"], fr["curr_desc"], 0.75, 1)
+        sel = np.nonzero(m12 >= 0)[0]
+        rec = dict(P=fr["prev_P"][sel], pl_obs=fr["curr_pl"][m12[sel]], sigma2p=fr["prev_sigma2"][sel],
+                   inlier_p=np.ones(len(sel), np.int32), sP=z3, eP=z3, le_obs=z3, spl=z2, epl=z2, sigma2l=np.zeros(0),
+                   inlier_l=np.zeros(0, np.int32))
+        orc.optimize_pose(np.eye(4), synth.KITTI_CAM, prm, rec)
+        done += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
+            "sample": f"{done} frame pairs of the same workload, oracle/stvo_oracle.c (-O3), {dt:.1f} s, "
+                      f"host has {os.cpu_count()} cores"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=512, help="frame pairs per step per GPU")
+    ap.add_argument("--keypoints", type=int, default=2000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from stvo_amd import capi, synth
+    from stvo_amd.ctypes_types import opt_params
+    from stvo_amd.devbatch import TrackBatch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+
+    B, n = args.batch, args.keypoints
+    max_pts = 2048 if n <= 2048 else None
+    if max_pts is None:
+        raise SystemExit("key-points per frame exceed STVO_POSE_MAX_POINTS (2048)")
+    # rank r processes sequence r (SURVEY.md §8d config 5 sharding: sequence s -> GPU s mod G)
+    frames = [synth.make_f2f_points(synth.frame_seed(rank, k), n=n) for k in range(B)]
+    batch = TrackBatch(frames, max_pts=max_pts, max_lines=0, device=dev)
+    prm = opt_params("kitti", has_lines=0)
+    ctx = capi.Context(device_id=local_rank, max_rows=max_pts, max_batch=B)
+    stream = torch.cuda.current_stream()
+    ctx.set_stream(stream.cuda_stream)
+
+    def step():
+        ctx.track_batched(batch, synth.KITTI_CAM, prm, 0.75, 0.75, 1)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # sanity: the timed work produced real poses
+    res = batch.results()
+    ok_frac = float((res["status"] == 0).mean())
+
+    out = None
+    if rank == 0:
+        frames_total = B * args.steps * world
+        k1_ms = ctx.time_stage(batch, synth.KITTI_CAM, prm, 0.75, 0, 10)
+        pose_ms = ctx.time_stage(batch, synth.KITTI_CAM, prm, 0.75, 1, 10)
+        alg_bytes = batch.algorithmic_bytes_match()
+        pairs = batch.pairs_match()
+        achieved_gbs = alg_bytes / (k1_ms * 1e-3) / 1e9
+        lane_ops = 2.0 * pairs * K1_LANE_OPS_PER_PAIR  # both directions are scanned
+        valu_meas = ctx.valu_peak()
+        out = {
+            "metric": "stereo frames/s (match+optimizePose)", "value": frames_total / dt, "unit": "frame-pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8+f64",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: synthetic 1241x376 stereo, 2000 ORB key-points/frame, "
+                                   "brute-force mutual-NNR point match + optimizePose (config_kitti.yaml), "
+                                   "batched independent frame pairs resident in HBM",
+                       "frame_pairs_per_step_per_gpu": B, "keypoints_per_frame": n, "parallelism": f"seq-shard x{world}",
+                       "committed_pose_fraction": ok_frac},
+            "roofline": {"kernel": "hamming_knn2_kernel", "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k1_ms,
+                         "note": "K1 is integer-VALU bound (~600 lane-ops per compulsory byte); see valu_roofline"},
+            "valu_roofline": {"kernel": "hamming_knn2_kernel", "lane_ops_per_launch": lane_ops,
+                              "achieved": lane_ops / (k1_ms * 1e-3) / 1e12, "peak": VALU_PEAK_LANE_OPS / 1e12,
+                              "unit": "T lane-ops/s", "frac": lane_ops / (k1_ms * 1e-3) / VALU_PEAK_LANE_OPS,
+                              "measured_peak_same_mix": valu_meas / 1e12,
+                              "frac_of_measured_peak": lane_ops / (k1_ms * 1e-3) / valu_meas},
+            "stage_ms": {"hamming_knn2": k1_ms, "pose": pose_ms},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(frames, prm)
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,151 @@
+/*
+ * stvo_hip.h — C-ABI of the MI355X-native PL-StVO hot path (libstvo_hip.so, gfx950 only).
+ *
+ * The reference (/root/reference) has NO plugin / FFI interface: its boundary is the C++ class API
+ * consumed by app/imagesStVO.cpp:86-124.  This header declares the `extern "C"` seams a maintainer
+ * binds in place of the reference's inner functions (see INTEGRATION.md for the stubs); every
+ * entry point cites the reference interface it replaces.  Plain pointers and sizes only.
+ *
+ *   - returns 0 (STVO_OK) or a negative STVO_ERR_* code; never throws, never aborts
+ *   - there is NO CPU fallback: without a gfx950 device stvo_ctx_create fails with
+ *     STVO_ERR_NO_DEVICE and nothing else can be called
+ *   - host-buffer entry points copy in/out through pinned staging and synchronise before returning
+ *   - *_dev entry points take DEVICE pointers, enqueue on the context's stream and do not
+ *     synchronise (use stvo_ctx_synchronize / your own events)
+ *   - descriptors: N x 32 bytes, contiguous; matrices row-major FP64; twists (t, w)
+ */
+#ifndef STVO_HIP_H
+#define STVO_HIP_H
+
+#include "stvo_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STVO_ABI_VERSION 1
+#define STVO_MAX_ROWS_LIMIT 65535 /* packed (distance << 16 | index) keys */
+#define STVO_POSE_MAX_POINTS 2048 /* per frame-pair, register-resident records in the pose kernel */
+#define STVO_POSE_MAX_LINES 512
+
+typedef struct stvo_ctx stvo_ctx;
+
+/* ---- library / context ------------------------------------------------------------------- */
+const char* stvo_backend_name(void); /* "hip-gfx950" */
+int stvo_abi_version(void);
+const char* stvo_error_string(int code);
+/* Last HIP error text recorded on this context ("" if none). */
+const char* stvo_ctx_last_error(const stvo_ctx* ctx);
+
+/* One context per sequence / host thread (the reference's StereoFrameHandler is not re-entrant
+ * either).  Owns device scratch sized for `max_rows` descriptors per set and
+ * `max_batch` problems per launch, pinned staging buffers and (unless set_stream is used) a stream. */
+int stvo_ctx_create(int device_id, int max_rows, int max_batch, stvo_ctx** out);
+int stvo_ctx_destroy(stvo_ctx* ctx);
+/* Borrow an existing hipStream_t (e.g. the caller's / torch's current stream); NULL = default. */
+int stvo_ctx_set_stream(stvo_ctx* ctx, void* hip_stream);
+int stvo_ctx_synchronize(stvo_ctx* ctx);
+
+/* ---- matching: host-buffer seams ------------------------------------------------------------ */
+
+/* Replaces  int StVO::match(const cv::Mat&, const cv::Mat&, float nnr, std::vector<int>&)
+ * (include/matching.h:52, src/matching.cpp:63-91; with mutual == 0: matchNNR, :41-61).
+ * m12[i] = matched row of d2 or -1;  *n_matches = return value of the reference function.
+ * n2 < 2 yields no matches (the reference reads out of bounds there, src/matching.cpp:54). */
+int stvo_match_nnr_mutual(stvo_ctx* ctx, const uint8_t* d1, int n1, const uint8_t* d2, int n2, float nnr, int mutual,
+                          int32_t* m12, int32_t* n_matches);
+
+/* Replaces  int StVO::matchGrid(const std::vector<point_2d>&, const cv::Mat&, const GridStructure&,
+ *                               const cv::Mat&, const GridWindow&, std::vector<int>&)
+ * (include/matching.h:57, src/matching.cpp:111-177).  The GridStructure (64x48 std::list buckets,
+ * src/gridStructure.cpp:43-83) is passed as CSR: cell c = y*64 + x owns
+ * cell_items[cell_start[c] .. cell_start[c+1]).  `ratio` = Config::minRatio12P() (double test, :160),
+ * `mutual` = Config::bestLRMatches(). */
+int stvo_match_grid_points(stvo_ctx* ctx, const int32_t* cell_xy1 /*[n1][2]*/, const uint8_t* d1, int n1,
+                           const int32_t* cell_start /*[3073]*/, const int32_t* cell_items, const uint8_t* d2, int n2,
+                           const stvo_grid_window* w, double ratio, int mutual, int32_t* m12, int32_t* n_matches);
+
+/* Replaces the line overload of StVO::matchGrid (include/matching.h:60, src/matching.cpp:179-258).
+ * cell_xy1 = [n1][4] (sx, sy, ex, ey) integer cells of the left end points; dir2 = [n2][2] unit
+ * directions of the right lines in grid space (src/stereoFrame.cpp:331-333). */
+int stvo_match_grid_lines(stvo_ctx* ctx, const int32_t* cell_xy1 /*[n1][4]*/, const uint8_t* d1, int n1,
+                          const int32_t* cell_start /*[3073]*/, const int32_t* cell_items, const uint8_t* d2, int n2,
+                          const double* dir2 /*[n2][2]*/, const stvo_grid_window* w, double ratio, double line_sim_th,
+                          int mutual, int32_t* m12, int32_t* n_matches);
+
+/* ---- optimizer: host-buffer seams ----------------------------------------------------------- */
+
+/* Replaces the private  void StereoFrameHandler::optimizeFunctions(Matrix4d, Matrix6d&, Vector6d&, double&)
+ * and optimizeFunctionsRobust (include/stereoFrameHandler.h:97-98, src/stereoFrameHandler.cpp:549-962):
+ * one evaluation of H (6x6), g (6), e at pose T over the inlier records. *n_used = N_p + N_l. */
+int stvo_normal_eq(stvo_ctx* ctx, const double T[16], const stvo_cam* cam, const stvo_opt_params* params,
+                   const stvo_matched* m, int robust, double H[36], double g[6], double* e, int32_t* n_used);
+
+/* Replaces  void StereoFrameHandler::optimizePose()  (include/stereoFrameHandler.h:54,
+ * src/stereoFrameHandler.cpp:307-392) minus the Tfw composition (:377-378, done by the caller):
+ * GN / robust GN / LM, removeOutliers (:988-1067), isGoodSolution (:292-305) and the commit rule.
+ * init_T = the DT chosen at :317-326.  m->inlier_* are updated in place. */
+int stvo_optimize_pose(stvo_ctx* ctx, const double init_T[16], const stvo_cam* cam, const stvo_opt_params* params,
+                       stvo_matched* m, stvo_pose_result* out);
+
+/* ---- batched, device-resident path (throughput mode; B independent frame pairs) --------------- */
+
+/* All pointers are DEVICE pointers.  Per-frame arrays are strided by max_pts / max_lines rows.
+ * Replaces, per frame pair, f2fTracking() + optimizePose() (src/stereoFrameHandler.cpp:106-180,
+ * 307-392): brute-force mutual NNR matching of prev->pdesc_l vs curr->pdesc_l (and ldesc_l),
+ * gathering of the matched records, and the full pose optimisation. */
+typedef struct stvo_track_batch_dev {
+    int32_t B, max_pts, max_lines, reserved;
+    /* prev frame: stereo points / lines that survived stereo association */
+    const int32_t* n_prev_pts;   /* [B] */
+    const uint8_t* prev_pdesc;   /* [B][max_pts][32] */
+    const double* prev_P;        /* [B][max_pts][3] */
+    const double* prev_sigma2p;  /* [B][max_pts] */
+    const int32_t* n_curr_pts;   /* [B] */
+    const uint8_t* curr_pdesc;   /* [B][max_pts][32] */
+    const double* curr_pl;       /* [B][max_pts][2]  -> pl_obs of the matched prev point */
+    const int32_t* n_prev_lines; /* [B]  (may be NULL when max_lines == 0) */
+    const uint8_t* prev_ldesc;   /* [B][max_lines][32] */
+    const double* prev_sP;       /* [B][max_lines][3] */
+    const double* prev_eP;       /* [B][max_lines][3] */
+    const double* prev_spl;      /* [B][max_lines][2] */
+    const double* prev_epl;      /* [B][max_lines][2] */
+    const double* prev_sigma2l;  /* [B][max_lines]  (after safeCopy's re-scaling) */
+    const int32_t* n_curr_lines; /* [B] */
+    const uint8_t* curr_ldesc;   /* [B][max_lines][32] */
+    const double* curr_le;       /* [B][max_lines][3] -> le_obs of the matched prev line */
+    const double* init_T;        /* [B][16] or NULL = identity */
+    /* outputs */
+    int32_t* m12_pts;            /* [B][max_pts]   */
+    int32_t* m12_lines;          /* [B][max_lines] */
+    int32_t* inlier_pts;         /* [B][max_pts]   -1 unmatched, 0 outlier, 1 inlier */
+    int32_t* inlier_lines;       /* [B][max_lines] */
+    stvo_pose_result* results;   /* [B] */
+} stvo_track_batch_dev;
+
+int stvo_track_batched_dev(stvo_ctx* ctx, const stvo_track_batch_dev* batch, const stvo_cam* cam,
+                           const stvo_opt_params* params, float nnr_points, float nnr_lines, int mutual);
+
+/* The matching stage alone (K1 + K2) on device-resident descriptor sets: m12[b][i]. */
+int stvo_match_nnr_mutual_batched_dev(stvo_ctx* ctx, int B, int row_stride, const uint8_t* d1, const int32_t* n1,
+                                      const uint8_t* d2, const int32_t* n2, float nnr, int mutual, int32_t* m12);
+
+/* The optimizer stage alone on device-resident, already associated records (m12 = identity). */
+int stvo_optimize_pose_batched_dev(stvo_ctx* ctx, const stvo_track_batch_dev* batch, const stvo_cam* cam,
+                                   const stvo_opt_params* params);
+
+/* ---- measurement helpers --------------------------------------------------------------------- */
+/* Times `iters` launches of the named kernel stage on the context's stream with hipEvents and
+ * returns the average milliseconds per launch (used by bench.py for the roofline line).
+ * stage: 0 = hamming_knn2 (K1) on the batch's point descriptors, 1 = pose kernel. */
+int stvo_time_stage_dev(stvo_ctx* ctx, const stvo_track_batch_dev* batch, const stvo_cam* cam,
+                        const stvo_opt_params* params, float nnr, int stage, int iters, float* avg_ms);
+
+/* Integer-VALU micro-benchmark (xor + popcount-accumulate chains, no memory traffic): measured
+ * 32-bit lane-ops/s of this device, the empirical roof K1 is priced against. */
+int stvo_valu_peak_probe(stvo_ctx* ctx, double* lane_ops_per_s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STVO_HIP_H */

@@ -100,6 +100,25 @@ typedef struct stvo_pose_result {
     int32_t n_inliers_pt, n_inliers_ls;
 } stvo_pose_result;
 
+/* Correspondence records handed to optimizePose: the live fields of matched_pt / matched_ls
+ * (include/stereoFeatures.h:30-121).  Host pointers for the host-buffer
+ * entry points.  `inlier_*` are in/out (1 = inlier). */
+typedef struct stvo_matched {
+    int32_t np;
+    const double* P;       /* [np][3]  PointFeature::P                                   */
+    const double* pl_obs;  /* [np][2]  PointFeature::pl_obs                              */
+    const double* sigma2p; /* [np]     PointFeature::sigma2                              */
+    int32_t* inlier_p;     /* [np]                                                       */
+    int32_t nl;
+    const double* sP;      /* [nl][3]  LineFeature::sP                                   */
+    const double* eP;      /* [nl][3]  LineFeature::eP                                   */
+    const double* le_obs;  /* [nl][3]  LineFeature::le_obs                               */
+    const double* spl;     /* [nl][2]  LineFeature::spl (prev-frame end point, overlap)  */
+    const double* epl;     /* [nl][2]  LineFeature::epl                                  */
+    const double* sigma2l; /* [nl]     LineFeature::sigma2 AFTER safeCopy's re-scaling   */
+    int32_t* inlier_l;     /* [nl]                                                       */
+} stvo_matched;
+
 /* Error codes of the C-ABI (0 ok, <0 error; never throws). */
 enum {
     STVO_OK = 0,

@@ -1,0 +1,92 @@
+// kernels.h — internal launch interface between the C-ABI translation unit and the HIP kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/stvo_hip.h"
+
+namespace stvo {
+
+// ---- K1 / K2: brute-force Hamming 2-NN, ratio test, mutual check ----------------------------
+// knn: [B][row_stride] packed (best_key, second_key), key = (distance << 16) | train_index.
+void launch_hamming_knn2(hipStream_t s, int B, int row_stride, int max_n, const uint8_t* d1, const int32_t* n1,
+                         const uint8_t* d2, const int32_t* n2, uint2* knn12, uint2* knn21, int both_directions);
+void launch_nnr_mutual(hipStream_t s, int B, int row_stride, const uint2* knn12, const uint2* knn21, const int32_t* n1,
+                       const int32_t* n2, float nnr, int mutual, int32_t* m12);
+void launch_valu_probe(hipStream_t s, int blocks, int iters, uint32_t* sink);
+extern const double kValuProbeOpsPerThreadIter;
+
+// ---- K4-K6: pose optimisation, one workgroup per frame pair ------------------------------------
+struct PoseArgs {
+    int B, max_pts, max_lines;
+    const int32_t* n_prev_pts;
+    const double* prev_P;
+    const double* prev_s2p;
+    const double* curr_pl;
+    const int32_t* m12p;        // nullptr: identity association (records mode)
+    const int32_t* init_inl_p;  // nullptr: every matched record starts as inlier
+    const int32_t* n_prev_lines;
+    const double* prev_sP;
+    const double* prev_eP;
+    const double* prev_spl;
+    const double* prev_epl;
+    const double* prev_s2l;
+    const double* curr_le;
+    const int32_t* m12l;
+    const int32_t* init_inl_l;
+    const double* init_T;  // [B][16] or nullptr
+    stvo_cam cam;
+    stvo_opt_params prm;
+    stvo_pose_result* results;
+    int32_t* inl_p_out;  // [B][max_pts] or nullptr
+    int32_t* inl_l_out;
+    int eval_only;       // 1: a single optimizeFunctions evaluation at init_T
+    int eval_robust;
+    double* eval_out;    // [B][44]: H(36) g(6) e n
+};
+int launch_pose(hipStream_t s, const PoseArgs& a);
+
+// ---- K3: grid-windowed stereo matchers ---------------------------------------------------------
+struct GridPointsArgs {
+    const int32_t* cell_xy1;  // [n1][2]
+    const uint8_t* d1;
+    int n1;
+    const int32_t* cell_start;  // [3073]
+    const int32_t* cell_items;
+    const uint8_t* d2;
+    int n2;
+    stvo_grid_window w;
+    double ratio;
+    int mutual;
+    int32_t* m12;
+    // scratch
+    uint32_t* best1;    // [n1]
+    uint32_t* second1;  // [n1]
+    int32_t* owner2;    // [n2]
+    int32_t* qcell_start;  // [3073]
+    int32_t* qcell_items;  // [n1]
+};
+int launch_grid_points(hipStream_t s, const GridPointsArgs& a);
+
+struct GridLinesArgs {
+    const int32_t* cell_xy1;  // [n1][4]
+    const uint8_t* d1;
+    int n1;
+    const int32_t* cell_start;
+    const int32_t* cell_items;
+    const uint8_t* d2;
+    int n2;
+    const double* dir2;
+    stvo_grid_window w;
+    double ratio, line_sim_th;
+    int mutual;
+    int32_t* m12;
+    uint32_t* cover;  // [n1][ceil(n2/32)] candidate bit-matrix scratch
+    uint32_t* best1;
+    uint32_t* second1;
+    int32_t* owner2;
+};
+int launch_grid_lines(hipStream_t s, const GridLinesArgs& a);
+
+}  // namespace stvo

@@ -1,0 +1,187 @@
+// match_kernels.hip — K1 `hamming_knn2` and K2 `nnr_mutual` for gfx950 (CDNA4, wave64).
+//
+// K1 replaces cv::BFMatcher(NORM_HAMMING).knnMatch(desc1, desc2, ., 2) as called from
+// StVO::matchNNR (/root/reference/src/matching.cpp:47-48), in both directions (:69-74).
+// K2 replaces the float ratio test (:53-58) and the mutual check of StVO::match (:80-86).
+//
+// K1 mapping (integer-VALU bound):
+//   * lane  = one QUERY row: its 256-bit descriptor lives in 8 VGPRs for the whole scan
+//             (two coalesced 16-byte loads per lane, 2 KiB contiguous per wave);
+//   * train rows are wave-uniform: fetched through the SCALAR cache (s_load_dwordx8, 32 B/row),
+//     so the inner loop issues no vector-memory or LDS instructions at all;
+//   * per (query, train) pair: 8 x v_xor_b32 + 8 x v_bcnt_u32_b32 (popcount-accumulate),
+//     then 3 VALU ops of top-2 bookkeeping on a packed key (distance << 16 | train index):
+//     v_lshl_or_b32, v_med3_u32 (new second = median(best, second, key)), v_min_u32.
+//     The packed key makes `min` pick the LOWEST train index among equal distances, which is
+//     knnMatch's tie order (strict '<' insertion over ascending train index).
+//   * grid = (query tiles of 256 rows, 2 directions, B frame pairs); no inter-workgroup traffic.
+#include "kernels.h"
+
+namespace stvo {
+
+__device__ __forceinline__ uint32_t med3_u32(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// popcount-accumulate: D = popcount(x) + acc in ONE VALU op.  Written as inline asm because the
+// compiler otherwise re-associates the 8-term sum into bcnt(x,0) + v_add3 trees (22 instead of
+// 19 VALU ops per pair).
+__device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc) {
+    uint32_t r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
+// key = (d << 16) | j with the wave-uniform train index taken from an SGPR (one VALU op; the
+// compiler's own lowering of (d << 16) | (j + u) is shift + v_or3 = two).
+__device__ __forceinline__ uint32_t pack_key(uint32_t d, uint32_t j_uniform) {
+    uint32_t r;
+    asm("v_lshl_or_b32 %0, %1, 16, %2" : "=v"(r) : "v"(d), "s"(j_uniform));
+    return r;
+}
+__device__ __forceinline__ uint32_t bcnt0(uint32_t x) {
+    uint32_t r;
+    asm("v_bcnt_u32_b32 %0, %1, 0" : "=v"(r) : "v"(x));
+    return r;
+}
+
+// t is wave-uniform -> 8 SGPRs feeding v_xor_b32 directly.
+__device__ __forceinline__ uint32_t hamming256(const uint4& q0, const uint4& q1, const uint32_t* __restrict__ t) {
+    uint32_t d = bcnt0(q0.x ^ t[0]);
+    d = bcnt_acc(q0.y ^ t[1], d);
+    d = bcnt_acc(q0.z ^ t[2], d);
+    d = bcnt_acc(q0.w ^ t[3], d);
+    d = bcnt_acc(q1.x ^ t[4], d);
+    d = bcnt_acc(q1.y ^ t[5], d);
+    d = bcnt_acc(q1.z ^ t[6], d);
+    d = bcnt_acc(q1.w ^ t[7], d);
+    return d;
+}
+
+constexpr int KNN_BLOCK = 256;
+
+__global__ __launch_bounds__(KNN_BLOCK) void hamming_knn2_kernel(int row_stride, const uint8_t* __restrict__ d1,
+                                                                 const int32_t* __restrict__ n1,
+                                                                 const uint8_t* __restrict__ d2,
+                                                                 const int32_t* __restrict__ n2,
+                                                                 uint2* __restrict__ knn12, uint2* __restrict__ knn21) {
+    const int b = blockIdx.z;
+    const int dir = blockIdx.y;
+    const int na = n1[b], nb = n2[b];
+    const int nq = dir == 0 ? na : nb;
+    const int nt = dir == 0 ? nb : na;
+    const int q_base = blockIdx.x * KNN_BLOCK;
+    if (q_base >= nq) return;  // block-uniform
+    const size_t frame_off = (size_t)b * row_stride;
+    const uint8_t* Q = (dir == 0 ? d1 : d2) + frame_off * STVO_DESC_BYTES;
+    const uint32_t* __restrict__ T = reinterpret_cast<const uint32_t*>((dir == 0 ? d2 : d1) + frame_off * STVO_DESC_BYTES);
+    uint2* __restrict__ out = (dir == 0 ? knn12 : knn21) + frame_off;
+
+    const int q = q_base + threadIdx.x;
+    const int qi = q < nq ? q : nq - 1;  // tail lanes scan a valid row and discard the result
+    const uint4 q0 = reinterpret_cast<const uint4*>(Q)[2 * qi];
+    const uint4 q1 = reinterpret_cast<const uint4*>(Q)[2 * qi + 1];
+
+    uint32_t best = 0xFFFFFFFFu, second = 0xFFFFFFFFu;
+    int j = 0;
+    // 4 train rows (128 B = two s_load_dwordx16) per trip: 4 independent popcount chains give the
+    // VALU ILP, 8 waves/SIMD hide the scalar-cache latency of the next trip's loads.
+    for (; j + 4 <= nt; j += 4) {
+        uint32_t t[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) t[k] = T[8 * j + k];
+        uint32_t d[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) d[u] = hamming256(q0, q1, t + 8 * u);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t key = pack_key(d[u], (uint32_t)(j + u));
+            second = med3_u32(best, second, key);
+            best = best < key ? best : key;
+        }
+    }
+    for (; j < nt; ++j) {
+        const uint32_t d = hamming256(q0, q1, T + 8 * j);
+        const uint32_t key = pack_key(d, (uint32_t)j);
+        second = med3_u32(best, second, key);
+        best = best < key ? best : key;
+    }
+    if (q < nq) out[q] = make_uint2(best, second);
+}
+
+void launch_hamming_knn2(hipStream_t s, int B, int row_stride, int max_n, const uint8_t* d1, const int32_t* n1,
+                         const uint8_t* d2, const int32_t* n2, uint2* knn12, uint2* knn21, int both_directions) {
+    if (B <= 0 || max_n <= 0) return;
+    dim3 grid((max_n + KNN_BLOCK - 1) / KNN_BLOCK, both_directions ? 2 : 1, B);
+    hipLaunchKernelGGL(hamming_knn2_kernel, grid, dim3(KNN_BLOCK), 0, s, row_stride, d1, n1, d2, n2, knn12, knn21);
+}
+
+// K2: m12[i] = j  iff  float(d0) < float(d1) * nnr  (12 direction)  and, when `mutual`, the 21
+// direction's own ratio-tested best of j is i.  Fewer than two train rows => no match (the
+// reference is undefined there, src/matching.cpp:54).
+__global__ __launch_bounds__(256) void nnr_mutual_kernel(int row_stride, const uint2* __restrict__ knn12,
+                                                         const uint2* __restrict__ knn21,
+                                                         const int32_t* __restrict__ n1, const int32_t* __restrict__ n2,
+                                                         float nnr, int mutual, int32_t* __restrict__ m12) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= row_stride) return;
+    const int na = n1[b], nb = n2[b];
+    const size_t off = (size_t)b * row_stride;
+    int m = -1;
+    if (i < na && nb >= 2) {
+        const uint2 k = knn12[off + i];
+        const float f0 = (float)(k.x >> 16), f1 = (float)(k.y >> 16);
+        if (f0 < f1 * nnr) m = (int)(k.x & 0xFFFFu);
+        if (mutual && m >= 0) {
+            bool keep = false;
+            if (na >= 2) {
+                const uint2 r = knn21[off + m];
+                const float r0 = (float)(r.x >> 16), r1 = (float)(r.y >> 16);
+                keep = (r0 < r1 * nnr) && ((int)(r.x & 0xFFFFu) == i);
+            }
+            if (!keep) m = -1;
+        }
+    }
+    m12[off + i] = m;
+}
+
+void launch_nnr_mutual(hipStream_t s, int B, int row_stride, const uint2* knn12, const uint2* knn21, const int32_t* n1,
+                       const int32_t* n2, float nnr, int mutual, int32_t* m12) {
+    if (B <= 0 || row_stride <= 0) return;
+    dim3 grid((row_stride + 255) / 256, B);
+    hipLaunchKernelGGL(nnr_mutual_kernel, grid, dim3(256), 0, s, row_stride, knn12, knn21, n1, n2, nnr, mutual, m12);
+}
+
+// Integer-VALU roof probe: the same instruction mix as K1's inner loop (xor, bcnt-accumulate,
+// lshl_or, med3, min) on register-only operands; 19 lane-ops per "pair", 8 pairs per iteration.
+const double kValuProbeOpsPerThreadIter = 19.0 * 8.0;
+
+__global__ __launch_bounds__(256) void valu_probe_kernel(int iters, uint32_t* sink) {
+    uint4 q0 = make_uint4(threadIdx.x * 2654435761u, blockIdx.x * 40503u + 1u, 0x9E3779B9u ^ threadIdx.x, 0x85EBCA6Bu);
+    uint4 q1 = make_uint4(q0.y * 3u, q0.z * 5u, q0.w * 7u, q0.x * 11u);
+    uint32_t best = 0xFFFFFFFFu, second = 0xFFFFFFFFu;
+    uint32_t t[8];
+    const uint32_t seed = __builtin_amdgcn_readfirstlane(blockIdx.x * 7919u + 13u);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] = seed * (2 * k + 3);
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] = __builtin_amdgcn_readfirstlane(t[k] + 0x01010101u * (k + 1));  // SALU
+            const uint32_t d = hamming256(q0, q1, t);
+            const uint32_t key = pack_key(d, (uint32_t)(it * 8 + u));
+            second = med3_u32(best, second, key);
+            best = best < key ? best : key;
+        }
+    }
+    if ((best ^ second) == 0x12345u) sink[0] = best;  // keep the chain alive
+}
+
+void launch_valu_probe(hipStream_t s, int blocks, int iters, uint32_t* sink) {
+    hipLaunchKernelGGL(valu_probe_kernel, dim3(blocks), dim3(256), 0, s, iters, sink);
+}
+
+}  // namespace stvo

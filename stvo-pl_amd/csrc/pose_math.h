@@ -1,0 +1,603 @@
+// pose_math.h — FP64 building blocks of the pose optimizer, usable from HIP device code and from
+// the C++ host mirror (StereoFrameHandler glue: Tfw composition, motion-model check).
+//
+// Everything here is written for REGISTER residency on gfx950: fixed-size arrays, loops with
+// compile-time trip counts and compile-time indices after unrolling (runtime-indexed private
+// arrays would be demoted to scratch memory).  Pivoting is expressed as predicated swaps.
+//
+// What each routine replaces in the reference (/root/reference):
+//   pm_expmap_se3 / pm_logmap_se3 / pm_inverse_se3 / pm_adjoint_se3 / pm_unccomp_se3
+//                         src/auxiliar.cpp:113-197
+//   pm_solve6             Eigen::ColPivHouseholderQR<Matrix6d>::solve + logAbsDeterminant
+//                         (call sites src/stereoFrameHandler.cpp:417-418,453-455,507-508,526-527)
+//   pm_inverse6           Matrix6d::inverse()            (:429,470,545)
+//   pm_eig6               SelfAdjointEigenSolver<Matrix6d>::eigenvalues()  (:294-295,379-380)
+//   pm_point_term / pm_line_term   the per-feature bodies of optimizeFunctions[Robust]
+//                         (:563-606, :610-684, :785-874, :878-952)
+//   pm_line_overlap       StereoFrame::lineSegmentOverlap  src/stereoFrame.cpp:510-616
+#pragma once
+
+#include <math.h>
+
+#include "../../include/stvo_types.h"
+
+#if defined(__HIPCC__)
+#define PM_HD __host__ __device__ __forceinline__
+#else
+#define PM_HD inline
+#endif
+
+namespace pm {
+
+PM_HD double dmax(double a, double b) { return a > b ? a : b; }  // std::max semantics (NaN in b is dropped)
+PM_HD double dmin(double a, double b) { return b < a ? b : a; }  // std::min semantics
+
+PM_HD void identity4(double* T) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) T[i] = (i % 5 == 0) ? 1.0 : 0.0;
+}
+
+PM_HD void mat4_mul(const double* A, const double* B, double* C) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s += A[i * 4 + k] * B[k * 4 + j];
+            C[i * 4 + j] = s;
+        }
+}
+
+PM_HD void mat3_mul(const double* A, const double* B, double* C) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) C[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
+}
+
+PM_HD void skew3(const double* v, double* S) {
+    S[0] = 0.0; S[1] = -v[2]; S[2] = v[1];
+    S[3] = v[2]; S[4] = 0.0; S[5] = -v[0];
+    S[6] = -v[1]; S[7] = v[0]; S[8] = 0.0;
+}
+
+// inverse_se3: [R^T, -R^T t]
+PM_HD void inverse_se3(const double* T, double* Ti) {
+    double o[16];
+    identity4(o);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) o[i * 4 + j] = T[j * 4 + i];
+        o[i * 4 + 3] = -(T[0 * 4 + i] * T[3] + T[1 * 4 + i] * T[7] + T[2 * 4 + i] * T[11]);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Ti[i] = o[i];
+}
+
+// expmap_se3, twist = (t, w); below theta = 1e-6 R = I and t is NOT multiplied by V.
+PM_HD void expmap_se3(const double* x, double* T) {
+    double t0 = x[0], t1 = x[1], t2 = x[2];
+    const double w[3] = {x[3], x[4], x[5]};
+    double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    const double theta = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    if (!(theta < 0.000001)) {
+        double sk[9], s[9], s2[9];
+        skew3(w, sk);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) s[i] = sk[i] / theta;
+        mat3_mul(s, s, s2);
+        const double sn = sin(theta), cs = cos(theta);
+        double V[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const double I = (i % 4 == 0) ? 1.0 : 0.0;
+            R[i] = I + s[i] * sn + s2[i] * (1.0 - cs);
+            V[i] = I + s[i] * (1.0 - cs) / theta + s2[i] * (theta - sn) / theta;
+        }
+        const double a = V[0] * t0 + V[1] * t1 + V[2] * t2;
+        const double b = V[3] * t0 + V[4] * t1 + V[5] * t2;
+        const double c = V[6] * t0 + V[7] * t1 + V[8] * t2;
+        t0 = a; t1 = b; t2 = c;
+    }
+    T[0] = R[0]; T[1] = R[1]; T[2] = R[2]; T[3] = t0;
+    T[4] = R[3]; T[5] = R[4]; T[6] = R[5]; T[7] = t1;
+    T[8] = R[6]; T[9] = R[7]; T[10] = R[8]; T[11] = t2;
+    T[12] = 0.0; T[13] = 0.0; T[14] = 0.0; T[15] = 1.0;
+}
+
+// 3x3 inverse by cofactors (what Eigen uses for fixed 3x3).
+PM_HD void inverse3(const double* A, double* Ai) {
+    const double c00 = A[4] * A[8] - A[5] * A[7];
+    const double c01 = A[5] * A[6] - A[3] * A[8];
+    const double c02 = A[3] * A[7] - A[4] * A[6];
+    const double id = 1.0 / (A[0] * c00 + A[1] * c01 + A[2] * c02);
+    Ai[0] = c00 * id;
+    Ai[1] = (A[2] * A[7] - A[1] * A[8]) * id;
+    Ai[2] = (A[1] * A[5] - A[2] * A[4]) * id;
+    Ai[3] = c01 * id;
+    Ai[4] = (A[0] * A[8] - A[2] * A[6]) * id;
+    Ai[5] = (A[2] * A[3] - A[0] * A[5]) * id;
+    Ai[6] = c02 * id;
+    Ai[7] = (A[1] * A[6] - A[0] * A[7]) * id;
+    Ai[8] = (A[0] * A[4] - A[1] * A[3]) * id;
+}
+
+// logmap_se3: cos from the trace (clamped), sine = sqrt(1-cos^2), V^-1 by 3x3 inverse.
+PM_HD void logmap_se3(const double* T, double* x) {
+    const double R[9] = {T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10]};
+    double V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    double w[3] = {0.0, 0.0, 0.0};
+    double cosine = (R[0] + R[4] + R[8] - 1.0) / 2.0;
+    if (cosine > 1.0) cosine = 1.0;
+    else if (cosine < -1.0) cosine = -1.0;
+    double sine = sqrt(1.0 - cosine * cosine);
+    if (sine > 1.0) sine = 1.0;
+    const double theta = acos(cosine);
+    if (theta > 0.000001) {
+        // skewcoords(theta (R - R^T) / (2 sine)) = (M(2,1), M(0,2), M(1,0))
+        w[0] = theta * (R[7] - R[5]) / (2.0 * sine);
+        w[1] = theta * (R[2] - R[6]) / (2.0 * sine);
+        w[2] = theta * (R[3] - R[1]) / (2.0 * sine);
+        double sk[9], s[9], s2[9];
+        skew3(w, sk);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) s[i] = sk[i] / theta;
+        mat3_mul(s, s, s2);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const double I = (i % 4 == 0) ? 1.0 : 0.0;
+            V[i] = I + s[i] * (1.0 - cosine) / theta + s2[i] * (theta - sine) / theta;
+        }
+    }
+    double Vi[9];
+    inverse3(V, Vi);
+    x[0] = Vi[0] * T[3] + Vi[1] * T[7] + Vi[2] * T[11];
+    x[1] = Vi[3] * T[3] + Vi[4] * T[7] + Vi[5] * T[11];
+    x[2] = Vi[6] * T[3] + Vi[7] * T[7] + Vi[8] * T[11];
+    x[3] = w[0]; x[4] = w[1]; x[5] = w[2];
+}
+
+// adjoint_se3 = [R, [t]x R; 0, R]
+PM_HD void adjoint_se3(const double* T, double* A) {
+    const double R[9] = {T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10]};
+    const double t[3] = {T[3], T[7], T[11]};
+    double sk[9], skR[9];
+    skew3(t, sk);
+    mat3_mul(sk, R, skR);
+#pragma unroll
+    for (int i = 0; i < 36; ++i) A[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            A[i * 6 + j] = R[i * 3 + j];
+            A[i * 6 + j + 3] = skR[i * 3 + j];
+            A[(i + 3) * 6 + j + 3] = R[i * 3 + j];
+        }
+}
+
+// unccomp_se3: cov1 + Ad(T1) covinc Ad(T1)^T
+PM_HD void unccomp_se3(const double* T1, const double* cov1, const double* covinc, double* out) {
+    double A[36], tmp[36];
+    adjoint_se3(T1, A);
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) s += A[i * 6 + k] * covinc[k * 6 + j];
+            tmp[i * 6 + j] = s;
+        }
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) s += tmp[i * 6 + k] * A[j * 6 + k];
+            out[i * 6 + j] = cov1[i * 6 + j] + s;
+        }
+}
+
+// DT <- DT * inverse_se3(expmap_se3(inc))        (src/stereoFrameHandler.cpp:419)
+PM_HD void step_pose(double* DT, const double* inc) {
+    double E[16], Ei[16], o[16];
+    expmap_se3(inc, E);
+    inverse_se3(E, Ei);
+    mat4_mul(DT, Ei, o);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) DT[i] = o[i];
+}
+
+// Column-pivoted Householder QR solve of the 6x6 normal equations, fully unrolled.
+// Pivot = largest remaining column norm; rank cut at machine precision; free components = 0.
+// Returns the numerical rank; *log_abs_det = sum log|R_ii|.
+PM_HD int solve6(const double* H, const double* g, double* x, double* log_abs_det) {
+    double A[36], c[6], y[6];
+    int perm[6];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) A[i] = H[i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        c[i] = g[i];
+        perm[i] = i;
+        y[i] = 0.0;
+    }
+    double maxnorm2 = 0.0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) s += A[i * 6 + j] * A[i * 6 + j];
+        maxnorm2 = s > maxnorm2 ? s : maxnorm2;
+    }
+    const double eps = 2.220446049250313e-16;
+    const double thr_helper = maxnorm2 * eps * eps / 6.0;
+    int rank = 6;
+    double lad = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        int big = k;
+        double bigsq = -1.0;
+#pragma unroll
+        for (int j = k; j < 6; ++j) {
+            double s = 0.0;
+#pragma unroll
+            for (int i = k; i < 6; ++i) s += A[i * 6 + j] * A[i * 6 + j];
+            if (s > bigsq) {
+                bigsq = s;
+                big = j;
+            }
+        }
+        if (rank == 6 && bigsq < thr_helper * (double)(6 - k)) rank = k;
+#pragma unroll
+        for (int j = k + 1; j < 6; ++j) {  // predicated column swap k <-> big (static indices)
+            const bool sw = (big == j);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const double a = A[i * 6 + k], b = A[i * 6 + j];
+                A[i * 6 + k] = sw ? b : a;
+                A[i * 6 + j] = sw ? a : b;
+            }
+            const int pa = perm[k], pb = perm[j];
+            perm[k] = sw ? pb : pa;
+            perm[j] = sw ? pa : pb;
+        }
+        const double c0 = A[k * 6 + k];
+        double tail = 0.0;
+#pragma unroll
+        for (int i = k + 1; i < 6; ++i) tail += A[i * 6 + k] * A[i * 6 + k];
+        double beta, tau;
+        if (tail <= 2.2250738585072014e-308) {
+            tau = 0.0;
+            beta = c0;
+#pragma unroll
+            for (int i = k + 1; i < 6; ++i) A[i * 6 + k] = 0.0;
+        } else {
+            beta = sqrt(c0 * c0 + tail);
+            if (c0 >= 0.0) beta = -beta;
+            const double den = c0 - beta;
+#pragma unroll
+            for (int i = k + 1; i < 6; ++i) A[i * 6 + k] /= den;
+            tau = (beta - c0) / beta;
+        }
+        A[k * 6 + k] = beta;
+        lad += log(fabs(beta));
+#pragma unroll
+        for (int j = k + 1; j < 6; ++j) {
+            double s = A[k * 6 + j];
+#pragma unroll
+            for (int i = k + 1; i < 6; ++i) s += A[i * 6 + k] * A[i * 6 + j];
+            s *= tau;
+            A[k * 6 + j] -= s;
+#pragma unroll
+            for (int i = k + 1; i < 6; ++i) A[i * 6 + j] -= s * A[i * 6 + k];
+        }
+        {
+            double s = c[k];
+#pragma unroll
+            for (int i = k + 1; i < 6; ++i) s += A[i * 6 + k] * c[i];
+            s *= tau;
+            c[k] -= s;
+#pragma unroll
+            for (int i = k + 1; i < 6; ++i) c[i] -= s * A[i * 6 + k];
+        }
+    }
+    if (log_abs_det) *log_abs_det = lad;
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+        double s = c[i];
+#pragma unroll
+        for (int j = i + 1; j < 6; ++j) s -= A[i * 6 + j] * y[j];  // y[j] == 0 for j >= rank
+        y[i] = (i < rank) ? s / A[i * 6 + i] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) x[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+            if (perm[i] == j) x[j] = y[i];
+    return rank;
+}
+
+// 6x6 inverse by LU with partial pivoting (rows swapped by predicated moves), fully unrolled.
+PM_HD void inverse6(const double* Ain, double* Ai) {
+    double A[36], B[36];  // B accumulates P * I, then is solved in place
+#pragma unroll
+    for (int i = 0; i < 36; ++i) {
+        A[i] = Ain[i];
+        B[i] = (i % 7 == 0) ? 1.0 : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        int p = k;
+        double best = fabs(A[k * 6 + k]);
+#pragma unroll
+        for (int i = k + 1; i < 6; ++i) {
+            const double v = fabs(A[i * 6 + k]);
+            if (v > best) {
+                best = v;
+                p = i;
+            }
+        }
+#pragma unroll
+        for (int i = k + 1; i < 6; ++i) {
+            const bool sw = (p == i);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const double a = A[k * 6 + j], b = A[i * 6 + j];
+                A[k * 6 + j] = sw ? b : a;
+                A[i * 6 + j] = sw ? a : b;
+                const double c = B[k * 6 + j], d = B[i * 6 + j];
+                B[k * 6 + j] = sw ? d : c;
+                B[i * 6 + j] = sw ? c : d;
+            }
+        }
+        const double piv = A[k * 6 + k];
+#pragma unroll
+        for (int i = k + 1; i < 6; ++i) {
+            const double l = A[i * 6 + k] / piv;
+            A[i * 6 + k] = l;
+#pragma unroll
+            for (int j = k + 1; j < 6; ++j) A[i * 6 + j] -= l * A[k * 6 + j];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) B[i * 6 + j] -= l * B[k * 6 + j];  // forward substitution on the fly
+        }
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+#pragma unroll
+        for (int col = 0; col < 6; ++col) {
+            double s = B[i * 6 + col];
+#pragma unroll
+            for (int j = i + 1; j < 6; ++j) s -= A[i * 6 + j] * B[j * 6 + col];
+            B[i * 6 + col] = s / A[i * 6 + i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 36; ++i) Ai[i] = B[i];
+}
+
+// Ascending eigenvalues of the symmetric matrix given by the LOWER triangle of Ain
+// (cyclic Jacobi, 15 rotations per sweep unrolled; the sweep loop is dynamic).
+PM_HD void eig6(const double* Ain, double* w) {
+    double A[36];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) A[i * 6 + j] = (i >= j) ? Ain[i * 6 + j] : Ain[j * 6 + i];
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0, diag = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                if (i != j) off += A[i * 6 + j] * A[i * 6 + j];
+                else diag += A[i * 6 + j] * A[i * 6 + j];
+            }
+        if (!(off > 1e-32 * diag) || !(off > 0.0)) break;
+#pragma unroll
+        for (int p = 0; p < 5; ++p)
+#pragma unroll
+            for (int q = p + 1; q < 6; ++q) {
+                const double apq = A[p * 6 + q];
+                if (apq != 0.0) {
+                    const double theta = (A[q * 6 + q] - A[p * 6 + p]) / (2.0 * apq);
+                    const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                    const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        const double akp = A[k * 6 + p], akq = A[k * 6 + q];
+                        A[k * 6 + p] = cs * akp - sn * akq;
+                        A[k * 6 + q] = sn * akp + cs * akq;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        const double apk = A[p * 6 + k], aqk = A[q * 6 + k];
+                        A[p * 6 + k] = cs * apk - sn * aqk;
+                        A[q * 6 + k] = sn * apk + cs * aqk;
+                    }
+                }
+            }
+    }
+    double v[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) v[i] = A[i * 7];
+    // ascending sorting network (odd-even transposition, 6 rounds); comparisons false on NaN
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int i = (r & 1); i + 1 < 6; i += 2) {
+            const double a = v[i], b = v[i + 1];
+            const bool sw = a > b;
+            v[i] = sw ? b : a;
+            v[i + 1] = sw ? a : b;
+        }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) w[i] = v[i];
+}
+
+PM_HD bool all_finite16(const double* T) {
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ok = ok && isfinite(T[i]);
+    return ok;
+}
+
+PM_HD bool is_identity16(const double* T) {
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ok = ok && (T[i] == ((i % 5 == 0) ? 1.0 : 0.0));
+    return ok;
+}
+
+// isGoodSolution (src/stereoFrameHandler.cpp:292-305) given precomputed ascending eigenvalues.
+PM_HD bool is_good_solution(const double* DT, const double* eig, double err) {
+    return !(eig[0] < 0.0 || eig[5] > 1.0 || err < 0.0 || err > 1.0 || !all_finite16(DT));
+}
+
+PM_HD double overlap_from_lambdas(double ls, double le) {
+    const double lmin = dmin(ls, le), lmax = dmax(ls, le);
+    if (lmin < 0.0 && lmax > 1.0) return 1.0;
+    if (lmax < 0.0 || lmin > 1.0) return 0.0;
+    if (lmin < 0.0) return lmax;
+    if (lmax > 1.0) return 1.0 - lmin;
+    return lmax - lmin;
+}
+
+// StereoFrame::lineSegmentOverlap: fraction of the observed segment (so,eo) covered by the
+// projection of (sp,ep) onto it; vertical / horizontal / general branches with 1 px thresholds.
+PM_HD double line_overlap(double sox, double soy, double eox, double eoy, double spx, double spy, double epx,
+                          double epy) {
+    const double lx = eox - sox, ly = eoy - soy;
+    if (fabs(sox - eox) < 1.0) return overlap_from_lambdas((spy - soy) / ly, (epy - soy) / ly);
+    if (fabs(soy - eoy) < 1.0) return overlap_from_lambdas((spx - sox) / lx, (epx - sox) / lx);
+    const double a = soy - eoy, b = eox - sox, c = sox * eoy - eox * soy;
+    const double lxy = 1.0 / (a * a + b * b);
+    const double fsx = (b * (b * spx - a * spy) - a * c) * lxy;
+    const double fex = (b * (b * epx - a * epy) - a * c) * lxy;
+    return overlap_from_lambdas((fsx - sox) / lx, (fex - sox) / lx);
+}
+
+struct Cam5 {
+    double fx, fy, cx, cy;
+};
+
+// P_ = R P + t ; projection (src/pinholeStereoCamera.cpp:231-237)
+PM_HD void transform_project(const double* DT, double X, double Y, double Z, const Cam5& cam, double* Pc,
+                             double* uv) {
+    Pc[0] = DT[0] * X + DT[1] * Y + DT[2] * Z + DT[3];
+    Pc[1] = DT[4] * X + DT[5] * Y + DT[6] * Z + DT[7];
+    Pc[2] = DT[8] * X + DT[9] * Y + DT[10] * Z + DT[11];
+    uv[0] = cam.cx + cam.fx * Pc[0] / Pc[2];
+    uv[1] = cam.cy + cam.fy * Pc[1] / Pc[2];
+}
+
+// 1x6 gradient of the scalar residual (translation first, rotation last; only fx appears).
+PM_HD void grad6(const double* Pc, double dx, double dy, double fx, double homog_th, double* J) {
+    const double gx = Pc[0], gy = Pc[1], gz = Pc[2];
+    const double gz2 = gz * gz;
+    const double fgz2 = fx / dmax(homog_th, gz2);
+    J[0] = +fgz2 * dx * gz;
+    J[1] = +fgz2 * dy * gz;
+    J[2] = -fgz2 * (gx * dx + gy * dy);
+    J[3] = -fgz2 * (gx * gy * dx + gy * gy * dy + gz * gz * dy);
+    J[4] = +fgz2 * (gx * gx * dx + gz * gz * dx + gx * gy * dy);
+    J[5] = +fgz2 * (gx * gz * dy - gy * gz * dx);
+}
+
+// acc[0..20] upper triangle of H (row-major i<=j), acc[21..26] g, acc[27] e
+PM_HD void accumulate28(double* acc, const double* J, double r, double w) {
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = i; j < 6; ++j) acc[k++] += J[i] * J[j] * w;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) acc[21 + i] += J[i] * r * w;
+    acc[27] += r * r * w;
+}
+
+// Reprojection residual norm of one point.
+PM_HD double point_residual(const double* DT, const Cam5& cam, double X, double Y, double Z, double ox, double oy) {
+    double Pc[3], uv[2];
+    transform_project(DT, X, Y, Z, cam, Pc, uv);
+    const double dx = uv[0] - ox, dy = uv[1] - oy;
+    return sqrt(dx * dx + dy * dy);
+}
+
+// One point of optimizeFunctions (robust == false: r = |e| sqrt(sigma2), w = Cauchy(r);
+// robust == true: r = |e|, w = Cauchy(r / s_p)).
+PM_HD void point_term(double* acc, const double* DT, const Cam5& cam, double homog_th, double X, double Y, double Z,
+                      double ox, double oy, double sigma2, bool robust, double s_p) {
+    double Pc[3], uv[2], J[6];
+    transform_project(DT, X, Y, Z, cam, Pc, uv);
+    const double dx = uv[0] - ox, dy = uv[1] - oy;
+    const double nrm = sqrt(dx * dx + dy * dy);
+    grad6(Pc, dx, dy, cam.fx, homog_th, J);
+    const double den = dmax(homog_th, nrm);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) J[i] = J[i] / den;
+    double r, w;
+    if (!robust) {
+        r = nrm * sqrt(sigma2);
+        w = 1.0 / (1.0 + r * r);
+    } else {
+        r = nrm;
+        const double xx = r / s_p;
+        w = 1.0 / (1.0 + xx * xx);
+    }
+    accumulate28(acc, J, r, w);
+}
+
+struct LineRec {
+    double sP[3], eP[3], le[3], spl[2], epl[2], sigma2;
+};
+
+PM_HD double line_residual(const double* DT, const Cam5& cam, const LineRec& L) {
+    double Pc[3], s[2], t[2];
+    transform_project(DT, L.sP[0], L.sP[1], L.sP[2], cam, Pc, s);
+    transform_project(DT, L.eP[0], L.eP[1], L.eP[2], cam, Pc, t);
+    const double ds = L.le[0] * s[0] + L.le[1] * s[1] + L.le[2];
+    const double de = L.le[0] * t[0] + L.le[1] * t[1] + L.le[2];
+    return sqrt(ds * ds + de * de);
+}
+
+PM_HD void line_term(double* acc, const double* DT, const Cam5& cam, double homog_th, const LineRec& L, bool robust,
+                     double s_l) {
+    double sPc[3], ePc[3], s[2], t[2], Js[6], Je[6], J[6];
+    transform_project(DT, L.sP[0], L.sP[1], L.sP[2], cam, sPc, s);
+    transform_project(DT, L.eP[0], L.eP[1], L.eP[2], cam, ePc, t);
+    const double ds = L.le[0] * s[0] + L.le[1] * s[1] + L.le[2];
+    const double de = L.le[0] * t[0] + L.le[1] * t[1] + L.le[2];
+    const double nrm = sqrt(ds * ds + de * de);
+    grad6(sPc, L.le[0], L.le[1], cam.fx, homog_th, Js);
+    grad6(ePc, L.le[0], L.le[1], cam.fx, homog_th, Je);
+    const double den = dmax(homog_th, nrm);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) J[i] = (Js[i] * ds + Je[i] * de) / den;
+    double r, w;
+    if (!robust) {
+        r = nrm * sqrt(L.sigma2);
+        w = 1.0 / (1.0 + r * r);
+    } else {
+        r = nrm;
+        const double xx = r / s_l;
+        w = 1.0 / (1.0 + xx * xx);
+    }
+    w *= line_overlap(L.spl[0], L.spl[1], L.epl[0], L.epl[1], s[0], s[1], t[0], t[1]);
+    accumulate28(acc, J, r, w);
+}
+
+PM_HD double clamp_scale(double s) {
+    const double th_min = 0.0001, th_max = sqrt(7.815);  // src/stereoFrameHandler.cpp:744-745
+    if (s < th_min) s = th_min;
+    if (s > th_max) s = th_max;
+    return s;
+}
+
+}  // namespace pm

@@ -1,0 +1,392 @@
+// stvo_capi.hip — the extern "C" boundary (include/stvo_hip.h) over the HIP kernels.
+// Host-buffer entry points stage through a per-context device arena; *_dev entry points only
+// enqueue.  No CPU fallback exists anywhere in this library: every path launches gfx950 kernels.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "ctx_internal.h"
+
+
+extern "C" {
+
+const char* stvo_backend_name(void) { return "hip-gfx950"; }
+int stvo_abi_version(void) { return STVO_ABI_VERSION; }
+
+const char* stvo_error_string(int code) {
+    switch (code) {
+        case STVO_OK: return "ok";
+        case STVO_ERR_INVALID_ARG: return "invalid argument";
+        case STVO_ERR_HIP: return "HIP runtime error";
+        case STVO_ERR_NO_DEVICE: return "no gfx950 device (this library has no CPU fallback)";
+        case STVO_ERR_CAPACITY: return "problem exceeds the context capacity";
+        case STVO_ERR_UNSUPPORTED: return "unsupported";
+        default: return "unknown error";
+    }
+}
+
+const char* stvo_ctx_last_error(const stvo_ctx* ctx) { return ctx ? ctx->last_error : ""; }
+
+int stvo_ctx_create(int device_id, int max_rows, int max_batch, stvo_ctx** out) {
+    if (!out || max_rows <= 0 || max_rows > STVO_MAX_ROWS_LIMIT || max_batch <= 0) return STVO_ERR_INVALID_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev)
+        return STVO_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return STVO_ERR_NO_DEVICE;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return STVO_ERR_NO_DEVICE;  // kernels exist for gfx950 only
+    stvo_ctx* ctx = new (std::nothrow) stvo_ctx();
+    if (!ctx) return STVO_ERR_HIP;
+    ctx->device = device_id;
+    ctx->max_rows = max_rows;
+    ctx->max_batch = max_batch;
+    bool ok = hip_ok(ctx, hipSetDevice(device_id), "hipSetDevice") &&
+              hip_ok(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking), "hipStreamCreate");
+    ctx->own_stream = ok;
+    const size_t knn_elems = (size_t)max_rows * (size_t)max_batch;
+    // arena: descriptors + records + per-row scratch of one host-buffer call, with slack
+    ctx->arena_size = (size_t)max_rows * 1024 + ((size_t)4 << 20);
+    ok = ok && hip_ok(ctx, hipMalloc((void**)&ctx->knn12, knn_elems * sizeof(uint2)), "hipMalloc knn12") &&
+         hip_ok(ctx, hipMalloc((void**)&ctx->knn21, knn_elems * sizeof(uint2)), "hipMalloc knn21") &&
+         hip_ok(ctx, hipMalloc((void**)&ctx->arena, ctx->arena_size), "hipMalloc arena") &&
+         hip_ok(ctx, hipMalloc((void**)&ctx->probe_sink, 256), "hipMalloc sink");
+    if (!ok) {
+        stvo_ctx_destroy(ctx);
+        return STVO_ERR_HIP;
+    }
+    *out = ctx;
+    return STVO_OK;
+}
+
+int stvo_ctx_destroy(stvo_ctx* ctx) {
+    if (!ctx) return STVO_OK;
+    hipSetDevice(ctx->device);
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    if (ctx->knn12) hipFree(ctx->knn12);
+    if (ctx->knn21) hipFree(ctx->knn21);
+    if (ctx->arena) hipFree(ctx->arena);
+    if (ctx->probe_sink) hipFree(ctx->probe_sink);
+    if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return STVO_OK;
+}
+
+int stvo_ctx_set_stream(stvo_ctx* ctx, void* hip_stream) {
+    if (!ctx) return STVO_ERR_INVALID_ARG;
+    if (ctx->own_stream && ctx->stream) {
+        hipStreamSynchronize(ctx->stream);
+        hipStreamDestroy(ctx->stream);
+    }
+    ctx->own_stream = false;
+    ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    return STVO_OK;
+}
+
+int stvo_ctx_synchronize(stvo_ctx* ctx) {
+    if (!ctx) return STVO_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return STVO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+int stvo_match_nnr_mutual(stvo_ctx* ctx, const uint8_t* d1, int n1, const uint8_t* d2, int n2, float nnr, int mutual,
+                          int32_t* m12, int32_t* n_matches) {
+    if (!ctx || n1 < 0 || n2 < 0 || (n1 > 0 && (!d1 || !m12)) || (n2 > 0 && !d2)) return STVO_ERR_INVALID_ARG;
+    if (!(nnr <= 1.0f)) return STVO_ERR_INVALID_ARG;  // tie handling is only order-independent for nnr <= 1
+    if (n1 > ctx->max_rows || n2 > ctx->max_rows) return STVO_ERR_CAPACITY;
+    if (n_matches) *n_matches = 0;
+    if (n1 == 0) return STVO_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->arena_off = 0;
+    const int stride = n1 > n2 ? n1 : n2;
+    uint8_t *dd1, *dd2;
+    int32_t *dn1, *dn2, *dm12;
+    TRY(upload(ctx, &dd1, (const uint8_t*)nullptr, (size_t)stride * STVO_DESC_BYTES));
+    TRY(upload(ctx, &dd2, (const uint8_t*)nullptr, (size_t)stride * STVO_DESC_BYTES));
+    HIP_TRY(ctx, hipMemcpyAsync(dd1, d1, (size_t)n1 * STVO_DESC_BYTES, hipMemcpyHostToDevice, ctx->stream));
+    if (n2) HIP_TRY(ctx, hipMemcpyAsync(dd2, d2, (size_t)n2 * STVO_DESC_BYTES, hipMemcpyHostToDevice, ctx->stream));
+    TRY(upload(ctx, &dn1, &n1, 1));
+    TRY(upload(ctx, &dn2, &n2, 1));
+    TRY(upload(ctx, &dm12, (const int32_t*)nullptr, (size_t)stride));
+    stvo::launch_hamming_knn2(ctx->stream, 1, stride, stride, dd1, dn1, dd2, dn2, ctx->knn12, ctx->knn21, mutual ? 1 : 0);
+    stvo::launch_nnr_mutual(ctx->stream, 1, stride, ctx->knn12, ctx->knn21, dn1, dn2, nnr, mutual, dm12);
+    TRY(check_launch(ctx));
+    HIP_TRY(ctx, hipMemcpyAsync(m12, dm12, (size_t)n1 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (n_matches) {
+        int c = 0;
+        for (int i = 0; i < n1; ++i) c += m12[i] >= 0;
+        *n_matches = c;
+    }
+    return STVO_OK;
+}
+
+int stvo_match_nnr_mutual_batched_dev(stvo_ctx* ctx, int B, int row_stride, const uint8_t* d1, const int32_t* n1,
+                                      const uint8_t* d2, const int32_t* n2, float nnr, int mutual, int32_t* m12) {
+    if (!ctx || B < 0 || row_stride <= 0 || !d1 || !d2 || !n1 || !n2 || !m12 || !(nnr <= 1.0f))
+        return STVO_ERR_INVALID_ARG;
+    if ((size_t)B * row_stride > (size_t)ctx->max_batch * ctx->max_rows || row_stride > STVO_MAX_ROWS_LIMIT)
+        return STVO_ERR_CAPACITY;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    stvo::launch_hamming_knn2(ctx->stream, B, row_stride, row_stride, d1, n1, d2, n2, ctx->knn12, ctx->knn21,
+                              mutual ? 1 : 0);
+    stvo::launch_nnr_mutual(ctx->stream, B, row_stride, ctx->knn12, ctx->knn21, n1, n2, nnr, mutual, m12);
+    return check_launch(ctx);
+}
+
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+// stage a stvo_matched (host) into the arena as a B = 1 records-mode problem
+int stage_records(stvo_ctx* ctx, const stvo_matched* m, const double* T, stvo::PoseArgs* a, int32_t** d_inl_p,
+                  int32_t** d_inl_l) {
+    std::memset(a, 0, sizeof(*a));
+    if (m->np < 0 || m->nl < 0) return STVO_ERR_INVALID_ARG;
+    if (m->np > STVO_POSE_MAX_POINTS || m->nl > STVO_POSE_MAX_LINES) return STVO_ERR_CAPACITY;
+    a->B = 1;
+    a->max_pts = m->np > 0 ? m->np : 1;
+    a->max_lines = m->nl;
+    double *P, *obs, *s2p, *sP, *eP, *le, *spl, *epl, *s2l, *dT;
+    int32_t *dnp, *dnl;
+    TRY(upload(ctx, &P, m->P, (size_t)m->np * 3));
+    TRY(upload(ctx, &obs, m->pl_obs, (size_t)m->np * 2));
+    TRY(upload(ctx, &s2p, m->sigma2p, (size_t)m->np));
+    TRY(upload(ctx, d_inl_p, (const int32_t*)m->inlier_p, (size_t)m->np));
+    TRY(upload(ctx, &sP, m->sP, (size_t)m->nl * 3));
+    TRY(upload(ctx, &eP, m->eP, (size_t)m->nl * 3));
+    TRY(upload(ctx, &le, m->le_obs, (size_t)m->nl * 3));
+    TRY(upload(ctx, &spl, m->spl, (size_t)m->nl * 2));
+    TRY(upload(ctx, &epl, m->epl, (size_t)m->nl * 2));
+    TRY(upload(ctx, &s2l, m->sigma2l, (size_t)m->nl));
+    TRY(upload(ctx, d_inl_l, (const int32_t*)m->inlier_l, (size_t)m->nl));
+    TRY(upload(ctx, &dnp, &m->np, 1));
+    TRY(upload(ctx, &dnl, &m->nl, 1));
+    TRY(upload(ctx, &dT, T, 16));
+    a->n_prev_pts = dnp;
+    a->prev_P = P;
+    a->prev_s2p = s2p;
+    a->curr_pl = obs;
+    a->m12p = nullptr;
+    a->init_inl_p = *d_inl_p;
+    a->n_prev_lines = dnl;
+    a->prev_sP = sP;
+    a->prev_eP = eP;
+    a->prev_spl = spl;
+    a->prev_epl = epl;
+    a->prev_s2l = s2l;
+    a->curr_le = le;
+    a->m12l = nullptr;
+    a->init_inl_l = *d_inl_l;
+    a->init_T = dT;
+    return STVO_OK;
+}
+
+}  // namespace
+
+int stvo_normal_eq(stvo_ctx* ctx, const double T[16], const stvo_cam* cam, const stvo_opt_params* params,
+                   const stvo_matched* m, int robust, double H[36], double g[6], double* e, int32_t* n_used) {
+    if (!ctx || !T || !cam || !params || !m || !H || !g || !e) return STVO_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->arena_off = 0;
+    stvo::PoseArgs a;
+    int32_t *dip, *dil;
+    TRY(stage_records(ctx, m, T, &a, &dip, &dil));
+    a.cam = *cam;
+    a.prm = *params;
+    a.prm.has_points = 1;  // a single evaluation sums whatever records are flagged as inliers
+    a.prm.has_lines = 1;
+    double* dout = arena_alloc<double>(ctx, 44);
+    if (!dout) return STVO_ERR_CAPACITY;
+    a.eval_only = 1;
+    a.eval_robust = robust;
+    a.eval_out = dout;
+    TRY(stvo::launch_pose(ctx->stream, a));
+    TRY(check_launch(ctx));
+    double out[44];
+    HIP_TRY(ctx, hipMemcpyAsync(out, dout, sizeof(out), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    std::memcpy(H, out, 36 * sizeof(double));
+    std::memcpy(g, out + 36, 6 * sizeof(double));
+    *e = out[42];
+    if (n_used) *n_used = (int32_t)out[43];
+    return STVO_OK;
+}
+
+int stvo_optimize_pose(stvo_ctx* ctx, const double init_T[16], const stvo_cam* cam, const stvo_opt_params* params,
+                       stvo_matched* m, stvo_pose_result* out) {
+    if (!ctx || !init_T || !cam || !params || !m || !out) return STVO_ERR_INVALID_ARG;
+    if ((m->np > 0 && (!m->P || !m->pl_obs || !m->sigma2p || !m->inlier_p)) ||
+        (m->nl > 0 && (!m->sP || !m->eP || !m->le_obs || !m->spl || !m->epl || !m->sigma2l || !m->inlier_l)))
+        return STVO_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->arena_off = 0;
+    stvo::PoseArgs a;
+    int32_t *dip, *dil;
+    TRY(stage_records(ctx, m, init_T, &a, &dip, &dil));
+    a.cam = *cam;
+    a.prm = *params;
+    stvo_pose_result* dres = arena_alloc<stvo_pose_result>(ctx, 1);
+    int32_t* dop = arena_alloc<int32_t>(ctx, (size_t)a.max_pts);
+    int32_t* dol = arena_alloc<int32_t>(ctx, (size_t)(a.max_lines > 0 ? a.max_lines : 1));
+    if (!dres || !dop || !dol) return STVO_ERR_CAPACITY;
+    a.results = dres;
+    a.inl_p_out = dop;
+    a.inl_l_out = dol;
+    TRY(stvo::launch_pose(ctx->stream, a));
+    TRY(check_launch(ctx));
+    HIP_TRY(ctx, hipMemcpyAsync(out, dres, sizeof(*out), hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<int32_t> ip((size_t)(m->np > 0 ? m->np : 1)), il((size_t)(m->nl > 0 ? m->nl : 1));
+    if (m->np) HIP_TRY(ctx, hipMemcpyAsync(ip.data(), dop, (size_t)m->np * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (m->nl) HIP_TRY(ctx, hipMemcpyAsync(il.data(), dol, (size_t)m->nl * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    // records the optimizer never saw (has_points / has_lines off) keep their flags
+    if (params->has_points)
+        for (int i = 0; i < m->np; ++i) m->inlier_p[i] = ip[i] > 0 ? 1 : 0;
+    if (params->has_lines)
+        for (int i = 0; i < m->nl; ++i) m->inlier_l[i] = il[i] > 0 ? 1 : 0;
+    return STVO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+int fill_pose_args(const stvo_track_batch_dev* b, const stvo_cam* cam, const stvo_opt_params* prm, bool identity,
+                   stvo::PoseArgs* a) {
+    std::memset(a, 0, sizeof(*a));
+    a->B = b->B;
+    a->max_pts = b->max_pts;
+    a->max_lines = b->max_lines;
+    a->n_prev_pts = b->n_prev_pts;
+    a->prev_P = b->prev_P;
+    a->prev_s2p = b->prev_sigma2p;
+    a->curr_pl = b->curr_pl;
+    a->m12p = identity ? nullptr : b->m12_pts;
+    a->n_prev_lines = b->max_lines > 0 ? b->n_prev_lines : nullptr;
+    a->prev_sP = b->prev_sP;
+    a->prev_eP = b->prev_eP;
+    a->prev_spl = b->prev_spl;
+    a->prev_epl = b->prev_epl;
+    a->prev_s2l = b->prev_sigma2l;
+    a->curr_le = b->curr_le;
+    a->m12l = identity ? nullptr : b->m12_lines;
+    a->init_T = b->init_T;
+    a->cam = *cam;
+    a->prm = *prm;
+    a->results = b->results;
+    a->inl_p_out = b->inlier_pts;
+    a->inl_l_out = b->inlier_lines;
+    return STVO_OK;
+}
+
+int check_batch(stvo_ctx* ctx, const stvo_track_batch_dev* b, bool need_desc) {
+    if (!ctx || !b || b->B < 0 || b->max_pts <= 0 || b->max_lines < 0) return STVO_ERR_INVALID_ARG;
+    if (!b->n_prev_pts || !b->prev_P || !b->prev_sigma2p || !b->curr_pl || !b->results) return STVO_ERR_INVALID_ARG;
+    if (need_desc && (!b->prev_pdesc || !b->curr_pdesc || !b->n_curr_pts || !b->m12_pts)) return STVO_ERR_INVALID_ARG;
+    if (b->max_lines > 0) {
+        if (!b->n_prev_lines || !b->prev_sP || !b->prev_eP || !b->prev_spl || !b->prev_epl || !b->prev_sigma2l ||
+            !b->curr_le)
+            return STVO_ERR_INVALID_ARG;
+        if (need_desc && (!b->prev_ldesc || !b->curr_ldesc || !b->n_curr_lines || !b->m12_lines))
+            return STVO_ERR_INVALID_ARG;
+    }
+    if (b->max_pts > STVO_POSE_MAX_POINTS || b->max_lines > STVO_POSE_MAX_LINES) return STVO_ERR_CAPACITY;
+    if ((size_t)b->B * (size_t)(b->max_pts > b->max_lines ? b->max_pts : b->max_lines) >
+        (size_t)ctx->max_batch * (size_t)ctx->max_rows)
+        return STVO_ERR_CAPACITY;
+    return STVO_OK;
+}
+
+}  // namespace
+
+int stvo_track_batched_dev(stvo_ctx* ctx, const stvo_track_batch_dev* b, const stvo_cam* cam,
+                           const stvo_opt_params* params, float nnr_points, float nnr_lines, int mutual) {
+    if (!cam || !params || !(nnr_points <= 1.0f) || !(nnr_lines <= 1.0f)) return STVO_ERR_INVALID_ARG;
+    TRY(check_batch(ctx, b, true));
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (b->B == 0) return STVO_OK;
+    // matchF2FPoints (:131-153)
+    if (params->has_points) {
+        stvo::launch_hamming_knn2(ctx->stream, b->B, b->max_pts, b->max_pts, b->prev_pdesc, b->n_prev_pts,
+                                  b->curr_pdesc, b->n_curr_pts, ctx->knn12, ctx->knn21, mutual ? 1 : 0);
+        stvo::launch_nnr_mutual(ctx->stream, b->B, b->max_pts, ctx->knn12, ctx->knn21, b->n_prev_pts, b->n_curr_pts,
+                                nnr_points, mutual, b->m12_pts);
+    }
+    // matchF2FLines (:155-180)
+    if (params->has_lines && b->max_lines > 0) {
+        stvo::launch_hamming_knn2(ctx->stream, b->B, b->max_lines, b->max_lines, b->prev_ldesc, b->n_prev_lines,
+                                  b->curr_ldesc, b->n_curr_lines, ctx->knn12, ctx->knn21, mutual ? 1 : 0);
+        stvo::launch_nnr_mutual(ctx->stream, b->B, b->max_lines, ctx->knn12, ctx->knn21, b->n_prev_lines,
+                                b->n_curr_lines, nnr_lines, mutual, b->m12_lines);
+    }
+    stvo::PoseArgs a;
+    fill_pose_args(b, cam, params, false, &a);
+    TRY(stvo::launch_pose(ctx->stream, a));
+    return check_launch(ctx);
+}
+
+int stvo_optimize_pose_batched_dev(stvo_ctx* ctx, const stvo_track_batch_dev* b, const stvo_cam* cam,
+                                   const stvo_opt_params* params) {
+    if (!cam || !params) return STVO_ERR_INVALID_ARG;
+    TRY(check_batch(ctx, b, false));
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    stvo::PoseArgs a;
+    fill_pose_args(b, cam, params, true, &a);
+    TRY(stvo::launch_pose(ctx->stream, a));
+    return check_launch(ctx);
+}
+
+int stvo_time_stage_dev(stvo_ctx* ctx, const stvo_track_batch_dev* b, const stvo_cam* cam,
+                        const stvo_opt_params* params, float nnr, int stage, int iters, float* avg_ms) {
+    if (!cam || !params || !avg_ms || iters <= 0) return STVO_ERR_INVALID_ARG;
+    TRY(check_batch(ctx, b, true));
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipEvent_t e0, e1;
+    HIP_TRY(ctx, hipEventCreate(&e0));
+    HIP_TRY(ctx, hipEventCreate(&e1));
+    stvo::PoseArgs a;
+    fill_pose_args(b, cam, params, false, &a);
+    (void)nnr;
+    HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
+    for (int it = 0; it < iters; ++it) {
+        if (stage == 0)
+            stvo::launch_hamming_knn2(ctx->stream, b->B, b->max_pts, b->max_pts, b->prev_pdesc, b->n_prev_pts,
+                                      b->curr_pdesc, b->n_curr_pts, ctx->knn12, ctx->knn21, 1);
+        else
+            stvo::launch_pose(ctx->stream, a);
+    }
+    HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
+    HIP_TRY(ctx, hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    *avg_ms = ms / (float)iters;
+    return check_launch(ctx);
+}
+
+int stvo_valu_peak_probe(stvo_ctx* ctx, double* lane_ops_per_s) {
+    if (!ctx || !lane_ops_per_s) return STVO_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int blocks = 256 * 8, iters = 4000;
+    hipEvent_t e0, e1;
+    HIP_TRY(ctx, hipEventCreate(&e0));
+    HIP_TRY(ctx, hipEventCreate(&e1));
+    stvo::launch_valu_probe(ctx->stream, blocks, 64, ctx->probe_sink);  // warm-up
+    HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
+    stvo::launch_valu_probe(ctx->stream, blocks, iters, ctx->probe_sink);
+    HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
+    HIP_TRY(ctx, hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    *lane_ops_per_s = (double)blocks * 256.0 * (double)iters * stvo::kValuProbeOpsPerThreadIter / ((double)ms * 1e-3);
+    return check_launch(ctx);
+}
+
+// K3 entry points live in grid_capi.hip
+}  // extern "C"

@@ -1,0 +1,224 @@
+"""ctypes binding of the product library stvo-pl_amd/libstvo_hip.so (include/stvo_hip.h).
+
+Plumbing for tests and bench only.  There is NO fallback: if the library is missing or no gfx950
+device is visible, loading / context creation raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from .ctypes_types import Cam, GridWindow, OptParams, PoseResult
+
+PKG_DIR = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # stvo-pl_amd/
+LIB_PATH = os.path.join(PKG_DIR, "libstvo_hip.so")
+
+EXPORTS = ["stvo_backend_name", "stvo_abi_version", "stvo_error_string", "stvo_ctx_last_error", "stvo_ctx_create",
+           "stvo_ctx_destroy", "stvo_ctx_set_stream", "stvo_ctx_synchronize", "stvo_match_nnr_mutual",
+           "stvo_match_grid_points", "stvo_match_grid_lines", "stvo_normal_eq", "stvo_optimize_pose",
+           "stvo_track_batched_dev", "stvo_match_nnr_mutual_batched_dev", "stvo_optimize_pose_batched_dev",
+           "stvo_time_stage_dev", "stvo_valu_peak_probe"]
+
+u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+
+
+class Matched(C.Structure):
+    _fields_ = [("np", C.c_int32), ("P", C.c_void_p), ("pl_obs", C.c_void_p), ("sigma2p", C.c_void_p),
+                ("inlier_p", C.c_void_p), ("nl", C.c_int32), ("sP", C.c_void_p), ("eP", C.c_void_p),
+                ("le_obs", C.c_void_p), ("spl", C.c_void_p), ("epl", C.c_void_p), ("sigma2l", C.c_void_p),
+                ("inlier_l", C.c_void_p)]
+
+
+class TrackBatchDev(C.Structure):
+    _fields_ = [("B", C.c_int32), ("max_pts", C.c_int32), ("max_lines", C.c_int32), ("reserved", C.c_int32)] + \
+               [(n, C.c_void_p) for n in ("n_prev_pts", "prev_pdesc", "prev_P", "prev_sigma2p", "n_curr_pts",
+                                          "curr_pdesc", "curr_pl", "n_prev_lines", "prev_ldesc", "prev_sP", "prev_eP",
+                                          "prev_spl", "prev_epl", "prev_sigma2l", "n_curr_lines", "curr_ldesc",
+                                          "curr_le", "init_T", "m12_pts", "m12_lines", "inlier_pts", "inlier_lines",
+                                          "results")]
+
+
+class StvoError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile libstvo_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-s", "-C", PKG_DIR, "clean"])
+    subprocess.check_call(["make", "-s", "-C", PKG_DIR, "-j4"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise StvoError(f"{LIB_PATH} is missing: run `make -C stvo-pl_amd` (python __graft_entry__.py). "
+                        "The product has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    L.stvo_backend_name.restype = C.c_char_p
+    L.stvo_error_string.restype = C.c_char_p
+    L.stvo_error_string.argtypes = [C.c_int]
+    L.stvo_ctx_last_error.restype = C.c_char_p
+    L.stvo_ctx_last_error.argtypes = [C.c_void_p]
+    L.stvo_ctx_create.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.stvo_ctx_destroy.argtypes = [C.c_void_p]
+    L.stvo_ctx_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    L.stvo_ctx_synchronize.argtypes = [C.c_void_p]
+    L.stvo_match_nnr_mutual.argtypes = [C.c_void_p, u8p, C.c_int, u8p, C.c_int, C.c_float, C.c_int, i32p,
+                                        C.POINTER(C.c_int32)]
+    L.stvo_match_grid_points.argtypes = [C.c_void_p, i32p, u8p, C.c_int, i32p, i32p, u8p, C.c_int,
+                                         C.POINTER(GridWindow), C.c_double, C.c_int, i32p, C.POINTER(C.c_int32)]
+    L.stvo_match_grid_lines.argtypes = [C.c_void_p, i32p, u8p, C.c_int, i32p, i32p, u8p, C.c_int, f64p,
+                                        C.POINTER(GridWindow), C.c_double, C.c_double, C.c_int, i32p,
+                                        C.POINTER(C.c_int32)]
+    L.stvo_normal_eq.argtypes = [C.c_void_p, f64p, C.POINTER(Cam), C.POINTER(OptParams), C.POINTER(Matched), C.c_int,
+                                 f64p, f64p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
+    L.stvo_optimize_pose.argtypes = [C.c_void_p, f64p, C.POINTER(Cam), C.POINTER(OptParams), C.POINTER(Matched),
+                                     C.POINTER(PoseResult)]
+    L.stvo_track_batched_dev.argtypes = [C.c_void_p, C.POINTER(TrackBatchDev), C.POINTER(Cam), C.POINTER(OptParams),
+                                         C.c_float, C.c_float, C.c_int]
+    L.stvo_match_nnr_mutual_batched_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                    C.c_void_p, C.c_float, C.c_int, C.c_void_p]
+    L.stvo_optimize_pose_batched_dev.argtypes = [C.c_void_p, C.POINTER(TrackBatchDev), C.POINTER(Cam),
+                                                 C.POINTER(OptParams)]
+    L.stvo_time_stage_dev.argtypes = [C.c_void_p, C.POINTER(TrackBatchDev), C.POINTER(Cam), C.POINTER(OptParams),
+                                      C.c_float, C.c_int, C.c_int, C.POINTER(C.c_float)]
+    L.stvo_valu_peak_probe.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    _lib = L
+    return L
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One stvo_ctx.  Raises StvoError on any non-zero status."""
+
+    def __init__(self, device_id=0, max_rows=4096, max_batch=64):
+        self.lib = load()
+        self.h = C.c_void_p()
+        rc = self.lib.stvo_ctx_create(device_id, max_rows, max_batch, C.byref(self.h))
+        if rc != 0:
+            self.h = None
+            raise StvoError(f"stvo_ctx_create failed: {self.lib.stvo_error_string(rc).decode()} ({rc})")
+
+    def close(self):
+        if self.h:
+            self.lib.stvo_ctx_destroy(self.h)
+            self.h = None
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise StvoError(f"{self.lib.stvo_error_string(rc).decode()} ({rc}): "
+                            f"{self.lib.stvo_ctx_last_error(self.h).decode()}")
+
+    def set_stream(self, stream_handle):
+        self._chk(self.lib.stvo_ctx_set_stream(self.h, C.c_void_p(stream_handle)))
+
+    def synchronize(self):
+        self._chk(self.lib.stvo_ctx_synchronize(self.h))
+
+    # ---- host-buffer seams ----
+    def match(self, d1, d2, nnr, mutual=1):
+        d1 = np.ascontiguousarray(d1, np.uint8).reshape(-1, 32)
+        d2 = np.ascontiguousarray(d2, np.uint8).reshape(-1, 32)
+        m12 = np.empty(max(len(d1), 1), np.int32)
+        n = C.c_int32()
+        self._chk(self.lib.stvo_match_nnr_mutual(self.h, d1 if len(d1) else np.zeros((1, 32), np.uint8), len(d1),
+                                                 d2 if len(d2) else np.zeros((1, 32), np.uint8), len(d2), nnr, mutual,
+                                                 m12, C.byref(n)))
+        return m12[:len(d1)], n.value
+
+    def match_grid_points(self, cell_xy1, d1, start, items, d2, w, ratio, mutual=1):
+        n1 = len(d1)
+        m12 = np.empty(max(n1, 1), np.int32)
+        n = C.c_int32()
+        gw = GridWindow(*w)
+        items_ = np.ascontiguousarray(items, np.int32) if len(items) else np.zeros(1, np.int32)
+        d1_ = d1 if n1 else np.zeros((1, 32), np.uint8)
+        d2_ = d2 if len(d2) else np.zeros((1, 32), np.uint8)
+        xy = np.ascontiguousarray(cell_xy1, np.int32).reshape(-1) if n1 else np.zeros(2, np.int32)
+        self._chk(self.lib.stvo_match_grid_points(self.h, xy, d1_, n1, np.ascontiguousarray(start, np.int32), items_,
+                                                  d2_, len(d2), C.byref(gw), ratio, mutual, m12, C.byref(n)))
+        return m12[:n1], n.value
+
+    def match_grid_lines(self, cell_xy1, d1, start, items, d2, dir2, w, ratio, line_sim_th, mutual=1):
+        n1 = len(d1)
+        m12 = np.empty(max(n1, 1), np.int32)
+        n = C.c_int32()
+        gw = GridWindow(*w)
+        items_ = np.ascontiguousarray(items, np.int32) if len(items) else np.zeros(1, np.int32)
+        d1_ = d1 if n1 else np.zeros((1, 32), np.uint8)
+        d2_ = d2 if len(d2) else np.zeros((1, 32), np.uint8)
+        xy = np.ascontiguousarray(cell_xy1, np.int32).reshape(-1) if n1 else np.zeros(4, np.int32)
+        dr = np.ascontiguousarray(dir2, np.float64).reshape(-1) if len(d2) else np.zeros(2)
+        self._chk(self.lib.stvo_match_grid_lines(self.h, xy, d1_, n1, np.ascontiguousarray(start, np.int32), items_,
+                                                 d2_, len(d2), dr, C.byref(gw), ratio, line_sim_th, mutual, m12,
+                                                 C.byref(n)))
+        return m12[:n1], n.value
+
+    @staticmethod
+    def _matched(rec):
+        keep = {k: np.ascontiguousarray(rec[k], np.float64)
+                for k in ("P", "pl_obs", "sigma2p", "sP", "eP", "le_obs", "spl", "epl", "sigma2l")}
+        keep["inlier_p"] = np.ascontiguousarray(rec["inlier_p"], np.int32).copy()
+        keep["inlier_l"] = np.ascontiguousarray(rec["inlier_l"], np.int32).copy()
+        m = Matched(len(keep["sigma2p"]), _ptr(keep["P"]), _ptr(keep["pl_obs"]), _ptr(keep["sigma2p"]),
+                    _ptr(keep["inlier_p"]), len(keep["sigma2l"]), _ptr(keep["sP"]), _ptr(keep["eP"]),
+                    _ptr(keep["le_obs"]), _ptr(keep["spl"]), _ptr(keep["epl"]), _ptr(keep["sigma2l"]),
+                    _ptr(keep["inlier_l"]))
+        return m, keep
+
+    def normal_eq(self, T, cam, params, rec, robust=0):
+        m, keep = self._matched(rec)
+        H = np.empty(36)
+        g = np.empty(6)
+        e = C.c_double()
+        n = C.c_int32()
+        camc = Cam.from_dict(cam)
+        self._chk(self.lib.stvo_normal_eq(self.h, np.ascontiguousarray(T, np.float64).reshape(-1), C.byref(camc),
+                                          C.byref(params), C.byref(m), robust, H, g, C.byref(e), C.byref(n)))
+        return H.reshape(6, 6), g, e.value, n.value
+
+    def optimize_pose(self, init_T, cam, params, rec):
+        m, keep = self._matched(rec)
+        res = PoseResult()
+        camc = Cam.from_dict(cam)
+        self._chk(self.lib.stvo_optimize_pose(self.h, np.ascontiguousarray(init_T, np.float64).reshape(-1),
+                                              C.byref(camc), C.byref(params), C.byref(m), C.byref(res)))
+        d = res.as_dict()
+        d["inlier_p"] = keep["inlier_p"]
+        d["inlier_l"] = keep["inlier_l"]
+        return d
+
+    def valu_peak(self):
+        v = C.c_double()
+        self._chk(self.lib.stvo_valu_peak_probe(self.h, C.byref(v)))
+        return v.value
+
+    # ---- batched device-resident path ----
+    def track_batched(self, batch, cam, params, nnr_p, nnr_l, mutual=1):
+        camc = Cam.from_dict(cam)
+        self._chk(self.lib.stvo_track_batched_dev(self.h, C.byref(batch.struct), C.byref(camc), C.byref(params), nnr_p,
+                                                  nnr_l, mutual))
+
+    def optimize_pose_batched(self, batch, cam, params):
+        camc = Cam.from_dict(cam)
+        self._chk(self.lib.stvo_optimize_pose_batched_dev(self.h, C.byref(batch.struct), C.byref(camc), C.byref(params)))
+
+    def time_stage(self, batch, cam, params, nnr, stage, iters):
+        camc = Cam.from_dict(cam)
+        ms = C.c_float()
+        self._chk(self.lib.stvo_time_stage_dev(self.h, C.byref(batch.struct), C.byref(camc), C.byref(params), nnr,
+                                               stage, iters, C.byref(ms)))
+        return ms.value

@@ -1,0 +1,44 @@
+// pm_host.cpp — TEST INFRASTRUCTURE ONLY: exposes the product's pose_math.h (the FP64 building
+// blocks the HIP pose kernel is made of) to the CPU test-suite, so that the algebra the GPU runs
+// is checked against the oracle in this GPU-less container.  Not part of the product library.
+#include "../../stvo-pl_amd/csrc/pose_math.h"
+
+extern "C" {
+void pmh_expmap(const double* x, double* T) { pm::expmap_se3(x, T); }
+void pmh_logmap(const double* T, double* x) { pm::logmap_se3(T, x); }
+void pmh_inverse_se3(const double* T, double* Ti) { pm::inverse_se3(T, Ti); }
+void pmh_adjoint(const double* T, double* A) { pm::adjoint_se3(T, A); }
+void pmh_unccomp(const double* T1, const double* c1, const double* ci, double* out) { pm::unccomp_se3(T1, c1, ci, out); }
+int pmh_solve6(const double* H, const double* g, double* x, double* lad) { return pm::solve6(H, g, x, lad); }
+void pmh_inverse6(const double* A, double* Ai) { pm::inverse6(A, Ai); }
+void pmh_eig6(const double* A, double* w) { pm::eig6(A, w); }
+void pmh_step_pose(double* DT, const double* inc) { pm::step_pose(DT, inc); }
+double pmh_line_overlap(const double* so, const double* eo, const double* sp, const double* ep) {
+    return pm::line_overlap(so[0], so[1], eo[0], eo[1], sp[0], sp[1], ep[0], ep[1]);
+}
+// serial emulation of one optimizeFunctions evaluation using the device per-feature terms
+void pmh_normal_eq(const double* DT, const stvo_cam* cam, double homog_th, const stvo_matched* m, int robust, double s_p,
+                   double s_l, double* acc28) {
+    pm::Cam5 c{cam->fx, cam->fy, cam->cx, cam->cy};
+    for (int i = 0; i < 28; ++i) acc28[i] = 0.0;
+    for (int i = 0; i < m->np; ++i)
+        if (m->inlier_p[i])
+            pm::point_term(acc28, DT, c, homog_th, m->P[3 * i], m->P[3 * i + 1], m->P[3 * i + 2], m->pl_obs[2 * i],
+                           m->pl_obs[2 * i + 1], m->sigma2p[i], robust != 0, s_p);
+    for (int i = 0; i < m->nl; ++i)
+        if (m->inlier_l[i]) {
+            pm::LineRec L;
+            for (int k = 0; k < 3; ++k) {
+                L.sP[k] = m->sP[3 * i + k];
+                L.eP[k] = m->eP[3 * i + k];
+                L.le[k] = m->le_obs[3 * i + k];
+            }
+            for (int k = 0; k < 2; ++k) {
+                L.spl[k] = m->spl[2 * i + k];
+                L.epl[k] = m->epl[2 * i + k];
+            }
+            L.sigma2 = m->sigma2l[i];
+            pm::line_term(acc28, DT, c, homog_th, L, robust != 0, s_l);
+        }
+}
+}

@@ -1,0 +1,83 @@
+"""GPU parity: K1/K2 (hamming_knn2 + nnr_mutual) through the C-ABI vs the oracle.  Bit-exact."""
+import numpy as np
+import pytest
+
+from stvo_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def rand_desc(rng, n, entropy_bits=256):
+    d = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    if entropy_bits < 256:
+        keep = np.zeros(32, np.uint8)
+        keep[: entropy_bits // 8] = 0xFF
+        d &= keep
+    return d
+
+
+@pytest.mark.parametrize("n1,n2,nnr,ent", [(2000, 2000, 0.75, 256), (1999, 1777, 0.9, 256), (800, 800, 0.9, 24),
+                                            (300, 257, 0.75, 16), (64, 64, 0.8, 8), (65, 63, 0.75, 256),
+                                            (1, 2, 0.75, 256), (2, 1, 0.75, 256), (5, 3, 1.0, 8), (3, 5, 0.5, 256),
+                                            (4096, 4095, 0.75, 256)])
+def test_match_bit_exact(hip, oracle, n1, n2, nnr, ent):
+    rng = np.random.default_rng(n1 * 7919 + n2)
+    d2 = rand_desc(rng, n2, ent)
+    d1 = rand_desc(rng, n1, ent)
+    k = min(n1, n2) // 2
+    if k:
+        d1[:k] = synth.flip_bits(rng, d2[rng.permutation(n2)[:k]], 0.06)
+    for mutual in (1, 0):
+        got, n = hip.match(d1, d2, nnr, mutual)
+        exp, en = oracle.match(d1, d2, nnr, mutual)
+        assert np.array_equal(got, exp), (n1, n2, mutual, np.nonzero(got != exp)[0][:10])
+        assert n == en
+
+
+def test_match_empty_and_errors(hip):
+    from stvo_amd.capi import StvoError
+    z = np.zeros((0, 32), np.uint8)
+    d = np.zeros((4, 32), np.uint8)
+    m, n = hip.match(z, d, 0.75)
+    assert len(m) == 0 and n == 0
+    m, n = hip.match(d, z, 0.75)
+    assert np.all(m == -1) and n == 0
+    with pytest.raises(StvoError):
+        hip.match(d, d, 1.5)  # nnr > 1 is outside the order-independent regime
+    with pytest.raises(StvoError):
+        hip.match(np.zeros((5000, 32), np.uint8), d, 0.75)  # capacity of the fixture context is 4096
+
+
+def test_match_config2_frames(hip, oracle):
+    for frame in range(3):
+        fr = synth.make_f2f_points(synth.frame_seed(0, frame), n=2000)
+        got, n = hip.match(fr["prev_desc"], fr["curr_desc"], 0.75)
+        exp, en = oracle.match(fr["prev_desc"], fr["curr_desc"], 0.75)
+        assert np.array_equal(got, exp) and n == en
+        assert 1300 <= n <= 1520  # SURVEY.md §8(d) config 2 expectation
+
+
+def test_match_all_identical_descriptors_no_match(hip, oracle):
+    d = np.tile(np.arange(32, dtype=np.uint8), (300, 1))
+    got, n = hip.match(d, d, 0.9)
+    exp, en = oracle.match(d, d, 0.9)
+    assert np.array_equal(got, exp) and n == en == 0  # best == second fails the ratio test
+
+
+def test_match_size_independent_properties(hip):
+    """Full-size property checks that need no oracle run: permutation equivariance and symmetry."""
+    rng = np.random.default_rng(5)
+    fr = synth.make_f2f_points(123, n=2000)
+    d1, d2 = fr["prev_desc"], fr["curr_desc"]
+    m12, _ = hip.match(d1, d2, 0.75)
+    m21, _ = hip.match(d2, d1, 0.75)
+    # mutual matching is symmetric: (i -> j) in 12  <=>  (j -> i) in 21
+    idx = np.nonzero(m12 >= 0)[0]
+    assert np.array_equal(m21[m12[idx]], idx)
+    assert (m21 >= 0).sum() == len(idx)
+    # permuting the train rows permutes the answer
+    perm = rng.permutation(len(d2))
+    mp, _ = hip.match(d1, d2[perm], 0.75)
+    inv = np.empty_like(perm); inv[perm] = np.arange(len(perm))
+    exp = np.where(m12 >= 0, inv[np.maximum(m12, 0)], -1)
+    assert np.array_equal(mp, exp)

@@ -1,0 +1,53 @@
+"""GPU parity of the batched, device-resident path (f2f match + optimizePose for B frame pairs)
+against per-frame oracle runs, at BASELINE config-2 size (2000 ORB rows per frame)."""
+import numpy as np
+import pytest
+
+import np_model
+from stvo_amd import synth
+from stvo_amd.ctypes_types import opt_params
+
+pytestmark = pytest.mark.gpu
+CAM = synth.KITTI_CAM
+
+
+def oracle_track(oracle, fr, prm, nnr):
+    m12, _ = oracle.match(fr["prev_desc"], fr["curr_desc"], nnr)
+    sel = np.nonzero(m12 >= 0)[0]
+    z3 = np.zeros((0, 3)); z2 = np.zeros((0, 2))
+    rec = dict(P=fr["prev_P"][sel], pl_obs=fr["curr_pl"][m12[sel]], sigma2p=fr["prev_sigma2"][sel],
+               inlier_p=np.ones(len(sel), np.int32), sP=z3, eP=z3, le_obs=z3, spl=z2, epl=z2, sigma2l=np.zeros(0),
+               inlier_l=np.zeros(0, np.int32))
+    out = oracle.optimize_pose(np.eye(4), CAM, prm, rec)
+    return m12, sel, out
+
+
+def test_track_batched_points_config2(hip, oracle):
+    import torch
+    from stvo_amd.devbatch import TrackBatch
+    B = 12
+    frames = [synth.make_f2f_points(synth.frame_seed(0, k), n=2000 - 37 * (k % 3)) for k in range(B)]
+    batch = TrackBatch(frames, max_pts=2048)
+    prm = opt_params("kitti", has_lines=0)
+    hip.set_stream(torch.cuda.current_stream().cuda_stream)
+    hip.track_batched(batch, CAM, prm, 0.75, 0.75, 1)
+    torch.cuda.synchronize()
+    res = batch.results(); m12_all = batch.m12_pts(); inl_all = batch.inlier_pts()
+    for b, fr in enumerate(frames):
+        m12, sel, ref = oracle_track(oracle, fr, prm, 0.75)
+        n1 = len(fr["prev_P"])
+        assert np.array_equal(m12_all[b, :n1], m12)
+        assert res["status"][b] == ref["status"] and res["path"][b] == ref["path"]
+        assert tuple(res["iters"][b]) == ref["iters"]
+        assert res["n_matched_pt"][b] == len(sel) and res["n_inliers_pt"][b] == ref["n_inliers_pt"]
+        exp_inl = -np.ones(n1, np.int32); exp_inl[sel] = ref["inlier_p"]
+        assert np.array_equal(inl_all[b, :n1], exp_inl)
+        T = res["T"][b].reshape(4, 4)
+        assert np_model.rot_angle(T[:3, :3], ref["T"][:3, :3]) < 1e-4
+        assert np.linalg.norm(T[:3, 3] - ref["T"][:3, 3]) < 1e-3
+        assert np.allclose(T, ref["T"], atol=1e-8)
+        assert np.isclose(res["err"][b], ref["err"], rtol=1e-8)
+        # and the estimate is the true motion (stored inverted) up to noise
+        Tt = np.linalg.inv(fr["T_true"])
+        assert np_model.rot_angle(T[:3, :3], Tt[:3, :3]) < 3e-3 and np.linalg.norm(T[:3, 3] - Tt[:3, 3]) < 0.05
+    hip.set_stream(None)

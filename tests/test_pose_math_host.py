@@ -1,0 +1,123 @@
+"""The product's FP64 building blocks (stvo-pl_amd/csrc/pose_math.h — the code the HIP pose kernel
+is assembled from) compiled for the HOST and checked against the oracle.  Runs without a GPU."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import np_model
+import oracle_lib
+from stvo_amd import synth
+from stvo_amd.ctypes_types import Cam, opt_params
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+
+
+@pytest.fixture(scope="module")
+def pmh():
+    src = os.path.join(HERE, "cpp", "pm_host.cpp")
+    so = os.path.join(HERE, "cpp", "libpm_host.so")
+    hdr = os.path.join(HERE, "..", "stvo-pl_amd", "csrc", "pose_math.h")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-o", so, src])
+    lib = C.CDLL(so)
+    for n in ("pmh_expmap", "pmh_logmap", "pmh_inverse_se3", "pmh_adjoint", "pmh_inverse6", "pmh_eig6", "pmh_step_pose"):
+        getattr(lib, n).argtypes = [f64p, f64p]; getattr(lib, n).restype = None
+    lib.pmh_unccomp.argtypes = [f64p] * 4
+    lib.pmh_solve6.argtypes = [f64p, f64p, f64p, C.POINTER(C.c_double)]; lib.pmh_solve6.restype = C.c_int
+    lib.pmh_line_overlap.argtypes = [f64p] * 4; lib.pmh_line_overlap.restype = C.c_double
+    lib.pmh_normal_eq.argtypes = [f64p, C.POINTER(Cam), C.c_double, C.c_void_p, C.c_int, C.c_double, C.c_double, f64p]
+    return lib
+
+
+def call(lib, name, x, nout):
+    out = np.empty(nout)
+    getattr(lib, name)(np.ascontiguousarray(x, np.float64).reshape(-1), out)
+    return out
+
+
+def test_se3_blocks(pmh, oracle):
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        x = np.concatenate([rng.normal(0, 1, 3), rng.normal(0, 0.4, 3)])
+        T = oracle.expmap(x)
+        assert np.allclose(call(pmh, "pmh_expmap", x, 16).reshape(4, 4), T, atol=1e-15)
+        assert np.allclose(call(pmh, "pmh_logmap", T, 6), oracle.logmap(T), atol=1e-13)
+        assert np.allclose(call(pmh, "pmh_inverse_se3", T, 16).reshape(4, 4), oracle.inverse_se3(T), atol=1e-15)
+        assert np.allclose(call(pmh, "pmh_adjoint", T, 36).reshape(6, 6), oracle.adjoint(T), atol=1e-15)
+    x = np.array([1.0, 2.0, 3.0, 3e-7, 0, 0])
+    T = call(pmh, "pmh_expmap", x, 16).reshape(4, 4)
+    assert np.array_equal(T[:3, :3], np.eye(3)) and np.array_equal(T[:3, 3], x[:3])
+    assert np.array_equal(call(pmh, "pmh_logmap", np.eye(4), 6), np.zeros(6))
+    A = rng.normal(size=(6, 6)); c1 = A @ A.T; B = rng.normal(size=(6, 6)); ci = B @ B.T
+    out = np.empty(36)
+    pmh.pmh_unccomp(T.reshape(-1), c1.reshape(-1), ci.reshape(-1), out)
+    assert np.allclose(out.reshape(6, 6), oracle.unccomp(T, c1, ci), rtol=1e-14)
+
+
+def test_dense6_blocks(pmh, oracle):
+    rng = np.random.default_rng(1)
+    for k in range(200):
+        J = rng.normal(size=(30, 6)) * np.array([1, 1, 1, 30, 30, 30.0])
+        H = J.T @ J if k % 4 else rng.normal(size=(6, 6))
+        g = rng.normal(size=6)
+        x = np.empty(6); lad = C.c_double()
+        rank = pmh.pmh_solve6(np.ascontiguousarray(H).reshape(-1), g, x, C.byref(lad))
+        ox, olad, orank = oracle.solve6(H, g)
+        assert rank == orank == 6
+        assert np.allclose(x, ox, rtol=1e-12, atol=1e-14) and np.isclose(lad.value, olad, rtol=1e-13)
+        assert np.allclose(call(pmh, "pmh_inverse6", H, 36), oracle.inverse6(H).reshape(-1), rtol=1e-11, atol=1e-15)
+        assert np.allclose(call(pmh, "pmh_eig6", H, 6), oracle.eig6(H), rtol=1e-11, atol=1e-11)
+    J = rng.normal(size=(3, 6)); H = J.T @ J; g = J.T @ np.ones(3)
+    x = np.empty(6); lad = C.c_double()
+    rank = pmh.pmh_solve6(H.reshape(-1).copy(), g, x, C.byref(lad))
+    ox, _, orank = oracle.solve6(H, g)
+    assert rank == orank == 3 and np.allclose(x, ox, atol=1e-9)
+    # NaN input must terminate and propagate
+    Hn = np.full((6, 6), np.nan)
+    assert np.all(np.isnan(call(pmh, "pmh_eig6", Hn, 6)))
+    pmh.pmh_solve6(Hn.reshape(-1).copy(), g, x, C.byref(lad))
+    DT = np.eye(4).reshape(-1).copy()
+    inc = rng.normal(0, 0.1, 6)
+    pmh.pmh_step_pose(DT, inc)
+    assert np.allclose(DT.reshape(4, 4), np.eye(4) @ np_model.inverse_se3(np_model.expmap_se3(inc)), atol=1e-15)
+
+
+def test_line_overlap_block(pmh, oracle):
+    rng = np.random.default_rng(2)
+    for _ in range(1000):
+        so = rng.uniform(0, 400, 2); eo = so + rng.uniform(-200, 200, 2)
+        k = rng.integers(0, 3)
+        if k == 0: eo[0] = so[0] + rng.uniform(-0.99, 0.99)
+        if k == 1: eo[1] = so[1] + rng.uniform(-0.99, 0.99)
+        sp = so + rng.uniform(-150, 150, 2); ep = eo + rng.uniform(-150, 150, 2)
+        a = pmh.pmh_line_overlap(so, eo, sp, ep); b = oracle.line_overlap(so, eo, sp, ep)
+        assert a == b or (np.isnan(a) and np.isnan(b))
+
+
+@pytest.mark.parametrize("robust", [0, 1])
+def test_feature_terms_vs_oracle(pmh, oracle, robust):
+    rec = synth.make_matched_records(7, n_pts=500, n_lines=80, octave_probs=[.5, .25, .15, .1])
+    prm = opt_params("kitti")
+    rec["inlier_p"][::9] = 0; rec["inlier_l"][::5] = 0
+    m, keep = oracle_lib.Oracle._matched(rec)
+    cam = Cam.from_dict(synth.KITTI_CAM)
+    for DT in (np.eye(4), rec["T_true"]):
+        s_p = s_l = 1.0
+        if robust:
+            clamp = lambda s: min(max(s, 1e-4), np.sqrt(7.815))
+            s_p = clamp(oracle.stdv_mad(np_model.point_residuals(synth.KITTI_CAM, DT, rec)[rec["inlier_p"] > 0]))
+            s_l = clamp(oracle.stdv_mad(np_model.line_residuals(synth.KITTI_CAM, DT, rec)[rec["inlier_l"] > 0]))
+        acc = np.empty(28)
+        pmh.pmh_normal_eq(np.ascontiguousarray(DT).reshape(-1), C.byref(cam), prm.homog_th, C.addressof(m), robust, s_p, s_l, acc)
+        H, g, e, n = oracle.optimize_functions(DT, synth.KITTI_CAM, prm, rec, robust)
+        Hd = np.zeros((6, 6)); k = 0
+        for i in range(6):
+            for j in range(i, 6):
+                Hd[i, j] = Hd[j, i] = acc[k]; k += 1
+        assert np.allclose(Hd, H, rtol=1e-12, atol=1e-12 * np.abs(H).max())
+        assert np.allclose(acc[21:27], g, rtol=1e-12, atol=1e-12 * np.abs(g).max())
+        assert np.isclose(acc[27] / n, e, rtol=1e-13)
