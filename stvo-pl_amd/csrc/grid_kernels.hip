@@ -1,8 +1,264 @@
-// grid_kernels.hip — K3 (placeholder until implemented)
+// grid_kernels.hip — K3: the grid-windowed stereo matchers for gfx950.
+//
+// Replaces both overloads of StVO::matchGrid (/root/reference/src/matching.cpp:111-177 points,
+// :179-258 lines) including GridStructure::get (src/gridStructure.cpp:65-76).
+//
+// The reference loop is sequential over the left features i1 with a running strict minimum per
+// right feature i2 (`distances[i2]`, :145-150): a candidate only takes part in i1's best / second
+// if it strictly improves on every EARLIER i1 that had i2 in its window.  Restated without the
+// loop-carried dependence:
+//     eligible(i1,i2)  <=>  D(i1,i2) < min over covering i1' < i1 of D(i1',i2)
+//     owner(i2)        =   lowest i1 attaining the global minimum of D(.,i2)   (= final matches_21)
+// which maps onto three kernels:
+//   A  `grid_cover`   lane = left feature: walks its window cells in the CSR grid and sets bit i2 of
+//                     its row of the candidate bit-matrix (the std::unordered_set de-duplication of
+//                     gridStructure.cpp:75 is the idempotence of OR; lines OR both end-point windows)
+//   B  `grid_scan`    lane = right feature, descriptor resident in 8 VGPRs; the left features stream
+//                     by in ASCENDING i1 as wave-uniform rows (scalar loads) — the same popcount
+//                     inner loop as K1, predicated by the candidate bit and (lines) the direction
+//                     cosine gate (:221-222); each lane carries its running minimum, so eligibility
+//                     and ownership fall out in order; eligible pairs update the left feature's
+//                     packed (best, second) keys with a 64-bit CAS (integer keys: order-independent)
+//   C  `grid_finalize` lane = left feature: DOUBLE ratio test best_d < best_d2 * ratio with
+//                     best_d2 = INT_MAX when only one candidate was eligible (:160), mutual check
+//                     against owner (:166-174).
 #include "ctx_internal.h"
-extern "C" {
-int stvo_match_grid_points(stvo_ctx*, const int32_t*, const uint8_t*, int, const int32_t*, const int32_t*, const uint8_t*,
-                           int, const stvo_grid_window*, double, int, int32_t*, int32_t*) { return STVO_ERR_UNSUPPORTED; }
-int stvo_match_grid_lines(stvo_ctx*, const int32_t*, const uint8_t*, int, const int32_t*, const int32_t*, const uint8_t*,
-                          int, const double*, const stvo_grid_window*, double, double, int, int32_t*, int32_t*) { return STVO_ERR_UNSUPPORTED; }
+
+namespace stvo {
+namespace {
+
+constexpr unsigned long long kTop2Empty = 0xFFFFFFFFFFFFFFFFull;
+
+struct GridArgs {
+    const int32_t* cell_xy1;  // [n1][2] points  |  [n1][4] lines (sx, sy, ex, ey)
+    const uint8_t* d1;
+    int n1;
+    const int32_t* cell_start;
+    const int32_t* cell_items;
+    const uint8_t* d2;
+    int n2;
+    const double* dir2;  // lines only
+    stvo_grid_window w;
+    double ratio, line_sim_th;
+    int mutual;
+    int words64;                 // 64-bit words per cover row = ceil(n2 / 64)
+    unsigned long long* cover;   // [n1][words64]
+    unsigned long long* top2;    // [n1] (second_key << 32) | best_key
+    int32_t* owner2;             // [n2]
+    int32_t* m12;                // [n1]
+};
+
+__device__ __forceinline__ void cover_window(const GridArgs& a, int x, int y, unsigned long long* row) {
+    // GridStructure::get clamping (src/gridStructure.cpp:67-71)
+    const int min_x = max(0, x - a.w.w_lo), max_x = min(STVO_GRID_COLS, x + a.w.w_hi + 1);
+    const int min_y = max(0, y - a.w.h_lo), max_y = min(STVO_GRID_ROWS, y + a.w.h_hi + 1);
+    for (int yy = min_y; yy < max_y; ++yy) {
+        if (min_x >= max_x) break;
+        // cells of one grid row are contiguous in the CSR (cell = y*64 + x)
+        const int lo = a.cell_start[yy * STVO_GRID_COLS + min_x], hi = a.cell_start[yy * STVO_GRID_COLS + max_x];
+        for (int k = lo; k < hi; ++k) {
+            const int id = a.cell_items[k];
+            if (id >= 0 && id < a.n2) row[id >> 6] |= 1ull << (id & 63);  // :141 skips out-of-range ids
+        }
+    }
 }
+
+template <bool LINES>
+__global__ __launch_bounds__(256) void grid_cover_kernel(GridArgs a) {
+    const int i1 = blockIdx.x * 256 + threadIdx.x;
+    if (i1 >= a.n1) return;
+    unsigned long long* row = a.cover + (size_t)i1 * a.words64;  // zeroed by the host (hipMemsetAsync)
+    if (LINES) {
+        const int4 c = reinterpret_cast<const int4*>(a.cell_xy1)[i1];
+        cover_window(a, c.x, c.y, row);
+        cover_window(a, c.z, c.w, row);
+    } else {
+        const int2 c = reinterpret_cast<const int2*>(a.cell_xy1)[i1];
+        cover_window(a, c.x, c.y, row);
+    }
+    a.top2[i1] = kTop2Empty;
+}
+
+__device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc) {
+    uint32_t r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
+
+__device__ __forceinline__ void top2_insert(unsigned long long* slot, uint32_t key) {
+    unsigned long long old = *reinterpret_cast<volatile unsigned long long*>(slot);
+    while (true) {
+        const uint32_t b = (uint32_t)old, s = (uint32_t)(old >> 32);
+        unsigned long long nw;
+        if (key < b)
+            nw = ((unsigned long long)b << 32) | key;
+        else if (key < s)
+            nw = ((unsigned long long)key << 32) | b;
+        else
+            return;
+        const unsigned long long prev = atomicCAS(slot, old, nw);
+        if (prev == old) return;
+        old = prev;
+    }
+}
+
+template <bool LINES>
+__global__ __launch_bounds__(256) void grid_scan_kernel(GridArgs a) {
+    const int i2 = blockIdx.x * 256 + threadIdx.x;
+    const int wave64 = i2 >> 6;  // wave-uniform: threadIdx.x / 64 is uniform within a wave
+    const int lane = threadIdx.x & 63;
+    if ((i2 & ~63) >= a.n2) return;  // whole wave past the last right feature (wave-uniform)
+    const bool live = i2 < a.n2;
+    const int i2c = live ? i2 : a.n2 - 1;
+    const uint4 t0 = reinterpret_cast<const uint4*>(a.d2)[2 * i2c];
+    const uint4 t1 = reinterpret_cast<const uint4*>(a.d2)[2 * i2c + 1];
+    double dirx = 0.0, diry = 0.0;
+    if (LINES) {
+        dirx = a.dir2[2 * i2c];
+        diry = a.dir2[2 * i2c + 1];
+    }
+    int run_min = 0x7FFFFFFF, owner = -1;
+    const int widx = __builtin_amdgcn_readfirstlane(wave64);
+    const uint32_t* __restrict__ Q = reinterpret_cast<const uint32_t*>(a.d1);
+    for (int i1 = 0; i1 < a.n1; ++i1) {
+        const unsigned long long mask = a.cover[(size_t)i1 * a.words64 + widx];  // wave-uniform
+        if (mask == 0ull) continue;
+        bool on = live && ((mask >> lane) & 1ull);
+        if (LINES) {
+            // direction of the LEFT line from INTEGER cell differences; 0/0 = NaN never skips (:207-222)
+            const int4 c = reinterpret_cast<const int4*>(a.cell_xy1)[i1];
+            double vx = (double)(c.z - c.x), vy = (double)(c.w - c.y);
+            const double mag = sqrt(vx * vx + vy * vy);
+            vx /= mag;
+            vy /= mag;
+            const double dot = vx * dirx + vy * diry;
+            if (fabs(dot) < a.line_sim_th) on = false;
+        }
+        if (!__any(on)) continue;
+        const uint32_t* __restrict__ q = Q + 8 * (size_t)i1;  // wave-uniform row -> scalar loads
+        uint32_t d = __builtin_popcount(t0.x ^ q[0]);
+        d = bcnt_acc(t0.y ^ q[1], d);
+        d = bcnt_acc(t0.z ^ q[2], d);
+        d = bcnt_acc(t0.w ^ q[3], d);
+        d = bcnt_acc(t1.x ^ q[4], d);
+        d = bcnt_acc(t1.y ^ q[5], d);
+        d = bcnt_acc(t1.z ^ q[6], d);
+        d = bcnt_acc(t1.w ^ q[7], d);
+        if (on) {
+            bool eligible = true;
+            if (a.mutual) {  // bestLRMatches: running strict minimum per right feature (:145-150)
+                eligible = (int)d < run_min;
+                if (eligible) {
+                    run_min = (int)d;
+                    owner = i1;
+                }
+            }
+            if (eligible) top2_insert(a.top2 + i1, (d << 16) | (uint32_t)i2);
+        }
+    }
+    if (live) a.owner2[i2] = owner;
+}
+
+__global__ __launch_bounds__(256) void grid_finalize_kernel(GridArgs a) {
+    const int i1 = blockIdx.x * 256 + threadIdx.x;
+    if (i1 >= a.n1) return;
+    const unsigned long long t = a.top2[i1];
+    const uint32_t b = (uint32_t)t, s = (uint32_t)(t >> 32);
+    int m = -1;
+    if (b != 0xFFFFFFFFu) {
+        const double best_d = (double)(int)(b >> 16);
+        const double best_d2 = (s == 0xFFFFFFFFu) ? 2147483647.0 : (double)(int)(s >> 16);
+        if (best_d < best_d2 * a.ratio) m = (int)(b & 0xFFFFu);  // :160 (double)
+    }
+    if (a.mutual && m >= 0 && a.owner2[m] != i1) m = -1;  // :166-174
+    a.m12[i1] = m;
+}
+
+template <bool LINES>
+int run_grid(stvo_ctx* ctx, const int32_t* cell_xy1, const uint8_t* d1, int n1, const int32_t* cell_start,
+             const int32_t* cell_items, const uint8_t* d2, int n2, const double* dir2, const stvo_grid_window* w,
+             double ratio, double line_sim_th, int mutual, int32_t* m12, int32_t* n_matches) {
+    if (!ctx || n1 < 0 || n2 < 0 || !cell_start || !w || (n1 > 0 && (!cell_xy1 || !d1 || !m12)) ||
+        (n2 > 0 && (!d2 || (LINES && !dir2))))
+        return STVO_ERR_INVALID_ARG;
+    if (!(ratio <= 1.0)) return STVO_ERR_INVALID_ARG;  // candidate-order independence needs ratio <= 1
+    if (n1 > ctx->max_rows || n2 > ctx->max_rows || n2 > STVO_MAX_ROWS_LIMIT) return STVO_ERR_CAPACITY;
+    if (n_matches) *n_matches = 0;
+    if (n1 == 0) return STVO_OK;
+    if (n2 == 0) {  // no candidates at all (stereoFrame.cpp:126-127 guards this upstream)
+        for (int i = 0; i < n1; ++i) m12[i] = -1;
+        return STVO_OK;
+    }
+    const int n_items = cell_start[STVO_GRID_CELLS];
+    if (n_items < 0) return STVO_ERR_INVALID_ARG;
+    if (n_items > 0 && !cell_items) return STVO_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->arena_off = 0;
+    GridArgs a;
+    std::memset(&a, 0, sizeof(a));
+    int32_t *dxy, *dstart, *ditems, *downer, *dm12;
+    uint8_t *dd1, *dd2;
+    double* ddir = nullptr;
+    TRY(upload(ctx, &dxy, cell_xy1, (size_t)n1 * (LINES ? 4 : 2)));
+    TRY(upload(ctx, &dd1, d1, (size_t)n1 * STVO_DESC_BYTES));
+    TRY(upload(ctx, &dstart, cell_start, (size_t)STVO_GRID_CELLS + 1));
+    TRY(upload(ctx, &ditems, cell_items, (size_t)n_items));
+    TRY(upload(ctx, &dd2, d2, (size_t)n2 * STVO_DESC_BYTES));
+    if (LINES) TRY(upload(ctx, &ddir, dir2, (size_t)n2 * 2));
+    a.words64 = (n2 + 63) / 64;
+    a.cover = arena_alloc<unsigned long long>(ctx, (size_t)n1 * a.words64);
+    a.top2 = arena_alloc<unsigned long long>(ctx, (size_t)n1);
+    downer = arena_alloc<int32_t>(ctx, (size_t)n2);
+    dm12 = arena_alloc<int32_t>(ctx, (size_t)n1);
+    if (!a.cover || !a.top2 || !downer || !dm12) return STVO_ERR_CAPACITY;
+    a.cell_xy1 = dxy;
+    a.d1 = dd1;
+    a.n1 = n1;
+    a.cell_start = dstart;
+    a.cell_items = ditems;
+    a.d2 = dd2;
+    a.n2 = n2;
+    a.dir2 = ddir;
+    a.w = *w;
+    a.ratio = ratio;
+    a.line_sim_th = line_sim_th;
+    a.mutual = mutual;
+    a.owner2 = downer;
+    a.m12 = dm12;
+    HIP_TRY(ctx, hipMemsetAsync(a.cover, 0, (size_t)n1 * a.words64 * sizeof(unsigned long long), ctx->stream));
+    const dim3 g1((n1 + 255) / 256), g2((n2 + 255) / 256), blk(256);
+    hipLaunchKernelGGL((grid_cover_kernel<LINES>), g1, blk, 0, ctx->stream, a);
+    hipLaunchKernelGGL((grid_scan_kernel<LINES>), g2, blk, 0, ctx->stream, a);
+    hipLaunchKernelGGL(grid_finalize_kernel, g1, blk, 0, ctx->stream, a);
+    TRY(check_launch(ctx));
+    HIP_TRY(ctx, hipMemcpyAsync(m12, dm12, (size_t)n1 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (n_matches) {
+        int c = 0;
+        for (int i = 0; i < n1; ++i) c += m12[i] >= 0;
+        *n_matches = c;
+    }
+    return STVO_OK;
+}
+
+}  // namespace
+}  // namespace stvo
+
+extern "C" {
+
+int stvo_match_grid_points(stvo_ctx* ctx, const int32_t* cell_xy1, const uint8_t* d1, int n1, const int32_t* cell_start,
+                           const int32_t* cell_items, const uint8_t* d2, int n2, const stvo_grid_window* w, double ratio,
+                           int mutual, int32_t* m12, int32_t* n_matches) {
+    return stvo::run_grid<false>(ctx, cell_xy1, d1, n1, cell_start, cell_items, d2, n2, nullptr, w, ratio, 0.0, mutual,
+                                 m12, n_matches);
+}
+
+int stvo_match_grid_lines(stvo_ctx* ctx, const int32_t* cell_xy1, const uint8_t* d1, int n1, const int32_t* cell_start,
+                          const int32_t* cell_items, const uint8_t* d2, int n2, const double* dir2,
+                          const stvo_grid_window* w, double ratio, double line_sim_th, int mutual, int32_t* m12,
+                          int32_t* n_matches) {
+    return stvo::run_grid<true>(ctx, cell_xy1, d1, n1, cell_start, cell_items, d2, n2, dir2, w, ratio, line_sim_th,
+                                mutual, m12, n_matches);
+}
+
+}  // extern "C"

@@ -47,46 +47,4 @@ struct PoseArgs {
 };
 int launch_pose(hipStream_t s, const PoseArgs& a);
 
-// ---- K3: grid-windowed stereo matchers ---------------------------------------------------------
-struct GridPointsArgs {
-    const int32_t* cell_xy1;  // [n1][2]
-    const uint8_t* d1;
-    int n1;
-    const int32_t* cell_start;  // [3073]
-    const int32_t* cell_items;
-    const uint8_t* d2;
-    int n2;
-    stvo_grid_window w;
-    double ratio;
-    int mutual;
-    int32_t* m12;
-    // scratch
-    uint32_t* best1;    // [n1]
-    uint32_t* second1;  // [n1]
-    int32_t* owner2;    // [n2]
-    int32_t* qcell_start;  // [3073]
-    int32_t* qcell_items;  // [n1]
-};
-int launch_grid_points(hipStream_t s, const GridPointsArgs& a);
-
-struct GridLinesArgs {
-    const int32_t* cell_xy1;  // [n1][4]
-    const uint8_t* d1;
-    int n1;
-    const int32_t* cell_start;
-    const int32_t* cell_items;
-    const uint8_t* d2;
-    int n2;
-    const double* dir2;
-    stvo_grid_window w;
-    double ratio, line_sim_th;
-    int mutual;
-    int32_t* m12;
-    uint32_t* cover;  // [n1][ceil(n2/32)] candidate bit-matrix scratch
-    uint32_t* best1;
-    uint32_t* second1;
-    int32_t* owner2;
-};
-int launch_grid_lines(hipStream_t s, const GridLinesArgs& a);
-
 }  // namespace stvo

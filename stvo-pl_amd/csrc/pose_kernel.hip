@@ -374,7 +374,9 @@ __global__ __launch_bounds__(BLOCK) void pose_kernel(PoseArgs a) {
     // ---------------- load the matched records (HBM -> VGPRs, once) ----------------
     double Px[PPT], Py[PPT], Pz[PPT], ox[PPT], oy[PPT], s2[PPT];
     unsigned pmatched = 0u, pinl = 0u;
-    const int n_prev_p = (a.n_prev_pts != nullptr && prm.has_points) ? a.n_prev_pts[f] : 0;
+    // like the reference, optimizeFunctions sums whatever is in matched_pt / matched_ls; has_points /
+    // has_lines only gate the matching (caller) and the two blocks of removeOutliers (:991,1026)
+    const int n_prev_p = (a.n_prev_pts != nullptr) ? a.n_prev_pts[f] : 0;
     {
         const size_t base = (size_t)f * a.max_pts;
 #pragma unroll
@@ -400,7 +402,7 @@ __global__ __launch_bounds__(BLOCK) void pose_kernel(PoseArgs a) {
     }
     pm::LineRec L[LPT];
     unsigned lmatched = 0u, linl = 0u;
-    const int n_prev_l = (a.n_prev_lines != nullptr && prm.has_lines && a.max_lines > 0) ? a.n_prev_lines[f] : 0;
+    const int n_prev_l = (a.n_prev_lines != nullptr && a.max_lines > 0) ? a.n_prev_lines[f] : 0;
     {
         const size_t base = (size_t)f * a.max_lines;
 #pragma unroll

@@ -197,8 +197,6 @@ int stvo_normal_eq(stvo_ctx* ctx, const double T[16], const stvo_cam* cam, const
     TRY(stage_records(ctx, m, T, &a, &dip, &dil));
     a.cam = *cam;
     a.prm = *params;
-    a.prm.has_points = 1;  // a single evaluation sums whatever records are flagged as inliers
-    a.prm.has_lines = 1;
     double* dout = arena_alloc<double>(ctx, 44);
     if (!dout) return STVO_ERR_CAPACITY;
     a.eval_only = 1;
@@ -243,11 +241,8 @@ int stvo_optimize_pose(stvo_ctx* ctx, const double init_T[16], const stvo_cam* c
     if (m->np) HIP_TRY(ctx, hipMemcpyAsync(ip.data(), dop, (size_t)m->np * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (m->nl) HIP_TRY(ctx, hipMemcpyAsync(il.data(), dol, (size_t)m->nl * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    // records the optimizer never saw (has_points / has_lines off) keep their flags
-    if (params->has_points)
-        for (int i = 0; i < m->np; ++i) m->inlier_p[i] = ip[i] > 0 ? 1 : 0;
-    if (params->has_lines)
-        for (int i = 0; i < m->nl; ++i) m->inlier_l[i] = il[i] > 0 ? 1 : 0;
+    for (int i = 0; i < m->np; ++i) m->inlier_p[i] = ip[i] > 0 ? 1 : 0;
+    for (int i = 0; i < m->nl; ++i) m->inlier_l[i] = il[i] > 0 ? 1 : 0;
     return STVO_OK;
 }
 
@@ -324,6 +319,9 @@ int stvo_track_batched_dev(stvo_ctx* ctx, const stvo_track_batch_dev* b, const s
     }
     stvo::PoseArgs a;
     fill_pose_args(b, cam, params, false, &a);
+    // a feature kind that is switched off is never matched => matched_pt / matched_ls stay empty (:137,160)
+    if (!params->has_points) a.n_prev_pts = nullptr;
+    if (!params->has_lines) a.n_prev_lines = nullptr;
     TRY(stvo::launch_pose(ctx->stream, a));
     return check_launch(ctx);
 }

@@ -63,6 +63,15 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise StvoError(f"{LIB_PATH} is missing: run `make -C stvo-pl_amd` (python __graft_entry__.py). "
                         "The product has no CPU fallback.")
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64; if this library pulled in
+    # /opt/rocm's copy first, torch would later find "No HIP GPUs".  Import torch first when it exists so
+    # both resolve to the same already-loaded runtime (torch is only plumbing: HBM buffers + streams).
+    try:
+        import torch  # noqa: F401
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     L.stvo_backend_name.restype = C.c_char_p
     L.stvo_error_string.restype = C.c_char_p
