@@ -40,11 +40,39 @@ struct PoseSh {
     int action, good, n_inl_p, n_inl_l, n_m_p, n_m_l, evals, itmp;
 };
 
-template <int BLOCK>
+// Block-wide primitives.  The workgroup has NWORK worker waves (threads 0 .. 64*NWORK-1, they own
+// the feature records) plus ONE solver wave (the last 64 threads: 6x6 algebra, SE(3), every
+// data-dependent decision).  Both roles run the SAME source with W = true / false, so they execute
+// identical barrier sequences by construction; with W == false a primitive only synchronises and
+// reads the result.  Keeping the serial algebra in its own wave keeps it out of the register budget
+// of the record-holding waves (no call-clobber spills: the first version of this kernel moved
+// ~1 MB of scratch per frame pair through HBM, see profiles/r01_a_hbm_counters.txt).
+template <int NWORK>
 struct BlockOps {
-    static constexpr int NW = BLOCK / 64;
+    static constexpr int NW = NWORK;
+    static constexpr int WTHREADS = NWORK * 64;
 
-    // xor-butterfly inside the wave: every lane ends with the wave total (fixed order)
+    // Wave64 sum with DPP register moves (no LDS crossbar): inclusive scan inside each 16-lane row
+    // (row_shr 1,2,4,8), then row_bcast:15 / row_bcast:31 carry the row totals across rows.  The
+    // total lands in LANE 63.  Fixed association order => bit-reproducible.  A 64-bit value moves as
+    // two 32-bit DPP movs; lanes with no source read 0 (bound_ctrl), which is neutral for a sum.
+    template <int CTRL, int ROW_MASK>
+    static __device__ __forceinline__ double dpp_add(double v) {
+        const long long b = __double_as_longlong(v);
+        const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xFFFFFFFFll), CTRL, ROW_MASK, 0xf, true);
+        const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xf, true);
+        return v + __longlong_as_double(((long long)hi << 32) | (unsigned long long)(unsigned)lo);
+    }
+    static __device__ __forceinline__ double wave_sum_lane63(double v) {
+        v = dpp_add<0x111, 0xf>(v);  // row_shr:1
+        v = dpp_add<0x112, 0xf>(v);  // row_shr:2
+        v = dpp_add<0x114, 0xf>(v);  // row_shr:4
+        v = dpp_add<0x118, 0xf>(v);  // row_shr:8
+        v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 -> rows 1 and 3
+        v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 -> rows 2 and 3
+        return v;
+    }
+    // xor-butterfly (LDS crossbar): every lane ends with the wave total; used for the small reductions
     static __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -56,32 +84,36 @@ struct BlockOps {
         return v;
     }
 
-    // 28-vector block sum -> sh->tot[0..27], valid for every thread after return
+    // 28-vector block sum -> sh->tot[0..27] (summed in wave order by the solver wave)
+    template <bool W>
     static __device__ __forceinline__ void sum28(double* acc, double (*red)[28], PoseSh* sh) {
         const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        if (W) {
 #pragma unroll
-        for (int k = 0; k < 28; ++k) {
-            const double s = wave_sum(acc[k]);
-            if (lane == 0) red[wv][k] = s;
+            for (int k = 0; k < 28; ++k) {
+                const double s = wave_sum_lane63(acc[k]);
+                if (lane == 63) red[wv][k] = s;
+            }
         }
         __syncthreads();
-        if (threadIdx.x < 28) {
-            double s = red[0][threadIdx.x];
+        if (!W && lane < 28) {
+            double s = red[0][lane];
 #pragma unroll
-            for (int w = 1; w < NW; ++w) s += red[w][threadIdx.x];
-            sh->tot[threadIdx.x] = s;
+            for (int w = 1; w < NW; ++w) s += red[w][lane];
+            sh->tot[lane] = s;
         }
         __syncthreads();
     }
 
-    // up to 4 doubles, result in sh->stat[0..n) for every thread
-    template <int N>
+    template <int N, bool W>
     static __device__ __forceinline__ void sum_small(const double* v, double (*red)[28], double* out) {
         const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        if (W) {
 #pragma unroll
-        for (int k = 0; k < N; ++k) {
-            const double s = wave_sum(v[k]);
-            if (lane == 0) red[wv][k] = s;
+            for (int k = 0; k < N; ++k) {
+                const double s = wave_sum(v[k]);
+                if (lane == 0) red[wv][k] = s;
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -94,10 +126,13 @@ struct BlockOps {
         __syncthreads();
     }
 
+    template <bool W>
     static __device__ __forceinline__ int sum_int(int v, int* ired) {
         const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        const int s = wave_sum_i(v);
-        if (lane == 0) ired[wv] = s;
+        if (W) {
+            const int s = wave_sum_i(v);
+            if (lane == 0) ired[wv] = s;
+        }
         __syncthreads();
         int t = 0;
 #pragma unroll
@@ -106,16 +141,19 @@ struct BlockOps {
         return t;
     }
 
-    // exclusive scan of per-thread counts (thread order); returns this thread's offset, *total = sum
+    // exclusive scan of per-thread counts (worker thread order); returns this thread's offset
+    template <bool W>
     static __device__ __forceinline__ int excl_scan(int count, int* ired, int* total) {
         const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
         int incl = count;
+        if (W) {
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int o = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += o;
+            for (int off = 1; off < 64; off <<= 1) {
+                const int o = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += o;
+            }
+            if (lane == 63) ired[wv] = incl;
         }
-        if (lane == 63) ired[wv] = incl;
         __syncthreads();
         int base = 0, tot = 0;
 #pragma unroll
@@ -129,43 +167,64 @@ struct BlockOps {
         return base + incl - count;
     }
 
-    // ascending bitonic sort of buf[0..n2), n2 a power of two
-    static __device__ __forceinline__ void bitonic_sort(double* buf, int n2) {
-        for (int k = 2; k <= n2; k <<= 1)
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                for (int i = threadIdx.x; i < n2; i += BLOCK) {
-                    const int ixj = i ^ j;
-                    if (ixj > i) {
-                        const double a = buf[i], b = buf[ixj];
-                        const bool asc = (i & k) == 0;
-                        if ((a > b) == asc && a != b) {
-                            buf[i] = b;
-                            buf[ixj] = a;
-                        }
-                    }
-                }
-                __syncthreads();
-            }
+    // count of set predicates over the workgroup; double-buffered partials => ONE barrier per call
+    template <bool W>
+    static __device__ __forceinline__ int count_db(int v, int (*ibuf)[NW], int parity) {
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        if (W) {
+            const int s = wave_sum_i(v);
+            if (lane == 0) ibuf[parity][wv] = s;
+        }
+        __syncthreads();
+        int t = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += ibuf[parity][w];
+        return t;
     }
 
-    // 1.4826 * MAD of buf[0..n) (values already compacted; buf is destroyed).  Follows
-    // vector_stdv_mad / the first half of vector_mean_stdv_mad, src/auxiliar.cpp:395-404,447-457.
-    // n == 0 -> 0.  Result returned to every thread.
-    static __device__ __forceinline__ double mad_sigma(double* buf, int n) {
+    // 1.4826 * MAD of the n values {v[k] : bit k of mask} held in REGISTERS across the workgroup.
+    // Follows vector_stdv_mad / the first half of vector_mean_stdv_mad (src/auxiliar.cpp:395-404,
+    // 447-457): median = sorted[n/2]; dev = fabsf(x - median) (FLOAT truncation); MAD = sorted dev[n/2].
+    // The two std::sort calls are replaced by exact k-th-element SELECTION: a most-significant-bit-first
+    // binary search on the order-preserving integer image of the values, one workgroup-wide count per
+    // bit (64 rounds for the doubles, 32 for the float deviations).  Same result as sorting, ~10x fewer
+    // barriers than a bitonic sort and no LDS buffer.  n == 0 -> 0.
+    template <int N, bool W>
+    static __device__ __forceinline__ double mad_sigma(const double* v, unsigned mask, int n, int (*ibuf)[NW]) {
         if (n == 0) return 0.0;  // block-uniform
-        int n2 = 1;
-        while (n2 < n) n2 <<= 1;
-        for (int i = n + threadIdx.x; i < n2; i += BLOCK) buf[i] = __builtin_inf();
-        __syncthreads();
-        bitonic_sort(buf, n2);
-        const double median = buf[n / 2];
-        __syncthreads();
-        for (int i = threadIdx.x; i < n; i += BLOCK) buf[i] = (double)fabsf((float)(buf[i] - median));
-        __syncthreads();
-        bitonic_sort(buf, n2);
-        const double s = 1.4826 * buf[n / 2];
-        __syncthreads();
-        return s;
+        const int kth = n / 2;
+        unsigned long long key[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const unsigned long long b = (unsigned long long)__double_as_longlong(v[k]);
+            key[k] = (b >> 63) ? ~b : (b | 0x8000000000000000ull);  // total order of IEEE doubles
+        }
+        unsigned long long res = 0ull;
+        int parity = 0;
+        for (int bit = 63; bit >= 0; --bit) {
+            const unsigned long long t = res | (1ull << bit);
+            int c = 0;
+#pragma unroll
+            for (int k = 0; k < N; ++k) c += (((mask >> k) & 1u) && key[k] < t) ? 1 : 0;
+            if (count_db<W>(c, ibuf, parity) <= kth) res = t;
+            parity ^= 1;
+        }
+        const unsigned long long mb = (res >> 63) ? (res & 0x7FFFFFFFFFFFFFFFull) : ~res;
+        const double median = __longlong_as_double((long long)mb);
+        unsigned fkey[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) fkey[k] = __float_as_uint(fabsf((float)(v[k] - median)));  // >= 0 (or NaN)
+        unsigned fres = 0u;
+        for (int bit = 31; bit >= 0; --bit) {
+            const unsigned t = fres | (1u << bit);
+            int c = 0;
+#pragma unroll
+            for (int k = 0; k < N; ++k) c += (((mask >> k) & 1u) && fkey[k] < t) ? 1 : 0;
+            if (count_db<W>(c, ibuf, parity) <= kth) fres = t;
+            parity ^= 1;
+        }
+        __syncthreads();  // ibuf is reused by the caller
+        return 1.4826 * (double)__uint_as_float(fres);
     }
 };
 
@@ -356,18 +415,20 @@ __device__ __noinline__ void t0_commit(PoseSh* sh, stvo_pose_result* out, int st
 
 }  // namespace
 
-template <int BLOCK, int PPT, int LPT>
-__global__ __launch_bounds__(BLOCK) void pose_kernel(PoseArgs a) {
-    using Ops = BlockOps<BLOCK>;
-    constexpr int NW = BLOCK / 64;
-    __shared__ double s_sort[BLOCK * PPT];
-    __shared__ double s_red[NW][28];
-    __shared__ int s_ired[NW];
-    __shared__ PoseSh s_sh;
-    PoseSh* sh = &s_sh;
-
+template <int BLOCK, int PPT, int LPT, bool W>
+__device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_ibuf)[BLOCK / 64], double (*s_red)[28],
+                                          int* s_ired, PoseSh* sh) {
+    using Ops = BlockOps<BLOCK / 64>;
     const int f = blockIdx.x;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x;              // workers: 0 .. BLOCK-1 ; solver wave: BLOCK .. BLOCK+63
+    const bool t0 = !W && (tid == BLOCK);     // the one lane that runs the serial algebra
+    // optional phase timing (solver lane, s_memtime ticks): [0] evaluate+reduce wait, [1] iteration
+    // algebra, [2] covariance + isGood + commit, [3] removeOutliers, [4] total
+    long long tprof[5] = {0, 0, 0, 0, 0};
+    long long wprof[3] = {0, 0, 0};  // worker lane 0: evaluate compute, reduction, robust pre-pass
+    const bool prof = a.prof_out != nullptr;
+    auto tick = [&]() -> long long { return prof ? (long long)__builtin_readcyclecounter() : 0ll; };
+    const long long t_begin = tick();
     const pm::Cam5 cam{a.cam.fx, a.cam.fy, a.cam.cx, a.cam.cy};
     const stvo_opt_params prm = a.prm;
 
@@ -376,7 +437,7 @@ __global__ __launch_bounds__(BLOCK) void pose_kernel(PoseArgs a) {
     unsigned pmatched = 0u, pinl = 0u;
     // like the reference, optimizeFunctions sums whatever is in matched_pt / matched_ls; has_points /
     // has_lines only gate the matching (caller) and the two blocks of removeOutliers (:991,1026)
-    const int n_prev_p = (a.n_prev_pts != nullptr) ? a.n_prev_pts[f] : 0;
+    const int n_prev_p = (W && a.n_prev_pts != nullptr) ? a.n_prev_pts[f] : 0;
     {
         const size_t base = (size_t)f * a.max_pts;
 #pragma unroll
@@ -402,7 +463,7 @@ __global__ __launch_bounds__(BLOCK) void pose_kernel(PoseArgs a) {
     }
     pm::LineRec L[LPT];
     unsigned lmatched = 0u, linl = 0u;
-    const int n_prev_l = (a.n_prev_lines != nullptr && a.max_lines > 0) ? a.n_prev_lines[f] : 0;
+    const int n_prev_l = (W && a.n_prev_lines != nullptr && a.max_lines > 0) ? a.n_prev_lines[f] : 0;
     {
         const size_t base = (size_t)f * a.max_lines;
 #pragma unroll
@@ -439,11 +500,11 @@ __global__ __launch_bounds__(BLOCK) void pose_kernel(PoseArgs a) {
     }
 
     {
-        const int nmp = Ops::sum_int(__popc(pmatched), s_ired);
-        const int nml = Ops::sum_int(__popc(lmatched), s_ired);
-        const int nip = Ops::sum_int(__popc(pinl), s_ired);
-        const int nil = Ops::sum_int(__popc(linl), s_ired);
-        if (tid == 0) {
+        const int nmp = Ops::template sum_int<W>(__popc(pmatched), s_ired);
+        const int nml = Ops::template sum_int<W>(__popc(lmatched), s_ired);
+        const int nip = Ops::template sum_int<W>(__popc(pinl), s_ired);
+        const int nil = Ops::template sum_int<W>(__popc(linl), s_ired);
+        if (t0) {
             sh->n_m_p = nmp;
             sh->n_m_l = nml;
             sh->n_inl_p = nip;
@@ -472,20 +533,17 @@ __global__ __launch_bounds__(BLOCK) void pose_kernel(PoseArgs a) {
         for (int i = 0; i < 16; ++i) DT[i] = sh->DT[i];
         double sp = 1.0, sl = 1.0;
         if (robust) {  // pre-pass :710-781: MAD scale of the inlier residual norms
-            int tot = 0;
-            int off = Ops::excl_scan(__popc(pinl), s_ired, &tot);
+            double rp[PPT];
 #pragma unroll
             for (int k = 0; k < PPT; ++k)
-                if ((pinl >> k) & 1u) s_sort[off++] = pm::point_residual(DT, cam, Px[k], Py[k], Pz[k], ox[k], oy[k]);
-            __syncthreads();
-            sp = pm::clamp_scale(Ops::mad_sigma(s_sort, tot));
-            off = Ops::excl_scan(__popc(linl), s_ired, &tot);
+                rp[k] = ((pinl >> k) & 1u) ? pm::point_residual(DT, cam, Px[k], Py[k], Pz[k], ox[k], oy[k]) : 0.0;
+            sp = pm::clamp_scale(Ops::template mad_sigma<PPT, W>(rp, pinl, sh->n_inl_p, s_ibuf));
+            double rl[LPT];
 #pragma unroll
-            for (int k = 0; k < LPT; ++k)
-                if ((linl >> k) & 1u) s_sort[off++] = pm::line_residual(DT, cam, L[k]);
-            __syncthreads();
-            sl = pm::clamp_scale(Ops::mad_sigma(s_sort, tot));
+            for (int k = 0; k < LPT; ++k) rl[k] = ((linl >> k) & 1u) ? pm::line_residual(DT, cam, L[k]) : 0.0;
+            sl = pm::clamp_scale(Ops::template mad_sigma<LPT, W>(rl, linl, sh->n_inl_l, s_ibuf));
         }
+        const long long tw0 = tick();
         double acc[28];
 #pragma unroll
         for (int i = 0; i < 28; ++i) acc[i] = 0.0;
@@ -496,12 +554,15 @@ __global__ __launch_bounds__(BLOCK) void pose_kernel(PoseArgs a) {
 #pragma unroll
         for (int k = 0; k < LPT; ++k)
             if ((linl >> k) & 1u) pm::line_term(acc, DT, cam, prm.homog_th, L[k], robust, sl);
-        Ops::sum28(acc, s_red, sh);
+        const long long tw1 = tick();
+        Ops::template sum28<W>(acc, s_red, sh);
+        wprof[0] += tw1 - tw0;
+        wprof[1] += tick() - tw1;
     };
 
     if (a.eval_only) {
         evaluate(a.eval_robust != 0);
-        if (tid == 0) {
+        if (t0) {
             t0_unpack(sh);
             double* o = a.eval_out + (size_t)f * 44;
 #pragma unroll
@@ -514,84 +575,6 @@ __global__ __launch_bounds__(BLOCK) void pose_kernel(PoseArgs a) {
         return;
     }
 
-    // ---------------- the three optimisers; each works on sh->DT, writes sh->cov / sh->err_out ----
-    auto run_gn = [&](int max_iters) -> int {  // :394-431
-        if (tid == 0) sh->err_prev = 999999999.9;
-        int evals = 0, action = ACT_BREAK;
-        for (int it = 0; it < max_iters; ++it) {
-            evaluate(false);
-            ++evals;
-            if (tid == 0) t0_gn_iter(sh, prm.min_error, prm.min_error_change, it);
-            __syncthreads();
-            action = sh->action;
-            if (action != ACT_CONTINUE) break;
-        }
-        if (tid == 0) {
-            if (action == ACT_FAIL)
-                sh->err_out = -1.0;  // :408-409, covariance left untouched
-            else {
-                t0_cov_from_H(sh);   // :429  (H of the last evaluation)
-                sh->err_out = max_iters > 0 ? sh->err : 0.0;
-            }
-        }
-        __syncthreads();
-        return evals;
-    };
-    auto run_gnr = [&](int max_iters) -> int {  // :433-480
-        if (tid == 0) {
-            sh->err_prev = 999999999.9;
-            sh->good = 1;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) sh->DTr[i] = sh->DT[i];
-        }
-        int evals = 0;
-        for (int it = 0; it < max_iters; ++it) {
-            evaluate(true);
-            ++evals;
-            if (tid == 0) t0_gnr_iter(sh, prm.min_error, prm.min_error_change);
-            __syncthreads();
-            if (sh->action != ACT_CONTINUE) break;
-        }
-        if (tid == 0) {
-            if (sh->good) {
-                t0_cov_from_H(sh);
-                sh->err_out = max_iters > 0 ? sh->err : 0.0;
-            } else {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) sh->DT[i] = sh->DTr[i];
-                sh->err_out = -1.0;
-#pragma unroll
-                for (int i = 0; i < 36; ++i) sh->cov[i] = (i % 7 == 0) ? 1.0 : 0.0;
-            }
-        }
-        __syncthreads();
-        return evals;
-    };
-    auto run_lm = [&](int max_iters) -> int {  // :482-547
-        evaluate(false);
-        int evals = 1;
-        if (tid == 0) t0_lm_iter(sh, prm.min_error, prm.min_error_change, 1);
-        __syncthreads();
-        for (int it = 1; it < max_iters; ++it) {
-            evaluate(false);
-            ++evals;
-            if (tid == 0) t0_lm_iter(sh, prm.min_error, prm.min_error_change, 0);
-            __syncthreads();
-            if (sh->action != ACT_CONTINUE) break;
-        }
-        if (tid == 0) {
-            t0_cov_from_H(sh);  // :545 — the damped H of the last solve
-            sh->err_out = sh->err;
-        }
-        __syncthreads();
-        return evals;
-    };
-    auto run_mode = [&](int mode, int iters) -> int {
-        if (mode == 1) return run_gnr(iters);
-        if (mode == 2) return run_lm(iters);
-        return run_gn(iters);
-    };
-
     // ---------------- removeOutliers at pose DT1 (:988-1067) ----------------
     auto remove_outliers = [&]() {
         double DT[16];
@@ -599,18 +582,12 @@ __global__ __launch_bounds__(BLOCK) void pose_kernel(PoseArgs a) {
         for (int i = 0; i < 16; ++i) DT[i] = sh->DT1[i];
         if (prm.has_points) {
             double res[PPT];
-            int tot = 0;
-            int off = Ops::excl_scan(__popc(pmatched), s_ired, &tot);
+            const int tot = sh->n_m_p;
 #pragma unroll
-            for (int k = 0; k < PPT; ++k) {
-                res[k] = 0.0;
-                if ((pmatched >> k) & 1u) {  // ALL matches, current outliers included
-                    res[k] = pm::point_residual(DT, cam, Px[k], Py[k], Pz[k], ox[k], oy[k]) * sqrt(s2[k]);
-                    s_sort[off++] = res[k];
-                }
-            }
-            __syncthreads();
-            const double stdv = Ops::mad_sigma(s_sort, tot);
+            for (int k = 0; k < PPT; ++k)  // ALL matches, current outliers included (:998-1005)
+                res[k] = ((pmatched >> k) & 1u)
+                             ? pm::point_residual(DT, cam, Px[k], Py[k], Pz[k], ox[k], oy[k]) * sqrt(s2[k]) : 0.0;
+            const double stdv = Ops::template mad_sigma<PPT, W>(res, pmatched, tot, s_ibuf);
             // mean of the samples below 2 sigma, or of all samples (src/auxiliar.cpp:405-427)
             double v[3] = {0.0, 0.0, 0.0};
 #pragma unroll
@@ -623,7 +600,7 @@ __global__ __launch_bounds__(BLOCK) void pose_kernel(PoseArgs a) {
                     v[2] += res[k];
                 }
             double t[3];
-            Ops::template sum_small<3>(v, s_red, t);
+            Ops::template sum_small<3, W>(v, s_red, t);
             double mean = 0.0;
             if (tot != 0) {
                 const int ksel = (int)t[1];
@@ -633,23 +610,16 @@ __global__ __launch_bounds__(BLOCK) void pose_kernel(PoseArgs a) {
 #pragma unroll
             for (int k = 0; k < PPT; ++k)
                 if (((pinl >> k) & 1u) && fabs(res[k] - mean) > th) pinl &= ~(1u << k);
-            const int nip = Ops::sum_int(__popc(pinl), s_ired);
-            if (tid == 0) sh->n_inl_p = nip;
+            const int nip = Ops::template sum_int<W>(__popc(pinl), s_ired);
+            if (t0) sh->n_inl_p = nip;
         }
         if (prm.has_lines) {
             double res[LPT];
-            int tot = 0;
-            int off = Ops::excl_scan(__popc(lmatched), s_ired, &tot);
+            const int tot = sh->n_m_l;
 #pragma unroll
-            for (int k = 0; k < LPT; ++k) {
-                res[k] = 0.0;
-                if ((lmatched >> k) & 1u) {
-                    res[k] = pm::line_residual(DT, cam, L[k]) * sqrt(L[k].sigma2);
-                    s_sort[off++] = res[k];
-                }
-            }
-            __syncthreads();
-            const double stdv = Ops::mad_sigma(s_sort, tot);
+            for (int k = 0; k < LPT; ++k)
+                res[k] = ((lmatched >> k) & 1u) ? pm::line_residual(DT, cam, L[k]) * sqrt(L[k].sigma2) : 0.0;
+            const double stdv = Ops::template mad_sigma<LPT, W>(res, lmatched, tot, s_ibuf);
             double v[3] = {0.0, 0.0, 0.0};
 #pragma unroll
             for (int k = 0; k < LPT; ++k)
@@ -661,7 +631,7 @@ __global__ __launch_bounds__(BLOCK) void pose_kernel(PoseArgs a) {
                     v[2] += res[k];
                 }
             double t[3];
-            Ops::template sum_small<3>(v, s_red, t);
+            Ops::template sum_small<3, W>(v, s_red, t);
             double mean = 0.0;
             if (tot != 0) {
                 const int ksel = (int)t[1];
@@ -671,56 +641,125 @@ __global__ __launch_bounds__(BLOCK) void pose_kernel(PoseArgs a) {
 #pragma unroll
             for (int k = 0; k < LPT; ++k)
                 if (((linl >> k) & 1u) && fabs(res[k] - mean) > th) linl &= ~(1u << k);
-            const int nil = Ops::sum_int(__popc(linl), s_ired);
-            if (tid == 0) sh->n_inl_l = nil;
+            const int nil = Ops::template sum_int<W>(__popc(linl), s_ired);
+            if (t0) sh->n_inl_l = nil;
         }
         __syncthreads();
     };
 
     // ---------------- optimizePose state machine (:332-370) ----------------
+    // One generic iteration loop drives GN (:394-431), robust GN (:433-480) and LM (:482-547) for
+    // stage 1, the refinement and the robust fallback, so that the (large) fused evaluation and
+    // the outlier removal are instantiated exactly once in the instruction stream.
     int status = STVO_POSE_OK, path = 0, it0 = 0, it1 = 0;
     if (sh->n_inl_p + sh->n_inl_l >= prm.min_features) {
-        it0 = run_mode(prm.mode, prm.max_iters);  // works on DT_ (= sh->DT, a copy of DT0)
-        if (tid == 0) {
+        int stage = 0;        // 0 = first optimisation (:335-338), 1 = refinement (:345-350), 2 = robust fallback (:359)
+        int alg = prm.mode;   // 0 GN, 1 robust GN, 2 LM
+        int max_it = prm.max_iters;
+        for (;;) {
+            if (t0) {
+                sh->err_prev = 999999999.9;
+                sh->good = 1;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) sh->DT1[i] = sh->DT[i];
-            t0_is_good(sh, sh->DT1, sh->err_out);
-        }
-        __syncthreads();
-        if (sh->good) {  // :341
-            path |= STVO_PATH_STAGE1_GOOD;
-            remove_outliers();
-            if (sh->n_inl_p + sh->n_inl_l >= prm.min_features) {  // :345 — restart from the INITIAL DT
-                path |= STVO_PATH_REFINED;
-                if (tid == 0) {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) sh->DT[i] = sh->DT0[i];
+                for (int i = 0; i < 16; ++i) sh->DTr[i] = sh->DT[i];  // robust GN's entry pose (:441)
+            }
+            const int n_it = (alg == 2 && max_it < 1) ? 1 : max_it;  // LM always evaluates once (:493)
+            int evals = 0, action = ACT_BREAK;
+            for (int it = 0; it < n_it; ++it) {
+                long long tq = tick();
+                evaluate(alg == 1);
+                tprof[0] += tick() - tq;
+                tq = tick();
+                ++evals;
+                if (t0) {
+                    if (alg == 0) t0_gn_iter(sh, prm.min_error, prm.min_error_change, it);
+                    else if (alg == 1) t0_gnr_iter(sh, prm.min_error, prm.min_error_change);
+                    else t0_lm_iter(sh, prm.min_error, prm.min_error_change, it == 0 ? 1 : 0);
                 }
                 __syncthreads();
-                it1 = run_mode(prm.mode, prm.max_iters_ref);
-            } else {
-                if (tid == 0) pm::identity4(sh->DT);
-                status = STVO_POSE_FEW_INLIERS_AFTER;
-                __syncthreads();
+                tprof[1] += tick() - tq;
+                action = sh->action;
+                if (action != ACT_CONTINUE) break;
             }
-        } else {  // :357-362 robust GN on everything, from the initial DT
-            path |= STVO_PATH_ROBUST_FALLBACK;
-            if (tid == 0) {
+            long long tq2 = tick();
+            if (t0) {
+                if (alg == 0 && action == ACT_FAIL) {
+                    sh->err_out = -1.0;  // :408-409, covariance left untouched
+                } else if (alg == 1 && !sh->good) {  // :473-478
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) sh->DT[i] = sh->DTr[i];
+                    sh->err_out = -1.0;
+#pragma unroll
+                    for (int i = 0; i < 36; ++i) sh->cov[i] = (i % 7 == 0) ? 1.0 : 0.0;
+                } else {
+                    t0_cov_from_H(sh);  // :429 / :470 / :545 — H of the last evaluation (damped for LM)
+                    sh->err_out = evals > 0 ? sh->err : 0.0;
+                }
+            }
+            __syncthreads();
+            tprof[2] += tick() - tq2;
+            if (stage != 0) {
+                it1 = evals;
+                break;
+            }
+            it0 = evals;
+            tq2 = tick();
+            if (t0) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sh->DT1[i] = sh->DT[i];
+                t0_is_good(sh, sh->DT1, sh->err_out);
+            }
+            __syncthreads();
+            tprof[2] += tick() - tq2;
+            if (sh->good) {  // :341
+                path |= STVO_PATH_STAGE1_GOOD;
+                tq2 = tick();
+                remove_outliers();
+                tprof[3] += tick() - tq2;
+                if (sh->n_inl_p + sh->n_inl_l >= prm.min_features) {  // :345 — restart from the INITIAL DT
+                    path |= STVO_PATH_REFINED;
+                    stage = 1;
+                } else {
+                    if (t0) pm::identity4(sh->DT);
+                    status = STVO_POSE_FEW_INLIERS_AFTER;
+                    __syncthreads();
+                    break;
+                }
+            } else {  // :357-362 robust GN on everything, from the initial DT
+                path |= STVO_PATH_ROBUST_FALLBACK;
+                stage = 2;
+                alg = 1;
+            }
+            max_it = prm.max_iters_ref;
+            if (t0) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) sh->DT[i] = sh->DT0[i];
             }
             __syncthreads();
-            it1 = run_gnr(prm.max_iters_ref);
         }
     } else {
-        if (tid == 0) pm::identity4(sh->DT);
+        if (t0) pm::identity4(sh->DT);
         status = STVO_POSE_FEW_INLIERS_BEFORE;
         __syncthreads();
     }
 
-    if (tid == 0) t0_commit(sh, a.results + f, status, path, it0, it1);
 
-    if (a.inl_p_out) {
+    {
+        const long long tq3 = tick();
+        if (t0) t0_commit(sh, a.results + f, status, path, it0, it1);
+        tprof[2] += tick() - tq3;
+    }
+    if (prof && t0) {
+        tprof[4] = tick() - t_begin;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) a.prof_out[(size_t)f * 8 + i] = tprof[i];
+    }
+    if (prof && W && tid == 0) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) a.prof_out[(size_t)f * 8 + 5 + i] = wprof[i];
+    }
+
+    if (W && a.inl_p_out) {
         const size_t base = (size_t)f * a.max_pts;
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
@@ -728,7 +767,7 @@ __global__ __launch_bounds__(BLOCK) void pose_kernel(PoseArgs a) {
             if (i < a.max_pts) a.inl_p_out[base + i] = ((pmatched >> k) & 1u) ? (int)((pinl >> k) & 1u) : -1;
         }
     }
-    if (a.inl_l_out && a.max_lines > 0) {
+    if (W && a.inl_l_out && a.max_lines > 0) {
         const size_t base = (size_t)f * a.max_lines;
 #pragma unroll
         for (int k = 0; k < LPT; ++k) {
@@ -738,14 +777,27 @@ __global__ __launch_bounds__(BLOCK) void pose_kernel(PoseArgs a) {
     }
 }
 
-constexpr int POSE_BLOCK = 256;
-constexpr int POSE_PPT = STVO_POSE_MAX_POINTS / POSE_BLOCK;  // 8
-constexpr int POSE_LPT = STVO_POSE_MAX_LINES / POSE_BLOCK;   // 2
+template <int BLOCK, int PPT, int LPT>
+__global__ __launch_bounds__(BLOCK + 64) void pose_kernel(PoseArgs a) {
+    __shared__ int s_ibuf[2][BLOCK / 64];
+    __shared__ double s_red[BLOCK / 64][28];
+    __shared__ int s_ired[BLOCK / 64];
+    __shared__ PoseSh s_sh;
+    if (threadIdx.x < BLOCK)
+        pose_body<BLOCK, PPT, LPT, true>(a, s_ibuf, s_red, s_ired, &s_sh);   // worker waves
+    else
+        pose_body<BLOCK, PPT, LPT, false>(a, s_ibuf, s_red, s_ired, &s_sh);  // solver wave
+}
+
+// 7 worker waves + 1 solver wave = 512 threads: two waves per SIMD, <= 256 VGPRs each, no spills.
+constexpr int POSE_BLOCK = 448;
+constexpr int POSE_PPT = (STVO_POSE_MAX_POINTS + POSE_BLOCK - 1) / POSE_BLOCK;  // 5
+constexpr int POSE_LPT = (STVO_POSE_MAX_LINES + POSE_BLOCK - 1) / POSE_BLOCK;   // 2
 
 int launch_pose(hipStream_t s, const PoseArgs& a) {
     if (a.B <= 0) return STVO_OK;
     if (a.max_pts > STVO_POSE_MAX_POINTS || a.max_lines > STVO_POSE_MAX_LINES) return STVO_ERR_CAPACITY;
-    hipLaunchKernelGGL((pose_kernel<POSE_BLOCK, POSE_PPT, POSE_LPT>), dim3(a.B), dim3(POSE_BLOCK), 0, s, a);
+    hipLaunchKernelGGL((pose_kernel<POSE_BLOCK, POSE_PPT, POSE_LPT>), dim3(a.B), dim3(POSE_BLOCK + 64), 0, s, a);
     return STVO_OK;
 }
 

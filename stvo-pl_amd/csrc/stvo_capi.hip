@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -363,6 +364,20 @@ int stvo_time_stage_dev(stvo_ctx* ctx, const stvo_track_batch_dev* b, const stvo
     hipEventDestroy(e0);
     hipEventDestroy(e1);
     *avg_ms = ms / (float)iters;
+    if (stage == 1 && std::getenv("STVO_POSE_PROF")) {  // developer aid: per-phase ticks of the solver lane
+        long long* dprof = nullptr;
+        HIP_TRY(ctx, hipMalloc((void**)&dprof, (size_t)b->B * 8 * sizeof(long long)));
+        a.prof_out = dprof;
+        stvo::launch_pose(ctx->stream, a);
+        std::vector<long long> h((size_t)b->B * 8);
+        HIP_TRY(ctx, hipMemcpy(h.data(), dprof, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+        double m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int f = 0; f < b->B; ++f)
+            for (int i = 0; i < 8; ++i) m[i] += (double)h[(size_t)f * 8 + i] / b->B;
+        std::fprintf(stderr, "[pose prof] mean ticks/frame: evaluate %.0f  iter-algebra %.0f  cov+isgood+commit %.0f  "
+                             "remove_outliers %.0f  total %.0f | worker: eval-compute %.0f  sum28 %.0f\n", m[0], m[1], m[2], m[3], m[4], m[5], m[6]);
+        hipFree(dprof);
+    }
     return check_launch(ctx);
 }
 
