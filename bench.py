@@ -67,9 +67,8 @@ def main():
     from stvo_amd.ctypes_types import opt_params
     from stvo_amd.devbatch import TrackBatch
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from stvo_amd import shard
+    world, rank, local_rank = shard.env_world()
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -109,10 +108,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    # whole-job frame pairs (sum over ranks) and the slowest rank's time (max over ranks)
+    frames_total, dt = shard.aggregate(dist, B * args.steps, dt, device=dev)
 
     # sanity: the timed work produced real poses
     res = batch.results()
@@ -120,7 +117,6 @@ def main():
 
     out = None
     if rank == 0:
-        frames_total = B * args.steps * world
         k1_ms = ctx.time_stage(batch, synth.KITTI_CAM, prm, 0.75, 0, 10)
         pose_ms = ctx.time_stage(batch, synth.KITTI_CAM, prm, 0.75, 1, 10)
         alg_bytes = batch.algorithmic_bytes_match()

@@ -1,0 +1,147 @@
+// imagesStVO_synth.cpp — the caller of the boundary: the per-frame loop of
+// /root/reference/app/imagesStVO.cpp:86-124 (initialize / insertStereoPair / optimizePose /
+// updateFrame, the "Proc. time" timer and the console line of :114-121), driven by a file of
+// pre-extracted stereo features instead of images (no OpenCV / datasets in this image; the
+// ORB / LSD+LBD front-end is out of scope).  Writes per-frame results for the parity tests.
+//
+//   imagesStVO_synth <sequence.bin> <results.bin> [--preset kitti|euroc|default] [-c config.yaml] [--mode 0|1|2] [-n N]
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "../host/stereoFrameHandler.h"
+
+using namespace StVO;
+
+namespace {
+template <typename T>
+bool rd(std::ifstream& f, T* p, size_t n = 1) {
+    f.read(reinterpret_cast<char*>(p), (std::streamsize)(sizeof(T) * n));
+    return (bool)f;
+}
+template <typename T>
+void wr(std::ofstream& f, const T* p, size_t n = 1) {
+    f.write(reinterpret_cast<const char*>(p), (std::streamsize)(sizeof(T) * n));
+}
+
+bool read_points(std::ifstream& f, int n, std::vector<KeyPoint>& kp, DescMat& d) {
+    kp.resize(n);
+    for (int i = 0; i < n; ++i) {
+        if (!rd(f, &kp[i].x) || !rd(f, &kp[i].y) || !rd(f, &kp[i].octave)) return false;
+    }
+    d.rows = n;
+    d.data.resize((size_t)n * 32);
+    return n == 0 || rd(f, d.data.data(), (size_t)n * 32);
+}
+bool read_lines(std::ifstream& f, int n, std::vector<KeyLine>& kl, DescMat& d) {
+    kl.resize(n);
+    for (int i = 0; i < n; ++i) {
+        if (!rd(f, &kl[i].startPointX) || !rd(f, &kl[i].startPointY) || !rd(f, &kl[i].endPointX) ||
+            !rd(f, &kl[i].endPointY) || !rd(f, &kl[i].angle) || !rd(f, &kl[i].octave))
+            return false;
+    }
+    d.rows = n;
+    d.data.resize((size_t)n * 32);
+    return n == 0 || rd(f, d.data.data(), (size_t)n * 32);
+}
+}  // namespace
+
+int main(int argc, char** argv) {
+    if (argc < 3) {
+        std::cerr << "usage: imagesStVO_synth <sequence.bin> <results.bin> [--preset kitti|euroc|default] [-c cfg] "
+                     "[--mode m] [-n frames]\n";
+        return -1;
+    }
+    std::string preset = "kitti", cfg;
+    int mode = 0, max_frames = 0;
+    for (int i = 3; i < argc; ++i) {
+        if (!std::strcmp(argv[i], "--preset") && i + 1 < argc) preset = argv[++i];
+        else if (!std::strcmp(argv[i], "-c") && i + 1 < argc) cfg = argv[++i];
+        else if (!std::strcmp(argv[i], "--mode") && i + 1 < argc) mode = std::atoi(argv[++i]);
+        else if (!std::strcmp(argv[i], "-n") && i + 1 < argc) max_frames = std::atoi(argv[++i]);
+    }
+    if (preset == "kitti") Config::setKittiPreset();
+    else if (preset == "euroc") Config::setEurocPreset();
+    else Config::setDefaults();
+    if (!cfg.empty()) Config::loadFromFile(cfg);
+
+    std::ifstream in(argv[1], std::ios::binary);
+    char magic[8];
+    int32_t n_frames = 0, cols = 0, rows = 0;
+    double camv[5];
+    if (!in || !rd(in, magic, 8) || std::memcmp(magic, "STVOSEQ1", 8) != 0 || !rd(in, &n_frames) || !rd(in, &cols) ||
+        !rd(in, &rows) || !rd(in, camv, 5)) {
+        std::cerr << "bad sequence file\n";
+        return -1;
+    }
+    if (max_frames > 0 && max_frames < n_frames) n_frames = max_frames;
+    std::ofstream out(argv[2], std::ios::binary);
+    PinholeStereoCamera* cam_pin = new PinholeStereoCamera(cols, rows, camv[0], camv[1], camv[2], camv[3], camv[4]);
+
+    StereoFrameHandler* StVO = nullptr;
+    try {
+        StVO = new StereoFrameHandler(cam_pin);
+    } catch (const std::exception& e) {
+        std::cerr << e.what() << std::endl;
+        return -2;
+    }
+    StVO->mode = mode;
+    double t_total = 0.0;
+    for (int frame_counter = 0; frame_counter < n_frames; ++frame_counter) {
+        FrameFeatures feat;
+        feat.img_cols = cols;
+        feat.img_rows = rows;
+        int32_t n[4];
+        if (!rd(in, n, 4) || !read_points(in, n[0], feat.points_l, feat.pdesc_l) ||
+            !read_points(in, n[1], feat.points_r, feat.pdesc_r) || !read_lines(in, n[2], feat.lines_l, feat.ldesc_l) ||
+            !read_lines(in, n[3], feat.lines_r, feat.ldesc_r)) {
+            std::cerr << "truncated sequence file at frame " << frame_counter << "\n";
+            return -1;
+        }
+        if (frame_counter == 0) {
+            StVO->initialize(feat, 0);
+            continue;
+        }
+        const auto t0 = std::chrono::high_resolution_clock::now();  // timer.start()  (imagesStVO.cpp:95)
+        StVO->insertStereoPair(feat, frame_counter);
+        StVO->optimizePose();
+        const double t1 =
+            std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
+        t_total += t1;
+
+        // console output (imagesStVO.cpp:114-121)
+        std::printf("Frame: %d\tRes.: %.8f \t Proc. time: %.3f ms\t ", frame_counter, StVO->curr_frame->err_norm, t1);
+        if (Config::adaptativeFAST()) std::printf("\t FAST: %d", StVO->orb_fast_th);
+        if (Config::hasPoints()) std::printf("\t Points: %zu (%d) ", StVO->matched_pt.size(), StVO->n_inliers_pt);
+        if (Config::hasLines()) std::printf("\t Lines:  %zu (%d) ", StVO->matched_ls.size(), StVO->n_inliers_ls);
+        std::printf("\n");
+
+        const stvo_pose_result& r = StVO->last_result;
+        const int32_t ints[12] = {frame_counter, r.status, r.path, r.iters[0], r.iters[1], (int32_t)StVO->matched_pt.size(),
+                                  StVO->n_inliers_pt, (int32_t)StVO->matched_ls.size(), StVO->n_inliers_ls,
+                                  (int32_t)StVO->curr_frame->stereo_pt.size(), (int32_t)StVO->curr_frame->stereo_ls.size(),
+                                  0};
+        wr(out, ints, 12);
+        wr(out, StVO->curr_frame->DT.m, 16);
+        wr(out, StVO->curr_frame->DT_cov.m, 36);
+        wr(out, StVO->curr_frame->DT_cov_eig.v, 6);
+        wr(out, &StVO->curr_frame->err_norm, 1);
+        wr(out, StVO->curr_frame->Tfw.m, 16);
+        wr(out, StVO->curr_frame->Tfw_cov.m, 36);
+        StVO->updateFrame();
+        const int32_t fast = StVO->orb_fast_th;
+        wr(out, &fast, 1);
+        const int32_t pad = 0;
+        wr(out, &pad, 1);
+    }
+    if (n_frames > 1)
+        std::printf("[imagesStVO_synth] %d frame pairs, mean Proc. time %.3f ms (single stream, incl. H2D/D2H)\n",
+                    n_frames - 1, t_total / (n_frames - 1));
+    delete StVO;
+    delete cam_pin;
+    return 0;
+}

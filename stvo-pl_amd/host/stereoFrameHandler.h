@@ -1,0 +1,53 @@
+// stereoFrameHandler.h — StVO::StereoFrameHandler with the reference's method names and public
+// fields (include/stereoFrameHandler.h:41-85).  `Mat img_l, img_r` arguments are replaced by the
+// frame's extracted FrameFeatures (feature extraction is out of scope); everything downstream —
+// stereo association, f2f tracking, optimizePose, updateFrame — keeps the reference's behaviour,
+// with the descriptor matching and the whole pose optimisation running on the GPU via the C-ABI.
+#pragma once
+#include <list>
+
+#include "../../include/stvo_hip.h"
+#include "stereoFrame.h"
+
+namespace StVO {
+
+class StereoFrameHandler {
+public:
+    explicit StereoFrameHandler(PinholeStereoCamera* cam_, int device_id = 0);
+    ~StereoFrameHandler();
+
+    void initialize(const FrameFeatures& feat, const int idx_);
+    void insertStereoPair(const FrameFeatures& feat, const int idx_);
+    void updateFrame();
+
+    void f2fTracking();
+    void matchF2FPoints();
+    void matchF2FLines();
+
+    bool isGoodSolution(Matrix4d DT, Matrix6d DTcov, double err);
+    void optimizePose();
+    void resetOutliers();
+    void setAsOutliers();
+
+    // adaptative fast
+    int orb_fast_th;
+    double llength_th;
+
+    std::list<PointFeature*> matched_pt;
+    std::list<LineFeature*> matched_ls;
+
+    StereoFrame* prev_frame;
+    StereoFrame* curr_frame;
+    PinholeStereoCamera* cam;
+
+    int n_inliers, n_inliers_pt, n_inliers_ls;
+
+    // what the GPU reported for the last optimizePose (status / path / iteration counts)
+    stvo_pose_result last_result;
+    int mode = 0;  // the local constant of src/stereoFrameHandler.cpp:329 (0 GN, 1 robust GN, 2 LM)
+
+private:
+    stvo_ctx* ctx;
+};
+
+}  // namespace StVO

@@ -1,0 +1,77 @@
+"""Oracle-driven restatement of the per-frame loop (initialize / insertStereoPair / optimizePose /
+updateFrame, /root/reference/src/stereoFrameHandler.cpp:35-180,307-392) — TEST INFRASTRUCTURE ONLY.
+Every numeric step goes through oracle/stvo_oracle.c; this file is only the list/record plumbing."""
+import numpy as np
+
+
+def stereo_frame(orc, fr, cam, mp, has_points=True, has_lines=True):
+    cols, rows = cam["width"], cam["height"]
+    out = {}
+    if has_points and len(fr["kp_l"]) and len(fr["kp_r"]):
+        sp = orc.stereo_points(fr["kp_l"], fr["oct_l"], fr["desc_l"], fr["kp_r"], fr["desc_r"], cols, rows, cam, mp)
+        out.update(pl=sp["pl"], P=sp["P"], sigma2p=sp["sigma2"], pdesc=np.ascontiguousarray(fr["desc_l"][sp["src_idx"]]))
+    else:
+        out.update(pl=np.zeros((0, 2)), P=np.zeros((0, 3)), sigma2p=np.zeros(0), pdesc=np.zeros((0, 32), np.uint8))
+    if has_lines and len(fr["kl_l"]) and len(fr["kl_r"]):
+        sl = orc.stereo_lines(fr["kl_l"], fr["ang_l"], fr["oct_ll"], fr["ldesc_l"], fr["kl_r"], fr["ldesc_r"], cols, rows, cam, mp)
+        out.update(spl=sl["spl"], epl=sl["epl"], sP=sl["sP"], eP=sl["eP"], le=sl["le"], sigma2l=sl["sigma2"],
+                   llevel=fr["oct_ll"][sl["src_idx"]], ldesc=np.ascontiguousarray(fr["ldesc_l"][sl["src_idx"]]))
+    else:
+        z3 = np.zeros((0, 3)); z2 = np.zeros((0, 2))
+        out.update(spl=z2, epl=z2.copy(), sP=z3, eP=z3.copy(), le=z3.copy(), sigma2l=np.zeros(0), llevel=np.zeros(0, np.int32),
+                   ldesc=np.zeros((0, 32), np.uint8))
+    return out
+
+
+def matched_line_sigma2(sigma2, level, lsd_scale):
+    """LineFeature::safeCopy re-applies the level scaling (src/stereoFeatures.cpp:117-135)."""
+    out = np.empty(len(sigma2))
+    for i, (s, lv) in enumerate(zip(sigma2, level)):
+        for _ in range(int(lv)):
+            s *= lsd_scale
+        out[i] = 1.0 / (s * s)
+    return out
+
+
+def run_sequence(orc, frames, cam, mp, prm, fast=dict(adaptive=True, th0=20, mn=7, mx=30, inc=5, feat=50, err=0.5)):
+    has_p, has_l = bool(prm.has_points), bool(prm.has_lines)
+    prev = stereo_frame(orc, frames[0], cam, mp, has_p, has_l)
+    prev.update(Tfw=np.eye(4), Tfw_cov=np.eye(6))
+    fast_th = fast["th0"]
+    results = []
+    for k in range(1, len(frames)):
+        curr = stereo_frame(orc, frames[k], cam, mp, has_p, has_l)
+        z3 = np.zeros((0, 3)); z2 = np.zeros((0, 2))
+        rec = dict(P=z3, pl_obs=z2, sigma2p=np.zeros(0), inlier_p=np.zeros(0, np.int32), sP=z3, eP=z3, le_obs=z3, spl=z2,
+                   epl=z2, sigma2l=np.zeros(0), inlier_l=np.zeros(0, np.int32))
+        if has_p and len(prev["P"]) and len(curr["P"]):
+            m12, _ = orc.match(prev["pdesc"], curr["pdesc"], mp.min_ratio_12_p, mp.best_lr_matches)
+            sel = np.nonzero(m12 >= 0)[0]
+            rec.update(P=prev["P"][sel], pl_obs=curr["pl"][m12[sel]], sigma2p=prev["sigma2p"][sel], inlier_p=np.ones(len(sel), np.int32))
+        if has_l and len(prev["sP"]) and len(curr["sP"]):
+            m12, _ = orc.match(prev["ldesc"], curr["ldesc"], mp.min_ratio_12_l, mp.best_lr_matches)
+            sel = np.nonzero(m12 >= 0)[0]
+            rec.update(sP=prev["sP"][sel], eP=prev["eP"][sel], le_obs=curr["le"][m12[sel]], spl=prev["spl"][sel],
+                       epl=prev["epl"][sel], sigma2l=matched_line_sigma2(prev["sigma2l"][sel], prev["llevel"][sel], mp.lsd_scale),
+                       inlier_l=np.ones(len(sel), np.int32))
+        out = orc.optimize_pose(np.eye(4), cam, prm, rec)
+        if out["status"] == 0:
+            curr["Tfw"] = orc.expmap(orc.logmap(prev["Tfw"] @ out["T"]))
+            curr["Tfw_cov"] = orc.unccomp(prev["Tfw"], prev["Tfw_cov"], out["cov"])
+        else:
+            curr["Tfw"], curr["Tfw_cov"] = prev["Tfw"], prev["Tfw_cov"]
+        n_inl_pt = out["n_inliers_pt"]
+        if fast["adaptive"]:  # updateFrame, :66-86
+            if np.array_equal(out["T"], np.eye(4)) or out["err"] > np.float32(fast["err"]):
+                fast_th = max(fast["mn"], fast_th - 2 * fast["inc"])
+            elif n_inl_pt < fast["feat"]:
+                fast_th = max(fast["mn"], fast_th - 2 * fast["inc"])
+            elif n_inl_pt < fast["feat"] * 2:
+                fast_th = max(fast["mn"], fast_th - fast["inc"])
+            elif n_inl_pt > fast["feat"] * 3:
+                fast_th = min(fast["mx"], fast_th + fast["inc"])
+        out.update(Tfw=curr["Tfw"], Tfw_cov=curr["Tfw_cov"], n_stereo_pt=len(curr["P"]), n_stereo_ls=len(curr["sP"]),
+                   n_matched_pt=len(rec["sigma2p"]), n_matched_ls=len(rec["sigma2l"]), fast=fast_th)
+        results.append(out)
+        prev = curr
+    return results
