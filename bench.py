@@ -23,8 +23,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "stvo-pl_amd", "python"))
 
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
-VALU_PEAK_LANE_OPS = 78.6e12  # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (32-bit integer VALU lane-ops/s)
-K1_LANE_OPS_PER_PAIR = 19     # 8 xor + 8 bcnt + lshl_or + med3 + min  
+# K1 issues, per (query, train) pair, 8 full-rate VALU ops (v_xor_b32: 32 lanes/clk/SIMD) and 11 half-rate
+# ones (v_bcnt_u32_b32, v_lshl_or_b32, v_med3_u32, v_min_u32: 16 lanes/clk/SIMD, measured with
+# tools/valu_rates.hip).  Roof of that mix at 256 CU x 4 SIMD x 2.4 GHz: 19 / (8/78.6e12 + 11/39.3e12).
+K1_LANE_OPS_PER_PAIR = 19
+VALU_PEAK_LANE_OPS = K1_LANE_OPS_PER_PAIR / (8 / 78.6e12 + 11 / 39.3e12)  # = 49.8e12
 
 
 def cpu_baseline(frames, prm, budget_s=15.0):

@@ -61,17 +61,29 @@ __device__ __forceinline__ uint32_t hamming256(const uint4& q0, const uint4& q1,
 
 constexpr int KNN_BLOCK = 256;
 
-__global__ __launch_bounds__(KNN_BLOCK) void hamming_knn2_kernel(int row_stride, const uint8_t* __restrict__ d1,
+__global__ __launch_bounds__(KNN_BLOCK) void hamming_knn2_kernel(int B, int tiles, int ndir, int row_stride,
+                                                                 const uint8_t* __restrict__ d1,
                                                                  const int32_t* __restrict__ n1,
                                                                  const uint8_t* __restrict__ d2,
                                                                  const int32_t* __restrict__ n2,
                                                                  uint2* __restrict__ knn12, uint2* __restrict__ knn21) {
-    const int b = blockIdx.z;
-    const int dir = blockIdx.y;
+    // XCD-aware block -> (frame pair, direction, tile) mapping.  Workgroups are dispatched round-robin
+    // over the 8 XCDs (workgroup L runs on XCD L % 8, each XCD has a private 4 MiB L2).  With the
+    // natural (tile, dir, frame) order the 2*tiles workgroups of one frame pair land on all 8 XCDs
+    // and every L2 fetches the pair's descriptors again (measured: FETCH_SIZE = 7.8x the compulsory
+    // bytes).  Here all workgroups of a frame pair share one XCD: frame = (k / per_frame) * 8 + xcd.
+    const int per_frame = tiles * ndir;
+    const int L = blockIdx.x;
+    const int xcd = L & 7, k = L >> 3;
+    const int b = (k / per_frame) * 8 + xcd;
+    if (b >= B) return;
+    const int local = k % per_frame;
+    const int dir = local / tiles;
+    const int tile = local % tiles;
     const int na = n1[b], nb = n2[b];
     const int nq = dir == 0 ? na : nb;
     const int nt = dir == 0 ? nb : na;
-    const int q_base = blockIdx.x * KNN_BLOCK;
+    const int q_base = tile * KNN_BLOCK;
     if (q_base >= nq) return;  // block-uniform
     const size_t frame_off = (size_t)b * row_stride;
     const uint8_t* Q = (dir == 0 ? d1 : d2) + frame_off * STVO_DESC_BYTES;
@@ -113,8 +125,11 @@ __global__ __launch_bounds__(KNN_BLOCK) void hamming_knn2_kernel(int row_stride,
 void launch_hamming_knn2(hipStream_t s, int B, int row_stride, int max_n, const uint8_t* d1, const int32_t* n1,
                          const uint8_t* d2, const int32_t* n2, uint2* knn12, uint2* knn21, int both_directions) {
     if (B <= 0 || max_n <= 0) return;
-    dim3 grid((max_n + KNN_BLOCK - 1) / KNN_BLOCK, both_directions ? 2 : 1, B);
-    hipLaunchKernelGGL(hamming_knn2_kernel, grid, dim3(KNN_BLOCK), 0, s, row_stride, d1, n1, d2, n2, knn12, knn21);
+    const int tiles = (max_n + KNN_BLOCK - 1) / KNN_BLOCK, ndir = both_directions ? 2 : 1;
+    const int groups = (B + 7) / 8;  // frame pairs are dealt to the 8 XCDs in groups of 8
+    dim3 grid((unsigned)(groups * 8 * tiles * ndir));
+    hipLaunchKernelGGL(hamming_knn2_kernel, grid, dim3(KNN_BLOCK), 0, s, B, tiles, ndir, row_stride, d1, n1, d2, n2,
+                       knn12, knn21);
 }
 
 // K2: m12[i] = j  iff  float(d0) < float(d1) * nnr  (12 direction)  and, when `mutual`, the 21
