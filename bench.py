@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--batch", type=int, default=512, help="frame pairs per step per GPU")
     ap.add_argument("--keypoints", type=int, default=2000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="strict stream order (no pose || matching overlap)")
     args = ap.parse_args()
 
     import torch
@@ -93,12 +94,14 @@ def main():
     ctx = capi.Context(device_id=local_rank, max_rows=max_pts, max_batch=B)
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)
+    ctx.set_overlap(not args.no_overlap)
 
     def step():
         ctx.track_batched(batch, synth.KITTI_CAM, prm, 0.75, 0.75, 1)
 
     for _ in range(args.warmup):
         step()
+    ctx.synchronize()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -106,6 +109,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    ctx.synchronize()           # both of the context's streams
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -136,7 +140,8 @@ def main():
                                    "brute-force mutual-NNR point match + optimizePose (config_kitti.yaml), "
                                    "batched independent frame pairs resident in HBM",
                        "frame_pairs_per_step_per_gpu": B, "keypoints_per_frame": n, "parallelism": f"seq-shard x{world}",
-                       "committed_pose_fraction": ok_frac},
+                       "committed_pose_fraction": ok_frac,
+                       "pose_overlaps_next_match": not args.no_overlap},
             "roofline": {"kernel": "hamming_knn2_kernel", "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k1_ms,

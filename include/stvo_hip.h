@@ -26,7 +26,7 @@ extern "C" {
 #define STVO_ABI_VERSION 1
 #define STVO_MAX_ROWS_LIMIT 65535 /* packed (distance << 16 | index) keys */
 #define STVO_POSE_MAX_POINTS 2048 /* per frame-pair, register-resident records in the pose kernel */
-#define STVO_POSE_MAX_LINES 448
+#define STVO_POSE_MAX_LINES 512
 
 typedef struct stvo_ctx stvo_ctx;
 
@@ -45,6 +45,13 @@ int stvo_ctx_destroy(stvo_ctx* ctx);
 /* Borrow an existing hipStream_t (e.g. the caller's / torch's current stream); NULL = default. */
 int stvo_ctx_set_stream(stvo_ctx* ctx, void* hip_stream);
 int stvo_ctx_synchronize(stvo_ctx* ctx);
+/* Throughput option for the batched path.  enable = 1: stvo_track_batched_dev enqueues the pose kernel
+ * on a second (context-owned) stream behind an event, so that the NEXT call's matching kernels — which
+ * are integer-VALU bound and are then launched with an occupancy cap — run concurrently with this
+ * call's latency-bound pose kernel.  Results of a call are complete after stvo_ctx_synchronize (or a
+ * device synchronise); hazards between consecutive calls on the same buffers are handled with events.
+ * enable = 0 (default): strict stream order on the context's stream. */
+int stvo_ctx_set_overlap(stvo_ctx* ctx, int enable);
 
 /* ---- matching: host-buffer seams ------------------------------------------------------------ */
 

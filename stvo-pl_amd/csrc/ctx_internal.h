@@ -19,6 +19,11 @@ struct stvo_ctx {
     char* arena = nullptr;
     size_t arena_size = 0, arena_off = 0;
     uint32_t* probe_sink = nullptr;
+    // overlap mode: pose kernels go to aux_stream; events order them against the matching kernels
+    int overlap = 0;
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_match_done = nullptr, ev_pose_done = nullptr;
+    bool pose_pending = false;
     char last_error[256] = {0};
 };
 

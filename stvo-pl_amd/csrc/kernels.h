@@ -11,7 +11,8 @@ namespace stvo {
 // ---- K1 / K2: brute-force Hamming 2-NN, ratio test, mutual check ----------------------------
 // knn: [B][row_stride] packed (best_key, second_key), key = (distance << 16) | train_index.
 void launch_hamming_knn2(hipStream_t s, int B, int row_stride, int max_n, const uint8_t* d1, const int32_t* n1,
-                         const uint8_t* d2, const int32_t* n2, uint2* knn12, uint2* knn21, int both_directions);
+                         const uint8_t* d2, const int32_t* n2, uint2* knn12, uint2* knn21, int both_directions,
+                         int lds_pad_bytes = 0);
 void launch_nnr_mutual(hipStream_t s, int B, int row_stride, const uint2* knn12, const uint2* knn21, const int32_t* n1,
                        const int32_t* n2, float nnr, int mutual, int32_t* m12);
 void launch_valu_probe(hipStream_t s, int blocks, int iters, uint32_t* sink);

@@ -123,12 +123,15 @@ __global__ __launch_bounds__(KNN_BLOCK) void hamming_knn2_kernel(int B, int tile
 }
 
 void launch_hamming_knn2(hipStream_t s, int B, int row_stride, int max_n, const uint8_t* d1, const int32_t* n1,
-                         const uint8_t* d2, const int32_t* n2, uint2* knn12, uint2* knn21, int both_directions) {
+                         const uint8_t* d2, const int32_t* n2, uint2* knn12, uint2* knn21, int both_directions,
+                         int lds_pad_bytes) {
     if (B <= 0 || max_n <= 0) return;
     const int tiles = (max_n + KNN_BLOCK - 1) / KNN_BLOCK, ndir = both_directions ? 2 : 1;
     const int groups = (B + 7) / 8;  // frame pairs are dealt to the 8 XCDs in groups of 8
     dim3 grid((unsigned)(groups * 8 * tiles * ndir));
-    hipLaunchKernelGGL(hamming_knn2_kernel, grid, dim3(KNN_BLOCK), 0, s, B, tiles, ndir, row_stride, d1, n1, d2, n2,
+    // lds_pad_bytes > 0 only caps the number of resident workgroups per CU (the kernel uses no LDS), leaving
+    // wave slots and VGPRs for a concurrently running pose kernel (stvo_ctx_set_overlap)
+    hipLaunchKernelGGL(hamming_knn2_kernel, grid, dim3(KNN_BLOCK), (size_t)lds_pad_bytes, s, B, tiles, ndir, row_stride, d1, n1, d2, n2,
                        knn12, knn21);
 }
 

@@ -432,72 +432,76 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_ibuf)[BLOCK
     const pm::Cam5 cam{a.cam.fx, a.cam.fy, a.cam.cx, a.cam.cy};
     const stvo_opt_params prm = a.prm;
 
-    // ---------------- load the matched records (HBM -> VGPRs, once) ----------------
-    double Px[PPT], Py[PPT], Pz[PPT], ox[PPT], oy[PPT], s2[PPT];
+    // ---------------- which records does this thread own?  (bitmasks only) ----------------
+    // Thread t of the worker waves owns prev features i = t + k*BLOCK, k < PPT.  Only two bitmasks
+    // (matched, inlier) live in registers for the whole optimisation; the record itself
+    // (52 B / point, 116 B / line, gathered through m12) is re-read at every evaluation.  It comes
+    // from HBM the first time and from L2 afterwards: the working set of the workgroups resident on
+    // one XCD is < 4 MiB.  Keeping the records out of the VGPR file is what lets three workgroups
+    // share a CU, so one pair's serial 6x6 algebra overlaps the parallel phases of the others.
     unsigned pmatched = 0u, pinl = 0u;
     // like the reference, optimizeFunctions sums whatever is in matched_pt / matched_ls; has_points /
     // has_lines only gate the matching (caller) and the two blocks of removeOutliers (:991,1026)
     const int n_prev_p = (W && a.n_prev_pts != nullptr) ? a.n_prev_pts[f] : 0;
-    {
-        const size_t base = (size_t)f * a.max_pts;
+    const size_t pbase = (size_t)f * a.max_pts;
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            const int i = tid + k * BLOCK;
-            Px[k] = Py[k] = Pz[k] = 1.0;
-            ox[k] = oy[k] = 0.0;
-            s2[k] = 1.0;
-            if (i < n_prev_p) {
-                const int j = a.m12p ? a.m12p[base + i] : i;
-                if (j >= 0) {
-                    Px[k] = a.prev_P[(base + i) * 3 + 0];
-                    Py[k] = a.prev_P[(base + i) * 3 + 1];
-                    Pz[k] = a.prev_P[(base + i) * 3 + 2];
-                    s2[k] = a.prev_s2p[base + i];
-                    ox[k] = a.curr_pl[(base + j) * 2 + 0];
-                    oy[k] = a.curr_pl[(base + j) * 2 + 1];
-                    pmatched |= 1u << k;
-                    if (a.init_inl_p == nullptr || a.init_inl_p[base + i] != 0) pinl |= 1u << k;
-                }
+    for (int k = 0; k < PPT; ++k) {
+        const int i = tid + k * BLOCK;
+        if (i < n_prev_p) {
+            const int j = a.m12p ? a.m12p[pbase + i] : i;
+            if (j >= 0) {
+                pmatched |= 1u << k;
+                if (a.init_inl_p == nullptr || a.init_inl_p[pbase + i] != 0) pinl |= 1u << k;
             }
         }
     }
-    pm::LineRec L[LPT];
     unsigned lmatched = 0u, linl = 0u;
     const int n_prev_l = (W && a.n_prev_lines != nullptr && a.max_lines > 0) ? a.n_prev_lines[f] : 0;
-    {
-        const size_t base = (size_t)f * a.max_lines;
+    const size_t lbase = (size_t)f * a.max_lines;
 #pragma unroll
-        for (int k = 0; k < LPT; ++k) {
-            const int i = tid + k * BLOCK;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                L[k].sP[c] = 1.0;
-                L[k].eP[c] = 1.0;
-                L[k].le[c] = 0.0;
-            }
-            L[k].spl[0] = L[k].spl[1] = L[k].epl[0] = L[k].epl[1] = 0.0;
-            L[k].sigma2 = 1.0;
-            if (i < n_prev_l) {
-                const int j = a.m12l ? a.m12l[base + i] : i;
-                if (j >= 0) {
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        L[k].sP[c] = a.prev_sP[(base + i) * 3 + c];
-                        L[k].eP[c] = a.prev_eP[(base + i) * 3 + c];
-                        L[k].le[c] = a.curr_le[(base + j) * 3 + c];
-                    }
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) {
-                        L[k].spl[c] = a.prev_spl[(base + i) * 2 + c];
-                        L[k].epl[c] = a.prev_epl[(base + i) * 2 + c];
-                    }
-                    L[k].sigma2 = a.prev_s2l[base + i];
-                    lmatched |= 1u << k;
-                    if (a.init_inl_l == nullptr || a.init_inl_l[base + i] != 0) linl |= 1u << k;
-                }
+    for (int k = 0; k < LPT; ++k) {
+        const int i = tid + k * BLOCK;
+        if (i < n_prev_l) {
+            const int j = a.m12l ? a.m12l[lbase + i] : i;
+            if (j >= 0) {
+                lmatched |= 1u << k;
+                if (a.init_inl_l == nullptr || a.init_inl_l[lbase + i] != 0) linl |= 1u << k;
             }
         }
     }
+    struct PointRec {
+        double X, Y, Z, ox, oy, s2;
+    };
+    auto load_point = [&](int k) -> PointRec {
+        const size_t i = pbase + (size_t)(tid + k * BLOCK);
+        const size_t j = a.m12p ? pbase + (size_t)a.m12p[i] : i;
+        PointRec r;
+        r.X = a.prev_P[i * 3 + 0];
+        r.Y = a.prev_P[i * 3 + 1];
+        r.Z = a.prev_P[i * 3 + 2];
+        r.s2 = a.prev_s2p[i];
+        r.ox = a.curr_pl[j * 2 + 0];
+        r.oy = a.curr_pl[j * 2 + 1];
+        return r;
+    };
+    auto load_line = [&](int k) -> pm::LineRec {
+        const size_t i = lbase + (size_t)(tid + k * BLOCK);
+        const size_t j = a.m12l ? lbase + (size_t)a.m12l[i] : i;
+        pm::LineRec L;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            L.sP[c] = a.prev_sP[i * 3 + c];
+            L.eP[c] = a.prev_eP[i * 3 + c];
+            L.le[c] = a.curr_le[j * 3 + c];
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            L.spl[c] = a.prev_spl[i * 2 + c];
+            L.epl[c] = a.prev_epl[i * 2 + c];
+        }
+        L.sigma2 = a.prev_s2l[i];
+        return L;
+    };
 
     {
         const int nmp = Ops::template sum_int<W>(__popc(pmatched), s_ired);
@@ -535,25 +539,40 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_ibuf)[BLOCK
         if (robust) {  // pre-pass :710-781: MAD scale of the inlier residual norms
             double rp[PPT];
 #pragma unroll
-            for (int k = 0; k < PPT; ++k)
-                rp[k] = ((pinl >> k) & 1u) ? pm::point_residual(DT, cam, Px[k], Py[k], Pz[k], ox[k], oy[k]) : 0.0;
+            for (int k = 0; k < PPT; ++k) {
+                rp[k] = 0.0;
+                if ((pinl >> k) & 1u) {
+                    const PointRec r = load_point(k);
+                    rp[k] = pm::point_residual(DT, cam, r.X, r.Y, r.Z, r.ox, r.oy);
+                }
+                __builtin_amdgcn_sched_barrier(0);  // keep one record in flight, not PPT of them
+            }
             sp = pm::clamp_scale(Ops::template mad_sigma<PPT, W>(rp, pinl, sh->n_inl_p, s_ibuf));
             double rl[LPT];
 #pragma unroll
-            for (int k = 0; k < LPT; ++k) rl[k] = ((linl >> k) & 1u) ? pm::line_residual(DT, cam, L[k]) : 0.0;
+            for (int k = 0; k < LPT; ++k) {
+                rl[k] = 0.0;
+                if ((linl >> k) & 1u) rl[k] = pm::line_residual(DT, cam, load_line(k));
+                __builtin_amdgcn_sched_barrier(0);
+            }
             sl = pm::clamp_scale(Ops::template mad_sigma<LPT, W>(rl, linl, sh->n_inl_l, s_ibuf));
         }
         const long long tw0 = tick();
         double acc[28];
 #pragma unroll
         for (int i = 0; i < 28; ++i) acc[i] = 0.0;
-#pragma unroll
+#pragma unroll 1
         for (int k = 0; k < PPT; ++k)
-            if ((pinl >> k) & 1u)
-                pm::point_term(acc, DT, cam, prm.homog_th, Px[k], Py[k], Pz[k], ox[k], oy[k], s2[k], robust, sp);
-#pragma unroll
+            if ((pinl >> k) & 1u) {
+                const PointRec r = load_point(k);
+                pm::point_term(acc, DT, cam, prm.homog_th, r.X, r.Y, r.Z, r.ox, r.oy, r.s2, robust, sp);
+            }
+#pragma unroll 1
         for (int k = 0; k < LPT; ++k)
-            if ((linl >> k) & 1u) pm::line_term(acc, DT, cam, prm.homog_th, L[k], robust, sl);
+            if ((linl >> k) & 1u) {
+                const pm::LineRec L = load_line(k);
+                pm::line_term(acc, DT, cam, prm.homog_th, L, robust, sl);
+            }
         const long long tw1 = tick();
         Ops::template sum28<W>(acc, s_red, sh);
         wprof[0] += tw1 - tw0;
@@ -584,9 +603,14 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_ibuf)[BLOCK
             double res[PPT];
             const int tot = sh->n_m_p;
 #pragma unroll
-            for (int k = 0; k < PPT; ++k)  // ALL matches, current outliers included (:998-1005)
-                res[k] = ((pmatched >> k) & 1u)
-                             ? pm::point_residual(DT, cam, Px[k], Py[k], Pz[k], ox[k], oy[k]) * sqrt(s2[k]) : 0.0;
+            for (int k = 0; k < PPT; ++k) {  // ALL matches, current outliers included (:998-1005)
+                res[k] = 0.0;
+                if ((pmatched >> k) & 1u) {
+                    const PointRec r = load_point(k);
+                    res[k] = pm::point_residual(DT, cam, r.X, r.Y, r.Z, r.ox, r.oy) * sqrt(r.s2);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
             const double stdv = Ops::template mad_sigma<PPT, W>(res, pmatched, tot, s_ibuf);
             // mean of the samples below 2 sigma, or of all samples (src/auxiliar.cpp:405-427)
             double v[3] = {0.0, 0.0, 0.0};
@@ -617,8 +641,14 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_ibuf)[BLOCK
             double res[LPT];
             const int tot = sh->n_m_l;
 #pragma unroll
-            for (int k = 0; k < LPT; ++k)
-                res[k] = ((lmatched >> k) & 1u) ? pm::line_residual(DT, cam, L[k]) * sqrt(L[k].sigma2) : 0.0;
+            for (int k = 0; k < LPT; ++k) {
+                res[k] = 0.0;
+                if ((lmatched >> k) & 1u) {
+                    const pm::LineRec L = load_line(k);
+                    res[k] = pm::line_residual(DT, cam, L) * sqrt(L.sigma2);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
             const double stdv = Ops::template mad_sigma<LPT, W>(res, lmatched, tot, s_ibuf);
             double v[3] = {0.0, 0.0, 0.0};
 #pragma unroll
@@ -778,19 +808,23 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_ibuf)[BLOCK
 }
 
 template <int BLOCK, int PPT, int LPT>
-__global__ __launch_bounds__(BLOCK + 64) void pose_kernel(PoseArgs a) {
+__global__ __launch_bounds__(BLOCK + 64, 2) void pose_kernel(PoseArgs a) {  // >= 2 waves/SIMD => <= 256 VGPRs, 2 workgroups per CU
     __shared__ int s_ibuf[2][BLOCK / 64];
     __shared__ double s_red[BLOCK / 64][28];
     __shared__ int s_ired[BLOCK / 64];
     __shared__ PoseSh s_sh;
+    // This kernel is latency-bound (dependent FP64 chains, barriers) and is meant to run CONCURRENTLY with
+    // the VALU-saturating matching kernel of the next batch (stvo_ctx_set_overlap): give its waves issue
+    // priority so its critical path is not stretched by the co-resident popcount waves.
+    __builtin_amdgcn_s_setprio(3);
     if (threadIdx.x < BLOCK)
         pose_body<BLOCK, PPT, LPT, true>(a, s_ibuf, s_red, s_ired, &s_sh);   // worker waves
     else
         pose_body<BLOCK, PPT, LPT, false>(a, s_ibuf, s_red, s_ired, &s_sh);  // solver wave
 }
 
-// 7 worker waves + 1 solver wave = 512 threads: two waves per SIMD, <= 256 VGPRs each, no spills.
-constexpr int POSE_BLOCK = 448;
+// 3 worker waves + 1 solver wave = 256 threads, <= 168 VGPRs: three workgroups per CU.
+constexpr int POSE_BLOCK = 192;
 constexpr int POSE_PPT = (STVO_POSE_MAX_POINTS + POSE_BLOCK - 1) / POSE_BLOCK;  // 5
 constexpr int POSE_LPT = (STVO_POSE_MAX_LINES + POSE_BLOCK - 1) / POSE_BLOCK;   // 2
 

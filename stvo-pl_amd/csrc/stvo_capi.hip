@@ -71,6 +71,12 @@ int stvo_ctx_destroy(stvo_ctx* ctx) {
     if (ctx->knn21) hipFree(ctx->knn21);
     if (ctx->arena) hipFree(ctx->arena);
     if (ctx->probe_sink) hipFree(ctx->probe_sink);
+    if (ctx->aux_stream) {
+        hipStreamSynchronize(ctx->aux_stream);
+        hipStreamDestroy(ctx->aux_stream);
+        hipEventDestroy(ctx->ev_match_done);
+        hipEventDestroy(ctx->ev_pose_done);
+    }
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return STVO_OK;
@@ -90,6 +96,21 @@ int stvo_ctx_set_stream(stvo_ctx* ctx, void* hip_stream) {
 int stvo_ctx_synchronize(stvo_ctx* ctx) {
     if (!ctx) return STVO_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->aux_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->aux_stream));
+    ctx->pose_pending = false;
+    return STVO_OK;
+}
+
+int stvo_ctx_set_overlap(stvo_ctx* ctx, int enable) {
+    if (!ctx) return STVO_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (enable && !ctx->aux_stream) {
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_match_done, hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_pose_done, hipEventDisableTiming));
+    }
+    if (!enable && ctx->aux_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->aux_stream));
+    ctx->overlap = enable ? 1 : 0;
     return STVO_OK;
 }
 
@@ -250,6 +271,8 @@ int stvo_optimize_pose(stvo_ctx* ctx, const double init_T[16], const stvo_cam* c
 // ------------------------------------------------------------------------------------------------
 namespace {
 
+constexpr int kOverlapLdsPad = 26 * 1024;  // 6 matching workgroups (24 waves) per CU instead of 8
+
 int fill_pose_args(const stvo_track_batch_dev* b, const stvo_cam* cam, const stvo_opt_params* prm, bool identity,
                    stvo::PoseArgs* a) {
     std::memset(a, 0, sizeof(*a));
@@ -304,26 +327,51 @@ int stvo_track_batched_dev(stvo_ctx* ctx, const stvo_track_batch_dev* b, const s
     TRY(check_batch(ctx, b, true));
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (b->B == 0) return STVO_OK;
+    // Overlap mode: the matching kernels of THIS call may run while the pose kernel of the PREVIOUS call
+    // is still in flight on aux_stream.  K1 only writes the context's knn scratch (never read by the pose
+    // kernel); K2 rewrites m12, which the previous pose kernel may still be reading => K2 waits for it.
+    const int pad = ctx->overlap ? kOverlapLdsPad : 0;
+    bool waited = !(ctx->overlap && ctx->pose_pending);
+    auto wait_prev_pose = [&]() -> int {
+        if (!waited) {
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_pose_done, 0));
+            waited = true;
+        }
+        return STVO_OK;
+    };
     // matchF2FPoints (:131-153)
     if (params->has_points) {
         stvo::launch_hamming_knn2(ctx->stream, b->B, b->max_pts, b->max_pts, b->prev_pdesc, b->n_prev_pts,
-                                  b->curr_pdesc, b->n_curr_pts, ctx->knn12, ctx->knn21, mutual ? 1 : 0);
+                                  b->curr_pdesc, b->n_curr_pts, ctx->knn12, ctx->knn21, mutual ? 1 : 0, pad);
+        TRY(wait_prev_pose());
         stvo::launch_nnr_mutual(ctx->stream, b->B, b->max_pts, ctx->knn12, ctx->knn21, b->n_prev_pts, b->n_curr_pts,
                                 nnr_points, mutual, b->m12_pts);
     }
     // matchF2FLines (:155-180)
     if (params->has_lines && b->max_lines > 0) {
         stvo::launch_hamming_knn2(ctx->stream, b->B, b->max_lines, b->max_lines, b->prev_ldesc, b->n_prev_lines,
-                                  b->curr_ldesc, b->n_curr_lines, ctx->knn12, ctx->knn21, mutual ? 1 : 0);
+                                  b->curr_ldesc, b->n_curr_lines, ctx->knn12, ctx->knn21, mutual ? 1 : 0, pad);
+        TRY(wait_prev_pose());
         stvo::launch_nnr_mutual(ctx->stream, b->B, b->max_lines, ctx->knn12, ctx->knn21, b->n_prev_lines,
                                 b->n_curr_lines, nnr_lines, mutual, b->m12_lines);
     }
+    TRY(wait_prev_pose());
     stvo::PoseArgs a;
     fill_pose_args(b, cam, params, false, &a);
     // a feature kind that is switched off is never matched => matched_pt / matched_ls stay empty (:137,160)
     if (!params->has_points) a.n_prev_pts = nullptr;
     if (!params->has_lines) a.n_prev_lines = nullptr;
-    TRY(stvo::launch_pose(ctx->stream, a));
+    hipStream_t pose_stream = ctx->stream;
+    if (ctx->overlap) {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_match_done, ctx->stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->ev_match_done, 0));
+        pose_stream = ctx->aux_stream;
+    }
+    TRY(stvo::launch_pose(pose_stream, a));
+    if (ctx->overlap) {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_pose_done, ctx->aux_stream));
+        ctx->pose_pending = true;
+    }
     return check_launch(ctx);
 }
 
@@ -353,7 +401,7 @@ int stvo_time_stage_dev(stvo_ctx* ctx, const stvo_track_batch_dev* b, const stvo
     for (int it = 0; it < iters; ++it) {
         if (stage == 0)
             stvo::launch_hamming_knn2(ctx->stream, b->B, b->max_pts, b->max_pts, b->prev_pdesc, b->n_prev_pts,
-                                      b->curr_pdesc, b->n_curr_pts, ctx->knn12, ctx->knn21, 1);
+                                      b->curr_pdesc, b->n_curr_pts, ctx->knn12, ctx->knn21, 1, ctx->overlap ? kOverlapLdsPad : 0);
         else
             stvo::launch_pose(ctx->stream, a);
     }

@@ -15,7 +15,7 @@ PKG_DIR = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file
 LIB_PATH = os.path.join(PKG_DIR, "libstvo_hip.so")
 
 EXPORTS = ["stvo_backend_name", "stvo_abi_version", "stvo_error_string", "stvo_ctx_last_error", "stvo_ctx_create",
-           "stvo_ctx_destroy", "stvo_ctx_set_stream", "stvo_ctx_synchronize", "stvo_match_nnr_mutual",
+           "stvo_ctx_destroy", "stvo_ctx_set_stream", "stvo_ctx_synchronize", "stvo_ctx_set_overlap", "stvo_match_nnr_mutual",
            "stvo_match_grid_points", "stvo_match_grid_lines", "stvo_normal_eq", "stvo_optimize_pose",
            "stvo_track_batched_dev", "stvo_match_nnr_mutual_batched_dev", "stvo_optimize_pose_batched_dev",
            "stvo_time_stage_dev", "stvo_valu_peak_probe"]
@@ -82,6 +82,7 @@ def load():
     L.stvo_ctx_destroy.argtypes = [C.c_void_p]
     L.stvo_ctx_set_stream.argtypes = [C.c_void_p, C.c_void_p]
     L.stvo_ctx_synchronize.argtypes = [C.c_void_p]
+    L.stvo_ctx_set_overlap.argtypes = [C.c_void_p, C.c_int]
     L.stvo_match_nnr_mutual.argtypes = [C.c_void_p, u8p, C.c_int, u8p, C.c_int, C.c_float, C.c_int, i32p,
                                         C.POINTER(C.c_int32)]
     L.stvo_match_grid_points.argtypes = [C.c_void_p, i32p, u8p, C.c_int, i32p, i32p, u8p, C.c_int,
@@ -136,6 +137,9 @@ class Context:
 
     def synchronize(self):
         self._chk(self.lib.stvo_ctx_synchronize(self.h))
+
+    def set_overlap(self, enable):
+        self._chk(self.lib.stvo_ctx_set_overlap(self.h, 1 if enable else 0))
 
     # ---- host-buffer seams ----
     def match(self, d1, d2, nnr, mutual=1):

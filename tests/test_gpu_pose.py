@@ -15,7 +15,7 @@ ROT_TOL, TRANS_TOL = 1e-4, 1e-3  # BASELINE.json north_star
 
 
 @pytest.mark.parametrize("npts,nl,robust", [(300, 0, 0), (300, 40, 0), (0, 60, 0), (250, 30, 1), (1500, 80, 0),
-                                             (2048, 448, 0), (2048, 448, 1), (1, 0, 0), (0, 1, 0)])
+                                             (2048, 512, 0), (2048, 512, 1), (1, 0, 0), (0, 1, 0)])
 def test_normal_eq_vs_oracle(hip, oracle, npts, nl, robust):
     rec = synth.make_matched_records(100 + npts + nl, n_pts=npts, n_lines=nl, octave_probs=[.5, .25, .15, .1])
     prm = opt_params("kitti")
@@ -50,7 +50,7 @@ def check_pose(out, ref):
 @pytest.mark.parametrize("seed,npts,nl,mode,preset", [(31, 1200, 0, 0, "kitti"), (32, 1000, 60, 0, "kitti"),
                                                       (33, 600, 200, 0, "euroc"), (34, 600, 200, 2, "euroc"),
                                                       (35, 600, 200, 1, "euroc"), (36, 60, 5, 0, "kitti"),
-                                                      (37, 2048, 448, 0, "kitti"), (38, 1400, 0, 0, "kitti"),
+                                                      (37, 2048, 512, 0, "kitti"), (38, 1400, 0, 0, "kitti"),
                                                       (39, 0, 300, 0, "euroc"), (40, 800, 300, 2, "kitti")])
 def test_optimize_pose_vs_oracle(hip, oracle, seed, npts, nl, mode, preset):
     rec = synth.make_matched_records(seed, n_pts=npts, n_lines=nl,

@@ -51,3 +51,32 @@ def test_track_batched_points_config2(hip, oracle):
         Tt = np.linalg.inv(fr["T_true"])
         assert np_model.rot_angle(T[:3, :3], Tt[:3, :3]) < 3e-3 and np.linalg.norm(T[:3, 3] - Tt[:3, 3]) < 0.05
     hip.set_stream(None)
+
+
+def test_overlap_mode_gives_identical_results(oracle):
+    """stvo_ctx_set_overlap: pose kernel on the context's second stream, concurrent with the next call's
+    matching kernels.  Back-to-back calls on two different batches must reproduce the in-order results."""
+    import torch
+    from stvo_amd import capi
+    from stvo_amd.devbatch import TrackBatch
+    prm = opt_params("kitti", has_lines=0)
+    fa = [synth.make_f2f_points(synth.frame_seed(3, k), n=900) for k in range(40)]
+    fb = [synth.make_f2f_points(synth.frame_seed(4, k), n=1100) for k in range(40)]
+    out = {}
+    for overlap in (0, 1):
+        ctx = capi.Context(device_id=0, max_rows=2048, max_batch=64)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ctx.set_overlap(overlap)
+        ba, bb = TrackBatch(fa, max_pts=2048), TrackBatch(fb, max_pts=2048)
+        for _ in range(3):  # a, b, a, b, ... : every hazard class (same buffers two calls apart, scratch reuse)
+            ctx.track_batched(ba, CAM, prm, 0.75, 0.75, 1)
+            ctx.track_batched(bb, CAM, prm, 0.75, 0.75, 1)
+            ctx.track_batched(bb, CAM, prm, 0.75, 0.75, 1)
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        out[overlap] = (ba.results().copy(), bb.results().copy(), ba.m12_pts().copy(), bb.m12_pts().copy(),
+                        ba.inlier_pts().copy(), bb.inlier_pts().copy())
+        ctx.close()
+    for x, y in zip(out[0], out[1]):
+        assert x.tobytes() == y.tobytes()
+    assert (out[1][0]["status"] == 0).all() and (out[1][1]["status"] == 0).all()
