@@ -144,6 +144,8 @@ def main():
                        "pose_overlaps_next_match": not args.no_overlap},
             "roofline": {"kernel": "hamming_knn2_kernel", "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "traffic_profile": "separate rocprofv3 --pmc passes, profiles/r01_b_hbm_counters.txt: FETCH_SIZE 69.9 MB + "
+                                            "WRITE_SIZE 16.0 MB per launch = 1.05x the algorithmic bytes",
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k1_ms,
                          "note": "K1 is integer-VALU bound (~600 lane-ops per compulsory byte); see valu_roofline"},
             "valu_roofline": {"kernel": "hamming_knn2_kernel", "lane_ops_per_launch": lane_ops,

@@ -96,9 +96,22 @@ __global__ __launch_bounds__(KNN_BLOCK) void hamming_knn2_kernel(int B, int tile
     const uint4 q1 = reinterpret_cast<const uint4*>(Q)[2 * qi + 1];
 
     uint32_t best = 0xFFFFFFFFu, second = 0xFFFFFFFFu;
+    uint32_t second_d = 0xFFFFu;  // == second >> 16, refreshed only when the top-2 changes
     int j = 0;
     // 4 train rows (128 B = two s_load_dwordx16) per trip: 4 independent popcount chains give the
     // VALU ILP, 8 waves/SIMD hide the scalar-cache latency of the next trip's loads.
+    // Top-2 bookkeeping (3 half-rate VALU ops) is skipped wave-uniformly when no lane can change:
+    // key > second for every lane  <=>  d >= second_d for every lane (train indices only grow, so an
+    // equal distance can never displace the current second).  After the first few hundred rows most
+    // rows take the skip: one v_cmp + s_cbranch instead of lshl_or + med3 + min.
+    auto update = [&](uint32_t d, uint32_t jj) {
+        if (__builtin_amdgcn_ballot_w64(d < second_d) != 0ull) {
+            const uint32_t key = pack_key(d, jj);
+            second = med3_u32(best, second, key);
+            best = best < key ? best : key;
+            second_d = second >> 16;
+        }
+    };
     for (; j + 4 <= nt; j += 4) {
         uint32_t t[32];
 #pragma unroll
@@ -107,18 +120,9 @@ __global__ __launch_bounds__(KNN_BLOCK) void hamming_knn2_kernel(int B, int tile
 #pragma unroll
         for (int u = 0; u < 4; ++u) d[u] = hamming256(q0, q1, t + 8 * u);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint32_t key = pack_key(d[u], (uint32_t)(j + u));
-            second = med3_u32(best, second, key);
-            best = best < key ? best : key;
-        }
+        for (int u = 0; u < 4; ++u) update(d[u], (uint32_t)(j + u));
     }
-    for (; j < nt; ++j) {
-        const uint32_t d = hamming256(q0, q1, T + 8 * j);
-        const uint32_t key = pack_key(d, (uint32_t)j);
-        second = med3_u32(best, second, key);
-        best = best < key ? best : key;
-    }
+    for (; j < nt; ++j) update(hamming256(q0, q1, T + 8 * j), (uint32_t)j);
     if (q < nq) out[q] = make_uint2(best, second);
 }
 
