@@ -319,3 +319,31 @@ RESULT_DTYPE = np.dtype([("ints", "<i4", (12,)), ("DT", "<f8", (16,)), ("DT_cov"
 
 def read_results(path):
     return np.fromfile(path, dtype=RESULT_DTYPE)
+
+
+def make_f2f_points_lines(seed, n=2000, n_lines=100, cam=KITTI_CAM, track_frac=0.75, **kw):
+    """BASELINE config 3/4 shape for the f2f + optimizePose stage: the point sets of make_f2f_points plus
+    prev/curr stereo-line sets (prev: 3-D end points, left-image end points, LBD rows; curr: line equations
+    of the re-observed segments, LBD rows, permuted, padded with unrelated lines)."""
+    fr = make_f2f_points(seed, n=n, cam=cam, track_frac=track_frac, **kw)
+    rng = np.random.default_rng(seed + 7919)
+    T = fr["T_true"]
+    sp, ep, sd, ed = make_line_set(rng, n_lines, cam)
+    sP = back_project(cam, sp[:, 0], sp[:, 1], sd); eP = back_project(cam, ep[:, 0], ep[:, 1], ed)
+    prev_ldesc = random_desc(rng, n_lines)
+    n_tr = int(round(track_frac * n_lines))
+    tracked = rng.permutation(n_lines)[:n_tr]
+    so = project(cam, sP[tracked] @ T[:3, :3].T + T[:3, 3]) + rng.normal(0, 0.5, (n_tr, 2))
+    eo = project(cam, eP[tracked] @ T[:3, :3].T + T[:3, 3]) + rng.normal(0, 0.5, (n_tr, 2))
+    n_out = int(round(0.15 * n_tr))
+    sel = rng.permutation(n_tr)[:n_out]
+    so[sel] += rng.uniform(-60, 60, (n_out, 2)); eo[sel] += rng.uniform(-60, 60, (n_out, 2))
+    n_new = n_lines - n_tr
+    nsp, nep, _, _ = make_line_set(rng, max(n_new, 1), cam)
+    curr_le = np.concatenate([line_eq(so, eo), line_eq(nsp[:n_new], nep[:n_new])])
+    curr_ldesc = np.concatenate([flip_bits(rng, prev_ldesc[tracked], 0.08), random_desc(rng, n_new)])
+    perm = rng.permutation(n_lines)
+    fr.update(prev_ldesc=prev_ldesc, prev_sP=np.ascontiguousarray(sP), prev_eP=np.ascontiguousarray(eP),
+              prev_spl=np.ascontiguousarray(sp), prev_epl=np.ascontiguousarray(ep), prev_sigma2l=np.ones(n_lines),
+              curr_le=np.ascontiguousarray(curr_le[perm]), curr_ldesc=np.ascontiguousarray(curr_ldesc[perm]))
+    return fr

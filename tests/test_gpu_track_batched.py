@@ -80,3 +80,49 @@ def test_overlap_mode_gives_identical_results(oracle):
     for x, y in zip(out[0], out[1]):
         assert x.tobytes() == y.tobytes()
     assert (out[1][0]["status"] == 0).all() and (out[1][1]["status"] == 0).all()
+
+
+def oracle_track_pl(oracle, fr, prm, nnr_p, nnr_l):
+    m12, _ = oracle.match(fr["prev_desc"], fr["curr_desc"], nnr_p)
+    sel = np.nonzero(m12 >= 0)[0]
+    m12l, _ = oracle.match(fr["prev_ldesc"], fr["curr_ldesc"], nnr_l)
+    sl = np.nonzero(m12l >= 0)[0]
+    rec = dict(P=fr["prev_P"][sel], pl_obs=fr["curr_pl"][m12[sel]], sigma2p=fr["prev_sigma2"][sel],
+               inlier_p=np.ones(len(sel), np.int32), sP=fr["prev_sP"][sl], eP=fr["prev_eP"][sl],
+               le_obs=fr["curr_le"][m12l[sl]], spl=fr["prev_spl"][sl], epl=fr["prev_epl"][sl],
+               sigma2l=fr["prev_sigma2l"][sl], inlier_l=np.ones(len(sl), np.int32))
+    return m12, sel, m12l, sl, oracle.optimize_pose(np.eye(4), CAM, prm, rec)
+
+
+@pytest.mark.parametrize("preset,mode,nl,nnr", [("kitti", 0, 100, 0.75), ("euroc", 2, 300, 0.9), ("euroc", 1, 300, 0.9)])
+def test_track_batched_points_and_lines(hip, oracle, preset, mode, nl, nnr):
+    """BASELINE configs[2] / [3] shapes through the batched device path: f2f match of points AND lines,
+    on-device gather of both record kinds, GN / LM / robust GN pose."""
+    import torch
+    from stvo_amd.devbatch import TrackBatch
+    B = 6
+    npts = 2000 if preset == "kitti" else 800
+    frames = [synth.make_f2f_points_lines(synth.frame_seed(2, k), n=npts - 13 * k, n_lines=nl - 3 * k,
+                                          octave_probs=None if preset == "kitti" else [.5, .25, .15, .1],
+                                          outlier_frac=0.15 if preset == "kitti" else 0.4) for k in range(B)]
+    batch = TrackBatch(frames, max_pts=2048, max_lines=320)
+    prm = opt_params(preset, mode=mode)
+    hip.set_stream(torch.cuda.current_stream().cuda_stream)
+    hip.track_batched(batch, CAM, prm, nnr, nnr, 1)
+    torch.cuda.synchronize()
+    res = batch.results(); mp_all = batch.m12_pts(); ml_all = batch.m12_lines(); ip_all = batch.inlier_pts(); il_all = batch.inlier_lines()
+    for b, fr in enumerate(frames):
+        m12, sel, m12l, sl, ref = oracle_track_pl(oracle, fr, prm, nnr, nnr)
+        n1, n1l = len(fr["prev_P"]), len(fr["prev_sP"])
+        assert np.array_equal(mp_all[b, :n1], m12) and np.array_equal(ml_all[b, :n1l], m12l)
+        assert res["status"][b] == ref["status"] and res["path"][b] == ref["path"] and tuple(res["iters"][b]) == ref["iters"]
+        assert res["n_matched_pt"][b] == len(sel) and res["n_matched_ls"][b] == len(sl)
+        assert res["n_inliers_pt"][b] == ref["n_inliers_pt"] and res["n_inliers_ls"][b] == ref["n_inliers_ls"]
+        e = -np.ones(n1, np.int32); e[sel] = ref["inlier_p"]
+        assert np.array_equal(ip_all[b, :n1], e)
+        e = -np.ones(n1l, np.int32); e[sl] = ref["inlier_l"]
+        assert np.array_equal(il_all[b, :n1l], e)
+        T = res["T"][b].reshape(4, 4)
+        assert np_model.rot_angle(T[:3, :3], ref["T"][:3, :3]) < 1e-4 and np.linalg.norm(T[:3, 3] - ref["T"][:3, 3]) < 1e-3
+        assert np.allclose(T, ref["T"], atol=1e-8) and np.isclose(res["err"][b], ref["err"], rtol=1e-8)
+    hip.set_stream(None)
