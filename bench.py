@@ -124,12 +124,17 @@ def main():
 
     out = None
     if rank == 0:
+        # K1 is launched twice per matching stage: forward scan of all prev rows, then the lazy reverse scan of
+        # the curr rows that are some prev row's accepted forward match.  Figures below are per launch (average
+        # of the two), which is also what rocprofv3's per-kernel average reports.
         k1_ms = ctx.time_stage(batch, synth.KITTI_CAM, prm, 0.75, 0, 10)
         pose_ms = ctx.time_stage(batch, synth.KITTI_CAM, prm, 0.75, 1, 10)
-        alg_bytes = batch.algorithmic_bytes_match()
-        pairs = batch.pairs_match()
+        n1v = batch.host["n_prev_pts"].astype(np.int64); n2v = batch.host["n_curr_pts"].astype(np.int64)
+        nsel = ctx.last_reverse_counts(B).astype(np.int64)
+        alg_bytes = int((32 * (n1v + n2v) + 8 * n1v).sum() + (32 * (nsel + n1v) + 4 * nsel + 8 * nsel).sum()) / 2.0
+        pairs = int((n1v * n2v).sum() + (nsel * n1v).sum()) / 2.0   # distance evaluations per launch
         achieved_gbs = alg_bytes / (k1_ms * 1e-3) / 1e9
-        lane_ops = 2.0 * pairs * K1_LANE_OPS_PER_PAIR  # both directions are scanned
+        lane_ops = pairs * K1_LANE_OPS_PER_PAIR
         valu_meas = ctx.valu_peak()
         out = {
             "metric": "stereo frames/s (match+optimizePose)", "value": frames_total / dt, "unit": "frame-pairs/s",
@@ -147,13 +152,15 @@ def main():
                          "traffic_profile": "separate rocprofv3 --pmc passes, profiles/r01_b_hbm_counters.txt: FETCH_SIZE 69.9 MB + "
                                             "WRITE_SIZE 16.0 MB per launch = 1.05x the algorithmic bytes",
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k1_ms,
-                         "note": "K1 is integer-VALU bound (~600 lane-ops per compulsory byte); see valu_roofline"},
+                         "note": "K1 is integer-VALU bound (~1000 lane-ops per compulsory byte); see valu_roofline. Two launches "
+                                 "per step (forward + lazy reverse); figures are per launch"},
             "valu_roofline": {"kernel": "hamming_knn2_kernel", "lane_ops_per_launch": lane_ops,
                               "achieved": lane_ops / (k1_ms * 1e-3) / 1e12, "peak": VALU_PEAK_LANE_OPS / 1e12,
                               "unit": "T lane-ops/s", "frac": lane_ops / (k1_ms * 1e-3) / VALU_PEAK_LANE_OPS,
                               "measured_peak_same_mix": valu_meas / 1e12,
                               "frac_of_measured_peak": lane_ops / (k1_ms * 1e-3) / valu_meas},
-            "stage_ms": {"hamming_knn2": k1_ms, "pose": pose_ms},
+            "stage_ms": {"hamming_knn2_per_launch": k1_ms, "hamming_knn2_launches_per_step": 2, "pose": pose_ms,
+                         "reverse_scan_fraction": float(nsel.sum()) / float(n2v.sum())},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames, prm)

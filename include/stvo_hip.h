@@ -144,9 +144,14 @@ int stvo_optimize_pose_batched_dev(stvo_ctx* ctx, const stvo_track_batch_dev* ba
 /* ---- measurement helpers --------------------------------------------------------------------- */
 /* Times `iters` launches of the named kernel stage on the context's stream with hipEvents and
  * returns the average milliseconds per launch (used by bench.py for the roofline line).
- * stage: 0 = hamming_knn2 (K1) on the batch's point descriptors, 1 = pose kernel. */
+ * stage: 0 = hamming_knn2 (K1): average over its two launches per matching stage (forward scan + lazy
+ * reverse scan with the column selection of the last stvo_track_batched_dev call), 1 = pose kernel. */
 int stvo_time_stage_dev(stvo_ctx* ctx, const stvo_track_batch_dev* batch, const stvo_cam* cam,
                         const stvo_opt_params* params, float nnr, int stage, int iters, float* avg_ms);
+
+/* Number of right-hand (curr) rows whose reverse scan the LAST batched mutual match actually ran, per frame
+ * pair (the lazy reverse pass only scans columns that are some row's accepted forward match). */
+int stvo_last_reverse_counts(stvo_ctx* ctx, int B, int32_t* counts);
 
 /* Integer-VALU micro-benchmark (xor + popcount-accumulate chains, no memory traffic): measured
  * 32-bit lane-ops/s of this device, the empirical roof K1 is priced against. */

@@ -15,6 +15,7 @@ struct stvo_ctx {
     // persistent scratch for the batched path
     uint2* knn12 = nullptr;
     uint2* knn21 = nullptr;
+    int32_t *cand = nullptr, *need = nullptr, *qsel = nullptr, *nsel = nullptr;  // lazy reverse pass
     // bump arena for the host-buffer entry points
     char* arena = nullptr;
     size_t arena_size = 0, arena_off = 0;

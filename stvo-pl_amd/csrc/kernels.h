@@ -8,11 +8,27 @@
 
 namespace stvo {
 
+constexpr int KNN_NSEG = 2;  // train-range segments per query tile in K1 (partial top-2 per segment)
+
 // ---- K1 / K2: brute-force Hamming 2-NN, ratio test, mutual check ----------------------------
-// knn: [B][row_stride] packed (best_key, second_key), key = (distance << 16) | train_index.
+// knn: [KNN_NSEG][B][row_stride] packed (best_key, second_key) per train segment,
+// key = (distance << 16) | train_index; consumers merge the segments.
 void launch_hamming_knn2(hipStream_t s, int B, int row_stride, int max_n, const uint8_t* d1, const int32_t* n1,
                          const uint8_t* d2, const int32_t* n2, uint2* knn12, uint2* knn21, int both_directions,
-                         int lds_pad_bytes = 0);
+                         int lds_pad_bytes = 0, int dir0 = 0, const int32_t* qsel = nullptr,
+                         const int32_t* nsel = nullptr);
+// mutual matching with a lazy reverse pass (only the columns that are an accepted forward match are scanned)
+struct LazyScratch {
+    uint2* knn12;
+    uint2* knn21;
+    int32_t* cand;  // [B][row_stride] forward ratio-tested best
+    int32_t* need;  // [B][row_stride] column flags
+    int32_t* qsel;  // [B][row_stride] compacted flagged columns
+    int32_t* nsel;  // [B]
+};
+void launch_match_mutual_lazy(hipStream_t s, int B, int row_stride, const uint8_t* d1, const int32_t* n1,
+                              const uint8_t* d2, const int32_t* n2, float nnr, const LazyScratch& w, int32_t* m12,
+                              int lds_pad_bytes, hipEvent_t wait_before_m12_write);
 void launch_nnr_mutual(hipStream_t s, int B, int row_stride, const uint2* knn12, const uint2* knn21, const int32_t* n1,
                        const int32_t* n2, float nnr, int mutual, int32_t* m12);
 void launch_valu_probe(hipStream_t s, int blocks, int iters, uint32_t* sink);

@@ -61,43 +61,72 @@ __device__ __forceinline__ uint32_t hamming256(const uint4& q0, const uint4& q1,
 
 constexpr int KNN_BLOCK = 256;
 
-__global__ __launch_bounds__(KNN_BLOCK) void hamming_knn2_kernel(int B, int tiles, int ndir, int row_stride,
+// merged top-2 of the KNN_NSEG per-segment partial results of one query row
+__device__ __forceinline__ uint2 merged_knn(const uint2* __restrict__ knn, size_t seg_stride, size_t idx) {
+    uint2 r = knn[idx];
+#pragma unroll
+    for (int sgm = 1; sgm < KNN_NSEG; ++sgm) {
+        const uint2 o = knn[(size_t)sgm * seg_stride + idx];
+        const uint32_t hi = r.x > o.x ? r.x : o.x;
+        uint32_t sec = r.y < o.y ? r.y : o.y;
+        sec = sec < hi ? sec : hi;
+        r.x = r.x < o.x ? r.x : o.x;
+        r.y = sec;
+    }
+    return r;
+}
+
+// qsel / nsel (optional): scan only the listed query rows of this direction (lazy reverse pass: the
+// columns that are some row's accepted forward match); qsel = nullptr scans every row.
+// nseg: the train range of every query tile is split into nseg segments scanned by different workgroups
+// (partial top-2 per segment, merged by the consumers).  One wave then works for ~N/nseg rows instead of N,
+// which keeps the dispatch rounds short: with 2000 rows a whole-range wave lasts ~0.5 ms and any grid that
+// is not a multiple of the 8192 resident waves wastes up to one such round.
+__global__ __launch_bounds__(KNN_BLOCK) void hamming_knn2_kernel(int B, int tiles, int ndir, int dir0, int nseg, int row_stride,
                                                                  const uint8_t* __restrict__ d1,
                                                                  const int32_t* __restrict__ n1,
                                                                  const uint8_t* __restrict__ d2,
                                                                  const int32_t* __restrict__ n2,
-                                                                 uint2* __restrict__ knn12, uint2* __restrict__ knn21) {
+                                                                 uint2* __restrict__ knn12, uint2* __restrict__ knn21,
+                                                                 const int32_t* __restrict__ qsel,
+                                                                 const int32_t* __restrict__ nsel) {
     // XCD-aware block -> (frame pair, direction, tile) mapping.  Workgroups are dispatched round-robin
     // over the 8 XCDs (workgroup L runs on XCD L % 8, each XCD has a private 4 MiB L2).  With the
     // natural (tile, dir, frame) order the 2*tiles workgroups of one frame pair land on all 8 XCDs
     // and every L2 fetches the pair's descriptors again (measured: FETCH_SIZE = 7.8x the compulsory
     // bytes).  Here all workgroups of a frame pair share one XCD: frame = (k / per_frame) * 8 + xcd.
-    const int per_frame = tiles * ndir;
+    const int per_frame = tiles * ndir * nseg;
     const int L = blockIdx.x;
     const int xcd = L & 7, k = L >> 3;
     const int b = (k / per_frame) * 8 + xcd;
     if (b >= B) return;
     const int local = k % per_frame;
-    const int dir = local / tiles;
-    const int tile = local % tiles;
+    const int seg = local % nseg;
+    const int dir = dir0 + (local / nseg) / tiles;
+    const int tile = (local / nseg) % tiles;
     const int na = n1[b], nb = n2[b];
-    const int nq = dir == 0 ? na : nb;
-    const int nt = dir == 0 ? nb : na;
+    const int nq = qsel ? nsel[b] : (dir == 0 ? na : nb);
+    const int nt_all = dir == 0 ? nb : na;
+    // this workgroup's train rows [j0, nt): equal segments rounded up to the 4-row trip
+    const int seg_len = (((nt_all + nseg - 1) / nseg) + 3) & ~3;
+    const int j0 = min(seg * seg_len, nt_all);
+    const int nt = min(j0 + seg_len, nt_all);
     const int q_base = tile * KNN_BLOCK;
-    if (q_base >= nq) return;  // block-uniform
+    if (q_base + (int)(threadIdx.x & ~63u) >= nq) return;  // wave-uniform: no barriers in this kernel
     const size_t frame_off = (size_t)b * row_stride;
     const uint8_t* Q = (dir == 0 ? d1 : d2) + frame_off * STVO_DESC_BYTES;
     const uint32_t* __restrict__ T = reinterpret_cast<const uint32_t*>((dir == 0 ? d2 : d1) + frame_off * STVO_DESC_BYTES);
-    uint2* __restrict__ out = (dir == 0 ? knn12 : knn21) + frame_off;
+    uint2* __restrict__ out = (dir == 0 ? knn12 : knn21) + (size_t)seg * B * row_stride + frame_off;
 
     const int q = q_base + threadIdx.x;
-    const int qi = q < nq ? q : nq - 1;  // tail lanes scan a valid row and discard the result
+    const int qc = q < nq ? q : nq - 1;  // tail lanes scan a valid row and discard the result
+    const int qi = qsel ? qsel[frame_off + qc] : qc;
     const uint4 q0 = reinterpret_cast<const uint4*>(Q)[2 * qi];
     const uint4 q1 = reinterpret_cast<const uint4*>(Q)[2 * qi + 1];
 
     uint32_t best = 0xFFFFFFFFu, second = 0xFFFFFFFFu;
     uint32_t second_d = 0xFFFFu;  // == second >> 16, refreshed only when the top-2 changes
-    int j = 0;
+    int j = j0;
     // 4 train rows (128 B = two s_load_dwordx16) per trip: 4 independent popcount chains give the
     // VALU ILP, 8 waves/SIMD hide the scalar-cache latency of the next trip's loads.
     // Top-2 bookkeeping (3 half-rate VALU ops) is skipped wave-uniformly when no lane can change:
@@ -123,20 +152,20 @@ __global__ __launch_bounds__(KNN_BLOCK) void hamming_knn2_kernel(int B, int tile
         for (int u = 0; u < 4; ++u) update(d[u], (uint32_t)(j + u));
     }
     for (; j < nt; ++j) update(hamming256(q0, q1, T + 8 * j), (uint32_t)j);
-    if (q < nq) out[q] = make_uint2(best, second);
+    if (q < nq) out[qi] = make_uint2(best, second);
 }
 
 void launch_hamming_knn2(hipStream_t s, int B, int row_stride, int max_n, const uint8_t* d1, const int32_t* n1,
                          const uint8_t* d2, const int32_t* n2, uint2* knn12, uint2* knn21, int both_directions,
-                         int lds_pad_bytes) {
+                         int lds_pad_bytes, int dir0, const int32_t* qsel, const int32_t* nsel) {
     if (B <= 0 || max_n <= 0) return;
     const int tiles = (max_n + KNN_BLOCK - 1) / KNN_BLOCK, ndir = both_directions ? 2 : 1;
     const int groups = (B + 7) / 8;  // frame pairs are dealt to the 8 XCDs in groups of 8
-    dim3 grid((unsigned)(groups * 8 * tiles * ndir));
+    dim3 grid((unsigned)(groups * 8 * tiles * ndir * KNN_NSEG));
     // lds_pad_bytes > 0 only caps the number of resident workgroups per CU (the kernel uses no LDS), leaving
     // wave slots and VGPRs for a concurrently running pose kernel (stvo_ctx_set_overlap)
-    hipLaunchKernelGGL(hamming_knn2_kernel, grid, dim3(KNN_BLOCK), (size_t)lds_pad_bytes, s, B, tiles, ndir, row_stride, d1, n1, d2, n2,
-                       knn12, knn21);
+    hipLaunchKernelGGL(hamming_knn2_kernel, grid, dim3(KNN_BLOCK), (size_t)lds_pad_bytes, s, B, tiles, ndir, dir0,
+                       KNN_NSEG, row_stride, d1, n1, d2, n2, knn12, knn21, qsel, nsel);
 }
 
 // K2: m12[i] = j  iff  float(d0) < float(d1) * nnr  (12 direction)  and, when `mutual`, the 21
@@ -153,13 +182,13 @@ __global__ __launch_bounds__(256) void nnr_mutual_kernel(int row_stride, const u
     const size_t off = (size_t)b * row_stride;
     int m = -1;
     if (i < na && nb >= 2) {
-        const uint2 k = knn12[off + i];
+        const uint2 k = merged_knn(knn12, (size_t)gridDim.y * row_stride, off + i);
         const float f0 = (float)(k.x >> 16), f1 = (float)(k.y >> 16);
         if (f0 < f1 * nnr) m = (int)(k.x & 0xFFFFu);
         if (mutual && m >= 0) {
             bool keep = false;
             if (na >= 2) {
-                const uint2 r = knn21[off + m];
+                const uint2 r = merged_knn(knn21, (size_t)gridDim.y * row_stride, off + m);
                 const float r0 = (float)(r.x >> 16), r1 = (float)(r.y >> 16);
                 keep = (r0 < r1 * nnr) && ((int)(r.x & 0xFFFFu) == i);
             }
@@ -174,6 +203,99 @@ void launch_nnr_mutual(hipStream_t s, int B, int row_stride, const uint2* knn12,
     if (B <= 0 || row_stride <= 0) return;
     dim3 grid((row_stride + 255) / 256, B);
     hipLaunchKernelGGL(nnr_mutual_kernel, grid, dim3(256), 0, s, row_stride, knn12, knn21, n1, n2, nnr, mutual, m12);
+}
+
+// ---- lazy mutual matching -----------------------------------------------------------------------
+// StVO::match needs matches_21[j] only for columns j that are some row's accepted forward match
+// (src/matching.cpp:80-86 reads matches_21[matches_12[i1]] and nothing else).  So: forward scan of all
+// rows, forward ratio test, compaction of the distinct accepted columns, reverse scan of THOSE columns
+// only, reverse ratio test + index check.  Identical result, ~N2 - #accepted fewer reverse scans.
+__global__ __launch_bounds__(256) void nnr_forward_kernel(int row_stride, const uint2* __restrict__ knn12,
+                                                          const int32_t* __restrict__ n1, const int32_t* __restrict__ n2,
+                                                          float nnr, int32_t* __restrict__ cand,
+                                                          int32_t* __restrict__ need /* zeroed */) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= row_stride) return;
+    const int na = n1[b], nb = n2[b];
+    const size_t off = (size_t)b * row_stride;
+    int m = -1;
+    if (i < na && nb >= 2) {
+        const uint2 k = merged_knn(knn12, (size_t)gridDim.y * row_stride, off + i);
+        const float f0 = (float)(k.x >> 16), f1 = (float)(k.y >> 16);
+        if (f0 < f1 * nnr) m = (int)(k.x & 0xFFFFu);
+    }
+    cand[off + i] = m;
+    if (m >= 0) need[off + m] = 1;  // benign race: every writer stores 1
+}
+
+// one workgroup per frame pair: ascending list of the flagged columns + their count
+__global__ __launch_bounds__(256) void compact_need_kernel(int row_stride, const int32_t* __restrict__ need,
+                                                           const int32_t* __restrict__ n2, int32_t* __restrict__ qsel,
+                                                           int32_t* __restrict__ nsel) {
+    __shared__ int s_wave[4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const size_t off = (size_t)b * row_stride;
+    const int nb = n2[b];
+    const int per = (row_stride + 255) / 256;
+    const int lo = tid * per, hi = min(lo + per, nb);
+    int cnt = 0;
+    for (int j = lo; j < hi; ++j) cnt += need[off + j] != 0;
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) s_wave[wv] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        if (w < wv) base += s_wave[w];
+        tot += s_wave[w];
+    }
+    int pos = base + incl - cnt;
+    for (int j = lo; j < hi; ++j)
+        if (need[off + j] != 0) qsel[off + pos++] = j;
+    if (tid == 0) nsel[b] = tot;
+}
+
+__global__ __launch_bounds__(256) void nnr_reverse_check_kernel(int row_stride, const int32_t* __restrict__ cand,
+                                                                const uint2* __restrict__ knn21,
+                                                                const int32_t* __restrict__ n1, float nnr,
+                                                                int32_t* __restrict__ m12) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= row_stride) return;
+    const size_t off = (size_t)b * row_stride;
+    int m = cand[off + i];
+    if (m >= 0) {
+        bool keep = false;
+        if (n1[b] >= 2) {
+            const uint2 r = merged_knn(knn21, (size_t)gridDim.y * row_stride, off + m);
+            const float r0 = (float)(r.x >> 16), r1 = (float)(r.y >> 16);
+            keep = (r0 < r1 * nnr) && ((int)(r.x & 0xFFFFu) == i);
+        }
+        if (!keep) m = -1;
+    }
+    m12[off + i] = m;
+}
+
+void launch_match_mutual_lazy(hipStream_t s, int B, int row_stride, const uint8_t* d1, const int32_t* n1,
+                              const uint8_t* d2, const int32_t* n2, float nnr, const LazyScratch& w, int32_t* m12,
+                              int lds_pad_bytes, hipEvent_t wait_before_m12_write) {
+    if (B <= 0 || row_stride <= 0) return;
+    const dim3 grid2((row_stride + 255) / 256, B);
+    (void)hipMemsetAsync(w.need, 0, (size_t)B * row_stride * sizeof(int32_t), s);
+    launch_hamming_knn2(s, B, row_stride, row_stride, d1, n1, d2, n2, w.knn12, w.knn21, 0, lds_pad_bytes, 0, nullptr,
+                        nullptr);
+    hipLaunchKernelGGL(nnr_forward_kernel, grid2, dim3(256), 0, s, row_stride, w.knn12, n1, n2, nnr, w.cand, w.need);
+    hipLaunchKernelGGL(compact_need_kernel, dim3(B), dim3(256), 0, s, row_stride, w.need, n2, w.qsel, w.nsel);
+    launch_hamming_knn2(s, B, row_stride, row_stride, d1, n1, d2, n2, w.knn12, w.knn21, 0, lds_pad_bytes, 1, w.qsel,
+                        w.nsel);
+    if (wait_before_m12_write) (void)hipStreamWaitEvent(s, wait_before_m12_write, 0);
+    hipLaunchKernelGGL(nnr_reverse_check_kernel, grid2, dim3(256), 0, s, row_stride, w.cand, w.knn21, n1, nnr, m12);
 }
 
 // Integer-VALU roof probe: the same instruction mix as K1's inner loop (xor, bcnt-accumulate,

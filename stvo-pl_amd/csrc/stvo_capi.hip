@@ -49,10 +49,15 @@ int stvo_ctx_create(int device_id, int max_rows, int max_batch, stvo_ctx** out) 
               hip_ok(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking), "hipStreamCreate");
     ctx->own_stream = ok;
     const size_t knn_elems = (size_t)max_rows * (size_t)max_batch;
+    const size_t knn_seg_elems = knn_elems * stvo::KNN_NSEG;
     // arena: descriptors + records + per-row scratch of one host-buffer call, with slack
     ctx->arena_size = (size_t)max_rows * 1024 + ((size_t)4 << 20);
-    ok = ok && hip_ok(ctx, hipMalloc((void**)&ctx->knn12, knn_elems * sizeof(uint2)), "hipMalloc knn12") &&
-         hip_ok(ctx, hipMalloc((void**)&ctx->knn21, knn_elems * sizeof(uint2)), "hipMalloc knn21") &&
+    ok = ok && hip_ok(ctx, hipMalloc((void**)&ctx->knn12, knn_seg_elems * sizeof(uint2)), "hipMalloc knn12") &&
+         hip_ok(ctx, hipMalloc((void**)&ctx->knn21, knn_seg_elems * sizeof(uint2)), "hipMalloc knn21") &&
+         hip_ok(ctx, hipMalloc((void**)&ctx->cand, knn_elems * sizeof(int32_t)), "hipMalloc cand") &&
+         hip_ok(ctx, hipMalloc((void**)&ctx->need, knn_elems * sizeof(int32_t)), "hipMalloc need") &&
+         hip_ok(ctx, hipMalloc((void**)&ctx->qsel, knn_elems * sizeof(int32_t)), "hipMalloc qsel") &&
+         hip_ok(ctx, hipMalloc((void**)&ctx->nsel, (size_t)max_batch * sizeof(int32_t)), "hipMalloc nsel") &&
          hip_ok(ctx, hipMalloc((void**)&ctx->arena, ctx->arena_size), "hipMalloc arena") &&
          hip_ok(ctx, hipMalloc((void**)&ctx->probe_sink, 256), "hipMalloc sink");
     if (!ok) {
@@ -69,6 +74,10 @@ int stvo_ctx_destroy(stvo_ctx* ctx) {
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     if (ctx->knn12) hipFree(ctx->knn12);
     if (ctx->knn21) hipFree(ctx->knn21);
+    if (ctx->cand) hipFree(ctx->cand);
+    if (ctx->need) hipFree(ctx->need);
+    if (ctx->qsel) hipFree(ctx->qsel);
+    if (ctx->nsel) hipFree(ctx->nsel);
     if (ctx->arena) hipFree(ctx->arena);
     if (ctx->probe_sink) hipFree(ctx->probe_sink);
     if (ctx->aux_stream) {
@@ -134,8 +143,13 @@ int stvo_match_nnr_mutual(stvo_ctx* ctx, const uint8_t* d1, int n1, const uint8_
     TRY(upload(ctx, &dn1, &n1, 1));
     TRY(upload(ctx, &dn2, &n2, 1));
     TRY(upload(ctx, &dm12, (const int32_t*)nullptr, (size_t)stride));
-    stvo::launch_hamming_knn2(ctx->stream, 1, stride, stride, dd1, dn1, dd2, dn2, ctx->knn12, ctx->knn21, mutual ? 1 : 0);
-    stvo::launch_nnr_mutual(ctx->stream, 1, stride, ctx->knn12, ctx->knn21, dn1, dn2, nnr, mutual, dm12);
+    if (mutual) {
+        const stvo::LazyScratch w{ctx->knn12, ctx->knn21, ctx->cand, ctx->need, ctx->qsel, ctx->nsel};
+        stvo::launch_match_mutual_lazy(ctx->stream, 1, stride, dd1, dn1, dd2, dn2, nnr, w, dm12, 0, nullptr);
+    } else {
+        stvo::launch_hamming_knn2(ctx->stream, 1, stride, stride, dd1, dn1, dd2, dn2, ctx->knn12, ctx->knn21, 0);
+        stvo::launch_nnr_mutual(ctx->stream, 1, stride, ctx->knn12, ctx->knn21, dn1, dn2, nnr, 0, dm12);
+    }
     TRY(check_launch(ctx));
     HIP_TRY(ctx, hipMemcpyAsync(m12, dm12, (size_t)n1 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -154,9 +168,13 @@ int stvo_match_nnr_mutual_batched_dev(stvo_ctx* ctx, int B, int row_stride, cons
     if ((size_t)B * row_stride > (size_t)ctx->max_batch * ctx->max_rows || row_stride > STVO_MAX_ROWS_LIMIT)
         return STVO_ERR_CAPACITY;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    stvo::launch_hamming_knn2(ctx->stream, B, row_stride, row_stride, d1, n1, d2, n2, ctx->knn12, ctx->knn21,
-                              mutual ? 1 : 0);
-    stvo::launch_nnr_mutual(ctx->stream, B, row_stride, ctx->knn12, ctx->knn21, n1, n2, nnr, mutual, m12);
+    if (mutual) {
+        const stvo::LazyScratch w{ctx->knn12, ctx->knn21, ctx->cand, ctx->need, ctx->qsel, ctx->nsel};
+        stvo::launch_match_mutual_lazy(ctx->stream, B, row_stride, d1, n1, d2, n2, nnr, w, m12, 0, nullptr);
+    } else {
+        stvo::launch_hamming_knn2(ctx->stream, B, row_stride, row_stride, d1, n1, d2, n2, ctx->knn12, ctx->knn21, 0);
+        stvo::launch_nnr_mutual(ctx->stream, B, row_stride, ctx->knn12, ctx->knn21, n1, n2, nnr, 0, m12);
+    }
     return check_launch(ctx);
 }
 
@@ -331,31 +349,25 @@ int stvo_track_batched_dev(stvo_ctx* ctx, const stvo_track_batch_dev* b, const s
     // is still in flight on aux_stream.  K1 only writes the context's knn scratch (never read by the pose
     // kernel); K2 rewrites m12, which the previous pose kernel may still be reading => K2 waits for it.
     const int pad = ctx->overlap ? kOverlapLdsPad : 0;
-    bool waited = !(ctx->overlap && ctx->pose_pending);
-    auto wait_prev_pose = [&]() -> int {
-        if (!waited) {
-            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_pose_done, 0));
-            waited = true;
+    hipEvent_t prev_pose = (ctx->overlap && ctx->pose_pending) ? ctx->ev_pose_done : nullptr;
+    const stvo::LazyScratch w{ctx->knn12, ctx->knn21, ctx->cand, ctx->need, ctx->qsel, ctx->nsel};
+    auto match_set = [&](int stride, const uint8_t* da, const int32_t* na, const uint8_t* db, const int32_t* nb,
+                         float nnr, int32_t* m12) {
+        if (mutual) {
+            stvo::launch_match_mutual_lazy(ctx->stream, b->B, stride, da, na, db, nb, nnr, w, m12, pad, prev_pose);
+        } else {
+            stvo::launch_hamming_knn2(ctx->stream, b->B, stride, stride, da, na, db, nb, ctx->knn12, ctx->knn21, 0, pad);
+            if (prev_pose) (void)hipStreamWaitEvent(ctx->stream, prev_pose, 0);
+            stvo::launch_nnr_mutual(ctx->stream, b->B, stride, ctx->knn12, ctx->knn21, na, nb, nnr, 0, m12);
         }
-        return STVO_OK;
     };
     // matchF2FPoints (:131-153)
-    if (params->has_points) {
-        stvo::launch_hamming_knn2(ctx->stream, b->B, b->max_pts, b->max_pts, b->prev_pdesc, b->n_prev_pts,
-                                  b->curr_pdesc, b->n_curr_pts, ctx->knn12, ctx->knn21, mutual ? 1 : 0, pad);
-        TRY(wait_prev_pose());
-        stvo::launch_nnr_mutual(ctx->stream, b->B, b->max_pts, ctx->knn12, ctx->knn21, b->n_prev_pts, b->n_curr_pts,
-                                nnr_points, mutual, b->m12_pts);
-    }
+    if (params->has_points)
+        match_set(b->max_pts, b->prev_pdesc, b->n_prev_pts, b->curr_pdesc, b->n_curr_pts, nnr_points, b->m12_pts);
     // matchF2FLines (:155-180)
-    if (params->has_lines && b->max_lines > 0) {
-        stvo::launch_hamming_knn2(ctx->stream, b->B, b->max_lines, b->max_lines, b->prev_ldesc, b->n_prev_lines,
-                                  b->curr_ldesc, b->n_curr_lines, ctx->knn12, ctx->knn21, mutual ? 1 : 0, pad);
-        TRY(wait_prev_pose());
-        stvo::launch_nnr_mutual(ctx->stream, b->B, b->max_lines, ctx->knn12, ctx->knn21, b->n_prev_lines,
-                                b->n_curr_lines, nnr_lines, mutual, b->m12_lines);
-    }
-    TRY(wait_prev_pose());
+    if (params->has_lines && b->max_lines > 0)
+        match_set(b->max_lines, b->prev_ldesc, b->n_prev_lines, b->curr_ldesc, b->n_curr_lines, nnr_lines, b->m12_lines);
+    if (prev_pose) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, prev_pose, 0));  // also when nothing was matched
     stvo::PoseArgs a;
     fill_pose_args(b, cam, params, false, &a);
     // a feature kind that is switched off is never matched => matched_pt / matched_ls stay empty (:137,160)
@@ -399,10 +411,22 @@ int stvo_time_stage_dev(stvo_ctx* ctx, const stvo_track_batch_dev* b, const stvo
     (void)nnr;
     HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
     for (int it = 0; it < iters; ++it) {
-        if (stage == 0)
+        if (stage == 0) {
+            // the two hamming_knn2 launches of one matching stage: forward scan of every prev row, then the
+            // lazy reverse scan of the columns selected by the LAST stvo_track_batched_dev call (ctx->qsel)
+            const int pad = ctx->overlap ? kOverlapLdsPad : 0;
             stvo::launch_hamming_knn2(ctx->stream, b->B, b->max_pts, b->max_pts, b->prev_pdesc, b->n_prev_pts,
-                                      b->curr_pdesc, b->n_curr_pts, ctx->knn12, ctx->knn21, 1, ctx->overlap ? kOverlapLdsPad : 0);
-        else
+                                      b->curr_pdesc, b->n_curr_pts, ctx->knn12, ctx->knn21, 0, pad, 0, nullptr, nullptr);
+            stvo::launch_hamming_knn2(ctx->stream, b->B, b->max_pts, b->max_pts, b->prev_pdesc, b->n_prev_pts,
+                                      b->curr_pdesc, b->n_curr_pts, ctx->knn12, ctx->knn21, 0, pad, 1, ctx->qsel,
+                                      ctx->nsel);
+        } else if (stage >= 2) {  // developer probes: 2 forward only, 3 lazy reverse only, 4 both directions in full
+            const int pad = ctx->overlap ? kOverlapLdsPad : 0;
+            stvo::launch_hamming_knn2(ctx->stream, b->B, b->max_pts, b->max_pts, b->prev_pdesc, b->n_prev_pts,
+                                      b->curr_pdesc, b->n_curr_pts, ctx->knn12, ctx->knn21, stage == 4 ? 1 : 0, pad,
+                                      stage == 3 ? 1 : 0, stage == 3 ? ctx->qsel : nullptr,
+                                      stage == 3 ? ctx->nsel : nullptr);
+        } else
             stvo::launch_pose(ctx->stream, a);
     }
     HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
@@ -411,7 +435,7 @@ int stvo_time_stage_dev(stvo_ctx* ctx, const stvo_track_batch_dev* b, const stvo
     HIP_TRY(ctx, hipEventElapsedTime(&ms, e0, e1));
     hipEventDestroy(e0);
     hipEventDestroy(e1);
-    *avg_ms = ms / (float)iters;
+    *avg_ms = ms / (float)iters / (stage == 0 ? 2.0f : 1.0f);  // stage 0 = two launches of the same kernel
     if (stage == 1 && std::getenv("STVO_POSE_PROF")) {  // developer aid: per-phase ticks of the solver lane
         long long* dprof = nullptr;
         HIP_TRY(ctx, hipMalloc((void**)&dprof, (size_t)b->B * 8 * sizeof(long long)));
@@ -427,6 +451,14 @@ int stvo_time_stage_dev(stvo_ctx* ctx, const stvo_track_batch_dev* b, const stvo
         hipFree(dprof);
     }
     return check_launch(ctx);
+}
+
+int stvo_last_reverse_counts(stvo_ctx* ctx, int B, int32_t* counts) {
+    if (!ctx || !counts || B <= 0 || B > ctx->max_batch) return STVO_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(counts, ctx->nsel, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return STVO_OK;
 }
 
 int stvo_valu_peak_probe(stvo_ctx* ctx, double* lane_ops_per_s) {

@@ -18,7 +18,7 @@ EXPORTS = ["stvo_backend_name", "stvo_abi_version", "stvo_error_string", "stvo_c
            "stvo_ctx_destroy", "stvo_ctx_set_stream", "stvo_ctx_synchronize", "stvo_ctx_set_overlap", "stvo_match_nnr_mutual",
            "stvo_match_grid_points", "stvo_match_grid_lines", "stvo_normal_eq", "stvo_optimize_pose",
            "stvo_track_batched_dev", "stvo_match_nnr_mutual_batched_dev", "stvo_optimize_pose_batched_dev",
-           "stvo_time_stage_dev", "stvo_valu_peak_probe"]
+           "stvo_time_stage_dev", "stvo_valu_peak_probe", "stvo_last_reverse_counts"]
 
 u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
 i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
@@ -103,6 +103,7 @@ def load():
     L.stvo_time_stage_dev.argtypes = [C.c_void_p, C.POINTER(TrackBatchDev), C.POINTER(Cam), C.POINTER(OptParams),
                                       C.c_float, C.c_int, C.c_int, C.POINTER(C.c_float)]
     L.stvo_valu_peak_probe.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    L.stvo_last_reverse_counts.argtypes = [C.c_void_p, C.c_int, i32p]
     _lib = L
     return L
 
@@ -218,6 +219,11 @@ class Context:
         v = C.c_double()
         self._chk(self.lib.stvo_valu_peak_probe(self.h, C.byref(v)))
         return v.value
+
+    def last_reverse_counts(self, B):
+        out = np.empty(B, np.int32)
+        self._chk(self.lib.stvo_last_reverse_counts(self.h, B, out))
+        return out
 
     # ---- batched device-resident path ----
     def track_batched(self, batch, cam, params, nnr_p, nnr_l, mutual=1):
