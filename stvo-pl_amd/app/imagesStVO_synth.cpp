@@ -90,7 +90,7 @@ int main(int argc, char** argv) {
         return -2;
     }
     StVO->mode = mode;
-    double t_total = 0.0;
+    double t_total = 0.0, t_st = 0.0, t_ff = 0.0, t_po = 0.0;
     for (int frame_counter = 0; frame_counter < n_frames; ++frame_counter) {
         FrameFeatures feat;
         feat.img_cols = cols;
@@ -112,6 +112,9 @@ int main(int argc, char** argv) {
         const double t1 =
             std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
         t_total += t1;
+        t_st += StVO->t_stereo_ms;
+        t_ff += StVO->t_f2f_ms;
+        t_po += StVO->t_pose_ms;
 
         // console output (imagesStVO.cpp:114-121)
         std::printf("Frame: %d\tRes.: %.8f \t Proc. time: %.3f ms\t ", frame_counter, StVO->curr_frame->err_norm, t1);
@@ -139,8 +142,10 @@ int main(int argc, char** argv) {
         wr(out, &pad, 1);
     }
     if (n_frames > 1)
-        std::printf("[imagesStVO_synth] %d frame pairs, mean Proc. time %.3f ms (single stream, incl. H2D/D2H)\n",
-                    n_frames - 1, t_total / (n_frames - 1));
+        std::printf("[imagesStVO_synth] %d frame pairs, mean Proc. time %.3f ms (single stream, incl. H2D/D2H): stereo "
+                    "association %.3f, f2f matching %.3f, optimizePose %.3f\n",
+                    n_frames - 1, t_total / (n_frames - 1), t_st / (n_frames - 1), t_ff / (n_frames - 1),
+                    t_po / (n_frames - 1));
     delete StVO;
     delete cam_pin;
     return 0;

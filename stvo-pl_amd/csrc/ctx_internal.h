@@ -15,6 +15,7 @@ struct stvo_ctx {
     // persistent scratch for the batched path
     uint2* knn12 = nullptr;
     uint2* knn21 = nullptr;
+    size_t knn_capacity = 0;  // elements in each of knn12 / knn21
     int32_t *cand = nullptr, *need = nullptr, *qsel = nullptr, *nsel = nullptr;  // lazy reverse pass
     // bump arena for the host-buffer entry points
     char* arena = nullptr;

@@ -22,6 +22,8 @@
 //   C  `grid_finalize` lane = left feature: DOUBLE ratio test best_d < best_d2 * ratio with
 //                     best_d2 = INT_MAX when only one candidate was eligible (:160), mutual check
 //                     against owner (:166-174).
+#include <vector>
+
 #include "ctx_internal.h"
 
 namespace stvo {
@@ -41,14 +43,17 @@ struct GridArgs {
     stvo_grid_window w;
     double ratio, line_sim_th;
     int mutual;
-    int words64;                 // 64-bit words per cover row = ceil(n2 / 64)
-    unsigned long long* cover;   // [n1][words64]
+    int words64;                 // number of 64-lane waves of right features = ceil(n2 / 64)
+    int n1p;                     // n1 rounded up to the 8-mask scan chunk
+    unsigned long long* cover;   // [words64][n1p]: bit p%64 of cover[p/64][i1] <=> right feature perm[p] is a candidate of i1
+    const int32_t* rank;         // [n2] right feature id -> scan position p (spatial = CSR order)
+    const int32_t* perm;         // [n2] scan position p -> right feature id
     unsigned long long* top2;    // [n1] (second_key << 32) | best_key
     int32_t* owner2;             // [n2]
     int32_t* m12;                // [n1]
 };
 
-__device__ __forceinline__ void cover_window(const GridArgs& a, int x, int y, unsigned long long* row) {
+__device__ __forceinline__ void cover_window(const GridArgs& a, int x, int y, int i1) {
     // GridStructure::get clamping (src/gridStructure.cpp:67-71)
     const int min_x = max(0, x - a.w.w_lo), max_x = min(STVO_GRID_COLS, x + a.w.w_hi + 1);
     const int min_y = max(0, y - a.w.h_lo), max_y = min(STVO_GRID_ROWS, y + a.w.h_hi + 1);
@@ -58,7 +63,10 @@ __device__ __forceinline__ void cover_window(const GridArgs& a, int x, int y, un
         const int lo = a.cell_start[yy * STVO_GRID_COLS + min_x], hi = a.cell_start[yy * STVO_GRID_COLS + max_x];
         for (int k = lo; k < hi; ++k) {
             const int id = a.cell_items[k];
-            if (id >= 0 && id < a.n2) row[id >> 6] |= 1ull << (id & 63);  // :141 skips out-of-range ids
+            if (id >= 0 && id < a.n2) {  // :141 skips out-of-range ids
+                const int p = a.rank[id];
+                a.cover[(size_t)(p >> 6) * a.n1p + i1] |= 1ull << (p & 63);  // column i1 is owned by this thread
+            }
         }
     }
 }
@@ -67,14 +75,14 @@ template <bool LINES>
 __global__ __launch_bounds__(256) void grid_cover_kernel(GridArgs a) {
     const int i1 = blockIdx.x * 256 + threadIdx.x;
     if (i1 >= a.n1) return;
-    unsigned long long* row = a.cover + (size_t)i1 * a.words64;  // zeroed by the host (hipMemsetAsync)
+    // cover is zeroed by the host (hipMemsetAsync)
     if (LINES) {
         const int4 c = reinterpret_cast<const int4*>(a.cell_xy1)[i1];
-        cover_window(a, c.x, c.y, row);
-        cover_window(a, c.z, c.w, row);
+        cover_window(a, c.x, c.y, i1);
+        cover_window(a, c.z, c.w, i1);
     } else {
         const int2 c = reinterpret_cast<const int2*>(a.cell_xy1)[i1];
-        cover_window(a, c.x, c.y, row);
+        cover_window(a, c.x, c.y, i1);
     }
     a.top2[i1] = kTop2Empty;
 }
@@ -104,56 +112,67 @@ __device__ __forceinline__ void top2_insert(unsigned long long* slot, uint32_t k
 
 template <bool LINES>
 __global__ __launch_bounds__(256) void grid_scan_kernel(GridArgs a) {
-    const int i2 = blockIdx.x * 256 + threadIdx.x;
-    const int wave64 = i2 >> 6;  // wave-uniform: threadIdx.x / 64 is uniform within a wave
+    // lane = scan position p; positions follow the CSR (cell) order of the right features, so the 64
+    // features of a wave are spatial neighbours and only the few left features whose window touches
+    // that neighbourhood have a non-zero mask: the scan skips 8 left features per scalar load.
+    const int p = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    if ((i2 & ~63) >= a.n2) return;  // whole wave past the last right feature (wave-uniform)
-    const bool live = i2 < a.n2;
-    const int i2c = live ? i2 : a.n2 - 1;
-    const uint4 t0 = reinterpret_cast<const uint4*>(a.d2)[2 * i2c];
-    const uint4 t1 = reinterpret_cast<const uint4*>(a.d2)[2 * i2c + 1];
+    if ((p & ~63) >= a.n2) return;  // whole wave past the last right feature (wave-uniform)
+    const bool live = p < a.n2;
+    const int i2 = a.perm[live ? p : a.n2 - 1];
+    const uint4 t0 = reinterpret_cast<const uint4*>(a.d2)[2 * i2];
+    const uint4 t1 = reinterpret_cast<const uint4*>(a.d2)[2 * i2 + 1];
     double dirx = 0.0, diry = 0.0;
     if (LINES) {
-        dirx = a.dir2[2 * i2c];
-        diry = a.dir2[2 * i2c + 1];
+        dirx = a.dir2[2 * i2];
+        diry = a.dir2[2 * i2 + 1];
     }
     int run_min = 0x7FFFFFFF, owner = -1;
-    const int widx = __builtin_amdgcn_readfirstlane(wave64);
+    const int widx = __builtin_amdgcn_readfirstlane(p >> 6);
+    const unsigned long long* __restrict__ col = a.cover + (size_t)widx * a.n1p;  // wave-uniform row of masks
     const uint32_t* __restrict__ Q = reinterpret_cast<const uint32_t*>(a.d1);
-    for (int i1 = 0; i1 < a.n1; ++i1) {
-        const unsigned long long mask = a.cover[(size_t)i1 * a.words64 + widx];  // wave-uniform
-        if (mask == 0ull) continue;
-        bool on = live && ((mask >> lane) & 1ull);
-        if (LINES) {
-            // direction of the LEFT line from INTEGER cell differences; 0/0 = NaN never skips (:207-222)
-            const int4 c = reinterpret_cast<const int4*>(a.cell_xy1)[i1];
-            double vx = (double)(c.z - c.x), vy = (double)(c.w - c.y);
-            const double mag = sqrt(vx * vx + vy * vy);
-            vx /= mag;
-            vy /= mag;
-            const double dot = vx * dirx + vy * diry;
-            if (fabs(dot) < a.line_sim_th) on = false;
-        }
-        if (!__any(on)) continue;
-        const uint32_t* __restrict__ q = Q + 8 * (size_t)i1;  // wave-uniform row -> scalar loads
-        uint32_t d = __builtin_popcount(t0.x ^ q[0]);
-        d = bcnt_acc(t0.y ^ q[1], d);
-        d = bcnt_acc(t0.z ^ q[2], d);
-        d = bcnt_acc(t0.w ^ q[3], d);
-        d = bcnt_acc(t1.x ^ q[4], d);
-        d = bcnt_acc(t1.y ^ q[5], d);
-        d = bcnt_acc(t1.z ^ q[6], d);
-        d = bcnt_acc(t1.w ^ q[7], d);
-        if (on) {
-            bool eligible = true;
-            if (a.mutual) {  // bestLRMatches: running strict minimum per right feature (:145-150)
-                eligible = (int)d < run_min;
-                if (eligible) {
-                    run_min = (int)d;
-                    owner = i1;
-                }
+    for (int base = 0; base < a.n1p; base += 8) {
+        unsigned long long m[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) m[u] = col[base + u];  // one s_load_dwordx16
+        if ((m[0] | m[1] | m[2] | m[3] | m[4] | m[5] | m[6] | m[7]) == 0ull) continue;
+#pragma unroll 1
+        for (int u = 0; u < 8; ++u) {
+            const unsigned long long mask = m[u];
+            if (mask == 0ull) continue;
+            const int i1 = base + u;
+            bool on = live && ((mask >> lane) & 1ull);
+            if (LINES) {
+                // direction of the LEFT line from INTEGER cell differences; 0/0 = NaN never skips (:207-222)
+                const int4 c = reinterpret_cast<const int4*>(a.cell_xy1)[i1];
+                double vx = (double)(c.z - c.x), vy = (double)(c.w - c.y);
+                const double mag = sqrt(vx * vx + vy * vy);
+                vx /= mag;
+                vy /= mag;
+                const double dot = vx * dirx + vy * diry;
+                if (fabs(dot) < a.line_sim_th) on = false;
             }
-            if (eligible) top2_insert(a.top2 + i1, (d << 16) | (uint32_t)i2);
+            if (!__any(on)) continue;
+            const uint32_t* __restrict__ q = Q + 8 * (size_t)i1;  // wave-uniform row -> scalar loads
+            uint32_t d = __builtin_popcount(t0.x ^ q[0]);
+            d = bcnt_acc(t0.y ^ q[1], d);
+            d = bcnt_acc(t0.z ^ q[2], d);
+            d = bcnt_acc(t0.w ^ q[3], d);
+            d = bcnt_acc(t1.x ^ q[4], d);
+            d = bcnt_acc(t1.y ^ q[5], d);
+            d = bcnt_acc(t1.z ^ q[6], d);
+            d = bcnt_acc(t1.w ^ q[7], d);
+            if (on) {
+                bool eligible = true;
+                if (a.mutual) {  // bestLRMatches: running strict minimum per right feature (:145-150)
+                    eligible = (int)d < run_min;
+                    if (eligible) {
+                        run_min = (int)d;
+                        owner = i1;
+                    }
+                }
+                if (eligible) top2_insert(a.top2 + i1, (d << 16) | (uint32_t)i2);
+            }
         }
     }
     if (live) a.owner2[i2] = owner;
@@ -206,7 +225,29 @@ int run_grid(stvo_ctx* ctx, const int32_t* cell_xy1, const uint8_t* d1, int n1, 
     TRY(upload(ctx, &dd2, d2, (size_t)n2 * STVO_DESC_BYTES));
     if (LINES) TRY(upload(ctx, &ddir, dir2, (size_t)n2 * 2));
     a.words64 = (n2 + 63) / 64;
-    a.cover = arena_alloc<unsigned long long>(ctx, (size_t)n1 * a.words64);
+    a.n1p = (n1 + 7) & ~7;
+    // scan order of the right features = order of first appearance in the CSR grid (cell-major, i.e.
+    // spatial); features that are in no cell come last (they are nobody's candidate anyway)
+    std::vector<int32_t> rank((size_t)n2, -1), perm((size_t)n2);
+    int np_ = 0;
+    for (int k = 0; k < n_items; ++k) {
+        const int id = cell_items[k];
+        if (id >= 0 && id < n2 && rank[id] < 0) {
+            rank[id] = np_;
+            perm[np_++] = id;
+        }
+    }
+    for (int id = 0; id < n2; ++id)
+        if (rank[id] < 0) {
+            rank[id] = np_;
+            perm[np_++] = id;
+        }
+    int32_t *drank, *dperm;
+    TRY(upload(ctx, &drank, rank.data(), (size_t)n2));
+    TRY(upload(ctx, &dperm, perm.data(), (size_t)n2));
+    a.rank = drank;
+    a.perm = dperm;
+    a.cover = arena_alloc<unsigned long long>(ctx, (size_t)a.n1p * a.words64);
     a.top2 = arena_alloc<unsigned long long>(ctx, (size_t)n1);
     downer = arena_alloc<int32_t>(ctx, (size_t)n2);
     dm12 = arena_alloc<int32_t>(ctx, (size_t)n1);
@@ -225,7 +266,7 @@ int run_grid(stvo_ctx* ctx, const int32_t* cell_xy1, const uint8_t* d1, int n1, 
     a.mutual = mutual;
     a.owner2 = downer;
     a.m12 = dm12;
-    HIP_TRY(ctx, hipMemsetAsync(a.cover, 0, (size_t)n1 * a.words64 * sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(a.cover, 0, (size_t)a.n1p * a.words64 * sizeof(unsigned long long), ctx->stream));
     const dim3 g1((n1 + 255) / 256), g2((n2 + 255) / 256), blk(256);
     hipLaunchKernelGGL((grid_cover_kernel<LINES>), g1, blk, 0, ctx->stream, a);
     hipLaunchKernelGGL((grid_scan_kernel<LINES>), g2, blk, 0, ctx->stream, a);

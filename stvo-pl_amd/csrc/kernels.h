@@ -8,15 +8,26 @@
 
 namespace stvo {
 
-constexpr int KNN_NSEG = 2;  // train-range segments per query tile in K1 (partial top-2 per segment)
+constexpr int KNN_MIN_NSEG = 2, KNN_MAX_NSEG = 16;  // train-range segments per query tile in K1
+// Segments per query tile: 2 for big batches (short dispatch rounds), up to 16 for a single frame pair so
+// that one 2000 x 2000 problem still spreads over a few hundred workgroups (single-stream latency).
+// `capacity` = elements of the context's knn scratch arrays: nseg * B * max_n must fit.
+inline int knn_pick_nseg(int B, int max_n, size_t capacity) {
+    const int tiles = (max_n + 255) / 256;
+    int nseg = (2048 + B * tiles - 1) / (B * tiles > 0 ? B * tiles : 1);
+    nseg = nseg < KNN_MIN_NSEG ? KNN_MIN_NSEG : (nseg > KNN_MAX_NSEG ? KNN_MAX_NSEG : nseg);
+    const size_t per_seg = (size_t)(B > 0 ? B : 1) * (size_t)(max_n > 0 ? max_n : 1);
+    while (nseg > 1 && (size_t)nseg * per_seg > capacity) --nseg;
+    return nseg;
+}
 
 // ---- K1 / K2: brute-force Hamming 2-NN, ratio test, mutual check ----------------------------
-// knn: [KNN_NSEG][B][row_stride] packed (best_key, second_key) per train segment,
+// knn: [nseg][B][row_stride] packed (best_key, second_key) per train segment,
 // key = (distance << 16) | train_index; consumers merge the segments.
 void launch_hamming_knn2(hipStream_t s, int B, int row_stride, int max_n, const uint8_t* d1, const int32_t* n1,
                          const uint8_t* d2, const int32_t* n2, uint2* knn12, uint2* knn21, int both_directions,
                          int lds_pad_bytes = 0, int dir0 = 0, const int32_t* qsel = nullptr,
-                         const int32_t* nsel = nullptr);
+                         const int32_t* nsel = nullptr, int nseg = KNN_MIN_NSEG);
 // mutual matching with a lazy reverse pass (only the columns that are an accepted forward match are scanned)
 struct LazyScratch {
     uint2* knn12;
@@ -25,12 +36,13 @@ struct LazyScratch {
     int32_t* need;  // [B][row_stride] column flags
     int32_t* qsel;  // [B][row_stride] compacted flagged columns
     int32_t* nsel;  // [B]
+    size_t knn_capacity;  // elements of knn12 / knn21
 };
 void launch_match_mutual_lazy(hipStream_t s, int B, int row_stride, const uint8_t* d1, const int32_t* n1,
                               const uint8_t* d2, const int32_t* n2, float nnr, const LazyScratch& w, int32_t* m12,
                               int lds_pad_bytes, hipEvent_t wait_before_m12_write);
 void launch_nnr_mutual(hipStream_t s, int B, int row_stride, const uint2* knn12, const uint2* knn21, const int32_t* n1,
-                       const int32_t* n2, float nnr, int mutual, int32_t* m12);
+                       const int32_t* n2, float nnr, int mutual, int32_t* m12, int nseg = KNN_MIN_NSEG);
 void launch_valu_probe(hipStream_t s, int blocks, int iters, uint32_t* sink);
 extern const double kValuProbeOpsPerThreadIter;
 

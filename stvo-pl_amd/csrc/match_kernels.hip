@@ -61,11 +61,10 @@ __device__ __forceinline__ uint32_t hamming256(const uint4& q0, const uint4& q1,
 
 constexpr int KNN_BLOCK = 256;
 
-// merged top-2 of the KNN_NSEG per-segment partial results of one query row
-__device__ __forceinline__ uint2 merged_knn(const uint2* __restrict__ knn, size_t seg_stride, size_t idx) {
+// merged top-2 of the nseg per-segment partial results of one query row
+__device__ __forceinline__ uint2 merged_knn(const uint2* __restrict__ knn, size_t seg_stride, size_t idx, int nseg) {
     uint2 r = knn[idx];
-#pragma unroll
-    for (int sgm = 1; sgm < KNN_NSEG; ++sgm) {
+    for (int sgm = 1; sgm < nseg; ++sgm) {
         const uint2 o = knn[(size_t)sgm * seg_stride + idx];
         const uint32_t hi = r.x > o.x ? r.x : o.x;
         uint32_t sec = r.y < o.y ? r.y : o.y;
@@ -157,21 +156,21 @@ __global__ __launch_bounds__(KNN_BLOCK) void hamming_knn2_kernel(int B, int tile
 
 void launch_hamming_knn2(hipStream_t s, int B, int row_stride, int max_n, const uint8_t* d1, const int32_t* n1,
                          const uint8_t* d2, const int32_t* n2, uint2* knn12, uint2* knn21, int both_directions,
-                         int lds_pad_bytes, int dir0, const int32_t* qsel, const int32_t* nsel) {
+                         int lds_pad_bytes, int dir0, const int32_t* qsel, const int32_t* nsel, int nseg) {
     if (B <= 0 || max_n <= 0) return;
     const int tiles = (max_n + KNN_BLOCK - 1) / KNN_BLOCK, ndir = both_directions ? 2 : 1;
     const int groups = (B + 7) / 8;  // frame pairs are dealt to the 8 XCDs in groups of 8
-    dim3 grid((unsigned)(groups * 8 * tiles * ndir * KNN_NSEG));
+    dim3 grid((unsigned)(groups * 8 * tiles * ndir * nseg));
     // lds_pad_bytes > 0 only caps the number of resident workgroups per CU (the kernel uses no LDS), leaving
     // wave slots and VGPRs for a concurrently running pose kernel (stvo_ctx_set_overlap)
     hipLaunchKernelGGL(hamming_knn2_kernel, grid, dim3(KNN_BLOCK), (size_t)lds_pad_bytes, s, B, tiles, ndir, dir0,
-                       KNN_NSEG, row_stride, d1, n1, d2, n2, knn12, knn21, qsel, nsel);
+                       nseg, row_stride, d1, n1, d2, n2, knn12, knn21, qsel, nsel);
 }
 
 // K2: m12[i] = j  iff  float(d0) < float(d1) * nnr  (12 direction)  and, when `mutual`, the 21
 // direction's own ratio-tested best of j is i.  Fewer than two train rows => no match (the
 // reference is undefined there, src/matching.cpp:54).
-__global__ __launch_bounds__(256) void nnr_mutual_kernel(int row_stride, const uint2* __restrict__ knn12,
+__global__ __launch_bounds__(256) void nnr_mutual_kernel(int nseg, int row_stride, const uint2* __restrict__ knn12,
                                                          const uint2* __restrict__ knn21,
                                                          const int32_t* __restrict__ n1, const int32_t* __restrict__ n2,
                                                          float nnr, int mutual, int32_t* __restrict__ m12) {
@@ -182,13 +181,13 @@ __global__ __launch_bounds__(256) void nnr_mutual_kernel(int row_stride, const u
     const size_t off = (size_t)b * row_stride;
     int m = -1;
     if (i < na && nb >= 2) {
-        const uint2 k = merged_knn(knn12, (size_t)gridDim.y * row_stride, off + i);
+        const uint2 k = merged_knn(knn12, (size_t)gridDim.y * row_stride, off + i, nseg);
         const float f0 = (float)(k.x >> 16), f1 = (float)(k.y >> 16);
         if (f0 < f1 * nnr) m = (int)(k.x & 0xFFFFu);
         if (mutual && m >= 0) {
             bool keep = false;
             if (na >= 2) {
-                const uint2 r = merged_knn(knn21, (size_t)gridDim.y * row_stride, off + m);
+                const uint2 r = merged_knn(knn21, (size_t)gridDim.y * row_stride, off + m, nseg);
                 const float r0 = (float)(r.x >> 16), r1 = (float)(r.y >> 16);
                 keep = (r0 < r1 * nnr) && ((int)(r.x & 0xFFFFu) == i);
             }
@@ -199,10 +198,10 @@ __global__ __launch_bounds__(256) void nnr_mutual_kernel(int row_stride, const u
 }
 
 void launch_nnr_mutual(hipStream_t s, int B, int row_stride, const uint2* knn12, const uint2* knn21, const int32_t* n1,
-                       const int32_t* n2, float nnr, int mutual, int32_t* m12) {
+                       const int32_t* n2, float nnr, int mutual, int32_t* m12, int nseg) {
     if (B <= 0 || row_stride <= 0) return;
     dim3 grid((row_stride + 255) / 256, B);
-    hipLaunchKernelGGL(nnr_mutual_kernel, grid, dim3(256), 0, s, row_stride, knn12, knn21, n1, n2, nnr, mutual, m12);
+    hipLaunchKernelGGL(nnr_mutual_kernel, grid, dim3(256), 0, s, nseg, row_stride, knn12, knn21, n1, n2, nnr, mutual, m12);
 }
 
 // ---- lazy mutual matching -----------------------------------------------------------------------
@@ -210,7 +209,7 @@ void launch_nnr_mutual(hipStream_t s, int B, int row_stride, const uint2* knn12,
 // (src/matching.cpp:80-86 reads matches_21[matches_12[i1]] and nothing else).  So: forward scan of all
 // rows, forward ratio test, compaction of the distinct accepted columns, reverse scan of THOSE columns
 // only, reverse ratio test + index check.  Identical result, ~N2 - #accepted fewer reverse scans.
-__global__ __launch_bounds__(256) void nnr_forward_kernel(int row_stride, const uint2* __restrict__ knn12,
+__global__ __launch_bounds__(256) void nnr_forward_kernel(int nseg, int row_stride, const uint2* __restrict__ knn12,
                                                           const int32_t* __restrict__ n1, const int32_t* __restrict__ n2,
                                                           float nnr, int32_t* __restrict__ cand,
                                                           int32_t* __restrict__ need /* zeroed */) {
@@ -221,7 +220,7 @@ __global__ __launch_bounds__(256) void nnr_forward_kernel(int row_stride, const 
     const size_t off = (size_t)b * row_stride;
     int m = -1;
     if (i < na && nb >= 2) {
-        const uint2 k = merged_knn(knn12, (size_t)gridDim.y * row_stride, off + i);
+        const uint2 k = merged_knn(knn12, (size_t)gridDim.y * row_stride, off + i, nseg);
         const float f0 = (float)(k.x >> 16), f1 = (float)(k.y >> 16);
         if (f0 < f1 * nnr) m = (int)(k.x & 0xFFFFu);
     }
@@ -261,7 +260,7 @@ __global__ __launch_bounds__(256) void compact_need_kernel(int row_stride, const
     if (tid == 0) nsel[b] = tot;
 }
 
-__global__ __launch_bounds__(256) void nnr_reverse_check_kernel(int row_stride, const int32_t* __restrict__ cand,
+__global__ __launch_bounds__(256) void nnr_reverse_check_kernel(int nseg, int row_stride, const int32_t* __restrict__ cand,
                                                                 const uint2* __restrict__ knn21,
                                                                 const int32_t* __restrict__ n1, float nnr,
                                                                 int32_t* __restrict__ m12) {
@@ -273,7 +272,7 @@ __global__ __launch_bounds__(256) void nnr_reverse_check_kernel(int row_stride, 
     if (m >= 0) {
         bool keep = false;
         if (n1[b] >= 2) {
-            const uint2 r = merged_knn(knn21, (size_t)gridDim.y * row_stride, off + m);
+            const uint2 r = merged_knn(knn21, (size_t)gridDim.y * row_stride, off + m, nseg);
             const float r0 = (float)(r.x >> 16), r1 = (float)(r.y >> 16);
             keep = (r0 < r1 * nnr) && ((int)(r.x & 0xFFFFu) == i);
         }
@@ -287,15 +286,16 @@ void launch_match_mutual_lazy(hipStream_t s, int B, int row_stride, const uint8_
                               int lds_pad_bytes, hipEvent_t wait_before_m12_write) {
     if (B <= 0 || row_stride <= 0) return;
     const dim3 grid2((row_stride + 255) / 256, B);
+    const int nseg = knn_pick_nseg(B, row_stride, w.knn_capacity);
     (void)hipMemsetAsync(w.need, 0, (size_t)B * row_stride * sizeof(int32_t), s);
     launch_hamming_knn2(s, B, row_stride, row_stride, d1, n1, d2, n2, w.knn12, w.knn21, 0, lds_pad_bytes, 0, nullptr,
-                        nullptr);
-    hipLaunchKernelGGL(nnr_forward_kernel, grid2, dim3(256), 0, s, row_stride, w.knn12, n1, n2, nnr, w.cand, w.need);
+                        nullptr, nseg);
+    hipLaunchKernelGGL(nnr_forward_kernel, grid2, dim3(256), 0, s, nseg, row_stride, w.knn12, n1, n2, nnr, w.cand, w.need);
     hipLaunchKernelGGL(compact_need_kernel, dim3(B), dim3(256), 0, s, row_stride, w.need, n2, w.qsel, w.nsel);
     launch_hamming_knn2(s, B, row_stride, row_stride, d1, n1, d2, n2, w.knn12, w.knn21, 0, lds_pad_bytes, 1, w.qsel,
-                        w.nsel);
+                        w.nsel, nseg);
     if (wait_before_m12_write) (void)hipStreamWaitEvent(s, wait_before_m12_write, 0);
-    hipLaunchKernelGGL(nnr_reverse_check_kernel, grid2, dim3(256), 0, s, row_stride, w.cand, w.knn21, n1, nnr, m12);
+    hipLaunchKernelGGL(nnr_reverse_check_kernel, grid2, dim3(256), 0, s, nseg, row_stride, w.cand, w.knn21, n1, nnr, m12);
 }
 
 // Integer-VALU roof probe: the same instruction mix as K1's inner loop (xor, bcnt-accumulate,

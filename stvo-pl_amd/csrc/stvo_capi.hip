@@ -49,7 +49,9 @@ int stvo_ctx_create(int device_id, int max_rows, int max_batch, stvo_ctx** out) 
               hip_ok(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking), "hipStreamCreate");
     ctx->own_stream = ok;
     const size_t knn_elems = (size_t)max_rows * (size_t)max_batch;
-    const size_t knn_seg_elems = knn_elems * stvo::KNN_NSEG;
+    // [nseg][B][rows] with nseg = 2 for full batches, up to 16 for a single problem (knn_pick_nseg)
+    const size_t knn_seg_elems = (size_t)max_rows * (size_t)(2 * max_batch > 16 ? 2 * max_batch : 16);
+    ctx->knn_capacity = knn_seg_elems;
     // arena: descriptors + records + per-row scratch of one host-buffer call, with slack
     ctx->arena_size = (size_t)max_rows * 1024 + ((size_t)4 << 20);
     ok = ok && hip_ok(ctx, hipMalloc((void**)&ctx->knn12, knn_seg_elems * sizeof(uint2)), "hipMalloc knn12") &&
@@ -144,11 +146,13 @@ int stvo_match_nnr_mutual(stvo_ctx* ctx, const uint8_t* d1, int n1, const uint8_
     TRY(upload(ctx, &dn2, &n2, 1));
     TRY(upload(ctx, &dm12, (const int32_t*)nullptr, (size_t)stride));
     if (mutual) {
-        const stvo::LazyScratch w{ctx->knn12, ctx->knn21, ctx->cand, ctx->need, ctx->qsel, ctx->nsel};
+        const stvo::LazyScratch w{ctx->knn12, ctx->knn21, ctx->cand, ctx->need, ctx->qsel, ctx->nsel, ctx->knn_capacity};
         stvo::launch_match_mutual_lazy(ctx->stream, 1, stride, dd1, dn1, dd2, dn2, nnr, w, dm12, 0, nullptr);
     } else {
-        stvo::launch_hamming_knn2(ctx->stream, 1, stride, stride, dd1, dn1, dd2, dn2, ctx->knn12, ctx->knn21, 0);
-        stvo::launch_nnr_mutual(ctx->stream, 1, stride, ctx->knn12, ctx->knn21, dn1, dn2, nnr, 0, dm12);
+        const int nseg = stvo::knn_pick_nseg(1, stride, ctx->knn_capacity);
+        stvo::launch_hamming_knn2(ctx->stream, 1, stride, stride, dd1, dn1, dd2, dn2, ctx->knn12, ctx->knn21, 0, 0, 0,
+                                  nullptr, nullptr, nseg);
+        stvo::launch_nnr_mutual(ctx->stream, 1, stride, ctx->knn12, ctx->knn21, dn1, dn2, nnr, 0, dm12, nseg);
     }
     TRY(check_launch(ctx));
     HIP_TRY(ctx, hipMemcpyAsync(m12, dm12, (size_t)n1 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -169,11 +173,13 @@ int stvo_match_nnr_mutual_batched_dev(stvo_ctx* ctx, int B, int row_stride, cons
         return STVO_ERR_CAPACITY;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (mutual) {
-        const stvo::LazyScratch w{ctx->knn12, ctx->knn21, ctx->cand, ctx->need, ctx->qsel, ctx->nsel};
+        const stvo::LazyScratch w{ctx->knn12, ctx->knn21, ctx->cand, ctx->need, ctx->qsel, ctx->nsel, ctx->knn_capacity};
         stvo::launch_match_mutual_lazy(ctx->stream, B, row_stride, d1, n1, d2, n2, nnr, w, m12, 0, nullptr);
     } else {
-        stvo::launch_hamming_knn2(ctx->stream, B, row_stride, row_stride, d1, n1, d2, n2, ctx->knn12, ctx->knn21, 0);
-        stvo::launch_nnr_mutual(ctx->stream, B, row_stride, ctx->knn12, ctx->knn21, n1, n2, nnr, 0, m12);
+        const int nseg = stvo::knn_pick_nseg(B, row_stride, ctx->knn_capacity);
+        stvo::launch_hamming_knn2(ctx->stream, B, row_stride, row_stride, d1, n1, d2, n2, ctx->knn12, ctx->knn21, 0, 0, 0,
+                                  nullptr, nullptr, nseg);
+        stvo::launch_nnr_mutual(ctx->stream, B, row_stride, ctx->knn12, ctx->knn21, n1, n2, nnr, 0, m12, nseg);
     }
     return check_launch(ctx);
 }
@@ -350,15 +356,17 @@ int stvo_track_batched_dev(stvo_ctx* ctx, const stvo_track_batch_dev* b, const s
     // kernel); K2 rewrites m12, which the previous pose kernel may still be reading => K2 waits for it.
     const int pad = ctx->overlap ? kOverlapLdsPad : 0;
     hipEvent_t prev_pose = (ctx->overlap && ctx->pose_pending) ? ctx->ev_pose_done : nullptr;
-    const stvo::LazyScratch w{ctx->knn12, ctx->knn21, ctx->cand, ctx->need, ctx->qsel, ctx->nsel};
+    const stvo::LazyScratch w{ctx->knn12, ctx->knn21, ctx->cand, ctx->need, ctx->qsel, ctx->nsel, ctx->knn_capacity};
     auto match_set = [&](int stride, const uint8_t* da, const int32_t* na, const uint8_t* db, const int32_t* nb,
                          float nnr, int32_t* m12) {
         if (mutual) {
             stvo::launch_match_mutual_lazy(ctx->stream, b->B, stride, da, na, db, nb, nnr, w, m12, pad, prev_pose);
         } else {
-            stvo::launch_hamming_knn2(ctx->stream, b->B, stride, stride, da, na, db, nb, ctx->knn12, ctx->knn21, 0, pad);
+            const int nseg = stvo::knn_pick_nseg(b->B, stride, ctx->knn_capacity);
+            stvo::launch_hamming_knn2(ctx->stream, b->B, stride, stride, da, na, db, nb, ctx->knn12, ctx->knn21, 0, pad, 0,
+                                      nullptr, nullptr, nseg);
             if (prev_pose) (void)hipStreamWaitEvent(ctx->stream, prev_pose, 0);
-            stvo::launch_nnr_mutual(ctx->stream, b->B, stride, ctx->knn12, ctx->knn21, na, nb, nnr, 0, m12);
+            stvo::launch_nnr_mutual(ctx->stream, b->B, stride, ctx->knn12, ctx->knn21, na, nb, nnr, 0, m12, nseg);
         }
     };
     // matchF2FPoints (:131-153)
@@ -416,16 +424,17 @@ int stvo_time_stage_dev(stvo_ctx* ctx, const stvo_track_batch_dev* b, const stvo
             // lazy reverse scan of the columns selected by the LAST stvo_track_batched_dev call (ctx->qsel)
             const int pad = ctx->overlap ? kOverlapLdsPad : 0;
             stvo::launch_hamming_knn2(ctx->stream, b->B, b->max_pts, b->max_pts, b->prev_pdesc, b->n_prev_pts,
-                                      b->curr_pdesc, b->n_curr_pts, ctx->knn12, ctx->knn21, 0, pad, 0, nullptr, nullptr);
+                                      b->curr_pdesc, b->n_curr_pts, ctx->knn12, ctx->knn21, 0, pad, 0, nullptr, nullptr,
+                                      stvo::knn_pick_nseg(b->B, b->max_pts, ctx->knn_capacity));
             stvo::launch_hamming_knn2(ctx->stream, b->B, b->max_pts, b->max_pts, b->prev_pdesc, b->n_prev_pts,
                                       b->curr_pdesc, b->n_curr_pts, ctx->knn12, ctx->knn21, 0, pad, 1, ctx->qsel,
-                                      ctx->nsel);
+                                      ctx->nsel, stvo::knn_pick_nseg(b->B, b->max_pts, ctx->knn_capacity));
         } else if (stage >= 2) {  // developer probes: 2 forward only, 3 lazy reverse only, 4 both directions in full
             const int pad = ctx->overlap ? kOverlapLdsPad : 0;
             stvo::launch_hamming_knn2(ctx->stream, b->B, b->max_pts, b->max_pts, b->prev_pdesc, b->n_prev_pts,
                                       b->curr_pdesc, b->n_curr_pts, ctx->knn12, ctx->knn21, stage == 4 ? 1 : 0, pad,
                                       stage == 3 ? 1 : 0, stage == 3 ? ctx->qsel : nullptr,
-                                      stage == 3 ? ctx->nsel : nullptr);
+                                      stage == 3 ? ctx->nsel : nullptr, stvo::knn_pick_nseg(b->B, b->max_pts, ctx->knn_capacity));
         } else
             stvo::launch_pose(ctx->stream, a);
     }

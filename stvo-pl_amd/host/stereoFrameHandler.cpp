@@ -2,6 +2,7 @@
 #include "stereoFrameHandler.h"
 
 #include <algorithm>
+#include <chrono>
 #include <iostream>
 #include <stdexcept>
 #include <string>
@@ -49,9 +50,14 @@ void StereoFrameHandler::initialize(const FrameFeatures& feat, const int idx_) {
 
 // :54-60
 void StereoFrameHandler::insertStereoPair(const FrameFeatures& feat, const int idx_) {
+    using clk = std::chrono::high_resolution_clock;
+    const auto t0 = clk::now();
     curr_frame = new StereoFrame(feat, idx_, cam, ctx);
     curr_frame->extractStereoFeatures(llength_th, orb_fast_th);
+    const auto t1 = clk::now();
     f2fTracking();
+    t_stereo_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    t_f2f_ms = std::chrono::duration<double, std::milli>(clk::now() - t1).count();
 }
 
 // :62-102
@@ -150,6 +156,7 @@ bool StereoFrameHandler::isGoodSolution(Matrix4d DT, Matrix6d DTcov, double err)
 
 // :307-392 — the optimisation itself (:332-370 and the goodness test of :372) runs on the GPU
 void StereoFrameHandler::optimizePose() {
+    const auto t_begin = std::chrono::high_resolution_clock::now();
     Matrix4d DT;
     if (Config::useMotionModel()) {  // :317-324
         DT = prev_frame->DT;
@@ -234,6 +241,7 @@ void StereoFrameHandler::optimizePose() {
         curr_frame->Tfw_cov = prev_frame->Tfw_cov;
         for (int i = 0; i < 6; ++i) curr_frame->DT_cov_eig(i) = 0.0;
     }
+    t_pose_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t_begin).count();
 }
 
 void StereoFrameHandler::resetOutliers() {

@@ -44,6 +44,8 @@ public:
 
     // what the GPU reported for the last optimizePose (status / path / iteration counts)
     stvo_pose_result last_result;
+    // host wall-clock per stage of the last frame, ms: stereo association, f2f matching, optimizePose
+    double t_stereo_ms = 0.0, t_f2f_ms = 0.0, t_pose_ms = 0.0;
     int mode = 0;  // the local constant of src/stereoFrameHandler.cpp:329 (0 GN, 1 robust GN, 2 LM)
 
 private:
