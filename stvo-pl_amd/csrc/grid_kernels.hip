@@ -10,15 +10,20 @@
 //     eligible(i1,i2)  <=>  D(i1,i2) < min over covering i1' < i1 of D(i1',i2)
 //     owner(i2)        =   lowest i1 attaining the global minimum of D(.,i2)   (= final matches_21)
 // which maps onto three kernels:
-//   A  `grid_cover`   lane = left feature: walks its window cells in the CSR grid and sets bit i2 of
-//                     its row of the candidate bit-matrix (the std::unordered_set de-duplication of
-//                     gridStructure.cpp:75 is the idempotence of OR; lines OR both end-point windows)
+//   A  `grid_cover`   lane = left feature: walks its window cells in the CSR grid and sets the bit of
+//                     every right feature found there in the candidate bit-matrix (the
+//                     std::unordered_set de-duplication of gridStructure.cpp:75 is the idempotence of
+//                     OR; lines OR both end-point windows).  The matrix is stored TRANSPOSED,
+//                     cover[wave of right features][left feature], and right features are numbered in
+//                     CSR (= spatial) order, so the masks one scanning wave needs are contiguous and
+//                     almost all zero.
 //   B  `grid_scan`    lane = right feature, descriptor resident in 8 VGPRs; the left features stream
 //                     by in ASCENDING i1 as wave-uniform rows (scalar loads) — the same popcount
 //                     inner loop as K1, predicated by the candidate bit and (lines) the direction
-//                     cosine gate (:221-222); each lane carries its running minimum, so eligibility
-//                     and ownership fall out in order; eligible pairs update the left feature's
-//                     packed (best, second) keys with a 64-bit CAS (integer keys: order-independent)
+//                     cosine gate (:221-222); 8 masks per s_load_dwordx16, all-zero chunks skipped;
+//                     each lane carries its running minimum, so eligibility and ownership fall out
+//                     in order; eligible pairs update the left feature's packed (best, second) keys
+//                     with a 64-bit CAS (integer keys: order-independent)
 //   C  `grid_finalize` lane = left feature: DOUBLE ratio test best_d < best_d2 * ratio with
 //                     best_d2 = INT_MAX when only one candidate was eligible (:160), mutual check
 //                     against owner (:166-174).

@@ -371,6 +371,24 @@ __device__ __noinline__ void t0_is_good(PoseSh* sh, const double* DT, double err
     sh->good = pm::is_good_solution(DT, w, err) ? 1 : 0;
 }
 
+// Same decision without the eigenvalues (the stage-1 test of :341 only needs the verdict): positive
+// definiteness by LDL^T pivots and lambda_max <= ||.||_inf <= 1 certify the two eigenvalue conditions; anything
+// not certified falls back to the eigen-decomposition the reference performs.
+__device__ __noinline__ void t0_is_good_fast(PoseSh* sh, const double* DT, double err) {
+    if (err < 0.0 || err > 1.0 || !pm::all_finite16(DT)) {
+        sh->good = 0;
+        return;
+    }
+    double C[36];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) C[i] = sh->cov[i];
+    if (pm::spd_unit_certificate(C) == 1) {
+        sh->good = 1;
+        return;
+    }
+    t0_is_good(sh, DT, err);
+}
+
 __device__ __noinline__ void t0_commit(PoseSh* sh, stvo_pose_result* out, int status, int path, int it0, int it1) {
     // :372-391
     t0_is_good(sh, sh->DT, sh->err_out);
@@ -561,12 +579,20 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_ibuf)[BLOCK
         double acc[28];
 #pragma unroll
         for (int i = 0; i < 28; ++i) acc[i] = 0.0;
-#pragma unroll 1
-        for (int k = 0; k < PPT; ++k)
-            if ((pinl >> k) & 1u) {
-                const PointRec r = load_point(k);
-                pm::point_term(acc, DT, cam, prm.homog_th, r.X, r.Y, r.Z, r.ox, r.oy, r.s2, robust, sp);
+        {
+            // software pipeline over this thread's inlier points: the record of the NEXT inlier is in flight
+            // (HBM / L2 latency, two dependent loads through m12) while the current one is evaluated
+            unsigned todo = pinl;
+            PointRec cur{1.0, 1.0, 1.0, 0.0, 0.0, 1.0};
+            if (todo) cur = load_point(__builtin_ctz(todo));
+            while (todo) {
+                todo &= todo - 1u;
+                PointRec nxt = cur;
+                if (todo) nxt = load_point(__builtin_ctz(todo));
+                pm::point_term(acc, DT, cam, prm.homog_th, cur.X, cur.Y, cur.Z, cur.ox, cur.oy, cur.s2, robust, sp);
+                cur = nxt;
             }
+        }
 #pragma unroll 1
         for (int k = 0; k < LPT; ++k)
             if ((linl >> k) & 1u) {
@@ -737,7 +763,7 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_ibuf)[BLOCK
             if (t0) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) sh->DT1[i] = sh->DT[i];
-                t0_is_good(sh, sh->DT1, sh->err_out);
+                t0_is_good_fast(sh, sh->DT1, sh->err_out);
             }
             __syncthreads();
             tprof[2] += tick() - tq2;
@@ -823,15 +849,29 @@ __global__ __launch_bounds__(BLOCK + 64, 2) void pose_kernel(PoseArgs a) {  // >
         pose_body<BLOCK, PPT, LPT, false>(a, s_ibuf, s_red, s_ired, &s_sh);  // solver wave
 }
 
-// 3 worker waves + 1 solver wave = 256 threads, <= 168 VGPRs: three workgroups per CU.
-constexpr int POSE_BLOCK = 192;
-constexpr int POSE_PPT = (STVO_POSE_MAX_POINTS + POSE_BLOCK - 1) / POSE_BLOCK;  // 5
-constexpr int POSE_LPT = (STVO_POSE_MAX_LINES + POSE_BLOCK - 1) / POSE_BLOCK;   // 2
+// Two instantiations of the same kernel:
+//   throughput: 3 worker waves + 1 solver wave (256 threads, <= 256 VGPRs): two workgroups per CU and room
+//               next to the matching kernel in overlap mode; used when the batch has more workgroups than CUs;
+//   latency:    7 worker waves + 1 solver wave (512 threads): the parallel phases of ONE frame pair run ~2.3x
+//               faster; used for small batches (single-stream operation through the handler API), where every
+//               workgroup has a CU to itself anyway.
+constexpr int POSE_BLOCK_T = 192, POSE_BLOCK_L = 448;
+constexpr int POSE_LATENCY_MAX_B = 256;
+
+template <int BLK>
+static void launch_pose_variant(hipStream_t s, const PoseArgs& a) {
+    constexpr int PPT = (STVO_POSE_MAX_POINTS + BLK - 1) / BLK;
+    constexpr int LPT = (STVO_POSE_MAX_LINES + BLK - 1) / BLK;
+    hipLaunchKernelGGL((pose_kernel<BLK, PPT, LPT>), dim3(a.B), dim3(BLK + 64), 0, s, a);
+}
 
 int launch_pose(hipStream_t s, const PoseArgs& a) {
     if (a.B <= 0) return STVO_OK;
     if (a.max_pts > STVO_POSE_MAX_POINTS || a.max_lines > STVO_POSE_MAX_LINES) return STVO_ERR_CAPACITY;
-    hipLaunchKernelGGL((pose_kernel<POSE_BLOCK, POSE_PPT, POSE_LPT>), dim3(a.B), dim3(POSE_BLOCK + 64), 0, s, a);
+    if (a.B <= POSE_LATENCY_MAX_B)
+        launch_pose_variant<POSE_BLOCK_L>(s, a);
+    else
+        launch_pose_variant<POSE_BLOCK_T>(s, a);
     return STVO_OK;
 }
 

@@ -441,6 +441,44 @@ PM_HD void eig6(const double* Ain, double* w) {
     for (int i = 0; i < 6; ++i) w[i] = v[i];
 }
 
+// Cheap certificate for the eigenvalue part of isGoodSolution (lambda_min >= 0 and lambda_max <= 1) that
+// avoids the eigen-decomposition in the common case: for the symmetric matrix S given by the LOWER
+// triangle of C,  lambda_max <= ||S||_inf,  and S is positive definite iff its LDL^T pivots are positive.
+// Returns +1 (certified good: ||S||_inf <= 1 and every pivot comfortably positive), or 0 (undecided: the
+// caller falls back to eig6, which is what the reference computes).  Never returns a wrong "good".
+PM_HD int spd_unit_certificate(const double* C) {
+    double S[36];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) S[i * 6 + j] = (i >= j) ? C[i * 6 + j] : C[j * 6 + i];
+    double rmax = 0.0, dmax_ = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double r = 0.0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) r += fabs(S[i * 6 + j]);
+        rmax = r > rmax ? r : rmax;
+        dmax_ = S[i * 7] > dmax_ ? S[i * 7] : dmax_;
+    }
+    if (!(rmax <= 1.0)) return 0;  // also catches NaN
+    const double tol = 1e-10 * dmax_;
+    bool ok = dmax_ > 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {  // in-place LDL^T on the lower triangle
+        const double piv = S[k * 7];
+        ok = ok && (piv > tol);
+        const double inv = 1.0 / piv;
+#pragma unroll
+        for (int i = k + 1; i < 6; ++i) {
+            const double l = S[i * 6 + k] * inv;
+#pragma unroll
+            for (int j = k + 1; j <= i; ++j) S[i * 6 + j] -= l * S[j * 6 + k];
+        }
+    }
+    return ok ? 1 : 0;
+}
+
 PM_HD bool all_finite16(const double* T) {
     bool ok = true;
 #pragma unroll

@@ -13,6 +13,7 @@ int pmh_solve6(const double* H, const double* g, double* x, double* lad) { retur
 void pmh_inverse6(const double* A, double* Ai) { pm::inverse6(A, Ai); }
 void pmh_eig6(const double* A, double* w) { pm::eig6(A, w); }
 void pmh_step_pose(double* DT, const double* inc) { pm::step_pose(DT, inc); }
+int pmh_spd_cert(const double* C) { return pm::spd_unit_certificate(C); }
 double pmh_line_overlap(const double* so, const double* eo, const double* sp, const double* ep) {
     return pm::line_overlap(so[0], so[1], eo[0], eo[1], sp[0], sp[1], ep[0], ep[1]);
 }

@@ -121,3 +121,27 @@ def test_feature_terms_vs_oracle(pmh, oracle, robust):
         assert np.allclose(Hd, H, rtol=1e-12, atol=1e-12 * np.abs(H).max())
         assert np.allclose(acc[21:27], g, rtol=1e-12, atol=1e-12 * np.abs(g).max())
         assert np.isclose(acc[27] / n, e, rtol=1e-13)
+
+
+def test_spd_certificate_never_contradicts_eig(pmh):
+    """spd_unit_certificate (the pose kernel's shortcut for isGoodSolution's eigenvalue test) may answer
+    'undecided' but must never certify a matrix whose eigenvalues violate 0 <= lambda <= 1."""
+    pmh.pmh_spd_cert.argtypes = [f64p]; pmh.pmh_spd_cert.restype = C.c_int
+    rng = np.random.default_rng(5)
+    n_cert = 0
+    for k in range(3000):
+        kind = k % 6
+        A = rng.normal(size=(6, 6))
+        if kind == 0: M = A @ A.T * 10 ** rng.uniform(-9, -1)          # typical covariances: tiny SPD
+        elif kind == 1: M = A @ A.T * 10 ** rng.uniform(-1, 1)         # around the lambda_max = 1 boundary
+        elif kind == 2: M = (A + A.T) * 0.01                            # indefinite
+        elif kind == 3: J = rng.normal(size=(4, 6)); M = J.T @ J * 0.01  # singular PSD
+        elif kind == 4: M = np.diag(rng.uniform(-0.1, 1.2, 6))
+        else: M = A @ A.T * 1e-6; M[0, 0] = np.nan if k % 12 == 5 else M[0, 0]
+        c = pmh.pmh_spd_cert(np.ascontiguousarray(M).reshape(-1))
+        if c == 1:
+            n_cert += 1
+            L = np.tril(M); S = L + L.T - np.diag(np.diag(M))
+            w = np.linalg.eigvalsh(S)
+            assert w[0] >= 0.0 and w[-1] <= 1.0, (kind, w)
+    assert n_cert > 500  # the shortcut actually fires on the common case
