@@ -19,7 +19,8 @@ struct stvo_ctx {
     int32_t *cand = nullptr, *need = nullptr, *qsel = nullptr, *nsel = nullptr;  // lazy reverse pass
     // bump arena for the host-buffer entry points
     char* arena = nullptr;
-    size_t arena_size = 0, arena_off = 0;
+    char* arena_host = nullptr;  // pinned mirror of the arena: uploads are gathered here and sent as ONE H2D copy
+    size_t arena_size = 0, arena_off = 0, upload_hi = 0;
     uint32_t* probe_sink = nullptr;
     // overlap mode: pose kernels go to aux_stream; events order them against the matching kernels
     int overlap = 0;
@@ -51,12 +52,38 @@ inline T* arena_alloc(stvo_ctx* ctx, size_t count) {
     return p;
 }
 
+// Host data is first gathered in the pinned mirror (same offset as the device allocation); flush_uploads()
+// then moves everything with a single asynchronous H2D copy.  A dozen small pageable hipMemcpyAsync calls
+// cost ~10-20 us each, which dominated the single-stream latency of the host-buffer entry points.
 template <typename T>
-inline int upload(stvo_ctx* ctx, T** dst, const T* src, size_t count) {
-    *dst = arena_alloc<T>(ctx, count);
+inline int upload(stvo_ctx* ctx, T** dst, const T* src, size_t count, size_t count_alloc = 0) {
+    *dst = arena_alloc<T>(ctx, count_alloc > count ? count_alloc : count);
     if (!*dst) return STVO_ERR_CAPACITY;
-    if (count && src) HIP_TRY(ctx, hipMemcpyAsync(*dst, src, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    if (count && src) {
+        const size_t off = (size_t)(reinterpret_cast<char*>(*dst) - ctx->arena);
+        std::memcpy(ctx->arena_host + off, src, count * sizeof(T));
+        if (off + count * sizeof(T) > ctx->upload_hi) ctx->upload_hi = off + count * sizeof(T);
+    }
     return STVO_OK;
+}
+
+inline int flush_uploads(stvo_ctx* ctx) {
+    if (ctx->upload_hi) {
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->arena, ctx->arena_host, ctx->upload_hi, hipMemcpyHostToDevice, ctx->stream));
+        ctx->upload_hi = 0;
+    }
+    return STVO_OK;
+}
+
+// asynchronous D2H of an arena region into the pinned mirror; read it through host_mirror() after the sync
+inline int download_begin(stvo_ctx* ctx, const void* dev, size_t bytes) {
+    const size_t off = (size_t)(reinterpret_cast<const char*>(dev) - ctx->arena);
+    if (bytes) HIP_TRY(ctx, hipMemcpyAsync(ctx->arena_host + off, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return STVO_OK;
+}
+template <typename T>
+inline const T* host_mirror(stvo_ctx* ctx, const T* dev) {
+    return reinterpret_cast<const T*>(ctx->arena_host + (reinterpret_cast<const char*>(dev) - ctx->arena));
 }
 #define TRY(expr)                \
     do {                         \

@@ -218,6 +218,7 @@ int run_grid(stvo_ctx* ctx, const int32_t* cell_xy1, const uint8_t* d1, int n1, 
     if (n_items > 0 && !cell_items) return STVO_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->arena_off = 0;
+    ctx->upload_hi = 0;
     GridArgs a;
     std::memset(&a, 0, sizeof(a));
     int32_t *dxy, *dstart, *ditems, *downer, *dm12;
@@ -252,6 +253,7 @@ int run_grid(stvo_ctx* ctx, const int32_t* cell_xy1, const uint8_t* d1, int n1, 
     TRY(upload(ctx, &dperm, perm.data(), (size_t)n2));
     a.rank = drank;
     a.perm = dperm;
+    TRY(flush_uploads(ctx));
     a.cover = arena_alloc<unsigned long long>(ctx, (size_t)a.n1p * a.words64);
     a.top2 = arena_alloc<unsigned long long>(ctx, (size_t)n1);
     downer = arena_alloc<int32_t>(ctx, (size_t)n2);
@@ -277,8 +279,9 @@ int run_grid(stvo_ctx* ctx, const int32_t* cell_xy1, const uint8_t* d1, int n1, 
     hipLaunchKernelGGL((grid_scan_kernel<LINES>), g2, blk, 0, ctx->stream, a);
     hipLaunchKernelGGL(grid_finalize_kernel, g1, blk, 0, ctx->stream, a);
     TRY(check_launch(ctx));
-    HIP_TRY(ctx, hipMemcpyAsync(m12, dm12, (size_t)n1 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    TRY(download_begin(ctx, dm12, (size_t)n1 * sizeof(int32_t)));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    std::memcpy(m12, host_mirror(ctx, dm12), (size_t)n1 * sizeof(int32_t));
     if (n_matches) {
         int c = 0;
         for (int i = 0; i < n1; ++i) c += m12[i] >= 0;

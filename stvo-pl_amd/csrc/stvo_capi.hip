@@ -61,6 +61,7 @@ int stvo_ctx_create(int device_id, int max_rows, int max_batch, stvo_ctx** out) 
          hip_ok(ctx, hipMalloc((void**)&ctx->qsel, knn_elems * sizeof(int32_t)), "hipMalloc qsel") &&
          hip_ok(ctx, hipMalloc((void**)&ctx->nsel, (size_t)max_batch * sizeof(int32_t)), "hipMalloc nsel") &&
          hip_ok(ctx, hipMalloc((void**)&ctx->arena, ctx->arena_size), "hipMalloc arena") &&
+         hip_ok(ctx, hipHostMalloc((void**)&ctx->arena_host, ctx->arena_size, hipHostMallocDefault), "hipHostMalloc") &&
          hip_ok(ctx, hipMalloc((void**)&ctx->probe_sink, 256), "hipMalloc sink");
     if (!ok) {
         stvo_ctx_destroy(ctx);
@@ -81,6 +82,7 @@ int stvo_ctx_destroy(stvo_ctx* ctx) {
     if (ctx->qsel) hipFree(ctx->qsel);
     if (ctx->nsel) hipFree(ctx->nsel);
     if (ctx->arena) hipFree(ctx->arena);
+    if (ctx->arena_host) hipHostFree(ctx->arena_host);
     if (ctx->probe_sink) hipFree(ctx->probe_sink);
     if (ctx->aux_stream) {
         hipStreamSynchronize(ctx->aux_stream);
@@ -135,15 +137,15 @@ int stvo_match_nnr_mutual(stvo_ctx* ctx, const uint8_t* d1, int n1, const uint8_
     if (n1 == 0) return STVO_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->arena_off = 0;
+    ctx->upload_hi = 0;
     const int stride = n1 > n2 ? n1 : n2;
     uint8_t *dd1, *dd2;
     int32_t *dn1, *dn2, *dm12;
-    TRY(upload(ctx, &dd1, (const uint8_t*)nullptr, (size_t)stride * STVO_DESC_BYTES));
-    TRY(upload(ctx, &dd2, (const uint8_t*)nullptr, (size_t)stride * STVO_DESC_BYTES));
-    HIP_TRY(ctx, hipMemcpyAsync(dd1, d1, (size_t)n1 * STVO_DESC_BYTES, hipMemcpyHostToDevice, ctx->stream));
-    if (n2) HIP_TRY(ctx, hipMemcpyAsync(dd2, d2, (size_t)n2 * STVO_DESC_BYTES, hipMemcpyHostToDevice, ctx->stream));
+    TRY(upload(ctx, &dd1, d1, (size_t)n1 * STVO_DESC_BYTES, (size_t)stride * STVO_DESC_BYTES));
+    TRY(upload(ctx, &dd2, d2, (size_t)n2 * STVO_DESC_BYTES, (size_t)stride * STVO_DESC_BYTES));
     TRY(upload(ctx, &dn1, &n1, 1));
     TRY(upload(ctx, &dn2, &n2, 1));
+    TRY(flush_uploads(ctx));
     TRY(upload(ctx, &dm12, (const int32_t*)nullptr, (size_t)stride));
     if (mutual) {
         const stvo::LazyScratch w{ctx->knn12, ctx->knn21, ctx->cand, ctx->need, ctx->qsel, ctx->nsel, ctx->knn_capacity};
@@ -155,8 +157,9 @@ int stvo_match_nnr_mutual(stvo_ctx* ctx, const uint8_t* d1, int n1, const uint8_
         stvo::launch_nnr_mutual(ctx->stream, 1, stride, ctx->knn12, ctx->knn21, dn1, dn2, nnr, 0, dm12, nseg);
     }
     TRY(check_launch(ctx));
-    HIP_TRY(ctx, hipMemcpyAsync(m12, dm12, (size_t)n1 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    TRY(download_begin(ctx, dm12, (size_t)n1 * sizeof(int32_t)));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    std::memcpy(m12, host_mirror(ctx, dm12), (size_t)n1 * sizeof(int32_t));
     if (n_matches) {
         int c = 0;
         for (int i = 0; i < n1; ++i) c += m12[i] >= 0;
@@ -212,6 +215,7 @@ int stage_records(stvo_ctx* ctx, const stvo_matched* m, const double* T, stvo::P
     TRY(upload(ctx, &dnp, &m->np, 1));
     TRY(upload(ctx, &dnl, &m->nl, 1));
     TRY(upload(ctx, &dT, T, 16));
+    TRY(flush_uploads(ctx));
     a->n_prev_pts = dnp;
     a->prev_P = P;
     a->prev_s2p = s2p;
@@ -238,6 +242,7 @@ int stvo_normal_eq(stvo_ctx* ctx, const double T[16], const stvo_cam* cam, const
     if (!ctx || !T || !cam || !params || !m || !H || !g || !e) return STVO_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->arena_off = 0;
+    ctx->upload_hi = 0;
     stvo::PoseArgs a;
     int32_t *dip, *dil;
     TRY(stage_records(ctx, m, T, &a, &dip, &dil));
@@ -250,9 +255,9 @@ int stvo_normal_eq(stvo_ctx* ctx, const double T[16], const stvo_cam* cam, const
     a.eval_out = dout;
     TRY(stvo::launch_pose(ctx->stream, a));
     TRY(check_launch(ctx));
-    double out[44];
-    HIP_TRY(ctx, hipMemcpyAsync(out, dout, sizeof(out), hipMemcpyDeviceToHost, ctx->stream));
+    TRY(download_begin(ctx, dout, 44 * sizeof(double)));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const double* out = host_mirror(ctx, dout);
     std::memcpy(H, out, 36 * sizeof(double));
     std::memcpy(g, out + 36, 6 * sizeof(double));
     *e = out[42];
@@ -268,6 +273,7 @@ int stvo_optimize_pose(stvo_ctx* ctx, const double init_T[16], const stvo_cam* c
         return STVO_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->arena_off = 0;
+    ctx->upload_hi = 0;
     stvo::PoseArgs a;
     int32_t *dip, *dil;
     TRY(stage_records(ctx, m, init_T, &a, &dip, &dil));
@@ -282,11 +288,13 @@ int stvo_optimize_pose(stvo_ctx* ctx, const double init_T[16], const stvo_cam* c
     a.inl_l_out = dol;
     TRY(stvo::launch_pose(ctx->stream, a));
     TRY(check_launch(ctx));
-    HIP_TRY(ctx, hipMemcpyAsync(out, dres, sizeof(*out), hipMemcpyDeviceToHost, ctx->stream));
-    std::vector<int32_t> ip((size_t)(m->np > 0 ? m->np : 1)), il((size_t)(m->nl > 0 ? m->nl : 1));
-    if (m->np) HIP_TRY(ctx, hipMemcpyAsync(ip.data(), dop, (size_t)m->np * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (m->nl) HIP_TRY(ctx, hipMemcpyAsync(il.data(), dol, (size_t)m->nl * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TRY(download_begin(ctx, dres, sizeof(*out)));
+    if (m->np) TRY(download_begin(ctx, dop, (size_t)m->np * 4));
+    if (m->nl) TRY(download_begin(ctx, dol, (size_t)m->nl * 4));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    std::memcpy(out, host_mirror(ctx, dres), sizeof(*out));
+    const int32_t* ip = host_mirror(ctx, dop);
+    const int32_t* il = host_mirror(ctx, dol);
     for (int i = 0; i < m->np; ++i) m->inlier_p[i] = ip[i] > 0 ? 1 : 0;
     for (int i = 0; i < m->nl; ++i) m->inlier_l[i] = il[i] > 0 ? 1 : 0;
     return STVO_OK;
