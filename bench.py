@@ -103,6 +103,7 @@ def main():
         step()
     ctx.synchronize()
     torch.cuda.synchronize()
+    ctx.set_kernel_timing(rank == 0)   # hipEvent pairs around every hamming_knn2 launch of the timed region
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -127,7 +128,10 @@ def main():
         # K1 is launched twice per matching stage: forward scan of all prev rows, then the lazy reverse scan of
         # the curr rows that are some prev row's accepted forward match.  Figures below are per launch (average
         # of the two), which is also what rocprofv3's per-kernel average reports.
-        k1_ms = ctx.time_stage(batch, synth.KITTI_CAM, prm, 0.75, 0, 10)
+        k1_fwd_ms, k1_rev_ms, k1_calls = ctx.get_kernel_timing()   # live, over the timed region
+        ctx.set_kernel_timing(False)
+        k1_ms = 0.5 * (k1_fwd_ms + k1_rev_ms)
+        k1_solo_ms = ctx.time_stage(batch, synth.KITTI_CAM, prm, 0.75, 0, 10)  # same launches with the GPU to themselves
         pose_ms = ctx.time_stage(batch, synth.KITTI_CAM, prm, 0.75, 1, 10)
         n1v = batch.host["n_prev_pts"].astype(np.int64); n2v = batch.host["n_curr_pts"].astype(np.int64)
         nsel = ctx.last_reverse_counts(B).astype(np.int64)
@@ -149,9 +153,9 @@ def main():
                        "pose_overlaps_next_match": not args.no_overlap},
             "roofline": {"kernel": "hamming_knn2_kernel", "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
-                         "traffic_profile": "separate rocprofv3 --pmc passes, profiles/r01_b_hbm_counters.txt: FETCH_SIZE 69.9 MB + "
-                                            "WRITE_SIZE 16.0 MB per launch = 1.05x the algorithmic bytes",
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k1_ms,
+                         "traffic_profile": "separate rocprofv3 --pmc passes, profiles/r01_c_hbm_counters.txt: FETCH_SIZE 48.8 MB + "
+                                            "WRITE_SIZE per launch, see file; <= 1.0x the algorithmic bytes (train rows come through the scalar cache / L2)",
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k1_ms, "timing": "hipEvent pairs around each launch inside the timed region, on the launch stream",
                          "note": "K1 is integer-VALU bound (~1000 lane-ops per compulsory byte); see valu_roofline. Two launches "
                                  "per step (forward + lazy reverse); figures are per launch"},
             "valu_roofline": {"kernel": "hamming_knn2_kernel", "lane_ops_per_launch": lane_ops,
@@ -159,7 +163,9 @@ def main():
                               "unit": "T lane-ops/s", "frac": lane_ops / (k1_ms * 1e-3) / VALU_PEAK_LANE_OPS,
                               "measured_peak_same_mix": valu_meas / 1e12,
                               "frac_of_measured_peak": lane_ops / (k1_ms * 1e-3) / valu_meas},
-            "stage_ms": {"hamming_knn2_per_launch": k1_ms, "hamming_knn2_launches_per_step": 2, "pose": pose_ms,
+            "stage_ms": {"hamming_knn2_per_launch": k1_ms, "hamming_knn2_forward": k1_fwd_ms, "hamming_knn2_lazy_reverse": k1_rev_ms,
+                         "hamming_knn2_calls_timed": k1_calls, "hamming_knn2_launches_per_step": 2,
+                         "hamming_knn2_per_launch_solo": k1_solo_ms, "pose_solo": pose_ms,
                          "reverse_scan_fraction": float(nsel.sum()) / float(n2v.sum())},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -149,6 +149,13 @@ int stvo_optimize_pose_batched_dev(stvo_ctx* ctx, const stvo_track_batch_dev* ba
 int stvo_time_stage_dev(stvo_ctx* ctx, const stvo_track_batch_dev* batch, const stvo_cam* cam,
                         const stvo_opt_params* params, float nnr, int stage, int iters, float* avg_ms);
 
+/* Live timing of the dominant kernel INSIDE the batched path: with enable = 1 every stvo_track_batched_dev
+ * call brackets its two hamming_knn2 launches on the point descriptors (forward scan, lazy reverse scan) with
+ * hipEvents on the stream they are launched on.  get_kernel_timing synchronises, returns the average
+ * duration of each and the number of calls measured since the last get / set, and resets the pool. */
+int stvo_ctx_set_kernel_timing(stvo_ctx* ctx, int enable);
+int stvo_ctx_get_kernel_timing(stvo_ctx* ctx, float* avg_ms_forward, float* avg_ms_reverse, int32_t* n_calls);
+
 /* Number of right-hand (curr) rows whose reverse scan the LAST batched mutual match actually ran, per frame
  * pair (the lazy reverse pass only scans columns that are some row's accepted forward match). */
 int stvo_last_reverse_counts(stvo_ctx* ctx, int B, int32_t* counts);

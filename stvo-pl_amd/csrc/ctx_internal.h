@@ -4,6 +4,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <vector>
 
 #include "kernels.h"
 
@@ -27,6 +28,10 @@ struct stvo_ctx {
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_match_done = nullptr, ev_pose_done = nullptr;
     bool pose_pending = false;
+    // optional live kernel timing (bench): event pairs around every hamming_knn2 launch of the batched path
+    int timing = 0;
+    std::vector<hipEvent_t> ev_pool;  // start/stop pairs, grown on demand
+    size_t ev_used = 0;
     char last_error[256] = {0};
 };
 

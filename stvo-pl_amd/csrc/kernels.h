@@ -40,7 +40,7 @@ struct LazyScratch {
 };
 void launch_match_mutual_lazy(hipStream_t s, int B, int row_stride, const uint8_t* d1, const int32_t* n1,
                               const uint8_t* d2, const int32_t* n2, float nnr, const LazyScratch& w, int32_t* m12,
-                              int lds_pad_bytes, hipEvent_t wait_before_m12_write);
+                              int lds_pad_bytes, hipEvent_t wait_before_m12_write, hipEvent_t* timing_events = nullptr);
 void launch_nnr_mutual(hipStream_t s, int B, int row_stride, const uint2* knn12, const uint2* knn21, const int32_t* n1,
                        const int32_t* n2, float nnr, int mutual, int32_t* m12, int nseg = KNN_MIN_NSEG);
 void launch_valu_probe(hipStream_t s, int blocks, int iters, uint32_t* sink);

@@ -283,17 +283,21 @@ __global__ __launch_bounds__(256) void nnr_reverse_check_kernel(int nseg, int ro
 
 void launch_match_mutual_lazy(hipStream_t s, int B, int row_stride, const uint8_t* d1, const int32_t* n1,
                               const uint8_t* d2, const int32_t* n2, float nnr, const LazyScratch& w, int32_t* m12,
-                              int lds_pad_bytes, hipEvent_t wait_before_m12_write) {
+                              int lds_pad_bytes, hipEvent_t wait_before_m12_write, hipEvent_t* tev) {
     if (B <= 0 || row_stride <= 0) return;
     const dim3 grid2((row_stride + 255) / 256, B);
     const int nseg = knn_pick_nseg(B, row_stride, w.knn_capacity);
     (void)hipMemsetAsync(w.need, 0, (size_t)B * row_stride * sizeof(int32_t), s);
+    if (tev) (void)hipEventRecord(tev[0], s);
     launch_hamming_knn2(s, B, row_stride, row_stride, d1, n1, d2, n2, w.knn12, w.knn21, 0, lds_pad_bytes, 0, nullptr,
                         nullptr, nseg);
+    if (tev) (void)hipEventRecord(tev[1], s);
     hipLaunchKernelGGL(nnr_forward_kernel, grid2, dim3(256), 0, s, nseg, row_stride, w.knn12, n1, n2, nnr, w.cand, w.need);
     hipLaunchKernelGGL(compact_need_kernel, dim3(B), dim3(256), 0, s, row_stride, w.need, n2, w.qsel, w.nsel);
+    if (tev) (void)hipEventRecord(tev[2], s);
     launch_hamming_knn2(s, B, row_stride, row_stride, d1, n1, d2, n2, w.knn12, w.knn21, 0, lds_pad_bytes, 1, w.qsel,
                         w.nsel, nseg);
+    if (tev) (void)hipEventRecord(tev[3], s);
     if (wait_before_m12_write) (void)hipStreamWaitEvent(s, wait_before_m12_write, 0);
     hipLaunchKernelGGL(nnr_reverse_check_kernel, grid2, dim3(256), 0, s, nseg, row_stride, w.cand, w.knn21, n1, nnr, m12);
 }

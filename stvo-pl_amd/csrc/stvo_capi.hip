@@ -84,6 +84,7 @@ int stvo_ctx_destroy(stvo_ctx* ctx) {
     if (ctx->arena) hipFree(ctx->arena);
     if (ctx->arena_host) hipHostFree(ctx->arena_host);
     if (ctx->probe_sink) hipFree(ctx->probe_sink);
+    for (hipEvent_t e : ctx->ev_pool) hipEventDestroy(e);
     if (ctx->aux_stream) {
         hipStreamSynchronize(ctx->aux_stream);
         hipStreamDestroy(ctx->aux_stream);
@@ -368,7 +369,19 @@ int stvo_track_batched_dev(stvo_ctx* ctx, const stvo_track_batch_dev* b, const s
     auto match_set = [&](int stride, const uint8_t* da, const int32_t* na, const uint8_t* db, const int32_t* nb,
                          float nnr, int32_t* m12) {
         if (mutual) {
-            stvo::launch_match_mutual_lazy(ctx->stream, b->B, stride, da, na, db, nb, nnr, w, m12, pad, prev_pose);
+            hipEvent_t* tev = nullptr;
+            if (ctx->timing && da == b->prev_pdesc) {  // time the point-descriptor launches only
+                while (ctx->ev_pool.size() < ctx->ev_used + 4) {
+                    hipEvent_t e;
+                    if (hipEventCreate(&e) != hipSuccess) break;
+                    ctx->ev_pool.push_back(e);
+                }
+                if (ctx->ev_pool.size() >= ctx->ev_used + 4) {
+                    tev = ctx->ev_pool.data() + ctx->ev_used;
+                    ctx->ev_used += 4;
+                }
+            }
+            stvo::launch_match_mutual_lazy(ctx->stream, b->B, stride, da, na, db, nb, nnr, w, m12, pad, prev_pose, tev);
         } else {
             const int nseg = stvo::knn_pick_nseg(b->B, stride, ctx->knn_capacity);
             stvo::launch_hamming_knn2(ctx->stream, b->B, stride, stride, da, na, db, nb, ctx->knn12, ctx->knn21, 0, pad, 0,
@@ -475,6 +488,34 @@ int stvo_last_reverse_counts(stvo_ctx* ctx, int B, int32_t* counts) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(counts, ctx->nsel, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return STVO_OK;
+}
+
+int stvo_ctx_set_kernel_timing(stvo_ctx* ctx, int enable) {
+    if (!ctx) return STVO_ERR_INVALID_ARG;
+    ctx->timing = enable ? 1 : 0;
+    ctx->ev_used = 0;
+    return STVO_OK;
+}
+
+int stvo_ctx_get_kernel_timing(stvo_ctx* ctx, float* avg_ms_forward, float* avg_ms_reverse, int32_t* n_pairs) {
+    if (!ctx || !avg_ms_forward || !avg_ms_reverse || !n_pairs) return STVO_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    double f = 0.0, r = 0.0;
+    int n = 0;
+    for (size_t k = 0; k + 4 <= ctx->ev_used; k += 4) {
+        float a = 0.f, c = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&a, ctx->ev_pool[k], ctx->ev_pool[k + 1]));
+        HIP_TRY(ctx, hipEventElapsedTime(&c, ctx->ev_pool[k + 2], ctx->ev_pool[k + 3]));
+        f += a;
+        r += c;
+        ++n;
+    }
+    *n_pairs = n;
+    *avg_ms_forward = n ? (float)(f / n) : 0.f;
+    *avg_ms_reverse = n ? (float)(r / n) : 0.f;
+    ctx->ev_used = 0;
     return STVO_OK;
 }
 

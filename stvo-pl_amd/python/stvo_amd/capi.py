@@ -18,7 +18,7 @@ EXPORTS = ["stvo_backend_name", "stvo_abi_version", "stvo_error_string", "stvo_c
            "stvo_ctx_destroy", "stvo_ctx_set_stream", "stvo_ctx_synchronize", "stvo_ctx_set_overlap", "stvo_match_nnr_mutual",
            "stvo_match_grid_points", "stvo_match_grid_lines", "stvo_normal_eq", "stvo_optimize_pose",
            "stvo_track_batched_dev", "stvo_match_nnr_mutual_batched_dev", "stvo_optimize_pose_batched_dev",
-           "stvo_time_stage_dev", "stvo_valu_peak_probe", "stvo_last_reverse_counts"]
+           "stvo_time_stage_dev", "stvo_valu_peak_probe", "stvo_last_reverse_counts", "stvo_ctx_set_kernel_timing", "stvo_ctx_get_kernel_timing"]
 
 u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
 i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
@@ -104,6 +104,8 @@ def load():
                                       C.c_float, C.c_int, C.c_int, C.POINTER(C.c_float)]
     L.stvo_valu_peak_probe.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     L.stvo_last_reverse_counts.argtypes = [C.c_void_p, C.c_int, i32p]
+    L.stvo_ctx_set_kernel_timing.argtypes = [C.c_void_p, C.c_int]
+    L.stvo_ctx_get_kernel_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int32)]
     _lib = L
     return L
 
@@ -219,6 +221,14 @@ class Context:
         v = C.c_double()
         self._chk(self.lib.stvo_valu_peak_probe(self.h, C.byref(v)))
         return v.value
+
+    def set_kernel_timing(self, enable):
+        self._chk(self.lib.stvo_ctx_set_kernel_timing(self.h, 1 if enable else 0))
+
+    def get_kernel_timing(self):
+        f = C.c_float(); r = C.c_float(); n = C.c_int32()
+        self._chk(self.lib.stvo_ctx_get_kernel_timing(self.h, C.byref(f), C.byref(r), C.byref(n)))
+        return f.value, r.value, n.value
 
     def last_reverse_counts(self, B):
         out = np.empty(B, np.int32)
