@@ -30,6 +30,20 @@ K1_LANE_OPS_PER_PAIR = 19
 VALU_PEAK_LANE_OPS = K1_LANE_OPS_PER_PAIR / (8 / 78.6e12 + 11 / 39.3e12)  # = 49.8e12
 
 
+def committed_traffic(kernel="hamming_knn2_kernel", path=os.path.join(ROOT, "profiles", "r01_c_hbm_counters.txt")):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, separate
+    `--pmc` runs summarised by tools/rocprof_summary.py; values there are KB per dispatch).  None if unavailable."""
+    try:
+        tot = {}
+        for line in open(path):
+            f = line.split()
+            if len(f) >= 6 and f[4] in ("FETCH_SIZE", "WRITE_SIZE") and kernel in line:
+                tot[f[4]] = float(f[1]) * 1024.0
+        return tot["FETCH_SIZE"] + tot["WRITE_SIZE"] if len(tot) == 2 else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def cpu_baseline(frames, prm, budget_s=15.0):
     """The oracle (scalar C port of the reference path) timed on this box's host cores, 1 thread,
     on a bounded sample of the same workload.  Checker code: used here ONLY as the CPU baseline."""
@@ -152,9 +166,9 @@ def main():
                        "committed_pose_fraction": ok_frac,
                        "pose_overlaps_next_match": not args.no_overlap},
             "roofline": {"kernel": "hamming_knn2_kernel", "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
-                         "traffic_profile": "separate rocprofv3 --pmc passes, profiles/r01_c_hbm_counters.txt: FETCH_SIZE 48.8 MB + "
-                                            "WRITE_SIZE per launch, see file; <= 1.0x the algorithmic bytes (train rows come through the scalar cache / L2)",
+                         "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": committed_traffic(),
+                         "traffic_source": "bytes per launch = FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes, read from "
+                                           "the committed profiles/r01_c_hbm_counters.txt (not re-measured by this run)",
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k1_ms, "timing": "hipEvent pairs around each launch inside the timed region, on the launch stream",
                          "note": "K1 is integer-VALU bound (~1000 lane-ops per compulsory byte); see valu_roofline. Two launches "
                                  "per step (forward + lazy reverse); figures are per launch"},
