@@ -141,6 +141,24 @@ int stvo_match_nnr_mutual_batched_dev(stvo_ctx* ctx, int B, int row_stride, cons
 int stvo_optimize_pose_batched_dev(stvo_ctx* ctx, const stvo_track_batch_dev* batch, const stvo_cam* cam,
                                    const stvo_opt_params* params);
 
+/* ---- device-resident per-frame pipeline ------------------------------------ */
+
+/* B independent stereo sequences advancing in lock-step; all per-frame state (stereo point / line sets of the
+ * previous frame, grids, matches) lives in HBM.  Replaces, per pushed frame and per sequence,
+ * StereoFrameHandler::initialize / insertStereoPair + optimizePose + updateFrame minus feature detection
+ * (src/stereoFrameHandler.cpp:35-60, 307-392, 89-100): stereo association on the 64x48 grid
+ * (src/stereoFrame.cpp:120-173, 309-415), f2f tracking, pose optimisation.  The Tfw composition (:377-378) and the
+ * adaptive FAST threshold (:66-86, a front-end knob) stay with the caller.  init_T is the identity
+ * (use_motion_model = false, as in every shipped configuration). */
+typedef struct stvo_seq stvo_seq;
+int stvo_seq_create(stvo_ctx* ctx, int B, int max_keypoints, int max_keylines, int img_cols, int img_rows,
+                    const stvo_cam* cam, const stvo_match_params* mp, const stvo_opt_params* op, stvo_seq** out);
+int stvo_seq_destroy(stvo_seq* seq);
+/* One upload, one synchronisation, one small download per frame.  results: [B] (zeroed for the first frame, which
+ * only builds the stereo sets); counts: optional [B][4] = stereo points, stereo lines, matched points, matched
+ * lines of this frame. */
+int stvo_seq_push(stvo_seq* seq, const stvo_frame_features* frame, stvo_pose_result* results, int32_t* counts);
+
 /* ---- measurement helpers --------------------------------------------------------------------- */
 /* Times `iters` launches of the named kernel stage on the context's stream with hipEvents and
  * returns the average milliseconds per launch (used by bench.py for the roofline line).

@@ -119,6 +119,28 @@ typedef struct stvo_matched {
     int32_t* inlier_l;     /* [nl]                                                       */
 } stvo_matched;
 
+/* Extracted features of ONE frame for B independent sequences: what detectStereoPoints / detectStereoLineSegments
+ * leave behind before the stereo association (src/stereoFrame.cpp:88-100,191-203).  Host pointers; per-sequence
+ * arrays are strided by stride_kp / stride_kl rows.  Key-points are cv::KeyPoint::pt (float x, y) + octave;
+ * key-lines are line_descriptor::KeyLine start/end points (float) + octave; descriptors are 32-byte rows. */
+typedef struct stvo_frame_features {
+    int32_t stride_kp, stride_kl;
+    const int32_t* n_kp_l;   /* [B] */
+    const int32_t* n_kp_r;   /* [B] */
+    const float* kp_l;       /* [B][stride_kp][2] */
+    const int32_t* oct_l;    /* [B][stride_kp]    */
+    const uint8_t* desc_l;   /* [B][stride_kp][32] */
+    const float* kp_r;       /* [B][stride_kp][2] */
+    const uint8_t* desc_r;   /* [B][stride_kp][32] */
+    const int32_t* n_kl_l;   /* [B] (may be NULL: no lines) */
+    const int32_t* n_kl_r;   /* [B] */
+    const float* kl_l;       /* [B][stride_kl][4]  sx, sy, ex, ey */
+    const int32_t* oct_ll;   /* [B][stride_kl]    */
+    const uint8_t* ldesc_l;  /* [B][stride_kl][32] */
+    const float* kl_r;       /* [B][stride_kl][4] */
+    const uint8_t* ldesc_r;  /* [B][stride_kl][32] */
+} stvo_frame_features;
+
 /* Error codes of the C-ABI (0 ok, <0 error; never throws). */
 enum {
     STVO_OK = 0,

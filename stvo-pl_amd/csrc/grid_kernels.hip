@@ -58,6 +58,32 @@ struct GridArgs {
     int32_t* m12;                // [n1]
 };
 
+// per-frame view of a batch (blockIdx.y = frame pair)
+__device__ __forceinline__ GridArgs frame_view(const GridBatch& g, int b) {
+    GridArgs a;
+    a.cell_xy1 = g.cell_xy1 + (size_t)b * g.stride1 * g.xy_width;
+    a.d1 = g.d1 + (size_t)b * g.stride1 * STVO_DESC_BYTES;
+    a.n1 = g.n1[b];
+    a.cell_start = g.cell_start + (size_t)b * (STVO_GRID_CELLS + 1);
+    a.cell_items = g.cell_items + (size_t)b * g.items_stride;
+    a.d2 = g.d2 + (size_t)b * g.stride2 * STVO_DESC_BYTES;
+    a.n2 = g.n2[b];
+    a.dir2 = g.dir2 ? g.dir2 + (size_t)b * g.stride2 * 2 : nullptr;
+    a.w = g.w;
+    a.ratio = g.ratio;
+    a.line_sim_th = g.line_sim_th;
+    a.mutual = g.mutual;
+    a.words64 = g.words64;
+    a.n1p = g.n1p;
+    a.cover = g.cover + (size_t)b * g.words64 * g.n1p;
+    a.rank = g.rank + (size_t)b * g.stride2;
+    a.perm = g.perm + (size_t)b * g.stride2;
+    a.top2 = g.top2 + (size_t)b * g.stride1;
+    a.owner2 = g.owner2 + (size_t)b * g.stride2;
+    a.m12 = g.m12 + (size_t)b * g.stride1;
+    return a;
+}
+
 __device__ __forceinline__ void cover_window(const GridArgs& a, int x, int y, int i1) {
     // GridStructure::get clamping (src/gridStructure.cpp:67-71)
     const int min_x = max(0, x - a.w.w_lo), max_x = min(STVO_GRID_COLS, x + a.w.w_hi + 1);
@@ -77,7 +103,8 @@ __device__ __forceinline__ void cover_window(const GridArgs& a, int x, int y, in
 }
 
 template <bool LINES>
-__global__ __launch_bounds__(256) void grid_cover_kernel(GridArgs a) {
+__global__ __launch_bounds__(256) void grid_cover_kernel(GridBatch g) {
+    const GridArgs a = frame_view(g, blockIdx.y);
     const int i1 = blockIdx.x * 256 + threadIdx.x;
     if (i1 >= a.n1) return;
     // cover is zeroed by the host (hipMemsetAsync)
@@ -116,7 +143,8 @@ __device__ __forceinline__ void top2_insert(unsigned long long* slot, uint32_t k
 }
 
 template <bool LINES>
-__global__ __launch_bounds__(256) void grid_scan_kernel(GridArgs a) {
+__global__ __launch_bounds__(256) void grid_scan_kernel(GridBatch g) {
+    const GridArgs a = frame_view(g, blockIdx.y);
     // lane = scan position p; positions follow the CSR (cell) order of the right features, so the 64
     // features of a wave are spatial neighbours and only the few left features whose window touches
     // that neighbourhood have a non-zero mask: the scan skips 8 left features per scalar load.
@@ -183,9 +211,14 @@ __global__ __launch_bounds__(256) void grid_scan_kernel(GridArgs a) {
     if (live) a.owner2[i2] = owner;
 }
 
-__global__ __launch_bounds__(256) void grid_finalize_kernel(GridArgs a) {
+__global__ __launch_bounds__(256) void grid_finalize_kernel(GridBatch g) {
+    const GridArgs a = frame_view(g, blockIdx.y);
     const int i1 = blockIdx.x * 256 + threadIdx.x;
-    if (i1 >= a.n1) return;
+    if (i1 >= g.stride1) return;
+    if (i1 >= a.n1) {
+        a.m12[i1] = -1;
+        return;
+    }
     const unsigned long long t = a.top2[i1];
     const uint32_t b = (uint32_t)t, s = (uint32_t)(t >> 32);
     int m = -1;
@@ -197,6 +230,25 @@ __global__ __launch_bounds__(256) void grid_finalize_kernel(GridArgs a) {
     if (a.mutual && m >= 0 && a.owner2[m] != i1) m = -1;  // :166-174
     a.m12[i1] = m;
 }
+
+}  // namespace
+
+// cover (zeroed here) -> scan -> finalize for a batch of frame pairs
+void launch_grid_batch(hipStream_t s, const GridBatch& g, bool lines) {
+    if (g.B <= 0 || g.stride1 <= 0 || g.stride2 <= 0) return;
+    (void)hipMemsetAsync(g.cover, 0, (size_t)g.B * g.words64 * g.n1p * sizeof(unsigned long long), s);
+    const dim3 g1((g.stride1 + 255) / 256, g.B), g2((g.stride2 + 255) / 256, g.B), blk(256);
+    if (lines) {
+        hipLaunchKernelGGL((grid_cover_kernel<true>), g1, blk, 0, s, g);
+        hipLaunchKernelGGL((grid_scan_kernel<true>), g2, blk, 0, s, g);
+    } else {
+        hipLaunchKernelGGL((grid_cover_kernel<false>), g1, blk, 0, s, g);
+        hipLaunchKernelGGL((grid_scan_kernel<false>), g2, blk, 0, s, g);
+    }
+    hipLaunchKernelGGL(grid_finalize_kernel, g1, blk, 0, s, g);
+}
+
+namespace {
 
 template <bool LINES>
 int run_grid(stvo_ctx* ctx, const int32_t* cell_xy1, const uint8_t* d1, int n1, const int32_t* cell_start,
@@ -219,9 +271,9 @@ int run_grid(stvo_ctx* ctx, const int32_t* cell_xy1, const uint8_t* d1, int n1, 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->arena_off = 0;
     ctx->upload_hi = 0;
-    GridArgs a;
+    GridBatch a;
     std::memset(&a, 0, sizeof(a));
-    int32_t *dxy, *dstart, *ditems, *downer, *dm12;
+    int32_t *dxy, *dstart, *ditems, *downer, *dm12, *dn1, *dn2;
     uint8_t *dd1, *dd2;
     double* ddir = nullptr;
     TRY(upload(ctx, &dxy, cell_xy1, (size_t)n1 * (LINES ? 4 : 2)));
@@ -230,6 +282,13 @@ int run_grid(stvo_ctx* ctx, const int32_t* cell_xy1, const uint8_t* d1, int n1, 
     TRY(upload(ctx, &ditems, cell_items, (size_t)n_items));
     TRY(upload(ctx, &dd2, d2, (size_t)n2 * STVO_DESC_BYTES));
     if (LINES) TRY(upload(ctx, &ddir, dir2, (size_t)n2 * 2));
+    TRY(upload(ctx, &dn1, &n1, 1));
+    TRY(upload(ctx, &dn2, &n2, 1));
+    a.B = 1;
+    a.stride1 = n1;
+    a.stride2 = n2;
+    a.xy_width = LINES ? 4 : 2;
+    a.items_stride = n_items;
     a.words64 = (n2 + 63) / 64;
     a.n1p = (n1 + 7) & ~7;
     // scan order of the right features = order of first appearance in the CSR grid (cell-major, i.e.
@@ -261,11 +320,11 @@ int run_grid(stvo_ctx* ctx, const int32_t* cell_xy1, const uint8_t* d1, int n1, 
     if (!a.cover || !a.top2 || !downer || !dm12) return STVO_ERR_CAPACITY;
     a.cell_xy1 = dxy;
     a.d1 = dd1;
-    a.n1 = n1;
+    a.n1 = dn1;
     a.cell_start = dstart;
     a.cell_items = ditems;
     a.d2 = dd2;
-    a.n2 = n2;
+    a.n2 = dn2;
     a.dir2 = ddir;
     a.w = *w;
     a.ratio = ratio;
@@ -273,11 +332,7 @@ int run_grid(stvo_ctx* ctx, const int32_t* cell_xy1, const uint8_t* d1, int n1, 
     a.mutual = mutual;
     a.owner2 = downer;
     a.m12 = dm12;
-    HIP_TRY(ctx, hipMemsetAsync(a.cover, 0, (size_t)a.n1p * a.words64 * sizeof(unsigned long long), ctx->stream));
-    const dim3 g1((n1 + 255) / 256), g2((n2 + 255) / 256), blk(256);
-    hipLaunchKernelGGL((grid_cover_kernel<LINES>), g1, blk, 0, ctx->stream, a);
-    hipLaunchKernelGGL((grid_scan_kernel<LINES>), g2, blk, 0, ctx->stream, a);
-    hipLaunchKernelGGL(grid_finalize_kernel, g1, blk, 0, ctx->stream, a);
+    launch_grid_batch(ctx->stream, a, LINES);
     TRY(check_launch(ctx));
     TRY(download_begin(ctx, dm12, (size_t)n1 * sizeof(int32_t)));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

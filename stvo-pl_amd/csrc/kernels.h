@@ -77,4 +77,30 @@ struct PoseArgs {
 };
 int launch_pose(hipStream_t s, const PoseArgs& a);
 
+// ---- K3: grid-windowed stereo matchers, batched over frame pairs (blockIdx.y) ----------------------
+struct GridBatch {
+    int B, stride1, stride2;   // frame pairs; rows per frame of the left / right feature arrays
+    int xy_width;              // 2 (points: cx, cy) or 4 (lines: sx, sy, ex, ey)
+    int items_stride;          // CSR items per frame
+    int words64, n1p;          // ceil(stride2 / 64); stride1 rounded up to 8
+    const int32_t* cell_xy1;   // [B][stride1][xy_width]
+    const uint8_t* d1;         // [B][stride1][32]
+    const int32_t* n1;         // [B]
+    const int32_t* cell_start; // [B][3073]
+    const int32_t* cell_items; // [B][items_stride]
+    const uint8_t* d2;         // [B][stride2][32]
+    const int32_t* n2;         // [B]
+    const double* dir2;        // [B][stride2][2] (lines) or nullptr
+    stvo_grid_window w;
+    double ratio, line_sim_th;
+    int mutual;
+    unsigned long long* cover; // [B][words64][n1p] scratch
+    const int32_t* rank;       // [B][stride2] right feature id -> scan position
+    const int32_t* perm;       // [B][stride2] scan position -> right feature id
+    unsigned long long* top2;  // [B][stride1] scratch
+    int32_t* owner2;           // [B][stride2] scratch
+    int32_t* m12;              // [B][stride1] out
+};
+void launch_grid_batch(hipStream_t s, const GridBatch& g, bool lines);
+
 }  // namespace stvo

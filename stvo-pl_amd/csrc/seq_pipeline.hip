@@ -1,0 +1,727 @@
+// seq_pipeline.hip — device-resident per-frame pipeline for B independent stereo sequences (SURVEY.md §8f
+// rank 1): everything between "features extracted" and "pose committed" stays in HBM.
+//
+//   stvo_seq_push(features of frame k for B sequences)
+//     1  point_cells_kernel   cell coordinates of the left key-points, CSR grid of the right key-points
+//                             (/root/reference/src/stereoFrame.cpp:129-139; GridStructure as CSR)
+//     2  K3 grid matcher      StVO::matchGrid (points)               (src/matching.cpp:111-177)
+//     3  point_tail_kernel    epipolar / disparity filters, back-projection, sigma2, ordered compaction of
+//                             the stereo points and their descriptor rows (stereoFrame.cpp:149-172)
+//     4  line_cells_kernel    end-point cells, Bresenham rasterisation of the right lines into the CSR grid,
+//                             unit directions (stereoFrame.cpp:318-338, src/lineIterator.cpp:34-77)
+//     5  K3 grid matcher      StVO::matchGrid (lines)                (src/matching.cpp:179-258)
+//     6  line_tail_kernel     overlap, end-point re-intersection, disparity filters, back-projection,
+//                             ordered compaction (stereoFrame.cpp:348-397, :405-415, :473-508)
+//     7  K1/K2                f2f mutual matching against the previous frame's stereo sets
+//                             (src/stereoFrameHandler.cpp:131-180 -> matching.cpp:63-91)
+//     8  pose kernel          optimizePose                           (src/stereoFrameHandler.cpp:307-392)
+//   then the two stereo-set buffers swap roles (updateFrame, :89-100).  One upload, one small download
+//   (B pose results + counters) and one synchronisation per frame.
+#include <vector>
+
+#include "ctx_internal.h"
+#include "pose_math.h"
+
+namespace stvo {
+namespace {
+
+constexpr int LENT = STVO_GRID_COLS + STVO_GRID_ROWS + 4;  // upper bound of Bresenham cells of one in-image line
+
+struct SeqDev {
+    int B, K, M;
+    double inv_w, inv_h;
+    stvo_cam cam;
+    stvo_match_params mp;
+    // raw features of the current frame
+    const float* kp_l;      // [B][K][2]
+    const int32_t* oct_l;   // [B][K]
+    const uint8_t* desc_l;  // [B][K][32]
+    const int32_t* n_kp_l;  // [B]
+    const float* kp_r;
+    const uint8_t* desc_r;
+    const int32_t* n_kp_r;
+    const float* kl_l;      // [B][M][4]
+    const int32_t* oct_ll;  // [B][M]
+    const uint8_t* ldesc_l;
+    const int32_t* n_kl_l;
+    const float* kl_r;
+    const uint8_t* ldesc_r;
+    const int32_t* n_kl_r;
+    // grid scratch
+    int32_t* pxy_l;    // [B][K][2]
+    int32_t* pstart;   // [B][3073]
+    int32_t* pitems;   // [B][K]
+    int32_t* prank;    // [B][K]
+    int32_t* pperm;    // [B][K]
+    int32_t* lxy_l;    // [B][M][4]
+    int32_t* lstart;   // [B][3073]
+    int32_t* litems;   // [B][M*LENT]
+    int32_t* lrank;    // [B][M]
+    int32_t* lperm;    // [B][M]
+    double* ldir;      // [B][M][2]
+    const int32_t* m12s_p;  // [B][K] stereo matches of the left points
+    const int32_t* m12s_l;  // [B][M]
+    // stereo set being built (curr)
+    double* pl;     // [B][K][2]
+    double* P;      // [B][K][3]
+    double* s2;     // [B][K]
+    uint8_t* desc;  // [B][K][32]
+    int32_t* n;     // [B]
+    double* spl;    // [B][M][2]
+    double* epl;
+    double* sP;     // [B][M][3]
+    double* eP;
+    double* le;     // [B][M][3]
+    double* s2l;    // [B][M] stereo sigma2
+    double* s2lm;   // [B][M] sigma2 after LineFeature::safeCopy's re-scaling (what matched_ls carries)
+    uint8_t* ldesc;
+    int32_t* nl;
+};
+
+__device__ __forceinline__ bool in_grid(int x, int y) {
+    return x >= 0 && x < STVO_GRID_COLS && y >= 0 && y < STVO_GRID_ROWS;
+}
+
+// exclusive scan of hist[0..3072) in LDS by 256 threads (12 cells each); writes start[0..3072]
+__device__ __forceinline__ void scan_cells(int* hist, int* s_wave, int32_t* start_out) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    constexpr int PER = STVO_GRID_CELLS / 256;  // 12
+    int local[PER];
+    int sum = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        local[k] = hist[tid * PER + k];
+        sum += local[k];
+    }
+    int incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) s_wave[wv] = incl;
+    __syncthreads();
+    int base = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+        if (w < wv) base += s_wave[w];
+    int run = base + incl - sum;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        hist[tid * PER + k] = run;  // hist becomes the exclusive start
+        start_out[tid * PER + k] = run;
+        run += local[k];
+    }
+    if (tid == 255) start_out[STVO_GRID_CELLS] = run;
+    __syncthreads();
+}
+
+// ---- 1: points — cells + CSR of the right key-points -----------------------------------------------
+__global__ __launch_bounds__(256) void point_cells_kernel(SeqDev s) {
+    __shared__ int hist[STVO_GRID_CELLS];
+    __shared__ int fill[STVO_GRID_CELLS];
+    __shared__ int s_wave[4];
+    __shared__ int s_extra;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int nl = s.n_kp_l[b], nr = s.n_kp_r[b];
+    const size_t off = (size_t)b * s.K;
+    for (int i = tid; i < nl; i += 256) {  // float * double -> int truncation (stereoFrame.cpp:132)
+        s.pxy_l[(off + i) * 2 + 0] = (int)((double)s.kp_l[(off + i) * 2 + 0] * s.inv_w);
+        s.pxy_l[(off + i) * 2 + 1] = (int)((double)s.kp_l[(off + i) * 2 + 1] * s.inv_h);
+    }
+    for (int c = tid; c < STVO_GRID_CELLS; c += 256) {
+        hist[c] = 0;
+        fill[c] = 0;
+    }
+    if (tid == 0) s_extra = 0;
+    __syncthreads();
+    for (int i = tid; i < nr; i += 256) {
+        const int x = (int)((double)s.kp_r[(off + i) * 2 + 0] * s.inv_w);
+        const int y = (int)((double)s.kp_r[(off + i) * 2 + 1] * s.inv_h);
+        if (in_grid(x, y)) atomicAdd(&hist[y * STVO_GRID_COLS + x], 1);
+    }
+    __syncthreads();
+    scan_cells(hist, s_wave, s.pstart + (size_t)b * (STVO_GRID_CELLS + 1));
+    const int n_in = s.pstart[(size_t)b * (STVO_GRID_CELLS + 1) + STVO_GRID_CELLS];
+    for (int i = tid; i < nr; i += 256) {
+        const int x = (int)((double)s.kp_r[(off + i) * 2 + 0] * s.inv_w);
+        const int y = (int)((double)s.kp_r[(off + i) * 2 + 1] * s.inv_h);
+        int pos;
+        if (in_grid(x, y)) {
+            const int c = y * STVO_GRID_COLS + x;
+            pos = hist[c] + atomicAdd(&fill[c], 1);
+            s.pitems[off + pos] = i;
+        } else {  // the reference's out_of_bounds sink: never a candidate, scanned last
+            pos = n_in + atomicAdd(&s_extra, 1);
+        }
+        s.pperm[off + pos] = i;  // scan order = CSR (spatial) order
+        s.prank[off + i] = pos;
+    }
+}
+
+// ---- 3: points — filters, back-projection, ordered compaction ---------------------------------------
+__global__ __launch_bounds__(256) void point_tail_kernel(SeqDev s) {
+    __shared__ int s_wave[4];
+    __shared__ int s_run;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nl = s.n_kp_l[b];
+    const size_t off = (size_t)b * s.K;
+    if (tid == 0) s_run = 0;
+    __syncthreads();
+    for (int base = 0; base < nl; base += 256) {
+        const int i = base + tid;
+        bool ok = false;
+        double disp = 0.0;
+        if (i < nl) {
+            const int i2 = s.m12s_p[off + i];
+            if (i2 >= 0) {
+                const float yl = s.kp_l[(off + i) * 2 + 1], yr = s.kp_r[(off + i2) * 2 + 1];
+                if ((double)fabsf(yl - yr) <= s.mp.max_dist_epip) {  // float difference (:157)
+                    disp = (double)(s.kp_l[(off + i) * 2 + 0] - s.kp_r[(off + i2) * 2 + 0]);  // float difference (:159)
+                    ok = disp >= s.mp.min_disp;
+                }
+            }
+        }
+        // ordered compaction: stereo_pt / pdesc_l keep ascending left index (:161-172)
+        const unsigned long long bal = __ballot(ok);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wave[wv] = __popcll(bal);
+        __syncthreads();
+        int wbase = s_run;
+        for (int w = 0; w < wv; ++w) wbase += s_wave[w];
+        if (ok) {
+            const size_t k = off + (size_t)(wbase + before);
+            const double u = (double)s.kp_l[(off + i) * 2 + 0], v = (double)s.kp_l[(off + i) * 2 + 1];
+            const double bd = s.cam.b / disp;  // backProjection (src/pinholeStereoCamera.cpp:221-229)
+            s.pl[k * 2 + 0] = u;
+            s.pl[k * 2 + 1] = v;
+            s.P[k * 3 + 0] = bd * (u - s.cam.cx);
+            s.P[k * 3 + 1] = bd * (v - s.cam.cy);
+            s.P[k * 3 + 2] = bd * s.cam.fx;
+            double sg = 1.0;  // PointFeature ctor: sigma2 = 1 / scale^(2 level) (src/stereoFeatures.cpp:41-47)
+            const int level = s.oct_l[off + i];
+            for (int t = 0; t < level; ++t) sg *= s.mp.orb_scale_factor;
+            s.s2[k] = 1.0 / (sg * sg);
+            const uint4* src = reinterpret_cast<const uint4*>(s.desc_l + (off + i) * STVO_DESC_BYTES);
+            uint4* dst = reinterpret_cast<uint4*>(s.desc + k * STVO_DESC_BYTES);
+            dst[0] = src[0];
+            dst[1] = src[1];
+        }
+        __syncthreads();
+        if (tid == 0) s_run += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        __syncthreads();
+    }
+    if (tid == 0) s.n[b] = s_run;
+}
+
+// LineIterator (src/lineIterator.cpp:34-77): calls f(x, y) for every Bresenham cell
+template <typename F>
+__device__ __forceinline__ void bresenham(double x1, double y1, double x2, double y2, F f) {
+    const bool steep = fabs(y2 - y1) > fabs(x2 - x1);
+    double t;
+    if (steep) {
+        t = x1; x1 = y1; y1 = t;
+        t = x2; x2 = y2; y2 = t;
+    }
+    if (x1 > x2) {
+        t = x1; x1 = x2; x2 = t;
+        t = y1; y1 = y2; y2 = t;
+    }
+    const double dx = x2 - x1, dy = fabs(y2 - y1);
+    double error = dx / 2.0;
+    const int ystep = (y1 < y2) ? 1 : -1;
+    int y = (int)y1;
+    const int maxX = (int)x2;
+    int guard = 0;
+    for (int x = (int)x1; x <= maxX && guard < LENT; ++x, ++guard) {
+        f(steep ? y : x, steep ? x : y);
+        error -= dy;
+        if (error < 0) {
+            y += ystep;
+            error += dx;
+        }
+    }
+}
+
+// ---- 4: lines — end-point cells, rasterised CSR of the right lines, directions ----------------------
+__global__ __launch_bounds__(256) void line_cells_kernel(SeqDev s) {
+    __shared__ int hist[STVO_GRID_CELLS];
+    __shared__ int fill[STVO_GRID_CELLS];
+    __shared__ int s_wave[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int nl = s.n_kl_l[b], nr = s.n_kl_r[b];
+    const size_t off = (size_t)b * s.M;
+    for (int i = tid; i < nl; i += 256) {  // :318-322
+        const float* kl = s.kl_l + (off + i) * 4;
+        s.lxy_l[(off + i) * 4 + 0] = (int)((double)kl[0] * s.inv_w);
+        s.lxy_l[(off + i) * 4 + 1] = (int)((double)kl[1] * s.inv_h);
+        s.lxy_l[(off + i) * 4 + 2] = (int)((double)kl[2] * s.inv_w);
+        s.lxy_l[(off + i) * 4 + 3] = (int)((double)kl[3] * s.inv_h);
+    }
+    for (int c = tid; c < STVO_GRID_CELLS; c += 256) {
+        hist[c] = 0;
+        fill[c] = 0;
+    }
+    __syncthreads();
+    for (int j = tid; j < nr; j += 256) {  // :325-338
+        const float* kl = s.kl_r + (off + j) * 4;
+        const double vx = (double)(kl[2] - kl[0]) * s.inv_w;  // float difference, then * double (:331)
+        const double vy = (double)(kl[3] - kl[1]) * s.inv_h;
+        const double mag = sqrt(vx * vx + vy * vy);
+        s.ldir[(off + j) * 2 + 0] = vx / mag;
+        s.ldir[(off + j) * 2 + 1] = vy / mag;
+        s.lperm[off + j] = j;  // few lines: identity scan order
+        s.lrank[off + j] = j;
+        bresenham((double)kl[0] * s.inv_w, (double)kl[1] * s.inv_h, (double)kl[2] * s.inv_w, (double)kl[3] * s.inv_h,
+                  [&](int x, int y) {
+                      if (in_grid(x, y)) atomicAdd(&hist[y * STVO_GRID_COLS + x], 1);
+                  });
+    }
+    __syncthreads();
+    scan_cells(hist, s_wave, s.lstart + (size_t)b * (STVO_GRID_CELLS + 1));
+    int32_t* items = s.litems + (size_t)b * s.M * LENT;
+    for (int j = tid; j < nr; j += 256) {
+        const float* kl = s.kl_r + (off + j) * 4;
+        bresenham((double)kl[0] * s.inv_w, (double)kl[1] * s.inv_h, (double)kl[2] * s.inv_w, (double)kl[3] * s.inv_h,
+                  [&](int x, int y) {
+                      if (in_grid(x, y)) {
+                          const int c = y * STVO_GRID_COLS + x;
+                          items[hist[c] + atomicAdd(&fill[c], 1)] = j;
+                      }
+                  });
+    }
+}
+
+// StereoFrame::lineSegmentOverlapStereo (src/stereoFrame.cpp:473-508; note length = eln - spn)
+__device__ __forceinline__ double overlap_stereo(double spl_obs, double epl_obs, double spl_proj, double epl_proj,
+                                                 double line_horiz_th) {
+    double overlap = 1.0;
+    if (fabs(epl_obs - spl_obs) > line_horiz_th) {
+        const double sln = pm::dmin(spl_obs, epl_obs), eln = pm::dmax(spl_obs, epl_obs);
+        const double spn = pm::dmin(spl_proj, epl_proj), epn = pm::dmax(spl_proj, epl_proj);
+        const double length = eln - spn;
+        if (epn < sln || spn > eln)
+            overlap = 0.0;
+        else if (epn > eln && spn < sln)
+            overlap = eln - sln;
+        else
+            overlap = pm::dmin(eln, epn) - pm::dmax(sln, spn);
+        if (length > (double)0.01f)
+            overlap = overlap / length;
+        else
+            overlap = 0.0;
+        if (overlap > 1.0) overlap = 1.0;
+    }
+    return overlap;
+}
+
+// ---- 6: lines — geometry filters, back-projection, ordered compaction --------------------------------
+__global__ __launch_bounds__(256) void line_tail_kernel(SeqDev s) {
+    __shared__ int s_wave[4];
+    __shared__ int s_run;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nl = s.n_kl_l[b];
+    const size_t off = (size_t)b * s.M;
+    if (tid == 0) s_run = 0;
+    __syncthreads();
+    for (int base = 0; base < nl; base += 256) {
+        const int i = base + tid;
+        bool ok = false;
+        double sp_l[2] = {0, 0}, ep_l[2] = {0, 0}, le_l[3] = {0, 0, 0}, disp_s = 0.0, disp_e = 0.0;
+        if (i < nl) {
+            const int i2 = s.m12s_l[off + i];
+            if (i2 >= 0) {
+                const float* l = s.kl_l + (off + i) * 4;
+                const float* r = s.kl_r + (off + i2) * 4;
+                sp_l[0] = (double)l[0]; sp_l[1] = (double)l[1];
+                ep_l[0] = (double)l[2]; ep_l[1] = (double)l[3];
+                // le_l = sp_l x ep_l (homogeneous, w = 1), normalised by |(l0, l1)|   (:353-355)
+                le_l[0] = sp_l[1] - ep_l[1];
+                le_l[1] = ep_l[0] - sp_l[0];
+                le_l[2] = sp_l[0] * ep_l[1] - sp_l[1] * ep_l[0];
+                const double nrm = sqrt(le_l[0] * le_l[0] + le_l[1] * le_l[1]);
+                le_l[0] /= nrm; le_l[1] /= nrm; le_l[2] /= nrm;
+                double sp_r[2] = {(double)r[0], (double)r[1]}, ep_r[2] = {(double)r[2], (double)r[3]};
+                const double overlap = overlap_stereo(sp_l[1], ep_l[1], sp_r[1], ep_r[1], s.mp.line_horiz_th);
+                // :363-364 — the second line reads the ALREADY overwritten sp_r (reference quirk, kept)
+                sp_r[0] = (sp_r[0] * (sp_l[1] - ep_r[1]) + ep_r[0] * (sp_r[1] - sp_l[1])) / (sp_r[1] - ep_r[1]);
+                sp_r[1] = sp_l[1];
+                ep_r[0] = (sp_r[0] * (ep_l[1] - ep_r[1]) + ep_r[0] * (sp_r[1] - ep_l[1])) / (sp_r[1] - ep_r[1]);
+                ep_r[1] = ep_l[1];
+                disp_s = sp_l[0] - sp_r[0];  // filterLineSegmentDisparity (:405-415)
+                disp_e = ep_l[0] - ep_r[0];
+                if (pm::dmin(disp_s, disp_e) / pm::dmax(disp_s, disp_e) < s.mp.ls_min_disp_ratio) {
+                    disp_s = -1.0;
+                    disp_e = -1.0;
+                }
+                ok = disp_s >= s.mp.min_disp && disp_e >= s.mp.min_disp && fabs(sp_l[1] - ep_l[1]) > s.mp.line_horiz_th &&
+                     fabs(sp_r[1] - ep_r[1]) > s.mp.line_horiz_th && overlap > s.mp.stereo_overlap_th;
+            }
+        }
+        const unsigned long long bal = __ballot(ok);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wave[wv] = __popcll(bal);
+        __syncthreads();
+        int wbase = s_run;
+        for (int w = 0; w < wv; ++w) wbase += s_wave[w];
+        if (ok) {
+            const size_t k = off + (size_t)(wbase + before);
+            const double bds = s.cam.b / disp_s, bde = s.cam.b / disp_e;
+            s.spl[k * 2 + 0] = sp_l[0]; s.spl[k * 2 + 1] = sp_l[1];
+            s.epl[k * 2 + 0] = ep_l[0]; s.epl[k * 2 + 1] = ep_l[1];
+            s.sP[k * 3 + 0] = bds * (sp_l[0] - s.cam.cx);
+            s.sP[k * 3 + 1] = bds * (sp_l[1] - s.cam.cy);
+            s.sP[k * 3 + 2] = bds * s.cam.fx;
+            s.eP[k * 3 + 0] = bde * (ep_l[0] - s.cam.cx);
+            s.eP[k * 3 + 1] = bde * (ep_l[1] - s.cam.cy);
+            s.eP[k * 3 + 2] = bde * s.cam.fx;
+            s.le[k * 3 + 0] = le_l[0]; s.le[k * 3 + 1] = le_l[1]; s.le[k * 3 + 2] = le_l[2];
+            const int level = s.oct_ll[off + i];
+            double sg = 1.0;  // LineFeature ctor (src/stereoFeatures.cpp:107-115)
+            for (int t = 0; t < level; ++t) sg *= s.mp.lsd_scale;
+            const double s2 = 1.0 / (sg * sg);
+            s.s2l[k] = s2;
+            double sm = s2;  // LineFeature::safeCopy re-applies the level scaling (:117-135)
+            for (int t = 0; t < level; ++t) sm *= s.mp.lsd_scale;
+            s.s2lm[k] = 1.0 / (sm * sm);
+            const uint4* src = reinterpret_cast<const uint4*>(s.ldesc_l + (off + i) * STVO_DESC_BYTES);
+            uint4* dst = reinterpret_cast<uint4*>(s.ldesc + k * STVO_DESC_BYTES);
+            dst[0] = src[0];
+            dst[1] = src[1];
+        }
+        __syncthreads();
+        if (tid == 0) s_run += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        __syncthreads();
+    }
+    if (tid == 0) s.nl[b] = s_run;
+}
+
+}  // namespace
+}  // namespace stvo
+
+// ======================================================================================================
+struct stvo_seq {
+    stvo_ctx* ctx = nullptr;
+    int B = 0, K = 0, M = 0, frame_idx = 0;
+    stvo_cam cam{};
+    stvo_match_params mp{};
+    stvo_opt_params op{};
+    double inv_w = 0, inv_h = 0;
+    char* dev = nullptr;     // one allocation, carved below
+    size_t dev_bytes = 0;
+    char* raw_host = nullptr;  // pinned mirror of the raw-feature block
+    size_t raw_bytes = 0;
+    stvo::SeqDev d{};          // pointers into `dev` (set = current)
+    // carve results
+    char* raw_dev = nullptr;
+    struct Set {
+        double *pl, *P, *s2;
+        uint8_t* desc;
+        int32_t* n;
+        double *spl, *epl, *sP, *eP, *le, *s2l, *s2lm;
+        uint8_t* ldesc;
+        int32_t* nl;
+    } set[2];
+    int cur = 0;
+    unsigned long long *cover, *top2;
+    int32_t *owner2, *m12s_p, *m12s_l, *m12p, *m12l, *inlp, *inll, *counts;
+    stvo_pose_result* results;
+    char* out_host = nullptr;  // pinned: results + counts
+    size_t off_kp_l, off_oct_l, off_desc_l, off_nkl, off_kp_r, off_desc_r, off_nkr, off_kl_l, off_oct_ll, off_ldesc_l,
+        off_nll, off_kl_r, off_ldesc_r, off_nlr;
+};
+
+namespace {
+
+struct Carver {
+    size_t off = 0;
+    size_t take(size_t bytes) {
+        const size_t o = off;
+        off += (bytes + 255) & ~size_t(255);
+        return o;
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+int stvo_seq_create(stvo_ctx* ctx, int B, int max_keypoints, int max_keylines, int img_cols, int img_rows,
+                    const stvo_cam* cam, const stvo_match_params* mp, const stvo_opt_params* op, stvo_seq** out) {
+    if (!ctx || !out || B <= 0 || max_keypoints <= 0 || max_keylines < 0 || img_cols <= 0 || img_rows <= 0 || !cam ||
+        !mp || !op)
+        return STVO_ERR_INVALID_ARG;
+    if (max_keypoints > STVO_POSE_MAX_POINTS || max_keylines > STVO_POSE_MAX_LINES) return STVO_ERR_CAPACITY;
+    if (B > ctx->max_batch || max_keypoints > ctx->max_rows) return STVO_ERR_CAPACITY;
+    if (!(mp->min_ratio_12_p <= 1.0f) || !(mp->min_ratio_12_l <= 1.0f)) return STVO_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    stvo_seq* s = new (std::nothrow) stvo_seq();
+    if (!s) return STVO_ERR_HIP;
+    s->ctx = ctx;
+    s->B = B;
+    const int K = s->K = (max_keypoints + 63) & ~63;
+    const int M = s->M = max_keylines > 0 ? ((max_keylines + 63) & ~63) : 64;
+    s->cam = *cam;
+    s->mp = *mp;
+    s->op = *op;
+    s->inv_w = STVO_GRID_COLS / (double)img_cols;  // stereoFrame.cpp:47-48
+    s->inv_h = STVO_GRID_ROWS / (double)img_rows;
+    const size_t nb = (size_t)B;
+    // ---- raw block (mirrored in pinned host memory, one H2D per frame)
+    Carver rc;
+    s->off_kp_l = rc.take(nb * K * 2 * 4);
+    s->off_oct_l = rc.take(nb * K * 4);
+    s->off_desc_l = rc.take(nb * K * 32);
+    s->off_nkl = rc.take(nb * 4);
+    s->off_kp_r = rc.take(nb * K * 2 * 4);
+    s->off_desc_r = rc.take(nb * K * 32);
+    s->off_nkr = rc.take(nb * 4);
+    s->off_kl_l = rc.take(nb * M * 4 * 4);
+    s->off_oct_ll = rc.take(nb * M * 4);
+    s->off_ldesc_l = rc.take(nb * M * 32);
+    s->off_nll = rc.take(nb * 4);
+    s->off_kl_r = rc.take(nb * M * 4 * 4);
+    s->off_ldesc_r = rc.take(nb * M * 32);
+    s->off_nlr = rc.take(nb * 4);
+    s->raw_bytes = rc.off;
+    // ---- everything else
+    Carver c;
+    const size_t o_raw = c.take(s->raw_bytes);
+    const size_t o_pxy = c.take(nb * K * 2 * 4), o_pstart = c.take(nb * (STVO_GRID_CELLS + 1) * 4), o_pitems = c.take(nb * K * 4),
+                 o_prank = c.take(nb * K * 4), o_pperm = c.take(nb * K * 4);
+    const size_t o_lxy = c.take(nb * M * 4 * 4), o_lstart = c.take(nb * (STVO_GRID_CELLS + 1) * 4),
+                 o_litems = c.take(nb * M * stvo::LENT * 4), o_lrank = c.take(nb * M * 4), o_lperm = c.take(nb * M * 4),
+                 o_ldir = c.take(nb * M * 2 * 8);
+    const int R = K > M ? K : M;
+    const size_t o_cover = c.take(nb * (size_t)(R / 64) * R * 8), o_top2 = c.take(nb * R * 8), o_owner = c.take(nb * R * 4);
+    const size_t o_m12sp = c.take(nb * K * 4), o_m12sl = c.take(nb * M * 4), o_m12p = c.take(nb * K * 4), o_m12l = c.take(nb * M * 4),
+                 o_inlp = c.take(nb * K * 4), o_inll = c.take(nb * M * 4), o_res = c.take(nb * sizeof(stvo_pose_result)),
+                 o_counts = c.take(nb * 4 * 4);
+    size_t o_set[2][14];
+    for (int t = 0; t < 2; ++t) {
+        o_set[t][0] = c.take(nb * K * 2 * 8);
+        o_set[t][1] = c.take(nb * K * 3 * 8);
+        o_set[t][2] = c.take(nb * K * 8);
+        o_set[t][3] = c.take(nb * K * 32);
+        o_set[t][4] = c.take(nb * 4);
+        o_set[t][5] = c.take(nb * M * 2 * 8);
+        o_set[t][6] = c.take(nb * M * 2 * 8);
+        o_set[t][7] = c.take(nb * M * 3 * 8);
+        o_set[t][8] = c.take(nb * M * 3 * 8);
+        o_set[t][9] = c.take(nb * M * 3 * 8);
+        o_set[t][10] = c.take(nb * M * 8);
+        o_set[t][11] = c.take(nb * M * 8);
+        o_set[t][12] = c.take(nb * M * 32);
+        o_set[t][13] = c.take(nb * 4);
+    }
+    s->dev_bytes = c.off;
+    bool ok = hip_ok(ctx, hipMalloc((void**)&s->dev, s->dev_bytes), "hipMalloc seq") &&
+              hip_ok(ctx, hipMemset(s->dev, 0, s->dev_bytes), "hipMemset seq") &&
+              hip_ok(ctx, hipHostMalloc((void**)&s->raw_host, s->raw_bytes, hipHostMallocDefault), "hipHostMalloc seq") &&
+              hip_ok(ctx, hipHostMalloc((void**)&s->out_host, nb * (sizeof(stvo_pose_result) + 16), hipHostMallocDefault),
+                     "hipHostMalloc seq out");
+    if (!ok) {
+        if (s->dev) hipFree(s->dev);
+        if (s->raw_host) hipHostFree(s->raw_host);
+        if (s->out_host) hipHostFree(s->out_host);
+        delete s;
+        return STVO_ERR_HIP;
+    }
+    std::memset(s->raw_host, 0, s->raw_bytes);
+    char* D = s->dev;
+    s->raw_dev = D + o_raw;
+    stvo::SeqDev& d = s->d;
+    d.B = B; d.K = K; d.M = M;
+    d.inv_w = s->inv_w; d.inv_h = s->inv_h;
+    d.cam = s->cam; d.mp = s->mp;
+    char* Rw = s->raw_dev;
+    d.kp_l = (const float*)(Rw + s->off_kp_l); d.oct_l = (const int32_t*)(Rw + s->off_oct_l);
+    d.desc_l = (const uint8_t*)(Rw + s->off_desc_l); d.n_kp_l = (const int32_t*)(Rw + s->off_nkl);
+    d.kp_r = (const float*)(Rw + s->off_kp_r); d.desc_r = (const uint8_t*)(Rw + s->off_desc_r);
+    d.n_kp_r = (const int32_t*)(Rw + s->off_nkr);
+    d.kl_l = (const float*)(Rw + s->off_kl_l); d.oct_ll = (const int32_t*)(Rw + s->off_oct_ll);
+    d.ldesc_l = (const uint8_t*)(Rw + s->off_ldesc_l); d.n_kl_l = (const int32_t*)(Rw + s->off_nll);
+    d.kl_r = (const float*)(Rw + s->off_kl_r); d.ldesc_r = (const uint8_t*)(Rw + s->off_ldesc_r);
+    d.n_kl_r = (const int32_t*)(Rw + s->off_nlr);
+    d.pxy_l = (int32_t*)(D + o_pxy); d.pstart = (int32_t*)(D + o_pstart); d.pitems = (int32_t*)(D + o_pitems);
+    d.prank = (int32_t*)(D + o_prank); d.pperm = (int32_t*)(D + o_pperm);
+    d.lxy_l = (int32_t*)(D + o_lxy); d.lstart = (int32_t*)(D + o_lstart); d.litems = (int32_t*)(D + o_litems);
+    d.lrank = (int32_t*)(D + o_lrank); d.lperm = (int32_t*)(D + o_lperm); d.ldir = (double*)(D + o_ldir);
+    s->cover = (unsigned long long*)(D + o_cover); s->top2 = (unsigned long long*)(D + o_top2);
+    s->owner2 = (int32_t*)(D + o_owner);
+    s->m12s_p = (int32_t*)(D + o_m12sp); s->m12s_l = (int32_t*)(D + o_m12sl);
+    s->m12p = (int32_t*)(D + o_m12p); s->m12l = (int32_t*)(D + o_m12l);
+    s->inlp = (int32_t*)(D + o_inlp); s->inll = (int32_t*)(D + o_inll);
+    s->results = (stvo_pose_result*)(D + o_res); s->counts = (int32_t*)(D + o_counts);
+    d.m12s_p = s->m12s_p; d.m12s_l = s->m12s_l;
+    for (int t = 0; t < 2; ++t) {
+        stvo_seq::Set& q = s->set[t];
+        q.pl = (double*)(D + o_set[t][0]); q.P = (double*)(D + o_set[t][1]); q.s2 = (double*)(D + o_set[t][2]);
+        q.desc = (uint8_t*)(D + o_set[t][3]); q.n = (int32_t*)(D + o_set[t][4]);
+        q.spl = (double*)(D + o_set[t][5]); q.epl = (double*)(D + o_set[t][6]); q.sP = (double*)(D + o_set[t][7]);
+        q.eP = (double*)(D + o_set[t][8]); q.le = (double*)(D + o_set[t][9]); q.s2l = (double*)(D + o_set[t][10]);
+        q.s2lm = (double*)(D + o_set[t][11]); q.ldesc = (uint8_t*)(D + o_set[t][12]); q.nl = (int32_t*)(D + o_set[t][13]);
+    }
+    *out = s;
+    return STVO_OK;
+}
+
+int stvo_seq_destroy(stvo_seq* s) {
+    if (!s) return STVO_OK;
+    hipSetDevice(s->ctx->device);
+    hipStreamSynchronize(s->ctx->stream);
+    if (s->ctx->aux_stream) hipStreamSynchronize(s->ctx->aux_stream);
+    if (s->dev) hipFree(s->dev);
+    if (s->raw_host) hipHostFree(s->raw_host);
+    if (s->out_host) hipHostFree(s->out_host);
+    delete s;
+    return STVO_OK;
+}
+
+// counts (optional, [B][4]): stereo points, stereo lines, matched points, matched lines of this frame
+int stvo_seq_push(stvo_seq* s, const stvo_frame_features* f, stvo_pose_result* results, int32_t* counts) {
+    if (!s || !f) return STVO_ERR_INVALID_ARG;
+    stvo_ctx* ctx = s->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int B = s->B, K = s->K, M = s->M;
+    // ---- gather the host arrays into the pinned raw block (row strides K / M), one H2D
+    char* H = s->raw_host;
+    int32_t* nkl = (int32_t*)(H + s->off_nkl);
+    int32_t* nkr = (int32_t*)(H + s->off_nkr);
+    int32_t* nll = (int32_t*)(H + s->off_nll);
+    int32_t* nlr = (int32_t*)(H + s->off_nlr);
+    for (int b = 0; b < B; ++b) {
+        const int a = f->n_kp_l ? f->n_kp_l[b] : 0, r = f->n_kp_r ? f->n_kp_r[b] : 0;
+        const int la = (f->n_kl_l && s->op.has_lines) ? f->n_kl_l[b] : 0, lr = (f->n_kl_r && s->op.has_lines) ? f->n_kl_r[b] : 0;
+        if (a < 0 || r < 0 || la < 0 || lr < 0 || a > K || r > K || la > M || lr > M || a > f->stride_kp || r > f->stride_kp ||
+            la > f->stride_kl || lr > f->stride_kl)
+            return STVO_ERR_CAPACITY;
+        nkl[b] = s->op.has_points ? a : 0;
+        nkr[b] = s->op.has_points ? r : 0;
+        nll[b] = la;
+        nlr[b] = lr;
+        const size_t so = (size_t)b * f->stride_kp, dof = (size_t)b * K;
+        if (nkl[b]) {
+            std::memcpy(H + s->off_kp_l + dof * 8, f->kp_l + so * 2, (size_t)a * 8);
+            std::memcpy(H + s->off_oct_l + dof * 4, f->oct_l + so, (size_t)a * 4);
+            std::memcpy(H + s->off_desc_l + dof * 32, f->desc_l + so * 32, (size_t)a * 32);
+        }
+        if (nkr[b]) {
+            std::memcpy(H + s->off_kp_r + dof * 8, f->kp_r + so * 2, (size_t)r * 8);
+            std::memcpy(H + s->off_desc_r + dof * 32, f->desc_r + so * 32, (size_t)r * 32);
+        }
+        const size_t sl = (size_t)b * f->stride_kl, dl = (size_t)b * M;
+        if (la) {
+            std::memcpy(H + s->off_kl_l + dl * 16, f->kl_l + sl * 4, (size_t)la * 16);
+            std::memcpy(H + s->off_oct_ll + dl * 4, f->oct_ll + sl, (size_t)la * 4);
+            std::memcpy(H + s->off_ldesc_l + dl * 32, f->ldesc_l + sl * 32, (size_t)la * 32);
+        }
+        if (lr) {
+            std::memcpy(H + s->off_kl_r + dl * 16, f->kl_r + sl * 4, (size_t)lr * 16);
+            std::memcpy(H + s->off_ldesc_r + dl * 32, f->ldesc_r + sl * 32, (size_t)lr * 32);
+        }
+    }
+    hipStream_t st = ctx->stream;
+    HIP_TRY(ctx, hipMemcpyAsync(s->raw_dev, s->raw_host, s->raw_bytes, hipMemcpyHostToDevice, st));
+
+    // ---- stereo association of the new frame into set[cur]
+    stvo_seq::Set& cs = s->set[s->cur];
+    stvo_seq::Set& ps = s->set[s->cur ^ 1];
+    stvo::SeqDev d = s->d;
+    d.pl = cs.pl; d.P = cs.P; d.s2 = cs.s2; d.desc = cs.desc; d.n = cs.n;
+    d.spl = cs.spl; d.epl = cs.epl; d.sP = cs.sP; d.eP = cs.eP; d.le = cs.le; d.s2l = cs.s2l; d.s2lm = cs.s2lm;
+    d.ldesc = cs.ldesc; d.nl = cs.nl;
+    const int R = K > M ? K : M;
+    (void)R;
+    if (s->op.has_points) {
+        hipLaunchKernelGGL(stvo::point_cells_kernel, dim3(B), dim3(256), 0, st, d);
+        stvo::GridBatch g;
+        std::memset(&g, 0, sizeof(g));
+        g.B = B; g.stride1 = K; g.stride2 = K; g.xy_width = 2; g.items_stride = K; g.words64 = K / 64; g.n1p = K;
+        g.cell_xy1 = d.pxy_l; g.d1 = d.desc_l; g.n1 = d.n_kp_l; g.cell_start = d.pstart; g.cell_items = d.pitems;
+        g.d2 = d.desc_r; g.n2 = d.n_kp_r; g.dir2 = nullptr;
+        g.w = stvo_grid_window{s->mp.matching_s_ws, 0, 0, 0};  // stereoFrame.cpp:141-143
+        g.ratio = (double)s->mp.min_ratio_12_p; g.line_sim_th = 0.0; g.mutual = s->mp.best_lr_matches;
+        g.cover = s->cover; g.rank = d.prank; g.perm = d.pperm; g.top2 = s->top2; g.owner2 = s->owner2; g.m12 = s->m12s_p;
+        stvo::launch_grid_batch(st, g, false);
+        hipLaunchKernelGGL(stvo::point_tail_kernel, dim3(B), dim3(256), 0, st, d);
+    } else {
+        HIP_TRY(ctx, hipMemsetAsync(cs.n, 0, (size_t)B * 4, st));
+    }
+    if (s->op.has_lines) {
+        hipLaunchKernelGGL(stvo::line_cells_kernel, dim3(B), dim3(256), 0, st, d);
+        stvo::GridBatch g;
+        std::memset(&g, 0, sizeof(g));
+        g.B = B; g.stride1 = M; g.stride2 = M; g.xy_width = 4; g.items_stride = M * stvo::LENT; g.words64 = M / 64; g.n1p = M;
+        g.cell_xy1 = d.lxy_l; g.d1 = d.ldesc_l; g.n1 = d.n_kl_l; g.cell_start = d.lstart; g.cell_items = d.litems;
+        g.d2 = d.ldesc_r; g.n2 = d.n_kl_r; g.dir2 = d.ldir;
+        g.w = stvo_grid_window{s->mp.matching_s_ws, 0, 0, 0};  // :340-342
+        g.ratio = (double)s->mp.min_ratio_12_p /* sic, matching.cpp:241 */; g.line_sim_th = s->mp.line_sim_th;
+        g.mutual = s->mp.best_lr_matches;
+        g.cover = s->cover; g.rank = d.lrank; g.perm = d.lperm; g.top2 = s->top2; g.owner2 = s->owner2; g.m12 = s->m12s_l;
+        stvo::launch_grid_batch(st, g, true);
+        hipLaunchKernelGGL(stvo::line_tail_kernel, dim3(B), dim3(256), 0, st, d);
+    } else {
+        HIP_TRY(ctx, hipMemsetAsync(cs.nl, 0, (size_t)B * 4, st));
+    }
+
+    const bool track = s->frame_idx > 0;
+    if (track) {
+        // ---- f2fTracking: prev stereo sets vs curr stereo sets
+        const stvo::LazyScratch w{ctx->knn12, ctx->knn21, ctx->cand, ctx->need, ctx->qsel, ctx->nsel, ctx->knn_capacity};
+        auto match_set = [&](int stride, const uint8_t* da, const int32_t* na, const uint8_t* db, const int32_t* nb, float nnr,
+                             int32_t* m12) {
+            if (s->mp.best_lr_matches) {
+                stvo::launch_match_mutual_lazy(st, B, stride, da, na, db, nb, nnr, w, m12, 0, nullptr);
+            } else {
+                const int nseg = stvo::knn_pick_nseg(B, stride, ctx->knn_capacity);
+                stvo::launch_hamming_knn2(st, B, stride, stride, da, na, db, nb, ctx->knn12, ctx->knn21, 0, 0, 0, nullptr,
+                                          nullptr, nseg);
+                stvo::launch_nnr_mutual(st, B, stride, ctx->knn12, ctx->knn21, na, nb, nnr, 0, m12, nseg);
+            }
+        };
+        if (s->op.has_points) match_set(K, ps.desc, ps.n, cs.desc, cs.n, s->mp.min_ratio_12_p, s->m12p);
+        if (s->op.has_lines) match_set(M, ps.ldesc, ps.nl, cs.ldesc, cs.nl, s->mp.min_ratio_12_l, s->m12l);
+        // ---- optimizePose
+        stvo::PoseArgs a;
+        std::memset(&a, 0, sizeof(a));
+        a.B = B; a.max_pts = K; a.max_lines = M;
+        a.n_prev_pts = s->op.has_points ? ps.n : nullptr;
+        a.prev_P = ps.P; a.prev_s2p = ps.s2; a.curr_pl = cs.pl; a.m12p = s->m12p;
+        a.n_prev_lines = s->op.has_lines ? ps.nl : nullptr;
+        a.prev_sP = ps.sP; a.prev_eP = ps.eP; a.prev_spl = ps.spl; a.prev_epl = ps.epl; a.prev_s2l = ps.s2lm;
+        a.curr_le = cs.le; a.m12l = s->m12l;
+        a.cam = s->cam; a.prm = s->op;
+        a.results = s->results; a.inl_p_out = s->inlp; a.inl_l_out = s->inll;
+        TRY(stvo::launch_pose(st, a));
+    }
+    TRY(check_launch(ctx));
+    // ---- one small download: results + stereo counts
+    char* OH = s->out_host;
+    const size_t res_bytes = (size_t)B * sizeof(stvo_pose_result);
+    if (track) HIP_TRY(ctx, hipMemcpyAsync(OH, s->results, res_bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(OH + res_bytes, cs.n, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(OH + res_bytes + (size_t)B * 4, cs.nl, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    const stvo_pose_result* hr = reinterpret_cast<const stvo_pose_result*>(OH);
+    const int32_t* hn = reinterpret_cast<const int32_t*>(OH + res_bytes);
+    for (int b = 0; b < B; ++b) {
+        if (results) {
+            if (track)
+                results[b] = hr[b];
+            else
+                std::memset(&results[b], 0, sizeof(stvo_pose_result));
+        }
+        if (counts) {
+            counts[4 * b + 0] = hn[b];
+            counts[4 * b + 1] = hn[B + b];
+            counts[4 * b + 2] = track ? hr[b].n_matched_pt : 0;
+            counts[4 * b + 3] = track ? hr[b].n_matched_ls : 0;
+        }
+    }
+    s->cur ^= 1;  // updateFrame: curr becomes prev
+    s->frame_idx++;
+    return STVO_OK;
+}
+
+}  // extern "C"

@@ -9,7 +9,7 @@ import subprocess
 
 import numpy as np
 
-from .ctypes_types import Cam, GridWindow, OptParams, PoseResult
+from .ctypes_types import Cam, GridWindow, MatchParams, OptParams, PoseResult, POSE_RESULT_DTYPE
 
 PKG_DIR = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # stvo-pl_amd/
 LIB_PATH = os.path.join(PKG_DIR, "libstvo_hip.so")
@@ -18,7 +18,8 @@ EXPORTS = ["stvo_backend_name", "stvo_abi_version", "stvo_error_string", "stvo_c
            "stvo_ctx_destroy", "stvo_ctx_set_stream", "stvo_ctx_synchronize", "stvo_ctx_set_overlap", "stvo_match_nnr_mutual",
            "stvo_match_grid_points", "stvo_match_grid_lines", "stvo_normal_eq", "stvo_optimize_pose",
            "stvo_track_batched_dev", "stvo_match_nnr_mutual_batched_dev", "stvo_optimize_pose_batched_dev",
-           "stvo_time_stage_dev", "stvo_valu_peak_probe", "stvo_last_reverse_counts", "stvo_ctx_set_kernel_timing", "stvo_ctx_get_kernel_timing"]
+           "stvo_time_stage_dev", "stvo_valu_peak_probe", "stvo_last_reverse_counts", "stvo_ctx_set_kernel_timing", "stvo_ctx_get_kernel_timing", "stvo_seq_create", "stvo_seq_destroy",
+           "stvo_seq_push"]
 
 u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
 i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
@@ -39,6 +40,12 @@ class TrackBatchDev(C.Structure):
                                           "prev_spl", "prev_epl", "prev_sigma2l", "n_curr_lines", "curr_ldesc",
                                           "curr_le", "init_T", "m12_pts", "m12_lines", "inlier_pts", "inlier_lines",
                                           "results")]
+
+
+class FrameFeatures(C.Structure):
+    _fields_ = [("stride_kp", C.c_int32), ("stride_kl", C.c_int32)] + \
+               [(n, C.c_void_p) for n in ("n_kp_l", "n_kp_r", "kp_l", "oct_l", "desc_l", "kp_r", "desc_r", "n_kl_l", "n_kl_r",
+                                          "kl_l", "oct_ll", "ldesc_l", "kl_r", "ldesc_r")]
 
 
 class StvoError(RuntimeError):
@@ -103,6 +110,10 @@ def load():
     L.stvo_time_stage_dev.argtypes = [C.c_void_p, C.POINTER(TrackBatchDev), C.POINTER(Cam), C.POINTER(OptParams),
                                       C.c_float, C.c_int, C.c_int, C.POINTER(C.c_float)]
     L.stvo_valu_peak_probe.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    L.stvo_seq_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Cam),
+                                  C.POINTER(MatchParams), C.POINTER(OptParams), C.POINTER(C.c_void_p)]
+    L.stvo_seq_destroy.argtypes = [C.c_void_p]
+    L.stvo_seq_push.argtypes = [C.c_void_p, C.POINTER(FrameFeatures), C.c_void_p, i32p]
     L.stvo_last_reverse_counts.argtypes = [C.c_void_p, C.c_int, i32p]
     L.stvo_ctx_set_kernel_timing.argtypes = [C.c_void_p, C.c_int]
     L.stvo_ctx_get_kernel_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int32)]
@@ -251,3 +262,45 @@ class Context:
         self._chk(self.lib.stvo_time_stage_dev(self.h, C.byref(batch.struct), C.byref(camc), C.byref(params), nnr,
                                                stage, iters, C.byref(ms)))
         return ms.value
+
+
+class Sequences:
+    """B independent stereo sequences on the device-resident per-frame pipeline (stvo_seq_*)."""
+
+    def __init__(self, ctx, B, max_kp, max_kl, cam, mp, op):
+        self.ctx, self.B = ctx, B
+        self.h = C.c_void_p()
+        camc = Cam.from_dict(cam)
+        ctx._chk(ctx.lib.stvo_seq_create(ctx.h, B, max_kp, max_kl, cam["width"], cam["height"], C.byref(camc), C.byref(mp),
+                                         C.byref(op), C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.stvo_seq_destroy(self.h)
+            self.h = None
+
+    def push(self, frames):
+        """frames: list of B per-sequence frame dicts as produced by synth.make_stereo_sequence."""
+        B = self.B
+        assert len(frames) == B
+        skp = max(max(len(f["kp_l"]), len(f["kp_r"])) for f in frames) or 1
+        skl = max(max(len(f["kl_l"]), len(f["kl_r"])) for f in frames) or 1
+        a = dict(n_kp_l=np.array([len(f["kp_l"]) for f in frames], np.int32), n_kp_r=np.array([len(f["kp_r"]) for f in frames], np.int32),
+                 n_kl_l=np.array([len(f["kl_l"]) for f in frames], np.int32), n_kl_r=np.array([len(f["kl_r"]) for f in frames], np.int32),
+                 kp_l=np.zeros((B, skp, 2), np.float32), oct_l=np.zeros((B, skp), np.int32), desc_l=np.zeros((B, skp, 32), np.uint8),
+                 kp_r=np.zeros((B, skp, 2), np.float32), desc_r=np.zeros((B, skp, 32), np.uint8),
+                 kl_l=np.zeros((B, skl, 4), np.float32), oct_ll=np.zeros((B, skl), np.int32), ldesc_l=np.zeros((B, skl, 32), np.uint8),
+                 kl_r=np.zeros((B, skl, 4), np.float32), ldesc_r=np.zeros((B, skl, 32), np.uint8))
+        for b, f in enumerate(frames):
+            n = len(f["kp_l"]); a["kp_l"][b, :n] = f["kp_l"]; a["oct_l"][b, :n] = f["oct_l"]; a["desc_l"][b, :n] = f["desc_l"]
+            n = len(f["kp_r"]); a["kp_r"][b, :n] = f["kp_r"]; a["desc_r"][b, :n] = f["desc_r"]
+            n = len(f["kl_l"]); a["kl_l"][b, :n] = f["kl_l"]; a["oct_ll"][b, :n] = f["oct_ll"]; a["ldesc_l"][b, :n] = f["ldesc_l"]
+            n = len(f["kl_r"]); a["kl_r"][b, :n] = f["kl_r"]; a["ldesc_r"][b, :n] = f["ldesc_r"]
+        ff = FrameFeatures()
+        ff.stride_kp, ff.stride_kl = skp, skl
+        for k, v in a.items():
+            setattr(ff, k, v.ctypes.data_as(C.c_void_p))
+        res = np.zeros(B, dtype=POSE_RESULT_DTYPE)
+        counts = np.zeros(B * 4, np.int32)
+        self.ctx._chk(self.ctx.lib.stvo_seq_push(self.h, C.byref(ff), res.ctypes.data_as(C.c_void_p), counts))
+        return res, counts.reshape(B, 4)

@@ -1,0 +1,73 @@
+"""GPU parity of the device-resident per-frame pipeline (stvo_seq_*: stereo association on the grid, tail filters,
+record building, f2f tracking and optimizePose all on the device, state kept in HBM across frames) against the
+oracle-driven pipeline, for several independent sequences advancing in lock-step."""
+import numpy as np
+import pytest
+
+import np_model
+import pipeline_ref
+from stvo_amd import synth
+from stvo_amd.ctypes_types import match_params, opt_params
+
+pytestmark = pytest.mark.gpu
+
+
+def run_and_compare(oracle, seqs, cam, preset, mode=0, has_lines=1, max_kp=2048, max_kl=320):
+    from stvo_amd import capi
+    B, nf = len(seqs), len(seqs[0])
+    mp = match_params(preset)
+    op = opt_params(preset, mode=mode, has_lines=has_lines)
+    ctx = capi.Context(device_id=0, max_rows=2048, max_batch=max(B, 1))
+    dev = capi.Sequences(ctx, B, max_kp, max_kl, cam, mp, op)
+    try:
+        refs = [pipeline_ref.run_sequence(oracle, seqs[b], cam, mp, op) for b in range(B)]
+        ref0 = [pipeline_ref.stereo_frame(oracle, seqs[b][0], cam, mp, True, bool(has_lines)) for b in range(B)]
+        for k in range(nf):
+            res, counts = dev.push([seqs[b][k] for b in range(B)])
+            for b in range(B):
+                if k == 0:
+                    assert counts[b, 0] == len(ref0[b]["P"]) and counts[b, 1] == len(ref0[b]["sP"])
+                    continue
+                o = refs[b][k - 1]
+                r = res[b]
+                assert counts[b, 0] == o["n_stereo_pt"] and counts[b, 1] == o["n_stereo_ls"], (b, k, counts[b], o["n_stereo_pt"], o["n_stereo_ls"])
+                assert r["n_matched_pt"] == o["n_matched_pt"] and r["n_matched_ls"] == o["n_matched_ls"]
+                assert r["status"] == o["status"] and r["path"] == o["path"] and tuple(r["iters"]) == o["iters"], (b, k)
+                assert r["n_inliers_pt"] == o["n_inliers_pt"] and r["n_inliers_ls"] == o["n_inliers_ls"]
+                T = r["T"].reshape(4, 4)
+                assert np_model.rot_angle(T[:3, :3], o["T"][:3, :3]) < 1e-4 and np.linalg.norm(T[:3, 3] - o["T"][:3, 3]) < 1e-3
+                assert np.allclose(T, o["T"], atol=1e-8) and np.isclose(r["err"], o["err"], rtol=1e-8)
+                assert np.allclose(r["cov"].reshape(6, 6), o["cov"], rtol=1e-6, atol=1e-12)
+    finally:
+        dev.close()
+        ctx.close()
+
+
+def test_seq_pipeline_kitti_points_and_lines(oracle):
+    cam = synth.KITTI_CAM
+    seqs = [synth.make_stereo_sequence(500 + b, n_frames=5, n_pts=600 + 150 * b, n_lines=60 + 10 * b, cam=cam) for b in range(3)]
+    run_and_compare(oracle, seqs, cam, "kitti")
+
+
+def test_seq_pipeline_kitti_points_only_2000(oracle):
+    cam = synth.KITTI_CAM
+    seqs = [synth.make_stereo_sequence(600 + b, n_frames=4, n_pts=1650, n_lines=0, cam=cam) for b in range(2)]
+    run_and_compare(oracle, seqs, cam, "kitti", has_lines=0)
+
+
+@pytest.mark.parametrize("mode", [0, 2])
+def test_seq_pipeline_euroc_line_heavy(oracle, mode):
+    cam = synth.EUROC_CAM
+    seqs = [synth.make_stereo_sequence(700 + b + mode, n_frames=4, n_pts=500, n_lines=200, cam=cam, depth=(1.0, 8.0),
+                                       octave_probs=[.5, .25, .15, .1], outlier_frac=0.2) for b in range(2)]
+    run_and_compare(oracle, seqs, cam, "euroc", mode=mode)
+
+
+def test_seq_pipeline_empty_and_tiny_frames(oracle):
+    """Frames with no right features, no lines, or too few features: in-band failures, no crashes."""
+    cam = synth.KITTI_CAM
+    seq = synth.make_stereo_sequence(800, n_frames=4, n_pts=300, n_lines=30, cam=cam)
+    z2 = np.zeros((0, 2), np.float32); zd = np.zeros((0, 32), np.uint8); z4 = np.zeros((0, 4), np.float32)
+    seq[2] = dict(seq[2], kp_r=z2, desc_r=zd, kl_r=z4, ldesc_r=zd)   # right camera dropped out
+    tiny = synth.make_stereo_sequence(801, n_frames=4, n_pts=6, n_lines=0, cam=cam, distract=0.0)
+    run_and_compare(oracle, [seq, tiny], cam, "kitti")
