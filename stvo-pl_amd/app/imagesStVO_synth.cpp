@@ -5,6 +5,7 @@
 // ORB / LSD+LBD front-end is out of scope).  Writes per-frame results for the parity tests.
 //
 //   imagesStVO_synth <sequence.bin> <results.bin> [--preset kitti|euroc|default] [-c config.yaml] [--mode 0|1|2] [-n N]
+//                    [--device-pipeline]   (stvo_seq_*: one upload + one synchronisation per frame, state in HBM)
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -58,11 +59,13 @@ int main(int argc, char** argv) {
     }
     std::string preset = "kitti", cfg;
     int mode = 0, max_frames = 0;
+    bool device_pipeline = false;
     for (int i = 3; i < argc; ++i) {
         if (!std::strcmp(argv[i], "--preset") && i + 1 < argc) preset = argv[++i];
         else if (!std::strcmp(argv[i], "-c") && i + 1 < argc) cfg = argv[++i];
         else if (!std::strcmp(argv[i], "--mode") && i + 1 < argc) mode = std::atoi(argv[++i]);
         else if (!std::strcmp(argv[i], "-n") && i + 1 < argc) max_frames = std::atoi(argv[++i]);
+        else if (!std::strcmp(argv[i], "--device-pipeline")) device_pipeline = true;
     }
     if (preset == "kitti") Config::setKittiPreset();
     else if (preset == "euroc") Config::setEurocPreset();
@@ -81,6 +84,86 @@ int main(int argc, char** argv) {
     if (max_frames > 0 && max_frames < n_frames) n_frames = max_frames;
     std::ofstream out(argv[2], std::ios::binary);
     PinholeStereoCamera* cam_pin = new PinholeStereoCamera(cols, rows, camv[0], camv[1], camv[2], camv[3], camv[4]);
+
+    if (device_pipeline) {
+        // ---- the same loop on the device-resident pipeline: pose + counters per frame, Tfw composed here
+        stvo_ctx* ctx = nullptr;
+        if (stvo_ctx_create(0, 2048, 1, &ctx) != STVO_OK) {
+            std::cerr << "[StVO-HIP] no MI355X available" << std::endl;
+            return -2;
+        }
+        stvo_match_params mp{};
+        mp.best_lr_matches = Config::bestLRMatches(); mp.matching_s_ws = Config::matchingSWs();
+        mp.min_ratio_12_p = (float)Config::minRatio12P(); mp.min_ratio_12_l = (float)Config::minRatio12L();
+        mp.max_dist_epip = Config::maxDistEpip(); mp.min_disp = Config::minDisp(); mp.line_sim_th = Config::lineSimTh();
+        mp.stereo_overlap_th = Config::stereoOverlapTh(); mp.line_horiz_th = Config::lineHorizTh();
+        mp.ls_min_disp_ratio = Config::lsMinDispRatio(); mp.orb_scale_factor = Config::orbScaleFactor();
+        mp.lsd_scale = Config::lsdScale();
+        stvo_opt_params op{};
+        op.mode = mode; op.has_points = Config::hasPoints(); op.has_lines = Config::hasLines();
+        op.min_features = Config::minFeatures(); op.max_iters = Config::maxIters(); op.max_iters_ref = Config::maxItersRef();
+        op.homog_th = Config::homogTh(); op.min_error = Config::minError(); op.min_error_change = Config::minErrorChange();
+        op.inlier_k = Config::inlierK();
+        const stvo_cam cam = cam_pin->abi();
+        stvo_seq* seq = nullptr;
+        if (stvo_seq_create(ctx, 1, 2048, 512, cols, rows, &cam, &mp, &op, &seq) != STVO_OK) {
+            std::cerr << "stvo_seq_create failed" << std::endl;
+            return -2;
+        }
+        double t_sum = 0.0;
+        for (int k = 0; k < n_frames; ++k) {
+            FrameFeatures feat;
+            int32_t n[4];
+            if (!rd(in, n, 4) || !read_points(in, n[0], feat.points_l, feat.pdesc_l) ||
+                !read_points(in, n[1], feat.points_r, feat.pdesc_r) || !read_lines(in, n[2], feat.lines_l, feat.ldesc_l) ||
+                !read_lines(in, n[3], feat.lines_r, feat.ldesc_r))
+                return -1;
+            std::vector<float> kpl(2 * n[0] + 2), kpr(2 * n[1] + 2), kll(4 * n[2] + 4), klr(4 * n[3] + 4);
+            std::vector<int32_t> ol(n[0] + 1), oll(n[2] + 1);
+            for (int i = 0; i < n[0]; ++i) { kpl[2 * i] = feat.points_l[i].x; kpl[2 * i + 1] = feat.points_l[i].y; ol[i] = feat.points_l[i].octave; }
+            for (int i = 0; i < n[1]; ++i) { kpr[2 * i] = feat.points_r[i].x; kpr[2 * i + 1] = feat.points_r[i].y; }
+            for (int i = 0; i < n[2]; ++i) { kll[4 * i] = feat.lines_l[i].startPointX; kll[4 * i + 1] = feat.lines_l[i].startPointY;
+                                             kll[4 * i + 2] = feat.lines_l[i].endPointX; kll[4 * i + 3] = feat.lines_l[i].endPointY; oll[i] = feat.lines_l[i].octave; }
+            for (int i = 0; i < n[3]; ++i) { klr[4 * i] = feat.lines_r[i].startPointX; klr[4 * i + 1] = feat.lines_r[i].startPointY;
+                                             klr[4 * i + 2] = feat.lines_r[i].endPointX; klr[4 * i + 3] = feat.lines_r[i].endPointY; }
+            stvo_frame_features ff{};
+            ff.stride_kp = n[0] > n[1] ? n[0] : n[1];
+            ff.stride_kl = n[2] > n[3] ? n[2] : n[3];
+            ff.n_kp_l = &n[0]; ff.n_kp_r = &n[1]; ff.n_kl_l = &n[2]; ff.n_kl_r = &n[3];
+            ff.kp_l = kpl.data(); ff.oct_l = ol.data(); ff.desc_l = feat.pdesc_l.ptr(); ff.kp_r = kpr.data(); ff.desc_r = feat.pdesc_r.ptr();
+            ff.kl_l = kll.data(); ff.oct_ll = oll.data(); ff.ldesc_l = feat.ldesc_l.ptr(); ff.kl_r = klr.data(); ff.ldesc_r = feat.ldesc_r.ptr();
+            stvo_pose_result r{};
+            int32_t cnt[4];
+            const auto t0 = std::chrono::high_resolution_clock::now();
+            if (stvo_seq_push(seq, &ff, &r, cnt) != STVO_OK) {
+                std::cerr << "stvo_seq_push failed: " << stvo_ctx_last_error(ctx) << std::endl;
+                return -3;
+            }
+            const double t1 = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
+            if (k == 0) continue;
+            t_sum += t1;
+            std::printf("Frame: %d\tRes.: %.8f \t Proc. time: %.3f ms\t \t Points: %d (%d) \t Lines:  %d (%d) \n", k, r.err, t1,
+                        r.n_matched_pt, r.n_inliers_pt, r.n_matched_ls, r.n_inliers_ls);
+            const int32_t ints[12] = {k, r.status, r.path, r.iters[0], r.iters[1], r.n_matched_pt, r.n_inliers_pt, r.n_matched_ls,
+                                      r.n_inliers_ls, cnt[0], cnt[1], 0};
+            wr(out, ints, 12);
+            wr(out, r.T, 16);
+            wr(out, r.cov, 36);
+            wr(out, r.cov_eig, 6);
+            wr(out, &r.err, 1);
+            const double zeros[52] = {0};
+            wr(out, zeros, 52);  // Tfw / Tfw_cov are composed by the caller in this mode
+            const int32_t z2[2] = {0, 0};
+            wr(out, z2, 2);
+        }
+        if (n_frames > 1)
+            std::printf("[imagesStVO_synth --device-pipeline] %d frame pairs, mean Proc. time %.3f ms (single stream, incl. H2D/D2H)\n",
+                        n_frames - 1, t_sum / (n_frames - 1));
+        stvo_seq_destroy(seq);
+        stvo_ctx_destroy(ctx);
+        delete cam_pin;
+        return 0;
+    }
 
     StereoFrameHandler* StVO = nullptr;
     try {

@@ -20,7 +20,7 @@
 //   B  `grid_scan`    lane = right feature, descriptor resident in 8 VGPRs; the left features stream
 //                     by in ASCENDING i1 as wave-uniform rows (scalar loads) — the same popcount
 //                     inner loop as K1, predicated by the candidate bit and (lines) the direction
-//                     cosine gate (:221-222); 8 masks per s_load_dwordx16, all-zero chunks skipped;
+//                     cosine gate (:221-222); 64 masks per coalesced load, non-zero ones found by ballot;
 //                     each lane carries its running minimum, so eligibility and ownership fall out
 //                     in order; eligible pairs update the left feature's packed (best, second) keys
 //                     with a 64-bit CAS (integer keys: order-independent)
@@ -49,7 +49,7 @@ struct GridArgs {
     double ratio, line_sim_th;
     int mutual;
     int words64;                 // number of 64-lane waves of right features = ceil(n2 / 64)
-    int n1p;                     // n1 rounded up to the 8-mask scan chunk
+    int n1p;                     // n1 rounded up to the 64-mask scan block
     unsigned long long* cover;   // [words64][n1p]: bit p%64 of cover[p/64][i1] <=> right feature perm[p] is a candidate of i1
     const int32_t* rank;         // [n2] right feature id -> scan position p (spatial = CSR order)
     const int32_t* perm;         // [n2] scan position p -> right feature id
@@ -164,16 +164,21 @@ __global__ __launch_bounds__(256) void grid_scan_kernel(GridBatch g) {
     const int widx = __builtin_amdgcn_readfirstlane(p >> 6);
     const unsigned long long* __restrict__ col = a.cover + (size_t)widx * a.n1p;  // wave-uniform row of masks
     const uint32_t* __restrict__ Q = reinterpret_cast<const uint32_t*>(a.d1);
-    for (int base = 0; base < a.n1p; base += 8) {
-        unsigned long long m[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) m[u] = col[base + u];  // one s_load_dwordx16
-        if ((m[0] | m[1] | m[2] | m[3] | m[4] | m[5] | m[6] | m[7]) == 0ull) continue;
-#pragma unroll 1
-        for (int u = 0; u < 8; ++u) {
-            const unsigned long long mask = m[u];
-            if (mask == 0ull) continue;
+    // 64 masks per coalesced vector load; the ballot of the non-zero ones is walked with scalar bit tricks, so an
+    // (almost always) all-zero block of 64 left features costs one load + one ballot.  The next block is
+    // requested before the current one is processed.
+    unsigned long long mv = col[lane];  // n1p is a multiple of 64
+    for (int base = 0; base < a.n1p; base += 64) {
+        const unsigned long long cur = mv;
+        if (base + 64 < a.n1p) mv = col[base + 64 + lane];
+        unsigned long long nz = __ballot(cur != 0ull);
+        while (nz) {
+            const int u = __builtin_ctzll(nz);
+            nz &= nz - 1ull;
             const int i1 = base + u;
+            const unsigned long long mask =
+                ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(cur >> 32), u) << 32) |
+                (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(cur & 0xFFFFFFFFull), u);
             bool on = live && ((mask >> lane) & 1ull);
             if (LINES) {
                 // direction of the LEFT line from INTEGER cell differences; 0/0 = NaN never skips (:207-222)
@@ -290,7 +295,7 @@ int run_grid(stvo_ctx* ctx, const int32_t* cell_xy1, const uint8_t* d1, int n1, 
     a.xy_width = LINES ? 4 : 2;
     a.items_stride = n_items;
     a.words64 = (n2 + 63) / 64;
-    a.n1p = (n1 + 7) & ~7;
+    a.n1p = (n1 + 63) & ~63;
     // scan order of the right features = order of first appearance in the CSR grid (cell-major, i.e.
     // spatial); features that are in no cell come last (they are nobody's candidate anyway)
     std::vector<int32_t> rank((size_t)n2, -1), perm((size_t)n2);

@@ -82,7 +82,7 @@ struct GridBatch {
     int B, stride1, stride2;   // frame pairs; rows per frame of the left / right feature arrays
     int xy_width;              // 2 (points: cx, cy) or 4 (lines: sx, sy, ex, ey)
     int items_stride;          // CSR items per frame
-    int words64, n1p;          // ceil(stride2 / 64); stride1 rounded up to 8
+    int words64, n1p;          // ceil(stride2 / 64); stride1 rounded up to 64
     const int32_t* cell_xy1;   // [B][stride1][xy_width]
     const uint8_t* d1;         // [B][stride1][32]
     const int32_t* n1;         // [B]
