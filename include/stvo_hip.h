@@ -158,6 +158,12 @@ int stvo_seq_destroy(stvo_seq* seq);
  * only builds the stereo sets); counts: optional [B][4] = stereo points, stereo lines, matched points, matched
  * lines of this frame. */
 int stvo_seq_push(stvo_seq* seq, const stvo_frame_features* frame, stvo_pose_result* results, int32_t* counts);
+/* The three halves of stvo_seq_push, for callers that keep frames resident in HBM (throughput mode): upload one
+ * frame's features into device slot 0 / 1 (asynchronous), run the pipeline on a resident slot (asynchronous, no
+ * host transfer), fetch the results of the last step (synchronises). */
+int stvo_seq_upload(stvo_seq* seq, int slot, const stvo_frame_features* frame);
+int stvo_seq_step_dev(stvo_seq* seq, int slot);
+int stvo_seq_read(stvo_seq* seq, stvo_pose_result* results, int32_t* counts);
 
 /* ---- measurement helpers --------------------------------------------------------------------- */
 /* Times `iters` launches of the named kernel stage on the context's stream with hipEvents and

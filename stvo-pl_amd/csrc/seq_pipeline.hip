@@ -413,7 +413,7 @@ struct stvo_seq {
     size_t raw_bytes = 0;
     stvo::SeqDev d{};          // pointers into `dev` (set = current)
     // carve results
-    char* raw_dev = nullptr;
+    char* raw_dev[2] = {nullptr, nullptr};  // two frame slots (push alternates; the throughput bench keeps both resident)
     struct Set {
         double *pl, *P, *s2;
         uint8_t* desc;
@@ -486,7 +486,7 @@ int stvo_seq_create(stvo_ctx* ctx, int B, int max_keypoints, int max_keylines, i
     s->raw_bytes = rc.off;
     // ---- everything else
     Carver c;
-    const size_t o_raw = c.take(s->raw_bytes);
+    const size_t o_raw = c.take(s->raw_bytes), o_raw1 = c.take(s->raw_bytes);
     const size_t o_pxy = c.take(nb * K * 2 * 4), o_pstart = c.take(nb * (STVO_GRID_CELLS + 1) * 4), o_pitems = c.take(nb * K * 4),
                  o_prank = c.take(nb * K * 4), o_pperm = c.take(nb * K * 4);
     const size_t o_lxy = c.take(nb * M * 4 * 4), o_lstart = c.take(nb * (STVO_GRID_CELLS + 1) * 4),
@@ -529,20 +529,12 @@ int stvo_seq_create(stvo_ctx* ctx, int B, int max_keypoints, int max_keylines, i
     }
     std::memset(s->raw_host, 0, s->raw_bytes);
     char* D = s->dev;
-    s->raw_dev = D + o_raw;
+    s->raw_dev[0] = D + o_raw;
+    s->raw_dev[1] = D + o_raw1;
     stvo::SeqDev& d = s->d;
     d.B = B; d.K = K; d.M = M;
     d.inv_w = s->inv_w; d.inv_h = s->inv_h;
     d.cam = s->cam; d.mp = s->mp;
-    char* Rw = s->raw_dev;
-    d.kp_l = (const float*)(Rw + s->off_kp_l); d.oct_l = (const int32_t*)(Rw + s->off_oct_l);
-    d.desc_l = (const uint8_t*)(Rw + s->off_desc_l); d.n_kp_l = (const int32_t*)(Rw + s->off_nkl);
-    d.kp_r = (const float*)(Rw + s->off_kp_r); d.desc_r = (const uint8_t*)(Rw + s->off_desc_r);
-    d.n_kp_r = (const int32_t*)(Rw + s->off_nkr);
-    d.kl_l = (const float*)(Rw + s->off_kl_l); d.oct_ll = (const int32_t*)(Rw + s->off_oct_ll);
-    d.ldesc_l = (const uint8_t*)(Rw + s->off_ldesc_l); d.n_kl_l = (const int32_t*)(Rw + s->off_nll);
-    d.kl_r = (const float*)(Rw + s->off_kl_r); d.ldesc_r = (const uint8_t*)(Rw + s->off_ldesc_r);
-    d.n_kl_r = (const int32_t*)(Rw + s->off_nlr);
     d.pxy_l = (int32_t*)(D + o_pxy); d.pstart = (int32_t*)(D + o_pstart); d.pitems = (int32_t*)(D + o_pitems);
     d.prank = (int32_t*)(D + o_prank); d.pperm = (int32_t*)(D + o_pperm);
     d.lxy_l = (int32_t*)(D + o_lxy); d.lstart = (int32_t*)(D + o_lstart); d.litems = (int32_t*)(D + o_litems);
@@ -578,13 +570,30 @@ int stvo_seq_destroy(stvo_seq* s) {
     return STVO_OK;
 }
 
-// counts (optional, [B][4]): stereo points, stereo lines, matched points, matched lines of this frame
-int stvo_seq_push(stvo_seq* s, const stvo_frame_features* f, stvo_pose_result* results, int32_t* counts) {
-    if (!s || !f) return STVO_ERR_INVALID_ARG;
+namespace {
+
+void bind_raw(stvo_seq* s, stvo::SeqDev& d, int slot) {
+    char* Rw = s->raw_dev[slot];
+    d.kp_l = (const float*)(Rw + s->off_kp_l); d.oct_l = (const int32_t*)(Rw + s->off_oct_l);
+    d.desc_l = (const uint8_t*)(Rw + s->off_desc_l); d.n_kp_l = (const int32_t*)(Rw + s->off_nkl);
+    d.kp_r = (const float*)(Rw + s->off_kp_r); d.desc_r = (const uint8_t*)(Rw + s->off_desc_r);
+    d.n_kp_r = (const int32_t*)(Rw + s->off_nkr);
+    d.kl_l = (const float*)(Rw + s->off_kl_l); d.oct_ll = (const int32_t*)(Rw + s->off_oct_ll);
+    d.ldesc_l = (const uint8_t*)(Rw + s->off_ldesc_l); d.n_kl_l = (const int32_t*)(Rw + s->off_nll);
+    d.kl_r = (const float*)(Rw + s->off_kl_r); d.ldesc_r = (const uint8_t*)(Rw + s->off_ldesc_r);
+    d.n_kl_r = (const int32_t*)(Rw + s->off_nlr);
+}
+
+}  // namespace
+
+// Copies one frame's features of all B sequences into device slot 0 / 1 (pinned gather + ONE H2D, asynchronous
+// on the context's stream).
+int stvo_seq_upload(stvo_seq* s, int slot, const stvo_frame_features* f) {
+    if (!s || !f || slot < 0 || slot > 1) return STVO_ERR_INVALID_ARG;
     stvo_ctx* ctx = s->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the pinned block may still be in flight from the last upload
     const int B = s->B, K = s->K, M = s->M;
-    // ---- gather the host arrays into the pinned raw block (row strides K / M), one H2D
     char* H = s->raw_host;
     int32_t* nkl = (int32_t*)(H + s->off_nkl);
     int32_t* nkr = (int32_t*)(H + s->off_nkr);
@@ -621,18 +630,25 @@ int stvo_seq_push(stvo_seq* s, const stvo_frame_features* f, stvo_pose_result* r
             std::memcpy(H + s->off_ldesc_r + dl * 32, f->ldesc_r + sl * 32, (size_t)lr * 32);
         }
     }
-    hipStream_t st = ctx->stream;
-    HIP_TRY(ctx, hipMemcpyAsync(s->raw_dev, s->raw_host, s->raw_bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(s->raw_dev[slot], s->raw_host, s->raw_bytes, hipMemcpyHostToDevice, ctx->stream));
+    return STVO_OK;
+}
 
+// Runs the whole per-frame pipeline on the features resident in `slot` (asynchronous; no host transfer).
+int stvo_seq_step_dev(stvo_seq* s, int slot) {
+    if (!s || slot < 0 || slot > 1) return STVO_ERR_INVALID_ARG;
+    stvo_ctx* ctx = s->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int B = s->B, K = s->K, M = s->M;
+    hipStream_t st = ctx->stream;
     // ---- stereo association of the new frame into set[cur]
     stvo_seq::Set& cs = s->set[s->cur];
     stvo_seq::Set& ps = s->set[s->cur ^ 1];
     stvo::SeqDev d = s->d;
+    bind_raw(s, d, slot);
     d.pl = cs.pl; d.P = cs.P; d.s2 = cs.s2; d.desc = cs.desc; d.n = cs.n;
     d.spl = cs.spl; d.epl = cs.epl; d.sP = cs.sP; d.eP = cs.eP; d.le = cs.le; d.s2l = cs.s2l; d.s2lm = cs.s2lm;
     d.ldesc = cs.ldesc; d.nl = cs.nl;
-    const int R = K > M ? K : M;
-    (void)R;
     if (s->op.has_points) {
         hipLaunchKernelGGL(stvo::point_cells_kernel, dim3(B), dim3(256), 0, st, d);
         stvo::GridBatch g;
@@ -664,7 +680,6 @@ int stvo_seq_push(stvo_seq* s, const stvo_frame_features* f, stvo_pose_result* r
     } else {
         HIP_TRY(ctx, hipMemsetAsync(cs.nl, 0, (size_t)B * 4, st));
     }
-
     const bool track = s->frame_idx > 0;
     if (track) {
         // ---- f2fTracking: prev stereo sets vs curr stereo sets
@@ -696,12 +711,26 @@ int stvo_seq_push(stvo_seq* s, const stvo_frame_features* f, stvo_pose_result* r
         TRY(stvo::launch_pose(st, a));
     }
     TRY(check_launch(ctx));
-    // ---- one small download: results + stereo counts
+    s->cur ^= 1;  // updateFrame: curr becomes prev
+    s->frame_idx++;
+    return STVO_OK;
+}
+
+// Results of the LAST step (synchronises).  counts (optional, [B][4]): stereo points, stereo lines, matched
+// points, matched lines of that frame; results are zeroed after the first frame (nothing to track against yet).
+int stvo_seq_read(stvo_seq* s, stvo_pose_result* results, int32_t* counts) {
+    if (!s) return STVO_ERR_INVALID_ARG;
+    stvo_ctx* ctx = s->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int B = s->B;
+    hipStream_t st = ctx->stream;
+    const stvo_seq::Set& ls = s->set[s->cur ^ 1];  // the set built by the last step (cur was flipped)
+    const bool track = s->frame_idx > 1;
     char* OH = s->out_host;
     const size_t res_bytes = (size_t)B * sizeof(stvo_pose_result);
     if (track) HIP_TRY(ctx, hipMemcpyAsync(OH, s->results, res_bytes, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipMemcpyAsync(OH + res_bytes, cs.n, (size_t)B * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipMemcpyAsync(OH + res_bytes + (size_t)B * 4, cs.nl, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(OH + res_bytes, ls.n, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(OH + res_bytes + (size_t)B * 4, ls.nl, (size_t)B * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     const stvo_pose_result* hr = reinterpret_cast<const stvo_pose_result*>(OH);
     const int32_t* hn = reinterpret_cast<const int32_t*>(OH + res_bytes);
@@ -719,9 +748,15 @@ int stvo_seq_push(stvo_seq* s, const stvo_frame_features* f, stvo_pose_result* r
             counts[4 * b + 3] = track ? hr[b].n_matched_ls : 0;
         }
     }
-    s->cur ^= 1;  // updateFrame: curr becomes prev
-    s->frame_idx++;
     return STVO_OK;
+}
+
+int stvo_seq_push(stvo_seq* s, const stvo_frame_features* f, stvo_pose_result* results, int32_t* counts) {
+    if (!s || !f) return STVO_ERR_INVALID_ARG;
+    const int slot = s->frame_idx & 1;
+    TRY(stvo_seq_upload(s, slot, f));
+    TRY(stvo_seq_step_dev(s, slot));
+    return stvo_seq_read(s, results, counts);
 }
 
 }  // extern "C"

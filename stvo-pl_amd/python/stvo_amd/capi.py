@@ -19,7 +19,7 @@ EXPORTS = ["stvo_backend_name", "stvo_abi_version", "stvo_error_string", "stvo_c
            "stvo_match_grid_points", "stvo_match_grid_lines", "stvo_normal_eq", "stvo_optimize_pose",
            "stvo_track_batched_dev", "stvo_match_nnr_mutual_batched_dev", "stvo_optimize_pose_batched_dev",
            "stvo_time_stage_dev", "stvo_valu_peak_probe", "stvo_last_reverse_counts", "stvo_ctx_set_kernel_timing", "stvo_ctx_get_kernel_timing", "stvo_seq_create", "stvo_seq_destroy",
-           "stvo_seq_push"]
+           "stvo_seq_push", "stvo_seq_upload", "stvo_seq_step_dev", "stvo_seq_read"]
 
 u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
 i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
@@ -114,6 +114,9 @@ def load():
                                   C.POINTER(MatchParams), C.POINTER(OptParams), C.POINTER(C.c_void_p)]
     L.stvo_seq_destroy.argtypes = [C.c_void_p]
     L.stvo_seq_push.argtypes = [C.c_void_p, C.POINTER(FrameFeatures), C.c_void_p, i32p]
+    L.stvo_seq_upload.argtypes = [C.c_void_p, C.c_int, C.POINTER(FrameFeatures)]
+    L.stvo_seq_step_dev.argtypes = [C.c_void_p, C.c_int]
+    L.stvo_seq_read.argtypes = [C.c_void_p, C.c_void_p, i32p]
     L.stvo_last_reverse_counts.argtypes = [C.c_void_p, C.c_int, i32p]
     L.stvo_ctx_set_kernel_timing.argtypes = [C.c_void_p, C.c_int]
     L.stvo_ctx_get_kernel_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int32)]
@@ -279,8 +282,7 @@ class Sequences:
             self.ctx.lib.stvo_seq_destroy(self.h)
             self.h = None
 
-    def push(self, frames):
-        """frames: list of B per-sequence frame dicts as produced by synth.make_stereo_sequence."""
+    def _pack(self, frames):
         B = self.B
         assert len(frames) == B
         skp = max(max(len(f["kp_l"]), len(f["kp_r"])) for f in frames) or 1
@@ -300,7 +302,26 @@ class Sequences:
         ff.stride_kp, ff.stride_kl = skp, skl
         for k, v in a.items():
             setattr(ff, k, v.ctypes.data_as(C.c_void_p))
-        res = np.zeros(B, dtype=POSE_RESULT_DTYPE)
-        counts = np.zeros(B * 4, np.int32)
+        return ff, a  # `a` keeps the arrays alive
+
+    def push(self, frames):
+        """frames: list of B per-sequence frame dicts as produced by synth.make_stereo_sequence."""
+        ff, keep = self._pack(frames)
+        res = np.zeros(self.B, dtype=POSE_RESULT_DTYPE)
+        counts = np.zeros(self.B * 4, np.int32)
         self.ctx._chk(self.ctx.lib.stvo_seq_push(self.h, C.byref(ff), res.ctypes.data_as(C.c_void_p), counts))
-        return res, counts.reshape(B, 4)
+        return res, counts.reshape(self.B, 4)
+
+    def upload(self, slot, frames):
+        ff, keep = self._pack(frames)
+        self.ctx._chk(self.ctx.lib.stvo_seq_upload(self.h, slot, C.byref(ff)))
+        self.ctx.synchronize()
+
+    def step_dev(self, slot):
+        self.ctx._chk(self.ctx.lib.stvo_seq_step_dev(self.h, slot))
+
+    def read(self):
+        res = np.zeros(self.B, dtype=POSE_RESULT_DTYPE)
+        counts = np.zeros(self.B * 4, np.int32)
+        self.ctx._chk(self.ctx.lib.stvo_seq_read(self.h, res.ctypes.data_as(C.c_void_p), counts))
+        return res, counts.reshape(self.B, 4)

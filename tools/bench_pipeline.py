@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Throughput of the WHOLE device-resident per-frame pipeline (stvo_seq_*) on one MI355X — BASELINE configs[2]
+shape: KITTI-00-shaped stereo with points + lines, grid-windowed stereo match + f2f match + full GN pose, for B
+independent sequences in lock-step, features resident in HBM (two frame slots per sequence, alternated).
+Secondary measurement (the headline metric of bench.py is configs[1]); prints one JSON line.
+
+    python tools/bench_pipeline.py [--batch 256] [--steps 20] [--points 1650] [--lines 85]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "stvo-pl_amd", "python"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--points", type=int, default=1650)  # + 20 % distractors ~ 2000 key-points per image
+    ap.add_argument("--lines", type=int, default=85)     # + 20 % ~ 100 key-lines per image
+    ap.add_argument("--cpu-frames", type=int, default=8)
+    a = ap.parse_args()
+    import torch  # noqa: F401  (one HIP runtime per process, see capi.load)
+    from stvo_amd import capi, synth
+    from stvo_amd.ctypes_types import match_params, opt_params
+    cam = synth.KITTI_CAM
+    mp = match_params("kitti")
+    op = opt_params("kitti", has_lines=1 if a.lines > 0 else 0)
+    B = a.batch
+    seqs = [synth.make_stereo_sequence(synth.frame_seed(b, 0), n_frames=2, n_pts=a.points, n_lines=a.lines, cam=cam) for b in range(B)]
+    ctx = capi.Context(device_id=0, max_rows=2048, max_batch=B)
+    dev = capi.Sequences(ctx, B, 2048, 512, cam, mp, op)
+    dev.upload(0, [s[0] for s in seqs])
+    dev.upload(1, [s[1] for s in seqs])
+    for k in range(a.warmup):
+        dev.step_dev(k & 1)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        dev.step_dev((a.warmup + k) & 1)
+    ctx.synchronize()
+    dt = time.perf_counter() - t0
+    res, counts = dev.read()
+    ok = float((res["status"] == 0).mean())
+    out = {"metric": "stereo frames/s (grid stereo match + f2f match + optimizePose), device-resident pipeline",
+           "value": B * a.steps / dt, "unit": "frame-pairs/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
+           "ms_per_step": dt / a.steps * 1e3, "data": "synthetic",
+           "config": {"workload": "BASELINE configs[2]: KITTI-00-shaped stereo, points + lines, grid-windowed stereo association, "
+                                  "f2f mutual matching, GN pose; B independent sequences, two frames per sequence resident in HBM",
+                      "sequences": B, "keypoints_per_image": len(seqs[0][0]["kp_l"]), "keylines_per_image": len(seqs[0][0]["kl_l"]),
+                      "mean_stereo_points": float(counts[:, 0].mean()), "mean_stereo_lines": float(counts[:, 1].mean()),
+                      "mean_matched_points": float(counts[:, 2].mean()), "committed_pose_fraction": ok}}
+    if a.cpu_frames > 0:
+        import oracle_lib
+        import pipeline_ref
+        orc = oracle_lib.load()
+        t1 = time.perf_counter()
+        for b in range(min(a.cpu_frames, B)):
+            pipeline_ref.run_sequence(orc, seqs[b], cam, mp, op)
+        n = min(a.cpu_frames, B)
+        dtc = time.perf_counter() - t1
+        out["cpu_baseline"] = {"value": n / dtc, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
+                               "sample": f"{n} sequences x (2 stereo associations + 1 f2f + 1 optimizePose), oracle, {dtc:.1f} s"}
+    dev.close()
+    ctx.close()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
