@@ -117,7 +117,6 @@ def main():
         step()
     ctx.synchronize()
     torch.cuda.synchronize()
-    ctx.set_kernel_timing(rank == 0)   # hipEvent pairs around every hamming_knn2 launch of the timed region
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -142,7 +141,14 @@ def main():
         # K1 is launched twice per matching stage: forward scan of all prev rows, then the lazy reverse scan of
         # the curr rows that are some prev row's accepted forward match.  Figures below are per launch (average
         # of the two), which is also what rocprofv3's per-kernel average reports.
-        k1_fwd_ms, k1_rev_ms, k1_calls = ctx.get_kernel_timing()   # live, over the timed region
+        # The dominant kernel is timed LIVE in a second pass over the same steps (same batch, same overlap mode):
+        # hipEvent pairs around every hamming_knn2 launch, on the stream it is launched on.  The pass is separate
+        # from the one that produced `value` because the event markers cost ~9 % of throughput.
+        ctx.set_kernel_timing(True)
+        for _ in range(args.steps):
+            step()
+        ctx.synchronize()
+        k1_fwd_ms, k1_rev_ms, k1_calls = ctx.get_kernel_timing()
         ctx.set_kernel_timing(False)
         k1_ms = 0.5 * (k1_fwd_ms + k1_rev_ms)
         k1_solo_ms = ctx.time_stage(batch, synth.KITTI_CAM, prm, 0.75, 0, 10)  # same launches with the GPU to themselves
@@ -169,7 +175,7 @@ def main():
                          "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": committed_traffic(),
                          "traffic_source": "bytes per launch = FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes, read from "
                                            "the committed profiles/r01_c_hbm_counters.txt (not re-measured by this run)",
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k1_ms, "timing": "hipEvent pairs around each launch inside the timed region, on the launch stream",
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k1_ms, "timing": "hipEvent pairs around each launch, on the launch stream, over a second pass of the same K steps",
                          "note": "K1 is integer-VALU bound (~1000 lane-ops per compulsory byte); see valu_roofline. Two launches "
                                  "per step (forward + lazy reverse); figures are per launch"},
             "valu_roofline": {"kernel": "hamming_knn2_kernel", "lane_ops_per_launch": lane_ops,
