@@ -168,20 +168,21 @@ int stvo_seq_read(stvo_seq* seq, stvo_pose_result* results, int32_t* counts);
 /* ---- measurement helpers --------------------------------------------------------------------- */
 /* Times `iters` launches of the named kernel stage on the context's stream with hipEvents and
  * returns the average milliseconds per launch (used by bench.py for the roofline line).
- * stage: 0 = hamming_knn2 (K1): average over its two launches per matching stage (forward scan + lazy
- * reverse scan with the column selection of the last stvo_track_batched_dev call), 1 = pose kernel. */
+ * stage: 0 = hamming_knn2 (K1, the forward top-2 scan), 1 = pose kernel, 3 = hamming_verify (the mutual-check
+ * range query) on the column claims left by the last stvo_track_batched_dev call. */
 int stvo_time_stage_dev(stvo_ctx* ctx, const stvo_track_batch_dev* batch, const stvo_cam* cam,
                         const stvo_opt_params* params, float nnr, int stage, int iters, float* avg_ms);
 
 /* Live timing of the dominant kernel INSIDE the batched path: with enable = 1 every stvo_track_batched_dev
- * call brackets its two hamming_knn2 launches on the point descriptors (forward scan, lazy reverse scan) with
- * hipEvents on the stream they are launched on.  get_kernel_timing synchronises, returns the average
- * duration of each and the number of calls measured since the last get / set, and resets the pool. */
+ * call brackets its hamming_knn2 launch (forward top-2 scan) and its hamming_verify launch (mutual check) on
+ * the point descriptors with hipEvents on the stream they are launched on.  get_kernel_timing synchronises,
+ * returns the average duration of each and the number of calls measured since the last get / set, and
+ * resets the pool. */
 int stvo_ctx_set_kernel_timing(stvo_ctx* ctx, int enable);
 int stvo_ctx_get_kernel_timing(stvo_ctx* ctx, float* avg_ms_forward, float* avg_ms_reverse, int32_t* n_calls);
 
-/* Number of right-hand (curr) rows whose reverse scan the LAST batched mutual match actually ran, per frame
- * pair (the lazy reverse pass only scans columns that are some row's accepted forward match). */
+/* Number of right-hand (curr) rows the LAST batched mutual match had to verify, per frame pair (only columns
+ * claimed by some row's accepted forward match are examined). */
 int stvo_last_reverse_counts(stvo_ctx* ctx, int B, int32_t* counts);
 
 /* Integer-VALU micro-benchmark (xor + popcount-accumulate chains, no memory traffic): measured

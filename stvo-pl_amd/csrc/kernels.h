@@ -28,12 +28,13 @@ void launch_hamming_knn2(hipStream_t s, int B, int row_stride, int max_n, const 
                          const uint8_t* d2, const int32_t* n2, uint2* knn12, uint2* knn21, int both_directions,
                          int lds_pad_bytes = 0, int dir0 = 0, const int32_t* qsel = nullptr,
                          const int32_t* nsel = nullptr, int nseg = KNN_MIN_NSEG);
-// mutual matching with a lazy reverse pass (only the columns that are an accepted forward match are scanned)
+// mutual matching with a lazy reverse pass: only the columns claimed by an accepted forward match are
+// examined, by a range query with early exit instead of a second top-2 scan (match_kernels.hip)
 struct LazyScratch {
     uint2* knn12;
-    uint2* knn21;
+    uint2* knn21;   // reused as int32 blocked[B][row_stride] by the verification pass
     int32_t* cand;  // [B][row_stride] forward ratio-tested best
-    int32_t* need;  // [B][row_stride] column flags
+    int32_t* need;  // [B][row_stride] per-column claim (d0 << 16 | claimant), 0xFFFFFFFF = unclaimed
     int32_t* qsel;  // [B][row_stride] compacted flagged columns
     int32_t* nsel;  // [B]
     size_t knn_capacity;  // elements of knn12 / knn21
@@ -41,6 +42,9 @@ struct LazyScratch {
 void launch_match_mutual_lazy(hipStream_t s, int B, int row_stride, const uint8_t* d1, const int32_t* n1,
                               const uint8_t* d2, const int32_t* n2, float nnr, const LazyScratch& w, int32_t* m12,
                               int lds_pad_bytes, hipEvent_t wait_before_m12_write, hipEvent_t* timing_events = nullptr);
+// the verification pass alone, on the claims left by the last launch_match_mutual_lazy (timing tools)
+void launch_hamming_verify(hipStream_t s, int B, int row_stride, const uint8_t* d1, const int32_t* n1, const uint8_t* d2,
+                           float nnr, const LazyScratch& w, int lds_pad_bytes, int nseg);
 void launch_nnr_mutual(hipStream_t s, int B, int row_stride, const uint2* knn12, const uint2* knn21, const int32_t* n1,
                        const int32_t* n2, float nnr, int mutual, int32_t* m12, int nseg = KNN_MIN_NSEG);
 void launch_valu_probe(hipStream_t s, int blocks, int iters, uint32_t* sink);

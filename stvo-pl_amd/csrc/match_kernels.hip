@@ -206,13 +206,27 @@ void launch_nnr_mutual(hipStream_t s, int B, int row_stride, const uint2* knn12,
 
 // ---- lazy mutual matching -----------------------------------------------------------------------
 // StVO::match needs matches_21[j] only for columns j that are some row's accepted forward match
-// (src/matching.cpp:80-86 reads matches_21[matches_12[i1]] and nothing else).  So: forward scan of all
-// rows, forward ratio test, compaction of the distinct accepted columns, reverse scan of THOSE columns
-// only, reverse ratio test + index check.  Identical result, ~N2 - #accepted fewer reverse scans.
+// (src/matching.cpp:80-86 reads matches_21[matches_12[i1]] and nothing else), and of matches_21[j] it only
+// needs to know whether it EQUALS i1.  With nnr <= 1 (enforced at the ABI) that is a RANGE question, not a
+// top-2 question.  Let i claim column j with forward distance d0 = D(i, j).  The reverse pass of the reference
+// gives matches_21[j] = i  iff  i is the column's nearest row (lowest index among equals) and
+// float(d0) < float(second) * nnr, second = the smallest distance of any other row.  x -> float(x) * nnr is
+// non-decreasing, and for nnr <= 1 "float(d0) < float(d') * nnr" already implies d' > d0, so
+//       matches_21[j] == i   <=>   no row i' != i has D(i', j) <= T,
+//       T = the largest d' for which float(d0) < float(d') * nnr is FALSE            (T >= d0).
+// Among several rows claiming the same column only the one with the smallest (d0, i) can survive (it blocks
+// all the others), so one claim per column is kept (atomicMin on the packed key).
+//
+// The verification scan therefore needs no top-2 bookkeeping, and it can stop a row early: the popcount of
+// the first 128 bits is a lower bound of the distance.  T is ~d0 / nnr (27 for a 20-bit match at 0.75) while
+// the first half of an unrelated row differs in 64 +- 5.7 bits, so practically every (wave, row) step takes
+// the wave-uniform short cut: 4 x (v_xor + v_bcnt) + one compare instead of 8 x (v_xor + v_bcnt) + the top-2
+// update.  Exactness does not depend on the data: whenever any lane's lower bound is within its T (its own
+// claimant excepted) the wave finishes the row at full length.
 __global__ __launch_bounds__(256) void nnr_forward_kernel(int nseg, int row_stride, const uint2* __restrict__ knn12,
                                                           const int32_t* __restrict__ n1, const int32_t* __restrict__ n2,
                                                           float nnr, int32_t* __restrict__ cand,
-                                                          int32_t* __restrict__ need /* zeroed */) {
+                                                          uint32_t* __restrict__ claim /* preset to 0xFFFFFFFF */) {
     const int b = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= row_stride) return;
@@ -222,16 +236,18 @@ __global__ __launch_bounds__(256) void nnr_forward_kernel(int nseg, int row_stri
     if (i < na && nb >= 2) {
         const uint2 k = merged_knn(knn12, (size_t)gridDim.y * row_stride, off + i, nseg);
         const float f0 = (float)(k.x >> 16), f1 = (float)(k.y >> 16);
-        if (f0 < f1 * nnr) m = (int)(k.x & 0xFFFFu);
+        if (f0 < f1 * nnr) {
+            m = (int)(k.x & 0xFFFFu);
+            atomicMin(&claim[off + m], (k.x & 0xFFFF0000u) | (uint32_t)i);  // (d0 << 16) | claimant
+        }
     }
     cand[off + i] = m;
-    if (m >= 0) need[off + m] = 1;  // benign race: every writer stores 1
 }
 
-// one workgroup per frame pair: ascending list of the flagged columns + their count
-__global__ __launch_bounds__(256) void compact_need_kernel(int row_stride, const int32_t* __restrict__ need,
+// one workgroup per frame pair: ascending list of the claimed columns + their count; clears their verdicts
+__global__ __launch_bounds__(256) void compact_need_kernel(int row_stride, const uint32_t* __restrict__ claim,
                                                            const int32_t* __restrict__ n2, int32_t* __restrict__ qsel,
-                                                           int32_t* __restrict__ nsel) {
+                                                           int32_t* __restrict__ nsel, int32_t* __restrict__ blocked) {
     __shared__ int s_wave[4];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const size_t off = (size_t)b * row_stride;
@@ -239,7 +255,7 @@ __global__ __launch_bounds__(256) void compact_need_kernel(int row_stride, const
     const int per = (row_stride + 255) / 256;
     const int lo = tid * per, hi = min(lo + per, nb);
     int cnt = 0;
-    for (int j = lo; j < hi; ++j) cnt += need[off + j] != 0;
+    for (int j = lo; j < hi; ++j) cnt += claim[off + j] != 0xFFFFFFFFu;
     int incl = cnt;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -256,13 +272,125 @@ __global__ __launch_bounds__(256) void compact_need_kernel(int row_stride, const
     }
     int pos = base + incl - cnt;
     for (int j = lo; j < hi; ++j)
-        if (need[off + j] != 0) qsel[off + pos++] = j;
+        if (claim[off + j] != 0xFFFFFFFFu) {
+            qsel[off + pos++] = j;
+            blocked[off + j] = 0;
+        }
     if (tid == 0) nsel[b] = tot;
 }
 
-__global__ __launch_bounds__(256) void nnr_reverse_check_kernel(int nseg, int row_stride, const int32_t* __restrict__ cand,
-                                                                const uint2* __restrict__ knn21,
-                                                                const int32_t* __restrict__ n1, float nnr,
+__device__ __forceinline__ uint32_t hamming128_lo(const uint4& q0, const uint32_t* __restrict__ t) {
+    uint32_t d = bcnt0(q0.x ^ t[0]);
+    d = bcnt_acc(q0.y ^ t[1], d);
+    d = bcnt_acc(q0.z ^ t[2], d);
+    d = bcnt_acc(q0.w ^ t[3], d);
+    return d;
+}
+__device__ __forceinline__ uint32_t hamming128_hi(const uint4& q1, const uint32_t* __restrict__ t, uint32_t d) {
+    d = bcnt_acc(q1.x ^ t[4], d);
+    d = bcnt_acc(q1.y ^ t[5], d);
+    d = bcnt_acc(q1.z ^ t[6], d);
+    d = bcnt_acc(q1.w ^ t[7], d);
+    return d;
+}
+
+// K1v: lane = one claimed column j of the curr frame (descriptor in 8 VGPRs, threshold T and claimant in two
+// more); the prev rows are wave-uniform scalar-cache loads exactly as in K1; same XCD-aware mapping and the same
+// row segments.  blocked[j] = 1 iff some prev row other than the claimant lies within T.
+__global__ __launch_bounds__(KNN_BLOCK) void hamming_verify_kernel(int B, int tiles, int nseg, int row_stride,
+                                                                   const uint8_t* __restrict__ d1,
+                                                                   const int32_t* __restrict__ n1,
+                                                                   const uint8_t* __restrict__ d2,
+                                                                   const uint32_t* __restrict__ claim,
+                                                                   const int32_t* __restrict__ qsel,
+                                                                   const int32_t* __restrict__ nsel, float nnr,
+                                                                   int32_t* __restrict__ blocked) {
+    const int per_frame = tiles * nseg;
+    const int L = blockIdx.x;
+    const int xcd = L & 7, k = L >> 3;
+    const int b = (k / per_frame) * 8 + xcd;
+    if (b >= B) return;
+    const int local = k % per_frame;
+    const int seg = local % nseg;
+    const int tile = local / nseg;
+    const int nq = nsel[b];
+    const int nt_all = n1[b];
+    const int seg_len = (((nt_all + nseg - 1) / nseg) + 3) & ~3;
+    const int j0 = min(seg * seg_len, nt_all);
+    const int nt = min(j0 + seg_len, nt_all);
+    const int q_base = tile * KNN_BLOCK;
+    if (q_base + (int)(threadIdx.x & ~63u) >= nq) return;  // wave-uniform
+    const size_t frame_off = (size_t)b * row_stride;
+    const uint32_t* __restrict__ T = reinterpret_cast<const uint32_t*>(d1 + frame_off * STVO_DESC_BYTES);
+
+    const int q = q_base + threadIdx.x;
+    const int qc = q < nq ? q : nq - 1;  // tail lanes repeat a valid column and discard the verdict
+    const int qi = qsel[frame_off + qc];
+    const uint4 q0 = reinterpret_cast<const uint4*>(d2 + frame_off * STVO_DESC_BYTES)[2 * qi];
+    const uint4 q1 = reinterpret_cast<const uint4*>(d2 + frame_off * STVO_DESC_BYTES)[2 * qi + 1];
+    const uint32_t c = claim[frame_off + qi];
+    const uint32_t istar = c & 0xFFFFu;
+    uint32_t thr = c >> 16;  // d0
+    {
+        const float f0 = (float)thr;
+        while (thr < 256u && !(f0 < (float)(thr + 1u) * nnr)) ++thr;  // largest distance that still blocks
+    }
+    bool blk = false;
+    // 4 prev rows (128 B, two s_load_dwordx16) per step
+    auto step4 = [&](const uint32_t* __restrict__ t, int jb) {
+        uint32_t p[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) p[u] = hamming128_lo(q0, t + 8 * u);
+        unsigned long long any = 0ull;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) any |= __builtin_amdgcn_ballot_w64(p[u] <= thr);
+        if (any != 0ull) {  // wave-uniform, rare: first discount every lane's own claimant, then go the full length
+            unsigned long long other = 0ull;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) other |= __builtin_amdgcn_ballot_w64(p[u] <= thr && (uint32_t)(jb + u) != istar);
+            if (other != 0ull) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t d = hamming128_hi(q1, t + 8 * u, p[u]);
+                    blk = blk || (d <= thr && (uint32_t)(jb + u) != istar);
+                }
+            }
+        }
+    };
+    int j = j0;
+    // two register sets of 32 SGPRs: the scalar loads of the next 4 rows are in flight while the current 4 are
+    // compared (a step is only ~36 VALU ops, too short to hide the scalar-cache latency behind other waves alone)
+    if (j + 4 <= nt) {
+        uint32_t ta[32], tb[32];
+#pragma unroll
+        for (int w = 0; w < 32; ++w) ta[w] = T[8 * j + w];
+        for (; j + 8 <= nt; j += 8) {
+#pragma unroll
+            for (int w = 0; w < 32; ++w) tb[w] = T[8 * (j + 4) + w];
+            step4(ta, j);
+            const int jn = (j + 12 <= nt) ? j + 8 : j;  // last round: reload something valid, result unused
+#pragma unroll
+            for (int w = 0; w < 32; ++w) ta[w] = T[8 * jn + w];
+            step4(tb, j + 4);
+        }
+        if (j + 4 <= nt) {
+            step4(ta, j);  // ta holds rows j..j+3 here (loaded by the prologue or by the last round)
+            j += 4;
+        }
+    }
+    for (; j < nt; ++j) {
+        const uint32_t d = hamming256(q0, q1, T + 8 * j);
+        blk = blk || (d <= thr && (uint32_t)j != istar);
+    }
+    if (q < nq && blk) blocked[frame_off + qi] = 1;  // benign race between segments: every writer stores 1
+}
+
+// m12[i] = cand[i] iff i holds the claim on that column and the verification found no blocking row.
+// Fewer than two prev rows => no match (the reference's knnMatch(k = 2) row would have one entry; :54 is UB).
+__global__ __launch_bounds__(256) void nnr_reverse_check_kernel(int row_stride, const int32_t* __restrict__ cand,
+                                                                const uint32_t* __restrict__ claim,
+                                                                const int32_t* __restrict__ blocked,
+                                                                const int32_t* __restrict__ n1,
                                                                 int32_t* __restrict__ m12) {
     const int b = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -270,15 +398,19 @@ __global__ __launch_bounds__(256) void nnr_reverse_check_kernel(int nseg, int ro
     const size_t off = (size_t)b * row_stride;
     int m = cand[off + i];
     if (m >= 0) {
-        bool keep = false;
-        if (n1[b] >= 2) {
-            const uint2 r = merged_knn(knn21, (size_t)gridDim.y * row_stride, off + m, nseg);
-            const float r0 = (float)(r.x >> 16), r1 = (float)(r.y >> 16);
-            keep = (r0 < r1 * nnr) && ((int)(r.x & 0xFFFFu) == i);
-        }
+        const bool keep = n1[b] >= 2 && (claim[off + m] & 0xFFFFu) == (uint32_t)i && blocked[off + m] == 0;
         if (!keep) m = -1;
     }
     m12[off + i] = m;
+}
+
+void launch_hamming_verify(hipStream_t s, int B, int row_stride, const uint8_t* d1, const int32_t* n1, const uint8_t* d2,
+                           float nnr, const LazyScratch& w, int lds_pad_bytes, int nseg) {
+    if (B <= 0 || row_stride <= 0) return;
+    const int tiles = (row_stride + KNN_BLOCK - 1) / KNN_BLOCK, groups = (B + 7) / 8;
+    hipLaunchKernelGGL(hamming_verify_kernel, dim3((unsigned)(groups * 8 * tiles * nseg)), dim3(KNN_BLOCK),
+                       (size_t)lds_pad_bytes, s, B, tiles, nseg, row_stride, d1, n1, d2,
+                       reinterpret_cast<const uint32_t*>(w.need), w.qsel, w.nsel, nnr, reinterpret_cast<int32_t*>(w.knn21));
 }
 
 void launch_match_mutual_lazy(hipStream_t s, int B, int row_stride, const uint8_t* d1, const int32_t* n1,
@@ -287,19 +419,20 @@ void launch_match_mutual_lazy(hipStream_t s, int B, int row_stride, const uint8_
     if (B <= 0 || row_stride <= 0) return;
     const dim3 grid2((row_stride + 255) / 256, B);
     const int nseg = knn_pick_nseg(B, row_stride, w.knn_capacity);
-    (void)hipMemsetAsync(w.need, 0, (size_t)B * row_stride * sizeof(int32_t), s);
+    uint32_t* claim = reinterpret_cast<uint32_t*>(w.need);
+    int32_t* blocked = reinterpret_cast<int32_t*>(w.knn21);  // the reverse top-2 array is not needed any more
+    (void)hipMemsetAsync(claim, 0xFF, (size_t)B * row_stride * sizeof(uint32_t), s);
     if (tev) (void)hipEventRecord(tev[0], s);
     launch_hamming_knn2(s, B, row_stride, row_stride, d1, n1, d2, n2, w.knn12, w.knn21, 0, lds_pad_bytes, 0, nullptr,
                         nullptr, nseg);
     if (tev) (void)hipEventRecord(tev[1], s);
-    hipLaunchKernelGGL(nnr_forward_kernel, grid2, dim3(256), 0, s, nseg, row_stride, w.knn12, n1, n2, nnr, w.cand, w.need);
-    hipLaunchKernelGGL(compact_need_kernel, dim3(B), dim3(256), 0, s, row_stride, w.need, n2, w.qsel, w.nsel);
+    hipLaunchKernelGGL(nnr_forward_kernel, grid2, dim3(256), 0, s, nseg, row_stride, w.knn12, n1, n2, nnr, w.cand, claim);
+    hipLaunchKernelGGL(compact_need_kernel, dim3(B), dim3(256), 0, s, row_stride, claim, n2, w.qsel, w.nsel, blocked);
     if (tev) (void)hipEventRecord(tev[2], s);
-    launch_hamming_knn2(s, B, row_stride, row_stride, d1, n1, d2, n2, w.knn12, w.knn21, 0, lds_pad_bytes, 1, w.qsel,
-                        w.nsel, nseg);
+    launch_hamming_verify(s, B, row_stride, d1, n1, d2, nnr, w, lds_pad_bytes, nseg);
     if (tev) (void)hipEventRecord(tev[3], s);
     if (wait_before_m12_write) (void)hipStreamWaitEvent(s, wait_before_m12_write, 0);
-    hipLaunchKernelGGL(nnr_reverse_check_kernel, grid2, dim3(256), 0, s, nseg, row_stride, w.cand, w.knn21, n1, nnr, m12);
+    hipLaunchKernelGGL(nnr_reverse_check_kernel, grid2, dim3(256), 0, s, row_stride, w.cand, claim, blocked, n1, m12);
 }
 
 // Integer-VALU roof probe: the same instruction mix as K1's inner loop (xor, bcnt-accumulate,

@@ -437,25 +437,20 @@ int stvo_time_stage_dev(stvo_ctx* ctx, const stvo_track_batch_dev* b, const stvo
     HIP_TRY(ctx, hipEventCreate(&e1));
     stvo::PoseArgs a;
     fill_pose_args(b, cam, params, false, &a);
-    (void)nnr;
     HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
+    const stvo::LazyScratch lw{ctx->knn12, ctx->knn21, ctx->cand, ctx->need, ctx->qsel, ctx->nsel, ctx->knn_capacity};
     for (int it = 0; it < iters; ++it) {
-        if (stage == 0) {
-            // the two hamming_knn2 launches of one matching stage: forward scan of every prev row, then the
-            // lazy reverse scan of the columns selected by the LAST stvo_track_batched_dev call (ctx->qsel)
-            const int pad = ctx->overlap ? kOverlapLdsPad : 0;
+        const int pad = ctx->overlap ? kOverlapLdsPad : 0;
+        const int nseg = stvo::knn_pick_nseg(b->B, b->max_pts, ctx->knn_capacity);
+        if (stage == 0 || stage == 2) {  // hamming_knn2: the forward top-2 scan of every prev row
             stvo::launch_hamming_knn2(ctx->stream, b->B, b->max_pts, b->max_pts, b->prev_pdesc, b->n_prev_pts,
-                                      b->curr_pdesc, b->n_curr_pts, ctx->knn12, ctx->knn21, 0, pad, 0, nullptr, nullptr,
-                                      stvo::knn_pick_nseg(b->B, b->max_pts, ctx->knn_capacity));
+                                      b->curr_pdesc, b->n_curr_pts, ctx->knn12, ctx->knn21, 0, pad, 0, nullptr, nullptr, nseg);
+        } else if (stage == 3) {  // hamming_verify on the claims of the LAST stvo_track_batched_dev call
+            stvo::launch_hamming_verify(ctx->stream, b->B, b->max_pts, b->prev_pdesc, b->n_prev_pts, b->curr_pdesc, nnr, lw,
+                                        pad, nseg);
+        } else if (stage == 4) {  // developer probe: both directions as full top-2 scans (the pre-lazy formulation)
             stvo::launch_hamming_knn2(ctx->stream, b->B, b->max_pts, b->max_pts, b->prev_pdesc, b->n_prev_pts,
-                                      b->curr_pdesc, b->n_curr_pts, ctx->knn12, ctx->knn21, 0, pad, 1, ctx->qsel,
-                                      ctx->nsel, stvo::knn_pick_nseg(b->B, b->max_pts, ctx->knn_capacity));
-        } else if (stage >= 2) {  // developer probes: 2 forward only, 3 lazy reverse only, 4 both directions in full
-            const int pad = ctx->overlap ? kOverlapLdsPad : 0;
-            stvo::launch_hamming_knn2(ctx->stream, b->B, b->max_pts, b->max_pts, b->prev_pdesc, b->n_prev_pts,
-                                      b->curr_pdesc, b->n_curr_pts, ctx->knn12, ctx->knn21, stage == 4 ? 1 : 0, pad,
-                                      stage == 3 ? 1 : 0, stage == 3 ? ctx->qsel : nullptr,
-                                      stage == 3 ? ctx->nsel : nullptr, stvo::knn_pick_nseg(b->B, b->max_pts, ctx->knn_capacity));
+                                      b->curr_pdesc, b->n_curr_pts, ctx->knn12, ctx->knn21, 1, pad, 0, nullptr, nullptr, nseg);
         } else
             stvo::launch_pose(ctx->stream, a);
     }
@@ -465,7 +460,7 @@ int stvo_time_stage_dev(stvo_ctx* ctx, const stvo_track_batch_dev* b, const stvo
     HIP_TRY(ctx, hipEventElapsedTime(&ms, e0, e1));
     hipEventDestroy(e0);
     hipEventDestroy(e1);
-    *avg_ms = ms / (float)iters / (stage == 0 ? 2.0f : 1.0f);  // stage 0 = two launches of the same kernel
+    *avg_ms = ms / (float)iters;
     if (stage == 1 && std::getenv("STVO_POSE_PROF")) {  // developer aid: per-phase ticks of the solver lane
         long long* dprof = nullptr;
         HIP_TRY(ctx, hipMalloc((void**)&dprof, (size_t)b->B * 8 * sizeof(long long)));
