@@ -81,3 +81,50 @@ def test_match_size_independent_properties(hip):
     inv = np.empty_like(perm); inv[perm] = np.arange(len(perm))
     exp = np.where(m12 >= 0, inv[np.maximum(m12, 0)], -1)
     assert np.array_equal(mp, exp)
+
+
+def test_match_verify_shortcut_adversarial(hip, oracle):
+    """The mutual check is a range query that stops a row after 128 bits when no lane can be blocked.  Inputs built
+    to sit on every edge of that short cut: several claimants per column, rows that agree with a column in the first
+    half only (lower bound 0, true distance large), in the second half only, and distances straddling T = d0 / nnr."""
+    rng = np.random.default_rng(77)
+    n2 = 640
+    d2 = rand_desc(rng, n2)
+    rows = []
+    for j in range(0, 320):
+        base = d2[j].copy()
+        kind = j % 8
+        if kind == 0:      # three claimants of column j at distances 3, 3 and 9 (tie between the first two)
+            for nb in (3, 3, 9):
+                r = base.copy(); bits = rng.permutation(256)[:nb]
+                for b in bits: r[b >> 3] ^= np.uint8(1 << (b & 7))
+                rows.append(r)
+        elif kind == 1:    # flips only in the second half: partial distance 0
+            r = base.copy(); bits = 128 + rng.permutation(128)[: int(rng.integers(1, 60))]
+            for b in bits: r[b >> 3] ^= np.uint8(1 << (b & 7))
+            rows.append(r)
+        elif kind == 2:    # flips only in the first half
+            r = base.copy(); bits = rng.permutation(128)[: int(rng.integers(1, 60))]
+            for b in bits: r[b >> 3] ^= np.uint8(1 << (b & 7))
+            rows.append(r)
+        elif kind == 3:    # a claimant at d0 and a second row exactly at / just above the blocking threshold
+            d0 = int(rng.integers(4, 40))
+            for nb in (d0, int(np.floor(d0 / 0.75)) + int(rng.integers(-1, 2))):
+                r = base.copy(); bits = rng.permutation(256)[:nb]
+                for b in bits: r[b >> 3] ^= np.uint8(1 << (b & 7))
+                rows.append(r)
+        elif kind == 4:    # first half identical, second half random (lower bound 0, distance ~64)
+            r = base.copy(); r[16:] = rng.integers(0, 256, 16, dtype=np.uint8)
+            rows.append(r)
+            r2 = base.copy(); bits = rng.permutation(256)[:45]
+            for b in bits: r2[b >> 3] ^= np.uint8(1 << (b & 7))
+            rows.append(r2)
+        else:
+            rows.append(synth.flip_bits(rng, base[None, :], 0.08)[0])
+    d1 = np.stack(rows)[rng.permutation(len(rows))]
+    for nnr in (0.75, 0.9, 1.0, 0.3):
+        for a, b in ((d1, d2), (d2, d1)):
+            got, n = hip.match(a, b, nnr, 1)
+            exp, en = oracle.match(a, b, nnr, 1)
+            assert np.array_equal(got, exp), (nnr, np.nonzero(got != exp)[0][:10])
+            assert n == en
