@@ -37,6 +37,7 @@ struct PoseSh {
     double err, err_prev, err_out, lambda;
     double stat[4];  // scratch scalars broadcast by thread 0 (median, stdv, mean, ...)
     double s_p, s_l;
+    unsigned long long xchg;  // select_kth's one-word mailbox
     int action, good, n_inl_p, n_inl_l, n_m_p, n_m_l, evals, itmp;
 };
 
@@ -84,25 +85,63 @@ struct BlockOps {
         return v;
     }
 
-    // 28-vector block sum -> sh->tot[0..27] (summed in wave order by the solver wave)
+    // Reduce-scatter steps on gfx950's lane-swap instructions.  v_permlane32_swap exchanges the upper half of one
+    // register with the lower half of another, so ONE swap per 32-bit word plus one add leaves, in lanes 0..31, the
+    // pair sums a[L] + a[L+32] and, in lanes 32..63, b[L-32] + b[L]: two values are folded for the price of one.
+    // v_permlane16_swap does the same between the odd and even 16-lane rows.
+    static __device__ __forceinline__ double fold32(double a, double b) {
+        const unsigned long long ab = (unsigned long long)__double_as_longlong(a), bb = (unsigned long long)__double_as_longlong(b);
+        const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)ab, (unsigned)bb, false, false);
+        const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(ab >> 32), (unsigned)(bb >> 32), false, false);
+        return __longlong_as_double((long long)(((unsigned long long)hi[0] << 32) | lo[0])) +
+               __longlong_as_double((long long)(((unsigned long long)hi[1] << 32) | lo[1]));
+    }
+    static __device__ __forceinline__ double fold16(double a, double b) {
+        const unsigned long long ab = (unsigned long long)__double_as_longlong(a), bb = (unsigned long long)__double_as_longlong(b);
+        const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)ab, (unsigned)bb, false, false);
+        const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(ab >> 32), (unsigned)(bb >> 32), false, false);
+        return __longlong_as_double((long long)(((unsigned long long)hi[0] << 32) | lo[0])) +
+               __longlong_as_double((long long)(((unsigned long long)hi[1] << 32) | lo[1]));
+    }
+
+    // 28-vector block sum -> sh->tot[0..27] (wave partials summed in wave order by the solver wave).
+    // Inside a wave: 28 values -> 14 (fold32) -> 7 (fold16) per lane, then a 16-lane row scan of those 7; row r
+    // ends up with the wave totals of values 7r .. 7r+6 in its last lane.  147 VALU ops instead of the 504 of 28
+    // independent 64-lane scans; fixed association order => bit-reproducible.
     template <bool W>
     static __device__ __forceinline__ void sum28(double* acc, double (*red)[28], PoseSh* sh) {
         const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
         if (W) {
+            double s14[14], s7[7];
 #pragma unroll
-            for (int k = 0; k < 28; ++k) {
-                const double s = wave_sum_lane63(acc[k]);
-                if (lane == 63) red[wv][k] = s;
+            for (int k = 0; k < 14; ++k) s14[k] = fold32(acc[k], acc[14 + k]);
+#pragma unroll
+            for (int k = 0; k < 7; ++k) s7[k] = fold16(s14[k], s14[7 + k]);
+#pragma unroll
+            for (int k = 0; k < 7; ++k) {
+                double v = s7[k];
+                v = dpp_add<0x111, 0xf>(v);  // row_shr:1
+                v = dpp_add<0x112, 0xf>(v);  // row_shr:2
+                v = dpp_add<0x114, 0xf>(v);  // row_shr:4
+                v = dpp_add<0x118, 0xf>(v);  // row_shr:8
+                if ((lane & 15) == 15) red[wv][(lane >> 4) * 7 + k] = v;
             }
         }
         __syncthreads();
-        if (!W && lane < 28) {
-            double s = red[0][lane];
+        if (!W) {
+            if (lane < 28) {
+                double s = red[0][lane];
 #pragma unroll
-            for (int w = 1; w < NW; ++w) s += red[w][lane];
-            sh->tot[lane] = s;
+                for (int w = 1; w < NW; ++w) s += red[w][lane];
+                sh->tot[lane] = s;
+            }
+            // tot[] is consumed by lane 0 of THIS wave only (t0_unpack), so a wave-level fence is enough; the
+            // worker waves run ahead to the barrier that follows the solver's algebra, which also keeps them from
+            // overwriting `red` before it has been read here.
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        __syncthreads();
     }
 
     template <int N, bool W>
@@ -167,14 +206,11 @@ struct BlockOps {
         return base + incl - count;
     }
 
-    // count of set predicates over the workgroup; double-buffered partials => ONE barrier per call
+    // workgroup-wide total of per-wave counts (wave-uniform `c`); double-buffered partials => ONE barrier per call
     template <bool W>
-    static __device__ __forceinline__ int count_db(int v, int (*ibuf)[NW], int parity) {
+    static __device__ __forceinline__ int count_db(int c, int (*ibuf)[NW], int parity) {
         const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        if (W) {
-            const int s = wave_sum_i(v);
-            if (lane == 0) ibuf[parity][wv] = s;
-        }
+        if (W && lane == 0) ibuf[parity][wv] = c;
         __syncthreads();
         int t = 0;
 #pragma unroll
@@ -182,15 +218,55 @@ struct BlockOps {
         return t;
     }
 
-    // 1.4826 * MAD of the n values {v[k] : bit k of mask} held in REGISTERS across the workgroup.
-    // Follows vector_stdv_mad / the first half of vector_mean_stdv_mad (src/auxiliar.cpp:395-404,
-    // 447-457): median = sorted[n/2]; dev = fabsf(x - median) (FLOAT truncation); MAD = sorted dev[n/2].
-    // The two std::sort calls are replaced by exact k-th-element SELECTION: a most-significant-bit-first
-    // binary search on the order-preserving integer image of the values, one workgroup-wide count per
-    // bit (64 rounds for the doubles, 32 for the float deviations).  Same result as sorting, ~10x fewer
-    // barriers than a bitonic sort and no LDS buffer.  n == 0 -> 0.
+    // k-th smallest (0-based) of the n keys {key[k] : bit k of mask} held in REGISTERS across the workgroup:
+    // most-significant-bit-first binary search, one workgroup-wide count per bit (per-wave counts come from
+    // ballots + s_bcnt1, no cross-lane data movement).  lo / hi bracket the number of keys below the current
+    // prefix and below its upper end; as soon as exactly one key is left in the bracket it IS the answer and is
+    // fetched directly — with n ~ 1500 distinct values that happens after ~25 of the 64 (or ~18 of the 32) bits.
+    // Equal keys simply keep the search going to the last bit.  Same result as sorting.
+    template <int N, bool W, typename K, int BITS>
+    static __device__ __forceinline__ K select_kth(const K* key, unsigned mask, int n, int kth, int (*ibuf)[NW], K* xchg) {
+        K res = 0;
+        int lo = 0, hi = n, parity = 0;
+        for (int bit = BITS - 1; bit >= 0; --bit) {
+            const K t = res | ((K)1 << bit);
+            int c = 0;
+            if (W) {
+#pragma unroll
+                for (int k = 0; k < N; ++k)
+                    c += __popcll(__builtin_amdgcn_ballot_w64(((mask >> k) & 1u) && key[k] < t));
+            }
+            c = count_db<W>(c, ibuf, parity);
+            parity ^= 1;
+            if (c <= kth) {
+                res = t;
+                lo = c;
+            } else {
+                hi = c;
+            }
+            if (hi - lo == 1 && bit > 0) {  // block-uniform: the single key in [res, res + 2^bit)
+                const K top = res + (((K)1 << bit) - 1);
+                if (W) {
+#pragma unroll
+                    for (int k = 0; k < N; ++k)
+                        if (((mask >> k) & 1u) && key[k] >= res && key[k] <= top) *xchg = key[k];
+                }
+                __syncthreads();
+                res = *xchg;
+                break;
+            }
+        }
+        __syncthreads();  // ibuf / xchg are reused by the caller
+        return res;
+    }
+
+    // 1.4826 * MAD of the n values {v[k] : bit k of mask}.  Follows vector_stdv_mad / the first half of
+    // vector_mean_stdv_mad (src/auxiliar.cpp:395-404, 447-457): median = sorted[n/2]; dev = fabsf(x - median)
+    // (FLOAT truncation); MAD = sorted dev[n/2].  The two std::sort calls are replaced by exact k-th-element
+    // selection on the order-preserving integer images of the values.  n == 0 -> 0.
     template <int N, bool W>
-    static __device__ __forceinline__ double mad_sigma(const double* v, unsigned mask, int n, int (*ibuf)[NW]) {
+    static __device__ __forceinline__ double mad_sigma(const double* v, unsigned mask, int n, int (*ibuf)[NW],
+                                                       unsigned long long* xchg) {
         if (n == 0) return 0.0;  // block-uniform
         const int kth = n / 2;
         unsigned long long key[N];
@@ -199,31 +275,13 @@ struct BlockOps {
             const unsigned long long b = (unsigned long long)__double_as_longlong(v[k]);
             key[k] = (b >> 63) ? ~b : (b | 0x8000000000000000ull);  // total order of IEEE doubles
         }
-        unsigned long long res = 0ull;
-        int parity = 0;
-        for (int bit = 63; bit >= 0; --bit) {
-            const unsigned long long t = res | (1ull << bit);
-            int c = 0;
-#pragma unroll
-            for (int k = 0; k < N; ++k) c += (((mask >> k) & 1u) && key[k] < t) ? 1 : 0;
-            if (count_db<W>(c, ibuf, parity) <= kth) res = t;
-            parity ^= 1;
-        }
+        const unsigned long long res = select_kth<N, W, unsigned long long, 64>(key, mask, n, kth, ibuf, xchg);
         const unsigned long long mb = (res >> 63) ? (res & 0x7FFFFFFFFFFFFFFFull) : ~res;
         const double median = __longlong_as_double((long long)mb);
         unsigned fkey[N];
 #pragma unroll
         for (int k = 0; k < N; ++k) fkey[k] = __float_as_uint(fabsf((float)(v[k] - median)));  // >= 0 (or NaN)
-        unsigned fres = 0u;
-        for (int bit = 31; bit >= 0; --bit) {
-            const unsigned t = fres | (1u << bit);
-            int c = 0;
-#pragma unroll
-            for (int k = 0; k < N; ++k) c += (((mask >> k) & 1u) && fkey[k] < t) ? 1 : 0;
-            if (count_db<W>(c, ibuf, parity) <= kth) fres = t;
-            parity ^= 1;
-        }
-        __syncthreads();  // ibuf is reused by the caller
+        const unsigned fres = select_kth<N, W, unsigned, 32>(fkey, mask, n, kth, ibuf, reinterpret_cast<unsigned*>(xchg));
         return 1.4826 * (double)__uint_as_float(fres);
     }
 };
@@ -232,7 +290,7 @@ __device__ __forceinline__ double norm3(const double* v) { return sqrt(v[0] * v[
 
 // ---- thread-0 sections (kept out of line: each instantiates fully unrolled 6x6 algebra) --------
 
-__device__ __noinline__ void t0_unpack(PoseSh* sh) {
+__device__ __forceinline__ void t0_unpack(PoseSh* sh) {
     int k = 0;
 #pragma unroll
     for (int i = 0; i < 6; ++i)
@@ -247,8 +305,19 @@ __device__ __noinline__ void t0_unpack(PoseSh* sh) {
     sh->err = sh->tot[27] / (double)(sh->n_inl_l + sh->n_inl_p);  // :692  (0/0 -> NaN)
 }
 
+// H inc = g (ColPivHouseholderQR::solve at :417-418 and siblings): LDL^T when H is certified positive definite
+// (the normal case), the pivoted QR otherwise — see pose_math.h.
+__device__ __forceinline__ void solve_normal_eq(PoseSh* sh, double* inc, double* log_abs_det) {
+    double H[36], g[6];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) H[i] = sh->H[i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) g[i] = sh->g[i];
+    if (!pm::solve6_spd(H, g, inc, log_abs_det)) pm::solve6(H, g, inc, log_abs_det);
+}
+
 // body of gaussNewtonOptimization after optimizeFunctions (:405-428)
-__device__ __noinline__ void t0_gn_iter(PoseSh* sh, double min_error, double min_error_change, int it) {
+__device__ __forceinline__ void t0_gn_iter(PoseSh* sh, double min_error, double min_error_change, int it) {
     t0_unpack(sh);
     const double err = sh->err;
     if (err > sh->err_prev) {
@@ -260,7 +329,7 @@ __device__ __noinline__ void t0_gn_iter(PoseSh* sh, double min_error, double min
         return;
     }
     double inc[6], DT[16];
-    pm::solve6(sh->H, sh->g, inc, nullptr);
+    solve_normal_eq(sh, inc, nullptr);
 #pragma unroll
     for (int i = 0; i < 16; ++i) DT[i] = sh->DT[i];
     pm::step_pose(DT, inc);
@@ -275,7 +344,7 @@ __device__ __noinline__ void t0_gn_iter(PoseSh* sh, double min_error, double min
 }
 
 // body of gaussNewtonOptimizationRobust after optimizeFunctionsRobust (:449-467)
-__device__ __noinline__ void t0_gnr_iter(PoseSh* sh, double min_error, double min_error_change) {
+__device__ __forceinline__ void t0_gnr_iter(PoseSh* sh, double min_error, double min_error_change) {
     t0_unpack(sh);
     const double err = sh->err;
     if (fabs(err - sh->err_prev) < min_error_change || err < min_error) {
@@ -283,7 +352,7 @@ __device__ __noinline__ void t0_gnr_iter(PoseSh* sh, double min_error, double mi
         return;
     }
     double inc[6], DT[16], lad;
-    pm::solve6(sh->H, sh->g, inc, &lad);
+    solve_normal_eq(sh, inc, &lad);
     if (lad < 0.0) {
         sh->good = 0;
         sh->action = ACT_BREAK;
@@ -306,7 +375,7 @@ __device__ __noinline__ void t0_gnr_iter(PoseSh* sh, double min_error, double mi
 }
 
 // LM first iteration (:486-510) and loop body (:518-542)
-__device__ __noinline__ void t0_lm_iter(PoseSh* sh, double min_error, double min_error_change, int first) {
+__device__ __forceinline__ void t0_lm_iter(PoseSh* sh, double min_error, double min_error_change, int first) {
     t0_unpack(sh);
     const double err = sh->err;
     double inc[6], DT[16];
@@ -320,7 +389,7 @@ __device__ __noinline__ void t0_lm_iter(PoseSh* sh, double min_error, double min
         sh->lambda = 0.000000001 * Hmax;
 #pragma unroll
         for (int i = 0; i < 6; ++i) sh->H[i * 7] += sh->lambda;
-        pm::solve6(sh->H, sh->g, inc, nullptr);
+        solve_normal_eq(sh, inc, nullptr);
 #pragma unroll
         for (int i = 0; i < 16; ++i) DT[i] = sh->DT[i];
         pm::step_pose(DT, inc);
@@ -336,7 +405,7 @@ __device__ __noinline__ void t0_lm_iter(PoseSh* sh, double min_error, double min
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) sh->H[i * 7] += sh->lambda;
-    pm::solve6(sh->H, sh->g, inc, nullptr);
+    solve_normal_eq(sh, inc, nullptr);
     if (err > sh->err_prev)
         sh->lambda /= 4.0;
     else {
@@ -355,17 +424,21 @@ __device__ __noinline__ void t0_lm_iter(PoseSh* sh, double min_error, double min
     sh->action = ACT_CONTINUE;
 }
 
-__device__ __noinline__ void t0_cov_from_H(PoseSh* sh) {
-    double Hi[36];
-    pm::inverse6(sh->H, Hi);
+__device__ __forceinline__ void t0_cov_from_H(PoseSh* sh) {
+    double H[36], Hi[36];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) H[i] = sh->H[i];
+    if (!pm::inverse6_spd(H, Hi)) pm::inverse6(H, Hi);  // Matrix6d::inverse(), :429 / :470 / :545
 #pragma unroll
     for (int i = 0; i < 36; ++i) sh->cov[i] = Hi[i];
 }
 
 // isGoodSolution(DT, cov, err) -> sh->good; eigenvalues left in sh->eig
-__device__ __noinline__ void t0_is_good(PoseSh* sh, const double* DT, double err) {
-    double w[6];
-    pm::eig6(sh->cov, w);
+__device__ __forceinline__ void t0_is_good(PoseSh* sh, const double* DT, double err) {
+    double C[36], w[6];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) C[i] = sh->cov[i];
+    pm::eig6_ql(C, w);  // SelfAdjointEigenSolver::eigenvalues(), :294-295
 #pragma unroll
     for (int i = 0; i < 6; ++i) sh->eig[i] = w[i];
     sh->good = pm::is_good_solution(DT, w, err) ? 1 : 0;
@@ -374,7 +447,7 @@ __device__ __noinline__ void t0_is_good(PoseSh* sh, const double* DT, double err
 // Same decision without the eigenvalues (the stage-1 test of :341 only needs the verdict): positive
 // definiteness by LDL^T pivots and lambda_max <= ||.||_inf <= 1 certify the two eigenvalue conditions; anything
 // not certified falls back to the eigen-decomposition the reference performs.
-__device__ __noinline__ void t0_is_good_fast(PoseSh* sh, const double* DT, double err) {
+__device__ __forceinline__ void t0_is_good_fast(PoseSh* sh, const double* DT, double err) {
     if (err < 0.0 || err > 1.0 || !pm::all_finite16(DT)) {
         sh->good = 0;
         return;
@@ -389,7 +462,7 @@ __device__ __noinline__ void t0_is_good_fast(PoseSh* sh, const double* DT, doubl
     t0_is_good(sh, DT, err);
 }
 
-__device__ __noinline__ void t0_commit(PoseSh* sh, stvo_pose_result* out, int status, int path, int it0, int it1) {
+__device__ __forceinline__ void t0_commit(PoseSh* sh, stvo_pose_result* out, int status, int path, int it0, int it1) {
     // :372-391
     t0_is_good(sh, sh->DT, sh->err_out);
     double DT[16];
@@ -490,9 +563,28 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_ibuf)[BLOCK
     struct PointRec {
         double X, Y, Z, ox, oy, s2;
     };
+    // latency variant (few records per thread): the match indices stay in registers, so that fetching a record
+    // is one level of loads instead of two dependent ones
+    constexpr bool CACHE_J = PPT <= 6;
+    int jcache[CACHE_J ? PPT : 1];
+    if (CACHE_J) {
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int i = tid + k * BLOCK;
+            jcache[k] = ((pmatched >> k) & 1u) ? (a.m12p ? a.m12p[pbase + i] : i) : 0;
+        }
+    }
     auto load_point = [&](int k) -> PointRec {
         const size_t i = pbase + (size_t)(tid + k * BLOCK);
-        const size_t j = a.m12p ? pbase + (size_t)a.m12p[i] : i;
+        size_t j;
+        if (CACHE_J) {
+            int jj = jcache[0];
+#pragma unroll
+            for (int q = 1; q < (CACHE_J ? PPT : 1); ++q) jj = (k == q) ? jcache[q] : jj;
+            j = pbase + (size_t)jj;
+        } else {
+            j = a.m12p ? pbase + (size_t)a.m12p[i] : i;
+        }
         PointRec r;
         r.X = a.prev_P[i * 3 + 0];
         r.Y = a.prev_P[i * 3 + 1];
@@ -548,6 +640,18 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_ibuf)[BLOCK
         __syncthreads();
     }
 
+    double fX = 1.0, fY = 1.0, fZ = 1.0, fox = 0.0, foy = 0.0, fs2 = 1.0;  // prefetched first inlier record
+    int first_k = -1;
+    auto prefetch_first = [&]() {
+        first_k = -1;
+        if (W && pinl) {
+            first_k = __builtin_ctz(pinl);
+            const PointRec r = load_point(first_k);
+            fX = r.X; fY = r.Y; fZ = r.Z; fox = r.ox; foy = r.oy; fs2 = r.s2;
+        }
+    };
+    prefetch_first();
+
     // ---------------- optimizeFunctions / optimizeFunctionsRobust at sh->DT ----------------
     auto evaluate = [&](bool robust) {
         double DT[16];
@@ -565,7 +669,7 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_ibuf)[BLOCK
                 }
                 __builtin_amdgcn_sched_barrier(0);  // keep one record in flight, not PPT of them
             }
-            sp = pm::clamp_scale(Ops::template mad_sigma<PPT, W>(rp, pinl, sh->n_inl_p, s_ibuf));
+            sp = pm::clamp_scale(Ops::template mad_sigma<PPT, W>(rp, pinl, sh->n_inl_p, s_ibuf, &sh->xchg));
             double rl[LPT];
 #pragma unroll
             for (int k = 0; k < LPT; ++k) {
@@ -573,7 +677,7 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_ibuf)[BLOCK
                 if ((linl >> k) & 1u) rl[k] = pm::line_residual(DT, cam, load_line(k));
                 __builtin_amdgcn_sched_barrier(0);
             }
-            sl = pm::clamp_scale(Ops::template mad_sigma<LPT, W>(rl, linl, sh->n_inl_l, s_ibuf));
+            sl = pm::clamp_scale(Ops::template mad_sigma<LPT, W>(rl, linl, sh->n_inl_l, s_ibuf, &sh->xchg));
         }
         const long long tw0 = tick();
         double acc[28];
@@ -581,10 +685,17 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_ibuf)[BLOCK
         for (int i = 0; i < 28; ++i) acc[i] = 0.0;
         {
             // software pipeline over this thread's inlier points: the record of the NEXT inlier is in flight
-            // (HBM / L2 latency, two dependent loads through m12) while the current one is evaluated
+            // (L2 latency) while the current one is evaluated; the FIRST record of an evaluation was requested at the
+            // end of the previous one (or by prefetch_first), i.e. while the workgroup waited for the solver wave
             unsigned todo = pinl;
             PointRec cur{1.0, 1.0, 1.0, 0.0, 0.0, 1.0};
-            if (todo) cur = load_point(__builtin_ctz(todo));
+            if (todo) {
+                if (first_k == __builtin_ctz(todo)) {
+                    cur.X = fX; cur.Y = fY; cur.Z = fZ; cur.ox = fox; cur.oy = foy; cur.s2 = fs2;
+                } else {
+                    cur = load_point(__builtin_ctz(todo));
+                }
+            }
             while (todo) {
                 todo &= todo - 1u;
                 PointRec nxt = cur;
@@ -600,6 +711,7 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_ibuf)[BLOCK
                 pm::line_term(acc, DT, cam, prm.homog_th, L, robust, sl);
             }
         const long long tw1 = tick();
+        prefetch_first();  // for the next evaluation; completes while this one is reduced and solved
         Ops::template sum28<W>(acc, s_red, sh);
         wprof[0] += tw1 - tw0;
         wprof[1] += tick() - tw1;
@@ -637,7 +749,7 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_ibuf)[BLOCK
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            const double stdv = Ops::template mad_sigma<PPT, W>(res, pmatched, tot, s_ibuf);
+            const double stdv = Ops::template mad_sigma<PPT, W>(res, pmatched, tot, s_ibuf, &sh->xchg);
             // mean of the samples below 2 sigma, or of all samples (src/auxiliar.cpp:405-427)
             double v[3] = {0.0, 0.0, 0.0};
 #pragma unroll
@@ -675,7 +787,7 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_ibuf)[BLOCK
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            const double stdv = Ops::template mad_sigma<LPT, W>(res, lmatched, tot, s_ibuf);
+            const double stdv = Ops::template mad_sigma<LPT, W>(res, lmatched, tot, s_ibuf, &sh->xchg);
             double v[3] = {0.0, 0.0, 0.0};
 #pragma unroll
             for (int k = 0; k < LPT; ++k)
@@ -700,6 +812,7 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_ibuf)[BLOCK
             const int nil = Ops::template sum_int<W>(__popc(linl), s_ired);
             if (t0) sh->n_inl_l = nil;
         }
+        prefetch_first();  // the inlier set changed
         __syncthreads();
     };
 

@@ -12,6 +12,9 @@ void pmh_unccomp(const double* T1, const double* c1, const double* ci, double* o
 int pmh_solve6(const double* H, const double* g, double* x, double* lad) { return pm::solve6(H, g, x, lad); }
 void pmh_inverse6(const double* A, double* Ai) { pm::inverse6(A, Ai); }
 void pmh_eig6(const double* A, double* w) { pm::eig6(A, w); }
+void pmh_eig6_ql(const double* A, double* w) { pm::eig6_ql(A, w); }
+int pmh_solve6_spd(const double* H, const double* g, double* x, double* lad) { return pm::solve6_spd(H, g, x, lad) ? 1 : 0; }
+int pmh_inverse6_spd(const double* A, double* Ai) { return pm::inverse6_spd(A, Ai) ? 1 : 0; }
 void pmh_step_pose(double* DT, const double* inc) { pm::step_pose(DT, inc); }
 int pmh_spd_cert(const double* C) { return pm::spd_unit_certificate(C); }
 double pmh_line_overlap(const double* so, const double* eo, const double* sp, const double* ep) {

@@ -24,10 +24,13 @@ def pmh():
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-o", so, src])
     lib = C.CDLL(so)
-    for n in ("pmh_expmap", "pmh_logmap", "pmh_inverse_se3", "pmh_adjoint", "pmh_inverse6", "pmh_eig6", "pmh_step_pose"):
+    for n in ("pmh_expmap", "pmh_logmap", "pmh_inverse_se3", "pmh_adjoint", "pmh_inverse6", "pmh_eig6", "pmh_step_pose",
+              "pmh_eig6_ql"):
         getattr(lib, n).argtypes = [f64p, f64p]; getattr(lib, n).restype = None
     lib.pmh_unccomp.argtypes = [f64p] * 4
     lib.pmh_solve6.argtypes = [f64p, f64p, f64p, C.POINTER(C.c_double)]; lib.pmh_solve6.restype = C.c_int
+    lib.pmh_solve6_spd.argtypes = [f64p, f64p, f64p, C.POINTER(C.c_double)]; lib.pmh_solve6_spd.restype = C.c_int
+    lib.pmh_inverse6_spd.argtypes = [f64p, f64p]; lib.pmh_inverse6_spd.restype = C.c_int
     lib.pmh_line_overlap.argtypes = [f64p] * 4; lib.pmh_line_overlap.restype = C.c_double
     lib.pmh_normal_eq.argtypes = [f64p, C.POINTER(Cam), C.c_double, C.c_void_p, C.c_int, C.c_double, C.c_double, f64p]
     return lib
@@ -84,6 +87,55 @@ def test_dense6_blocks(pmh, oracle):
     inc = rng.normal(0, 0.1, 6)
     pmh.pmh_step_pose(DT, inc)
     assert np.allclose(DT.reshape(4, 4), np.eye(4) @ np_model.inverse_se3(np_model.expmap_se3(inc)), atol=1e-15)
+
+
+def test_spd_fast_paths(pmh, oracle):
+    """LDL^T solve / inverse and the tridiagonal-QL eigenvalues (what the kernel runs when H is certified SPD)
+    against the pivoted routines of the oracle; tolerances scale with the condition number."""
+    rng = np.random.default_rng(11)
+    for k in range(300):
+        scale = np.array([1, 1, 1, 30, 30, 30.0]) * 10.0 ** rng.uniform(-2, 3)
+        J = rng.normal(size=(int(rng.integers(6, 60)), 6)) * scale
+        H = J.T @ J
+        g = J.T @ rng.normal(size=J.shape[0])
+        cond = np.linalg.cond(H)
+        x = np.empty(6); lad = C.c_double()
+        ok = pmh.pmh_solve6_spd(np.ascontiguousarray(H).reshape(-1), g, x, C.byref(lad))
+        ox, olad, _ = oracle.solve6(H, g)
+        if cond < 1e9:
+            assert ok == 1
+        if ok:
+            assert np.allclose(x, ox, rtol=1e-14 * cond + 1e-13, atol=1e-15 * cond * np.abs(ox).max())
+            assert np.isclose(lad.value, olad, rtol=1e-12, atol=1e-10)
+            Ai = np.empty(36)
+            assert pmh.pmh_inverse6_spd(np.ascontiguousarray(H).reshape(-1), Ai) == 1
+            oi = oracle.inverse6(H)
+            assert np.allclose(Ai.reshape(6, 6), oi, rtol=1e-14 * cond + 1e-13, atol=1e-15 * cond * np.abs(oi).max())
+            assert np.array_equal(Ai.reshape(6, 6), Ai.reshape(6, 6).T)
+        C_ = np.linalg.inv(H)
+        C_ = 0.5 * (C_ + C_.T)
+        w = call(pmh, "pmh_eig6_ql", C_, 6)
+        ref = np.linalg.eigvalsh(C_)
+        assert np.allclose(w, ref, rtol=1e-9, atol=1e-14 * np.abs(ref).max())
+        assert np.allclose(w, oracle.eig6(C_), rtol=1e-9, atol=1e-14 * np.abs(ref).max())
+    # general symmetric (indefinite) matrices, repeated eigenvalues, diagonal and zero matrices
+    for k in range(200):
+        A = rng.normal(size=(6, 6)); A = A + A.T
+        if k % 5 == 0:
+            q, _ = np.linalg.qr(rng.normal(size=(6, 6))); A = q @ np.diag([1, 1, 1, 2, 2, -3.0]) @ q.T; A = 0.5 * (A + A.T)
+        if k % 7 == 0:
+            A = np.diag(rng.normal(size=6))
+        w = call(pmh, "pmh_eig6_ql", A, 6)
+        assert np.allclose(w, np.linalg.eigvalsh(A), rtol=1e-10, atol=1e-13)
+    assert np.array_equal(call(pmh, "pmh_eig6_ql", np.zeros((6, 6)), 6), np.zeros(6))
+    assert np.all(np.isnan(call(pmh, "pmh_eig6_ql", np.full((6, 6), np.nan), 6)))
+    # not positive definite / rank deficient / NaN: the fast paths must decline
+    x = np.empty(6); lad = C.c_double(); Ai = np.empty(36)
+    J = rng.normal(size=(3, 6)); Hs = J.T @ J
+    for bad in (Hs, -np.eye(6), np.zeros((6, 6)), np.full((6, 6), np.nan), np.diag([1, 1, 1, 1, 1, -1e-3])):
+        b = np.ascontiguousarray(bad, np.float64).reshape(-1)
+        assert pmh.pmh_solve6_spd(b, np.ones(6), x, C.byref(lad)) == 0
+        assert pmh.pmh_inverse6_spd(b, Ai) == 0
 
 
 def test_line_overlap_block(pmh, oracle):
