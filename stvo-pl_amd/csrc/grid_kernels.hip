@@ -18,15 +18,20 @@
 //                     CSR (= spatial) order, so the masks one scanning wave needs are contiguous and
 //                     almost all zero.
 //   B  `grid_scan`    lane = right feature, descriptor resident in 8 VGPRs; the left features stream
-//                     by in ASCENDING i1 as wave-uniform rows (scalar loads) — the same popcount
-//                     inner loop as K1, predicated by the candidate bit and (lines) the direction
-//                     cosine gate (:221-222); 64 masks per coalesced load, non-zero ones found by ballot;
-//                     each lane carries its running minimum, so eligibility and ownership fall out
-//                     in order; eligible pairs update the left feature's packed (best, second) keys
-//                     with a 64-bit CAS (integer keys: order-independent)
-//   C  `grid_finalize` lane = left feature: DOUBLE ratio test best_d < best_d2 * ratio with
-//                     best_d2 = INT_MAX when only one candidate was eligible (:160), mutual check
-//                     against owner (:166-174).
+//                     by in ASCENDING i1 as wave-uniform rows (scalar loads, the next row requested while the
+//                     current one is compared) — the same popcount inner loop as K1, predicated by the
+//                     candidate bit and (lines) the direction cosine gate (:221-222); 64 masks per coalesced
+//                     load, non-zero ones found by ballot; each lane carries its running minimum, so
+//                     eligibility and ownership fall out in order.  The scan runs TWICE so that no atomic
+//                     ever has to return a value (a returning global atomic costs ~1 us and one wave issues
+//                     ~150 of them back to back; that chain was the whole latency of this stage):
+//                       pass 1: best_key[i1] = min over eligible pairs of (d << 16 | i2)   (atomic min, no return)
+//                       pass 2: blocked[i1] = 1 if another eligible pair fails  best_d < d * ratio  (plain store)
+//                     With ratio <= 1 (enforced) "best_d < second_d * ratio" holds iff it holds for every
+//                     eligible candidate other than the best one, so the second-best distance itself is never
+//                     needed; one eligible candidate => nothing can block (the reference's best_d2 = INT_MAX).
+//   C  `grid_finalize` lane = left feature: accepts best unless blocked (DOUBLE ratio test of :160, evaluated
+//                     pairwise in pass 2), mutual check against owner (:166-174).
 #include <vector>
 
 #include "ctx_internal.h"
@@ -34,7 +39,7 @@
 namespace stvo {
 namespace {
 
-constexpr unsigned long long kTop2Empty = 0xFFFFFFFFFFFFFFFFull;
+constexpr unsigned long long kTop2Empty = 0x00000000FFFFFFFFull;  // no eligible candidate yet, not blocked
 
 struct GridArgs {
     const int32_t* cell_xy1;  // [n1][2] points  |  [n1][4] lines (sx, sy, ex, ey)
@@ -53,7 +58,7 @@ struct GridArgs {
     unsigned long long* cover;   // [words64][n1p]: bit p%64 of cover[p/64][i1] <=> right feature perm[p] is a candidate of i1
     const int32_t* rank;         // [n2] right feature id -> scan position p (spatial = CSR order)
     const int32_t* perm;         // [n2] scan position p -> right feature id
-    unsigned long long* top2;    // [n1] (second_key << 32) | best_key
+    unsigned long long* top2;    // [n1] low word: best eligible key (d << 16 | i2), high word: blocked flag
     int32_t* owner2;             // [n2]
     int32_t* m12;                // [n1]
 };
@@ -125,29 +130,12 @@ __device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc) {
     return r;
 }
 
-__device__ __forceinline__ void top2_insert(unsigned long long* slot, uint32_t key) {
-    unsigned long long old = *reinterpret_cast<volatile unsigned long long*>(slot);
-    while (true) {
-        const uint32_t b = (uint32_t)old, s = (uint32_t)(old >> 32);
-        unsigned long long nw;
-        if (key < b)
-            nw = ((unsigned long long)b << 32) | key;
-        else if (key < s)
-            nw = ((unsigned long long)key << 32) | b;
-        else
-            return;
-        const unsigned long long prev = atomicCAS(slot, old, nw);
-        if (prev == old) return;
-        old = prev;
-    }
-}
-
-template <bool LINES>
+template <bool LINES, int PASS>
 __global__ __launch_bounds__(256) void grid_scan_kernel(GridBatch g) {
     const GridArgs a = frame_view(g, blockIdx.y);
     // lane = scan position p; positions follow the CSR (cell) order of the right features, so the 64
     // features of a wave are spatial neighbours and only the few left features whose window touches
-    // that neighbourhood have a non-zero mask: the scan skips 8 left features per scalar load.
+    // that neighbourhood have a non-zero mask: the scan skips 64 left features per vector load.
     const int p = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
     if ((p & ~63) >= a.n2) return;  // whole wave past the last right feature (wave-uniform)
@@ -164,6 +152,7 @@ __global__ __launch_bounds__(256) void grid_scan_kernel(GridBatch g) {
     const int widx = __builtin_amdgcn_readfirstlane(p >> 6);
     const unsigned long long* __restrict__ col = a.cover + (size_t)widx * a.n1p;  // wave-uniform row of masks
     const uint32_t* __restrict__ Q = reinterpret_cast<const uint32_t*>(a.d1);
+    uint32_t* __restrict__ best_key = reinterpret_cast<uint32_t*>(a.top2);  // [2 * i1] key, [2 * i1 + 1] blocked
     // 64 masks per coalesced vector load; the ballot of the non-zero ones is walked with scalar bit tricks, so an
     // (almost always) all-zero block of 64 left features costs one load + one ballot.  The next block is
     // requested before the current one is processed.
@@ -172,10 +161,30 @@ __global__ __launch_bounds__(256) void grid_scan_kernel(GridBatch g) {
         const unsigned long long cur = mv;
         if (base + 64 < a.n1p) mv = col[base + 64 + lane];
         unsigned long long nz = __ballot(cur != 0ull);
+        // the left row of the NEXT non-zero mask (wave-uniform: scalar loads) is in flight while the current one is
+        // compared
+        uint32_t qn[8];
+        uint32_t bn = 0u;
+        if (nz) {
+            const int i1n = base + __builtin_ctzll(nz);
+#pragma unroll
+            for (int w = 0; w < 8; ++w) qn[w] = Q[8 * (size_t)i1n + w];
+            if (PASS == 2) bn = best_key[2 * (size_t)i1n];
+        }
         while (nz) {
             const int u = __builtin_ctzll(nz);
             nz &= nz - 1ull;
             const int i1 = base + u;
+            uint32_t q[8];
+#pragma unroll
+            for (int w = 0; w < 8; ++w) q[w] = qn[w];
+            const uint32_t bk = bn;
+            if (nz) {
+                const int i1n = base + __builtin_ctzll(nz);
+#pragma unroll
+                for (int w = 0; w < 8; ++w) qn[w] = Q[8 * (size_t)i1n + w];
+                if (PASS == 2) bn = best_key[2 * (size_t)i1n];
+            }
             const unsigned long long mask =
                 ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(cur >> 32), u) << 32) |
                 (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(cur & 0xFFFFFFFFull), u);
@@ -191,7 +200,6 @@ __global__ __launch_bounds__(256) void grid_scan_kernel(GridBatch g) {
                 if (fabs(dot) < a.line_sim_th) on = false;
             }
             if (!__any(on)) continue;
-            const uint32_t* __restrict__ q = Q + 8 * (size_t)i1;  // wave-uniform row -> scalar loads
             uint32_t d = __builtin_popcount(t0.x ^ q[0]);
             d = bcnt_acc(t0.y ^ q[1], d);
             d = bcnt_acc(t0.z ^ q[2], d);
@@ -209,11 +217,20 @@ __global__ __launch_bounds__(256) void grid_scan_kernel(GridBatch g) {
                         owner = i1;
                     }
                 }
-                if (eligible) top2_insert(a.top2 + i1, (d << 16) | (uint32_t)i2);
+                if (eligible) {
+                    const uint32_t key = (d << 16) | (uint32_t)i2;
+                    if (PASS == 1) {
+                        atomicMin(best_key + 2 * (size_t)i1, key);  // result unused: no-return atomic
+                    } else if (key != bk) {
+                        // :160 for the pair (best, this candidate): best_d < best_d2 * minRatio12P in DOUBLE
+                        const double best_d = (double)(int)(bk >> 16), d2 = (double)(int)d;
+                        if (!(best_d < d2 * a.ratio)) best_key[2 * (size_t)i1 + 1] = 1u;
+                    }
+                }
             }
         }
     }
-    if (live) a.owner2[i2] = owner;
+    if (PASS == 1 && live) a.owner2[i2] = owner;
 }
 
 __global__ __launch_bounds__(256) void grid_finalize_kernel(GridBatch g) {
@@ -225,13 +242,10 @@ __global__ __launch_bounds__(256) void grid_finalize_kernel(GridBatch g) {
         return;
     }
     const unsigned long long t = a.top2[i1];
-    const uint32_t b = (uint32_t)t, s = (uint32_t)(t >> 32);
+    const uint32_t b = (uint32_t)t, blocked = (uint32_t)(t >> 32);
     int m = -1;
-    if (b != 0xFFFFFFFFu) {
-        const double best_d = (double)(int)(b >> 16);
-        const double best_d2 = (s == 0xFFFFFFFFu) ? 2147483647.0 : (double)(int)(s >> 16);
-        if (best_d < best_d2 * a.ratio) m = (int)(b & 0xFFFFu);  // :160 (double)
-    }
+    // :160 — decided pairwise by scan pass 2; with a single eligible candidate best_d2 stays INT_MAX
+    if (b != 0xFFFFFFFFu && !blocked && (double)(int)(b >> 16) < 2147483647.0 * a.ratio) m = (int)(b & 0xFFFFu);
     if (a.mutual && m >= 0 && a.owner2[m] != i1) m = -1;  // :166-174
     a.m12[i1] = m;
 }
@@ -245,10 +259,12 @@ void launch_grid_batch(hipStream_t s, const GridBatch& g, bool lines) {
     const dim3 g1((g.stride1 + 255) / 256, g.B), g2((g.stride2 + 255) / 256, g.B), blk(256);
     if (lines) {
         hipLaunchKernelGGL((grid_cover_kernel<true>), g1, blk, 0, s, g);
-        hipLaunchKernelGGL((grid_scan_kernel<true>), g2, blk, 0, s, g);
+        hipLaunchKernelGGL((grid_scan_kernel<true, 1>), g2, blk, 0, s, g);
+        hipLaunchKernelGGL((grid_scan_kernel<true, 2>), g2, blk, 0, s, g);
     } else {
         hipLaunchKernelGGL((grid_cover_kernel<false>), g1, blk, 0, s, g);
-        hipLaunchKernelGGL((grid_scan_kernel<false>), g2, blk, 0, s, g);
+        hipLaunchKernelGGL((grid_scan_kernel<false, 1>), g2, blk, 0, s, g);
+        hipLaunchKernelGGL((grid_scan_kernel<false, 2>), g2, blk, 0, s, g);
     }
     hipLaunchKernelGGL(grid_finalize_kernel, g1, blk, 0, s, g);
 }

@@ -1,0 +1,13 @@
+#!/bin/bash
+# Single-stream latency of the per-frame pipeline (unprofiled): handler API vs device pipeline, points only and points + lines.
+#   tools/latency.sh <outfile>
+R=$PWD; OUT=$R/$1; mkdir -p $(dirname $OUT)
+python tools/make_sequence.py /tmp/seq_p.bin --frames 51 > /dev/null
+python tools/make_sequence.py /tmp/seq_l.bin --frames 51 --lines 100 > /dev/null
+{
+for s in p l; do
+  $R/stvo-pl_amd/bin/imagesStVO_synth /tmp/seq_$s.bin /tmp/res_h$s.bin --preset kitti | tail -1
+  $R/stvo-pl_amd/bin/imagesStVO_synth /tmp/seq_$s.bin /tmp/res_d$s.bin --preset kitti --device-pipeline | tail -1
+done
+} > $OUT 2>&1
+cat $OUT
