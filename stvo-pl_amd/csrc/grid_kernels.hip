@@ -39,6 +39,9 @@
 namespace stvo {
 namespace {
 
+#ifndef GRID_ROWS_PER_TRIP
+#define GRID_ROWS_PER_TRIP 1
+#endif
 constexpr unsigned long long kTop2Empty = 0x00000000FFFFFFFFull;  // no eligible candidate yet, not blocked
 
 struct GridArgs {
@@ -151,80 +154,128 @@ __global__ __launch_bounds__(256) void grid_scan_kernel(GridBatch g) {
     int run_min = 0x7FFFFFFF, owner = -1;
     const int widx = __builtin_amdgcn_readfirstlane(p >> 6);
     const unsigned long long* __restrict__ col = a.cover + (size_t)widx * a.n1p;  // wave-uniform row of masks
-    const uint32_t* __restrict__ Q = reinterpret_cast<const uint32_t*>(a.d1);
     uint32_t* __restrict__ best_key = reinterpret_cast<uint32_t*>(a.top2);  // [2 * i1] key, [2 * i1 + 1] blocked
     // 64 masks per coalesced vector load; the ballot of the non-zero ones is walked with scalar bit tricks, so an
-    // (almost always) all-zero block of 64 left features costs one load + one ballot.  The next block is
-    // requested before the current one is processed.
-    unsigned long long mv = col[lane];  // n1p is a multiple of 64
-    for (int base = 0; base < a.n1p; base += 64) {
-        const unsigned long long cur = mv;
-        if (base + 64 < a.n1p) mv = col[base + 64 + lane];
-        unsigned long long nz = __ballot(cur != 0ull);
-        // the left row of the NEXT non-zero mask (wave-uniform: scalar loads) is in flight while the current one is
-        // compared
-        uint32_t qn[8];
-        uint32_t bn = 0u;
-        if (nz) {
-            const int i1n = base + __builtin_ctzll(nz);
-#pragma unroll
-            for (int w = 0; w < 8; ++w) qn[w] = Q[8 * (size_t)i1n + w];
-            if (PASS == 2) bn = best_key[2 * (size_t)i1n];
+    // (almost always) all-zero block of 64 left features costs one load + one ballot.
+    // Software pipeline, two blocks deep: lane u of the wave fetches the mask of left feature base + u, and — one
+    // block later, once the mask is known to be non-zero — that feature's descriptor row (and, per variant, its
+    // cell coordinates / best key) with ordinary vector loads.  The row loop then broadcasts row u out of lane u's
+    // registers with v_readlane: no memory access, hence no memory latency, inside the per-row loop.  (Fetching
+    // each row with wave-uniform scalar loads cost one scalar-cache miss, ~0.3 us, per row even with the next row
+    // prefetched.)
+    const uint4* __restrict__ Q4 = reinterpret_cast<const uint4*>(a.d1);
+    const int4* __restrict__ XY4 = reinterpret_cast<const int4*>(a.cell_xy1);
+    (void)XY4;
+    // branch-free loads (clamped index, value discarded) so that the compiler can count the loads in flight and
+    // wait for exactly the ones it needs instead of draining the queue in every block
+    const int last_blk = a.n1p - 64;
+    auto mask_at = [&](int blk) -> unsigned long long {
+        const unsigned long long m = col[(blk < a.n1p ? blk : last_blk) + lane];
+        return blk < a.n1p ? m : 0ull;
+    };
+    unsigned long long m_next = mask_at(0), m_next2 = mask_at(64);
+    uint4 ra = make_uint4(0, 0, 0, 0), rb = make_uint4(0, 0, 0, 0);
+    double rvx = 0.0, rvy = 0.0;  // lines: unit direction of left line base + lane, computed once per line by its lane
+    uint32_t rk = 0u;
+    auto rows_at = [&](int blk, unsigned long long m) {
+        // lanes whose left feature is nobody's candidate in this wave read row 0 instead (one shared cache line)
+        const size_t i1 = (m != 0ull) ? (size_t)(blk + lane) : (size_t)0;
+        ra = Q4[2 * i1];
+        rb = Q4[2 * i1 + 1];
+        if (LINES) {
+            // direction of the LEFT line from INTEGER cell differences; 0/0 = NaN never skips (:207-222)
+            const int4 c = XY4[i1];
+            const double vx = (double)(c.z - c.x), vy = (double)(c.w - c.y);
+            const double mag = sqrt(vx * vx + vy * vy);
+            rvx = vx / mag;
+            rvy = vy / mag;
         }
+        if (PASS == 2) rk = best_key[2 * i1];
+    };
+    rows_at(0, m_next);
+    for (int base = 0; base < a.n1p; base += 64) {
+        const unsigned long long cur = m_next;
+        const uint4 qa = ra, qb = rb;
+        const double qvx = rvx, qvy = rvy;
+        const uint32_t qk = rk;
+        m_next = m_next2;
+        m_next2 = mask_at(base + 128);
+        rows_at(base + 64, m_next);
+        unsigned long long nz = __ballot(cur != 0ull);
+        // R rows per trip: their masks / descriptors are broadcast and their distances computed as independent
+        // chains (with one wave per SIMD in single-stream operation every dependent instruction pays its full
+        // latency), then eligibility is applied in ascending i1.  A short last group repeats its last row, masked off.
+        constexpr int R = GRID_ROWS_PER_TRIP;
         while (nz) {
-            const int u = __builtin_ctzll(nz);
-            nz &= nz - 1ull;
-            const int i1 = base + u;
-            uint32_t q[8];
+            int us[R];
+            bool valid[R];
 #pragma unroll
-            for (int w = 0; w < 8; ++w) q[w] = qn[w];
-            const uint32_t bk = bn;
-            if (nz) {
-                const int i1n = base + __builtin_ctzll(nz);
+            for (int k = 0; k < R; ++k) {
+                valid[k] = nz != 0ull;
+                us[k] = valid[k] ? __builtin_ctzll(nz) : us[k > 0 ? k - 1 : 0];
+                if (valid[k]) nz &= nz - 1ull;
+            }
+            bool on[R];
+            uint32_t d[R];
 #pragma unroll
-                for (int w = 0; w < 8; ++w) qn[w] = Q[8 * (size_t)i1n + w];
-                if (PASS == 2) bn = best_key[2 * (size_t)i1n];
+            for (int k = 0; k < R; ++k) {
+                const int u = us[k];
+                const unsigned long long mask =
+                    ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(cur >> 32), u) << 32) |
+                    (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(cur & 0xFFFFFFFFull), u);
+                on[k] = valid[k] && live && ((mask >> lane) & 1ull);
+                if (LINES) {
+                    auto bcast = [&](double v) -> double {
+                        const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+                        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(bits & 0xFFFFFFFFull), u);
+                        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(bits >> 32), u);
+                        return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+                    };
+                    const double dot = bcast(qvx) * dirx + bcast(qvy) * diry;
+                    if (fabs(dot) < a.line_sim_th) on[k] = false;  // NaN direction: comparison false, candidate kept
+                }
+                uint32_t q[8];
+                q[0] = (uint32_t)__builtin_amdgcn_readlane((int)qa.x, u);
+                q[1] = (uint32_t)__builtin_amdgcn_readlane((int)qa.y, u);
+                q[2] = (uint32_t)__builtin_amdgcn_readlane((int)qa.z, u);
+                q[3] = (uint32_t)__builtin_amdgcn_readlane((int)qa.w, u);
+                q[4] = (uint32_t)__builtin_amdgcn_readlane((int)qb.x, u);
+                q[5] = (uint32_t)__builtin_amdgcn_readlane((int)qb.y, u);
+                q[6] = (uint32_t)__builtin_amdgcn_readlane((int)qb.z, u);
+                q[7] = (uint32_t)__builtin_amdgcn_readlane((int)qb.w, u);
+                uint32_t dd = __builtin_popcount(t0.x ^ q[0]);
+                dd = bcnt_acc(t0.y ^ q[1], dd);
+                dd = bcnt_acc(t0.z ^ q[2], dd);
+                dd = bcnt_acc(t0.w ^ q[3], dd);
+                dd = bcnt_acc(t1.x ^ q[4], dd);
+                dd = bcnt_acc(t1.y ^ q[5], dd);
+                dd = bcnt_acc(t1.z ^ q[6], dd);
+                dd = bcnt_acc(t1.w ^ q[7], dd);
+                d[k] = dd;
             }
-            const unsigned long long mask =
-                ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(cur >> 32), u) << 32) |
-                (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(cur & 0xFFFFFFFFull), u);
-            bool on = live && ((mask >> lane) & 1ull);
-            if (LINES) {
-                // direction of the LEFT line from INTEGER cell differences; 0/0 = NaN never skips (:207-222)
-                const int4 c = reinterpret_cast<const int4*>(a.cell_xy1)[i1];
-                double vx = (double)(c.z - c.x), vy = (double)(c.w - c.y);
-                const double mag = sqrt(vx * vx + vy * vy);
-                vx /= mag;
-                vy /= mag;
-                const double dot = vx * dirx + vy * diry;
-                if (fabs(dot) < a.line_sim_th) on = false;
-            }
-            if (!__any(on)) continue;
-            uint32_t d = __builtin_popcount(t0.x ^ q[0]);
-            d = bcnt_acc(t0.y ^ q[1], d);
-            d = bcnt_acc(t0.z ^ q[2], d);
-            d = bcnt_acc(t0.w ^ q[3], d);
-            d = bcnt_acc(t1.x ^ q[4], d);
-            d = bcnt_acc(t1.y ^ q[5], d);
-            d = bcnt_acc(t1.z ^ q[6], d);
-            d = bcnt_acc(t1.w ^ q[7], d);
-            if (on) {
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                if (!on[k]) continue;  // per lane
+                const int i1 = base + us[k];
                 bool eligible = true;
                 if (a.mutual) {  // bestLRMatches: running strict minimum per right feature (:145-150)
-                    eligible = (int)d < run_min;
+                    eligible = (int)d[k] < run_min;
                     if (eligible) {
-                        run_min = (int)d;
+                        run_min = (int)d[k];
                         owner = i1;
                     }
                 }
                 if (eligible) {
-                    const uint32_t key = (d << 16) | (uint32_t)i2;
+                    const uint32_t key = (d[k] << 16) | (uint32_t)i2;
                     if (PASS == 1) {
                         atomicMin(best_key + 2 * (size_t)i1, key);  // result unused: no-return atomic
-                    } else if (key != bk) {
-                        // :160 for the pair (best, this candidate): best_d < best_d2 * minRatio12P in DOUBLE
-                        const double best_d = (double)(int)(bk >> 16), d2 = (double)(int)d;
-                        if (!(best_d < d2 * a.ratio)) best_key[2 * (size_t)i1 + 1] = 1u;
+                    } else {
+                        const uint32_t bk = (uint32_t)__builtin_amdgcn_readlane((int)qk, us[k]);
+                        if (key != bk) {
+                            // :160 for the pair (best, this candidate): best_d < best_d2 * minRatio12P in DOUBLE
+                            const double best_d = (double)(int)(bk >> 16), d2 = (double)(int)d[k];
+                            if (!(best_d < d2 * a.ratio)) best_key[2 * (size_t)i1 + 1] = 1u;
+                        }
                     }
                 }
             }
