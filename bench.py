@@ -30,7 +30,7 @@ K1_LANE_OPS_PER_PAIR = 19
 VALU_PEAK_LANE_OPS = K1_LANE_OPS_PER_PAIR / (8 / 78.6e12 + 11 / 39.3e12)  # = 49.8e12
 
 
-def committed_traffic(kernel="hamming_knn2_kernel", path=os.path.join(ROOT, "profiles", "r01_c_hbm_counters.txt")):
+def committed_traffic(kernel="hamming_knn2_kernel", path=os.path.join(ROOT, "profiles", "r01_e_hbm_counters.txt")):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, separate
     `--pmc` runs summarised by tools/rocprof_summary.py; values there are KB per dispatch).  None if unavailable."""
     try:
@@ -174,7 +174,7 @@ def main():
             "roofline": {"kernel": "hamming_knn2_kernel", "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": committed_traffic(),
                          "traffic_source": "bytes per launch = FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes, read from "
-                                           "the committed profiles/r01_c_hbm_counters.txt (not re-measured by this run)",
+                                           "the committed profiles/r01_e_hbm_counters.txt (not re-measured by this run)",
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k1_ms, "timing": "hipEvent pairs around each launch, on the launch stream, over a second pass of the same K steps",
                          "note": "K1 is integer-VALU bound (~1000 lane-ops per compulsory byte); see valu_roofline. One launch per step"},
             "valu_roofline": {"kernel": "hamming_knn2_kernel", "lane_ops_per_launch": lane_ops,

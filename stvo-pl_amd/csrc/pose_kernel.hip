@@ -2,19 +2,21 @@
 // (/root/reference/src/stereoFrameHandler.cpp:307-392) as ONE kernel launch, one workgroup per
 // frame pair, FP64 throughout.
 //
-//   * each thread owns up to PPT matched points and LPT matched lines; their records (52 B / 116 B
-//     of live data) are read from HBM exactly ONCE and then stay in VGPRs
-//     for all <= 15 optimizeFunctions evaluations, the outlier removal and the commit;
+//   * worker waves + ONE solver wave per workgroup (same source, template flag W): a worker thread owns
+//     up to PPT matched points and LPT matched lines as two bitmasks (matched / inlier); the records
+//     (52 B / 116 B of live data) are streamed from L2 at every evaluation
+//     with the next record in flight, so that several workgroups share a CU;
 //   * optimizeFunctions / optimizeFunctionsRobust (:549-962): fused transform + project + residual
 //     + 1x6 gradient + Cauchy weight (x overlap for lines) per feature, 28 FP64 partial sums per
-//     thread (21 upper-triangular H + 6 g + 1 e), fixed-order reduction: xor-butterfly inside
-//     each wave64, then wave partials summed in wave order through LDS => bit-reproducible;
-//   * removeOutliers (:988-1067) and the robust scale (:742-781): residuals compacted into an LDS
-//     buffer, bitonic sort, median / MAD with the reference's fabsf float truncation
-//     (src/auxiliar.cpp:387-460);
+//     thread (21 upper-triangular H + 6 g + 1 e); wave reduction = reduce-scatter on
+//     v_permlane32_swap / v_permlane16_swap + a 16-lane DPP row scan, wave partials summed in wave
+//     order by the solver wave => bit-reproducible;
+//   * removeOutliers (:988-1067) and the robust scale (:742-781): median / MAD by exact k-th element
+//     selection on register-resident values (no sort, no LDS buffer), with the reference's fabsf
+//     float truncation (src/auxiliar.cpp:387-460);
 //   * the 6x6 algebra, SE(3) updates and every data-dependent branch of the GN / robust-GN / LM
-//     loops (:394-547) run on thread 0 from registers (pose_math.h) and are broadcast through LDS,
-//     so the control flow is block-uniform and matches the reference iteration for iteration.
+//     loops (:394-547) run on one lane of the solver wave (pose_math.h) and are broadcast through
+//     LDS, so the control flow is block-uniform and matches the reference iteration for iteration.
 #include "kernels.h"
 #include "pose_math.h"
 
@@ -288,7 +290,7 @@ struct BlockOps {
 
 __device__ __forceinline__ double norm3(const double* v) { return sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
 
-// ---- thread-0 sections (kept out of line: each instantiates fully unrolled 6x6 algebra) --------
+// ---- solver-lane sections (inlined into the solver instantiation only: W == true never reaches them) ----
 
 __device__ __forceinline__ void t0_unpack(PoseSh* sh) {
     int k = 0;
