@@ -202,6 +202,31 @@ PM_HD void unccomp_se3(const double* T1, const double* cov1, const double* covin
         }
 }
 
+// uncTinv_se3: Ad(T^-1) cov Ad(T^-1)^T            (src/auxiliar.cpp:184-190)
+PM_HD void uncTinv_se3(const double* T, const double* cov, double* out) {
+    double Ti[16], A[36], tmp[36];
+    inverse_se3(T, Ti);
+    adjoint_se3(Ti, A);
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) s += A[i * 6 + k] * cov[k * 6 + j];
+            tmp[i * 6 + j] = s;
+        }
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) s += tmp[i * 6 + k] * A[j * 6 + k];
+            out[i * 6 + j] = s;
+        }
+}
+
 // DT <- DT * inverse_se3(expmap_se3(inc))        (src/stereoFrameHandler.cpp:419)
 PM_HD void step_pose(double* DT, const double* inc) {
     double E[16], Ei[16], o[16];
@@ -380,6 +405,48 @@ PM_HD void inverse6(const double* Ain, double* Ai) {
     }
 #pragma unroll
     for (int i = 0; i < 36; ++i) Ai[i] = B[i];
+}
+
+// Determinant by LU with partial pivoting (what Matrix6d::determinant() does for a 6x6: PartialPivLU).
+PM_HD double det6(const double* Ain) {
+    double A[36];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) A[i] = Ain[i];
+    double det = 1.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        int p = k;
+        double best = fabs(A[k * 6 + k]);
+#pragma unroll
+        for (int i = k + 1; i < 6; ++i) {
+            const double v = fabs(A[i * 6 + k]);
+            if (v > best) {
+                best = v;
+                p = i;
+            }
+        }
+#pragma unroll
+        for (int i = k + 1; i < 6; ++i) {
+            const bool sw = (p == i);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const double a = A[k * 6 + j], b = A[i * 6 + j];
+                A[k * 6 + j] = sw ? b : a;
+                A[i * 6 + j] = sw ? a : b;
+            }
+        }
+        if (p != k) det = -det;
+        const double piv = A[k * 6 + k];
+        det *= piv;
+        if (piv == 0.0) return 0.0;
+#pragma unroll
+        for (int i = k + 1; i < 6; ++i) {
+            const double l = A[i * 6 + k] / piv;
+#pragma unroll
+            for (int j = k + 1; j < 6; ++j) A[i * 6 + j] -= l * A[k * 6 + j];
+        }
+    }
+    return det;
 }
 
 // Ascending eigenvalues of the symmetric matrix given by the LOWER triangle of Ain

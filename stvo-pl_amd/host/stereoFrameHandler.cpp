@@ -46,6 +46,7 @@ void StereoFrameHandler::initialize(const FrameFeatures& feat, const int idx_) {
     prev_frame->Tfw_cov = Matrix6d::Identity();
     prev_frame->DT = Matrix4d::Identity();
     curr_frame = prev_frame;
+    kf = KeyFrameState{};  // :48-51
 }
 
 // :54-60
@@ -250,6 +251,23 @@ void StereoFrameHandler::resetOutliers() {
     n_inliers_pt = (int)matched_pt.size();
     n_inliers_ls = (int)matched_ls.size();
     n_inliers = n_inliers_pt + n_inliers_ls;
+}
+
+// :1136-1188
+bool StereoFrameHandler::needNewKF() {
+    return kf_need_new(kf, curr_frame->Tfw, curr_frame->DT, curr_frame->DT_cov, Config::minEntropyRatio(), Config::maxKFTDist(),
+                       Config::maxKFRDist());
+}
+
+// :1190-1218
+void StereoFrameHandler::currFrameIsKF() {
+    int idx_pt = 0;
+    for (auto pt : curr_frame->stereo_pt) pt->idx = idx_pt++;
+    int idx_ls = 0;
+    for (auto ls : curr_frame->stereo_ls) ls->idx = idx_ls++;
+    curr_frame->Tfw = Matrix4d::Identity();
+    curr_frame->Tfw_cov = Matrix6d::Identity();
+    kf_reset(kf, curr_frame->Tfw);
 }
 
 void StereoFrameHandler::setAsOutliers() {

@@ -7,6 +7,7 @@
 #include <list>
 
 #include "../../include/stvo_hip.h"
+#include "keyframe.h"
 #include "stereoFrame.h"
 
 namespace StVO {
@@ -28,6 +29,11 @@ public:
     void optimizePose();
     void resetOutliers();
     void setAsOutliers();
+
+    // slam functions (src/stereoFrameHandler.cpp:1134-1218)
+    bool needNewKF();
+    void currFrameIsKF();
+    KeyFrameState kf;  // prev_f_iskf, entropy_first_prevKF, T_prevKF, cov_prevKF_currF, N_prevKF_currF (:81-85)
 
     // adaptative fast
     int orb_fast_th;

@@ -2,8 +2,28 @@
 // blocks the HIP pose kernel is made of) to the CPU test-suite, so that the algebra the GPU runs
 // is checked against the oracle in this GPU-less container.  Not part of the product library.
 #include "../../stvo-pl_amd/csrc/pose_math.h"
+#include "../../stvo-pl_amd/host/keyframe.h"
 
 extern "C" {
+double pmh_det6(const double* A) { return pm::det6(A); }
+void pmh_unctinv(const double* T, const double* cov, double* out) { pm::uncTinv_se3(T, cov, out); }
+// key-frame decision over a sequence of n frames: inputs Tfw[n][16], DT[n][16], DTcov[n][36]; a frame that needs a new
+// key-frame is made one (its Tfw becomes identity for the state, like currFrameIsKF).  out[n] = decision, acc[n][36] =
+// accumulated covariance after each call, ent[n] = entropy_first_prevKF after each call.
+void pmh_kf_sequence(int n, const double* Tfw, const double* DT, const double* DTcov, double min_ratio, double max_t, double max_r,
+                     int* out, double* acc, double* ent) {
+    StVO::KeyFrameState k;
+    for (int f = 0; f < n; ++f) {
+        StVO::Matrix4d T, D;
+        StVO::Matrix6d C;
+        for (int i = 0; i < 16; ++i) { T.m[i] = Tfw[f * 16 + i]; D.m[i] = DT[f * 16 + i]; }
+        for (int i = 0; i < 36; ++i) C.m[i] = DTcov[f * 36 + i];
+        out[f] = StVO::kf_need_new(k, T, D, C, min_ratio, max_t, max_r, false) ? 1 : 0;
+        for (int i = 0; i < 36; ++i) acc[f * 36 + i] = k.cov_prevKF_currF.m[i];
+        ent[f] = k.entropy_first_prevKF;
+        if (out[f]) StVO::kf_reset(k, StVO::Matrix4d::Identity());
+    }
+}
 void pmh_expmap(const double* x, double* T) { pm::expmap_se3(x, T); }
 void pmh_logmap(const double* T, double* x) { pm::logmap_se3(T, x); }
 void pmh_inverse_se3(const double* T, double* Ti) { pm::inverse_se3(T, Ti); }

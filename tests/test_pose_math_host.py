@@ -197,3 +197,65 @@ def test_spd_certificate_never_contradicts_eig(pmh):
             w = np.linalg.eigvalsh(S)
             assert w[0] >= 0.0 and w[-1] <= 1.0, (kind, w)
     assert n_cert > 500  # the shortcut actually fires on the common case
+
+
+def test_keyframe_decision(pmh):
+    """needNewKF / currFrameIsKF (src/stereoFrameHandler.cpp:1134-1218) of the host mirror against a numpy model:
+    entropy of the first frame after a key-frame, accumulated covariance through Ad(T_prevKF) uncTinv(DT, DT_cov)
+    Ad^T, geometric thresholds, the 10-frame limit and the DT == I / cov == 0 (failed frame) rule."""
+    i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+    pmh.pmh_kf_sequence.argtypes = [C.c_int, f64p, f64p, f64p, C.c_double, C.c_double, C.c_double, i32p, f64p, f64p]
+    pmh.pmh_det6.argtypes = [f64p]; pmh.pmh_det6.restype = C.c_double
+    pmh.pmh_unctinv.argtypes = [f64p, f64p, f64p]
+    rng = np.random.default_rng(5)
+    for _ in range(50):
+        A = rng.normal(size=(6, 6))
+        assert np.isclose(pmh.pmh_det6(np.ascontiguousarray(A).reshape(-1)), np.linalg.det(A), rtol=1e-11, atol=1e-13)
+    assert pmh.pmh_det6(np.zeros(36)) == 0.0
+
+    def adj(T):
+        R, t = T[:3, :3], T[:3, 3]
+        sk = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+        Ad = np.zeros((6, 6)); Ad[:3, :3] = R; Ad[:3, 3:] = sk @ R; Ad[3:, 3:] = R
+        return Ad
+
+    n = 60
+    Tfw = np.zeros((n, 4, 4)); DT = np.zeros((n, 4, 4)); DC = np.zeros((n, 6, 6))
+    T = np.eye(4)
+    for f in range(n):
+        inc = np.concatenate([rng.normal(0, 0.02, 2), [-rng.uniform(0.3, 1.2)], rng.normal(0, 0.01, 3)])
+        D = np_model.expmap_se3(inc)
+        J = rng.normal(size=(20, 6)) * np.array([30, 30, 30, 300, 300, 300.0]) * rng.uniform(0.5, 3)
+        Cv = np.linalg.inv(J.T @ J)
+        if f % 17 == 9:  # a failed frame as optimizePose leaves it (:382-391)
+            D = np.eye(4); Cv = np.zeros((6, 6))
+        T = T @ D
+        Tfw[f], DT[f], DC[f] = T, D, Cv
+    # numpy model (Tfw is taken relative to the last key-frame exactly as the C side is driven: state reset to identity)
+    exp_out = np.zeros(n, np.int32); exp_acc = np.zeros((n, 6, 6)); exp_ent = np.zeros(n)
+    k_is, k_ent, k_T, k_cov, k_N = True, 0.0, np.eye(4), np.zeros((6, 6)), 0
+    c0 = 3.0 * (1.0 + np.log(2.0 * np.pi))
+    for f in range(n):
+        if k_is:
+            det = np.linalg.det(DC[f])
+            k_ent = c0 + 0.5 * np.log(det) if det != 0.0 else -999999999.99
+            k_is = False
+        dX = np_model.logmap_se3(np_model.inverse_se3(Tfw[f]) @ k_T)
+        t = np.linalg.norm(dX[:3]); r = np.linalg.norm(dX[3:]) * 180.0 / np.pi
+        Ai = adj(np_model.inverse_se3(DT[f])); cinv = Ai @ DC[f] @ Ai.T
+        Ak = adj(k_T); k_cov = k_cov + Ak @ cinv @ Ak.T
+        with np.errstate(divide="ignore", invalid="ignore"):
+            ratio = (c0 + 0.5 * np.log(np.linalg.det(k_cov))) / k_ent
+        need = bool(ratio < 0.85 or np.isnan(ratio) or np.isinf(ratio) or (not DC[f].any() and np.array_equal(DT[f], np.eye(4)))
+                    or t > 5.0 or r > 15.0 or k_N > 10)
+        exp_out[f] = need; exp_acc[f] = k_cov; exp_ent[f] = k_ent
+        if need:
+            k_T, k_cov, k_is, k_N = np.eye(4), np.zeros((6, 6)), True, 0
+        else:
+            k_N += 1
+    out = np.zeros(n, np.int32); acc = np.zeros((n, 36)); ent = np.zeros(n)
+    pmh.pmh_kf_sequence(n, Tfw.reshape(-1).copy(), DT.reshape(-1).copy(), DC.reshape(-1).copy(), 0.85, 5.0, 15.0, out, acc.reshape(-1), ent)
+    assert np.array_equal(out, exp_out)
+    assert 3 <= out.sum() < n  # both outcomes occur
+    assert np.allclose(acc.reshape(n, 6, 6), exp_acc, rtol=1e-9, atol=1e-18)
+    assert np.allclose(ent, exp_ent, rtol=1e-10)
