@@ -445,6 +445,14 @@ struct stvo_seq {
     int32_t *owner2, *m12s_p, *m12s_l, *m12p, *m12l, *inlp, *inll, *counts;
     stvo_pose_result* results;
     char* out_host = nullptr;  // pinned: results + counts
+    // second stream: the line stage (stereo association + f2f of the key-lines) is independent of the point stage
+    // until optimizePose (the reference runs the two in parallel threads, stereoFrame.cpp:67-72, stereoFrameHandler.cpp:
+    // 115-118) and its kernels are far too small to fill the GPU, so it runs concurrently on its own scratch
+    hipStream_t line_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    unsigned long long *cover_l = nullptr, *top2_l = nullptr;
+    int32_t* owner2_l = nullptr;
+    stvo::LazyScratch lazy_l{};
     bool zero_copy = false;    // small batches: kernels write results / counts straight into out_host
     bool raw_lines[2] = {false, false};  // slot holds at least one left and one right key-line
     bool set_lines[2] = {false, false};  // stereo set was built from a frame with key-lines
@@ -519,6 +527,10 @@ int stvo_seq_create(stvo_ctx* ctx, int B, int max_keypoints, int max_keylines, i
     const size_t o_m12sp = c.take(nb * K * 4), o_m12sl = c.take(nb * M * 4), o_m12p = c.take(nb * K * 4), o_m12l = c.take(nb * M * 4),
                  o_inlp = c.take(nb * K * 4), o_inll = c.take(nb * M * 4), o_res = c.take(nb * sizeof(stvo_pose_result)),
                  o_counts = c.take(nb * 4 * 4);
+    const size_t cap_l = nb * (size_t)M * 4;  // line f2f: up to 4 train segments
+    const size_t o_cover_l = c.take(nb * (size_t)(M / 64) * M * 8), o_top2_l = c.take(nb * M * 8), o_owner_l = c.take(nb * M * 4),
+                 o_knn12_l = c.take(cap_l * 8), o_knn21_l = c.take(cap_l * 8), o_cand_l = c.take(nb * M * 4),
+                 o_need_l = c.take(nb * M * 4), o_qsel_l = c.take(nb * M * 4), o_nsel_l = c.take(nb * 4);
     size_t o_set[2][14];
     for (int t = 0; t < 2; ++t) {
         o_set[t][0] = c.take(nb * K * 2 * 8);
@@ -541,12 +553,18 @@ int stvo_seq_create(stvo_ctx* ctx, int B, int max_keypoints, int max_keylines, i
               hip_ok(ctx, hipMemset(s->dev, 0, s->dev_bytes), "hipMemset seq") &&
               hip_ok(ctx, hipHostMalloc((void**)&s->raw_host, s->raw_bytes, hipHostMallocDefault), "hipHostMalloc seq") &&
               hip_ok(ctx, hipHostMalloc((void**)&s->out_host, nb * (sizeof(stvo_pose_result) + 16), hipHostMallocDefault),
-                     "hipHostMalloc seq out");
+                     "hipHostMalloc seq out") &&
+              hip_ok(ctx, hipStreamCreateWithFlags(&s->line_stream, hipStreamNonBlocking), "hipStreamCreate seq") &&
+              hip_ok(ctx, hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming), "hipEventCreate seq") &&
+              hip_ok(ctx, hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming), "hipEventCreate seq");
     s->zero_copy = B <= 16;
     if (!ok) {
         if (s->dev) hipFree(s->dev);
         if (s->raw_host) hipHostFree(s->raw_host);
         if (s->out_host) hipHostFree(s->out_host);
+        if (s->line_stream) hipStreamDestroy(s->line_stream);
+        if (s->ev_fork) hipEventDestroy(s->ev_fork);
+        if (s->ev_join) hipEventDestroy(s->ev_join);
         delete s;
         return STVO_ERR_HIP;
     }
@@ -564,6 +582,10 @@ int stvo_seq_create(stvo_ctx* ctx, int B, int max_keypoints, int max_keylines, i
     d.lrank = (int32_t*)(D + o_lrank); d.lperm = (int32_t*)(D + o_lperm); d.ldir = (double*)(D + o_ldir);
     s->cover = (unsigned long long*)(D + o_cover); s->top2 = (unsigned long long*)(D + o_top2);
     s->owner2 = (int32_t*)(D + o_owner);
+    s->cover_l = (unsigned long long*)(D + o_cover_l); s->top2_l = (unsigned long long*)(D + o_top2_l);
+    s->owner2_l = (int32_t*)(D + o_owner_l);
+    s->lazy_l = stvo::LazyScratch{(uint2*)(D + o_knn12_l), (uint2*)(D + o_knn21_l), (int32_t*)(D + o_cand_l), (int32_t*)(D + o_need_l),
+                                  (int32_t*)(D + o_qsel_l), (int32_t*)(D + o_nsel_l), cap_l};
     s->m12s_p = (int32_t*)(D + o_m12sp); s->m12s_l = (int32_t*)(D + o_m12sl);
     s->m12p = (int32_t*)(D + o_m12p); s->m12l = (int32_t*)(D + o_m12l);
     s->inlp = (int32_t*)(D + o_inlp); s->inll = (int32_t*)(D + o_inll);
@@ -586,6 +608,12 @@ int stvo_seq_destroy(stvo_seq* s) {
     hipSetDevice(s->ctx->device);
     hipStreamSynchronize(s->ctx->stream);
     if (s->ctx->aux_stream) hipStreamSynchronize(s->ctx->aux_stream);
+    if (s->line_stream) {
+        hipStreamSynchronize(s->line_stream);
+        hipStreamDestroy(s->line_stream);
+    }
+    if (s->ev_fork) hipEventDestroy(s->ev_fork);
+    if (s->ev_join) hipEventDestroy(s->ev_join);
     if (s->dev) hipFree(s->dev);
     if (s->raw_host) hipHostFree(s->raw_host);
     if (s->out_host) hipHostFree(s->out_host);
@@ -689,6 +717,13 @@ int stvo_seq_step_dev(stvo_seq* s, int slot) {
     const bool lines_prev = s->op.has_lines && s->set_lines[s->cur ^ 1];
     s->set_lines[s->cur] = lines_now;
     s->last_lines = lines_now;
+    // fork: everything enqueued so far (ingest, the previous step) happens-before the line stream's work
+    const bool par = lines_now && s->op.has_points;
+    hipStream_t sl = par ? s->line_stream : st;
+    if (par) {
+        HIP_TRY(ctx, hipEventRecord(s->ev_fork, st));
+        HIP_TRY(ctx, hipStreamWaitEvent(sl, s->ev_fork, 0));
+    }
     if (s->op.has_points) {
         hipLaunchKernelGGL(stvo::point_cells_kernel, dim3(B), dim3(256), 0, st, d);
         stvo::GridBatch g;
@@ -705,7 +740,7 @@ int stvo_seq_step_dev(stvo_seq* s, int slot) {
         HIP_TRY(ctx, hipMemsetAsync(cs.n, 0, (size_t)B * 4, st));
     }
     if (lines_now) {
-        hipLaunchKernelGGL(stvo::line_cells_kernel, dim3(B), dim3(256), 0, st, d);
+        hipLaunchKernelGGL(stvo::line_cells_kernel, dim3(B), dim3(256), 0, sl, d);
         stvo::GridBatch g;
         std::memset(&g, 0, sizeof(g));
         g.B = B; g.stride1 = M; g.stride2 = M; g.xy_width = 4; g.items_stride = M * stvo::LENT; g.words64 = M / 64; g.n1p = M;
@@ -714,9 +749,9 @@ int stvo_seq_step_dev(stvo_seq* s, int slot) {
         g.w = stvo_grid_window{s->mp.matching_s_ws, 0, 0, 0};  // :340-342
         g.ratio = (double)s->mp.min_ratio_12_p /* sic, matching.cpp:241 */; g.line_sim_th = s->mp.line_sim_th;
         g.mutual = s->mp.best_lr_matches;
-        g.cover = s->cover; g.rank = d.lrank; g.perm = d.lperm; g.top2 = s->top2; g.owner2 = s->owner2; g.m12 = s->m12s_l;
-        stvo::launch_grid_batch(st, g, true);
-        hipLaunchKernelGGL(stvo::line_tail_kernel, dim3(B), dim3(256), 0, st, d);
+        g.cover = s->cover_l; g.rank = d.lrank; g.perm = d.lperm; g.top2 = s->top2_l; g.owner2 = s->owner2_l; g.m12 = s->m12s_l;
+        stvo::launch_grid_batch(sl, g, true);
+        hipLaunchKernelGGL(stvo::line_tail_kernel, dim3(B), dim3(256), 0, sl, d);
     } else {
         HIP_TRY(ctx, hipMemsetAsync(cs.nl, 0, (size_t)B * 4, st));
     }
@@ -724,22 +759,25 @@ int stvo_seq_step_dev(stvo_seq* s, int slot) {
     if (track) {
         // ---- f2fTracking: prev stereo sets vs curr stereo sets
         const stvo::LazyScratch w{ctx->knn12, ctx->knn21, ctx->cand, ctx->need, ctx->qsel, ctx->nsel, ctx->knn_capacity};
-        auto match_set = [&](int stride, const uint8_t* da, const int32_t* na, const uint8_t* db, const int32_t* nb, float nnr,
-                             int32_t* m12) {
+        auto match_set = [&](hipStream_t q, const stvo::LazyScratch& ws, int stride, const uint8_t* da, const int32_t* na,
+                             const uint8_t* db, const int32_t* nb, float nnr, int32_t* m12) {
             if (s->mp.best_lr_matches) {
-                stvo::launch_match_mutual_lazy(st, B, stride, da, na, db, nb, nnr, w, m12, 0, nullptr);
+                stvo::launch_match_mutual_lazy(q, B, stride, da, na, db, nb, nnr, ws, m12, 0, nullptr);
             } else {
-                const int nseg = stvo::knn_pick_nseg(B, stride, ctx->knn_capacity);
-                stvo::launch_hamming_knn2(st, B, stride, stride, da, na, db, nb, ctx->knn12, ctx->knn21, 0, 0, 0, nullptr,
-                                          nullptr, nseg);
-                stvo::launch_nnr_mutual(st, B, stride, ctx->knn12, ctx->knn21, na, nb, nnr, 0, m12, nseg);
+                const int nseg = stvo::knn_pick_nseg(B, stride, ws.knn_capacity);
+                stvo::launch_hamming_knn2(q, B, stride, stride, da, na, db, nb, ws.knn12, ws.knn21, 0, 0, 0, nullptr, nullptr, nseg);
+                stvo::launch_nnr_mutual(q, B, stride, ws.knn12, ws.knn21, na, nb, nnr, 0, m12, nseg);
             }
         };
-        if (s->op.has_points) match_set(K, ps.desc, ps.n, cs.desc, cs.n, s->mp.min_ratio_12_p, s->m12p);
+        if (s->op.has_points) match_set(st, w, K, ps.desc, ps.n, cs.desc, cs.n, s->mp.min_ratio_12_p, s->m12p);
         if (lines_prev && lines_now)
-            match_set(M, ps.ldesc, ps.nl, cs.ldesc, cs.nl, s->mp.min_ratio_12_l, s->m12l);
+            match_set(sl, s->lazy_l, M, ps.ldesc, ps.nl, cs.ldesc, cs.nl, s->mp.min_ratio_12_l, s->m12l);
         else if (lines_prev)  // nothing to match against: every prev line is unmatched
             HIP_TRY(ctx, hipMemsetAsync(s->m12l, 0xFF, (size_t)B * M * sizeof(int32_t), st));
+        if (par) {  // join before optimizePose
+            HIP_TRY(ctx, hipEventRecord(s->ev_join, sl));
+            HIP_TRY(ctx, hipStreamWaitEvent(st, s->ev_join, 0));
+        }
         // ---- optimizePose
         stvo::PoseArgs a;
         std::memset(&a, 0, sizeof(a));
@@ -753,6 +791,9 @@ int stvo_seq_step_dev(stvo_seq* s, int slot) {
         a.results = s->zero_copy ? reinterpret_cast<stvo_pose_result*>(s->out_host) : s->results;
         a.inl_p_out = s->inlp; a.inl_l_out = s->inll;
         TRY(stvo::launch_pose(st, a));
+    } else if (par) {  // first frame: nothing to track, but the main stream must still see the line stage's results
+        HIP_TRY(ctx, hipEventRecord(s->ev_join, sl));
+        HIP_TRY(ctx, hipStreamWaitEvent(st, s->ev_join, 0));
     }
     TRY(check_launch(ctx));
     s->cur ^= 1;  // updateFrame: curr becomes prev
