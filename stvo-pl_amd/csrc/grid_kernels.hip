@@ -114,8 +114,11 @@ template <bool LINES>
 __global__ __launch_bounds__(256) void grid_cover_kernel(GridBatch g) {
     const GridArgs a = frame_view(g, blockIdx.y);
     const int i1 = blockIdx.x * 256 + threadIdx.x;
+    // every thread first clears its own column of the bit-matrix (all words64 words; coalesced across the lanes of a
+    // wave), padding columns included — no separate memset launch
+    if (i1 < a.n1p)
+        for (int w = 0; w < a.words64; ++w) a.cover[(size_t)w * a.n1p + i1] = 0ull;
     if (i1 >= a.n1) return;
-    // cover is zeroed by the host (hipMemsetAsync)
     if (LINES) {
         const int4 c = reinterpret_cast<const int4*>(a.cell_xy1)[i1];
         cover_window(a, c.x, c.y, i1);
@@ -306,14 +309,13 @@ __global__ __launch_bounds__(256) void grid_finalize_kernel(GridBatch g) {
 // cover (zeroed here) -> scan -> finalize for a batch of frame pairs
 void launch_grid_batch(hipStream_t s, const GridBatch& g, bool lines) {
     if (g.B <= 0 || g.stride1 <= 0 || g.stride2 <= 0) return;
-    (void)hipMemsetAsync(g.cover, 0, (size_t)g.B * g.words64 * g.n1p * sizeof(unsigned long long), s);
-    const dim3 g1((g.stride1 + 255) / 256, g.B), g2((g.stride2 + 255) / 256, g.B), blk(256);
+    const dim3 g1((g.stride1 + 255) / 256, g.B), g2((g.stride2 + 255) / 256, g.B), gc((g.n1p + 255) / 256, g.B), blk(256);
     if (lines) {
-        hipLaunchKernelGGL((grid_cover_kernel<true>), g1, blk, 0, s, g);
+        hipLaunchKernelGGL((grid_cover_kernel<true>), gc, blk, 0, s, g);
         hipLaunchKernelGGL((grid_scan_kernel<true, 1>), g2, blk, 0, s, g);
         hipLaunchKernelGGL((grid_scan_kernel<true, 2>), g2, blk, 0, s, g);
     } else {
-        hipLaunchKernelGGL((grid_cover_kernel<false>), g1, blk, 0, s, g);
+        hipLaunchKernelGGL((grid_cover_kernel<false>), gc, blk, 0, s, g);
         hipLaunchKernelGGL((grid_scan_kernel<false, 1>), g2, blk, 0, s, g);
         hipLaunchKernelGGL((grid_scan_kernel<false, 2>), g2, blk, 0, s, g);
     }

@@ -88,7 +88,8 @@ __global__ __launch_bounds__(KNN_BLOCK) void hamming_knn2_kernel(int B, int tile
                                                                  const int32_t* __restrict__ n2,
                                                                  uint2* __restrict__ knn12, uint2* __restrict__ knn21,
                                                                  const int32_t* __restrict__ qsel,
-                                                                 const int32_t* __restrict__ nsel) {
+                                                                 const int32_t* __restrict__ nsel,
+                                                                 uint32_t* __restrict__ claim_init) {
     // XCD-aware block -> (frame pair, direction, tile) mapping.  Workgroups are dispatched round-robin
     // over the 8 XCDs (workgroup L runs on XCD L % 8, each XCD has a private 4 MiB L2).  With the
     // natural (tile, dir, frame) order the 2*tiles workgroups of one frame pair land on all 8 XCDs
@@ -111,8 +112,12 @@ __global__ __launch_bounds__(KNN_BLOCK) void hamming_knn2_kernel(int B, int tile
     const int j0 = min(seg * seg_len, nt_all);
     const int nt = min(j0 + seg_len, nt_all);
     const int q_base = tile * KNN_BLOCK;
-    if (q_base + (int)(threadIdx.x & ~63u) >= nq) return;  // wave-uniform: no barriers in this kernel
     const size_t frame_off = (size_t)b * row_stride;
+    // lazy mutual matching: the per-column claims consumed by nnr_forward_kernel are reset here (segment 0 covers
+    // every column index once) instead of by a separate memset launch
+    if (claim_init && seg == 0 && dir == dir0 && q_base + (int)threadIdx.x < row_stride)
+        claim_init[frame_off + q_base + threadIdx.x] = 0xFFFFFFFFu;
+    if (q_base + (int)(threadIdx.x & ~63u) >= nq) return;  // wave-uniform: no barriers in this kernel
     const uint8_t* Q = (dir == 0 ? d1 : d2) + frame_off * STVO_DESC_BYTES;
     const uint32_t* __restrict__ T = reinterpret_cast<const uint32_t*>((dir == 0 ? d2 : d1) + frame_off * STVO_DESC_BYTES);
     uint2* __restrict__ out = (dir == 0 ? knn12 : knn21) + (size_t)seg * B * row_stride + frame_off;
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(KNN_BLOCK) void hamming_knn2_kernel(int B, int tile
 
 void launch_hamming_knn2(hipStream_t s, int B, int row_stride, int max_n, const uint8_t* d1, const int32_t* n1,
                          const uint8_t* d2, const int32_t* n2, uint2* knn12, uint2* knn21, int both_directions,
-                         int lds_pad_bytes, int dir0, const int32_t* qsel, const int32_t* nsel, int nseg) {
+                         int lds_pad_bytes, int dir0, const int32_t* qsel, const int32_t* nsel, int nseg, uint32_t* claim_init) {
     if (B <= 0 || max_n <= 0) return;
     const int tiles = (max_n + KNN_BLOCK - 1) / KNN_BLOCK, ndir = both_directions ? 2 : 1;
     const int groups = (B + 7) / 8;  // frame pairs are dealt to the 8 XCDs in groups of 8
@@ -164,7 +169,7 @@ void launch_hamming_knn2(hipStream_t s, int B, int row_stride, int max_n, const 
     // lds_pad_bytes > 0 only caps the number of resident workgroups per CU (the kernel uses no LDS), leaving
     // wave slots and VGPRs for a concurrently running pose kernel (stvo_ctx_set_overlap)
     hipLaunchKernelGGL(hamming_knn2_kernel, grid, dim3(KNN_BLOCK), (size_t)lds_pad_bytes, s, B, tiles, ndir, dir0,
-                       nseg, row_stride, d1, n1, d2, n2, knn12, knn21, qsel, nsel);
+                       nseg, row_stride, d1, n1, d2, n2, knn12, knn21, qsel, nsel, claim_init);
 }
 
 // K2: m12[i] = j  iff  float(d0) < float(d1) * nnr  (12 direction)  and, when `mutual`, the 21
@@ -223,35 +228,34 @@ void launch_nnr_mutual(hipStream_t s, int B, int row_stride, const uint2* knn12,
 // the wave-uniform short cut: 4 x (v_xor + v_bcnt) + one compare instead of 8 x (v_xor + v_bcnt) + the top-2
 // update.  Exactness does not depend on the data: whenever any lane's lower bound is within its T (its own
 // claimant excepted) the wave finishes the row at full length.
-__global__ __launch_bounds__(256) void nnr_forward_kernel(int nseg, int row_stride, const uint2* __restrict__ knn12,
-                                                          const int32_t* __restrict__ n1, const int32_t* __restrict__ n2,
-                                                          float nnr, int32_t* __restrict__ cand,
-                                                          uint32_t* __restrict__ claim /* preset to 0xFFFFFFFF */) {
-    const int b = blockIdx.y;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= row_stride) return;
-    const int na = n1[b], nb = n2[b];
-    const size_t off = (size_t)b * row_stride;
-    int m = -1;
-    if (i < na && nb >= 2) {
-        const uint2 k = merged_knn(knn12, (size_t)gridDim.y * row_stride, off + i, nseg);
-        const float f0 = (float)(k.x >> 16), f1 = (float)(k.y >> 16);
-        if (f0 < f1 * nnr) {
-            m = (int)(k.x & 0xFFFFu);
-            atomicMin(&claim[off + m], (k.x & 0xFFFF0000u) | (uint32_t)i);  // (d0 << 16) | claimant
-        }
-    }
-    cand[off + i] = m;
-}
-
-// one workgroup per frame pair: ascending list of the claimed columns + their count; clears their verdicts
-__global__ __launch_bounds__(256) void compact_need_kernel(int row_stride, const uint32_t* __restrict__ claim,
-                                                           const int32_t* __restrict__ n2, int32_t* __restrict__ qsel,
-                                                           int32_t* __restrict__ nsel, int32_t* __restrict__ blocked) {
+// One workgroup per frame pair: forward ratio test + column claims for every row, then (all claims of the frame are
+// made by this workgroup, so a block barrier orders them) the ascending list of the claimed columns + their count;
+// clears their verdicts.
+__global__ __launch_bounds__(256) void nnr_forward_compact_kernel(int B, int nseg, int row_stride,
+                                                                  const uint2* __restrict__ knn12,
+                                                                  const int32_t* __restrict__ n1, const int32_t* __restrict__ n2,
+                                                                  float nnr, int32_t* __restrict__ cand,
+                                                                  uint32_t* __restrict__ claim /* preset to 0xFFFFFFFF */,
+                                                                  int32_t* __restrict__ qsel, int32_t* __restrict__ nsel,
+                                                                  int32_t* __restrict__ blocked) {
     __shared__ int s_wave[4];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const size_t off = (size_t)b * row_stride;
-    const int nb = n2[b];
+    const int na = n1[b], nb = n2[b];
+    for (int i = tid; i < row_stride; i += 256) {
+        int m = -1;
+        if (i < na && nb >= 2) {
+            const uint2 k = merged_knn(knn12, (size_t)B * row_stride, off + i, nseg);
+            const float f0 = (float)(k.x >> 16), f1 = (float)(k.y >> 16);
+            if (f0 < f1 * nnr) {
+                m = (int)(k.x & 0xFFFFu);
+                atomicMin(&claim[off + m], (k.x & 0xFFFF0000u) | (uint32_t)i);  // (d0 << 16) | claimant
+            }
+        }
+        cand[off + i] = m;
+    }
+    __threadfence();
+    __syncthreads();
     const int per = (row_stride + 255) / 256;
     const int lo = tid * per, hi = min(lo + per, nb);
     int cnt = 0;
@@ -421,13 +425,12 @@ void launch_match_mutual_lazy(hipStream_t s, int B, int row_stride, const uint8_
     const int nseg = knn_pick_nseg(B, row_stride, w.knn_capacity);
     uint32_t* claim = reinterpret_cast<uint32_t*>(w.need);
     int32_t* blocked = reinterpret_cast<int32_t*>(w.knn21);  // the reverse top-2 array is not needed any more
-    (void)hipMemsetAsync(claim, 0xFF, (size_t)B * row_stride * sizeof(uint32_t), s);
     if (tev) (void)hipEventRecord(tev[0], s);
     launch_hamming_knn2(s, B, row_stride, row_stride, d1, n1, d2, n2, w.knn12, w.knn21, 0, lds_pad_bytes, 0, nullptr,
-                        nullptr, nseg);
+                        nullptr, nseg, claim);
     if (tev) (void)hipEventRecord(tev[1], s);
-    hipLaunchKernelGGL(nnr_forward_kernel, grid2, dim3(256), 0, s, nseg, row_stride, w.knn12, n1, n2, nnr, w.cand, claim);
-    hipLaunchKernelGGL(compact_need_kernel, dim3(B), dim3(256), 0, s, row_stride, claim, n2, w.qsel, w.nsel, blocked);
+    hipLaunchKernelGGL(nnr_forward_compact_kernel, dim3(B), dim3(256), 0, s, B, nseg, row_stride, w.knn12, n1, n2, nnr, w.cand,
+                       claim, w.qsel, w.nsel, blocked);
     if (tev) (void)hipEventRecord(tev[2], s);
     launch_hamming_verify(s, B, row_stride, d1, n1, d2, nnr, w, lds_pad_bytes, nseg);
     if (tev) (void)hipEventRecord(tev[3], s);

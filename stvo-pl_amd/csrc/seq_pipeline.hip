@@ -453,6 +453,7 @@ struct stvo_seq {
     unsigned long long *cover_l = nullptr, *top2_l = nullptr;
     int32_t* owner2_l = nullptr;
     stvo::LazyScratch lazy_l{};
+    hipEvent_t pev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // STVO_SEQ_PROF stage markers (developer aid)
     bool zero_copy = false;    // small batches: kernels write results / counts straight into out_host
     bool raw_lines[2] = {false, false};  // slot holds at least one left and one right key-line
     bool set_lines[2] = {false, false};  // stereo set was built from a frame with key-lines
@@ -614,6 +615,8 @@ int stvo_seq_destroy(stvo_seq* s) {
     }
     if (s->ev_fork) hipEventDestroy(s->ev_fork);
     if (s->ev_join) hipEventDestroy(s->ev_join);
+    for (auto e : s->pev)
+        if (e) hipEventDestroy(e);
     if (s->dev) hipFree(s->dev);
     if (s->raw_host) hipHostFree(s->raw_host);
     if (s->out_host) hipHostFree(s->out_host);
@@ -724,6 +727,7 @@ int stvo_seq_step_dev(stvo_seq* s, int slot) {
         HIP_TRY(ctx, hipEventRecord(s->ev_fork, st));
         HIP_TRY(ctx, hipStreamWaitEvent(sl, s->ev_fork, 0));
     }
+    if (s->pev[0]) (void)hipEventRecord(s->pev[1], st);  // pev[0] was recorded before the ingest
     if (s->op.has_points) {
         hipLaunchKernelGGL(stvo::point_cells_kernel, dim3(B), dim3(256), 0, st, d);
         stvo::GridBatch g;
@@ -755,6 +759,7 @@ int stvo_seq_step_dev(stvo_seq* s, int slot) {
     } else {
         HIP_TRY(ctx, hipMemsetAsync(cs.nl, 0, (size_t)B * 4, st));
     }
+    if (s->pev[0]) (void)hipEventRecord(s->pev[2], st);
     const bool track = s->frame_idx > 0;
     if (track) {
         // ---- f2fTracking: prev stereo sets vs curr stereo sets
@@ -778,6 +783,7 @@ int stvo_seq_step_dev(stvo_seq* s, int slot) {
             HIP_TRY(ctx, hipEventRecord(s->ev_join, sl));
             HIP_TRY(ctx, hipStreamWaitEvent(st, s->ev_join, 0));
         }
+        if (s->pev[0]) (void)hipEventRecord(s->pev[3], st);
         // ---- optimizePose
         stvo::PoseArgs a;
         std::memset(&a, 0, sizeof(a));
@@ -791,6 +797,7 @@ int stvo_seq_step_dev(stvo_seq* s, int slot) {
         a.results = s->zero_copy ? reinterpret_cast<stvo_pose_result*>(s->out_host) : s->results;
         a.inl_p_out = s->inlp; a.inl_l_out = s->inll;
         TRY(stvo::launch_pose(st, a));
+        if (s->pev[0]) (void)hipEventRecord(s->pev[4], st);
     } else if (par) {  // first frame: nothing to track, but the main stream must still see the line stage's results
         HIP_TRY(ctx, hipEventRecord(s->ev_join, sl));
         HIP_TRY(ctx, hipStreamWaitEvent(st, s->ev_join, 0));
@@ -848,9 +855,12 @@ int stvo_seq_push(stvo_seq* s, const stvo_frame_features* f, stvo_pose_result* r
         return stvo_seq_read(s, results, counts);
     }
     using clk = std::chrono::steady_clock;
-    static double acc[4] = {0, 0, 0, 0};
-    static int n = 0;
+    static double acc[4] = {0, 0, 0, 0}, gacc[4] = {0, 0, 0, 0};
+    static int n = 0, gn = 0;
+    if (!s->pev[0])
+        for (auto& e : s->pev) hipEventCreate(&e);
     const auto t0 = clk::now();
+    hipEventRecord(s->pev[0], s->ctx->stream);
     TRY(stvo_seq_upload(s, slot, f));
     const auto t1 = clk::now();
     TRY(stvo_seq_step_dev(s, slot));
@@ -860,10 +870,22 @@ int stvo_seq_push(stvo_seq* s, const stvo_frame_features* f, stvo_pose_result* r
     const int rc = stvo_seq_read(s, results, counts);
     const auto t4 = clk::now();
     auto us = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
-    acc[0] += us(t0, t1); acc[1] += us(t1, t2); acc[2] += us(t2, t3); acc[3] += us(t3, t4);
-    if (++n % 25 == 0)
-        std::fprintf(stderr, "[seq prof] mean us over %d frames: pack + H2D enqueue %.1f | kernel launches %.1f | wait for GPU %.1f | read-back %.1f\n",
-                     n, acc[0] / n, acc[1] / n, acc[2] / n, acc[3] / n);
+    if (s->frame_idx > 10) {  // skip the warm-up frames
+        acc[0] += us(t0, t1); acc[1] += us(t1, t2); acc[2] += us(t2, t3); acc[3] += us(t3, t4);
+        ++n;
+        float ms[4] = {0, 0, 0, 0};
+        bool okev = true;
+        for (int k = 0; k < 4; ++k) okev = okev && hipEventElapsedTime(&ms[k], s->pev[k], s->pev[k + 1]) == hipSuccess;
+        if (okev) {
+            for (int k = 0; k < 4; ++k) gacc[k] += ms[k] * 1e3;
+            ++gn;
+        }
+        if (n % 20 == 0)
+            std::fprintf(stderr, "[seq prof] host, mean us over %d frames: pack + ingest enqueue %.1f | kernel launches %.1f | wait for GPU %.1f | "
+                                 "read-back %.1f || GPU (events): ingest %.1f | stereo stage %.1f | f2f stage %.1f | pose %.1f\n",
+                         n, acc[0] / n, acc[1] / n, acc[2] / n, acc[3] / n, gacc[0] / (gn ? gn : 1), gacc[1] / (gn ? gn : 1),
+                         gacc[2] / (gn ? gn : 1), gacc[3] / (gn ? gn : 1));
+    }
     return rc;
 }
 

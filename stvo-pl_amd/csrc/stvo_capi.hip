@@ -49,8 +49,9 @@ int stvo_ctx_create(int device_id, int max_rows, int max_batch, stvo_ctx** out) 
               hip_ok(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking), "hipStreamCreate");
     ctx->own_stream = ok;
     const size_t knn_elems = (size_t)max_rows * (size_t)max_batch;
-    // [nseg][B][rows] with nseg = 2 for full batches, up to 16 for a single problem (knn_pick_nseg)
-    const size_t knn_seg_elems = (size_t)max_rows * (size_t)(2 * max_batch > 16 ? 2 * max_batch : 16);
+    // [nseg][B][rows] with nseg = 2 for full batches, up to KNN_MAX_NSEG for a single problem (knn_pick_nseg)
+    const size_t knn_seg_elems =
+        (size_t)max_rows * (size_t)(2 * max_batch > stvo::KNN_MAX_NSEG ? 2 * max_batch : stvo::KNN_MAX_NSEG);
     ctx->knn_capacity = knn_seg_elems;
     // arena: descriptors + records + per-row scratch of one host-buffer call, with slack
     ctx->arena_size = (size_t)max_rows * 1024 + ((size_t)4 << 20);
