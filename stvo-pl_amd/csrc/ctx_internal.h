@@ -74,7 +74,10 @@ inline int upload(stvo_ctx* ctx, T** dst, const T* src, size_t count, size_t cou
 
 inline int flush_uploads(stvo_ctx* ctx) {
     if (ctx->upload_hi) {
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->arena, ctx->arena_host, ctx->upload_hi, hipMemcpyHostToDevice, ctx->stream));
+        if (ctx->upload_hi <= ((size_t)4 << 20))  // arena offsets are multiples of 256: 16-byte granularity is safe
+            stvo::launch_copy16(ctx->stream, ctx->arena_host, ctx->arena, ctx->upload_hi);
+        else
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->arena, ctx->arena_host, ctx->upload_hi, hipMemcpyHostToDevice, ctx->stream));
         ctx->upload_hi = 0;
     }
     return STVO_OK;
@@ -83,7 +86,11 @@ inline int flush_uploads(stvo_ctx* ctx) {
 // asynchronous D2H of an arena region into the pinned mirror; read it through host_mirror() after the sync
 inline int download_begin(stvo_ctx* ctx, const void* dev, size_t bytes) {
     const size_t off = (size_t)(reinterpret_cast<const char*>(dev) - ctx->arena);
-    if (bytes) HIP_TRY(ctx, hipMemcpyAsync(ctx->arena_host + off, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (bytes == 0) return STVO_OK;
+    if (bytes <= ((size_t)256 << 10) && (off & 15) == 0)
+        stvo::launch_copy16(ctx->stream, dev, ctx->arena_host + off, bytes);  // may write up to 15 bytes of slack (arena blocks are 256-aligned)
+    else
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->arena_host + off, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
     return STVO_OK;
 }
 template <typename T>

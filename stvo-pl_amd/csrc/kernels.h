@@ -48,6 +48,10 @@ void launch_hamming_verify(hipStream_t s, int B, int row_stride, const uint8_t* 
 void launch_nnr_mutual(hipStream_t s, int B, int row_stride, const uint2* knn12, const uint2* knn21, const int32_t* n1,
                        const int32_t* n2, float nnr, int mutual, int32_t* m12, int nseg = KNN_MIN_NSEG);
 void launch_valu_probe(hipStream_t s, int blocks, int iters, uint32_t* sink);
+// 16-byte-granular copy kernel; either side may be pinned host memory.  For the few hundred KB a single-stream call
+// moves it has ~5 us less latency than the DMA engine behind hipMemcpyAsync (6 us vs 11 us on top of an empty launch,
+// and ~0 vs 3 us for a result block written straight into pinned memory).
+void launch_copy16(hipStream_t s, const void* src, void* dst, size_t bytes);
 extern const double kValuProbeOpsPerThreadIter;
 
 // ---- K4-K6: pose optimisation, one workgroup per frame pair ------------------------------------

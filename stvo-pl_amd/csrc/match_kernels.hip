@@ -464,6 +464,18 @@ __global__ __launch_bounds__(256) void valu_probe_kernel(int iters, uint32_t* si
     if ((best ^ second) == 0x12345u) sink[0] = best;  // keep the chain alive
 }
 
+__global__ __launch_bounds__(256) void copy16_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+
+void launch_copy16(hipStream_t s, const void* src, void* dst, size_t bytes) {
+    const size_t n16 = (bytes + 15) / 16;
+    if (n16 == 0) return;
+    const size_t blocks = (n16 + 255) / 256;
+    hipLaunchKernelGGL(copy16_kernel, dim3((unsigned)(blocks < 256 ? blocks : 256)), dim3(256), 0, s,
+                       reinterpret_cast<const uint4*>(src), reinterpret_cast<uint4*>(dst), n16);
+}
+
 void launch_valu_probe(hipStream_t s, int blocks, int iters, uint32_t* sink) {
     hipLaunchKernelGGL(valu_probe_kernel, dim3(blocks), dim3(256), 0, s, iters, sink);
 }

@@ -4,6 +4,8 @@
 // is double, products are truncated to int (:47-48,129-139,318-338).
 #include "stereoFrame.h"
 
+#include <future>
+
 #include <algorithm>
 #include <cmath>
 #include <stdexcept>
@@ -19,9 +21,9 @@ void check(int rc, const char* what) {
 }
 }  // namespace
 
-StereoFrame::StereoFrame(const FrameFeatures& f, const int idx_, PinholeStereoCamera* cam_, stvo_ctx* ctx_)
+StereoFrame::StereoFrame(const FrameFeatures& f, const int idx_, PinholeStereoCamera* cam_, stvo_ctx* ctx_, stvo_ctx* ctx_lines_)
     : frame_idx(idx_), points_l(f.points_l), points_r(f.points_r), lines_l(f.lines_l), lines_r(f.lines_r),
-      pdesc_l(f.pdesc_l), pdesc_r(f.pdesc_r), ldesc_l(f.ldesc_l), ldesc_r(f.ldesc_r), cam(cam_), ctx(ctx_) {
+      pdesc_l(f.pdesc_l), pdesc_r(f.pdesc_r), ldesc_l(f.ldesc_l), ldesc_r(f.ldesc_r), cam(cam_), ctx(ctx_), ctx_l(ctx_lines_ ? ctx_lines_ : ctx_) {
     if (f.img_cols <= 0 || f.img_rows <= 0) throw std::runtime_error("[StereoFrame] invalid image size");
     if ((int)points_l.size() != pdesc_l.rows || (int)points_r.size() != pdesc_r.rows ||
         (int)lines_l.size() != ldesc_l.rows || (int)lines_r.size() != ldesc_r.rows)
@@ -42,7 +44,15 @@ StereoFrame::~StereoFrame() {
 }
 
 void StereoFrame::extractStereoFeatures(double /*llength_th*/, int /*fast_th*/) {
-    // detection is done upstream of this library; the two associations are independent (:64-67)
+    // detection is done upstream of this library; the two associations are independent.  Like the reference
+    // (:64-72: two std::async tasks when plInParallel), points and lines run concurrently when a second context
+    // exists: each task owns its context (stream + staging arena), so the GPU overlaps the two kernel chains.
+    if (Config::plInParallel() && Config::hasPoints() && Config::hasLines() && ctx_l != ctx && !lines_l.empty() && !lines_r.empty()) {
+        auto lines = std::async(std::launch::async, [&] { matchStereoLines(lines_l, lines_r, ldesc_l, ldesc_r, (frame_idx == 0)); });
+        matchStereoPoints(points_l, points_r, pdesc_l, pdesc_r, (frame_idx == 0));
+        lines.get();  // rethrows
+        return;
+    }
     if (Config::hasPoints()) matchStereoPoints(points_l, points_r, pdesc_l, pdesc_r, (frame_idx == 0));
     if (Config::hasLines()) matchStereoLines(lines_l, lines_r, ldesc_l, ldesc_r, (frame_idx == 0));
 }
@@ -173,7 +183,7 @@ void StereoFrame::matchStereoLines(std::vector<KeyLine> lines_l_, std::vector<Ke
 
     stvo_grid_window w{Config::matchingSWs(), 0, 0, 0};
     std::vector<int32_t> matches_12(lines_l_.size());
-    check(stvo_match_grid_lines(ctx, coords.data(), ldesc_l_.ptr(), (int)lines_l_.size(), start.data(), items.data(),
+    check(stvo_match_grid_lines(ctx_l, coords.data(), ldesc_l_.ptr(), (int)lines_l_.size(), start.data(), items.data(),
                                 ldesc_r_.ptr(), (int)lines_r_.size(), directions.data(), &w, Config::minRatio12P(),
                                 Config::lineSimTh(), Config::bestLRMatches() ? 1 : 0, matches_12.data(), nullptr),
           "stvo_match_grid_lines");

@@ -17,7 +17,9 @@ namespace StVO {
 
 class StereoFrame {
 public:
-    StereoFrame(const FrameFeatures& feat_, const int idx_, PinholeStereoCamera* cam_, stvo_ctx* ctx_);
+    // ctx_lines_: optional second context (own stream / staging arena) so that the line association can run on its own
+    // thread like the reference's plInParallel branch (src/stereoFrame.cpp:64-72); nullptr = everything on ctx_
+    StereoFrame(const FrameFeatures& feat_, const int idx_, PinholeStereoCamera* cam_, stvo_ctx* ctx_, stvo_ctx* ctx_lines_ = nullptr);
     ~StereoFrame();
 
     void extractStereoFeatures(double llength_th, int fast_th = 20);
@@ -50,6 +52,7 @@ public:
 
 private:
     stvo_ctx* ctx;
+    stvo_ctx* ctx_l;  // context used by matchStereoLines (== ctx when no second context was given)
 };
 
 }  // namespace StVO

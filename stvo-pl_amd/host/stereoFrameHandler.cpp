@@ -3,6 +3,8 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
+#include <future>
 #include <iostream>
 #include <stdexcept>
 #include <string>
@@ -22,10 +24,11 @@ void check(int rc, const char* what, stvo_ctx* ctx) {
 
 StereoFrameHandler::StereoFrameHandler(PinholeStereoCamera* cam_, int device_id)
     : orb_fast_th(20), llength_th(0.0), prev_frame(nullptr), curr_frame(nullptr), cam(cam_), n_inliers(0),
-      n_inliers_pt(0), n_inliers_ls(0), ctx(nullptr) {
+      n_inliers_pt(0), n_inliers_ls(0), ctx(nullptr), ctx_lines(nullptr) {
     last_result = stvo_pose_result{};
     // no CPU path exists: without a gfx950 device this throws
     check(stvo_ctx_create(device_id, 8192, 1, &ctx), "stvo_ctx_create", nullptr);
+    if (!std::getenv("STVO_NO_LINE_CTX")) check(stvo_ctx_create(device_id, 2048, 1, &ctx_lines), "stvo_ctx_create(lines)", nullptr);
 }
 
 StereoFrameHandler::~StereoFrameHandler() {
@@ -33,6 +36,7 @@ StereoFrameHandler::~StereoFrameHandler() {
     for (auto ls : matched_ls) delete ls;
     if (curr_frame && curr_frame != prev_frame) delete curr_frame;
     delete prev_frame;
+    if (ctx_lines) stvo_ctx_destroy(ctx_lines);
     stvo_ctx_destroy(ctx);
 }
 
@@ -40,7 +44,7 @@ StereoFrameHandler::~StereoFrameHandler() {
 void StereoFrameHandler::initialize(const FrameFeatures& feat, const int idx_) {
     orb_fast_th = Config::orbFastTh();
     llength_th = Config::minLineLength() * std::min(cam->getWidth(), cam->getHeight());
-    prev_frame = new StereoFrame(feat, idx_, cam, ctx);
+    prev_frame = new StereoFrame(feat, idx_, cam, ctx, ctx_lines);
     prev_frame->extractStereoFeatures(llength_th, orb_fast_th);
     prev_frame->Tfw = Matrix4d::Identity();
     prev_frame->Tfw_cov = Matrix6d::Identity();
@@ -53,7 +57,7 @@ void StereoFrameHandler::initialize(const FrameFeatures& feat, const int idx_) {
 void StereoFrameHandler::insertStereoPair(const FrameFeatures& feat, const int idx_) {
     using clk = std::chrono::high_resolution_clock;
     const auto t0 = clk::now();
-    curr_frame = new StereoFrame(feat, idx_, cam, ctx);
+    curr_frame = new StereoFrame(feat, idx_, cam, ctx, ctx_lines);
     curr_frame->extractStereoFeatures(llength_th, orb_fast_th);
     const auto t1 = clk::now();
     f2fTracking();
@@ -87,14 +91,21 @@ void StereoFrameHandler::updateFrame() {
     curr_frame = nullptr;
 }
 
-// :106-129 — the reference forks points || lines on two threads; both go to the same GPU queue here
+// :106-129 — like the reference, points || lines on two threads when plInParallel (each with its own GPU stream)
 void StereoFrameHandler::f2fTracking() {
     for (auto pt : matched_pt) delete pt;
     for (auto ls : matched_ls) delete ls;
     matched_pt.clear();
     matched_ls.clear();
-    if (Config::hasPoints()) matchF2FPoints();
-    if (Config::hasLines()) matchF2FLines();
+    if (ctx_lines && Config::plInParallel() && Config::hasPoints() && Config::hasLines() && !curr_frame->stereo_ls.empty() &&
+        !prev_frame->stereo_ls.empty()) {  // :115-118 — two tasks, each on its own context
+        auto lines = std::async(std::launch::async, [&] { matchF2FLines(); });
+        matchF2FPoints();
+        lines.get();
+    } else {
+        if (Config::hasPoints()) matchF2FPoints();
+        if (Config::hasLines()) matchF2FLines();
+    }
     n_inliers_pt = (int)matched_pt.size();
     n_inliers_ls = (int)matched_ls.size();
     n_inliers = n_inliers_pt + n_inliers_ls;
@@ -124,10 +135,11 @@ void StereoFrameHandler::matchF2FLines() {
     matched_ls.clear();
     if (!Config::hasLines() || curr_frame->stereo_ls.empty() || prev_frame->stereo_ls.empty()) return;
     std::vector<int32_t> matches_12(prev_frame->ldesc_l.rows);
-    check(stvo_match_nnr_mutual(ctx, prev_frame->ldesc_l.ptr(), prev_frame->ldesc_l.rows, curr_frame->ldesc_l.ptr(),
+    stvo_ctx* cl = ctx_lines ? ctx_lines : ctx;
+    check(stvo_match_nnr_mutual(cl, prev_frame->ldesc_l.ptr(), prev_frame->ldesc_l.rows, curr_frame->ldesc_l.ptr(),
                                 curr_frame->ldesc_l.rows, (float)Config::minRatio12L(), Config::bestLRMatches() ? 1 : 0,
                                 matches_12.data(), nullptr),
-          "stvo_match_nnr_mutual(lines)", ctx);
+          "stvo_match_nnr_mutual(lines)", cl);
     for (size_t i1 = 0; i1 < matches_12.size(); ++i1) {
         const int i2 = matches_12[i1];
         if (i2 < 0) continue;

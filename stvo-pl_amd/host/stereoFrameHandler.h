@@ -56,6 +56,7 @@ public:
 
 private:
     stvo_ctx* ctx;
+    stvo_ctx* ctx_lines;  // second context for the line tasks of the plInParallel branches (:115-118, stereoFrame.cpp:64-72)
 };
 
 }  // namespace StVO
