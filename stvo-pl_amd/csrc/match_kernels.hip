@@ -228,34 +228,37 @@ void launch_nnr_mutual(hipStream_t s, int B, int row_stride, const uint2* knn12,
 // the wave-uniform short cut: 4 x (v_xor + v_bcnt) + one compare instead of 8 x (v_xor + v_bcnt) + the top-2
 // update.  Exactness does not depend on the data: whenever any lane's lower bound is within its T (its own
 // claimant excepted) the wave finishes the row at full length.
-// One workgroup per frame pair: forward ratio test + column claims for every row, then (all claims of the frame are
-// made by this workgroup, so a block barrier orders them) the ascending list of the claimed columns + their count;
-// clears their verdicts.
-__global__ __launch_bounds__(256) void nnr_forward_compact_kernel(int B, int nseg, int row_stride,
-                                                                  const uint2* __restrict__ knn12,
-                                                                  const int32_t* __restrict__ n1, const int32_t* __restrict__ n2,
-                                                                  float nnr, int32_t* __restrict__ cand,
-                                                                  uint32_t* __restrict__ claim /* preset to 0xFFFFFFFF */,
-                                                                  int32_t* __restrict__ qsel, int32_t* __restrict__ nsel,
-                                                                  int32_t* __restrict__ blocked) {
+__global__ __launch_bounds__(256) void nnr_forward_kernel(int nseg, int row_stride, const uint2* __restrict__ knn12,
+                                                          const int32_t* __restrict__ n1, const int32_t* __restrict__ n2,
+                                                          float nnr, int32_t* __restrict__ cand,
+                                                          uint32_t* __restrict__ claim /* preset to 0xFFFFFFFF by K1 */) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= row_stride) return;
+    const int na = n1[b], nb = n2[b];
+    const size_t off = (size_t)b * row_stride;
+    int m = -1;
+    if (i < na && nb >= 2) {
+        const uint2 k = merged_knn(knn12, (size_t)gridDim.y * row_stride, off + i, nseg);
+        const float f0 = (float)(k.x >> 16), f1 = (float)(k.y >> 16);
+        if (f0 < f1 * nnr) {
+            m = (int)(k.x & 0xFFFFu);
+            atomicMin(&claim[off + m], (k.x & 0xFFFF0000u) | (uint32_t)i);  // (d0 << 16) | claimant
+        }
+    }
+    cand[off + i] = m;
+}
+
+// one workgroup per frame pair: ascending list of the claimed columns + their count; clears their verdicts.
+// (Fusing this with the forward test into one workgroup per frame pair was tried and is slower: a single workgroup
+// then merges 2000 x nseg partial keys serially — 18 us instead of 6 + 5 for one frame, 68 us instead of 36 for 512.)
+__global__ __launch_bounds__(256) void compact_need_kernel(int row_stride, const uint32_t* __restrict__ claim,
+                                                           const int32_t* __restrict__ n2, int32_t* __restrict__ qsel,
+                                                           int32_t* __restrict__ nsel, int32_t* __restrict__ blocked) {
     __shared__ int s_wave[4];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const size_t off = (size_t)b * row_stride;
-    const int na = n1[b], nb = n2[b];
-    for (int i = tid; i < row_stride; i += 256) {
-        int m = -1;
-        if (i < na && nb >= 2) {
-            const uint2 k = merged_knn(knn12, (size_t)B * row_stride, off + i, nseg);
-            const float f0 = (float)(k.x >> 16), f1 = (float)(k.y >> 16);
-            if (f0 < f1 * nnr) {
-                m = (int)(k.x & 0xFFFFu);
-                atomicMin(&claim[off + m], (k.x & 0xFFFF0000u) | (uint32_t)i);  // (d0 << 16) | claimant
-            }
-        }
-        cand[off + i] = m;
-    }
-    __threadfence();
-    __syncthreads();
+    const int nb = n2[b];
     const int per = (row_stride + 255) / 256;
     const int lo = tid * per, hi = min(lo + per, nb);
     int cnt = 0;
@@ -429,8 +432,8 @@ void launch_match_mutual_lazy(hipStream_t s, int B, int row_stride, const uint8_
     launch_hamming_knn2(s, B, row_stride, row_stride, d1, n1, d2, n2, w.knn12, w.knn21, 0, lds_pad_bytes, 0, nullptr,
                         nullptr, nseg, claim);
     if (tev) (void)hipEventRecord(tev[1], s);
-    hipLaunchKernelGGL(nnr_forward_compact_kernel, dim3(B), dim3(256), 0, s, B, nseg, row_stride, w.knn12, n1, n2, nnr, w.cand,
-                       claim, w.qsel, w.nsel, blocked);
+    hipLaunchKernelGGL(nnr_forward_kernel, grid2, dim3(256), 0, s, nseg, row_stride, w.knn12, n1, n2, nnr, w.cand, claim);
+    hipLaunchKernelGGL(compact_need_kernel, dim3(B), dim3(256), 0, s, row_stride, claim, n2, w.qsel, w.nsel, blocked);
     if (tev) (void)hipEventRecord(tev[2], s);
     launch_hamming_verify(s, B, row_stride, d1, n1, d2, nnr, w, lds_pad_bytes, nseg);
     if (tev) (void)hipEventRecord(tev[3], s);

@@ -82,6 +82,7 @@ struct SeqDev {
     // optional mirrors of n / nl in pinned HOST memory (zero-copy read-back for small batches), or nullptr
     int32_t* host_n;
     int32_t* host_nl;
+    int zero_nl;  // line stage skipped for this frame: the point tail clears nl[b] (saves a memset launch)
 };
 
 __device__ __forceinline__ bool in_grid(int x, int y) {
@@ -220,6 +221,7 @@ __global__ __launch_bounds__(256) void point_tail_kernel(SeqDev s) {
     if (tid == 0) {
         s.n[b] = s_run;
         if (s.host_n) s.host_n[b] = s_run;
+        if (s.zero_nl) s.nl[b] = 0;
     }
 }
 
@@ -720,6 +722,7 @@ int stvo_seq_step_dev(stvo_seq* s, int slot) {
         HIP_TRY(ctx, hipEventRecord(s->ev_fork, st));
         HIP_TRY(ctx, hipStreamWaitEvent(sl, s->ev_fork, 0));
     }
+    d.zero_nl = (!lines_now && s->op.has_points) ? 1 : 0;
     if (s->pev[0]) (void)hipEventRecord(s->pev[1], st);  // pev[0] was recorded before the ingest
     if (s->op.has_points) {
         hipLaunchKernelGGL(stvo::point_cells_kernel, dim3(B), dim3(256), 0, st, d);
@@ -749,7 +752,7 @@ int stvo_seq_step_dev(stvo_seq* s, int slot) {
         g.cover = s->cover_l; g.rank = d.lrank; g.perm = d.lperm; g.top2 = s->top2_l; g.owner2 = s->owner2_l; g.m12 = s->m12s_l;
         stvo::launch_grid_batch(sl, g, true);
         hipLaunchKernelGGL(stvo::line_tail_kernel, dim3(B), dim3(256), 0, sl, d);
-    } else {
+    } else if (!d.zero_nl) {
         HIP_TRY(ctx, hipMemsetAsync(cs.nl, 0, (size_t)B * 4, st));
     }
     if (s->pev[0]) (void)hipEventRecord(s->pev[2], st);
