@@ -71,3 +71,14 @@ def test_seq_pipeline_empty_and_tiny_frames(oracle):
     seq[2] = dict(seq[2], kp_r=z2, desc_r=zd, kl_r=z4, ldesc_r=zd)   # right camera dropped out
     tiny = synth.make_stereo_sequence(801, n_frames=4, n_pts=6, n_lines=0, cam=cam, distract=0.0)
     run_and_compare(oracle, [seq, tiny], cam, "kitti")
+
+
+def test_seq_pipeline_line_stage_skipped_and_resumed(oracle):
+    """A frame without key-lines skips the line stage (and the f2f line matching on both sides of it); the stage
+    must pick up again on the next frame with lines.  Single sequence, so the zero-copy read-back path is used."""
+    cam = synth.KITTI_CAM
+    seq = synth.make_stereo_sequence(900, n_frames=6, n_pts=500, n_lines=50, cam=cam)
+    zd = np.zeros((0, 32), np.uint8); z4 = np.zeros((0, 4), np.float32); zi = np.zeros(0, np.int32)
+    for k in (1, 4):  # the line detector found nothing in these frames
+        seq[k] = dict(seq[k], kl_l=z4, kl_r=z4, ldesc_l=zd, ldesc_r=zd, oct_ll=zi, ang_l=np.zeros(0, np.float32))
+    run_and_compare(oracle, [seq], cam, "kitti")
