@@ -165,6 +165,21 @@ int stvo_seq_upload(stvo_seq* seq, int slot, const stvo_frame_features* frame);
 int stvo_seq_step_dev(stvo_seq* seq, int slot);
 int stvo_seq_read(stvo_seq* seq, stvo_pose_result* results, int32_t* counts);
 
+/* By-products for callers that keep the reference's HOST-side feature lists (the StereoFrameHandler mirror):
+ * with fetch enabled every step also copies to pinned memory (a) right after the f2f stage — while the pose
+ * kernel still runs — the raw stereo matches of the new frame (left key-point / key-line i -> right index or -1,
+ * what matchGrid returns at stereoFrame.cpp:145,344, [B][K] / [B][M] with K, M = the capacities rounded up to 64)
+ * and the f2f matches (prev stereo feature k -> curr stereo feature or -1, what StVO::match returns at
+ * stereoFrameHandler.cpp:141,164), and (b) after the pose kernel the inlier flags of the prev stereo features
+ * (-1 unmatched, 0 outlier, 1 inlier; removeOutliers :988-1067).  fetch_matches waits for (a) only; the pointers
+ * stay valid until the next step.  fetch_inliers synchronises the stream. */
+int stvo_seq_enable_fetch(stvo_seq* seq, int enable);
+int stvo_seq_fetch_matches(stvo_seq* seq, const int32_t** m12_stereo_pts, const int32_t** m12_stereo_lines,
+                           const int32_t** m12_pts, const int32_t** m12_lines);
+int stvo_seq_fetch_inliers(stvo_seq* seq, const int32_t** inl_pts, const int32_t** inl_lines);
+/* Row strides of the arrays above. */
+int stvo_seq_strides(const stvo_seq* seq, int32_t* stride_pts, int32_t* stride_lines);
+
 /* ---- measurement helpers --------------------------------------------------------------------- */
 /* Times `iters` launches of the named kernel stage on the context's stream with hipEvents and
  * returns the average milliseconds per launch (used by bench.py for the roofline line).

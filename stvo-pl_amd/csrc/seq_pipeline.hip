@@ -449,6 +449,13 @@ struct stvo_seq {
     unsigned long long *cover_l = nullptr, *top2_l = nullptr;
     int32_t* owner2_l = nullptr;
     stvo::LazyScratch lazy_l{};
+    // optional by-products for callers that mirror the reference's host-side feature lists (StereoFrameHandler):
+    // the four match-index arrays are copied to pinned memory right after the f2f stage (ev_fetch), i.e. while the
+    // pose kernel still runs; the inlier masks follow the pose kernel
+    bool fetch = false;
+    char* fetch_host = nullptr;
+    hipEvent_t ev_fetch = nullptr;
+    size_t m12_span = 0, inl_span = 0;  // bytes of the contiguous [m12s_p | m12s_l | m12p | m12l] and [inlp | inll] blocks
     hipEvent_t pev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // STVO_SEQ_PROF stage markers (developer aid)
     bool zero_copy = false;    // small batches: kernels write results / counts straight into out_host
     bool raw_lines[2] = {false, false};  // slot holds at least one left and one right key-line
@@ -587,6 +594,8 @@ int stvo_seq_create(stvo_ctx* ctx, int B, int max_keypoints, int max_keylines, i
     s->m12p = (int32_t*)(D + o_m12p); s->m12l = (int32_t*)(D + o_m12l);
     s->inlp = (int32_t*)(D + o_inlp); s->inll = (int32_t*)(D + o_inll);
     s->results = (stvo_pose_result*)(D + o_res); s->counts = (int32_t*)(D + o_counts);
+    s->m12_span = o_inlp - o_m12sp;  // m12s_p, m12s_l, m12p, m12l are carved back to back
+    s->inl_span = o_res - o_inlp;    // inlp, inll likewise
     d.m12s_p = s->m12s_p; d.m12s_l = s->m12s_l;
     for (int t = 0; t < 2; ++t) {
         stvo_seq::Set& q = s->set[t];
@@ -613,6 +622,8 @@ int stvo_seq_destroy(stvo_seq* s) {
     if (s->ev_join) hipEventDestroy(s->ev_join);
     for (auto e : s->pev)
         if (e) hipEventDestroy(e);
+    if (s->ev_fetch) hipEventDestroy(s->ev_fetch);
+    if (s->fetch_host) hipHostFree(s->fetch_host);
     if (s->dev) hipFree(s->dev);
     if (s->raw_host) hipHostFree(s->raw_host);
     if (s->out_host) hipHostFree(s->out_host);
@@ -780,6 +791,10 @@ int stvo_seq_step_dev(stvo_seq* s, int slot) {
             HIP_TRY(ctx, hipStreamWaitEvent(st, s->ev_join, 0));
         }
         if (s->pev[0]) (void)hipEventRecord(s->pev[3], st);
+        if (s->fetch) {
+            stvo::launch_copy16(st, s->m12s_p, s->fetch_host, s->m12_span);
+            HIP_TRY(ctx, hipEventRecord(s->ev_fetch, st));
+        }
         // ---- optimizePose
         stvo::PoseArgs a;
         std::memset(&a, 0, sizeof(a));
@@ -794,9 +809,16 @@ int stvo_seq_step_dev(stvo_seq* s, int slot) {
         a.inl_p_out = s->inlp; a.inl_l_out = s->inll;
         TRY(stvo::launch_pose(st, a));
         if (s->pev[0]) (void)hipEventRecord(s->pev[4], st);
-    } else if (par) {  // first frame: nothing to track, but the main stream must still see the line stage's results
-        HIP_TRY(ctx, hipEventRecord(s->ev_join, sl));
-        HIP_TRY(ctx, hipStreamWaitEvent(st, s->ev_join, 0));
+        if (s->fetch) stvo::launch_copy16(st, s->inlp, s->fetch_host + s->m12_span, s->inl_span);
+    } else {
+        if (par) {  // first frame: nothing to track, but the main stream must still see the line stage's results
+            HIP_TRY(ctx, hipEventRecord(s->ev_join, sl));
+            HIP_TRY(ctx, hipStreamWaitEvent(st, s->ev_join, 0));
+        }
+        if (s->fetch) {
+            stvo::launch_copy16(st, s->m12s_p, s->fetch_host, s->m12_span);
+            HIP_TRY(ctx, hipEventRecord(s->ev_fetch, st));
+        }
     }
     TRY(check_launch(ctx));
     s->cur ^= 1;  // updateFrame: curr becomes prev
@@ -838,6 +860,51 @@ int stvo_seq_read(stvo_seq* s, stvo_pose_result* results, int32_t* counts) {
             counts[4 * b + 3] = track ? hr[b].n_matched_ls : 0;
         }
     }
+    return STVO_OK;
+}
+
+int stvo_seq_strides(const stvo_seq* s, int32_t* stride_pts, int32_t* stride_lines) {
+    if (!s) return STVO_ERR_INVALID_ARG;
+    if (stride_pts) *stride_pts = s->K;
+    if (stride_lines) *stride_lines = s->M;
+    return STVO_OK;
+}
+
+int stvo_seq_enable_fetch(stvo_seq* s, int enable) {
+    if (!s) return STVO_ERR_INVALID_ARG;
+    stvo_ctx* ctx = s->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (enable && !s->fetch_host) {
+        HIP_TRY(ctx, hipHostMalloc((void**)&s->fetch_host, s->m12_span + s->inl_span, hipHostMallocDefault));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&s->ev_fetch, hipEventDisableTiming));
+    }
+    s->fetch = enable != 0;
+    return STVO_OK;
+}
+
+int stvo_seq_fetch_matches(stvo_seq* s, const int32_t** m12_stereo_pts, const int32_t** m12_stereo_lines,
+                           const int32_t** m12_pts, const int32_t** m12_lines) {
+    if (!s || !s->fetch || s->frame_idx == 0) return STVO_ERR_INVALID_ARG;
+    stvo_ctx* ctx = s->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipEventSynchronize(s->ev_fetch));  // the f2f stage of the last step; its pose kernel may still run
+    const char* H = s->fetch_host;
+    const char* D0 = reinterpret_cast<const char*>(s->m12s_p);
+    if (m12_stereo_pts) *m12_stereo_pts = reinterpret_cast<const int32_t*>(H);
+    if (m12_stereo_lines) *m12_stereo_lines = reinterpret_cast<const int32_t*>(H + (reinterpret_cast<const char*>(s->m12s_l) - D0));
+    if (m12_pts) *m12_pts = reinterpret_cast<const int32_t*>(H + (reinterpret_cast<const char*>(s->m12p) - D0));
+    if (m12_lines) *m12_lines = reinterpret_cast<const int32_t*>(H + (reinterpret_cast<const char*>(s->m12l) - D0));
+    return STVO_OK;
+}
+
+int stvo_seq_fetch_inliers(stvo_seq* s, const int32_t** inl_pts, const int32_t** inl_lines) {
+    if (!s || !s->fetch || s->frame_idx < 2) return STVO_ERR_INVALID_ARG;
+    stvo_ctx* ctx = s->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const char* H = s->fetch_host + s->m12_span;
+    if (inl_pts) *inl_pts = reinterpret_cast<const int32_t*>(H);
+    if (inl_lines) *inl_lines = reinterpret_cast<const int32_t*>(H + (reinterpret_cast<const char*>(s->inll) - reinterpret_cast<const char*>(s->inlp)));
     return STVO_OK;
 }
 

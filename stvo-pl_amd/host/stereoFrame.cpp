@@ -129,7 +129,17 @@ void StereoFrame::matchStereoPoints(std::vector<KeyPoint> points_l_, std::vector
                                  pdesc_r_.ptr(), (int)points_r_.size(), &w, Config::minRatio12P(),
                                  Config::bestLRMatches() ? 1 : 0, matches_12.data(), nullptr),
           "stvo_match_grid_points");
+    buildStereoPoints(points_l_, points_r_, pdesc_l_, matches_12.data(), initial);
+}
 
+// :149-172 — epipolar / disparity filters, back-projection and the filtered descriptor matrix, given matches_12
+void StereoFrame::buildStereoPoints(const std::vector<KeyPoint>& points_l_, const std::vector<KeyPoint>& points_r_,
+                                    DescMat& pdesc_l_, const int32_t* matches_12_, bool initial) {
+    for (auto pt : stereo_pt) delete pt;
+    stereo_pt.clear();
+    if (!Config::hasPoints() || points_l_.empty() || points_r_.empty()) return;
+    struct View { const int32_t* p; size_t n; size_t size() const { return n; } int operator[](size_t i) const { return p[i]; } };
+    const View matches_12{matches_12_, points_l_.size()};
     DescMat pdesc_l_aux;
     int pt_idx = 0;
     for (size_t i1 = 0; i1 < matches_12.size(); ++i1) {
@@ -187,7 +197,17 @@ void StereoFrame::matchStereoLines(std::vector<KeyLine> lines_l_, std::vector<Ke
                                 ldesc_r_.ptr(), (int)lines_r_.size(), directions.data(), &w, Config::minRatio12P(),
                                 Config::lineSimTh(), Config::bestLRMatches() ? 1 : 0, matches_12.data(), nullptr),
           "stvo_match_grid_lines");
+    buildStereoLines(lines_l_, lines_r_, ldesc_l_, matches_12.data(), initial);
+}
 
+// :348-397 — overlap / disparity / horizontality filters, end-point re-intersection, back-projection, given matches_12
+void StereoFrame::buildStereoLines(const std::vector<KeyLine>& lines_l_, const std::vector<KeyLine>& lines_r_,
+                                   DescMat& ldesc_l_, const int32_t* matches_12_, bool initial) {
+    for (auto ls : stereo_ls) delete ls;
+    stereo_ls.clear();
+    if (!Config::hasLines() || lines_l_.empty() || lines_r_.empty()) return;
+    struct View { const int32_t* p; size_t n; size_t size() const { return n; } int operator[](size_t i) const { return p[i]; } };
+    const View matches_12{matches_12_, lines_l_.size()};
     DescMat ldesc_l_aux;
     int ls_idx = 0;
     for (size_t i1 = 0; i1 < matches_12.size(); ++i1) {
@@ -231,6 +251,13 @@ void StereoFrame::matchStereoLines(std::vector<KeyLine> lines_l_, std::vector<Ke
         }
     }
     ldesc_l_ = ldesc_l_aux;
+}
+
+// Device-pipeline mode of the handler: the grid matching of this frame has already run on the GPU (stvo_seq_*);
+// only the host-side feature lists remain to be built, exactly as after matchGrid in the two functions above.
+void StereoFrame::adoptStereoMatches(const int32_t* m12_points, const int32_t* m12_lines) {
+    if (Config::hasPoints()) buildStereoPoints(points_l, points_r, pdesc_l, m12_points, (frame_idx == 0));
+    if (Config::hasLines()) buildStereoLines(lines_l, lines_r, ldesc_l, m12_lines, (frame_idx == 0));
 }
 
 // :405-415

@@ -27,6 +27,13 @@ public:
                            DescMat pdesc_r, bool initial = false);
     void matchStereoLines(std::vector<KeyLine> lines_l, std::vector<KeyLine> lines_r, DescMat& ldesc_l_,
                           DescMat ldesc_r, bool initial = false);
+    // the host halves of the two functions above (everything after matchGrid), and their use with matches that were
+    // computed by the device-resident pipeline
+    void buildStereoPoints(const std::vector<KeyPoint>& points_l, const std::vector<KeyPoint>& points_r, DescMat& pdesc_l_,
+                           const int32_t* matches_12, bool initial);
+    void buildStereoLines(const std::vector<KeyLine>& lines_l, const std::vector<KeyLine>& lines_r, DescMat& ldesc_l_,
+                          const int32_t* matches_12, bool initial);
+    void adoptStereoMatches(const int32_t* m12_points, const int32_t* m12_lines);
     void filterLineSegmentDisparity(Vector2d spl, Vector2d epl, Vector2d spr, Vector2d epr, double& disp_s,
                                     double& disp_e);
     double lineSegmentOverlapStereo(double spl_obs, double epl_obs, double spl_proj, double epl_proj);

@@ -29,6 +29,8 @@ StereoFrameHandler::StereoFrameHandler(PinholeStereoCamera* cam_, int device_id)
     // no CPU path exists: without a gfx950 device this throws
     check(stvo_ctx_create(device_id, 8192, 1, &ctx), "stvo_ctx_create", nullptr);
     if (!std::getenv("STVO_NO_LINE_CTX")) check(stvo_ctx_create(device_id, 2048, 1, &ctx_lines), "stvo_ctx_create(lines)", nullptr);
+    const char* e = std::getenv("STVO_HANDLER_PIPELINE");
+    if (e && e[0] == '0') use_pipeline = false;
 }
 
 StereoFrameHandler::~StereoFrameHandler() {
@@ -36,6 +38,7 @@ StereoFrameHandler::~StereoFrameHandler() {
     for (auto ls : matched_ls) delete ls;
     if (curr_frame && curr_frame != prev_frame) delete curr_frame;
     delete prev_frame;
+    if (seq) stvo_seq_destroy(seq);
     if (ctx_lines) stvo_ctx_destroy(ctx_lines);
     stvo_ctx_destroy(ctx);
 }
@@ -45,7 +48,15 @@ void StereoFrameHandler::initialize(const FrameFeatures& feat, const int idx_) {
     orb_fast_th = Config::orbFastTh();
     llength_th = Config::minLineLength() * std::min(cam->getWidth(), cam->getHeight());
     prev_frame = new StereoFrame(feat, idx_, cam, ctx, ctx_lines);
-    prev_frame->extractStereoFeatures(llength_th, orb_fast_th);
+    pose_pending = false;
+    if (seq) {  // a new sequence starts
+        stvo_seq_destroy(seq);
+        seq = nullptr;
+    }
+    if (!(use_pipeline && !Config::useMotionModel() && pipelineStep(feat, prev_frame))) {
+        use_pipeline = false;
+        prev_frame->extractStereoFeatures(llength_th, orb_fast_th);
+    }
     prev_frame->Tfw = Matrix4d::Identity();
     prev_frame->Tfw_cov = Matrix6d::Identity();
     prev_frame->DT = Matrix4d::Identity();
@@ -58,6 +69,16 @@ void StereoFrameHandler::insertStereoPair(const FrameFeatures& feat, const int i
     using clk = std::chrono::high_resolution_clock;
     const auto t0 = clk::now();
     curr_frame = new StereoFrame(feat, idx_, cam, ctx, ctx_lines);
+    if (use_pipeline) {
+        if (pipelineStep(feat, curr_frame)) {
+            t_stereo_ms = std::chrono::duration<double, std::milli>(clk::now() - t0).count();
+            t_f2f_ms = 0.0;
+            return;
+        }
+        // the frame exceeds the pipeline's capacity: the host-side lists are complete, so the per-call path can take over
+        // from here (and keeps the sequence: the device-side state would be stale after this frame)
+        use_pipeline = false;
+    }
     curr_frame->extractStereoFeatures(llength_th, orb_fast_th);
     const auto t1 = clk::now();
     f2fTracking();
@@ -120,7 +141,12 @@ void StereoFrameHandler::matchF2FPoints() {
                                 curr_frame->pdesc_l.rows, (float)Config::minRatio12P(), Config::bestLRMatches() ? 1 : 0,
                                 matches_12.data(), nullptr),
           "stvo_match_nnr_mutual(points)", ctx);
-    for (size_t i1 = 0; i1 < matches_12.size(); ++i1) {
+    buildMatchedPoints(matches_12.data(), matches_12.size());
+}
+
+// :144-152
+void StereoFrameHandler::buildMatchedPoints(const int32_t* matches_12, size_t n) {
+    for (size_t i1 = 0; i1 < n; ++i1) {
         const int i2 = matches_12[i1];
         if (i2 < 0) continue;
         prev_frame->stereo_pt[i1]->pl_obs = curr_frame->stereo_pt[i2]->pl;
@@ -140,7 +166,12 @@ void StereoFrameHandler::matchF2FLines() {
                                 curr_frame->ldesc_l.rows, (float)Config::minRatio12L(), Config::bestLRMatches() ? 1 : 0,
                                 matches_12.data(), nullptr),
           "stvo_match_nnr_mutual(lines)", cl);
-    for (size_t i1 = 0; i1 < matches_12.size(); ++i1) {
+    buildMatchedLines(matches_12.data(), matches_12.size());
+}
+
+// :167-179
+void StereoFrameHandler::buildMatchedLines(const int32_t* matches_12, size_t n) {
+    for (size_t i1 = 0; i1 < n; ++i1) {
         const int i2 = matches_12[i1];
         if (i2 < 0) continue;
         LineFeature* p = prev_frame->stereo_ls[i1];
@@ -170,6 +201,31 @@ bool StereoFrameHandler::isGoodSolution(Matrix4d DT, Matrix6d DTcov, double err)
 // :307-392 — the optimisation itself (:332-370 and the goodness test of :372) runs on the GPU
 void StereoFrameHandler::optimizePose() {
     const auto t_begin = std::chrono::high_resolution_clock::now();
+    if (use_pipeline) {
+        // the optimisation was enqueued by insertStereoPair right behind the f2f matching; collect it
+        if (!pose_pending) throw std::runtime_error("[StVO-HIP] optimizePose() without a preceding insertStereoPair()");
+        pose_pending = false;
+        int32_t counts[4];
+        check(stvo_seq_read(seq, &last_result, counts), "stvo_seq_read", ctx);
+        const int32_t *ip = nullptr, *il = nullptr;
+        check(stvo_seq_fetch_inliers(seq, &ip, &il), "stvo_seq_fetch_inliers", ctx);
+        // inlier flags of the MATCHED prev features, in list order (= ascending prev stereo index)
+        size_t k = 0;
+        for (auto pt : matched_pt) {
+            while (k < prev_frame->stereo_pt.size() && ip[k] < 0) ++k;
+            pt->inlier = (k < prev_frame->stereo_pt.size()) ? ip[k] != 0 : false;
+            ++k;
+        }
+        k = 0;
+        for (auto ls : matched_ls) {
+            while (k < prev_frame->stereo_ls.size() && il[k] < 0) ++k;
+            ls->inlier = (k < prev_frame->stereo_ls.size()) ? il[k] != 0 : false;
+            ++k;
+        }
+        publishPose();
+        t_pose_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t_begin).count();
+        return;
+    }
     Matrix4d DT;
     if (Config::useMotionModel()) {  // :317-324
         DT = prev_frame->DT;
@@ -227,6 +283,12 @@ void StereoFrameHandler::optimizePose() {
     for (auto pt : matched_pt) pt->inlier = ip[k++] != 0;
     k = 0;
     for (auto ls : matched_ls) ls->inlier = il[k++] != 0;
+    publishPose();
+    t_pose_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t_begin).count();
+}
+
+// counters, console notes and the "set estimated pose" block of optimizePose (:372-391) from last_result
+void StereoFrameHandler::publishPose() {
     n_inliers_pt = last_result.n_inliers_pt;
     n_inliers_ls = last_result.n_inliers_ls;
     n_inliers = n_inliers_pt + n_inliers_ls;
@@ -254,7 +316,86 @@ void StereoFrameHandler::optimizePose() {
         curr_frame->Tfw_cov = prev_frame->Tfw_cov;
         for (int i = 0; i < 6; ++i) curr_frame->DT_cov_eig(i) = 0.0;
     }
-    t_pose_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t_begin).count();
+}
+
+// One frame through the device-resident pipeline: upload, enqueue stereo association -> f2f -> pose, then rebuild the
+// host-side lists from the fetched match indices while the pose kernel runs.  false = the frame does not fit.
+bool StereoFrameHandler::pipelineStep(const FrameFeatures& feat, StereoFrame* frame) {
+    const int n0 = (int)feat.points_l.size(), n1 = (int)feat.points_r.size(), n2 = (int)feat.lines_l.size(),
+              n3 = (int)feat.lines_r.size();
+    if (n0 > STVO_POSE_MAX_POINTS || n1 > STVO_POSE_MAX_POINTS || n2 > STVO_POSE_MAX_LINES || n3 > STVO_POSE_MAX_LINES) return false;
+    if (!seq) {
+        stvo_match_params mp{};
+        mp.best_lr_matches = Config::bestLRMatches(); mp.matching_s_ws = Config::matchingSWs();
+        mp.min_ratio_12_p = (float)Config::minRatio12P(); mp.min_ratio_12_l = (float)Config::minRatio12L();
+        mp.max_dist_epip = Config::maxDistEpip(); mp.min_disp = Config::minDisp(); mp.line_sim_th = Config::lineSimTh();
+        mp.stereo_overlap_th = Config::stereoOverlapTh(); mp.line_horiz_th = Config::lineHorizTh();
+        mp.ls_min_disp_ratio = Config::lsMinDispRatio(); mp.orb_scale_factor = Config::orbScaleFactor();
+        mp.lsd_scale = Config::lsdScale();
+        stvo_opt_params op{};
+        op.mode = mode; op.has_points = Config::hasPoints(); op.has_lines = Config::hasLines();
+        op.min_features = Config::minFeatures(); op.max_iters = Config::maxIters(); op.max_iters_ref = Config::maxItersRef();
+        op.homog_th = Config::homogTh(); op.min_error = Config::minError(); op.min_error_change = Config::minErrorChange();
+        op.inlier_k = Config::inlierK();
+        const stvo_cam c = cam->abi();
+        check(stvo_seq_create(ctx, 1, STVO_POSE_MAX_POINTS, STVO_POSE_MAX_LINES, feat.img_cols, feat.img_rows, &c, &mp, &op, &seq),
+              "stvo_seq_create", ctx);
+        check(stvo_seq_enable_fetch(seq, 1), "stvo_seq_enable_fetch", ctx);
+        int32_t K = 0, M = 0;
+        check(stvo_seq_strides(seq, &K, &M), "stvo_seq_strides", ctx);
+        seq_K = K; seq_M = M;
+    }
+    // cv::KeyPoint / KeyLine arrays -> the plain arrays of stvo_frame_features
+    static thread_local std::vector<float> kpl, kpr, kll, klr;
+    static thread_local std::vector<int32_t> ol, oll;
+    kpl.resize(2 * n0 + 2); kpr.resize(2 * n1 + 2); kll.resize(4 * n2 + 4); klr.resize(4 * n3 + 4);
+    ol.resize(n0 + 1); oll.resize(n2 + 1);
+    for (int i = 0; i < n0; ++i) { kpl[2 * i] = feat.points_l[i].x; kpl[2 * i + 1] = feat.points_l[i].y; ol[i] = feat.points_l[i].octave; }
+    for (int i = 0; i < n1; ++i) { kpr[2 * i] = feat.points_r[i].x; kpr[2 * i + 1] = feat.points_r[i].y; }
+    for (int i = 0; i < n2; ++i) {
+        kll[4 * i] = feat.lines_l[i].startPointX; kll[4 * i + 1] = feat.lines_l[i].startPointY;
+        kll[4 * i + 2] = feat.lines_l[i].endPointX; kll[4 * i + 3] = feat.lines_l[i].endPointY;
+        oll[i] = feat.lines_l[i].octave;
+    }
+    for (int i = 0; i < n3; ++i) {
+        klr[4 * i] = feat.lines_r[i].startPointX; klr[4 * i + 1] = feat.lines_r[i].startPointY;
+        klr[4 * i + 2] = feat.lines_r[i].endPointX; klr[4 * i + 3] = feat.lines_r[i].endPointY;
+    }
+    const int32_t n[4] = {n0, n1, n2, n3};
+    stvo_frame_features ff{};
+    ff.stride_kp = n0 > n1 ? n0 : n1;
+    ff.stride_kl = n2 > n3 ? n2 : n3;
+    ff.n_kp_l = &n[0]; ff.n_kp_r = &n[1]; ff.n_kl_l = &n[2]; ff.n_kl_r = &n[3];
+    ff.kp_l = kpl.data(); ff.oct_l = ol.data(); ff.desc_l = feat.pdesc_l.ptr(); ff.kp_r = kpr.data(); ff.desc_r = feat.pdesc_r.ptr();
+    ff.kl_l = kll.data(); ff.oct_ll = oll.data(); ff.ldesc_l = feat.ldesc_l.ptr(); ff.kl_r = klr.data(); ff.ldesc_r = feat.ldesc_r.ptr();
+    const bool first = (frame == prev_frame);
+    check(stvo_seq_upload(seq, pipe_slot, &ff), "stvo_seq_upload", ctx);
+    check(stvo_seq_step_dev(seq, pipe_slot), "stvo_seq_step_dev", ctx);
+    pipe_slot ^= 1;
+    // GPU: stereo association + f2f done => match indices in pinned memory; the pose kernel is still running
+    const int32_t *ms_p = nullptr, *ms_l = nullptr, *m_p = nullptr, *m_l = nullptr;
+    check(stvo_seq_fetch_matches(seq, &ms_p, &ms_l, &m_p, &m_l), "stvo_seq_fetch_matches", ctx);
+    frame->adoptStereoMatches(ms_p, ms_l);
+    if (first) {
+        int32_t counts[4];
+        stvo_pose_result dummy;
+        check(stvo_seq_read(seq, &dummy, counts), "stvo_seq_read", ctx);  // nothing to track on the first frame
+        return true;
+    }
+    // f2fTracking (:106-129) from the fetched f2f matches
+    for (auto pt : matched_pt) delete pt;
+    for (auto ls : matched_ls) delete ls;
+    matched_pt.clear();
+    matched_ls.clear();
+    if (Config::hasPoints() && !curr_frame->stereo_pt.empty() && !prev_frame->stereo_pt.empty())
+        buildMatchedPoints(m_p, prev_frame->stereo_pt.size());
+    if (Config::hasLines() && !curr_frame->stereo_ls.empty() && !prev_frame->stereo_ls.empty())
+        buildMatchedLines(m_l, prev_frame->stereo_ls.size());
+    n_inliers_pt = (int)matched_pt.size();
+    n_inliers_ls = (int)matched_ls.size();
+    n_inliers = n_inliers_pt + n_inliers_ls;
+    pose_pending = true;
+    return true;
 }
 
 void StereoFrameHandler::resetOutliers() {

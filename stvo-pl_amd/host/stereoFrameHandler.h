@@ -54,7 +54,22 @@ public:
     double t_stereo_ms = 0.0, t_f2f_ms = 0.0, t_pose_ms = 0.0;
     int mode = 0;  // the local constant of src/stereoFrameHandler.cpp:329 (0 GN, 1 robust GN, 2 LM)
 
+    // Device-resident pipeline (stvo_seq_*) behind the same methods: insertStereoPair uploads the frame
+    // once and enqueues stereo association -> f2f -> optimizePose on the GPU; the host-side lists (stereo_pt / stereo_ls,
+    // matched_pt / matched_ls) are rebuilt from the fetched match indices WHILE the pose kernel runs, and optimizePose()
+    // only collects the result.  On by default; off when Config::useMotionModel() (the pipeline starts from DT = I),
+    // when a frame exceeds the pipeline's capacity (2048 key-points / 512 key-lines per image), or with
+    // STVO_HANDLER_PIPELINE=0 in the environment.
+    bool use_pipeline = true;
+
 private:
+    bool pipelineStep(const FrameFeatures& feat, StereoFrame* frame);  // false: frame does not fit -> legacy path
+    void buildMatchedPoints(const int32_t* matches_12, size_t n);
+    void buildMatchedLines(const int32_t* matches_12, size_t n);
+    void publishPose();
+    stvo_seq* seq = nullptr;
+    int seq_K = 0, seq_M = 0, pipe_slot = 0;
+    bool pose_pending = false;
     stvo_ctx* ctx;
     stvo_ctx* ctx_lines;  // second context for the line tasks of the plInParallel branches (:115-118, stereoFrame.cpp:64-72)
 };

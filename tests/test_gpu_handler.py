@@ -18,10 +18,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 APP = os.path.join(ROOT, "stvo-pl_amd", "bin", "imagesStVO_synth")
 
 
-def run_app(tmp_path, frames, cam, preset, mode=0, extra=()):
+def run_app(tmp_path, frames, cam, preset, mode=0, extra=(), pipeline=True):
+    """pipeline=True: the handler runs on the device-resident pipeline (its default); False: one synchronous C-ABI
+    call per stage (STVO_HANDLER_PIPELINE=0)."""
     seq = str(tmp_path / "seq.bin"); res = str(tmp_path / "res.bin")
     synth.write_sequence(seq, frames, cam)
-    p = subprocess.run([APP, seq, res, "--preset", preset, "--mode", str(mode), *extra], capture_output=True, text=True, timeout=300)
+    env = dict(os.environ, STVO_HANDLER_PIPELINE="1" if pipeline else "0")
+    p = subprocess.run([APP, seq, res, "--preset", preset, "--mode", str(mode), *extra], capture_output=True, text=True, timeout=300,
+                       env=env)
     assert p.returncode == 0, p.stderr + p.stdout
     return synth.read_results(res), p.stdout
 
@@ -45,10 +49,11 @@ def compare(res, ref):
         assert r["fast"] == o["fast"]
 
 
-def test_kitti_points_and_lines_sequence(tmp_path, oracle):
+@pytest.mark.parametrize("pipeline", [True, False])
+def test_kitti_points_and_lines_sequence(tmp_path, oracle, pipeline):
     cam = synth.KITTI_CAM
     frames = synth.make_stereo_sequence(2025, n_frames=6, n_pts=700, n_lines=70, cam=cam)
-    res, out = run_app(tmp_path, frames, cam, "kitti")
+    res, out = run_app(tmp_path, frames, cam, "kitti", pipeline=pipeline)
     ref = pipeline_ref.run_sequence(oracle, frames, cam, match_params("kitti"), opt_params("kitti"))
     compare(res, ref)
     assert all(r["ints"][1] == 0 for r in res)            # every frame committed
@@ -60,25 +65,38 @@ def test_kitti_points_and_lines_sequence(tmp_path, oracle):
         assert np_model.rot_angle(DT[:3, :3], Tt[:3, :3]) < 5e-3 and np.linalg.norm(DT[:3, 3] - Tt[:3, 3]) < 0.1
 
 
-def test_kitti_points_only_2000(tmp_path, oracle):
+@pytest.mark.parametrize("pipeline", [True, False])
+def test_kitti_points_only_2000(tmp_path, oracle, pipeline):
     """BASELINE configs[0] shape: KITTI-00-like pairs, points only, through the handler API."""
     cam = synth.KITTI_CAM
     frames = synth.make_stereo_sequence(7, n_frames=4, n_pts=1650, n_lines=0, cam=cam)  # 1650 + 20% = ~2000 key-points
     cfg = tmp_path / "cfg.yaml"
     cfg.write_text("has_lines : false   # points-only\n")
-    res, _ = run_app(tmp_path, frames, cam, "kitti", extra=("-c", str(cfg)))
+    res, _ = run_app(tmp_path, frames, cam, "kitti", extra=("-c", str(cfg)), pipeline=pipeline)
     ref = pipeline_ref.run_sequence(oracle, frames, cam, match_params("kitti"), opt_params("kitti", has_lines=0))
     compare(res, ref)
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2])
-def test_euroc_shaped_line_heavy(tmp_path, oracle, mode):
+@pytest.mark.parametrize("mode,pipeline", [(0, True), (1, True), (2, True), (0, False), (2, False)])
+def test_euroc_shaped_line_heavy(tmp_path, oracle, mode, pipeline):
     cam = synth.EUROC_CAM
     frames = synth.make_stereo_sequence(99 + mode, n_frames=4, n_pts=500, n_lines=200, cam=cam, depth=(1.0, 8.0),
                                         octave_probs=[.5, .25, .15, .1], outlier_frac=0.2)
-    for fr in frames:  # EuRoC-like slow motion: scale the true motion down is not needed for parity
-        pass
-    res, _ = run_app(tmp_path, frames, cam, "euroc", mode=mode)
+    res, _ = run_app(tmp_path, frames, cam, "euroc", mode=mode, pipeline=pipeline)
     fast = dict(adaptive=True, th0=20, mn=5, mx=50, inc=5, feat=50, err=0.5)
     ref = pipeline_ref.run_sequence(oracle, frames, cam, match_params("euroc"), opt_params("euroc", mode=mode), fast)
+    compare(res, ref)
+
+
+def test_oversized_frame_falls_back_to_the_per_call_path(tmp_path, oracle):
+    """A frame with more key-points than the device pipeline holds (2048 per image) makes the handler continue on the
+    per-call path from that frame on, without losing the sequence."""
+    cam = synth.KITTI_CAM
+    frames = synth.make_stereo_sequence(31, n_frames=5, n_pts=900, n_lines=0, cam=cam)
+    big = synth.make_stereo_sequence(32, n_frames=1, n_pts=2400, n_lines=0, cam=cam)[0]   # ~2900 key-points per image
+    frames[3] = dict(big, T_true=frames[3]["T_true"])
+    cfg = tmp_path / "cfg.yaml"
+    cfg.write_text("has_lines : false\n")
+    res, _ = run_app(tmp_path, frames, cam, "kitti", extra=("-c", str(cfg)))
+    ref = pipeline_ref.run_sequence(oracle, frames, cam, match_params("kitti"), opt_params("kitti", has_lines=0))
     compare(res, ref)
