@@ -92,7 +92,10 @@ __device__ __forceinline__ GridArgs frame_view(const GridBatch& g, int b) {
     return a;
 }
 
-__device__ __forceinline__ void cover_window(const GridArgs& a, int x, int y, int i1) {
+// ORs the bit of every right feature found in the window of cell (x, y) into column i1.  `col` / `stride`: where the
+// column's words live — an LDS staging column of the calling thread (stride 256) or the global bit-matrix (stride n1p).
+template <typename P>
+__device__ __forceinline__ void cover_window(const GridArgs& a, int x, int y, P col, size_t stride) {
     // GridStructure::get clamping (src/gridStructure.cpp:67-71)
     const int min_x = max(0, x - a.w.w_lo), max_x = min(STVO_GRID_COLS, x + a.w.w_hi + 1);
     const int min_y = max(0, y - a.w.h_lo), max_y = min(STVO_GRID_ROWS, y + a.w.h_hi + 1);
@@ -104,30 +107,49 @@ __device__ __forceinline__ void cover_window(const GridArgs& a, int x, int y, in
             const int id = a.cell_items[k];
             if (id >= 0 && id < a.n2) {  // :141 skips out-of-range ids
                 const int p = a.rank[id];
-                a.cover[(size_t)(p >> 6) * a.n1p + i1] |= 1ull << (p & 63);  // column i1 is owned by this thread
+                col[(size_t)(p >> 6) * stride] |= 1ull << (p & 63);  // the column is owned by this thread
             }
         }
     }
 }
 
-template <bool LINES>
+// Builds column i1 of the transposed candidate bit-matrix.  USE_LDS: the column (words64 words) is assembled in an LDS
+// staging column of the thread and then written out once with plain stores that are coalesced across the wave — no
+// read-modify-write on global memory (each of the ~20 (points) to several hundred (lines) candidate bits of a left
+// feature used to cost a dependent L2 round trip) and no separate memset of the matrix.
+template <bool LINES, bool USE_LDS>
 __global__ __launch_bounds__(256) void grid_cover_kernel(GridBatch g) {
+    extern __shared__ unsigned long long s_col[];  // [words64][256] when USE_LDS
     const GridArgs a = frame_view(g, blockIdx.y);
     const int i1 = blockIdx.x * 256 + threadIdx.x;
-    // every thread first clears its own column of the bit-matrix (all words64 words; coalesced across the lanes of a
-    // wave), padding columns included — no separate memset launch
-    if (i1 < a.n1p)
-        for (int w = 0; w < a.words64; ++w) a.cover[(size_t)w * a.n1p + i1] = 0ull;
-    if (i1 >= a.n1) return;
-    if (LINES) {
-        const int4 c = reinterpret_cast<const int4*>(a.cell_xy1)[i1];
-        cover_window(a, c.x, c.y, i1);
-        cover_window(a, c.z, c.w, i1);
+    if (i1 >= a.n1p) return;
+    unsigned long long* gcol = a.cover + i1;
+    if (USE_LDS) {
+        for (int w = 0; w < a.words64; ++w) s_col[w * 256 + threadIdx.x] = 0ull;
     } else {
-        const int2 c = reinterpret_cast<const int2*>(a.cell_xy1)[i1];
-        cover_window(a, c.x, c.y, i1);
+        for (int w = 0; w < a.words64; ++w) gcol[(size_t)w * a.n1p] = 0ull;
     }
-    a.top2[i1] = kTop2Empty;
+    if (i1 < a.n1) {
+        if (LINES) {
+            const int4 c = reinterpret_cast<const int4*>(a.cell_xy1)[i1];
+            if (USE_LDS) {
+                cover_window(a, c.x, c.y, s_col + threadIdx.x, (size_t)256);
+                cover_window(a, c.z, c.w, s_col + threadIdx.x, (size_t)256);
+            } else {
+                cover_window(a, c.x, c.y, gcol, (size_t)a.n1p);
+                cover_window(a, c.z, c.w, gcol, (size_t)a.n1p);
+            }
+        } else {
+            const int2 c = reinterpret_cast<const int2*>(a.cell_xy1)[i1];
+            if (USE_LDS)
+                cover_window(a, c.x, c.y, s_col + threadIdx.x, (size_t)256);
+            else
+                cover_window(a, c.x, c.y, gcol, (size_t)a.n1p);
+        }
+        a.top2[i1] = kTop2Empty;
+    }
+    if (USE_LDS)
+        for (int w = 0; w < a.words64; ++w) gcol[(size_t)w * a.n1p] = s_col[w * 256 + threadIdx.x];  // padding columns: zeros
 }
 
 __device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc) {
@@ -310,12 +332,21 @@ __global__ __launch_bounds__(256) void grid_finalize_kernel(GridBatch g) {
 void launch_grid_batch(hipStream_t s, const GridBatch& g, bool lines) {
     if (g.B <= 0 || g.stride1 <= 0 || g.stride2 <= 0) return;
     const dim3 g1((g.stride1 + 255) / 256, g.B), g2((g.stride2 + 255) / 256, g.B), gc((g.n1p + 255) / 256, g.B), blk(256);
+    // LDS staging column per thread: words64 x 256 x 8 B per workgroup (64 KB at 2048 right features)
+    const size_t lds = (size_t)g.words64 * 256 * sizeof(unsigned long long);
+    const bool use_lds = lds <= ((size_t)64 << 10);
     if (lines) {
-        hipLaunchKernelGGL((grid_cover_kernel<true>), gc, blk, 0, s, g);
+        if (use_lds)
+            hipLaunchKernelGGL((grid_cover_kernel<true, true>), gc, blk, lds, s, g);
+        else
+            hipLaunchKernelGGL((grid_cover_kernel<true, false>), gc, blk, 0, s, g);
         hipLaunchKernelGGL((grid_scan_kernel<true, 1>), g2, blk, 0, s, g);
         hipLaunchKernelGGL((grid_scan_kernel<true, 2>), g2, blk, 0, s, g);
     } else {
-        hipLaunchKernelGGL((grid_cover_kernel<false>), gc, blk, 0, s, g);
+        if (use_lds)
+            hipLaunchKernelGGL((grid_cover_kernel<false, true>), gc, blk, lds, s, g);
+        else
+            hipLaunchKernelGGL((grid_cover_kernel<false, false>), gc, blk, 0, s, g);
         hipLaunchKernelGGL((grid_scan_kernel<false, 1>), g2, blk, 0, s, g);
         hipLaunchKernelGGL((grid_scan_kernel<false, 2>), g2, blk, 0, s, g);
     }
