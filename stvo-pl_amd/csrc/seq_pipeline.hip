@@ -563,12 +563,12 @@ int stvo_seq_create(stvo_ctx* ctx, int B, int max_keypoints, int max_keylines, i
               hip_ok(ctx, hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming), "hipEventCreate seq");
     s->zero_copy = B <= 16;
     if (!ok) {
-        if (s->dev) hipFree(s->dev);
-        if (s->raw_host) hipHostFree(s->raw_host);
-        if (s->out_host) hipHostFree(s->out_host);
-        if (s->line_stream) hipStreamDestroy(s->line_stream);
-        if (s->ev_fork) hipEventDestroy(s->ev_fork);
-        if (s->ev_join) hipEventDestroy(s->ev_join);
+        if (s->dev) (void)hipFree(s->dev);
+        if (s->raw_host) (void)hipHostFree(s->raw_host);
+        if (s->out_host) (void)hipHostFree(s->out_host);
+        if (s->line_stream) (void)hipStreamDestroy(s->line_stream);
+        if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
+        if (s->ev_join) (void)hipEventDestroy(s->ev_join);
         delete s;
         return STVO_ERR_HIP;
     }
@@ -611,22 +611,22 @@ int stvo_seq_create(stvo_ctx* ctx, int B, int max_keypoints, int max_keylines, i
 
 int stvo_seq_destroy(stvo_seq* s) {
     if (!s) return STVO_OK;
-    hipSetDevice(s->ctx->device);
-    hipStreamSynchronize(s->ctx->stream);
-    if (s->ctx->aux_stream) hipStreamSynchronize(s->ctx->aux_stream);
+    (void)hipSetDevice(s->ctx->device);
+    (void)hipStreamSynchronize(s->ctx->stream);
+    if (s->ctx->aux_stream) (void)hipStreamSynchronize(s->ctx->aux_stream);
     if (s->line_stream) {
-        hipStreamSynchronize(s->line_stream);
-        hipStreamDestroy(s->line_stream);
+        (void)hipStreamSynchronize(s->line_stream);
+        (void)hipStreamDestroy(s->line_stream);
     }
-    if (s->ev_fork) hipEventDestroy(s->ev_fork);
-    if (s->ev_join) hipEventDestroy(s->ev_join);
+    if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
+    if (s->ev_join) (void)hipEventDestroy(s->ev_join);
     for (auto e : s->pev)
-        if (e) hipEventDestroy(e);
-    if (s->ev_fetch) hipEventDestroy(s->ev_fetch);
-    if (s->fetch_host) hipHostFree(s->fetch_host);
-    if (s->dev) hipFree(s->dev);
-    if (s->raw_host) hipHostFree(s->raw_host);
-    if (s->out_host) hipHostFree(s->out_host);
+        if (e) (void)hipEventDestroy(e);
+    if (s->ev_fetch) (void)hipEventDestroy(s->ev_fetch);
+    if (s->fetch_host) (void)hipHostFree(s->fetch_host);
+    if (s->dev) (void)hipFree(s->dev);
+    if (s->raw_host) (void)hipHostFree(s->raw_host);
+    if (s->out_host) (void)hipHostFree(s->out_host);
     delete s;
     return STVO_OK;
 }
@@ -921,14 +921,14 @@ int stvo_seq_push(stvo_seq* s, const stvo_frame_features* f, stvo_pose_result* r
     static double acc[4] = {0, 0, 0, 0}, gacc[4] = {0, 0, 0, 0};
     static int n = 0, gn = 0;
     if (!s->pev[0])
-        for (auto& e : s->pev) hipEventCreate(&e);
+        for (auto& e : s->pev) (void)hipEventCreate(&e);
     const auto t0 = clk::now();
-    hipEventRecord(s->pev[0], s->ctx->stream);
+    (void)hipEventRecord(s->pev[0], s->ctx->stream);
     TRY(stvo_seq_upload(s, slot, f));
     const auto t1 = clk::now();
     TRY(stvo_seq_step_dev(s, slot));
     const auto t2 = clk::now();
-    hipStreamSynchronize(s->ctx->stream);
+    (void)hipStreamSynchronize(s->ctx->stream);
     const auto t3 = clk::now();
     const int rc = stvo_seq_read(s, results, counts);
     const auto t4 = clk::now();

@@ -74,25 +74,25 @@ int stvo_ctx_create(int device_id, int max_rows, int max_batch, stvo_ctx** out) 
 
 int stvo_ctx_destroy(stvo_ctx* ctx) {
     if (!ctx) return STVO_OK;
-    hipSetDevice(ctx->device);
-    if (ctx->stream) hipStreamSynchronize(ctx->stream);
-    if (ctx->knn12) hipFree(ctx->knn12);
-    if (ctx->knn21) hipFree(ctx->knn21);
-    if (ctx->cand) hipFree(ctx->cand);
-    if (ctx->need) hipFree(ctx->need);
-    if (ctx->qsel) hipFree(ctx->qsel);
-    if (ctx->nsel) hipFree(ctx->nsel);
-    if (ctx->arena) hipFree(ctx->arena);
-    if (ctx->arena_host) hipHostFree(ctx->arena_host);
-    if (ctx->probe_sink) hipFree(ctx->probe_sink);
-    for (hipEvent_t e : ctx->ev_pool) hipEventDestroy(e);
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->knn12) (void)hipFree(ctx->knn12);
+    if (ctx->knn21) (void)hipFree(ctx->knn21);
+    if (ctx->cand) (void)hipFree(ctx->cand);
+    if (ctx->need) (void)hipFree(ctx->need);
+    if (ctx->qsel) (void)hipFree(ctx->qsel);
+    if (ctx->nsel) (void)hipFree(ctx->nsel);
+    if (ctx->arena) (void)hipFree(ctx->arena);
+    if (ctx->arena_host) (void)hipHostFree(ctx->arena_host);
+    if (ctx->probe_sink) (void)hipFree(ctx->probe_sink);
+    for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->aux_stream) {
-        hipStreamSynchronize(ctx->aux_stream);
-        hipStreamDestroy(ctx->aux_stream);
-        hipEventDestroy(ctx->ev_match_done);
-        hipEventDestroy(ctx->ev_pose_done);
+        (void)hipStreamSynchronize(ctx->aux_stream);
+        (void)hipStreamDestroy(ctx->aux_stream);
+        (void)hipEventDestroy(ctx->ev_match_done);
+        (void)hipEventDestroy(ctx->ev_pose_done);
     }
-    if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return STVO_OK;
 }
@@ -100,8 +100,8 @@ int stvo_ctx_destroy(stvo_ctx* ctx) {
 int stvo_ctx_set_stream(stvo_ctx* ctx, void* hip_stream) {
     if (!ctx) return STVO_ERR_INVALID_ARG;
     if (ctx->own_stream && ctx->stream) {
-        hipStreamSynchronize(ctx->stream);
-        hipStreamDestroy(ctx->stream);
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamDestroy(ctx->stream);
     }
     ctx->own_stream = false;
     ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
@@ -459,8 +459,8 @@ int stvo_time_stage_dev(stvo_ctx* ctx, const stvo_track_batch_dev* b, const stvo
     HIP_TRY(ctx, hipEventSynchronize(e1));
     float ms = 0.f;
     HIP_TRY(ctx, hipEventElapsedTime(&ms, e0, e1));
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
     *avg_ms = ms / (float)iters;
     if (stage == 1 && std::getenv("STVO_POSE_PROF")) {  // developer aid: per-phase ticks of the solver lane
         long long* dprof = nullptr;
@@ -474,7 +474,7 @@ int stvo_time_stage_dev(stvo_ctx* ctx, const stvo_track_batch_dev* b, const stvo
             for (int i = 0; i < 8; ++i) m[i] += (double)h[(size_t)f * 8 + i] / b->B;
         std::fprintf(stderr, "[pose prof] mean ticks/frame: evaluate %.0f  iter-algebra %.0f  cov+isgood+commit %.0f  "
                              "remove_outliers %.0f  total %.0f | worker: eval-compute %.0f  sum28 %.0f\n", m[0], m[1], m[2], m[3], m[4], m[5], m[6]);
-        hipFree(dprof);
+        (void)hipFree(dprof);
     }
     return check_launch(ctx);
 }
@@ -529,8 +529,8 @@ int stvo_valu_peak_probe(stvo_ctx* ctx, double* lane_ops_per_s) {
     HIP_TRY(ctx, hipEventSynchronize(e1));
     float ms = 0.f;
     HIP_TRY(ctx, hipEventElapsedTime(&ms, e0, e1));
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
     *lane_ops_per_s = (double)blocks * 256.0 * (double)iters * stvo::kValuProbeOpsPerThreadIter / ((double)ms * 1e-3);
     return check_launch(ctx);
 }
