@@ -70,6 +70,56 @@ def cpu_baseline(frames, prm, budget_s=12.0):
                       f"host has {os.cpu_count()} cores"}
 
 
+def cpu_baseline_variants(frames, prm, budget_s=5.0):
+    """Two more CPU figures asked for by SURVEY.md §8(d), same oracle, same workload: (a) the reference's own thread
+    fan-out for this config — matches_12 and matches_21 on two threads (lrInParallel, src/matching.cpp:68-78), the
+    optimisation single-threaded; (b) independent frame pairs on many host threads (the oracle's C functions run
+    outside the GIL).  Reported next to `cpu_baseline`, never instead of it."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from concurrent.futures import ThreadPoolExecutor
+    import oracle_lib
+    from stvo_amd import synth
+    orc = oracle_lib.load()
+    z3, z2 = np.zeros((0, 3)), np.zeros((0, 2))
+
+    def pose(fr, m12):
+        sel = np.nonzero(m12 >= 0)[0]
+        rec = dict(P=fr["prev_P"][sel], pl_obs=fr["curr_pl"][m12[sel]], sigma2p=fr["prev_sigma2"][sel],
+                   inlier_p=np.ones(len(sel), np.int32), sP=z3, eP=z3, le_obs=z3, spl=z2, epl=z2, sigma2l=np.zeros(0),
+                   inlier_l=np.zeros(0, np.int32))
+        orc.optimize_pose(np.eye(4), synth.KITTI_CAM, prm, rec)
+
+    out = {}
+    with ThreadPoolExecutor(2) as ex:  # (a)
+        done, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget_s:
+            fr = frames[done % len(frames)]
+            f21 = ex.submit(orc.match_nnr, fr["curr_desc"], fr["prev_desc"], 0.75)
+            m12, _ = orc.match_nnr(fr["prev_desc"], fr["curr_desc"], 0.75)
+            m21, _ = f21.result()
+            ok = (m12 >= 0) & (m21[np.maximum(m12, 0)] == np.arange(len(m12)))  # src/matching.cpp:80-86
+            pose(fr, np.where(ok, m12, -1))
+            done += 1
+        dt = time.perf_counter() - t0
+    out["cpu_baseline_fanout"] = {"value": done / dt, "unit": "frame-pairs/s", "cores": 2, "kind": "port",
+                                  "sample": f"{done} frame pairs, 12 || 21 matching on two threads like the reference, {dt:.1f} s"}
+    nthr = min(32, os.cpu_count() or 1)
+
+    def one(i):
+        fr = frames[i % len(frames)]
+        m12, _ = orc.match(fr["prev_desc"], fr["curr_desc"], 0.75, 1)
+        pose(fr, m12)
+
+    with ThreadPoolExecutor(nthr) as ex:  # (b)
+        n_jobs = max(2 * nthr, int(budget_s * 90 * nthr / 2))
+        t0 = time.perf_counter()
+        list(ex.map(one, range(n_jobs)))
+        dt = time.perf_counter() - t0
+    out["cpu_baseline_threads"] = {"value": n_jobs / dt, "unit": "frame-pairs/s", "cores": nthr, "kind": "port",
+                                   "sample": f"{n_jobs} independent frame pairs on {nthr} host threads, {dt:.1f} s"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -190,6 +240,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames, prm)
+            out.update(cpu_baseline_variants(frames, prm))
     ctx.close()
     if dist is not None:
         dist.barrier()
