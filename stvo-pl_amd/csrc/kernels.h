@@ -81,7 +81,7 @@ struct PoseArgs {
     int eval_only;       // 1: a single optimizeFunctions evaluation at init_T
     int eval_robust;
     double* eval_out;    // [B][44]: H(36) g(6) e n
-    long long* prof_out; // optional [B][5] phase ticks (tools only)
+    long long* prof_out; // optional [B][16] phase ticks (tools only)
 };
 int launch_pose(hipStream_t s, const PoseArgs& a);
 

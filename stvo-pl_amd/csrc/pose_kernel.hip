@@ -111,7 +111,7 @@ struct BlockOps {
     // ends up with the wave totals of values 7r .. 7r+6 in its last lane.  147 VALU ops instead of the 504 of 28
     // independent 64-lane scans; fixed association order => bit-reproducible.
     template <bool W>
-    static __device__ __forceinline__ void sum28(double* acc, double (*red)[28], PoseSh* sh) {
+    static __device__ __forceinline__ void sum28_fold(double* acc, double (*red)[28]) {
         const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
         if (W) {
             double s14[14], s7[7];
@@ -129,6 +129,10 @@ struct BlockOps {
                 if ((lane & 15) == 15) red[wv][(lane >> 4) * 7 + k] = v;
             }
         }
+    }
+    template <bool W>
+    static __device__ __forceinline__ void sum28_finish(double (*red)[28], PoseSh* sh) {
+        const int lane = threadIdx.x & 63;
         __syncthreads();
         if (!W) {
             if (lane < 28) {
@@ -519,6 +523,7 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_ibuf)[BLOCK
     // algebra, [2] covariance + isGood + commit, [3] removeOutliers, [4] total
     long long tprof[5] = {0, 0, 0, 0, 0};
     long long wprof[3] = {0, 0, 0};  // worker lane 0: evaluate compute, reduction, robust pre-pass
+    long long wave_busy = 0;
     const bool prof = a.prof_out != nullptr;
     auto tick = [&]() -> long long { return prof ? (long long)__builtin_readcyclecounter() : 0ll; };
     const long long t_begin = tick();
@@ -714,9 +719,13 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_ibuf)[BLOCK
             }
         const long long tw1 = tick();
         prefetch_first();  // for the next evaluation; completes while this one is reduced and solved
-        Ops::template sum28<W>(acc, s_red, sh);
+        Ops::template sum28_fold<W>(acc, s_red);
+        const long long tw2 = tick();
+        Ops::template sum28_finish<W>(s_red, sh);
         wprof[0] += tw1 - tw0;
-        wprof[1] += tick() - tw1;
+        wprof[1] += tick() - tw2;
+        wprof[2] += tw2 - tw1;
+        wave_busy += tw2 - tw0;  // this wave's own compute + fold (per-wave load balance, lane 0 of every worker wave)
     };
 
     if (a.eval_only) {
@@ -923,11 +932,12 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_ibuf)[BLOCK
     if (prof && t0) {
         tprof[4] = tick() - t_begin;
 #pragma unroll
-        for (int i = 0; i < 5; ++i) a.prof_out[(size_t)f * 8 + i] = tprof[i];
+        for (int i = 0; i < 5; ++i) a.prof_out[(size_t)f * 16 + i] = tprof[i];
     }
+    if (prof && W && (tid & 63) == 0 && (tid >> 6) < 8) a.prof_out[(size_t)f * 16 + 8 + (tid >> 6)] = wave_busy;
     if (prof && W && tid == 0) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) a.prof_out[(size_t)f * 8 + 5 + i] = wprof[i];
+        for (int i = 0; i < 3; ++i) a.prof_out[(size_t)f * 16 + 5 + i] = wprof[i];
     }
 
     if (W && a.inl_p_out) {

@@ -464,16 +464,18 @@ int stvo_time_stage_dev(stvo_ctx* ctx, const stvo_track_batch_dev* b, const stvo
     *avg_ms = ms / (float)iters;
     if (stage == 1 && std::getenv("STVO_POSE_PROF")) {  // developer aid: per-phase ticks of the solver lane
         long long* dprof = nullptr;
-        HIP_TRY(ctx, hipMalloc((void**)&dprof, (size_t)b->B * 8 * sizeof(long long)));
+        HIP_TRY(ctx, hipMalloc((void**)&dprof, (size_t)b->B * 16 * sizeof(long long)));
         a.prof_out = dprof;
         stvo::launch_pose(ctx->stream, a);
-        std::vector<long long> h((size_t)b->B * 8);
+        std::vector<long long> h((size_t)b->B * 16);
         HIP_TRY(ctx, hipMemcpy(h.data(), dprof, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
-        double m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        double m[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         for (int f = 0; f < b->B; ++f)
-            for (int i = 0; i < 8; ++i) m[i] += (double)h[(size_t)f * 8 + i] / b->B;
+            for (int i = 0; i < 16; ++i) m[i] += (double)h[(size_t)f * 16 + i] / b->B;
         std::fprintf(stderr, "[pose prof] mean ticks/frame: evaluate %.0f  iter-algebra %.0f  cov+isgood+commit %.0f  "
-                             "remove_outliers %.0f  total %.0f | worker: eval-compute %.0f  sum28 %.0f\n", m[0], m[1], m[2], m[3], m[4], m[5], m[6]);
+                             "remove_outliers %.0f  total %.0f | worker: eval-compute %.0f  barrier+solver-sum %.0f  prefetch+fold %.0f\n", m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7]);
+        std::fprintf(stderr, "[pose prof] per worker wave, compute + fold ticks/frame: %.0f %.0f %.0f %.0f %.0f %.0f %.0f %.0f\n", m[8], m[9], m[10],
+                     m[11], m[12], m[13], m[14], m[15]);
         (void)hipFree(dprof);
     }
     return check_launch(ctx);
