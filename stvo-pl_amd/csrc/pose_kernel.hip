@@ -212,43 +212,67 @@ struct BlockOps {
         return base + incl - count;
     }
 
-    // workgroup-wide total of per-wave counts (wave-uniform `c`); double-buffered partials => ONE barrier per call
+    // workgroup-wide totals of three per-wave counts (wave-uniform c[0..2]); double-buffered partials => ONE barrier per call
     template <bool W>
-    static __device__ __forceinline__ int count_db(int c, int (*ibuf)[NW], int parity) {
+    static __device__ __forceinline__ void count3_db(int* c, int (*ibuf)[3 * NW], int parity) {
         const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        if (W && lane == 0) ibuf[parity][wv] = c;
+        if (W && lane == 0) {
+            ibuf[parity][wv] = c[0];
+            ibuf[parity][NW + wv] = c[1];
+            ibuf[parity][2 * NW + wv] = c[2];
+        }
         __syncthreads();
-        int t = 0;
+        int t0 = 0, t1 = 0, t2 = 0;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) t += ibuf[parity][w];
-        return t;
+        for (int w = 0; w < NW; ++w) {
+            t0 += ibuf[parity][w];
+            t1 += ibuf[parity][NW + w];
+            t2 += ibuf[parity][2 * NW + w];
+        }
+        c[0] = t0;
+        c[1] = t1;
+        c[2] = t2;
     }
 
     // k-th smallest (0-based) of the n keys {key[k] : bit k of mask} held in REGISTERS across the workgroup:
-    // most-significant-bit-first binary search, one workgroup-wide count per bit (per-wave counts come from
-    // ballots + s_bcnt1, no cross-lane data movement).  lo / hi bracket the number of keys below the current
-    // prefix and below its upper end; as soon as exactly one key is left in the bracket it IS the answer and is
-    // fetched directly — with n ~ 1500 distinct values that happens after ~25 of the 64 (or ~18 of the 32) bits.
-    // Equal keys simply keep the search going to the last bit.  Same result as sorting.
+    // most-significant-first radix search on two bits per round — three thresholds, three workgroup-wide counts (per-wave
+    // counts from ballots + s_bcnt1, no cross-lane data movement), one barrier.  lo / hi bracket the number of keys
+    // below the current prefix and below its upper end; as soon as exactly one key is left in the bracket it IS the
+    // answer and is fetched directly — with n ~ 1500 distinct values that happens after ~13 of the 32 (or ~9 of the 16)
+    // rounds.  Equal keys simply keep the search going to the last bit.  Same result as sorting.
     template <int N, bool W, typename K, int BITS>
-    static __device__ __forceinline__ K select_kth(const K* key, unsigned mask, int n, int kth, int (*ibuf)[NW], K* xchg) {
+    static __device__ __forceinline__ K select_kth(const K* key, unsigned mask, int n, int kth, int (*ibuf)[3 * NW], K* xchg) {
+        static_assert(BITS % 2 == 0, "two bits per round");
         K res = 0;
         int lo = 0, hi = n, parity = 0;
-        for (int bit = BITS - 1; bit >= 0; --bit) {
-            const K t = res | ((K)1 << bit);
-            int c = 0;
+        for (int bit = BITS - 2; bit >= 0; bit -= 2) {
+            const K t1 = res | ((K)1 << bit), t2 = res | ((K)2 << bit), t3 = res | ((K)3 << bit);
+            int c[3] = {0, 0, 0};
             if (W) {
 #pragma unroll
-                for (int k = 0; k < N; ++k)
-                    c += __popcll(__builtin_amdgcn_ballot_w64(((mask >> k) & 1u) && key[k] < t));
+                for (int k = 0; k < N; ++k) {
+                    const bool in = (mask >> k) & 1u;
+                    c[0] += __popcll(__builtin_amdgcn_ballot_w64(in && key[k] < t1));
+                    c[1] += __popcll(__builtin_amdgcn_ballot_w64(in && key[k] < t2));
+                    c[2] += __popcll(__builtin_amdgcn_ballot_w64(in && key[k] < t3));
+                }
             }
-            c = count_db<W>(c, ibuf, parity);
+            count3_db<W>(c, ibuf, parity);
             parity ^= 1;
-            if (c <= kth) {
-                res = t;
-                lo = c;
+            // the largest threshold with at most kth keys below it becomes the new prefix
+            if (c[2] <= kth) {
+                res = t3;
+                lo = c[2];
+            } else if (c[1] <= kth) {
+                res = t2;
+                lo = c[1];
+                hi = c[2];
+            } else if (c[0] <= kth) {
+                res = t1;
+                lo = c[0];
+                hi = c[1];
             } else {
-                hi = c;
+                hi = c[0];
             }
             if (hi - lo == 1 && bit > 0) {  // block-uniform: the single key in [res, res + 2^bit)
                 const K top = res + (((K)1 << bit) - 1);
@@ -271,7 +295,7 @@ struct BlockOps {
     // (FLOAT truncation); MAD = sorted dev[n/2].  The two std::sort calls are replaced by exact k-th-element
     // selection on the order-preserving integer images of the values.  n == 0 -> 0.
     template <int N, bool W>
-    static __device__ __forceinline__ double mad_sigma(const double* v, unsigned mask, int n, int (*ibuf)[NW],
+    static __device__ __forceinline__ double mad_sigma(const double* v, unsigned mask, int n, int (*ibuf)[3 * NW],
                                                        unsigned long long* xchg) {
         if (n == 0) return 0.0;  // block-uniform
         const int kth = n / 2;
@@ -513,7 +537,7 @@ __device__ __forceinline__ void t0_commit(PoseSh* sh, stvo_pose_result* out, int
 }  // namespace
 
 template <int BLOCK, int PPT, int LPT, bool W>
-__device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_ibuf)[BLOCK / 64], double (*s_red)[28],
+__device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_ibuf)[3 * (BLOCK / 64)], double (*s_red)[28],
                                           int* s_ired, PoseSh* sh) {
     using Ops = BlockOps<BLOCK / 64>;
     const int f = blockIdx.x;
@@ -960,7 +984,7 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_ibuf)[BLOCK
 
 template <int BLOCK, int PPT, int LPT>
 __global__ __launch_bounds__(BLOCK + 64, 2) void pose_kernel(PoseArgs a) {  // >= 2 waves/SIMD => <= 256 VGPRs, 2 workgroups per CU
-    __shared__ int s_ibuf[2][BLOCK / 64];
+    __shared__ int s_ibuf[2][3 * (BLOCK / 64)];
     __shared__ double s_red[BLOCK / 64][28];
     __shared__ int s_ired[BLOCK / 64];
     __shared__ PoseSh s_sh;

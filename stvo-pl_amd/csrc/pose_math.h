@@ -83,18 +83,22 @@ PM_HD void expmap_se3(const double* x, double* T) {
     double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     const double theta = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
     if (!(theta < 0.000001)) {
+        // one reciprocal of theta instead of the reference's eleven divisions by it, and one sincos (<= 1 ulp per term)
+        const double itheta = 1.0 / theta;
         double sk[9], s[9], s2[9];
         skew3(w, sk);
 #pragma unroll
-        for (int i = 0; i < 9; ++i) s[i] = sk[i] / theta;
+        for (int i = 0; i < 9; ++i) s[i] = sk[i] * itheta;
         mat3_mul(s, s, s2);
-        const double sn = sin(theta), cs = cos(theta);
+        double sn, cs;
+        sincos(theta, &sn, &cs);
+        const double ka = (1.0 - cs) * itheta, kb = (theta - sn) * itheta;
         double V[9];
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
             const double I = (i % 4 == 0) ? 1.0 : 0.0;
             R[i] = I + s[i] * sn + s2[i] * (1.0 - cs);
-            V[i] = I + s[i] * (1.0 - cs) / theta + s2[i] * (theta - sn) / theta;
+            V[i] = I + s[i] * ka + s2[i] * kb;
         }
         const double a = V[0] * t0 + V[1] * t1 + V[2] * t2;
         const double b = V[3] * t0 + V[4] * t1 + V[5] * t2;
