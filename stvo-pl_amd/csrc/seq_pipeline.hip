@@ -167,15 +167,18 @@ __global__ __launch_bounds__(256) void point_cells_kernel(SeqDev s) {
 }
 
 // ---- 3: points — filters, back-projection, ordered compaction ---------------------------------------
-__global__ __launch_bounds__(256) void point_tail_kernel(SeqDev s) {
-    __shared__ int s_wave[4];
+// 1024 threads per frame: the compaction offset is carried from chunk to chunk (three barriers each), so fewer, larger
+// chunks shorten the chain — 2 chunks instead of 8 for ~2000 key-points.
+constexpr int TAIL_BLOCK = 1024;
+__global__ __launch_bounds__(TAIL_BLOCK) void point_tail_kernel(SeqDev s) {
+    __shared__ int s_wave[TAIL_BLOCK / 64];
     __shared__ int s_run;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nl = s.n_kp_l[b];
     const size_t off = (size_t)b * s.K;
     if (tid == 0) s_run = 0;
     __syncthreads();
-    for (int base = 0; base < nl; base += 256) {
+    for (int base = 0; base < nl; base += TAIL_BLOCK) {
         const int i = base + tid;
         bool ok = false;
         double disp = 0.0;
@@ -215,7 +218,11 @@ __global__ __launch_bounds__(256) void point_tail_kernel(SeqDev s) {
             dst[1] = src[1];
         }
         __syncthreads();
-        if (tid == 0) s_run += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        if (tid == 0) {
+            int t = 0;
+            for (int w = 0; w < TAIL_BLOCK / 64; ++w) t += s_wave[w];
+            s_run += t;
+        }
         __syncthreads();
     }
     if (tid == 0) {
@@ -746,7 +753,7 @@ int stvo_seq_step_dev(stvo_seq* s, int slot) {
         g.ratio = (double)s->mp.min_ratio_12_p; g.line_sim_th = 0.0; g.mutual = s->mp.best_lr_matches;
         g.cover = s->cover; g.rank = d.prank; g.perm = d.pperm; g.top2 = s->top2; g.owner2 = s->owner2; g.m12 = s->m12s_p;
         stvo::launch_grid_batch(st, g, false);
-        hipLaunchKernelGGL(stvo::point_tail_kernel, dim3(B), dim3(256), 0, st, d);
+        hipLaunchKernelGGL(stvo::point_tail_kernel, dim3(B), dim3(stvo::TAIL_BLOCK), 0, st, d);
     } else {
         HIP_TRY(ctx, hipMemsetAsync(cs.n, 0, (size_t)B * 4, st));
     }
