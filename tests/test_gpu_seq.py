@@ -82,3 +82,10 @@ def test_seq_pipeline_line_stage_skipped_and_resumed(oracle):
     for k in (1, 4):  # the line detector found nothing in these frames
         seq[k] = dict(seq[k], kl_l=z4, kl_r=z4, ldesc_l=zd, ldesc_r=zd, oct_ll=zi, ang_l=np.zeros(0, np.float32))
     run_and_compare(oracle, [seq], cam, "kitti")
+
+
+def test_seq_pipeline_many_sequences_copy_back_path(oracle):
+    """More than 16 sequences: results and counts come back through explicit D2H copies instead of zero-copy writes."""
+    cam = synth.KITTI_CAM
+    seqs = [synth.make_stereo_sequence(1000 + b, n_frames=3, n_pts=120 + 7 * b, n_lines=12 if b % 3 else 0, cam=cam) for b in range(20)]
+    run_and_compare(oracle, seqs, cam, "kitti", max_kp=512, max_kl=64)
