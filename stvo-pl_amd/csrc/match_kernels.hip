@@ -75,8 +75,8 @@ __device__ __forceinline__ uint2 merged_knn(const uint2* __restrict__ knn, size_
     return r;
 }
 
-// qsel / nsel (optional): scan only the listed query rows of this direction (lazy reverse pass: the
-// columns that are some row's accepted forward match); qsel = nullptr scans every row.
+// qsel / nsel (optional): scan only the listed query rows of this direction (not used by the product path any more:
+// the mutual check is hamming_verify below); qsel = nullptr scans every row.
 // nseg: the train range of every query tile is split into nseg segments scanned by different workgroups
 // (partial top-2 per segment, merged by the consumers).  One wave then works for ~N/nseg rows instead of N,
 // which keeps the dispatch rounds short: with 2000 rows a whole-range wave lasts ~0.5 ms and any grid that
