@@ -25,7 +25,7 @@ extern "C" {
 
 #define STVO_ABI_VERSION 1
 #define STVO_MAX_ROWS_LIMIT 65535 /* packed (distance << 16 | index) keys */
-#define STVO_POSE_MAX_POINTS 2048 /* per frame-pair, register-resident records in the pose kernel */
+#define STVO_POSE_MAX_POINTS 2048 /* per frame pair: points owned per worker thread x worker threads of the pose kernel */
 #define STVO_POSE_MAX_LINES 512
 
 typedef struct stvo_ctx stvo_ctx;
