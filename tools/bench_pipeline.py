@@ -27,15 +27,21 @@ def main():
     ap.add_argument("--points", type=int, default=1650)  # + 20 % distractors ~ 2000 key-points per image
     ap.add_argument("--lines", type=int, default=85)     # + 20 % ~ 100 key-lines per image
     ap.add_argument("--cpu-frames", type=int, default=8)
+    ap.add_argument("--preset", default="kitti", choices=["kitti", "euroc"],
+                    help="euroc: BASELINE configs[3] shape (752x480, 800 points over 4 octaves, 300 lines, 40 %% outliers)")
+    ap.add_argument("--mode", type=int, default=0, help="0 GN, 1 robust GN, 2 LM")
     a = ap.parse_args()
     import torch  # noqa: F401  (one HIP runtime per process, see capi.load)
     from stvo_amd import capi, synth
     from stvo_amd.ctypes_types import match_params, opt_params
-    cam = synth.KITTI_CAM
-    mp = match_params("kitti")
-    op = opt_params("kitti", has_lines=1 if a.lines > 0 else 0)
+    euroc = a.preset == "euroc"
+    cam = synth.EUROC_CAM if euroc else synth.KITTI_CAM
+    mp = match_params(a.preset)
+    op = opt_params(a.preset, has_lines=1 if a.lines > 0 else 0, mode=a.mode)
     B = a.batch
-    seqs = [synth.make_stereo_sequence(synth.frame_seed(b, 0), n_frames=2, n_pts=a.points, n_lines=a.lines, cam=cam) for b in range(B)]
+    extra = dict(depth=(0.5, 8.0), octave_probs=[.5, .25, .15, .1], outlier_frac=0.4) if euroc else {}
+    seqs = [synth.make_stereo_sequence(synth.frame_seed(b, 0), n_frames=2, n_pts=a.points, n_lines=a.lines, cam=cam, **extra)
+            for b in range(B)]
     ctx = capi.Context(device_id=0, max_rows=2048, max_batch=B)
     dev = capi.Sequences(ctx, B, 2048, 512, cam, mp, op)
     dev.upload(0, [s[0] for s in seqs])
@@ -53,8 +59,10 @@ def main():
     out = {"metric": "stereo frames/s (grid stereo match + f2f match + optimizePose), device-resident pipeline",
            "value": B * a.steps / dt, "unit": "frame-pairs/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
            "ms_per_step": dt / a.steps * 1e3, "data": "synthetic",
-           "config": {"workload": "BASELINE configs[2]: KITTI-00-shaped stereo, points + lines, grid-windowed stereo association, "
-                                  "f2f mutual matching, GN pose; B independent sequences, two frames per sequence resident in HBM",
+           "config": {"workload": ("BASELINE configs[3]: EuRoC-shaped 752x480 stereo, line-heavy, 40 % point outliers, "
+                                   f"optimiser mode {a.mode} (0 GN / 1 robust GN / 2 LM)" if euroc else
+                                   "BASELINE configs[2]: KITTI-00-shaped stereo, points + lines, grid-windowed stereo association, "
+                                   "f2f mutual matching, GN pose") + "; B independent sequences, two frames per sequence resident in HBM",
                       "sequences": B, "keypoints_per_image": len(seqs[0][0]["kp_l"]), "keylines_per_image": len(seqs[0][0]["kl_l"]),
                       "mean_stereo_points": float(counts[:, 0].mean()), "mean_stereo_lines": float(counts[:, 1].mean()),
                       "mean_matched_points": float(counts[:, 2].mean()), "committed_pose_fraction": ok}}

@@ -15,8 +15,11 @@ ap.add_argument("--points", type=int, default=1650)  # + 20 % distractors ~ 2000
 ap.add_argument("--lines", type=int, default=0)
 ap.add_argument("--cam", default="kitti")
 ap.add_argument("--seed", type=int, default=synth.SEED0)
+ap.add_argument("--config4", action="store_true",
+                help="BASELINE configs[3] statistics: depth 0.5-8 m, octaves {.5,.25,.15,.1}, 40 %% point outliers (use with --cam euroc)")
 a = ap.parse_args()
 cam = synth.KITTI_CAM if a.cam == "kitti" else synth.EUROC_CAM
-frames = synth.make_stereo_sequence(a.seed, n_frames=a.frames, n_pts=a.points, n_lines=a.lines, cam=cam)
+extra = dict(depth=(0.5, 8.0), octave_probs=[.5, .25, .15, .1], outlier_frac=0.4) if a.config4 else {}
+frames = synth.make_stereo_sequence(a.seed, n_frames=a.frames, n_pts=a.points, n_lines=a.lines, cam=cam, **extra)
 synth.write_sequence(a.out, frames, cam)
 print(f"wrote {a.out}: {a.frames} frames, {len(frames[0]['kp_l'])} key-points, {len(frames[0]['kl_l'])} key-lines per image")
