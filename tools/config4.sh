@@ -9,7 +9,7 @@ for m in 0 1 2; do
   echo "# optimiser mode $m: handler (device pipeline) | stvo_seq_push directly"
   $R/stvo-pl_amd/bin/imagesStVO_synth /tmp/seq_e.bin /tmp/res_e.bin --preset euroc --mode $m | tail -1
   $R/stvo-pl_amd/bin/imagesStVO_synth /tmp/seq_e.bin /tmp/res_e.bin --preset euroc --mode $m --device-pipeline | tail -1
-  python tools/bench_pipeline.py --preset euroc --mode $m --batch 512 --points 660 --lines 250 --cpu-frames 4 2>/dev/null
+  python tools/bench_pipeline.py --preset euroc --mode $m --batch 512 --points 660 --lines 250 --cpu-frames 6 2>/dev/null
 done
 } > $OUT 2>&1
 cat $OUT
