@@ -117,6 +117,11 @@ def load():
     L.stvo_seq_upload.argtypes = [C.c_void_p, C.c_int, C.POINTER(FrameFeatures)]
     L.stvo_seq_step_dev.argtypes = [C.c_void_p, C.c_int]
     L.stvo_seq_read.argtypes = [C.c_void_p, C.c_void_p, i32p]
+    pp32 = C.POINTER(C.POINTER(C.c_int32))
+    L.stvo_seq_enable_fetch.argtypes = [C.c_void_p, C.c_int]
+    L.stvo_seq_fetch_matches.argtypes = [C.c_void_p, pp32, pp32, pp32, pp32]
+    L.stvo_seq_fetch_inliers.argtypes = [C.c_void_p, pp32, pp32]
+    L.stvo_seq_strides.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.stvo_last_reverse_counts.argtypes = [C.c_void_p, C.c_int, i32p]
     L.stvo_ctx_set_kernel_timing.argtypes = [C.c_void_p, C.c_int]
     L.stvo_ctx_get_kernel_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int32)]
@@ -325,3 +330,25 @@ class Sequences:
         counts = np.zeros(self.B * 4, np.int32)
         self.ctx._chk(self.ctx.lib.stvo_seq_read(self.h, res.ctypes.data_as(C.c_void_p), counts))
         return res, counts.reshape(self.B, 4)
+
+    def enable_fetch(self, on=True):
+        self.ctx._chk(self.ctx.lib.stvo_seq_enable_fetch(self.h, 1 if on else 0))
+
+    def strides(self):
+        k, m = C.c_int32(), C.c_int32()
+        self.ctx._chk(self.ctx.lib.stvo_seq_strides(self.h, C.byref(k), C.byref(m)))
+        return k.value, m.value
+
+    def fetch_matches(self):
+        """(stereo m12 points [B,K], stereo m12 lines [B,M], f2f m12 points [B,K], f2f m12 lines [B,M]) of the last step."""
+        K, M = self.strides()
+        ps = [C.POINTER(C.c_int32)() for _ in range(4)]
+        self.ctx._chk(self.ctx.lib.stvo_seq_fetch_matches(self.h, *[C.byref(p) for p in ps]))
+        shapes = [(self.B, K), (self.B, M), (self.B, K), (self.B, M)]
+        return tuple(np.ctypeslib.as_array(p, shape=sh).copy() for p, sh in zip(ps, shapes))
+
+    def fetch_inliers(self):
+        K, M = self.strides()
+        ps = [C.POINTER(C.c_int32)() for _ in range(2)]
+        self.ctx._chk(self.ctx.lib.stvo_seq_fetch_inliers(self.h, *[C.byref(p) for p in ps]))
+        return tuple(np.ctypeslib.as_array(p, shape=sh).copy() for p, sh in zip(ps, [(self.B, K), (self.B, M)]))

@@ -89,3 +89,43 @@ def test_seq_pipeline_many_sequences_copy_back_path(oracle):
     cam = synth.KITTI_CAM
     seqs = [synth.make_stereo_sequence(1000 + b, n_frames=3, n_pts=120 + 7 * b, n_lines=12 if b % 3 else 0, cam=cam) for b in range(20)]
     run_and_compare(oracle, seqs, cam, "kitti", max_kp=512, max_kl=64)
+
+
+def test_seq_fetch_by_products(oracle):
+    """stvo_seq_enable_fetch / fetch_matches / fetch_inliers (what the handler mirror rebuilds its host lists from): the raw
+    stereo matches equal the oracle's grid matcher on the same frame, and the f2f matches / inlier flags are consistent
+    with the pose result of the same step."""
+    from stvo_amd import capi
+    from stvo_amd.capi import StvoError
+    cam = synth.KITTI_CAM
+    seq = synth.make_stereo_sequence(1234, n_frames=3, n_pts=400, n_lines=40, cam=cam)
+    mp = match_params("kitti"); op = opt_params("kitti")
+    ctx = capi.Context(device_id=0, max_rows=2048, max_batch=1)
+    dev = capi.Sequences(ctx, 1, 512, 64, cam, mp, op)
+    try:
+        with pytest.raises(StvoError):
+            dev.fetch_matches()  # not enabled
+        dev.enable_fetch(True)
+        for k, fr in enumerate(seq):
+            res, counts = dev.push([fr])
+            ms_p, ms_l, m_p, m_l = dev.fetch_matches()
+            ref = pipeline_ref.stereo_frame(oracle, fr, cam, mp, True, True)
+            n_l, n_ll = len(fr["kp_l"]), len(fr["kl_l"])
+            # every stereo feature of the oracle comes from an accepted raw match
+            assert (ms_p[0, :n_l] >= 0).sum() >= len(ref["P"]) == counts[0, 0]
+            assert (ms_l[0, :n_ll] >= 0).sum() >= len(ref["sP"]) == counts[0, 1]
+            if k == 0:
+                prev_counts = counts.copy()
+                continue
+            r = res[0]
+            assert (m_p[0, :prev_counts[0, 0]] >= 0).sum() == r["n_matched_pt"]
+            assert (m_l[0, :prev_counts[0, 1]] >= 0).sum() == r["n_matched_ls"]
+            assert np.all(m_p[0, :prev_counts[0, 0]] < counts[0, 0])
+            ip, il = dev.fetch_inliers()
+            assert (ip[0, :prev_counts[0, 0]] == 1).sum() == r["n_inliers_pt"]
+            assert (il[0, :prev_counts[0, 1]] == 1).sum() == r["n_inliers_ls"]
+            assert np.array_equal(ip[0, :prev_counts[0, 0]] >= 0, m_p[0, :prev_counts[0, 0]] >= 0)
+            prev_counts = counts.copy()
+    finally:
+        dev.close()
+        ctx.close()
