@@ -227,7 +227,7 @@ def main():
                          "traffic_source": "bytes per launch = FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes, read from "
                                            "the committed profiles/r01_e_hbm_counters.txt (not re-measured by this run)",
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k1_ms, "timing": "hipEvent pairs around each launch, on the launch stream, over a second pass of the same K steps",
-                         "note": "K1 is integer-VALU bound (~1000 lane-ops per compulsory byte); see valu_roofline. One launch per step"},
+                         "note": "K1 is integer-VALU bound (~530 lane-ops per compulsory byte); see valu_roofline. One launch per step"},
             "valu_roofline": {"kernel": "hamming_knn2_kernel", "lane_ops_per_launch": lane_ops,
                               "achieved": lane_ops / (k1_ms * 1e-3) / 1e12, "peak": VALU_PEAK_LANE_OPS / 1e12,
                               "unit": "T lane-ops/s", "frac": lane_ops / (k1_ms * 1e-3) / VALU_PEAK_LANE_OPS,
