@@ -1063,24 +1063,26 @@ template <int BLK, bool LDSREC>
 static void launch_pose_variant(hipStream_t s, const PoseArgs& a) {
     constexpr int PPT = (STVO_POSE_MAX_POINTS + BLK - 1) / BLK;
     constexpr int LPT = (STVO_POSE_MAX_LINES + BLK - 1) / BLK;
-    size_t lds = 0;
-    if (LDSREC) {
-        lds = ((size_t)a.max_pts * 6 + (size_t)a.max_lines * 14) * sizeof(double);
-        static bool attr_set = false;  // more than the default 64 KB of dynamic LDS needs an explicit opt-in (once)
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pose_kernel<BLK, PPT, LPT, LDSREC>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)POSE_LDSREC_MAX_BYTES);
-            attr_set = true;
-        }
-    }
+    const size_t lds = LDSREC ? ((size_t)a.max_pts * 6 + (size_t)a.max_lines * 14) * sizeof(double) : 0;
     hipLaunchKernelGGL((pose_kernel<BLK, PPT, LPT, LDSREC>), dim3(a.B), dim3(BLK + 64), lds, s, a);
+}
+
+// More than the default 64 KB of dynamic LDS needs an explicit opt-in; done once.  false: the runtime refused, callers use
+// the streamed-record variant instead.
+template <int BLK>
+static bool pose_ldsrec_available() {
+    constexpr int PPT = (STVO_POSE_MAX_POINTS + BLK - 1) / BLK;
+    constexpr int LPT = (STVO_POSE_MAX_LINES + BLK - 1) / BLK;
+    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&pose_kernel<BLK, PPT, LPT, true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)POSE_LDSREC_MAX_BYTES) == hipSuccess;
+    return ok;
 }
 
 int launch_pose(hipStream_t s, const PoseArgs& a) {
     if (a.B <= 0) return STVO_OK;
     if (a.max_pts > STVO_POSE_MAX_POINTS || a.max_lines > STVO_POSE_MAX_LINES) return STVO_ERR_CAPACITY;
     const size_t rec_bytes = ((size_t)a.max_pts * 6 + (size_t)a.max_lines * 14) * sizeof(double);
-    if (a.B <= POSE_LATENCY_MAX_B && rec_bytes <= POSE_LDSREC_MAX_BYTES)
+    if (a.B <= POSE_LATENCY_MAX_B && rec_bytes <= POSE_LDSREC_MAX_BYTES && pose_ldsrec_available<POSE_BLOCK_L>())
         launch_pose_variant<POSE_BLOCK_L, true>(s, a);   // one workgroup per CU: records resident in LDS
     else if (a.B <= POSE_LATENCY_MAX_B)
         launch_pose_variant<POSE_BLOCK_L, false>(s, a);
