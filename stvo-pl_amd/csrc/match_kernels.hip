@@ -17,6 +17,8 @@
 //   * grid = (query tiles of 256 rows, 2 directions, B frame pairs); no inter-workgroup traffic.
 #include "kernels.h"
 
+#include <stdlib.h>
+
 namespace stvo {
 
 __device__ __forceinline__ uint32_t med3_u32(uint32_t a, uint32_t b, uint32_t c) {
@@ -163,6 +165,12 @@ void launch_hamming_knn2(hipStream_t s, int B, int row_stride, int max_n, const 
                          const uint8_t* d2, const int32_t* n2, uint2* knn12, uint2* knn21, int both_directions,
                          int lds_pad_bytes, int dir0, const int32_t* qsel, const int32_t* nsel, int nseg, uint32_t* claim_init) {
     if (B <= 0 || max_n <= 0) return;
+    static const int mfma_qb = [] { const char* e = getenv("STVO_KNN_MFMA"); return e ? atoi(e) : 0; }();
+    if (mfma_qb > 0 && max_n <= 8192) {
+        launch_hamming_knn2_mfma(s, B, row_stride, max_n, d1, n1, d2, n2, knn12, knn21, both_directions, dir0, qsel, nsel, nseg,
+                                 claim_init, mfma_qb);
+        return;
+    }
     const int tiles = (max_n + KNN_BLOCK - 1) / KNN_BLOCK, ndir = both_directions ? 2 : 1;
     const int groups = (B + 7) / 8;  // frame pairs are dealt to the 8 XCDs in groups of 8
     dim3 grid((unsigned)(groups * 8 * tiles * ndir * nseg));

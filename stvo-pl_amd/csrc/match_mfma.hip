@@ -1,0 +1,217 @@
+// match_mfma.hip — K1m `hamming_knn2_mfma`: the brute-force Hamming 2-NN scan of K1 (match_kernels.hip) with the
+// 256-bit distances taken from the gfx950 matrix cores instead of 8 x (v_xor + v_bcnt) per pair.
+//
+// Same contract as hamming_knn2_kernel — cv::BFMatcher(NORM_HAMMING).knnMatch(desc1, desc2, ., 2) as called from
+// StVO::matchNNR (/root/reference/src/matching.cpp:47-48): per query row the two smallest distances in ascending
+// order, lowest train index first among equal distances — and the same output ([nseg][B][row_stride] packed keys).
+//
+// Why this is a matrix product and not a reshaping trick: the all-pairs Hamming distance of bit rows IS a Gram
+// matrix.  With bits mapped to x = +-64 (query: +64 for a set bit) and y = -+64 (train: -64 for a set bit),
+//       sum_k x_k * y_k = 4096 * (#differing - #equal) = 8192 * h - 2^20,
+// exact in the i32 accumulator of v_mfma_i32_32x32x32_i8.  One extra K slice carries the train index
+// (1 * (j & 63) + 64 * (j >> 6)), so the accumulator leaves the matrix pipe already as the packed key
+// 8192 * h + j - 2^20 whose signed order is the (distance, train index) order knnMatch uses.  The VALU work
+// per (query, train) pair drops from 16 + ~2 ops (K1) to 2: v_med3_i32 + v_min_i32.
+//
+// Mapping (wave64, 32x32 tiles):
+//   * MFMA "A" operand = 32 TRAIN rows, expanded from bits to i8 once per workgroup into LDS (double-buffered,
+//     one barrier per tile) and read back as ready-made fragments (one contiguous ds_read_b128 per K step);
+//   * MFMA "B" operand = 32 QUERY rows per block, expanded once and kept in VGPRs for the whole scan
+//     (QB blocks per wave -> every train fragment read from LDS feeds QB matrix instructions);
+//   * D[train][query]: a lane owns ONE query column and 16 train rows of the tile, so the running (best, second)
+//     of a query is two VGPRs per lane and the final cross-lane merge is a single swap of the wave halves.
+//   * bit -> K element mapping: K step kk covers descriptor word kk; wave half hf, dword d, byte p holds bit
+//     (4 hf + d) + 8 p of that word.  Any mapping works as long as both operands use the same one (a sum over k).
+//     This one costs a shift + v_and_or_b32 per four elements: ((w << (7 - s)) & 0x80808080) | 0x40404040.
+#include "kernels.h"
+
+namespace stvo {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+constexpr int MF_BLOCK = 256;        // 4 waves
+constexpr int MF_TILE = 32;          // train rows per tile
+constexpr int MF_KEY_SHIFT = 13;     // key = (h << 13) + j - MF_KEY_BIAS, j < 8192
+constexpr int MF_KEY_BIAS = 1 << 20;
+constexpr int MF_NO_KEY = 0x7FFFFFFF;
+
+// four K elements (bytes) from bits s, s+8, s+16, s+24 of w: byte = 0x40 | bit << 7  (+64 clear, -64 set)
+template <int S>
+__device__ __forceinline__ int expand4(uint32_t w) {
+    const uint32_t sh = S == 7 ? w : (w << (7 - S));
+    return (int)((sh & 0x80808080u) | 0x40404040u);
+}
+__device__ __forceinline__ v4i expand_half(uint32_t w, int hf) {
+    v4i r;
+    if (hf == 0) {
+        r.x = expand4<0>(w); r.y = expand4<1>(w); r.z = expand4<2>(w); r.w = expand4<3>(w);
+    } else {
+        r.x = expand4<4>(w); r.y = expand4<5>(w); r.z = expand4<6>(w); r.w = expand4<7>(w);
+    }
+    return r;
+}
+__device__ __forceinline__ int med3_i32(int a, int b, int c) {
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ uint32_t key_to_knn(int key) {  // -> K1's (distance << 16) | train index
+    if (key == MF_NO_KEY) return 0xFFFFFFFFu;
+    const uint32_t u = (uint32_t)(key + MF_KEY_BIAS);
+    return ((u >> MF_KEY_SHIFT) << 16) | (u & ((1u << MF_KEY_SHIFT) - 1u));
+}
+
+template <int QB>
+__global__ __launch_bounds__(MF_BLOCK) void hamming_knn2_mfma_kernel(int B, int tiles, int ndir, int dir0, int nseg, int row_stride,
+                                                                      const uint8_t* __restrict__ d1,
+                                                                      const int32_t* __restrict__ n1,
+                                                                      const uint8_t* __restrict__ d2,
+                                                                      const int32_t* __restrict__ n2,
+                                                                      uint2* __restrict__ knn12, uint2* __restrict__ knn21,
+                                                                      const int32_t* __restrict__ qsel,
+                                                                      const int32_t* __restrict__ nsel,
+                                                                      uint32_t* __restrict__ claim_init) {
+    constexpr int ROWS = 4 * QB * 32;  // query rows per workgroup
+    __shared__ v4i s_tile[2][16 * 32]; // [buffer][(kk * 2 + hf) * 32 + train row] = one 16-byte fragment
+    // XCD-aware block -> (frame pair, direction, tile, segment) mapping: as hamming_knn2_kernel
+    const int per_frame = tiles * ndir * nseg;
+    const int L = blockIdx.x;
+    const int xcd = L & 7, k = L >> 3;
+    const int b = (k / per_frame) * 8 + xcd;
+    if (b >= B) return;
+    const int local = k % per_frame;
+    const int seg = local % nseg;
+    const int dir = dir0 + (local / nseg) / tiles;
+    const int tile = (local / nseg) % tiles;
+    const int na = n1[b], nb = n2[b];
+    const int nq = qsel ? nsel[b] : (dir == 0 ? na : nb);
+    const int nt_all = dir == 0 ? nb : na;
+    const int seg_len = (((nt_all + nseg - 1) / nseg) + MF_TILE - 1) & ~(MF_TILE - 1);
+    const int j0 = min(seg * seg_len, nt_all);
+    const int nt = min(j0 + seg_len, nt_all);
+    const int q_base = tile * ROWS;
+    const size_t frame_off = (size_t)b * row_stride;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, col = lane & 31, hf = lane >> 5;
+    if (claim_init && seg == 0 && dir == dir0)
+        for (int c = q_base + tid; c < min(q_base + ROWS, row_stride); c += MF_BLOCK) claim_init[frame_off + c] = 0xFFFFFFFFu;
+    if (q_base >= nq) return;  // workgroup-uniform
+    const uint32_t* __restrict__ Q = reinterpret_cast<const uint32_t*>((dir == 0 ? d1 : d2) + frame_off * STVO_DESC_BYTES);
+    const uint32_t* __restrict__ T = reinterpret_cast<const uint32_t*>((dir == 0 ? d2 : d1) + frame_off * STVO_DESC_BYTES);
+    uint2* __restrict__ out = (dir == 0 ? knn12 : knn21) + (size_t)seg * B * row_stride + frame_off;
+
+    // query fragments: block qb of this wave = rows q_base + (wv * QB + qb) * 32 + col, kept for the whole scan
+    const bool wave_active = q_base + wv * QB * 32 < nq;
+    v4i qf[QB][8];
+    int qi[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int q = q_base + (wv * QB + qb) * 32 + col;
+        const int qc = q < nq ? q : nq - 1;  // tail lanes scan a valid row and discard the result
+        qi[qb] = qsel ? qsel[frame_off + qc] : qc;
+        const uint4 w0 = reinterpret_cast<const uint4*>(Q)[2 * qi[qb]];
+        const uint4 w1 = reinterpret_cast<const uint4*>(Q)[2 * qi[qb] + 1];
+        const uint32_t w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) qf[qb][kk] = expand_half(~w[kk], hf);
+    }
+    // index slice, query side: K elements 0 and 1 of the ninth step are 1 and 64
+    v4i qf_idx = {0, 0, 0, 0};
+    if (hf == 0) qf_idx.x = 1 | (64 << 8);
+
+    int best[QB], second[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) best[qb] = second[qb] = MF_NO_KEY;
+
+    // staging role of this thread: word xk of train row xr of the tile
+    const int xr = tid & 31, xk = tid >> 5;
+    const int ntiles = (nt - j0 + MF_TILE - 1) / MF_TILE;
+    auto fetch = [&](int t) -> uint32_t {
+        const int j = j0 + t * MF_TILE + xr;
+        return j < nt ? T[(size_t)j * 8 + xk] : 0u;
+    };
+    auto stage = [&](int buf, uint32_t w) {
+        s_tile[buf][(xk * 2 + 0) * 32 + xr] = expand_half(w, 0);
+        s_tile[buf][(xk * 2 + 1) * 32 + xr] = expand_half(w, 1);
+    };
+    if (ntiles > 0) stage(0, fetch(0));
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        uint32_t w_next = 0;
+        if (t + 1 < ntiles) w_next = fetch(t + 1);
+        if (wave_active) {
+            v16i acc[QB];
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[qb][r] = 0;
+            const int jt = j0 + t * MF_TILE;
+            // index slice, train side: elements 0 and 1 of row `col` are (j & 63) and (j >> 6)
+            v4i tf_idx = {0, 0, 0, 0};
+            if (hf == 0) tf_idx.x = ((jt + col) & 63) | (((jt + col) >> 6) << 8);
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const v4i tf = s_tile[buf][kk * 64 + lane];
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) acc[qb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(tf, qf[qb][kk], acc[qb], 0, 0, 0);
+            }
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) acc[qb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(tf_idx, qf_idx, acc[qb], 0, 0, 0);
+            if (jt + MF_TILE <= nt) {
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = acc[qb][r];
+                        second[qb] = med3_i32(best[qb], second[qb], key);
+                        best[qb] = min(best[qb], key);
+                    }
+            } else {  // ragged last tile: rows past the segment end carry no key
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int jr = jt + (r & 3) + 8 * (r >> 2) + 4 * hf;
+                        const int key = jr < nt ? acc[qb][r] : MF_NO_KEY;
+                        second[qb] = med3_i32(best[qb], second[qb], key);
+                        best[qb] = min(best[qb], key);
+                    }
+            }
+        }
+        if (t + 1 < ntiles) stage(buf ^ 1, w_next);
+        __syncthreads();
+    }
+    if (!wave_active) return;
+    // the two wave halves hold the same query columns over different train rows: merge, lower half writes
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int ob = __shfl_xor(best[qb], 32), os = __shfl_xor(second[qb], 32);
+        const int hi = max(best[qb], ob);
+        const int sec = min(min(second[qb], os), hi);
+        const int bst = min(best[qb], ob);
+        const int q = q_base + (wv * QB + qb) * 32 + col;
+        if (hf == 0 && q < nq) out[qi[qb]] = make_uint2(key_to_knn(bst), key_to_knn(sec));
+    }
+}
+
+int mfma_rows_per_block(int qb) { return 4 * qb * 32; }
+
+void launch_hamming_knn2_mfma(hipStream_t s, int B, int row_stride, int max_n, const uint8_t* d1, const int32_t* n1,
+                              const uint8_t* d2, const int32_t* n2, uint2* knn12, uint2* knn21, int both_directions,
+                              int dir0, const int32_t* qsel, const int32_t* nsel, int nseg, uint32_t* claim_init, int qb) {
+    if (B <= 0 || max_n <= 0) return;
+    const int rows = mfma_rows_per_block(qb);
+    const int tiles = (max_n + rows - 1) / rows, ndir = both_directions ? 2 : 1;
+    const int groups = (B + 7) / 8;
+    dim3 grid((unsigned)(groups * 8 * tiles * ndir * nseg));
+#define STVO_MF_LAUNCH(QBV)                                                                                              \
+    hipLaunchKernelGGL(hamming_knn2_mfma_kernel<QBV>, grid, dim3(MF_BLOCK), 0, s, B, tiles, ndir, dir0, nseg, row_stride, \
+                       d1, n1, d2, n2, knn12, knn21, qsel, nsel, claim_init)
+    if (qb == 1) STVO_MF_LAUNCH(1);
+    else if (qb == 2) STVO_MF_LAUNCH(2);
+    else STVO_MF_LAUNCH(4);
+#undef STVO_MF_LAUNCH
+}
+
+}  // namespace stvo
