@@ -32,7 +32,9 @@ void launch_hamming_knn2(hipStream_t s, int B, int row_stride, int max_n, const 
 // wave (1, 2 or 4; a workgroup covers 128 * qb query rows).  Train indices must fit 13 bits (max_n <= 8192).
 void launch_hamming_knn2_mfma(hipStream_t s, int B, int row_stride, int max_n, const uint8_t* d1, const int32_t* n1,
                               const uint8_t* d2, const int32_t* n2, uint2* knn12, uint2* knn21, int both_directions,
-                              int dir0, const int32_t* qsel, const int32_t* nsel, int nseg, uint32_t* claim_init, int qb);
+                              int dir0, const int32_t* qsel, const int32_t* nsel, int nseg, uint32_t* claim_init, int qb,
+                              int lds_pad_bytes = 0);
+int knn_mfma_qb(int max_n);  // query blocks per wave of K1m for this problem size, 0 = VALU kernels
 // mutual matching with a lazy reverse pass: only the columns claimed by an accepted forward match are
 // examined, by a range query with early exit instead of a second top-2 scan (match_kernels.hip)
 struct LazyScratch {

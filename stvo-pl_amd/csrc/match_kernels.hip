@@ -161,12 +161,20 @@ __global__ __launch_bounds__(KNN_BLOCK) void hamming_knn2_kernel(int B, int tile
     if (q < nq) out[qi] = make_uint2(best, second);
 }
 
+// Query blocks per wave of the matrix-core scan (match_mfma.hip), 0 = use the VALU scan: train indices must fit the
+// 13 index bits of its keys.  STVO_KNN_MFMA=0 selects the VALU kernels (K1 + K1v) for comparison runs.
+int knn_mfma_qb(int max_n) {
+    static const int qb = [] { const char* e = getenv("STVO_KNN_MFMA"); return e ? atoi(e) : 2; }();
+    return max_n <= 8192 ? qb : 0;
+}
+
 void launch_hamming_knn2(hipStream_t s, int B, int row_stride, int max_n, const uint8_t* d1, const int32_t* n1,
                          const uint8_t* d2, const int32_t* n2, uint2* knn12, uint2* knn21, int both_directions,
                          int lds_pad_bytes, int dir0, const int32_t* qsel, const int32_t* nsel, int nseg, uint32_t* claim_init) {
     if (B <= 0 || max_n <= 0) return;
-    static const int mfma_qb = [] { const char* e = getenv("STVO_KNN_MFMA"); return e ? atoi(e) : 0; }();
-    if (mfma_qb > 0 && max_n <= 8192) {
+    const int mfma_qb = knn_mfma_qb(max_n);
+    if (mfma_qb > 0) {
+        // (lds_pad_bytes is not applied: co-residency with the pose kernel does not pay for this kernel)
         launch_hamming_knn2_mfma(s, B, row_stride, max_n, d1, n1, d2, n2, knn12, knn21, both_directions, dir0, qsel, nsel, nseg,
                                  claim_init, mfma_qb);
         return;
@@ -419,9 +427,38 @@ __global__ __launch_bounds__(256) void nnr_reverse_check_kernel(int row_stride, 
     m12[off + i] = m;
 }
 
+// The same decision from a reverse top-2 of the claimed columns (matrix-core path): matches_21[m] == i iff the column's
+// nearest row is i and its own ratio test holds (src/matching.cpp:53-58 applied to the 21 direction, :80-86).
+__global__ __launch_bounds__(256) void nnr_reverse_top2_kernel(int nseg, int row_stride, const int32_t* __restrict__ cand,
+                                                               const uint2* __restrict__ knn21,
+                                                               const int32_t* __restrict__ n1, float nnr,
+                                                               int32_t* __restrict__ m12) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= row_stride) return;
+    const size_t off = (size_t)b * row_stride;
+    int m = cand[off + i];
+    if (m >= 0) {
+        bool keep = false;
+        if (n1[b] >= 2) {
+            const uint2 r = merged_knn(knn21, (size_t)gridDim.y * row_stride, off + m, nseg);
+            const float r0 = (float)(r.x >> 16), r1 = (float)(r.y >> 16);
+            keep = (r0 < r1 * nnr) && ((int)(r.x & 0xFFFFu) == i);
+        }
+        if (!keep) m = -1;
+    }
+    m12[off + i] = m;
+}
+
 void launch_hamming_verify(hipStream_t s, int B, int row_stride, const uint8_t* d1, const int32_t* n1, const uint8_t* d2,
                            float nnr, const LazyScratch& w, int lds_pad_bytes, int nseg) {
     if (B <= 0 || row_stride <= 0) return;
+    const int mfma_qb = knn_mfma_qb(row_stride);
+    if (mfma_qb > 0) {  // reverse top-2 of the claimed columns only (gathered through qsel), on the matrix cores
+        launch_hamming_knn2_mfma(s, B, row_stride, row_stride, d1, n1, d2, /*n2 unused for dir 1 queries*/ n1, w.knn12, w.knn21, 0,
+                                 1, w.qsel, w.nsel, nseg, nullptr, mfma_qb);
+        return;
+    }
     const int tiles = (row_stride + KNN_BLOCK - 1) / KNN_BLOCK, groups = (B + 7) / 8;
     hipLaunchKernelGGL(hamming_verify_kernel, dim3((unsigned)(groups * 8 * tiles * nseg)), dim3(KNN_BLOCK),
                        (size_t)lds_pad_bytes, s, B, tiles, nseg, row_stride, d1, n1, d2,
@@ -446,7 +483,10 @@ void launch_match_mutual_lazy(hipStream_t s, int B, int row_stride, const uint8_
     launch_hamming_verify(s, B, row_stride, d1, n1, d2, nnr, w, lds_pad_bytes, nseg);
     if (tev) (void)hipEventRecord(tev[3], s);
     if (wait_before_m12_write) (void)hipStreamWaitEvent(s, wait_before_m12_write, 0);
-    hipLaunchKernelGGL(nnr_reverse_check_kernel, grid2, dim3(256), 0, s, row_stride, w.cand, claim, blocked, n1, m12);
+    if (knn_mfma_qb(row_stride) > 0)
+        hipLaunchKernelGGL(nnr_reverse_top2_kernel, grid2, dim3(256), 0, s, nseg, row_stride, w.cand, w.knn21, n1, nnr, m12);
+    else
+        hipLaunchKernelGGL(nnr_reverse_check_kernel, grid2, dim3(256), 0, s, row_stride, w.cand, claim, blocked, n1, m12);
 }
 
 // Integer-VALU roof probe: the same instruction mix as K1's inner loop (xor, bcnt-accumulate,

@@ -8,8 +8,8 @@
 // Why this is a matrix product and not a reshaping trick: the all-pairs Hamming distance of bit rows IS a Gram
 // matrix.  With bits mapped to x = +-64 (query: +64 for a set bit) and y = -+64 (train: -64 for a set bit),
 //       sum_k x_k * y_k = 4096 * (#differing - #equal) = 8192 * h - 2^20,
-// exact in the i32 accumulator of v_mfma_i32_32x32x32_i8.  One extra K slice carries the train index
-// (1 * (j & 63) + 64 * (j >> 6)), so the accumulator leaves the matrix pipe already as the packed key
+// exact in the i32 accumulator of v_mfma_i32_32x32x32_i8.  The C operand of a tile's first matrix instruction
+// carries the (tile-relative) train index, so the accumulator leaves the matrix pipe already as the packed key
 // 8192 * h + j - 2^20 whose signed order is the (distance, train index) order knnMatch uses.  The VALU work
 // per (query, train) pair drops from 16 + ~2 ops (K1) to 2: v_med3_i32 + v_min_i32.
 //
@@ -35,6 +35,7 @@ constexpr int MF_TILE = 32;          // train rows per tile
 constexpr int MF_KEY_SHIFT = 13;     // key = (h << 13) + j - MF_KEY_BIAS, j < 8192
 constexpr int MF_KEY_BIAS = 1 << 20;
 constexpr int MF_NO_KEY = 0x7FFFFFFF;
+constexpr int MF_NO_KEY_MIN = 0x40000000;  // the sentinel after any number of per-tile rebasings (<= 256 x 32)
 
 // four K elements (bytes) from bits s, s+8, s+16, s+24 of w: byte = 0x40 | bit << 7  (+64 clear, -64 set)
 template <int S>
@@ -56,14 +57,15 @@ __device__ __forceinline__ int med3_i32(int a, int b, int c) {
     asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
-__device__ __forceinline__ uint32_t key_to_knn(int key) {  // -> K1's (distance << 16) | train index
-    if (key == MF_NO_KEY) return 0xFFFFFFFFu;
-    const uint32_t u = (uint32_t)(key + MF_KEY_BIAS);
+// tile-relative key -> K1's (distance << 16) | train index; base = first train row of the tile the key is relative to
+__device__ __forceinline__ uint32_t key_to_knn(int key, int base) {
+    if (key >= MF_NO_KEY_MIN) return 0xFFFFFFFFu;
+    const uint32_t u = (uint32_t)(key + base + MF_KEY_BIAS);
     return ((u >> MF_KEY_SHIFT) << 16) | (u & ((1u << MF_KEY_SHIFT) - 1u));
 }
 
 template <int QB>
-__global__ __launch_bounds__(MF_BLOCK) void hamming_knn2_mfma_kernel(int B, int tiles, int ndir, int dir0, int nseg, int row_stride,
+__global__ __launch_bounds__(MF_BLOCK, (QB == 1 ? 4 : QB == 2 ? 3 : 1)) void hamming_knn2_mfma_kernel(int B, int tiles, int ndir, int dir0, int nseg, int row_stride,
                                                                       const uint8_t* __restrict__ d1,
                                                                       const int32_t* __restrict__ n1,
                                                                       const uint8_t* __restrict__ d2,
@@ -103,21 +105,27 @@ __global__ __launch_bounds__(MF_BLOCK) void hamming_knn2_mfma_kernel(int B, int 
     // query fragments: block qb of this wave = rows q_base + (wv * QB + qb) * 32 + col, kept for the whole scan
     const bool wave_active = q_base + wv * QB * 32 < nq;
     v4i qf[QB][8];
-    int qi[QB];
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
+    auto query_row = [&](int qb) {  // recomputed for the final store rather than kept live across the scan
         const int q = q_base + (wv * QB + qb) * 32 + col;
         const int qc = q < nq ? q : nq - 1;  // tail lanes scan a valid row and discard the result
-        qi[qb] = qsel ? qsel[frame_off + qc] : qc;
-        const uint4 w0 = reinterpret_cast<const uint4*>(Q)[2 * qi[qb]];
-        const uint4 w1 = reinterpret_cast<const uint4*>(Q)[2 * qi[qb] + 1];
+        return qsel ? qsel[frame_off + qc] : qc;
+    };
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int qi = query_row(qb);
+        const uint4 w0 = reinterpret_cast<const uint4*>(Q)[2 * qi];
+        const uint4 w1 = reinterpret_cast<const uint4*>(Q)[2 * qi + 1];
         const uint32_t w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) qf[qb][kk] = expand_half(~w[kk], hf);
     }
-    // index slice, query side: K elements 0 and 1 of the ninth step are 1 and 64
-    v4i qf_idx = {0, 0, 0, 0};
-    if (hf == 0) qf_idx.x = 1 | (64 << 8);
+    // The train index enters through the C operand of the first matrix instruction of a tile: accumulator register r of
+    // this lane belongs to tile row (r & 3) + 8 (r >> 2) + 4 hf.  Keys are therefore TILE-RELATIVE (index - first row of
+    // the tile) and the running (best, second) are rebased by -32 per tile: 2 VALU ops per tile and query block instead
+    // of a ninth matrix instruction per block.
+    v16i cidx;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cidx[r] = (r & 3) + 8 * (r >> 2) + 4 * hf;
 
     int best[QB], second[QB];
 #pragma unroll
@@ -136,51 +144,73 @@ __global__ __launch_bounds__(MF_BLOCK) void hamming_knn2_mfma_kernel(int B, int 
     };
     if (ntiles > 0) stage(0, fetch(0));
     __syncthreads();
-    for (int t = 0; t < ntiles; ++t) {
+    // Software pipeline, depth one tile: step t issues the matrix instructions of tile t and, in their shadow, folds the
+    // accumulators of tile t - 1 into (best, second) — a v_mfma occupies the matrix pipe for 8 passes while the wave's
+    // VALU slots stay free.  Only the last tile of a segment can be ragged and it is folded after the loop (masked).
+    auto rebase = [&]() {  // (best, second) relative to the next tile; the no-key sentinel stays far above any key
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            best[qb] -= MF_TILE;
+            second[qb] -= MF_TILE;
+        }
+    };
+    auto fold = [&](int qb, int key) {
+        second[qb] = med3_i32(best[qb], second[qb], key);
+        best[qb] = min(best[qb], key);
+    };
+    auto step = [&](v16i (&cur)[QB], const v16i (&prev)[QB], int t) {
         const int buf = t & 1;
         uint32_t w_next = 0;
         if (t + 1 < ntiles) w_next = fetch(t + 1);
         if (wave_active) {
-            v16i acc[QB];
-#pragma unroll
-            for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[qb][r] = 0;
-            const int jt = j0 + t * MF_TILE;
-            // index slice, train side: elements 0 and 1 of row `col` are (j & 63) and (j >> 6)
-            v4i tf_idx = {0, 0, 0, 0};
-            if (hf == 0) tf_idx.x = ((jt + col) & 63) | (((jt + col) >> 6) << 8);
+            const bool fold_prev = t > 0;  // tile t - 1 is a full tile here
+            if (fold_prev) rebase();
+            v4i tf = s_tile[buf][lane];
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk) {
-                const v4i tf = s_tile[buf][kk * 64 + lane];
-#pragma unroll
-                for (int qb = 0; qb < QB; ++qb) acc[qb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(tf, qf[qb][kk], acc[qb], 0, 0, 0);
-            }
-#pragma unroll
-            for (int qb = 0; qb < QB; ++qb) acc[qb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(tf_idx, qf_idx, acc[qb], 0, 0, 0);
-            if (jt + MF_TILE <= nt) {
+                v4i tf_ahead = tf;
+                if (kk < 7) tf_ahead = s_tile[buf][(kk + 1) * 64 + lane];  // one K step ahead of its use
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb)
+                    cur[qb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(tf, qf[qb][kk], kk == 0 ? cidx : cur[qb], 0, 0, 0);
+                if (fold_prev) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int key = acc[qb][r];
-                        second[qb] = med3_i32(best[qb], second[qb], key);
-                        best[qb] = min(best[qb], key);
+                    for (int qb = 0; qb < QB; ++qb) {
+                        fold(qb, prev[qb][2 * kk]);
+                        fold(qb, prev[qb][2 * kk + 1]);
                     }
-            } else {  // ragged last tile: rows past the segment end carry no key
-#pragma unroll
-                for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int jr = jt + (r & 3) + 8 * (r >> 2) + 4 * hf;
-                        const int key = jr < nt ? acc[qb][r] : MF_NO_KEY;
-                        second[qb] = med3_i32(best[qb], second[qb], key);
-                        best[qb] = min(best[qb], key);
-                    }
+                }
+                if (kk < 7) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 LDS read (the next step's fragment)
+                __builtin_amdgcn_sched_group_barrier(0x008, QB, 0);             // QB matrix instructions
+                __builtin_amdgcn_sched_group_barrier(0x002, 4 * QB, 0);         // their shadow: 4 * QB VALU ops
+                tf = tf_ahead;
             }
         }
         if (t + 1 < ntiles) stage(buf ^ 1, w_next);
         __syncthreads();
+    };
+    v16i accA[QB], accB[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accA[qb][r] = accB[qb][r] = 0;
+    int t = 0;
+    for (; t + 2 <= ntiles; t += 2) {
+        step(accA, accB, t);
+        step(accB, accA, t + 1);
+    }
+    if (t < ntiles) step(accA, accB, t);
+    if (wave_active && ntiles > 0) {  // drain: the last tile, rows past the segment end carry no key
+        const int jt = j0 + (ntiles - 1) * MF_TILE;
+        const v16i(&last)[QB] = (ntiles & 1) ? accA : accB;
+        rebase();
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int jr = jt + (r & 3) + 8 * (r >> 2) + 4 * hf;
+                fold(qb, jr < nt ? last[qb][r] : MF_NO_KEY);
+            }
     }
     if (!wave_active) return;
     // the two wave halves hold the same query columns over different train rows: merge, lower half writes
@@ -191,7 +221,8 @@ __global__ __launch_bounds__(MF_BLOCK) void hamming_knn2_mfma_kernel(int B, int 
         const int sec = min(min(second[qb], os), hi);
         const int bst = min(best[qb], ob);
         const int q = q_base + (wv * QB + qb) * 32 + col;
-        if (hf == 0 && q < nq) out[qi[qb]] = make_uint2(key_to_knn(bst), key_to_knn(sec));
+        const int base = j0 + (ntiles - 1) * MF_TILE;  // the frame of the last rebasing
+        if (hf == 0 && q < nq) out[query_row(qb)] = make_uint2(key_to_knn(bst, base), key_to_knn(sec, base));
     }
 }
 
@@ -199,14 +230,15 @@ int mfma_rows_per_block(int qb) { return 4 * qb * 32; }
 
 void launch_hamming_knn2_mfma(hipStream_t s, int B, int row_stride, int max_n, const uint8_t* d1, const int32_t* n1,
                               const uint8_t* d2, const int32_t* n2, uint2* knn12, uint2* knn21, int both_directions,
-                              int dir0, const int32_t* qsel, const int32_t* nsel, int nseg, uint32_t* claim_init, int qb) {
+                              int dir0, const int32_t* qsel, const int32_t* nsel, int nseg, uint32_t* claim_init, int qb,
+                              int lds_pad_bytes) {
     if (B <= 0 || max_n <= 0) return;
     const int rows = mfma_rows_per_block(qb);
     const int tiles = (max_n + rows - 1) / rows, ndir = both_directions ? 2 : 1;
     const int groups = (B + 7) / 8;
     dim3 grid((unsigned)(groups * 8 * tiles * ndir * nseg));
 #define STVO_MF_LAUNCH(QBV)                                                                                              \
-    hipLaunchKernelGGL(hamming_knn2_mfma_kernel<QBV>, grid, dim3(MF_BLOCK), 0, s, B, tiles, ndir, dir0, nseg, row_stride, \
+    hipLaunchKernelGGL(hamming_knn2_mfma_kernel<QBV>, grid, dim3(MF_BLOCK), (size_t)lds_pad_bytes, s, B, tiles, ndir, dir0, nseg, row_stride, \
                        d1, n1, d2, n2, knn12, knn21, qsel, nsel, claim_init)
     if (qb == 1) STVO_MF_LAUNCH(1);
     else if (qb == 2) STVO_MF_LAUNCH(2);
