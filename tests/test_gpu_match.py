@@ -128,3 +128,73 @@ def test_match_verify_shortcut_adversarial(hip, oracle):
             exp, en = oracle.match(a, b, nnr, 1)
             assert np.array_equal(got, exp), (nnr, np.nonzero(got != exp)[0][:10])
             assert n == en
+
+
+def test_match_matrix_core_key_edges(hip, oracle):
+    """K1m builds its packed (distance, index) keys inside the matrix-core accumulator, tile-relative and rebased per
+    32-row tile.  Exercise what that encoding could get wrong: distances 0 and 256, equal distances inside one tile and
+    across tiles (lowest train index wins), copies of one row on both sides of every tile edge, ragged last tiles."""
+    rng = np.random.default_rng(2024)
+    for n2 in (2, 31, 32, 33, 63, 64, 65, 95, 97, 129, 517):
+        d2 = rand_desc(rng, n2)
+        # the same train row planted on both sides of tile edges: equal distances, the lower index must be reported
+        for a, b in ((0, n2 - 1), (31, 32), (30, 33), (63, 64), (1, 96)):
+            if b < n2:
+                d2[b] = d2[a]
+        if n2 > 40:
+            d2[40] = 0x00    # all clear
+            d2[7] = 0xFF     # all set: distance 256 to row 40
+        q = [d2[j].copy() for j in range(0, n2, 3)]
+        q.append(np.zeros(32, np.uint8)); q.append(np.full(32, 0xFF, np.uint8))
+        q += list(synth.flip_bits(rng, d2[rng.integers(0, n2, 40)], 0.05))
+        d1 = np.stack(q)
+        for nnr in (0.75, 1.0):
+            for mutual in (1, 0):
+                for x, y in ((d1, d2), (d2, d1)):
+                    got, n = hip.match(x, y, nnr, mutual)
+                    exp, en = oracle.match(x, y, nnr, mutual)
+                    assert np.array_equal(got, exp), (n2, nnr, mutual, np.nonzero(got != exp)[0][:10])
+                    assert n == en
+
+
+def test_match_low_entropy_many_ties(hip, oracle):
+    """Descriptors with 6 random bits: almost every distance is shared by dozens of train rows, so the answer is
+    decided by the tie order alone (strict '<' over ascending train index, oracle/stvo_oracle.c orc_knn2)."""
+    rng = np.random.default_rng(99)
+    d1 = np.zeros((700, 32), np.uint8); d2 = np.zeros((900, 32), np.uint8)
+    d1[:, 5] = rng.integers(0, 64, 700); d2[:, 5] = rng.integers(0, 64, 900)
+    d1[:, 20] = rng.integers(0, 4, 700) << 3; d2[:, 20] = rng.integers(0, 4, 900) << 3
+    for mutual in (1, 0):
+        got, n = hip.match(d1, d2, 1.0, mutual)
+        exp, en = oracle.match(d1, d2, 1.0, mutual)
+        assert np.array_equal(got, exp) and n == en
+
+
+def test_match_beyond_matrix_core_index_range(oracle):
+    """More than 8192 rows per side do not fit the 13 index bits of K1m's keys: the context must take the VALU kernels
+    (K1 + K1v) and still agree with the oracle."""
+    from stvo_amd import capi
+    ctx = capi.Context(device_id=0, max_rows=8300, max_batch=1)
+    try:
+        rng = np.random.default_rng(8300)
+        d2 = rand_desc(rng, 8300)
+        d1 = rand_desc(rng, 8250)
+        d1[:3000] = synth.flip_bits(rng, d2[rng.permutation(8300)[:3000]], 0.06)
+        got, n = ctx.match(d1, d2, 0.75, 1)
+        exp, en = oracle.match(d1, d2, 0.75, 1)
+        assert np.array_equal(got, exp) and n == en
+    finally:
+        ctx.close()
+
+
+def test_match_valu_kernels_still_agree():
+    """The VALU matcher (K1 + K1v, STVO_KNN_MFMA=0) is kept for sizes K1m cannot index and as the comparison point of
+    the profiles: run this file's parity cases against it in a child process (the switch is read once per process)."""
+    import os, subprocess, sys
+    if os.environ.get("STVO_KNN_MFMA") == "0":
+        pytest.skip("already the child run")
+    env = dict(os.environ, STVO_KNN_MFMA="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q",
+                        "-k", "bit_exact or adversarial or key_edges or many_ties"], env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
