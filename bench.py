@@ -30,7 +30,15 @@ K1_LANE_OPS_PER_PAIR = 19
 VALU_PEAK_LANE_OPS = K1_LANE_OPS_PER_PAIR / (8 / 78.6e12 + 11 / 39.3e12)  # = 49.8e12
 
 
-def committed_traffic(kernel="hamming_knn2_kernel", path=os.path.join(ROOT, "profiles", "r01_e_hbm_counters.txt")):
+# K1m (the default matcher) takes the 256-bit distances from the matrix cores: 2 x 256 int8 multiply-accumulate ops per
+# (query, train) pair.  Dense int8 peak = 2x the bf16 dense peak (MI355X_MICROARCH.md: bf16 ~2.5 PF dense, "i8 ~2x bf16
+# rate (2xK)"; the guide's own micro-benchmark floor for v_mfma_i32_32x32x32_i8 is 4404 TOP/s).
+I8_MFMA_PEAK_TOPS = 5000.0
+I8_MFMA_MEASURED_FLOOR_TOPS = 4404.0
+K1M_OPS_PER_PAIR = 2 * 256
+
+
+def committed_traffic(kernel="hamming_knn2_kernel", path=os.path.join(ROOT, "profiles", "r01_f_hbm_counters.txt")):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, separate
     `--pmc` runs summarised by tools/rocprof_summary.py; values there are KB per dispatch).  None if unavailable."""
     try:
@@ -211,10 +219,12 @@ def main():
         achieved_gbs = alg_bytes / (k1_ms * 1e-3) / 1e9
         lane_ops = pairs * K1_LANE_OPS_PER_PAIR
         valu_meas = ctx.valu_peak()
+        mfma = os.environ.get("STVO_KNN_MFMA", "2") != "0" and max_pts <= 8192   # the library's own rule (knn_mfma_qb)
+        k1_name = "hamming_knn2_mfma_kernel<2, false>" if mfma else "hamming_knn2_kernel"
         out = {
             "metric": "stereo frames/s (match+optimizePose)", "value": frames_total / dt, "unit": "frame-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8+f64",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i8+f64",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: synthetic 1241x376 stereo, 2000 ORB key-points/frame, "
                                    "brute-force mutual-NNR point match + optimizePose (config_kitti.yaml), "
@@ -222,22 +232,42 @@ def main():
                        "frame_pairs_per_step_per_gpu": B, "keypoints_per_frame": n, "parallelism": f"seq-shard x{world}",
                        "committed_pose_fraction": ok_frac,
                        "pose_overlaps_next_match": not args.no_overlap},
-            "roofline": {"kernel": "hamming_knn2_kernel", "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": committed_traffic(),
-                         "traffic_source": "bytes per launch = FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes, read from "
-                                           "the committed profiles/r01_e_hbm_counters.txt (not re-measured by this run)",
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k1_ms, "timing": "hipEvent pairs around each launch, on the launch stream, over a second pass of the same K steps",
-                         "note": "K1 is integer-VALU bound (~530 lane-ops per compulsory byte); see valu_roofline. One launch per step"},
-            "valu_roofline": {"kernel": "hamming_knn2_kernel", "lane_ops_per_launch": lane_ops,
-                              "achieved": lane_ops / (k1_ms * 1e-3) / 1e12, "peak": VALU_PEAK_LANE_OPS / 1e12,
-                              "unit": "T lane-ops/s", "frac": lane_ops / (k1_ms * 1e-3) / VALU_PEAK_LANE_OPS,
-                              "measured_peak_same_mix": valu_meas / 1e12,
-                              "frac_of_measured_peak": lane_ops / (k1_ms * 1e-3) / valu_meas},
+            "roofline": None, "hbm_view": None, "valu_roofline": None,
             "stage_ms": {"hamming_knn2": k1_ms, "hamming_verify": verify_ms, "hamming_knn2_calls_timed": k1_calls,
                          "hamming_knn2_launches_per_step": 1, "hamming_knn2_solo": k1_solo_ms,
                          "hamming_verify_solo": verify_solo_ms, "pose_solo": pose_ms,
                          "verified_column_fraction": float(nsel.sum()) / float(n2v.sum())},
         }
+        traffic = committed_traffic(k1_name)
+        traffic_src = ("bytes per launch = FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes, read from the committed "
+                       "profiles/r01_f_hbm_counters.txt (not re-measured by this run)")
+        timing = "hipEvent pairs around each launch, on the launch stream, over a second pass of the same K steps"
+        hbm_view = {"kernel": k1_name, "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                    "algorithmic_bytes_per_launch": alg_bytes,
+                    "note": "brute-force matching does ~56 k distance bit-operations per compulsory byte: HBM is idle by construction"}
+        if mfma:
+            ops = pairs * K1M_OPS_PER_PAIR
+            achieved_tops = ops / (k1_ms * 1e-3) / 1e12
+            out["roofline"] = {"kernel": k1_name, "bound": "mfma", "achieved": achieved_tops, "peak": I8_MFMA_PEAK_TOPS,
+                               "unit": "TFLOP/s", "unit_note": "int8 multiply-accumulate ops (TOP/s); 2 x 256 per distance",
+                               "frac": achieved_tops / I8_MFMA_PEAK_TOPS, "traffic": traffic, "traffic_source": traffic_src,
+                               "algorithmic_ops_per_launch": ops, "algorithmic_bytes_per_launch": alg_bytes,
+                               "avg_launch_ms": k1_ms, "avg_launch_ms_solo": k1_solo_ms, "timing": timing,
+                               "frac_of_measured_mfma_floor": achieved_tops / I8_MFMA_MEASURED_FLOOR_TOPS,
+                               "note": "K1m: all-pairs Hamming distance as an int8 Gram matrix on the matrix cores, top-2 fold "
+                                       "(2 VALU ops per pair) in the shadow of the matrix instructions; one launch per step"}
+            out["hbm_view"] = hbm_view
+            del out["valu_roofline"]
+        else:
+            out["roofline"] = dict(hbm_view, bound="hbm", avg_launch_ms=k1_ms, timing=timing,
+                                   note="K1 is integer-VALU bound (~530 lane-ops per compulsory byte); see valu_roofline")
+            out["valu_roofline"] = {"kernel": k1_name, "lane_ops_per_launch": lane_ops,
+                                    "achieved": lane_ops / (k1_ms * 1e-3) / 1e12, "peak": VALU_PEAK_LANE_OPS / 1e12,
+                                    "unit": "T lane-ops/s", "frac": lane_ops / (k1_ms * 1e-3) / VALU_PEAK_LANE_OPS,
+                                    "measured_peak_same_mix": valu_meas / 1e12,
+                                    "frac_of_measured_peak": lane_ops / (k1_ms * 1e-3) / valu_meas}
+            del out["hbm_view"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames, prm)
             out.update(cpu_baseline_variants(frames, prm))

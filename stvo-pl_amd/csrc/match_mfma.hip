@@ -64,7 +64,9 @@ __device__ __forceinline__ uint32_t key_to_knn(int key, int base) {
     return ((u >> MF_KEY_SHIFT) << 16) | (u & ((1u << MF_KEY_SHIFT) - 1u));
 }
 
-template <int QB>
+// GATHER: the query rows are the ones listed in qsel (the reverse check of the claimed columns); a separate instantiation
+// so that the two uses show up under different names in kernel traces.
+template <int QB, bool GATHER>
 __global__ __launch_bounds__(MF_BLOCK, (QB == 1 ? 4 : QB == 2 ? 3 : 1)) void hamming_knn2_mfma_kernel(int B, int tiles, int ndir, int dir0, int nseg, int row_stride,
                                                                       const uint8_t* __restrict__ d1,
                                                                       const int32_t* __restrict__ n1,
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(MF_BLOCK, (QB == 1 ? 4 : QB == 2 ? 3 : 1)) void ham
     const int dir = dir0 + (local / nseg) / tiles;
     const int tile = (local / nseg) % tiles;
     const int na = n1[b], nb = n2[b];
-    const int nq = qsel ? nsel[b] : (dir == 0 ? na : nb);
+    const int nq = GATHER ? nsel[b] : (dir == 0 ? na : nb);
     const int nt_all = dir == 0 ? nb : na;
     const int seg_len = (((nt_all + nseg - 1) / nseg) + MF_TILE - 1) & ~(MF_TILE - 1);
     const int j0 = min(seg * seg_len, nt_all);
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(MF_BLOCK, (QB == 1 ? 4 : QB == 2 ? 3 : 1)) void ham
     auto query_row = [&](int qb) {  // recomputed for the final store rather than kept live across the scan
         const int q = q_base + (wv * QB + qb) * 32 + col;
         const int qc = q < nq ? q : nq - 1;  // tail lanes scan a valid row and discard the result
-        return qsel ? qsel[frame_off + qc] : qc;
+        return GATHER ? qsel[frame_off + qc] : qc;
     };
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
@@ -237,12 +239,18 @@ void launch_hamming_knn2_mfma(hipStream_t s, int B, int row_stride, int max_n, c
     const int tiles = (max_n + rows - 1) / rows, ndir = both_directions ? 2 : 1;
     const int groups = (B + 7) / 8;
     dim3 grid((unsigned)(groups * 8 * tiles * ndir * nseg));
-#define STVO_MF_LAUNCH(QBV)                                                                                              \
-    hipLaunchKernelGGL(hamming_knn2_mfma_kernel<QBV>, grid, dim3(MF_BLOCK), (size_t)lds_pad_bytes, s, B, tiles, ndir, dir0, nseg, row_stride, \
-                       d1, n1, d2, n2, knn12, knn21, qsel, nsel, claim_init)
-    if (qb == 1) STVO_MF_LAUNCH(1);
-    else if (qb == 2) STVO_MF_LAUNCH(2);
-    else STVO_MF_LAUNCH(4);
+#define STVO_MF_LAUNCH(QBV, G)                                                                                              \
+    hipLaunchKernelGGL((hamming_knn2_mfma_kernel<QBV, G>), grid, dim3(MF_BLOCK), (size_t)lds_pad_bytes, s, B, tiles, ndir, dir0, \
+                       nseg, row_stride, d1, n1, d2, n2, knn12, knn21, qsel, nsel, claim_init)
+    if (qsel) {
+        if (qb == 1) STVO_MF_LAUNCH(1, true);
+        else if (qb == 2) STVO_MF_LAUNCH(2, true);
+        else STVO_MF_LAUNCH(4, true);
+    } else {
+        if (qb == 1) STVO_MF_LAUNCH(1, false);
+        else if (qb == 2) STVO_MF_LAUNCH(2, false);
+        else STVO_MF_LAUNCH(4, false);
+    }
 #undef STVO_MF_LAUNCH
 }
 
