@@ -199,6 +199,11 @@ int stvo_ctx_get_kernel_timing(stvo_ctx* ctx, float* avg_ms_forward, float* avg_
 /* Number of right-hand (curr) rows the LAST batched mutual match had to verify, per frame pair (only columns
  * claimed by some row's accepted forward match are examined). */
 int stvo_last_reverse_counts(stvo_ctx* ctx, int B, int32_t* counts);
+/* The plan of the LAST mutual match's reverse check on the matrix cores (B = the batch size of that call; 1 for
+ * stvo_match_nnr_mutual), plan = [5][B]: claimed columns; LIGHT columns (verified against the few rows whose second-best
+ * forward distance is within the cut); HEAVY columns (verified against every row); |S| = number of such rows; the cut tau
+ * (-1: every column heavy).  Diagnostics for tests and bench.py; meaningless after a match that took the VALU kernels. */
+int stvo_last_reverse_plan(stvo_ctx* ctx, int B, int32_t* plan);
 
 /* Integer-VALU micro-benchmark (xor + popcount-accumulate chains, no memory traffic): measured
  * 32-bit lane-ops/s of this device, the empirical roof K1 is priced against. */

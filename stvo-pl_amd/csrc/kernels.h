@@ -33,7 +33,7 @@ void launch_hamming_knn2(hipStream_t s, int B, int row_stride, int max_n, const 
 void launch_hamming_knn2_mfma(hipStream_t s, int B, int row_stride, int max_n, const uint8_t* d1, const int32_t* n1,
                               const uint8_t* d2, const int32_t* n2, uint2* knn12, uint2* knn21, int both_directions,
                               int dir0, const int32_t* qsel, const int32_t* nsel, int nseg, uint32_t* claim_init, int qb,
-                              int lds_pad_bytes = 0);
+                              int qsel_from_back = 0, const int32_t* tsel = nullptr, const int32_t* ntsel = nullptr);
 int knn_mfma_qb(int max_n);  // query blocks per wave of K1m for this problem size, 0 = VALU kernels
 // mutual matching with a lazy reverse pass: only the columns claimed by an accepted forward match are
 // examined, by a range query with early exit instead of a second top-2 scan (match_kernels.hip)
@@ -43,7 +43,7 @@ struct LazyScratch {
     int32_t* cand;  // [B][row_stride] forward ratio-tested best
     int32_t* need;  // [B][row_stride] per-column claim (d0 << 16 | claimant), 0xFFFFFFFF = unclaimed
     int32_t* qsel;  // [B][row_stride] compacted flagged columns
-    int32_t* nsel;  // [B]
+    int32_t* nsel;  // [5][B]: claimed columns; light, heavy, |S|, tau of the matrix-core reverse check (reverse_plan_kernel)
     size_t knn_capacity;  // elements of knn12 / knn21
 };
 void launch_match_mutual_lazy(hipStream_t s, int B, int row_stride, const uint8_t* d1, const int32_t* n1,

@@ -244,7 +244,7 @@ void launch_nnr_mutual(hipStream_t s, int B, int row_stride, const uint2* knn12,
 // the wave-uniform short cut: 4 x (v_xor + v_bcnt) + one compare instead of 8 x (v_xor + v_bcnt) + the top-2
 // update.  Exactness does not depend on the data: whenever any lane's lower bound is within its T (its own
 // claimant excepted) the wave finishes the row at full length.
-__global__ __launch_bounds__(256) void nnr_forward_kernel(int nseg, int row_stride, const uint2* __restrict__ knn12,
+__global__ __launch_bounds__(256) void nnr_forward_kernel(int nseg, int row_stride, uint2* __restrict__ knn12,
                                                           const int32_t* __restrict__ n1, const int32_t* __restrict__ n2,
                                                           float nnr, int32_t* __restrict__ cand,
                                                           uint32_t* __restrict__ claim /* preset to 0xFFFFFFFF by K1 */) {
@@ -256,6 +256,7 @@ __global__ __launch_bounds__(256) void nnr_forward_kernel(int nseg, int row_stri
     int m = -1;
     if (i < na && nb >= 2) {
         const uint2 k = merged_knn(knn12, (size_t)gridDim.y * row_stride, off + i, nseg);
+        if (nseg > 1) knn12[off + i] = k;  // segment 0 now holds the row's merged top-2 (read again by reverse_plan_kernel)
         const float f0 = (float)(k.x >> 16), f1 = (float)(k.y >> 16);
         if (f0 < f1 * nnr) {
             m = (int)(k.x & 0xFFFFu);
@@ -427,36 +428,170 @@ __global__ __launch_bounds__(256) void nnr_reverse_check_kernel(int row_stride, 
     m12[off + i] = m;
 }
 
-// The same decision from a reverse top-2 of the claimed columns (matrix-core path): matches_21[m] == i iff the column's
-// nearest row is i and its own ratio test holds (src/matching.cpp:53-58 applied to the 21 direction, :80-86).
-__global__ __launch_bounds__(256) void nnr_reverse_top2_kernel(int nseg, int row_stride, const int32_t* __restrict__ cand,
-                                                               const uint2* __restrict__ knn21,
-                                                               const int32_t* __restrict__ n1, float nnr,
-                                                               int32_t* __restrict__ m12) {
-    const int b = blockIdx.y;
+// ---- reverse check on the matrix cores: which (column, row) pairs still have to be looked at ------------------
+// Row i* holds the claim on column j with d0 = D(i*, j); the match survives iff no other row i' has D(i', j) <= T_j,
+// T_j = block_threshold(d0) (see the derivation above).  Let (b, s) be the forward top-2 of such a row i' (already
+// computed by the forward scan).  Either j is one of its two entries — then D(i', j) is KNOWN and the row can be judged
+// from knn12 alone — or j is not, and then both entries sort before (D(i', j), j), so  second_distance(i') <= D(i', j) <= T_j.
+// Hence the only rows whose distance to column j must be evaluated are  S_j = { i' : second_distance(i') <= T_j }.
+// For descriptors that discriminate at all S_j is tiny (a second-best distance is that of an unrelated row, T_j that of
+// a good match), and the |claimed| x N1 reverse scan collapses to |claimed| x |S|.  Exactness never depends on that:
+// a per-frame cut tau splits the claimed columns into LIGHT (T_j <= tau: scanned against S = { second <= tau }, a
+// superset of every S_j) and HEAVY (T_j > tau: scanned against all rows); tau minimises the number of distance
+// evaluations (C - L(tau)) * N1 + L(tau) * |S(tau)| from two 257-bin histograms, tau = -1 being "everything heavy".
+__device__ __forceinline__ uint32_t block_threshold(uint32_t d0, float nnr) {
+    const float f0 = (float)d0;
+    uint32_t thr = d0;
+    while (thr < 256u && !(f0 < (float)(thr + 1u) * nnr)) ++thr;  // largest distance that still blocks
+    return thr;
+}
+
+// one workgroup per frame pair.  knn12 = merged forward top-2 (segment 0 after nnr_forward_kernel).
+// out: blocked[j] (verdicts that need no distance evaluation), qsel (LIGHT columns from the front, HEAVY from the back
+// of the frame's slot), tsel (the rows of S), nsel[0][b] = claimed columns, [1] = light, [2] = heavy, [3] = |S|, [4] = tau.
+__global__ __launch_bounds__(256) void reverse_plan_kernel(int B, int row_stride, const uint2* __restrict__ knn12,
+                                                           const uint32_t* __restrict__ claim,
+                                                           const int32_t* __restrict__ n1, const int32_t* __restrict__ n2,
+                                                           float nnr, int32_t* __restrict__ blocked,
+                                                           int32_t* __restrict__ qsel, int32_t* __restrict__ tsel,
+                                                           int32_t* __restrict__ nsel) {
+    __shared__ int hT[257], hS[257], s_cnt[3];
+    __shared__ unsigned long long s_best;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const size_t off = (size_t)b * row_stride;
+    const int na = n1[b], nb = n2[b];
+    for (int t = tid; t < 257; t += 256) hT[t] = hS[t] = 0;
+    if (tid < 3) s_cnt[tid] = 0;
+    if (tid == 0) s_best = ~0ull;
+    for (int j = tid; j < row_stride; j += 256) blocked[off + j] = 0;
+    __syncthreads();
+    const bool active = nb >= 2 && na >= 1;
+    if (active) {
+        for (int i = tid; i < na; i += 256) {
+            const uint2 k = knn12[off + i];
+            const uint32_t key[2] = {k.x, k.y};
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                if (key[e] == 0xFFFFFFFFu) continue;
+                const uint32_t j = key[e] & 0xFFFFu, c = claim[off + j];
+                if (c != 0xFFFFFFFFu && (c & 0xFFFFu) != (uint32_t)i && (key[e] >> 16) <= block_threshold(c >> 16, nnr))
+                    blocked[off + j] = 1;  // benign race: every writer stores 1
+            }
+            if (k.y != 0xFFFFFFFFu) atomicAdd(&hS[min(k.y >> 16, 256u)], 1);
+        }
+        for (int j = tid; j < nb; j += 256) {
+            const uint32_t c = claim[off + j];
+            if (c != 0xFFFFFFFFu) atomicAdd(&hT[block_threshold(c >> 16, nnr)], 1);
+        }
+    }
+    __syncthreads();
+    {   // candidate cut tau = tid - 1 (thresholds above 254 are always heavy: they would need S = every row)
+        int cT = 0, cS = 0, C = 0;
+        for (int t = 0; t < 257; ++t) {
+            C += hT[t];
+            if (t < tid) {
+                cT += hT[t];
+                cS += hS[t];
+            }
+        }
+        const unsigned long long cost = (unsigned long long)(C - cT) * (unsigned)na + (unsigned long long)cT * (unsigned)cS;
+        atomicMin(&s_best, (cost << 9) | (unsigned)tid);
+    }
+    __syncthreads();
+    const int tau = (int)(s_best & 511ull) - 1;
+    if (active) {
+        for (int j = tid; j < nb; j += 256) {
+            const uint32_t c = claim[off + j];
+            if (c == 0xFFFFFFFFu) continue;
+            if ((int)block_threshold(c >> 16, nnr) <= tau)
+                qsel[off + atomicAdd(&s_cnt[0], 1)] = j;
+            else
+                qsel[off + row_stride - 1 - atomicAdd(&s_cnt[1], 1)] = j;
+        }
+        for (int i = tid; i < na; i += 256) {
+            const uint2 k = knn12[off + i];
+            if (k.y != 0xFFFFFFFFu && (int)(k.y >> 16) <= tau) tsel[off + atomicAdd(&s_cnt[2], 1)] = i;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        nsel[b] = s_cnt[0] + s_cnt[1];
+        nsel[(size_t)B + b] = s_cnt[0];
+        nsel[2 * (size_t)B + b] = s_cnt[1];
+        nsel[3 * (size_t)B + b] = s_cnt[2];
+        nsel[4 * (size_t)B + b] = tau;
+    }
+}
+
+// m12[i] = cand[i] iff i holds the claim on that column, no row was found within T from knn12 alone, and the reverse
+// top-2 of the column (over S for a light column, over all rows for a heavy one) holds no OTHER row within T.
+// Fewer than two prev rows => no match (the reference's knnMatch(k = 2) row would have one entry; :54 is UB).
+__global__ __launch_bounds__(256) void nnr_reverse_final_kernel(int nseg, int row_stride, const int32_t* __restrict__ cand,
+                                                                const uint32_t* __restrict__ claim,
+                                                                const int32_t* __restrict__ blocked,
+                                                                const uint2* __restrict__ knn21,
+                                                                const int32_t* __restrict__ tsel,
+                                                                const int32_t* __restrict__ nsel,
+                                                                const int32_t* __restrict__ n1, float nnr,
+                                                                int32_t* __restrict__ m12) {
+    const int b = blockIdx.y, B = gridDim.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= row_stride) return;
     const size_t off = (size_t)b * row_stride;
     int m = cand[off + i];
     if (m >= 0) {
         bool keep = false;
-        if (n1[b] >= 2) {
-            const uint2 r = merged_knn(knn21, (size_t)gridDim.y * row_stride, off + m, nseg);
-            const float r0 = (float)(r.x >> 16), r1 = (float)(r.y >> 16);
-            keep = (r0 < r1 * nnr) && ((int)(r.x & 0xFFFFu) == i);
+        const uint32_t c = claim[off + m];
+        if (n1[b] >= 2 && (c & 0xFFFFu) == (uint32_t)i && blocked[off + m] == 0) {
+            const uint32_t T = block_threshold(c >> 16, nnr);
+            const bool light = (int)T <= nsel[4 * (size_t)B + b];
+            const uint2 r = merged_knn(knn21, (size_t)B * row_stride, off + m, nseg);
+            bool blk = false;
+            if (r.x != 0xFFFFFFFFu) {
+                const int pos = (int)(r.x & 0xFFFFu);
+                const int row = light ? tsel[off + pos] : pos;
+                blk = row != i ? (r.x >> 16) <= T : (r.y != 0xFFFFFFFFu && (r.y >> 16) <= T);
+            }
+            keep = !blk;
         }
         if (!keep) m = -1;
     }
     m12[off + i] = m;
 }
 
+// scratch of the matrix-core reverse check: the last B * row_stride uint2 of knn21 hold blocked[] and tsel[]; the reverse
+// top-2 arrays in front of them get as many train segments as fit
+struct ReversePlan {
+    int32_t* blocked;
+    int32_t* tsel;
+    int nseg;
+};
+static ReversePlan reverse_plan(const LazyScratch& w, int B, int row_stride, int nseg_forward) {
+    const size_t per = (size_t)B * row_stride;
+    ReversePlan p;
+    p.blocked = reinterpret_cast<int32_t*>(w.knn21 + (w.knn_capacity - per));
+    p.tsel = p.blocked + per;
+    const size_t fit = (w.knn_capacity - per) / per;
+    p.nseg = (int)(fit < (size_t)nseg_forward ? fit : (size_t)nseg_forward);
+    if (p.nseg < 1) p.nseg = 1;
+    return p;
+}
+
+static void launch_reverse_scans(hipStream_t s, int B, int row_stride, const uint8_t* d1, const int32_t* n1, const uint8_t* d2,
+                                 const LazyScratch& w, const ReversePlan& rp, int mfma_qb) {
+    // light columns against the rows of S (positions in tsel), heavy columns against every row; disjoint column sets
+    launch_hamming_knn2_mfma(s, B, row_stride, row_stride, d1, n1, d2, n1, w.knn12, w.knn21, 0, 1, w.qsel, w.nsel + B, rp.nseg,
+                             nullptr, mfma_qb, 0, rp.tsel, w.nsel + 3 * (size_t)B);
+    launch_hamming_knn2_mfma(s, B, row_stride, row_stride, d1, n1, d2, n1, w.knn12, w.knn21, 0, 1, w.qsel, w.nsel + 2 * (size_t)B,
+                             rp.nseg, nullptr, mfma_qb, 1, nullptr, nullptr);
+}
+
 void launch_hamming_verify(hipStream_t s, int B, int row_stride, const uint8_t* d1, const int32_t* n1, const uint8_t* d2,
                            float nnr, const LazyScratch& w, int lds_pad_bytes, int nseg) {
     if (B <= 0 || row_stride <= 0) return;
     const int mfma_qb = knn_mfma_qb(row_stride);
-    if (mfma_qb > 0) {  // reverse top-2 of the claimed columns only (gathered through qsel), on the matrix cores
-        launch_hamming_knn2_mfma(s, B, row_stride, row_stride, d1, n1, d2, /*n2 unused for dir 1 queries*/ n1, w.knn12, w.knn21, 0,
-                                 1, w.qsel, w.nsel, nseg, nullptr, mfma_qb);
+    if (mfma_qb > 0) {  // the two reverse scans on the lists left by the last reverse_plan_kernel
+        launch_reverse_scans(s, B, row_stride, d1, n1, d2, w, reverse_plan(w, B, row_stride, nseg), mfma_qb);
         return;
     }
     const int tiles = (row_stride + KNN_BLOCK - 1) / KNN_BLOCK, groups = (B + 7) / 8;
@@ -478,15 +613,25 @@ void launch_match_mutual_lazy(hipStream_t s, int B, int row_stride, const uint8_
                         nullptr, nseg, claim);
     if (tev) (void)hipEventRecord(tev[1], s);
     hipLaunchKernelGGL(nnr_forward_kernel, grid2, dim3(256), 0, s, nseg, row_stride, w.knn12, n1, n2, nnr, w.cand, claim);
+    const int mfma_qb = knn_mfma_qb(row_stride);
+    if (mfma_qb > 0) {
+        const ReversePlan rp = reverse_plan(w, B, row_stride, nseg);
+        if (tev) (void)hipEventRecord(tev[2], s);
+        hipLaunchKernelGGL(reverse_plan_kernel, dim3(B), dim3(256), 0, s, B, row_stride, w.knn12, claim, n1, n2, nnr, rp.blocked,
+                           w.qsel, rp.tsel, w.nsel);
+        launch_reverse_scans(s, B, row_stride, d1, n1, d2, w, rp, mfma_qb);
+        if (tev) (void)hipEventRecord(tev[3], s);
+        if (wait_before_m12_write) (void)hipStreamWaitEvent(s, wait_before_m12_write, 0);
+        hipLaunchKernelGGL(nnr_reverse_final_kernel, grid2, dim3(256), 0, s, rp.nseg, row_stride, w.cand, claim, rp.blocked, w.knn21,
+                           rp.tsel, w.nsel, n1, nnr, m12);
+        return;
+    }
     hipLaunchKernelGGL(compact_need_kernel, dim3(B), dim3(256), 0, s, row_stride, claim, n2, w.qsel, w.nsel, blocked);
     if (tev) (void)hipEventRecord(tev[2], s);
     launch_hamming_verify(s, B, row_stride, d1, n1, d2, nnr, w, lds_pad_bytes, nseg);
     if (tev) (void)hipEventRecord(tev[3], s);
     if (wait_before_m12_write) (void)hipStreamWaitEvent(s, wait_before_m12_write, 0);
-    if (knn_mfma_qb(row_stride) > 0)
-        hipLaunchKernelGGL(nnr_reverse_top2_kernel, grid2, dim3(256), 0, s, nseg, row_stride, w.cand, w.knn21, n1, nnr, m12);
-    else
-        hipLaunchKernelGGL(nnr_reverse_check_kernel, grid2, dim3(256), 0, s, row_stride, w.cand, claim, blocked, n1, m12);
+    hipLaunchKernelGGL(nnr_reverse_check_kernel, grid2, dim3(256), 0, s, row_stride, w.cand, claim, blocked, n1, m12);
 }
 
 // Integer-VALU roof probe: the same instruction mix as K1's inner loop (xor, bcnt-accumulate,

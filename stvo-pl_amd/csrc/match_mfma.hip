@@ -64,9 +64,11 @@ __device__ __forceinline__ uint32_t key_to_knn(int key, int base) {
     return ((u >> MF_KEY_SHIFT) << 16) | (u & ((1u << MF_KEY_SHIFT) - 1u));
 }
 
-// GATHER: the query rows are the ones listed in qsel (the reverse check of the claimed columns); a separate instantiation
-// so that the two uses show up under different names in kernel traces.
-template <int QB, bool GATHER>
+// MODE 0: every row of the direction's query side against every row of its train side (the forward scan).
+// MODE 1: the query rows listed in qsel (front of the per-frame list, or its back when qsel_from_back) against every train row.
+// MODE 2: as 1, and the train rows are the ones listed in tsel; the indices in the keys are then positions in tsel.
+// (the reverse check of the claimed columns, match_kernels.hip; separate instantiations also keep the uses apart in traces)
+template <int QB, int MODE>
 __global__ __launch_bounds__(MF_BLOCK, (QB == 1 ? 4 : QB == 2 ? 3 : 1)) void hamming_knn2_mfma_kernel(int B, int tiles, int ndir, int dir0, int nseg, int row_stride,
                                                                       const uint8_t* __restrict__ d1,
                                                                       const int32_t* __restrict__ n1,
@@ -75,7 +77,10 @@ __global__ __launch_bounds__(MF_BLOCK, (QB == 1 ? 4 : QB == 2 ? 3 : 1)) void ham
                                                                       uint2* __restrict__ knn12, uint2* __restrict__ knn21,
                                                                       const int32_t* __restrict__ qsel,
                                                                       const int32_t* __restrict__ nsel,
-                                                                      uint32_t* __restrict__ claim_init) {
+                                                                      uint32_t* __restrict__ claim_init, int qsel_from_back,
+                                                                      const int32_t* __restrict__ tsel,
+                                                                      const int32_t* __restrict__ ntsel) {
+    constexpr bool GATHER = MODE >= 1, TGATHER = MODE == 2;
     constexpr int ROWS = 4 * QB * 32;  // query rows per workgroup
     __shared__ v4i s_tile[2][16 * 32]; // [buffer][(kk * 2 + hf) * 32 + train row] = one 16-byte fragment
     // XCD-aware block -> (frame pair, direction, tile, segment) mapping: as hamming_knn2_kernel
@@ -90,7 +95,7 @@ __global__ __launch_bounds__(MF_BLOCK, (QB == 1 ? 4 : QB == 2 ? 3 : 1)) void ham
     const int tile = (local / nseg) % tiles;
     const int na = n1[b], nb = n2[b];
     const int nq = GATHER ? nsel[b] : (dir == 0 ? na : nb);
-    const int nt_all = dir == 0 ? nb : na;
+    const int nt_all = TGATHER ? ntsel[b] : (dir == 0 ? nb : na);
     const int seg_len = (((nt_all + nseg - 1) / nseg) + MF_TILE - 1) & ~(MF_TILE - 1);
     const int j0 = min(seg * seg_len, nt_all);
     const int nt = min(j0 + seg_len, nt_all);
@@ -110,7 +115,7 @@ __global__ __launch_bounds__(MF_BLOCK, (QB == 1 ? 4 : QB == 2 ? 3 : 1)) void ham
     auto query_row = [&](int qb) {  // recomputed for the final store rather than kept live across the scan
         const int q = q_base + (wv * QB + qb) * 32 + col;
         const int qc = q < nq ? q : nq - 1;  // tail lanes scan a valid row and discard the result
-        return GATHER ? qsel[frame_off + qc] : qc;
+        return GATHER ? qsel[frame_off + (qsel_from_back ? row_stride - 1 - qc : qc)] : qc;
     };
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
@@ -138,7 +143,9 @@ __global__ __launch_bounds__(MF_BLOCK, (QB == 1 ? 4 : QB == 2 ? 3 : 1)) void ham
     const int ntiles = (nt - j0 + MF_TILE - 1) / MF_TILE;
     auto fetch = [&](int t) -> uint32_t {
         const int j = j0 + t * MF_TILE + xr;
-        return j < nt ? T[(size_t)j * 8 + xk] : 0u;
+        if (j >= nt) return 0u;
+        const int row = TGATHER ? tsel[frame_off + j] : j;
+        return T[(size_t)row * 8 + xk];
     };
     auto stage = [&](int buf, uint32_t w) {
         s_tile[buf][(xk * 2 + 0) * 32 + xr] = expand_half(w, 0);
@@ -233,24 +240,23 @@ int mfma_rows_per_block(int qb) { return 4 * qb * 32; }
 void launch_hamming_knn2_mfma(hipStream_t s, int B, int row_stride, int max_n, const uint8_t* d1, const int32_t* n1,
                               const uint8_t* d2, const int32_t* n2, uint2* knn12, uint2* knn21, int both_directions,
                               int dir0, const int32_t* qsel, const int32_t* nsel, int nseg, uint32_t* claim_init, int qb,
-                              int lds_pad_bytes) {
+                              int qsel_from_back, const int32_t* tsel, const int32_t* ntsel) {
     if (B <= 0 || max_n <= 0) return;
     const int rows = mfma_rows_per_block(qb);
     const int tiles = (max_n + rows - 1) / rows, ndir = both_directions ? 2 : 1;
     const int groups = (B + 7) / 8;
     dim3 grid((unsigned)(groups * 8 * tiles * ndir * nseg));
-#define STVO_MF_LAUNCH(QBV, G)                                                                                              \
-    hipLaunchKernelGGL((hamming_knn2_mfma_kernel<QBV, G>), grid, dim3(MF_BLOCK), (size_t)lds_pad_bytes, s, B, tiles, ndir, dir0, \
-                       nseg, row_stride, d1, n1, d2, n2, knn12, knn21, qsel, nsel, claim_init)
-    if (qsel) {
-        if (qb == 1) STVO_MF_LAUNCH(1, true);
-        else if (qb == 2) STVO_MF_LAUNCH(2, true);
-        else STVO_MF_LAUNCH(4, true);
-    } else {
-        if (qb == 1) STVO_MF_LAUNCH(1, false);
-        else if (qb == 2) STVO_MF_LAUNCH(2, false);
-        else STVO_MF_LAUNCH(4, false);
-    }
+#define STVO_MF_LAUNCH(QBV, M)                                                                                               \
+    hipLaunchKernelGGL((hamming_knn2_mfma_kernel<QBV, M>), grid, dim3(MF_BLOCK), 0, s, B, tiles, ndir, dir0, nseg, row_stride, \
+                       d1, n1, d2, n2, knn12, knn21, qsel, nsel, claim_init, qsel_from_back, tsel, ntsel)
+#define STVO_MF_LAUNCH_QB(M)            \
+    if (qb == 1) STVO_MF_LAUNCH(1, M);  \
+    else if (qb == 2) STVO_MF_LAUNCH(2, M); \
+    else STVO_MF_LAUNCH(4, M)
+    if (!qsel) { STVO_MF_LAUNCH_QB(0); }
+    else if (!tsel) { STVO_MF_LAUNCH_QB(1); }
+    else { STVO_MF_LAUNCH_QB(2); }
+#undef STVO_MF_LAUNCH_QB
 #undef STVO_MF_LAUNCH
 }
 

@@ -541,7 +541,7 @@ int stvo_seq_create(stvo_ctx* ctx, int B, int max_keypoints, int max_keylines, i
     const size_t cap_l = nb * (size_t)M * 4;  // line f2f: up to 4 train segments
     const size_t o_cover_l = c.take(nb * (size_t)(M / 64) * M * 8), o_top2_l = c.take(nb * M * 8), o_owner_l = c.take(nb * M * 4),
                  o_knn12_l = c.take(cap_l * 8), o_knn21_l = c.take(cap_l * 8), o_cand_l = c.take(nb * M * 4),
-                 o_need_l = c.take(nb * M * 4), o_qsel_l = c.take(nb * M * 4), o_nsel_l = c.take(nb * 4);
+                 o_need_l = c.take(nb * M * 4), o_qsel_l = c.take(nb * M * 4), o_nsel_l = c.take(nb * 4 * 5);
     size_t o_set[2][14];
     for (int t = 0; t < 2; ++t) {
         o_set[t][0] = c.take(nb * K * 2 * 8);

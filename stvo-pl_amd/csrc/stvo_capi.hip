@@ -60,7 +60,7 @@ int stvo_ctx_create(int device_id, int max_rows, int max_batch, stvo_ctx** out) 
          hip_ok(ctx, hipMalloc((void**)&ctx->cand, knn_elems * sizeof(int32_t)), "hipMalloc cand") &&
          hip_ok(ctx, hipMalloc((void**)&ctx->need, knn_elems * sizeof(int32_t)), "hipMalloc need") &&
          hip_ok(ctx, hipMalloc((void**)&ctx->qsel, knn_elems * sizeof(int32_t)), "hipMalloc qsel") &&
-         hip_ok(ctx, hipMalloc((void**)&ctx->nsel, (size_t)max_batch * sizeof(int32_t)), "hipMalloc nsel") &&
+         hip_ok(ctx, hipMalloc((void**)&ctx->nsel, (size_t)max_batch * 5 * sizeof(int32_t)), "hipMalloc nsel") &&
          hip_ok(ctx, hipMalloc((void**)&ctx->arena, ctx->arena_size), "hipMalloc arena") &&
          hip_ok(ctx, hipHostMalloc((void**)&ctx->arena_host, ctx->arena_size, hipHostMallocDefault), "hipHostMalloc") &&
          hip_ok(ctx, hipMalloc((void**)&ctx->probe_sink, 256), "hipMalloc sink");
@@ -486,6 +486,14 @@ int stvo_last_reverse_counts(stvo_ctx* ctx, int B, int32_t* counts) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(counts, ctx->nsel, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return STVO_OK;
+}
+
+int stvo_last_reverse_plan(stvo_ctx* ctx, int B, int32_t* plan) {
+    if (!ctx || !plan || B <= 0 || B > ctx->max_batch) return STVO_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(plan, ctx->nsel, (size_t)B * 5 * sizeof(int32_t), hipMemcpyDeviceToHost));
     return STVO_OK;
 }
 

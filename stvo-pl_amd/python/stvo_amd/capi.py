@@ -18,7 +18,7 @@ EXPORTS = ["stvo_backend_name", "stvo_abi_version", "stvo_error_string", "stvo_c
            "stvo_ctx_destroy", "stvo_ctx_set_stream", "stvo_ctx_synchronize", "stvo_ctx_set_overlap", "stvo_match_nnr_mutual",
            "stvo_match_grid_points", "stvo_match_grid_lines", "stvo_normal_eq", "stvo_optimize_pose",
            "stvo_track_batched_dev", "stvo_match_nnr_mutual_batched_dev", "stvo_optimize_pose_batched_dev",
-           "stvo_time_stage_dev", "stvo_valu_peak_probe", "stvo_last_reverse_counts", "stvo_ctx_set_kernel_timing", "stvo_ctx_get_kernel_timing", "stvo_seq_create", "stvo_seq_destroy", "stvo_seq_enable_fetch", "stvo_seq_fetch_matches", "stvo_seq_fetch_inliers", "stvo_seq_strides",
+           "stvo_time_stage_dev", "stvo_valu_peak_probe", "stvo_last_reverse_counts", "stvo_last_reverse_plan", "stvo_ctx_set_kernel_timing", "stvo_ctx_get_kernel_timing", "stvo_seq_create", "stvo_seq_destroy", "stvo_seq_enable_fetch", "stvo_seq_fetch_matches", "stvo_seq_fetch_inliers", "stvo_seq_strides",
            "stvo_seq_push", "stvo_seq_upload", "stvo_seq_step_dev", "stvo_seq_read"]
 
 u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
@@ -123,6 +123,7 @@ def load():
     L.stvo_seq_fetch_inliers.argtypes = [C.c_void_p, pp32, pp32]
     L.stvo_seq_strides.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.stvo_last_reverse_counts.argtypes = [C.c_void_p, C.c_int, i32p]
+    L.stvo_last_reverse_plan.argtypes = [C.c_void_p, C.c_int, i32p]
     L.stvo_ctx_set_kernel_timing.argtypes = [C.c_void_p, C.c_int]
     L.stvo_ctx_get_kernel_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int32)]
     _lib = L
@@ -252,6 +253,12 @@ class Context:
     def last_reverse_counts(self, B):
         out = np.empty(B, np.int32)
         self._chk(self.lib.stvo_last_reverse_counts(self.h, B, out))
+        return out
+
+    def last_reverse_plan(self, B):
+        """[5][B]: claimed, light, heavy columns, |S|, tau of the last mutual match's reverse check (matrix-core path)."""
+        out = np.empty((5, B), np.int32)
+        self._chk(self.lib.stvo_last_reverse_plan(self.h, B, out))
         return out
 
     # ---- batched device-resident path ----

@@ -198,3 +198,67 @@ def test_match_valu_kernels_still_agree():
                         "-k", "bit_exact or adversarial or key_edges or many_ties"], env=env, capture_output=True, text=True,
                        timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def _flip(rng, row, nbits, lo=0, hi=256):
+    r = row.copy()
+    for b in lo + rng.permutation(hi - lo)[:nbits]:
+        r[b >> 3] ^= np.uint8(1 << (b & 7))
+    return r
+
+
+def test_match_reverse_plan_adversarial(hip, oracle):
+    """The matrix-core reverse check evaluates D(i', j) only for rows i' whose SECOND-best forward distance is within the
+    column's blocking threshold T_j; every other potential blocker must have j among its own top-2.  Build the cases that
+    separate the two routes: clusters of near-identical train rows (a blocker whose two best entries are OTHER members of the
+    cluster, so column j is in nobody's top-2 but its claimant's), blockers exactly at T and T + 1, claimants that are
+    themselves members of S, weak claims with large thresholds (heavy columns) next to strong ones (light columns)."""
+    rng = np.random.default_rng(4242)
+    seen_heavy = False
+    for trial, (nnr, n_fill) in enumerate(((0.75, 900), (0.9, 300), (1.0, 64), (0.5, 1500))):
+        train, query = [], []
+        for c in range(60):
+            base = rand_desc(rng, 1)[0]
+            kind = c % 6
+            if kind == 0:    # cluster j, j1, j2; i* near j; i' near j1/j2 and at distance <= T of j without j in its top-2
+                j = base; j1 = _flip(rng, base, 12, 0, 64); j2 = _flip(rng, j1, 1, 64, 128)
+                train += [j, j1, j2]
+                d0 = int(rng.integers(6, 14))
+                query.append(_flip(rng, j, d0, 128, 256))              # claimant of j
+                query.append(_flip(rng, j1, int(rng.integers(0, 3)), 128, 256))  # near j1, j2; D(., j) ~ 12-14
+            elif kind == 1:  # second row exactly at T / T + 1 / T - 1 of the column (T = largest blocking distance)
+                d0 = int(rng.integers(3, 60)); f0 = np.float32(d0); T = d0
+                while T < 256 and not (f0 < np.float32(T + 1) * np.float32(nnr)):
+                    T += 1
+                train.append(base)
+                query.append(_flip(rng, base, d0))
+                query.append(_flip(rng, base, min(256, max(d0, T + int(rng.integers(-1, 2))))))
+            elif kind == 2:  # two train rows 3 bits apart, two queries each nearest to a different one: both in S
+                t2 = _flip(rng, base, 3)
+                train += [base, t2]
+                query += [_flip(rng, base, 2, 128, 256), _flip(rng, t2, 2, 0, 128)]
+            elif kind == 3:  # weak claim: distance 70-90 (heavy column when the rest of the frame is strong)
+                train.append(base)
+                query.append(_flip(rng, base, int(rng.integers(70, 90))))
+            elif kind == 4:  # the same train row twice (tie in every query's top-2)
+                train += [base, base.copy()]
+                query += [_flip(rng, base, 5), _flip(rng, base, 9)]
+            else:
+                train.append(base)
+                query.append(synth.flip_bits(rng, base[None, :], 0.07)[0])
+        train += list(rand_desc(rng, n_fill)); query += list(rand_desc(rng, n_fill // 2))
+        d2 = np.stack(train)[rng.permutation(len(train))]
+        d1 = np.stack(query)[rng.permutation(len(query))]
+        import os
+        routes = np.zeros(3, np.int64)
+        for a, b in ((d1, d2), (d2, d1)):
+            got, n = hip.match(a, b, nnr, 1)
+            exp, en = oracle.match(a, b, nnr, 1)
+            assert np.array_equal(got, exp), (trial, nnr, np.nonzero(got != exp)[0][:10])
+            assert n == en
+            routes += hip.last_reverse_plan(1)[1:4, 0]
+        if os.environ.get("STVO_KNN_MFMA") != "0":  # the inputs really took all three routes: light, heavy, non-empty S
+            assert routes[0] > 0 and routes[2] > 0, routes
+            seen_heavy = seen_heavy or routes[1] > 0
+    if os.environ.get("STVO_KNN_MFMA") != "0":
+        assert seen_heavy
