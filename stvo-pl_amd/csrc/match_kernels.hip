@@ -244,7 +244,7 @@ void launch_nnr_mutual(hipStream_t s, int B, int row_stride, const uint2* knn12,
 // the wave-uniform short cut: 4 x (v_xor + v_bcnt) + one compare instead of 8 x (v_xor + v_bcnt) + the top-2
 // update.  Exactness does not depend on the data: whenever any lane's lower bound is within its T (its own
 // claimant excepted) the wave finishes the row at full length.
-__global__ __launch_bounds__(256) void nnr_forward_kernel(int nseg, int row_stride, uint2* __restrict__ knn12,
+__global__ __launch_bounds__(256) void nnr_forward_kernel(int nseg, int row_stride, const uint2* __restrict__ knn12,
                                                           const int32_t* __restrict__ n1, const int32_t* __restrict__ n2,
                                                           float nnr, int32_t* __restrict__ cand,
                                                           uint32_t* __restrict__ claim /* preset to 0xFFFFFFFF by K1 */) {
@@ -256,7 +256,6 @@ __global__ __launch_bounds__(256) void nnr_forward_kernel(int nseg, int row_stri
     int m = -1;
     if (i < na && nb >= 2) {
         const uint2 k = merged_knn(knn12, (size_t)gridDim.y * row_stride, off + i, nseg);
-        if (nseg > 1) knn12[off + i] = k;  // segment 0 now holds the row's merged top-2 (read again by reverse_plan_kernel)
         const float f0 = (float)(k.x >> 16), f1 = (float)(k.y >> 16);
         if (f0 < f1 * nnr) {
             m = (int)(k.x & 0xFFFFu);
@@ -446,46 +445,76 @@ __device__ __forceinline__ uint32_t block_threshold(uint32_t d0, float nnr) {
     return thr;
 }
 
-// one workgroup per frame pair.  knn12 = merged forward top-2 (segment 0 after nnr_forward_kernel).
-// out: blocked[j] (verdicts that need no distance evaluation), qsel (LIGHT columns from the front, HEAVY from the back
-// of the frame's slot), tsel (the rows of S), nsel[0][b] = claimed columns, [1] = light, [2] = heavy, [3] = |S|, [4] = tau.
-__global__ __launch_bounds__(256) void reverse_plan_kernel(int B, int row_stride, const uint2* __restrict__ knn12,
-                                                           const uint32_t* __restrict__ claim,
-                                                           const int32_t* __restrict__ n1, const int32_t* __restrict__ n2,
-                                                           float nnr, int32_t* __restrict__ blocked,
-                                                           int32_t* __restrict__ qsel, int32_t* __restrict__ tsel,
-                                                           int32_t* __restrict__ nsel) {
+// One workgroup per frame pair does everything between the forward scan and the reverse scans:
+//   1. merges the per-segment top-2 of every row, applies the forward ratio test (StVO::matchNNR, matching.cpp:53-58) and
+//      resolves the column claims with LDS atomics (one claim per column: the smallest (d0, row));
+//   2. judges from the forward top-2 alone every (row, column) pair where the column is one of the row's two entries;
+//   3. picks the cut tau and writes the LIGHT / HEAVY column lists and the row list S.
+// out: cand[i], claim[j], blocked[j], qsel (LIGHT columns from the front, HEAVY from the back of the frame's slot), tsel,
+// nsel[0][b] = claimed columns, [1] = light, [2] = heavy, [3] = |S|, [4] = tau.  knn12 segment 0 is left holding the merged top-2.
+constexpr int PLAN_BLOCK = 1024;
+__global__ __launch_bounds__(PLAN_BLOCK) void forward_plan_kernel(int B, int nseg, int row_stride, uint2* __restrict__ knn12,
+                                                                  const int32_t* __restrict__ n1,
+                                                                  const int32_t* __restrict__ n2, float nnr,
+                                                                  int32_t* __restrict__ cand, uint32_t* __restrict__ claim_g,
+                                                                  int32_t* __restrict__ blocked_g, int32_t* __restrict__ qsel,
+                                                                  int32_t* __restrict__ tsel, int32_t* __restrict__ nsel) {
+    extern __shared__ uint32_t plan_lds[];  // claim u32[stride] | T u16[stride] | verdict u8[stride]
+    uint32_t* claim = plan_lds;
+    uint16_t* Tc = reinterpret_cast<uint16_t*>(claim + row_stride);
+    uint8_t* blk = reinterpret_cast<uint8_t*>(Tc + row_stride);
     __shared__ int hT[257], hS[257], s_cnt[3];
     __shared__ unsigned long long s_best;
     const int b = blockIdx.x, tid = threadIdx.x;
     const size_t off = (size_t)b * row_stride;
     const int na = n1[b], nb = n2[b];
-    for (int t = tid; t < 257; t += 256) hT[t] = hS[t] = 0;
+    for (int j = tid; j < row_stride; j += PLAN_BLOCK) {
+        claim[j] = 0xFFFFFFFFu;
+        blk[j] = 0;
+    }
+    if (tid < 257) hT[tid] = hS[tid] = 0;
     if (tid < 3) s_cnt[tid] = 0;
     if (tid == 0) s_best = ~0ull;
-    for (int j = tid; j < row_stride; j += 256) blocked[off + j] = 0;
     __syncthreads();
     const bool active = nb >= 2 && na >= 1;
-    if (active) {
-        for (int i = tid; i < na; i += 256) {
-            const uint2 k = knn12[off + i];
+    for (int i = tid; i < row_stride; i += PLAN_BLOCK) {  // forward ratio test + claims
+        int m = -1;
+        if (active && i < na) {
+            const uint2 k = merged_knn(knn12, (size_t)B * row_stride, off + i, nseg);
+            if (nseg > 1) knn12[off + i] = k;
+            const float f0 = (float)(k.x >> 16), f1 = (float)(k.y >> 16);
+            if (f0 < f1 * nnr) {
+                m = (int)(k.x & 0xFFFFu);
+                atomicMin(&claim[m], (k.x & 0xFFFF0000u) | (uint32_t)i);  // (d0 << 16) | claimant
+            }
+        }
+        cand[off + i] = m;
+    }
+    __syncthreads();
+    for (int j = tid; j < row_stride; j += PLAN_BLOCK) {  // thresholds of the claimed columns
+        const uint32_t c = claim[j];
+        claim_g[off + j] = c;
+        if (c != 0xFFFFFFFFu) {
+            const uint32_t T = block_threshold(c >> 16, nnr);
+            Tc[j] = (uint16_t)T;
+            atomicAdd(&hT[T], 1);
+        }
+    }
+    __syncthreads();
+    if (active)
+        for (int i = tid; i < na; i += PLAN_BLOCK) {  // verdicts that need no distance evaluation; histogram of the second-best distances
+            const uint2 k = knn12[off + i];           // written by this very thread above
             const uint32_t key[2] = {k.x, k.y};
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 if (key[e] == 0xFFFFFFFFu) continue;
-                const uint32_t j = key[e] & 0xFFFFu, c = claim[off + j];
-                if (c != 0xFFFFFFFFu && (c & 0xFFFFu) != (uint32_t)i && (key[e] >> 16) <= block_threshold(c >> 16, nnr))
-                    blocked[off + j] = 1;  // benign race: every writer stores 1
+                const uint32_t j = key[e] & 0xFFFFu, c = claim[j];
+                if (c != 0xFFFFFFFFu && (c & 0xFFFFu) != (uint32_t)i && (key[e] >> 16) <= (uint32_t)Tc[j]) blk[j] = 1;
             }
             if (k.y != 0xFFFFFFFFu) atomicAdd(&hS[min(k.y >> 16, 256u)], 1);
         }
-        for (int j = tid; j < nb; j += 256) {
-            const uint32_t c = claim[off + j];
-            if (c != 0xFFFFFFFFu) atomicAdd(&hT[block_threshold(c >> 16, nnr)], 1);
-        }
-    }
     __syncthreads();
-    {   // candidate cut tau = tid - 1 (thresholds above 254 are always heavy: they would need S = every row)
+    if (tid < 256) {  // candidate cut tau = tid - 1 (thresholds above 254 are always heavy: they would need S = every row)
         int cT = 0, cS = 0, C = 0;
         for (int t = 0; t < 257; ++t) {
             C += hT[t];
@@ -499,20 +528,19 @@ __global__ __launch_bounds__(256) void reverse_plan_kernel(int B, int row_stride
     }
     __syncthreads();
     const int tau = (int)(s_best & 511ull) - 1;
-    if (active) {
-        for (int j = tid; j < nb; j += 256) {
-            const uint32_t c = claim[off + j];
-            if (c == 0xFFFFFFFFu) continue;
-            if ((int)block_threshold(c >> 16, nnr) <= tau)
-                qsel[off + atomicAdd(&s_cnt[0], 1)] = j;
-            else
-                qsel[off + row_stride - 1 - atomicAdd(&s_cnt[1], 1)] = j;
-        }
-        for (int i = tid; i < na; i += 256) {
+    for (int j = tid; j < row_stride; j += PLAN_BLOCK) {
+        blocked_g[off + j] = blk[j];
+        if (claim[j] == 0xFFFFFFFFu) continue;
+        if ((int)Tc[j] <= tau)
+            qsel[off + atomicAdd(&s_cnt[0], 1)] = j;
+        else
+            qsel[off + row_stride - 1 - atomicAdd(&s_cnt[1], 1)] = j;
+    }
+    if (active)
+        for (int i = tid; i < na; i += PLAN_BLOCK) {
             const uint2 k = knn12[off + i];
             if (k.y != 0xFFFFFFFFu && (int)(k.y >> 16) <= tau) tsel[off + atomicAdd(&s_cnt[2], 1)] = i;
         }
-    }
     __syncthreads();
     if (tid == 0) {
         nsel[b] = s_cnt[0] + s_cnt[1];
@@ -545,7 +573,9 @@ __global__ __launch_bounds__(256) void nnr_reverse_final_kernel(int nseg, int ro
         if (n1[b] >= 2 && (c & 0xFFFFu) == (uint32_t)i && blocked[off + m] == 0) {
             const uint32_t T = block_threshold(c >> 16, nnr);
             const bool light = (int)T <= nsel[4 * (size_t)B + b];
-            const uint2 r = merged_knn(knn21, (size_t)B * row_stride, off + m, nseg);
+            // (a light column of a frame with an empty S was not scanned at all: nothing can block it any more)
+            const bool scanned = !light || nsel[3 * (size_t)B + b] > 0;
+            const uint2 r = scanned ? merged_knn(knn21, (size_t)B * row_stride, off + m, nseg) : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
             bool blk = false;
             if (r.x != 0xFFFFFFFFu) {
                 const int pos = (int)(r.x & 0xFFFFu);
@@ -612,13 +642,12 @@ void launch_match_mutual_lazy(hipStream_t s, int B, int row_stride, const uint8_
     launch_hamming_knn2(s, B, row_stride, row_stride, d1, n1, d2, n2, w.knn12, w.knn21, 0, lds_pad_bytes, 0, nullptr,
                         nullptr, nseg, claim);
     if (tev) (void)hipEventRecord(tev[1], s);
-    hipLaunchKernelGGL(nnr_forward_kernel, grid2, dim3(256), 0, s, nseg, row_stride, w.knn12, n1, n2, nnr, w.cand, claim);
     const int mfma_qb = knn_mfma_qb(row_stride);
     if (mfma_qb > 0) {
         const ReversePlan rp = reverse_plan(w, B, row_stride, nseg);
         if (tev) (void)hipEventRecord(tev[2], s);
-        hipLaunchKernelGGL(reverse_plan_kernel, dim3(B), dim3(256), 0, s, B, row_stride, w.knn12, claim, n1, n2, nnr, rp.blocked,
-                           w.qsel, rp.tsel, w.nsel);
+        hipLaunchKernelGGL(forward_plan_kernel, dim3(B), dim3(PLAN_BLOCK), (size_t)row_stride * 7, s, B, nseg, row_stride, w.knn12,
+                           n1, n2, nnr, w.cand, claim, rp.blocked, w.qsel, rp.tsel, w.nsel);
         launch_reverse_scans(s, B, row_stride, d1, n1, d2, w, rp, mfma_qb);
         if (tev) (void)hipEventRecord(tev[3], s);
         if (wait_before_m12_write) (void)hipStreamWaitEvent(s, wait_before_m12_write, 0);
@@ -626,6 +655,7 @@ void launch_match_mutual_lazy(hipStream_t s, int B, int row_stride, const uint8_
                            rp.tsel, w.nsel, n1, nnr, m12);
         return;
     }
+    hipLaunchKernelGGL(nnr_forward_kernel, grid2, dim3(256), 0, s, nseg, row_stride, w.knn12, n1, n2, nnr, w.cand, claim);
     hipLaunchKernelGGL(compact_need_kernel, dim3(B), dim3(256), 0, s, row_stride, claim, n2, w.qsel, w.nsel, blocked);
     if (tev) (void)hipEventRecord(tev[2], s);
     launch_hamming_verify(s, B, row_stride, d1, n1, d2, nnr, w, lds_pad_bytes, nseg);

@@ -96,6 +96,7 @@ __global__ __launch_bounds__(MF_BLOCK, (QB == 1 ? 4 : QB == 2 ? 3 : 1)) void ham
     const int na = n1[b], nb = n2[b];
     const int nq = GATHER ? nsel[b] : (dir == 0 ? na : nb);
     const int nt_all = TGATHER ? ntsel[b] : (dir == 0 ? nb : na);
+    if (TGATHER && nt_all == 0) return;  // an empty row list: the consumer does not read this frame's results (nsel[3][b] == 0)
     const int seg_len = (((nt_all + nseg - 1) / nseg) + MF_TILE - 1) & ~(MF_TILE - 1);
     const int j0 = min(seg * seg_len, nt_all);
     const int nt = min(j0 + seg_len, nt_all);
