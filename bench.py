@@ -197,12 +197,12 @@ def main():
 
     out = None
     if rank == 0:
-        # The dominant kernel is hamming_knn2 (K1): ONE launch per step, the forward top-2 scan of every prev row
-        # against every curr row.  (The mutual check is a separate, cheaper kernel, hamming_verify: a range query
-        # with early exit over the claimed columns.)
-        # K1 is timed LIVE in a second pass over the same steps (same batch, same overlap mode): hipEvent pairs
+        # The dominant kernel is the forward top-2 scan (K1m hamming_knn2_mfma_kernel<2, 0>, or K1 hamming_knn2_kernel with
+        # STVO_KNN_MFMA=0): ONE launch per step, every prev row against every curr row.  The reverse (mutual) check is a
+        # per-frame planning kernel plus two sparse scans of the same kernel family.
+        # K1m is timed LIVE in a second pass over the same steps (same batch, same overlap mode): hipEvent pairs
         # around every launch, on the stream it is launched on.  The pass is separate from the one that produced
-        # `value` because the event markers cost ~9 % of throughput.
+        # `value` because the event markers cost throughput (each is a barrier packet).
         ctx.set_kernel_timing(True)
         for _ in range(args.steps):
             step()
@@ -220,7 +220,7 @@ def main():
         lane_ops = pairs * K1_LANE_OPS_PER_PAIR
         valu_meas = ctx.valu_peak()
         mfma = os.environ.get("STVO_KNN_MFMA", "2") != "0" and max_pts <= 8192   # the library's own rule (knn_mfma_qb)
-        k1_name = "hamming_knn2_mfma_kernel<2, false>" if mfma else "hamming_knn2_kernel"
+        k1_name = "hamming_knn2_mfma_kernel<2, 0>" if mfma else "hamming_knn2_kernel"
         out = {
             "metric": "stereo frames/s (match+optimizePose)", "value": frames_total / dt, "unit": "frame-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -233,10 +233,10 @@ def main():
                        "committed_pose_fraction": ok_frac,
                        "pose_overlaps_next_match": not args.no_overlap},
             "roofline": None, "hbm_view": None, "valu_roofline": None,
-            "stage_ms": {"hamming_knn2": k1_ms, "hamming_verify": verify_ms, "hamming_knn2_calls_timed": k1_calls,
+            "stage_ms": {"hamming_knn2": k1_ms, "reverse_check": verify_ms, "hamming_knn2_calls_timed": k1_calls,
                          "hamming_knn2_launches_per_step": 1, "hamming_knn2_solo": k1_solo_ms,
-                         "hamming_verify_solo": verify_solo_ms, "pose_solo": pose_ms,
-                         "verified_column_fraction": float(nsel.sum()) / float(n2v.sum())},
+                         "reverse_scans_solo": verify_solo_ms, "pose_solo": pose_ms,
+                         "claimed_column_fraction": float(nsel.sum()) / float(n2v.sum())},
         }
         traffic = committed_traffic(k1_name)
         traffic_src = ("bytes per launch = FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes, read from the committed "
@@ -247,6 +247,14 @@ def main():
                     "algorithmic_bytes_per_launch": alg_bytes,
                     "note": "brute-force matching does ~56 k distance bit-operations per compulsory byte: HBM is idle by construction"}
         if mfma:
+            plan = ctx.last_reverse_plan(B).astype(np.int64)   # [claimed, light, heavy, |S|, tau] per frame pair
+            out["stage_ms"]["reverse_plan"] = {
+                "light_column_fraction": float(plan[1].sum()) / max(float(plan[0].sum()), 1.0),
+                "heavy_column_fraction": float(plan[2].sum()) / max(float(plan[0].sum()), 1.0),
+                "mean_rows_in_S": float(plan[3].mean()), "mean_tau": float(plan[4].mean()),
+                "reverse_distance_evaluations_per_frame": float((plan[1] * plan[3] + plan[2] * n1v).mean()),
+                "note": "reverse check: light columns are scanned against the |S| rows whose second-best forward distance is "
+                        "within the cut tau, heavy columns against all rows (DESIGN.md §5)"}
             ops = pairs * K1M_OPS_PER_PAIR
             achieved_tops = ops / (k1_ms * 1e-3) / 1e12
             out["roofline"] = {"kernel": k1_name, "bound": "mfma", "achieved": achieved_tops, "peak": I8_MFMA_PEAK_TOPS,

@@ -639,8 +639,9 @@ void launch_match_mutual_lazy(hipStream_t s, int B, int row_stride, const uint8_
     uint32_t* claim = reinterpret_cast<uint32_t*>(w.need);
     int32_t* blocked = reinterpret_cast<int32_t*>(w.knn21);  // the reverse top-2 array is not needed any more
     if (tev) (void)hipEventRecord(tev[0], s);
+    // (the VALU path resets the column claims inside K1; forward_plan_kernel of the matrix-core path builds them in LDS)
     launch_hamming_knn2(s, B, row_stride, row_stride, d1, n1, d2, n2, w.knn12, w.knn21, 0, lds_pad_bytes, 0, nullptr,
-                        nullptr, nseg, claim);
+                        nullptr, nseg, knn_mfma_qb(row_stride) > 0 ? nullptr : claim);
     if (tev) (void)hipEventRecord(tev[1], s);
     const int mfma_qb = knn_mfma_qb(row_stride);
     if (mfma_qb > 0) {
