@@ -82,7 +82,7 @@ __global__ __launch_bounds__(MF_BLOCK, (QB == 1 ? 4 : QB == 2 ? 3 : 1)) void ham
                                                                       const int32_t* __restrict__ ntsel) {
     constexpr bool GATHER = MODE >= 1, TGATHER = MODE == 2;
     constexpr int ROWS = 4 * QB * 32;  // query rows per workgroup
-    __shared__ v4i s_tile[2][16 * 32]; // [buffer][(kk * 2 + hf) * 32 + train row] = one 16-byte fragment
+    __shared__ v4i s_tile[2][16 * 32];  // [tile parity][(kk * 2 + hf) * 32 + train row] = one 16-byte fragment
     // XCD-aware block -> (frame pair, direction, tile, segment) mapping: as hamming_knn2_kernel
     const int per_frame = tiles * ndir * nseg;
     const int L = blockIdx.x;
@@ -148,9 +148,9 @@ __global__ __launch_bounds__(MF_BLOCK, (QB == 1 ? 4 : QB == 2 ? 3 : 1)) void ham
         const int row = TGATHER ? tsel[frame_off + j] : j;
         return T[(size_t)row * 8 + xk];
     };
-    auto stage = [&](int buf, uint32_t w) {
-        s_tile[buf][(xk * 2 + 0) * 32 + xr] = expand_half(w, 0);
-        s_tile[buf][(xk * 2 + 1) * 32 + xr] = expand_half(w, 1);
+    auto stage = [&](int t, uint32_t w) {
+        s_tile[t & 1][(xk * 2 + 0) * 32 + xr] = expand_half(w, 0);
+        s_tile[t & 1][(xk * 2 + 1) * 32 + xr] = expand_half(w, 1);
     };
     if (ntiles > 0) stage(0, fetch(0));
     __syncthreads();
@@ -168,18 +168,16 @@ __global__ __launch_bounds__(MF_BLOCK, (QB == 1 ? 4 : QB == 2 ? 3 : 1)) void ham
         second[qb] = med3_i32(best[qb], second[qb], key);
         best[qb] = min(best[qb], key);
     };
-    auto step = [&](v16i (&cur)[QB], const v16i (&prev)[QB], int t) {
-        const int buf = t & 1;
-        uint32_t w_next = 0;
-        if (t + 1 < ntiles) w_next = fetch(t + 1);
+    auto mma_fold = [&](v16i (&cur)[QB], const v16i (&prev)[QB], int t) {
         if (wave_active) {
+            const v4i* frag = s_tile[t & 1];
             const bool fold_prev = t > 0;  // tile t - 1 is a full tile here
             if (fold_prev) rebase();
-            v4i tf = s_tile[buf][lane];
+            v4i tf = frag[lane];
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk) {
                 v4i tf_ahead = tf;
-                if (kk < 7) tf_ahead = s_tile[buf][(kk + 1) * 64 + lane];  // one K step ahead of its use
+                if (kk < 7) tf_ahead = frag[(kk + 1) * 64 + lane];  // one K step ahead of its use
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb)
                     cur[qb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(tf, qf[qb][kk], kk == 0 ? cidx : cur[qb], 0, 0, 0);
@@ -196,7 +194,12 @@ __global__ __launch_bounds__(MF_BLOCK, (QB == 1 ? 4 : QB == 2 ? 3 : 1)) void ham
                 tf = tf_ahead;
             }
         }
-        if (t + 1 < ntiles) stage(buf ^ 1, w_next);
+    };
+    auto step = [&](v16i (&cur)[QB], const v16i (&prev)[QB], int t) {
+        uint32_t w_next = 0;
+        if (t + 1 < ntiles) w_next = fetch(t + 1);
+        mma_fold(cur, prev, t);
+        if (t + 1 < ntiles) stage(t + 1, w_next);
         __syncthreads();
     };
     v16i accA[QB], accB[QB];
