@@ -35,11 +35,13 @@ void launch_hamming_knn2_mfma(hipStream_t s, int B, int row_stride, int max_n, c
                               int dir0, const int32_t* qsel, const int32_t* nsel, int nseg, uint32_t* claim_init, int qb,
                               int qsel_from_back = 0, const int32_t* tsel = nullptr, const int32_t* ntsel = nullptr);
 int knn_mfma_qb(int max_n);  // query blocks per wave of K1m for this problem size, 0 = VALU kernels
-// mutual matching with a lazy reverse pass: only the columns claimed by an accepted forward match are
-// examined, by a range query with early exit instead of a second top-2 scan (match_kernels.hip)
+// mutual matching with a lazy reverse pass: only the columns claimed by an accepted forward match are examined
+// (match_kernels.hip) — on the matrix-core path by a per-frame plan + two sparse scans of K1m, on the VALU path
+// (> 8192 rows, STVO_KNN_MFMA=0) by a range query with early exit
 struct LazyScratch {
     uint2* knn12;
-    uint2* knn21;   // reused as int32 blocked[B][row_stride] by the verification pass
+    uint2* knn21;   // VALU path: reused as int32 blocked[B][row_stride].  Matrix-core path: [nseg_r][B][row_stride] reverse top-2
+                    // of the scanned columns in front, blocked[] and tsel[] (B * row_stride int32 each) in the last B * row_stride entries
     int32_t* cand;  // [B][row_stride] forward ratio-tested best
     int32_t* need;  // [B][row_stride] per-column claim (d0 << 16 | claimant), 0xFFFFFFFF = unclaimed
     int32_t* qsel;  // [B][row_stride] compacted flagged columns

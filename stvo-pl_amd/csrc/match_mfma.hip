@@ -22,7 +22,8 @@
 //     of a query is two VGPRs per lane and the final cross-lane merge is a single swap of the wave halves.
 //   * bit -> K element mapping: K step kk covers descriptor word kk; wave half hf, dword d, byte p holds bit
 //     (4 hf + d) + 8 p of that word.  Any mapping works as long as both operands use the same one (a sum over k).
-//     This one costs a shift + v_and_or_b32 per four elements: ((w << (7 - s)) & 0x80808080) | 0x40404040.
+//     This one costs shift + and + or per four elements: ((w << (7 - s)) & 0x80808080) | 0x40404040 (a single
+//     v_and_or_b32 with the mask in an SGPR was measured: no difference, the kernel is not bound by the VALU count).
 #include "kernels.h"
 
 namespace stvo {
