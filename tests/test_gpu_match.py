@@ -195,7 +195,7 @@ def test_match_valu_kernels_still_agree():
         pytest.skip("already the child run")
     env = dict(os.environ, STVO_KNN_MFMA="0")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q",
-                        "-k", "bit_exact or adversarial or key_edges or many_ties"], env=env, capture_output=True, text=True,
+                        "-k", "bit_exact or adversarial or key_edges or many_ties or fuzz"], env=env, capture_output=True, text=True,
                        timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
@@ -262,3 +262,22 @@ def test_match_reverse_plan_adversarial(hip, oracle):
             seen_heavy = seen_heavy or routes[1] > 0
     if os.environ.get("STVO_KNN_MFMA") != "0":
         assert seen_heavy
+
+
+def test_match_fuzz_sizes_and_entropy(hip, oracle):
+    """Seeded sweep over ragged sizes (tile and segment edges of both matchers), descriptor entropies (from tie-dominated
+    to random) and ratios; every case against the oracle, mutual and one-way."""
+    rng = np.random.default_rng(31337)
+    for case in range(120):
+        n1 = int(rng.integers(1, 700)); n2 = int(rng.integers(1, 700))
+        ent = int(rng.choice([8, 16, 24, 64, 256]))
+        nnr = float(rng.choice([0.5, 0.75, 0.8, 0.9, 1.0]))
+        d2 = rand_desc(rng, n2, ent); d1 = rand_desc(rng, n1, ent)
+        k = int(rng.integers(0, min(n1, n2) + 1))
+        if k:
+            d1[:k] = synth.flip_bits(rng, d2[rng.permutation(n2)[:k]], float(rng.choice([0.0, 0.02, 0.06, 0.12])))
+        mutual = int(case % 3 != 0)
+        got, n = hip.match(d1, d2, nnr, mutual)
+        exp, en = oracle.match(d1, d2, nnr, mutual)
+        assert np.array_equal(got, exp), (case, n1, n2, ent, nnr, mutual, np.nonzero(got != exp)[0][:10])
+        assert n == en
