@@ -3,12 +3,12 @@
 #   tools/collect_profiles.sh gpurun_out/<dir>
 R=$PWD; OUT=$R/$1; mkdir -p $OUT
 python bench.py > $OUT/bench_default.json 2>/dev/null
-python bench.py --no-overlap --no-cpu-baseline > $OUT/bench_inorder.json 2>/dev/null
+python bench.py --overlap --no-cpu-baseline > $OUT/bench_overlap.json 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d /tmp/kt -- python $R/bench.py > $OUT/bench_profiled.json 2>/dev/null
 cd $R; python tools/rocprof_summary.py stats $(find /tmp/kt -name "*.db" | head -1) > $OUT/kernel_stats.txt; rm -rf /tmp/kt
 for c in FETCH_SIZE WRITE_SIZE; do
-  cd /tmp; rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc_$c -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-overlap > /dev/null 2>&1
+  cd /tmp; rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc_$c -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
   cd $R; python tools/rocprof_summary.py pmc $(find /tmp/pmc_$c -name "*.db" | head -1) $c > $OUT/pmc_$c.txt; rm -rf /tmp/pmc_$c
 done
 tools/latency.sh $1/latency.txt > /dev/null
