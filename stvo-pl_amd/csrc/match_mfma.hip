@@ -53,6 +53,16 @@ __device__ __forceinline__ v4i expand_half(uint32_t w, int hf) {
     }
     return r;
 }
+// the same with a PER-LANE half (the two halves of a wave expand their own four bit positions; no divergent branch)
+__device__ __forceinline__ v4i expand_half_lane(uint32_t w, int hf) {
+    const int sh = 7 - 4 * hf;  // shift of dword 0; dword d uses sh - d >= 0
+    v4i r;
+    r.x = (int)(((w << sh) & 0x80808080u) | 0x40404040u);
+    r.y = (int)(((w << (sh - 1)) & 0x80808080u) | 0x40404040u);
+    r.z = (int)(((w << (sh - 2)) & 0x80808080u) | 0x40404040u);
+    r.w = (int)(((w << (sh - 3)) & 0x80808080u) | 0x40404040u);
+    return r;
+}
 __device__ __forceinline__ int med3_i32(int a, int b, int c) {
     int r;
     asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
@@ -94,6 +104,21 @@ __global__ __launch_bounds__(MF_BLOCK, (QB == 1 ? 4 : QB == 2 ? 3 : 1)) void ham
     const int seg = local % nseg;
     const int dir = dir0 + (local / nseg) / tiles;
     const int tile = (local / nseg) % tiles;
+    const size_t frame_off = (size_t)b * row_stride;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, col = lane & 31, hf = lane >> 5;
+    const int q_base = tile * ROWS;
+    const uint32_t* __restrict__ Q = reinterpret_cast<const uint32_t*>((dir == 0 ? d1 : d2) + frame_off * STVO_DESC_BYTES);
+    // The query rows of the forward scan do not depend on the frame's row counts: fetch them while n1 / n2 are still on
+    // their way (rows past the count are inside the frame's slot, are scanned like any other row and never stored).
+    uint4 qw[QB][2];
+    if (!GATHER) {
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            const int qi = min(q_base + (wv * QB + qb) * 32 + col, row_stride - 1);
+            qw[qb][0] = reinterpret_cast<const uint4*>(Q)[2 * qi];
+            qw[qb][1] = reinterpret_cast<const uint4*>(Q)[2 * qi + 1];
+        }
+    }
     const int na = n1[b], nb = n2[b];
     const int nq = GATHER ? nsel[b] : (dir == 0 ? na : nb);
     const int nt_all = TGATHER ? ntsel[b] : (dir == 0 ? nb : na);
@@ -101,13 +126,9 @@ __global__ __launch_bounds__(MF_BLOCK, (QB == 1 ? 4 : QB == 2 ? 3 : 1)) void ham
     const int seg_len = (((nt_all + nseg - 1) / nseg) + MF_TILE - 1) & ~(MF_TILE - 1);
     const int j0 = min(seg * seg_len, nt_all);
     const int nt = min(j0 + seg_len, nt_all);
-    const int q_base = tile * ROWS;
-    const size_t frame_off = (size_t)b * row_stride;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, col = lane & 31, hf = lane >> 5;
     if (claim_init && seg == 0 && dir == dir0)
         for (int c = q_base + tid; c < min(q_base + ROWS, row_stride); c += MF_BLOCK) claim_init[frame_off + c] = 0xFFFFFFFFu;
     if (q_base >= nq) return;  // workgroup-uniform
-    const uint32_t* __restrict__ Q = reinterpret_cast<const uint32_t*>((dir == 0 ? d1 : d2) + frame_off * STVO_DESC_BYTES);
     const uint32_t* __restrict__ T = reinterpret_cast<const uint32_t*>((dir == 0 ? d2 : d1) + frame_off * STVO_DESC_BYTES);
     uint2* __restrict__ out = (dir == 0 ? knn12 : knn21) + (size_t)seg * B * row_stride + frame_off;
 
@@ -119,14 +140,19 @@ __global__ __launch_bounds__(MF_BLOCK, (QB == 1 ? 4 : QB == 2 ? 3 : 1)) void ham
         const int qc = q < nq ? q : nq - 1;  // tail lanes scan a valid row and discard the result
         return GATHER ? qsel[frame_off + (qsel_from_back ? row_stride - 1 - qc : qc)] : qc;
     };
+    if (GATHER) {
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            const int qi = query_row(qb);
+            qw[qb][0] = reinterpret_cast<const uint4*>(Q)[2 * qi];
+            qw[qb][1] = reinterpret_cast<const uint4*>(Q)[2 * qi + 1];
+        }
+    }
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
-        const int qi = query_row(qb);
-        const uint4 w0 = reinterpret_cast<const uint4*>(Q)[2 * qi];
-        const uint4 w1 = reinterpret_cast<const uint4*>(Q)[2 * qi + 1];
-        const uint32_t w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+        const uint32_t w[8] = {qw[qb][0].x, qw[qb][0].y, qw[qb][0].z, qw[qb][0].w, qw[qb][1].x, qw[qb][1].y, qw[qb][1].z, qw[qb][1].w};
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) qf[qb][kk] = expand_half(~w[kk], hf);
+        for (int kk = 0; kk < 8; ++kk) qf[qb][kk] = expand_half_lane(~w[kk], hf);
     }
     // The train index enters through the C operand of the first matrix instruction of a tile: accumulator register r of
     // this lane belongs to tile row (r & 3) + 8 (r >> 2) + 4 hf.  Keys are therefore TILE-RELATIVE (index - first row of
