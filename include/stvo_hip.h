@@ -46,9 +46,9 @@ int stvo_ctx_destroy(stvo_ctx* ctx);
 int stvo_ctx_set_stream(stvo_ctx* ctx, void* hip_stream);
 int stvo_ctx_synchronize(stvo_ctx* ctx);
 /* Throughput option for the batched path.  enable = 1: stvo_track_batched_dev enqueues the pose kernel
- * on a second (context-owned) stream behind an event, so that the NEXT call's matching kernels — which
- * are integer-VALU bound and are then launched with an occupancy cap — run concurrently with this
- * call's latency-bound pose kernel.  Results of a call are complete after stvo_ctx_synchronize (or a
+ * on a second (context-owned) stream behind an event, so that the NEXT call's matching kernels run
+ * concurrently with this call's latency-bound pose kernel (worth ~7 % with the VALU matcher, which is then
+ * launched with an occupancy cap, ~1-2 % with the matrix-core matcher).  Results of a call are complete after stvo_ctx_synchronize (or a
  * device synchronise); hazards between consecutive calls on the same buffers are handled with events.
  * enable = 0 (default): strict stream order on the context's stream. */
 int stvo_ctx_set_overlap(stvo_ctx* ctx, int enable);
@@ -133,7 +133,7 @@ typedef struct stvo_track_batch_dev {
 int stvo_track_batched_dev(stvo_ctx* ctx, const stvo_track_batch_dev* batch, const stvo_cam* cam,
                            const stvo_opt_params* params, float nnr_points, float nnr_lines, int mutual);
 
-/* The matching stage alone (K1 + K2) on device-resident descriptor sets: m12[b][i]. */
+/* The matching stage alone (forward scan + mutual check) on device-resident descriptor sets: m12[b][i]. */
 int stvo_match_nnr_mutual_batched_dev(stvo_ctx* ctx, int B, int row_stride, const uint8_t* d1, const int32_t* n1,
                                       const uint8_t* d2, const int32_t* n2, float nnr, int mutual, int32_t* m12);
 
@@ -183,13 +183,14 @@ int stvo_seq_strides(const stvo_seq* seq, int32_t* stride_pts, int32_t* stride_l
 /* ---- measurement helpers --------------------------------------------------------------------- */
 /* Times `iters` launches of the named kernel stage on the context's stream with hipEvents and
  * returns the average milliseconds per launch (used by bench.py for the roofline line).
- * stage: 0 = hamming_knn2 (K1, the forward top-2 scan), 1 = pose kernel, 3 = hamming_verify (the mutual-check
- * range query) on the column claims left by the last stvo_track_batched_dev call. */
+ * stage: 0 = the forward top-2 scan (K1m hamming_knn2_mfma, or K1 hamming_knn2 for contexts beyond 8192 rows /
+ * STVO_KNN_MFMA=0), 1 = pose kernel, 3 = the reverse-check scans (K1m's two sparse scans, or K1v hamming_verify) on
+ * the column claims and lists left by the last stvo_track_batched_dev call. */
 int stvo_time_stage_dev(stvo_ctx* ctx, const stvo_track_batch_dev* batch, const stvo_cam* cam,
                         const stvo_opt_params* params, float nnr, int stage, int iters, float* avg_ms);
 
 /* Live timing of the dominant kernel INSIDE the batched path: with enable = 1 every stvo_track_batched_dev
- * call brackets its hamming_knn2 launch (forward top-2 scan) and its hamming_verify launch (mutual check) on
+ * call brackets its forward top-2 scan and its reverse (mutual) check — planning kernel + scans — on
  * the point descriptors with hipEvents on the stream they are launched on.  get_kernel_timing synchronises,
  * returns the average duration of each and the number of calls measured since the last get / set, and
  * resets the pool. */
