@@ -187,6 +187,26 @@ def test_match_beyond_matrix_core_index_range(oracle):
         ctx.close()
 
 
+def test_match_at_the_matrix_core_index_limit(oracle):
+    """Exactly 8192 rows per side: the largest frame K1m can index (13 index bits, tile-relative keys rebased 256 times),
+    with the true matches planted in the LAST rows so that the highest indices carry the answers."""
+    from stvo_amd import capi
+    ctx = capi.Context(device_id=0, max_rows=8192, max_batch=1)
+    try:
+        rng = np.random.default_rng(8192)
+        d2 = rand_desc(rng, 8192)
+        d1 = rand_desc(rng, 8192)
+        d1[-2500:] = synth.flip_bits(rng, d2[-2500:][rng.permutation(2500)], 0.05)
+        d1[:5] = d2[-5:]                      # distance 0 to the very last rows
+        for mutual in (1, 0):
+            got, n = ctx.match(d1, d2, 0.75, mutual)
+            exp, en = oracle.match(d1, d2, 0.75, mutual)
+            assert np.array_equal(got, exp) and n == en
+            assert (got[-2500:] >= 8192 - 2500).sum() > 2000
+    finally:
+        ctx.close()
+
+
 def test_match_valu_kernels_still_agree():
     """The VALU matcher (K1 + K1v, STVO_KNN_MFMA=0) is kept for sizes K1m cannot index and as the comparison point of
     the profiles: run this file's parity cases against it in a child process (the switch is read once per process)."""
