@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define STVO_ABI_VERSION 1
+#define STVO_ABI_VERSION 2
 #define STVO_MAX_ROWS_LIMIT 65535 /* packed (distance << 16 | index) keys */
 #define STVO_POSE_MAX_POINTS 2048 /* per frame pair: points owned per worker thread x worker threads of the pose kernel */
 #define STVO_POSE_MAX_LINES 512
@@ -153,7 +153,19 @@ int stvo_optimize_pose_batched_dev(stvo_ctx* ctx, const stvo_track_batch_dev* ba
 typedef struct stvo_seq stvo_seq;
 int stvo_seq_create(stvo_ctx* ctx, int B, int max_keypoints, int max_keylines, int img_cols, int img_rows,
                     const stvo_cam* cam, const stvo_match_params* mp, const stvo_opt_params* op, stvo_seq** out);
+/* As stvo_seq_create with one calibration and image size PER SEQUENCE: cams[B], img_cols[B], img_rows[B] (host arrays).
+ * BASELINE configs[4] runs KITTI sequences 00-07 side by side and the reference builds one PinholeStereoCamera per
+ * dataset (app/imagesStVO.cpp:66): config/dataset_params/kitti00-02.yaml, kitti03.yaml and kitti04-10.yaml differ in
+ * focal length, principal point, baseline and image size (1241x376, 1242x375, 1226x370), i.e. in the grid scale
+ * 64 / cols, 48 / rows of src/stereoFrame.cpp:47-48 as well. */
+int stvo_seq_create_multi(stvo_ctx* ctx, int B, int max_keypoints, int max_keylines, const int32_t* img_cols,
+                          const int32_t* img_rows, const stvo_cam* cams, const stvo_match_params* mp,
+                          const stvo_opt_params* op, stvo_seq** out);
 int stvo_seq_destroy(stvo_seq* seq);
+/* Number of raw frame slots (2 .. STVO_SEQ_MAX_SLOTS; 2 after create).  A throughput caller uploads several consecutive
+ * frames of every sequence once (stvo_seq_upload) and rotates stvo_seq_step_dev through the slots. */
+#define STVO_SEQ_MAX_SLOTS 16
+int stvo_seq_set_slots(stvo_seq* seq, int n_slots);
 /* One upload, one synchronisation, one small download per frame.  results: [B] (zeroed for the first frame, which
  * only builds the stereo sets); counts: optional [B][4] = stereo points, stereo lines, matched points, matched
  * lines of this frame. */
@@ -179,6 +191,24 @@ int stvo_seq_fetch_matches(stvo_seq* seq, const int32_t** m12_stereo_pts, const 
 int stvo_seq_fetch_inliers(stvo_seq* seq, const int32_t** inl_pts, const int32_t** inl_lines);
 /* Row strides of the arrays above. */
 int stvo_seq_strides(const stvo_seq* seq, int32_t* stride_pts, int32_t* stride_lines);
+
+/* Live per-stage timing of the pipeline (bench.py): with enable = 1 every stvo_seq_step_dev brackets, with hipEvents on
+ * the stream the kernels run on, stage 0 = the whole stereo point stage (cells + grid matcher + tail), 1 = the two
+ * grid_scan passes of the point grid matcher alone, 2 = the forward top-2 scan of the point f2f match (K1m), 3 = plan +
+ * reverse scans of its mutual check, 4 = the pose kernel.  get synchronises, returns the average milliseconds per stage over
+ * the steps measured since the last get / set (n_steps = the largest number of samples any stage has) and resets. */
+#define STVO_SEQ_NSTAGE 5
+int stvo_seq_set_stage_timing(stvo_seq* seq, int enable);
+int stvo_seq_get_stage_timing(stvo_seq* seq, float avg_ms[STVO_SEQ_NSTAGE], int32_t* n_steps);
+
+/* TEST HOOK: the grid structures the last step built ON THE DEVICE for sequence b (lines = 0: key-points, 1: key-lines):
+ * cell_start[3073] / cell_items (cell c = y * 64 + x owns cell_items[cell_start[c] .. cell_start[c+1]); the order inside a
+ * cell is unspecified) = GridStructure after src/stereoFrame.cpp:135-139 / :325-338 (lines: every LineIterator cell);
+ * cells_left [n_left][2 | 4] = the integer cells of the left features (:129-132, :318-322); cand_off[n_left + 1] / cand =
+ * the candidate set GridStructure::get (src/gridStructure.cpp:65-76) yields for every left feature with the stereo window
+ * (:141-143, :340-342; lines: the union over both end points, src/matching.cpp:213-215), ascending right ids. */
+int stvo_seq_debug_grid(stvo_seq* seq, int b, int lines, int32_t* cell_start, int32_t* cell_items, int32_t cap_items,
+                        int32_t* cells_left, int32_t* cand_off, int32_t* cand, int32_t cap_cand, int32_t* n_left);
 
 /* ---- measurement helpers --------------------------------------------------------------------- */
 /* Times `iters` launches of the named kernel stage on the context's stream with hipEvents and

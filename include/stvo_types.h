@@ -66,6 +66,10 @@ typedef struct stvo_match_params {
     double  ls_min_disp_ratio;
     double  orb_scale_factor;
     double  lsd_scale;
+    /* Config::minRatio12P() as the DOUBLE both matchGrid overloads compare with (src/matching.cpp:160,241), used by the
+     * stereo stage of the stvo_seq_* pipeline; 0 = (double)min_ratio_12_p.  (match() takes the ratio as float,
+     * src/matching.cpp:63, so the f2f stage keeps the float fields above.) */
+    double  min_ratio_12_p_d;
 } stvo_match_params;
 
 /* Status of one optimizePose call (the in-band failure modes of

@@ -338,7 +338,7 @@ int orc_stereo_points(const float* kp_l, const int32_t* oct_l, const uint8_t* de
     orc_grid_build(rcells, NULL, nr, cell_start, cell_items);
     stvo_grid_window w = {mp->matching_s_ws, 0, 0, 0}; /* :141-143 */
     int32_t* m12 = (int32_t*)malloc(sizeof(int32_t) * (size_t)nl);
-    orc_match_grid_points(coords, desc_l, nl, cell_start, cell_items, desc_r, nr, &w, (double)mp->min_ratio_12_p,
+    orc_match_grid_points(coords, desc_l, nl, cell_start, cell_items, desc_r, nr, &w, mp->min_ratio_12_p_d > 0.0 ? mp->min_ratio_12_p_d : (double)mp->min_ratio_12_p /* Config::minRatio12P(), a double */,
                           mp->best_lr_matches, m12);
     if (m12_raw) memcpy(m12_raw, m12, sizeof(int32_t) * (size_t)nl);
     int k = 0;
@@ -437,7 +437,7 @@ int orc_stereo_lines(const float* kl_l, const float* angle_l, const int32_t* oct
     orc_grid_build(ent_xy, ent_owner, ne, cell_start, cell_items);
     stvo_grid_window w = {mp->matching_s_ws, 0, 0, 0}; /* :340-342 */
     int32_t* m12 = (int32_t*)malloc(sizeof(int32_t) * (size_t)nl);
-    orc_match_grid_lines(coords, desc_l, nl, cell_start, cell_items, desc_r, nr, dir2, &w, (double)mp->min_ratio_12_p,
+    orc_match_grid_lines(coords, desc_l, nl, cell_start, cell_items, desc_r, nr, dir2, &w, mp->min_ratio_12_p_d > 0.0 ? mp->min_ratio_12_p_d : (double)mp->min_ratio_12_p /* Config::minRatio12P(), a double */,
                          mp->line_sim_th, mp->best_lr_matches, m12);
     if (m12_raw) memcpy(m12_raw, m12, sizeof(int32_t) * (size_t)nl);
     int k = 0;

@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void grid_finalize_kernel(GridBatch g) {
 }  // namespace
 
 // cover (zeroed here) -> scan -> finalize for a batch of frame pairs
-void launch_grid_batch(hipStream_t s, const GridBatch& g, bool lines) {
+void launch_grid_batch(hipStream_t s, const GridBatch& g, bool lines, hipEvent_t* scan_events) {
     if (g.B <= 0 || g.stride1 <= 0 || g.stride2 <= 0) return;
     const dim3 g1((g.stride1 + 255) / 256, g.B), g2((g.stride2 + 255) / 256, g.B), gc((g.n1p + 255) / 256, g.B), blk(256);
     // LDS staging column per thread: words64 x 256 x 8 B per workgroup (64 KB at 2048 right features)
@@ -340,15 +340,19 @@ void launch_grid_batch(hipStream_t s, const GridBatch& g, bool lines) {
             hipLaunchKernelGGL((grid_cover_kernel<true, true>), gc, blk, lds, s, g);
         else
             hipLaunchKernelGGL((grid_cover_kernel<true, false>), gc, blk, 0, s, g);
+        if (scan_events) (void)hipEventRecord(scan_events[0], s);
         hipLaunchKernelGGL((grid_scan_kernel<true, 1>), g2, blk, 0, s, g);
         hipLaunchKernelGGL((grid_scan_kernel<true, 2>), g2, blk, 0, s, g);
+        if (scan_events) (void)hipEventRecord(scan_events[1], s);
     } else {
         if (use_lds)
             hipLaunchKernelGGL((grid_cover_kernel<false, true>), gc, blk, lds, s, g);
         else
             hipLaunchKernelGGL((grid_cover_kernel<false, false>), gc, blk, 0, s, g);
+        if (scan_events) (void)hipEventRecord(scan_events[0], s);
         hipLaunchKernelGGL((grid_scan_kernel<false, 1>), g2, blk, 0, s, g);
         hipLaunchKernelGGL((grid_scan_kernel<false, 2>), g2, blk, 0, s, g);
+        if (scan_events) (void)hipEventRecord(scan_events[1], s);
     }
     hipLaunchKernelGGL(grid_finalize_kernel, g1, blk, 0, s, g);
 }

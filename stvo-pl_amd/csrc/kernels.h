@@ -83,6 +83,7 @@ struct PoseArgs {
     const int32_t* init_inl_l;
     const double* init_T;  // [B][16] or nullptr
     stvo_cam cam;
+    const stvo_cam* cams;  // [B] per-frame-pair calibration (device) or nullptr: `cam` for every pair
     stvo_opt_params prm;
     stvo_pose_result* results;
     int32_t* inl_p_out;  // [B][max_pts] or nullptr
@@ -118,6 +119,7 @@ struct GridBatch {
     int32_t* owner2;           // [B][stride2] scratch
     int32_t* m12;              // [B][stride1] out
 };
-void launch_grid_batch(hipStream_t s, const GridBatch& g, bool lines);
+// scan_events (optional): [0] / [1] are recorded on `s` before / after the two grid_scan passes
+void launch_grid_batch(hipStream_t s, const GridBatch& g, bool lines, hipEvent_t* scan_events = nullptr);
 
 }  // namespace stvo

@@ -556,7 +556,8 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_ibuf)[3 * (
     const bool prof = a.prof_out != nullptr;
     auto tick = [&]() -> long long { return prof ? (long long)__builtin_readcyclecounter() : 0ll; };
     const long long t_begin = tick();
-    const pm::Cam5 cam{a.cam.fx, a.cam.fy, a.cam.cx, a.cam.cy};
+    const stvo_cam cam_f = a.cams ? a.cams[f] : a.cam;  // per-sequence calibration (stvo_seq_create_multi) or one for the batch
+    const pm::Cam5 cam{cam_f.fx, cam_f.fy, cam_f.cx, cam_f.cy};
     const stvo_opt_params prm = a.prm;
 
     // ---------------- which records does this thread own?  (bitmasks only) ----------------

@@ -17,6 +17,7 @@
 //     8  pose kernel          optimizePose                           (src/stereoFrameHandler.cpp:307-392)
 //   then the two stereo-set buffers swap roles (updateFrame, :89-100).  One upload, one small download
 //   (B pose results + counters) and one synchronisation per frame.
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -25,6 +26,11 @@
 #include "ctx_internal.h"
 #include "pose_math.h"
 
+// The geometry filters of the tail kernels decide on thresholds (min_disp, ls_min_disp_ratio, stereo_overlap_th): no
+// fused multiply-adds, so that they round exactly like the reference's separate operations (and like the host mirror,
+// which is built with -ffp-contract=off).
+#pragma clang fp contract(off)
+
 namespace stvo {
 namespace {
 
@@ -32,8 +38,8 @@ constexpr int LENT = STVO_GRID_COLS + STVO_GRID_ROWS + 4;  // upper bound of Bre
 
 struct SeqDev {
     int B, K, M;
-    double inv_w, inv_h;
-    stvo_cam cam;
+    const stvo_cam* cams;   // [B] one calibration per sequence (config/dataset_params/kitti00-02 / 03 / 04-10.yaml differ)
+    const double* inv_wh;   // [B][2] 64 / cols, 48 / rows of the sequence's images (stereoFrame.cpp:47-48)
     stvo_match_params mp;
     // raw features of the current frame
     const float* kp_l;      // [B][K][2]
@@ -132,9 +138,10 @@ __global__ __launch_bounds__(256) void point_cells_kernel(SeqDev s) {
     const int b = blockIdx.x, tid = threadIdx.x;
     const int nl = s.n_kp_l[b], nr = s.n_kp_r[b];
     const size_t off = (size_t)b * s.K;
+    const double inv_w = s.inv_wh[2 * b], inv_h = s.inv_wh[2 * b + 1];
     for (int i = tid; i < nl; i += 256) {  // float * double -> int truncation (stereoFrame.cpp:132)
-        s.pxy_l[(off + i) * 2 + 0] = (int)((double)s.kp_l[(off + i) * 2 + 0] * s.inv_w);
-        s.pxy_l[(off + i) * 2 + 1] = (int)((double)s.kp_l[(off + i) * 2 + 1] * s.inv_h);
+        s.pxy_l[(off + i) * 2 + 0] = (int)((double)s.kp_l[(off + i) * 2 + 0] * inv_w);
+        s.pxy_l[(off + i) * 2 + 1] = (int)((double)s.kp_l[(off + i) * 2 + 1] * inv_h);
     }
     for (int c = tid; c < STVO_GRID_CELLS; c += 256) {
         hist[c] = 0;
@@ -143,16 +150,16 @@ __global__ __launch_bounds__(256) void point_cells_kernel(SeqDev s) {
     if (tid == 0) s_extra = 0;
     __syncthreads();
     for (int i = tid; i < nr; i += 256) {
-        const int x = (int)((double)s.kp_r[(off + i) * 2 + 0] * s.inv_w);
-        const int y = (int)((double)s.kp_r[(off + i) * 2 + 1] * s.inv_h);
+        const int x = (int)((double)s.kp_r[(off + i) * 2 + 0] * inv_w);
+        const int y = (int)((double)s.kp_r[(off + i) * 2 + 1] * inv_h);
         if (in_grid(x, y)) atomicAdd(&hist[y * STVO_GRID_COLS + x], 1);
     }
     __syncthreads();
     scan_cells(hist, s_wave, s.pstart + (size_t)b * (STVO_GRID_CELLS + 1));
     const int n_in = s.pstart[(size_t)b * (STVO_GRID_CELLS + 1) + STVO_GRID_CELLS];
     for (int i = tid; i < nr; i += 256) {
-        const int x = (int)((double)s.kp_r[(off + i) * 2 + 0] * s.inv_w);
-        const int y = (int)((double)s.kp_r[(off + i) * 2 + 1] * s.inv_h);
+        const int x = (int)((double)s.kp_r[(off + i) * 2 + 0] * inv_w);
+        const int y = (int)((double)s.kp_r[(off + i) * 2 + 1] * inv_h);
         int pos;
         if (in_grid(x, y)) {
             const int c = y * STVO_GRID_COLS + x;
@@ -176,6 +183,7 @@ __global__ __launch_bounds__(TAIL_BLOCK) void point_tail_kernel(SeqDev s) {
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nl = s.n_kp_l[b];
     const size_t off = (size_t)b * s.K;
+    const stvo_cam cam = s.cams[b];
     if (tid == 0) s_run = 0;
     __syncthreads();
     for (int base = 0; base < nl; base += TAIL_BLOCK) {
@@ -202,12 +210,12 @@ __global__ __launch_bounds__(TAIL_BLOCK) void point_tail_kernel(SeqDev s) {
         if (ok) {
             const size_t k = off + (size_t)(wbase + before);
             const double u = (double)s.kp_l[(off + i) * 2 + 0], v = (double)s.kp_l[(off + i) * 2 + 1];
-            const double bd = s.cam.b / disp;  // backProjection (src/pinholeStereoCamera.cpp:221-229)
+            const double bd = cam.b / disp;  // backProjection (src/pinholeStereoCamera.cpp:221-229)
             s.pl[k * 2 + 0] = u;
             s.pl[k * 2 + 1] = v;
-            s.P[k * 3 + 0] = bd * (u - s.cam.cx);
-            s.P[k * 3 + 1] = bd * (v - s.cam.cy);
-            s.P[k * 3 + 2] = bd * s.cam.fx;
+            s.P[k * 3 + 0] = bd * (u - cam.cx);
+            s.P[k * 3 + 1] = bd * (v - cam.cy);
+            s.P[k * 3 + 2] = bd * cam.fx;
             double sg = 1.0;  // PointFeature ctor: sigma2 = 1 / scale^(2 level) (src/stereoFeatures.cpp:41-47)
             const int level = s.oct_l[off + i];
             for (int t = 0; t < level; ++t) sg *= s.mp.orb_scale_factor;
@@ -269,12 +277,13 @@ __global__ __launch_bounds__(256) void line_cells_kernel(SeqDev s) {
     const int b = blockIdx.x, tid = threadIdx.x;
     const int nl = s.n_kl_l[b], nr = s.n_kl_r[b];
     const size_t off = (size_t)b * s.M;
+    const double inv_w = s.inv_wh[2 * b], inv_h = s.inv_wh[2 * b + 1];
     for (int i = tid; i < nl; i += 256) {  // :318-322
         const float* kl = s.kl_l + (off + i) * 4;
-        s.lxy_l[(off + i) * 4 + 0] = (int)((double)kl[0] * s.inv_w);
-        s.lxy_l[(off + i) * 4 + 1] = (int)((double)kl[1] * s.inv_h);
-        s.lxy_l[(off + i) * 4 + 2] = (int)((double)kl[2] * s.inv_w);
-        s.lxy_l[(off + i) * 4 + 3] = (int)((double)kl[3] * s.inv_h);
+        s.lxy_l[(off + i) * 4 + 0] = (int)((double)kl[0] * inv_w);
+        s.lxy_l[(off + i) * 4 + 1] = (int)((double)kl[1] * inv_h);
+        s.lxy_l[(off + i) * 4 + 2] = (int)((double)kl[2] * inv_w);
+        s.lxy_l[(off + i) * 4 + 3] = (int)((double)kl[3] * inv_h);
     }
     for (int c = tid; c < STVO_GRID_CELLS; c += 256) {
         hist[c] = 0;
@@ -283,14 +292,14 @@ __global__ __launch_bounds__(256) void line_cells_kernel(SeqDev s) {
     __syncthreads();
     for (int j = tid; j < nr; j += 256) {  // :325-338
         const float* kl = s.kl_r + (off + j) * 4;
-        const double vx = (double)(kl[2] - kl[0]) * s.inv_w;  // float difference, then * double (:331)
-        const double vy = (double)(kl[3] - kl[1]) * s.inv_h;
+        const double vx = (double)(kl[2] - kl[0]) * inv_w;  // float difference, then * double (:331)
+        const double vy = (double)(kl[3] - kl[1]) * inv_h;
         const double mag = sqrt(vx * vx + vy * vy);
         s.ldir[(off + j) * 2 + 0] = vx / mag;
         s.ldir[(off + j) * 2 + 1] = vy / mag;
         s.lperm[off + j] = j;  // few lines: identity scan order
         s.lrank[off + j] = j;
-        bresenham((double)kl[0] * s.inv_w, (double)kl[1] * s.inv_h, (double)kl[2] * s.inv_w, (double)kl[3] * s.inv_h,
+        bresenham((double)kl[0] * inv_w, (double)kl[1] * inv_h, (double)kl[2] * inv_w, (double)kl[3] * inv_h,
                   [&](int x, int y) {
                       if (in_grid(x, y)) atomicAdd(&hist[y * STVO_GRID_COLS + x], 1);
                   });
@@ -300,7 +309,7 @@ __global__ __launch_bounds__(256) void line_cells_kernel(SeqDev s) {
     int32_t* items = s.litems + (size_t)b * s.M * LENT;
     for (int j = tid; j < nr; j += 256) {
         const float* kl = s.kl_r + (off + j) * 4;
-        bresenham((double)kl[0] * s.inv_w, (double)kl[1] * s.inv_h, (double)kl[2] * s.inv_w, (double)kl[3] * s.inv_h,
+        bresenham((double)kl[0] * inv_w, (double)kl[1] * inv_h, (double)kl[2] * inv_w, (double)kl[3] * inv_h,
                   [&](int x, int y) {
                       if (in_grid(x, y)) {
                           const int c = y * STVO_GRID_COLS + x;
@@ -340,6 +349,7 @@ __global__ __launch_bounds__(256) void line_tail_kernel(SeqDev s) {
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nl = s.n_kl_l[b];
     const size_t off = (size_t)b * s.M;
+    const stvo_cam cam = s.cams[b];
     if (tid == 0) s_run = 0;
     __syncthreads();
     for (int base = 0; base < nl; base += 256) {
@@ -384,15 +394,15 @@ __global__ __launch_bounds__(256) void line_tail_kernel(SeqDev s) {
         for (int w = 0; w < wv; ++w) wbase += s_wave[w];
         if (ok) {
             const size_t k = off + (size_t)(wbase + before);
-            const double bds = s.cam.b / disp_s, bde = s.cam.b / disp_e;
+            const double bds = cam.b / disp_s, bde = cam.b / disp_e;
             s.spl[k * 2 + 0] = sp_l[0]; s.spl[k * 2 + 1] = sp_l[1];
             s.epl[k * 2 + 0] = ep_l[0]; s.epl[k * 2 + 1] = ep_l[1];
-            s.sP[k * 3 + 0] = bds * (sp_l[0] - s.cam.cx);
-            s.sP[k * 3 + 1] = bds * (sp_l[1] - s.cam.cy);
-            s.sP[k * 3 + 2] = bds * s.cam.fx;
-            s.eP[k * 3 + 0] = bde * (ep_l[0] - s.cam.cx);
-            s.eP[k * 3 + 1] = bde * (ep_l[1] - s.cam.cy);
-            s.eP[k * 3 + 2] = bde * s.cam.fx;
+            s.sP[k * 3 + 0] = bds * (sp_l[0] - cam.cx);
+            s.sP[k * 3 + 1] = bds * (sp_l[1] - cam.cy);
+            s.sP[k * 3 + 2] = bds * cam.fx;
+            s.eP[k * 3 + 0] = bde * (ep_l[0] - cam.cx);
+            s.eP[k * 3 + 1] = bde * (ep_l[1] - cam.cy);
+            s.eP[k * 3 + 2] = bde * cam.fx;
             s.le[k * 3 + 0] = le_l[0]; s.le[k * 3 + 1] = le_l[1]; s.le[k * 3 + 2] = le_l[2];
             const int level = s.oct_ll[off + i];
             double sg = 1.0;  // LineFeature ctor (src/stereoFeatures.cpp:107-115)
@@ -424,17 +434,26 @@ __global__ __launch_bounds__(256) void line_tail_kernel(SeqDev s) {
 struct stvo_seq {
     stvo_ctx* ctx = nullptr;
     int B = 0, K = 0, M = 0, frame_idx = 0;
-    stvo_cam cam{};
     stvo_match_params mp{};
     stvo_opt_params op{};
-    double inv_w = 0, inv_h = 0;
+    double ratio_grid = 0;         // Config::minRatio12P() as the DOUBLE matchGrid compares with (matching.cpp:160,241)
+    stvo_cam* d_cams = nullptr;    // [B] per-sequence calibration (device)
+    double* d_inv_wh = nullptr;    // [B][2] per-sequence grid scale (device)
     char* dev = nullptr;     // one allocation, carved below
     size_t dev_bytes = 0;
-    char* raw_host = nullptr;  // pinned mirror of the raw-feature block
+    // pinned mirrors of the raw-feature block: two, used alternately, each guarded by the event of the copy that last
+    // read it — packing frame k + 1 on the host overlaps the device work of frame k (no stream synchronisation per upload)
+    char* raw_host[2] = {nullptr, nullptr};
+    hipEvent_t ev_stage[2] = {nullptr, nullptr};
+    bool stage_busy[2] = {false, false};
+    int stage_next = 0;
     size_t raw_bytes = 0;
     stvo::SeqDev d{};          // pointers into `dev` (set = current)
     // carve results
-    char* raw_dev[2] = {nullptr, nullptr};  // two frame slots (push alternates; the throughput bench keeps both resident)
+    // raw frame slots: 0 / 1 are carved from `dev` (push alternates between them); stvo_seq_set_slots adds more so that a
+    // throughput caller can keep several frames of every sequence resident in HBM and rotate through them
+    std::vector<char*> raw_dev;
+    char* extra_raw = nullptr;
     struct Set {
         double *pl, *P, *s2;
         uint8_t* desc;
@@ -464,10 +483,15 @@ struct stvo_seq {
     hipEvent_t ev_fetch = nullptr;
     size_t m12_span = 0, inl_span = 0;  // bytes of the contiguous [m12s_p | m12s_l | m12p | m12l] and [inlp | inll] blocks
     hipEvent_t pev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // STVO_SEQ_PROF stage markers (developer aid)
+    // optional live stage timing (bench.py): event pairs around the kernels of every step, on the stream they run on
+    bool timing = false;
+    std::vector<hipEvent_t> tev;  // STVO_SEQ_NSTAGE start/stop pairs per step, grown on demand
+    size_t tev_used = 0;
     bool zero_copy = false;    // small batches: kernels write results / counts straight into out_host
-    bool raw_lines[2] = {false, false};  // slot holds at least one left and one right key-line
+    std::vector<char> raw_lines;  // slot holds at least one left and one right key-line
     bool set_lines[2] = {false, false};  // stereo set was built from a frame with key-lines
     bool last_lines = false;             // the last step ran the line stage
+    int last_slot = 0;                   // raw slot of the last step
     size_t off_kp_l, off_oct_l, off_desc_l, off_nkl, off_kp_r, off_desc_r, off_nkr, off_kl_l, off_oct_ll, off_ldesc_l,
         off_nll, off_kl_r, off_ldesc_r, off_nlr;
 };
@@ -487,26 +511,36 @@ struct Carver {
 
 extern "C" {
 
-int stvo_seq_create(stvo_ctx* ctx, int B, int max_keypoints, int max_keylines, int img_cols, int img_rows,
-                    const stvo_cam* cam, const stvo_match_params* mp, const stvo_opt_params* op, stvo_seq** out) {
-    if (!ctx || !out || B <= 0 || max_keypoints <= 0 || max_keylines < 0 || img_cols <= 0 || img_rows <= 0 || !cam ||
-        !mp || !op)
+int stvo_seq_create_multi(stvo_ctx* ctx, int B, int max_keypoints, int max_keylines, const int32_t* img_cols,
+                          const int32_t* img_rows, const stvo_cam* cams, const stvo_match_params* mp,
+                          const stvo_opt_params* op, stvo_seq** out) {
+    if (!ctx || !out || B <= 0 || max_keypoints <= 0 || max_keylines < 0 || !img_cols || !img_rows || !cams || !mp || !op)
         return STVO_ERR_INVALID_ARG;
+    for (int b = 0; b < B; ++b)
+        if (img_cols[b] <= 0 || img_rows[b] <= 0) return STVO_ERR_INVALID_ARG;
     if (max_keypoints > STVO_POSE_MAX_POINTS || max_keylines > STVO_POSE_MAX_LINES) return STVO_ERR_CAPACITY;
-    if (B > ctx->max_batch || max_keypoints > ctx->max_rows) return STVO_ERR_CAPACITY;
+    // the pipeline runs the context's matching scratch (cand / need / qsel: max_rows x max_batch ints, nsel: [5][max_batch])
+    // with K = max_keypoints rounded up to 64 as row stride: validate the ROUNDED figures
+    const int K = (max_keypoints + 63) & ~63;
+    const int M = max_keylines > 0 ? ((max_keylines + 63) & ~63) : 64;
+    if (B > ctx->max_batch || K > ctx->max_rows || (size_t)B * (size_t)K > (size_t)ctx->max_batch * (size_t)ctx->max_rows)
+        return STVO_ERR_CAPACITY;
+    if ((size_t)2 * B * K > ctx->knn_capacity) return STVO_ERR_CAPACITY;  // forward top-2 + reverse-check scratch (reverse_plan)
     if (!(mp->min_ratio_12_p <= 1.0f) || !(mp->min_ratio_12_l <= 1.0f)) return STVO_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     stvo_seq* s = new (std::nothrow) stvo_seq();
     if (!s) return STVO_ERR_HIP;
     s->ctx = ctx;
     s->B = B;
-    const int K = s->K = (max_keypoints + 63) & ~63;
-    const int M = s->M = max_keylines > 0 ? ((max_keylines + 63) & ~63) : 64;
-    s->cam = *cam;
+    s->K = K;
+    s->M = M;
     s->mp = *mp;
     s->op = *op;
-    s->inv_w = STVO_GRID_COLS / (double)img_cols;  // stereoFrame.cpp:47-48
-    s->inv_h = STVO_GRID_ROWS / (double)img_rows;
+    s->ratio_grid = mp->min_ratio_12_p_d > 0.0 ? mp->min_ratio_12_p_d : (double)mp->min_ratio_12_p;
+    if (!(s->ratio_grid <= 1.0)) {
+        delete s;
+        return STVO_ERR_INVALID_ARG;
+    }
     const size_t nb = (size_t)B;
     // ---- raw block (mirrored in pinned host memory, one H2D per frame)
     Carver rc;
@@ -528,6 +562,7 @@ int stvo_seq_create(stvo_ctx* ctx, int B, int max_keypoints, int max_keylines, i
     // ---- everything else
     Carver c;
     const size_t o_raw = c.take(s->raw_bytes), o_raw1 = c.take(s->raw_bytes);
+    const size_t o_cams = c.take(nb * sizeof(stvo_cam)), o_invwh = c.take(nb * 2 * 8);
     const size_t o_pxy = c.take(nb * K * 2 * 4), o_pstart = c.take(nb * (STVO_GRID_CELLS + 1) * 4), o_pitems = c.take(nb * K * 4),
                  o_prank = c.take(nb * K * 4), o_pperm = c.take(nb * K * 4);
     const size_t o_lxy = c.take(nb * M * 4 * 4), o_lstart = c.take(nb * (STVO_GRID_CELLS + 1) * 4),
@@ -562,31 +597,44 @@ int stvo_seq_create(stvo_ctx* ctx, int B, int max_keypoints, int max_keylines, i
     s->dev_bytes = c.off;
     bool ok = hip_ok(ctx, hipMalloc((void**)&s->dev, s->dev_bytes), "hipMalloc seq") &&
               hip_ok(ctx, hipMemset(s->dev, 0, s->dev_bytes), "hipMemset seq") &&
-              hip_ok(ctx, hipHostMalloc((void**)&s->raw_host, s->raw_bytes, hipHostMallocDefault), "hipHostMalloc seq") &&
+              hip_ok(ctx, hipHostMalloc((void**)&s->raw_host[0], s->raw_bytes, hipHostMallocDefault), "hipHostMalloc seq") &&
+              hip_ok(ctx, hipHostMalloc((void**)&s->raw_host[1], s->raw_bytes, hipHostMallocDefault), "hipHostMalloc seq") &&
               hip_ok(ctx, hipHostMalloc((void**)&s->out_host, nb * (sizeof(stvo_pose_result) + 16), hipHostMallocDefault),
                      "hipHostMalloc seq out") &&
               hip_ok(ctx, hipStreamCreateWithFlags(&s->line_stream, hipStreamNonBlocking), "hipStreamCreate seq") &&
               hip_ok(ctx, hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming), "hipEventCreate seq") &&
-              hip_ok(ctx, hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming), "hipEventCreate seq");
+              hip_ok(ctx, hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming), "hipEventCreate seq") &&
+              hip_ok(ctx, hipEventCreateWithFlags(&s->ev_stage[0], hipEventDisableTiming), "hipEventCreate seq") &&
+              hip_ok(ctx, hipEventCreateWithFlags(&s->ev_stage[1], hipEventDisableTiming), "hipEventCreate seq");
     s->zero_copy = B <= 16;
     if (!ok) {
-        if (s->dev) (void)hipFree(s->dev);
-        if (s->raw_host) (void)hipHostFree(s->raw_host);
-        if (s->out_host) (void)hipHostFree(s->out_host);
-        if (s->line_stream) (void)hipStreamDestroy(s->line_stream);
-        if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
-        if (s->ev_join) (void)hipEventDestroy(s->ev_join);
-        delete s;
+        stvo_seq_destroy(s);
         return STVO_ERR_HIP;
     }
-    std::memset(s->raw_host, 0, s->raw_bytes);
+    std::memset(s->raw_host[0], 0, s->raw_bytes);
+    std::memset(s->raw_host[1], 0, s->raw_bytes);
     char* D = s->dev;
-    s->raw_dev[0] = D + o_raw;
-    s->raw_dev[1] = D + o_raw1;
+    s->raw_dev = {D + o_raw, D + o_raw1};
+    s->raw_lines.assign(2, 0);
+    s->d_cams = (stvo_cam*)(D + o_cams);
+    s->d_inv_wh = (double*)(D + o_invwh);
+    {
+        std::vector<double> iw(2 * nb);
+        for (int b = 0; b < B; ++b) {
+            iw[2 * b + 0] = STVO_GRID_COLS / (double)img_cols[b];  // stereoFrame.cpp:47-48
+            iw[2 * b + 1] = STVO_GRID_ROWS / (double)img_rows[b];
+        }
+        ok = hip_ok(ctx, hipMemcpy(s->d_cams, cams, nb * sizeof(stvo_cam), hipMemcpyHostToDevice), "hipMemcpy cams") &&
+             hip_ok(ctx, hipMemcpy(s->d_inv_wh, iw.data(), iw.size() * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy inv_wh");
+        if (!ok) {
+            stvo_seq_destroy(s);
+            return STVO_ERR_HIP;
+        }
+    }
     stvo::SeqDev& d = s->d;
     d.B = B; d.K = K; d.M = M;
-    d.inv_w = s->inv_w; d.inv_h = s->inv_h;
-    d.cam = s->cam; d.mp = s->mp;
+    d.cams = s->d_cams; d.inv_wh = s->d_inv_wh;
+    d.mp = s->mp;
     d.pxy_l = (int32_t*)(D + o_pxy); d.pstart = (int32_t*)(D + o_pstart); d.pitems = (int32_t*)(D + o_pitems);
     d.prank = (int32_t*)(D + o_prank); d.pperm = (int32_t*)(D + o_pperm);
     d.lxy_l = (int32_t*)(D + o_lxy); d.lstart = (int32_t*)(D + o_lstart); d.litems = (int32_t*)(D + o_litems);
@@ -616,6 +664,39 @@ int stvo_seq_create(stvo_ctx* ctx, int B, int max_keypoints, int max_keylines, i
     return STVO_OK;
 }
 
+int stvo_seq_create(stvo_ctx* ctx, int B, int max_keypoints, int max_keylines, int img_cols, int img_rows,
+                    const stvo_cam* cam, const stvo_match_params* mp, const stvo_opt_params* op, stvo_seq** out) {
+    if (B <= 0 || !cam) return STVO_ERR_INVALID_ARG;
+    const std::vector<int32_t> cols((size_t)B, img_cols), rows((size_t)B, img_rows);
+    const std::vector<stvo_cam> cams((size_t)B, *cam);
+    return stvo_seq_create_multi(ctx, B, max_keypoints, max_keylines, cols.data(), rows.data(), cams.data(), mp, op, out);
+}
+
+// More raw frame slots than the two of stvo_seq_push: a throughput caller uploads n_slots consecutive frames of every
+// sequence once and rotates stvo_seq_step_dev through them, so that the per-step working set is not the same two frames
+// over and over.  Slots 0 / 1 keep their contents.
+int stvo_seq_set_slots(stvo_seq* s, int n_slots) {
+    if (!s || n_slots < 2 || n_slots > STVO_SEQ_MAX_SLOTS) return STVO_ERR_INVALID_ARG;
+    stvo_ctx* ctx = s->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (s->extra_raw) {
+        HIP_TRY(ctx, hipFree(s->extra_raw));
+        s->extra_raw = nullptr;
+    }
+    s->raw_dev.resize(2);
+    s->raw_lines.resize(2);
+    if (n_slots > 2) {
+        HIP_TRY(ctx, hipMalloc((void**)&s->extra_raw, (size_t)(n_slots - 2) * s->raw_bytes));
+        HIP_TRY(ctx, hipMemset(s->extra_raw, 0, (size_t)(n_slots - 2) * s->raw_bytes));
+        for (int k = 2; k < n_slots; ++k) {
+            s->raw_dev.push_back(s->extra_raw + (size_t)(k - 2) * s->raw_bytes);
+            s->raw_lines.push_back(0);
+        }
+    }
+    return STVO_OK;
+}
+
 int stvo_seq_destroy(stvo_seq* s) {
     if (!s) return STVO_OK;
     (void)hipSetDevice(s->ctx->device);
@@ -627,12 +708,17 @@ int stvo_seq_destroy(stvo_seq* s) {
     }
     if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
     if (s->ev_join) (void)hipEventDestroy(s->ev_join);
+    for (auto e : s->ev_stage)
+        if (e) (void)hipEventDestroy(e);
     for (auto e : s->pev)
         if (e) (void)hipEventDestroy(e);
+    for (auto e : s->tev) (void)hipEventDestroy(e);
     if (s->ev_fetch) (void)hipEventDestroy(s->ev_fetch);
     if (s->fetch_host) (void)hipHostFree(s->fetch_host);
     if (s->dev) (void)hipFree(s->dev);
-    if (s->raw_host) (void)hipHostFree(s->raw_host);
+    if (s->extra_raw) (void)hipFree(s->extra_raw);
+    for (auto h : s->raw_host)
+        if (h) (void)hipHostFree(h);
     if (s->out_host) (void)hipHostFree(s->out_host);
     delete s;
     return STVO_OK;
@@ -657,12 +743,23 @@ void bind_raw(stvo_seq* s, stvo::SeqDev& d, int slot) {
 // Copies one frame's features of all B sequences into device slot 0 / 1 (pinned gather + ONE H2D, asynchronous
 // on the context's stream).
 int stvo_seq_upload(stvo_seq* s, int slot, const stvo_frame_features* f) {
-    if (!s || !f || slot < 0 || slot > 1) return STVO_ERR_INVALID_ARG;
+    if (!s || !f || slot < 0 || slot >= (int)s->raw_dev.size()) return STVO_ERR_INVALID_ARG;
     stvo_ctx* ctx = s->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the pinned block may still be in flight from the last upload
     const int B = s->B, K = s->K, M = s->M;
-    char* H = s->raw_host;
+    // contract: a positive count needs its arrays (checked before anything is touched)
+    for (int b = 0; b < B; ++b) {
+        const bool kl = f->n_kp_l && f->n_kp_l[b] > 0, kr = f->n_kp_r && f->n_kp_r[b] > 0;
+        const bool ll = f->n_kl_l && f->n_kl_l[b] > 0 && s->op.has_lines, lr = f->n_kl_r && f->n_kl_r[b] > 0 && s->op.has_lines;
+        if ((kl && (!f->kp_l || !f->oct_l || !f->desc_l)) || (kr && (!f->kp_r || !f->desc_r)) ||
+            (ll && (!f->kl_l || !f->oct_ll || !f->ldesc_l)) || (lr && (!f->kl_r || !f->ldesc_r)))
+            return STVO_ERR_INVALID_ARG;
+    }
+    // two pinned staging blocks used alternately: only wait for the copy that last read THIS block (two uploads ago)
+    const int sb = s->stage_next;
+    s->stage_next ^= 1;
+    if (s->stage_busy[sb]) HIP_TRY(ctx, hipEventSynchronize(s->ev_stage[sb]));
+    char* H = s->raw_host[sb];
     int32_t* nkl = (int32_t*)(H + s->off_nkl);
     int32_t* nkr = (int32_t*)(H + s->off_nkr);
     int32_t* nll = (int32_t*)(H + s->off_nll);
@@ -703,20 +800,38 @@ int stvo_seq_upload(stvo_seq* s, int slot, const stvo_frame_features* f) {
     s->raw_lines[slot] = any_lines;
     if (s->raw_bytes <= (size_t)4 << 20) {
         // copy kernel instead of the DMA engine: ~5 us less latency for the ~200 KB of one frame
-        stvo::launch_copy16(ctx->stream, s->raw_host, s->raw_dev[slot], s->raw_bytes);
+        stvo::launch_copy16(ctx->stream, H, s->raw_dev[slot], s->raw_bytes);
     } else {
-        HIP_TRY(ctx, hipMemcpyAsync(s->raw_dev[slot], s->raw_host, s->raw_bytes, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(s->raw_dev[slot], H, s->raw_bytes, hipMemcpyHostToDevice, ctx->stream));
     }
+    HIP_TRY(ctx, hipEventRecord(s->ev_stage[sb], ctx->stream));
+    s->stage_busy[sb] = true;
     return STVO_OK;
 }
 
 // Runs the whole per-frame pipeline on the features resident in `slot` (asynchronous; no host transfer).
 int stvo_seq_step_dev(stvo_seq* s, int slot) {
-    if (!s || slot < 0 || slot > 1) return STVO_ERR_INVALID_ARG;
+    if (!s || slot < 0 || slot >= (int)s->raw_dev.size()) return STVO_ERR_INVALID_ARG;
     stvo_ctx* ctx = s->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int B = s->B, K = s->K, M = s->M;
     hipStream_t st = ctx->stream;
+    // live stage timing: STVO_SEQ_NSTAGE event pairs per step (see stvo_seq_get_stage_timing)
+    hipEvent_t* tev = nullptr;
+    if (s->timing) {
+        while (s->tev.size() < s->tev_used + 2 * STVO_SEQ_NSTAGE) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) break;
+            s->tev.push_back(e);
+        }
+        if (s->tev.size() >= s->tev_used + 2 * STVO_SEQ_NSTAGE) {
+            tev = s->tev.data() + s->tev_used;
+            s->tev_used += 2 * STVO_SEQ_NSTAGE;
+        }
+    }
+    auto mark = [&](int k, hipStream_t q) {
+        if (tev) (void)hipEventRecord(tev[k], q);
+    };
     // ---- stereo association of the new frame into set[cur]
     stvo_seq::Set& cs = s->set[s->cur];
     stvo_seq::Set& ps = s->set[s->cur ^ 1];
@@ -733,6 +848,7 @@ int stvo_seq_step_dev(stvo_seq* s, int slot) {
     const bool lines_prev = s->op.has_lines && s->set_lines[s->cur ^ 1];
     s->set_lines[s->cur] = lines_now;
     s->last_lines = lines_now;
+    s->last_slot = slot;
     // fork: everything enqueued so far (ingest, the previous step) happens-before the line stream's work
     const bool par = lines_now && s->op.has_points;
     hipStream_t sl = par ? s->line_stream : st;
@@ -743,6 +859,7 @@ int stvo_seq_step_dev(stvo_seq* s, int slot) {
     d.zero_nl = (!lines_now && s->op.has_points) ? 1 : 0;
     if (s->pev[0]) (void)hipEventRecord(s->pev[1], st);  // pev[0] was recorded before the ingest
     if (s->op.has_points) {
+        mark(0, st);
         hipLaunchKernelGGL(stvo::point_cells_kernel, dim3(B), dim3(256), 0, st, d);
         stvo::GridBatch g;
         std::memset(&g, 0, sizeof(g));
@@ -750,10 +867,11 @@ int stvo_seq_step_dev(stvo_seq* s, int slot) {
         g.cell_xy1 = d.pxy_l; g.d1 = d.desc_l; g.n1 = d.n_kp_l; g.cell_start = d.pstart; g.cell_items = d.pitems;
         g.d2 = d.desc_r; g.n2 = d.n_kp_r; g.dir2 = nullptr;
         g.w = stvo_grid_window{s->mp.matching_s_ws, 0, 0, 0};  // stereoFrame.cpp:141-143
-        g.ratio = (double)s->mp.min_ratio_12_p; g.line_sim_th = 0.0; g.mutual = s->mp.best_lr_matches;
+        g.ratio = s->ratio_grid; g.line_sim_th = 0.0; g.mutual = s->mp.best_lr_matches;
         g.cover = s->cover; g.rank = d.prank; g.perm = d.pperm; g.top2 = s->top2; g.owner2 = s->owner2; g.m12 = s->m12s_p;
-        stvo::launch_grid_batch(st, g, false);
+        stvo::launch_grid_batch(st, g, false, tev ? tev + 2 : nullptr);
         hipLaunchKernelGGL(stvo::point_tail_kernel, dim3(B), dim3(stvo::TAIL_BLOCK), 0, st, d);
+        mark(1, st);
     } else {
         HIP_TRY(ctx, hipMemsetAsync(cs.n, 0, (size_t)B * 4, st));
     }
@@ -765,7 +883,7 @@ int stvo_seq_step_dev(stvo_seq* s, int slot) {
         g.cell_xy1 = d.lxy_l; g.d1 = d.ldesc_l; g.n1 = d.n_kl_l; g.cell_start = d.lstart; g.cell_items = d.litems;
         g.d2 = d.ldesc_r; g.n2 = d.n_kl_r; g.dir2 = d.ldir;
         g.w = stvo_grid_window{s->mp.matching_s_ws, 0, 0, 0};  // :340-342
-        g.ratio = (double)s->mp.min_ratio_12_p /* sic, matching.cpp:241 */; g.line_sim_th = s->mp.line_sim_th;
+        g.ratio = s->ratio_grid /* sic, minRatio12P: matching.cpp:241 */; g.line_sim_th = s->mp.line_sim_th;
         g.mutual = s->mp.best_lr_matches;
         g.cover = s->cover_l; g.rank = d.lrank; g.perm = d.lperm; g.top2 = s->top2_l; g.owner2 = s->owner2_l; g.m12 = s->m12s_l;
         stvo::launch_grid_batch(sl, g, true);
@@ -779,18 +897,18 @@ int stvo_seq_step_dev(stvo_seq* s, int slot) {
         // ---- f2fTracking: prev stereo sets vs curr stereo sets
         const stvo::LazyScratch w{ctx->knn12, ctx->knn21, ctx->cand, ctx->need, ctx->qsel, ctx->nsel, ctx->knn_capacity};
         auto match_set = [&](hipStream_t q, const stvo::LazyScratch& ws, int stride, const uint8_t* da, const int32_t* na,
-                             const uint8_t* db, const int32_t* nb, float nnr, int32_t* m12) {
+                             const uint8_t* db, const int32_t* nb, float nnr, int32_t* m12, hipEvent_t* mev) {
             if (s->mp.best_lr_matches) {
-                stvo::launch_match_mutual_lazy(q, B, stride, da, na, db, nb, nnr, ws, m12, 0, nullptr);
+                stvo::launch_match_mutual_lazy(q, B, stride, da, na, db, nb, nnr, ws, m12, 0, nullptr, mev);
             } else {
                 const int nseg = stvo::knn_pick_nseg(B, stride, ws.knn_capacity);
                 stvo::launch_hamming_knn2(q, B, stride, stride, da, na, db, nb, ws.knn12, ws.knn21, 0, 0, 0, nullptr, nullptr, nseg);
                 stvo::launch_nnr_mutual(q, B, stride, ws.knn12, ws.knn21, na, nb, nnr, 0, m12, nseg);
             }
         };
-        if (s->op.has_points) match_set(st, w, K, ps.desc, ps.n, cs.desc, cs.n, s->mp.min_ratio_12_p, s->m12p);
+        if (s->op.has_points) match_set(st, w, K, ps.desc, ps.n, cs.desc, cs.n, s->mp.min_ratio_12_p, s->m12p, tev ? tev + 4 : nullptr);
         if (lines_prev && lines_now)
-            match_set(sl, s->lazy_l, M, ps.ldesc, ps.nl, cs.ldesc, cs.nl, s->mp.min_ratio_12_l, s->m12l);
+            match_set(sl, s->lazy_l, M, ps.ldesc, ps.nl, cs.ldesc, cs.nl, s->mp.min_ratio_12_l, s->m12l, nullptr);
         else if (lines_prev)  // nothing to match against: every prev line is unmatched
             HIP_TRY(ctx, hipMemsetAsync(s->m12l, 0xFF, (size_t)B * M * sizeof(int32_t), st));
         if (par) {  // join before optimizePose
@@ -811,10 +929,12 @@ int stvo_seq_step_dev(stvo_seq* s, int slot) {
         a.n_prev_lines = s->op.has_lines ? ps.nl : nullptr;
         a.prev_sP = ps.sP; a.prev_eP = ps.eP; a.prev_spl = ps.spl; a.prev_epl = ps.epl; a.prev_s2l = ps.s2lm;
         a.curr_le = cs.le; a.m12l = s->m12l;
-        a.cam = s->cam; a.prm = s->op;
+        a.cams = s->d_cams; a.prm = s->op;
         a.results = s->zero_copy ? reinterpret_cast<stvo_pose_result*>(s->out_host) : s->results;
         a.inl_p_out = s->inlp; a.inl_l_out = s->inll;
+        mark(8, st);
         TRY(stvo::launch_pose(st, a));
+        mark(9, st);
         if (s->pev[0]) (void)hipEventRecord(s->pev[4], st);
         if (s->fetch) stvo::launch_copy16(st, s->inlp, s->fetch_host + s->m12_span, s->inl_span);
     } else {
@@ -915,9 +1035,100 @@ int stvo_seq_fetch_inliers(stvo_seq* s, const int32_t** inl_pts, const int32_t**
     return STVO_OK;
 }
 
+int stvo_seq_set_stage_timing(stvo_seq* s, int enable) {
+    if (!s) return STVO_ERR_INVALID_ARG;
+    s->timing = enable != 0;
+    s->tev_used = 0;
+    return STVO_OK;
+}
+
+int stvo_seq_get_stage_timing(stvo_seq* s, float avg_ms[STVO_SEQ_NSTAGE], int32_t* n_steps) {
+    if (!s || !avg_ms || !n_steps) return STVO_ERR_INVALID_ARG;
+    stvo_ctx* ctx = s->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    double acc[STVO_SEQ_NSTAGE] = {0};
+    int cnt[STVO_SEQ_NSTAGE] = {0};
+    for (size_t k = 0; k + 2 * STVO_SEQ_NSTAGE <= s->tev_used; k += 2 * STVO_SEQ_NSTAGE)
+        for (int st = 0; st < STVO_SEQ_NSTAGE; ++st) {
+            float ms = 0.f;  // a stage that did not run in this step (first frame: no f2f, no pose) left its events unrecorded
+            if (hipEventElapsedTime(&ms, s->tev[k + 2 * st], s->tev[k + 2 * st + 1]) == hipSuccess) {
+                acc[st] += ms;
+                ++cnt[st];
+            }
+        }
+    (void)hipGetLastError();  // unrecorded events report an error that is not one
+    int n = 0;
+    for (int st = 0; st < STVO_SEQ_NSTAGE; ++st) {
+        avg_ms[st] = cnt[st] ? (float)(acc[st] / cnt[st]) : 0.f;
+        if (cnt[st] > n) n = cnt[st];
+    }
+    *n_steps = n;
+    s->tev_used = 0;
+    return STVO_OK;
+}
+
+// TEST HOOK.  The grid structures the LAST step built on the device for sequence b: the CSR bucket grid of the right
+// features (point_cells_kernel / line_cells_kernel: GridStructure + LineIterator of the reference), the integer cells of
+// the left features, and — decoded from grid_cover's bit matrix — the candidate set GridStructure::get returned for every
+// left feature.  tests/test_gpu_grid_ref.py compares them cell for cell with outputs of the reference's own
+// gridStructure.cpp / lineIterator.cpp (tests/golden/ref_device_grid_goldens.npz).
+int stvo_seq_debug_grid(stvo_seq* s, int b, int lines, int32_t* cell_start, int32_t* cell_items, int32_t cap_items,
+                        int32_t* cells_left, int32_t* cand_off, int32_t* cand, int32_t cap_cand, int32_t* n_left_out) {
+    if (!s || b < 0 || b >= s->B || !cell_start || !cell_items || !cells_left || !cand_off || !cand || !n_left_out || s->frame_idx == 0)
+        return STVO_ERR_INVALID_ARG;
+    stvo_ctx* ctx = s->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(s->line_stream));
+    const stvo::SeqDev& d = s->d;
+    const int R = lines ? s->M : s->K, xyw = lines ? 4 : 2;
+    const size_t items_stride = lines ? (size_t)s->M * stvo::LENT : (size_t)s->K;
+    // counts of the slot the last step ran on are not tracked per slot: read them through the last bound raw block
+    const char* Rw = s->raw_dev[s->last_slot];
+    int32_t nl = 0, nr = 0;
+    HIP_TRY(ctx, hipMemcpy(&nl, Rw + (lines ? s->off_nll : s->off_nkl) + (size_t)b * 4, 4, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(&nr, Rw + (lines ? s->off_nlr : s->off_nkr) + (size_t)b * 4, 4, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(cell_start, (lines ? d.lstart : d.pstart) + (size_t)b * (STVO_GRID_CELLS + 1),
+                           (STVO_GRID_CELLS + 1) * sizeof(int32_t), hipMemcpyDeviceToHost));
+    const int n_items = cell_start[STVO_GRID_CELLS];
+    if (n_items < 0 || (size_t)n_items > items_stride) return STVO_ERR_HIP;
+    if (n_items > cap_items) return STVO_ERR_CAPACITY;
+    if (n_items) HIP_TRY(ctx, hipMemcpy(cell_items, (lines ? d.litems : d.pitems) + (size_t)b * items_stride, (size_t)n_items * 4, hipMemcpyDeviceToHost));
+    if (nl) HIP_TRY(ctx, hipMemcpy(cells_left, (lines ? d.lxy_l : d.pxy_l) + (size_t)b * R * xyw, (size_t)nl * xyw * 4, hipMemcpyDeviceToHost));
+    // candidate sets: bit p % 64 of cover[p / 64][i1] <=> right feature perm[p] is a candidate of left feature i1
+    const int words64 = R / 64;
+    std::vector<unsigned long long> cover((size_t)words64 * R);
+    std::vector<int32_t> perm((size_t)R);
+    HIP_TRY(ctx, hipMemcpy(cover.data(), (lines ? s->cover_l : s->cover) + (size_t)b * words64 * R, cover.size() * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(perm.data(), (lines ? d.lperm : d.pperm) + (size_t)b * R, perm.size() * 4, hipMemcpyDeviceToHost));
+    int tot = 0;
+    std::vector<int32_t> row;
+    for (int i1 = 0; i1 < nl; ++i1) {
+        row.clear();
+        for (int w = 0; w < words64; ++w) {
+            unsigned long long m = cover[(size_t)w * R + i1];
+            while (m) {
+                const int p = w * 64 + __builtin_ctzll(m);
+                m &= m - 1ull;
+                if (p < nr) row.push_back(perm[p]);
+            }
+        }
+        std::sort(row.begin(), row.end());
+        cand_off[i1] = tot;
+        for (int id : row) {
+            if (tot < cap_cand) cand[tot] = id;
+            ++tot;
+        }
+    }
+    cand_off[nl] = tot;
+    *n_left_out = nl;
+    return tot > cap_cand ? STVO_ERR_CAPACITY : STVO_OK;
+}
+
 int stvo_seq_push(stvo_seq* s, const stvo_frame_features* f, stvo_pose_result* results, int32_t* counts) {
     if (!s || !f) return STVO_ERR_INVALID_ARG;
-    const int slot = s->frame_idx & 1;
+    const int slot = s->frame_idx & 1;  // (slots beyond the first two belong to callers of upload / step_dev)
     static const bool prof = std::getenv("STVO_SEQ_PROF") != nullptr;  // developer aid: host-side phase times
     if (!prof) {
         TRY(stvo_seq_upload(s, slot, f));

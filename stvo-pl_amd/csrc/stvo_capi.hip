@@ -174,7 +174,10 @@ int stvo_match_nnr_mutual_batched_dev(stvo_ctx* ctx, int B, int row_stride, cons
                                       const uint8_t* d2, const int32_t* n2, float nnr, int mutual, int32_t* m12) {
     if (!ctx || B < 0 || row_stride <= 0 || !d1 || !d2 || !n1 || !n2 || !m12 || !(nnr <= 1.0f))
         return STVO_ERR_INVALID_ARG;
-    if ((size_t)B * row_stride > (size_t)ctx->max_batch * ctx->max_rows || row_stride > STVO_MAX_ROWS_LIMIT)
+    // per-problem scratch (nsel: [5][max_batch]) and per-row scratch (cand / need / qsel: max_batch x max_rows; the knn
+    // arrays hold the forward top-2 plus the reverse-check lists: 2 x B x row_stride) are sized by the context
+    if (B > ctx->max_batch || (size_t)B * row_stride > (size_t)ctx->max_batch * ctx->max_rows || row_stride > STVO_MAX_ROWS_LIMIT ||
+        (size_t)2 * B * row_stride > ctx->knn_capacity)
         return STVO_ERR_CAPACITY;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (mutual) {
@@ -347,8 +350,9 @@ int check_batch(stvo_ctx* ctx, const stvo_track_batch_dev* b, bool need_desc) {
             return STVO_ERR_INVALID_ARG;
     }
     if (b->max_pts > STVO_POSE_MAX_POINTS || b->max_lines > STVO_POSE_MAX_LINES) return STVO_ERR_CAPACITY;
-    if ((size_t)b->B * (size_t)(b->max_pts > b->max_lines ? b->max_pts : b->max_lines) >
-        (size_t)ctx->max_batch * (size_t)ctx->max_rows)
+    const size_t rows = (size_t)(b->max_pts > b->max_lines ? b->max_pts : b->max_lines);
+    if (b->B > ctx->max_batch || (size_t)b->B * rows > (size_t)ctx->max_batch * (size_t)ctx->max_rows ||
+        (size_t)2 * b->B * rows > ctx->knn_capacity)
         return STVO_ERR_CAPACITY;
     return STVO_OK;
 }

@@ -332,6 +332,7 @@ bool StereoFrameHandler::pipelineStep(const FrameFeatures& feat, StereoFrame* fr
         mp.stereo_overlap_th = Config::stereoOverlapTh(); mp.line_horiz_th = Config::lineHorizTh();
         mp.ls_min_disp_ratio = Config::lsMinDispRatio(); mp.orb_scale_factor = Config::orbScaleFactor();
         mp.lsd_scale = Config::lsdScale();
+        mp.min_ratio_12_p_d = Config::minRatio12P();  // matchGrid compares with the double
         stvo_opt_params op{};
         op.mode = mode; op.has_points = Config::hasPoints(); op.has_lines = Config::hasLines();
         op.min_features = Config::minFeatures(); op.max_iters = Config::maxIters(); op.max_iters_ref = Config::maxItersRef();

@@ -19,7 +19,11 @@ EXPORTS = ["stvo_backend_name", "stvo_abi_version", "stvo_error_string", "stvo_c
            "stvo_match_grid_points", "stvo_match_grid_lines", "stvo_normal_eq", "stvo_optimize_pose",
            "stvo_track_batched_dev", "stvo_match_nnr_mutual_batched_dev", "stvo_optimize_pose_batched_dev",
            "stvo_time_stage_dev", "stvo_valu_peak_probe", "stvo_last_reverse_counts", "stvo_last_reverse_plan", "stvo_ctx_set_kernel_timing", "stvo_ctx_get_kernel_timing", "stvo_seq_create", "stvo_seq_destroy", "stvo_seq_enable_fetch", "stvo_seq_fetch_matches", "stvo_seq_fetch_inliers", "stvo_seq_strides",
-           "stvo_seq_push", "stvo_seq_upload", "stvo_seq_step_dev", "stvo_seq_read"]
+           "stvo_seq_push", "stvo_seq_upload", "stvo_seq_step_dev", "stvo_seq_read", "stvo_seq_create_multi", "stvo_seq_set_slots",
+           "stvo_seq_set_stage_timing", "stvo_seq_get_stage_timing", "stvo_seq_debug_grid"]
+
+SEQ_NSTAGE = 5  # include/stvo_hip.h: STVO_SEQ_NSTAGE
+SEQ_STAGE_NAMES = ("stereo_points_stage", "grid_scan", "hamming_knn2", "reverse_check", "pose")
 
 u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
 i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
@@ -112,6 +116,13 @@ def load():
     L.stvo_valu_peak_probe.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     L.stvo_seq_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Cam),
                                   C.POINTER(MatchParams), C.POINTER(OptParams), C.POINTER(C.c_void_p)]
+    L.stvo_seq_create_multi.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, i32p, i32p, C.c_void_p, C.POINTER(MatchParams),
+                                        C.POINTER(OptParams), C.POINTER(C.c_void_p)]
+    L.stvo_seq_set_slots.argtypes = [C.c_void_p, C.c_int]
+    L.stvo_seq_set_stage_timing.argtypes = [C.c_void_p, C.c_int]
+    L.stvo_seq_get_stage_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
+    L.stvo_seq_debug_grid.argtypes = [C.c_void_p, C.c_int, C.c_int, i32p, i32p, C.c_int32, i32p, i32p, i32p, C.c_int32,
+                                      C.POINTER(C.c_int32)]
     L.stvo_seq_destroy.argtypes = [C.c_void_p]
     L.stvo_seq_push.argtypes = [C.c_void_p, C.POINTER(FrameFeatures), C.c_void_p, i32p]
     L.stvo_seq_upload.argtypes = [C.c_void_p, C.c_int, C.POINTER(FrameFeatures)]
@@ -283,11 +294,48 @@ class Sequences:
     """B independent stereo sequences on the device-resident per-frame pipeline (stvo_seq_*)."""
 
     def __init__(self, ctx, B, max_kp, max_kl, cam, mp, op):
+        """cam: one camera dict for all B sequences, or a list of B dicts (stvo_seq_create_multi)."""
         self.ctx, self.B = ctx, B
         self.h = C.c_void_p()
-        camc = Cam.from_dict(cam)
-        ctx._chk(ctx.lib.stvo_seq_create(ctx.h, B, max_kp, max_kl, cam["width"], cam["height"], C.byref(camc), C.byref(mp),
-                                         C.byref(op), C.byref(self.h)))
+        if isinstance(cam, dict):
+            camc = Cam.from_dict(cam)
+            ctx._chk(ctx.lib.stvo_seq_create(ctx.h, B, max_kp, max_kl, cam["width"], cam["height"], C.byref(camc), C.byref(mp),
+                                             C.byref(op), C.byref(self.h)))
+        else:
+            assert len(cam) == B
+            cams = (Cam * B)(*[Cam.from_dict(c) for c in cam])
+            cols = np.array([c["width"] for c in cam], np.int32)
+            rows = np.array([c["height"] for c in cam], np.int32)
+            ctx._chk(ctx.lib.stvo_seq_create_multi(ctx.h, B, max_kp, max_kl, cols, rows, C.cast(cams, C.c_void_p), C.byref(mp),
+                                                   C.byref(op), C.byref(self.h)))
+
+    def set_slots(self, n):
+        self.ctx._chk(self.ctx.lib.stvo_seq_set_slots(self.h, n))
+
+    def set_stage_timing(self, on=True):
+        self.ctx._chk(self.ctx.lib.stvo_seq_set_stage_timing(self.h, 1 if on else 0))
+
+    def get_stage_timing(self):
+        """({stage name: average ms per step}, number of steps measured) since the last call."""
+        ms = (C.c_float * SEQ_NSTAGE)()
+        n = C.c_int32()
+        self.ctx._chk(self.ctx.lib.stvo_seq_get_stage_timing(self.h, ms, C.byref(n)))
+        return {k: float(ms[i]) for i, k in enumerate(SEQ_STAGE_NAMES)}, n.value
+
+    def debug_grid(self, b, lines):
+        """Device-built grid of sequence b after the last step: (cell_start[3073], cell_items, cells_left, cand_off, cand)."""
+        K, M = self.strides()
+        cap_items = (M * 116) if lines else K
+        cap_cand = (M * M) if lines else (K * 256)
+        start = np.empty(64 * 48 + 1, np.int32); items = np.empty(cap_items, np.int32)
+        cells = np.empty((M if lines else K) * (4 if lines else 2), np.int32)
+        off = np.empty((M if lines else K) + 1, np.int32); cand = np.empty(cap_cand, np.int32)
+        n = C.c_int32()
+        self.ctx._chk(self.ctx.lib.stvo_seq_debug_grid(self.h, b, 1 if lines else 0, start, items, cap_items, cells, off, cand, cap_cand,
+                                                      C.byref(n)))
+        nl = n.value
+        return (start, items[:start[-1]].copy(), cells[:nl * (4 if lines else 2)].reshape(nl, -1).copy(), off[:nl + 1].copy(),
+                cand[:off[nl]].copy())
 
     def close(self):
         if self.h:

@@ -27,7 +27,8 @@ class MatchParams(C.Structure):
     _fields_ = [("best_lr_matches", C.c_int32), ("matching_s_ws", C.c_int32), ("min_ratio_12_p", C.c_float),
                 ("min_ratio_12_l", C.c_float), ("max_dist_epip", C.c_double), ("min_disp", C.c_double),
                 ("line_sim_th", C.c_double), ("stereo_overlap_th", C.c_double), ("line_horiz_th", C.c_double),
-                ("ls_min_disp_ratio", C.c_double), ("orb_scale_factor", C.c_double), ("lsd_scale", C.c_double)]
+                ("ls_min_disp_ratio", C.c_double), ("orb_scale_factor", C.c_double), ("lsd_scale", C.c_double),
+                ("min_ratio_12_p_d", C.c_double)]
 
 
 class PoseResult(C.Structure):
@@ -83,4 +84,5 @@ def match_params(preset="kitti", **kw):
     base.update(kw)
     return MatchParams(base["best_lr_matches"], base["matching_s_ws"], base["min_ratio_12_p"], base["min_ratio_12_l"],
                        base["max_dist_epip"], base["min_disp"], base["line_sim_th"], base["stereo_overlap_th"],
-                       base["line_horiz_th"], base["ls_min_disp_ratio"], base["orb_scale_factor"], base["lsd_scale"])
+                       base["line_horiz_th"], base["ls_min_disp_ratio"], base["orb_scale_factor"], base["lsd_scale"],
+                       float(base["min_ratio_12_p"]))  # matchGrid compares with the double (src/matching.cpp:160,241)
