@@ -1,19 +1,29 @@
 #!/usr/bin/env python3
-"""bench.py — stereo frame-pairs/s through the hot path {f2f brute-force match + optimizePose} on MI355X.
+"""bench.py — stereo frame pairs/s through the per-frame hot path of PL-StVO on MI355X.
 
-One "step" = one pass of the hot path over one batch of B synthetic frame pairs that are already
-resident in HBM (BASELINE.json configs[1]: synthetic 1241x376 stereo, ~2000 ORB key-points per frame,
-brute-force point match + optimizePose, KITTI parameters).  Prints ONE JSON line (rank 0).
+One "step" = one pass of the WHOLE hot path over one batch: B independent stereo sequences advance by one frame each
+through the device-resident pipeline (stvo_seq_step_dev): stereo association of points and lines on the 64x48 grid
+(matchGrid), f2f brute-force mutual-NNR matching of points and lines (match), optimizePose — BASELINE.json configs[2]
+(KITTI-00-shaped stereo with points + lines, ~2000 ORB key-points and ~100 key-lines per image, config_kitti.yaml).
+The B streams of a rank cycle through the eight sequence ids of configs[4] with the calibration of their KITTI dataset
+(kitti00-02 / kitti03 / kitti04-10); stream g = rank + world * b is sequence g mod 8, i.e. sequence s lives on rank
+s mod G.  Every stream keeps `--slots` consecutive frames resident in HBM and the steps ping-pong through them, so the
+per-step working set (>= 4 x ~110 MB of raw features + the stereo sets and scratch) does not fit the 256 MB Infinity Cache.
+Prints ONE JSON line (rank 0).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--slots S]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Multi-GPU: independent sequences are sharded one batch per rank (weak scaling); the only collective
-is the timing barrier / max-reduction over RCCL — the path itself has no exchange step.
+`--gpus N` without a torch.distributed environment re-executes itself under torch.distributed.run with N ranks (one
+process per GPU, RCCL).  Multi-GPU: the path has no exchange step — the only collectives are the timing barrier and the
+max / sum reductions of the report (weak scaling: B streams per GPU).
 """
 import argparse
 import json
 import os
+import re
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,132 +33,243 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "stvo-pl_amd", "python"))
 
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
-# K1 issues, per (query, train) pair, 8 full-rate VALU ops (v_xor_b32: 32 lanes/clk/SIMD) and 11 half-rate
-# ones (v_bcnt_u32_b32, v_lshl_or_b32, v_med3_u32, v_min_u32: 16 lanes/clk/SIMD, measured with
-# tools/valu_rates.hip).  Roof of that mix at 256 CU x 4 SIMD x 2.4 GHz: 19 / (8/78.6e12 + 11/39.3e12).
-K1_LANE_OPS_PER_PAIR = 19
-VALU_PEAK_LANE_OPS = K1_LANE_OPS_PER_PAIR / (8 / 78.6e12 + 11 / 39.3e12)  # = 49.8e12
-
-
-# K1m (the default matcher) takes the 256-bit distances from the matrix cores: 2 x 256 int8 multiply-accumulate ops per
-# (query, train) pair.  Dense int8 peak = 2x the bf16 dense peak (MI355X_MICROARCH.md: bf16 ~2.5 PF dense, "i8 ~2x bf16
-# rate (2xK)"; the guide's own micro-benchmark floor for v_mfma_i32_32x32x32_i8 is 4404 TOP/s).
+# K1m takes the 256-bit distances from the matrix cores: 2 x 256 int8 multiply-accumulate ops per (query, train) pair.
+# Dense int8 peak = 2x the bf16 dense peak (MI355X_MICROARCH.md: bf16 ~2.5 PF dense, "i8 ~2x bf16 rate (2xK)"; the
+# guide's own micro-benchmark floor for v_mfma_i32_32x32x32_i8 is 4404 TOP/s).
 I8_MFMA_PEAK_TOPS = 5000.0
 I8_MFMA_MEASURED_FLOOR_TOPS = 4404.0
 K1M_OPS_PER_PAIR = 2 * 256
+PROFILE_TAG = "r02"          # committed rocprofv3 PMC passes the `traffic` figures are read from
 
 
-def committed_traffic(kernel="hamming_knn2_kernel", path=os.path.join(ROOT, "profiles", "r01_f_hbm_counters.txt")):
+def committed_traffic(kernel, tag=PROFILE_TAG):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, separate
     `--pmc` runs summarised by tools/rocprof_summary.py; values there are KB per dispatch).  None if unavailable."""
+    path = os.path.join(ROOT, "profiles", f"{tag}_hbm_counters.txt")
     try:
         tot = {}
         for line in open(path):
             f = line.split()
-            if len(f) >= 6 and f[4] in ("FETCH_SIZE", "WRITE_SIZE") and kernel in line:
+            if len(f) >= 6 and f[4] in ("FETCH_SIZE", "WRITE_SIZE") and kernel in line and f[4] not in tot:
                 tot[f[4]] = float(f[1]) * 1024.0
-        return tot["FETCH_SIZE"] + tot["WRITE_SIZE"] if len(tot) == 2 else None
+        return (tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) if len(tot) == 2 else None
     except (OSError, ValueError, KeyError):
         return None
 
 
-def cpu_baseline(frames, prm, budget_s=12.0):
-    """The oracle (scalar C port of the reference path) timed on this box's host cores, 1 thread,
-    on a bounded sample of the same workload.  Checker code: used here ONLY as the CPU baseline."""
+TRAFFIC_SRC = (f"bytes per launch = FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes over this command, read from the "
+               f"committed profiles/{PROFILE_TAG}_hbm_counters.txt (not re-measured by this run); null until that file exists")
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def stream_ids(rank, world, B):
+    """(sequence id 0..7, replica) of the B streams of this rank: global stream g = rank + world * b."""
+    from stvo_amd import synth
+    g = rank + world * np.arange(B)
+    return g % synth.CONFIG5_N_SEQUENCES, g // synth.CONFIG5_N_SEQUENCES
+
+
+def _gen_stream(args):
+    from stvo_amd import synth
+    s, rep, n_frames, n_pts, n_lines = args
+    return synth.make_config5_sequence(int(s), n_frames=n_frames, n_pts=n_pts, n_lines=n_lines, replica=int(rep))
+
+
+def generate_streams(seq_ids, replicas, n_frames, n_pts, n_lines):
+    jobs = [(s, r, n_frames, n_pts, n_lines) for s, r in zip(seq_ids, replicas)]
+    nproc = min(16, os.cpu_count() or 1, max(1, len(jobs) // 8))
+    if nproc <= 1:
+        return [_gen_stream(j) for j in jobs]
+    import multiprocessing as mp
+    with mp.get_context("fork").Pool(nproc) as pool:
+        return pool.map(_gen_stream, jobs, chunksize=max(1, len(jobs) // (4 * nproc)))
+
+
+def ping_pong(n_slots):
+    """0, 1, .., S-1, S-2, .., 1, 0, 1, ...: every transition is between temporally adjacent frames."""
+    period = list(range(n_slots)) + list(range(n_slots - 2, 0, -1))
+    k = 0
+    while True:
+        yield period[k % len(period)]
+        k += 1
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU legs (checker code used ONLY as the timed CPU baseline, after the timed GPU region)
+# ---------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(n_pts, n_lines, budget_s=12.0):
+    """The oracle (scalar C port of the reference path, oracle/stvo_oracle.c) on the same per-frame pipeline — stereo
+    association + f2f + optimizePose per frame — on this box's host cores, 1 thread, bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
+    import pipeline_ref
     from stvo_amd import synth
+    from stvo_amd.ctypes_types import match_params, opt_params
     orc = oracle_lib.load()
-    z3, z2 = np.zeros((0, 3)), np.zeros((0, 2))
-    done, t0 = 0, time.perf_counter()
-    # ~10-15 s of CPU work: the batch of this step, repeated until the time budget is used up
-    for fr in (frames[i % len(frames)] for i in range(4 * len(frames))):
-        m12, _ = orc.match(fr["prev_desc"], fr["curr_desc"], 0.75, 1)
-        sel = np.nonzero(m12 >= 0)[0]
-        rec = dict(P=fr["prev_P"][sel], pl_obs=fr["curr_pl"][m12[sel]], sigma2p=fr["prev_sigma2"][sel],
-                   inlier_p=np.ones(len(sel), np.int32), sP=z3, eP=z3, le_obs=z3, spl=z2, epl=z2, sigma2l=np.zeros(0),
-                   inlier_l=np.zeros(0, np.int32))
-        orc.optimize_pose(np.eye(4), synth.KITTI_CAM, prm, rec)
-        done += 1
-        if time.perf_counter() - t0 > budget_s:
-            break
-    dt = time.perf_counter() - t0
-    return {"value": done / dt, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
-            "sample": f"{done} frame pairs of the same workload (the step's batch, cycled), oracle/stvo_oracle.c (-O3), {dt:.1f} s, "
-                      f"host has {os.cpu_count()} cores"}
+    mp, op = match_params("kitti"), opt_params("kitti")
+    nf = 6
+    warm = synth.make_config5_sequence(0, n_frames=3, n_pts=n_pts, n_lines=n_lines, replica=900)
+    pipeline_ref.run_sequence(orc, warm, synth.config5_cam(0), mp, op)   # untimed: library load, page faults
+    done, t_used, k = 0, 0.0, 0
+    while t_used < budget_s:
+        s = k % synth.CONFIG5_N_SEQUENCES
+        sq = synth.make_config5_sequence(s, n_frames=nf, n_pts=n_pts, n_lines=n_lines, replica=901 + k // 8)
+        t0 = time.perf_counter()
+        pipeline_ref.run_sequence(orc, sq, synth.config5_cam(s), mp, op)
+        t_used += time.perf_counter() - t0
+        done += nf   # nf stereo associations, nf - 1 x (f2f + optimizePose): counted as nf frames, as the GPU steps are
+        k += 1
+    return {"value": done / t_used, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
+            "sample": f"{k} sequences x {nf} frames of the same workload (stereo association + f2f + optimizePose per frame), "
+                      f"oracle/stvo_oracle.c (-O3), {t_used:.1f} s of CPU work, host has {os.cpu_count()} cores",
+            "ms_per_frame": t_used / done * 1e3}
 
 
-def cpu_baseline_variants(frames, prm, budget_s=5.0):
-    """Two more CPU figures asked for by SURVEY.md §8(d), same oracle, same workload: (a) the reference's own thread
-    fan-out for this config — matches_12 and matches_21 on two threads (lrInParallel, src/matching.cpp:68-78), the
-    optimisation single-threaded; (b) independent frame pairs on many host threads (the oracle's C functions run
-    outside the GIL).  Reported next to `cpu_baseline`, never instead of it."""
+def cpu_baseline_threads(n_pts, n_lines, budget_s=6.0):
+    """Independent sequences on many host threads (the oracle's C functions run outside the GIL): the all-cores figure
+    SURVEY.md §8(d) asks for next to the 1-thread one.  Reported beside `cpu_baseline`, never instead of it."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from concurrent.futures import ThreadPoolExecutor
     import oracle_lib
+    import pipeline_ref
     from stvo_amd import synth
+    from stvo_amd.ctypes_types import match_params, opt_params
     orc = oracle_lib.load()
-    z3, z2 = np.zeros((0, 3)), np.zeros((0, 2))
-
-    def pose(fr, m12):
-        sel = np.nonzero(m12 >= 0)[0]
-        rec = dict(P=fr["prev_P"][sel], pl_obs=fr["curr_pl"][m12[sel]], sigma2p=fr["prev_sigma2"][sel],
-                   inlier_p=np.ones(len(sel), np.int32), sP=z3, eP=z3, le_obs=z3, spl=z2, epl=z2, sigma2l=np.zeros(0),
-                   inlier_l=np.zeros(0, np.int32))
-        orc.optimize_pose(np.eye(4), synth.KITTI_CAM, prm, rec)
-
-    out = {}
-    with ThreadPoolExecutor(2) as ex:  # (a)
-        done, t0 = 0, time.perf_counter()
-        while time.perf_counter() - t0 < budget_s:
-            fr = frames[done % len(frames)]
-            f21 = ex.submit(orc.match_nnr, fr["curr_desc"], fr["prev_desc"], 0.75)
-            m12, _ = orc.match_nnr(fr["prev_desc"], fr["curr_desc"], 0.75)
-            m21, _ = f21.result()
-            ok = (m12 >= 0) & (m21[np.maximum(m12, 0)] == np.arange(len(m12)))  # src/matching.cpp:80-86
-            pose(fr, np.where(ok, m12, -1))
-            done += 1
-        dt = time.perf_counter() - t0
-    out["cpu_baseline_fanout"] = {"value": done / dt, "unit": "frame-pairs/s", "cores": 2, "kind": "port",
-                                  "sample": f"{done} frame pairs, 12 || 21 matching on two threads like the reference, {dt:.1f} s"}
+    mp, op = match_params("kitti"), opt_params("kitti")
     nthr = min(32, os.cpu_count() or 1)
+    nf = 4
+    n_jobs = max(nthr, int(budget_s * nthr / (nf * 0.009)) // 2)
+    seqs = [synth.make_config5_sequence(k % 8, n_frames=nf, n_pts=n_pts, n_lines=n_lines, replica=950 + k // 8) for k in range(min(n_jobs, 2 * nthr))]
 
-    def one(i):
-        fr = frames[i % len(frames)]
-        m12, _ = orc.match(fr["prev_desc"], fr["curr_desc"], 0.75, 1)
-        pose(fr, m12)
+    def one(k):
+        pipeline_ref.run_sequence(orc, seqs[k % len(seqs)], synth.config5_cam(k % len(seqs) % 8), mp, op)
 
-    with ThreadPoolExecutor(nthr) as ex:  # (b)
-        n_jobs = max(2 * nthr, int(budget_s * 90 * nthr / 2))
+    with ThreadPoolExecutor(nthr) as ex:
         t0 = time.perf_counter()
         list(ex.map(one, range(n_jobs)))
         dt = time.perf_counter() - t0
-    out["cpu_baseline_threads"] = {"value": n_jobs / dt, "unit": "frame-pairs/s", "cores": nthr, "kind": "port",
-                                   "sample": f"{n_jobs} independent frame pairs on {nthr} host threads, {dt:.1f} s"}
+    return {"value": n_jobs * nf / dt, "unit": "frame-pairs/s", "cores": nthr, "kind": "port",
+            "sample": f"{n_jobs} independent sequences x {nf} frames on {nthr} host threads, {dt:.1f} s"}
+
+
+def single_stream_latency(local_rank, n_pts, n_lines, n_frames=61):
+    """Single-stream latency incl. every H2D / D2H copy and synchronisation (host feature buffers in, pose out) —
+    PCIe-inclusive, never `value`: (a) stvo_seq_push through the C-ABI in this process, (b) the imagesStVO loop through
+    the StereoFrameHandler mirror (stvo-pl_amd/bin/imagesStVO_synth, "Proc. time"), when the binary exists."""
+    from stvo_amd import capi, synth
+    from stvo_amd.ctypes_types import match_params, opt_params
+    cam = synth.KITTI_CAM
+    seq = synth.make_stereo_sequence(synth.frame_seed(77, 0), n_frames=n_frames, n_pts=n_pts, n_lines=n_lines, cam=cam)
+    out = {"workload": f"one KITTI-00-shaped sequence, {len(seq[0]['kp_l'])} key-points + {len(seq[0]['kl_l'])} key-lines per image, "
+                       f"{n_frames - 1} frame pairs after 10 warm-up frames; host buffers in, pose out (PCIe and synchronisation included)"}
+    ctx = capi.Context(device_id=local_rank, max_rows=2048, max_batch=1)
+    dev = capi.Sequences(ctx, 1, 2048, 512, cam, match_params("kitti"), opt_params("kitti"))
+    try:
+        packed = [dev._pack([fr]) for fr in seq]   # the caller's own buffers: packing them is not part of the path
+        import ctypes as C
+        from stvo_amd.ctypes_types import POSE_RESULT_DTYPE
+        res = np.zeros(1, dtype=POSE_RESULT_DTYPE); counts = np.zeros(4, np.int32)
+        ts = []
+        for k, (ff, keep) in enumerate(packed):
+            t0 = time.perf_counter()
+            ctx._chk(ctx.lib.stvo_seq_push(dev.h, C.byref(ff), res.ctypes.data_as(C.c_void_p), counts))
+            ts.append(time.perf_counter() - t0)
+        ts = np.array(ts[10:]) * 1e3
+        out["seq_push_ms"] = {"median": float(np.median(ts)), "mean": float(ts.mean()), "p90": float(np.percentile(ts, 90))}
+    finally:
+        dev.close()
+        ctx.close()
+    exe = os.path.join(ROOT, "stvo-pl_amd", "bin", "imagesStVO_synth")
+    if os.path.exists(exe):
+        try:
+            import tempfile
+            with tempfile.TemporaryDirectory() as td:
+                sp = os.path.join(td, "seq.bin")
+                synth.write_sequence(sp, seq, cam)
+                env = dict(os.environ, HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", str(local_rank)))
+                txt = subprocess.run([exe, sp, os.path.join(td, "res.bin"), "--preset", "kitti"], capture_output=True, text=True,
+                                     timeout=120, env=env).stdout
+                m = re.search(r"mean Proc\. time ([0-9.]+) ms", txt)
+                if m:
+                    out["handler_ms"] = {"mean": float(m.group(1)), "what": "StereoFrameHandler mirror (insertStereoPair + optimizePose), "
+                                                                            "app/imagesStVO.cpp:95-98 timed region"}
+        except (OSError, subprocess.SubprocessError):
+            pass
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def configs1_leg(ctx_dev, rank, B=512, n=2000, steps=10):
+    """The round-1 headline, kept as an extra key: BASELINE configs[1] — f2f brute-force mutual-NNR match of 2000 x 2000
+    ORB rows + optimizePose for B frame pairs resident in HBM (stvo_track_batched_dev)."""
+    import torch
+    from stvo_amd import capi, synth
+    from stvo_amd.ctypes_types import opt_params
+    from stvo_amd.devbatch import TrackBatch
+    frames = [synth.make_f2f_points(synth.frame_seed(rank, k), n=n) for k in range(B)]
+    batch = TrackBatch(frames, max_pts=2048, max_lines=0, device=ctx_dev)
+    prm = opt_params("kitti", has_lines=0)
+    ctx = capi.Context(device_id=int(ctx_dev.split(":")[1]), max_rows=2048, max_batch=B)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        for _ in range(3):
+            ctx.track_batched(batch, synth.KITTI_CAM, prm, 0.75, 0.75, 1)
+        ctx.synchronize(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ctx.track_batched(batch, synth.KITTI_CAM, prm, 0.75, 0.75, 1)
+        ctx.synchronize(); torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        ok = float((batch.results()["status"] == 0).mean())
+    finally:
+        ctx.close()
+    return {"workload": "BASELINE configs[1]: f2f brute-force mutual-NNR point match (2000 x 2000 ORB rows) + optimizePose, "
+                        f"{B} frame pairs per step resident in HBM (the same batch every step: fits the Infinity Cache)",
+            "value": B * steps / dt, "unit": "frame-pairs/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+            "committed_pose_fraction": ok}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=512, help="frame pairs per step per GPU")
-    ap.add_argument("--keypoints", type=int, default=2000)
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--batch", type=int, default=512, help="independent stereo sequences (streams) per GPU")
+    ap.add_argument("--slots", type=int, default=4, help="consecutive frames of every stream kept resident in HBM")
+    ap.add_argument("--points", type=int, default=1650, help="landmarks per stream; + 20 %% distractors ~ 2000 key-points per image")
+    ap.add_argument("--lines", type=int, default=85, help="3-D segments per stream; + 20 %% distractors ~ 100 key-lines per image")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--overlap", action="store_true",
-                    help="run the pose kernel of batch s on a second stream beside the matching kernels of batch s+1 (+2 %%; "
-                         "both kernels then share the CUs and per-kernel durations are no longer those of the kernel alone)")
-    ap.add_argument("--no-overlap", action="store_true", help="accepted for compatibility: strict stream order is the default")
+    ap.add_argument("--no-extras", action="store_true", help="skip the latency / configs[1] / correlated-descriptor legs")
     args = ap.parse_args()
 
-    import torch
-    from stvo_amd import capi, synth
-    from stvo_amd.ctypes_types import opt_params
-    from stvo_amd.devbatch import TrackBatch
+    # ---- `--gpus N` from a plain `python bench.py`: spawn N ranks (one process per GPU) under torch.distributed.run
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import torch
+        n_vis = torch.cuda.device_count()
+        if n_vis < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {n_vis} GPU(s) visible")
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
 
-    from stvo_amd import shard
+    from stvo_amd import shard, synth
     world, rank, local_rank = shard.env_world()
+    # synthetic streams first: the generator forks worker processes, which must happen before this process touches the GPU
+    B, S = args.batch, max(2, min(args.slots, 16))
+    seq_ids, replicas = stream_ids(rank, world, B)
+    streams = generate_streams(seq_ids, replicas, S, args.points, args.lines)
+
+    import torch
+    from stvo_amd import capi
+    from stvo_amd.ctypes_types import match_params, opt_params
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -156,28 +277,23 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X: the product path has no CPU fallback")
+    if args.gpus != world and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but the torch.distributed world has {world} rank(s); reporting n_gpus = {world}", file=sys.stderr)
     torch.cuda.set_device(local_rank)
-    dev = f"cuda:{local_rank}"
+    dev_name = f"cuda:{local_rank}"
 
-    B, n = args.batch, args.keypoints
-    max_pts = 2048 if n <= 2048 else None
-    if max_pts is None:
-        raise SystemExit("key-points per frame exceed STVO_POSE_MAX_POINTS (2048)")
-    # rank r processes sequence r (SURVEY.md §8d config 5 sharding: sequence s -> GPU s mod G)
-    frames = [synth.make_f2f_points(synth.frame_seed(rank, k), n=n) for k in range(B)]
-    batch = TrackBatch(frames, max_pts=max_pts, max_lines=0, device=dev)
-    prm = opt_params("kitti", has_lines=0)
-    ctx = capi.Context(device_id=local_rank, max_rows=max_pts, max_batch=B)
-    stream = torch.cuda.current_stream()
-    ctx.set_stream(stream.cuda_stream)
-    overlap = args.overlap and not args.no_overlap
-    ctx.set_overlap(overlap)
-
-    def step():
-        ctx.track_batched(batch, synth.KITTI_CAM, prm, 0.75, 0.75, 1)
+    cams = [synth.config5_cam(int(s)) for s in seq_ids]
+    mp, op = match_params("kitti"), opt_params("kitti")
+    ctx = capi.Context(device_id=local_rank, max_rows=2048, max_batch=B)
+    pipe = capi.Sequences(ctx, B, 2048, 512, cams, mp, op)
+    pipe.set_slots(S)
+    for k in range(S):
+        pipe.upload(k, [st[k] for st in streams])
+    ctx.synchronize()
+    order = ping_pong(S)
 
     for _ in range(args.warmup):
-        step()
+        pipe.step_dev(next(order))
     ctx.synchronize()
     torch.cuda.synchronize()
     if dist is not None:
@@ -185,105 +301,110 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
-    ctx.synchronize()           # both of the context's streams
+        pipe.step_dev(next(order))
+    ctx.synchronize()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    # whole-job frame pairs (sum over ranks) and the slowest rank's time (max over ranks)
-    frames_total, dt = shard.aggregate(dist, B * args.steps, dt, device=dev)
+    frames_total, dt = shard.aggregate(dist, B * args.steps, dt, device=dev_name)   # sum of frame pairs, max of seconds
 
-    # sanity: the timed work produced real poses
-    res = batch.results()
+    res, counts = pipe.read()   # sanity: the timed work produced real poses
     ok_frac = float((res["status"] == 0).mean())
 
     out = None
     if rank == 0:
-        # The dominant kernel is the forward top-2 scan (K1m hamming_knn2_mfma_kernel<2, 0>, or K1 hamming_knn2_kernel with
-        # STVO_KNN_MFMA=0): ONE launch per step, every prev row against every curr row.  The reverse (mutual) check is a
-        # per-frame planning kernel plus two sparse scans of the same kernel family.
-        # K1m is timed LIVE in a second pass over the same steps (same batch, same stream order): hipEvent pairs
-        # around every launch, on the stream it is launched on.  The pass is separate from the one that produced
-        # `value` because the event markers cost throughput (each is a barrier packet).
-        ctx.set_kernel_timing(True)
+        # ---- per-kernel figures, measured LIVE in a second pass over the same steps (same streams, same slot order): hipEvent pairs
+        # around the kernels on the stream they run on.  Separate from the pass that produced `value` because every marker is a
+        # barrier packet that keeps a kernel from starting under the tail of the previous one.
+        pipe.set_stage_timing(True)
+        pairs, n1s, n2s, nps, nls, grid_b = [], [], [], [], [], []
+        prev_counts = counts
         for _ in range(args.steps):
-            step()
-        ctx.synchronize()
-        k1_ms, verify_ms, k1_calls = ctx.get_kernel_timing()
-        ctx.set_kernel_timing(False)
-        k1_solo_ms = ctx.time_stage(batch, synth.KITTI_CAM, prm, 0.75, 0, 10)  # same launch with the GPU to itself
-        verify_solo_ms = ctx.time_stage(batch, synth.KITTI_CAM, prm, 0.75, 3, 10)
-        pose_ms = ctx.time_stage(batch, synth.KITTI_CAM, prm, 0.75, 1, 10)
-        n1v = batch.host["n_prev_pts"].astype(np.int64); n2v = batch.host["n_curr_pts"].astype(np.int64)
-        nsel = ctx.last_reverse_counts(B).astype(np.int64)
-        alg_bytes = float((32 * (n1v + n2v) + 8 * n1v).sum())   # descriptors in once, one packed top-2 per prev row out
-        pairs = float((n1v * n2v).sum())                        # distance evaluations per launch
-        achieved_gbs = alg_bytes / (k1_ms * 1e-3) / 1e9
-        lane_ops = pairs * K1_LANE_OPS_PER_PAIR
-        mfma = os.environ.get("STVO_KNN_MFMA", "2") != "0" and max_pts <= 8192   # the library's own rule (knn_mfma_qb)
-        k1_name = "hamming_knn2_mfma_kernel<2, 0>" if mfma else "hamming_knn2_kernel"
+            pipe.step_dev(next(order))
+            r_k, c_k = pipe.read()
+            n_prev, n_curr = prev_counts[:, 0].astype(np.int64), c_k[:, 0].astype(np.int64)
+            pairs.append(float((n_prev * n_curr).sum())); n1s.append(float(n_prev.sum())); n2s.append(float(n_curr.sum()))
+            nps.append(float(c_k[:, 2].sum())); nls.append(float(c_k[:, 3].sum()))
+            prev_counts = c_k
+        stage_ms, n_timed = pipe.get_stage_timing()
+        pipe.set_stage_timing(False)
+        n_kp = np.array([[len(st[k]["kp_l"]) + len(st[k]["kp_r"]) for k in range(S)] for st in streams], np.float64)  # [B][S]
+        pairs_l, n1_l, n2_l, np_l, nl_l = (float(np.mean(v)) for v in (pairs, n1s, n2s, nps, nls))
+
+        # K1m forward scan: every prev stereo point against every curr stereo point, one launch per step
+        k1_ms = stage_ms["hamming_knn2"]
+        ops = pairs_l * K1M_OPS_PER_PAIR
+        k1_bytes = 32.0 * (n1_l + n2_l) + 8.0 * n1_l      # descriptors in once, one packed top-2 per prev row out
+        k1_tops = ops / (k1_ms * 1e-3) / 1e12 if k1_ms > 0 else 0.0
+        timing = "hipEvent pairs around the launch(es), on the launch stream, over a second pass of the same K steps"
+        k1_name = "hamming_knn2_mfma_kernel<2, 0>"
+        roofline = {"kernel": k1_name, "bound": "mfma", "achieved": k1_tops, "peak": I8_MFMA_PEAK_TOPS, "unit": "TFLOP/s",
+                    "unit_note": "int8 multiply-accumulate ops (TOP/s); 2 x 256 per 256-bit Hamming distance",
+                    "frac": k1_tops / I8_MFMA_PEAK_TOPS, "traffic": committed_traffic(k1_name), "traffic_source": TRAFFIC_SRC,
+                    "algorithmic_ops_per_launch": ops, "algorithmic_bytes_per_launch": k1_bytes, "avg_launch_ms": k1_ms,
+                    "timing": timing, "frac_of_measured_mfma_floor": k1_tops / I8_MFMA_MEASURED_FLOOR_TOPS,
+                    "hbm_view_frac": k1_bytes / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if k1_ms > 0 else 0.0,
+                    "note": "dominant kernel: all-pairs Hamming distances of the f2f point match as an int8 Gram matrix on the matrix "
+                            "cores, top-2 fold in the shadow of the matrix instructions; ~56 k bit-operations per compulsory byte, so "
+                            "HBM is idle by construction (hbm_view_frac)"}
+        # pose kernel: priced against HBM (SURVEY.md §8d gn_accumulate + remove_outliers: records once, m12 + inlier masks, result)
+        pose_ms = stage_ms["pose"]
+        pose_bytes = 52.0 * np_l + 116.0 * nl_l + 8.0 * n1_l + 8.0 * (B * 64.0) + B * 840.0
+        pose_gbs = pose_bytes / (pose_ms * 1e-3) / 1e9 if pose_ms > 0 else 0.0
+        pose_name = "pose_kernel"
+        roofline_pose = {"kernel": pose_name, "bound": "hbm", "achieved": pose_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": pose_gbs / HBM_PEAK_GBS, "traffic": committed_traffic(pose_name), "traffic_source": TRAFFIC_SRC,
+                         "algorithmic_bytes_per_launch": pose_bytes, "avg_launch_ms": pose_ms, "timing": timing,
+                         "note": "optimizePose for B frame pairs in one launch; algorithmic bytes = 52 B per matched point + 116 B per "
+                                 "matched line (read once) + m12 and inlier masks (4 + 4 B per prev stereo feature) + 840 B result"}
+        # grid scan (two passes of the point grid matcher): SURVEY.md §8d match_grid bytes
+        scan_ms = stage_ms["grid_scan"]
+        n_kp_step = float(n_kp.mean(axis=1).sum())   # left + right key-points of one step, all streams
+        scan_bytes = 32.0 * n_kp_step + 12.0 * n_kp_step / 2 + 4.0 * (3073.0 * B + n_kp_step / 2)
+        scan_gbs = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+        scan_name = "grid_scan_kernel<false"
+        roofline_grid = {"kernel": "grid_scan_kernel<false, 1> + <false, 2>", "bound": "hbm", "achieved": scan_gbs, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": scan_gbs / HBM_PEAK_GBS, "traffic": committed_traffic(scan_name), "traffic_source": TRAFFIC_SRC,
+                         "algorithmic_bytes_per_launch": scan_bytes, "avg_launch_ms": scan_ms, "timing": timing,
+                         "note": "the two scan passes of matchGrid (points): 32 (N1 + N2) + 8 N1 + 4 (3073 + N2) + 4 N1 bytes per frame; "
+                                 "~35 k distance evaluations per frame — bound by the issue of the sparse row walk, not by HBM or VALU rate"}
+        resident_mb = S * B * (2 * 2048 * (8 + 32) + 2048 * 4 + 2 * 512 * (16 + 32) + 512 * 4) / 1e6
         out = {
             "metric": "stereo frames/s (match+optimizePose)", "value": frames_total / dt, "unit": "frame-pairs/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i8+f64",
-            "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: synthetic 1241x376 stereo, 2000 ORB key-points/frame, "
-                                   "brute-force mutual-NNR point match + optimizePose (config_kitti.yaml), "
-                                   "batched independent frame pairs resident in HBM",
-                       "frame_pairs_per_step_per_gpu": B, "keypoints_per_frame": n, "parallelism": f"seq-shard x{world}",
-                       "committed_pose_fraction": ok_frac,
-                       "pose_overlaps_next_match": overlap},
-            "roofline": None, "hbm_view": None, "valu_roofline": None,
-            "stage_ms": {"hamming_knn2": k1_ms, "reverse_check": verify_ms, "hamming_knn2_calls_timed": k1_calls,
-                         "hamming_knn2_launches_per_step": 1, "hamming_knn2_solo": k1_solo_ms,
-                         "reverse_scans_solo": verify_solo_ms, "pose_solo": pose_ms,
-                         "claimed_column_fraction": float(nsel.sum()) / float(n2v.sum())},
+            "n_gpus": world, "rccl_ranks": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/i8+f64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: KITTI-00-shaped stereo with points + lines (ORB + LBD rows), grid-windowed stereo "
+                                   "match (points and lines) + f2f brute-force mutual-NNR match (points and lines) + full GN optimizePose "
+                                   "(config_kitti.yaml), device-resident per-frame pipeline; the streams cycle through the 8 sequence ids / 3 "
+                                   "KITTI calibrations of configs[4] (sequence s on rank s mod G)",
+                       "streams_per_gpu": B, "resident_frames_per_stream": S, "slot_order": "ping-pong",
+                       "resident_raw_features_MB_per_gpu": resident_mb,
+                       "keypoints_per_image": float(n_kp.mean() / 2), "keylines_per_image": float(np.mean([len(st[0]["kl_l"]) for st in streams])),
+                       "mean_stereo_points": n2_l / B, "mean_matched_points": np_l / B, "mean_matched_lines": nl_l / B,
+                       "cameras": "kitti00-02 (seq 0-2), kitti03 (seq 3), kitti04-10 (seq 4-7)",
+                       "parallelism": f"seq-shard x{world}", "committed_pose_fraction": ok_frac},
+            "roofline": roofline, "roofline_pose": roofline_pose, "roofline_grid_scan": roofline_grid,
+            "stage_ms": dict(stage_ms, steps_timed=n_timed,
+                             note="stereo_points_stage = cells + cover + 2 scans + finalize + tail of the key-points (contains grid_scan); "
+                                  "the key-line stage runs concurrently on a second stream and is not on the critical path"),
         }
-        traffic = committed_traffic(k1_name)
-        traffic_src = ("bytes per launch = FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes, read from the committed "
-                       "profiles/r01_f_hbm_counters.txt (not re-measured by this run)")
-        timing = "hipEvent pairs around each launch, on the launch stream, over a second pass of the same K steps"
-        hbm_view = {"kernel": k1_name, "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                    "algorithmic_bytes_per_launch": alg_bytes,
-                    "note": "brute-force matching does ~56 k distance bit-operations per compulsory byte: HBM is idle by construction"}
-        if mfma:
-            plan = ctx.last_reverse_plan(B).astype(np.int64)   # [claimed, light, heavy, |S|, tau] per frame pair
-            out["stage_ms"]["reverse_plan"] = {
-                "light_column_fraction": float(plan[1].sum()) / max(float(plan[0].sum()), 1.0),
-                "heavy_column_fraction": float(plan[2].sum()) / max(float(plan[0].sum()), 1.0),
-                "mean_rows_in_S": float(plan[3].mean()), "mean_tau": float(plan[4].mean()),
-                "reverse_distance_evaluations_per_frame": float((plan[1] * plan[3] + plan[2] * n1v).mean()),
-                "note": "reverse check: light columns are scanned against the |S| rows whose second-best forward distance is "
-                        "within the cut tau, heavy columns against all rows (DESIGN.md §5)"}
-            ops = pairs * K1M_OPS_PER_PAIR
-            achieved_tops = ops / (k1_ms * 1e-3) / 1e12
-            out["roofline"] = {"kernel": k1_name, "bound": "mfma", "achieved": achieved_tops, "peak": I8_MFMA_PEAK_TOPS,
-                               "unit": "TFLOP/s", "unit_note": "int8 multiply-accumulate ops (TOP/s); 2 x 256 per distance",
-                               "frac": achieved_tops / I8_MFMA_PEAK_TOPS, "traffic": traffic, "traffic_source": traffic_src,
-                               "algorithmic_ops_per_launch": ops, "algorithmic_bytes_per_launch": alg_bytes,
-                               "avg_launch_ms": k1_ms, "avg_launch_ms_solo": k1_solo_ms, "timing": timing,
-                               "frac_of_measured_mfma_floor": achieved_tops / I8_MFMA_MEASURED_FLOOR_TOPS,
-                               "note": "K1m: all-pairs Hamming distance as an int8 Gram matrix on the matrix cores, top-2 fold "
-                                       "(2 VALU ops per pair) in the shadow of the matrix instructions; one launch per step"}
-            out["hbm_view"] = hbm_view
-            del out["valu_roofline"]
-        else:
-            valu_meas = ctx.valu_peak()
-            out["roofline"] = dict(hbm_view, bound="hbm", avg_launch_ms=k1_ms, timing=timing,
-                                   note="K1 is integer-VALU bound (~530 lane-ops per compulsory byte); see valu_roofline")
-            out["valu_roofline"] = {"kernel": k1_name, "lane_ops_per_launch": lane_ops,
-                                    "achieved": lane_ops / (k1_ms * 1e-3) / 1e12, "peak": VALU_PEAK_LANE_OPS / 1e12,
-                                    "unit": "T lane-ops/s", "frac": lane_ops / (k1_ms * 1e-3) / VALU_PEAK_LANE_OPS,
-                                    "measured_peak_same_mix": valu_meas / 1e12,
-                                    "frac_of_measured_peak": lane_ops / (k1_ms * 1e-3) / valu_meas}
-            del out["hbm_view"]
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(frames, prm)
-            out.update(cpu_baseline_variants(frames, prm))
+    pipe.close()
     ctx.close()
+    if rank == 0 and world == 1 and not args.no_extras:
+        out["latency"] = single_stream_latency(local_rank, args.points, args.lines)
+        out["configs1"] = configs1_leg(dev_name, rank)
+        try:
+            out["reverse_check_correlated"] = correlated_leg(dev_name, rank)
+        except NameError:
+            pass
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.points, args.lines)
+        out["cpu_baseline_threads"] = cpu_baseline_threads(args.points, args.lines)
+        if "latency" in out:
+            out["latency"]["oracle_ms_1_core"] = out["cpu_baseline"]["ms_per_frame"]
+            out["latency"]["speedup_vs_oracle_1_core"] = out["cpu_baseline"]["ms_per_frame"] / out["latency"]["seq_push_ms"]["median"]
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

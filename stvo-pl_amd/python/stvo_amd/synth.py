@@ -347,3 +347,22 @@ def make_f2f_points_lines(seed, n=2000, n_lines=100, cam=KITTI_CAM, track_frac=0
               prev_spl=np.ascontiguousarray(sp), prev_epl=np.ascontiguousarray(ep), prev_sigma2l=np.ones(n_lines),
               curr_le=np.ascontiguousarray(curr_le[perm]), curr_ldesc=np.ascontiguousarray(curr_ldesc[perm]))
     return fr
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE configs[4] / SURVEY.md §8(d) config 5: KITTI sequences 00-07 side by side, one calibration per dataset
+# (config/dataset_params/kitti00-02.yaml, kitti03.yaml, kitti04-10.yaml)
+# ------------------------------------------------------------------------------------------------
+CONFIG5_N_SEQUENCES = 8
+CONFIG5_CAMS = [KITTI_CAM] * 3 + [KITTI03_CAM] + [KITTI04_CAM] * 4
+
+
+def config5_cam(seq: int):
+    return CONFIG5_CAMS[seq % CONFIG5_N_SEQUENCES]
+
+
+def make_config5_sequence(seq: int, n_frames: int, n_pts=1650, n_lines=85, replica=0, **kw):
+    """Sequence `seq` (0..7) of config 5: generated as config 3 (points + lines, make_stereo_sequence) with the camera of
+    that KITTI sequence.  `replica` > 0 gives further independent streams of the same shape (bench: B streams per GPU)."""
+    return make_stereo_sequence(frame_seed(seq + CONFIG5_N_SEQUENCES * replica, 0), n_frames=n_frames, n_pts=n_pts,
+                                n_lines=n_lines, cam=config5_cam(seq), **kw)

@@ -9,17 +9,20 @@ def stereo_frame(orc, fr, cam, mp, has_points=True, has_lines=True):
     out = {}
     if has_points and len(fr["kp_l"]) and len(fr["kp_r"]):
         sp = orc.stereo_points(fr["kp_l"], fr["oct_l"], fr["desc_l"], fr["kp_r"], fr["desc_r"], cols, rows, cam, mp)
-        out.update(pl=sp["pl"], P=sp["P"], sigma2p=sp["sigma2"], pdesc=np.ascontiguousarray(fr["desc_l"][sp["src_idx"]]))
+        out.update(pl=sp["pl"], P=sp["P"], sigma2p=sp["sigma2"], pdesc=np.ascontiguousarray(fr["desc_l"][sp["src_idx"]]),
+                   m12_raw_p=sp["m12_raw"])
     else:
-        out.update(pl=np.zeros((0, 2)), P=np.zeros((0, 3)), sigma2p=np.zeros(0), pdesc=np.zeros((0, 32), np.uint8))
+        out.update(pl=np.zeros((0, 2)), P=np.zeros((0, 3)), sigma2p=np.zeros(0), pdesc=np.zeros((0, 32), np.uint8),
+                   m12_raw_p=-np.ones(len(fr["kp_l"]), np.int32))
     if has_lines and len(fr["kl_l"]) and len(fr["kl_r"]):
         sl = orc.stereo_lines(fr["kl_l"], fr["ang_l"], fr["oct_ll"], fr["ldesc_l"], fr["kl_r"], fr["ldesc_r"], cols, rows, cam, mp)
         out.update(spl=sl["spl"], epl=sl["epl"], sP=sl["sP"], eP=sl["eP"], le=sl["le"], sigma2l=sl["sigma2"],
-                   llevel=fr["oct_ll"][sl["src_idx"]], ldesc=np.ascontiguousarray(fr["ldesc_l"][sl["src_idx"]]))
+                   llevel=fr["oct_ll"][sl["src_idx"]], ldesc=np.ascontiguousarray(fr["ldesc_l"][sl["src_idx"]]),
+                   m12_raw_l=sl["m12_raw"])
     else:
         z3 = np.zeros((0, 3)); z2 = np.zeros((0, 2))
         out.update(spl=z2, epl=z2.copy(), sP=z3, eP=z3.copy(), le=z3.copy(), sigma2l=np.zeros(0), llevel=np.zeros(0, np.int32),
-                   ldesc=np.zeros((0, 32), np.uint8))
+                   ldesc=np.zeros((0, 32), np.uint8), m12_raw_l=-np.ones(len(fr["kl_l"]), np.int32))
     return out
 
 

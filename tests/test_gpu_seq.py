@@ -17,11 +17,12 @@ def run_and_compare(oracle, seqs, cam, preset, mode=0, has_lines=1, max_kp=2048,
     B, nf = len(seqs), len(seqs[0])
     mp = match_params(preset)
     op = opt_params(preset, mode=mode, has_lines=has_lines)
+    cams = [cam] * B if isinstance(cam, dict) else list(cam)   # one calibration for all, or one per sequence
     ctx = capi.Context(device_id=0, max_rows=2048, max_batch=max(B, 1))
     dev = capi.Sequences(ctx, B, max_kp, max_kl, cam, mp, op)
     try:
-        refs = [pipeline_ref.run_sequence(oracle, seqs[b], cam, mp, op) for b in range(B)]
-        ref0 = [pipeline_ref.stereo_frame(oracle, seqs[b][0], cam, mp, True, bool(has_lines)) for b in range(B)]
+        refs = [pipeline_ref.run_sequence(oracle, seqs[b], cams[b], mp, op) for b in range(B)]
+        ref0 = [pipeline_ref.stereo_frame(oracle, seqs[b][0], cams[b], mp, True, bool(has_lines)) for b in range(B)]
         for k in range(nf):
             res, counts = dev.push([seqs[b][k] for b in range(B)])
             for b in range(B):
@@ -91,6 +92,45 @@ def test_seq_pipeline_many_sequences_copy_back_path(oracle):
     run_and_compare(oracle, seqs, cam, "kitti", max_kp=512, max_kl=64)
 
 
+def test_seq_pipeline_config5_eight_sequences_three_cameras(oracle):
+    """BASELINE configs[4] on ONE GPU: KITTI sequences 00-07 side by side in one stvo_seq, each with the calibration and
+    image size of its dataset (kitti00-02 / kitti03 / kitti04-10), points + lines, grid stereo + f2f + pose; every
+    sequence must reproduce the oracle pipeline run with ITS camera."""
+    seqs = [synth.make_config5_sequence(s, n_frames=4, n_pts=700 + 60 * s, n_lines=50 + 5 * s) for s in range(synth.CONFIG5_N_SEQUENCES)]
+    run_and_compare(oracle, seqs, synth.CONFIG5_CAMS, "kitti")
+    # the three calibrations really differ in what the pipeline computes: sequence 3 run with the camera of sequence 0 disagrees
+    mp = match_params("kitti"); op = opt_params("kitti")
+    a = pipeline_ref.run_sequence(oracle, seqs[3], synth.KITTI03_CAM, mp, op)
+    b = pipeline_ref.run_sequence(oracle, seqs[3], synth.KITTI_CAM, mp, op)
+    assert not np.allclose(a[0]["T"], b[0]["T"], atol=1e-6)
+
+
+def test_seq_rotating_slots_equal_push(oracle):
+    """stvo_seq_set_slots + upload / step_dev over more than two resident frames (what bench.py rotates through) gives
+    exactly the results of pushing the same frames one by one."""
+    from stvo_amd import capi
+    cams = [synth.config5_cam(s) for s in (0, 3, 5)]
+    seqs = [synth.make_config5_sequence(s, n_frames=5, n_pts=400, n_lines=40) for s in (0, 3, 5)]
+    mp = match_params("kitti"); op = opt_params("kitti")
+    ctx = capi.Context(device_id=0, max_rows=1024, max_batch=3)
+    a = capi.Sequences(ctx, 3, 1024, 128, cams, mp, op)
+    b = capi.Sequences(ctx, 3, 1024, 128, cams, mp, op)
+    try:
+        b.set_slots(5)
+        for k in range(5):
+            b.upload(k, [s[k] for s in seqs])
+        order = [0, 1, 2, 3, 4, 3, 2, 1, 0, 1]   # ping-pong through the resident frames
+        for k in order:
+            ra, ca = a.push([s[k] for s in seqs])
+            b.step_dev(k)
+            rb, cb = b.read()
+            assert np.array_equal(ca, cb)
+            assert ra.tobytes() == rb.tobytes()   # bit-identical results
+    finally:
+        a.close(); b.close()
+        ctx.close()
+
+
 def test_seq_fetch_by_products(oracle):
     """stvo_seq_enable_fetch / fetch_matches / fetch_inliers (what the handler mirror rebuilds its host lists from): the raw
     stereo matches equal the oracle's grid matcher on the same frame, and the f2f matches / inlier flags are consistent
@@ -111,9 +151,11 @@ def test_seq_fetch_by_products(oracle):
             ms_p, ms_l, m_p, m_l = dev.fetch_matches()
             ref = pipeline_ref.stereo_frame(oracle, fr, cam, mp, True, True)
             n_l, n_ll = len(fr["kp_l"]), len(fr["kl_l"])
-            # every stereo feature of the oracle comes from an accepted raw match
-            assert (ms_p[0, :n_l] >= 0).sum() >= len(ref["P"]) == counts[0, 0]
-            assert (ms_l[0, :n_ll] >= 0).sum() >= len(ref["sP"]) == counts[0, 1]
+            # the raw stereo matches (what matchGrid returns, stereoFrame.cpp:145,344) equal the oracle's, index for index
+            assert np.array_equal(ms_p[0, :n_l], ref["m12_raw_p"])
+            assert np.array_equal(ms_l[0, :n_ll], ref["m12_raw_l"])
+            assert np.all(ms_p[0, n_l:] == -1) and np.all(ms_l[0, n_ll:] == -1)
+            assert len(ref["P"]) == counts[0, 0] and len(ref["sP"]) == counts[0, 1]
             if k == 0:
                 prev_counts = counts.copy()
                 continue

@@ -46,3 +46,32 @@ def test_live_reference_build_matches_oracle(oracle):
             y2 = y1
         n = ref.ref_line_coords(x1, y1, x2, y2, buf.reshape(-1), 512)
         assert np.array_equal(oracle.line_coords(x1, y1, x2, y2), buf[:n])
+
+
+DEV_GOLD = os.path.join(os.path.dirname(__file__), "golden", "ref_device_grid_goldens.npz")
+
+
+def test_oracle_vs_pixel_space_goldens_three_kitti_calibrations(oracle):
+    """The oracle's cell computation, bucket grid, Bresenham and window gather against reference outputs generated from
+    PIXEL coordinates at the three KITTI image sizes of BASELINE configs[4] (1241x376, 1242x375, 1226x370)."""
+    g = np.load(DEV_GOLD)
+    ws = int(g["ws"])
+    for c, (cols, rows) in enumerate(g["sizes"]):
+        inv = np.array([64.0 / cols, 48.0 / rows])
+        kp_l, kp_r = g[f"kp_l_{c}"], g[f"kp_r_{c}"]
+        ent = (kp_r.astype(np.float64) * inv).astype(np.int32)
+        start, items = oracle.grid_build(ent)
+        off, out = g[f"pcell_off_{c}"], g[f"pcell_out_{c}"]
+        for cell in range(64 * 48):
+            assert np.array_equal(np.sort(items[start[cell]:start[cell + 1]]), out[off[cell]:off[cell + 1]]), (c, cell)
+        q = g[f"pcells_l_{c}"]
+        assert np.array_equal((kp_l.astype(np.float64) * inv).astype(np.int32), q)
+        off, out = g[f"pcand_off_{c}"], g[f"pcand_out_{c}"]
+        for i in range(len(q)):
+            got = np.sort(oracle.window_gather(start, items, int(q[i, 0]), int(q[i, 1]), (ws, 0, 0, 0), len(kp_r)))
+            assert np.array_equal(got, out[off[i]:off[i + 1]]), (c, i)
+        kl_r = g[f"kl_r_{c}"].astype(np.float64)
+        loff, lcells = g[f"lline_off_{c}"], g[f"lline_cells_{c}"]
+        for j in range(len(kl_r)):
+            got = oracle.line_coords(kl_r[j, 0] * inv[0], kl_r[j, 1] * inv[1], kl_r[j, 2] * inv[0], kl_r[j, 3] * inv[1])
+            assert np.array_equal(got, lcells[loff[j]:loff[j + 1]]), (c, j)
