@@ -93,7 +93,8 @@ struct PoseArgs {
     double* eval_out;    // [B][44]: H(36) g(6) e n
     long long* prof_out; // optional [B][16] phase ticks (tools only)
 };
-int launch_pose(hipStream_t s, const PoseArgs& a);
+int launch_pose(hipStream_t s, const PoseArgs& a);   // dispatches to pose_kernel2.hip (default) or pose_kernel.hip (STVO_POSE_KERNEL=1)
+int launch_pose2(hipStream_t s, const PoseArgs& a);  // pose_kernel2.hip: every wave a worker, 128 VGPRs, records in LDS
 
 // ---- K3: grid-windowed stereo matchers, batched over frame pairs (blockIdx.y) ----------------------
 struct GridBatch {

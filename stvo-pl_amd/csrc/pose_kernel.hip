@@ -17,524 +17,11 @@
 //   * the 6x6 algebra, SE(3) updates and every data-dependent branch of the GN / robust-GN / LM
 //     loops (:394-547) run on one lane of the solver wave (pose_math.h) and are broadcast through
 //     LDS, so the control flow is block-uniform and matches the reference iteration for iteration.
-#include "kernels.h"
-#include "pose_math.h"
+#include <cstdlib>
+
+#include "pose_block.h"
 
 namespace stvo {
-
-namespace {
-
-constexpr int ACT_CONTINUE = 0, ACT_BREAK = 1, ACT_FAIL = 2;
-
-struct PoseSh {
-    double tot[28];
-    double DT[16];   // optimiser variable
-    double DT0[16];  // initial DT of optimizePose (:317-326)
-    double DT1[16];  // stage-1 result DT_ (:335)
-    double DTr[16];  // robust GN's saved entry pose (:441)
-    double cov[36];
-    double eig[6];
-    double H[36];
-    double g[6];
-    double err, err_prev, err_out, lambda;
-    double stat[4];  // scratch scalars broadcast by thread 0 (median, stdv, mean, ...)
-    double s_p, s_l;
-    unsigned long long xchg;  // select_kth's one-word mailbox
-    int action, good, n_inl_p, n_inl_l, n_m_p, n_m_l, evals, itmp;
-};
-
-// Block-wide primitives.  The workgroup has NWORK worker waves (threads 0 .. 64*NWORK-1, they own
-// the feature records) plus ONE solver wave (the last 64 threads: 6x6 algebra, SE(3), every
-// data-dependent decision).  Both roles run the SAME source with W = true / false, so they execute
-// identical barrier sequences by construction; with W == false a primitive only synchronises and
-// reads the result.  Keeping the serial algebra in its own wave keeps it out of the register budget
-// of the record-holding waves (no call-clobber spills: the first version of this kernel moved
-// ~1 MB of scratch per frame pair through HBM, see profiles/r01_a_hbm_counters.txt).
-template <int NWORK>
-struct BlockOps {
-    static constexpr int NW = NWORK;
-    static constexpr int WTHREADS = NWORK * 64;
-
-    // Wave64 sum with DPP register moves (no LDS crossbar): inclusive scan inside each 16-lane row
-    // (row_shr 1,2,4,8), then row_bcast:15 / row_bcast:31 carry the row totals across rows.  The
-    // total lands in LANE 63.  Fixed association order => bit-reproducible.  A 64-bit value moves as
-    // two 32-bit DPP movs; lanes with no source read 0 (bound_ctrl), which is neutral for a sum.
-    template <int CTRL, int ROW_MASK>
-    static __device__ __forceinline__ double dpp_add(double v) {
-        const long long b = __double_as_longlong(v);
-        const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xFFFFFFFFll), CTRL, ROW_MASK, 0xf, true);
-        const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xf, true);
-        return v + __longlong_as_double(((long long)hi << 32) | (unsigned long long)(unsigned)lo);
-    }
-    static __device__ __forceinline__ double wave_sum_lane63(double v) {
-        v = dpp_add<0x111, 0xf>(v);  // row_shr:1
-        v = dpp_add<0x112, 0xf>(v);  // row_shr:2
-        v = dpp_add<0x114, 0xf>(v);  // row_shr:4
-        v = dpp_add<0x118, 0xf>(v);  // row_shr:8
-        v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 -> rows 1 and 3
-        v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 -> rows 2 and 3
-        return v;
-    }
-    // xor-butterfly (LDS crossbar): every lane ends with the wave total; used for the small reductions
-    static __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-        return v;
-    }
-    static __device__ __forceinline__ int wave_sum_i(int v) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-        return v;
-    }
-
-    // Reduce-scatter steps on gfx950's lane-swap instructions.  v_permlane32_swap exchanges the upper half of one
-    // register with the lower half of another, so ONE swap per 32-bit word plus one add leaves, in lanes 0..31, the
-    // pair sums a[L] + a[L+32] and, in lanes 32..63, b[L-32] + b[L]: two values are folded for the price of one.
-    // v_permlane16_swap does the same between the odd and even 16-lane rows.
-    static __device__ __forceinline__ double fold32(double a, double b) {
-        const unsigned long long ab = (unsigned long long)__double_as_longlong(a), bb = (unsigned long long)__double_as_longlong(b);
-        const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)ab, (unsigned)bb, false, false);
-        const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(ab >> 32), (unsigned)(bb >> 32), false, false);
-        return __longlong_as_double((long long)(((unsigned long long)hi[0] << 32) | lo[0])) +
-               __longlong_as_double((long long)(((unsigned long long)hi[1] << 32) | lo[1]));
-    }
-    static __device__ __forceinline__ double fold16(double a, double b) {
-        const unsigned long long ab = (unsigned long long)__double_as_longlong(a), bb = (unsigned long long)__double_as_longlong(b);
-        const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)ab, (unsigned)bb, false, false);
-        const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(ab >> 32), (unsigned)(bb >> 32), false, false);
-        return __longlong_as_double((long long)(((unsigned long long)hi[0] << 32) | lo[0])) +
-               __longlong_as_double((long long)(((unsigned long long)hi[1] << 32) | lo[1]));
-    }
-
-    // 28-vector block sum -> sh->tot[0..27] (wave partials summed in wave order by the solver wave).
-    // Inside a wave: 28 values -> 14 (fold32) -> 7 (fold16) per lane, then a 16-lane row scan of those 7; row r
-    // ends up with the wave totals of values 7r .. 7r+6 in its last lane.  147 VALU ops instead of the 504 of 28
-    // independent 64-lane scans; fixed association order => bit-reproducible.
-    template <bool W>
-    static __device__ __forceinline__ void sum28_fold(double* acc, double (*red)[28]) {
-        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        if (W) {
-            double s14[14], s7[7];
-#pragma unroll
-            for (int k = 0; k < 14; ++k) s14[k] = fold32(acc[k], acc[14 + k]);
-#pragma unroll
-            for (int k = 0; k < 7; ++k) s7[k] = fold16(s14[k], s14[7 + k]);
-#pragma unroll
-            for (int k = 0; k < 7; ++k) {
-                double v = s7[k];
-                v = dpp_add<0x111, 0xf>(v);  // row_shr:1
-                v = dpp_add<0x112, 0xf>(v);  // row_shr:2
-                v = dpp_add<0x114, 0xf>(v);  // row_shr:4
-                v = dpp_add<0x118, 0xf>(v);  // row_shr:8
-                if ((lane & 15) == 15) red[wv][(lane >> 4) * 7 + k] = v;
-            }
-        }
-    }
-    template <bool W>
-    static __device__ __forceinline__ void sum28_finish(double (*red)[28], PoseSh* sh) {
-        const int lane = threadIdx.x & 63;
-        __syncthreads();
-        if (!W) {
-            if (lane < 28) {
-                double s = red[0][lane];
-#pragma unroll
-                for (int w = 1; w < NW; ++w) s += red[w][lane];
-                sh->tot[lane] = s;
-            }
-            // tot[] is consumed by lane 0 of THIS wave only (t0_unpack), so a wave-level fence is enough; the
-            // worker waves run ahead to the barrier that follows the solver's algebra, which also keeps them from
-            // overwriting `red` before it has been read here.
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        }
-    }
-
-    template <int N, bool W>
-    static __device__ __forceinline__ void sum_small(const double* v, double (*red)[28], double* out) {
-        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        if (W) {
-#pragma unroll
-            for (int k = 0; k < N; ++k) {
-                const double s = wave_sum(v[k]);
-                if (lane == 0) red[wv][k] = s;
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < N; ++k) {
-            double s = red[0][k];
-#pragma unroll
-            for (int w = 1; w < NW; ++w) s += red[w][k];
-            out[k] = s;
-        }
-        __syncthreads();
-    }
-
-    template <bool W>
-    static __device__ __forceinline__ int sum_int(int v, int* ired) {
-        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        if (W) {
-            const int s = wave_sum_i(v);
-            if (lane == 0) ired[wv] = s;
-        }
-        __syncthreads();
-        int t = 0;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) t += ired[w];
-        __syncthreads();
-        return t;
-    }
-
-    // exclusive scan of per-thread counts (worker thread order); returns this thread's offset
-    template <bool W>
-    static __device__ __forceinline__ int excl_scan(int count, int* ired, int* total) {
-        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        int incl = count;
-        if (W) {
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int o = __shfl_up(incl, off, 64);
-                if (lane >= off) incl += o;
-            }
-            if (lane == 63) ired[wv] = incl;
-        }
-        __syncthreads();
-        int base = 0, tot = 0;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) {
-            const int c = ired[w];
-            if (w < wv) base += c;
-            tot += c;
-        }
-        __syncthreads();
-        *total = tot;
-        return base + incl - count;
-    }
-
-    // workgroup-wide totals of three per-wave counts (wave-uniform c[0..2]); double-buffered partials => ONE barrier per call
-    template <bool W>
-    static __device__ __forceinline__ void count3_db(int* c, int (*ibuf)[3 * NW], int parity) {
-        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        if (W && lane == 0) {
-            ibuf[parity][wv] = c[0];
-            ibuf[parity][NW + wv] = c[1];
-            ibuf[parity][2 * NW + wv] = c[2];
-        }
-        __syncthreads();
-        int t0 = 0, t1 = 0, t2 = 0;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) {
-            t0 += ibuf[parity][w];
-            t1 += ibuf[parity][NW + w];
-            t2 += ibuf[parity][2 * NW + w];
-        }
-        c[0] = t0;
-        c[1] = t1;
-        c[2] = t2;
-    }
-
-    // k-th smallest (0-based) of the n keys {key[k] : bit k of mask} held in REGISTERS across the workgroup:
-    // most-significant-first radix search on two bits per round — three thresholds, three workgroup-wide counts (per-wave
-    // counts from ballots + s_bcnt1, no cross-lane data movement), one barrier.  lo / hi bracket the number of keys
-    // below the current prefix and below its upper end; as soon as exactly one key is left in the bracket it IS the
-    // answer and is fetched directly — with n ~ 1500 distinct values that happens after ~13 of the 32 (or ~9 of the 16)
-    // rounds.  Equal keys simply keep the search going to the last bit.  Same result as sorting.
-    template <int N, bool W, typename K, int BITS>
-    static __device__ __forceinline__ K select_kth(const K* key, unsigned mask, int n, int kth, int (*ibuf)[3 * NW], K* xchg) {
-        static_assert(BITS % 2 == 0, "two bits per round");
-        K res = 0;
-        int lo = 0, hi = n, parity = 0;
-        for (int bit = BITS - 2; bit >= 0; bit -= 2) {
-            const K t1 = res | ((K)1 << bit), t2 = res | ((K)2 << bit), t3 = res | ((K)3 << bit);
-            int c[3] = {0, 0, 0};
-            if (W) {
-#pragma unroll
-                for (int k = 0; k < N; ++k) {
-                    const bool in = (mask >> k) & 1u;
-                    c[0] += __popcll(__builtin_amdgcn_ballot_w64(in && key[k] < t1));
-                    c[1] += __popcll(__builtin_amdgcn_ballot_w64(in && key[k] < t2));
-                    c[2] += __popcll(__builtin_amdgcn_ballot_w64(in && key[k] < t3));
-                }
-            }
-            count3_db<W>(c, ibuf, parity);
-            parity ^= 1;
-            // the largest threshold with at most kth keys below it becomes the new prefix
-            if (c[2] <= kth) {
-                res = t3;
-                lo = c[2];
-            } else if (c[1] <= kth) {
-                res = t2;
-                lo = c[1];
-                hi = c[2];
-            } else if (c[0] <= kth) {
-                res = t1;
-                lo = c[0];
-                hi = c[1];
-            } else {
-                hi = c[0];
-            }
-            if (hi - lo == 1 && bit > 0) {  // block-uniform: the single key in [res, res + 2^bit)
-                const K top = res + (((K)1 << bit) - 1);
-                if (W) {
-#pragma unroll
-                    for (int k = 0; k < N; ++k)
-                        if (((mask >> k) & 1u) && key[k] >= res && key[k] <= top) *xchg = key[k];
-                }
-                __syncthreads();
-                res = *xchg;
-                break;
-            }
-        }
-        __syncthreads();  // ibuf / xchg are reused by the caller
-        return res;
-    }
-
-    // 1.4826 * MAD of the n values {v[k] : bit k of mask}.  Follows vector_stdv_mad / the first half of
-    // vector_mean_stdv_mad (src/auxiliar.cpp:395-404, 447-457): median = sorted[n/2]; dev = fabsf(x - median)
-    // (FLOAT truncation); MAD = sorted dev[n/2].  The two std::sort calls are replaced by exact k-th-element
-    // selection on the order-preserving integer images of the values.  n == 0 -> 0.
-    template <int N, bool W>
-    static __device__ __forceinline__ double mad_sigma(const double* v, unsigned mask, int n, int (*ibuf)[3 * NW],
-                                                       unsigned long long* xchg) {
-        if (n == 0) return 0.0;  // block-uniform
-        const int kth = n / 2;
-        unsigned long long key[N];
-#pragma unroll
-        for (int k = 0; k < N; ++k) {
-            const unsigned long long b = (unsigned long long)__double_as_longlong(v[k]);
-            key[k] = (b >> 63) ? ~b : (b | 0x8000000000000000ull);  // total order of IEEE doubles
-        }
-        const unsigned long long res = select_kth<N, W, unsigned long long, 64>(key, mask, n, kth, ibuf, xchg);
-        const unsigned long long mb = (res >> 63) ? (res & 0x7FFFFFFFFFFFFFFFull) : ~res;
-        const double median = __longlong_as_double((long long)mb);
-        unsigned fkey[N];
-#pragma unroll
-        for (int k = 0; k < N; ++k) fkey[k] = __float_as_uint(fabsf((float)(v[k] - median)));  // >= 0 (or NaN)
-        const unsigned fres = select_kth<N, W, unsigned, 32>(fkey, mask, n, kth, ibuf, reinterpret_cast<unsigned*>(xchg));
-        return 1.4826 * (double)__uint_as_float(fres);
-    }
-};
-
-__device__ __forceinline__ double norm3(const double* v) { return sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
-
-// ---- solver-lane sections (inlined into the solver instantiation only: W == true never reaches them) ----
-
-__device__ __forceinline__ void t0_unpack(PoseSh* sh) {
-    int k = 0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int j = i; j < 6; ++j) {
-            const double v = sh->tot[k++];
-            sh->H[i * 6 + j] = v;
-            sh->H[j * 6 + i] = v;
-        }
-#pragma unroll
-    for (int i = 0; i < 6; ++i) sh->g[i] = sh->tot[21 + i];
-    sh->err = sh->tot[27] / (double)(sh->n_inl_l + sh->n_inl_p);  // :692  (0/0 -> NaN)
-}
-
-// H inc = g (ColPivHouseholderQR::solve at :417-418 and siblings): LDL^T when H is certified positive definite
-// (the normal case), the pivoted QR otherwise — see pose_math.h.
-__device__ __forceinline__ void solve_normal_eq(PoseSh* sh, double* inc, double* log_abs_det) {
-    double H[36], g[6];
-#pragma unroll
-    for (int i = 0; i < 36; ++i) H[i] = sh->H[i];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) g[i] = sh->g[i];
-    if (!pm::solve6_spd(H, g, inc, log_abs_det)) pm::solve6(H, g, inc, log_abs_det);
-}
-
-// body of gaussNewtonOptimization after optimizeFunctions (:405-428)
-__device__ __forceinline__ void t0_gn_iter(PoseSh* sh, double min_error, double min_error_change, int it) {
-    t0_unpack(sh);
-    const double err = sh->err;
-    if (err > sh->err_prev) {
-        sh->action = it > 0 ? ACT_BREAK : ACT_FAIL;
-        return;
-    }
-    if ((err < min_error) || fabs(err - sh->err_prev) < min_error_change) {
-        sh->action = ACT_BREAK;
-        return;
-    }
-    double inc[6], DT[16];
-    solve_normal_eq(sh, inc, nullptr);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) DT[i] = sh->DT[i];
-    pm::step_pose(DT, inc);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) sh->DT[i] = DT[i];
-    if (norm3(inc) < min_error_change && norm3(inc + 3) < min_error_change) {
-        sh->action = ACT_BREAK;
-        return;
-    }
-    sh->err_prev = err;
-    sh->action = ACT_CONTINUE;
-}
-
-// body of gaussNewtonOptimizationRobust after optimizeFunctionsRobust (:449-467)
-__device__ __forceinline__ void t0_gnr_iter(PoseSh* sh, double min_error, double min_error_change) {
-    t0_unpack(sh);
-    const double err = sh->err;
-    if (fabs(err - sh->err_prev) < min_error_change || err < min_error) {
-        sh->action = ACT_BREAK;
-        return;
-    }
-    double inc[6], DT[16], lad;
-    solve_normal_eq(sh, inc, &lad);
-    if (lad < 0.0) {
-        sh->good = 0;
-        sh->action = ACT_BREAK;
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) DT[i] = sh->DT[i];
-    pm::step_pose(DT, inc);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) sh->DT[i] = DT[i];
-    double n6 = 0.0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) n6 += inc[i] * inc[i];
-    if (sqrt(n6) < min_error_change) {
-        sh->action = ACT_BREAK;
-        return;
-    }
-    sh->err_prev = err;
-    sh->action = ACT_CONTINUE;
-}
-
-// LM first iteration (:486-510) and loop body (:518-542)
-__device__ __forceinline__ void t0_lm_iter(PoseSh* sh, double min_error, double min_error_change, int first) {
-    t0_unpack(sh);
-    const double err = sh->err;
-    double inc[6], DT[16];
-    if (first) {
-        double Hmax = 0.0;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const double h = sh->H[i * 7];
-            if (h > Hmax || h < -Hmax) Hmax = fabs(h);
-        }
-        sh->lambda = 0.000000001 * Hmax;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) sh->H[i * 7] += sh->lambda;
-        solve_normal_eq(sh, inc, nullptr);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) DT[i] = sh->DT[i];
-        pm::step_pose(DT, inc);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) sh->DT[i] = DT[i];
-        sh->err_prev = err;
-        sh->action = ACT_CONTINUE;
-        return;
-    }
-    if (fabs(err - sh->err_prev) < min_error_change || err < min_error) {
-        sh->action = ACT_BREAK;
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < 6; ++i) sh->H[i * 7] += sh->lambda;
-    solve_normal_eq(sh, inc, nullptr);
-    if (err > sh->err_prev)
-        sh->lambda /= 4.0;
-    else {
-        sh->lambda *= 4.0;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) DT[i] = sh->DT[i];
-        pm::step_pose(DT, inc);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) sh->DT[i] = DT[i];
-    }
-    if (norm3(inc) < min_error_change && norm3(inc + 3) < min_error_change) {
-        sh->action = ACT_BREAK;
-        return;
-    }
-    sh->err_prev = err;
-    sh->action = ACT_CONTINUE;
-}
-
-__device__ __forceinline__ void t0_cov_from_H(PoseSh* sh) {
-    double H[36], Hi[36];
-#pragma unroll
-    for (int i = 0; i < 36; ++i) H[i] = sh->H[i];
-    if (!pm::inverse6_spd(H, Hi)) pm::inverse6(H, Hi);  // Matrix6d::inverse(), :429 / :470 / :545
-#pragma unroll
-    for (int i = 0; i < 36; ++i) sh->cov[i] = Hi[i];
-}
-
-// isGoodSolution(DT, cov, err) -> sh->good; eigenvalues left in sh->eig
-__device__ __forceinline__ void t0_is_good(PoseSh* sh, const double* DT, double err) {
-    double C[36], w[6];
-#pragma unroll
-    for (int i = 0; i < 36; ++i) C[i] = sh->cov[i];
-    pm::eig6_ql(C, w);  // SelfAdjointEigenSolver::eigenvalues(), :294-295
-#pragma unroll
-    for (int i = 0; i < 6; ++i) sh->eig[i] = w[i];
-    sh->good = pm::is_good_solution(DT, w, err) ? 1 : 0;
-}
-
-// Same decision without the eigenvalues (the stage-1 test of :341 only needs the verdict): positive
-// definiteness by LDL^T pivots and lambda_max <= ||.||_inf <= 1 certify the two eigenvalue conditions; anything
-// not certified falls back to the eigen-decomposition the reference performs.
-__device__ __forceinline__ void t0_is_good_fast(PoseSh* sh, const double* DT, double err) {
-    if (err < 0.0 || err > 1.0 || !pm::all_finite16(DT)) {
-        sh->good = 0;
-        return;
-    }
-    double C[36];
-#pragma unroll
-    for (int i = 0; i < 36; ++i) C[i] = sh->cov[i];
-    if (pm::spd_unit_certificate(C) == 1) {
-        sh->good = 1;
-        return;
-    }
-    t0_is_good(sh, DT, err);
-}
-
-__device__ __forceinline__ void t0_commit(PoseSh* sh, stvo_pose_result* out, int status, int path, int it0, int it1) {
-    // :372-391
-    t0_is_good(sh, sh->DT, sh->err_out);
-    double DT[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        DT[i] = sh->DT[i];
-        out->T_opt[i] = DT[i];
-    }
-    out->err_opt = sh->err_out;
-    if (sh->good && !pm::is_identity16(DT)) {
-        double Ti[16], x[6], T[16];
-        pm::inverse_se3(DT, Ti);
-        pm::logmap_se3(Ti, x);
-        pm::expmap_se3(x, T);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) out->T[i] = T[i];
-#pragma unroll
-        for (int i = 0; i < 36; ++i) out->cov[i] = sh->cov[i];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) out->cov_eig[i] = sh->eig[i];
-        out->err = sh->err_out;
-    } else {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) out->T[i] = (i % 5 == 0) ? 1.0 : 0.0;
-#pragma unroll
-        for (int i = 0; i < 36; ++i) out->cov[i] = 0.0;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) out->cov_eig[i] = 0.0;
-        out->err = -1.0;
-        if (status == STVO_POSE_OK) status = STVO_POSE_REJECTED;
-    }
-    out->status = status;
-    out->path = path;
-    out->iters[0] = it0;
-    out->iters[1] = it1;
-    out->n_matched_pt = sh->n_m_p;
-    out->n_matched_ls = sh->n_m_l;
-    out->n_inliers_pt = sh->n_inl_p;
-    out->n_inliers_ls = sh->n_inl_l;
-}
-
-}  // namespace
 
 // LDSREC: the matched records of the frame pair live in LDS for the whole optimisation (latency variant: one workgroup
 // per CU, up to 152 KB of its 160 KB LDS).  Each worker thread stages ITS OWN records once (gathered through m12 from
@@ -926,9 +413,9 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_ibuf)[3 * (
                 tq = tick();
                 ++evals;
                 if (t0) {
-                    if (alg == 0) t0_gn_iter(sh, prm.min_error, prm.min_error_change, it);
-                    else if (alg == 1) t0_gnr_iter(sh, prm.min_error, prm.min_error_change);
-                    else t0_lm_iter(sh, prm.min_error, prm.min_error_change, it == 0 ? 1 : 0);
+                    if (alg == 0) t0_gn_iter<false>(sh, prm.min_error, prm.min_error_change, it);
+                    else if (alg == 1) t0_gnr_iter<false>(sh, prm.min_error, prm.min_error_change);
+                    else t0_lm_iter<false>(sh, prm.min_error, prm.min_error_change, it == 0 ? 1 : 0);
                 }
                 __syncthreads();
                 tprof[1] += tick() - tq;
@@ -946,7 +433,7 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_ibuf)[3 * (
 #pragma unroll
                     for (int i = 0; i < 36; ++i) sh->cov[i] = (i % 7 == 0) ? 1.0 : 0.0;
                 } else {
-                    t0_cov_from_H(sh);  // :429 / :470 / :545 — H of the last evaluation (damped for LM)
+                    t0_cov_from_H<false>(sh);  // :429 / :470 / :545 — H of the last evaluation (damped for LM)
                     sh->err_out = evals > 0 ? sh->err : 0.0;
                 }
             }
@@ -961,7 +448,7 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_ibuf)[3 * (
             if (t0) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) sh->DT1[i] = sh->DT[i];
-                t0_is_good_fast(sh, sh->DT1, sh->err_out);
+                t0_is_good_fast<false>(sh, sh->DT1, sh->err_out);
             }
             __syncthreads();
             tprof[2] += tick() - tq2;
@@ -1081,6 +568,13 @@ static bool pose_ldsrec_available() {
 
 int launch_pose(hipStream_t s, const PoseArgs& a) {
     if (a.B <= 0) return STVO_OK;
+    // the occupancy-oriented formulation (pose_kernel2.hip) is the default; STVO_POSE_KERNEL=1 selects this file's kernels
+    // (kept as the measured comparison point and exercised by the same parity tests)
+    const char* env = std::getenv("STVO_POSE_KERNEL");  // read per call: the parity tests switch between the two kernels
+    const int which = env ? std::atoi(env) : 0;
+    // default: batches beyond one workgroup per CU take pose_kernel2.hip (same speed, every record read from HBM once);
+    // up to 256 frame pairs this file's latency variant is the faster one (profiles/r02_*_pose_variants.txt)
+    if (which == 2 || (which == 0 && a.B > POSE_LATENCY_MAX_B)) return launch_pose2(s, a);
     if (a.max_pts > STVO_POSE_MAX_POINTS || a.max_lines > STVO_POSE_MAX_LINES) return STVO_ERR_CAPACITY;
     const size_t rec_bytes = ((size_t)a.max_pts * 6 + (size_t)a.max_lines * 14) * sizeof(double);
     if (a.B <= POSE_LATENCY_MAX_B && rec_bytes <= POSE_LDSREC_MAX_BYTES && pose_ldsrec_available<POSE_BLOCK_L>())

@@ -11,6 +11,30 @@ from stvo_amd.ctypes_types import opt_params
 
 pytestmark = pytest.mark.gpu
 CAM = synth.KITTI_CAM
+
+
+@pytest.fixture(autouse=True, params=["default", "1", "2:16", "2:8", "2:4", "2:2"])
+def pose_kernel_variant(request):
+    """Every test of this module runs against both pose kernels: pose_kernel.hip (worker waves + solver wave, "1") and
+    pose_kernel2.hip (every wave a worker, row-distributed algebra, records compacted in LDS) with 16 / 8 / 4 / 2 waves per
+    frame pair; "default" is the library's own choice.  The library reads the two variables at every launch."""
+    import os
+    old = {k: os.environ.get(k) for k in ("STVO_POSE_KERNEL", "STVO_POSE2_NW")}
+    if request.param == "default":
+        os.environ.pop("STVO_POSE_KERNEL", None); os.environ.pop("STVO_POSE2_NW", None)
+    else:
+        k, _, nw = request.param.partition(":")
+        os.environ["STVO_POSE_KERNEL"] = k
+        if nw:
+            os.environ["STVO_POSE2_NW"] = nw
+        else:
+            os.environ.pop("STVO_POSE2_NW", None)
+    yield request.param
+    for k, v in old.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
 ROT_TOL, TRANS_TOL = 1e-4, 1e-3  # BASELINE.json north_star
 
 
