@@ -896,6 +896,36 @@ PM_HD void point_term(double* acc, const double* DT, const Cam5& cam, double hom
     accumulate28(acc, J, r, w);
 }
 
+// Reciprocal / square root for the per-feature hot loop of pose_kernel2.hip: hardware seed (v_rcp_f64 / v_rsq_f64) + two
+// Newton steps, <= 1 ulp from the correctly rounded value for the normal, positive arguments that occur there (depths,
+// residual norms, 1 + r^2), without the scaling / special-case instructions of the IEEE expansions (5 / 8 instead of
+// ~12 / ~15 instructions; the kernel is bound by FP64 issue).  Host builds use the exact operations.
+PM_HD double fast_rcp(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double y = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-x, y, 1.0);
+    return fma(y, e, y);
+#else
+    return 1.0 / x;
+#endif
+}
+PM_HD double fast_sqrt(double x) {  // x >= 0 (NaN propagates)
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    const double d = fma(-g, g, x);
+    g = fma(d, h, g);
+    return x > 0.0 ? g : x;  // sqrt(0) = 0 (the seed is inf there)
+#else
+    return sqrt(x);
+#endif
+}
+
 // The same sums with the weight folded into one factor first: Jw = J w (6 products), then one FMA per entry — 35
 // instructions instead of 56 (pose_kernel2.hip; the products differ from accumulate28's by at most one rounding each).
 PM_HD void accumulate28w(double* acc, const double* J, double r, double w) {
@@ -913,24 +943,44 @@ PM_HD void accumulate28w(double* acc, const double* J, double r, double w) {
 }
 
 // point_term with sqrt(sigma2) supplied by the caller (computed once per record instead of once per evaluation).
+PM_HD void transform_project_fast(const double* DT, double X, double Y, double Z, const Cam5& cam, double* Pc, double* uv) {
+    Pc[0] = DT[0] * X + DT[1] * Y + DT[2] * Z + DT[3];
+    Pc[1] = DT[4] * X + DT[5] * Y + DT[6] * Z + DT[7];
+    Pc[2] = DT[8] * X + DT[9] * Y + DT[10] * Z + DT[11];
+    const double iz = fast_rcp(Pc[2]);
+    uv[0] = cam.cx + cam.fx * Pc[0] * iz;
+    uv[1] = cam.cy + cam.fy * Pc[1] * iz;
+}
+PM_HD void grad6_fast(const double* Pc, double dx, double dy, double fx, double homog_th, double* J) {
+    const double gx = Pc[0], gy = Pc[1], gz = Pc[2];
+    const double gz2 = gz * gz;
+    const double fgz2 = fx * fast_rcp(dmax(homog_th, gz2));
+    J[0] = +fgz2 * dx * gz;
+    J[1] = +fgz2 * dy * gz;
+    J[2] = -fgz2 * (gx * dx + gy * dy);
+    J[3] = -fgz2 * (gx * gy * dx + gy * gy * dy + gz * gz * dy);
+    J[4] = +fgz2 * (gx * gx * dx + gz * gz * dx + gx * gy * dy);
+    J[5] = +fgz2 * (gx * gz * dy - gy * gz * dx);
+}
+
 PM_HD void point_term_q(double* acc, const double* DT, const Cam5& cam, double homog_th, double X, double Y, double Z,
                         double ox, double oy, double sqrt_sigma2, bool robust, double s_p) {
     double Pc[3], uv[2], J[6];
-    transform_project(DT, X, Y, Z, cam, Pc, uv);
+    transform_project_fast(DT, X, Y, Z, cam, Pc, uv);
     const double dx = uv[0] - ox, dy = uv[1] - oy;
-    const double nrm = sqrt(dx * dx + dy * dy);
-    grad6(Pc, dx, dy, cam.fx, homog_th, J);
-    const double iden = 1.0 / dmax(homog_th, nrm);
+    const double nrm = fast_sqrt(dx * dx + dy * dy);
+    grad6_fast(Pc, dx, dy, cam.fx, homog_th, J);
+    const double iden = fast_rcp(dmax(homog_th, nrm));
 #pragma unroll
     for (int i = 0; i < 6; ++i) J[i] = J[i] * iden;
     double r, w;
     if (!robust) {
         r = nrm * sqrt_sigma2;
-        w = 1.0 / (1.0 + r * r);
+        w = fast_rcp(1.0 + r * r);
     } else {
         r = nrm;
         const double xx = r / s_p;
-        w = 1.0 / (1.0 + xx * xx);
+        w = fast_rcp(1.0 + xx * xx);
     }
     accumulate28w(acc, J, r, w);
 }
