@@ -64,6 +64,11 @@ struct GridArgs {
     unsigned long long* top2;    // [n1] low word: best eligible key (d << 16 | i2), high word: blocked flag
     int32_t* owner2;             // [n2]
     int32_t* m12;                // [n1]
+    uint32_t* elig;              // [GRID_ELIG][elig_stride] or nullptr
+    int32_t* elig_cnt;           // [n2]
+    int32_t* ovf;                // [1]
+    int elig_stride;
+    const int32_t* range1;       // [n1][2] candidate range (lo, hi) in scan positions, range formulation only
 };
 
 // per-frame view of a batch (blockIdx.y = frame pair)
@@ -89,6 +94,11 @@ __device__ __forceinline__ GridArgs frame_view(const GridBatch& g, int b) {
     a.top2 = g.top2 + (size_t)b * g.stride1;
     a.owner2 = g.owner2 + (size_t)b * g.stride2;
     a.m12 = g.m12 + (size_t)b * g.stride1;
+    a.elig = g.elig ? g.elig + (size_t)b * GRID_ELIG * g.stride2 : nullptr;
+    a.elig_cnt = g.elig ? g.elig_cnt + (size_t)b * g.stride2 : nullptr;
+    a.ovf = g.elig ? g.ovf + b : nullptr;
+    a.elig_stride = g.stride2;
+    a.range1 = g.range1 ? g.range1 + (size_t)b * g.stride1 * 2 : nullptr;
     return a;
 }
 
@@ -122,6 +132,7 @@ __global__ __launch_bounds__(256) void grid_cover_kernel(GridBatch g) {
     extern __shared__ unsigned long long s_col[];  // [words64][256] when USE_LDS
     const GridArgs a = frame_view(g, blockIdx.y);
     const int i1 = blockIdx.x * 256 + threadIdx.x;
+    if (i1 == 0 && a.ovf) a.ovf[0] = 0;
     if (i1 >= a.n1p) return;
     unsigned long long* gcol = a.cover + i1;
     if (USE_LDS) {
@@ -158,7 +169,27 @@ __device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc) {
     return r;
 }
 
-template <bool LINES, int PASS>
+// GridStructure::get for a one-row window (src/gridStructure.cpp:65-76) when the right features are numbered in CSR order:
+// the cells x - w_lo .. x + w_hi of row y are contiguous in the CSR, so the candidates of left feature i1 are the scan
+// positions [lo, hi) and the share of the wave that owns positions wbase .. wbase + 63 is one run of mask bits.
+// (lo, hi) come from the kernel that built the CSR (point_cells_kernel, seq_pipeline.hip): one coalesced 8-byte load per lane.
+__device__ __forceinline__ unsigned long long range_mask(const GridArgs& a, int i1, int wbase) {
+    const int2 r = reinterpret_cast<const int2*>(a.range1)[i1 < a.n1 ? i1 : 0];
+    const int b0 = max(r.x, wbase) - wbase, b1 = min(r.y, wbase + 64) - wbase;
+    const bool any = i1 < a.n1 && b1 > b0;
+    const unsigned long long run = (b1 - b0 >= 64) ? ~0ull : (((1ull << (b1 - b0)) - 1ull) << b0);
+    return any ? run : 0ull;
+}
+
+// TEST HOOK (stvo_seq_debug_grid): materialises the masks the range formulation feeds the scan into the bit-matrix layout
+__global__ __launch_bounds__(256) void grid_range_debug_kernel(GridBatch g) {
+    const GridArgs a = frame_view(g, blockIdx.y);
+    const int i1 = blockIdx.x * 256 + threadIdx.x;
+    if (i1 >= a.n1p) return;
+    for (int w = 0; w < a.words64; ++w) a.cover[(size_t)w * a.n1p + i1] = range_mask(a, i1, w * 64);
+}
+
+template <bool LINES, int PASS, bool RANGE>
 __global__ __launch_bounds__(256) void grid_scan_kernel(GridBatch g) {
     const GridArgs a = frame_view(g, blockIdx.y);
     // lane = scan position p; positions follow the CSR (cell) order of the right features, so the 64
@@ -167,6 +198,10 @@ __global__ __launch_bounds__(256) void grid_scan_kernel(GridBatch g) {
     const int p = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
     if ((p & ~63) >= a.n2) return;  // whole wave past the last right feature (wave-uniform)
+    // single-scan formulation: pass 1 records the eligible pairs, grid_elig_kernel judges them; this full second scan only
+    // runs for a frame in which some right feature met more than GRID_ELIG of them
+    if (PASS == 2 && a.elig && a.ovf[0] == 0) return;
+    int n_elig = 0;
     const bool live = p < a.n2;
     const int i2 = a.perm[live ? p : a.n2 - 1];
     const uint4 t0 = reinterpret_cast<const uint4*>(a.d2)[2 * i2];
@@ -194,7 +229,9 @@ __global__ __launch_bounds__(256) void grid_scan_kernel(GridBatch g) {
     // branch-free loads (clamped index, value discarded) so that the compiler can count the loads in flight and
     // wait for exactly the ones it needs instead of draining the queue in every block
     const int last_blk = a.n1p - 64;
+    const int wbase = widx * 64;
     auto mask_at = [&](int blk) -> unsigned long long {
+        if (RANGE) return range_mask(a, blk + lane, wbase);
         const unsigned long long m = col[(blk < a.n1p ? blk : last_blk) + lane];
         return blk < a.n1p ? m : 0ull;
     };
@@ -293,6 +330,10 @@ __global__ __launch_bounds__(256) void grid_scan_kernel(GridBatch g) {
                 if (eligible) {
                     const uint32_t key = (d[k] << 16) | (uint32_t)i2;
                     if (PASS == 1) {
+                        if (a.elig) {  // (mutual only: the eligible pairs of a lane are its strict running minima, ~ln(rows) of them)
+                            if (n_elig < GRID_ELIG) a.elig[(size_t)n_elig * a.elig_stride + p] = ((uint32_t)i1 << 16) | d[k];
+                            ++n_elig;
+                        }
                         atomicMin(best_key + 2 * (size_t)i1, key);  // result unused: no-return atomic
                     } else {
                         const uint32_t bk = (uint32_t)__builtin_amdgcn_readlane((int)qk, us[k]);
@@ -307,6 +348,30 @@ __global__ __launch_bounds__(256) void grid_scan_kernel(GridBatch g) {
         }
     }
     if (PASS == 1 && live) a.owner2[i2] = owner;
+    if (PASS == 1 && a.elig && live) {
+        a.elig_cnt[p] = n_elig < GRID_ELIG ? n_elig : GRID_ELIG;
+        if (n_elig > GRID_ELIG) a.ovf[0] = 1;  // benign race: every writer stores 1
+    }
+}
+
+// Pass 2 of the single-scan formulation: lane = right feature (scan position p); for each eligible pair (i1, d) it met in
+// pass 1 that is not i1's best: :160 for the pair (best, this candidate), best_d < d * minRatio12P in DOUBLE, else block i1.
+__global__ __launch_bounds__(256) void grid_elig_kernel(GridBatch g) {
+    const GridArgs a = frame_view(g, blockIdx.y);
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= a.n2 || a.ovf[0] != 0) return;
+    const int i2 = a.perm[p];
+    const int cnt = a.elig_cnt[p];
+    uint32_t* __restrict__ best_key = reinterpret_cast<uint32_t*>(a.top2);
+    for (int s = 0; s < cnt; ++s) {
+        const uint32_t e = a.elig[(size_t)s * a.elig_stride + p];
+        const uint32_t i1 = e >> 16, d = e & 0xFFFFu;
+        const uint32_t bk = best_key[2 * (size_t)i1];
+        if (((d << 16) | (uint32_t)i2) != bk) {
+            const double best_d = (double)(int)(bk >> 16), d2 = (double)(int)d;
+            if (!(best_d < d2 * a.ratio)) best_key[2 * (size_t)i1 + 1] = 1u;
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void grid_finalize_kernel(GridBatch g) {
@@ -341,20 +406,35 @@ void launch_grid_batch(hipStream_t s, const GridBatch& g, bool lines, hipEvent_t
         else
             hipLaunchKernelGGL((grid_cover_kernel<true, false>), gc, blk, 0, s, g);
         if (scan_events) (void)hipEventRecord(scan_events[0], s);
-        hipLaunchKernelGGL((grid_scan_kernel<true, 1>), g2, blk, 0, s, g);
-        hipLaunchKernelGGL((grid_scan_kernel<true, 2>), g2, blk, 0, s, g);
+        hipLaunchKernelGGL((grid_scan_kernel<true, 1, false>), g2, blk, 0, s, g);
+        if (g.elig) hipLaunchKernelGGL(grid_elig_kernel, g2, blk, 0, s, g);
+        hipLaunchKernelGGL((grid_scan_kernel<true, 2, false>), g2, blk, 0, s, g);
         if (scan_events) (void)hipEventRecord(scan_events[1], s);
     } else {
-        if (use_lds)
-            hipLaunchKernelGGL((grid_cover_kernel<false, true>), gc, blk, lds, s, g);
-        else
-            hipLaunchKernelGGL((grid_cover_kernel<false, false>), gc, blk, 0, s, g);
-        if (scan_events) (void)hipEventRecord(scan_events[0], s);
-        hipLaunchKernelGGL((grid_scan_kernel<false, 1>), g2, blk, 0, s, g);
-        hipLaunchKernelGGL((grid_scan_kernel<false, 2>), g2, blk, 0, s, g);
+        const bool range = g.range_points && g.range1 != nullptr;
+        if (range) {
+            if (scan_events) (void)hipEventRecord(scan_events[0], s);
+            hipLaunchKernelGGL((grid_scan_kernel<false, 1, true>), g2, blk, 0, s, g);
+            if (g.elig) hipLaunchKernelGGL(grid_elig_kernel, g2, blk, 0, s, g);
+            hipLaunchKernelGGL((grid_scan_kernel<false, 2, true>), g2, blk, 0, s, g);
+        } else {
+            if (use_lds)
+                hipLaunchKernelGGL((grid_cover_kernel<false, true>), gc, blk, lds, s, g);
+            else
+                hipLaunchKernelGGL((grid_cover_kernel<false, false>), gc, blk, 0, s, g);
+            if (scan_events) (void)hipEventRecord(scan_events[0], s);
+            hipLaunchKernelGGL((grid_scan_kernel<false, 1, false>), g2, blk, 0, s, g);
+            if (g.elig) hipLaunchKernelGGL(grid_elig_kernel, g2, blk, 0, s, g);
+            hipLaunchKernelGGL((grid_scan_kernel<false, 2, false>), g2, blk, 0, s, g);
+        }
         if (scan_events) (void)hipEventRecord(scan_events[1], s);
     }
     hipLaunchKernelGGL(grid_finalize_kernel, g1, blk, 0, s, g);
+}
+
+// test hook: the candidate masks of the range formulation, written into g.cover in the bit-matrix layout
+void launch_grid_range_debug(hipStream_t s, const GridBatch& g) {
+    hipLaunchKernelGGL(grid_range_debug_kernel, dim3((g.n1p + 255) / 256, g.B), dim3(256), 0, s, g);
 }
 
 namespace {
@@ -422,6 +502,12 @@ int run_grid(stvo_ctx* ctx, const int32_t* cell_xy1, const uint8_t* d1, int n1, 
     a.rank = drank;
     a.perm = dperm;
     TRY(flush_uploads(ctx));
+    if (mutual) {
+        a.elig = arena_alloc<uint32_t>(ctx, (size_t)GRID_ELIG * n2);
+        a.elig_cnt = arena_alloc<int32_t>(ctx, (size_t)n2);
+        a.ovf = arena_alloc<int32_t>(ctx, 1);
+        if (!a.elig || !a.elig_cnt || !a.ovf) return STVO_ERR_CAPACITY;
+    }
     a.cover = arena_alloc<unsigned long long>(ctx, (size_t)a.n1p * a.words64);
     a.top2 = arena_alloc<unsigned long long>(ctx, (size_t)n1);
     downer = arena_alloc<int32_t>(ctx, (size_t)n2);

@@ -119,8 +119,21 @@ struct GridBatch {
     unsigned long long* top2;  // [B][stride1] scratch
     int32_t* owner2;           // [B][stride2] scratch
     int32_t* m12;              // [B][stride1] out
+    // optional scratch of the single-scan formulation (mutual != 0): the ELIGIBLE (left feature, distance) pairs every right
+    // feature met in scan pass 1 — nullptr: two full scan passes
+    // range_points != 0 (points, window of one grid row, right features numbered in CSR order — the stvo_seq pipeline): the
+    // candidates of a left feature are ONE contiguous range of scan positions, cell_start[row][x - w_lo] .. cell_start[row][x +
+    // w_hi + 1); the scan derives its masks from cell_start and no candidate bit-matrix is built (cover may be nullptr);
+    // top2 / ovf must then be initialised by the caller (kTop2Empty = 0x00000000FFFFFFFF, 0)
+    int range_points;
+    const int32_t* range1;     // [B][stride1][2] (lo, hi) of every left feature when range_points != 0
+    uint32_t* elig;            // [B][GRID_ELIG][stride2]  (i1 << 16 | d), slot-major
+    int32_t* elig_cnt;         // [B][stride2]
+    int32_t* ovf;              // [B] set when some right feature of the frame met more than GRID_ELIG eligible pairs
 };
+constexpr int GRID_ELIG = 16;
 // scan_events (optional): [0] / [1] are recorded on `s` before / after the two grid_scan passes
 void launch_grid_batch(hipStream_t s, const GridBatch& g, bool lines, hipEvent_t* scan_events = nullptr);
+void launch_grid_range_debug(hipStream_t s, const GridBatch& g);  // test hook, see stvo_seq_debug_grid
 
 }  // namespace stvo

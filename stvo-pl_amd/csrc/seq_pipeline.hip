@@ -89,6 +89,10 @@ struct SeqDev {
     int32_t* host_n;
     int32_t* host_nl;
     int zero_nl;  // line stage skipped for this frame: the point tail clears nl[b] (saves a memset launch)
+    // scratch of the point grid matcher that point_cells_kernel initialises (no candidate bit-matrix kernel runs for points)
+    unsigned long long* top2_p;  // [B][K]
+    int32_t* govf_p;             // [B]
+    int32_t* prange;             // [B][K][2] candidate range of every left key-point in CSR positions (GridStructure::get, one-row window)
 };
 
 __device__ __forceinline__ bool in_grid(int x, int y) {
@@ -147,7 +151,11 @@ __global__ __launch_bounds__(256) void point_cells_kernel(SeqDev s) {
         hist[c] = 0;
         fill[c] = 0;
     }
-    if (tid == 0) s_extra = 0;
+    for (int i = tid; i < s.K; i += 256) s.top2_p[off + i] = 0x00000000FFFFFFFFull;  // grid matcher: no eligible candidate yet
+    if (tid == 0) {
+        s.govf_p[b] = 0;
+        s_extra = 0;
+    }
     __syncthreads();
     for (int i = tid; i < nr; i += 256) {
         const int x = (int)((double)s.kp_r[(off + i) * 2 + 0] * inv_w);
@@ -157,6 +165,21 @@ __global__ __launch_bounds__(256) void point_cells_kernel(SeqDev s) {
     __syncthreads();
     scan_cells(hist, s_wave, s.pstart + (size_t)b * (STVO_GRID_CELLS + 1));
     const int n_in = s.pstart[(size_t)b * (STVO_GRID_CELLS + 1) + STVO_GRID_CELLS];
+    // GridStructure::get with the stereo window (matching_s_ws cells to the left, same row; src/gridStructure.cpp:65-76,
+    // src/stereoFrame.cpp:141-143): cells x - ws .. x of row y are contiguous in the CSR => candidates = positions [lo, hi)
+    for (int i = tid; i < nl; i += 256) {
+        const int x = s.pxy_l[(off + i) * 2 + 0], y = s.pxy_l[(off + i) * 2 + 1];
+        int lo = 0, hi = 0;
+        if (y >= 0 && y < STVO_GRID_ROWS) {
+            const int min_x = min(max(0, x - s.mp.matching_s_ws), STVO_GRID_COLS), max_x = max(min(STVO_GRID_COLS, x + 1), min_x);
+            const int c0 = y * STVO_GRID_COLS + min_x, c1 = y * STVO_GRID_COLS + max_x;
+            lo = hist[c0];
+            hi = c1 < STVO_GRID_CELLS ? hist[c1] : n_in;
+        }
+        s.prange[(off + i) * 2 + 0] = lo;
+        s.prange[(off + i) * 2 + 1] = hi;
+    }
+    __syncthreads();  // hist (the cell starts) is read above and advanced by nobody: fill[] takes the scatter counters
     for (int i = tid; i < nr; i += 256) {
         const int x = (int)((double)s.kp_r[(off + i) * 2 + 0] * inv_w);
         const int y = (int)((double)s.kp_r[(off + i) * 2 + 1] * inv_h);
@@ -464,6 +487,8 @@ struct stvo_seq {
     } set[2];
     int cur = 0;
     unsigned long long *cover, *top2;
+    uint32_t *elig = nullptr, *elig_l = nullptr;         // eligible pairs of the grid scans (points / lines), see GridBatch
+    int32_t *elig_cnt = nullptr, *elig_cnt_l = nullptr, *govf = nullptr, *govf_l = nullptr;
     int32_t *owner2, *m12s_p, *m12s_l, *m12p, *m12l, *inlp, *inll, *counts;
     stvo_pose_result* results;
     char* out_host = nullptr;  // pinned: results + counts
@@ -492,6 +517,7 @@ struct stvo_seq {
     bool set_lines[2] = {false, false};  // stereo set was built from a frame with key-lines
     bool last_lines = false;             // the last step ran the line stage
     int last_slot = 0;                   // raw slot of the last step
+    stvo::GridBatch last_point_grid{};   // arguments of the last point grid match (test hook)
     size_t off_kp_l, off_oct_l, off_desc_l, off_nkl, off_kp_r, off_desc_r, off_nkr, off_kl_l, off_oct_ll, off_ldesc_l,
         off_nll, off_kl_r, off_ldesc_r, off_nlr;
 };
@@ -564,12 +590,14 @@ int stvo_seq_create_multi(stvo_ctx* ctx, int B, int max_keypoints, int max_keyli
     const size_t o_raw = c.take(s->raw_bytes), o_raw1 = c.take(s->raw_bytes);
     const size_t o_cams = c.take(nb * sizeof(stvo_cam)), o_invwh = c.take(nb * 2 * 8);
     const size_t o_pxy = c.take(nb * K * 2 * 4), o_pstart = c.take(nb * (STVO_GRID_CELLS + 1) * 4), o_pitems = c.take(nb * K * 4),
-                 o_prank = c.take(nb * K * 4), o_pperm = c.take(nb * K * 4);
+                 o_prank = c.take(nb * K * 4), o_pperm = c.take(nb * K * 4), o_prange = c.take(nb * K * 2 * 4);
     const size_t o_lxy = c.take(nb * M * 4 * 4), o_lstart = c.take(nb * (STVO_GRID_CELLS + 1) * 4),
                  o_litems = c.take(nb * M * stvo::LENT * 4), o_lrank = c.take(nb * M * 4), o_lperm = c.take(nb * M * 4),
                  o_ldir = c.take(nb * M * 2 * 8);
     const int R = K > M ? K : M;
     const size_t o_cover = c.take(nb * (size_t)(R / 64) * R * 8), o_top2 = c.take(nb * R * 8), o_owner = c.take(nb * R * 4);
+    const size_t o_elig = c.take(nb * stvo::GRID_ELIG * (size_t)K * 4), o_eligc = c.take(nb * K * 4), o_govf = c.take(nb * 4);
+    const size_t o_elig_l = c.take(nb * stvo::GRID_ELIG * (size_t)M * 4), o_eligc_l = c.take(nb * M * 4), o_govf_l = c.take(nb * 4);
     const size_t o_m12sp = c.take(nb * K * 4), o_m12sl = c.take(nb * M * 4), o_m12p = c.take(nb * K * 4), o_m12l = c.take(nb * M * 4),
                  o_inlp = c.take(nb * K * 4), o_inll = c.take(nb * M * 4), o_res = c.take(nb * sizeof(stvo_pose_result)),
                  o_counts = c.take(nb * 4 * 4);
@@ -641,6 +669,8 @@ int stvo_seq_create_multi(stvo_ctx* ctx, int B, int max_keypoints, int max_keyli
     d.lrank = (int32_t*)(D + o_lrank); d.lperm = (int32_t*)(D + o_lperm); d.ldir = (double*)(D + o_ldir);
     s->cover = (unsigned long long*)(D + o_cover); s->top2 = (unsigned long long*)(D + o_top2);
     s->owner2 = (int32_t*)(D + o_owner);
+    s->elig = (uint32_t*)(D + o_elig); s->elig_cnt = (int32_t*)(D + o_eligc); s->govf = (int32_t*)(D + o_govf);
+    s->elig_l = (uint32_t*)(D + o_elig_l); s->elig_cnt_l = (int32_t*)(D + o_eligc_l); s->govf_l = (int32_t*)(D + o_govf_l);
     s->cover_l = (unsigned long long*)(D + o_cover_l); s->top2_l = (unsigned long long*)(D + o_top2_l);
     s->owner2_l = (int32_t*)(D + o_owner_l);
     s->lazy_l = stvo::LazyScratch{(uint2*)(D + o_knn12_l), (uint2*)(D + o_knn21_l), (int32_t*)(D + o_cand_l), (int32_t*)(D + o_need_l),
@@ -652,6 +682,7 @@ int stvo_seq_create_multi(stvo_ctx* ctx, int B, int max_keypoints, int max_keyli
     s->m12_span = o_inlp - o_m12sp;  // m12s_p, m12s_l, m12p, m12l are carved back to back
     s->inl_span = o_res - o_inlp;    // inlp, inll likewise
     d.m12s_p = s->m12s_p; d.m12s_l = s->m12s_l;
+    d.top2_p = s->top2; d.govf_p = s->govf; d.prange = (int32_t*)(D + o_prange);
     for (int t = 0; t < 2; ++t) {
         stvo_seq::Set& q = s->set[t];
         q.pl = (double*)(D + o_set[t][0]); q.P = (double*)(D + o_set[t][1]); q.s2 = (double*)(D + o_set[t][2]);
@@ -869,6 +900,10 @@ int stvo_seq_step_dev(stvo_seq* s, int slot) {
         g.w = stvo_grid_window{s->mp.matching_s_ws, 0, 0, 0};  // stereoFrame.cpp:141-143
         g.ratio = s->ratio_grid; g.line_sim_th = 0.0; g.mutual = s->mp.best_lr_matches;
         g.cover = s->cover; g.rank = d.prank; g.perm = d.pperm; g.top2 = s->top2; g.owner2 = s->owner2; g.m12 = s->m12s_p;
+        if (g.mutual) { g.elig = s->elig; g.elig_cnt = s->elig_cnt; g.ovf = s->govf; }
+        g.range_points = 1;  // device CSR: right key-points are numbered in cell order, one grid row per window
+        g.range1 = d.prange;
+        s->last_point_grid = g;
         stvo::launch_grid_batch(st, g, false, tev ? tev + 2 : nullptr);
         hipLaunchKernelGGL(stvo::point_tail_kernel, dim3(B), dim3(stvo::TAIL_BLOCK), 0, st, d);
         mark(1, st);
@@ -886,6 +921,7 @@ int stvo_seq_step_dev(stvo_seq* s, int slot) {
         g.ratio = s->ratio_grid /* sic, minRatio12P: matching.cpp:241 */; g.line_sim_th = s->mp.line_sim_th;
         g.mutual = s->mp.best_lr_matches;
         g.cover = s->cover_l; g.rank = d.lrank; g.perm = d.lperm; g.top2 = s->top2_l; g.owner2 = s->owner2_l; g.m12 = s->m12s_l;
+        if (g.mutual) { g.elig = s->elig_l; g.elig_cnt = s->elig_cnt_l; g.ovf = s->govf_l; }
         stvo::launch_grid_batch(sl, g, true);
         hipLaunchKernelGGL(stvo::line_tail_kernel, dim3(B), dim3(256), 0, sl, d);
     } else if (!d.zero_nl) {
@@ -1097,6 +1133,10 @@ int stvo_seq_debug_grid(stvo_seq* s, int b, int lines, int32_t* cell_start, int3
     if (n_items) HIP_TRY(ctx, hipMemcpy(cell_items, (lines ? d.litems : d.pitems) + (size_t)b * items_stride, (size_t)n_items * 4, hipMemcpyDeviceToHost));
     if (nl) HIP_TRY(ctx, hipMemcpy(cells_left, (lines ? d.lxy_l : d.pxy_l) + (size_t)b * R * xyw, (size_t)nl * xyw * 4, hipMemcpyDeviceToHost));
     // candidate sets: bit p % 64 of cover[p / 64][i1] <=> right feature perm[p] is a candidate of left feature i1
+    if (!lines && s->last_point_grid.range_points) {  // the point scan derives its masks from ranges: materialise exactly those
+        stvo::launch_grid_range_debug(ctx->stream, s->last_point_grid);
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
     const int words64 = R / 64;
     std::vector<unsigned long long> cover((size_t)words64 * R);
     std::vector<int32_t> perm((size_t)R);
