@@ -236,6 +236,60 @@ def configs1_leg(ctx_dev, rank, B=512, n=2000, steps=10):
             "committed_pose_fraction": ok}
 
 
+CORRELATED_MODELS = {
+    "clustered": dict(cluster_frac=0.6, cluster_size=8, spread_p=0.06),
+    "heavily_clustered": dict(cluster_frac=0.9, cluster_size=16, spread_p=0.04),
+}
+
+
+def correlated_leg(ctx_dev, rank, B=512, n=2000, steps=8):
+    """What the mutual (reverse) check of StVO::match costs when descriptors do NOT discriminate like i.i.d. bits: the
+    configs[1] batch (f2f brute-force mutual-NNR match + optimizePose) with clustered descriptor rows (synth.clustered_desc:
+    groups of near-duplicates, so that second-best distances overlap the blocking thresholds).  The i.i.d. workload needs
+    ZERO reverse distance evaluations; these need the sparse reverse scans.  Live hipEvent timing of the forward scan and of
+    plan + reverse scans, and the plan statistics of the last step."""
+    import torch
+    from stvo_amd import capi, synth
+    from stvo_amd.ctypes_types import opt_params
+    from stvo_amd.devbatch import TrackBatch
+    prm = opt_params("kitti", has_lines=0)
+    out = {}
+    for name, kw in [("iid", None)] + list(CORRELATED_MODELS.items()):
+        frames = [synth.make_f2f_points(synth.frame_seed(rank + 40, k), n=n, desc_model="iid" if kw is None else "clustered", cluster_kw=kw)
+                  for k in range(B)]
+        batch = TrackBatch(frames, max_pts=2048, max_lines=0, device=ctx_dev)
+        ctx = capi.Context(device_id=int(ctx_dev.split(":")[1]), max_rows=2048, max_batch=B)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        try:
+            for _ in range(2):
+                ctx.track_batched(batch, synth.KITTI_CAM, prm, 0.75, 0.75, 1)
+            ctx.synchronize(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                ctx.track_batched(batch, synth.KITTI_CAM, prm, 0.75, 0.75, 1)
+            ctx.synchronize(); torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            ctx.set_kernel_timing(True)
+            for _ in range(steps):
+                ctx.track_batched(batch, synth.KITTI_CAM, prm, 0.75, 0.75, 1)
+            fwd_ms, rev_ms, _ = ctx.get_kernel_timing()
+            ctx.set_kernel_timing(False)
+            plan = ctx.last_reverse_plan(B).astype(np.int64)
+            n1v = batch.host["n_prev_pts"].astype(np.int64)
+            res = batch.results()
+            out[name] = {"descriptor_model": "i.i.d. bits (SURVEY 8d)" if kw is None else kw, "ms_per_step": dt / steps * 1e3,
+                         "forward_scan_ms": fwd_ms, "reverse_check_ms": rev_ms,
+                         "claimed_columns": float(plan[0].mean()), "light_columns": float(plan[1].mean()), "heavy_columns": float(plan[2].mean()),
+                         "rows_in_S": float(plan[3].mean()), "rows_in_S_fraction": float((plan[3] / np.maximum(n1v, 1)).mean()), "tau": float(plan[4].mean()),
+                         "reverse_distance_evaluations_per_frame": float((plan[1] * plan[3] + plan[2] * n1v).mean()),
+                         "accepted_matches": float(res["n_matched_pt"].mean()), "committed_pose_fraction": float((res["status"] == 0).mean())}
+        finally:
+            ctx.close()
+    out["note"] = ("reverse check = forward_plan kernel + two sparse scans of K1m (light columns against the rows of S, heavy columns against all "
+                   "rows, DESIGN.md section 5); the plan of a frame of near-duplicates degrades towards the full reverse scan")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -395,10 +449,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_extras:
         out["latency"] = single_stream_latency(local_rank, args.points, args.lines)
         out["configs1"] = configs1_leg(dev_name, rank)
-        try:
-            out["reverse_check_correlated"] = correlated_leg(dev_name, rank)
-        except NameError:
-            pass
+        out["reverse_check_correlated"] = correlated_leg(dev_name, rank)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.points, args.lines)
         out["cpu_baseline_threads"] = cpu_baseline_threads(args.points, args.lines)

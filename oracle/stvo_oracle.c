@@ -1258,3 +1258,103 @@ void orc_optimize_pose(const double init_T[16], const stvo_cam* cam, const stvo_
     out->n_inliers_pt = n_pt;
     out->n_inliers_ls = n_ls;
 }
+
+
+/* ---- key-frame decision: StereoFrameHandler::needNewKF / currFrameIsKF (src/stereoFrameHandler.cpp:1136-1218), the
+ * "slam functions" PL-SLAM drives on top of PL-StVO.  Eigen's Matrix6d::determinant() (PartialPivLU) is restated as
+ * Gaussian elimination with partial pivoting; uncTinv_se3 follows src/auxiliar.cpp:184-190. ---- */
+static double orc_det6(const double* Ain) {
+    double A[36];
+    memcpy(A, Ain, sizeof(A));
+    double det = 1.0;
+    for (int k = 0; k < 6; ++k) {
+        int p = k;
+        double big = fabs(A[k * 6 + k]);
+        for (int i = k + 1; i < 6; ++i)
+            if (fabs(A[i * 6 + k]) > big) {
+                big = fabs(A[i * 6 + k]);
+                p = i;
+            }
+        if (big == 0.0) return 0.0;
+        if (p != k) {
+            for (int j = 0; j < 6; ++j) {
+                const double t = A[k * 6 + j];
+                A[k * 6 + j] = A[p * 6 + j];
+                A[p * 6 + j] = t;
+            }
+            det = -det;
+        }
+        det *= A[k * 6 + k];
+        for (int i = k + 1; i < 6; ++i) {
+            const double f = A[i * 6 + k] / A[k * 6 + k];
+            for (int j = k; j < 6; ++j) A[i * 6 + j] -= f * A[k * 6 + j];
+        }
+    }
+    return det;
+}
+
+static void orc_sandwich6(const double* A, const double* C, double* out) { /* out = A C A^T */
+    double T[36];
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) {
+            double s = 0.0;
+            for (int k = 0; k < 6; ++k) s += A[i * 6 + k] * C[k * 6 + j];
+            T[i * 6 + j] = s;
+        }
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) {
+            double s = 0.0;
+            for (int k = 0; k < 6; ++k) s += T[i * 6 + k] * A[j * 6 + k];
+            out[i * 6 + j] = s;
+        }
+}
+
+/* state = {prev_f_iskf, entropy_first_prevKF, N_prevKF_currF, T_prevKF[16], cov_prevKF_currF[36]} = 55 doubles
+ * (src/stereoFrameHandler.cpp:48-51).  Returns 1 when a new key-frame is needed (:1173-1178), else counts the frame. */
+int orc_need_new_kf(double* st, const double* Tfw, const double* DT, const double* DT_cov, double min_entropy_ratio,
+                    double max_kf_t_dist, double max_kf_r_dist) {
+    double* T_prevKF = st + 3;
+    double* cov_acc = st + 19;
+    const double c0 = 3.0 * (1.0 + log(2.0 * acos(-1.0)));
+    if (st[0] != 0.0) { /* :1140-1153 */
+        const double det = orc_det6(DT_cov);
+        st[1] = det != 0.0 ? c0 + 0.5 * log(det) : -999999999.99;
+        st[0] = 0.0;
+    }
+    double Ti[16], D[16], dX[6];
+    orc_inverse_se3(Tfw, Ti);
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            double s = 0.0;
+            for (int k = 0; k < 4; ++k) s += Ti[i * 4 + k] * T_prevKF[k * 4 + j];
+            D[i * 4 + j] = s;
+        }
+    orc_logmap_se3(D, dX);
+    const double t = sqrt(dX[0] * dX[0] + dX[1] * dX[1] + dX[2] * dX[2]);
+    const double r = sqrt(dX[3] * dX[3] + dX[4] * dX[4] + dX[5] * dX[5]) * 180.f / 3.1415926535897932384626433832795;
+    double A[36], DTi[16], Ai[36], cinv[36], add[36];
+    orc_adjoint_se3(T_prevKF, A);
+    orc_inverse_se3(DT, DTi);
+    orc_adjoint_se3(DTi, Ai);
+    orc_sandwich6(Ai, DT_cov, cinv); /* uncTinv_se3 */
+    orc_sandwich6(A, cinv, add);
+    for (int i = 0; i < 36; ++i) cov_acc[i] += add[i];
+    const double entropy_curr = c0 + 0.5 * log(orc_det6(cov_acc));
+    const double ratio = entropy_curr / st[1];
+    int zero_cov = 1, ident = 1;
+    for (int i = 0; i < 36; ++i) zero_cov = zero_cov && DT_cov[i] == 0.0;
+    for (int i = 0; i < 16; ++i) ident = ident && DT[i] == ((i % 5 == 0) ? 1.0 : 0.0);
+    if (ratio < min_entropy_ratio || isnan(ratio) || isinf(ratio) || (zero_cov && ident) || t > max_kf_t_dist ||
+        r > max_kf_r_dist || st[2] > 10.0)
+        return 1;
+    st[2] += 1.0;
+    return 0;
+}
+
+/* the state part of currFrameIsKF (:1205-1216): Tfw = I, then T_prevKF = Tfw, covariance and counter reset */
+void orc_curr_frame_is_kf(double* st) {
+    st[0] = 1.0;
+    st[2] = 0.0;
+    for (int i = 0; i < 16; ++i) st[3 + i] = (i % 5 == 0) ? 1.0 : 0.0;
+    for (int i = 0; i < 36; ++i) st[19 + i] = 0.0;
+}

@@ -99,6 +99,9 @@ void orc_optimize_functions(const double DT[16], const stvo_cam* cam, const stvo
                             int robust, double H[36], double g[6], double* e, int32_t* n_used);
 void orc_remove_outliers(const double DT[16], const stvo_cam* cam, const stvo_opt_params* p, orc_matched* m,
                          int32_t* n_inl_pt, int32_t* n_inl_ls);
+int orc_need_new_kf(double* state55, const double* Tfw, const double* DT, const double* DT_cov, double min_entropy_ratio,
+                    double max_kf_t_dist, double max_kf_r_dist);
+void orc_curr_frame_is_kf(double* state55);
 void orc_optimize_pose(const double init_T[16], const stvo_cam* cam, const stvo_opt_params* p, orc_matched* m,
                        stvo_pose_result* out);
 

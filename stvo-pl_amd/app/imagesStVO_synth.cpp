@@ -4,7 +4,9 @@
 // pre-extracted stereo features instead of images (no OpenCV / datasets in this image; the
 // ORB / LSD+LBD front-end is out of scope).  Writes per-frame results for the parity tests.
 //
-//   imagesStVO_synth <sequence.bin> <results.bin> [--preset kitti|euroc|default] [-c config.yaml] [--mode 0|1|2] [-n N]
+//   imagesStVO_synth <sequence.bin> <results.bin> [--preset kitti|euroc|default] [-c config.yaml] [--mode 0|1|2]
+//                    [-o offset] [-n N] [-s step]   (the reference's options, app/imagesStVO.cpp:138-171)
+//                    [--keyframes]   (needNewKF / currFrameIsKF after every optimizePose, as PL-SLAM drives them)
 //                    [--device-pipeline]   (stvo_seq_*: one upload + one synchronisation per frame, state in HBM)
 #include <chrono>
 #include <cstdio>
@@ -58,7 +60,8 @@ int main(int argc, char** argv) {
         return -1;
     }
     std::string preset = "kitti", cfg;
-    int mode = 0, max_frames = 0;
+    int mode = 0, max_frames = 0, frame_offset = 0, frame_step = 1;
+    bool keyframes = false;
     bool device_pipeline = false;
     for (int i = 3; i < argc; ++i) {
         if (!std::strcmp(argv[i], "--preset") && i + 1 < argc) preset = argv[++i];
@@ -66,6 +69,9 @@ int main(int argc, char** argv) {
         else if (!std::strcmp(argv[i], "--mode") && i + 1 < argc) mode = std::atoi(argv[++i]);
         else if (!std::strcmp(argv[i], "-n") && i + 1 < argc) max_frames = std::atoi(argv[++i]);
         else if (!std::strcmp(argv[i], "--device-pipeline")) device_pipeline = true;
+        else if (!std::strcmp(argv[i], "--keyframes")) keyframes = true;
+        else if (!std::strcmp(argv[i], "-o") && i + 1 < argc) frame_offset = std::atoi(argv[++i]);  // imagesStVO.cpp:158-159
+        else if (!std::strcmp(argv[i], "-s") && i + 1 < argc) frame_step = std::atoi(argv[++i]);    // imagesStVO.cpp:162-163
     }
     if (preset == "kitti") Config::setKittiPreset();
     else if (preset == "euroc") Config::setEurocPreset();
@@ -81,7 +87,13 @@ int main(int argc, char** argv) {
         std::cerr << "bad sequence file\n";
         return -1;
     }
-    if (max_frames > 0 && max_frames < n_frames) n_frames = max_frames;
+    if (frame_offset < 0) frame_offset = 0;
+    if (frame_step < 1) frame_step = 1;
+    const int n_file_frames = n_frames;
+    {   // frames the run will process: offset, step, then -n
+        const int avail = n_file_frames > frame_offset ? (n_file_frames - frame_offset + frame_step - 1) / frame_step : 0;
+        n_frames = (max_frames > 0 && max_frames < avail) ? max_frames : avail;
+    }
     std::ofstream out(argv[2], std::ios::binary);
     PinholeStereoCamera* cam_pin = new PinholeStereoCamera(cols, rows, camv[0], camv[1], camv[2], camv[3], camv[4]);
 
@@ -99,6 +111,11 @@ int main(int argc, char** argv) {
         mp.stereo_overlap_th = Config::stereoOverlapTh(); mp.line_horiz_th = Config::lineHorizTh();
         mp.ls_min_disp_ratio = Config::lsMinDispRatio(); mp.orb_scale_factor = Config::orbScaleFactor();
         mp.lsd_scale = Config::lsdScale();
+        mp.min_ratio_12_p_d = Config::minRatio12P();
+        if (frame_offset != 0 || frame_step != 1 || keyframes) {
+            std::cerr << "--device-pipeline takes the sequence as it is: -o / -s / --keyframes belong to the handler path" << std::endl;
+            return -1;
+        }
         stvo_opt_params op{};
         op.mode = mode; op.has_points = Config::hasPoints(); op.has_lines = Config::hasLines();
         op.min_features = Config::minFeatures(); op.max_iters = Config::maxIters(); op.max_iters_ref = Config::maxItersRef();
@@ -174,7 +191,10 @@ int main(int argc, char** argv) {
     }
     StVO->mode = mode;
     double t_total = 0.0, t_st = 0.0, t_ff = 0.0, t_po = 0.0;
-    for (int frame_counter = 0; frame_counter < n_frames; ++frame_counter) {
+    // -o / -s / -n as the reference's Dataset applies them (src/dataset.cpp: skip `offset` frames, then take every `step`-th
+    // frame, at most `n` of them): frames that are not selected are read and dropped
+    int frame_counter = -1, n_done = 0;
+    for (int file_idx = 0; file_idx < n_file_frames; ++file_idx) {
         FrameFeatures feat;
         feat.img_cols = cols;
         feat.img_rows = rows;
@@ -182,9 +202,13 @@ int main(int argc, char** argv) {
         if (!rd(in, n, 4) || !read_points(in, n[0], feat.points_l, feat.pdesc_l) ||
             !read_points(in, n[1], feat.points_r, feat.pdesc_r) || !read_lines(in, n[2], feat.lines_l, feat.ldesc_l) ||
             !read_lines(in, n[3], feat.lines_r, feat.ldesc_r)) {
-            std::cerr << "truncated sequence file at frame " << frame_counter << "\n";
+            std::cerr << "truncated sequence file at frame " << file_idx << "\n";
             return -1;
         }
+        if (file_idx < frame_offset || (file_idx - frame_offset) % frame_step != 0) continue;
+        if (max_frames > 0 && n_done >= max_frames) break;
+        ++frame_counter;
+        ++n_done;
         if (frame_counter == 0) {
             StVO->initialize(feat, 0);
             continue;
@@ -211,6 +235,7 @@ int main(int argc, char** argv) {
                                   StVO->n_inliers_pt, (int32_t)StVO->matched_ls.size(), StVO->n_inliers_ls,
                                   (int32_t)StVO->curr_frame->stereo_pt.size(), (int32_t)StVO->curr_frame->stereo_ls.size(),
                                   0};
+        int32_t new_kf = 0;
         wr(out, ints, 12);
         wr(out, StVO->curr_frame->DT.m, 16);
         wr(out, StVO->curr_frame->DT_cov.m, 36);
@@ -218,11 +243,16 @@ int main(int argc, char** argv) {
         wr(out, &StVO->curr_frame->err_norm, 1);
         wr(out, StVO->curr_frame->Tfw.m, 16);
         wr(out, StVO->curr_frame->Tfw_cov.m, 36);
+        // the key-frame decision PL-SLAM drives on top of the odometry (src/stereoFrameHandler.cpp:1136-1218): the pose of the
+        // frame has been written above; a new key-frame restarts the map frame (Tfw = I) for the frames that follow
+        if (keyframes && StVO->needNewKF()) {
+            StVO->currFrameIsKF();
+            new_kf = 1;
+        }
         StVO->updateFrame();
         const int32_t fast = StVO->orb_fast_th;
         wr(out, &fast, 1);
-        const int32_t pad = 0;
-        wr(out, &pad, 1);
+        wr(out, &new_kf, 1);  // (the spare word of the record)
     }
     if (n_frames > 1)
         std::printf("[imagesStVO_synth] %d frame pairs, mean Proc. time %.3f ms (single stream, incl. H2D/D2H): stereo "

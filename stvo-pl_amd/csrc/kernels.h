@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdlib>
+
 #include "../../include/stvo_hip.h"
 
 namespace stvo {
@@ -16,6 +18,7 @@ inline int knn_pick_nseg(int B, int max_n, size_t capacity) {
     const int tiles = (max_n + 255) / 256;
     int nseg = (2048 + B * tiles - 1) / (B * tiles > 0 ? B * tiles : 1);
     nseg = nseg < KNN_MIN_NSEG ? KNN_MIN_NSEG : (nseg > KNN_MAX_NSEG ? KNN_MAX_NSEG : nseg);
+    if (const char* e = std::getenv("STVO_KNN_NSEG")) nseg = std::atoi(e) > 0 ? std::atoi(e) : nseg;  // developer override
     const size_t per_seg = (size_t)(B > 0 ? B : 1) * (size_t)(max_n > 0 ? max_n : 1);
     while (nseg > 1 && (size_t)nseg * per_seg > capacity) --nseg;
     return nseg;

@@ -822,6 +822,35 @@ PM_HD double line_overlap(double sox, double soy, double eox, double eoy, double
     return overlap_from_lambdas((fsx - sox) / lx, (fex - sox) / lx);
 }
 
+// Stereo association of a line pair, shared by line_tail_kernel (seq_pipeline.hip) and the host mirror (host/stereoFrame.cpp).
+// Fraction of the left segment's row span [min(y_s, y_e), max(y_s, y_e)] that the right segment's rows cover
+// (StereoFrame::lineSegmentOverlapStereo, src/stereoFrame.cpp:473-508): 1 for a left segment flatter than horiz_th, and the
+// reference normalises by  max(left rows) - min(right rows)  (not by the left span) and clips at 1.
+PM_HD double stereo_row_overlap(double yl_s, double yl_e, double yr_s, double yr_e, double horiz_th) {
+    if (!(fabs(yl_e - yl_s) > horiz_th)) return 1.0;
+    const double l_top = dmin(yl_s, yl_e), l_bot = dmax(yl_s, yl_e);
+    const double r_top = dmin(yr_s, yr_e), r_bot = dmax(yr_s, yr_e);
+    double cover;
+    if (r_bot < l_top || r_top > l_bot)
+        cover = 0.0;                                   // disjoint row ranges
+    else if (r_bot > l_bot && r_top < l_top)
+        cover = l_bot - l_top;                         // the right segment spans the whole left one
+    else
+        cover = dmin(l_bot, r_bot) - dmax(l_top, r_top);
+    const double denom = l_bot - r_top;
+    cover = denom > (double)0.01f ? cover / denom : 0.0;
+    return cover > 1.0 ? 1.0 : cover;
+}
+// End-point disparities of a stereo line; both become -1 when their ratio is below min_ratio
+// (StereoFrame::filterLineSegmentDisparity, src/stereoFrame.cpp:405-415).
+PM_HD void stereo_line_disparities(double xl_s, double xl_e, double xr_s, double xr_e, double min_ratio, double* disp_s,
+                                   double* disp_e) {
+    const double ds = xl_s - xr_s, de = xl_e - xr_e;
+    const bool consistent = !(dmin(ds, de) / dmax(ds, de) < min_ratio);
+    *disp_s = consistent ? ds : -1.0;
+    *disp_e = consistent ? de : -1.0;
+}
+
 struct Cam5 {
     double fx, fy, cx, cy;
 };

@@ -342,29 +342,6 @@ __global__ __launch_bounds__(256) void line_cells_kernel(SeqDev s) {
     }
 }
 
-// StereoFrame::lineSegmentOverlapStereo (src/stereoFrame.cpp:473-508; note length = eln - spn)
-__device__ __forceinline__ double overlap_stereo(double spl_obs, double epl_obs, double spl_proj, double epl_proj,
-                                                 double line_horiz_th) {
-    double overlap = 1.0;
-    if (fabs(epl_obs - spl_obs) > line_horiz_th) {
-        const double sln = pm::dmin(spl_obs, epl_obs), eln = pm::dmax(spl_obs, epl_obs);
-        const double spn = pm::dmin(spl_proj, epl_proj), epn = pm::dmax(spl_proj, epl_proj);
-        const double length = eln - spn;
-        if (epn < sln || spn > eln)
-            overlap = 0.0;
-        else if (epn > eln && spn < sln)
-            overlap = eln - sln;
-        else
-            overlap = pm::dmin(eln, epn) - pm::dmax(sln, spn);
-        if (length > (double)0.01f)
-            overlap = overlap / length;
-        else
-            overlap = 0.0;
-        if (overlap > 1.0) overlap = 1.0;
-    }
-    return overlap;
-}
-
 // ---- 6: lines — geometry filters, back-projection, ordered compaction --------------------------------
 __global__ __launch_bounds__(256) void line_tail_kernel(SeqDev s) {
     __shared__ int s_wave[4];
@@ -393,18 +370,13 @@ __global__ __launch_bounds__(256) void line_tail_kernel(SeqDev s) {
                 const double nrm = sqrt(le_l[0] * le_l[0] + le_l[1] * le_l[1]);
                 le_l[0] /= nrm; le_l[1] /= nrm; le_l[2] /= nrm;
                 double sp_r[2] = {(double)r[0], (double)r[1]}, ep_r[2] = {(double)r[2], (double)r[3]};
-                const double overlap = overlap_stereo(sp_l[1], ep_l[1], sp_r[1], ep_r[1], s.mp.line_horiz_th);
+                const double overlap = pm::stereo_row_overlap(sp_l[1], ep_l[1], sp_r[1], ep_r[1], s.mp.line_horiz_th);
                 // :363-364 — the second line reads the ALREADY overwritten sp_r (reference quirk, kept)
                 sp_r[0] = (sp_r[0] * (sp_l[1] - ep_r[1]) + ep_r[0] * (sp_r[1] - sp_l[1])) / (sp_r[1] - ep_r[1]);
                 sp_r[1] = sp_l[1];
                 ep_r[0] = (sp_r[0] * (ep_l[1] - ep_r[1]) + ep_r[0] * (sp_r[1] - ep_l[1])) / (sp_r[1] - ep_r[1]);
                 ep_r[1] = ep_l[1];
-                disp_s = sp_l[0] - sp_r[0];  // filterLineSegmentDisparity (:405-415)
-                disp_e = ep_l[0] - ep_r[0];
-                if (pm::dmin(disp_s, disp_e) / pm::dmax(disp_s, disp_e) < s.mp.ls_min_disp_ratio) {
-                    disp_s = -1.0;
-                    disp_e = -1.0;
-                }
+                pm::stereo_line_disparities(sp_l[0], ep_l[0], sp_r[0], ep_r[0], s.mp.ls_min_disp_ratio, &disp_s, &disp_e);  // :405-415
                 ok = disp_s >= s.mp.min_disp && disp_e >= s.mp.min_disp && fabs(sp_l[1] - ep_l[1]) > s.mp.line_horiz_th &&
                      fabs(sp_r[1] - ep_r[1]) > s.mp.line_horiz_th && overlap > s.mp.stereo_overlap_th;
             }

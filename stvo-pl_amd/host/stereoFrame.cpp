@@ -260,37 +260,14 @@ void StereoFrame::adoptStereoMatches(const int32_t* m12_points, const int32_t* m
     if (Config::hasLines()) buildStereoLines(lines_l, lines_r, ldesc_l, m12_lines, (frame_idx == 0));
 }
 
-// :405-415
+// :405-415 and :473-508 — the same building blocks line_tail_kernel uses (csrc/pose_math.h)
 void StereoFrame::filterLineSegmentDisparity(Vector2d spl, Vector2d epl, Vector2d spr, Vector2d epr, double& disp_s,
                                              double& disp_e) {
-    disp_s = spl(0) - spr(0);
-    disp_e = epl(0) - epr(0);
-    if (std::min(disp_s, disp_e) / std::max(disp_s, disp_e) < Config::lsMinDispRatio()) {
-        disp_s = -1.0;
-        disp_e = -1.0;
-    }
+    pm::stereo_line_disparities(spl(0), epl(0), spr(0), epr(0), Config::lsMinDispRatio(), &disp_s, &disp_e);
 }
 
-// :473-508 (note length = eln - spn)
 double StereoFrame::lineSegmentOverlapStereo(double spl_obs, double epl_obs, double spl_proj, double epl_proj) {
-    double overlap = 1.f;
-    if (std::fabs(epl_obs - spl_obs) > Config::lineHorizTh()) {
-        const double sln = std::min(spl_obs, epl_obs), eln = std::max(spl_obs, epl_obs);
-        const double spn = std::min(spl_proj, epl_proj), epn = std::max(spl_proj, epl_proj);
-        const double length = eln - spn;
-        if ((epn < sln) || (spn > eln))
-            overlap = 0.f;
-        else if ((epn > eln) && (spn < sln))
-            overlap = eln - sln;
-        else
-            overlap = std::min(eln, epn) - std::max(sln, spn);
-        if (length > 0.01f)
-            overlap = overlap / length;
-        else
-            overlap = 0.f;
-        if (overlap > 1.f) overlap = 1.f;
-    }
-    return overlap;
+    return pm::stereo_row_overlap(spl_obs, epl_obs, spl_proj, epl_proj, Config::lineHorizTh());
 }
 
 // :510-616 — same building block the device kernel uses

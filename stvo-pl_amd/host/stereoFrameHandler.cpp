@@ -86,22 +86,37 @@ void StereoFrameHandler::insertStereoPair(const FrameFeatures& feat, const int i
     t_f2f_ms = std::chrono::duration<double, std::milli>(clk::now() - t1).count();
 }
 
+// The adaptive FAST threshold of updateFrame (:66-86) as a decision table: the first rule that applies moves the threshold
+// by `steps` increments, clipped at the side it moves towards.  A lost frame (DT == I or err above fast_err_th) counts as
+// "fewer than feat_th inliers"; the last row can never fire (the row above shadows it), upstream as here.
+static int adaptFastThreshold(int th, bool lost, int n_inliers_pt) {
+    struct Rule {
+        int mult;   // compared with mult * fast_feat_th
+        bool below; // applies when n_inliers_pt is below (true) / above (false) that figure
+        int steps;  // increments of fast_inc_th
+    };
+    static const Rule rules[] = {{1, true, -2}, {2, true, -1}, {3, false, +1}, {4, false, +2}};
+    int steps = lost ? -2 : 0;
+    if (!lost)
+        for (const Rule& r : rules) {
+            const int ref = r.mult * Config::fastFeatTh();
+            if (r.below ? n_inliers_pt < ref : n_inliers_pt > ref) {
+                steps = r.steps;
+                break;
+            }
+        }
+    const int moved = th + steps * Config::fastIncTh();
+    if (steps < 0) return std::max(Config::fastMinTh(), moved);
+    if (steps > 0) return std::min(Config::fastMaxTh(), moved);
+    return th;
+}
+
 // :62-102
 void StereoFrameHandler::updateFrame() {
     if (Config::adaptativeFAST()) {
-        const int min_fast = Config::fastMinTh(), max_fast = Config::fastMaxTh(), fast_inc = Config::fastIncTh(),
-                  feat_th = Config::fastFeatTh();
         const float err_th = Config::fastErrTh();
-        if (curr_frame->DT == Matrix4d::Identity() || curr_frame->err_norm > err_th)
-            orb_fast_th = std::max(min_fast, orb_fast_th - 2 * fast_inc);
-        else if (n_inliers_pt < feat_th)
-            orb_fast_th = std::max(min_fast, orb_fast_th - 2 * fast_inc);
-        else if (n_inliers_pt < feat_th * 2)
-            orb_fast_th = std::max(min_fast, orb_fast_th - fast_inc);
-        else if (n_inliers_pt > feat_th * 3)
-            orb_fast_th = std::min(max_fast, orb_fast_th + fast_inc);
-        else if (n_inliers_pt > feat_th * 4)  // unreachable upstream too (shadowed by the branch above)
-            orb_fast_th = std::min(max_fast, orb_fast_th + 2 * fast_inc);
+        const bool lost = curr_frame->DT == Matrix4d::Identity() || curr_frame->err_norm > err_th;
+        orb_fast_th = adaptFastThreshold(orb_fast_th, lost, n_inliers_pt);
     }
     for (auto pt : matched_pt) delete pt;
     for (auto ls : matched_ls) delete ls;

@@ -57,6 +57,21 @@ def flip_bits(rng, desc, p):
     return desc ^ mask
 
 
+def clustered_desc(rng, n, cluster_frac=0.6, cluster_size=8, spread_p=0.06):
+    """Descriptors that do NOT discriminate like i.i.d. bits: `cluster_frac` of the rows come in groups of ~`cluster_size`
+    near-duplicates (a common centre with each bit flipped w.p. `spread_p`: intra-cluster distance ~ 2 p (1 - p) 256),
+    as repeated structure (windows, foliage, road markings) produces in real ORB / LBD rows; the rest are i.i.d.
+    A clustered row's second-best distance is that of a cluster sibling, i.e. of the order of a true match's distance, so
+    the ratio test and the mutual check of StVO::match (src/matching.cpp:53-58,80-86) are decided by close calls."""
+    d = random_desc(rng, n)
+    n_cl = int(round(cluster_frac * n))
+    n_groups = max(1, n_cl // cluster_size)
+    centres = random_desc(rng, n_groups)
+    member = rng.integers(0, n_groups, n_cl)
+    d[:n_cl] = flip_bits(rng, centres[member], spread_p)
+    return np.ascontiguousarray(d[rng.permutation(n)])
+
+
 def random_motion(rng, t_fwd=(0.5, 1.5), w_sigma=0.01, t_sigma=0.02):
     w = rng.normal(0.0, w_sigma, 3)
     t = np.array([rng.normal(0, t_sigma), rng.normal(0, t_sigma), -rng.uniform(*t_fwd)])
@@ -67,7 +82,8 @@ def random_motion(rng, t_fwd=(0.5, 1.5), w_sigma=0.01, t_sigma=0.02):
 
 
 def make_f2f_points(seed, n=2000, cam=KITTI_CAM, track_frac=0.75, outlier_frac=0.15, flip_p=0.08, noise_px=0.5,
-                    depth=(4.0, 80.0), octave_probs=None, scale_factor=1.2, edge=19, motion=None):
+                    depth=(4.0, 80.0), octave_probs=None, scale_factor=1.2, edge=19, motion=None, desc_model="iid",
+                    cluster_kw=None):
     """BASELINE config 2: one prev/curr pair of stereo-point sets for brute-force f2f matching +
     optimizePose.  Returns a dict of numpy arrays (see keys below)."""
     rng = np.random.default_rng(seed)
@@ -84,7 +100,8 @@ def make_f2f_points(seed, n=2000, cam=KITTI_CAM, track_frac=0.75, outlier_frac=0
         level = rng.choice(len(octave_probs), size=n, p=octave_probs).astype(np.int32)
     sigma2 = 1.0 / (scale_factor ** level.astype(np.float64)) ** 2
 
-    prev_desc = random_desc(rng, n)
+    # desc_model "iid": 256 independent bits per row; "clustered": groups of near-duplicate rows
+    prev_desc = random_desc(rng, n) if desc_model == "iid" else clustered_desc(rng, n, **(cluster_kw or {}))
     n_tr = int(round(track_frac * n))
     tracked = rng.permutation(n)[:n_tr]
     Pc = P[tracked] @ T[:3, :3].T + T[:3, 3]
@@ -98,7 +115,7 @@ def make_f2f_points(seed, n=2000, cam=KITTI_CAM, track_frac=0.75, outlier_frac=0
     curr_desc[:n_tr] = flip_bits(rng, prev_desc[tracked], flip_p)
     curr_pl[:n_tr] = obs
     n_new = n - n_tr
-    curr_desc[n_tr:] = random_desc(rng, n_new)
+    curr_desc[n_tr:] = random_desc(rng, n_new) if desc_model == "iid" else clustered_desc(rng, n_new, **(cluster_kw or {}))
     curr_pl[n_tr:, 0] = rng.uniform(edge, W - edge, n_new)
     curr_pl[n_tr:, 1] = rng.uniform(edge, Hh - edge, n_new)
     perm = rng.permutation(n)

@@ -203,6 +203,26 @@ class Oracle:
     def is_good(self, DT, cov, err):
         return bool(self.lib.orc_is_good_solution(np.ascontiguousarray(DT).reshape(-1), np.ascontiguousarray(cov).reshape(-1), err))
 
+    # ---- key-frame decision ----
+    @staticmethod
+    def kf_state():
+        """{prev_f_iskf = true, entropy, N = 0, T_prevKF = I, cov = 0} (src/stereoFrameHandler.cpp:48-51)"""
+        st = np.zeros(55)
+        st[0] = 1.0
+        st[3:19] = np.eye(4).reshape(-1)
+        return st
+
+    def need_new_kf(self, st, Tfw, DT, DT_cov, min_entropy_ratio=0.85, max_kf_t_dist=5.0, max_kf_r_dist=15.0):
+        self.lib.orc_need_new_kf.argtypes = [f64p, f64p, f64p, f64p, C.c_double, C.c_double, C.c_double]
+        self.lib.orc_need_new_kf.restype = C.c_int
+        return int(self.lib.orc_need_new_kf(st, np.ascontiguousarray(Tfw, np.float64).reshape(-1), np.ascontiguousarray(DT, np.float64).reshape(-1),
+                                            np.ascontiguousarray(DT_cov, np.float64).reshape(-1), min_entropy_ratio, max_kf_t_dist, max_kf_r_dist))
+
+    def curr_frame_is_kf(self, st):
+        self.lib.orc_curr_frame_is_kf.argtypes = [f64p]
+        self.lib.orc_curr_frame_is_kf.restype = None
+        self.lib.orc_curr_frame_is_kf(st)
+
     # ---- optimizer ----
     @staticmethod
     def _matched(rec):

@@ -36,8 +36,11 @@ def matched_line_sigma2(sigma2, level, lsd_scale):
     return out
 
 
-def run_sequence(orc, frames, cam, mp, prm, fast=dict(adaptive=True, th0=20, mn=7, mx=30, inc=5, feat=50, err=0.5)):
+def run_sequence(orc, frames, cam, mp, prm, fast=dict(adaptive=True, th0=20, mn=7, mx=30, inc=5, feat=50, err=0.5), keyframes=None):
+    """keyframes: None, or dict(min_entropy_ratio, max_kf_t_dist, max_kf_r_dist) to run needNewKF / currFrameIsKF after every
+    optimizePose (src/stereoFrameHandler.cpp:1136-1218); every result then carries `new_kf`."""
     has_p, has_l = bool(prm.has_points), bool(prm.has_lines)
+    kf_state = orc.kf_state() if keyframes else None
     prev = stereo_frame(orc, frames[0], cam, mp, has_p, has_l)
     prev.update(Tfw=np.eye(4), Tfw_cov=np.eye(6))
     fast_th = fast["th0"]
@@ -75,6 +78,11 @@ def run_sequence(orc, frames, cam, mp, prm, fast=dict(adaptive=True, th0=20, mn=
                 fast_th = min(fast["mx"], fast_th + fast["inc"])
         out.update(Tfw=curr["Tfw"], Tfw_cov=curr["Tfw_cov"], n_stereo_pt=len(curr["P"]), n_stereo_ls=len(curr["sP"]),
                    n_matched_pt=len(rec["sigma2p"]), n_matched_ls=len(rec["sigma2l"]), fast=fast_th)
+        if keyframes:
+            out["new_kf"] = orc.need_new_kf(kf_state, curr["Tfw"], out["T"], out["cov"], **keyframes)
+            if out["new_kf"]:  # currFrameIsKF: the map frame restarts at this frame
+                orc.curr_frame_is_kf(kf_state)
+                curr["Tfw"], curr["Tfw_cov"] = np.eye(4), np.eye(6)
         results.append(out)
         prev = curr
     return results

@@ -100,3 +100,25 @@ def test_oversized_frame_falls_back_to_the_per_call_path(tmp_path, oracle):
     res, _ = run_app(tmp_path, frames, cam, "kitti", extra=("-c", str(cfg)))
     ref = pipeline_ref.run_sequence(oracle, frames, cam, match_params("kitti"), opt_params("kitti", has_lines=0))
     compare(res, ref)
+
+
+def test_keyframe_decisions_and_cli_offset_step(tmp_path, oracle):
+    """--keyframes: needNewKF / currFrameIsKF (src/stereoFrameHandler.cpp:1136-1218) after every optimizePose of the handler,
+    against the oracle's restatement — same decisions, and the poses after a key-frame are expressed in the restarted map
+    frame.  -o / -s: the reference's frame offset / step options (app/imagesStVO.cpp:138-171)."""
+    cam = synth.KITTI_CAM
+    frames = synth.make_stereo_sequence(4242, n_frames=16, n_pts=500, n_lines=40, cam=cam)
+    cfg = tmp_path / "cfg.yaml"
+    cfg.write_text("max_kf_t_dist : 2.5   # a key-frame every few metres of forward motion\n")
+    res, _ = run_app(tmp_path, frames, cam, "kitti", extra=("--keyframes", "-c", str(cfg)))
+    ref = pipeline_ref.run_sequence(oracle, frames, cam, match_params("kitti"), opt_params("kitti"),
+                                    keyframes=dict(min_entropy_ratio=0.85, max_kf_t_dist=2.5, max_kf_r_dist=15.0))
+    compare(res, ref)
+    got = [int(r["pad"]) for r in res]
+    assert got == [o["new_kf"] for o in ref]
+    assert 2 <= sum(got) < len(got)                      # both outcomes occur
+    # offset 3, every second frame, 5 frames: frames 3, 5, 7, 9, 11
+    res2, _ = run_app(tmp_path, frames, cam, "kitti", extra=("-o", "3", "-s", "2", "-n", "5"))
+    sub = [frames[k] for k in (3, 5, 7, 9, 11)]
+    ref2 = pipeline_ref.run_sequence(oracle, sub, cam, match_params("kitti"), opt_params("kitti"))
+    compare(res2, ref2)

@@ -301,3 +301,19 @@ def test_match_fuzz_sizes_and_entropy(hip, oracle):
         exp, en = oracle.match(d1, d2, nnr, mutual)
         assert np.array_equal(got, exp), (case, n1, n2, ent, nnr, mutual, np.nonzero(got != exp)[0][:10])
         assert n == en
+
+
+@pytest.mark.parametrize("kw", [dict(cluster_frac=0.6, cluster_size=8, spread_p=0.06), dict(cluster_frac=0.9, cluster_size=16, spread_p=0.04),
+                                dict(cluster_frac=1.0, cluster_size=40, spread_p=0.02)])
+def test_match_clustered_descriptors_2000x2000(hip, oracle, kw):
+    """Descriptor rows in groups of near-duplicates (bench.py's `reverse_check_correlated` workload): second-best distances
+    overlap the blocking thresholds, so the reverse check needs its light AND heavy scans with a non-empty row list S.
+    Bit-exact against the oracle at 2000 x 2000, and the plan statistics show that the non-trivial routes were taken."""
+    fr = synth.make_f2f_points(synth.frame_seed(9, int(kw["cluster_size"])), n=2000, desc_model="clustered", cluster_kw=kw)
+    for nnr in (0.75, 0.9):
+        m12, n = hip.match(fr["prev_desc"], fr["curr_desc"], nnr)
+        exp, en = oracle.match(fr["prev_desc"], fr["curr_desc"], nnr)
+        assert np.array_equal(m12, exp) and n == en
+        plan = hip.last_reverse_plan(1)[:, 0]
+        assert plan[0] > 0 and plan[3] > 0, plan          # claimed columns, rows in S
+        assert plan[1] > 0 and plan[2] > 0, plan          # both light and heavy columns

@@ -259,3 +259,14 @@ def test_keyframe_decision(pmh):
     assert 3 <= out.sum() < n  # both outcomes occur
     assert np.allclose(acc.reshape(n, 6, 6), exp_acc, rtol=1e-9, atol=1e-18)
     assert np.allclose(ent, exp_ent, rtol=1e-10)
+    # the oracle's C restatement (oracle/stvo_oracle.c: orc_need_new_kf / orc_curr_frame_is_kf) takes the same decisions and
+    # accumulates the same covariance: a third, independent statement of the rule
+    import oracle_lib
+    orc = oracle_lib.load()
+    st = orc.kf_state()
+    for f in range(n):
+        need = orc.need_new_kf(st, Tfw[f], DT[f], DC[f])
+        assert need == exp_out[f], f
+        assert np.allclose(st[19:55].reshape(6, 6), exp_acc[f], rtol=1e-9, atol=1e-18)
+        if need:
+            orc.curr_frame_is_kf(st)
