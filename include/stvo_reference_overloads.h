@@ -1,0 +1,212 @@
+/*
+ * stvo_reference_overloads.h — the C-ABI seams of stvo_hip.h with the REFERENCE's own argument types.
+ *
+ * Header-only and compiled only where the reference's dependencies exist (OpenCV 3 + Eigen 3 and the reference's
+ * include directory on the include path): there the functions below have exactly the signatures of
+ * include/matching.h:50-60 and can replace the bodies in src/matching.cpp one for one; `hip::optimizePose` is the body a
+ * maintainer drops into StereoFrameHandler::optimizePose (src/stereoFrameHandler.cpp:307-392).  In this repository's own
+ * image neither library exists, so the header preprocesses to nothing and the same calls are exercised through the
+ * value-type mirror in stvo-pl_amd/host/ (tests/test_gpu_handler.py); INTEGRATION.md walks through the wiring.
+ *
+ *   #include <stvo_reference_overloads.h>       // after the reference's own headers
+ *   StVO::hip::set_context(ctx);                // one stvo_ctx per StereoFrameHandler / thread
+ */
+#ifndef STVO_REFERENCE_OVERLOADS_H
+#define STVO_REFERENCE_OVERLOADS_H
+
+#if defined(__has_include)
+#if __has_include(<opencv2/core.hpp>) && __has_include(<eigen3/Eigen/Core>) && __has_include("matching.h") && \
+    __has_include("stereoFrameHandler.h")
+#define STVO_HAVE_REFERENCE_TYPES 1
+#endif
+#endif
+
+#ifdef STVO_HAVE_REFERENCE_TYPES
+
+#include <list>
+#include <stdexcept>
+#include <unordered_set>
+#include <utility>
+#include <vector>
+
+#include <opencv2/core.hpp>
+
+#include "matching.h"            /* the reference's: point_2d, line_2d, GridStructure, GridWindow */
+#include "stereoFrameHandler.h"  /* the reference's: StereoFrameHandler, PointFeature, LineFeature, Config */
+#include "stvo_hip.h"
+
+namespace StVO {
+namespace hip {
+
+inline stvo_ctx*& context_slot() {
+    static thread_local stvo_ctx* ctx = nullptr;
+    return ctx;
+}
+inline void set_context(stvo_ctx* ctx) { context_slot() = ctx; }
+inline stvo_ctx* context() {
+    if (!context_slot()) throw std::runtime_error("[StVO-HIP] no context: call StVO::hip::set_context first");
+    return context_slot();
+}
+inline void check(int rc) {
+    if (rc != STVO_OK) throw std::runtime_error(std::string("[StVO-HIP] ") + stvo_error_string(rc));
+}
+inline const uint8_t* rows32(const cv::Mat& d) {
+    if (d.rows > 0 && (!d.isContinuous() || d.cols != STVO_DESC_BYTES || d.type() != CV_8UC1))
+        throw std::runtime_error("[StVO-HIP] descriptors must be continuous N x 32 CV_8UC1");
+    return d.ptr<uint8_t>();
+}
+
+/* int StVO::matchNNR(const cv::Mat&, const cv::Mat&, float, std::vector<int>&)   include/matching.h:50 */
+inline int matchNNR(const cv::Mat& desc1, const cv::Mat& desc2, float nnr, std::vector<int>& matches_12) {
+    matches_12.assign(desc1.rows, -1);
+    int32_t n = 0;
+    check(stvo_match_nnr_mutual(context(), rows32(desc1), desc1.rows, rows32(desc2), desc2.rows, nnr, 0, matches_12.data(), &n));
+    return n;
+}
+
+/* int StVO::match(const cv::Mat&, const cv::Mat&, float, std::vector<int>&)      include/matching.h:52 */
+inline int match(const cv::Mat& desc1, const cv::Mat& desc2, float nnr, std::vector<int>& matches_12) {
+    matches_12.assign(desc1.rows, -1);
+    int32_t n = 0;
+    check(stvo_match_nnr_mutual(context(), rows32(desc1), desc1.rows, rows32(desc2), desc2.rows, nnr,
+                                Config::bestLRMatches() ? 1 : 0, matches_12.data(), &n));
+    return n;
+}
+
+/* GridStructure -> CSR (cell c = y * 64 + x).  The buckets are private; GridStructure::get with a zero window returns
+ * exactly one cell (src/gridStructure.cpp:65-76), which is all the matcher needs (candidate order is irrelevant). */
+inline void grid_to_csr(const GridStructure& grid, std::vector<int32_t>& start, std::vector<int32_t>& items) {
+    if (grid.cols != STVO_GRID_COLS || grid.rows != STVO_GRID_ROWS)
+        throw std::runtime_error("[StVO-HIP] the bucketing grid must be 64 x 48 (include/stereoFrame.h:51-52)");
+    GridWindow one;
+    one.width = std::make_pair(0, 0);
+    one.height = std::make_pair(0, 0);
+    start.assign(STVO_GRID_CELLS + 1, 0);
+    items.clear();
+    std::unordered_set<int> cell;
+    for (int y = 0; y < STVO_GRID_ROWS; ++y)
+        for (int x = 0; x < STVO_GRID_COLS; ++x) {
+            cell.clear();
+            grid.get(x, y, one, cell);
+            items.insert(items.end(), cell.begin(), cell.end());
+            start[y * STVO_GRID_COLS + x + 1] = (int32_t)items.size();
+        }
+}
+
+/* points overload                                                                  include/matching.h:57 */
+inline int matchGrid(const std::vector<point_2d>& points1, const cv::Mat& desc1, const GridStructure& grid,
+                     const cv::Mat& desc2, const GridWindow& w, std::vector<int>& matches_12) {
+    if ((int)points1.size() != desc1.rows) throw std::runtime_error("[matchGrid] Each point needs a corresponding descriptor!");
+    std::vector<int32_t> start, items, xy(2 * points1.size() + 2);
+    grid_to_csr(grid, start, items);
+    for (size_t i = 0; i < points1.size(); ++i) {
+        xy[2 * i] = points1[i].first;
+        xy[2 * i + 1] = points1[i].second;
+    }
+    const stvo_grid_window win{w.width.first, w.width.second, w.height.first, w.height.second};
+    matches_12.assign(desc1.rows, -1);
+    int32_t n = 0;
+    items.push_back(0);
+    check(stvo_match_grid_points(context(), xy.data(), rows32(desc1), desc1.rows, start.data(), items.data(), rows32(desc2),
+                                 desc2.rows, &win, Config::minRatio12P(), Config::bestLRMatches() ? 1 : 0, matches_12.data(), &n));
+    return n;
+}
+
+/* lines overload                                                                   include/matching.h:60 */
+inline int matchGrid(const std::vector<line_2d>& lines1, const cv::Mat& desc1, const GridStructure& grid, const cv::Mat& desc2,
+                     const std::vector<std::pair<double, double>>& directions2, const GridWindow& w,
+                     std::vector<int>& matches_12) {
+    if ((int)lines1.size() != desc1.rows) throw std::runtime_error("[matchGrid] Each line needs a corresponding descriptor!");
+    std::vector<int32_t> start, items, xy(4 * lines1.size() + 4);
+    grid_to_csr(grid, start, items);
+    for (size_t i = 0; i < lines1.size(); ++i) {
+        xy[4 * i + 0] = lines1[i].first.first;
+        xy[4 * i + 1] = lines1[i].first.second;
+        xy[4 * i + 2] = lines1[i].second.first;
+        xy[4 * i + 3] = lines1[i].second.second;
+    }
+    std::vector<double> dir(2 * directions2.size() + 2);
+    for (size_t j = 0; j < directions2.size(); ++j) {
+        dir[2 * j] = directions2[j].first;
+        dir[2 * j + 1] = directions2[j].second;
+    }
+    const stvo_grid_window win{w.width.first, w.width.second, w.height.first, w.height.second};
+    matches_12.assign(desc1.rows, -1);
+    int32_t n = 0;
+    items.push_back(0);
+    /* minRatio12P, not ...12L: src/matching.cpp:241 */
+    check(stvo_match_grid_lines(context(), xy.data(), rows32(desc1), desc1.rows, start.data(), items.data(), rows32(desc2),
+                                desc2.rows, dir.data(), &win, Config::minRatio12P(), Config::lineSimTh(),
+                                Config::bestLRMatches() ? 1 : 0, matches_12.data(), &n));
+    return n;
+}
+
+/* The body of StereoFrameHandler::optimizePose (src/stereoFrameHandler.cpp:307-392) on the GPU: matched_pt / matched_ls ->
+ * stvo_matched, one stvo_optimize_pose call, inlier flags / counters / curr_frame fields written back, Tfw composed as
+ * :377-378 do.  `mode` is the local constant of :329 (0 in the reference). */
+inline void optimizePose(StereoFrameHandler& h, PinholeStereoCamera* cam, int mode = 0) {
+    std::vector<double> P, obs, s2p, sP, eP, le, spl, epl, s2l;
+    std::vector<int32_t> inl_p, inl_l;
+    for (auto* pt : h.matched_pt) {
+        for (int c = 0; c < 3; ++c) P.push_back(pt->P(c));
+        obs.push_back(pt->pl_obs(0));
+        obs.push_back(pt->pl_obs(1));
+        s2p.push_back(pt->sigma2);
+        inl_p.push_back(pt->inlier ? 1 : 0);
+    }
+    for (auto* ls : h.matched_ls) {
+        for (int c = 0; c < 3; ++c) sP.push_back(ls->sP(c));
+        for (int c = 0; c < 3; ++c) eP.push_back(ls->eP(c));
+        for (int c = 0; c < 3; ++c) le.push_back(ls->le_obs(c));
+        for (int c = 0; c < 2; ++c) spl.push_back(ls->spl(c));
+        for (int c = 0; c < 2; ++c) epl.push_back(ls->epl(c));
+        s2l.push_back(ls->sigma2);
+        inl_l.push_back(ls->inlier ? 1 : 0);
+    }
+    stvo_matched m{};
+    m.np = (int32_t)s2p.size();
+    m.P = P.data(); m.pl_obs = obs.data(); m.sigma2p = s2p.data(); m.inlier_p = inl_p.data();
+    m.nl = (int32_t)s2l.size();
+    m.sP = sP.data(); m.eP = eP.data(); m.le_obs = le.data(); m.spl = spl.data(); m.epl = epl.data(); m.sigma2l = s2l.data();
+    m.inlier_l = inl_l.data();
+    stvo_opt_params prm{};
+    prm.mode = mode;
+    prm.has_points = Config::hasPoints(); prm.has_lines = Config::hasLines(); prm.min_features = Config::minFeatures();
+    prm.max_iters = Config::maxIters(); prm.max_iters_ref = Config::maxItersRef(); prm.homog_th = Config::homogTh();
+    prm.min_error = Config::minError(); prm.min_error_change = Config::minErrorChange(); prm.inlier_k = Config::inlierK();
+    const stvo_cam c{cam->getFx(), cam->getFy(), cam->getCx(), cam->getCy(), cam->getB()};
+    /* :317-326 — identity, or the previous increment under the motion model */
+    double init[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    if (Config::useMotionModel())
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) init[i * 4 + j] = h.prev_frame->DT(i, j);
+    stvo_pose_result r{};
+    check(stvo_optimize_pose(context(), init, &c, &prm, &m, &r));
+    size_t k = 0;
+    for (auto* pt : h.matched_pt) pt->inlier = inl_p[k++] != 0;
+    k = 0;
+    for (auto* ls : h.matched_ls) ls->inlier = inl_l[k++] != 0;
+    h.n_inliers_pt = r.n_inliers_pt;
+    h.n_inliers_ls = r.n_inliers_ls;
+    h.n_inliers = r.n_inliers_pt + r.n_inliers_ls;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) h.curr_frame->DT(i, j) = r.T[i * 4 + j];
+    for (int i = 0; i < 6; ++i) {
+        for (int j = 0; j < 6; ++j) h.curr_frame->DT_cov(i, j) = r.cov[i * 6 + j];
+        h.curr_frame->DT_cov_eig(i) = r.cov_eig[i];
+    }
+    h.curr_frame->err_norm = r.err;
+    if (r.status == STVO_POSE_OK) { /* :377-380 */
+        h.curr_frame->Tfw = expmap_se3(logmap_se3(h.prev_frame->Tfw * h.curr_frame->DT));
+        h.curr_frame->Tfw_cov = unccomp_se3(h.prev_frame->Tfw, h.prev_frame->Tfw_cov, h.curr_frame->DT_cov);
+    } else { /* :382-391 */
+        h.curr_frame->Tfw = h.prev_frame->Tfw;
+        h.curr_frame->Tfw_cov = h.prev_frame->Tfw_cov;
+    }
+}
+
+}  // namespace hip
+}  // namespace StVO
+
+#endif /* STVO_HAVE_REFERENCE_TYPES */
+#endif /* STVO_REFERENCE_OVERLOADS_H */
