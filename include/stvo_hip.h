@@ -210,6 +210,29 @@ int stvo_seq_get_stage_timing(stvo_seq* seq, float avg_ms[STVO_SEQ_NSTAGE], int3
 int stvo_seq_debug_grid(stvo_seq* seq, int b, int lines, int32_t* cell_start, int32_t* cell_items, int32_t cap_items,
                         int32_t* cells_left, int32_t* cand_off, int32_t* cand, int32_t cap_cand, int32_t* n_left);
 
+/* ---- ORB point front-end ------------------------------------------------------------------ */
+
+/* Replaces, for one pyramid level,  cv::ORB::create(...)->detectAndCompute(img, Mat(), points, pdesc, false)  as called by
+ * StereoFrame::detectPointFeatures (src/stereoFrame.cpp:104-118) for B images of cols x rows bytes at once: FAST-9/16 with
+ * non-maximum suppression, border filter, retainBest(nfeatures) on the FAST response (ties at the cut are kept, so up to
+ * max_keypoints may come back), intensity-centroid orientation, 7x7 Gaussian blur and the 256-bit rotated BRIEF descriptor.
+ * Key-points are emitted in row-major order (OpenCV leaves the order to std::nth_element).  OpenCV is third-party code that
+ * is not part of the reference tree: the semantics are pinned to oracle/stvo_orb_oracle.c only (parity unpinned). */
+typedef struct stvo_orb stvo_orb;
+int stvo_orb_create(stvo_ctx* ctx, int B, int cols, int rows, int max_keypoints, const stvo_orb_params* prm, stvo_orb** out);
+int stvo_orb_destroy(stvo_orb* orb);
+/* The 256 x 4 test pattern (x0, y0, x1, y1 per bit, |coordinate| <= 13).  The default is a seeded table; OpenCV's learned
+ * table (bit_pattern_31_ of features2d/src/orb.cpp) is data this repository does not hold — pass it here to reproduce it. */
+int stvo_orb_set_pattern(stvo_orb* orb, const int8_t* pattern /*[1024]*/);
+int stvo_orb_get_pattern(const stvo_orb* orb, int8_t* pattern /*[1024]*/);
+/* Host buffers in / out, synchronises.  images [B][rows][cols]; kp_xy [B][max_keypoints][2] = cv::KeyPoint::pt; response =
+ * cv::KeyPoint::response (FAST score); angle in degrees = cv::KeyPoint::angle; desc [B][max_keypoints][32]; n_kp [B]. */
+int stvo_orb_detect(stvo_orb* orb, const uint8_t* images, float* kp_xy, float* response, float* angle, uint8_t* desc,
+                    int32_t* n_kp);
+/* The same with DEVICE pointers, enqueued on the context's stream (no synchronisation). */
+int stvo_orb_detect_dev(stvo_orb* orb, const uint8_t* images, float* kp_xy, float* response, float* angle, uint8_t* desc,
+                        int32_t* n_kp);
+
 /* ---- measurement helpers --------------------------------------------------------------------- */
 /* Times `iters` launches of the named kernel stage on the context's stream with hipEvents and
  * returns the average milliseconds per launch (used by bench.py for the roofline line).

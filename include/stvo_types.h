@@ -145,6 +145,16 @@ typedef struct stvo_frame_features {
     const uint8_t* ldesc_r;  /* [B][stride_kl][32] */
 } stvo_frame_features;
 
+/* Parameters of the ORB point front-end = the cv::ORB::create arguments the reference passes (src/stereoFrame.cpp:112-114)
+ * that vary between its configurations; fixed here: one pyramid level (orb_nlevels 1 of config_kitti.yaml), WTA_K 2,
+ * FAST_SCORE ranking (orb_score 1), patch size 31. */
+typedef struct stvo_orb_params {
+    int32_t nfeatures;       /* Config::orbNFeatures()  (2000 in config_kitti.yaml)                     */
+    int32_t fast_threshold;  /* Config::orbFastTh() or the handler's adaptive orb_fast_th (1 .. 254)     */
+    int32_t edge_threshold;  /* Config::orbEdgeTh()  (19; must be >= 19: patch radius 15, pattern reach) */
+    int32_t reserved;
+} stvo_orb_params;
+
 /* Error codes of the C-ABI (0 ok, <0 error; never throws). */
 enum {
     STVO_OK = 0,

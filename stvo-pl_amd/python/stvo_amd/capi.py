@@ -20,7 +20,8 @@ EXPORTS = ["stvo_backend_name", "stvo_abi_version", "stvo_error_string", "stvo_c
            "stvo_track_batched_dev", "stvo_match_nnr_mutual_batched_dev", "stvo_optimize_pose_batched_dev",
            "stvo_time_stage_dev", "stvo_valu_peak_probe", "stvo_last_reverse_counts", "stvo_last_reverse_plan", "stvo_ctx_set_kernel_timing", "stvo_ctx_get_kernel_timing", "stvo_seq_create", "stvo_seq_destroy", "stvo_seq_enable_fetch", "stvo_seq_fetch_matches", "stvo_seq_fetch_inliers", "stvo_seq_strides",
            "stvo_seq_push", "stvo_seq_upload", "stvo_seq_step_dev", "stvo_seq_read", "stvo_seq_create_multi", "stvo_seq_set_slots",
-           "stvo_seq_set_stage_timing", "stvo_seq_get_stage_timing", "stvo_seq_debug_grid"]
+           "stvo_seq_set_stage_timing", "stvo_seq_get_stage_timing", "stvo_seq_debug_grid", "stvo_orb_create", "stvo_orb_destroy",
+           "stvo_orb_set_pattern", "stvo_orb_get_pattern", "stvo_orb_detect", "stvo_orb_detect_dev"]
 
 SEQ_NSTAGE = 5  # include/stvo_hip.h: STVO_SEQ_NSTAGE
 SEQ_STAGE_NAMES = ("stereo_points_stage", "grid_scan", "hamming_knn2", "reverse_check", "pose")
@@ -123,6 +124,14 @@ def load():
     L.stvo_seq_get_stage_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
     L.stvo_seq_debug_grid.argtypes = [C.c_void_p, C.c_int, C.c_int, i32p, i32p, C.c_int32, i32p, i32p, i32p, C.c_int32,
                                       C.POINTER(C.c_int32)]
+    L.stvo_orb_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(OrbParams), C.POINTER(C.c_void_p)]
+    L.stvo_orb_destroy.argtypes = [C.c_void_p]
+    i8p = np.ctypeslib.ndpointer(np.int8, flags="C_CONTIGUOUS")
+    f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+    L.stvo_orb_set_pattern.argtypes = [C.c_void_p, i8p]
+    L.stvo_orb_get_pattern.argtypes = [C.c_void_p, i8p]
+    L.stvo_orb_detect.argtypes = [C.c_void_p, u8p, f32p, f32p, f32p, u8p, i32p]
+    L.stvo_orb_detect_dev.argtypes = [C.c_void_p] + [C.c_void_p] * 6
     L.stvo_seq_destroy.argtypes = [C.c_void_p]
     L.stvo_seq_push.argtypes = [C.c_void_p, C.POINTER(FrameFeatures), C.c_void_p, i32p]
     L.stvo_seq_upload.argtypes = [C.c_void_p, C.c_int, C.POINTER(FrameFeatures)]
@@ -288,6 +297,42 @@ class Context:
         self._chk(self.lib.stvo_time_stage_dev(self.h, C.byref(batch.struct), C.byref(camc), C.byref(params), nnr,
                                                stage, iters, C.byref(ms)))
         return ms.value
+
+
+class OrbParams(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("fast_threshold", C.c_int32), ("edge_threshold", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Orb:
+    """The ORB point front-end for B images of one size (stvo_orb_*)."""
+
+    def __init__(self, ctx, B, cols, rows, max_keypoints=2048, nfeatures=2000, fast_threshold=20, edge_threshold=19):
+        self.ctx, self.B, self.cols, self.rows, self.K = ctx, B, cols, rows, max_keypoints
+        self.h = C.c_void_p()
+        prm = OrbParams(nfeatures, fast_threshold, edge_threshold, 0)
+        ctx._chk(ctx.lib.stvo_orb_create(ctx.h, B, cols, rows, max_keypoints, C.byref(prm), C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.stvo_orb_destroy(self.h)
+            self.h = None
+
+    def pattern(self):
+        p = np.zeros(1024, np.int8)
+        self.ctx._chk(self.ctx.lib.stvo_orb_get_pattern(self.h, p))
+        return p.reshape(256, 4)
+
+    def set_pattern(self, pattern):
+        self.ctx._chk(self.ctx.lib.stvo_orb_set_pattern(self.h, np.ascontiguousarray(pattern, np.int8).reshape(-1)))
+
+    def detect(self, images):
+        """images: uint8 [B, rows, cols] -> list of B dicts(kp [n,2] float32, response, angle, desc [n,32])."""
+        images = np.ascontiguousarray(images, np.uint8).reshape(self.B, self.rows, self.cols)
+        kp = np.zeros((self.B, self.K, 2), np.float32); resp = np.zeros((self.B, self.K), np.float32)
+        ang = np.zeros((self.B, self.K), np.float32); desc = np.zeros((self.B, self.K, 32), np.uint8); n = np.zeros(self.B, np.int32)
+        self.ctx._chk(self.ctx.lib.stvo_orb_detect(self.h, images.reshape(-1), kp.reshape(-1), resp.reshape(-1), ang.reshape(-1), desc.reshape(-1), n))
+        return [dict(kp=kp[b, :n[b]].copy(), response=resp[b, :n[b]].copy(), angle=ang[b, :n[b]].copy(), desc=desc[b, :n[b]].copy())
+                for b in range(self.B)]
 
 
 class Sequences:

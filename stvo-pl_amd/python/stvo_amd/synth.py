@@ -383,3 +383,24 @@ def make_config5_sequence(seq: int, n_frames: int, n_pts=1650, n_lines=85, repli
     that KITTI sequence.  `replica` > 0 gives further independent streams of the same shape (bench: B streams per GPU)."""
     return make_stereo_sequence(frame_seed(seq + CONFIG5_N_SEQUENCES * replica, 0), n_frames=n_frames, n_pts=n_pts,
                                 n_lines=n_lines, cam=config5_cam(seq), **kw)
+
+
+# ------------------------------------------------------------------------------------------------
+# Synthetic grey images for the ORB front-end (there is no KITTI / EuRoC data in the image): overlapping rectangles and
+# discs of random brightness (corners and edges for FAST), a smooth illumination gradient and sensor noise
+# ------------------------------------------------------------------------------------------------
+def make_image(seed, cols=1241, rows=376, n_rects=1000, n_discs=250, noise=3.0):
+    rng = np.random.default_rng(seed)
+    img = np.full((rows, cols), 110.0)
+    yy, xx = np.mgrid[0:rows, 0:cols]
+    img += 25.0 * np.sin(xx / cols * 3.1) + 18.0 * np.cos(yy / rows * 2.3)
+    for _ in range(n_rects):
+        w, h = rng.integers(6, 90), rng.integers(6, 70)
+        x0, y0 = rng.integers(-20, cols), rng.integers(-20, rows)
+        img[max(y0, 0):max(y0 + h, 0), max(x0, 0):max(x0 + w, 0)] = rng.uniform(15, 240)
+    for _ in range(n_discs):
+        cx, cy, r = rng.uniform(0, cols), rng.uniform(0, rows), rng.uniform(3, 22)
+        m = (xx - cx) ** 2 + (yy - cy) ** 2 <= r * r
+        img[m] = rng.uniform(15, 240)
+    img += rng.normal(0.0, noise, img.shape)
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)

@@ -203,6 +203,44 @@ class Oracle:
     def is_good(self, DT, cov, err):
         return bool(self.lib.orc_is_good_solution(np.ascontiguousarray(DT).reshape(-1), np.ascontiguousarray(cov).reshape(-1), err))
 
+    # ---- ORB front-end (oracle/stvo_orb_oracle.c) ----
+    def orb_default_pattern(self):
+        i8p = np.ctypeslib.ndpointer(np.int8, flags="C_CONTIGUOUS")
+        self.lib.orc_orb_default_pattern.argtypes = [i8p]; self.lib.orc_orb_default_pattern.restype = None
+        p = np.zeros(1024, np.int8)
+        self.lib.orc_orb_default_pattern(p)
+        return p.reshape(256, 4)
+
+    def fast_scores(self, img, threshold):
+        i16p = np.ctypeslib.ndpointer(np.int16, flags="C_CONTIGUOUS")
+        self.lib.orc_fast_scores.argtypes = [u8p, C.c_int, C.c_int, C.c_int, i16p]; self.lib.orc_fast_scores.restype = None
+        img = np.ascontiguousarray(img, np.uint8)
+        out = np.zeros(img.shape, np.int16)
+        self.lib.orc_fast_scores(img.reshape(-1), img.shape[1], img.shape[0], threshold, out.reshape(-1))
+        return out
+
+    def gaussian_blur7(self, img):
+        self.lib.orc_gaussian_blur7.argtypes = [u8p, C.c_int, C.c_int, u8p]; self.lib.orc_gaussian_blur7.restype = None
+        img = np.ascontiguousarray(img, np.uint8)
+        out = np.zeros_like(img)
+        self.lib.orc_gaussian_blur7(img.reshape(-1), img.shape[1], img.shape[0], out.reshape(-1))
+        return out
+
+    def fast_atan2(self, y, x):
+        self.lib.orc_fast_atan2.argtypes = [C.c_float, C.c_float]; self.lib.orc_fast_atan2.restype = C.c_float
+        return self.lib.orc_fast_atan2(y, x)
+
+    def orb_detect(self, img, nfeatures=2000, fast_th=20, edge_th=19, pattern=None, cap=4096):
+        i8p = np.ctypeslib.ndpointer(np.int8, flags="C_CONTIGUOUS")
+        self.lib.orc_orb_detect.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, i8p, C.c_int, f32p, f32p, f32p, u8p]
+        self.lib.orc_orb_detect.restype = C.c_int
+        img = np.ascontiguousarray(img, np.uint8)
+        pat = np.ascontiguousarray(self.orb_default_pattern() if pattern is None else pattern, np.int8).reshape(-1)
+        kp = np.zeros((cap, 2), np.float32); resp = np.zeros(cap, np.float32); ang = np.zeros(cap, np.float32); desc = np.zeros((cap, 32), np.uint8)
+        n = self.lib.orc_orb_detect(img.reshape(-1), img.shape[1], img.shape[0], nfeatures, fast_th, edge_th, pat, cap, kp.reshape(-1), resp, ang,
+                                    desc.reshape(-1))
+        return dict(kp=kp[:n].copy(), response=resp[:n].copy(), angle=ang[:n].copy(), desc=desc[:n].copy())
+
     # ---- key-frame decision ----
     @staticmethod
     def kf_state():
