@@ -21,6 +21,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <unordered_map>
 #include <vector>
 
 #include "ctx_internal.h"
@@ -480,6 +481,9 @@ struct stvo_seq {
     hipEvent_t ev_fetch = nullptr;
     size_t m12_span = 0, inl_span = 0;  // bytes of the contiguous [m12s_p | m12s_l | m12p | m12l] and [inlp | inll] blocks
     hipEvent_t pev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // STVO_SEQ_PROF stage markers (developer aid)
+    // captured step chains, keyed by (slot, buffer parity, line-stage flags); small batches only (launch-bound)
+    bool graph_mode = false;
+    std::unordered_map<unsigned, hipGraphExec_t> graphs;
     // optional live stage timing (bench.py): event pairs around the kernels of every step, on the stream they run on
     bool timing = false;
     std::vector<hipEvent_t> tev;  // STVO_SEQ_NSTAGE start/stop pairs per step, grown on demand
@@ -607,6 +611,12 @@ int stvo_seq_create_multi(stvo_ctx* ctx, int B, int max_keypoints, int max_keyli
               hip_ok(ctx, hipEventCreateWithFlags(&s->ev_stage[0], hipEventDisableTiming), "hipEventCreate seq") &&
               hip_ok(ctx, hipEventCreateWithFlags(&s->ev_stage[1], hipEventDisableTiming), "hipEventCreate seq");
     s->zero_copy = B <= 16;
+    {   // graph replay of the step chain: opt-in (STVO_SEQ_GRAPH=1).  Measured on ROCm 7.2 / MI355X for one sequence: 0.290 vs
+        // 0.282 ms per frame points-only and 0.477 vs 0.310 ms with the line stage on its second stream — the graph executor
+        // adds more per-node latency than the host-side launches cost (profiles/r02_single_stream_latency.txt)
+        const char* e = std::getenv("STVO_SEQ_GRAPH");
+        s->graph_mode = e ? std::atoi(e) != 0 : false;
+    }
     if (!ok) {
         stvo_seq_destroy(s);
         return STVO_ERR_HIP;
@@ -716,6 +726,7 @@ int stvo_seq_destroy(stvo_seq* s) {
     for (auto e : s->pev)
         if (e) (void)hipEventDestroy(e);
     for (auto e : s->tev) (void)hipEventDestroy(e);
+    for (auto& g : s->graphs) (void)hipGraphExecDestroy(g.second);
     if (s->ev_fetch) (void)hipEventDestroy(s->ev_fetch);
     if (s->fetch_host) (void)hipHostFree(s->fetch_host);
     if (s->dev) (void)hipFree(s->dev);
@@ -813,10 +824,16 @@ int stvo_seq_upload(stvo_seq* s, int slot, const stvo_frame_features* f) {
 }
 
 // Runs the whole per-frame pipeline on the features resident in `slot` (asynchronous; no host transfer).
-int stvo_seq_step_dev(stvo_seq* s, int slot) {
-    if (!s || slot < 0 || slot >= (int)s->raw_dev.size()) return STVO_ERR_INVALID_ARG;
+namespace {
+
+struct StepFlags {
+    bool lines_now, lines_prev, track;
+};
+
+// Enqueues the kernel chain of one step on the context's stream (and the line stream).  No state of `s` changes here, so
+// the same code serves direct launches and stream capture into a hipGraph.
+int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl) {
     stvo_ctx* ctx = s->ctx;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int B = s->B, K = s->K, M = s->M;
     hipStream_t st = ctx->stream;
     // live stage timing: STVO_SEQ_NSTAGE event pairs per step (see stvo_seq_get_stage_timing)
@@ -847,11 +864,7 @@ int stvo_seq_step_dev(stvo_seq* s, int slot) {
     d.host_n = s->zero_copy ? reinterpret_cast<int32_t*>(s->out_host + res_bytes) : nullptr;
     d.host_nl = s->zero_copy ? reinterpret_cast<int32_t*>(s->out_host + res_bytes + (size_t)B * 4) : nullptr;
     // a frame without key-lines skips the whole line stage (7 launches) and, below, the f2f line matching (6)
-    const bool lines_now = s->op.has_lines && s->raw_lines[slot];
-    const bool lines_prev = s->op.has_lines && s->set_lines[s->cur ^ 1];
-    s->set_lines[s->cur] = lines_now;
-    s->last_lines = lines_now;
-    s->last_slot = slot;
+    const bool lines_now = fl.lines_now, lines_prev = fl.lines_prev;
     // fork: everything enqueued so far (ingest, the previous step) happens-before the line stream's work
     const bool par = lines_now && s->op.has_points;
     hipStream_t sl = par ? s->line_stream : st;
@@ -900,7 +913,7 @@ int stvo_seq_step_dev(stvo_seq* s, int slot) {
         HIP_TRY(ctx, hipMemsetAsync(cs.nl, 0, (size_t)B * 4, st));
     }
     if (s->pev[0]) (void)hipEventRecord(s->pev[2], st);
-    const bool track = s->frame_idx > 0;
+    const bool track = fl.track;
     if (track) {
         // ---- f2fTracking: prev stereo sets vs curr stereo sets
         const stvo::LazyScratch w{ctx->knn12, ctx->knn21, ctx->cand, ctx->need, ctx->qsel, ctx->nsel, ctx->knn_capacity};
@@ -955,7 +968,55 @@ int stvo_seq_step_dev(stvo_seq* s, int slot) {
             HIP_TRY(ctx, hipEventRecord(s->ev_fetch, st));
         }
     }
-    TRY(check_launch(ctx));
+    return check_launch(ctx);
+}
+
+}  // namespace
+
+// Runs the whole per-frame pipeline on the features resident in `slot` (asynchronous; no host transfer).  Optionally
+// (STVO_SEQ_GRAPH=1) the chain of ~25 short kernels on two streams is captured ONCE per (slot, buffer parity, line-stage
+// flags) into a hipGraph and replayed with a single launch; measured slower than direct launches, see stvo_seq_create_multi.
+int stvo_seq_step_dev(stvo_seq* s, int slot) {
+    if (!s || slot < 0 || slot >= (int)s->raw_dev.size()) return STVO_ERR_INVALID_ARG;
+    stvo_ctx* ctx = s->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    StepFlags fl;
+    fl.lines_now = s->op.has_lines && s->raw_lines[slot];
+    fl.lines_prev = s->op.has_lines && s->set_lines[s->cur ^ 1];
+    fl.track = s->frame_idx > 0;
+    // the first steps run directly (lazy one-time initialisations must not happen inside a capture); timing / fetch /
+    // profiling modes record events the host waits on, which a captured graph cannot provide
+    const bool use_graph = s->graph_mode && s->frame_idx >= 2 && !s->timing && !s->fetch && !s->pev[0] && !ctx->overlap;
+    if (use_graph) {
+        const unsigned key = (unsigned)slot | ((unsigned)s->cur << 8) | ((unsigned)fl.lines_now << 9) | ((unsigned)fl.lines_prev << 10) |
+                             ((unsigned)fl.track << 11);
+        auto it = s->graphs.find(key);
+        if (it == s->graphs.end()) {
+            hipGraph_t graph = nullptr;
+            hipGraphExec_t exec = nullptr;
+            bool ok = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+            int rc = STVO_ERR_HIP;
+            if (ok) {
+                rc = seq_enqueue_step(s, slot, fl);
+                ok = hipStreamEndCapture(ctx->stream, &graph) == hipSuccess && rc == STVO_OK && graph != nullptr;
+            }
+            if (ok) ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+            if (graph) (void)hipGraphDestroy(graph);
+            if (!ok) {  // capture unsupported for some node: fall back to direct launches for good
+                (void)hipGetLastError();
+                s->graph_mode = false;
+                TRY(seq_enqueue_step(s, slot, fl));
+            } else {
+                it = s->graphs.emplace(key, exec).first;
+            }
+        }
+        if (s->graph_mode) HIP_TRY(ctx, hipGraphLaunch(it->second, ctx->stream));
+    } else {
+        TRY(seq_enqueue_step(s, slot, fl));
+    }
+    s->set_lines[s->cur] = fl.lines_now;
+    s->last_lines = fl.lines_now;
+    s->last_slot = slot;
     s->cur ^= 1;  // updateFrame: curr becomes prev
     s->frame_idx++;
     return STVO_OK;
