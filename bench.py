@@ -196,10 +196,10 @@ def single_stream_latency(local_rank, n_pts, n_lines, n_frames=61):
                 env = dict(os.environ, HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", str(local_rank)))
                 txt = subprocess.run([exe, sp, os.path.join(td, "res.bin"), "--preset", "kitti"], capture_output=True, text=True,
                                      timeout=120, env=env).stdout
-                m = re.search(r"mean Proc\. time ([0-9.]+) ms", txt)
+                m = re.search(r"mean Proc\. time ([0-9.]+) ms, median ([0-9.]+) ms", txt)
                 if m:
-                    out["handler_ms"] = {"mean": float(m.group(1)), "what": "StereoFrameHandler mirror (insertStereoPair + optimizePose), "
-                                                                            "app/imagesStVO.cpp:95-98 timed region"}
+                    out["handler_ms"] = {"mean": float(m.group(1)), "median": float(m.group(2)),
+                                         "what": "StereoFrameHandler mirror (insertStereoPair + optimizePose), app/imagesStVO.cpp:95-98 timed region"}
         except (OSError, subprocess.SubprocessError):
             pass
     return out
@@ -228,12 +228,66 @@ def configs1_leg(ctx_dev, rank, B=512, n=2000, steps=10):
         ctx.synchronize(); torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         ok = float((batch.results()["status"] == 0).mean())
+        ctx.set_kernel_timing(True)
+        for _ in range(steps):
+            ctx.track_batched(batch, synth.KITTI_CAM, prm, 0.75, 0.75, 1)
+        k1_ms, rev_ms, _ = ctx.get_kernel_timing()
+        ctx.set_kernel_timing(False)
+        pose_ms = ctx.time_stage(batch, synth.KITTI_CAM, prm, 0.75, 1, 5)
     finally:
         ctx.close()
+    ops = float((batch.host["n_prev_pts"].astype(np.int64) * batch.host["n_curr_pts"].astype(np.int64)).sum()) * K1M_OPS_PER_PAIR
+    tops = ops / (k1_ms * 1e-3) / 1e12
     return {"workload": "BASELINE configs[1]: f2f brute-force mutual-NNR point match (2000 x 2000 ORB rows) + optimizePose, "
                         f"{B} frame pairs per step resident in HBM (the same batch every step: fits the Infinity Cache)",
             "value": B * steps / dt, "unit": "frame-pairs/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
-            "committed_pose_fraction": ok}
+            "committed_pose_fraction": ok,
+            "stage_ms": {"hamming_knn2": k1_ms, "reverse_check": rev_ms, "pose_solo": pose_ms},
+            "roofline": {"kernel": "hamming_knn2_mfma_kernel<2, 0>", "bound": "mfma", "achieved": tops, "peak": I8_MFMA_PEAK_TOPS,
+                         "unit": "TFLOP/s", "frac": tops / I8_MFMA_PEAK_TOPS, "avg_launch_ms": k1_ms,
+                         "note": "the same kernel on full 2000 x 2000 problems (8 query tiles of 256 rows, all full): the headline workload's "
+                                 "~1650-row sets leave the 7th tile 43 % full"}}
+
+
+def orb_leg(local_rank, B=256):
+    """SURVEY 8(f) rank 3, measured beside the hot path: the ORB point front-end (stvo_orb_detect_dev) on B synthetic
+    KITTI-size images resident in HBM — FAST-9 + NMS + retainBest(2000) + orientation + blur + rBRIEF."""
+    import torch
+    from stvo_amd import capi, synth
+    K = 2048
+    base = [synth.make_image(500 + k) for k in range(8)]
+    imgs = np.stack([np.roll(base[b % 8], 7 * (b // 8), axis=1) for b in range(B)])
+    ctx = capi.Context(device_id=local_rank, max_rows=2048, max_batch=4)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    orb = capi.Orb(ctx, B, 1241, 376, max_keypoints=K)
+    dev = f"cuda:{local_rank}"
+    d = dict(img=torch.from_numpy(imgs).to(dev), kp=torch.zeros(B, K, 2, device=dev), resp=torch.zeros(B, K, device=dev),
+             ang=torch.zeros(B, K, device=dev), desc=torch.zeros(B, K, 32, dtype=torch.uint8, device=dev),
+             n=torch.zeros(B, dtype=torch.int32, device=dev))
+
+    def run():
+        ctx._chk(ctx.lib.stvo_orb_detect_dev(orb.h, d["img"].data_ptr(), d["kp"].data_ptr(), d["resp"].data_ptr(), d["ang"].data_ptr(),
+                                             d["desc"].data_ptr(), d["n"].data_ptr()))
+    try:
+        for _ in range(2):
+            run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            run()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 5
+        nk = float(d["n"].float().mean())
+    finally:
+        orb.close(); ctx.close()
+    px = 1241 * 376
+    alg = B * (2.0 * px + nk * (8 + 4 + 4 + 32))   # image in once, blurred image out once, key-point records out
+    return {"workload": f"{B} synthetic 1241 x 376 images, orb_nfeatures 2000, FAST threshold 20, one pyramid level", "images_per_s": B / dt,
+            "ms_per_launch": dt * 1e3, "mean_keypoints": nk,
+            "roofline": {"bound": "hbm", "achieved": alg / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / dt / 1e9 / HBM_PEAK_GBS,
+                         "algorithmic_bytes_per_launch": alg, "traffic": None,
+                         "note": "all kernels of the front-end together; algorithmic bytes = image read once + blurred image written once + "
+                                 "key-point records (the score / keep maps are intermediate)"}}
 
 
 CORRELATED_MODELS = {
@@ -450,6 +504,7 @@ def main():
         out["latency"] = single_stream_latency(local_rank, args.points, args.lines)
         out["configs1"] = configs1_leg(dev_name, rank)
         out["reverse_check_correlated"] = correlated_leg(dev_name, rank)
+        out["orb_front_end"] = orb_leg(local_rank)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.points, args.lines)
         out["cpu_baseline_threads"] = cpu_baseline_threads(args.points, args.lines)

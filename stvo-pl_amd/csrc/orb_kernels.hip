@@ -1,10 +1,10 @@
 // orb_kernels.hip — the ORB point front-end on gfx950: what the reference obtains from
 //     cv::ORB::create(...)->detectAndCompute(img, Mat(), points, pdesc, false)     (/root/reference/src/stereoFrame.cpp:104-118)
 // for ONE pyramid level (config_kitti.yaml: orb_nlevels 1), FAST_SCORE ranking (orb_score 1), WTA_K 2, patch 31:
-//   orb_fast_kernel      FAST-9/16 score of every pixel (cornerScore<16>), LDS-tiled, cheap compass-point rejection first
-//   orb_nms_kernel       3x3 non-maximum suppression + border filter, response histogram per image
-//   orb_cut_kernel       KeyPointsFilter::retainBest as a histogram cut (ties kept) + row offsets of the survivors
-//   orb_emit_kernel      ordered (row-major) emission of the key-points: one wave per image row
+//   orb_fast_nms_kernel  FAST-9/16 score (cornerScore<16>) + 3x3 non-maximum suppression + border filter per 64 x 16 tile, all in
+//                        LDS: compass-point rejection, candidates compacted so that the full score runs on dense lanes;
+//                        survivors go to a per-image list + response histogram (no score map in global memory)
+//   orb_order_kernel     KeyPointsFilter::retainBest as a histogram cut (ties kept) + row-major ordering (bitonic sort in LDS)
 //   orb_blur_kernel      GaussianBlur 7x7, sigma 2, 8-bit fixed point, BORDER_REFLECT_101
 //   orb_describe_kernel  intensity-centroid angle (ICAngles, fastAtan2) + rotated BRIEF, one wave per key-point
 // OpenCV is third-party code that is not under /root/reference: the semantics are those of oracle/stvo_orb_oracle.c (a
@@ -28,12 +28,10 @@ constexpr int TILE_W = 64, TILE_H = 8;
 struct OrbDev {
     int B, cols, rows, K, nfeatures, fast_th, edge_th;
     const uint8_t* img;   // [B][rows][cols]
-    uint8_t* score;       // [B][rows][cols] FAST score of corners (>= fast_th), 0 elsewhere
-    uint8_t* keep;        // [B][rows][cols] response of the key-points that survive NMS + border, 0 elsewhere
     uint8_t* blur;        // [B][rows][cols]
-    int32_t* hist;        // [B][256]
-    int32_t* rowcnt;      // [B][rows] key-points >= cut per row, then exclusive offsets
-    int32_t* cut;         // [B]
+    int32_t* hist;        // [B][256] responses of the key-points that survive NMS + border
+    uint32_t* cand;       // [B][CAND_CAP] the survivors, unordered: (y << 20 | x << 8 | response)
+    int32_t* n_cand;      // [B]
     float* kp;            // [B][K][2]
     float* resp;          // [B][K]
     float* angle;         // [B][K]
@@ -46,160 +44,190 @@ struct OrbDev {
 __device__ __constant__ int8_t c_circle[16][2] = {{0, 3},  {1, 3},   {2, 2},   {3, 1},   {3, 0},  {3, -1}, {2, -2}, {1, -3},
                                                   {0, -3}, {-1, -3}, {-2, -2}, {-3, -1}, {-3, 0}, {-3, 1}, {-2, 2}, {-1, 3}};
 
-__global__ __launch_bounds__(TILE_W* TILE_H) void orb_fast_kernel(OrbDev o) {
-    __shared__ uint8_t tile[TILE_H + 6][TILE_W + 8];  // halo of 3 (row padded to a multiple of 4 bytes)
-    const int b = blockIdx.z, x0 = blockIdx.x * TILE_W, y0 = blockIdx.y * TILE_H;
+constexpr int FT_W = 64, FT_H = 16;               // output tile of the fused FAST + NMS kernel
+constexpr int SC_W = FT_W + 2, SC_H = FT_H + 2;   // scores are needed one pixel beyond the tile (3x3 maximum test)
+constexpr int IM_W = FT_W + 8, IM_H = FT_H + 8;   // image tile: + the circle radius 3
+constexpr int CAND_CAP = 16384;                    // survivors of NMS + border per image (typ. 2-3 k at threshold 20)
+
+// cornerScore<16> of the pixel at (lx, ly) of the LDS image tile: max over the 16 arcs of 9 contiguous circle pixels of the
+// smallest (signed) difference in the arc, bright and dark, minus 1 — min / max over every window of 9 by doubling
+__device__ __forceinline__ int fast_score_lds(const uint8_t (*tile)[IM_W + 4], int lx, int ly) {
+    const int v = tile[ly][lx];
+    int d[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) d[k] = (int)tile[ly + c_circle[k][1]][lx + c_circle[k][0]] - v;
+    int mn2[16], mx2[16], mn4[16], mx4[16], mn8[16], mx8[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        mn2[k] = min(d[k], d[(k + 1) & 15]);
+        mx2[k] = max(d[k], d[(k + 1) & 15]);
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        mn4[k] = min(mn2[k], mn2[(k + 2) & 15]);
+        mx4[k] = max(mx2[k], mx2[(k + 2) & 15]);
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        mn8[k] = min(mn4[k], mn4[(k + 4) & 15]);
+        mx8[k] = max(mx4[k], mx4[(k + 4) & 15]);
+    }
+    int sb = -255, sd = -255;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        sb = max(sb, min(mn8[k], d[(k + 8) & 15]));
+        sd = max(sd, -max(mx8[k], d[(k + 8) & 15]));
+    }
+    return max(sb, sd) - 1;
+}
+
+// FAST-9/16 + non-maximum suppression + border filter of one 64 x 16 tile, entirely in LDS:
+//   1. the image tile (+ halo 4) is staged once;
+//   2. every score position (tile + halo 1) takes the cheap compass-point test (any arc of 9 contiguous circle pixels holds
+//      at least two of the four compass points); the few survivors are COMPACTED into a list, so that
+//   3. the 150-instruction corner score runs on dense lanes (it used to run for a whole wave whenever one lane needed it);
+//   4. a pixel whose score beats its 8 neighbours (and lies inside the border) is appended to the image's candidate list and
+//      counted in the response histogram — no score / keep maps ever reach global memory.
+__global__ __launch_bounds__(256) void orb_fast_nms_kernel(OrbDev o) {
+    __shared__ uint8_t tile[IM_H][IM_W + 4];
+    __shared__ uint8_t sc[SC_H][SC_W + 2];
+    __shared__ uint16_t s_list[SC_H * SC_W];
+    __shared__ uint32_t s_kp[256];  // key-points of this tile (a 3x3 maximum every 4 pixels at most: 64 x 16 / 4)
+    __shared__ int s_n, s_nkp, s_base;
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.z, x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H, tid = threadIdx.x;
     const uint8_t* img = o.img + (size_t)b * o.rows * o.cols;
-    const int tid = threadIdx.y * TILE_W + threadIdx.x;
-    for (int i = tid; i < (TILE_H + 6) * (TILE_W + 6); i += TILE_W * TILE_H) {
-        const int ty = i / (TILE_W + 6), tx = i % (TILE_W + 6);
-        const int gx = min(max(x0 + tx - 3, 0), o.cols - 1), gy = min(max(y0 + ty - 3, 0), o.rows - 1);
+    for (int i = tid; i < IM_H * IM_W; i += 256) {
+        const int ty = i / IM_W, tx = i % IM_W;
+        const int gx = min(max(x0 + tx - 4, 0), o.cols - 1), gy = min(max(y0 + ty - 4, 0), o.rows - 1);
         tile[ty][tx] = img[(size_t)gy * o.cols + gx];
     }
-    __syncthreads();
-    const int x = x0 + threadIdx.x, y = y0 + threadIdx.y;
-    if (x >= o.cols || y >= o.rows) return;
-    int out = 0;
-    if (x >= 3 && x < o.cols - 3 && y >= 3 && y < o.rows - 3) {
-        const int lx = threadIdx.x + 3, ly = threadIdx.y + 3;
-        const int v = tile[ly][lx];
-        const int t = o.fast_th;
-        // any arc of 9 contiguous circle pixels holds at least two of the four compass points: cheap rejection
-        const int c0 = tile[ly + 3][lx] - v, c4 = tile[ly][lx + 3] - v, c8 = tile[ly - 3][lx] - v, c12 = tile[ly][lx - 3] - v;
-        const int nb = (c0 > t) + (c4 > t) + (c8 > t) + (c12 > t), nd = (c0 < -t) + (c4 < -t) + (c8 < -t) + (c12 < -t);
-        if (nb >= 2 || nd >= 2) {
-            int d[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) d[k] = (int)tile[ly + c_circle[k][1]][lx + c_circle[k][0]] - v;
-            // min / max over every window of 9 consecutive circle positions by doubling: 2, 4, 8, then + 1
-            int mn2[16], mx2[16], mn4[16], mx4[16], mn8[16], mx8[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                mn2[k] = min(d[k], d[(k + 1) & 15]);
-                mx2[k] = max(d[k], d[(k + 1) & 15]);
-            }
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                mn4[k] = min(mn2[k], mn2[(k + 2) & 15]);
-                mx4[k] = max(mx2[k], mx2[(k + 2) & 15]);
-            }
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                mn8[k] = min(mn4[k], mn4[(k + 4) & 15]);
-                mx8[k] = max(mx4[k], mx4[(k + 4) & 15]);
-            }
-            int sb = -255, sd = -255;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                sb = max(sb, min(mn8[k], d[(k + 8) & 15]));
-                sd = max(sd, -max(mx8[k], d[(k + 8) & 15]));
-            }
-            const int s = max(sb, sd) - 1;  // cornerScore<16>
-            if (s >= t) out = s > 0 ? s : 0;
-        }
-    }
-    o.score[(size_t)b * o.rows * o.cols + (size_t)y * o.cols + x] = (uint8_t)out;
-}
-
-__global__ __launch_bounds__(256) void orb_nms_kernel(OrbDev o) {
-    __shared__ int s_hist[256];
-    const int b = blockIdx.z, y = blockIdx.y;
-    const int x = blockIdx.x * 256 + threadIdx.x;
-    s_hist[threadIdx.x] = 0;
-    __syncthreads();
-    const size_t base = (size_t)b * o.rows * o.cols;
-    if (x < o.cols) {
-        int kept = 0;
-        if (x >= 3 && x < o.cols - 3 && y >= 3 && y < o.rows - 3) {
-            const uint8_t* sc = o.score + base + (size_t)y * o.cols + x;
-            const int s = sc[0];
-            if (s > 0) {
-                const int c = o.cols;
-                const bool is_max = s > sc[-c - 1] && s > sc[-c] && s > sc[-c + 1] && s > sc[-1] && s > sc[1] && s > sc[c - 1] && s > sc[c] &&
-                                    s > sc[c + 1];
-                // KeyPointsFilter::runByImageBorder
-                if (is_max && x >= o.edge_th && x < o.cols - o.edge_th && y >= o.edge_th && y < o.rows - o.edge_th) kept = s;
-            }
-        }
-        o.keep[base + (size_t)y * o.cols + x] = (uint8_t)kept;
-        if (kept) atomicAdd(&s_hist[kept], 1);
+    for (int i = tid; i < SC_H * (SC_W + 2); i += 256) (&sc[0][0])[i] = 0;
+    if (tid == 0) {
+        s_n = 0;
+        s_nkp = 0;
     }
     __syncthreads();
-    if (s_hist[threadIdx.x]) atomicAdd(&o.hist[(size_t)b * 256 + threadIdx.x], s_hist[threadIdx.x]);
+    const int t = o.fast_th;
+    // (all lanes of a wave run the same number of trips: the ballots below need the whole wave)
+    for (int i0 = 0; i0 < SC_H * SC_W; i0 += 256) {
+        const int i = i0 + tid;
+        const int sy = i / SC_W, sx = i % SC_W;            // score position; image pixel (x0 + sx - 1, y0 + sy - 1)
+        const int x = x0 + sx - 1, y = y0 + sy - 1;
+        bool cand = false;
+        if (i < SC_H * SC_W && x >= 3 && x < o.cols - 3 && y >= 3 && y < o.rows - 3) {
+            const int lx = sx + 3, ly = sy + 3;
+            const int v = tile[ly][lx];
+            const int c0 = tile[ly + 3][lx] - v, c4 = tile[ly][lx + 3] - v, c8 = tile[ly - 3][lx] - v, c12 = tile[ly][lx - 3] - v;
+            const int nb = (c0 > t) + (c4 > t) + (c8 > t) + (c12 > t), nd = (c0 < -t) + (c4 < -t) + (c8 < -t) + (c12 < -t);
+            cand = nb >= 2 || nd >= 2;
+        }
+        // wave-aggregated append: one LDS atomic per wave and trip (lanes hammering one counter serialise)
+        const unsigned long long bal = __ballot(cand);
+        int base = 0;
+        if (lane == 0 && bal) base = atomicAdd(&s_n, __popcll(bal));
+        base = __shfl(base, 0, 64);
+        if (cand) s_list[base + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)i;
+    }
+    __syncthreads();
+    const int n = s_n;
+    for (int j = tid; j < n; j += 256) {
+        const int i = s_list[j], sy = i / SC_W, sx = i % SC_W;
+        const int s = fast_score_lds(tile, sx + 3, sy + 3);
+        if (s >= t) sc[sy][sx] = (uint8_t)s;  // t >= 1, so a corner's score is positive
+    }
+    __syncthreads();
+    for (int i = tid; i < FT_H * FT_W; i += 256) {  // FT_H * FT_W is a multiple of 256: whole waves
+        const int py = i / FT_W, px = i % FT_W, x = x0 + px, y = y0 + py;
+        const int s = sc[py + 1][px + 1];
+        bool kp = false;
+        if (s != 0 && x < o.cols && y < o.rows) {
+            const bool is_max = s > sc[py][px] && s > sc[py][px + 1] && s > sc[py][px + 2] && s > sc[py + 1][px] && s > sc[py + 1][px + 2] &&
+                                s > sc[py + 2][px] && s > sc[py + 2][px + 1] && s > sc[py + 2][px + 2];
+            // KeyPointsFilter::runByImageBorder
+            kp = is_max && x >= o.edge_th && x < o.cols - o.edge_th && y >= o.edge_th && y < o.rows - o.edge_th;
+        }
+        const unsigned long long bal = __ballot(kp);
+        int base = 0;
+        if (lane == 0 && bal) base = atomicAdd(&s_nkp, __popcll(bal));
+        base = __shfl(base, 0, 64);
+        if (kp) s_kp[base + __popcll(bal & ((1ull << lane) - 1ull))] = ((uint32_t)y << 20) | ((uint32_t)x << 8) | (uint32_t)s;
+    }
+    __syncthreads();
+    const int nkp = s_nkp;
+    if (nkp == 0) return;
+    if (tid == 0) s_base = atomicAdd(&o.n_cand[b], nkp);  // ONE global reservation per tile
+    __syncthreads();
+    if (tid < nkp) {
+        const uint32_t c = s_kp[tid];
+        const int slot = s_base + tid;
+        if (slot < CAND_CAP) o.cand[(size_t)b * CAND_CAP + slot] = c;
+        atomicAdd(&o.hist[(size_t)b * 256 + (c & 255u)], 1);
+    }
 }
 
-// retainBest(nfeatures): the smallest response `cut` such that at least nfeatures key-points are >= cut (or 1)
-__global__ __launch_bounds__(256) void orb_cut_kernel(OrbDev o) {
-    __shared__ int s_h[256];
+// retainBest(nfeatures) as a histogram cut (the smallest response such that at least nfeatures key-points are >= it; ties at
+// the cut are all kept) + ROW-MAJOR ordering of the survivors: one workgroup per image, bitonic sort of (y, x, response) words
+// in LDS.  Writes key-points and responses, n_kp (capped at K), and resets the image's counters for the next frame.
+constexpr int ORD_CAP = 4096;
+__global__ __launch_bounds__(1024) void orb_order_kernel(OrbDev o) {
+    __shared__ uint32_t s_key[ORD_CAP];
+    __shared__ int s_cut, s_n;
     const int b = blockIdx.x, tid = threadIdx.x;
-    s_h[tid] = o.hist[(size_t)b * 256 + tid];
-    __syncthreads();
     if (tid == 0) {
         int cut = 1, acc = 0;
         for (int s = 255; s >= 1; --s) {
-            acc += s_h[s];
+            acc += o.hist[(size_t)b * 256 + s];
             if (acc >= o.nfeatures) {
                 cut = s;
                 break;
             }
         }
-        o.cut[b] = cut;
+        s_cut = cut;
+        s_n = 0;
     }
-    o.hist[(size_t)b * 256 + tid] = 0;  // ready for the next frame
-}
-
-// one wave per image row: PASS 0 counts the survivors of the row, PASS 1 writes them at the row's offset in ascending x
-template <int PASS>
-__global__ __launch_bounds__(64) void orb_emit_kernel(OrbDev o) {
-    const int b = blockIdx.y, y = blockIdx.x, lane = threadIdx.x;
-    const int cut = o.cut[b];
-    const uint8_t* kr = o.keep + (size_t)b * o.rows * o.cols + (size_t)y * o.cols;
-    int run = PASS == 1 ? o.rowcnt[(size_t)b * o.rows + y] : 0;
-    for (int x0 = 0; x0 < o.cols; x0 += 64) {
-        const int x = x0 + lane;
-        const int r = x < o.cols ? kr[x] : 0;
-        const bool ok = r >= cut && r > 0;
-        const unsigned long long bal = __ballot(ok);
-        if (PASS == 1 && ok) {
-            const int idx = run + __popcll(bal & ((1ull << lane) - 1ull));
-            if (idx < o.K) {
-                const size_t k = (size_t)b * o.K + idx;
-                o.kp[2 * k] = (float)x;
-                o.kp[2 * k + 1] = (float)y;
-                o.resp[k] = (float)r;
+    for (int i = tid; i < ORD_CAP; i += 1024) s_key[i] = 0xFFFFFFFFu;
+    __syncthreads();
+    const int nc = min(o.n_cand[b], CAND_CAP), cut = s_cut;
+    for (int i = tid; i < nc; i += 1024) {
+        const uint32_t c = o.cand[(size_t)b * CAND_CAP + i];
+        if ((int)(c & 255u) >= cut) {
+            const int slot = atomicAdd(&s_n, 1);
+            if (slot < ORD_CAP) s_key[slot] = c;
+        }
+    }
+    __syncthreads();
+    const int n = min(s_n, ORD_CAP);
+    int np2 = 64;
+    while (np2 < n) np2 <<= 1;
+    for (int k = 2; k <= np2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < np2; i += 1024) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const uint32_t a = s_key[i], c = s_key[l];
+                    const bool up = (i & k) == 0;
+                    if ((a > c) == up) {
+                        s_key[i] = c;
+                        s_key[l] = a;
+                    }
+                }
             }
+            __syncthreads();
         }
-        run += __popcll(bal);
+    const int n_out = min(n, o.K);
+    for (int i = tid; i < n_out; i += 1024) {
+        const uint32_t c = s_key[i];
+        const size_t k = (size_t)b * o.K + i;
+        o.kp[2 * k] = (float)((c >> 8) & 0xFFFu);
+        o.kp[2 * k + 1] = (float)(c >> 20);
+        o.resp[k] = (float)(c & 255u);
     }
-    if (PASS == 0 && lane == 0) o.rowcnt[(size_t)b * o.rows + y] = run;
-}
-
-// exclusive scan of the row counts of one image (<= 1024 rows per pass, looped), total -> n_kp (capped at K)
-__global__ __launch_bounds__(256) void orb_rowscan_kernel(OrbDev o) {
-    __shared__ int s_part[256];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    int32_t* rc = o.rowcnt + (size_t)b * o.rows;
-    const int per = (o.rows + 255) / 256;
-    const int lo = tid * per, hi = min(lo + per, o.rows);
-    int sum = 0;
-    for (int y = lo; y < hi; ++y) sum += rc[y];
-    s_part[tid] = sum;
     __syncthreads();
+    if (tid < 256) o.hist[(size_t)b * 256 + tid] = 0;  // ready for the next frame
     if (tid == 0) {
-        int run = 0;
-        for (int i = 0; i < 256; ++i) {
-            const int v = s_part[i];
-            s_part[i] = run;
-            run += v;
-        }
-        o.n_kp[b] = run < o.K ? run : o.K;
-    }
-    __syncthreads();
-    int run = s_part[tid];
-    for (int y = lo; y < hi; ++y) {
-        const int v = rc[y];
-        rc[y] = run;
-        run += v;
+        o.n_kp[b] = n_out;
+        o.n_cand[b] = 0;
     }
 }
 
@@ -323,7 +351,7 @@ struct stvo_orb {
     stvo_ctx* ctx = nullptr;
     stvo::OrbDev d{};
     stvo_orb_params prm{};
-    char* dev = nullptr;  // score | keep | blur | hist | rowcnt | cut | pattern
+    char* dev = nullptr;  // blur | hist | cand | n_cand | pattern
     char* io = nullptr;   // staging for the host-buffer entry point: images in, results out
     size_t io_bytes = 0;
     int8_t pattern[1024];
@@ -364,8 +392,9 @@ int stvo_orb_create(stvo_ctx* ctx, int B, int cols, int rows, int max_keypoints,
     o->prm = *prm;
     const size_t px = (size_t)B * rows * cols;
     auto al = [](size_t v) { return (v + 255) & ~size_t(255); };
-    const size_t o_score = 0, o_keep = al(px), o_blur = o_keep + al(px), o_hist = o_blur + al(px), o_rowcnt = o_hist + al((size_t)B * 256 * 4),
-                 o_cut = o_rowcnt + al((size_t)B * rows * 4), o_pat = o_cut + al((size_t)B * 4), total = o_pat + 1024;
+    const size_t o_blur = 0, o_hist = al(px), o_cand = o_hist + al((size_t)B * 256 * 4), o_ncand = o_cand + al((size_t)B * stvo::CAND_CAP * 4),
+                 o_pat = o_ncand + al((size_t)B * 4), total = o_pat + 1024;
+    if (rows >= 4096 || cols >= 4096) return STVO_ERR_CAPACITY;  // candidates pack (y, x) in 12 bits each
     if (!hip_ok(ctx, hipMalloc((void**)&o->dev, total), "hipMalloc orb") || !hip_ok(ctx, hipMemset(o->dev, 0, total), "hipMemset orb")) {
         if (o->dev) (void)hipFree(o->dev);
         delete o;
@@ -374,8 +403,8 @@ int stvo_orb_create(stvo_ctx* ctx, int B, int cols, int rows, int max_keypoints,
     stvo::OrbDev& d = o->d;
     d.B = B; d.cols = cols; d.rows = rows; d.K = max_keypoints;
     d.nfeatures = prm->nfeatures; d.fast_th = prm->fast_threshold; d.edge_th = prm->edge_threshold;
-    d.score = (uint8_t*)(o->dev + o_score); d.keep = (uint8_t*)(o->dev + o_keep); d.blur = (uint8_t*)(o->dev + o_blur);
-    d.hist = (int32_t*)(o->dev + o_hist); d.rowcnt = (int32_t*)(o->dev + o_rowcnt); d.cut = (int32_t*)(o->dev + o_cut);
+    d.blur = (uint8_t*)(o->dev + o_blur);
+    d.hist = (int32_t*)(o->dev + o_hist); d.cand = (uint32_t*)(o->dev + o_cand); d.n_cand = (int32_t*)(o->dev + o_ncand);
     d.pattern = (const int8_t*)(o->dev + o_pat);
     default_pattern(o->pattern);
     if (!hip_ok(ctx, hipMemcpy(o->dev + o_pat, o->pattern, 1024, hipMemcpyHostToDevice), "hipMemcpy pattern")) {
@@ -440,13 +469,10 @@ int stvo_orb_detect_dev(stvo_orb* o, const uint8_t* images, float* kp_xy, float*
     d.img = images; d.kp = kp_xy; d.resp = response; d.angle = angle; d.desc = desc; d.n_kp = n_kp;
     hipStream_t s = ctx->stream;
     const dim3 tiles((d.cols + stvo::TILE_W - 1) / stvo::TILE_W, (d.rows + stvo::TILE_H - 1) / stvo::TILE_H, d.B), tb(stvo::TILE_W, stvo::TILE_H);
-    hipLaunchKernelGGL(stvo::orb_fast_kernel, tiles, tb, 0, s, d);
+    hipLaunchKernelGGL(stvo::orb_fast_nms_kernel, dim3((d.cols + stvo::FT_W - 1) / stvo::FT_W, (d.rows + stvo::FT_H - 1) / stvo::FT_H, d.B),
+                       dim3(256), 0, s, d);
     hipLaunchKernelGGL(stvo::orb_blur_kernel, tiles, tb, 0, s, d, o->blur_k);
-    hipLaunchKernelGGL(stvo::orb_nms_kernel, dim3((d.cols + 255) / 256, d.rows, d.B), dim3(256), 0, s, d);
-    hipLaunchKernelGGL(stvo::orb_cut_kernel, dim3(d.B), dim3(256), 0, s, d);
-    hipLaunchKernelGGL(stvo::orb_emit_kernel<0>, dim3(d.rows, d.B), dim3(64), 0, s, d);
-    hipLaunchKernelGGL(stvo::orb_rowscan_kernel, dim3(d.B), dim3(256), 0, s, d);
-    hipLaunchKernelGGL(stvo::orb_emit_kernel<1>, dim3(d.rows, d.B), dim3(64), 0, s, d);
+    hipLaunchKernelGGL(stvo::orb_order_kernel, dim3(d.B), dim3(1024), 0, s, d);
     hipLaunchKernelGGL(stvo::orb_describe_kernel, dim3((d.K + 3) / 4, d.B), dim3(256), 0, s, d, o->umax);
     return check_launch(ctx);
 }

@@ -560,8 +560,10 @@ int launch_pose2(hipStream_t s, const PoseArgs& a) {
     const int force_nw = env ? std::atoi(env) : 0;
     // waves per frame pair: as many as keep ~4096 wave slots (4 per SIMD) filled with INDEPENDENT problems — a frame pair is
     // a chain of ~14 evaluate / solve rounds, and the chains of co-resident workgroups overlap each other's serial sections
+    // 16 waves per frame pair while every pair has a CU to itself, 8 (two pairs per CU, records still in LDS) beyond; the 4- and
+    // 2-wave variants (more pairs per CU, records mostly streamed) were measured slower and spill (NOTES.md): override only
     int nw = force_nw;
-    if (nw == 0) nw = a.B <= POSE2_LATENCY_MAX_B ? 16 : a.B <= 640 ? 8 : a.B <= 1536 ? 4 : 2;
+    if (nw == 0) nw = a.B <= POSE2_LATENCY_MAX_B ? 16 : 8;
     if (nw >= 16) launch_pose2_variant<16>(s, a);
     else if (nw >= 8) launch_pose2_variant<8>(s, a);
     else if (nw >= 4) launch_pose2_variant<4>(s, a);
