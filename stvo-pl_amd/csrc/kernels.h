@@ -87,6 +87,8 @@ struct PoseArgs {
     const double* init_T;  // [B][16] or nullptr
     stvo_cam cam;
     const stvo_cam* cams;  // [B] per-frame-pair calibration (device) or nullptr: `cam` for every pair
+    // set by launch_pose: prev points / lines with an index below these live in the workgroup's LDS record cache
+    int lds_cap_pts, lds_cap_lines;
     stvo_opt_params prm;
     stvo_pose_result* results;
     int32_t* inl_p_out;  // [B][max_pts] or nullptr

@@ -17,6 +17,7 @@
 //   * the 6x6 algebra, SE(3) updates and every data-dependent branch of the GN / robust-GN / LM
 //     loops (:394-547) run on one lane of the solver wave (pose_math.h) and are broadcast through
 //     LDS, so the control flow is block-uniform and matches the reference iteration for iteration.
+#include <algorithm>
 #include <cstdlib>
 
 #include "pose_block.h"
@@ -98,8 +99,14 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_ibuf)[3 * (
             jcache[k] = ((pmatched >> k) & 1u) ? (a.m12p ? a.m12p[pbase + i] : i) : 0;
         }
     }
-    double* s_pts = s_rec;                                  // [max_pts][6]  X Y Z ox oy s2
-    double* s_lns = s_rec + (size_t)a.max_pts * 6;          // [max_lines][14] sP eP le spl epl s2
+    // record cache: prev points with index < cap_p and prev lines with index < cap_l (everything in the latency variant; what
+    // fits half a CU's LDS in the throughput variant — the rest is gathered from L2 at every evaluation)
+    // (PARTIAL is a compile-time property of the small-workgroup variant: the latency variant holds everything and must not pay
+    // for the index tests — they cost it 87 spilled registers)
+    constexpr bool PARTIAL = LDSREC && BLOCK < 256;
+    const int cap_p = !LDSREC ? 0 : (PARTIAL ? a.lds_cap_pts : a.max_pts), cap_l = !LDSREC ? 0 : (PARTIAL ? a.lds_cap_lines : a.max_lines);
+    double* s_pts = s_rec;                                  // [cap_p][6]  X Y Z ox oy s2
+    double* s_lns = s_rec + (size_t)cap_p * 6;              // [cap_l][14] sP eP le spl epl s2
     auto load_point_global = [&](int k) -> PointRec {
         const size_t i = pbase + (size_t)(tid + k * BLOCK);
         size_t j;
@@ -121,7 +128,7 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_ibuf)[3 * (
         return r;
     };
     auto load_point = [&](int k) -> PointRec {
-        if (!LDSREC) return load_point_global(k);
+        if (!LDSREC || (PARTIAL && tid + k * BLOCK >= cap_p)) return load_point_global(k);
         const double2* q = reinterpret_cast<const double2*>(s_pts + (size_t)(tid + k * BLOCK) * 6);
         const double2 v0 = q[0], v1 = q[1], v2 = q[2];
         PointRec r;
@@ -147,7 +154,7 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_ibuf)[3 * (
         return L;
     };
     auto load_line = [&](int k) -> pm::LineRec {
-        if (!LDSREC) return load_line_global(k);
+        if (!LDSREC || (PARTIAL && tid + k * BLOCK >= cap_l)) return load_line_global(k);
         const double2* q = reinterpret_cast<const double2*>(s_lns + (size_t)(tid + k * BLOCK) * 14);
         pm::LineRec L;
         const double2 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3], v4 = q[4], v5 = q[5], v6 = q[6];
@@ -159,7 +166,7 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_ibuf)[3 * (
     if (LDSREC && W) {  // stage this thread's own records (thread-private slots: no barrier needed)
 #pragma unroll
         for (int k = 0; k < PPT; ++k)
-            if ((pmatched >> k) & 1u) {
+            if (((pmatched >> k) & 1u) && (!PARTIAL || tid + k * BLOCK < cap_p)) {
                 const PointRec r = load_point_global(k);
                 double2* q = reinterpret_cast<double2*>(s_pts + (size_t)(tid + k * BLOCK) * 6);
                 q[0] = make_double2(r.X, r.Y);
@@ -168,7 +175,7 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_ibuf)[3 * (
             }
 #pragma unroll
         for (int k = 0; k < LPT; ++k)
-            if ((lmatched >> k) & 1u) {
+            if (((lmatched >> k) & 1u) && (!PARTIAL || tid + k * BLOCK < cap_l)) {
                 const pm::LineRec L = load_line_global(k);
                 double2* q = reinterpret_cast<double2*>(s_lns + (size_t)(tid + k * BLOCK) * 14);
                 q[0] = make_double2(L.sP[0], L.sP[1]);
@@ -546,12 +553,28 @@ constexpr int POSE_BLOCK_T = 192, POSE_BLOCK_L = 448;
 constexpr int POSE_LATENCY_MAX_B = 256;
 // dynamic LDS available to the record cache: 160 KB per CU minus the kernel's static LDS (PoseSh, partial sums, counters)
 constexpr size_t POSE_LDSREC_MAX_BYTES = (size_t)160 * 1024 - 6 * 1024;
+constexpr size_t POSE_LDSREC_T_BYTES = (size_t)80 * 1024 - 4 * 1024;  // throughput variant: two workgroups share a CU
 
+// lds_budget: bytes of dynamic LDS the record cache may use (LDSREC only): lines first (their gather is the longer chain),
+// points with what is left
 template <int BLK, bool LDSREC>
-static void launch_pose_variant(hipStream_t s, const PoseArgs& a) {
+static void launch_pose_variant(hipStream_t s, const PoseArgs& a_in, size_t lds_budget = 0) {
     constexpr int PPT = (STVO_POSE_MAX_POINTS + BLK - 1) / BLK;
     constexpr int LPT = (STVO_POSE_MAX_LINES + BLK - 1) / BLK;
-    const size_t lds = LDSREC ? ((size_t)a.max_pts * 6 + (size_t)a.max_lines * 14) * sizeof(double) : 0;
+    PoseArgs a = a_in;
+    a.lds_cap_pts = a.lds_cap_lines = 0;
+    size_t lds = 0;
+    if (LDSREC) {
+        const size_t lb = 14 * sizeof(double), pb = 6 * sizeof(double);
+        if ((size_t)a.max_lines * lb + (size_t)a.max_pts * pb <= lds_budget) {  // everything fits (latency variant)
+            a.lds_cap_lines = a.max_lines;
+            a.lds_cap_pts = a.max_pts;
+        } else {  // an eighth for the lines (86 of them in 76 KB: the KITTI configuration detects ~100 per image)
+            a.lds_cap_lines = (int)std::min<size_t>((size_t)a.max_lines, lds_budget / 8 / lb);
+            a.lds_cap_pts = (int)std::min<size_t>((size_t)a.max_pts, (lds_budget - (size_t)a.lds_cap_lines * lb) / pb);
+        }
+        lds = ((size_t)a.lds_cap_pts * 6 + (size_t)a.lds_cap_lines * 14) * sizeof(double);
+    }
     hipLaunchKernelGGL((pose_kernel<BLK, PPT, LPT, LDSREC>), dim3(a.B), dim3(BLK + 64), lds, s, a);
 }
 
@@ -578,10 +601,15 @@ int launch_pose(hipStream_t s, const PoseArgs& a) {
     if (which == 2) return launch_pose2(s, a);
     if (a.max_pts > STVO_POSE_MAX_POINTS || a.max_lines > STVO_POSE_MAX_LINES) return STVO_ERR_CAPACITY;
     const size_t rec_bytes = ((size_t)a.max_pts * 6 + (size_t)a.max_lines * 14) * sizeof(double);
+    // throughput variant: two workgroups per CU, each with half of the CU's LDS as record cache — most records are then read
+    // from HBM once instead of at every evaluation (the gathers of ~64 co-resident pairs overflow an XCD's 4 MB L2)
+    static const bool lds_t = std::getenv("STVO_POSE_LDS_T") ? std::atoi(std::getenv("STVO_POSE_LDS_T")) != 0 : true;
     if (a.B <= POSE_LATENCY_MAX_B && rec_bytes <= POSE_LDSREC_MAX_BYTES && pose_ldsrec_available<POSE_BLOCK_L>())
-        launch_pose_variant<POSE_BLOCK_L, true>(s, a);   // one workgroup per CU: records resident in LDS
+        launch_pose_variant<POSE_BLOCK_L, true>(s, a, POSE_LDSREC_MAX_BYTES);   // one workgroup per CU: records resident in LDS
     else if (a.B <= POSE_LATENCY_MAX_B)
         launch_pose_variant<POSE_BLOCK_L, false>(s, a);
+    else if (lds_t && pose_ldsrec_available<POSE_BLOCK_T>())
+        launch_pose_variant<POSE_BLOCK_T, true>(s, a, POSE_LDSREC_T_BYTES);
     else
         launch_pose_variant<POSE_BLOCK_T, false>(s, a);
     return STVO_OK;
