@@ -122,7 +122,7 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_ibuf)[3 * (
         r.X = a.prev_P[i * 3 + 0];
         r.Y = a.prev_P[i * 3 + 1];
         r.Z = a.prev_P[i * 3 + 2];
-        r.s2 = a.prev_s2p[i];
+        r.s2 = sqrt(a.prev_s2p[i]);  // records carry sqrt(sigma2): computed once for the LDS-resident ones
         r.ox = a.curr_pl[j * 2 + 0];
         r.oy = a.curr_pl[j * 2 + 1];
         return r;
@@ -150,7 +150,7 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_ibuf)[3 * (
             L.spl[c] = a.prev_spl[i * 2 + c];
             L.epl[c] = a.prev_epl[i * 2 + c];
         }
-        L.sigma2 = a.prev_s2l[i];
+        L.sigma2 = sqrt(a.prev_s2l[i]);  // sqrt(sigma2), see pm::line_term_q
         return L;
     };
     auto load_line = [&](int k) -> pm::LineRec {
@@ -275,7 +275,7 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_ibuf)[3 * (
                 todo &= todo - 1u;
                 PointRec nxt = cur;
                 if (todo) nxt = load_point(__builtin_ctz(todo));
-                pm::point_term(acc, DT, cam, prm.homog_th, cur.X, cur.Y, cur.Z, cur.ox, cur.oy, cur.s2, robust, sp);
+                pm::point_term_q(acc, DT, cam, prm.homog_th, cur.X, cur.Y, cur.Z, cur.ox, cur.oy, cur.s2, robust, sp);
                 cur = nxt;
             }
         }
@@ -283,7 +283,7 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_ibuf)[3 * (
         for (int k = 0; k < LPT; ++k)
             if ((linl >> k) & 1u) {
                 const pm::LineRec L = load_line(k);
-                pm::line_term(acc, DT, cam, prm.homog_th, L, robust, sl);
+                pm::line_term_q(acc, DT, cam, prm.homog_th, L, robust, sl);
             }
         const long long tw1 = tick();
         prefetch_first();  // for the next evaluation; completes while this one is reduced and solved
@@ -324,7 +324,7 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_ibuf)[3 * (
                 res[k] = 0.0;
                 if ((pmatched >> k) & 1u) {
                     const PointRec r = load_point(k);
-                    res[k] = pm::point_residual(DT, cam, r.X, r.Y, r.Z, r.ox, r.oy) * sqrt(r.s2);
+                    res[k] = pm::point_residual(DT, cam, r.X, r.Y, r.Z, r.ox, r.oy) * r.s2;  // r.s2 = sqrt(sigma2)
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -362,7 +362,7 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_ibuf)[3 * (
                 res[k] = 0.0;
                 if ((lmatched >> k) & 1u) {
                     const pm::LineRec L = load_line(k);
-                    res[k] = pm::line_residual(DT, cam, L) * sqrt(L.sigma2);
+                    res[k] = pm::line_residual(DT, cam, L) * L.sigma2;  // sqrt(sigma2)
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
