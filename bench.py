@@ -353,6 +353,8 @@ def main():
     ap.add_argument("--slots", type=int, default=4, help="consecutive frames of every stream kept resident in HBM")
     ap.add_argument("--points", type=int, default=1650, help="landmarks per stream; + 20 %% distractors ~ 2000 key-points per image")
     ap.add_argument("--lines", type=int, default=85, help="3-D segments per stream; + 20 %% distractors ~ 100 key-lines per image")
+    ap.add_argument("--max-keylines", type=int, default=128,
+                    help="key-line capacity per image of the pipeline (config_kitti.yaml: lsd_nfeatures 100; the library allows up to 512)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the latency / configs[1] / correlated-descriptor legs")
     args = ap.parse_args()
@@ -393,7 +395,7 @@ def main():
     cams = [synth.config5_cam(int(s)) for s in seq_ids]
     mp, op = match_params("kitti"), opt_params("kitti")
     ctx = capi.Context(device_id=local_rank, max_rows=2048, max_batch=B)
-    pipe = capi.Sequences(ctx, B, 2048, 512, cams, mp, op)
+    pipe = capi.Sequences(ctx, B, 2048, args.max_keylines, cams, mp, op)
     pipe.set_slots(S)
     for k in range(S):
         pipe.upload(k, [st[k] for st in streams])

@@ -595,10 +595,11 @@ int launch_pose(hipStream_t s, const PoseArgs& a) {
     // (kept as the measured comparison point and exercised by the same parity tests)
     const char* env = std::getenv("STVO_POSE_KERNEL");  // read per call: the parity tests switch between the two kernels
     const int which = env ? std::atoi(env) : 0;
-    // default: this file's kernels — measured faster on the full pipeline (1.07 vs 1.11 ms per 512-stream step, bench.py) and
-    // for single frame pairs (137 vs 167 us); STVO_POSE_KERNEL=2 selects pose_kernel2.hip, which reads every record from HBM
-    // once (compacted LDS cache) at the same per-launch time for points-only batches (profiles/r02_pose_variants.txt)
-    if (which == 2) return launch_pose2(s, a);
+    // default: up to 256 frame pairs this file's latency variant (121 vs 176 us for one pair); larger batches take
+    // pose_kernel2.hip with four waves per pair at 256 VGPRs — every wave a worker, all records in the workgroup's LDS half:
+    // 465 vs 568 us per 1024 points-only pairs, 0.53 vs 0.57 ms inside the pipeline (profiles/r02_pose_variants.txt).
+    // STVO_POSE_KERNEL = 1 / 2 forces one of the two for every batch size.
+    if (which == 2 || (which == 0 && a.B > POSE_LATENCY_MAX_B)) return launch_pose2(s, a);
     if (a.max_pts > STVO_POSE_MAX_POINTS || a.max_lines > STVO_POSE_MAX_LINES) return STVO_ERR_CAPACITY;
     const size_t rec_bytes = ((size_t)a.max_pts * 6 + (size_t)a.max_lines * 14) * sizeof(double);
     // throughput variant: two workgroups per CU, each with half of the CU's LDS as record cache — most records are then read

@@ -36,8 +36,9 @@ struct PointRec2 {
 
 constexpr int REC_P_BYTES = 48, REC_L_BYTES = 112;
 
-template <int NW>
-__global__ __launch_bounds__(NW * 64, 4) void pose2_kernel(PoseArgs a, int lds_rec_bytes) {
+// NW waves per frame pair; WPE = waves per SIMD the register budget is set for (4: 128 VGPRs, 2: 256 VGPRs)
+template <int NW, int WPE>
+__global__ __launch_bounds__(NW * 64, WPE) void pose2_kernel(PoseArgs a, int lds_rec_bytes) {
     constexpr int BLOCK = NW * 64;
     constexpr int PPT = (STVO_POSE_MAX_POINTS + BLOCK - 1) / BLOCK;
     constexpr int LPT = (STVO_POSE_MAX_LINES + BLOCK - 1) / BLOCK;
@@ -528,25 +529,25 @@ __global__ __launch_bounds__(NW * 64, 4) void pose2_kernel(PoseArgs a, int lds_r
 }
 
 // LDS share of the record cache: 160 KB per CU, WG workgroups per CU, minus the kernel's static LDS and some slack
-template <int NW>
-constexpr int pose2_lds_budget() {  // 16 / NW workgroups per CU share its 160 KB
-    return (160 * 1024) / (16 / NW) - (int)(sizeof(PoseSh) + NW * 28 * 8 + 2 * 3 * NW * 4 + NW * 4) - 768;
+template <int NW, int WPE>
+constexpr int pose2_lds_budget() {  // 4 WPE / NW workgroups per CU share its 160 KB
+    return (160 * 1024) / ((4 * WPE) / NW) - (int)(sizeof(PoseSh) + NW * 28 * 8 + 2 * 3 * NW * 4 + NW * 4) - 768;
 }
 
-template <int NW>
+template <int NW, int WPE>
 bool pose2_attr_ok() {
-    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&pose2_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               pose2_lds_budget<NW>()) == hipSuccess;
+    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&pose2_kernel<NW, WPE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               pose2_lds_budget<NW, WPE>()) == hipSuccess;
     return ok;
 }
 
-template <int NW>
+template <int NW, int WPE>
 void launch_pose2_variant(hipStream_t s, const PoseArgs& a) {
     // no more LDS than the records of the largest possible problem need (a small batch item leaves room for other kernels)
     const long long need = (long long)a.max_pts * REC_P_BYTES + (long long)a.max_lines * REC_L_BYTES;
-    int lds = pose2_attr_ok<NW>() ? pose2_lds_budget<NW>() : 48 * 1024;
+    int lds = pose2_attr_ok<NW, WPE>() ? pose2_lds_budget<NW, WPE>() : 48 * 1024;
     if (need < lds) lds = (int)((need + 15) & ~15ll);
-    hipLaunchKernelGGL((pose2_kernel<NW>), dim3(a.B), dim3(NW * 64), (size_t)lds, s, a, lds);
+    hipLaunchKernelGGL((pose2_kernel<NW, WPE>), dim3(a.B), dim3(NW * 64), (size_t)lds, s, a, lds);
 }
 
 }  // namespace
@@ -563,11 +564,13 @@ int launch_pose2(hipStream_t s, const PoseArgs& a) {
     // 16 waves per frame pair while every pair has a CU to itself, 8 (two pairs per CU, records still in LDS) beyond; the 4- and
     // 2-wave variants (more pairs per CU, records mostly streamed) were measured slower and spill (NOTES.md): override only
     int nw = force_nw;
-    if (nw == 0) nw = a.B <= POSE2_LATENCY_MAX_B ? 16 : 8;
-    if (nw >= 16) launch_pose2_variant<16>(s, a);
-    else if (nw >= 8) launch_pose2_variant<8>(s, a);
-    else if (nw >= 4) launch_pose2_variant<4>(s, a);
-    else launch_pose2_variant<2>(s, a);
+    if (nw == 0) nw = a.B <= POSE2_LATENCY_MAX_B ? 16 : 40;
+    // nw == 40: four waves per pair at 256 VGPRs — two workgroups per CU with ALL records in LDS and every wave a worker
+    if (nw == 40) launch_pose2_variant<4, 2>(s, a);
+    else if (nw >= 16) launch_pose2_variant<16, 4>(s, a);
+    else if (nw >= 8) launch_pose2_variant<8, 4>(s, a);
+    else if (nw >= 4) launch_pose2_variant<4, 4>(s, a);
+    else launch_pose2_variant<2, 4>(s, a);
     return STVO_OK;
 }
 

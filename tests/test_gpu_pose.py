@@ -13,11 +13,11 @@ pytestmark = pytest.mark.gpu
 CAM = synth.KITTI_CAM
 
 
-@pytest.fixture(autouse=True, params=["default", "1", "2:16", "2:8", "2:4", "2:2"])
+@pytest.fixture(autouse=True, params=["default", "1", "2:16", "2:8", "2:4", "2:2", "2:40"])
 def pose_kernel_variant(request):
     """Every test of this module runs against both pose kernels: pose_kernel.hip (worker waves + solver wave, "1") and
     pose_kernel2.hip (every wave a worker, row-distributed algebra, records compacted in LDS) with 16 / 8 / 4 / 2 waves per
-    frame pair; "default" is the library's own choice.  The library reads the two variables at every launch."""
+    frame pair at 128 VGPRs, or 4 at 256 VGPRs ("2:40", the default for big batches); "default" is the library's own choice.  The library reads the two variables at every launch."""
     import os
     old = {k: os.environ.get(k) for k in ("STVO_POSE_KERNEL", "STVO_POSE2_NW")}
     if request.param == "default":
