@@ -35,11 +35,16 @@ struct PointRec2 {
 };
 
 constexpr int REC_P_BYTES = 48, REC_L_BYTES = 112;
+constexpr bool POSE2_PRIO = true;  // serial sections at wave priority 3 (measured: 239 -> 230 us per 512 pairs with four waves per pair)
 
 // NW waves per frame pair; WPE = waves per SIMD the register budget is set for (4: 128 VGPRs, 2: 256 VGPRs)
 template <int NW, int WPE>
 __global__ __launch_bounds__(NW * 64, WPE) void pose2_kernel(PoseArgs a, int lds_rec_bytes) {
     constexpr int BLOCK = NW * 64;
+    // 6x6 systems: on ROWS (row_solve_spd & co., no 36-element arrays per lane) in the 128-VGPR variants; with the serial
+    // routines of pose_math.h, executed redundantly by every lane of wave 0, in the 256-VGPR variant, where the arrays fit and
+    // the serial form is the faster one (80 k vs 88 k cycles of solver time per frame pair)
+    constexpr bool POSE2_ROW = WPE >= 4;
     constexpr int PPT = (STVO_POSE_MAX_POINTS + BLOCK - 1) / BLOCK;
     constexpr int LPT = (STVO_POSE_MAX_LINES + BLOCK - 1) / BLOCK;
     using Ops = BlockOps<NW>;
@@ -425,9 +430,13 @@ __global__ __launch_bounds__(NW * 64, WPE) void pose2_kernel(PoseArgs a, int lds
                 tq = tick();
                 ++evals;
                 if (w0) {
-                    if (alg == 0) t0_gn_iter<true>(sh, prm.min_error, prm.min_error_change, it);
-                    else if (alg == 1) t0_gnr_iter<true>(sh, prm.min_error, prm.min_error_change);
-                    else t0_lm_iter<true>(sh, prm.min_error, prm.min_error_change, it == 0 ? 1 : 0);
+                    // the serial section is one wave's dependent chain while the co-resident workgroup's waves evaluate on the
+                    // same SIMD: let it win the issue arbitration
+                    if (POSE2_PRIO) __builtin_amdgcn_s_setprio(3);
+                    if (alg == 0) t0_gn_iter<POSE2_ROW>(sh, prm.min_error, prm.min_error_change, it);
+                    else if (alg == 1) t0_gnr_iter<POSE2_ROW>(sh, prm.min_error, prm.min_error_change);
+                    else t0_lm_iter<POSE2_ROW>(sh, prm.min_error, prm.min_error_change, it == 0 ? 1 : 0);
+                    if (POSE2_PRIO) __builtin_amdgcn_s_setprio(0);
                 }
                 __syncthreads();
                 tprof[1] += tick() - tq;
@@ -445,7 +454,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void pose2_kernel(PoseArgs a, int lds
 #pragma unroll
                     for (int i = 0; i < 36; ++i) sh->cov[i] = (i % 7 == 0) ? 1.0 : 0.0;
                 } else {
-                    t0_cov_from_H<true>(sh);  // :429 / :470 / :545 — H of the last evaluation (damped for LM)
+                    t0_cov_from_H<POSE2_ROW>(sh);  // :429 / :470 / :545 — H of the last evaluation (damped for LM)
                     sh->err_out = evals > 0 ? sh->err : 0.0;
                 }
             }
@@ -460,7 +469,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void pose2_kernel(PoseArgs a, int lds
             if (w0) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) sh->DT1[i] = sh->DT[i];
-                t0_is_good_fast<true>(sh, sh->DT1, sh->err_out);
+                t0_is_good_fast<POSE2_ROW>(sh, sh->DT1, sh->err_out);
             }
             __syncthreads();
             tprof[2] += tick() - tq2;
