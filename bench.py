@@ -463,7 +463,9 @@ def main():
         pose_ms = stage_ms["pose"]
         pose_bytes = 52.0 * np_l + 116.0 * nl_l + 8.0 * n1_l + 8.0 * (B * 64.0) + B * 840.0
         pose_gbs = pose_bytes / (pose_ms * 1e-3) / 1e9 if pose_ms > 0 else 0.0
-        pose_name = "pose_kernel"
+        # kernel the library picks for this batch size (csrc/pose_kernel.hip: launch_pose), as rocprofv3 names it
+        forced = os.environ.get("STVO_POSE_KERNEL", "")
+        pose_name = "pose_kernel<" if forced == "1" or (forced != "2" and B <= 256) else "pose2_kernel<"
         roofline_pose = {"kernel": pose_name, "bound": "hbm", "achieved": pose_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": pose_gbs / HBM_PEAK_GBS, "traffic": committed_traffic(pose_name), "traffic_source": TRAFFIC_SRC,
                          "algorithmic_bytes_per_launch": pose_bytes, "avg_launch_ms": pose_ms, "timing": timing,
