@@ -32,6 +32,7 @@
 //                     needed; one eligible candidate => nothing can block (the reference's best_d2 = INT_MAX).
 //   C  `grid_finalize` lane = left feature: accepts best unless blocked (DOUBLE ratio test of :160, evaluated
 //                     pairwise in pass 2), mutual check against owner (:166-174).
+#include <cstdlib>
 #include <vector>
 
 #include "ctx_internal.h"
@@ -190,12 +191,10 @@ __global__ __launch_bounds__(256) void grid_range_debug_kernel(GridBatch g) {
 }
 
 template <bool LINES, int PASS, bool RANGE>
-__global__ __launch_bounds__(256) void grid_scan_kernel(GridBatch g) {
-    const GridArgs a = frame_view(g, blockIdx.y);
+__device__ __forceinline__ void grid_scan_body(const GridArgs& a, const int p) {
     // lane = scan position p; positions follow the CSR (cell) order of the right features, so the 64
     // features of a wave are spatial neighbours and only the few left features whose window touches
     // that neighbourhood have a non-zero mask: the scan skips 64 left features per vector load.
-    const int p = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
     if ((p & ~63) >= a.n2) return;  // whole wave past the last right feature (wave-uniform)
     // single-scan formulation: pass 1 records the eligible pairs, grid_elig_kernel judges them; this full second scan only
@@ -354,11 +353,14 @@ __global__ __launch_bounds__(256) void grid_scan_kernel(GridBatch g) {
     }
 }
 
+template <bool LINES, int PASS, bool RANGE>
+__global__ __launch_bounds__(256) void grid_scan_kernel(GridBatch g) {
+    grid_scan_body<LINES, PASS, RANGE>(frame_view(g, blockIdx.y), blockIdx.x * 256 + threadIdx.x);
+}
+
 // Pass 2 of the single-scan formulation: lane = right feature (scan position p); for each eligible pair (i1, d) it met in
 // pass 1 that is not i1's best: :160 for the pair (best, this candidate), best_d < d * minRatio12P in DOUBLE, else block i1.
-__global__ __launch_bounds__(256) void grid_elig_kernel(GridBatch g) {
-    const GridArgs a = frame_view(g, blockIdx.y);
-    const int p = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void grid_elig_body(const GridArgs& a, const int p) {
     if (p >= a.n2 || a.ovf[0] != 0) return;
     const int i2 = a.perm[p];
     const int cnt = a.elig_cnt[p];
@@ -374,10 +376,12 @@ __global__ __launch_bounds__(256) void grid_elig_kernel(GridBatch g) {
     }
 }
 
-__global__ __launch_bounds__(256) void grid_finalize_kernel(GridBatch g) {
-    const GridArgs a = frame_view(g, blockIdx.y);
-    const int i1 = blockIdx.x * 256 + threadIdx.x;
-    if (i1 >= g.stride1) return;
+__global__ __launch_bounds__(256) void grid_elig_kernel(GridBatch g) {
+    grid_elig_body(frame_view(g, blockIdx.y), blockIdx.x * 256 + threadIdx.x);
+}
+
+__device__ __forceinline__ void grid_finalize_body(const GridArgs& a, const int i1, const int stride1) {
+    if (i1 >= stride1) return;
     if (i1 >= a.n1) {
         a.m12[i1] = -1;
         return;
@@ -389,6 +393,340 @@ __global__ __launch_bounds__(256) void grid_finalize_kernel(GridBatch g) {
     if (b != 0xFFFFFFFFu && !blocked && (double)(int)(b >> 16) < 2147483647.0 * a.ratio) m = (int)(b & 0xFFFFu);
     if (a.mutual && m >= 0 && a.owner2[m] != i1) m = -1;  // :166-174
     a.m12[i1] = m;
+}
+
+__global__ __launch_bounds__(256) void grid_finalize_kernel(GridBatch g) {
+    grid_finalize_body(frame_view(g, blockIdx.y), blockIdx.x * 256 + threadIdx.x, g.stride1);
+}
+
+// ---- points, one-row windows, at most 2048 x 2048 key-points: the whole matcher of one frame in ONE workgroup -------------------------
+// The scan above gives every left row a whole wave although only ~6 of its 64 lanes hold a candidate.  Here a THREAD owns a
+// RIGHT feature (two per thread, in scan = cell order) and walks its own candidates: the left key-points of the cells
+// x .. x + w_lo of its grid row, which are one contiguous range of a cell-ordered copy of the left descriptors the workgroup
+// builds in LDS (counting sort; neighbouring lanes read neighbouring rows).  Every lane computes a distance in every trip.
+// The order dependence of :145-150 (a pair takes part only if it strictly improves on every earlier left row that met the
+// same right feature) is then local to the thread: it sorts its (left row, distance) keys by left row in registers (bitonic
+// network, 16 slots) and takes the strict prefix minima — the eligible pairs; the last one is matches_21 (:148).  Eligible
+// pairs meet their left rows through LDS: atomic min of (d << 16 | position) = best (:151-154), then one more look at every
+// eligible pair that is not the best for the ratio test (:160, pairwise as in the scan formulation), then one thread per left
+// row applies the mutual check (:166-174).  Right features with more than 16 candidates keep their keys in LDS and extract the
+// chain by repeated minimum searches.  Frames that do not fit (more such keys than the LDS holds) are flagged and run the
+// scan formulation above in grid_points_misfit_kernel.
+constexpr int FUSED_T = 1024, FUSED_ROWS = 2048, FUSED_REG = 16;
+constexpr int FUSED_LW = STVO_GRID_COLS + 16;                 // left key-points up to w_lo columns right of the grid still have candidates
+constexpr int FUSED_LCELLS = STVO_GRID_ROWS * FUSED_LW;       // 3840
+constexpr int FUSED_PADDED = FUSED_ROWS + FUSED_REG;          // the unrolled walks read up to 15 rows past a range
+constexpr int FUSED_KEY_CAP = 8192;                           // keys of the right features with more than 16 candidates, whole frame
+constexpr size_t FUSED_LDS = (size_t)FUSED_PADDED * (16 + 16 + 2) + (size_t)(FUSED_LCELLS + 4) * 4 + (size_t)FUSED_ROWS * (4 + 2 + 1) +
+                             (size_t)FUSED_KEY_CAP * 4;
+
+// the scan formulation for the frames the fused kernel flagged (launched right behind it; a workgroup whose frame fitted returns
+// at once): 16 waves over the blocks of 64 scan positions
+__global__ __launch_bounds__(FUSED_T) void grid_points_misfit_kernel(GridBatch g) {
+    if (g.misfit[blockIdx.x] == 0) return;
+    const GridArgs a = frame_view(g, blockIdx.x);
+    const int stride1 = g.stride1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int blocks = (a.n2 + 63) >> 6;
+    for (int w = wave; w < blocks; w += FUSED_T / 64) grid_scan_body<false, 1, true>(a, w * 64 + lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (a.elig)
+        for (int w = wave; w < blocks; w += FUSED_T / 64) grid_elig_body(a, w * 64 + lane);
+    for (int w = wave; w < blocks; w += FUSED_T / 64) grid_scan_body<false, 2, true>(a, w * 64 + lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    for (int i1 = tid; i1 < stride1; i1 += FUSED_T) grid_finalize_body(a, i1, stride1);
+}
+
+__device__ __forceinline__ uint32_t hamming256(const uint4& t0, const uint4& t1, const uint4& q0, const uint4& q1) {
+    uint32_t dd = __builtin_popcount(t0.x ^ q0.x);
+    dd = bcnt_acc(t0.y ^ q0.y, dd);
+    dd = bcnt_acc(t0.z ^ q0.z, dd);
+    dd = bcnt_acc(t0.w ^ q0.w, dd);
+    dd = bcnt_acc(t1.x ^ q1.x, dd);
+    dd = bcnt_acc(t1.y ^ q1.y, dd);
+    dd = bcnt_acc(t1.z ^ q1.z, dd);
+    dd = bcnt_acc(t1.w ^ q1.w, dd);
+    return dd;
+}
+
+// ascending bitonic network over 16 registers
+__device__ __forceinline__ void sort16(uint32_t (&k)[FUSED_REG]) {
+#pragma unroll
+    for (int size = 2; size <= FUSED_REG; size <<= 1) {
+#pragma unroll
+        for (int j = size >> 1; j > 0; j >>= 1) {
+#pragma unroll
+            for (int i = 0; i < FUSED_REG; ++i) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const uint32_t lo = min(k[i], k[l]), hi = max(k[i], k[l]);
+                    const bool asc = (i & size) == 0;
+                    k[i] = asc ? lo : hi;
+                    k[l] = asc ? hi : lo;
+                }
+            }
+        }
+    }
+}
+
+constexpr uint32_t FUSED_NOKEY = 0xFFFFFFFFu, FUSED_FLAG = 1u << 30;  // key = left row << 9 | distance (0..256)
+
+__global__ __launch_bounds__(FUSED_T) void grid_points_fused_kernel(GridBatch g, const int key_cap, const int prof) {
+    extern __shared__ uint4 s_fused[];
+    __shared__ int s_wsum[FUSED_T / 64];
+    uint4* s_llo = s_fused;                                                              // [pos] first / second half of the left rows,
+    uint4* s_lhi = s_llo + FUSED_PADDED;                                                 //       cell order
+    uint32_t* s_start = reinterpret_cast<uint32_t*>(s_lhi + FUSED_PADDED);               // [cell] histogram, then exclusive start
+    uint32_t* s_best = s_start + FUSED_LCELLS + 4;                                       // [left row] min (d << 16 | scan position)
+    uint32_t* s_keys = s_best + FUSED_ROWS;                                              // keys of the wide right features
+    unsigned short* s_lperm = reinterpret_cast<unsigned short*>(s_keys + FUSED_KEY_CAP); // [pos] -> left row
+    unsigned short* s_owner = s_lperm + FUSED_PADDED;                                    // [scan position] matches_21 (:148)
+    unsigned char* s_blocked = reinterpret_cast<unsigned char*>(s_owner + FUSED_ROWS);   // [left row] ratio test failed
+    const GridArgs a = frame_view(g, blockIdx.x);
+    const int32_t* __restrict__ cell2 = g.cell2 + (size_t)blockIdx.x * g.stride2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    long long tk[6] = {0, 0, 0, 0, 0, 0};
+    if (prof) tk[0] = (long long)__builtin_readcyclecounter();
+    const uint4* __restrict__ D2 = reinterpret_cast<const uint4*>(a.d2);
+    const uint4* __restrict__ D1 = reinterpret_cast<const uint4*>(a.d1);
+    // ---- counting sort of the left key-points by cell (x may exceed the grid by up to w_lo columns: :67-71 clamp the WINDOW)
+    for (int c = tid; c < FUSED_LCELLS + 4; c += FUSED_T) s_start[c] = 0u;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        s_best[tid + r * FUSED_T] = 0xFFFFFFFFu;
+        s_blocked[tid + r * FUSED_T] = 0;
+    }
+    int lcell[2], lrank[2] = {0, 0};
+    const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+    uint4 l0[2] = {z4, z4}, l1[2] = {z4, z4}, q0[2] = {z4, z4}, q1[2] = {z4, z4};
+    int rc[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int i1 = tid + r * FUSED_T;
+        lcell[r] = -1;
+        if (i1 < a.n1) {
+            const int2 c = reinterpret_cast<const int2*>(a.cell_xy1)[i1];
+            if (c.y >= 0 && c.y < STVO_GRID_ROWS && c.x >= 0 && c.x <= STVO_GRID_COLS - 1 + a.w.w_lo) lcell[r] = c.y * FUSED_LW + c.x;
+            l0[r] = D1[2 * i1];
+            l1[r] = D1[2 * i1 + 1];
+        }
+        const int p = tid + r * FUSED_T;
+        rc[r] = -1;
+        if (p < a.n2) {
+            const int i2 = a.perm[p];
+            rc[r] = cell2[p];
+            q0[r] = D2[2 * i2];
+            q1[r] = D2[2 * i2 + 1];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+        if (lcell[r] >= 0) lrank[r] = (int)atomicAdd(&s_start[lcell[r]], 1u);
+    __syncthreads();
+    {  // exclusive scan: 4 cells per thread
+        const int c0 = tid * 4;
+        uint32_t v[4] = {0u, 0u, 0u, 0u};
+        if (c0 < FUSED_LCELLS) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = s_start[c0 + k];
+        }
+        const int sum = (int)(v[0] + v[1] + v[2] + v[3]);
+        int incl = sum;
+#pragma unroll
+        for (int sh = 1; sh < 64; sh <<= 1) {
+            const int up = __shfl_up(incl, sh);
+            if (lane >= sh) incl += up;
+        }
+        if (lane == 63) s_wsum[wave] = incl;
+        __syncthreads();
+        int run = incl - sum;
+#pragma unroll
+        for (int w = 0; w < FUSED_T / 64; ++w)
+            if (w < wave) run += s_wsum[w];
+        if (c0 < FUSED_LCELLS) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                s_start[c0 + k] = (uint32_t)run;
+                run += (int)v[k];
+            }
+        }
+        if (c0 == FUSED_LCELLS) s_start[FUSED_LCELLS] = (uint32_t)run;  // thread 960: everything before it
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+        if (lcell[r] >= 0) {
+            const int pos = (int)s_start[lcell[r]] + lrank[r];
+            s_llo[pos] = l0[r];
+            s_lhi[pos] = l1[r];
+            s_lperm[pos] = (unsigned short)(tid + r * FUSED_T);
+        }
+    // candidate range of this thread's right features in the cell-ordered left rows, slots for the keys of the wide ones
+    int la[2], cnt[2], xoff[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        la[r] = 0;
+        cnt[r] = 0;
+        if (rc[r] >= 0) {
+            const int y = rc[r] >> 6, x = rc[r] & (STVO_GRID_COLS - 1);
+            la[r] = (int)s_start[y * FUSED_LW + x];
+            cnt[r] = (int)s_start[y * FUSED_LW + x + a.w.w_lo + 1] - la[r];
+        }
+    }
+    {
+        const int w0 = cnt[0] > FUSED_REG ? cnt[0] : 0, w1 = cnt[1] > FUSED_REG ? cnt[1] : 0;
+        const int mine = w0 + w1;
+        int incl = mine;
+#pragma unroll
+        for (int sh = 1; sh < 64; sh <<= 1) {
+            const int up = __shfl_up(incl, sh);
+            if (lane >= sh) incl += up;
+        }
+        __syncthreads();  // s_wsum reuse; also: the cell-ordered left rows are complete
+        if (lane == 63) s_wsum[wave] = incl;
+        __syncthreads();
+        int wbase = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < FUSED_T / 64; ++w) {
+            const int v = s_wsum[w];
+            if (w < wave) wbase += v;
+            total += v;
+        }
+        xoff[0] = wbase + incl - mine;
+        xoff[1] = xoff[0] + w0;
+        if (total > key_cap) {  // block-uniform
+            if (tid == 0) g.misfit[blockIdx.x] = 1;
+            return;
+        }
+        if (tid == 0) g.misfit[blockIdx.x] = 0;
+    }
+    if (prof) tk[1] = (long long)__builtin_readcyclecounter();
+    // ---- distances, eligible chains, best per left row
+    uint32_t key[2][FUSED_REG];
+    uint32_t elig[2] = {0u, 0u};
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int p = tid + r * FUSED_T;
+        const bool wide = cnt[r] > FUSED_REG;
+        const int c16 = wide ? 0 : cnt[r];
+        const uint4* lo_row = s_llo + la[r];  // constant offsets from one base: LDS immediates, no address registers
+        const uint4* hi_row = s_lhi + la[r];
+        const unsigned short* perm_row = s_lperm + la[r];
+#pragma unroll
+        for (int k4 = 0; k4 < FUSED_REG; k4 += 4) {
+            if (!__any(c16 > k4)) {  // wave-uniform
+#pragma unroll
+                for (int j = 0; j < 4; ++j) key[r][k4 + j] = FUSED_NOKEY;
+                continue;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // past the range: a neighbour's row or padding, result masked
+                const uint32_t dd = hamming256(lo_row[k4 + j], hi_row[k4 + j], q0[r], q1[r]);
+                const uint32_t i1 = perm_row[k4 + j];
+                key[r][k4 + j] = k4 + j < c16 ? ((i1 << 9) | dd) : FUSED_NOKEY;
+            }
+        }
+        uint32_t owner = 0xFFFFu;
+        if (a.mutual) {  // :145-150 — ascending left row, strict running minimum
+            sort16(key[r]);
+            uint32_t thr = 512u;
+#pragma unroll
+            for (int k = 0; k < FUSED_REG; ++k) {
+                const uint32_t dd = key[r][k] & 511u;
+                if (key[r][k] != FUSED_NOKEY && dd < thr) {
+                    thr = dd;
+                    owner = key[r][k] >> 9;
+                    elig[r] |= 1u << k;
+                }
+            }
+        } else {
+            elig[r] = (1u << c16) - 1u;
+        }
+#pragma unroll
+        for (int k = 0; k < FUSED_REG; ++k)
+            if (elig[r] & (1u << k)) atomicMin(&s_best[key[r][k] >> 9], ((key[r][k] & 511u) << 16) | (uint32_t)p);
+        if (wide) {  // keys in LDS; the chain by repeated searches for the lowest left row below the threshold
+            uint32_t* kk = s_keys + xoff[r];
+            for (int k = 0; k < cnt[r]; ++k) {
+                const int pos = la[r] + k;
+                kk[k] = ((uint32_t)s_lperm[pos] << 9) | hamming256(s_llo[pos], s_lhi[pos], q0[r], q1[r]);
+            }
+            uint32_t thr = 512u;
+            for (;;) {
+                uint32_t bestk = FUSED_NOKEY;
+                for (int k = 0; k < cnt[r]; ++k) {
+                    const uint32_t v = kk[k];
+                    if (!(v & FUSED_FLAG) && (!a.mutual || (v & 511u) < thr)) bestk = min(bestk, v);
+                }
+                if (bestk == FUSED_NOKEY) break;
+                thr = bestk & 511u;
+                owner = bestk >> 9;
+                atomicMin(&s_best[owner], (thr << 16) | (uint32_t)p);
+                for (int k = 0; k < cnt[r]; ++k)  // left rows are unique per right feature
+                    if (kk[k] == bestk) kk[k] = bestk | FUSED_FLAG;
+            }
+        }
+        if (p < FUSED_ROWS) s_owner[p] = (unsigned short)owner;
+    }
+    __syncthreads();
+    if (prof) tk[2] = (long long)__builtin_readcyclecounter();
+    // ---- :160 for every eligible pair that is not its left row's best: best_d < d * minRatio12P in DOUBLE, else the row is out
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const uint32_t p = (uint32_t)(tid + r * FUSED_T);
+        auto judge = [&](uint32_t k) {
+            const uint32_t i1 = (k >> 9) & 2047u, dd = k & 511u;
+            const uint32_t bk = s_best[i1];
+            if (bk != ((dd << 16) | p)) {
+                const double best_d = (double)(int)(bk >> 16), d2 = (double)(int)dd;
+                if (!(best_d < d2 * a.ratio)) s_blocked[i1] = 1;
+            }
+        };
+#pragma unroll
+        for (int k4 = 0; k4 < FUSED_REG; k4 += 4) {
+            if (!__any((elig[r] >> k4) & 0xFu)) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (elig[r] & (1u << (k4 + j))) judge(key[r][k4 + j]);
+        }
+        if (cnt[r] > FUSED_REG) {
+            const uint32_t* kk = s_keys + xoff[r];
+            for (int k = 0; k < cnt[r]; ++k) {
+                const uint32_t v = kk[k];
+                if (v & FUSED_FLAG) judge(v & ~FUSED_FLAG);
+            }
+        }
+    }
+    __syncthreads();
+    if (prof) tk[3] = (long long)__builtin_readcyclecounter();
+    // ---- one thread per left row: accept unless blocked, mutual check (:166-174)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int i1 = tid + r * FUSED_T;
+        if (i1 >= g.stride1) continue;
+        const uint32_t bk = s_best[i1];
+        int mm = -1;
+        if (i1 < a.n1 && bk != 0xFFFFFFFFu && !s_blocked[i1] && (double)(int)(bk >> 16) < 2147483647.0 * a.ratio) {
+            const int pb = (int)(bk & 0xFFFFu);
+            if (!a.mutual || (int)s_owner[pb] == i1) mm = a.perm[pb];
+        }
+        a.m12[i1] = mm;
+    }
+#ifdef STVO_GRID_FUSED_PROFILE  // developer build: device printf costs the kernel a scratch allocation
+    if (prof && blockIdx.x == 0 && (tid == 0 || tid == 700)) {
+        tk[4] = (long long)__builtin_readcyclecounter();
+        printf("[grid fused] tid %d: sort %lld, distances + chains %lld, judge %lld, finalize %lld cycles\n", tid, tk[1] - tk[0],
+               tk[2] - tk[1], tk[3] - tk[2], tk[4] - tk[3]);
+    }
+#else
+    (void)tk;
+#endif
 }
 
 }  // namespace
@@ -412,6 +750,26 @@ void launch_grid_batch(hipStream_t s, const GridBatch& g, bool lines, hipEvent_t
         if (scan_events) (void)hipEventRecord(scan_events[1], s);
     } else {
         const bool range = g.range_points && g.range1 != nullptr;
+        // STVO_GRID_FUSED=0: the scan formulation for every batch; STVO_GRID_FUSED_CAP: capacity for the keys of right features with more than 16 candidates (tests force the misfit path with -1)
+        const char* ef = std::getenv("STVO_GRID_FUSED");
+        const bool fused = range && g.misfit && g.cell2 && g.stride1 <= FUSED_ROWS && g.stride2 <= FUSED_ROWS && g.w.w_lo >= 0 &&
+                           g.w.w_lo <= FUSED_LW - STVO_GRID_COLS && g.w.w_hi == 0 && g.w.h_lo == 0 && g.w.h_hi == 0 && !(ef && ef[0] == '0');
+        if (fused) {
+            static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(grid_points_fused_kernel),
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS) == hipSuccess;
+            const char* ec = std::getenv("STVO_GRID_FUSED_CAP");
+            int cap = ec ? std::atoi(ec) : FUSED_KEY_CAP;
+            if (cap > FUSED_KEY_CAP) cap = FUSED_KEY_CAP;  // negative: every frame misfits
+            const char* ep = std::getenv("STVO_GRID_FUSED_PROF");
+            const int prof = ep ? std::atoi(ep) : 0;  // developer aid: cycle counts of frame 0 on stdout
+            if (attr_ok) {
+                if (scan_events) (void)hipEventRecord(scan_events[0], s);
+                hipLaunchKernelGGL(grid_points_fused_kernel, dim3(g.B), dim3(FUSED_T), FUSED_LDS, s, g, cap, prof);
+                hipLaunchKernelGGL(grid_points_misfit_kernel, dim3(g.B), dim3(FUSED_T), 0, s, g);
+                if (scan_events) (void)hipEventRecord(scan_events[1], s);
+                return;
+            }
+        }
         if (range) {
             if (scan_events) (void)hipEventRecord(scan_events[0], s);
             hipLaunchKernelGGL((grid_scan_kernel<false, 1, true>), g2, blk, 0, s, g);

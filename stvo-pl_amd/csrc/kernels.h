@@ -132,9 +132,11 @@ struct GridBatch {
     // top2 / ovf must then be initialised by the caller (kTop2Empty = 0x00000000FFFFFFFF, 0)
     int range_points;
     const int32_t* range1;     // [B][stride1][2] (lo, hi) of every left feature when range_points != 0
+    const int32_t* cell2;      // [B][stride2] or nullptr: grid cell (y * 64 + x) of the right feature at each scan position, -1 outside the grid
     uint32_t* elig;            // [B][GRID_ELIG][stride2]  (i1 << 16 | d), slot-major
     int32_t* elig_cnt;         // [B][stride2]
     int32_t* ovf;              // [B] set when some right feature of the frame met more than GRID_ELIG eligible pairs
+    int32_t* misfit;           // [B] or nullptr: written by the one-workgroup-per-frame point matcher (1: frame left to the scan formulation)
 };
 constexpr int GRID_ELIG = 16;
 // scan_events (optional): [0] / [1] are recorded on `s` before / after the two grid_scan passes

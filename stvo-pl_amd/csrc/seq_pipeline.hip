@@ -93,6 +93,7 @@ struct SeqDev {
     // scratch of the point grid matcher that point_cells_kernel initialises (no candidate bit-matrix kernel runs for points)
     unsigned long long* top2_p;  // [B][K]
     int32_t* govf_p;             // [B]
+    int32_t* pcell;              // [B][K] grid cell (y * 64 + x) of the right key-point at each CSR position, -1: outside the grid
     int32_t* prange;             // [B][K][2] candidate range of every left key-point in CSR positions (GridStructure::get, one-row window)
 };
 
@@ -193,6 +194,7 @@ __global__ __launch_bounds__(256) void point_cells_kernel(SeqDev s) {
             pos = n_in + atomicAdd(&s_extra, 1);
         }
         s.pperm[off + pos] = i;  // scan order = CSR (spatial) order
+        s.pcell[off + pos] = in_grid(x, y) ? y * STVO_GRID_COLS + x : -1;
         s.prank[off + i] = pos;
     }
 }
@@ -566,13 +568,13 @@ int stvo_seq_create_multi(stvo_ctx* ctx, int B, int max_keypoints, int max_keyli
     const size_t o_raw = c.take(s->raw_bytes), o_raw1 = c.take(s->raw_bytes);
     const size_t o_cams = c.take(nb * sizeof(stvo_cam)), o_invwh = c.take(nb * 2 * 8);
     const size_t o_pxy = c.take(nb * K * 2 * 4), o_pstart = c.take(nb * (STVO_GRID_CELLS + 1) * 4), o_pitems = c.take(nb * K * 4),
-                 o_prank = c.take(nb * K * 4), o_pperm = c.take(nb * K * 4), o_prange = c.take(nb * K * 2 * 4);
+                 o_prank = c.take(nb * K * 4), o_pperm = c.take(nb * K * 4), o_prange = c.take(nb * K * 2 * 4), o_pcell = c.take(nb * K * 4);
     const size_t o_lxy = c.take(nb * M * 4 * 4), o_lstart = c.take(nb * (STVO_GRID_CELLS + 1) * 4),
                  o_litems = c.take(nb * M * stvo::LENT * 4), o_lrank = c.take(nb * M * 4), o_lperm = c.take(nb * M * 4),
                  o_ldir = c.take(nb * M * 2 * 8);
     const int R = K > M ? K : M;
     const size_t o_cover = c.take(nb * (size_t)(R / 64) * R * 8), o_top2 = c.take(nb * R * 8), o_owner = c.take(nb * R * 4);
-    const size_t o_elig = c.take(nb * stvo::GRID_ELIG * (size_t)K * 4), o_eligc = c.take(nb * K * 4), o_govf = c.take(nb * 4);
+    const size_t o_elig = c.take(nb * stvo::GRID_ELIG * (size_t)K * 4), o_eligc = c.take(nb * K * 4), o_govf = c.take(nb * 8);  // ovf[nb] + misfit[nb]
     const size_t o_elig_l = c.take(nb * stvo::GRID_ELIG * (size_t)M * 4), o_eligc_l = c.take(nb * M * 4), o_govf_l = c.take(nb * 4);
     const size_t o_m12sp = c.take(nb * K * 4), o_m12sl = c.take(nb * M * 4), o_m12p = c.take(nb * K * 4), o_m12l = c.take(nb * M * 4),
                  o_inlp = c.take(nb * K * 4), o_inll = c.take(nb * M * 4), o_res = c.take(nb * sizeof(stvo_pose_result)),
@@ -664,7 +666,7 @@ int stvo_seq_create_multi(stvo_ctx* ctx, int B, int max_keypoints, int max_keyli
     s->m12_span = o_inlp - o_m12sp;  // m12s_p, m12s_l, m12p, m12l are carved back to back
     s->inl_span = o_res - o_inlp;    // inlp, inll likewise
     d.m12s_p = s->m12s_p; d.m12s_l = s->m12s_l;
-    d.top2_p = s->top2; d.govf_p = s->govf; d.prange = (int32_t*)(D + o_prange);
+    d.top2_p = s->top2; d.govf_p = s->govf; d.prange = (int32_t*)(D + o_prange); d.pcell = (int32_t*)(D + o_pcell);
     for (int t = 0; t < 2; ++t) {
         stvo_seq::Set& q = s->set[t];
         q.pl = (double*)(D + o_set[t][0]); q.P = (double*)(D + o_set[t][1]); q.s2 = (double*)(D + o_set[t][2]);
@@ -886,8 +888,10 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl) {
         g.ratio = s->ratio_grid; g.line_sim_th = 0.0; g.mutual = s->mp.best_lr_matches;
         g.cover = s->cover; g.rank = d.prank; g.perm = d.pperm; g.top2 = s->top2; g.owner2 = s->owner2; g.m12 = s->m12s_p;
         if (g.mutual) { g.elig = s->elig; g.elig_cnt = s->elig_cnt; g.ovf = s->govf; }
+        g.misfit = s->govf + s->B;
         g.range_points = 1;  // device CSR: right key-points are numbered in cell order, one grid row per window
         g.range1 = d.prange;
+        g.cell2 = d.pcell;
         s->last_point_grid = g;
         stvo::launch_grid_batch(st, g, false, tev ? tev + 2 : nullptr);
         hipLaunchKernelGGL(stvo::point_tail_kernel, dim3(B), dim3(stvo::TAIL_BLOCK), 0, st, d);

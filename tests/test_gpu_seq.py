@@ -171,3 +171,71 @@ def test_seq_fetch_by_products(oracle):
     finally:
         dev.close()
         ctx.close()
+
+
+@pytest.mark.parametrize("env", [{"STVO_GRID_FUSED": "0"}, {"STVO_GRID_FUSED_CAP": "-1"}], ids=["scan", "misfit"])
+def test_seq_point_grid_other_formulations(oracle, monkeypatch, env):
+    """The stereo point matcher runs as one workgroup per frame by default; the scan formulation (separate launches) and the
+    scan formulation inside the fused launch (frames whose pairs do not fit the LDS) must give the same pipeline results."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    cam = synth.KITTI_CAM
+    seqs = [synth.make_stereo_sequence(520 + b, n_frames=4, n_pts=500 + 500 * b, n_lines=30, cam=cam) for b in range(3)]
+    run_and_compare(oracle, seqs, cam, "kitti")
+
+
+def crowd(fr, rng, frac, box):
+    """Moves a fraction of the key-points of both images into a small box (left / right keep their disparity): many candidates
+    per window, long eligibility chains, near-duplicate descriptors."""
+    fr = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in fr.items()}
+    n = min(len(fr["kp_l"]), len(fr["kp_r"]))
+    idx = rng.choice(n, int(frac * n), replace=False)
+    u0, v0, w, h = box
+    for key in ("kp_l", "kp_r"):
+        kp = fr[key]
+        kp[idx, 0] = (u0 + (kp[idx, 0] % w)).astype(np.float32)
+        kp[idx, 1] = (v0 + (kp[idx, 1] % h)).astype(np.float32)
+    # near-duplicate descriptors inside the crowd: ties and one-bit differences between candidates of the same window
+    base = fr["desc_l"][idx[0]].copy()
+    for j in idx[: len(idx) // 2]:
+        flips = rng.integers(0, 256, size=rng.integers(0, 4))
+        for side in ("desc_l", "desc_r"):
+            d = base.copy()
+            for f in flips:
+                d[f >> 3] ^= np.uint8(1 << (f & 7))
+            if side == "desc_r" and rng.random() < 0.5:
+                d[0] ^= np.uint8(1)
+            fr[side][j] = d
+    return fr
+
+
+@pytest.mark.parametrize("frac,box", [(0.5, (300, 100, 200, 12)), (0.95, (500, 200, 60, 7)), (0.3, (0, 0, 1241, 8)),
+                                      (0.12, (200, 80, 600, 30)), (0.1, (200, 80, 500, 24))],
+                         ids=["half-in-strip", "all-in-one-window", "top-row", "mild-crowd", "mild-crowd-wide-rows"])
+@pytest.mark.parametrize("env", [{}, {"STVO_GRID_FUSED": "0"}], ids=["fused", "scan"])
+def test_seq_point_grid_crowded_frames(oracle, monkeypatch, frac, box, env):
+    """Raw matchGrid output (stereoFrame.cpp:145) on frames whose key-points crowd into a few grid cells: rows with more than
+    64 candidates and frames with more pairs than the one-workgroup formulation holds (it must then take the scan
+    formulation on its own), chains of equal distances — index for index against the oracle."""
+    from stvo_amd import capi
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    cam = synth.KITTI_CAM
+    rng = np.random.default_rng(77)
+    seq = synth.make_stereo_sequence(4321, n_frames=2, n_pts=1600, n_lines=0, cam=cam)
+    mp = match_params("kitti"); op = opt_params("kitti", has_lines=0)
+    ctx = capi.Context(device_id=0, max_rows=2048, max_batch=1)
+    dev = capi.Sequences(ctx, 1, 2048, 64, cam, mp, op)
+    try:
+        dev.enable_fetch(True)
+        for fr in seq:
+            fr = crowd(fr, rng, frac, box)
+            dev.push([fr])
+            ms_p = dev.fetch_matches()[0]
+            ref = pipeline_ref.stereo_frame(oracle, fr, cam, mp, True, False)
+            n_l = len(fr["kp_l"])
+            assert np.array_equal(ms_p[0, :n_l], ref["m12_raw_p"])
+            assert (ref["m12_raw_p"] >= 0).sum() > 50
+    finally:
+        dev.close()
+        ctx.close()
