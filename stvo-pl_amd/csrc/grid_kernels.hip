@@ -402,19 +402,18 @@ __global__ __launch_bounds__(256) void grid_finalize_kernel(GridBatch g) {
 // ---- points, one-row windows, at most 2048 x 2048 key-points: the whole matcher of one frame in ONE workgroup -------------------------
 // The scan above gives every left row a whole wave although only ~6 of its 64 lanes hold a candidate.  Here a THREAD owns a
 // RIGHT feature (two per thread, in scan = cell order) and walks its own candidates: the left key-points of the cells
-// x .. x + w_lo of its grid row, which are one contiguous range of a cell-ordered copy of the left descriptors the workgroup
-// builds in LDS (counting sort; neighbouring lanes read neighbouring rows).  Every lane computes a distance in every trip.
-// The order dependence of :145-150 (a pair takes part only if it strictly improves on every earlier left row that met the
-// same right feature) is then local to the thread: it sorts its (left row, distance) keys by left row in registers (bitonic
-// network, 16 slots) and takes the strict prefix minima — the eligible pairs; the last one is matches_21 (:148).  Eligible
-// pairs meet their left rows through LDS: atomic min of (d << 16 | position) = best (:151-154), then one more look at every
-// eligible pair that is not the best for the ratio test (:160, pairwise as in the scan formulation), then one thread per left
-// row applies the mutual check (:166-174).  Right features with more than 16 candidates keep their keys in LDS and extract the
-// chain by repeated minimum searches.  Frames that do not fit (more such keys than the LDS holds) are flagged and run the
-// scan formulation above in grid_points_misfit_kernel.
+// x .. x + w_lo of its grid row, which are one contiguous range of a cell-ordered copy of the left descriptors in LDS
+// (point_cells_kernel counting-sorts the left indices; neighbouring lanes read neighbouring rows).  Every lane computes a
+// distance in every trip.  The order dependence of :145-150 (a pair takes part only if it strictly improves on every earlier
+// left row that met the same right feature) is then local to the thread: it sorts its (left row << 9 | distance) keys in
+// registers (bitonic network, 16 slots) and takes the strict prefix minima — the eligible pairs; the last one is matches_21
+// (:148).  Eligible pairs meet their left rows through LDS: atomic min of (d << 16 | position) = best (:151-154), then one more
+// look at every eligible pair that is not the best for the ratio test (:160, pairwise as in the scan formulation), then one
+// thread per left row applies the mutual check (:166-174).  A right feature with more than 16 candidates (rare) is taken by
+// its whole wave, lane = candidate, keys in LDS.  Frames with more such keys than the LDS holds are flagged and run the scan
+// formulation above in grid_points_misfit_kernel, launched right behind.
 constexpr int FUSED_T = 1024, FUSED_ROWS = 2048, FUSED_REG = 16;
-constexpr int FUSED_LW = STVO_GRID_COLS + 16;                 // left key-points up to w_lo columns right of the grid still have candidates
-constexpr int FUSED_LCELLS = STVO_GRID_ROWS * FUSED_LW;       // 3840
+constexpr int FUSED_LW = GRID_LW, FUSED_LCELLS = GRID_LCELLS;  // left key-points up to 16 columns right of the grid still have candidates
 constexpr int FUSED_PADDED = FUSED_ROWS + FUSED_REG;          // the unrolled walks read up to 15 rows past a range
 constexpr int FUSED_KEY_CAP = 8192;                           // keys of the right features with more than 16 candidates, whole frame
 constexpr size_t FUSED_LDS = (size_t)FUSED_PADDED * (16 + 16 + 2) + (size_t)(FUSED_LCELLS + 4) * 4 + (size_t)FUSED_ROWS * (4 + 2 + 1) +
@@ -477,7 +476,7 @@ constexpr uint32_t FUSED_NOKEY = 0xFFFFFFFFu, FUSED_FLAG = 1u << 30;  // key = l
 
 __global__ __launch_bounds__(FUSED_T) void grid_points_fused_kernel(GridBatch g, const int key_cap, const int prof) {
     extern __shared__ uint4 s_fused[];
-    __shared__ int s_wsum[FUSED_T / 64];
+    __shared__ int s_wsum[1];
     uint4* s_llo = s_fused;                                                              // [pos] first / second half of the left rows,
     uint4* s_lhi = s_llo + FUSED_PADDED;                                                 //       cell order
     uint32_t* s_start = reinterpret_cast<uint32_t*>(s_lhi + FUSED_PADDED);               // [cell] histogram, then exclusive start
@@ -487,87 +486,44 @@ __global__ __launch_bounds__(FUSED_T) void grid_points_fused_kernel(GridBatch g,
     unsigned short* s_owner = s_lperm + FUSED_PADDED;                                    // [scan position] matches_21 (:148)
     unsigned char* s_blocked = reinterpret_cast<unsigned char*>(s_owner + FUSED_ROWS);   // [left row] ratio test failed
     const GridArgs a = frame_view(g, blockIdx.x);
-    const int32_t* __restrict__ cell2 = g.cell2 + (size_t)blockIdx.x * g.stride2;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x;
     long long tk[6] = {0, 0, 0, 0, 0, 0};
     if (prof) tk[0] = (long long)__builtin_readcyclecounter();
-    const uint4* __restrict__ D2 = reinterpret_cast<const uint4*>(a.d2);
+    // ---- the left rows into LDS in cell order (point_cells_kernel sorted the indices); this thread's two right rows into registers
+    const int32_t* __restrict__ cell2 = g.cell2 + (size_t)blockIdx.x * g.stride2;
+    const uint32_t* __restrict__ lstart = g.lstart + (size_t)blockIdx.x * GRID_LSTART_STRIDE;
+    const int32_t* __restrict__ lperm = g.lperm + (size_t)blockIdx.x * g.stride1;
     const uint4* __restrict__ D1 = reinterpret_cast<const uint4*>(a.d1);
-    // ---- counting sort of the left key-points by cell (x may exceed the grid by up to w_lo columns: :67-71 clamp the WINDOW)
-    for (int c = tid; c < FUSED_LCELLS + 4; c += FUSED_T) s_start[c] = 0u;
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        s_best[tid + r * FUSED_T] = 0xFFFFFFFFu;
-        s_blocked[tid + r * FUSED_T] = 0;
-    }
-    int lcell[2], lrank[2] = {0, 0};
+    const uint4* __restrict__ D2 = reinterpret_cast<const uint4*>(a.d2);
+    const int n_placed = (int)lstart[FUSED_LCELLS];
     const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
-    uint4 l0[2] = {z4, z4}, l1[2] = {z4, z4}, q0[2] = {z4, z4}, q1[2] = {z4, z4};
+    uint4 q0[2] = {z4, z4}, q1[2] = {z4, z4};
     int rc[2];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-        const int i1 = tid + r * FUSED_T;
-        lcell[r] = -1;
-        if (i1 < a.n1) {
-            const int2 c = reinterpret_cast<const int2*>(a.cell_xy1)[i1];
-            if (c.y >= 0 && c.y < STVO_GRID_ROWS && c.x >= 0 && c.x <= STVO_GRID_COLS - 1 + a.w.w_lo) lcell[r] = c.y * FUSED_LW + c.x;
-            l0[r] = D1[2 * i1];
-            l1[r] = D1[2 * i1 + 1];
+        const int pos = tid + r * FUSED_T;
+        if (pos < n_placed) {
+            const int i1 = lperm[pos];
+            s_llo[pos] = D1[2 * i1];
+            s_lhi[pos] = D1[2 * i1 + 1];
+            s_lperm[pos] = (unsigned short)i1;
         }
-        const int p = tid + r * FUSED_T;
+        s_best[pos] = 0xFFFFFFFFu;
+        s_blocked[pos] = 0;
         rc[r] = -1;
-        if (p < a.n2) {
-            const int i2 = a.perm[p];
-            rc[r] = cell2[p];
+        if (pos < a.n2) {
+            const int i2 = a.perm[pos];
+            rc[r] = cell2[pos];
             q0[r] = D2[2 * i2];
             q1[r] = D2[2 * i2 + 1];
         }
     }
+    for (int c = tid; c <= FUSED_LCELLS; c += FUSED_T) s_start[c] = lstart[c];
+    if (tid == 0) s_wsum[0] = 0;  // bump allocator of the key slots
     __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-        if (lcell[r] >= 0) lrank[r] = (int)atomicAdd(&s_start[lcell[r]], 1u);
-    __syncthreads();
-    {  // exclusive scan: 4 cells per thread
-        const int c0 = tid * 4;
-        uint32_t v[4] = {0u, 0u, 0u, 0u};
-        if (c0 < FUSED_LCELLS) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = s_start[c0 + k];
-        }
-        const int sum = (int)(v[0] + v[1] + v[2] + v[3]);
-        int incl = sum;
-#pragma unroll
-        for (int sh = 1; sh < 64; sh <<= 1) {
-            const int up = __shfl_up(incl, sh);
-            if (lane >= sh) incl += up;
-        }
-        if (lane == 63) s_wsum[wave] = incl;
-        __syncthreads();
-        int run = incl - sum;
-#pragma unroll
-        for (int w = 0; w < FUSED_T / 64; ++w)
-            if (w < wave) run += s_wsum[w];
-        if (c0 < FUSED_LCELLS) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                s_start[c0 + k] = (uint32_t)run;
-                run += (int)v[k];
-            }
-        }
-        if (c0 == FUSED_LCELLS) s_start[FUSED_LCELLS] = (uint32_t)run;  // thread 960: everything before it
-        __syncthreads();
-    }
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-        if (lcell[r] >= 0) {
-            const int pos = (int)s_start[lcell[r]] + lrank[r];
-            s_llo[pos] = l0[r];
-            s_lhi[pos] = l1[r];
-            s_lperm[pos] = (unsigned short)(tid + r * FUSED_T);
-        }
     // candidate range of this thread's right features in the cell-ordered left rows, slots for the keys of the wide ones
-    int la[2], cnt[2], xoff[2];
+    int la[2], cnt[2], xoff[2] = {0, 0};
+    int over = 0;
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         la[r] = 0;
@@ -577,34 +533,14 @@ __global__ __launch_bounds__(FUSED_T) void grid_points_fused_kernel(GridBatch g,
             la[r] = (int)s_start[y * FUSED_LW + x];
             cnt[r] = (int)s_start[y * FUSED_LW + x + a.w.w_lo + 1] - la[r];
         }
+        if (cnt[r] > FUSED_REG) {
+            xoff[r] = atomicAdd(&s_wsum[0], cnt[r]);
+            over |= xoff[r] + cnt[r] > key_cap;
+        }
     }
-    {
-        const int w0 = cnt[0] > FUSED_REG ? cnt[0] : 0, w1 = cnt[1] > FUSED_REG ? cnt[1] : 0;
-        const int mine = w0 + w1;
-        int incl = mine;
-#pragma unroll
-        for (int sh = 1; sh < 64; sh <<= 1) {
-            const int up = __shfl_up(incl, sh);
-            if (lane >= sh) incl += up;
-        }
-        __syncthreads();  // s_wsum reuse; also: the cell-ordered left rows are complete
-        if (lane == 63) s_wsum[wave] = incl;
-        __syncthreads();
-        int wbase = 0, total = 0;
-#pragma unroll
-        for (int w = 0; w < FUSED_T / 64; ++w) {
-            const int v = s_wsum[w];
-            if (w < wave) wbase += v;
-            total += v;
-        }
-        xoff[0] = wbase + incl - mine;
-        xoff[1] = xoff[0] + w0;
-        if (total > key_cap) {  // block-uniform
-            if (tid == 0) g.misfit[blockIdx.x] = 1;
-            return;
-        }
-        if (tid == 0) g.misfit[blockIdx.x] = 0;
-    }
+    over = __syncthreads_or(over || key_cap < 0);
+    if (tid == 0) g.misfit[blockIdx.x] = over != 0;
+    if (over) return;  // block-uniform: grid_points_misfit_kernel takes the frame
     if (prof) tk[1] = (long long)__builtin_readcyclecounter();
     // ---- distances, eligible chains, best per left row
     uint32_t key[2][FUSED_REG];
@@ -627,13 +563,23 @@ __global__ __launch_bounds__(FUSED_T) void grid_points_fused_kernel(GridBatch g,
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 // past the range: a neighbour's row or padding, result masked
+#ifdef STVO_GRID_FUSED_PROFILE
+                uint32_t dd, i1;
+                if (prof & 2) { dd = hamming256(q1[r], q0[r], q0[r], q1[r]) + j; i1 = tid + k4 + j; }          // no LDS reads
+                else if (prof & 4) { dd = (lo_row[k4 + j].x + hi_row[k4 + j].y) & 255u; i1 = perm_row[k4 + j]; }  // no popcounts
+                else { dd = hamming256(lo_row[k4 + j], hi_row[k4 + j], q0[r], q1[r]); i1 = perm_row[k4 + j]; }
+#else
                 const uint32_t dd = hamming256(lo_row[k4 + j], hi_row[k4 + j], q0[r], q1[r]);
                 const uint32_t i1 = perm_row[k4 + j];
+#endif
                 key[r][k4 + j] = k4 + j < c16 ? ((i1 << 9) | dd) : FUSED_NOKEY;
             }
         }
         uint32_t owner = 0xFFFFu;
         if (a.mutual) {  // :145-150 — ascending left row, strict running minimum
+#ifdef STVO_GRID_FUSED_PROFILE
+            if (!(prof & 8))
+#endif
             sort16(key[r]);
             uint32_t thr = 512u;
 #pragma unroll
@@ -648,31 +594,50 @@ __global__ __launch_bounds__(FUSED_T) void grid_points_fused_kernel(GridBatch g,
         } else {
             elig[r] = (1u << c16) - 1u;
         }
+#ifdef STVO_GRID_FUSED_PROFILE
+        if (!(prof & 16))
+#endif
 #pragma unroll
         for (int k = 0; k < FUSED_REG; ++k)
             if (elig[r] & (1u << k)) atomicMin(&s_best[key[r][k] >> 9], ((key[r][k] & 511u) << 16) | (uint32_t)p);
-        if (wide) {  // keys in LDS; the chain by repeated searches for the lowest left row below the threshold
-            uint32_t* kk = s_keys + xoff[r];
-            for (int k = 0; k < cnt[r]; ++k) {
-                const int pos = la[r] + k;
-                kk[k] = ((uint32_t)s_lperm[pos] << 9) | hamming256(s_llo[pos], s_lhi[pos], q0[r], q1[r]);
+        if (!wide) s_owner[p] = (unsigned short)owner;
+        // right features with more than 16 candidates (rare): the whole wave takes them one at a time — keys to LDS (lane =
+        // candidate), then every lane decides its candidates against all the others: eligible unless an earlier left row is at
+        // least as close (:145-150), matches_21 = the eligible one no later row beats
+        for (unsigned long long wm = __ballot(wide); wm; wm &= wm - 1ull) {
+            const int L = __builtin_ctzll(wm);
+            const int w_la = __builtin_amdgcn_readlane(la[r], L), w_cnt = __builtin_amdgcn_readlane(cnt[r], L);
+            const int w_xoff = __builtin_amdgcn_readlane(xoff[r], L);
+            const uint32_t w_p = (uint32_t)((tid & ~63) + L + r * FUSED_T);
+            uint4 wq0, wq1;
+            wq0.x = __builtin_amdgcn_readlane(q0[r].x, L); wq0.y = __builtin_amdgcn_readlane(q0[r].y, L);
+            wq0.z = __builtin_amdgcn_readlane(q0[r].z, L); wq0.w = __builtin_amdgcn_readlane(q0[r].w, L);
+            wq1.x = __builtin_amdgcn_readlane(q1[r].x, L); wq1.y = __builtin_amdgcn_readlane(q1[r].y, L);
+            wq1.z = __builtin_amdgcn_readlane(q1[r].z, L); wq1.w = __builtin_amdgcn_readlane(q1[r].w, L);
+            uint32_t* kk = s_keys + w_xoff;
+            for (int k = tid & 63; k < w_cnt; k += 64) {
+                const int pos = w_la + k;
+                kk[k] = ((uint32_t)s_lperm[pos] << 9) | hamming256(s_llo[pos], s_lhi[pos], wq0, wq1);
             }
-            uint32_t thr = 512u;
-            for (;;) {
-                uint32_t bestk = FUSED_NOKEY;
-                for (int k = 0; k < cnt[r]; ++k) {
-                    const uint32_t v = kk[k];
-                    if (!(v & FUSED_FLAG) && (!a.mutual || (v & 511u) < thr)) bestk = min(bestk, v);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int k = tid & 63; k < w_cnt; k += 64) {
+                const uint32_t mine = kk[k] & ~FUSED_FLAG, i1 = mine >> 9, dd = mine & 511u;
+                bool dominated = false, later_better = false;
+                for (int j = 0; j < w_cnt; ++j) {
+                    const uint32_t v = kk[j], vi = (v >> 9) & 2047u, vd = v & 511u;
+                    dominated |= vi < i1 && vd <= dd;
+                    later_better |= vi > i1 && vd < dd;
                 }
-                if (bestk == FUSED_NOKEY) break;
-                thr = bestk & 511u;
-                owner = bestk >> 9;
-                atomicMin(&s_best[owner], (thr << 16) | (uint32_t)p);
-                for (int k = 0; k < cnt[r]; ++k)  // left rows are unique per right feature
-                    if (kk[k] == bestk) kk[k] = bestk | FUSED_FLAG;
+                if (!a.mutual || !dominated) {
+                    kk[k] = mine | FUSED_FLAG;
+                    atomicMin(&s_best[i1], (dd << 16) | w_p);
+                    if (a.mutual && !later_better) s_owner[w_p] = (unsigned short)i1;
+                }
             }
         }
-        if (p < FUSED_ROWS) s_owner[p] = (unsigned short)owner;
+        if (wide && !a.mutual) s_owner[p] = 0xFFFFu;
     }
     __syncthreads();
     if (prof) tk[2] = (long long)__builtin_readcyclecounter();
@@ -680,10 +645,10 @@ __global__ __launch_bounds__(FUSED_T) void grid_points_fused_kernel(GridBatch g,
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const uint32_t p = (uint32_t)(tid + r * FUSED_T);
-        auto judge = [&](uint32_t k) {
+        auto judge = [&](uint32_t k, uint32_t pos) {
             const uint32_t i1 = (k >> 9) & 2047u, dd = k & 511u;
             const uint32_t bk = s_best[i1];
-            if (bk != ((dd << 16) | p)) {
+            if (bk != ((dd << 16) | pos)) {
                 const double best_d = (double)(int)(bk >> 16), d2 = (double)(int)dd;
                 if (!(best_d < d2 * a.ratio)) s_blocked[i1] = 1;
             }
@@ -693,13 +658,15 @@ __global__ __launch_bounds__(FUSED_T) void grid_points_fused_kernel(GridBatch g,
             if (!__any((elig[r] >> k4) & 0xFu)) continue;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (elig[r] & (1u << (k4 + j))) judge(key[r][k4 + j]);
+                if (elig[r] & (1u << (k4 + j))) judge(key[r][k4 + j], p);
         }
-        if (cnt[r] > FUSED_REG) {
-            const uint32_t* kk = s_keys + xoff[r];
-            for (int k = 0; k < cnt[r]; ++k) {
-                const uint32_t v = kk[k];
-                if (v & FUSED_FLAG) judge(v & ~FUSED_FLAG);
+        for (unsigned long long wm = __ballot(cnt[r] > FUSED_REG); wm; wm &= wm - 1ull) {  // the wide ones, lane = candidate
+            const int L = __builtin_ctzll(wm);
+            const int w_cnt = __builtin_amdgcn_readlane(cnt[r], L), w_xoff = __builtin_amdgcn_readlane(xoff[r], L);
+            const uint32_t w_p = (uint32_t)((tid & ~63) + L + r * FUSED_T);
+            for (int k = tid & 63; k < w_cnt; k += 64) {
+                const uint32_t v = s_keys[w_xoff + k];
+                if (v & FUSED_FLAG) judge(v & ~FUSED_FLAG, w_p);
             }
         }
     }
@@ -752,7 +719,7 @@ void launch_grid_batch(hipStream_t s, const GridBatch& g, bool lines, hipEvent_t
         const bool range = g.range_points && g.range1 != nullptr;
         // STVO_GRID_FUSED=0: the scan formulation for every batch; STVO_GRID_FUSED_CAP: capacity for the keys of right features with more than 16 candidates (tests force the misfit path with -1)
         const char* ef = std::getenv("STVO_GRID_FUSED");
-        const bool fused = range && g.misfit && g.cell2 && g.stride1 <= FUSED_ROWS && g.stride2 <= FUSED_ROWS && g.w.w_lo >= 0 &&
+        const bool fused = range && g.misfit && g.cell2 && g.lperm && g.lstart && g.stride1 <= FUSED_ROWS && g.stride2 <= FUSED_ROWS && g.w.w_lo >= 0 &&
                            g.w.w_lo <= FUSED_LW - STVO_GRID_COLS && g.w.w_hi == 0 && g.w.h_lo == 0 && g.w.h_hi == 0 && !(ef && ef[0] == '0');
         if (fused) {
             static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(grid_points_fused_kernel),

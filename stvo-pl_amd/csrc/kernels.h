@@ -102,6 +102,7 @@ int launch_pose(hipStream_t s, const PoseArgs& a);   // dispatches to pose_kerne
 int launch_pose2(hipStream_t s, const PoseArgs& a);  // pose_kernel2.hip: every wave a worker, 128 VGPRs, records in LDS
 
 // ---- K3: grid-windowed stereo matchers, batched over frame pairs (blockIdx.y) ----------------------
+constexpr int GRID_LW = STVO_GRID_COLS + 16, GRID_LCELLS = STVO_GRID_ROWS * GRID_LW, GRID_LSTART_STRIDE = GRID_LCELLS + 4;
 struct GridBatch {
     int B, stride1, stride2;   // frame pairs; rows per frame of the left / right feature arrays
     int xy_width;              // 2 (points: cx, cy) or 4 (lines: sx, sy, ex, ey)
@@ -133,6 +134,10 @@ struct GridBatch {
     int range_points;
     const int32_t* range1;     // [B][stride1][2] (lo, hi) of every left feature when range_points != 0
     const int32_t* cell2;      // [B][stride2] or nullptr: grid cell (y * 64 + x) of the right feature at each scan position, -1 outside the grid
+    // left key-points counting-sorted by cell for the one-workgroup-per-frame point matcher (both or none), on a grid GRID_LW
+    // columns wide (a left key-point up to w_lo columns right of the grid still has candidates)
+    const uint32_t* lstart;    // [B][GRID_LSTART_STRIDE] exclusive cell starts, [GRID_LCELLS] = number of placed left key-points
+    const int32_t* lperm;      // [B][stride1] position -> left feature
     uint32_t* elig;            // [B][GRID_ELIG][stride2]  (i1 << 16 | d), slot-major
     int32_t* elig_cnt;         // [B][stride2]
     int32_t* ovf;              // [B] set when some right feature of the frame met more than GRID_ELIG eligible pairs

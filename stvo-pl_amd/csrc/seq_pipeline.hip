@@ -93,6 +93,8 @@ struct SeqDev {
     // scratch of the point grid matcher that point_cells_kernel initialises (no candidate bit-matrix kernel runs for points)
     unsigned long long* top2_p;  // [B][K]
     int32_t* govf_p;             // [B]
+    uint32_t* plstart;           // [B][GRID_LSTART_STRIDE] | left key-points counting-sorted by cell for the one-workgroup-per-frame
+    int32_t* plperm;             // [B][K]                  | matcher (GridBatch); nullptr when capacity or window exceed what it handles
     int32_t* pcell;              // [B][K] grid cell (y * 64 + x) of the right key-point at each CSR position, -1: outside the grid
     int32_t* prange;             // [B][K][2] candidate range of every left key-point in CSR positions (GridStructure::get, one-row window)
 };
@@ -101,10 +103,10 @@ __device__ __forceinline__ bool in_grid(int x, int y) {
     return x >= 0 && x < STVO_GRID_COLS && y >= 0 && y < STVO_GRID_ROWS;
 }
 
-// exclusive scan of hist[0..3072) in LDS by 256 threads (12 cells each); writes start[0..3072]
-__device__ __forceinline__ void scan_cells(int* hist, int* s_wave, int32_t* start_out) {
+// exclusive scan of hist[0..256 * PER) in LDS by 256 threads (PER cells each); writes start[0..256 * PER]
+template <int PER>
+__device__ __forceinline__ void scan_cells_n(int* hist, int* s_wave, int32_t* start_out) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    constexpr int PER = STVO_GRID_CELLS / 256;  // 12
     int local[PER];
     int sum = 0;
 #pragma unroll
@@ -131,17 +133,23 @@ __device__ __forceinline__ void scan_cells(int* hist, int* s_wave, int32_t* star
         start_out[tid * PER + k] = run;
         run += local[k];
     }
-    if (tid == 255) start_out[STVO_GRID_CELLS] = run;
+    if (tid == 255) start_out[256 * PER] = run;
     __syncthreads();
+}
+__device__ __forceinline__ void scan_cells(int* hist, int* s_wave, int32_t* start_out) {
+    scan_cells_n<STVO_GRID_CELLS / 256>(hist, s_wave, start_out);
 }
 
 // ---- 1: points — cells + CSR of the right key-points -----------------------------------------------
 __global__ __launch_bounds__(256) void point_cells_kernel(SeqDev s) {
     __shared__ int hist[STVO_GRID_CELLS];
     __shared__ int fill[STVO_GRID_CELLS];
+    __shared__ int lhist[GRID_LCELLS];
     __shared__ int s_wave[4];
     __shared__ int s_extra;
+    static_assert(GRID_LCELLS % 256 == 0, "scan_cells_n");
     const int b = blockIdx.x, tid = threadIdx.x;
+    const bool lsort = s.plperm != nullptr;  // host: K <= 2048 (8 key-points per thread), window within GRID_LW
     const int nl = s.n_kp_l[b], nr = s.n_kp_r[b];
     const size_t off = (size_t)b * s.K;
     const double inv_w = s.inv_wh[2 * b], inv_h = s.inv_wh[2 * b + 1];
@@ -153,6 +161,7 @@ __global__ __launch_bounds__(256) void point_cells_kernel(SeqDev s) {
         hist[c] = 0;
         fill[c] = 0;
     }
+    for (int c = tid; c < GRID_LCELLS; c += 256) lhist[c] = 0;
     for (int i = tid; i < s.K; i += 256) s.top2_p[off + i] = 0x00000000FFFFFFFFull;  // grid matcher: no eligible candidate yet
     if (tid == 0) {
         s.govf_p[b] = 0;
@@ -164,8 +173,33 @@ __global__ __launch_bounds__(256) void point_cells_kernel(SeqDev s) {
         const int y = (int)((double)s.kp_r[(off + i) * 2 + 1] * inv_h);
         if (in_grid(x, y)) atomicAdd(&hist[y * STVO_GRID_COLS + x], 1);
     }
+    // counting sort of the LEFT key-points by cell, for the matcher that walks the candidates of a right key-point: the window
+    // is clamped, not the cell (src/gridStructure.cpp:67-71), so columns up to 63 + ws still see the last grid columns
+    int lcel[8], lrnk[8];
+    if (lsort) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = tid + 256 * k;
+            lcel[k] = -1;
+            lrnk[k] = 0;
+            if (i < nl) {
+                const int x = (int)((double)s.kp_l[(off + i) * 2 + 0] * inv_w);
+                const int y = (int)((double)s.kp_l[(off + i) * 2 + 1] * inv_h);
+                if (y >= 0 && y < STVO_GRID_ROWS && x >= 0 && x <= STVO_GRID_COLS - 1 + s.mp.matching_s_ws) {
+                    lcel[k] = y * GRID_LW + x;
+                    lrnk[k] = atomicAdd(&lhist[lcel[k]], 1);
+                }
+            }
+        }
+    }
     __syncthreads();
     scan_cells(hist, s_wave, s.pstart + (size_t)b * (STVO_GRID_CELLS + 1));
+    if (lsort) {
+        scan_cells_n<GRID_LCELLS / 256>(lhist, s_wave, reinterpret_cast<int32_t*>(s.plstart) + (size_t)b * GRID_LSTART_STRIDE);
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (lcel[k] >= 0) s.plperm[off + lhist[lcel[k]] + lrnk[k]] = tid + 256 * k;
+    }
     const int n_in = s.pstart[(size_t)b * (STVO_GRID_CELLS + 1) + STVO_GRID_CELLS];
     // GridStructure::get with the stereo window (matching_s_ws cells to the left, same row; src/gridStructure.cpp:65-76,
     // src/stereoFrame.cpp:141-143): cells x - ws .. x of row y are contiguous in the CSR => candidates = positions [lo, hi)
@@ -569,6 +603,8 @@ int stvo_seq_create_multi(stvo_ctx* ctx, int B, int max_keypoints, int max_keyli
     const size_t o_cams = c.take(nb * sizeof(stvo_cam)), o_invwh = c.take(nb * 2 * 8);
     const size_t o_pxy = c.take(nb * K * 2 * 4), o_pstart = c.take(nb * (STVO_GRID_CELLS + 1) * 4), o_pitems = c.take(nb * K * 4),
                  o_prank = c.take(nb * K * 4), o_pperm = c.take(nb * K * 4), o_prange = c.take(nb * K * 2 * 4), o_pcell = c.take(nb * K * 4);
+    const bool lsort = K <= 2048 && mp->matching_s_ws >= 0 && mp->matching_s_ws <= stvo::GRID_LW - STVO_GRID_COLS;
+    const size_t o_plstart = c.take(lsort ? nb * stvo::GRID_LSTART_STRIDE * 4 : 0), o_plperm = c.take(lsort ? nb * K * 4 : 0);
     const size_t o_lxy = c.take(nb * M * 4 * 4), o_lstart = c.take(nb * (STVO_GRID_CELLS + 1) * 4),
                  o_litems = c.take(nb * M * stvo::LENT * 4), o_lrank = c.take(nb * M * 4), o_lperm = c.take(nb * M * 4),
                  o_ldir = c.take(nb * M * 2 * 8);
@@ -667,6 +703,9 @@ int stvo_seq_create_multi(stvo_ctx* ctx, int B, int max_keypoints, int max_keyli
     s->inl_span = o_res - o_inlp;    // inlp, inll likewise
     d.m12s_p = s->m12s_p; d.m12s_l = s->m12s_l;
     d.top2_p = s->top2; d.govf_p = s->govf; d.prange = (int32_t*)(D + o_prange); d.pcell = (int32_t*)(D + o_pcell);
+    if (lsort) {
+        d.plstart = (uint32_t*)(D + o_plstart); d.plperm = (int32_t*)(D + o_plperm);
+    }
     for (int t = 0; t < 2; ++t) {
         stvo_seq::Set& q = s->set[t];
         q.pl = (double*)(D + o_set[t][0]); q.P = (double*)(D + o_set[t][1]); q.s2 = (double*)(D + o_set[t][2]);
@@ -892,6 +931,7 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl) {
         g.range_points = 1;  // device CSR: right key-points are numbered in cell order, one grid row per window
         g.range1 = d.prange;
         g.cell2 = d.pcell;
+        g.lstart = d.plstart; g.lperm = d.plperm;
         s->last_point_grid = g;
         stvo::launch_grid_batch(st, g, false, tev ? tev + 2 : nullptr);
         hipLaunchKernelGGL(stvo::point_tail_kernel, dim3(B), dim3(stvo::TAIL_BLOCK), 0, st, d);
