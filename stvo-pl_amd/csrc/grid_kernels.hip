@@ -413,11 +413,10 @@ __global__ __launch_bounds__(256) void grid_finalize_kernel(GridBatch g) {
 // its whole wave, lane = candidate, keys in LDS.  Frames with more such keys than the LDS holds are flagged and run the scan
 // formulation above in grid_points_misfit_kernel, launched right behind.
 constexpr int FUSED_T = 1024, FUSED_ROWS = 2048, FUSED_REG = 16;
-constexpr int FUSED_LW = GRID_LW, FUSED_LCELLS = GRID_LCELLS;  // left key-points up to 16 columns right of the grid still have candidates
+constexpr int FUSED_LW = GRID_LW;  // left key-points up to 16 columns right of the grid still have candidates
 constexpr int FUSED_PADDED = FUSED_ROWS + FUSED_REG;          // the unrolled walks read up to 15 rows past a range
 constexpr int FUSED_KEY_CAP = 8192;                           // keys of the right features with more than 16 candidates, whole frame
-constexpr size_t FUSED_LDS = (size_t)FUSED_PADDED * (16 + 16 + 2) + (size_t)(FUSED_LCELLS + 4) * 4 + (size_t)FUSED_ROWS * (4 + 2 + 1) +
-                             (size_t)FUSED_KEY_CAP * 4;
+constexpr size_t FUSED_LDS = (size_t)FUSED_PADDED * (16 + 16 + 2) + (size_t)FUSED_ROWS * (4 + 2 + 1) + (size_t)FUSED_KEY_CAP * 4;
 
 // the scan formulation for the frames the fused kernel flagged (launched right behind it; a workgroup whose frame fitted returns
 // at once): 16 waves over the blocks of 64 scan positions
@@ -438,6 +437,13 @@ __global__ __launch_bounds__(FUSED_T) void grid_points_misfit_kernel(GridBatch g
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     for (int i1 = tid; i1 < stride1; i1 += FUSED_T) grid_finalize_body(a, i1, stride1);
+}
+
+// native 16-byte vector: an LDS load of it is one ds_read_b128 (HIP's uint4 is a struct, loaded member by member)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 lds_row(const uint4* p) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(p);
+    return make_uint4(v.x, v.y, v.z, v.w);
 }
 
 __device__ __forceinline__ uint32_t hamming256(const uint4& t0, const uint4& t1, const uint4& q0, const uint4& q1) {
@@ -474,226 +480,246 @@ __device__ __forceinline__ void sort16(uint32_t (&k)[FUSED_REG]) {
 
 constexpr uint32_t FUSED_NOKEY = 0xFFFFFFFFu, FUSED_FLAG = 1u << 30;  // key = left row << 9 | distance (0..256)
 
-__global__ __launch_bounds__(FUSED_T) void grid_points_fused_kernel(GridBatch g, const int key_cap, const int prof) {
+// what a workgroup fetches ahead for its next frame while it works on the current one (all 256 workgroups of a launch run
+// in step, so without this the HBM sits idle during the compute phases and every frame start waits for a burst)
+struct FusedNext {
+    int i1[2], i2[2], rc[2];   // level 1: left row at this thread's two cell-order positions, right feature and its cell at its two scan positions
+    uint4 l0[2], l1[2];        // level 2: the left descriptor rows,
+    uint4 q0[2], q1[2];        //          the right descriptor rows,
+    int la[2], lb[2];          //          the candidate range [la, lb) of the right features in cell-order positions
+};
+
+__device__ __forceinline__ void fused_fetch1(const GridBatch& g, const int f, FusedNext& n) {
+    const int tid = threadIdx.x;
+    const int32_t* __restrict__ cell2 = g.cell2 + (size_t)f * g.stride2;
+    const int32_t* __restrict__ lperm = g.lperm + (size_t)f * g.stride1;
+    const int32_t* __restrict__ perm = g.perm + (size_t)f * g.stride2;
+    const int n_placed = (int)g.lstart[(size_t)f * GRID_LSTART_STRIDE + GRID_LCELLS], n2 = g.n2[f];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int pos = tid + r * FUSED_T;
+        n.i1[r] = pos < n_placed ? lperm[pos] : -1;
+        n.i2[r] = pos < n2 ? perm[pos] : -1;
+        n.rc[r] = pos < n2 ? cell2[pos] : -1;
+    }
+}
+
+__device__ __forceinline__ void fused_fetch2(const GridBatch& g, const int f, FusedNext& n) {
+    const uint4* __restrict__ D1 = reinterpret_cast<const uint4*>(g.d1) + (size_t)f * g.stride1 * 2;
+    const uint4* __restrict__ D2 = reinterpret_cast<const uint4*>(g.d2) + (size_t)f * g.stride2 * 2;
+    const uint32_t* __restrict__ lstart = g.lstart + (size_t)f * GRID_LSTART_STRIDE;
+    const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        n.l0[r] = n.l1[r] = n.q0[r] = n.q1[r] = z4;
+        n.la[r] = n.lb[r] = 0;
+        if (n.i1[r] >= 0) {
+            n.l0[r] = D1[2 * n.i1[r]];
+            n.l1[r] = D1[2 * n.i1[r] + 1];
+        }
+        if (n.i2[r] >= 0) {
+            n.q0[r] = D2[2 * n.i2[r]];
+            n.q1[r] = D2[2 * n.i2[r] + 1];
+        }
+        if (n.rc[r] >= 0) {  // GridStructure::get seen from the right feature: left cells x .. x + w_lo of its row (the window is clamped, :67-71)
+            const int y = n.rc[r] >> 6, x = n.rc[r] & (STVO_GRID_COLS - 1);
+            n.la[r] = (int)lstart[y * FUSED_LW + x];
+            n.lb[r] = (int)lstart[y * FUSED_LW + x + g.w.w_lo + 1];
+        }
+    }
+}
+
+// Persistent: workgroup w takes frames w, w + gridDim.x, ...
+__global__ __launch_bounds__(FUSED_T) void grid_points_fused_kernel(GridBatch g, const int key_cap) {
     extern __shared__ uint4 s_fused[];
-    __shared__ int s_wsum[1];
+    __shared__ int s_ctl[2];  // [0] bump allocator of the key slots, [1] the frame misfits
     uint4* s_llo = s_fused;                                                              // [pos] first / second half of the left rows,
     uint4* s_lhi = s_llo + FUSED_PADDED;                                                 //       cell order
-    uint32_t* s_start = reinterpret_cast<uint32_t*>(s_lhi + FUSED_PADDED);               // [cell] histogram, then exclusive start
-    uint32_t* s_best = s_start + FUSED_LCELLS + 4;                                       // [left row] min (d << 16 | scan position)
+    uint32_t* s_best = reinterpret_cast<uint32_t*>(s_lhi + FUSED_PADDED);                // [left row] min (d << 16 | scan position)
     uint32_t* s_keys = s_best + FUSED_ROWS;                                              // keys of the wide right features
     unsigned short* s_lperm = reinterpret_cast<unsigned short*>(s_keys + FUSED_KEY_CAP); // [pos] -> left row
     unsigned short* s_owner = s_lperm + FUSED_PADDED;                                    // [scan position] matches_21 (:148)
     unsigned char* s_blocked = reinterpret_cast<unsigned char*>(s_owner + FUSED_ROWS);   // [left row] ratio test failed
-    const GridArgs a = frame_view(g, blockIdx.x);
     const int tid = threadIdx.x;
-    long long tk[6] = {0, 0, 0, 0, 0, 0};
-    if (prof) tk[0] = (long long)__builtin_readcyclecounter();
-    // ---- the left rows into LDS in cell order (point_cells_kernel sorted the indices); this thread's two right rows into registers
-    const int32_t* __restrict__ cell2 = g.cell2 + (size_t)blockIdx.x * g.stride2;
-    const uint32_t* __restrict__ lstart = g.lstart + (size_t)blockIdx.x * GRID_LSTART_STRIDE;
-    const int32_t* __restrict__ lperm = g.lperm + (size_t)blockIdx.x * g.stride1;
-    const uint4* __restrict__ D1 = reinterpret_cast<const uint4*>(a.d1);
-    const uint4* __restrict__ D2 = reinterpret_cast<const uint4*>(a.d2);
-    const int n_placed = (int)lstart[FUSED_LCELLS];
-    const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
-    uint4 q0[2] = {z4, z4}, q1[2] = {z4, z4};
-    int rc[2];
+    FusedNext nx;
+    int f = blockIdx.x;
+    if (f >= g.B) return;
+    fused_fetch1(g, f, nx);
+    fused_fetch2(g, f, nx);
+    for (; f < g.B; f += gridDim.x) {
+        const GridArgs a = frame_view(g, f);
+        // ---- commit the fetched frame: left rows into LDS in cell order, this thread's two right rows stay in registers
+        uint4 q0[2], q1[2];
+        int la[2], cnt[2], xoff[2] = {0, 0};
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int pos = tid + r * FUSED_T;
-        if (pos < n_placed) {
-            const int i1 = lperm[pos];
-            s_llo[pos] = D1[2 * i1];
-            s_lhi[pos] = D1[2 * i1 + 1];
-            s_lperm[pos] = (unsigned short)i1;
-        }
-        s_best[pos] = 0xFFFFFFFFu;
-        s_blocked[pos] = 0;
-        rc[r] = -1;
-        if (pos < a.n2) {
-            const int i2 = a.perm[pos];
-            rc[r] = cell2[pos];
-            q0[r] = D2[2 * i2];
-            q1[r] = D2[2 * i2 + 1];
-        }
-    }
-    for (int c = tid; c <= FUSED_LCELLS; c += FUSED_T) s_start[c] = lstart[c];
-    if (tid == 0) s_wsum[0] = 0;  // bump allocator of the key slots
-    __syncthreads();
-    // candidate range of this thread's right features in the cell-ordered left rows, slots for the keys of the wide ones
-    int la[2], cnt[2], xoff[2] = {0, 0};
-    int over = 0;
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        la[r] = 0;
-        cnt[r] = 0;
-        if (rc[r] >= 0) {
-            const int y = rc[r] >> 6, x = rc[r] & (STVO_GRID_COLS - 1);
-            la[r] = (int)s_start[y * FUSED_LW + x];
-            cnt[r] = (int)s_start[y * FUSED_LW + x + a.w.w_lo + 1] - la[r];
-        }
-        if (cnt[r] > FUSED_REG) {
-            xoff[r] = atomicAdd(&s_wsum[0], cnt[r]);
-            over |= xoff[r] + cnt[r] > key_cap;
-        }
-    }
-    over = __syncthreads_or(over || key_cap < 0);
-    if (tid == 0) g.misfit[blockIdx.x] = over != 0;
-    if (over) return;  // block-uniform: grid_points_misfit_kernel takes the frame
-    if (prof) tk[1] = (long long)__builtin_readcyclecounter();
-    // ---- distances, eligible chains, best per left row
-    uint32_t key[2][FUSED_REG];
-    uint32_t elig[2] = {0u, 0u};
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int p = tid + r * FUSED_T;
-        const bool wide = cnt[r] > FUSED_REG;
-        const int c16 = wide ? 0 : cnt[r];
-        const uint4* lo_row = s_llo + la[r];  // constant offsets from one base: LDS immediates, no address registers
-        const uint4* hi_row = s_lhi + la[r];
-        const unsigned short* perm_row = s_lperm + la[r];
-#pragma unroll
-        for (int k4 = 0; k4 < FUSED_REG; k4 += 4) {
-            if (!__any(c16 > k4)) {  // wave-uniform
-#pragma unroll
-                for (int j = 0; j < 4; ++j) key[r][k4 + j] = FUSED_NOKEY;
-                continue;
+        for (int r = 0; r < 2; ++r) {
+            const int pos = tid + r * FUSED_T;
+            if (nx.i1[r] >= 0) {
+                s_llo[pos] = nx.l0[r];
+                s_lhi[pos] = nx.l1[r];
+                s_lperm[pos] = (unsigned short)nx.i1[r];
             }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                // past the range: a neighbour's row or padding, result masked
-#ifdef STVO_GRID_FUSED_PROFILE
-                uint32_t dd, i1;
-                if (prof & 2) { dd = hamming256(q1[r], q0[r], q0[r], q1[r]) + j; i1 = tid + k4 + j; }          // no LDS reads
-                else if (prof & 4) { dd = (lo_row[k4 + j].x + hi_row[k4 + j].y) & 255u; i1 = perm_row[k4 + j]; }  // no popcounts
-                else { dd = hamming256(lo_row[k4 + j], hi_row[k4 + j], q0[r], q1[r]); i1 = perm_row[k4 + j]; }
-#else
-                const uint32_t dd = hamming256(lo_row[k4 + j], hi_row[k4 + j], q0[r], q1[r]);
-                const uint32_t i1 = perm_row[k4 + j];
-#endif
-                key[r][k4 + j] = k4 + j < c16 ? ((i1 << 9) | dd) : FUSED_NOKEY;
-            }
+            s_best[pos] = 0xFFFFFFFFu;
+            s_blocked[pos] = 0;
+            q0[r] = nx.q0[r];
+            q1[r] = nx.q1[r];
+            la[r] = nx.la[r];
+            cnt[r] = nx.lb[r] - nx.la[r];
         }
-        uint32_t owner = 0xFFFFu;
-        if (a.mutual) {  // :145-150 — ascending left row, strict running minimum
-#ifdef STVO_GRID_FUSED_PROFILE
-            if (!(prof & 8))
-#endif
-            sort16(key[r]);
-            uint32_t thr = 512u;
+        if (tid == 0) {
+            s_ctl[0] = 0;
+            s_ctl[1] = key_cap < 0;
+        }
+        const int fn = f + gridDim.x;
+        const bool more = fn < g.B;  // block-uniform
+        if (more) fused_fetch1(g, fn, nx);
+        __syncthreads();
+        // ---- distances, eligible chains, best per left row
+        uint32_t key[2][FUSED_REG];
+        uint32_t elig[2] = {0u, 0u};
 #pragma unroll
-            for (int k = 0; k < FUSED_REG; ++k) {
-                const uint32_t dd = key[r][k] & 511u;
-                if (key[r][k] != FUSED_NOKEY && dd < thr) {
-                    thr = dd;
-                    owner = key[r][k] >> 9;
-                    elig[r] |= 1u << k;
+        for (int r = 0; r < 2; ++r) {
+            const int p = tid + r * FUSED_T;
+            bool wide = cnt[r] > FUSED_REG;
+            if (wide) {  // slots for its keys; a frame with more of them than the LDS holds is left to the scan formulation
+                xoff[r] = atomicAdd(&s_ctl[0], cnt[r]);
+                if (xoff[r] + cnt[r] > key_cap) {
+                    s_ctl[1] = 1;
+                    wide = false;
+                    cnt[r] = 0;
                 }
             }
-        } else {
-            elig[r] = (1u << c16) - 1u;
-        }
-#ifdef STVO_GRID_FUSED_PROFILE
-        if (!(prof & 16))
-#endif
+            const int c16 = wide ? 0 : cnt[r];
+            const uint4* lo_row = s_llo + la[r];  // constant offsets from one base: LDS immediates, no address registers
+            const uint4* hi_row = s_lhi + la[r];
+            const unsigned short* perm_row = s_lperm + la[r];
 #pragma unroll
-        for (int k = 0; k < FUSED_REG; ++k)
-            if (elig[r] & (1u << k)) atomicMin(&s_best[key[r][k] >> 9], ((key[r][k] & 511u) << 16) | (uint32_t)p);
-        if (!wide) s_owner[p] = (unsigned short)owner;
-        // right features with more than 16 candidates (rare): the whole wave takes them one at a time — keys to LDS (lane =
-        // candidate), then every lane decides its candidates against all the others: eligible unless an earlier left row is at
-        // least as close (:145-150), matches_21 = the eligible one no later row beats
-        for (unsigned long long wm = __ballot(wide); wm; wm &= wm - 1ull) {
-            const int L = __builtin_ctzll(wm);
-            const int w_la = __builtin_amdgcn_readlane(la[r], L), w_cnt = __builtin_amdgcn_readlane(cnt[r], L);
-            const int w_xoff = __builtin_amdgcn_readlane(xoff[r], L);
-            const uint32_t w_p = (uint32_t)((tid & ~63) + L + r * FUSED_T);
-            uint4 wq0, wq1;
-            wq0.x = __builtin_amdgcn_readlane(q0[r].x, L); wq0.y = __builtin_amdgcn_readlane(q0[r].y, L);
-            wq0.z = __builtin_amdgcn_readlane(q0[r].z, L); wq0.w = __builtin_amdgcn_readlane(q0[r].w, L);
-            wq1.x = __builtin_amdgcn_readlane(q1[r].x, L); wq1.y = __builtin_amdgcn_readlane(q1[r].y, L);
-            wq1.z = __builtin_amdgcn_readlane(q1[r].z, L); wq1.w = __builtin_amdgcn_readlane(q1[r].w, L);
-            uint32_t* kk = s_keys + w_xoff;
-            for (int k = tid & 63; k < w_cnt; k += 64) {
-                const int pos = w_la + k;
-                kk[k] = ((uint32_t)s_lperm[pos] << 9) | hamming256(s_llo[pos], s_lhi[pos], wq0, wq1);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            for (int k = tid & 63; k < w_cnt; k += 64) {
-                const uint32_t mine = kk[k] & ~FUSED_FLAG, i1 = mine >> 9, dd = mine & 511u;
-                bool dominated = false, later_better = false;
-                for (int j = 0; j < w_cnt; ++j) {
-                    const uint32_t v = kk[j], vi = (v >> 9) & 2047u, vd = v & 511u;
-                    dominated |= vi < i1 && vd <= dd;
-                    later_better |= vi > i1 && vd < dd;
+            for (int k4 = 0; k4 < FUSED_REG; k4 += 4) {
+                if (!__any(c16 > k4)) {  // wave-uniform
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) key[r][k4 + j] = FUSED_NOKEY;
+                    continue;
                 }
-                if (!a.mutual || !dominated) {
-                    kk[k] = mine | FUSED_FLAG;
-                    atomicMin(&s_best[i1], (dd << 16) | w_p);
-                    if (a.mutual && !later_better) s_owner[w_p] = (unsigned short)i1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    // past the range: a neighbour's row or padding, result masked
+                    const uint32_t dd = hamming256(lds_row(lo_row + k4 + j), lds_row(hi_row + k4 + j), q0[r], q1[r]);
+                    const uint32_t i1 = perm_row[k4 + j];
+                    key[r][k4 + j] = k4 + j < c16 ? ((i1 << 9) | dd) : FUSED_NOKEY;
                 }
             }
-        }
-        if (wide && !a.mutual) s_owner[p] = 0xFFFFu;
-    }
-    __syncthreads();
-    if (prof) tk[2] = (long long)__builtin_readcyclecounter();
-    // ---- :160 for every eligible pair that is not its left row's best: best_d < d * minRatio12P in DOUBLE, else the row is out
+            uint32_t owner = 0xFFFFu;
+            if (a.mutual) {  // :145-150 — ascending left row, strict running minimum
+                sort16(key[r]);
+                uint32_t thr = 512u;
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const uint32_t p = (uint32_t)(tid + r * FUSED_T);
-        auto judge = [&](uint32_t k, uint32_t pos) {
-            const uint32_t i1 = (k >> 9) & 2047u, dd = k & 511u;
-            const uint32_t bk = s_best[i1];
-            if (bk != ((dd << 16) | pos)) {
-                const double best_d = (double)(int)(bk >> 16), d2 = (double)(int)dd;
-                if (!(best_d < d2 * a.ratio)) s_blocked[i1] = 1;
+                for (int k = 0; k < FUSED_REG; ++k) {
+                    const uint32_t dd = key[r][k] & 511u;
+                    if (key[r][k] != FUSED_NOKEY && dd < thr) {
+                        thr = dd;
+                        owner = key[r][k] >> 9;
+                        elig[r] |= 1u << k;
+                    }
+                }
+            } else {
+                elig[r] = (1u << c16) - 1u;
             }
-        };
 #pragma unroll
-        for (int k4 = 0; k4 < FUSED_REG; k4 += 4) {
-            if (!__any((elig[r] >> k4) & 0xFu)) continue;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (elig[r] & (1u << (k4 + j))) judge(key[r][k4 + j], p);
+            for (int k = 0; k < FUSED_REG; ++k)
+                if (elig[r] & (1u << k)) atomicMin(&s_best[key[r][k] >> 9], ((key[r][k] & 511u) << 16) | (uint32_t)p);
+            if (!wide) s_owner[p] = (unsigned short)owner;
+            // right features with more than 16 candidates (rare): the whole wave takes them one at a time — keys to LDS (lane =
+            // candidate), then every lane decides its candidates against all the others: eligible unless an earlier left row is
+            // at least as close (:145-150), matches_21 = the eligible one no later row beats
+            for (unsigned long long wm = __ballot(wide); wm; wm &= wm - 1ull) {
+                const int L = __builtin_ctzll(wm);
+                const int w_la = __builtin_amdgcn_readlane(la[r], L), w_cnt = __builtin_amdgcn_readlane(cnt[r], L);
+                const int w_xoff = __builtin_amdgcn_readlane(xoff[r], L);
+                const uint32_t w_p = (uint32_t)((tid & ~63) + L + r * FUSED_T);
+                uint4 wq0, wq1;
+                wq0.x = __builtin_amdgcn_readlane(q0[r].x, L); wq0.y = __builtin_amdgcn_readlane(q0[r].y, L);
+                wq0.z = __builtin_amdgcn_readlane(q0[r].z, L); wq0.w = __builtin_amdgcn_readlane(q0[r].w, L);
+                wq1.x = __builtin_amdgcn_readlane(q1[r].x, L); wq1.y = __builtin_amdgcn_readlane(q1[r].y, L);
+                wq1.z = __builtin_amdgcn_readlane(q1[r].z, L); wq1.w = __builtin_amdgcn_readlane(q1[r].w, L);
+                uint32_t* kk = s_keys + w_xoff;
+                for (int k = tid & 63; k < w_cnt; k += 64) {
+                    const int pos = w_la + k;
+                    kk[k] = ((uint32_t)s_lperm[pos] << 9) | hamming256(lds_row(s_llo + pos), lds_row(s_lhi + pos), wq0, wq1);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                for (int k = tid & 63; k < w_cnt; k += 64) {
+                    const uint32_t mine = kk[k] & ~FUSED_FLAG, i1 = mine >> 9, dd = mine & 511u;
+                    bool dominated = false, later_better = false;
+                    for (int j = 0; j < w_cnt; ++j) {
+                        const uint32_t v = kk[j], vi = (v >> 9) & 2047u, vd = v & 511u;
+                        dominated |= vi < i1 && vd <= dd;
+                        later_better |= vi > i1 && vd < dd;
+                    }
+                    if (!a.mutual || !dominated) {
+                        kk[k] = mine | FUSED_FLAG;
+                        atomicMin(&s_best[i1], (dd << 16) | w_p);
+                        if (a.mutual && !later_better) s_owner[w_p] = (unsigned short)i1;
+                    }
+                }
+            }
+            if (wide && !a.mutual) s_owner[p] = 0xFFFFu;
+            cnt[r] = wide ? cnt[r] : 0;  // from here on: the number of keys this thread's feature has in LDS
         }
-        for (unsigned long long wm = __ballot(cnt[r] > FUSED_REG); wm; wm &= wm - 1ull) {  // the wide ones, lane = candidate
-            const int L = __builtin_ctzll(wm);
-            const int w_cnt = __builtin_amdgcn_readlane(cnt[r], L), w_xoff = __builtin_amdgcn_readlane(xoff[r], L);
-            const uint32_t w_p = (uint32_t)((tid & ~63) + L + r * FUSED_T);
-            for (int k = tid & 63; k < w_cnt; k += 64) {
-                const uint32_t v = s_keys[w_xoff + k];
-                if (v & FUSED_FLAG) judge(v & ~FUSED_FLAG, w_p);
+        if (more) fused_fetch2(g, fn, nx);  // lands during the two phases below
+        __syncthreads();
+        const bool misfit = s_ctl[1] != 0;  // block-uniform
+        if (tid == 0) g.misfit[f] = misfit;
+        if (!misfit) {
+            // ---- :160 for every eligible pair that is not its left row's best: best_d < d * minRatio12P in DOUBLE, else the row is out
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const uint32_t p = (uint32_t)(tid + r * FUSED_T);
+                auto judge = [&](uint32_t k, uint32_t pos) {
+                    const uint32_t i1 = (k >> 9) & 2047u, dd = k & 511u;
+                    const uint32_t bk = s_best[i1];
+                    if (bk != ((dd << 16) | pos)) {
+                        const double best_d = (double)(int)(bk >> 16), d2 = (double)(int)dd;
+                        if (!(best_d < d2 * a.ratio)) s_blocked[i1] = 1;
+                    }
+                };
+#pragma unroll
+                for (int k4 = 0; k4 < FUSED_REG; k4 += 4) {
+                    if (!__any((elig[r] >> k4) & 0xFu)) continue;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (elig[r] & (1u << (k4 + j))) judge(key[r][k4 + j], p);
+                }
+                for (unsigned long long wm = __ballot(cnt[r] > 0); wm; wm &= wm - 1ull) {  // the wide ones, lane = candidate
+                    const int L = __builtin_ctzll(wm);
+                    const int w_cnt = __builtin_amdgcn_readlane(cnt[r], L), w_xoff = __builtin_amdgcn_readlane(xoff[r], L);
+                    const uint32_t w_p = (uint32_t)((tid & ~63) + L + r * FUSED_T);
+                    for (int k = tid & 63; k < w_cnt; k += 64) {
+                        const uint32_t v = s_keys[w_xoff + k];
+                        if (v & FUSED_FLAG) judge(v & ~FUSED_FLAG, w_p);
+                    }
+                }
             }
         }
-    }
-    __syncthreads();
-    if (prof) tk[3] = (long long)__builtin_readcyclecounter();
-    // ---- one thread per left row: accept unless blocked, mutual check (:166-174)
+        __syncthreads();
+        // ---- one thread per left row: accept unless blocked, mutual check (:166-174)
+        if (!misfit) {
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int i1 = tid + r * FUSED_T;
-        if (i1 >= g.stride1) continue;
-        const uint32_t bk = s_best[i1];
-        int mm = -1;
-        if (i1 < a.n1 && bk != 0xFFFFFFFFu && !s_blocked[i1] && (double)(int)(bk >> 16) < 2147483647.0 * a.ratio) {
-            const int pb = (int)(bk & 0xFFFFu);
-            if (!a.mutual || (int)s_owner[pb] == i1) mm = a.perm[pb];
+            for (int r = 0; r < 2; ++r) {
+                const int i1 = tid + r * FUSED_T;
+                if (i1 >= g.stride1) continue;
+                const uint32_t bk = s_best[i1];
+                int mm = -1;
+                if (i1 < a.n1 && bk != 0xFFFFFFFFu && !s_blocked[i1] && (double)(int)(bk >> 16) < 2147483647.0 * a.ratio) {
+                    const int pb = (int)(bk & 0xFFFFu);
+                    if (!a.mutual || (int)s_owner[pb] == i1) mm = a.perm[pb];
+                }
+                a.m12[i1] = mm;
+            }
         }
-        a.m12[i1] = mm;
+        if (more) __syncthreads();  // the next frame's commit overwrites what the phase above reads
     }
-#ifdef STVO_GRID_FUSED_PROFILE  // developer build: device printf costs the kernel a scratch allocation
-    if (prof && blockIdx.x == 0 && (tid == 0 || tid == 700)) {
-        tk[4] = (long long)__builtin_readcyclecounter();
-        printf("[grid fused] tid %d: sort %lld, distances + chains %lld, judge %lld, finalize %lld cycles\n", tid, tk[1] - tk[0],
-               tk[2] - tk[1], tk[3] - tk[2], tk[4] - tk[3]);
-    }
-#else
-    (void)tk;
-#endif
 }
 
 }  // namespace
@@ -727,11 +753,14 @@ void launch_grid_batch(hipStream_t s, const GridBatch& g, bool lines, hipEvent_t
             const char* ec = std::getenv("STVO_GRID_FUSED_CAP");
             int cap = ec ? std::atoi(ec) : FUSED_KEY_CAP;
             if (cap > FUSED_KEY_CAP) cap = FUSED_KEY_CAP;  // negative: every frame misfits
-            const char* ep = std::getenv("STVO_GRID_FUSED_PROF");
-            const int prof = ep ? std::atoi(ep) : 0;  // developer aid: cycle counts of frame 0 on stdout
+            static const int fused_wgs = [] {  // one persistent workgroup per CU (its LDS and registers fill one)
+                int dev = 0, cus = 0;
+                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+                return cus;
+            }();
             if (attr_ok) {
                 if (scan_events) (void)hipEventRecord(scan_events[0], s);
-                hipLaunchKernelGGL(grid_points_fused_kernel, dim3(g.B), dim3(FUSED_T), FUSED_LDS, s, g, cap, prof);
+                hipLaunchKernelGGL(grid_points_fused_kernel, dim3(g.B < fused_wgs ? g.B : fused_wgs), dim3(FUSED_T), FUSED_LDS, s, g, cap);
                 hipLaunchKernelGGL(grid_points_misfit_kernel, dim3(g.B), dim3(FUSED_T), 0, s, g);
                 if (scan_events) (void)hipEventRecord(scan_events[1], s);
                 return;
