@@ -471,17 +471,19 @@ def main():
                          "algorithmic_bytes_per_launch": pose_bytes, "avg_launch_ms": pose_ms, "timing": timing,
                          "note": "optimizePose for B frame pairs in one launch; algorithmic bytes = 52 B per matched point + 116 B per "
                                  "matched line (read once) + m12 and inlier masks (4 + 4 B per prev stereo feature) + 840 B result"}
-        # grid scan (two passes of the point grid matcher): SURVEY.md §8d match_grid bytes
+        # point grid matcher (one workgroup per frame; STVO_GRID_FUSED=0: the scan formulation): SURVEY.md §8d match_grid bytes
         scan_ms = stage_ms["grid_scan"]
         n_kp_step = float(n_kp.mean(axis=1).sum())   # left + right key-points of one step, all streams
         scan_bytes = 32.0 * n_kp_step + 12.0 * n_kp_step / 2 + 4.0 * (3073.0 * B + n_kp_step / 2)
         scan_gbs = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
-        scan_name = "grid_scan_kernel<false"
-        roofline_grid = {"kernel": "grid_scan_kernel<false, 1> + <false, 2>", "bound": "hbm", "achieved": scan_gbs, "peak": HBM_PEAK_GBS,
+        fused = os.environ.get("STVO_GRID_FUSED", "1") != "0"
+        scan_name = "grid_points_fused_kernel" if fused else "grid_scan_kernel<false"
+        roofline_grid = {"kernel": scan_name if fused else "grid_scan_kernel<false, 1> + <false, 2>", "bound": "hbm", "achieved": scan_gbs, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": scan_gbs / HBM_PEAK_GBS, "traffic": committed_traffic(scan_name), "traffic_source": TRAFFIC_SRC,
                          "algorithmic_bytes_per_launch": scan_bytes, "avg_launch_ms": scan_ms, "timing": timing,
-                         "note": "the two scan passes of matchGrid (points): 32 (N1 + N2) + 8 N1 + 4 (3073 + N2) + 4 N1 bytes per frame; "
-                                 "~35 k distance evaluations per frame — bound by the issue of the sparse row walk, not by HBM or VALU rate"}
+                         "note": "matchGrid (points), all frames in one launch: 32 (N1 + N2) + 8 N1 + 4 (3073 + N2) + 4 N1 bytes per frame; "
+                                 "~16 k candidate pairs per frame — bound by LDS gathers and the issue of the per-thread sort / chain code "
+                                 "at 4 waves per SIMD (one workgroup per CU), not by HBM"}
         resident_mb = S * B * (2 * 2048 * (8 + 32) + 2048 * 4 + 2 * 512 * (16 + 32) + 512 * 4) / 1e6
         out = {
             "metric": "stereo frames/s (match+optimizePose)", "value": frames_total / dt, "unit": "frame-pairs/s",
@@ -499,7 +501,7 @@ def main():
                        "parallelism": f"seq-shard x{world}", "committed_pose_fraction": ok_frac},
             "roofline": roofline, "roofline_pose": roofline_pose, "roofline_grid_scan": roofline_grid,
             "stage_ms": dict(stage_ms, steps_timed=n_timed,
-                             note="stereo_points_stage = cells + cover + 2 scans + finalize + tail of the key-points (contains grid_scan); "
+                             note="stereo_points_stage = cells + grid matcher + tail of the key-points (contains grid_scan = the matcher launch); "
                                   "the key-line stage runs concurrently on a second stream and is not on the critical path"),
         }
     pipe.close()
