@@ -23,7 +23,6 @@ namespace stvo {
 namespace {
 
 constexpr int ORB_HP = 15;  // half patch
-constexpr int TILE_W = 64, TILE_H = 8;
 
 struct OrbDev {
     int B, cols, rows, K, nfeatures, fast_th, edge_th;
@@ -243,33 +242,80 @@ struct BlurK {
     int k[7];
 };
 
-__global__ __launch_bounds__(TILE_W* TILE_H) void orb_blur_kernel(OrbDev o, BlurK kk) {
-    __shared__ uint8_t tile[TILE_H + 6][TILE_W + 8];
-    __shared__ int hrow[TILE_H + 6][TILE_W];
-    const int b = blockIdx.z, x0 = blockIdx.x * TILE_W, y0 = blockIdx.y * TILE_H;
+// Separable 7 x 7 blur in registers, no LDS: a thread produces 4 adjacent pixels (one packed word) of BL_R consecutive rows.
+// Per input row it loads the 12 bytes x - 4 .. x + 7 as three (unaligned) words, forms the four horizontal sums with byte
+// alignment + 4-way byte dot products (v_alignbyte_b32 / v_dot4_u32_u8: 16 instructions instead of 12 extractions + 28
+// multiply-adds), keeps the last seven rows of sums in a register ring and emits one output row per input row.  The arithmetic
+// is the integer one of the tile version (weights * 2^8 per pass, (s + 2^15) >> 16), so the sums may be taken in any order.
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+constexpr int BL_R = 16, BL_T = 64;
+
+__global__ __launch_bounds__(BL_T) void orb_blur_kernel(OrbDev o, BlurK kk) {
+    const int b = blockIdx.z, x = (blockIdx.x * BL_T + threadIdx.x) * 4, y0 = blockIdx.y * BL_R;
+    if (x >= o.cols) return;
     const uint8_t* img = o.img + (size_t)b * o.rows * o.cols;
-    const int tid = threadIdx.y * TILE_W + threadIdx.x;
-    for (int i = tid; i < (TILE_H + 6) * (TILE_W + 6); i += TILE_W * TILE_H) {
-        const int ty = i / (TILE_W + 6), tx = i % (TILE_W + 6);
-        const int gx = reflect101(x0 + tx - 3, o.cols), gy = reflect101(y0 + ty - 3, o.rows);
-        tile[ty][tx] = img[(size_t)gy * o.cols + gx];
-    }
-    __syncthreads();
-    for (int i = tid; i < (TILE_H + 6) * TILE_W; i += TILE_W * TILE_H) {  // horizontal pass (integers, kernel * 2^8)
-        const int ty = i / TILE_W, tx = i % TILE_W;
-        int s = 0;
+    uint8_t* out = o.blur + (size_t)b * o.rows * o.cols;
+    const uint32_t k03 = (uint32_t)kk.k[0] | ((uint32_t)kk.k[1] << 8) | ((uint32_t)kk.k[2] << 16) | ((uint32_t)kk.k[3] << 24);
+    const uint32_t k46 = (uint32_t)kk.k[4] | ((uint32_t)kk.k[5] << 8) | ((uint32_t)kk.k[6] << 16);
+    const bool interior = x >= 4 && x + 8 <= o.cols;
+    uint32_t h[7][4];
 #pragma unroll
-        for (int j = 0; j < 7; ++j) s += kk.k[j] * tile[ty][tx + j];
-        hrow[ty][tx] = s;
-    }
-    __syncthreads();
-    const int x = x0 + threadIdx.x, y = y0 + threadIdx.y;
-    if (x >= o.cols || y >= o.rows) return;
-    int s = 0;
+    for (int j = 0; j < 7; ++j)
 #pragma unroll
-    for (int j = 0; j < 7; ++j) s += kk.k[j] * hrow[threadIdx.y + j][threadIdx.x];
-    s = (s + (1 << 15)) >> 16;
-    o.blur[(size_t)b * o.rows * o.cols + (size_t)y * o.cols + x] = (uint8_t)min(max(s, 0), 255);
+        for (int i = 0; i < 4; ++i) h[j][i] = 0u;
+#pragma unroll
+    for (int r = 0; r < BL_R + 6; ++r) {
+        const int yo = y0 + r - 6;                  // output row completed by this input row
+        if (r >= 6 && yo >= o.rows) break;          // uniform over the workgroup
+        const int gy = reflect101(y0 + r - 3, o.rows);
+        const uint8_t* row = img + (size_t)gy * o.cols;
+        uint32_t w0, w1, w2;  // bytes x - 4 .. x - 1, x .. x + 3, x + 4 .. x + 7
+        if (interior) {
+            w0 = *reinterpret_cast<const u32_unaligned*>(row + x - 4);
+            w1 = *reinterpret_cast<const u32_unaligned*>(row + x);
+            w2 = *reinterpret_cast<const u32_unaligned*>(row + x + 4);
+        } else {  // image border: BORDER_REFLECT_101 byte by byte
+            w0 = w1 = w2 = 0u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                w0 |= (uint32_t)row[reflect101(x - 4 + i, o.cols)] << (8 * i);
+                w1 |= (uint32_t)row[reflect101(x + i, o.cols)] << (8 * i);
+                w2 |= (uint32_t)row[reflect101(x + 4 + i, o.cols)] << (8 * i);
+            }
+        }
+        // output i: taps x + i - 3 .. x + i + 3 = bytes i + 1 .. i + 7 of (w0, w1, w2)
+        uint32_t hs[4];
+        hs[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 1), k03, 0u, false);
+        hs[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 1), k46, hs[0], false);
+        hs[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 2), k03, 0u, false);
+        hs[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 2), k46, hs[1], false);
+        hs[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 3), k03, 0u, false);
+        hs[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 3), k46, hs[2], false);
+        hs[3] = __builtin_amdgcn_udot4(w1, k03, 0u, false);
+        hs[3] = __builtin_amdgcn_udot4(w2, k46, hs[3], false);
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) h[j][i] = h[j + 1][i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) h[6][i] = hs[i];
+        if (r >= 6) {
+            uint32_t px = 0u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                uint32_t sv = 1u << 15;
+#pragma unroll
+                for (int j = 0; j < 7; ++j) sv += (uint32_t)kk.k[j] * h[j][i];
+                px |= min(sv >> 16, 255u) << (8 * i);
+            }
+            uint8_t* dst = out + (size_t)yo * o.cols + x;
+            if (x + 4 <= o.cols) {
+                *reinterpret_cast<u32_unaligned*>(dst) = px;
+            } else {
+                for (int i = 0; x + i < o.cols; ++i) dst[i] = (uint8_t)(px >> (8 * i));
+            }
+        }
+    }
 }
 
 // OpenCV fastAtan2 (degrees): 7th-order odd polynomial on [0, 1], octant folding
@@ -297,51 +343,63 @@ struct Umax {
     int u[ORB_HP + 2];
 };
 
-// one wave per key-point: intensity-centroid angle on the image, rotated BRIEF on the blurred image
+// 16 lanes per key-point (4 key-points per wave, 16 per workgroup): intensity-centroid angle on the image, rotated BRIEF on the
+// blurred image.  The sine / cosine of the angle (double precision, like the oracle's libm call) is the longest instruction
+// sequence of the kernel and runs once per wave: four key-points share it.
+constexpr int DESC_KP_PER_WG = 16;
 __global__ __launch_bounds__(256) void orb_describe_kernel(OrbDev o, Umax um) {
-    const int b = blockIdx.y, lane = threadIdx.x & 63;
-    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (k >= o.n_kp[b]) return;  // wave-uniform
+    const int b = blockIdx.y, lane = threadIdx.x & 63, l = lane & 15;
+    const int n = o.n_kp[b];
+    const int k_first = blockIdx.x * DESC_KP_PER_WG + (threadIdx.x >> 6) * 4;
+    if (k_first >= n) return;  // wave-uniform
+    const int k_own = k_first + (lane >> 4);
+    const bool valid = k_own < n;
+    const int k = valid ? k_own : n - 1;  // idle groups shadow the last key-point (the shuffles below want every lane)
     const size_t kk = (size_t)b * o.K + k;
     const int x = (int)o.kp[2 * kk], y = (int)o.kp[2 * kk + 1];
     const size_t base = (size_t)b * o.rows * o.cols;
     const uint8_t* img = o.img + base;
-    // ICAngles: lane u + 15 owns column u of the circular patch; integer moments, so the summation order is free
+    // ICAngles: lane l owns columns l - 15 and l + 1 of the circular patch; integer moments, so the summation order is free
     int m10 = 0, m01 = 0;
-    if (lane <= 2 * ORB_HP) {
-        const int u = lane - ORB_HP, au = u < 0 ? -u : u;
-        const uint8_t* c = img + (size_t)y * o.cols + (x + u);
-        m10 = u * (int)c[0];
-        for (int v = 1; v <= ORB_HP; ++v)
-            if (au <= um.u[v]) {
-                const int vp = c[(ptrdiff_t)v * o.cols], vm = c[-(ptrdiff_t)v * o.cols];
-                m10 += u * (vp + vm);
-                m01 += v * (vp - vm);
-            }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int u = h == 0 ? l - ORB_HP : l + 1;
+        if (u <= ORB_HP) {
+            const int au = u < 0 ? -u : u;
+            const uint8_t* c = img + (size_t)y * o.cols + (x + u);
+            m10 += u * (int)c[0];
+            for (int v = 1; v <= ORB_HP; ++v)
+                if (au <= um.u[v]) {
+                    const int vp = c[(ptrdiff_t)v * o.cols], vm = c[-(ptrdiff_t)v * o.cols];
+                    m10 += u * (vp + vm);
+                    m01 += v * (vp - vm);
+                }
+        }
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
+    for (int off = 8; off > 0; off >>= 1) {
         m10 += __shfl_xor(m10, off, 64);
         m01 += __shfl_xor(m01, off, 64);
     }
     const float ang = fast_atan2_deg((float)m01, (float)m10);
-    if (lane == 0) o.angle[kk] = ang;
-    // computeOrbDescriptors, WTA_K = 2: lane l evaluates tests 4 l .. 4 l + 3
+    if (valid && l == 0) o.angle[kk] = ang;
+    // computeOrbDescriptors, WTA_K = 2: lane l evaluates tests 16 l .. 16 l + 15 = bytes 2 l, 2 l + 1 of the descriptor
     const float rad = ang * (float)(3.14159265358979323846 / 180.0);
     const float a = (float)cos((double)rad), sb = (float)sin((double)rad);
     const uint8_t* bl = o.blur + base + (size_t)y * o.cols + x;
-    int nib = 0;
+    const int* pat = reinterpret_cast<const int*>(o.pattern) + 16 * l;  // (x0, y0, x1, y1) of a test as one word
+    uint32_t bits = 0u;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int8_t* p = o.pattern + 4 * (4 * lane + t);
-        const float px0 = (float)p[0], py0 = (float)p[1], px1 = (float)p[2], py1 = (float)p[3];
+    for (int t = 0; t < 16; ++t) {
+        const int w = pat[t];
+        const float px0 = (float)(int8_t)(w & 0xFF), py0 = (float)(int8_t)((w >> 8) & 0xFF);
+        const float px1 = (float)(int8_t)((w >> 16) & 0xFF), py1 = (float)(int8_t)((w >> 24) & 0xFF);
         const int ix0 = __float2int_rn(px0 * a - py0 * sb), iy0 = __float2int_rn(px0 * sb + py0 * a);
         const int ix1 = __float2int_rn(px1 * a - py1 * sb), iy1 = __float2int_rn(px1 * sb + py1 * a);
         const int t0 = bl[(ptrdiff_t)iy0 * o.cols + ix0], t1 = bl[(ptrdiff_t)iy1 * o.cols + ix1];
-        nib |= (t0 < t1) << t;
+        bits |= (uint32_t)(t0 < t1) << t;
     }
-    const int hi = __shfl_down(nib, 1, 64);
-    if ((lane & 1) == 0) o.desc[kk * 32 + (lane >> 1)] = (uint8_t)(nib | (hi << 4));
+    if (valid) *reinterpret_cast<uint16_t*>(o.desc + kk * 32 + 2 * l) = (uint16_t)bits;
 }
 
 }  // namespace
@@ -468,12 +526,12 @@ int stvo_orb_detect_dev(stvo_orb* o, const uint8_t* images, float* kp_xy, float*
     stvo::OrbDev d = o->d;
     d.img = images; d.kp = kp_xy; d.resp = response; d.angle = angle; d.desc = desc; d.n_kp = n_kp;
     hipStream_t s = ctx->stream;
-    const dim3 tiles((d.cols + stvo::TILE_W - 1) / stvo::TILE_W, (d.rows + stvo::TILE_H - 1) / stvo::TILE_H, d.B), tb(stvo::TILE_W, stvo::TILE_H);
+    const dim3 tiles((d.cols + 4 * stvo::BL_T - 1) / (4 * stvo::BL_T), (d.rows + stvo::BL_R - 1) / stvo::BL_R, d.B), tb(stvo::BL_T);
     hipLaunchKernelGGL(stvo::orb_fast_nms_kernel, dim3((d.cols + stvo::FT_W - 1) / stvo::FT_W, (d.rows + stvo::FT_H - 1) / stvo::FT_H, d.B),
                        dim3(256), 0, s, d);
     hipLaunchKernelGGL(stvo::orb_blur_kernel, tiles, tb, 0, s, d, o->blur_k);
     hipLaunchKernelGGL(stvo::orb_order_kernel, dim3(d.B), dim3(1024), 0, s, d);
-    hipLaunchKernelGGL(stvo::orb_describe_kernel, dim3((d.K + 3) / 4, d.B), dim3(256), 0, s, d, o->umax);
+    hipLaunchKernelGGL(stvo::orb_describe_kernel, dim3((d.K + stvo::DESC_KP_PER_WG - 1) / stvo::DESC_KP_PER_WG, d.B), dim3(256), 0, s, d, o->umax);
     return check_launch(ctx);
 }
 

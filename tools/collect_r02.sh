@@ -13,14 +13,14 @@ for pk in 1 2; do
   for c in FETCH_SIZE WRITE_SIZE; do
     cd /tmp; rm -rf /tmp/pmc_$c
     STVO_POSE_KERNEL=$pk timeout 150 rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc_$c -- $BENCH --steps 3 --warmup 2 > /dev/null 2>&1
-    cd $R; python tools/rocprof_summary.py pmc $(find /tmp/pmc_$c -name "*.db" | head -1) $c | head -14 > $OUT/pmc_pose${pk}_$c.txt; rm -rf /tmp/pmc_$c
+    cd $R; python tools/rocprof_summary.py pmc $(find /tmp/pmc_$c -name "*.db" | head -1) $c | head -40 > $OUT/pmc_pose${pk}_$c.txt; rm -rf /tmp/pmc_$c
   done
 done
 : > $OUT/pmc_sq.txt
 for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVES"; do
   cd /tmp; rm -rf /tmp/pmc_g
   timeout 150 rocprofv3 --pmc $grp --kernel-trace -d /tmp/pmc_g -- $BENCH --steps 3 --warmup 2 > /dev/null 2>&1
-  cd $R; python tools/rocprof_summary.py pmc $(find /tmp/pmc_g -name "*.db" | head -1) | grep -i "hamming_knn2_mfma_kernel<2, 0>\|pose\|grid_scan_kernel<false, 1\|counter" >> $OUT/pmc_sq.txt; rm -rf /tmp/pmc_g
+  cd $R; python tools/rocprof_summary.py pmc $(find /tmp/pmc_g -name "*.db" | head -1) | grep -i "hamming_knn2_mfma_kernel<2, 0>\|pose\|grid_points_fused\|counter" >> $OUT/pmc_sq.txt; rm -rf /tmp/pmc_g
 done
 tools/latency.sh $1/latency.txt > /dev/null 2>&1
 python tools/cpu_pipeline_time.py >> $OUT/latency.txt 2>/dev/null
