@@ -43,18 +43,22 @@ struct OrbDev {
 __device__ __constant__ int8_t c_circle[16][2] = {{0, 3},  {1, 3},   {2, 2},   {3, 1},   {3, 0},  {3, -1}, {2, -2}, {1, -3},
                                                   {0, -3}, {-1, -3}, {-2, -2}, {-3, -1}, {-3, 0}, {-3, 1}, {-2, 2}, {-1, 3}};
 
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;  // a word at any byte address (gfx950 global memory allows it)
 constexpr int FT_W = 64, FT_H = 16;               // output tile of the fused FAST + NMS kernel
 constexpr int SC_W = FT_W + 2, SC_H = FT_H + 2;   // scores are needed one pixel beyond the tile (3x3 maximum test)
-constexpr int IM_W = FT_W + 8, IM_H = FT_H + 8;   // image tile: + the circle radius 3
+constexpr int IM_H = FT_H + 8;                    // image tile rows: + 1 (score halo) + 3 (circle radius) on both sides
+constexpr int IM_DW = 19, IM_PITCH = 20;          // image tile row: 19 words = pixels x0 - 5 .. x0 + 70 (score position sx <-> byte sx + 4: word aligned)
+constexpr int SC_PITCH = 72;                      // score row, bytes (18 words)
 constexpr int CAND_CAP = 16384;                    // survivors of NMS + border per image (typ. 2-3 k at threshold 20)
 
-// cornerScore<16> of the pixel at (lx, ly) of the LDS image tile: max over the 16 arcs of 9 contiguous circle pixels of the
-// smallest (signed) difference in the arc, bright and dark, minus 1 — min / max over every window of 9 by doubling
-__device__ __forceinline__ int fast_score_lds(const uint8_t (*tile)[IM_W + 4], int lx, int ly) {
-    const int v = tile[ly][lx];
+// cornerScore<16> of the pixel at byte (lx, ly) of the LDS image tile: max over the 16 arcs of 9 contiguous circle pixels of
+// the smallest (signed) difference in the arc, bright and dark, minus 1 — min / max over every window of 9 by doubling
+__device__ __forceinline__ int fast_score_lds(const uint8_t* tile, int lx, int ly) {
+    const uint8_t* c = tile + ly * (IM_PITCH * 4) + lx;
+    const int v = c[0];
     int d[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) d[k] = (int)tile[ly + c_circle[k][1]][lx + c_circle[k][0]] - v;
+    for (int k = 0; k < 16; ++k) d[k] = (int)c[c_circle[k][1] * (IM_PITCH * 4) + c_circle[k][0]] - v;
     int mn2[16], mx2[16], mn4[16], mx4[16], mn8[16], mx8[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
@@ -80,77 +84,124 @@ __device__ __forceinline__ int fast_score_lds(const uint8_t (*tile)[IM_W + 4], i
     return max(sb, sd) - 1;
 }
 
-// FAST-9/16 + non-maximum suppression + border filter of one 64 x 16 tile, entirely in LDS:
-//   1. the image tile (+ halo 4) is staged once;
+// wave-aggregated append of up to four flagged items per lane: ONE LDS atomic per wave (lanes hammering one counter serialise)
+__device__ __forceinline__ void append4(const bool (&flag)[4], int* counter, int (&slot)[4]) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long bal[4];
+    int total = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        bal[j] = __ballot(flag[j]);
+        total += __popcll(bal[j]);
+    }
+    int base = 0;
+    if (lane == 0 && total) base = atomicAdd(counter, total);
+    base = __shfl(base, 0, 64);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        slot[j] = base + __popcll(bal[j] & ((1ull << lane) - 1ull));
+        base += __popcll(bal[j]);
+    }
+}
+
+// FAST-9/16 + non-maximum suppression + border filter of one 64 x 16 tile, entirely in LDS, four pixels per thread and step:
+//   1. the image tile (+ halo) is staged once, word by word (unaligned global words; byte by byte only at the image border);
 //   2. every score position (tile + halo 1) takes the cheap compass-point test (any arc of 9 contiguous circle pixels holds
-//      at least two of the four compass points); the few survivors are COMPACTED into a list, so that
+//      at least two of the four compass points) on words: centre / north / south words and the east / west ones by byte
+//      alignment; the few survivors are COMPACTED into a list, so that
 //   3. the 150-instruction corner score runs on dense lanes (it used to run for a whole wave whenever one lane needed it);
 //   4. a pixel whose score beats its 8 neighbours (and lies inside the border) is appended to the image's candidate list and
 //      counted in the response histogram — no score / keep maps ever reach global memory.
 __global__ __launch_bounds__(256) void orb_fast_nms_kernel(OrbDev o) {
-    __shared__ uint8_t tile[IM_H][IM_W + 4];
-    __shared__ uint8_t sc[SC_H][SC_W + 2];
-    __shared__ uint16_t s_list[SC_H * SC_W];
+    __shared__ uint32_t tile[IM_H][IM_PITCH];
+    __shared__ uint32_t sc_w[SC_H][SC_PITCH / 4];
+    __shared__ uint16_t s_list[SC_H * SC_W + 8];
     __shared__ uint32_t s_kp[256];  // key-points of this tile (a 3x3 maximum every 4 pixels at most: 64 x 16 / 4)
     __shared__ int s_n, s_nkp, s_base;
-    const int lane = threadIdx.x & 63;
     const int b = blockIdx.z, x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H, tid = threadIdx.x;
     const uint8_t* img = o.img + (size_t)b * o.rows * o.cols;
-    for (int i = tid; i < IM_H * IM_W; i += 256) {
-        const int ty = i / IM_W, tx = i % IM_W;
-        const int gx = min(max(x0 + tx - 4, 0), o.cols - 1), gy = min(max(y0 + ty - 4, 0), o.rows - 1);
-        tile[ty][tx] = img[(size_t)gy * o.cols + gx];
+    const uint8_t* tile8 = reinterpret_cast<const uint8_t*>(&tile[0][0]);
+    uint8_t* sc = reinterpret_cast<uint8_t*>(&sc_w[0][0]);
+    for (int i = tid; i < IM_H * IM_DW; i += 256) {
+        const int ty = i / IM_DW, td = i - ty * IM_DW;
+        const int gx = x0 - 5 + 4 * td, gy = min(max(y0 + ty - 4, 0), o.rows - 1);
+        const uint8_t* row = img + (size_t)gy * o.cols;
+        uint32_t w;
+        if (gx >= 0 && gx + 4 <= o.cols) {
+            w = *reinterpret_cast<const u32_unaligned*>(row + gx);
+        } else {  // image border: replicate (those pixels never pass the border test below, their values only have to exist)
+            w = 0u;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) w |= (uint32_t)row[min(max(gx + k, 0), o.cols - 1)] << (8 * k);
+        }
+        tile[ty][td] = w;
     }
-    for (int i = tid; i < SC_H * (SC_W + 2); i += 256) (&sc[0][0])[i] = 0;
+    for (int i = tid; i < SC_H * (SC_PITCH / 4); i += 256) (&sc_w[0][0])[i] = 0u;
     if (tid == 0) {
         s_n = 0;
         s_nkp = 0;
     }
     __syncthreads();
     const int t = o.fast_th;
-    // (all lanes of a wave run the same number of trips: the ballots below need the whole wave)
-    for (int i0 = 0; i0 < SC_H * SC_W; i0 += 256) {
+    // (all lanes of a wave run the same number of trips: the ballots of append4 need the whole wave)
+    constexpr int GROUPS = (SC_W + 3) / 4;  // 17 groups of four score positions per row
+    for (int i0 = 0; i0 < SC_H * GROUPS; i0 += 256) {
         const int i = i0 + tid;
-        const int sy = i / SC_W, sx = i % SC_W;            // score position; image pixel (x0 + sx - 1, y0 + sy - 1)
-        const int x = x0 + sx - 1, y = y0 + sy - 1;
-        bool cand = false;
-        if (i < SC_H * SC_W && x >= 3 && x < o.cols - 3 && y >= 3 && y < o.rows - 3) {
-            const int lx = sx + 3, ly = sy + 3;
-            const int v = tile[ly][lx];
-            const int c0 = tile[ly + 3][lx] - v, c4 = tile[ly][lx + 3] - v, c8 = tile[ly - 3][lx] - v, c12 = tile[ly][lx - 3] - v;
+        const bool item = i < SC_H * GROUPS;
+        const int sy = item ? i / GROUPS : 0, g = item ? i - sy * GROUPS : 0;
+        const int r = sy + 3, y = y0 + sy - 1;
+        const uint32_t C = tile[r][g + 1], L = tile[r][g], R = tile[r][g + 2], N = tile[r - 3][g + 1], S = tile[r + 3][g + 1];
+        const uint32_t W4 = __builtin_amdgcn_alignbyte(C, L, 1), E4 = __builtin_amdgcn_alignbyte(R, C, 3);
+        const bool row_ok = item && y >= 3 && y < o.rows - 3;
+        bool cand[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int sx = 4 * g + j, x = x0 + sx - 1;
+            const int v = (int)((C >> (8 * j)) & 255u);
+            const int c0 = (int)((S >> (8 * j)) & 255u) - v, c4 = (int)((E4 >> (8 * j)) & 255u) - v;
+            const int c8 = (int)((N >> (8 * j)) & 255u) - v, c12 = (int)((W4 >> (8 * j)) & 255u) - v;
             const int nb = (c0 > t) + (c4 > t) + (c8 > t) + (c12 > t), nd = (c0 < -t) + (c4 < -t) + (c8 < -t) + (c12 < -t);
-            cand = nb >= 2 || nd >= 2;
+            cand[j] = row_ok && sx < SC_W && x >= 3 && x < o.cols - 3 && (nb >= 2 || nd >= 2);
         }
-        // wave-aggregated append: one LDS atomic per wave and trip (lanes hammering one counter serialise)
-        const unsigned long long bal = __ballot(cand);
-        int base = 0;
-        if (lane == 0 && bal) base = atomicAdd(&s_n, __popcll(bal));
-        base = __shfl(base, 0, 64);
-        if (cand) s_list[base + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)i;
+        int slot[4];
+        append4(cand, &s_n, slot);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (cand[j]) s_list[slot[j]] = (uint16_t)(sy * SC_W + 4 * g + j);
     }
     __syncthreads();
     const int n = s_n;
     for (int j = tid; j < n; j += 256) {
-        const int i = s_list[j], sy = i / SC_W, sx = i % SC_W;
-        const int s = fast_score_lds(tile, sx + 3, sy + 3);
-        if (s >= t) sc[sy][sx] = (uint8_t)s;  // t >= 1, so a corner's score is positive
+        const int i = s_list[j], sy = i / SC_W, sx = i - sy * SC_W;
+        const int s = fast_score_lds(tile8, sx + 4, sy + 3);
+        if (s >= t) sc[sy * SC_PITCH + sx] = (uint8_t)s;  // t >= 1, so a corner's score is positive
     }
     __syncthreads();
-    for (int i = tid; i < FT_H * FT_W; i += 256) {  // FT_H * FT_W is a multiple of 256: whole waves
-        const int py = i / FT_W, px = i % FT_W, x = x0 + px, y = y0 + py;
-        const int s = sc[py + 1][px + 1];
-        bool kp = false;
-        if (s != 0 && x < o.cols && y < o.rows) {
-            const bool is_max = s > sc[py][px] && s > sc[py][px + 1] && s > sc[py][px + 2] && s > sc[py + 1][px] && s > sc[py + 1][px + 2] &&
-                                s > sc[py + 2][px] && s > sc[py + 2][px + 1] && s > sc[py + 2][px + 2];
-            // KeyPointsFilter::runByImageBorder
-            kp = is_max && x >= o.edge_th && x < o.cols - o.edge_th && y >= o.edge_th && y < o.rows - o.edge_th;
+    {  // 64 x 16 pixels = 256 threads x 4: thread -> row py, pixels 4 h .. 4 h + 3; score rows py .. py + 2, bytes 4 h .. 4 h + 5
+        const int py = tid >> 4, h = tid & 15, y = y0 + py;
+        unsigned long long rw[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) rw[k] = (unsigned long long)sc_w[py + k][h] | ((unsigned long long)sc_w[py + k][h + 1] << 32);
+        bool kp[4];
+        uint32_t word[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int x = x0 + 4 * h + j;
+            const uint32_t top = (uint32_t)(rw[0] >> (8 * j)) & 0xFFFFFFu, mid = (uint32_t)(rw[1] >> (8 * j)) & 0xFFFFFFu,
+                           bot = (uint32_t)(rw[2] >> (8 * j)) & 0xFFFFFFu;
+            const uint32_t s = (mid >> 8) & 255u;
+            const uint32_t m8 = max(max(max(top & 255u, (top >> 8) & 255u), max(top >> 16, mid & 255u)),
+                                    max(max(mid >> 16, bot & 255u), max((bot >> 8) & 255u, bot >> 16)));
+            // 3x3 strict maximum, then KeyPointsFilter::runByImageBorder
+            kp[j] = s != 0u && s > m8 && x < o.cols && y < o.rows && x >= o.edge_th && x < o.cols - o.edge_th && y >= o.edge_th &&
+                    y < o.rows - o.edge_th;
+            word[j] = ((uint32_t)y << 20) | ((uint32_t)x << 8) | s;
         }
-        const unsigned long long bal = __ballot(kp);
-        int base = 0;
-        if (lane == 0 && bal) base = atomicAdd(&s_nkp, __popcll(bal));
-        base = __shfl(base, 0, 64);
-        if (kp) s_kp[base + __popcll(bal & ((1ull << lane) - 1ull))] = ((uint32_t)y << 20) | ((uint32_t)x << 8) | (uint32_t)s;
+        int slot[4];
+        append4(kp, &s_nkp, slot);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (kp[j]) s_kp[slot[j]] = word[j];
     }
     __syncthreads();
     const int nkp = s_nkp;
@@ -247,7 +298,6 @@ struct BlurK {
 // alignment + 4-way byte dot products (v_alignbyte_b32 / v_dot4_u32_u8: 16 instructions instead of 12 extractions + 28
 // multiply-adds), keeps the last seven rows of sums in a register ring and emits one output row per input row.  The arithmetic
 // is the integer one of the tile version (weights * 2^8 per pass, (s + 2^15) >> 16), so the sums may be taken in any order.
-typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 constexpr int BL_R = 16, BL_T = 64;
 
 __global__ __launch_bounds__(BL_T) void orb_blur_kernel(OrbDev o, BlurK kk) {
@@ -344,36 +394,66 @@ struct Umax {
 };
 
 // 16 lanes per key-point (4 key-points per wave, 16 per workgroup): intensity-centroid angle on the image, rotated BRIEF on the
-// blurred image.  The sine / cosine of the angle (double precision, like the oracle's libm call) is the longest instruction
-// sequence of the kernel and runs once per wave: four key-points share it.
+// blurred image.  Both patches are first copied into LDS with word loads (a row of a patch is 32 / 40 contiguous bytes, one
+// cache line per key-point and load instruction); the 512 rotated test points of a key-point are then gathered from LDS.
+// Gathered from global memory, every test load of a wave touched up to 64 different cache lines — the texture-address path,
+// not arithmetic, set the pace of the first two versions (675 / 450 us per 512 k key-points).  The sine / cosine of the angle
+// (double precision, like the oracle's libm call) runs once per wave: four key-points share it.
 constexpr int DESC_KP_PER_WG = 16;
+constexpr int DESC_R = 19;                        // |rotated pattern coordinate| <= 13 sqrt 2 < 19
+constexpr int DESC_PW = 10, DESC_PH = 2 * DESC_R + 1;  // blurred patch: 39 rows of 10 words = bytes x - 20 .. x + 19
+constexpr int IC_PW = 8, IC_PH = 2 * ORB_HP + 1;       // image patch: 31 rows of 8 words = bytes x - 16 .. x + 15
 __global__ __launch_bounds__(256) void orb_describe_kernel(OrbDev o, Umax um) {
+    __shared__ uint32_t s_patch[DESC_KP_PER_WG][DESC_PH * DESC_PW];  // the image patch first (31 x 8 words), then the blurred one
     const int b = blockIdx.y, lane = threadIdx.x & 63, l = lane & 15;
     const int n = o.n_kp[b];
     const int k_first = blockIdx.x * DESC_KP_PER_WG + (threadIdx.x >> 6) * 4;
     if (k_first >= n) return;  // wave-uniform
+    const int slot = (threadIdx.x >> 6) * 4 + (lane >> 4);
     const int k_own = k_first + (lane >> 4);
     const bool valid = k_own < n;
     const int k = valid ? k_own : n - 1;  // idle groups shadow the last key-point (the shuffles below want every lane)
     const size_t kk = (size_t)b * o.K + k;
     const int x = (int)o.kp[2 * kk], y = (int)o.kp[2 * kk + 1];
     const size_t base = (size_t)b * o.rows * o.cols;
-    const uint8_t* img = o.img + base;
+    uint32_t* patch = s_patch[slot];
+    const uint8_t* patch8 = reinterpret_cast<const uint8_t*>(patch);
+    // the patches lie inside the image (edge threshold >= 19 + 1 word of slack is NOT guaranteed on the left / right: clamp the
+    // word address into the image buffer; the clamped words hold columns the disc / the pattern never reads)
+    const uint8_t* img_lo = o.img + base;
+    const uint8_t* img_hi = o.img + base + (size_t)o.rows * o.cols - 4;
+    {
+        const uint8_t* org = o.img + base + (size_t)(y - ORB_HP) * o.cols + (x - 16);
+        for (int i = l; i < IC_PH * IC_PW; i += 16) {
+            const int r = i >> 3, w = i & 7;
+            const uint8_t* p = org + (size_t)r * o.cols + 4 * w;
+            p = p < img_lo ? img_lo : (p > img_hi ? img_hi : p);
+            patch[i] = *reinterpret_cast<const u32_unaligned*>(p);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // ICAngles: lane l owns columns l - 15 and l + 1 of the circular patch; integer moments, so the summation order is free
     int m10 = 0, m01 = 0;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        const int u = h == 0 ? l - ORB_HP : l + 1;
-        if (u <= ORB_HP) {
-            const int au = u < 0 ? -u : u;
-            const uint8_t* c = img + (size_t)y * o.cols + (x + u);
-            m10 += u * (int)c[0];
-            for (int v = 1; v <= ORB_HP; ++v)
-                if (au <= um.u[v]) {
-                    const int vp = c[(ptrdiff_t)v * o.cols], vm = c[-(ptrdiff_t)v * o.cols];
-                    m10 += u * (vp + vm);
-                    m01 += v * (vp - vm);
-                }
+        const int u_raw = h == 0 ? l - ORB_HP : l + 1;
+        const bool col_ok = u_raw <= ORB_HP;
+        const int u = col_ok ? u_raw : ORB_HP;
+        const int au = u < 0 ? -u : u;
+        const uint8_t* c = patch8 + ORB_HP * (IC_PW * 4) + (16 + u);  // centre row, column x + u
+        int s10 = c[0], s01 = 0;
+#pragma unroll
+        for (int v = 1; v <= ORB_HP; ++v) {
+            const int vp = c[v * (IC_PW * 4)], vm = c[-v * (IC_PW * 4)];
+            const bool in = au <= um.u[v];
+            s10 += in ? vp + vm : 0;
+            s01 += in ? v * (vp - vm) : 0;
+        }
+        if (col_ok) {
+            m10 += u * s10;
+            m01 += s01;
         }
     }
 #pragma unroll
@@ -383,10 +463,27 @@ __global__ __launch_bounds__(256) void orb_describe_kernel(OrbDev o, Umax um) {
     }
     const float ang = fast_atan2_deg((float)m01, (float)m10);
     if (valid && l == 0) o.angle[kk] = ang;
+    // the blurred patch replaces the image patch (every lane of the group is past its reads: the shuffles above synchronise)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    {
+        const uint8_t* blur_lo = o.blur + base;
+        const uint8_t* blur_hi = o.blur + base + (size_t)o.rows * o.cols - 4;
+        const uint8_t* org = o.blur + base + (size_t)(y - DESC_R) * o.cols + (x - 20);
+        for (int i = l; i < DESC_PH * DESC_PW; i += 16) {
+            const int r = i / DESC_PW, w = i - r * DESC_PW;
+            const uint8_t* p = org + (size_t)r * o.cols + 4 * w;
+            p = p < blur_lo ? blur_lo : (p > blur_hi ? blur_hi : p);
+            patch[i] = *reinterpret_cast<const u32_unaligned*>(p);
+        }
+    }
     // computeOrbDescriptors, WTA_K = 2: lane l evaluates tests 16 l .. 16 l + 15 = bytes 2 l, 2 l + 1 of the descriptor
     const float rad = ang * (float)(3.14159265358979323846 / 180.0);
     const float a = (float)cos((double)rad), sb = (float)sin((double)rad);
-    const uint8_t* bl = o.blur + base + (size_t)y * o.cols + x;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint8_t* bl = patch8 + DESC_R * (DESC_PW * 4) + 20;  // the key-point's own pixel
     const int* pat = reinterpret_cast<const int*>(o.pattern) + 16 * l;  // (x0, y0, x1, y1) of a test as one word
     uint32_t bits = 0u;
 #pragma unroll
@@ -396,7 +493,7 @@ __global__ __launch_bounds__(256) void orb_describe_kernel(OrbDev o, Umax um) {
         const float px1 = (float)(int8_t)((w >> 16) & 0xFF), py1 = (float)(int8_t)((w >> 24) & 0xFF);
         const int ix0 = __float2int_rn(px0 * a - py0 * sb), iy0 = __float2int_rn(px0 * sb + py0 * a);
         const int ix1 = __float2int_rn(px1 * a - py1 * sb), iy1 = __float2int_rn(px1 * sb + py1 * a);
-        const int t0 = bl[(ptrdiff_t)iy0 * o.cols + ix0], t1 = bl[(ptrdiff_t)iy1 * o.cols + ix1];
+        const int t0 = bl[iy0 * (DESC_PW * 4) + ix0], t1 = bl[iy1 * (DESC_PW * 4) + ix1];
         bits |= (uint32_t)(t0 < t1) << t;
     }
     if (valid) *reinterpret_cast<uint16_t*>(o.desc + kk * 32 + 2 * l) = (uint16_t)bits;
