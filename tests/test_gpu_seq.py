@@ -239,3 +239,40 @@ def test_seq_point_grid_crowded_frames(oracle, monkeypatch, frac, box, env):
     finally:
         dev.close()
         ctx.close()
+
+
+def test_seq_point_grid_persistent_workgroups_many_frames(oracle, monkeypatch):
+    """More frames than CUs: every persistent workgroup of the one-workgroup-per-frame matcher takes several frames and
+    prefetches the next one while it works — the raw stereo matches and the pose blocks of 600 small sequences must equal the
+    scan formulation's, and sequence 0 / 599 the oracle's."""
+    from stvo_amd import capi
+    cam = synth.KITTI_CAM
+    B = 600
+    seqs = [synth.make_stereo_sequence(9000 + b, n_frames=2, n_pts=60 + (b % 7) * 40, n_lines=0, cam=cam) for b in range(B)]
+    mp = match_params("kitti"); op = opt_params("kitti", has_lines=0)
+
+    def run():
+        ctx = capi.Context(device_id=0, max_rows=512, max_batch=B)
+        dev = capi.Sequences(ctx, B, 512, 64, cam, mp, op)
+        try:
+            dev.enable_fetch(True)
+            out = []
+            for k in range(2):
+                res, counts = dev.push([seqs[b][k] for b in range(B)])
+                ms_p = dev.fetch_matches()[0].copy()
+                out.append((ms_p, counts.copy(), res.copy() if k else None))
+            return out
+        finally:
+            dev.close()
+            ctx.close()
+
+    fused = run()
+    monkeypatch.setenv("STVO_GRID_FUSED", "0")
+    scan = run()
+    for k in range(2):
+        assert np.array_equal(fused[k][0], scan[k][0]) and np.array_equal(fused[k][1], scan[k][1])
+    assert np.array_equal(fused[1][2]["T"], scan[1][2]["T"]) and np.array_equal(fused[1][2]["iters"], scan[1][2]["iters"])
+    assert np.array_equal(fused[1][2]["status"], scan[1][2]["status"])
+    for b in (0, B - 1):
+        ref = pipeline_ref.stereo_frame(oracle, seqs[b][1], cam, mp, True, False)
+        assert np.array_equal(fused[1][0][b, :len(seqs[b][1]["kp_l"])], ref["m12_raw_p"])
