@@ -30,7 +30,7 @@ namespace stvo {
 // frame pair: with the records streamed from L2 at every evaluation the workers spend ~70 % of an evaluation waiting for
 // them (a CU's L1 moves a whole sector per gathered 16-byte observation), 102 k vs 27 k ticks per frame.
 template <int BLOCK, int PPT, int LPT, bool W, bool LDSREC>
-__device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_ibuf)[3 * (BLOCK / 64)], double (*s_red)[28],
+__device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_hist)[BlockOps<BLOCK / 64>::HIST_W], double (*s_red)[28],
                                           int* s_ired, PoseSh* sh, double* s_rec) {
     using Ops = BlockOps<BLOCK / 64>;
     const int f = blockIdx.x;
@@ -244,7 +244,7 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_ibuf)[3 * (
                 }
                 __builtin_amdgcn_sched_barrier(0);  // keep one record in flight, not PPT of them
             }
-            sp = pm::clamp_scale(Ops::template mad_sigma<PPT, W>(rp, pinl, sh->n_inl_p, s_ibuf, &sh->xchg));
+            sp = pm::clamp_scale(Ops::template mad_sigma<PPT, W>(rp, pinl, sh->n_inl_p, s_hist, &sh->xchg));
             double rl[LPT];
 #pragma unroll
             for (int k = 0; k < LPT; ++k) {
@@ -252,7 +252,7 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_ibuf)[3 * (
                 if ((linl >> k) & 1u) rl[k] = pm::line_residual(DT, cam, load_line(k));
                 __builtin_amdgcn_sched_barrier(0);
             }
-            sl = pm::clamp_scale(Ops::template mad_sigma<LPT, W>(rl, linl, sh->n_inl_l, s_ibuf, &sh->xchg));
+            sl = pm::clamp_scale(Ops::template mad_sigma<LPT, W>(rl, linl, sh->n_inl_l, s_hist, &sh->xchg));
         }
         const long long tw0 = tick();
         double acc[28];
@@ -328,7 +328,7 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_ibuf)[3 * (
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            const double stdv = Ops::template mad_sigma<PPT, W>(res, pmatched, tot, s_ibuf, &sh->xchg);
+            const double stdv = Ops::template mad_sigma<PPT, W>(res, pmatched, tot, s_hist, &sh->xchg);
             // mean of the samples below 2 sigma, or of all samples (src/auxiliar.cpp:405-427)
             double v[3] = {0.0, 0.0, 0.0};
 #pragma unroll
@@ -366,7 +366,7 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_ibuf)[3 * (
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            const double stdv = Ops::template mad_sigma<LPT, W>(res, lmatched, tot, s_ibuf, &sh->xchg);
+            const double stdv = Ops::template mad_sigma<LPT, W>(res, lmatched, tot, s_hist, &sh->xchg);
             double v[3] = {0.0, 0.0, 0.0};
 #pragma unroll
             for (int k = 0; k < LPT; ++k)
@@ -529,7 +529,7 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_ibuf)[3 * (
 template <int BLOCK, int PPT, int LPT, bool LDSREC>
 __global__ __launch_bounds__(BLOCK + 64, 2) void pose_kernel(PoseArgs a) {  // >= 2 waves/SIMD => <= 256 VGPRs, 2 workgroups per CU
     extern __shared__ double s_rec[];  // LDSREC: [max_pts][6] + [max_lines][14] doubles (dynamic, sized at launch)
-    __shared__ int s_ibuf[2][3 * (BLOCK / 64)];
+    __shared__ int s_hist[2][BlockOps<BLOCK / 64>::HIST_W];  // select_kth_hist
     __shared__ double s_red[BLOCK / 64][28];
     __shared__ int s_ired[BLOCK / 64];
     __shared__ PoseSh s_sh;
@@ -538,9 +538,9 @@ __global__ __launch_bounds__(BLOCK + 64, 2) void pose_kernel(PoseArgs a) {  // >
     // priority so its critical path is not stretched by the co-resident popcount waves.
     __builtin_amdgcn_s_setprio(3);
     if (threadIdx.x < BLOCK)
-        pose_body<BLOCK, PPT, LPT, true, LDSREC>(a, s_ibuf, s_red, s_ired, &s_sh, s_rec);   // worker waves
+        pose_body<BLOCK, PPT, LPT, true, LDSREC>(a, s_hist, s_red, s_ired, &s_sh, s_rec);   // worker waves
     else
-        pose_body<BLOCK, PPT, LPT, false, LDSREC>(a, s_ibuf, s_red, s_ired, &s_sh, s_rec);  // solver wave
+        pose_body<BLOCK, PPT, LPT, false, LDSREC>(a, s_hist, s_red, s_ired, &s_sh, s_rec);  // solver wave
 }
 
 // Two instantiations of the same kernel:
@@ -552,8 +552,8 @@ __global__ __launch_bounds__(BLOCK + 64, 2) void pose_kernel(PoseArgs a) {  // >
 constexpr int POSE_BLOCK_T = 192, POSE_BLOCK_L = 448;
 constexpr int POSE_LATENCY_MAX_B = 256;
 // dynamic LDS available to the record cache: 160 KB per CU minus the kernel's static LDS (PoseSh, partial sums, counters)
-constexpr size_t POSE_LDSREC_MAX_BYTES = (size_t)160 * 1024 - 6 * 1024;
-constexpr size_t POSE_LDSREC_T_BYTES = (size_t)80 * 1024 - 4 * 1024;  // throughput variant: two workgroups share a CU
+constexpr size_t POSE_LDSREC_MAX_BYTES = (size_t)160 * 1024 - 8 * 1024;
+constexpr size_t POSE_LDSREC_T_BYTES = (size_t)80 * 1024 - 6 * 1024;  // throughput variant: two workgroups share a CU
 
 // lds_budget: bytes of dynamic LDS the record cache may use (LDSREC only): lines first (their gather is the longer chain),
 // points with what is left

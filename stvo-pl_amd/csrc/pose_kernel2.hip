@@ -49,7 +49,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void pose2_kernel(PoseArgs a, int lds
     constexpr int LPT = (STVO_POSE_MAX_LINES + BLOCK - 1) / BLOCK;
     using Ops = BlockOps<NW>;
     extern __shared__ double s_rec[];  // [cap_l][14] line records, then [cap_p][6] point records (compacted)
-    __shared__ int s_ibuf[2][3 * NW];
+    __shared__ int s_hist[2][Ops::HIST_W];  // select_kth_hist
     __shared__ double s_red[NW][28];
     __shared__ int s_ired[NW];
     __shared__ PoseSh s_sh;
@@ -259,14 +259,14 @@ __global__ __launch_bounds__(NW * 64, WPE) void pose2_kernel(PoseArgs a, int lds
                     rp[k] = pm::point_residual(DT, cam, r.X, r.Y, r.Z, r.ox, r.oy);
                 }
             }
-            sp = pm::clamp_scale(Ops::template mad_sigma<PPT, true>(rp, pinl, sh->n_inl_p, s_ibuf, &sh->xchg));
+            sp = pm::clamp_scale(Ops::template mad_sigma<PPT, true>(rp, pinl, sh->n_inl_p, s_hist, &sh->xchg));
             double rlv[LPT];
 #pragma unroll
             for (int k = 0; k < LPT; ++k) {
                 rlv[k] = 0.0;
                 if ((linl >> k) & 1u) rlv[k] = pm::line_residual(DT, cam, load_line(k));
             }
-            sl = pm::clamp_scale(Ops::template mad_sigma<LPT, true>(rlv, linl, sh->n_inl_l, s_ibuf, &sh->xchg));
+            sl = pm::clamp_scale(Ops::template mad_sigma<LPT, true>(rlv, linl, sh->n_inl_l, s_hist, &sh->xchg));
         }
         const long long tw0 = tick();
         double acc[28];
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void pose2_kernel(PoseArgs a, int lds
                     res[k] = pm::point_residual(DT, cam, r.X, r.Y, r.Z, r.ox, r.oy) * r.q;
                 }
             }
-            const double stdv = Ops::template mad_sigma<PPT, true>(res, pmatched, tot, s_ibuf, &sh->xchg);
+            const double stdv = Ops::template mad_sigma<PPT, true>(res, pmatched, tot, s_hist, &sh->xchg);
             double v[3] = {0.0, 0.0, 0.0};  // mean of the samples below 2 sigma, or of all samples (src/auxiliar.cpp:405-427)
 #pragma unroll
             for (int k = 0; k < PPT; ++k)
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void pose2_kernel(PoseArgs a, int lds
                     res[k] = pm::line_residual(DT, cam, L) * L.sigma2;  // L.sigma2 = sqrt(sigma2)
                 }
             }
-            const double stdv = Ops::template mad_sigma<LPT, true>(res, lmatched, tot, s_ibuf, &sh->xchg);
+            const double stdv = Ops::template mad_sigma<LPT, true>(res, lmatched, tot, s_hist, &sh->xchg);
             double v[3] = {0.0, 0.0, 0.0};
 #pragma unroll
             for (int k = 0; k < LPT; ++k)
@@ -540,7 +540,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void pose2_kernel(PoseArgs a, int lds
 // LDS share of the record cache: 160 KB per CU, WG workgroups per CU, minus the kernel's static LDS and some slack
 template <int NW, int WPE>
 constexpr int pose2_lds_budget() {  // 4 WPE / NW workgroups per CU share its 160 KB
-    return (160 * 1024) / ((4 * WPE) / NW) - (int)(sizeof(PoseSh) + NW * 28 * 8 + 2 * 3 * NW * 4 + NW * 4) - 768;
+    return (160 * 1024) / ((4 * WPE) / NW) - (int)(sizeof(PoseSh) + NW * 28 * 8 + NW * 4 + 2 * 260 * 4) - 768;
 }
 
 template <int NW, int WPE>
