@@ -118,8 +118,15 @@ __global__ __launch_bounds__(NW * 64, WPE) void pose2_kernel(PoseArgs a, int lds
     const int cap_p = (lds_rec_bytes - cap_l * REC_L_BYTES) / REC_P_BYTES;
     double* s_lns = s_rec;
     double* s_pts = s_rec + (size_t)cap_l * 14;
+    // (the index of a record is laundered through an empty asm at every use: otherwise the compiler hoists the 64-bit addresses
+    //  of all PPT records of all six arrays — and their LDS slots — out of the iteration loop and carries ~100 VGPRs of
+    //  loop-invariant addresses through the whole kernel: 115 doubles of scratch per lane, written once = 250 KB per frame pair)
+    auto launder = [](int v) -> int {
+        asm volatile("" : "+v"(v));
+        return v;
+    };
     auto load_point_global = [&](int k) -> PointRec2 {
-        const size_t i = pbase + (size_t)(tid + k * BLOCK);
+        const size_t i = pbase + (size_t)launder(tid + k * BLOCK);
         const size_t j = a.m12p ? pbase + (size_t)a.m12p[i] : i;
         PointRec2 r;
         r.X = a.prev_P[i * 3 + 0];
@@ -132,7 +139,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void pose2_kernel(PoseArgs a, int lds
     };
     auto point_slot = [&](int k) -> int { return base_p + __popc(pmatched & ((1u << k) - 1u)); };
     auto load_point = [&](int k) -> PointRec2 {
-        const int slot = point_slot(k);
+        const int slot = launder(point_slot(k));
         if (slot < cap_p) {
             const double2* q = reinterpret_cast<const double2*>(s_pts + (size_t)slot * 6);
             const double2 v0 = q[0], v1 = q[1], v2 = q[2];
@@ -144,7 +151,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void pose2_kernel(PoseArgs a, int lds
     };
     auto line_slot = [&](int k) -> int { return base_l + __popc(lmatched & ((1u << k) - 1u)); };
     auto load_line_global = [&](int k) -> pm::LineRec {
-        const size_t i = lbase + (size_t)(li0 + k * BLOCK);
+        const size_t i = lbase + (size_t)launder(li0 + k * BLOCK);
         const size_t j = a.m12l ? lbase + (size_t)a.m12l[i] : i;
         pm::LineRec L;
 #pragma unroll
@@ -162,7 +169,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void pose2_kernel(PoseArgs a, int lds
         return L;
     };
     auto load_line = [&](int k) -> pm::LineRec {
-        const int slot = line_slot(k);
+        const int slot = launder(line_slot(k));
         if (slot < cap_l) {
             const double2* q = reinterpret_cast<const double2*>(s_lns + (size_t)slot * 14);
             pm::LineRec L;
@@ -174,31 +181,41 @@ __global__ __launch_bounds__(NW * 64, WPE) void pose2_kernel(PoseArgs a, int lds
         }
         return load_line_global(k);
     };
-    // stage this thread's own records (thread-private slots: no barrier between staging and use)
-    {
-        PointRec2 rec[PPT];
+    // stage this thread's own records (thread-private slots: no barrier between staging and use), STAGE_CH records at a
+    // time: with all PPT records in flight at once (96 VGPRs of loaded values next to their address arithmetic) the compiler
+    // spilled 115 doubles per lane here — 250 KB of scratch per frame pair written once, 2.7x the kernel's compulsory bytes
+    constexpr int STAGE_CH = PPT < 4 ? PPT : 4;
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) {  // unconditional loads from clamped (valid) addresses
+    for (int k0 = 0; k0 < PPT; k0 += STAGE_CH) {
+        PointRec2 rec[STAGE_CH];
+#pragma unroll
+        for (int c = 0; c < STAGE_CH; ++c) {  // unconditional loads from clamped (valid) addresses
+            const int k = k0 + c;
+            if (k >= PPT) continue;
             const int ik = tid + k * BLOCK;
             const size_t i = pbase + (size_t)(ik < n_prev_p ? ik : 0), j = pbase + (size_t)jj[k];
-            rec[k].X = a.prev_P[i * 3 + 0];
-            rec[k].Y = a.prev_P[i * 3 + 1];
-            rec[k].Z = a.prev_P[i * 3 + 2];
-            rec[k].q = a.prev_s2p[i];
-            rec[k].ox = a.curr_pl[j * 2 + 0];
-            rec[k].oy = a.curr_pl[j * 2 + 1];
+            rec[c].X = a.prev_P[i * 3 + 0];
+            rec[c].Y = a.prev_P[i * 3 + 1];
+            rec[c].Z = a.prev_P[i * 3 + 2];
+            rec[c].q = a.prev_s2p[i];
+            rec[c].ox = a.curr_pl[j * 2 + 0];
+            rec[c].oy = a.curr_pl[j * 2 + 1];
         }
 #pragma unroll
-        for (int k = 0; k < PPT; ++k)
+        for (int c = 0; c < STAGE_CH; ++c) {
+            const int k = k0 + c;
+            if (k >= PPT) continue;
             if ((pmatched >> k) & 1u) {
                 const int slot = point_slot(k);
                 if (slot < cap_p) {
                     double2* q = reinterpret_cast<double2*>(s_pts + (size_t)slot * 6);
-                    q[0] = make_double2(rec[k].X, rec[k].Y);
-                    q[1] = make_double2(rec[k].Z, rec[k].ox);
-                    q[2] = make_double2(rec[k].oy, sqrt(rec[k].q));
+                    q[0] = make_double2(rec[c].X, rec[c].Y);
+                    q[1] = make_double2(rec[c].Z, rec[c].ox);
+                    q[2] = make_double2(rec[c].oy, sqrt(rec[c].q));
                 }
             }
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll 1
     for (int k = 0; k < LPT; ++k)

@@ -77,6 +77,20 @@ PM_HD void inverse_se3(const double* T, double* Ti) {
 }
 
 // expmap_se3, twist = (t, w); below theta = 1e-6 R = I and t is NOT multiplied by V.
+// sincos / acos as real calls on the device: inlined, every instance's ~40 polynomial coefficients are hoisted out of the
+// optimiser's iteration loop as 64-bit register constants and then spilled (46 doubles of scratch per lane in pose_kernel2)
+#if defined(__HIP_DEVICE_COMPILE__)
+struct SinCos {
+    double s, c;
+};
+static __device__ __noinline__ SinCos sincos_call(double x) {
+    SinCos r;
+    sincos(x, &r.s, &r.c);
+    return r;
+}
+static __device__ __noinline__ double acos_call(double x) { return acos(x); }
+#endif
+
 PM_HD void expmap_se3(const double* x, double* T) {
     double t0 = x[0], t1 = x[1], t2 = x[2];
     const double w[3] = {x[3], x[4], x[5]};
@@ -91,7 +105,13 @@ PM_HD void expmap_se3(const double* x, double* T) {
         for (int i = 0; i < 9; ++i) s[i] = sk[i] * itheta;
         mat3_mul(s, s, s2);
         double sn, cs;
+#if defined(__HIP_DEVICE_COMPILE__)
+        const SinCos sc = sincos_call(theta);
+        sn = sc.s;
+        cs = sc.c;
+#else
         sincos(theta, &sn, &cs);
+#endif
         const double ka = (1.0 - cs) * itheta, kb = (theta - sn) * itheta;
         double V[9];
 #pragma unroll
@@ -138,7 +158,11 @@ PM_HD void logmap_se3(const double* T, double* x) {
     else if (cosine < -1.0) cosine = -1.0;
     double sine = sqrt(1.0 - cosine * cosine);
     if (sine > 1.0) sine = 1.0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double theta = acos_call(cosine);
+#else
     const double theta = acos(cosine);
+#endif
     if (theta > 0.000001) {
         // skewcoords(theta (R - R^T) / (2 sine)) = (M(2,1), M(0,2), M(1,0))
         w[0] = theta * (R[7] - R[5]) / (2.0 * sine);
