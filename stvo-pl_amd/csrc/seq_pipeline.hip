@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void point_cells_kernel(SeqDev s) {
 // chunks shorten the chain — 2 chunks instead of 8 for ~2000 key-points.
 constexpr int TAIL_BLOCK = 1024;
 __global__ __launch_bounds__(TAIL_BLOCK) void point_tail_kernel(SeqDev s) {
-    __shared__ int s_wave[2][TAIL_BLOCK / 64];
+    __shared__ int s_wave[TAIL_BLOCK / 64];
     __shared__ int s_run;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nl = s.n_kp_l[b];
@@ -246,80 +246,51 @@ __global__ __launch_bounds__(TAIL_BLOCK) void point_tail_kernel(SeqDev s) {
     const stvo_cam cam = s.cams[b];
     if (tid == 0) s_run = 0;
     __syncthreads();
-    // two key-points per thread and trip (i, i + TAIL_BLOCK): every load of both is in flight before the first use, and the
-    // frame is one or two trips instead of two or four chains of dependent loads and barriers
-    for (int base = 0; base < nl; base += 2 * TAIL_BLOCK) {
-        int idx[2], i2[2], level[2];
-        float xl[2], yl[2], xr[2], yr[2];
-        uint4 d0[2], d1[2];
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            idx[r] = base + r * TAIL_BLOCK + tid;
-            const int ic = idx[r] < nl ? idx[r] : 0;
-            i2[r] = idx[r] < nl ? s.m12s_p[off + ic] : -1;
-            xl[r] = s.kp_l[(off + ic) * 2 + 0];
-            yl[r] = s.kp_l[(off + ic) * 2 + 1];
-            level[r] = s.oct_l[off + ic];
-            const uint4* src = reinterpret_cast<const uint4*>(s.desc_l + (off + ic) * STVO_DESC_BYTES);
-            d0[r] = src[0];
-            d1[r] = src[1];
-        }
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int jc = i2[r] >= 0 ? i2[r] : 0;
-            xr[r] = s.kp_r[(off + jc) * 2 + 0];
-            yr[r] = s.kp_r[(off + jc) * 2 + 1];
-        }
-        bool ok[2];
-        double disp[2];
-        int before[2];
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            ok[r] = false;
-            disp[r] = 0.0;
-            if (i2[r] >= 0 && (double)fabsf(yl[r] - yr[r]) <= s.mp.max_dist_epip) {  // float difference (:157)
-                disp[r] = (double)(xl[r] - xr[r]);                                    // float difference (:159)
-                ok[r] = disp[r] >= s.mp.min_disp;
+    for (int base = 0; base < nl; base += TAIL_BLOCK) {
+        const int i = base + tid;
+        bool ok = false;
+        double disp = 0.0;
+        if (i < nl) {
+            const int i2 = s.m12s_p[off + i];
+            if (i2 >= 0) {
+                const float yl = s.kp_l[(off + i) * 2 + 1], yr = s.kp_r[(off + i2) * 2 + 1];
+                if ((double)fabsf(yl - yr) <= s.mp.max_dist_epip) {  // float difference (:157)
+                    disp = (double)(s.kp_l[(off + i) * 2 + 0] - s.kp_r[(off + i2) * 2 + 0]);  // float difference (:159)
+                    ok = disp >= s.mp.min_disp;
+                }
             }
-            // ordered compaction: stereo_pt / pdesc_l keep ascending left index (:161-172)
-            const unsigned long long bal = __ballot(ok[r]);
-            before[r] = __popcll(bal & ((1ull << lane) - 1ull));
-            if (lane == 0) s_wave[r][wv] = __popcll(bal);
+        }
+        // ordered compaction: stereo_pt / pdesc_l keep ascending left index (:161-172)
+        const unsigned long long bal = __ballot(ok);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wave[wv] = __popcll(bal);
+        __syncthreads();
+        int wbase = s_run;
+        for (int w = 0; w < wv; ++w) wbase += s_wave[w];
+        if (ok) {
+            const size_t k = off + (size_t)(wbase + before);
+            const double u = (double)s.kp_l[(off + i) * 2 + 0], v = (double)s.kp_l[(off + i) * 2 + 1];
+            const double bd = cam.b / disp;  // backProjection (src/pinholeStereoCamera.cpp:221-229)
+            s.pl[k * 2 + 0] = u;
+            s.pl[k * 2 + 1] = v;
+            s.P[k * 3 + 0] = bd * (u - cam.cx);
+            s.P[k * 3 + 1] = bd * (v - cam.cy);
+            s.P[k * 3 + 2] = bd * cam.fx;
+            double sg = 1.0;  // PointFeature ctor: sigma2 = 1 / scale^(2 level) (src/stereoFeatures.cpp:41-47)
+            const int level = s.oct_l[off + i];
+            for (int t = 0; t < level; ++t) sg *= s.mp.orb_scale_factor;
+            s.s2[k] = 1.0 / (sg * sg);
+            const uint4* src = reinterpret_cast<const uint4*>(s.desc_l + (off + i) * STVO_DESC_BYTES);
+            uint4* dst = reinterpret_cast<uint4*>(s.desc + k * STVO_DESC_BYTES);
+            dst[0] = src[0];
+            dst[1] = src[1];
         }
         __syncthreads();
-        int wbase[2] = {s_run, s_run};
-        int tot0 = 0, tot1 = 0;
-#pragma unroll
-        for (int w = 0; w < TAIL_BLOCK / 64; ++w) {
-            const int c0 = s_wave[0][w], c1 = s_wave[1][w];
-            if (w < wv) {
-                wbase[0] += c0;
-                wbase[1] += c1;
-            }
-            tot0 += c0;
-            tot1 += c1;
+        if (tid == 0) {
+            int t = 0;
+            for (int w = 0; w < TAIL_BLOCK / 64; ++w) t += s_wave[w];
+            s_run += t;
         }
-        wbase[1] += tot0;  // the second half of the trip follows the whole first half
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-            if (ok[r]) {
-                const size_t k = off + (size_t)(wbase[r] + before[r]);
-                const double u = (double)xl[r], v = (double)yl[r];
-                const double bd = cam.b / disp[r];  // backProjection (src/pinholeStereoCamera.cpp:221-229)
-                s.pl[k * 2 + 0] = u;
-                s.pl[k * 2 + 1] = v;
-                s.P[k * 3 + 0] = bd * (u - cam.cx);
-                s.P[k * 3 + 1] = bd * (v - cam.cy);
-                s.P[k * 3 + 2] = bd * cam.fx;
-                double sg = 1.0;  // PointFeature ctor: sigma2 = 1 / scale^(2 level) (src/stereoFeatures.cpp:41-47)
-                for (int t = 0; t < level[r]; ++t) sg *= s.mp.orb_scale_factor;
-                s.s2[k] = 1.0 / (sg * sg);
-                uint4* dst = reinterpret_cast<uint4*>(s.desc + k * STVO_DESC_BYTES);
-                dst[0] = d0[r];
-                dst[1] = d1[r];
-            }
-        __syncthreads();
-        if (tid == 0) s_run += tot0 + tot1;
         __syncthreads();
     }
     if (tid == 0) {
