@@ -174,6 +174,12 @@ int stvo_seq_push(stvo_seq* seq, const stvo_frame_features* frame, stvo_pose_res
  * frame's features into device slot 0 / 1 (asynchronous), run the pipeline on a resident slot (asynchronous, no
  * host transfer), fetch the results of the last step (synchronises). */
 int stvo_seq_upload(stvo_seq* seq, int slot, const stvo_frame_features* frame);
+/* stvo_seq_upload for features that already live in DEVICE memory — every pointer of `frame`, the count arrays included; oct_l /
+ * oct_ll may be NULL (octave 0, e.g. the one-level ORB front-end below).  Asynchronous on the context's stream; counts are
+ * clamped to the capacities on the device.  Together with stvo_orb_detect_dev: images in, poses out, nothing through the host
+ * (replaces detectStereoPoints + matchStereoPoints + f2fTracking + optimizePose, src/stereoFrame.cpp:88-173,
+ * src/stereoFrameHandler.cpp:106-392). */
+int stvo_seq_upload_dev(stvo_seq* seq, int slot, const stvo_frame_features* frame);
 int stvo_seq_step_dev(stvo_seq* seq, int slot);
 int stvo_seq_read(stvo_seq* seq, stvo_pose_result* results, int32_t* counts);
 

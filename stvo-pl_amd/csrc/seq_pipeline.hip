@@ -536,6 +536,44 @@ struct stvo_seq {
 
 namespace {
 
+// ---- 0: device-resident features (e.g. the output of stvo_orb_detect_dev) into a raw frame slot ------------------------------
+struct IngestArgs {
+    int B, K, M, has_points, has_lines;
+    stvo_frame_features f;  // DEVICE pointers, counts included
+    float* kp_l; int32_t* oct_l; uint8_t* desc_l; int32_t* n_kp_l;
+    float* kp_r; uint8_t* desc_r; int32_t* n_kp_r;
+    float* kl_l; int32_t* oct_ll; uint8_t* ldesc_l; int32_t* n_kl_l;
+    float* kl_r; uint8_t* ldesc_r; int32_t* n_kl_r;
+};
+__global__ __launch_bounds__(256) void seq_ingest_kernel(IngestArgs a) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    auto count = [&](const int32_t* n, int cap, int stride) { return n ? min(max(n[b], 0), min(cap, stride)) : 0; };
+    const int nl = a.has_points ? count(a.f.n_kp_l, a.K, a.f.stride_kp) : 0, nr = a.has_points ? count(a.f.n_kp_r, a.K, a.f.stride_kp) : 0;
+    const int ml = a.has_lines ? count(a.f.n_kl_l, a.M, a.f.stride_kl) : 0, mr = a.has_lines ? count(a.f.n_kl_r, a.M, a.f.stride_kl) : 0;
+    if (tid == 0) {
+        a.n_kp_l[b] = nl;
+        a.n_kp_r[b] = nr;
+        a.n_kl_l[b] = ml;
+        a.n_kl_r[b] = mr;
+    }
+    const size_t sp = (size_t)b * a.f.stride_kp, dp = (size_t)b * a.K, sl = (size_t)b * a.f.stride_kl, dl = (size_t)b * a.M;
+    auto rows32 = [&](const uint8_t* src, uint8_t* dst, int n) {  // 32-byte rows as two 16-byte words
+        const uint4* s4 = reinterpret_cast<const uint4*>(src);
+        uint4* d4 = reinterpret_cast<uint4*>(dst);
+        for (int i = tid; i < 2 * n; i += 256) d4[i] = s4[i];
+    };
+    for (int i = tid; i < 2 * nl; i += 256) a.kp_l[dp * 2 + i] = a.f.kp_l[sp * 2 + i];
+    for (int i = tid; i < nl; i += 256) a.oct_l[dp + i] = a.f.oct_l ? a.f.oct_l[sp + i] : 0;  // no octaves: one pyramid level
+    rows32(a.f.desc_l + sp * 32, a.desc_l + dp * 32, nl);
+    for (int i = tid; i < 2 * nr; i += 256) a.kp_r[dp * 2 + i] = a.f.kp_r[sp * 2 + i];
+    rows32(a.f.desc_r + sp * 32, a.desc_r + dp * 32, nr);
+    for (int i = tid; i < 4 * ml; i += 256) a.kl_l[dl * 4 + i] = a.f.kl_l[sl * 4 + i];
+    for (int i = tid; i < ml; i += 256) a.oct_ll[dl + i] = a.f.oct_ll ? a.f.oct_ll[sl + i] : 0;
+    if (ml) rows32(a.f.ldesc_l + sl * 32, a.ldesc_l + dl * 32, ml);
+    for (int i = tid; i < 4 * mr; i += 256) a.kl_r[dl * 4 + i] = a.f.kl_r[sl * 4 + i];
+    if (mr) rows32(a.f.ldesc_r + sl * 32, a.ldesc_r + dl * 32, mr);
+}
+
 struct Carver {
     size_t off = 0;
     size_t take(size_t bytes) {
@@ -862,6 +900,30 @@ int stvo_seq_upload(stvo_seq* s, int slot, const stvo_frame_features* f) {
     HIP_TRY(ctx, hipEventRecord(s->ev_stage[sb], ctx->stream));
     s->stage_busy[sb] = true;
     return STVO_OK;
+}
+
+// The same for features that are already in device memory (every pointer of `f`, the count arrays included, is a DEVICE
+// pointer; oct_l / oct_ll may be NULL = octave 0).  Enqueued on the context's stream, no host transfer, no synchronisation:
+// counts are clamped to the capacities on the device instead of being validated on the host.
+int stvo_seq_upload_dev(stvo_seq* s, int slot, const stvo_frame_features* f) {
+    if (!s || !f || slot < 0 || slot >= (int)s->raw_dev.size()) return STVO_ERR_INVALID_ARG;
+    if (f->stride_kp < 0 || f->stride_kl < 0) return STVO_ERR_INVALID_ARG;
+    const bool pts = s->op.has_points && f->n_kp_l && f->n_kp_r, lns = s->op.has_lines && f->n_kl_l && f->n_kl_r;
+    if ((pts && (!f->kp_l || !f->desc_l || !f->kp_r || !f->desc_r)) || (lns && (!f->kl_l || !f->ldesc_l || !f->kl_r || !f->ldesc_r)))
+        return STVO_ERR_INVALID_ARG;
+    stvo_ctx* ctx = s->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    char* Rw = s->raw_dev[slot];
+    IngestArgs a{};
+    a.B = s->B; a.K = s->K; a.M = s->M; a.has_points = pts; a.has_lines = lns; a.f = *f;
+    a.kp_l = (float*)(Rw + s->off_kp_l); a.oct_l = (int32_t*)(Rw + s->off_oct_l); a.desc_l = (uint8_t*)(Rw + s->off_desc_l);
+    a.n_kp_l = (int32_t*)(Rw + s->off_nkl); a.kp_r = (float*)(Rw + s->off_kp_r); a.desc_r = (uint8_t*)(Rw + s->off_desc_r);
+    a.n_kp_r = (int32_t*)(Rw + s->off_nkr); a.kl_l = (float*)(Rw + s->off_kl_l); a.oct_ll = (int32_t*)(Rw + s->off_oct_ll);
+    a.ldesc_l = (uint8_t*)(Rw + s->off_ldesc_l); a.n_kl_l = (int32_t*)(Rw + s->off_nll); a.kl_r = (float*)(Rw + s->off_kl_r);
+    a.ldesc_r = (uint8_t*)(Rw + s->off_ldesc_r); a.n_kl_r = (int32_t*)(Rw + s->off_nlr);
+    hipLaunchKernelGGL(seq_ingest_kernel, dim3(s->B), dim3(256), 0, ctx->stream, a);
+    s->raw_lines[slot] = lns;  // the line stage runs whenever line arrays were given (empty sets cost two small launches)
+    return check_launch(ctx);
 }
 
 // Runs the whole per-frame pipeline on the features resident in `slot` (asynchronous; no host transfer).

@@ -21,7 +21,7 @@ EXPORTS = ["stvo_backend_name", "stvo_abi_version", "stvo_error_string", "stvo_c
            "stvo_time_stage_dev", "stvo_valu_peak_probe", "stvo_last_reverse_counts", "stvo_last_reverse_plan", "stvo_ctx_set_kernel_timing", "stvo_ctx_get_kernel_timing", "stvo_seq_create", "stvo_seq_destroy", "stvo_seq_enable_fetch", "stvo_seq_fetch_matches", "stvo_seq_fetch_inliers", "stvo_seq_strides",
            "stvo_seq_push", "stvo_seq_upload", "stvo_seq_step_dev", "stvo_seq_read", "stvo_seq_create_multi", "stvo_seq_set_slots",
            "stvo_seq_set_stage_timing", "stvo_seq_get_stage_timing", "stvo_seq_debug_grid", "stvo_orb_create", "stvo_orb_destroy",
-           "stvo_orb_set_pattern", "stvo_orb_get_pattern", "stvo_orb_detect", "stvo_orb_detect_dev"]
+           "stvo_orb_set_pattern", "stvo_orb_get_pattern", "stvo_orb_detect", "stvo_orb_detect_dev", "stvo_seq_upload_dev"]
 
 SEQ_NSTAGE = 5  # include/stvo_hip.h: STVO_SEQ_NSTAGE
 SEQ_STAGE_NAMES = ("stereo_points_stage", "grid_scan", "hamming_knn2", "reverse_check", "pose")
@@ -135,6 +135,7 @@ def load():
     L.stvo_seq_destroy.argtypes = [C.c_void_p]
     L.stvo_seq_push.argtypes = [C.c_void_p, C.POINTER(FrameFeatures), C.c_void_p, i32p]
     L.stvo_seq_upload.argtypes = [C.c_void_p, C.c_int, C.POINTER(FrameFeatures)]
+    L.stvo_seq_upload_dev.argtypes = [C.c_void_p, C.c_int, C.POINTER(FrameFeatures)]
     L.stvo_seq_step_dev.argtypes = [C.c_void_p, C.c_int]
     L.stvo_seq_read.argtypes = [C.c_void_p, C.c_void_p, i32p]
     pp32 = C.POINTER(C.POINTER(C.c_int32))
@@ -334,6 +335,10 @@ class Orb:
         return [dict(kp=kp[b, :n[b]].copy(), response=resp[b, :n[b]].copy(), angle=ang[b, :n[b]].copy(), desc=desc[b, :n[b]].copy())
                 for b in range(self.B)]
 
+    def detect_dev(self, img, kp, resp, ang, desc, n):
+        """Device buffers (integers = device addresses): images in, key-points / descriptors out, on the context's stream."""
+        self.ctx._chk(self.ctx.lib.stvo_orb_detect_dev(self.h, img, kp, resp, ang, desc, n))
+
 
 class Sequences:
     """B independent stereo sequences on the device-resident per-frame pipeline (stvo_seq_*)."""
@@ -421,6 +426,10 @@ class Sequences:
         ff, keep = self._pack(frames)
         self.ctx._chk(self.ctx.lib.stvo_seq_upload(self.h, slot, C.byref(ff)))
         self.ctx.synchronize()
+
+    def upload_dev(self, slot, ff):
+        """ff: FrameFeatures whose pointers (count arrays included) are DEVICE pointers; asynchronous."""
+        self.ctx._chk(self.ctx.lib.stvo_seq_upload_dev(self.h, slot, C.byref(ff)))
 
     def step_dev(self, slot):
         self.ctx._chk(self.ctx.lib.stvo_seq_step_dev(self.h, slot))

@@ -404,3 +404,44 @@ def make_image(seed, cols=1241, rows=376, n_rects=1000, n_discs=250, noise=3.0):
         img[m] = rng.uniform(15, 240)
     img += rng.normal(0.0, noise, img.shape)
     return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def make_stereo_image_sequence(seed, n_frames, cam, disparities=(8, 12, 16, 24, 32), shift_per_disp=0.3, cover=0.3):
+    """Rectified stereo IMAGE pairs of a camera translating along +x past fronto-parallel textured layers: a layer of disparity d
+    appears d pixels further left in the right image and moves round(shift_per_disp * d) pixels to the left per frame (integer
+    shifts, so every view is an exact crop — no resampling; the rounding leaves residuals of a few tenths of a pixel, like the
+    quantisation of real key-points).  Nearer layers cover `cover` of the layer behind them.  Ground truth: tx ~ shift_per_disp * b
+    per frame.  Returns [(left, right)] uint8 [rows, cols]."""
+    cols, rows = cam["width"], cam["height"]
+    disparities = sorted(disparities)
+    shifts = [int(round(shift_per_disp * d)) for d in disparities]
+    margin = max(d + n_frames * sh for d, sh in zip(disparities, shifts)) + 8
+    W = cols + margin
+    rng = np.random.default_rng(seed + 1)
+    layers, masks = [], []
+    for li, d in enumerate(disparities):
+        layers.append(make_image(seed + 7919 * li, W, rows, n_rects=int(1000 * W / 1241), n_discs=int(250 * W / 1241)))
+        m = np.zeros((rows, W), bool)
+        if li > 0:  # blobs of this layer in front of everything farther away
+            while m.mean() < cover:
+                w, h = rng.integers(40, 160), rng.integers(30, 100)
+                x0, y0 = rng.integers(0, W - w), rng.integers(0, rows - h)
+                m[y0:y0 + h, x0:x0 + w] = True
+        else:
+            m[:] = True
+        masks.append(m)
+    out = []
+    for k in range(n_frames):
+        views = []
+        for right in (0, 1):
+            v = None
+            for layer, m, d, sh in zip(layers, masks, disparities, shifts):
+                o = k * sh + right * d
+                if v is None:
+                    v = layer[:, o:o + cols].copy()
+                else:
+                    mm = m[:, o:o + cols]
+                    v[mm] = layer[:, o:o + cols][mm]
+            views.append(v)
+        out.append((views[0], views[1]))
+    return out

@@ -1,0 +1,55 @@
+"""Images in, poses out on the device (stvo_orb_detect_dev -> stvo_seq_upload_dev -> stvo_seq_step_dev) against the same chain
+on the CPU: the ORB oracle on every image, its key-points / descriptors through the oracle-driven per-frame pipeline."""
+import numpy as np
+import pytest
+
+import np_model
+import pipeline_ref
+from stvo_amd import synth
+from stvo_amd.ctypes_types import match_params, opt_params
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_frames(oracle, pairs, pattern):
+    frames = []
+    for left, right in pairs:
+        l, r = oracle.orb_detect(left, pattern=pattern), oracle.orb_detect(right, pattern=pattern)
+        frames.append(dict(kp_l=l["kp"], oct_l=np.zeros(len(l["kp"]), np.int32), desc_l=l["desc"], kp_r=r["kp"], desc_r=r["desc"],
+                           kl_l=np.zeros((0, 4), np.float32), oct_ll=np.zeros(0, np.int32), ldesc_l=np.zeros((0, 32), np.uint8),
+                           kl_r=np.zeros((0, 4), np.float32), ldesc_r=np.zeros((0, 32), np.uint8)))
+    return frames
+
+
+def test_images_to_poses_two_streams(oracle):
+    from stvo_amd import capi, images
+    cam = dict(synth.KITTI_CAM, width=640, height=240)   # smaller images keep the CPU side of the test short
+    mp = match_params("kitti"); op = opt_params("kitti", has_lines=0)
+    B, nf = 2, 4
+    seqs = [synth.make_stereo_image_sequence(50 + b, nf, cam, shift_per_disp=0.3 - 0.05 * b) for b in range(B)]
+    ctx = capi.Context(device_id=0, max_rows=2048, max_batch=B)
+    pipe = images.ImagePipeline(ctx, B, cam, mp, op, max_kp=2048)
+    n_committed = 0
+    try:
+        pattern = pipe.orb.pattern()
+        frames = [oracle_frames(oracle, seqs[b], pattern) for b in range(B)]
+        refs = [pipeline_ref.run_sequence(oracle, frames[b], cam, mp, op) for b in range(B)]
+        for k in range(nf):
+            res, counts = pipe.push_images(np.stack([seqs[b][k][0] for b in range(B)]), np.stack([seqs[b][k][1] for b in range(B)]))
+            if k == 0:
+                continue
+            for b in range(B):
+                o, r = refs[b][k - 1], res[b]
+                assert counts[b, 0] == o["n_stereo_pt"] and r["n_matched_pt"] == o["n_matched_pt"], (b, k, counts[b], o["n_stereo_pt"])
+                assert r["status"] == o["status"] and r["path"] == o["path"] and tuple(r["iters"]) == o["iters"]
+                assert r["n_inliers_pt"] == o["n_inliers_pt"]
+                T = r["T"].reshape(4, 4)
+                assert np_model.rot_angle(T[:3, :3], o["T"][:3, :3]) < 1e-4 and np.linalg.norm(T[:3, 3] - o["T"][:3, 3]) < 1e-3
+                assert np.allclose(T, o["T"], atol=1e-8)
+                if r["status"] == 0:  # the scene: a camera translating a few tenths of the baseline along +x per frame
+                    n_committed += 1
+                    assert 0.05 < abs(T[0, 3]) < 0.3 and abs(T[1, 3]) < 0.05 and abs(T[2, 3]) < 0.1, T[:3, 3]
+        assert n_committed >= 3
+    finally:
+        pipe.close()
+        ctx.close()
