@@ -291,6 +291,49 @@ def orb_leg(local_rank, B=256):
                                  "key-point records (the score / keep maps are intermediate)"}}
 
 
+def images_leg(local_rank, B=128, steps=8):
+    """SURVEY 8(f) rank 3 joined to the hot path: stereo IMAGES in, poses out, nothing through the host — the ORB point
+    front-end on 2 B KITTI-size images, its key-points ingested on the device (stvo_seq_upload_dev), then the per-frame pipeline
+    (grid stereo association, f2f, optimizePose) for B streams.  Key-points only: the LSD / LBD line front-end is not built."""
+    import torch
+    from stvo_amd import capi, images, synth
+    from stvo_amd.ctypes_types import match_params, opt_params
+    cam = synth.KITTI_CAM
+    nf = 4
+    base = [synth.make_stereo_image_sequence(900 + j, nf, cam) for j in range(2)]
+    dev = f"cuda:{local_rank}"
+    frames = torch.empty((nf, 2 * B, cam["height"], cam["width"]), dtype=torch.uint8, device=dev)
+    for k in range(nf):
+        for side in (0, 1):
+            for b in range(B):  # streams = the two scenes, rolled horizontally (the seam is a vertical edge like any other)
+                frames[k, side * B + b] = torch.from_numpy(np.roll(base[b % 2][k][side], 11 * (b // 2), axis=1))
+    ctx = capi.Context(device_id=local_rank, max_rows=2048, max_batch=B)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    pipe = images.ImagePipeline(ctx, B, cam, match_params("kitti"), opt_params("kitti", has_lines=0), max_kp=2048, device=dev)
+    order = [0, 1, 2, 3, 2, 1]  # consecutive views are always neighbours of the same scene
+    try:
+        for k in (0, 1):
+            pipe.enqueue(frames[k].data_ptr())
+        pipe.seq.read()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ok = 0
+        for i in range(steps):
+            pipe.enqueue(frames[order[(i + 2) % len(order)]].data_ptr())
+        res, counts = pipe.seq.read()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        ok = float((res["status"] == 0).mean())
+        nk = float(pipe.n.float().mean())
+    finally:
+        pipe.close(); ctx.close()
+    return {"workload": f"{B} stereo streams of 1241 x 376 image pairs resident in HBM (two synthetic layered scenes, rolled per stream), "
+                        "orb_nfeatures 2000, one pyramid level, key-points only; per step: ORB on 2 B images -> device ingest -> grid stereo "
+                        "association -> f2f -> optimizePose", "stereo_pairs_per_s": B / dt, "ms_per_step": dt * 1e3, "streams": B,
+            "mean_keypoints_per_image": nk, "committed_pose_fraction_last_step": ok, "mean_stereo_points_last_step": float(counts[:, 0].mean()),
+            "mean_matched_points_last_step": float(counts[:, 2].mean())}
+
+
 CORRELATED_MODELS = {
     "clustered": dict(cluster_frac=0.6, cluster_size=8, spread_p=0.06),
     "heavily_clustered": dict(cluster_frac=0.9, cluster_size=16, spread_p=0.04),
@@ -513,6 +556,7 @@ def main():
         out["configs1"] = configs1_leg(dev_name, rank)
         out["reverse_check_correlated"] = correlated_leg(dev_name, rank)
         out["orb_front_end"] = orb_leg(local_rank)
+        out["images_to_poses"] = images_leg(local_rank)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.points, args.lines)
         out["cpu_baseline_threads"] = cpu_baseline_threads(args.points, args.lines)

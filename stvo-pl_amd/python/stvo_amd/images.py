@@ -45,9 +45,10 @@ class ImagePipeline:
         self.img[:B].copy_(torch.as_tensor(left).reshape(B, self.rows, self.cols), non_blocking=True)
         self.img[B:].copy_(torch.as_tensor(right).reshape(B, self.rows, self.cols), non_blocking=True)
 
-    def enqueue(self):
-        """Detection + description of the 2 B resident images, ingestion, one pipeline step — all asynchronous."""
-        self.orb.detect_dev(self.img.data_ptr(), self.kp.data_ptr(), self.resp.data_ptr(), self.ang.data_ptr(), self.desc.data_ptr(),
+    def enqueue(self, img_ptr=None):
+        """Detection + description of the 2 B resident images (or of the uint8 [2 B, rows, cols] device buffer at img_ptr: B left,
+        then B right), ingestion, one pipeline step — all asynchronous."""
+        self.orb.detect_dev(img_ptr if img_ptr is not None else self.img.data_ptr(), self.kp.data_ptr(), self.resp.data_ptr(), self.ang.data_ptr(), self.desc.data_ptr(),
                             self.n.data_ptr())
         self.seq.upload_dev(self.slot, self.ff)
         self.seq.step_dev(self.slot)
