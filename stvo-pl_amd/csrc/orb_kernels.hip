@@ -44,7 +44,8 @@ __device__ __constant__ int8_t c_circle[16][2] = {{0, 3},  {1, 3},   {2, 2},   {
                                                   {0, -3}, {-1, -3}, {-2, -2}, {-3, -1}, {-3, 0}, {-3, 1}, {-2, 2}, {-1, 3}};
 
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;  // a word at any byte address (gfx950 global memory allows it)
-constexpr int FT_W = 64, FT_H = 16;               // output tile of the fused FAST + NMS kernel
+constexpr int FT_W = 64, FT_H = 64;               // output tile of the fused FAST + NMS kernel (a workgroup's life is a chain of
+                                                  // memory round trips and barriers: 64 x 32 halves their share against 64 x 16)
 constexpr int SC_W = FT_W + 2, SC_H = FT_H + 2;   // scores are needed one pixel beyond the tile (3x3 maximum test)
 constexpr int IM_H = FT_H + 8;                    // image tile rows: + 1 (score halo) + 3 (circle radius) on both sides
 constexpr int IM_DW = 19, IM_PITCH = 20;          // image tile row: 19 words = pixels x0 - 5 .. x0 + 70 (score position sx <-> byte sx + 4: word aligned)
@@ -104,21 +105,26 @@ __device__ __forceinline__ void append4(const bool (&flag)[4], int* counter, int
     }
 }
 
-// FAST-9/16 + non-maximum suppression + border filter of one 64 x 16 tile, entirely in LDS, four pixels per thread and step:
+// FAST-9/16 + non-maximum suppression + border filter of one 64 x 32 tile, entirely in LDS:
 //   1. the image tile (+ halo) is staged once, word by word (unaligned global words; byte by byte only at the image border);
-//   2. every score position (tile + halo 1) takes the cheap compass-point test (any arc of 9 contiguous circle pixels holds
-//      at least two of the four compass points) on words: centre / north / south words and the east / west ones by byte
-//      alignment; the few survivors are COMPACTED into a list, so that
-//   3. the 150-instruction corner score runs on dense lanes (it used to run for a whole wave whenever one lane needed it);
-//   4. a pixel whose score beats its 8 neighbours (and lies inside the border) is appended to the image's candidate list and
-//      counted in the response histogram — no score / keep maps ever reach global memory.
+//   2. every score position (tile + halo 1) takes a cheap NECESSARY test, four positions per thread on words: an arc of 9
+//      contiguous circle pixels holds at least two of the four compass points, so a corner has sum |compass - centre| >= 2 (t + 1).
+//      The 4 x 4 bytes (north, south, east, west of four pixels; east / west by byte alignment) are transposed with v_perm_b32
+//      and each pixel's sum is ONE v_sad_u8 — 8 instructions per pixel instead of the 26 of the signed compass test;
+//   3. the survivors (~15 % of the positions) are COMPACTED into a list, so that the signed compass test (at least two compass
+//      points brighter, or two darker, than the centre by more than t) and the 150-instruction corner score run on dense lanes;
+//      the scores go to an LDS tile and the corners to a second list;
+//   4. non-maximum suppression walks that corner list (~3 % of the positions), not the tile; a corner that beats its 8
+//      neighbours and lies inside the border is appended to the image's candidate list and counted in the response histogram —
+//      no score / keep maps ever reach global memory.
 __global__ __launch_bounds__(256) void orb_fast_nms_kernel(OrbDev o) {
     __shared__ uint32_t tile[IM_H][IM_PITCH];
     __shared__ uint32_t sc_w[SC_H][SC_PITCH / 4];
     __shared__ uint16_t s_list[SC_H * SC_W + 8];
-    __shared__ uint32_t s_kp[256];  // key-points of this tile (a 3x3 maximum every 4 pixels at most: 64 x 16 / 4)
-    __shared__ int s_n, s_nkp, s_base;
-    const int b = blockIdx.z, x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H, tid = threadIdx.x;
+    __shared__ uint16_t s_corner[SC_H * SC_W + 8];
+    __shared__ uint32_t s_kp[FT_W * FT_H / 4];  // key-points of this tile (a 3x3 maximum every 4 pixels at most)
+    __shared__ int s_n, s_nc, s_nkp, s_base;
+    const int b = blockIdx.z, x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H, tid = threadIdx.x, lane = tid & 63;
     const uint8_t* img = o.img + (size_t)b * o.rows * o.cols;
     const uint8_t* tile8 = reinterpret_cast<const uint8_t*>(&tile[0][0]);
     uint8_t* sc = reinterpret_cast<uint8_t*>(&sc_w[0][0]);
@@ -139,12 +145,14 @@ __global__ __launch_bounds__(256) void orb_fast_nms_kernel(OrbDev o) {
     for (int i = tid; i < SC_H * (SC_PITCH / 4); i += 256) (&sc_w[0][0])[i] = 0u;
     if (tid == 0) {
         s_n = 0;
+        s_nc = 0;
         s_nkp = 0;
     }
     __syncthreads();
     const int t = o.fast_th;
     // (all lanes of a wave run the same number of trips: the ballots of append4 need the whole wave)
     constexpr int GROUPS = (SC_W + 3) / 4;  // 17 groups of four score positions per row
+    const uint32_t sad_min = 2u * (uint32_t)(t + 1);
     for (int i0 = 0; i0 < SC_H * GROUPS; i0 += 256) {
         const int i = i0 + tid;
         const bool item = i < SC_H * GROUPS;
@@ -152,16 +160,22 @@ __global__ __launch_bounds__(256) void orb_fast_nms_kernel(OrbDev o) {
         const int r = sy + 3, y = y0 + sy - 1;
         const uint32_t C = tile[r][g + 1], L = tile[r][g], R = tile[r][g + 2], N = tile[r - 3][g + 1], S = tile[r + 3][g + 1];
         const uint32_t W4 = __builtin_amdgcn_alignbyte(C, L, 1), E4 = __builtin_amdgcn_alignbyte(R, C, 3);
+        // 4 x 4 byte transpose: Q[j] = (N, S, E, W) of pixel j
+        const uint32_t ns01 = __builtin_amdgcn_perm(S, N, 0x05010400u), ns23 = __builtin_amdgcn_perm(S, N, 0x07030602u);
+        const uint32_t ew01 = __builtin_amdgcn_perm(W4, E4, 0x05010400u), ew23 = __builtin_amdgcn_perm(W4, E4, 0x07030602u);
+        uint32_t Q[4];
+        Q[0] = __builtin_amdgcn_perm(ew01, ns01, 0x05040100u);
+        Q[1] = __builtin_amdgcn_perm(ew01, ns01, 0x07060302u);
+        Q[2] = __builtin_amdgcn_perm(ew23, ns23, 0x05040100u);
+        Q[3] = __builtin_amdgcn_perm(ew23, ns23, 0x07060302u);
         const bool row_ok = item && y >= 3 && y < o.rows - 3;
+        const int xb = x0 + 4 * g - 1;  // image column of pixel 0
         bool cand[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int sx = 4 * g + j, x = x0 + sx - 1;
-            const int v = (int)((C >> (8 * j)) & 255u);
-            const int c0 = (int)((S >> (8 * j)) & 255u) - v, c4 = (int)((E4 >> (8 * j)) & 255u) - v;
-            const int c8 = (int)((N >> (8 * j)) & 255u) - v, c12 = (int)((W4 >> (8 * j)) & 255u) - v;
-            const int nb = (c0 > t) + (c4 > t) + (c8 > t) + (c12 > t), nd = (c0 < -t) + (c4 < -t) + (c8 < -t) + (c12 < -t);
-            cand[j] = row_ok && sx < SC_W && x >= 3 && x < o.cols - 3 && (nb >= 2 || nd >= 2);
+            const uint32_t V = __builtin_amdgcn_perm(C, C, 0x01010101u * (uint32_t)j);  // the centre in all four bytes
+            const uint32_t sad = __builtin_amdgcn_sad_u8(Q[j], V, 0u);
+            cand[j] = row_ok && 4 * g + j < SC_W && xb + j >= 3 && xb + j < o.cols - 3 && sad >= sad_min;
         }
         int slot[4];
         append4(cand, &s_n, slot);
@@ -171,46 +185,52 @@ __global__ __launch_bounds__(256) void orb_fast_nms_kernel(OrbDev o) {
     }
     __syncthreads();
     const int n = s_n;
-    for (int j = tid; j < n; j += 256) {
+    for (int j = tid; j < n; j += 256) {  // lanes of a wave carry consecutive j: lane 0 is active whenever any lane is
         const int i = s_list[j], sy = i / SC_W, sx = i - sy * SC_W;
-        const int s = fast_score_lds(tile8, sx + 4, sy + 3);
-        if (s >= t) sc[sy * SC_PITCH + sx] = (uint8_t)s;  // t >= 1, so a corner's score is positive
+        const uint8_t* c = tile8 + (sy + 3) * (IM_PITCH * 4) + (sx + 4);
+        const int v = c[0];
+        // the signed compass test on the dense list (circle points 0, 4, 8, 12 = south, east, north, west)
+        const int c0 = (int)c[3 * (IM_PITCH * 4)] - v, c4 = (int)c[3] - v, c8 = (int)c[-3 * (IM_PITCH * 4)] - v, c12 = (int)c[-3] - v;
+        const int nb = (c0 > t) + (c4 > t) + (c8 > t) + (c12 > t), nd = (c0 < -t) + (c4 < -t) + (c8 < -t) + (c12 < -t);
+        int s = 0;
+        if (nb >= 2 || nd >= 2) s = fast_score_lds(tile8, sx + 4, sy + 3);
+        const bool corner = s >= t;  // t >= 1, so a corner's score is positive
+        if (corner) sc[sy * SC_PITCH + sx] = (uint8_t)s;
+        const unsigned long long bal = __ballot(corner);
+        int base = 0;
+        if (lane == 0 && bal) base = atomicAdd(&s_nc, __popcll(bal));
+        base = __shfl(base, 0, 64);
+        if (corner) s_corner[base + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)i;
     }
     __syncthreads();
-    {  // 64 x 16 pixels = 256 threads x 4: thread -> row py, pixels 4 h .. 4 h + 3; score rows py .. py + 2, bytes 4 h .. 4 h + 5
-        const int py = tid >> 4, h = tid & 15, y = y0 + py;
-        unsigned long long rw[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) rw[k] = (unsigned long long)sc_w[py + k][h] | ((unsigned long long)sc_w[py + k][h + 1] << 32);
-        bool kp[4];
-        uint32_t word[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int x = x0 + 4 * h + j;
-            const uint32_t top = (uint32_t)(rw[0] >> (8 * j)) & 0xFFFFFFu, mid = (uint32_t)(rw[1] >> (8 * j)) & 0xFFFFFFu,
-                           bot = (uint32_t)(rw[2] >> (8 * j)) & 0xFFFFFFu;
-            const uint32_t s = (mid >> 8) & 255u;
-            const uint32_t m8 = max(max(max(top & 255u, (top >> 8) & 255u), max(top >> 16, mid & 255u)),
-                                    max(max(mid >> 16, bot & 255u), max((bot >> 8) & 255u, bot >> 16)));
+    const int nc = s_nc;
+    for (int j = tid; j < nc; j += 256) {
+        const int i = s_corner[j], sy = i / SC_W, sx = i - sy * SC_W;
+        const int x = x0 + sx - 1, y = y0 + sy - 1;
+        bool kp = false;
+        uint32_t s = 0u;
+        if (sy >= 1 && sy <= FT_H && sx >= 1 && sx <= FT_W && x < o.cols && y < o.rows) {  // inside the tile proper (the halo only serves as neighbours)
+            const uint8_t* q = sc + sy * SC_PITCH + sx;
+            s = q[0];
+            const uint32_t m8 = max(max(max((uint32_t)q[-SC_PITCH - 1], (uint32_t)q[-SC_PITCH]), max((uint32_t)q[-SC_PITCH + 1], (uint32_t)q[-1])),
+                                    max(max((uint32_t)q[1], (uint32_t)q[SC_PITCH - 1]), max((uint32_t)q[SC_PITCH], (uint32_t)q[SC_PITCH + 1])));
             // 3x3 strict maximum, then KeyPointsFilter::runByImageBorder
-            kp[j] = s != 0u && s > m8 && x < o.cols && y < o.rows && x >= o.edge_th && x < o.cols - o.edge_th && y >= o.edge_th &&
-                    y < o.rows - o.edge_th;
-            word[j] = ((uint32_t)y << 20) | ((uint32_t)x << 8) | s;
+            kp = s > m8 && x >= o.edge_th && x < o.cols - o.edge_th && y >= o.edge_th && y < o.rows - o.edge_th;
         }
-        int slot[4];
-        append4(kp, &s_nkp, slot);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (kp[j]) s_kp[slot[j]] = word[j];
+        const unsigned long long bal = __ballot(kp);
+        int base = 0;
+        if (lane == 0 && bal) base = atomicAdd(&s_nkp, __popcll(bal));
+        base = __shfl(base, 0, 64);
+        if (kp) s_kp[base + __popcll(bal & ((1ull << lane) - 1ull))] = ((uint32_t)y << 20) | ((uint32_t)x << 8) | s;
     }
     __syncthreads();
     const int nkp = s_nkp;
     if (nkp == 0) return;
     if (tid == 0) s_base = atomicAdd(&o.n_cand[b], nkp);  // ONE global reservation per tile
     __syncthreads();
-    if (tid < nkp) {
-        const uint32_t c = s_kp[tid];
-        const int slot = s_base + tid;
+    for (int k = tid; k < nkp; k += 256) {
+        const uint32_t c = s_kp[k];
+        const int slot = s_base + k;
         if (slot < CAND_CAP) o.cand[(size_t)b * CAND_CAP + slot] = c;
         atomicAdd(&o.hist[(size_t)b * 256 + (c & 255u)], 1);
     }
