@@ -1,7 +1,7 @@
 // orb_kernels.hip — the ORB point front-end on gfx950: what the reference obtains from
 //     cv::ORB::create(...)->detectAndCompute(img, Mat(), points, pdesc, false)     (/root/reference/src/stereoFrame.cpp:104-118)
 // for ONE pyramid level (config_kitti.yaml: orb_nlevels 1), FAST_SCORE ranking (orb_score 1), WTA_K 2, patch 31:
-//   orb_fast_nms_kernel  FAST-9/16 score (cornerScore<16>) + 3x3 non-maximum suppression + border filter per 64 x 16 tile, all in
+//   orb_fast_nms_kernel  FAST-9/16 score (cornerScore<16>) + 3x3 non-maximum suppression + border filter per 64 x 64 tile, all in
 //                        LDS: compass-point rejection, candidates compacted so that the full score runs on dense lanes;
 //                        survivors go to a per-image list + response histogram (no score map in global memory)
 //   orb_order_kernel     KeyPointsFilter::retainBest as a histogram cut (ties kept) + row-major ordering (bitonic sort in LDS)
