@@ -11,13 +11,15 @@
 namespace stvo {
 
 constexpr int KNN_MIN_NSEG = 2, KNN_MAX_NSEG = 16;  // train-range segments per query tile in K1
-// Segments per query tile: 2 for big batches (short dispatch rounds), up to 16 for a single frame pair so
+// Segments per query tile: 1 for very big batches, 2 for big ones (short dispatch rounds), up to 16 for a single frame pair so
 // that one 2000 x 2000 problem still spreads over a few hundred workgroups (single-stream latency).
 // `capacity` = elements of the context's knn scratch arrays: nseg * B * max_n must fit.
 inline int knn_pick_nseg(int B, int max_n, size_t capacity) {
     const int tiles = (max_n + 255) / 256;
     int nseg = (2048 + B * tiles - 1) / (B * tiles > 0 ? B * tiles : 1);
     nseg = nseg < KNN_MIN_NSEG ? KNN_MIN_NSEG : (nseg > KNN_MAX_NSEG ? KNN_MAX_NSEG : nseg);
+    if ((long long)B * tiles >= 4096) nseg = 1;  // >= 5 dispatch rounds even unsegmented: a workgroup's fixed cost is paid once per query tile
+                                                 // (1024 frames: K1m 0.562 -> 0.551 ms, reverse check 0.054 -> 0.050 ms)
     if (const char* e = std::getenv("STVO_KNN_NSEG")) nseg = std::atoi(e) > 0 ? std::atoi(e) : nseg;  // developer override
     const size_t per_seg = (size_t)(B > 0 ? B : 1) * (size_t)(max_n > 0 ? max_n : 1);
     while (nseg > 1 && (size_t)nseg * per_seg > capacity) --nseg;
