@@ -393,7 +393,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=6)
-    ap.add_argument("--batch", type=int, default=1024, help="independent stereo sequences (streams) per GPU")
+    ap.add_argument("--batch", type=int, default=1024, help="independent stereo sequences (streams) per GPU; the committed PMC passes (roofline traffic) are of this default")
     ap.add_argument("--slots", type=int, default=4, help="consecutive frames of every stream kept resident in HBM")
     ap.add_argument("--points", type=int, default=1650, help="landmarks per stream; + 20 %% distractors ~ 2000 key-points per image")
     ap.add_argument("--lines", type=int, default=85, help="3-D segments per stream; + 20 %% distractors ~ 100 key-lines per image")
