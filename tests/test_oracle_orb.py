@@ -93,3 +93,28 @@ def test_descriptor_bits_from_an_independent_statement(oracle):
         ix1 = np.rint(pat[:, 2] * a - pat[:, 3] * b).astype(int); iy1 = np.rint(pat[:, 2] * b + pat[:, 3] * a).astype(int)
         bits = (blur[y + iy0, x + ix0] < blur[y + iy1, x + ix1]).astype(np.uint8)
         assert np.array_equal(np.packbits(bits, bitorder="little"), r["desc"][n]), n
+
+
+def test_image_sequences_drive_the_oracle_chain(oracle):
+    """The CPU side of tests/test_gpu_images.py on its own: ORB oracle on synthetic layered stereo image sequences, its key-points
+    through the oracle pipeline — stereo disparities are the layers', and committed poses translate along x."""
+    import pipeline_ref
+    from stvo_amd import synth
+    from stvo_amd.ctypes_types import match_params, opt_params
+    cam = dict(synth.KITTI_CAM, width=640, height=240)
+    mp = match_params("kitti"); op = opt_params("kitti", has_lines=0)
+    pairs = synth.make_stereo_image_sequence(50, 4, cam)
+    frames = []
+    for left, right in pairs:
+        l, r = oracle.orb_detect(left), oracle.orb_detect(right)
+        frames.append(dict(kp_l=l["kp"], oct_l=np.zeros(len(l["kp"]), np.int32), desc_l=l["desc"], kp_r=r["kp"], desc_r=r["desc"],
+                           kl_l=np.zeros((0, 4), np.float32), oct_ll=np.zeros(0, np.int32), ldesc_l=np.zeros((0, 32), np.uint8),
+                           kl_r=np.zeros((0, 4), np.float32), ldesc_r=np.zeros((0, 32), np.uint8)))
+    st = pipeline_ref.stereo_frame(oracle, frames[0], cam, mp, True, False)
+    disp = np.round(cam["fx"] * cam["b"] / st["P"][:, 2]).astype(int)
+    assert np.isin(disp, [8, 12, 16, 24, 32]).mean() > 0.9 and len(st["P"]) > 300   # a few wrong associations survive the filters
+    res = pipeline_ref.run_sequence(oracle, frames, cam, mp, op)
+    good = [o for o in res if o["status"] == 0]
+    assert len(good) >= 2
+    for o in good:
+        assert 0.05 < abs(o["T"][0, 3]) < 0.3 and abs(o["T"][1, 3]) < 0.05
