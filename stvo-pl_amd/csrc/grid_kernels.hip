@@ -411,18 +411,17 @@ __global__ __launch_bounds__(256) void grid_finalize_kernel(GridBatch g) {
 // look at every eligible pair that is not the best for the ratio test (:160, pairwise as in the scan formulation), then one
 // thread per left row applies the mutual check (:166-174).  A right feature with more than 16 candidates (rare) is taken by
 // its whole wave, lane = candidate, keys in LDS.  Frames with more such keys than the LDS holds are flagged and run the scan
-// formulation above in grid_points_misfit_kernel, launched right behind.
+// formulation above by the same workgroup after its last frame (fused_misfit_frame).
 constexpr int FUSED_T = 1024, FUSED_ROWS = 2048, FUSED_REG = 16;
 constexpr int FUSED_LW = GRID_LW;  // left key-points up to 16 columns right of the grid still have candidates
 constexpr int FUSED_PADDED = FUSED_ROWS + FUSED_REG;          // the unrolled walks read up to 15 rows past a range
 constexpr int FUSED_KEY_CAP = 8192;                           // keys of the right features with more than 16 candidates, whole frame
 constexpr size_t FUSED_LDS = (size_t)FUSED_PADDED * (16 + 16 + 2) + (size_t)FUSED_ROWS * (4 + 2 + 1) + (size_t)FUSED_KEY_CAP * 4;
 
-// the scan formulation for the frames the fused kernel flagged (launched right behind it; a workgroup whose frame fitted returns
-// at once): 16 waves over the blocks of 64 scan positions
-__global__ __launch_bounds__(FUSED_T) void grid_points_misfit_kernel(GridBatch g) {
-    if (g.misfit[blockIdx.x] == 0) return;
-    const GridArgs a = frame_view(g, blockIdx.x);
+// the scan formulation for a frame the fused kernel flagged (run by the same workgroup after its last frame): 16 waves over the
+// blocks of 64 scan positions
+__device__ __forceinline__ void fused_misfit_frame(const GridBatch& g, const int f) {
+    const GridArgs a = frame_view(g, f);
     const int stride1 = g.stride1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int blocks = (a.n2 + 63) >> 6;
@@ -544,6 +543,8 @@ __global__ __launch_bounds__(FUSED_T) void grid_points_fused_kernel(GridBatch g,
     FusedNext nx;
     int f = blockIdx.x;
     if (f >= g.B) return;
+    unsigned long long misfit_mask = 0ull;  // bit i: the i-th frame of this workgroup is left to the scan formulation (block-uniform)
+    int trip = 0;
     fused_fetch1(g, f, nx);
     fused_fetch2(g, f, nx);
     for (; f < g.B; f += gridDim.x) {
@@ -671,6 +672,8 @@ __global__ __launch_bounds__(FUSED_T) void grid_points_fused_kernel(GridBatch g,
         __syncthreads();
         const bool misfit = s_ctl[1] != 0;  // block-uniform
         if (tid == 0) g.misfit[f] = misfit;
+        if (misfit && trip < 64) misfit_mask |= 1ull << trip;
+        ++trip;
         if (!misfit) {
             // ---- :160 for every eligible pair that is not its left row's best: best_d < d * minRatio12P in DOUBLE, else the row is out
 #pragma unroll
@@ -720,6 +723,17 @@ __global__ __launch_bounds__(FUSED_T) void grid_points_fused_kernel(GridBatch g,
         }
         if (more) __syncthreads();  // the next frame's commit overwrites what the phase above reads
     }
+    // frames that did not fit (rare): the scan formulation, by the workgroup that flagged them — no second launch
+    if (misfit_mask != 0ull || trip > 64) {
+        int i = 0;
+        for (int fm = blockIdx.x; fm < g.B; fm += gridDim.x, ++i) {
+            const bool todo = i < 64 ? ((misfit_mask >> i) & 1ull) != 0ull : g.misfit[fm] != 0;  // (beyond 64 frames per workgroup: the flag it stored)
+            if (todo) {
+                __syncthreads();
+                fused_misfit_frame(g, fm);
+            }
+        }
+    }
 }
 
 }  // namespace
@@ -761,7 +775,6 @@ void launch_grid_batch(hipStream_t s, const GridBatch& g, bool lines, hipEvent_t
             if (attr_ok) {
                 if (scan_events) (void)hipEventRecord(scan_events[0], s);
                 hipLaunchKernelGGL(grid_points_fused_kernel, dim3(g.B < fused_wgs ? g.B : fused_wgs), dim3(FUSED_T), FUSED_LDS, s, g, cap);
-                hipLaunchKernelGGL(grid_points_misfit_kernel, dim3(g.B), dim3(FUSED_T), 0, s, g);
                 if (scan_events) (void)hipEventRecord(scan_events[1], s);
                 return;
             }
