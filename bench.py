@@ -35,31 +35,39 @@ sys.path.insert(0, os.path.join(ROOT, "stvo-pl_amd", "python"))
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 # K1m takes the 256-bit distances from the matrix cores: 2 x 256 int8 multiply-accumulate ops per (query, train) pair.
 # Dense int8 peak = 2x the bf16 dense peak (MI355X_MICROARCH.md: bf16 ~2.5 PF dense, "i8 ~2x bf16 rate (2xK)"; the
-# guide's own micro-benchmark floor for v_mfma_i32_32x32x32_i8 is 4404 TOP/s).
+# micro-benchmark floor for v_mfma_i32_32x32x32_i8 in /opt/skills/guides/cdna_hip_programming.md is 4404 TOP/s).
 I8_MFMA_PEAK_TOPS = 5000.0
 I8_MFMA_MEASURED_FLOOR_TOPS = 4404.0
 K1M_OPS_PER_PAIR = 2 * 256
-PROFILE_TAG = "r02"          # committed rocprofv3 PMC passes the `traffic` figures are read from
+PREV_PROFILE_TAG = "r02"
+PROFILE_TAG = "r03"          # committed rocprofv3 PMC passes the `traffic` figures are read from
+FP64_PEAK_TFLOPS = 78.6      # MI355X_MICROARCH.md: vector FP64 (the matrix FP64 rate is the same on gfx950)
+TOL_RAD, TOL_M = 1e-4, 1e-3  # BASELINE.json north_star: pose within 1e-4 rad / 1e-3 m of the reference CPU path per frame
 
 
-def committed_traffic(kernel, tag=PROFILE_TAG, col=1):
+def committed_traffic(kernel, col=1):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, separate
     `--pmc` runs summarised by tools/rocprof_summary.py; values there are KB per dispatch: n, avg, min, max).  `col`: 1 = the
-    average over the launches, 3 = the largest launch (a kernel that also runs on the small key-line problems).  None if unavailable."""
-    path = os.path.join(ROOT, "profiles", f"{tag}_hbm_counters.txt")
-    try:
-        tot = {}
-        for line in open(path):
-            f = line.split()
-            if len(f) >= 6 and f[4] in ("FETCH_SIZE", "WRITE_SIZE") and kernel in line and f[4] not in tot:
-                tot[f[4]] = float(f[col]) * 1024.0
-        return (tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) if len(tot) == 2 else None
-    except (OSError, ValueError, KeyError):
-        return None
+    average over the launches, 3 = the largest launch (a kernel that also runs on the small key-line problems).  The newest
+    committed pass that lists the kernel is used (this round's, else the previous round's).  None if unavailable."""
+    for tag in (PROFILE_TAG, PREV_PROFILE_TAG):
+        path = os.path.join(ROOT, "profiles", f"{tag}_hbm_counters.txt")
+        try:
+            tot = {}
+            for line in open(path):
+                f = line.split()
+                if len(f) >= 6 and f[4] in ("FETCH_SIZE", "WRITE_SIZE") and kernel in line and f[4] not in tot:
+                    tot[f[4]] = float(f[col]) * 1024.0
+            if len(tot) == 2:
+                return tot["FETCH_SIZE"] + tot["WRITE_SIZE"]
+        except (OSError, ValueError, KeyError):
+            pass
+    return None
 
 
 TRAFFIC_SRC = (f"bytes per launch = FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes over this command, read from the "
-               f"committed profiles/{PROFILE_TAG}_hbm_counters.txt (not re-measured by this run); null until that file exists")
+               f"committed profiles/{PROFILE_TAG}_hbm_counters.txt (profiles/{PREV_PROFILE_TAG}_hbm_counters.txt for kernels that file "
+               f"does not list; not re-measured by this run); null when neither lists the kernel")
 
 
 def free_port():
@@ -388,6 +396,146 @@ def correlated_leg(ctx_dev, rank, B=512, n=2000, steps=8):
     return out
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Parity at the headline shape (checker code, AFTER the timed region): a sample of the bench's own streams against the
+# oracle-driven per-frame loop (tests/pipeline_ref.py over oracle/stvo_oracle.c)
+# ---------------------------------------------------------------------------------------------------------------------
+def rot_angle(Ra, Rb):
+    c = (np.trace(Ra.T @ Rb) - 1.0) / 2.0
+    return float(np.arccos(min(1.0, max(-1.0, c))))
+
+
+def parity_sample(pipe, streams, cams, mp, op, order, last_slot, sample):
+    """Advance the pipeline by further steps of the bench's own slot order until a forward AND a backward (ping-pong)
+    transition have been seen, and compare the streams in `sample` with the oracle on exactly those frame pairs: set sizes,
+    match counts, status, path, iteration counts and inlier counts exactly, pose within the north star's tolerance."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    import pipeline_ref
+    orc = oracle_lib.load()
+    seen, checked, worst_rad, worst_m, bad = set(), 0, 0.0, 0.0, []
+    prev = last_slot
+    for _ in range(8):
+        cur = next(order)
+        pipe.step_dev(cur)
+        res, counts = pipe.read()
+        kind = "forward" if cur > prev else "backward"
+        if kind not in seen:
+            seen.add(kind)
+            for b in sample:
+                o = pipeline_ref.run_sequence(orc, [streams[b][prev], streams[b][cur]], cams[b], mp, op)[0]
+                r = res[b]
+                T = r["T"].reshape(4, 4)
+                d_rad, d_m = rot_angle(T[:3, :3], o["T"][:3, :3]), float(np.linalg.norm(T[:3, 3] - o["T"][:3, 3]))
+                worst_rad, worst_m = max(worst_rad, d_rad), max(worst_m, d_m)
+                same = (int(counts[b, 0]) == o["n_stereo_pt"] and int(counts[b, 1]) == o["n_stereo_ls"]
+                        and int(r["n_matched_pt"]) == o["n_matched_pt"] and int(r["n_matched_ls"]) == o["n_matched_ls"]
+                        and int(r["status"]) == o["status"] and int(r["path"]) == o["path"] and tuple(int(v) for v in r["iters"]) == tuple(o["iters"])
+                        and int(r["n_inliers_pt"]) == o["n_inliers_pt"] and int(r["n_inliers_ls"]) == o["n_inliers_ls"]
+                        and d_rad < TOL_RAD and d_m < TOL_M)
+                checked += 1
+                if not same:
+                    bad.append({"stream": int(b), "slots": [int(prev), int(cur)]})
+        prev = cur
+        if len(seen) == 2:
+            break
+    return {"streams": len(sample), "frame_pairs_checked": checked, "transitions": sorted(seen), "ok": not bad and len(seen) == 2,
+            "max_rot_err_rad": worst_rad, "max_trans_err_m": worst_m, "tolerance": {"rad": TOL_RAD, "m": TOL_M}, "mismatches": bad,
+            "what": "streams of THIS run (one per sequence id 0-7, i.e. all three KITTI calibrations) after the timed region, HIP pipeline vs "
+                    "oracle/stvo_oracle.c on the same frame pairs: stereo-set sizes, f2f match counts, status, path, iteration counts and inlier "
+                    "counts exact; pose within the tolerance"}, prev
+
+
+CONFIGS3_SHAPE = dict(n_pts=660, n_lines=250, depth=(0.5, 8.0), octave_probs=[.5, .25, .15, .1], outlier_frac=0.4)
+
+
+def _gen_configs3(args):
+    from stvo_amd import synth
+    seed, nf = args
+    return synth.make_stereo_sequence(synth.frame_seed(3000 + seed, 0), n_frames=nf, cam=synth.EUROC_CAM, **CONFIGS3_SHAPE)
+
+
+def configs3_leg(local_rank, seqs, B=512, steps=10):
+    """BASELINE configs[3] on this round's code: EuRoC-MH_01-shaped 752 x 480 stereo (synthetic rectified intrinsics), ~800
+    key-points over 4 octaves, 300 key-lines, depth 0.5-8 m, 40 % point outliers, config_euroc.yaml values; optimiser modes
+    0 (GN) / 1 (robust GN) / 2 (LM).  Per mode: batched throughput (B streams, two resident frames), single-stream latency
+    (stvo_seq_push, host buffers in / pose out) and the oracle on one host core on the same shape."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ctypes as C
+    import oracle_lib
+    import pipeline_ref
+    from stvo_amd import capi, synth
+    from stvo_amd.ctypes_types import POSE_RESULT_DTYPE, match_params, opt_params
+    cam = synth.EUROC_CAM
+    mp = match_params("euroc")
+    orc = oracle_lib.load()
+    n_dist = len(seqs)
+    out = {"workload": f"BASELINE configs[3]: EuRoC-shaped 752 x 480, {len(seqs[0][0]['kp_l'])} key-points over 4 octaves + "
+                       f"{len(seqs[0][0]['kl_l'])} key-lines per image, 40 % point outliers, config_euroc.yaml (nnr 0.9, inlier_k 4); "
+                       f"{B} streams = {n_dist} distinct synthetic sequences replicated, two resident frames"}
+    for mode, name in ((0, "gn"), (1, "robust_gn"), (2, "lm")):
+        op = opt_params("euroc", mode=mode)
+        ctx = capi.Context(device_id=local_rank, max_rows=2048, max_batch=B)
+        dev = capi.Sequences(ctx, B, 1024, 512, cam, mp, op)
+        try:
+            for k in (0, 1):
+                dev.upload(k, [seqs[b % n_dist][k] for b in range(B)])
+            for k in range(4):
+                dev.step_dev(k & 1)
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            for k in range(steps):
+                dev.step_dev(k & 1)
+            ctx.synchronize()
+            dt = time.perf_counter() - t0
+            res, counts = dev.read()
+        finally:
+            dev.close(); ctx.close()
+        # parity of the sample against the oracle on the same frame pair (last step: slot 0 -> slot 1 for even `steps`)
+        a, b_ = ((steps - 2) & 1, (steps - 1) & 1)
+        ok = True
+        for s in range(min(4, n_dist)):
+            o = pipeline_ref.run_sequence(orc, [seqs[s][a], seqs[s][b_]], cam, mp, op)[0]
+            r = res[s]
+            T = r["T"].reshape(4, 4)
+            ok = ok and (int(r["status"]) == o["status"] and int(r["path"]) == o["path"] and tuple(int(v) for v in r["iters"]) == tuple(o["iters"])
+                         and int(r["n_inliers_pt"]) == o["n_inliers_pt"] and int(r["n_inliers_ls"]) == o["n_inliers_ls"]
+                         and rot_angle(T[:3, :3], o["T"][:3, :3]) < TOL_RAD and float(np.linalg.norm(T[:3, 3] - o["T"][:3, 3])) < TOL_M)
+        # single stream
+        ctx = capi.Context(device_id=local_rank, max_rows=2048, max_batch=1)
+        one = capi.Sequences(ctx, 1, 1024, 512, cam, mp, op)
+        try:
+            pp = ping_pong(len(seqs[0]))             # there and back again: consecutive frames stay neighbours
+            packed = [one._pack([seqs[0][next(pp)]]) for _ in range(46)]
+            r1 = np.zeros(1, dtype=POSE_RESULT_DTYPE); c1 = np.zeros(4, np.int32)
+            ts = []
+            for ff, keep in packed:
+                t1 = time.perf_counter()
+                ctx._chk(ctx.lib.stvo_seq_push(one.h, C.byref(ff), r1.ctypes.data_as(C.c_void_p), c1))
+                ts.append(time.perf_counter() - t1)
+            lat = float(np.median(np.array(ts[6:]) * 1e3))
+        finally:
+            one.close(); ctx.close()
+        # the oracle on one host core, same shape (bounded: ~1 s per mode)
+        pipeline_ref.run_sequence(orc, seqs[1 % n_dist], cam, mp, op)
+        t2 = time.perf_counter(); nfr = 0
+        for s in range(min(6, n_dist)):
+            pipeline_ref.run_sequence(orc, seqs[s], cam, mp, op); nfr += len(seqs[s])
+        cpu_ms = (time.perf_counter() - t2) / nfr * 1e3
+        out[name] = {"mode": mode, "value": B * steps / dt, "unit": "frame-pairs/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+                     "committed_pose_fraction": float((res["status"] == 0).mean()), "mean_stereo_points": float(counts[:, 0].mean()),
+                     "mean_stereo_lines": float(counts[:, 1].mean()), "mean_matched_points": float(counts[:, 2].mean()),
+                     "mean_matched_lines": float(counts[:, 3].mean()), "single_stream_push_ms_median": lat,
+                     "parity_sampled_ok": bool(ok),
+                     "cpu_baseline": {"value": 1e3 / cpu_ms, "unit": "frame-pairs/s", "ms_per_frame": cpu_ms, "cores": 1, "kind": "port",
+                                      "sample": f"{min(6, n_dist)} sequences x {len(seqs[0])} frames of this shape, oracle/stvo_oracle.c"},
+                     "single_stream_speedup_vs_oracle_1_core": cpu_ms / lat}
+    out["note"] = ("mode 1: optimizeFunctionsRobust leaves the residual unscaled (stereoFrameHandler.cpp:813,923), err ~ 6 > 1, so isGoodSolution "
+                   "rejects every frame on the GPU exactly as in the oracle (committed_pose_fraction 0); the reference reaches that optimiser "
+                   "only as the fallback of :359")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -399,6 +547,7 @@ def main():
     ap.add_argument("--lines", type=int, default=85, help="3-D segments per stream; + 20 %% distractors ~ 100 key-lines per image")
     ap.add_argument("--max-keylines", type=int, default=128,
                     help="key-line capacity per image of the pipeline (config_kitti.yaml: lsd_nfeatures 100; the library allows up to 512)")
+    ap.add_argument("--repeats", type=int, default=5, help="the timed region (exactly --steps steps between barriers) is repeated this often; value = median")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the latency / configs[1] / correlated-descriptor legs")
     args = ap.parse_args()
@@ -420,6 +569,11 @@ def main():
     B, S = args.batch, max(2, min(args.slots, 16))
     seq_ids, replicas = stream_ids(rank, world, B)
     streams = generate_streams(seq_ids, replicas, S, args.points, args.lines)
+    c3_seqs = None
+    if rank == 0 and world == 1 and not args.no_extras:   # configs[3] sequences, also before the GPU is touched (fork)
+        import multiprocessing as mp_
+        with mp_.get_context("fork").Pool(min(16, os.cpu_count() or 1)) as pool:
+            c3_seqs = pool.map(_gen_configs3, [(k, 5) for k in range(64)])
 
     import torch
     from stvo_amd import capi
@@ -446,23 +600,31 @@ def main():
     ctx.synchronize()
     order = ping_pong(S)
 
+    last_slot = None
     for _ in range(args.warmup):
-        pipe.step_dev(next(order))
+        last_slot = next(order); pipe.step_dev(last_slot)
     ctx.synchronize()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        pipe.step_dev(next(order))
-    ctx.synchronize()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    frames_total, dt = shard.aggregate(dist, B * args.steps, dt, device=dev_name)   # sum of frame pairs, max of seconds
+    # ---- the timed region: EXACTLY --steps steps between barrier + synchronize on both sides, max over ranks; repeated
+    # --repeats times back to back, `value` = the median repeat (min / max beside it)
+    rep_dt = []
+    frames_total = B * args.steps * world
+    for _ in range(max(1, args.repeats)):
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            last_slot = next(order); pipe.step_dev(last_slot)
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt_r = time.perf_counter() - t0
+        frames_total, dt_r = shard.aggregate(dist, B * args.steps, dt_r, device=dev_name)   # sum of frame pairs, max of seconds
+        rep_dt.append(dt_r)
+    dt = float(np.median(rep_dt))
 
     res, counts = pipe.read()   # sanity: the timed work produced real poses
     ok_frac = float((res["status"] == 0).mean())
@@ -475,15 +637,19 @@ def main():
         pipe.set_stage_timing(True)
         pairs, n1s, n2s, nps, nls, grid_b = [], [], [], [], [], []
         prev_counts = counts
+        evals = []
         for _ in range(args.steps):
-            pipe.step_dev(next(order))
+            last_slot = next(order); pipe.step_dev(last_slot)
             r_k, c_k = pipe.read()
+            evals.append(float(r_k["iters"].sum()))
             n_prev, n_curr = prev_counts[:, 0].astype(np.int64), c_k[:, 0].astype(np.int64)
             pairs.append(float((n_prev * n_curr).sum())); n1s.append(float(n_prev.sum())); n2s.append(float(n_curr.sum()))
             nps.append(float(c_k[:, 2].sum())); nls.append(float(c_k[:, 3].sum()))
             prev_counts = c_k
         stage_ms, n_timed = pipe.get_stage_timing()
         pipe.set_stage_timing(False)
+        # parity at the headline shape: 8 streams of this run (sequence ids 0-7 = all three calibrations) vs the oracle
+        parity, last_slot = parity_sample(pipe, streams, cams, mp, op, order, last_slot, list(range(min(8, B))))
         n_kp = np.array([[len(st[k]["kp_l"]) + len(st[k]["kp_r"]) for k in range(S)] for st in streams], np.float64)  # [B][S]
         pairs_l, n1_l, n2_l, np_l, nl_l = (float(np.mean(v)) for v in (pairs, n1s, n2s, nps, nls))
 
@@ -511,9 +677,17 @@ def main():
         # kernel the library picks for this batch size (csrc/pose_kernel.hip: launch_pose), as rocprofv3 names it
         forced = os.environ.get("STVO_POSE_KERNEL", "")
         pose_name = "pose_kernel<" if forced == "1" or (forced != "2" and B <= 256) else "pose2_kernel<"
+        # FP64 view (SURVEY.md §8d gn_accumulate): 150 flop per point and 400 per line and evaluation; evaluations = the iteration
+        # counts the kernel reports (stage 1 + refinement), all matched features priced at every evaluation
+        evals_l = float(np.mean(evals)) / B
+        pose_flops = (150.0 * np_l + 400.0 * nl_l) * evals_l
+        pose_tf = pose_flops / (pose_ms * 1e-3) / 1e12 if pose_ms > 0 else 0.0
         roofline_pose = {"kernel": pose_name, "bound": "hbm", "achieved": pose_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": pose_gbs / HBM_PEAK_GBS, "traffic": committed_traffic(pose_name), "traffic_source": TRAFFIC_SRC,
                          "algorithmic_bytes_per_launch": pose_bytes, "avg_launch_ms": pose_ms, "timing": timing,
+                         "fp64_view": {"achieved": pose_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": pose_tf / FP64_PEAK_TFLOPS,
+                                       "algorithmic_flops_per_launch": pose_flops, "mean_evaluations_per_pair": evals_l,
+                                       "note": "(150 Np + 400 Nl) flop per evaluation x evaluations per frame pair (SURVEY.md 8d)"},
                          "note": "optimizePose for B frame pairs in one launch; algorithmic bytes = 52 B per matched point + 116 B per "
                                  "matched line (read once) + m12 and inlier masks (4 + 4 B per prev stereo feature) + 840 B result"}
         # point grid matcher (one workgroup per frame; STVO_GRID_FUSED=0: the scan formulation): SURVEY.md §8d match_grid bytes
@@ -533,6 +707,9 @@ def main():
         out = {
             "metric": "stereo frames/s (match+optimizePose)", "value": frames_total / dt, "unit": "frame-pairs/s",
             "n_gpus": world, "rccl_ranks": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "repeats": {"n": len(rep_dt), "statistic": "median", "value_min": frames_total / max(rep_dt), "value_max": frames_total / min(rep_dt),
+                        "ms_per_step_all": [d / args.steps * 1e3 for d in rep_dt]},
+            "parity_sampled": parity,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/i8+f64", "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: KITTI-00-shaped stereo with points + lines (ORB + LBD rows), grid-windowed stereo "
                                    "match (points and lines) + f2f brute-force mutual-NNR match (points and lines) + full GN optimizePose "
@@ -554,6 +731,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_extras:
         out["latency"] = single_stream_latency(local_rank, args.points, args.lines)
         out["configs1"] = configs1_leg(dev_name, rank)
+        out["configs3"] = configs3_leg(local_rank, c3_seqs)
         out["reverse_check_correlated"] = correlated_leg(dev_name, rank)
         out["orb_front_end"] = orb_leg(local_rank)
         out["images_to_poses"] = images_leg(local_rank)

@@ -762,16 +762,11 @@ void launch_grid_batch(hipStream_t s, const GridBatch& g, bool lines, hipEvent_t
         const bool fused = range && g.misfit && g.cell2 && g.lperm && g.lstart && g.stride1 <= FUSED_ROWS && g.stride2 <= FUSED_ROWS && g.w.w_lo >= 0 &&
                            g.w.w_lo <= FUSED_LW - STVO_GRID_COLS && g.w.w_hi == 0 && g.w.h_lo == 0 && g.w.h_hi == 0 && !(ef && ef[0] == '0');
         if (fused) {
-            static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(grid_points_fused_kernel),
-                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS) == hipSuccess;
+            const bool attr_ok = lds_opt_in(reinterpret_cast<const void*>(grid_points_fused_kernel), (int)FUSED_LDS);
             const char* ec = std::getenv("STVO_GRID_FUSED_CAP");
             int cap = ec ? std::atoi(ec) : FUSED_KEY_CAP;
             if (cap > FUSED_KEY_CAP) cap = FUSED_KEY_CAP;  // negative: every frame misfits
-            static const int fused_wgs = [] {  // one persistent workgroup per CU (its LDS and registers fill one)
-                int dev = 0, cus = 0;
-                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-                return cus;
-            }();
+            const int fused_wgs = device_cu_count();  // one persistent workgroup per CU (its LDS and registers fill one)
             if (attr_ok) {
                 if (scan_events) (void)hipEventRecord(scan_events[0], s);
                 hipLaunchKernelGGL(grid_points_fused_kernel, dim3(g.B < fused_wgs ? g.B : fused_wgs), dim3(FUSED_T), FUSED_LDS, s, g, cap);

@@ -5,10 +5,29 @@
 #include <stdint.h>
 
 #include <cstdlib>
+#include <map>
+#include <mutex>
+#include <utility>
 
 #include "../../include/stvo_hip.h"
 
 namespace stvo {
+
+// More than 64 KB of dynamic LDS per workgroup needs an explicit opt-in, and hipFuncSetAttribute applies to the CURRENT device
+// only: the verdict is cached per (kernel, device), so contexts on several devices of one process each get their opt-in.
+inline bool lds_opt_in(const void* kernel, int bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<const void*, int>, bool> done;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    std::lock_guard<std::mutex> lk(mu);
+    const auto key = std::make_pair(kernel, dev);
+    const auto it = done.find(key);
+    if (it != done.end()) return it->second;
+    const bool ok = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+    done[key] = ok;
+    return ok;
+}
 
 constexpr int KNN_MIN_NSEG = 2, KNN_MAX_NSEG = 16;  // train-range segments per query tile in K1
 // Segments per query tile: 1 for very big batches, 2 for big ones (short dispatch rounds), up to 16 for a single frame pair so
@@ -24,6 +43,21 @@ inline int knn_pick_nseg(int B, int max_n, size_t capacity) {
     const size_t per_seg = (size_t)(B > 0 ? B : 1) * (size_t)(max_n > 0 ? max_n : 1);
     while (nseg > 1 && (size_t)nseg * per_seg > capacity) --nseg;
     return nseg;
+}
+
+// CUs of the current device (persistent-workgroup launches size their grids with it), cached per device
+inline int device_cu_count() {
+    static std::mutex mu;
+    static std::map<int, int> cus;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    std::lock_guard<std::mutex> lk(mu);
+    const auto it = cus.find(dev);
+    if (it != cus.end()) return it->second;
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cus[dev] = n;
+    return n;
 }
 
 // ---- K1 / K2: brute-force Hamming 2-NN, ratio test, mutual check ----------------------------

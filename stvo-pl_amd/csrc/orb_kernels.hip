@@ -560,6 +560,7 @@ int stvo_orb_create(stvo_ctx* ctx, int B, int cols, int rows, int max_keypoints,
     if (prm->nfeatures <= 0 || prm->fast_threshold < 1 || prm->fast_threshold > 254 || prm->edge_threshold < 19 ||
         2 * prm->edge_threshold >= cols || 2 * prm->edge_threshold >= rows)
         return STVO_ERR_INVALID_ARG;
+    if (rows >= 4096 || cols >= 4096) return STVO_ERR_CAPACITY;  // candidates pack (y, x) in 12 bits each
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     stvo_orb* o = new (std::nothrow) stvo_orb();
     if (!o) return STVO_ERR_HIP;
@@ -569,7 +570,6 @@ int stvo_orb_create(stvo_ctx* ctx, int B, int cols, int rows, int max_keypoints,
     auto al = [](size_t v) { return (v + 255) & ~size_t(255); };
     const size_t o_blur = 0, o_hist = al(px), o_cand = o_hist + al((size_t)B * 256 * 4), o_ncand = o_cand + al((size_t)B * stvo::CAND_CAP * 4),
                  o_pat = o_ncand + al((size_t)B * 4), total = o_pat + 1024;
-    if (rows >= 4096 || cols >= 4096) return STVO_ERR_CAPACITY;  // candidates pack (y, x) in 12 bits each
     if (!hip_ok(ctx, hipMalloc((void**)&o->dev, total), "hipMalloc orb") || !hip_ok(ctx, hipMemset(o->dev, 0, total), "hipMemset orb")) {
         if (o->dev) (void)hipFree(o->dev);
         delete o;

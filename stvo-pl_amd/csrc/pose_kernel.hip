@@ -584,9 +584,7 @@ template <int BLK>
 static bool pose_ldsrec_available() {
     constexpr int PPT = (STVO_POSE_MAX_POINTS + BLK - 1) / BLK;
     constexpr int LPT = (STVO_POSE_MAX_LINES + BLK - 1) / BLK;
-    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&pose_kernel<BLK, PPT, LPT, true>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)POSE_LDSREC_MAX_BYTES) == hipSuccess;
-    return ok;
+    return lds_opt_in(reinterpret_cast<const void*>(&pose_kernel<BLK, PPT, LPT, true>), (int)POSE_LDSREC_MAX_BYTES);
 }
 
 int launch_pose(hipStream_t s, const PoseArgs& a) {

@@ -562,9 +562,7 @@ constexpr int pose2_lds_budget() {  // 4 WPE / NW workgroups per CU share its 16
 
 template <int NW, int WPE>
 bool pose2_attr_ok() {
-    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&pose2_kernel<NW, WPE>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               pose2_lds_budget<NW, WPE>()) == hipSuccess;
-    return ok;
+    return lds_opt_in(reinterpret_cast<const void*>(&pose2_kernel<NW, WPE>), pose2_lds_budget<NW, WPE>());
 }
 
 template <int NW, int WPE>

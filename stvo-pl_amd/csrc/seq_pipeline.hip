@@ -772,6 +772,9 @@ int stvo_seq_set_slots(stvo_seq* s, int n_slots) {
     stvo_ctx* ctx = s->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    // captured step graphs (STVO_SEQ_GRAPH=1) hold the raw-slot addresses of the slots they were captured for
+    for (auto& g : s->graphs) (void)hipGraphExecDestroy(g.second);
+    s->graphs.clear();
     if (s->extra_raw) {
         HIP_TRY(ctx, hipFree(s->extra_raw));
         s->extra_raw = nullptr;

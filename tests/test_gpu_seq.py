@@ -276,3 +276,50 @@ def test_seq_point_grid_persistent_workgroups_many_frames(oracle, monkeypatch):
     for b in (0, B - 1):
         ref = pipeline_ref.stereo_frame(oracle, seqs[b][1], cam, mp, True, False)
         assert np.array_equal(fused[1][0][b, :len(seqs[b][1]["kp_l"])], ref["m12_raw_p"])
+
+
+def test_seq_pipeline_headline_shape_every_stream_vs_oracle(oracle):
+    """The shape bench.py's `value` is quoted on — hundreds of streams x (1650 landmarks ~ 2000 key-points + 85 segments ~ 100
+    key-lines), the eight sequence ids / three KITTI calibrations of configs[4], resident frame slots advanced with
+    upload / step_dev in ping-pong order, the batch-size default of the pose kernel — with EVERY stream compared with the
+    oracle-driven per-frame loop on every transition (forward and backward), not with another formulation of itself."""
+    from concurrent.futures import ThreadPoolExecutor
+    from stvo_amd import capi
+    B, S = 320, 3
+    ids = np.arange(B) % synth.CONFIG5_N_SEQUENCES
+    streams = [synth.make_config5_sequence(int(s), n_frames=S, n_pts=1650, n_lines=85, replica=400 + b // 8) for b, s in enumerate(ids)]
+    cams = [synth.config5_cam(int(s)) for s in ids]
+    mp = match_params("kitti"); op = opt_params("kitti")
+    order = [0, 1, 2, 1, 0]   # 0->1, 1->2 forward; 2->1, 1->0 backward
+
+    def ref_pair(args):
+        b, a, c = args
+        return pipeline_ref.run_sequence(oracle, [streams[b][a], streams[b][c]], cams[b], mp, op)[0]
+
+    ctx = capi.Context(device_id=0, max_rows=2048, max_batch=B)
+    dev = capi.Sequences(ctx, B, 2048, 128, cams, mp, op)
+    try:
+        dev.set_slots(S)
+        for k in range(S):
+            dev.upload(k, [st[k] for st in streams])
+        prev = None
+        with ThreadPoolExecutor(16) as ex:   # the oracle's C functions run outside the GIL
+            for cur in order:
+                dev.step_dev(cur)
+                res, counts = dev.read()
+                if prev is not None:
+                    refs = list(ex.map(ref_pair, [(b, prev, cur) for b in range(B)]))
+                    for b, o in enumerate(refs):
+                        r = res[b]
+                        assert counts[b, 0] == o["n_stereo_pt"] and counts[b, 1] == o["n_stereo_ls"], (b, prev, cur)
+                        assert r["n_matched_pt"] == o["n_matched_pt"] and r["n_matched_ls"] == o["n_matched_ls"], (b, prev, cur)
+                        assert r["status"] == o["status"] and r["path"] == o["path"] and tuple(r["iters"]) == o["iters"], (b, prev, cur)
+                        assert r["n_inliers_pt"] == o["n_inliers_pt"] and r["n_inliers_ls"] == o["n_inliers_ls"], (b, prev, cur)
+                        T = r["T"].reshape(4, 4)
+                        assert np_model.rot_angle(T[:3, :3], o["T"][:3, :3]) < 1e-4 and np.linalg.norm(T[:3, 3] - o["T"][:3, 3]) < 1e-3
+                        assert np.allclose(T, o["T"], atol=1e-8), (b, prev, cur)
+                    assert (res["status"] == 0).mean() > 0.95 and res["n_matched_pt"].mean() > 1300
+                prev = cur
+    finally:
+        dev.close()
+        ctx.close()

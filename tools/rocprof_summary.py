@@ -3,6 +3,10 @@
 
     python tools/rocprof_summary.py stats  <trace.db>            -> per-kernel calls / total / average (us)
     python tools/rocprof_summary.py pmc    <pmc.db> [COUNTER]    -> per-kernel average counter value per dispatch
+    python tools/rocprof_summary.py split  <trace.db> [PATTERN]  -> per-kernel AND per-launch-shape (grid x workgroup size) calls /
+                                                                    total / average / min / max (us): a kernel that is launched on
+                                                                    problems of different sizes (K1m: key-points and key-lines) gets
+                                                                    one line per shape, so the dominant launch can be read off alone
 """
 import sqlite3
 import sys
@@ -27,8 +31,48 @@ def pmc(db, counter=None):
         print(f"{n:5d} {a:14.3f} {lo:14.3f} {hi:14.3f}  {c}  {k[:90]}")
 
 
+def _table_like(con, stem):
+    """rocpd names its tables `rocpd_<stem>_<uuid>` and offers views without the suffix; take whichever exists."""
+    names = [r[0] for r in con.execute("select name from sqlite_master where type in ('table', 'view')")]
+    if stem in names:
+        return stem
+    for prefix in (f"rocpd_{stem}", stem):
+        for n in names:
+            if n.startswith(prefix):
+                return n
+    return None
+
+
+def split(db, pattern=None):
+    con = sqlite3.connect(db)
+    view = _table_like(con, "kernels")   # the `kernels` view: name, start, end, grid_size*, workgroup_size*, ...
+    if view is None:
+        raise SystemExit("no kernel dispatch table in " + db)
+    cols = [r[1] for r in con.execute(f"pragma table_info('{view}')")]
+
+    def pick(*cands):
+        for c in cands:
+            if c in cols:
+                return c
+        return None
+    name, start, end = pick("name", "kernel_name"), pick("start", "start_timestamp"), pick("end", "end_timestamp")
+    gx, wx = pick("grid_size_x", "grid_x", "grid_size"), pick("workgroup_size_x", "workgroup_x", "workgroup_size")
+    if None in (name, start, end, gx, wx):
+        raise SystemExit(f"unexpected columns in {view}: {cols}")
+    q = (f"select {name}, {gx}, {wx}, count(*), sum({end} - {start}) / 1e3, avg({end} - {start}) / 1e3, min({end} - {start}) / 1e3, "
+         f"max({end} - {start}) / 1e3 from {view}")
+    if pattern:
+        q += f" where {name} like '%{pattern}%'"
+    q += f" group by {name}, {gx}, {wx} order by sum({end} - {start}) desc"
+    print(f"{'calls':>6} {'grid_x':>10} {'wg_x':>5} {'total_us':>12} {'avg_us':>10} {'min_us':>10} {'max_us':>10}  kernel")
+    for k, g, w, n, tot, avg, lo, hi in con.execute(q):
+        print(f"{n:6d} {g:10d} {w:5d} {tot:12.1f} {avg:10.2f} {lo:10.2f} {hi:10.2f}  {k[:100]}")
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2])
+    elif sys.argv[1] == "split":
+        split(sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else None)
     else:
         pmc(sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else None)
