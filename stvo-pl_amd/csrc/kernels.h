@@ -133,9 +133,14 @@ struct PoseArgs {
     int eval_robust;
     double* eval_out;    // [B][44]: H(36) g(6) e n
     long long* prof_out; // optional [B][16] phase ticks (tools only)
+    int obs_f32;         // hint: every curr_pl value is exactly a float (key-point coordinates): pose_kernel3 keeps them as floats in LDS
+                         // (verified per frame pair on the device; pairs that fail take the full-width path)
 };
 int launch_pose(hipStream_t s, const PoseArgs& a);   // dispatches to pose_kernel2.hip (default) or pose_kernel.hip (STVO_POSE_KERNEL=1)
 int launch_pose2(hipStream_t s, const PoseArgs& a);  // pose_kernel2.hip: every wave a worker, 128 VGPRs, records in LDS
+// pose_kernel2's batch kernel on the frame pairs list[0 .. *count - 1] (device memory; a.B = capacity of the list)
+int launch_pose2_list(hipStream_t s, const PoseArgs& a, const int* list, const int* count);
+int launch_pose3(hipStream_t s, const PoseArgs& a);  // pose_kernel3.hip: two frame pairs per workgroup, owner + evaluator waves
 
 // ---- K3: grid-windowed stereo matchers, batched over frame pairs (blockIdx.y) ----------------------
 constexpr int GRID_LW = STVO_GRID_COLS + 16, GRID_LCELLS = STVO_GRID_ROWS * GRID_LW, GRID_LSTART_STRIDE = GRID_LCELLS + 4;

@@ -597,6 +597,9 @@ int launch_pose(hipStream_t s, const PoseArgs& a) {
     // pose_kernel2.hip with four waves per pair at 256 VGPRs — every wave a worker, all records in the workgroup's LDS half:
     // 465 vs 568 us per 1024 points-only pairs, 0.53 vs 0.57 ms inside the pipeline (profiles/r02_pose_variants.txt).
     // STVO_POSE_KERNEL = 1 / 2 forces one of the two for every batch size.
+    // STVO_POSE_KERNEL = 3: pose_kernel3.hip (two frame pairs per workgroup, owner + evaluator waves) — until it is the measured
+    // default for batches it is opt-in
+    if (which == 3 && !a.eval_only) return launch_pose3(s, a);
     if (which == 2 || (which == 0 && a.B > POSE_LATENCY_MAX_B)) return launch_pose2(s, a);
     if (a.max_pts > STVO_POSE_MAX_POINTS || a.max_lines > STVO_POSE_MAX_LINES) return STVO_ERR_CAPACITY;
     const size_t rec_bytes = ((size_t)a.max_pts * 6 + (size_t)a.max_lines * 14) * sizeof(double);

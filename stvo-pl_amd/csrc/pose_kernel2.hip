@@ -39,7 +39,7 @@ constexpr bool POSE2_PRIO = true;  // serial sections at wave priority 3 (measur
 
 // NW waves per frame pair; WPE = waves per SIMD the register budget is set for (4: 128 VGPRs, 2: 256 VGPRs)
 template <int NW, int WPE>
-__global__ __launch_bounds__(NW * 64, WPE) void pose2_kernel(PoseArgs a, int lds_rec_bytes) {
+__global__ __launch_bounds__(NW * 64, WPE) void pose2_kernel(PoseArgs a, int lds_rec_bytes, const int* list, const int* list_count) {
     constexpr int BLOCK = NW * 64;
     // 6x6 systems: on ROWS (row_solve_spd & co., no 36-element arrays per lane) in the 128-VGPR variants; with the serial
     // routines of pose_math.h, executed redundantly by every lane of wave 0, in the 256-VGPR variant, where the arrays fit and
@@ -54,7 +54,9 @@ __global__ __launch_bounds__(NW * 64, WPE) void pose2_kernel(PoseArgs a, int lds
     __shared__ int s_ired[NW];
     __shared__ PoseSh s_sh;
     PoseSh* sh = &s_sh;
-    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // list != nullptr: the frame pairs list[0 .. *list_count - 1] (what pose_kernel3 left aside); workgroups beyond the count leave
+    if (list != nullptr && (int)blockIdx.x >= *list_count) return;
+    const int f = list != nullptr ? list[blockIdx.x] : (int)blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const bool w0 = wv == 0;   // the wave that also runs the serial sections (all of its lanes, redundantly)
     const bool t0 = tid == 0;  // the lane that writes results to global memory
     const bool prof = a.prof_out != nullptr;
@@ -566,12 +568,12 @@ bool pose2_attr_ok() {
 }
 
 template <int NW, int WPE>
-void launch_pose2_variant(hipStream_t s, const PoseArgs& a) {
+void launch_pose2_variant(hipStream_t s, const PoseArgs& a, const int* list = nullptr, const int* list_count = nullptr) {
     // no more LDS than the records of the largest possible problem need (a small batch item leaves room for other kernels)
     const long long need = (long long)a.max_pts * REC_P_BYTES + (long long)a.max_lines * REC_L_BYTES;
     int lds = pose2_attr_ok<NW, WPE>() ? pose2_lds_budget<NW, WPE>() : 48 * 1024;
     if (need < lds) lds = (int)((need + 15) & ~15ll);
-    hipLaunchKernelGGL((pose2_kernel<NW, WPE>), dim3(a.B), dim3(NW * 64), (size_t)lds, s, a, lds);
+    hipLaunchKernelGGL((pose2_kernel<NW, WPE>), dim3(a.B), dim3(NW * 64), (size_t)lds, s, a, lds, list, list_count);
 }
 
 }  // namespace
@@ -595,6 +597,13 @@ int launch_pose2(hipStream_t s, const PoseArgs& a) {
     else if (nw >= 8) launch_pose2_variant<8, 4>(s, a);
     else if (nw >= 4) launch_pose2_variant<4, 4>(s, a);
     else launch_pose2_variant<2, 4>(s, a);
+    return STVO_OK;
+}
+
+int launch_pose2_list(hipStream_t s, const PoseArgs& a, const int* list, const int* count) {
+    if (a.B <= 0) return STVO_OK;
+    if (a.max_pts > STVO_POSE_MAX_POINTS || a.max_lines > STVO_POSE_MAX_LINES) return STVO_ERR_CAPACITY;
+    launch_pose2_variant<4, 2>(s, a, list, count);
     return STVO_OK;
 }
 

@@ -1060,6 +1060,7 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl) {
         a.prev_sP = ps.sP; a.prev_eP = ps.eP; a.prev_spl = ps.spl; a.prev_epl = ps.epl; a.prev_s2l = ps.s2lm;
         a.curr_le = cs.le; a.m12l = s->m12l;
         a.cams = s->d_cams; a.prm = s->op;
+        a.obs_f32 = 1;  // curr_pl holds key-point coordinates widened from float (point_tail_kernel)
         a.results = s->zero_copy ? reinterpret_cast<stvo_pose_result*>(s->out_host) : s->results;
         a.inl_p_out = s->inlp; a.inl_l_out = s->inll;
         mark(8, st);

@@ -13,22 +13,26 @@ pytestmark = pytest.mark.gpu
 CAM = synth.KITTI_CAM
 
 
-@pytest.fixture(autouse=True, params=["default", "1", "2:16", "2:8", "2:4", "2:2", "2:40"])
+@pytest.fixture(autouse=True, params=["default", "1", "2:16", "2:8", "2:4", "2:2", "2:40", "3:16", "3:8"])
 def pose_kernel_variant(request):
     """Every test of this module runs against both pose kernels: pose_kernel.hip (worker waves + solver wave, "1") and
     pose_kernel2.hip (every wave a worker, row-distributed algebra, records compacted in LDS) with 16 / 8 / 4 / 2 waves per
-    frame pair at 128 VGPRs, or 4 at 256 VGPRs ("2:40", the default for big batches); "default" is the library's own choice.  The library reads the two variables at every launch."""
+    frame pair at 128 VGPRs, or 4 at 256 VGPRs ("2:40", the default for big batches), and pose_kernel3.hip (two frame pairs per
+    workgroup, owner + evaluator waves) with 16 waves at 128 VGPRs / 8 waves at 256 VGPRs ("3:16", "3:8"; problems whose
+    records do not fit its LDS share are handed to pose_kernel2's kernel by the library); "default" is the library's own
+    choice.  The library reads the variables at every launch."""
     import os
-    old = {k: os.environ.get(k) for k in ("STVO_POSE_KERNEL", "STVO_POSE2_NW")}
+    old = {k: os.environ.get(k) for k in ("STVO_POSE_KERNEL", "STVO_POSE2_NW", "STVO_POSE3_NW")}
     if request.param == "default":
-        os.environ.pop("STVO_POSE_KERNEL", None); os.environ.pop("STVO_POSE2_NW", None)
+        for k in old:
+            os.environ.pop(k, None)
     else:
         k, _, nw = request.param.partition(":")
         os.environ["STVO_POSE_KERNEL"] = k
+        var = "STVO_POSE3_NW" if k == "3" else "STVO_POSE2_NW"
+        os.environ.pop("STVO_POSE2_NW", None); os.environ.pop("STVO_POSE3_NW", None)
         if nw:
-            os.environ["STVO_POSE2_NW"] = nw
-        else:
-            os.environ.pop("STVO_POSE2_NW", None)
+            os.environ[var] = nw
     yield request.param
     for k, v in old.items():
         if v is None:

@@ -278,13 +278,17 @@ def test_seq_point_grid_persistent_workgroups_many_frames(oracle, monkeypatch):
         assert np.array_equal(fused[1][0][b, :len(seqs[b][1]["kp_l"])], ref["m12_raw_p"])
 
 
-def test_seq_pipeline_headline_shape_every_stream_vs_oracle(oracle):
+@pytest.mark.parametrize("pose", ["default", "3:16", "3:8"])
+def test_seq_pipeline_headline_shape_every_stream_vs_oracle(oracle, monkeypatch, pose):
     """The shape bench.py's `value` is quoted on — hundreds of streams x (1650 landmarks ~ 2000 key-points + 85 segments ~ 100
     key-lines), the eight sequence ids / three KITTI calibrations of configs[4], resident frame slots advanced with
     upload / step_dev in ping-pong order, the batch-size default of the pose kernel — with EVERY stream compared with the
     oracle-driven per-frame loop on every transition (forward and backward), not with another formulation of itself."""
     from concurrent.futures import ThreadPoolExecutor
     from stvo_amd import capi
+    if pose != "default":   # pose_kernel3.hip (two frame pairs per workgroup) with 16 / 8 waves
+        monkeypatch.setenv("STVO_POSE_KERNEL", pose.split(":")[0])
+        monkeypatch.setenv("STVO_POSE3_NW", pose.split(":")[1])
     B, S = 320, 3
     ids = np.arange(B) % synth.CONFIG5_N_SEQUENCES
     streams = [synth.make_config5_sequence(int(s), n_frames=S, n_pts=1650, n_lines=85, replica=400 + b // 8) for b, s in enumerate(ids)]
