@@ -259,44 +259,53 @@ def configs1_leg(ctx_dev, rank, B=512, n=2000, steps=10):
 
 
 def orb_leg(local_rank, B=256):
-    """SURVEY 8(f) rank 3, measured beside the hot path: the ORB point front-end (stvo_orb_detect_dev) on B synthetic
-    KITTI-size images resident in HBM — FAST-9 + NMS + retainBest(2000) + orientation + blur + rBRIEF."""
+    """SURVEY 8(f) rank 3, measured beside the hot path: the ORB point front-end (stvo_orb_detect_levels_dev) on B synthetic
+    images resident in HBM — per level FAST-9 + NMS + retainBest + orientation + blur + rBRIEF; KITTI size with one pyramid
+    level (config_kitti.yaml) and EuRoC size with four levels at 1.2 (config_euroc.yaml:60-61)."""
     import torch
     from stvo_amd import capi, synth
     K = 2048
-    base = [synth.make_image(500 + k) for k in range(8)]
-    imgs = np.stack([np.roll(base[b % 8], 7 * (b // 8), axis=1) for b in range(B)])
-    ctx = capi.Context(device_id=local_rank, max_rows=2048, max_batch=4)
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    orb = capi.Orb(ctx, B, 1241, 376, max_keypoints=K)
     dev = f"cuda:{local_rank}"
-    d = dict(img=torch.from_numpy(imgs).to(dev), kp=torch.zeros(B, K, 2, device=dev), resp=torch.zeros(B, K, device=dev),
-             ang=torch.zeros(B, K, device=dev), desc=torch.zeros(B, K, 32, dtype=torch.uint8, device=dev),
-             n=torch.zeros(B, dtype=torch.int32, device=dev))
+    out = {}
+    for name, cols, rows, nlev, nfeat in (("kitti_1_level", 1241, 376, 1, 2000), ("euroc_4_levels", 752, 480, 4, 600)):
+        base = [synth.make_image(500 + k, cols=cols, rows=rows) for k in range(8)]
+        imgs = np.stack([np.roll(base[b % 8], 7 * (b // 8), axis=1) for b in range(B)])
+        ctx = capi.Context(device_id=local_rank, max_rows=2048, max_batch=4)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        orb = capi.Orb(ctx, B, cols, rows, max_keypoints=K, nfeatures=nfeat, nlevels=nlev)
+        d = dict(img=torch.from_numpy(imgs).to(dev), kp=torch.zeros(B, K, 2, device=dev), resp=torch.zeros(B, K, device=dev),
+                 ang=torch.zeros(B, K, device=dev), desc=torch.zeros(B, K, 32, dtype=torch.uint8, device=dev),
+                 n=torch.zeros(B, dtype=torch.int32, device=dev), oct=torch.zeros(B, K, dtype=torch.int32, device=dev),
+                 nt=torch.zeros(B, dtype=torch.int32, device=dev))
 
-    def run():
-        ctx._chk(ctx.lib.stvo_orb_detect_dev(orb.h, d["img"].data_ptr(), d["kp"].data_ptr(), d["resp"].data_ptr(), d["ang"].data_ptr(),
-                                             d["desc"].data_ptr(), d["n"].data_ptr()))
-    try:
-        for _ in range(2):
-            run()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(5):
-            run()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / 5
-        nk = float(d["n"].float().mean())
-    finally:
-        orb.close(); ctx.close()
-    px = 1241 * 376
-    alg = B * (2.0 * px + nk * (8 + 4 + 4 + 32))   # image in once, blurred image out once, key-point records out
-    return {"workload": f"{B} synthetic 1241 x 376 images, orb_nfeatures 2000, FAST threshold 20, one pyramid level", "images_per_s": B / dt,
-            "ms_per_launch": dt * 1e3, "mean_keypoints": nk,
-            "roofline": {"bound": "hbm", "achieved": alg / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / dt / 1e9 / HBM_PEAK_GBS,
-                         "algorithmic_bytes_per_launch": alg, "traffic": None,
-                         "note": "all kernels of the front-end together; algorithmic bytes = image read once + blurred image written once + "
-                                 "key-point records (the score / keep maps are intermediate)"}}
+        def run():
+            orb.detect_dev(d["img"].data_ptr(), d["kp"].data_ptr(), d["resp"].data_ptr(), d["ang"].data_ptr(), d["desc"].data_ptr(), d["n"].data_ptr(),
+                           octave=d["oct"].data_ptr(), n_total=d["nt"].data_ptr())
+        try:
+            for _ in range(2):
+                run()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                run()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 5
+            nk = float(d["n"].float().mean())
+            truncated = int((d["nt"] > d["n"]).sum())
+            per_level = [float((d["oct"][:, :int(nk)] == l).float().sum(dim=1).mean()) for l in range(nlev)]
+        finally:
+            orb.close(); ctx.close()
+        px = float(sum((round(cols / 1.2 ** l) * round(rows / 1.2 ** l)) for l in range(nlev)))
+        alg = B * (2.0 * px + nk * (8 + 4 + 4 + 4 + 32))   # level images in once, blurred images out once, key-point records out
+        out[name] = {"workload": f"{B} synthetic {cols} x {rows} images, orb_nfeatures {nfeat}, FAST threshold 20, {nlev} pyramid level(s)",
+                     "levels": nlev, "images_per_s": B / dt, "ms_per_launch": dt * 1e3, "mean_keypoints": nk, "mean_keypoints_per_level": per_level,
+                     "images_truncated_at_capacity": truncated,
+                     "roofline": {"bound": "hbm", "achieved": alg / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / dt / 1e9 / HBM_PEAK_GBS,
+                                  "algorithmic_bytes_per_launch": alg, "traffic": committed_traffic("orb_fast_nms_kernel") if nlev == 1 else None,
+                                  "note": "all kernels of the front-end together; algorithmic bytes = level images read once + blurred images "
+                                          "written once + key-point records (score / keep maps are intermediate); traffic = the FAST + NMS kernel's "
+                                          "counted bytes (the largest kernel), when a committed PMC pass lists it"}}
+    return out
 
 
 def images_leg(local_rank, B=128, steps=8):

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define STVO_ABI_VERSION 2
+#define STVO_ABI_VERSION 3
 #define STVO_MAX_ROWS_LIMIT 65535 /* packed (distance << 16 | index) keys */
 #define STVO_POSE_MAX_POINTS 2048 /* per frame pair: points owned per worker thread x worker threads of the pose kernel */
 #define STVO_POSE_MAX_LINES 512
@@ -218,12 +218,16 @@ int stvo_seq_debug_grid(stvo_seq* seq, int b, int lines, int32_t* cell_start, in
 
 /* ---- ORB point front-end ------------------------------------------------------------------ */
 
-/* Replaces, for one pyramid level,  cv::ORB::create(...)->detectAndCompute(img, Mat(), points, pdesc, false)  as called by
- * StereoFrame::detectPointFeatures (src/stereoFrame.cpp:104-118) for B images of cols x rows bytes at once: FAST-9/16 with
- * non-maximum suppression, border filter, retainBest(nfeatures) on the FAST response (ties at the cut are kept, so up to
- * max_keypoints may come back), intensity-centroid orientation, 7x7 Gaussian blur and the 256-bit rotated BRIEF descriptor.
- * Key-points are emitted in row-major order (OpenCV leaves the order to std::nth_element).  OpenCV is third-party code that
- * is not part of the reference tree: the semantics are pinned to oracle/stvo_orb_oracle.c only (parity unpinned). */
+/* Replaces  cv::ORB::create(nfeatures, scaleFactor, nlevels, ...)->detectAndCompute(img, Mat(), points, pdesc, false)  as
+ * called by StereoFrame::detectPointFeatures (src/stereoFrame.cpp:104-118) for B images of cols x rows bytes at once: the image
+ * pyramid (8-bit bilinear resize level by level), per level FAST-9/16 with non-maximum suppression, border filter,
+ * retainBest(the level's share of nfeatures) on the FAST response (ties at the cut are kept), intensity-centroid orientation,
+ * 7x7 Gaussian blur and the 256-bit rotated BRIEF descriptor; key-points of all levels in level order with their octave and
+ * coordinates scaled back to the full image.  Within a level key-points are emitted in row-major order (OpenCV leaves the
+ * order to std::nth_element).  When more key-points qualify than max_keypoints holds, the first max_keypoints of that order
+ * come back (deterministically) and the uncapped count is reported in n_total.  max_keypoints may not exceed 4096
+ * (STVO_ERR_CAPACITY).  OpenCV is third-party code that is not part of the reference tree: the semantics are pinned to
+ * oracle/stvo_orb_oracle.c only (parity unpinned). */
 typedef struct stvo_orb stvo_orb;
 int stvo_orb_create(stvo_ctx* ctx, int B, int cols, int rows, int max_keypoints, const stvo_orb_params* prm, stvo_orb** out);
 int stvo_orb_destroy(stvo_orb* orb);
@@ -238,6 +242,13 @@ int stvo_orb_detect(stvo_orb* orb, const uint8_t* images, float* kp_xy, float* r
 /* The same with DEVICE pointers, enqueued on the context's stream (no synchronisation). */
 int stvo_orb_detect_dev(stvo_orb* orb, const uint8_t* images, float* kp_xy, float* response, float* angle, uint8_t* desc,
                         int32_t* n_kp);
+/* The full forms: octave [B][max_keypoints] = cv::KeyPoint::octave (the pyramid level, what PointFeature's sigma2 is made of,
+ * src/stereoFeatures.cpp:41-47) and n_total [B] = the number of key-points that qualified before the max_keypoints cap
+ * (n_total > n_kp: the output was truncated).  Either may be NULL. */
+int stvo_orb_detect_levels(stvo_orb* orb, const uint8_t* images, float* kp_xy, float* response, float* angle, int32_t* octave,
+                           uint8_t* desc, int32_t* n_kp, int32_t* n_total);
+int stvo_orb_detect_levels_dev(stvo_orb* orb, const uint8_t* images, float* kp_xy, float* response, float* angle, int32_t* octave,
+                               uint8_t* desc, int32_t* n_kp, int32_t* n_total);
 
 /* ---- measurement helpers --------------------------------------------------------------------- */
 /* Times `iters` launches of the named kernel stage on the context's stream with hipEvents and

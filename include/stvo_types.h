@@ -148,13 +148,15 @@ typedef struct stvo_frame_features {
 } stvo_frame_features;
 
 /* Parameters of the ORB point front-end = the cv::ORB::create arguments the reference passes (src/stereoFrame.cpp:112-114)
- * that vary between its configurations; fixed here: one pyramid level (orb_nlevels 1 of config_kitti.yaml), WTA_K 2,
- * FAST_SCORE ranking (orb_score 1), patch size 31. */
+ * that vary between its configurations; fixed here: WTA_K 2, FAST_SCORE ranking (orb_score 1), patch size 31. */
+#define STVO_ORB_MAX_LEVELS 8
 typedef struct stvo_orb_params {
     int32_t nfeatures;       /* Config::orbNFeatures()  (2000 in config_kitti.yaml)                     */
     int32_t fast_threshold;  /* Config::orbFastTh() or the handler's adaptive orb_fast_th (1 .. 254)     */
     int32_t edge_threshold;  /* Config::orbEdgeTh()  (19; must be >= 19: patch radius 15, pattern reach) */
-    int32_t reserved;
+    int32_t nlevels;         /* Config::orbNLevels()  (1 in config_kitti.yaml, 4 in config_euroc.yaml:61 and src/config.cpp:97);
+                                0 is read as 1; at most STVO_ORB_MAX_LEVELS */
+    double scale_factor;     /* Config::orbScaleFactor()  (1.2; > 1; ignored for one level) */
 } stvo_orb_params;
 
 /* Error codes of the C-ABI (0 ok, <0 error; never throws). */

@@ -1,12 +1,15 @@
 // orb_kernels.hip — the ORB point front-end on gfx950: what the reference obtains from
 //     cv::ORB::create(...)->detectAndCompute(img, Mat(), points, pdesc, false)     (/root/reference/src/stereoFrame.cpp:104-118)
-// for ONE pyramid level (config_kitti.yaml: orb_nlevels 1), FAST_SCORE ranking (orb_score 1), WTA_K 2, patch 31:
+// for orb_nlevels pyramid levels (config_kitti.yaml: 1; config_euroc.yaml / src/config.cpp:96-97: 4 at scale 1.2), FAST_SCORE
+// ranking (orb_score 1), WTA_K 2, patch 31.  Per level:
 //   orb_fast_nms_kernel  FAST-9/16 score (cornerScore<16>) + 3x3 non-maximum suppression + border filter per 64 x 64 tile, all in
 //                        LDS: compass-point rejection, candidates compacted so that the full score runs on dense lanes;
 //                        survivors go to a per-image list + response histogram (no score map in global memory)
 //   orb_order_kernel     KeyPointsFilter::retainBest as a histogram cut (ties kept) + row-major ordering (bitonic sort in LDS)
 //   orb_blur_kernel      GaussianBlur 7x7, sigma 2, 8-bit fixed point, BORDER_REFLECT_101
 //   orb_describe_kernel  intensity-centroid angle (ICAngles, fastAtan2) + rotated BRIEF, one wave per key-point
+// around them (more than one level): orb_resize_kernel (level l from level l - 1, OpenCV's 8-bit bilinear resize in 11-bit fixed
+// point) and orb_concat_kernel (levels in order, coordinates x scale, octave = level).
 // OpenCV is third-party code that is not under /root/reference: the semantics are those of oracle/stvo_orb_oracle.c (a
 // restatement of OpenCV's algorithm, parity unpinned), against which these kernels are bit-exact (tests/test_gpu_orb.py).
 // Integer / byte work throughout; the only floating point is the angle polynomial and the rotation of the test pattern, in
@@ -26,10 +29,12 @@ constexpr int ORB_HP = 15;  // half patch
 
 struct OrbDev {
     int B, cols, rows, K, nfeatures, fast_th, edge_th;
+    int cand_cap;         // rows * cols / 4 + 64: a 3x3 strict maximum every 2 x 2 pixels at most, so the list cannot overflow
+    int32_t* n_total;     // [B] or nullptr: key-points that qualified before the cap K
     const uint8_t* img;   // [B][rows][cols]
     uint8_t* blur;        // [B][rows][cols]
     int32_t* hist;        // [B][256] responses of the key-points that survive NMS + border
-    uint32_t* cand;       // [B][CAND_CAP] the survivors, unordered: (y << 20 | x << 8 | response)
+    uint32_t* cand;       // [B][cand_cap] the survivors, unordered: (y << 20 | x << 8 | response)
     int32_t* n_cand;      // [B]
     float* kp;            // [B][K][2]
     float* resp;          // [B][K]
@@ -50,7 +55,6 @@ constexpr int SC_W = FT_W + 2, SC_H = FT_H + 2;   // scores are needed one pixel
 constexpr int IM_H = FT_H + 8;                    // image tile rows: + 1 (score halo) + 3 (circle radius) on both sides
 constexpr int IM_DW = 19, IM_PITCH = 20;          // image tile row: 19 words = pixels x0 - 5 .. x0 + 70 (score position sx <-> byte sx + 4: word aligned)
 constexpr int SC_PITCH = 72;                      // score row, bytes (18 words)
-constexpr int CAND_CAP = 16384;                    // survivors of NMS + border per image (typ. 2-3 k at threshold 20)
 
 // cornerScore<16> of the pixel at byte (lx, ly) of the LDS image tile: max over the 16 arcs of 9 contiguous circle pixels of
 // the smallest (signed) difference in the arc, bright and dark, minus 1 — min / max over every window of 9 by doubling
@@ -231,18 +235,38 @@ __global__ __launch_bounds__(256) void orb_fast_nms_kernel(OrbDev o) {
     for (int k = tid; k < nkp; k += 256) {
         const uint32_t c = s_kp[k];
         const int slot = s_base + k;
-        if (slot < CAND_CAP) o.cand[(size_t)b * CAND_CAP + slot] = c;
+        if (slot < o.cand_cap) o.cand[(size_t)b * o.cand_cap + slot] = c;
         atomicAdd(&o.hist[(size_t)b * 256 + (c & 255u)], 1);
     }
 }
 
 // retainBest(nfeatures) as a histogram cut (the smallest response such that at least nfeatures key-points are >= it; ties at
 // the cut are all kept) + ROW-MAJOR ordering of the survivors: one workgroup per image, bitonic sort of (y, x, response) words
-// in LDS.  Writes key-points and responses, n_kp (capped at K), and resets the image's counters for the next frame.
+// in LDS.  Writes key-points and responses, n_kp (capped at K), n_total, and resets the image's counters for the next frame.
+// When more key-points qualify than the LDS holds (ORD_CAP; masses of equal responses at the cut), the FIRST K of the row-major
+// order are selected exactly — histogram of the qualifying key-points over image rows, then over the columns of the boundary
+// row — so the output never depends on the order in which tiles appended their candidates.
 constexpr int ORD_CAP = 4096;
+__device__ __forceinline__ void order_block_scan(int* bins /* [4096], in place -> inclusive prefix */, int* s_part /* [1024] */) {
+    const int tid = threadIdx.x;
+    int v0 = bins[4 * tid], v1 = bins[4 * tid + 1], v2 = bins[4 * tid + 2], v3 = bins[4 * tid + 3];
+    v1 += v0; v2 += v1; v3 += v2;
+    s_part[tid] = v3;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int add = tid >= off ? s_part[tid - off] : 0;
+        __syncthreads();
+        s_part[tid] += add;
+        __syncthreads();
+    }
+    const int base = tid ? s_part[tid - 1] : 0;
+    bins[4 * tid] = base + v0; bins[4 * tid + 1] = base + v1; bins[4 * tid + 2] = base + v2; bins[4 * tid + 3] = base + v3;
+    __syncthreads();
+}
 __global__ __launch_bounds__(1024) void orb_order_kernel(OrbDev o) {
     __shared__ uint32_t s_key[ORD_CAP];
-    __shared__ int s_cut, s_n;
+    __shared__ int s_part[1024];
+    __shared__ int s_cut, s_n, s_acc, s_ystar, s_xstar;
     const int b = blockIdx.x, tid = threadIdx.x;
     if (tid == 0) {
         int cut = 1, acc = 0;
@@ -254,14 +278,50 @@ __global__ __launch_bounds__(1024) void orb_order_kernel(OrbDev o) {
             }
         }
         s_cut = cut;
+        s_acc = acc;  // key-points with response >= cut (all of them when fewer than nfeatures exist: cut stays 1)
         s_n = 0;
+    }
+    __syncthreads();
+    const int nc = min(o.n_cand[b], o.cand_cap), cut = s_cut, n_acc = s_acc;
+    const uint32_t* cand = o.cand + (size_t)b * o.cand_cap;
+    uint32_t bound = 0xFFFFFFFFu;  // accept keys (y << 12 | x) <= bound
+    if (n_acc > ORD_CAP) {  // block-uniform, rare: select the first K of the row-major order exactly
+        const int want = min(o.K, ORD_CAP);
+        int* bins = reinterpret_cast<int*>(s_key);
+        for (int i = tid; i < ORD_CAP; i += 1024) bins[i] = 0;
+        __syncthreads();
+        for (int i = tid; i < nc; i += 1024) {
+            const uint32_t c = cand[i];
+            if ((int)(c & 255u) >= cut) atomicAdd(&bins[c >> 20], 1);
+        }
+        __syncthreads();
+        order_block_scan(bins, s_part);
+        for (int i = tid; i < ORD_CAP; i += 1024)  // the row in which the cumulative count reaches `want`
+            if (bins[i] >= want && (i == 0 || bins[i - 1] < want)) s_ystar = i;
+        __syncthreads();
+        const int ystar = s_ystar;
+        const int before = ystar ? bins[ystar - 1] : 0;  // key-points in the rows above
+        __syncthreads();
+        for (int i = tid; i < ORD_CAP; i += 1024) bins[i] = 0;
+        __syncthreads();
+        for (int i = tid; i < nc; i += 1024) {
+            const uint32_t c = cand[i];
+            if ((int)(c & 255u) >= cut && (int)(c >> 20) == ystar) atomicAdd(&bins[(c >> 8) & 0xFFFu], 1);
+        }
+        __syncthreads();
+        order_block_scan(bins, s_part);
+        const int need = want - before;  // >= 1 key-points of the boundary row, lowest columns first
+        for (int i = tid; i < ORD_CAP; i += 1024)
+            if (bins[i] >= need && (i == 0 || bins[i - 1] < need)) s_xstar = i;
+        __syncthreads();
+        bound = ((uint32_t)ystar << 12) | (uint32_t)s_xstar;
+        __syncthreads();
     }
     for (int i = tid; i < ORD_CAP; i += 1024) s_key[i] = 0xFFFFFFFFu;
     __syncthreads();
-    const int nc = min(o.n_cand[b], CAND_CAP), cut = s_cut;
     for (int i = tid; i < nc; i += 1024) {
-        const uint32_t c = o.cand[(size_t)b * CAND_CAP + i];
-        if ((int)(c & 255u) >= cut) {
+        const uint32_t c = cand[i];
+        if ((int)(c & 255u) >= cut && (c >> 8) <= bound) {
             const int slot = atomicAdd(&s_n, 1);
             if (slot < ORD_CAP) s_key[slot] = c;
         }
@@ -297,7 +357,100 @@ __global__ __launch_bounds__(1024) void orb_order_kernel(OrbDev o) {
     if (tid < 256) o.hist[(size_t)b * 256 + tid] = 0;  // ready for the next frame
     if (tid == 0) {
         o.n_kp[b] = n_out;
+        if (o.n_total) o.n_total[b] = n_acc;
         o.n_cand[b] = 0;
+    }
+}
+
+// Level l of the pyramid from level l - 1: OpenCV's resize(src, dst, dsize, 0, 0, INTER_LINEAR) for 8-bit images — source
+// position (d + 0.5) scale - 0.5 in double -> float, weights cvRound((1 - f) 2048) / cvRound(f 2048) as shorts, horizontal pass
+// in integers, rows combined as (((b0 (S0 >> 4)) >> 16) + ((b1 (S1 >> 4)) >> 16) + 2) >> 2 (oracle/stvo_orb_oracle.c:
+// orc_resize_linear).  One thread per output pixel; the coefficient arithmetic is a few FP ops next to four byte loads.
+struct ResizeArgs {
+    int B, scols, srows, dcols, drows;
+    double scale_x, scale_y;  // 1 / (dcols / scols), 1 / (drows / srows) as OpenCV forms them
+    const uint8_t* src;
+    uint8_t* dst;
+};
+__global__ __launch_bounds__(256) void orb_resize_kernel(ResizeArgs r) {
+    const int dx = blockIdx.x * 256 + threadIdx.x, dy = blockIdx.y, b = blockIdx.z;
+    if (dx >= r.dcols) return;
+    float fx = (float)(((double)dx + 0.5) * r.scale_x - 0.5);
+    int sx = (int)floorf(fx);
+    fx -= (float)sx;
+    if (sx < 0) {
+        fx = 0.f;
+        sx = 0;
+    }
+    if (sx >= r.scols - 1) {
+        fx = 0.f;
+        sx = r.scols - 1;
+    }
+    const int a0 = (short)__float2int_rn((1.f - fx) * 2048.f), a1 = (short)__float2int_rn(fx * 2048.f);
+    float fy = (float)(((double)dy + 0.5) * r.scale_y - 0.5);
+    const int sy = (int)floorf(fy);
+    fy -= (float)sy;
+    const int b0 = (short)__float2int_rn((1.f - fy) * 2048.f), b1 = (short)__float2int_rn(fy * 2048.f);
+    const uint8_t* img = r.src + (size_t)b * r.srows * r.scols;
+    const int y0 = min(max(sy, 0), r.srows - 1), y1 = min(max(sy + 1, 0), r.srows - 1);
+    const uint8_t* r0 = img + (size_t)y0 * r.scols;
+    const uint8_t* r1 = img + (size_t)y1 * r.scols;
+    int S0, S1;
+    if (sx < r.scols - 1) {
+        S0 = (int)r0[sx] * a0 + (int)r0[sx + 1] * a1;
+        S1 = (int)r1[sx] * a0 + (int)r1[sx + 1] * a1;
+    } else {
+        S0 = (int)r0[sx] * 2048;
+        S1 = (int)r1[sx] * 2048;
+    }
+    const int v = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2;
+    r.dst[((size_t)b * r.drows + dy) * r.dcols + dx] = (uint8_t)min(max(v, 0), 255);
+}
+
+// Key-points of all levels in level order (ORB_Impl::computeKeyPoints appends level after level): coordinates multiplied by the
+// level's scale in float (pt *= scale), octave = level; one workgroup per image, capped at K.
+struct ConcatArgs {
+    int B, K, nlevels, Kl;  // Kl: stride of the per-level arrays
+    float scale[STVO_ORB_MAX_LEVELS];
+    const float* kp[STVO_ORB_MAX_LEVELS];
+    const float* resp[STVO_ORB_MAX_LEVELS];
+    const float* ang[STVO_ORB_MAX_LEVELS];
+    const uint8_t* desc[STVO_ORB_MAX_LEVELS];
+    const int32_t* n[STVO_ORB_MAX_LEVELS];
+    const int32_t* n_tot[STVO_ORB_MAX_LEVELS];
+    float* kp_o;
+    float* resp_o;
+    float* ang_o;
+    int32_t* oct_o;  // may be nullptr
+    uint8_t* desc_o;
+    int32_t* n_o;
+    int32_t* n_total_o;  // may be nullptr
+};
+__global__ __launch_bounds__(256) void orb_concat_kernel(ConcatArgs c) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    int off = 0, total = 0;
+    for (int l = 0; l < c.nlevels; ++l) {
+        const int nl = c.n[l][b];
+        total += c.n_tot[l][b];
+        const float sc = c.scale[l];
+        for (int i = tid; i < nl && off + i < c.K; i += 256) {
+            const size_t s = (size_t)b * c.Kl + i, d = (size_t)b * c.K + off + i;
+            const float x = c.kp[l][2 * s], y = c.kp[l][2 * s + 1];
+            c.kp_o[2 * d] = l ? x * sc : x;
+            c.kp_o[2 * d + 1] = l ? y * sc : y;
+            c.resp_o[d] = c.resp[l][s];
+            c.ang_o[d] = c.ang[l][s];
+            if (c.oct_o) c.oct_o[d] = l;
+            const uint4* src = reinterpret_cast<const uint4*>(c.desc[l] + s * 32);
+            uint4* dst = reinterpret_cast<uint4*>(c.desc_o + d * 32);
+            dst[0] = src[0];
+            dst[1] = src[1];
+        }
+        off += nl;
+    }
+    if (tid == 0) {
+        c.n_o[b] = min(off, c.K);
+        if (c.n_total_o) c.n_total_o[b] = total;
     }
 }
 
@@ -524,12 +677,23 @@ __global__ __launch_bounds__(256) void orb_describe_kernel(OrbDev o, Umax um) {
 
 struct stvo_orb {
     stvo_ctx* ctx = nullptr;
-    stvo::OrbDev d{};
+    int B = 0, K = 0, nlevels = 1;
     stvo_orb_params prm{};
-    char* dev = nullptr;  // blur | hist | cand | n_cand | pattern
+    struct Level {
+        stvo::OrbDev d{};      // geometry, budget and scratch of the level (img / outputs are set per call)
+        float scale = 1.f;
+        uint8_t* img = nullptr;  // the resized image of the level (levels > 0)
+        // per-level outputs when there is more than one level (level coordinates; orb_concat_kernel assembles the result)
+        float *kp = nullptr, *resp = nullptr, *ang = nullptr;
+        uint8_t* desc = nullptr;
+        int32_t *n = nullptr, *n_tot = nullptr;
+        bool active = true;    // a level without budget, or smaller than the border, yields nothing
+    } lev[STVO_ORB_MAX_LEVELS];
+    char* dev = nullptr;  // every device array of the object, carved from one allocation
     char* io = nullptr;   // staging for the host-buffer entry point: images in, results out
     size_t io_bytes = 0;
     int8_t pattern[1024];
+    int8_t* d_pattern = nullptr;
     stvo::BlurK blur_k{};
     stvo::Umax umax{};
 };
@@ -550,6 +714,8 @@ void default_pattern(int8_t* pattern) {  // seeded stand-in for OpenCV's learned
     }
 }
 
+int cv_round_f(float v) { return (int)std::lrintf(v); }  // cvRound: half to even
+
 }  // namespace
 
 extern "C" {
@@ -560,29 +726,81 @@ int stvo_orb_create(stvo_ctx* ctx, int B, int cols, int rows, int max_keypoints,
     if (prm->nfeatures <= 0 || prm->fast_threshold < 1 || prm->fast_threshold > 254 || prm->edge_threshold < 19 ||
         2 * prm->edge_threshold >= cols || 2 * prm->edge_threshold >= rows)
         return STVO_ERR_INVALID_ARG;
+    const int nlevels = prm->nlevels <= 0 ? 1 : prm->nlevels;
+    if (nlevels > STVO_ORB_MAX_LEVELS || (nlevels > 1 && !(prm->scale_factor > 1.0 && prm->scale_factor <= 2.0))) return STVO_ERR_INVALID_ARG;
     if (rows >= 4096 || cols >= 4096) return STVO_ERR_CAPACITY;  // candidates pack (y, x) in 12 bits each
+    // the ordering kernel emits at most ORD_CAP key-points per level (its LDS sort): an output capacity beyond it cannot be honoured.
+    // (nfeatures may be anything: when more key-points qualify than max_keypoints, the first max_keypoints of the row-major order
+    // are selected exactly and n_total reports how many qualified)
+    if (max_keypoints > stvo::ORD_CAP) return STVO_ERR_CAPACITY;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     stvo_orb* o = new (std::nothrow) stvo_orb();
     if (!o) return STVO_ERR_HIP;
     o->ctx = ctx;
     o->prm = *prm;
-    const size_t px = (size_t)B * rows * cols;
+    o->B = B; o->K = max_keypoints; o->nlevels = nlevels;
+    // level geometry and feature budgets exactly as ORB_Impl forms them (oracle/stvo_orb_oracle.c: orc_orb_levels)
+    int nf[STVO_ORB_MAX_LEVELS];
+    {
+        const float factor = (float)(1.0 / (nlevels > 1 ? prm->scale_factor : 1.2));
+        float nd = (float)prm->nfeatures * (1.f - factor) / (1.f - (float)std::pow((double)factor, (double)nlevels));
+        int sum = 0;
+        for (int l = 0; l < nlevels - 1; ++l) {
+            nf[l] = cv_round_f(nd);
+            sum += nf[l];
+            nd *= factor;
+        }
+        nf[nlevels - 1] = prm->nfeatures - sum > 0 ? prm->nfeatures - sum : 0;
+        if (nlevels == 1) nf[0] = prm->nfeatures;
+    }
     auto al = [](size_t v) { return (v + 255) & ~size_t(255); };
-    const size_t o_blur = 0, o_hist = al(px), o_cand = o_hist + al((size_t)B * 256 * 4), o_ncand = o_cand + al((size_t)B * stvo::CAND_CAP * 4),
-                 o_pat = o_ncand + al((size_t)B * 4), total = o_pat + 1024;
+    size_t total = 1024;  // the pattern
+    size_t off_blur[STVO_ORB_MAX_LEVELS], off_hist[STVO_ORB_MAX_LEVELS], off_cand[STVO_ORB_MAX_LEVELS], off_nc[STVO_ORB_MAX_LEVELS],
+        off_img[STVO_ORB_MAX_LEVELS], off_out[STVO_ORB_MAX_LEVELS];
+    for (int l = 0; l < nlevels; ++l) {
+        stvo_orb::Level& L = o->lev[l];
+        L.scale = l ? (float)std::pow(prm->scale_factor, (double)l) : 1.f;
+        stvo::OrbDev& d = L.d;
+        d.B = B; d.K = max_keypoints;
+        d.cols = l ? cv_round_f((float)cols / L.scale) : cols;
+        d.rows = l ? cv_round_f((float)rows / L.scale) : rows;
+        d.nfeatures = nf[l]; d.fast_th = prm->fast_threshold; d.edge_th = prm->edge_threshold;
+        d.cand_cap = d.rows * d.cols / 4 + 64;
+        L.active = nf[l] > 0 && 2 * prm->edge_threshold < d.cols && 2 * prm->edge_threshold < d.rows && d.cols >= 16 && d.rows >= 16;
+        const size_t px = (size_t)B * d.rows * d.cols, nk = (size_t)B * max_keypoints;
+        off_blur[l] = total; total += al(px);
+        off_hist[l] = total; total += al((size_t)B * 256 * 4);
+        off_cand[l] = total; total += al((size_t)B * d.cand_cap * 4);
+        off_nc[l] = total; total += al((size_t)B * 4);
+        off_img[l] = total; if (l) total += al(px);
+        off_out[l] = total; if (nlevels > 1) total += al(nk * 8) + 2 * al(nk * 4) + al(nk * 32) + 2 * al((size_t)B * 4);
+    }
     if (!hip_ok(ctx, hipMalloc((void**)&o->dev, total), "hipMalloc orb") || !hip_ok(ctx, hipMemset(o->dev, 0, total), "hipMemset orb")) {
         if (o->dev) (void)hipFree(o->dev);
         delete o;
         return STVO_ERR_HIP;
     }
-    stvo::OrbDev& d = o->d;
-    d.B = B; d.cols = cols; d.rows = rows; d.K = max_keypoints;
-    d.nfeatures = prm->nfeatures; d.fast_th = prm->fast_threshold; d.edge_th = prm->edge_threshold;
-    d.blur = (uint8_t*)(o->dev + o_blur);
-    d.hist = (int32_t*)(o->dev + o_hist); d.cand = (uint32_t*)(o->dev + o_cand); d.n_cand = (int32_t*)(o->dev + o_ncand);
-    d.pattern = (const int8_t*)(o->dev + o_pat);
+    o->d_pattern = (int8_t*)o->dev;
+    for (int l = 0; l < nlevels; ++l) {
+        stvo_orb::Level& L = o->lev[l];
+        stvo::OrbDev& d = L.d;
+        const size_t nk = (size_t)B * max_keypoints;
+        d.blur = (uint8_t*)(o->dev + off_blur[l]);
+        d.hist = (int32_t*)(o->dev + off_hist[l]); d.cand = (uint32_t*)(o->dev + off_cand[l]); d.n_cand = (int32_t*)(o->dev + off_nc[l]);
+        d.pattern = o->d_pattern;
+        if (l) L.img = (uint8_t*)(o->dev + off_img[l]);
+        if (nlevels > 1) {
+            char* q = o->dev + off_out[l];
+            L.kp = (float*)q; q += al(nk * 8);
+            L.resp = (float*)q; q += al(nk * 4);
+            L.ang = (float*)q; q += al(nk * 4);
+            L.desc = (uint8_t*)q; q += al(nk * 32);
+            L.n = (int32_t*)q; q += al((size_t)B * 4);
+            L.n_tot = (int32_t*)q;
+        }
+    }
     default_pattern(o->pattern);
-    if (!hip_ok(ctx, hipMemcpy(o->dev + o_pat, o->pattern, 1024, hipMemcpyHostToDevice), "hipMemcpy pattern")) {
+    if (!hip_ok(ctx, hipMemcpy(o->d_pattern, o->pattern, 1024, hipMemcpyHostToDevice), "hipMemcpy pattern")) {
         (void)hipFree(o->dev);
         delete o;
         return STVO_ERR_HIP;
@@ -625,7 +843,7 @@ int stvo_orb_set_pattern(stvo_orb* o, const int8_t* pattern) {
     HIP_TRY(o->ctx, hipSetDevice(o->ctx->device));
     HIP_TRY(o->ctx, hipStreamSynchronize(o->ctx->stream));
     std::memcpy(o->pattern, pattern, 1024);
-    HIP_TRY(o->ctx, hipMemcpy(const_cast<int8_t*>(o->d.pattern), pattern, 1024, hipMemcpyHostToDevice));
+    HIP_TRY(o->ctx, hipMemcpy(o->d_pattern, pattern, 1024, hipMemcpyHostToDevice));
     return STVO_OK;
 }
 
@@ -635,32 +853,73 @@ int stvo_orb_get_pattern(const stvo_orb* o, int8_t* pattern) {
     return STVO_OK;
 }
 
-int stvo_orb_detect_dev(stvo_orb* o, const uint8_t* images, float* kp_xy, float* response, float* angle, uint8_t* desc,
-                        int32_t* n_kp) {
+int stvo_orb_detect_levels_dev(stvo_orb* o, const uint8_t* images, float* kp_xy, float* response, float* angle, int32_t* octave,
+                               uint8_t* desc, int32_t* n_kp, int32_t* n_total) {
     if (!o || !images || !kp_xy || !response || !angle || !desc || !n_kp) return STVO_ERR_INVALID_ARG;
     stvo_ctx* ctx = o->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    stvo::OrbDev d = o->d;
-    d.img = images; d.kp = kp_xy; d.resp = response; d.angle = angle; d.desc = desc; d.n_kp = n_kp;
     hipStream_t s = ctx->stream;
-    const dim3 tiles((d.cols + 4 * stvo::BL_T - 1) / (4 * stvo::BL_T), (d.rows + stvo::BL_R - 1) / stvo::BL_R, d.B), tb(stvo::BL_T);
-    hipLaunchKernelGGL(stvo::orb_fast_nms_kernel, dim3((d.cols + stvo::FT_W - 1) / stvo::FT_W, (d.rows + stvo::FT_H - 1) / stvo::FT_H, d.B),
-                       dim3(256), 0, s, d);
-    hipLaunchKernelGGL(stvo::orb_blur_kernel, tiles, tb, 0, s, d, o->blur_k);
-    hipLaunchKernelGGL(stvo::orb_order_kernel, dim3(d.B), dim3(1024), 0, s, d);
-    hipLaunchKernelGGL(stvo::orb_describe_kernel, dim3((d.K + stvo::DESC_KP_PER_WG - 1) / stvo::DESC_KP_PER_WG, d.B), dim3(256), 0, s, d, o->umax);
+    const bool multi = o->nlevels > 1;
+    const uint8_t* prev = images;
+    for (int l = 0; l < o->nlevels; ++l) {
+        stvo_orb::Level& L = o->lev[l];
+        stvo::OrbDev d = L.d;
+        if (l) {  // resize(level l - 1): needed by the next level even when this one yields nothing
+            const stvo::OrbDev& p = o->lev[l - 1].d;
+            stvo::ResizeArgs r{d.B, p.cols, p.rows, d.cols, d.rows, 1.0 / ((double)d.cols / p.cols), 1.0 / ((double)d.rows / p.rows), prev, L.img};
+            hipLaunchKernelGGL(stvo::orb_resize_kernel, dim3((d.cols + 255) / 256, d.rows, d.B), dim3(256), 0, s, r);
+            d.img = L.img;
+        } else {
+            d.img = images;
+        }
+        prev = d.img;
+        if (multi) {
+            d.kp = L.kp; d.resp = L.resp; d.angle = L.ang; d.desc = L.desc; d.n_kp = L.n; d.n_total = L.n_tot;
+        } else {
+            d.kp = kp_xy; d.resp = response; d.angle = angle; d.desc = desc; d.n_kp = n_kp; d.n_total = n_total;
+        }
+        if (!L.active) {
+            HIP_TRY(ctx, hipMemsetAsync(d.n_kp, 0, (size_t)d.B * 4, s));
+            if (d.n_total) HIP_TRY(ctx, hipMemsetAsync(d.n_total, 0, (size_t)d.B * 4, s));
+            continue;
+        }
+        const dim3 tiles((d.cols + 4 * stvo::BL_T - 1) / (4 * stvo::BL_T), (d.rows + stvo::BL_R - 1) / stvo::BL_R, d.B), tb(stvo::BL_T);
+        hipLaunchKernelGGL(stvo::orb_fast_nms_kernel, dim3((d.cols + stvo::FT_W - 1) / stvo::FT_W, (d.rows + stvo::FT_H - 1) / stvo::FT_H, d.B),
+                           dim3(256), 0, s, d);
+        hipLaunchKernelGGL(stvo::orb_blur_kernel, tiles, tb, 0, s, d, o->blur_k);
+        hipLaunchKernelGGL(stvo::orb_order_kernel, dim3(d.B), dim3(1024), 0, s, d);
+        hipLaunchKernelGGL(stvo::orb_describe_kernel, dim3((d.K + stvo::DESC_KP_PER_WG - 1) / stvo::DESC_KP_PER_WG, d.B), dim3(256), 0, s, d, o->umax);
+    }
+    if (multi) {
+        stvo::ConcatArgs c{};
+        c.B = o->B; c.K = o->K; c.nlevels = o->nlevels; c.Kl = o->K;
+        for (int l = 0; l < o->nlevels; ++l) {
+            const stvo_orb::Level& L = o->lev[l];
+            c.scale[l] = L.scale; c.kp[l] = L.kp; c.resp[l] = L.resp; c.ang[l] = L.ang; c.desc[l] = L.desc; c.n[l] = L.n; c.n_tot[l] = L.n_tot;
+        }
+        c.kp_o = kp_xy; c.resp_o = response; c.ang_o = angle; c.oct_o = octave; c.desc_o = desc; c.n_o = n_kp; c.n_total_o = n_total;
+        hipLaunchKernelGGL(stvo::orb_concat_kernel, dim3(o->B), dim3(256), 0, s, c);
+    } else if (octave) {
+        HIP_TRY(ctx, hipMemsetAsync(octave, 0, (size_t)o->B * o->K * 4, s));
+    }
     return check_launch(ctx);
 }
 
-int stvo_orb_detect(stvo_orb* o, const uint8_t* images, float* kp_xy, float* response, float* angle, uint8_t* desc, int32_t* n_kp) {
+int stvo_orb_detect_dev(stvo_orb* o, const uint8_t* images, float* kp_xy, float* response, float* angle, uint8_t* desc,
+                        int32_t* n_kp) {
+    return stvo_orb_detect_levels_dev(o, images, kp_xy, response, angle, nullptr, desc, n_kp, nullptr);
+}
+
+int stvo_orb_detect_levels(stvo_orb* o, const uint8_t* images, float* kp_xy, float* response, float* angle, int32_t* octave, uint8_t* desc,
+                           int32_t* n_kp, int32_t* n_total) {
     if (!o || !images || !kp_xy || !response || !angle || !desc || !n_kp) return STVO_ERR_INVALID_ARG;
     stvo_ctx* ctx = o->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const stvo::OrbDev& d = o->d;
+    const stvo::OrbDev& d = o->lev[0].d;
     const size_t px = (size_t)d.B * d.rows * d.cols, nk = (size_t)d.B * d.K;
     auto al = [](size_t v) { return (v + 255) & ~size_t(255); };
-    const size_t o_img = 0, o_kp = al(px), o_resp = o_kp + al(nk * 8), o_ang = o_resp + al(nk * 4), o_desc = o_ang + al(nk * 4),
-                 o_n = o_desc + al(nk * 32), total = o_n + al((size_t)d.B * 4);
+    const size_t o_img = 0, o_kp = al(px), o_resp = o_kp + al(nk * 8), o_ang = o_resp + al(nk * 4), o_oct = o_ang + al(nk * 4),
+                 o_desc = o_oct + al(nk * 4), o_n = o_desc + al(nk * 32), o_nt = o_n + al((size_t)d.B * 4), total = o_nt + al((size_t)d.B * 4);
     if (o->io_bytes < total) {
         if (o->io) (void)hipFree(o->io);
         o->io = nullptr;
@@ -671,15 +930,21 @@ int stvo_orb_detect(stvo_orb* o, const uint8_t* images, float* kp_xy, float* res
     char* D = o->io;
     HIP_TRY(ctx, hipMemcpyAsync(D + o_img, images, px, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(D + o_kp, 0, total - o_kp, ctx->stream));
-    TRY(stvo_orb_detect_dev(o, (const uint8_t*)(D + o_img), (float*)(D + o_kp), (float*)(D + o_resp), (float*)(D + o_ang),
-                            (uint8_t*)(D + o_desc), (int32_t*)(D + o_n)));
+    TRY(stvo_orb_detect_levels_dev(o, (const uint8_t*)(D + o_img), (float*)(D + o_kp), (float*)(D + o_resp), (float*)(D + o_ang),
+                                   (int32_t*)(D + o_oct), (uint8_t*)(D + o_desc), (int32_t*)(D + o_n), (int32_t*)(D + o_nt)));
     HIP_TRY(ctx, hipMemcpyAsync(kp_xy, D + o_kp, nk * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(response, D + o_resp, nk * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(angle, D + o_ang, nk * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (octave) HIP_TRY(ctx, hipMemcpyAsync(octave, D + o_oct, nk * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(desc, D + o_desc, nk * 32, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(n_kp, D + o_n, (size_t)d.B * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (n_total) HIP_TRY(ctx, hipMemcpyAsync(n_total, D + o_nt, (size_t)d.B * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return STVO_OK;
+}
+
+int stvo_orb_detect(stvo_orb* o, const uint8_t* images, float* kp_xy, float* response, float* angle, uint8_t* desc, int32_t* n_kp) {
+    return stvo_orb_detect_levels(o, images, kp_xy, response, angle, nullptr, desc, n_kp, nullptr);
 }
 
 }  // extern "C"

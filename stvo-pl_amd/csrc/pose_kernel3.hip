@@ -289,7 +289,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void pose3_kernel(const PoseArgs a
 #pragma unroll 1
     for (int f = blockIdx.x * 2 + p; f < a.B; f += 2 * gridDim.x) {
         const long long t_begin = tick();
-        long long t_wait = 0, t_stage = 0, t_out = 0;
+        long long t_wait = 0, t_stage = 0, t_out = 0, t_alg = 0, t_cov = 0, t_rm = 0, t_commit = 0, t_pre = 0, t_post = 0, t_sum = 0;
         const stvo_opt_params& prm = a.prm;
         const stvo_cam cam_f = a.cams ? a.cams[f] : a.cam;
         const pm::Cam5 cam{cam_f.fx, cam_f.fy, cam_f.cx, cam_f.cy};
@@ -506,6 +506,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void pose3_kernel(const PoseArgs a
         // ---------------- optimizeFunctions / optimizeFunctionsRobust at sh->DT: a job for the evaluator waves ----------------
         auto evaluate = [&](bool robust) {
             double sp = 1.0, sl = 1.0;
+            const long long te0 = tick();
             if (robust) {  // pre-pass :710-781: MAD scale of the inlier residual norms (this wave alone)
                 double DT[12];
                 pose12(sh->DT, DT);
@@ -538,6 +539,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void pose3_kernel(const PoseArgs a
                     sl = pm::clamp_scale(wave_mad_sigma<P3_LPT>(rl_, msk, sh->n_inl_l, hist));
                 }
             }
+            const long long te1 = tick();
+            t_pre += te1 - te0;
             if (lane < 12) job->DT[lane] = sh->DT[lane];
             if (lane == 0) {
                 job->sp = sp;
@@ -549,6 +552,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void pose3_kernel(const PoseArgs a
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) st_rel(&job->seq, njob);
             const long long tw = tick();
+            t_post += tw - te1;
             {
                 int spins = 0;
                 while (ld_acq(&job->done) < NEV) {
@@ -559,7 +563,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void pose3_kernel(const PoseArgs a
                     }
                 }
             }
-            t_wait += tick() - tw;
+            const long long tw2 = tick();
+            t_wait += tw2 - tw;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             if (lane < 28) {  // wave partials summed in wave order => bit-reproducible
                 double s = s_red[p][0][lane];
@@ -568,6 +573,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void pose3_kernel(const PoseArgs a
                 sh->tot[lane] = s;
             }
             wave_sync_lds();
+            t_sum += tick() - tw2;
         };
 
         // ---------------- removeOutliers at pose DT1 (:988-1067), this wave alone ----------------
@@ -682,14 +688,17 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void pose3_kernel(const PoseArgs a
                     evaluate(alg == 1);
                     if (aborted) break;
                     ++evals;
+                    const long long ta = tick();
                     if (alg == 0) t0_gn_iter<ROW>(sh, prm.min_error, prm.min_error_change, it);
                     else if (alg == 1) t0_gnr_iter<ROW>(sh, prm.min_error, prm.min_error_change);
                     else t0_lm_iter<ROW>(sh, prm.min_error, prm.min_error_change, it == 0 ? 1 : 0);
                     wave_sync_lds();
+                    t_alg += tick() - ta;
                     action = sh->action;
                     if (action != ACT_CONTINUE) break;
                 }
                 if (aborted) break;
+                const long long tc = tick();
                 if (alg == 0 && action == ACT_FAIL) {
                     sh->err_out = -1.0;  // :408-409, covariance left untouched
                 } else if (alg == 1 && !sh->good) {  // :473-478
@@ -703,6 +712,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void pose3_kernel(const PoseArgs a
                 wave_sync_lds();
                 if (stage != 0) {
                     it1 = evals;
+                    t_cov += tick() - tc;
                     break;
                 }
                 it0 = evals;
@@ -710,9 +720,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void pose3_kernel(const PoseArgs a
                 wave_sync_lds();
                 t0_is_good_fast<ROW>(sh, sh->DT1, sh->err_out);
                 wave_sync_lds();
+                t_cov += tick() - tc;
                 if (sh->good) {  // :341
                     path |= STVO_PATH_STAGE1_GOOD;
+                    const long long tr = tick();
                     remove_outliers();
+                    t_rm += tick() - tr;
                     if (sh->n_inl_p + sh->n_inl_l >= prm.min_features) {  // :345 — restart from the INITIAL DT
                         path |= STVO_PATH_REFINED;
                         stage = 1;
@@ -743,12 +756,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void pose3_kernel(const PoseArgs a
             }
             break;
         }
+        const long long tcm = tick();
         if (lane == 0) t0_commit(sh, a.results + f, status, path, it0, it1);
         if (POSE2_PRIO_P3) __builtin_amdgcn_s_setprio(0);
         wave_sync_lds();
 
         // ---------------- inlier flags out: -1 unmatched, 0 outlier, 1 inlier, in prev index order ----------------
         const long long to = tick();
+        t_commit = to - tcm;
         if (a.inl_p_out) {
             const int nch_all = (a.max_pts + 63) >> 6;
 #pragma unroll 1
@@ -787,6 +802,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void pose3_kernel(const PoseArgs a
             o[2] = t_stage;
             o[3] = t_out;
             o[4] = njob;
+            o[5] = t_alg;     // serial algebra of the iterations
+            o[6] = t_cov;     // covariance + isGoodSolution between the stages
+            o[7] = t_rm;      // removeOutliers
+            o[8] = t_commit;
+            o[9] = t_pre;     // robust pre-pass
+            o[10] = t_post;   // posting a job
+            o[11] = t_sum;    // collecting the partial sums
         }
     }
     if (lane == 0) st_rel(&job->seq, P3_SEQ_EXIT);
@@ -851,7 +873,8 @@ int launch_pose3(hipStream_t s, const PoseArgs& a) {
     if (!mb) return STVO_ERR_HIP;
     const char* env = std::getenv("STVO_POSE3_NW");  // developer override: 16 (128 VGPRs, rows) or 8 (256 VGPRs, serial 6x6)
     const int nw = env ? std::atoi(env) : 16;
-    const bool compact = a.obs_f32 != 0;
+    const char* ec = std::getenv("STVO_POSE3_COMPACT");  // developer override of the hint (the device still verifies every pair)
+    const bool compact = ec ? std::atoi(ec) != 0 : a.obs_f32 != 0;
     if (nw == 8) return compact ? launch_pose3_variant<8, false, true>(s, a, mb) : launch_pose3_variant<8, false, false>(s, a, mb);
     return compact ? launch_pose3_variant<16, true, true>(s, a, mb) : launch_pose3_variant<16, true, false>(s, a, mb);
 }

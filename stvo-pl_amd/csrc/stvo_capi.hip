@@ -476,6 +476,11 @@ int stvo_time_stage_dev(stvo_ctx* ctx, const stvo_track_batch_dev* b, const stvo
         double m[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         for (int f = 0; f < b->B; ++f)
             for (int i = 0; i < 16; ++i) m[i] += (double)h[(size_t)f * 16 + i] / b->B;
+        if (std::getenv("STVO_POSE_KERNEL") && std::atoi(std::getenv("STVO_POSE_KERNEL")) == 3)
+            std::fprintf(stderr, "[pose3 prof] mean ticks/pair: chain %.0f = stage %.0f + eval-wait %.0f + iter-algebra %.0f + cov/isgood %.0f + "
+                                 "remove_outliers %.0f + commit %.0f + out %.0f + post %.0f + sum %.0f + robust-pre %.0f; jobs (cumulative per owner) %.1f\n",
+                         m[0], m[2], m[1], m[5], m[6], m[7], m[8], m[3], m[10], m[11], m[9], m[4]);
+        else
         std::fprintf(stderr, "[pose prof] mean ticks/frame: evaluate %.0f  iter-algebra %.0f  cov+isgood+commit %.0f  "
                              "remove_outliers %.0f  total %.0f | worker: eval-compute %.0f  barrier+solver-sum %.0f  prefetch+fold %.0f\n", m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7]);
         std::fprintf(stderr, "[pose prof] per worker wave, compute + fold ticks/frame: %.0f %.0f %.0f %.0f %.0f %.0f %.0f %.0f\n", m[8], m[9], m[10],

@@ -21,7 +21,8 @@ EXPORTS = ["stvo_backend_name", "stvo_abi_version", "stvo_error_string", "stvo_c
            "stvo_time_stage_dev", "stvo_valu_peak_probe", "stvo_last_reverse_counts", "stvo_last_reverse_plan", "stvo_ctx_set_kernel_timing", "stvo_ctx_get_kernel_timing", "stvo_seq_create", "stvo_seq_destroy", "stvo_seq_enable_fetch", "stvo_seq_fetch_matches", "stvo_seq_fetch_inliers", "stvo_seq_strides",
            "stvo_seq_push", "stvo_seq_upload", "stvo_seq_step_dev", "stvo_seq_read", "stvo_seq_create_multi", "stvo_seq_set_slots",
            "stvo_seq_set_stage_timing", "stvo_seq_get_stage_timing", "stvo_seq_debug_grid", "stvo_orb_create", "stvo_orb_destroy",
-           "stvo_orb_set_pattern", "stvo_orb_get_pattern", "stvo_orb_detect", "stvo_orb_detect_dev", "stvo_seq_upload_dev"]
+           "stvo_orb_set_pattern", "stvo_orb_get_pattern", "stvo_orb_detect", "stvo_orb_detect_dev", "stvo_orb_detect_levels",
+           "stvo_orb_detect_levels_dev", "stvo_seq_upload_dev"]
 
 SEQ_NSTAGE = 5  # include/stvo_hip.h: STVO_SEQ_NSTAGE
 SEQ_STAGE_NAMES = ("stereo_points_stage", "grid_scan", "hamming_knn2", "reverse_check", "pose")
@@ -132,6 +133,8 @@ def load():
     L.stvo_orb_get_pattern.argtypes = [C.c_void_p, i8p]
     L.stvo_orb_detect.argtypes = [C.c_void_p, u8p, f32p, f32p, f32p, u8p, i32p]
     L.stvo_orb_detect_dev.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+    L.stvo_orb_detect_levels.argtypes = [C.c_void_p, u8p, f32p, f32p, f32p, i32p, u8p, i32p, i32p]
+    L.stvo_orb_detect_levels_dev.argtypes = [C.c_void_p] + [C.c_void_p] * 8
     L.stvo_seq_destroy.argtypes = [C.c_void_p]
     L.stvo_seq_push.argtypes = [C.c_void_p, C.POINTER(FrameFeatures), C.c_void_p, i32p]
     L.stvo_seq_upload.argtypes = [C.c_void_p, C.c_int, C.POINTER(FrameFeatures)]
@@ -301,16 +304,18 @@ class Context:
 
 
 class OrbParams(C.Structure):
-    _fields_ = [("nfeatures", C.c_int32), ("fast_threshold", C.c_int32), ("edge_threshold", C.c_int32), ("reserved", C.c_int32)]
+    _fields_ = [("nfeatures", C.c_int32), ("fast_threshold", C.c_int32), ("edge_threshold", C.c_int32), ("nlevels", C.c_int32),
+                ("scale_factor", C.c_double)]
 
 
 class Orb:
     """The ORB point front-end for B images of one size (stvo_orb_*)."""
 
-    def __init__(self, ctx, B, cols, rows, max_keypoints=2048, nfeatures=2000, fast_threshold=20, edge_threshold=19):
+    def __init__(self, ctx, B, cols, rows, max_keypoints=2048, nfeatures=2000, fast_threshold=20, edge_threshold=19, nlevels=1,
+                 scale_factor=1.2):
         self.ctx, self.B, self.cols, self.rows, self.K = ctx, B, cols, rows, max_keypoints
         self.h = C.c_void_p()
-        prm = OrbParams(nfeatures, fast_threshold, edge_threshold, 0)
+        prm = OrbParams(nfeatures, fast_threshold, edge_threshold, nlevels, scale_factor)
         ctx._chk(ctx.lib.stvo_orb_create(ctx.h, B, cols, rows, max_keypoints, C.byref(prm), C.byref(self.h)))
 
     def close(self):
@@ -331,13 +336,15 @@ class Orb:
         images = np.ascontiguousarray(images, np.uint8).reshape(self.B, self.rows, self.cols)
         kp = np.zeros((self.B, self.K, 2), np.float32); resp = np.zeros((self.B, self.K), np.float32)
         ang = np.zeros((self.B, self.K), np.float32); desc = np.zeros((self.B, self.K, 32), np.uint8); n = np.zeros(self.B, np.int32)
-        self.ctx._chk(self.ctx.lib.stvo_orb_detect(self.h, images.reshape(-1), kp.reshape(-1), resp.reshape(-1), ang.reshape(-1), desc.reshape(-1), n))
-        return [dict(kp=kp[b, :n[b]].copy(), response=resp[b, :n[b]].copy(), angle=ang[b, :n[b]].copy(), desc=desc[b, :n[b]].copy())
-                for b in range(self.B)]
+        octv = np.zeros((self.B, self.K), np.int32); ntot = np.zeros(self.B, np.int32)
+        self.ctx._chk(self.ctx.lib.stvo_orb_detect_levels(self.h, images.reshape(-1), kp.reshape(-1), resp.reshape(-1), ang.reshape(-1),
+                                                          octv.reshape(-1), desc.reshape(-1), n, ntot))
+        return [dict(kp=kp[b, :n[b]].copy(), response=resp[b, :n[b]].copy(), angle=ang[b, :n[b]].copy(), desc=desc[b, :n[b]].copy(),
+                     octave=octv[b, :n[b]].copy(), n_total=int(ntot[b])) for b in range(self.B)]
 
-    def detect_dev(self, img, kp, resp, ang, desc, n):
+    def detect_dev(self, img, kp, resp, ang, desc, n, octave=None, n_total=None):
         """Device buffers (integers = device addresses): images in, key-points / descriptors out, on the context's stream."""
-        self.ctx._chk(self.ctx.lib.stvo_orb_detect_dev(self.h, img, kp, resp, ang, desc, n))
+        self.ctx._chk(self.ctx.lib.stvo_orb_detect_levels_dev(self.h, img, kp, resp, ang, octave, desc, n, n_total))
 
 
 class Sequences:

@@ -15,11 +15,13 @@ from .capi import FrameFeatures
 
 
 class ImagePipeline:
-    def __init__(self, ctx, B, cam, mp, op, max_kp=2048, nfeatures=2000, fast_threshold=20, edge_threshold=19, device="cuda:0"):
-        """cam: one camera dict (width / height = image size) for all B streams.  op must have has_lines = 0."""
+    def __init__(self, ctx, B, cam, mp, op, max_kp=2048, nfeatures=2000, fast_threshold=20, edge_threshold=19, device="cuda:0", nlevels=1,
+                 scale_factor=1.2):
+        """cam: one camera dict (width / height = image size) for all B streams.  op must have has_lines = 0.  nlevels / scale_factor:
+        Config::orbNLevels / orbScaleFactor (the key-point octaves travel with the key-points: sigma2 = 1 / scale^(2 level))."""
         self.ctx, self.B, self.K = ctx, B, max_kp
         self.cols, self.rows = cam["width"], cam["height"]
-        self.orb = capi.Orb(ctx, 2 * B, self.cols, self.rows, max_kp, nfeatures, fast_threshold, edge_threshold)  # left images, then right
+        self.orb = capi.Orb(ctx, 2 * B, self.cols, self.rows, max_kp, nfeatures, fast_threshold, edge_threshold, nlevels, scale_factor)  # left images, then right
         self.seq = capi.Sequences(ctx, B, max_kp, 64, cam, mp, op)
         dev = torch.device(device)
         self.img = torch.zeros((2 * B, self.rows, self.cols), dtype=torch.uint8, device=dev)
@@ -28,6 +30,7 @@ class ImagePipeline:
         self.ang = torch.zeros((2 * B, max_kp), dtype=torch.float32, device=dev)
         self.desc = torch.zeros((2 * B, max_kp, 32), dtype=torch.uint8, device=dev)
         self.n = torch.zeros((2 * B,), dtype=torch.int32, device=dev)
+        self.oct = torch.zeros((2 * B, max_kp), dtype=torch.int32, device=dev)
         ff = FrameFeatures()
         ff.stride_kp, ff.stride_kl = max_kp, 0
         ff.n_kp_l = C.c_void_p(self.n.data_ptr())
@@ -36,7 +39,8 @@ class ImagePipeline:
         ff.kp_r = C.c_void_p(self.kp.data_ptr() + 8 * B * max_kp)
         ff.desc_l = C.c_void_p(self.desc.data_ptr())
         ff.desc_r = C.c_void_p(self.desc.data_ptr() + 32 * B * max_kp)
-        self.ff = ff  # oct_l and every line pointer stay NULL: octave 0, no key-lines
+        ff.oct_l = C.c_void_p(self.oct.data_ptr())
+        self.ff = ff  # every line pointer stays NULL: no key-lines
         self.slot = 0
 
     def set_images(self, left, right):
@@ -49,7 +53,7 @@ class ImagePipeline:
         """Detection + description of the 2 B resident images (or of the uint8 [2 B, rows, cols] device buffer at img_ptr: B left,
         then B right), ingestion, one pipeline step — all asynchronous."""
         self.orb.detect_dev(img_ptr if img_ptr is not None else self.img.data_ptr(), self.kp.data_ptr(), self.resp.data_ptr(), self.ang.data_ptr(), self.desc.data_ptr(),
-                            self.n.data_ptr())
+                            self.n.data_ptr(), octave=self.oct.data_ptr())
         self.seq.upload_dev(self.slot, self.ff)
         self.seq.step_dev(self.slot)
         self.slot ^= 1

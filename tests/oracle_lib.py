@@ -241,6 +241,35 @@ class Oracle:
                                     desc.reshape(-1))
         return dict(kp=kp[:n].copy(), response=resp[:n].copy(), angle=ang[:n].copy(), desc=desc[:n].copy())
 
+    def orb_detect_levels(self, img, nfeatures=2000, nlevels=4, scale_factor=1.2, fast_th=20, edge_th=19, pattern=None, cap=4096):
+        i8p = np.ctypeslib.ndpointer(np.int8, flags="C_CONTIGUOUS")
+        self.lib.orc_orb_detect_levels.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, i8p, C.c_int, f32p, f32p,
+                                                   f32p, i32p, u8p]
+        self.lib.orc_orb_detect_levels.restype = C.c_int
+        img = np.ascontiguousarray(img, np.uint8)
+        pat = np.ascontiguousarray(self.orb_default_pattern() if pattern is None else pattern, np.int8).reshape(-1)
+        kp = np.zeros((cap, 2), np.float32); resp = np.zeros(cap, np.float32); ang = np.zeros(cap, np.float32); desc = np.zeros((cap, 32), np.uint8)
+        octv = np.zeros(cap, np.int32)
+        n = self.lib.orc_orb_detect_levels(img.reshape(-1), img.shape[1], img.shape[0], nfeatures, nlevels, scale_factor, fast_th, edge_th, pat, cap,
+                                           kp.reshape(-1), resp, ang, octv, desc.reshape(-1))
+        assert n >= 0
+        return dict(kp=kp[:n].copy(), response=resp[:n].copy(), angle=ang[:n].copy(), desc=desc[:n].copy(), octave=octv[:n].copy())
+
+    def resize_linear(self, img, dcols, drows):
+        self.lib.orc_resize_linear.argtypes = [u8p, C.c_int, C.c_int, u8p, C.c_int, C.c_int]; self.lib.orc_resize_linear.restype = None
+        img = np.ascontiguousarray(img, np.uint8)
+        out = np.zeros((drows, dcols), np.uint8)
+        self.lib.orc_resize_linear(img.reshape(-1), img.shape[1], img.shape[0], out.reshape(-1), dcols, drows)
+        return out
+
+    def orb_levels(self, cols, rows, nfeatures, nlevels, scale_factor):
+        f32p_ = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+        self.lib.orc_orb_levels.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, f32p_, i32p, i32p, i32p]
+        self.lib.orc_orb_levels.restype = None
+        sc = np.zeros(8, np.float32); lc = np.zeros(8, np.int32); lr = np.zeros(8, np.int32); nf = np.zeros(8, np.int32)
+        self.lib.orc_orb_levels(cols, rows, nfeatures, nlevels, scale_factor, sc, lc, lr, nf)
+        return sc[:nlevels], lc[:nlevels], lr[:nlevels], nf[:nlevels]
+
     # ---- key-frame decision ----
     @staticmethod
     def kf_state():

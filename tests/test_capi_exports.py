@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 def test_identity_and_error_strings(lib):
     assert lib.stvo_backend_name() == b"hip-gfx950"
-    assert lib.stvo_abi_version() == 2
+    assert lib.stvo_abi_version() == 3
     assert lib.stvo_error_string(0) == b"ok"
     assert b"no CPU fallback" in lib.stvo_error_string(-3)
 

@@ -13,6 +13,7 @@ ap.add_argument("--batch", type=int, default=512)
 ap.add_argument("--points", type=int, default=2000)
 ap.add_argument("--lines", type=int, default=0)
 ap.add_argument("--iters", type=int, default=10)
+ap.add_argument("--f32-obs", action="store_true", help="round the observations to float (what the per-frame pipeline feeds): pose_kernel3's compact format applies")
 a = ap.parse_args()
 import torch  # noqa: E402
 from stvo_amd import capi, synth  # noqa: E402
@@ -24,6 +25,10 @@ if a.lines:
     frames = [synth.make_f2f_points_lines(synth.frame_seed(0, k), n=a.points, n_lines=a.lines) for k in range(B)]
 else:
     frames = [synth.make_f2f_points(synth.frame_seed(0, k), n=a.points) for k in range(B)]
+if a.f32_obs:
+    import numpy as np
+    for fr in frames:
+        fr["curr_pl"] = fr["curr_pl"].astype(np.float32).astype(np.float64)
 batch = TrackBatch(frames, max_pts=2048, max_lines=128 if a.lines else 0)
 prm = opt_params("kitti", has_lines=1 if a.lines else 0)
 ctx = capi.Context(device_id=0, max_rows=2048, max_batch=B)
