@@ -234,6 +234,9 @@ int stvo_orb_destroy(stvo_orb* orb);
 /* The 256 x 4 test pattern (x0, y0, x1, y1 per bit, |coordinate| <= 13).  The default is a seeded table; OpenCV's learned
  * table (bit_pattern_31_ of features2d/src/orb.cpp) is data this repository does not hold — pass it here to reproduce it. */
 int stvo_orb_set_pattern(stvo_orb* orb, const int8_t* pattern /*[1024]*/);
+/* The FAST threshold of the following calls: StereoFrameHandler::updateFrame adapts orb_fast_th frame by frame
+ * (src/stereoFrameHandler.cpp:66-86) and passes it to detectStereoFeatures (:56 -> src/stereoFrame.cpp:59,104-118). */
+int stvo_orb_set_fast_threshold(stvo_orb* orb, int fast_threshold /* 1 .. 254 */);
 int stvo_orb_get_pattern(const stvo_orb* orb, int8_t* pattern /*[1024]*/);
 /* Host buffers in / out, synchronises.  images [B][rows][cols]; kp_xy [B][max_keypoints][2] = cv::KeyPoint::pt; response =
  * cv::KeyPoint::response (FAST score); angle in degrees = cv::KeyPoint::angle; desc [B][max_keypoints][32]; n_kp [B]. */

@@ -8,6 +8,10 @@
 //                    [-o offset] [-n N] [-s step]   (the reference's options, app/imagesStVO.cpp:138-171)
 //                    [--keyframes]   (needNewKF / currFrameIsKF after every optimizePose, as PL-SLAM drives them)
 //                    [--device-pipeline]   (stvo_seq_*: one upload + one synchronisation per frame, state in HBM)
+//                    [--no-lines]    (Config::hasLines() = false)
+// A sequence file that starts with "STVOIMG1" holds stereo IMAGES (n_frames, cols, rows, camera, then per frame the left and the
+// right 8-bit image): the loop then calls the reference's own entry points initialize / insertStereoPair(img_l, img_r, idx)
+// (include/stereoFrameHandler.h:44-45), whose ORB point front-end runs on the GPU (key-points only: no LSD / LBD here).
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -63,7 +67,7 @@ int main(int argc, char** argv) {
     std::string preset = "kitti", cfg;
     int mode = 0, max_frames = 0, frame_offset = 0, frame_step = 1;
     bool keyframes = false;
-    bool device_pipeline = false;
+    bool device_pipeline = false, no_lines = false;
     for (int i = 3; i < argc; ++i) {
         if (!std::strcmp(argv[i], "--preset") && i + 1 < argc) preset = argv[++i];
         else if (!std::strcmp(argv[i], "-c") && i + 1 < argc) cfg = argv[++i];
@@ -71,6 +75,7 @@ int main(int argc, char** argv) {
         else if (!std::strcmp(argv[i], "-n") && i + 1 < argc) max_frames = std::atoi(argv[++i]);
         else if (!std::strcmp(argv[i], "--device-pipeline")) device_pipeline = true;
         else if (!std::strcmp(argv[i], "--keyframes")) keyframes = true;
+        else if (!std::strcmp(argv[i], "--no-lines")) no_lines = true;
         else if (!std::strcmp(argv[i], "-o") && i + 1 < argc) frame_offset = std::atoi(argv[++i]);  // imagesStVO.cpp:158-159
         else if (!std::strcmp(argv[i], "-s") && i + 1 < argc) frame_step = std::atoi(argv[++i]);    // imagesStVO.cpp:162-163
     }
@@ -78,14 +83,20 @@ int main(int argc, char** argv) {
     else if (preset == "euroc") Config::setEurocPreset();
     else Config::setDefaults();
     if (!cfg.empty()) Config::loadFromFile(cfg);
+    if (no_lines) Config::hasLines() = false;
 
     std::ifstream in(argv[1], std::ios::binary);
     char magic[8];
     int32_t n_frames = 0, cols = 0, rows = 0;
     double camv[5];
-    if (!in || !rd(in, magic, 8) || std::memcmp(magic, "STVOSEQ1", 8) != 0 || !rd(in, &n_frames) || !rd(in, &cols) ||
-        !rd(in, &rows) || !rd(in, camv, 5)) {
+    if (!in || !rd(in, magic, 8) || (std::memcmp(magic, "STVOSEQ1", 8) != 0 && std::memcmp(magic, "STVOIMG1", 8) != 0) || !rd(in, &n_frames) ||
+        !rd(in, &cols) || !rd(in, &rows) || !rd(in, camv, 5)) {
         std::cerr << "bad sequence file\n";
+        return -1;
+    }
+    const bool image_file = std::memcmp(magic, "STVOIMG1", 8) == 0;
+    if (image_file && device_pipeline) {
+        std::cerr << "--device-pipeline takes feature files; image files go through the handler" << std::endl;
         return -1;
     }
     if (frame_offset < 0) frame_offset = 0;
@@ -205,23 +216,37 @@ int main(int argc, char** argv) {
         FrameFeatures feat;
         feat.img_cols = cols;
         feat.img_rows = rows;
-        int32_t n[4];
-        if (!rd(in, n, 4) || !read_points(in, n[0], feat.points_l, feat.pdesc_l) ||
-            !read_points(in, n[1], feat.points_r, feat.pdesc_r) || !read_lines(in, n[2], feat.lines_l, feat.ldesc_l) ||
-            !read_lines(in, n[3], feat.lines_r, feat.ldesc_r)) {
-            std::cerr << "truncated sequence file at frame " << file_idx << "\n";
-            return -1;
+        std::vector<uint8_t> img_l, img_r;
+        if (image_file) {
+            const size_t px = (size_t)cols * rows;
+            img_l.resize(px);
+            img_r.resize(px);
+            if (!rd(in, img_l.data(), px) || !rd(in, img_r.data(), px)) {
+                std::cerr << "truncated image file at frame " << file_idx << "\n";
+                return -1;
+            }
+        } else {
+            int32_t n[4];
+            if (!rd(in, n, 4) || !read_points(in, n[0], feat.points_l, feat.pdesc_l) ||
+                !read_points(in, n[1], feat.points_r, feat.pdesc_r) || !read_lines(in, n[2], feat.lines_l, feat.ldesc_l) ||
+                !read_lines(in, n[3], feat.lines_r, feat.ldesc_r)) {
+                std::cerr << "truncated sequence file at frame " << file_idx << "\n";
+                return -1;
+            }
         }
         if (file_idx < frame_offset || (file_idx - frame_offset) % frame_step != 0) continue;
         if (max_frames > 0 && n_done >= max_frames) break;
         ++frame_counter;
         ++n_done;
+        const GrayImage gl{img_l.data(), rows, cols, (size_t)cols}, gr{img_r.data(), rows, cols, (size_t)cols};
         if (frame_counter == 0) {
-            StVO->initialize(feat, 0);
+            if (image_file) StVO->initialize(gl, gr, 0);  // initialize(img_l, img_r, 0), imagesStVO.cpp:90
+            else StVO->initialize(feat, 0);
             continue;
         }
         const auto t0 = std::chrono::high_resolution_clock::now();  // timer.start()  (imagesStVO.cpp:95)
-        StVO->insertStereoPair(feat, frame_counter);
+        if (image_file) StVO->insertStereoPair(gl, gr, frame_counter);  // imagesStVO.cpp:96
+        else StVO->insertStereoPair(feat, frame_counter);
         StVO->optimizePose();
         const double t1 =
             std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();

@@ -847,6 +847,13 @@ int stvo_orb_set_pattern(stvo_orb* o, const int8_t* pattern) {
     return STVO_OK;
 }
 
+int stvo_orb_set_fast_threshold(stvo_orb* o, int fast_threshold) {
+    if (!o || fast_threshold < 1 || fast_threshold > 254) return STVO_ERR_INVALID_ARG;
+    o->prm.fast_threshold = fast_threshold;
+    for (int l = 0; l < o->nlevels; ++l) o->lev[l].d.fast_th = fast_threshold;  // kernel argument of the next launches
+    return STVO_OK;
+}
+
 int stvo_orb_get_pattern(const stvo_orb* o, int8_t* pattern) {
     if (!o || !pattern) return STVO_ERR_INVALID_ARG;
     std::memcpy(pattern, o->pattern, 1024);

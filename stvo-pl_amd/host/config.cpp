@@ -33,7 +33,7 @@ void Config::setDefaults() {
     c.homog_th = 1e-7; c.min_features = 10; c.max_iters = 5; c.max_iters_ref = 10; c.min_error = 1e-7;
     c.min_error_change = 1e-7; c.inlier_k = 4.0;
     c.matching_strategy = 0; c.matching_s_ws = 10; c.matching_f2f_ws = 3;
-    c.orb_nfeatures = 1200; c.orb_scale_factor = 1.2; c.orb_nlevels = 4; c.orb_fast_th = 20;
+    c.orb_nfeatures = 1200; c.orb_scale_factor = 1.2; c.orb_nlevels = 4; c.orb_fast_th = 20; c.orb_edge_th = 19;  // src/config.cpp:95-102
     c.lsd_nfeatures = 300; c.lsd_scale = 1.2;
 }
 
@@ -93,7 +93,7 @@ void Config::loadFromFile(const std::string& path) {
     I("matching_strategy", matching_strategy)  // NB: config_kitti.yaml's `matching_stereo` is not read upstream either
     I("matching_s_ws", matching_s_ws) I("matching_f2f_ws", matching_f2f_ws)
     I("orb_nfeatures", orb_nfeatures) D("orb_scale_factor", orb_scale_factor) I("orb_nlevels", orb_nlevels)
-    I("orb_fast_th", orb_fast_th) I("lsd_nfeatures", lsd_nfeatures) D("lsd_scale", lsd_scale)
+    I("orb_fast_th", orb_fast_th) I("orb_edge_th", orb_edge_th) I("lsd_nfeatures", lsd_nfeatures) D("lsd_scale", lsd_scale)
     D("min_entropy_ratio", min_entropy_ratio) D("max_kf_t_dist", max_kf_t_dist) D("max_kf_r_dist", max_kf_r_dist)
 #undef B
 #undef D

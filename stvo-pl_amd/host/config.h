@@ -33,7 +33,7 @@ public:
     STVO_CFG(int, matchingStrategy, matching_strategy) STVO_CFG(int, matchingSWs, matching_s_ws)
     STVO_CFG(int, matchingF2FWs, matching_f2f_ws)
     STVO_CFG(int, orbNFeatures, orb_nfeatures) STVO_CFG(double, orbScaleFactor, orb_scale_factor)
-    STVO_CFG(int, orbNLevels, orb_nlevels) STVO_CFG(int, orbFastTh, orb_fast_th)
+    STVO_CFG(int, orbNLevels, orb_nlevels) STVO_CFG(int, orbFastTh, orb_fast_th) STVO_CFG(int, orbEdgeTh, orb_edge_th)
     STVO_CFG(int, lsdNFeatures, lsd_nfeatures) STVO_CFG(double, lsdScale, lsd_scale)
     STVO_CFG(double, minEntropyRatio, min_entropy_ratio) STVO_CFG(double, maxKFTDist, max_kf_t_dist)
     STVO_CFG(double, maxKFRDist, max_kf_r_dist)
@@ -51,7 +51,7 @@ public:
     int matching_strategy, matching_s_ws, matching_f2f_ws;
     int orb_nfeatures;
     double orb_scale_factor;
-    int orb_nlevels, orb_fast_th;
+    int orb_nlevels, orb_fast_th, orb_edge_th;
     int lsd_nfeatures;
     double lsd_scale;
     double min_entropy_ratio, max_kf_t_dist, max_kf_r_dist;

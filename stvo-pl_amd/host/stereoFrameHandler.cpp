@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdlib>
+#include <cstring>
 #include <future>
 #include <iostream>
 #include <stdexcept>
@@ -39,6 +40,7 @@ StereoFrameHandler::~StereoFrameHandler() {
     if (curr_frame && curr_frame != prev_frame) delete curr_frame;
     delete prev_frame;
     if (seq) stvo_seq_destroy(seq);
+    if (orb) stvo_orb_destroy(orb);
     if (ctx_lines) stvo_ctx_destroy(ctx_lines);
     stvo_ctx_destroy(ctx);
 }
@@ -62,6 +64,67 @@ void StereoFrameHandler::initialize(const FrameFeatures& feat, const int idx_) {
     prev_frame->DT = Matrix4d::Identity();
     curr_frame = prev_frame;
     kf = KeyFrameState{};  // :48-51
+}
+
+// StereoFrame::detectStereoPoints (src/stereoFrame.cpp:88-118) for the pair: both images in one batched launch chain of the ORB
+// front-end (the reference runs the two detectPointFeatures calls on two threads when lrInParallel), key-points with their
+// octaves and descriptors back on the host where the StereoFrame keeps them (points_l / points_r / pdesc_l / pdesc_r).
+FrameFeatures StereoFrameHandler::detectStereoFeatures(const GrayImage& img_l, const GrayImage& img_r) {
+    if (img_l.empty() || img_r.empty() || img_l.rows != img_r.rows || img_l.cols != img_r.cols)
+        throw std::runtime_error("[StVO-HIP] detectStereoFeatures: two non-empty 8-bit images of one size expected");
+    FrameFeatures feat;
+    feat.img_cols = img_l.cols;
+    feat.img_rows = img_l.rows;
+    if (!Config::hasPoints()) return feat;  // src/stereoFrame.cpp:106
+    const int K = 4096;  // capacity per image: orb_nfeatures plus the ties at the cut
+    if (orb && (orb_cols != img_l.cols || orb_rows != img_l.rows)) {
+        stvo_orb_destroy(orb);
+        orb = nullptr;
+    }
+    if (!orb) {
+        stvo_orb_params prm{};
+        prm.nfeatures = Config::orbNFeatures();
+        prm.fast_threshold = std::min(254, std::max(1, orb_fast_th));
+        prm.edge_threshold = Config::orbEdgeTh();
+        prm.nlevels = Config::orbNLevels();
+        prm.scale_factor = Config::orbScaleFactor();
+        check(stvo_orb_create(ctx, 2, img_l.cols, img_l.rows, K, &prm, &orb), "stvo_orb_create", ctx);
+        orb_cols = img_l.cols;
+        orb_rows = img_l.rows;
+    }
+    check(stvo_orb_set_fast_threshold(orb, std::min(254, std::max(1, orb_fast_th))), "stvo_orb_set_fast_threshold", ctx);
+    const size_t px = (size_t)img_l.rows * img_l.cols;
+    std::vector<uint8_t> pair(2 * px);
+    const GrayImage* im[2] = {&img_l, &img_r};
+    for (int s = 0; s < 2; ++s) {
+        const size_t step = im[s]->step ? im[s]->step : (size_t)im[s]->cols;
+        for (int r = 0; r < im[s]->rows; ++r) std::memcpy(pair.data() + s * px + (size_t)r * im[s]->cols, im[s]->data + r * step, (size_t)im[s]->cols);
+    }
+    std::vector<float> kp((size_t)2 * K * 2), resp((size_t)2 * K), ang((size_t)2 * K);
+    std::vector<int32_t> oct((size_t)2 * K);
+    std::vector<uint8_t> desc((size_t)2 * K * 32);
+    int32_t n[2] = {0, 0}, nt[2] = {0, 0};
+    check(stvo_orb_detect_levels(orb, pair.data(), kp.data(), resp.data(), ang.data(), oct.data(), desc.data(), n, nt), "stvo_orb_detect_levels", ctx);
+    for (int s = 0; s < 2; ++s) {
+        std::vector<KeyPoint>& pts = s ? feat.points_r : feat.points_l;
+        DescMat& dm = s ? feat.pdesc_r : feat.pdesc_l;
+        pts.reserve(n[s]);
+        for (int i = 0; i < n[s]; ++i) {
+            const size_t k = (size_t)s * K + i;
+            pts.push_back(KeyPoint{kp[2 * k], kp[2 * k + 1], oct[k]});
+            dm.push_back_row(desc.data() + k * 32);
+        }
+    }
+    return feat;
+}
+
+void StereoFrameHandler::initialize(const GrayImage& img_l, const GrayImage& img_r, const int idx_) {
+    orb_fast_th = Config::orbFastTh();  // :37 (before the detection, which takes it)
+    initialize(detectStereoFeatures(img_l, img_r), idx_);
+}
+
+void StereoFrameHandler::insertStereoPair(const GrayImage& img_l, const GrayImage& img_r, const int idx_) {
+    insertStereoPair(detectStereoFeatures(img_l, img_r), idx_);
 }
 
 // :54-60

@@ -19,6 +19,15 @@ public:
 
     void initialize(const FrameFeatures& feat, const int idx_);
     void insertStereoPair(const FrameFeatures& feat, const int idx_);
+    // The reference's own entry points, initialize / insertStereoPair(const Mat img_l, const Mat img_r, const int idx)
+    // (include/stereoFrameHandler.h:44-45): the two rectified 8-bit images go through the ORB point front-end on the GPU
+    // (stvo_orb_detect_levels with Config's orb_* values and the handler's adaptive orb_fast_th — what
+    // StereoFrame::detectStereoPoints does with cv::ORB, src/stereoFrame.cpp:88-118) and continue as extracted features.
+    // Key-lines: the LSD / LBD front-end is not built, so a frame entered this way carries none (Config::hasLines() is
+    // honoured by the rest of the path; it simply finds empty sets).
+    void initialize(const GrayImage& img_l, const GrayImage& img_r, const int idx_);
+    void insertStereoPair(const GrayImage& img_l, const GrayImage& img_r, const int idx_);
+    FrameFeatures detectStereoFeatures(const GrayImage& img_l, const GrayImage& img_r);
     void updateFrame();
 
     void f2fTracking();
@@ -67,6 +76,8 @@ private:
     void buildMatchedPoints(const int32_t* matches_12, size_t n);
     void buildMatchedLines(const int32_t* matches_12, size_t n);
     void publishPose();
+    stvo_orb* orb = nullptr;  // created at the first image pair (image size, Config's orb_* values)
+    int orb_cols = 0, orb_rows = 0;
     stvo_seq* seq = nullptr;
     int seq_K = 0, seq_M = 0, pipe_slot = 0;
     bool pose_pending = false;

@@ -58,4 +58,12 @@ struct FrameFeatures {
     DescMat ldesc_l, ldesc_r;
 };
 
+// cv::Mat as the image-taking entry points use it (CV_8UC1): rows x cols bytes, `step` bytes from row to row
+struct GrayImage {
+    const uint8_t* data = nullptr;
+    int rows = 0, cols = 0;
+    size_t step = 0;  // 0: rows are contiguous (step == cols)
+    bool empty() const { return data == nullptr || rows <= 0 || cols <= 0; }
+};
+
 }  // namespace StVO

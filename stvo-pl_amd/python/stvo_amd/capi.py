@@ -22,7 +22,7 @@ EXPORTS = ["stvo_backend_name", "stvo_abi_version", "stvo_error_string", "stvo_c
            "stvo_seq_push", "stvo_seq_upload", "stvo_seq_step_dev", "stvo_seq_read", "stvo_seq_create_multi", "stvo_seq_set_slots",
            "stvo_seq_set_stage_timing", "stvo_seq_get_stage_timing", "stvo_seq_debug_grid", "stvo_orb_create", "stvo_orb_destroy",
            "stvo_orb_set_pattern", "stvo_orb_get_pattern", "stvo_orb_detect", "stvo_orb_detect_dev", "stvo_orb_detect_levels",
-           "stvo_orb_detect_levels_dev", "stvo_seq_upload_dev"]
+           "stvo_orb_detect_levels_dev", "stvo_orb_set_fast_threshold", "stvo_seq_upload_dev"]
 
 SEQ_NSTAGE = 5  # include/stvo_hip.h: STVO_SEQ_NSTAGE
 SEQ_STAGE_NAMES = ("stereo_points_stage", "grid_scan", "hamming_knn2", "reverse_check", "pose")
@@ -133,6 +133,7 @@ def load():
     L.stvo_orb_get_pattern.argtypes = [C.c_void_p, i8p]
     L.stvo_orb_detect.argtypes = [C.c_void_p, u8p, f32p, f32p, f32p, u8p, i32p]
     L.stvo_orb_detect_dev.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+    L.stvo_orb_set_fast_threshold.argtypes = [C.c_void_p, C.c_int]
     L.stvo_orb_detect_levels.argtypes = [C.c_void_p, u8p, f32p, f32p, f32p, i32p, u8p, i32p, i32p]
     L.stvo_orb_detect_levels_dev.argtypes = [C.c_void_p] + [C.c_void_p] * 8
     L.stvo_seq_destroy.argtypes = [C.c_void_p]
@@ -330,6 +331,9 @@ class Orb:
 
     def set_pattern(self, pattern):
         self.ctx._chk(self.ctx.lib.stvo_orb_set_pattern(self.h, np.ascontiguousarray(pattern, np.int8).reshape(-1)))
+
+    def set_fast_threshold(self, th):
+        self.ctx._chk(self.ctx.lib.stvo_orb_set_fast_threshold(self.h, th))
 
     def detect(self, images):
         """images: uint8 [B, rows, cols] -> list of B dicts(kp [n,2] float32, response, angle, desc [n,32])."""

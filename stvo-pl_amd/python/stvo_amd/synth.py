@@ -330,6 +330,18 @@ def write_sequence(path, frames, cam):
                 f.write(rec.tobytes()); f.write(np.ascontiguousarray(desc, np.uint8).tobytes())
 
 
+def write_image_sequence(path, pairs, cam):
+    """Stereo IMAGE hand-over file read by stvo-pl_amd/app/imagesStVO_synth.cpp ("STVOIMG1"): pairs = [(left, right), ...] uint8."""
+    import struct
+    with open(path, "wb") as f:
+        f.write(b"STVOIMG1")
+        f.write(struct.pack("<iii", len(pairs), cam["width"], cam["height"]))
+        f.write(struct.pack("<5d", cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["b"]))
+        for left, right in pairs:
+            assert left.shape == (cam["height"], cam["width"]) and right.shape == left.shape
+            f.write(np.ascontiguousarray(left, np.uint8).tobytes()); f.write(np.ascontiguousarray(right, np.uint8).tobytes())
+
+
 RESULT_DTYPE = np.dtype([("ints", "<i4", (12,)), ("DT", "<f8", (16,)), ("DT_cov", "<f8", (36,)), ("cov_eig", "<f8", (6,)),
                          ("err", "<f8"), ("Tfw", "<f8", (16,)), ("Tfw_cov", "<f8", (36,)), ("fast", "<i4"), ("pad", "<i4")])
 

@@ -122,3 +122,35 @@ def test_keyframe_decisions_and_cli_offset_step(tmp_path, oracle):
     sub = [frames[k] for k in (3, 5, 7, 9, 11)]
     ref2 = pipeline_ref.run_sequence(oracle, sub, cam, match_params("kitti"), opt_params("kitti"))
     compare(res2, ref2)
+
+
+@pytest.mark.parametrize("preset,nlevels", [("kitti", 1), ("euroc", 4)])
+def test_image_entry_points_of_the_handler(tmp_path, oracle, preset, nlevels):
+    """initialize / insertStereoPair(img_l, img_r, idx) (include/stereoFrameHandler.h:44-45) through the C++ mirror: stereo images in,
+    the ORB point front-end on the GPU with Config's orb_* values (1 level for config_kitti.yaml, 4 at 1.2 for config_euroc.yaml) and
+    the handler's ADAPTIVE FAST threshold, then the usual path — against the CPU chain: ORB oracle on every image with the threshold
+    the previous frame left behind, its key-points through the oracle-driven per-frame loop."""
+    cam = dict(synth.KITTI_CAM if preset == "kitti" else synth.EUROC_CAM, width=640, height=240)
+    pairs = synth.make_stereo_image_sequence(77, 5, cam)
+    seq = str(tmp_path / "img.bin"); res_path = str(tmp_path / "res.bin")
+    synth.write_image_sequence(seq, pairs, cam)
+    p = subprocess.run([APP, seq, res_path, "--preset", preset, "--no-lines"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr + p.stdout
+    res = synth.read_results(res_path)
+    mp = match_params(preset); op = opt_params(preset, has_lines=0)
+    nfeat = {"kitti": 2000, "euroc": 800}[preset]
+    fast = dict(adaptive=True, th0=20, mn=7, mx=30, inc=5, feat=50, err=0.5) if preset == "kitti" else \
+        dict(adaptive=True, th0=20, mn=5, mx=50, inc=5, feat=50, err=0.5)   # config_kitti.yaml / config_euroc.yaml fast_* values
+    pattern = oracle.orb_default_pattern()
+    z4 = np.zeros((0, 4), np.float32); zd = np.zeros((0, 32), np.uint8)
+    frames, th, ref = [], fast["th0"], []
+    for k, (left, right) in enumerate(pairs):
+        l = oracle.orb_detect_levels(left, nfeatures=nfeat, nlevels=nlevels, fast_th=th, pattern=pattern)
+        r = oracle.orb_detect_levels(right, nfeatures=nfeat, nlevels=nlevels, fast_th=th, pattern=pattern)
+        frames.append(dict(kp_l=l["kp"], oct_l=l["octave"], desc_l=l["desc"], kp_r=r["kp"], desc_r=r["desc"], kl_l=z4, oct_ll=np.zeros(0, np.int32),
+                           ldesc_l=zd, kl_r=z4, ldesc_r=zd, ang_l=np.zeros(0, np.float32)))
+        if k:
+            ref = pipeline_ref.run_sequence(oracle, frames, cam, mp, op, fast=fast)
+            th = ref[-1]["fast"]   # updateFrame's threshold for the NEXT detection
+    compare(res, ref)
+    assert sum(r["ints"][1] == 0 for r in res) >= 2 and "FAST:" in p.stdout
