@@ -253,6 +253,26 @@ int stvo_orb_detect_levels(stvo_orb* orb, const uint8_t* images, float* kp_xy, f
 int stvo_orb_detect_levels_dev(stvo_orb* orb, const uint8_t* images, float* kp_xy, float* response, float* angle, int32_t* octave,
                                uint8_t* desc, int32_t* n_kp, int32_t* n_total);
 
+/* ---- LBD line descriptor (first half) ------------------------------------------------------- */
+
+/* Replaces  BinaryDescriptor::createBinaryDescriptor()->compute(img, lines, ldesc)  as called by StereoFrame::detectLineFeatures
+ * (src/stereoFrame.cpp:213,243,303) for B images of cols x rows bytes with up to max_keylines octave-0 key-lines each:
+ * GaussianBlur(5 x 5, sigma 1), Sobel 3 x 3, the 9-band statistics of the 63-row line support region in float and in the source's
+ * order of operations, both normalisations, and the 32-byte binary form (3rdparty/line_descriptor/src/binary_descriptor_custom.cpp:
+ * 350-412, 539-687, 1026-1340 — source the reference holds; semantics pinned to oracle/stvo_lbd_oracle.c, which cites it line by
+ * line; parity unpinned because that file needs OpenCV to build).  The key-lines themselves come from the caller: the LSD / FLD
+ * detectors are not built. */
+typedef struct stvo_lbd stvo_lbd;
+int stvo_lbd_create(stvo_ctx* ctx, int B, int cols, int rows, int max_keylines, stvo_lbd** out);
+int stvo_lbd_destroy(stvo_lbd* lbd);
+/* Host buffers in / out, synchronises.  images [B][rows][cols]; lines [B][max_keylines]; n_lines [B]; desc [B][max_keylines][32] =
+ * the rows of ldesc; desc_float (may be NULL) [B][max_keylines][72] = the float descriptor (returnFloatDescr). */
+int stvo_lbd_compute(stvo_lbd* lbd, const uint8_t* images, const stvo_keyline* lines, const int32_t* n_lines, uint8_t* desc,
+                     float* desc_float);
+/* The same with DEVICE pointers, enqueued on the context's stream (no synchronisation). */
+int stvo_lbd_compute_dev(stvo_lbd* lbd, const uint8_t* images, const stvo_keyline* lines, const int32_t* n_lines, uint8_t* desc,
+                         float* desc_float);
+
 /* ---- measurement helpers --------------------------------------------------------------------- */
 /* Times `iters` launches of the named kernel stage on the context's stream with hipEvents and
  * returns the average milliseconds per launch (used by bench.py for the roofline line).

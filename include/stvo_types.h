@@ -159,6 +159,14 @@ typedef struct stvo_orb_params {
     double scale_factor;     /* Config::orbScaleFactor()  (1.2; > 1; ignored for one level) */
 } stvo_orb_params;
 
+/* A key-line as the LBD descriptor consumes it: the line_descriptor::KeyLine fields BinaryDescriptor::computeImpl copies into its
+ * OctaveSingleLine (3rdparty/line_descriptor/src/binary_descriptor_custom.cpp:592-609), octave 0. */
+typedef struct stvo_keyline {
+    float sx, sy, ex, ey;  /* sPointInOctaveX / Y, ePointInOctaveX / Y */
+    float angle;           /* KeyLine::angle = atan2(ey - sy, ex - sx), radians */
+    int32_t num_pixels;    /* KeyLine::numOfPixels (cv::LineIterator count): the length of the line support region */
+} stvo_keyline;
+
 /* Error codes of the C-ABI (0 ok, <0 error; never throws). */
 enum {
     STVO_OK = 0,

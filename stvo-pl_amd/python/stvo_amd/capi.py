@@ -22,7 +22,8 @@ EXPORTS = ["stvo_backend_name", "stvo_abi_version", "stvo_error_string", "stvo_c
            "stvo_seq_push", "stvo_seq_upload", "stvo_seq_step_dev", "stvo_seq_read", "stvo_seq_create_multi", "stvo_seq_set_slots",
            "stvo_seq_set_stage_timing", "stvo_seq_get_stage_timing", "stvo_seq_debug_grid", "stvo_orb_create", "stvo_orb_destroy",
            "stvo_orb_set_pattern", "stvo_orb_get_pattern", "stvo_orb_detect", "stvo_orb_detect_dev", "stvo_orb_detect_levels",
-           "stvo_orb_detect_levels_dev", "stvo_orb_set_fast_threshold", "stvo_seq_upload_dev"]
+           "stvo_orb_detect_levels_dev", "stvo_orb_set_fast_threshold", "stvo_seq_upload_dev", "stvo_lbd_create", "stvo_lbd_destroy",
+           "stvo_lbd_compute", "stvo_lbd_compute_dev"]
 
 SEQ_NSTAGE = 5  # include/stvo_hip.h: STVO_SEQ_NSTAGE
 SEQ_STAGE_NAMES = ("stereo_points_stage", "grid_scan", "hamming_knn2", "reverse_check", "pose")
@@ -136,6 +137,10 @@ def load():
     L.stvo_orb_set_fast_threshold.argtypes = [C.c_void_p, C.c_int]
     L.stvo_orb_detect_levels.argtypes = [C.c_void_p, u8p, f32p, f32p, f32p, i32p, u8p, i32p, i32p]
     L.stvo_orb_detect_levels_dev.argtypes = [C.c_void_p] + [C.c_void_p] * 8
+    L.stvo_lbd_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.stvo_lbd_destroy.argtypes = [C.c_void_p]
+    L.stvo_lbd_compute.argtypes = [C.c_void_p, u8p, C.c_void_p, i32p, u8p, C.c_void_p]
+    L.stvo_lbd_compute_dev.argtypes = [C.c_void_p] + [C.c_void_p] * 5
     L.stvo_seq_destroy.argtypes = [C.c_void_p]
     L.stvo_seq_push.argtypes = [C.c_void_p, C.POINTER(FrameFeatures), C.c_void_p, i32p]
     L.stvo_seq_upload.argtypes = [C.c_void_p, C.c_int, C.POINTER(FrameFeatures)]
@@ -349,6 +354,42 @@ class Orb:
     def detect_dev(self, img, kp, resp, ang, desc, n, octave=None, n_total=None):
         """Device buffers (integers = device addresses): images in, key-points / descriptors out, on the context's stream."""
         self.ctx._chk(self.ctx.lib.stvo_orb_detect_levels_dev(self.h, img, kp, resp, ang, octave, desc, n, n_total))
+
+
+KEYLINE_DTYPE = np.dtype([("sx", "<f4"), ("sy", "<f4"), ("ex", "<f4"), ("ey", "<f4"), ("angle", "<f4"), ("num_pixels", "<i4")])  # stvo_keyline
+
+
+class Lbd:
+    """The LBD line descriptor for B images of one size with up to M key-lines each (stvo_lbd_*)."""
+
+    def __init__(self, ctx, B, cols, rows, max_keylines=512):
+        self.ctx, self.B, self.cols, self.rows, self.M = ctx, B, cols, rows, max_keylines
+        self.h = C.c_void_p()
+        ctx._chk(ctx.lib.stvo_lbd_create(ctx.h, B, cols, rows, max_keylines, C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.stvo_lbd_destroy(self.h)
+            self.h = None
+
+    def compute(self, images, lines, num_pixels, want_float=False):
+        """images uint8 [B, rows, cols]; lines: list of B arrays [n_b, 5] (sx, sy, ex, ey, angle); num_pixels: list of B int arrays.
+        -> list of B uint8 [n_b, 32] (and float32 [n_b, 72])."""
+        images = np.ascontiguousarray(images, np.uint8).reshape(self.B, self.rows, self.cols)
+        rec = np.zeros((self.B, self.M), KEYLINE_DTYPE)
+        n = np.zeros(self.B, np.int32)
+        for b in range(self.B):
+            ln = np.asarray(lines[b], np.float32).reshape(-1, 5)
+            n[b] = len(ln)
+            for k, f in enumerate(("sx", "sy", "ex", "ey", "angle")):
+                rec[f][b, :len(ln)] = ln[:, k]
+            rec["num_pixels"][b, :len(ln)] = num_pixels[b]
+        desc = np.zeros((self.B, self.M, 32), np.uint8)
+        df = np.zeros((self.B, self.M, 72), np.float32) if want_float else None
+        self.ctx._chk(self.ctx.lib.stvo_lbd_compute(self.h, images.reshape(-1), rec.ctypes.data_as(C.c_void_p), n, desc.reshape(-1),
+                                                    df.ctypes.data_as(C.c_void_p) if want_float else None))
+        out = [desc[b, :n[b]].copy() for b in range(self.B)]
+        return (out, [df[b, :n[b]].copy() for b in range(self.B)]) if want_float else out
 
 
 class Sequences:

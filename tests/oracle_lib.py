@@ -270,6 +270,41 @@ class Oracle:
         self.lib.orc_orb_levels(cols, rows, nfeatures, nlevels, scale_factor, sc, lc, lr, nf)
         return sc[:nlevels], lc[:nlevels], lr[:nlevels], nf[:nlevels]
 
+    # ---- LBD line descriptor (oracle/stvo_lbd_oracle.c) ----
+    def lbd_compute(self, img, lines, num_pixels, want_float=False):
+        """lines [n, 5] float32 (sx, sy, ex, ey, angle), num_pixels [n] int32 -> desc [n, 32] uint8 (and [n, 72] float32)."""
+        self.lib.orc_lbd_compute.argtypes = [u8p, C.c_int, C.c_int, C.c_int, f32p, i32p, u8p, C.c_void_p]
+        self.lib.orc_lbd_compute.restype = None
+        img = np.ascontiguousarray(img, np.uint8)
+        lines = np.ascontiguousarray(lines, np.float32).reshape(-1, 5)
+        npx = np.ascontiguousarray(num_pixels, np.int32)
+        n = len(lines)
+        desc = np.zeros((max(n, 1), 32), np.uint8); df = np.zeros((max(n, 1), 72), np.float32)
+        self.lib.orc_lbd_compute(img.reshape(-1), img.shape[1], img.shape[0], n, lines.reshape(-1) if n else np.zeros(5, np.float32),
+                                 npx if n else np.zeros(1, np.int32), desc.reshape(-1), df.ctypes.data_as(C.c_void_p))
+        return (desc[:n], df[:n]) if want_float else desc[:n]
+
+    def gaussian_blur5(self, img):
+        self.lib.orc_gaussian_blur5.argtypes = [u8p, C.c_int, C.c_int, u8p]; self.lib.orc_gaussian_blur5.restype = None
+        img = np.ascontiguousarray(img, np.uint8)
+        out = np.zeros_like(img)
+        self.lib.orc_gaussian_blur5(img.reshape(-1), img.shape[1], img.shape[0], out.reshape(-1))
+        return out
+
+    def sobel3(self, img):
+        i16p = np.ctypeslib.ndpointer(np.int16, flags="C_CONTIGUOUS")
+        self.lib.orc_sobel3.argtypes = [u8p, C.c_int, C.c_int, i16p, i16p]; self.lib.orc_sobel3.restype = None
+        img = np.ascontiguousarray(img, np.uint8)
+        dx = np.zeros(img.shape, np.int16); dy = np.zeros(img.shape, np.int16)
+        self.lib.orc_sobel3(img.reshape(-1), img.shape[1], img.shape[0], dx.reshape(-1), dy.reshape(-1))
+        return dx, dy
+
+    def lbd_tables(self):
+        self.lib.orc_lbd_tables.argtypes = [f64p, f64p]; self.lib.orc_lbd_tables.restype = None
+        a = np.zeros(21); b = np.zeros(63)
+        self.lib.orc_lbd_tables(a, b)
+        return a, b
+
     # ---- key-frame decision ----
     @staticmethod
     def kf_state():

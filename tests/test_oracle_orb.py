@@ -118,3 +118,33 @@ def test_image_sequences_drive_the_oracle_chain(oracle):
     assert len(good) >= 2
     for o in good:
         assert 0.05 < abs(o["T"][0, 3]) < 0.3 and abs(o["T"][1, 3]) < 0.05
+
+
+def test_lbd_oracle_pieces_against_independent_statements(oracle):
+    """oracle/stvo_lbd_oracle.c piece by piece against numpy statements of the definitions: the fixed-point 5 x 5 blur, the Sobel
+    derivatives, the weight tables (with the source's integer divisions), and the binary form of a float descriptor."""
+    from stvo_amd import synth
+    img = synth.make_image(3, cols=97, rows=61, n_rects=30, n_discs=8)
+    k = np.exp(-(np.arange(5) - 2.0) ** 2 / 2.0); k /= k.sum()
+    ki = np.rint(k.astype(np.float32).astype(np.float64) * 256.0).astype(np.int64)
+    pad = np.pad(img.astype(np.int64), 2, mode="reflect")
+    h = sum(ki[i] * pad[:, i:i + 97] for i in range(5))
+    v = sum(ki[i] * h[i:i + 61, :] for i in range(5))
+    assert np.array_equal(oracle.gaussian_blur5(img), np.clip((v + (1 << 15)) >> 16, 0, 255).astype(np.uint8))
+    p = np.pad(img.astype(np.int64), 1, mode="reflect")
+    dx = (p[:-2, 2:] + 2 * p[1:-1, 2:] + p[2:, 2:]) - (p[:-2, :-2] + 2 * p[1:-1, :-2] + p[2:, :-2])
+    dy = (p[2:, :-2] + 2 * p[2:, 1:-1] + p[2:, 2:]) - (p[:-2, :-2] + 2 * p[:-2, 1:-1] + p[:-2, 2:])
+    odx, ody = oracle.sobel3(img)
+    assert np.array_equal(odx, dx) and np.array_equal(ody, dy)
+    cl, cg = oracle.lbd_tables()
+    assert np.allclose(cl, np.exp(-(np.arange(21) - 10.0) ** 2 / (2 * 7.0 ** 2)), rtol=1e-15)   # u = 20 // 2, sigma = 15 // 2
+    assert np.allclose(cg, np.exp(-(np.arange(63) - 31.0) ** 2 / (2 * 31.0 ** 2)), rtol=1e-15)
+    # binary form: byte c = sum 2^i [f(band a)[i] > f(band b)[i]] over the 32 pairs of the source's table
+    rng = np.random.default_rng(1)
+    lines = np.array([[20, 20, 80, 45, np.arctan2(25, 60)]], np.float32)
+    desc, df = oracle.lbd_compute(img, lines, np.array([61], np.int32), want_float=True)
+    pairs = [(a, b) for a in range(9) for b in range(a + 1, 9) if not (a < 2 and b > 6)]
+    assert len(pairs) == 32
+    f = df[0].reshape(9, 8)
+    want = [sum((1 << i) for i in range(8) if f[a][i] > f[b][i]) for a, b in pairs]
+    assert list(desc[0]) == want and abs(np.linalg.norm(df[0]) - 1.0) < 1e-5
