@@ -140,6 +140,7 @@ int launch_pose(hipStream_t s, const PoseArgs& a);   // dispatches to pose_kerne
 int launch_pose2(hipStream_t s, const PoseArgs& a);  // pose_kernel2.hip: every wave a worker, 128 VGPRs, records in LDS
 // pose_kernel2's batch kernel on the frame pairs list[0 .. *count - 1] (device memory; a.B = capacity of the list)
 int launch_pose2_list(hipStream_t s, const PoseArgs& a, const int* list, const int* count);
+int launch_pose2p(hipStream_t s, const PoseArgs& a); // pose_kernel2p.hip: thread-private records (LDS planes + global arena), four frame pairs per CU
 int launch_pose3(hipStream_t s, const PoseArgs& a);  // pose_kernel3.hip: two frame pairs per workgroup, owner + evaluator waves
 
 // ---- K3: grid-windowed stereo matchers, batched over frame pairs (blockIdx.y) ----------------------

@@ -600,6 +600,7 @@ int launch_pose(hipStream_t s, const PoseArgs& a) {
     // STVO_POSE_KERNEL = 3: pose_kernel3.hip (two frame pairs per workgroup, owner + evaluator waves) — until it is the measured
     // default for batches it is opt-in
     if (which == 3 && !a.eval_only) return launch_pose3(s, a);
+    if (which == 4 && !a.eval_only) return launch_pose2p(s, a);  // pose_kernel2p.hip (thread-private records, four pairs per CU)
     if (which == 2 || (which == 0 && a.B > POSE_LATENCY_MAX_B)) return launch_pose2(s, a);
     if (a.max_pts > STVO_POSE_MAX_POINTS || a.max_lines > STVO_POSE_MAX_LINES) return STVO_ERR_CAPACITY;
     const size_t rec_bytes = ((size_t)a.max_pts * 6 + (size_t)a.max_lines * 14) * sizeof(double);

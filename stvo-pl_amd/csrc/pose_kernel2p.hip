@@ -1,0 +1,620 @@
+// pose_kernel2p.hip — K4/K5/K6, the batch formulation with THREAD-PRIVATE record storage: the whole of
+// StereoFrameHandler::optimizePose (/root/reference/src/stereoFrameHandler.cpp:307-392) in one launch, one workgroup per
+// frame pair, built so that FOUR frame pairs share a CU.
+//
+// pose_kernel2.hip keeps the matched records of a pair compacted in LDS (80 KB per pair: two pairs per CU).  A pair is a
+// chain of ~13.7 evaluate -> solve rounds with serial sections in which its other waves idle (NOTES.md), so what the CU's FP64
+// pipes do depends on how many independent chains it holds.  Here a thread owns its matched records privately:
+//   * its first K_lds records live in LDS planes [record ordinal][thread] (16-byte parts of neighbouring threads are
+//     neighbours: conflict-free b128 accesses, and no cross-thread compaction — the two block-wide scans of the prologue go);
+//   * the others live in a global arena with the SAME plane layout ([ordinal][part][thread]: a wave's load of one part is one
+//     contiguous 1 KB run) written once at staging and read with a three-deep register ring, the first three requested at the
+//     start of an evaluation and consumed after the LDS-resident records;
+//   * key-lines (~75 per pair, at most one per thread in practice) live in the arena only.
+// With two waves per pair at 256 VGPRs and a 40 KB LDS share, four workgroups fit a CU.  Same contract, same PoseArgs, same
+// arithmetic and association order as pose_kernel2.hip's kernel of the same wave count (thread t owns prev points t + k BLOCK
+// and accumulates them in index order), so the results are bit-identical to it.
+#include <cstdlib>
+
+#include <map>
+#include <mutex>
+
+#include "pose_block.h"
+
+namespace stvo {
+namespace {
+
+__device__ __forceinline__ double uni(double v) {  // a value every lane holds identically -> SGPR pair
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readfirstlane((int)(b & 0xFFFFFFFFll)), hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned long long)(unsigned)lo);
+}
+
+struct PointRec2 {
+    double X, Y, Z, ox, oy, q;  // q = sqrt(sigma2)
+};
+
+constexpr bool POSE2P_PRIO = true;  // serial sections at wave priority 3 (measured: 239 -> 230 us per 512 pairs with four waves per pair)
+
+// NW waves per frame pair at 256 VGPRs (two waves per SIMD); k_lds record ordinals of every thread live in LDS
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void pose2p_kernel(PoseArgs a, const int k_lds, double2* arena, const size_t arena_pair) {
+    constexpr int WPE = 2;
+    constexpr int BLOCK = NW * 64;
+    // 6x6 systems: on ROWS (row_solve_spd & co., no 36-element arrays per lane) in the 128-VGPR variants; with the serial
+    // routines of pose_math.h, executed redundantly by every lane of wave 0, in the 256-VGPR variant, where the arrays fit and
+    // the serial form is the faster one (80 k vs 88 k cycles of solver time per frame pair)
+    constexpr bool POSE2_ROW = WPE >= 4;
+    constexpr int PPT = (STVO_POSE_MAX_POINTS + BLOCK - 1) / BLOCK;
+    constexpr int LPT = (STVO_POSE_MAX_LINES + BLOCK - 1) / BLOCK;
+    using Ops = BlockOps<NW>;
+    extern __shared__ double2 s_pl[];  // [k_lds][3][BLOCK]: 16-byte part `part` of this thread's record ordinal r at (r * 3 + part) * BLOCK + tid
+    __shared__ int s_hist[2][Ops::HIST_W];  // select_kth_hist
+    __shared__ double s_red[NW][28];
+    __shared__ int s_ired[NW];
+    __shared__ PoseSh s_sh;
+    PoseSh* sh = &s_sh;
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const bool w0 = wv == 0;   // the wave that also runs the serial sections (all of its lanes, redundantly)
+    const bool t0 = tid == 0;  // the lane that writes results to global memory
+    const bool prof = a.prof_out != nullptr;
+    long long tprof[5] = {0, 0, 0, 0, 0};
+    long long wprof[3] = {0, 0, 0}, wave_busy = 0;  // developer aid: loop compute, fold, barrier + partial sums; per-wave busy ticks
+    auto tick = [&]() -> long long { return prof ? (long long)__builtin_readcyclecounter() : 0ll; };
+    const long long t_begin = tick();
+    const stvo_cam cam_f = a.cams ? a.cams[f] : a.cam;
+    const pm::Cam5 cam{cam_f.fx, cam_f.fy, cam_f.cx, cam_f.cy};
+    const stvo_opt_params prm = a.prm;
+
+    // ---------------- ownership: thread t owns prev points t + k BLOCK and prev line BLOCK - 1 - t ----------------
+    // (lines are handed out from the top: the last threads own the fewest points, a line term costs about two points)
+    unsigned pmatched = 0u, pinl = 0u;
+    const int n_prev_p = a.n_prev_pts != nullptr ? min(a.n_prev_pts[f], a.max_pts) : 0;
+    const size_t pbase = (size_t)f * a.max_pts;
+    // branch-free, clamped loads: the PPT match indices (and below the PPT records) of a thread are all in flight at once —
+    // the prologue is a chain of dependent HBM round trips otherwise (index -> record -> LDS)
+    int jj[PPT];
+    {
+        int init[PPT];
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int i = tid + k * BLOCK;
+            const int ic = i < n_prev_p ? i : 0;
+            jj[k] = a.m12p ? a.m12p[pbase + ic] : ic;
+            init[k] = a.init_inl_p ? a.init_inl_p[pbase + ic] : 1;
+        }
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int i = tid + k * BLOCK;
+            if (i < n_prev_p && jj[k] >= 0) {
+                pmatched |= 1u << k;
+                if (init[k] != 0) pinl |= 1u << k;
+            } else {
+                jj[k] = 0;
+            }
+        }
+    }
+    unsigned lmatched = 0u, linl = 0u;
+    const int n_prev_l = (a.n_prev_lines != nullptr && a.max_lines > 0) ? a.n_prev_lines[f] : 0;
+    const size_t lbase = (size_t)f * a.max_lines;
+    const int li0 = BLOCK - 1 - tid;  // line k of this thread: li0 + k BLOCK
+#pragma unroll
+    for (int k = 0; k < LPT; ++k) {
+        const int li = li0 + k * BLOCK;
+        if (li < n_prev_l && li < a.max_lines) {
+            const int j = a.m12l ? a.m12l[lbase + li] : li;
+            if (j >= 0) {
+                lmatched |= 1u << k;
+                if (a.init_inl_l == nullptr || a.init_inl_l[lbase + li] != 0) linl |= 1u << k;
+            }
+        }
+    }
+
+    // ---------------- thread-private records: LDS planes for the first k_lds ordinals, the global arena for the rest ----------------
+    const int n_m_p = Ops::template sum_int<true>(__popc(pmatched), s_ired);
+    const int n_m_l = Ops::template sum_int<true>(__popc(lmatched), s_ired);
+    // (the index of a record is laundered through an empty asm at every use: otherwise the compiler hoists the 64-bit addresses
+    //  of all PPT records out of the iteration loop and carries them through the whole kernel — see pose_kernel2.hip)
+    auto launder = [](int v) -> int {
+        asm volatile("" : "+v"(v));
+        return v;
+    };
+    double2* ar = arena + (size_t)f * arena_pair;              // points: ordinal r, part p at (r * 3 + p) * BLOCK + tid
+    double2* ar_l = ar + (size_t)PPT * 3 * BLOCK;               // lines:  ordinal r, part p at (r * 7 + p) * BLOCK + tid
+    unsigned arena_mask = pmatched;                             // the owned matched points whose ordinal is >= k_lds
+    for (int i = 0; i < k_lds; ++i) arena_mask &= arena_mask - 1u;
+    const unsigned lds_mask = pmatched & ~arena_mask;
+    auto ordinal = [&](int k) -> int { return __popc(pmatched & ((1u << k) - 1u)); };
+    auto load_point_lds = [&](int k) -> PointRec2 {
+        const int r = launder(ordinal(k));
+        const double2* q = s_pl + (size_t)(r * 3) * BLOCK + tid;
+        const double2 v0 = q[0], v1 = q[BLOCK], v2 = q[2 * BLOCK];
+        PointRec2 rec;
+        rec.X = v0.x; rec.Y = v0.y; rec.Z = v1.x; rec.ox = v1.y; rec.oy = v2.x; rec.q = v2.y;
+        return rec;
+    };
+    auto load_point_arena = [&](int k) -> PointRec2 {
+        const int r = launder(ordinal(k));
+        const double2* q = ar + (size_t)(r * 3) * BLOCK + tid;
+        const double2 v0 = q[0], v1 = q[BLOCK], v2 = q[2 * BLOCK];
+        PointRec2 rec;
+        rec.X = v0.x; rec.Y = v0.y; rec.Z = v1.x; rec.ox = v1.y; rec.oy = v2.x; rec.q = v2.y;
+        return rec;
+    };
+    auto load_point = [&](int k) -> PointRec2 { return ((lds_mask >> k) & 1u) ? load_point_lds(k) : load_point_arena(k); };
+    auto load_line = [&](int k) -> pm::LineRec {
+        const int r = launder(__popc(lmatched & ((1u << k) - 1u)));
+        const double2* q = ar_l + (size_t)(r * 7) * BLOCK + tid;
+        pm::LineRec L;
+        const double2 v0 = q[0], v1 = q[BLOCK], v2 = q[2 * BLOCK], v3 = q[3 * BLOCK], v4 = q[4 * BLOCK], v5 = q[5 * BLOCK], v6 = q[6 * BLOCK];
+        L.sP[0] = v0.x; L.sP[1] = v0.y; L.sP[2] = v1.x; L.eP[0] = v1.y; L.eP[1] = v2.x; L.eP[2] = v2.y;
+        L.le[0] = v3.x; L.le[1] = v3.y; L.le[2] = v4.x; L.spl[0] = v4.y; L.spl[1] = v5.x; L.epl[0] = v5.y; L.epl[1] = v6.x;
+        L.sigma2 = v6.y;
+        return L;
+    };
+    // stage this thread's own records (thread-private slots: no barrier between staging and use), STAGE_CH records at a time
+    constexpr int STAGE_CH = PPT < 4 ? PPT : 4;
+#pragma unroll
+    for (int k0 = 0; k0 < PPT; k0 += STAGE_CH) {
+        PointRec2 rec[STAGE_CH];
+#pragma unroll
+        for (int c = 0; c < STAGE_CH; ++c) {  // unconditional loads from clamped (valid) addresses
+            const int k = k0 + c;
+            if (k >= PPT) continue;
+            const int ik = tid + k * BLOCK;
+            const size_t i = pbase + (size_t)(ik < n_prev_p ? ik : 0), j = pbase + (size_t)jj[k];
+            rec[c].X = a.prev_P[i * 3 + 0];
+            rec[c].Y = a.prev_P[i * 3 + 1];
+            rec[c].Z = a.prev_P[i * 3 + 2];
+            rec[c].q = a.prev_s2p[i];
+            rec[c].ox = a.curr_pl[j * 2 + 0];
+            rec[c].oy = a.curr_pl[j * 2 + 1];
+        }
+#pragma unroll
+        for (int c = 0; c < STAGE_CH; ++c) {
+            const int k = k0 + c;
+            if (k >= PPT) continue;
+            if ((pmatched >> k) & 1u) {
+                const int r = ordinal(k);
+                double2* q = (((lds_mask >> k) & 1u) ? s_pl : ar) + (size_t)(r * 3) * BLOCK + tid;
+                q[0] = make_double2(rec[c].X, rec[c].Y);
+                q[BLOCK] = make_double2(rec[c].Z, rec[c].ox);
+                q[2 * BLOCK] = make_double2(rec[c].oy, sqrt(rec[c].q));
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll 1
+    for (int k = 0; k < LPT; ++k)
+        if ((lmatched >> k) & 1u) {
+            const size_t i = lbase + (size_t)(li0 + k * BLOCK);
+            const size_t j = a.m12l ? lbase + (size_t)a.m12l[i] : i;
+            const int r = __popc(lmatched & ((1u << k) - 1u));
+            double2* q = ar_l + (size_t)(r * 7) * BLOCK + tid;
+            q[0] = make_double2(a.prev_sP[i * 3 + 0], a.prev_sP[i * 3 + 1]);
+            q[BLOCK] = make_double2(a.prev_sP[i * 3 + 2], a.prev_eP[i * 3 + 0]);
+            q[2 * BLOCK] = make_double2(a.prev_eP[i * 3 + 1], a.prev_eP[i * 3 + 2]);
+            q[3 * BLOCK] = make_double2(a.curr_le[j * 3 + 0], a.curr_le[j * 3 + 1]);
+            q[4 * BLOCK] = make_double2(a.curr_le[j * 3 + 2], a.prev_spl[i * 2 + 0]);
+            q[5 * BLOCK] = make_double2(a.prev_spl[i * 2 + 1], a.prev_epl[i * 2 + 0]);
+            q[6 * BLOCK] = make_double2(a.prev_epl[i * 2 + 1], sqrt(a.prev_s2l[i]));  // the record carries sqrt(sigma2) (pm::line_term_q)
+        }
+    // (a thread reads back only what it wrote itself: program order is enough, no fence)
+
+    {
+        const int nip = Ops::template sum_int<true>(__popc(pinl), s_ired);
+        const int nil = Ops::template sum_int<true>(__popc(linl), s_ired);
+        if (w0) {
+            sh->n_m_p = n_m_p;
+            sh->n_m_l = n_m_l;
+            sh->n_inl_p = nip;
+            sh->n_inl_l = nil;
+            sh->good = 1;
+            sh->err_out = -1.0;  // :313
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const double v = a.init_T ? a.init_T[(size_t)f * 16 + i] : ((i % 5 == 0) ? 1.0 : 0.0);
+                sh->DT[i] = v;
+                sh->DT0[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < 36; ++i) {
+                sh->cov[i] = 0.0;
+                sh->H[i] = 0.0;
+            }
+        }
+        __syncthreads();
+    }
+
+    const long long t_prologue = tick() - t_begin;
+    // ---------------- optimizeFunctions / optimizeFunctionsRobust at sh->DT ----------------
+    auto pose_sgpr = [&](const double* src, double* DT) {  // rows 0..2 of the 4x4 pose, wave-uniform -> SGPRs
+#pragma unroll
+        for (int i = 0; i < 12; ++i) DT[i] = uni(src[i]);
+    };
+    auto evaluate = [&](bool robust) {
+        double DT[12];
+        pose_sgpr(sh->DT, DT);
+        double sp = 1.0, sl = 1.0;
+        if (robust) {  // pre-pass :710-781: MAD scale of the inlier residual norms
+            double rp[PPT];
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                rp[k] = 0.0;
+                if ((pinl >> k) & 1u) {
+                    const PointRec2 r = load_point(k);
+                    rp[k] = pm::point_residual(DT, cam, r.X, r.Y, r.Z, r.ox, r.oy);
+                }
+            }
+            sp = pm::clamp_scale(Ops::template mad_sigma<PPT, true>(rp, pinl, sh->n_inl_p, s_hist, &sh->xchg));
+            double rlv[LPT];
+#pragma unroll
+            for (int k = 0; k < LPT; ++k) {
+                rlv[k] = 0.0;
+                if ((linl >> k) & 1u) rlv[k] = pm::line_residual(DT, cam, load_line(k));
+            }
+            sl = pm::clamp_scale(Ops::template mad_sigma<LPT, true>(rlv, linl, sh->n_inl_l, s_hist, &sh->xchg));
+        }
+        const long long tw0 = tick();
+        double acc[28];
+#pragma unroll
+        for (int i = 0; i < 28; ++i) acc[i] = 0.0;
+        {
+            // the arena-resident inliers (the thread's highest ordinals): three records in flight, the first three requested now
+            // and consumed after the LDS-resident ones — same ascending order as pose_kernel2.hip's accumulation
+            unsigned pend = pinl & arena_mask;
+            PointRec2 r0{1.0, 1.0, 1.0, 0.0, 0.0, 1.0}, r1 = r0, r2 = r0;
+            auto req = [&](PointRec2& dst) -> bool {
+                if (!pend) return false;
+                const int k = __builtin_ctz(pend);
+                pend &= pend - 1u;
+                dst = load_point_arena(k);
+                return true;
+            };
+            bool v0 = req(r0), v1 = req(r1), v2 = req(r2);
+            // the first inlier line of the thread travels with them
+            pm::LineRec L0{};
+            int kl0 = -1;
+            if (linl) {
+                kl0 = __builtin_ctz(linl);
+                L0 = load_line(kl0);
+            }
+            // LDS-resident inliers, one record ahead
+            unsigned todo = pinl & lds_mask;
+            PointRec2 cur{1.0, 1.0, 1.0, 0.0, 0.0, 1.0};
+            if (todo) cur = load_point_lds(__builtin_ctz(todo));
+            while (todo) {
+                todo &= todo - 1u;
+                PointRec2 nxt = cur;
+                if (todo) nxt = load_point_lds(__builtin_ctz(todo));
+                pm::point_term_q(acc, DT, cam, prm.homog_th, cur.X, cur.Y, cur.Z, cur.ox, cur.oy, cur.q, robust, sp);
+                cur = nxt;
+            }
+            for (;;) {
+                if (!v0) break;
+                pm::point_term_q(acc, DT, cam, prm.homog_th, r0.X, r0.Y, r0.Z, r0.ox, r0.oy, r0.q, robust, sp);
+                v0 = req(r0);
+                if (!v1) break;
+                pm::point_term_q(acc, DT, cam, prm.homog_th, r1.X, r1.Y, r1.Z, r1.ox, r1.oy, r1.q, robust, sp);
+                v1 = req(r1);
+                if (!v2) break;
+                pm::point_term_q(acc, DT, cam, prm.homog_th, r2.X, r2.Y, r2.Z, r2.ox, r2.oy, r2.q, robust, sp);
+                v2 = req(r2);
+            }
+            if (kl0 >= 0) pm::line_term_q(acc, DT, cam, prm.homog_th, L0, robust, sl);
+#pragma unroll 1
+            for (int k = 0; k < LPT; ++k)
+                if (((linl >> k) & 1u) && k != kl0) {
+                    const pm::LineRec L = load_line(k);
+                    pm::line_term_q(acc, DT, cam, prm.homog_th, L, robust, sl);
+                }
+        }
+        const long long tw1 = tick();
+        Ops::template sum28_fold<true>(acc, s_red);
+        const long long tw2 = tick();
+        wave_busy += tw2 - tw0;
+        __syncthreads();
+        if (w0) {  // wave partials summed in wave order => bit-reproducible
+            if (lane < 28) {
+                double s = s_red[0][lane];
+#pragma unroll
+                for (int w = 1; w < NW; ++w) s += s_red[w][lane];
+                sh->tot[lane] = s;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        wprof[0] += tw1 - tw0;
+        wprof[1] += tw2 - tw1;
+        wprof[2] += tick() - tw2;
+    };
+
+    if (a.eval_only) {
+        evaluate(a.eval_robust != 0);
+        if (w0) {
+            t0_unpack(sh);
+            if (t0) {
+                double* o = a.eval_out + (size_t)f * 44;
+#pragma unroll
+                for (int i = 0; i < 36; ++i) o[i] = sh->H[i];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) o[36 + i] = sh->g[i];
+                o[42] = sh->err;
+                o[43] = (double)(sh->n_inl_p + sh->n_inl_l);
+            }
+        }
+        return;
+    }
+
+    // ---------------- removeOutliers at pose DT1 (:988-1067) ----------------
+    auto remove_outliers = [&]() {
+        double DT[12];
+        pose_sgpr(sh->DT1, DT);
+        if (prm.has_points) {
+            double res[PPT];
+            const int tot = sh->n_m_p;
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {  // ALL matches, current outliers included (:998-1005)
+                res[k] = 0.0;
+                if ((pmatched >> k) & 1u) {
+                    const PointRec2 r = load_point(k);
+                    res[k] = pm::point_residual(DT, cam, r.X, r.Y, r.Z, r.ox, r.oy) * r.q;
+                }
+            }
+            const double stdv = Ops::template mad_sigma<PPT, true>(res, pmatched, tot, s_hist, &sh->xchg);
+            double v[3] = {0.0, 0.0, 0.0};  // mean of the samples below 2 sigma, or of all samples (src/auxiliar.cpp:405-427)
+#pragma unroll
+            for (int k = 0; k < PPT; ++k)
+                if ((pmatched >> k) & 1u) {
+                    if (res[k] < 2.0 * stdv) {
+                        v[0] += res[k];
+                        v[1] += 1.0;
+                    }
+                    v[2] += res[k];
+                }
+            double t[3];
+            Ops::template sum_small<3, true>(v, s_red, t);
+            double mean = 0.0;
+            if (tot != 0) {
+                const int ksel = (int)t[1];
+                mean = (ksel >= (int)(0.2 * (double)tot)) ? t[0] / (double)ksel : t[2] / (double)tot;
+            }
+            const double th = prm.inlier_k * stdv;
+#pragma unroll
+            for (int k = 0; k < PPT; ++k)
+                if (((pinl >> k) & 1u) && fabs(res[k] - mean) > th) pinl &= ~(1u << k);
+            const int nip = Ops::template sum_int<true>(__popc(pinl), s_ired);
+            if (w0) sh->n_inl_p = nip;
+        }
+        if (prm.has_lines) {
+            double res[LPT];
+            const int tot = sh->n_m_l;
+#pragma unroll
+            for (int k = 0; k < LPT; ++k) {
+                res[k] = 0.0;
+                if ((lmatched >> k) & 1u) {
+                    const pm::LineRec L = load_line(k);
+                    res[k] = pm::line_residual(DT, cam, L) * L.sigma2;  // L.sigma2 = sqrt(sigma2)
+                }
+            }
+            const double stdv = Ops::template mad_sigma<LPT, true>(res, lmatched, tot, s_hist, &sh->xchg);
+            double v[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+            for (int k = 0; k < LPT; ++k)
+                if ((lmatched >> k) & 1u) {
+                    if (res[k] < 2.0 * stdv) {
+                        v[0] += res[k];
+                        v[1] += 1.0;
+                    }
+                    v[2] += res[k];
+                }
+            double t[3];
+            Ops::template sum_small<3, true>(v, s_red, t);
+            double mean = 0.0;
+            if (tot != 0) {
+                const int ksel = (int)t[1];
+                mean = (ksel >= (int)(0.2 * (double)tot)) ? t[0] / (double)ksel : t[2] / (double)tot;
+            }
+            const double th = prm.inlier_k * stdv;
+#pragma unroll
+            for (int k = 0; k < LPT; ++k)
+                if (((linl >> k) & 1u) && fabs(res[k] - mean) > th) linl &= ~(1u << k);
+            const int nil = Ops::template sum_int<true>(__popc(linl), s_ired);
+            if (w0) sh->n_inl_l = nil;
+        }
+        __syncthreads();
+    };
+
+    // ---------------- optimizePose state machine (:332-370), as in pose_kernel.hip ----------------
+    int status = STVO_POSE_OK, path = 0, it0 = 0, it1 = 0;
+    if (sh->n_inl_p + sh->n_inl_l >= prm.min_features) {
+        int stage = 0;        // 0 = first optimisation (:335-338), 1 = refinement (:345-350), 2 = robust fallback (:359)
+        int alg = prm.mode;   // 0 GN, 1 robust GN, 2 LM
+        int max_it = prm.max_iters;
+        for (;;) {
+            if (w0) {
+                sh->err_prev = 999999999.9;
+                sh->good = 1;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sh->DTr[i] = sh->DT[i];  // robust GN's entry pose (:441)
+            }
+            const int n_it = (alg == 2 && max_it < 1) ? 1 : max_it;  // LM always evaluates once (:493)
+            int evals = 0, action = ACT_BREAK;
+            for (int it = 0; it < n_it; ++it) {
+                long long tq = tick();
+                evaluate(alg == 1);
+                tprof[0] += tick() - tq;
+                tq = tick();
+                ++evals;
+                if (w0) {
+                    // the serial section is one wave's dependent chain while the co-resident workgroup's waves evaluate on the
+                    // same SIMD: let it win the issue arbitration
+                    if (POSE2P_PRIO) __builtin_amdgcn_s_setprio(3);
+                    if (alg == 0) t0_gn_iter<POSE2_ROW>(sh, prm.min_error, prm.min_error_change, it);
+                    else if (alg == 1) t0_gnr_iter<POSE2_ROW>(sh, prm.min_error, prm.min_error_change);
+                    else t0_lm_iter<POSE2_ROW>(sh, prm.min_error, prm.min_error_change, it == 0 ? 1 : 0);
+                    if (POSE2P_PRIO) __builtin_amdgcn_s_setprio(0);
+                }
+                __syncthreads();
+                tprof[1] += tick() - tq;
+                action = sh->action;
+                if (action != ACT_CONTINUE) break;
+            }
+            long long tq2 = tick();
+            if (w0) {
+                if (alg == 0 && action == ACT_FAIL) {
+                    sh->err_out = -1.0;  // :408-409, covariance left untouched
+                } else if (alg == 1 && !sh->good) {  // :473-478
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) sh->DT[i] = sh->DTr[i];
+                    sh->err_out = -1.0;
+#pragma unroll
+                    for (int i = 0; i < 36; ++i) sh->cov[i] = (i % 7 == 0) ? 1.0 : 0.0;
+                } else {
+                    t0_cov_from_H<POSE2_ROW>(sh);  // :429 / :470 / :545 — H of the last evaluation (damped for LM)
+                    sh->err_out = evals > 0 ? sh->err : 0.0;
+                }
+            }
+            __syncthreads();
+            tprof[2] += tick() - tq2;
+            if (stage != 0) {
+                it1 = evals;
+                break;
+            }
+            it0 = evals;
+            tq2 = tick();
+            if (w0) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sh->DT1[i] = sh->DT[i];
+                t0_is_good_fast<POSE2_ROW>(sh, sh->DT1, sh->err_out);
+            }
+            __syncthreads();
+            tprof[2] += tick() - tq2;
+            if (sh->good) {  // :341
+                path |= STVO_PATH_STAGE1_GOOD;
+                tq2 = tick();
+                remove_outliers();
+                tprof[3] += tick() - tq2;
+                if (sh->n_inl_p + sh->n_inl_l >= prm.min_features) {  // :345 — restart from the INITIAL DT
+                    path |= STVO_PATH_REFINED;
+                    stage = 1;
+                } else {
+                    if (w0) pm::identity4(sh->DT);
+                    status = STVO_POSE_FEW_INLIERS_AFTER;
+                    __syncthreads();
+                    break;
+                }
+            } else {  // :357-362 robust GN on everything, from the initial DT
+                path |= STVO_PATH_ROBUST_FALLBACK;
+                stage = 2;
+                alg = 1;
+            }
+            max_it = prm.max_iters_ref;
+            if (w0) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sh->DT[i] = sh->DT0[i];
+            }
+            __syncthreads();
+        }
+    } else {
+        if (w0) pm::identity4(sh->DT);
+        status = STVO_POSE_FEW_INLIERS_BEFORE;
+        __syncthreads();
+    }
+
+    {
+        const long long tq3 = tick();
+        if (t0) t0_commit(sh, a.results + f, status, path, it0, it1);
+        tprof[2] += tick() - tq3;
+    }
+    if (prof && t0) {
+        tprof[4] = tick() - t_begin;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) a.prof_out[(size_t)f * 16 + i] = tprof[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) a.prof_out[(size_t)f * 16 + 5 + i] = wprof[i];
+    }
+    if (prof && lane == 0 && (wv < 6 || wv == NW - 1)) a.prof_out[(size_t)f * 16 + 8 + (wv < 6 ? wv : 7)] = wave_busy;  // waves 0..5 and the last
+    if (prof && t0) a.prof_out[(size_t)f * 16 + 14] = t_prologue;
+
+    if (a.inl_p_out) {
+        const size_t base = (size_t)f * a.max_pts;
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int i = tid + k * BLOCK;
+            if (i < a.max_pts) a.inl_p_out[base + i] = ((pmatched >> k) & 1u) ? (int)((pinl >> k) & 1u) : -1;
+        }
+    }
+    if (a.inl_l_out && a.max_lines > 0) {
+#pragma unroll
+        for (int k = 0; k < LPT; ++k) {
+            const int li = li0 + k * BLOCK;
+            if (li < a.max_lines) a.inl_l_out[(size_t)f * a.max_lines + li] = ((lmatched >> k) & 1u) ? (int)((linl >> k) & 1u) : -1;
+        }
+    }
+}
+
+struct ArenaBuf {
+    double2* dev = nullptr;
+    size_t bytes = 0;
+};
+
+// the record arena of a (device, stream): grown on demand, never shrunk (B pairs x ~152 KB)
+ArenaBuf* arena_buf(hipStream_t s, size_t bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, ArenaBuf> bufs;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    ArenaBuf& b = bufs[std::make_pair(dev, s)];
+    if (b.bytes < bytes) {
+        if (b.dev) {
+            (void)hipStreamSynchronize(s);
+            (void)hipFree(b.dev);
+            b.dev = nullptr;
+            b.bytes = 0;
+        }
+        if (hipMalloc((void**)&b.dev, bytes) != hipSuccess) return nullptr;
+        b.bytes = bytes;
+    }
+    return &b;
+}
+
+template <int NW>
+constexpr int pose2p_static_lds() {
+    return (int)(sizeof(PoseSh) + NW * 28 * 8 + NW * 4 + 2 * 260 * 4);
+}
+
+template <int NW>
+int launch_pose2p_variant(hipStream_t s, const PoseArgs& a, int wgs_per_cu) {
+    constexpr int BLOCK = NW * 64;
+    constexpr int PPT = (STVO_POSE_MAX_POINTS + BLOCK - 1) / BLOCK, LPT = (STVO_POSE_MAX_LINES + BLOCK - 1) / BLOCK;
+    // LDS planes: as many record ordinals per thread as the workgroup's share of the CU's 160 KB holds (a plane of one ordinal
+    // is BLOCK x 48 bytes); STVO_POSE2P_KLDS overrides (developer)
+    const int share = (160 * 1024) / wgs_per_cu - pose2p_static_lds<NW>();
+    int k_lds = share / (BLOCK * 48);
+    if (const char* e = std::getenv("STVO_POSE2P_KLDS")) k_lds = std::atoi(e);
+    k_lds = k_lds < 0 ? 0 : (k_lds > PPT ? PPT : k_lds);
+    const int lds = k_lds * BLOCK * 48;
+    if (lds > 48 * 1024 && !lds_opt_in(reinterpret_cast<const void*>(&pose2p_kernel<NW>), lds)) return STVO_ERR_CAPACITY;
+    const size_t pair_d2 = (size_t)(PPT * 3 + LPT * 7) * BLOCK;
+    ArenaBuf* ab = arena_buf(s, (size_t)a.B * pair_d2 * sizeof(double2));
+    if (!ab) return STVO_ERR_HIP;
+    hipLaunchKernelGGL((pose2p_kernel<NW>), dim3(a.B), dim3(BLOCK), (size_t)lds, s, a, k_lds, ab->dev, pair_d2);
+    return STVO_OK;
+}
+
+}  // namespace
+
+int launch_pose2p(hipStream_t s, const PoseArgs& a) {
+    if (a.B <= 0) return STVO_OK;
+    if (a.max_pts > STVO_POSE_MAX_POINTS || a.max_lines > STVO_POSE_MAX_LINES) return STVO_ERR_CAPACITY;
+    if (a.eval_only) return launch_pose2(s, a);
+    const char* env = std::getenv("STVO_POSE2P_NW");  // developer override: waves per frame pair (2: four pairs per CU, 4: two)
+    const int nw = env ? std::atoi(env) : 2;
+    if (nw >= 4) return launch_pose2p_variant<4>(s, a, 2);
+    return launch_pose2p_variant<2>(s, a, 4);
+}
+
+}  // namespace stvo

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 CAM = synth.KITTI_CAM
 
 
-@pytest.fixture(autouse=True, params=["default", "1", "2:16", "2:8", "2:4", "2:2", "2:40", "3:16", "3:8"])
+@pytest.fixture(autouse=True, params=["default", "1", "2:16", "2:8", "2:4", "2:2", "2:40", "3:16", "3:8", "4:2", "4:4"])
 def pose_kernel_variant(request):
     """Every test of this module runs against both pose kernels: pose_kernel.hip (worker waves + solver wave, "1") and
     pose_kernel2.hip (every wave a worker, row-distributed algebra, records compacted in LDS) with 16 / 8 / 4 / 2 waves per
@@ -22,15 +22,16 @@ def pose_kernel_variant(request):
     records do not fit its LDS share are handed to pose_kernel2's kernel by the library); "default" is the library's own
     choice.  The library reads the variables at every launch."""
     import os
-    old = {k: os.environ.get(k) for k in ("STVO_POSE_KERNEL", "STVO_POSE2_NW", "STVO_POSE3_NW")}
+    old = {k: os.environ.get(k) for k in ("STVO_POSE_KERNEL", "STVO_POSE2_NW", "STVO_POSE3_NW", "STVO_POSE2P_NW")}
     if request.param == "default":
         for k in old:
             os.environ.pop(k, None)
     else:
         k, _, nw = request.param.partition(":")
         os.environ["STVO_POSE_KERNEL"] = k
-        var = "STVO_POSE3_NW" if k == "3" else "STVO_POSE2_NW"
-        os.environ.pop("STVO_POSE2_NW", None); os.environ.pop("STVO_POSE3_NW", None)
+        var = {"3": "STVO_POSE3_NW", "4": "STVO_POSE2P_NW"}.get(k, "STVO_POSE2_NW")   # "4": pose_kernel2p.hip (thread-private records)
+        for v in ("STVO_POSE2_NW", "STVO_POSE3_NW", "STVO_POSE2P_NW"):
+            os.environ.pop(v, None)
         if nw:
             os.environ[var] = nw
     yield request.param

@@ -278,7 +278,7 @@ def test_seq_point_grid_persistent_workgroups_many_frames(oracle, monkeypatch):
         assert np.array_equal(fused[1][0][b, :len(seqs[b][1]["kp_l"])], ref["m12_raw_p"])
 
 
-@pytest.mark.parametrize("pose", ["default", "3:16", "3:8"])
+@pytest.mark.parametrize("pose", ["default", "3:16", "3:8", "4:2", "4:4"])
 def test_seq_pipeline_headline_shape_every_stream_vs_oracle(oracle, monkeypatch, pose):
     """The shape bench.py's `value` is quoted on — hundreds of streams x (1650 landmarks ~ 2000 key-points + 85 segments ~ 100
     key-lines), the eight sequence ids / three KITTI calibrations of configs[4], resident frame slots advanced with
@@ -288,7 +288,7 @@ def test_seq_pipeline_headline_shape_every_stream_vs_oracle(oracle, monkeypatch,
     from stvo_amd import capi
     if pose != "default":   # pose_kernel3.hip (two frame pairs per workgroup) with 16 / 8 waves
         monkeypatch.setenv("STVO_POSE_KERNEL", pose.split(":")[0])
-        monkeypatch.setenv("STVO_POSE3_NW", pose.split(":")[1])
+        monkeypatch.setenv("STVO_POSE3_NW" if pose[0] == "3" else "STVO_POSE2P_NW", pose.split(":")[1])
     B, S = 320, 3
     ids = np.arange(B) % synth.CONFIG5_N_SEQUENCES
     streams = [synth.make_config5_sequence(int(s), n_frames=S, n_pts=1650, n_lines=85, replica=400 + b // 8) for b, s in enumerate(ids)]
