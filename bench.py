@@ -685,7 +685,7 @@ def main():
         pose_gbs = pose_bytes / (pose_ms * 1e-3) / 1e9 if pose_ms > 0 else 0.0
         # kernel the library picks for this batch size (csrc/pose_kernel.hip: launch_pose), as rocprofv3 names it
         forced = os.environ.get("STVO_POSE_KERNEL", "")
-        pose_name = "pose_kernel<" if forced == "1" or (forced != "2" and B <= 256) else "pose2_kernel<"
+        pose_name = {"1": "pose_kernel<", "2": "pose2_kernel<", "3": "pose3_kernel<", "4": "pose2p_kernel<"}.get(forced, "pose_kernel<" if B <= 256 else "pose2p_kernel<")
         # FP64 view (SURVEY.md §8d gn_accumulate): 150 flop per point and 400 per line and evaluation; evaluations = the iteration
         # counts the kernel reports (stage 1 + refinement), all matched features priced at every evaluation
         evals_l = float(np.mean(evals)) / B

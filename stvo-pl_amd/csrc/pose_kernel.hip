@@ -600,7 +600,10 @@ int launch_pose(hipStream_t s, const PoseArgs& a) {
     // STVO_POSE_KERNEL = 3: pose_kernel3.hip (two frame pairs per workgroup, owner + evaluator waves) — until it is the measured
     // default for batches it is opt-in
     if (which == 3 && !a.eval_only) return launch_pose3(s, a);
-    if (which == 4 && !a.eval_only) return launch_pose2p(s, a);  // pose_kernel2p.hip (thread-private records, four pairs per CU)
+    // batches beyond one frame pair per CU: pose_kernel2p.hip — thread-private records (LDS planes + a coalesced global arena), two
+    // waves per pair at 256 VGPRs, FOUR pairs per CU: 0.43 -> 0.33 ms per 1024 pairs inside the pipeline against pose_kernel2.hip's
+    // four-wave kernel (profiles/r03_pose_variants.txt).  STVO_POSE_KERNEL = 2 / 4 force either for every batch size.
+    if ((which == 4 || (which == 0 && a.B > POSE_LATENCY_MAX_B)) && !a.eval_only) return launch_pose2p(s, a);
     if (which == 2 || (which == 0 && a.B > POSE_LATENCY_MAX_B)) return launch_pose2(s, a);
     if (a.max_pts > STVO_POSE_MAX_POINTS || a.max_lines > STVO_POSE_MAX_LINES) return STVO_ERR_CAPACITY;
     const size_t rec_bytes = ((size_t)a.max_pts * 6 + (size_t)a.max_lines * 14) * sizeof(double);

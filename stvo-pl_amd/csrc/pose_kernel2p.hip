@@ -98,14 +98,24 @@ __global__ __launch_bounds__(NW * 64, 2) void pose2p_kernel(PoseArgs a, const in
     const int n_prev_l = (a.n_prev_lines != nullptr && a.max_lines > 0) ? a.n_prev_lines[f] : 0;
     const size_t lbase = (size_t)f * a.max_lines;
     const int li0 = BLOCK - 1 - tid;  // line k of this thread: li0 + k BLOCK
+    int jl[LPT];
+    {   // branch-free, clamped loads as for the points: all LPT match indices of the thread in one round trip
+        int initl[LPT];
 #pragma unroll
-    for (int k = 0; k < LPT; ++k) {
-        const int li = li0 + k * BLOCK;
-        if (li < n_prev_l && li < a.max_lines) {
-            const int j = a.m12l ? a.m12l[lbase + li] : li;
-            if (j >= 0) {
+        for (int k = 0; k < LPT; ++k) {
+            const int li = li0 + k * BLOCK;
+            const int lc = (li < n_prev_l && li < a.max_lines) ? li : 0;
+            jl[k] = (a.m12l && a.max_lines > 0) ? a.m12l[lbase + lc] : lc;
+            initl[k] = (a.init_inl_l && a.max_lines > 0) ? a.init_inl_l[lbase + lc] : 1;
+        }
+#pragma unroll
+        for (int k = 0; k < LPT; ++k) {
+            const int li = li0 + k * BLOCK;
+            if (li < n_prev_l && li < a.max_lines && jl[k] >= 0) {
                 lmatched |= 1u << k;
-                if (a.init_inl_l == nullptr || a.init_inl_l[lbase + li] != 0) linl |= 1u << k;
+                if (initl[k] != 0) linl |= 1u << k;
+            } else {
+                jl[k] = 0;
             }
         }
     }
@@ -153,7 +163,7 @@ __global__ __launch_bounds__(NW * 64, 2) void pose2p_kernel(PoseArgs a, const in
         return L;
     };
     // stage this thread's own records (thread-private slots: no barrier between staging and use), STAGE_CH records at a time
-    constexpr int STAGE_CH = PPT < 4 ? PPT : 4;
+    constexpr int STAGE_CH = PPT < 8 ? PPT : 8;  // 96 VGPRs of loaded values in flight: half as many round trips as with 4
 #pragma unroll
     for (int k0 = 0; k0 < PPT; k0 += STAGE_CH) {
         PointRec2 rec[STAGE_CH];
@@ -184,11 +194,11 @@ __global__ __launch_bounds__(NW * 64, 2) void pose2p_kernel(PoseArgs a, const in
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-#pragma unroll 1
+#pragma unroll
     for (int k = 0; k < LPT; ++k)
         if ((lmatched >> k) & 1u) {
             const size_t i = lbase + (size_t)(li0 + k * BLOCK);
-            const size_t j = a.m12l ? lbase + (size_t)a.m12l[i] : i;
+            const size_t j = lbase + (size_t)jl[k];
             const int r = __popc(lmatched & ((1u << k) - 1u));
             double2* q = ar_l + (size_t)(r * 7) * BLOCK + tid;
             q[0] = make_double2(a.prev_sP[i * 3 + 0], a.prev_sP[i * 3 + 1]);

@@ -483,7 +483,7 @@ int stvo_time_stage_dev(stvo_ctx* ctx, const stvo_track_batch_dev* b, const stvo
         else
         std::fprintf(stderr, "[pose prof] mean ticks/frame: evaluate %.0f  iter-algebra %.0f  cov+isgood+commit %.0f  "
                              "remove_outliers %.0f  total %.0f | worker: eval-compute %.0f  barrier+solver-sum %.0f  prefetch+fold %.0f\n", m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7]);
-        std::fprintf(stderr, "[pose prof] per worker wave, compute + fold ticks/frame: %.0f %.0f %.0f %.0f %.0f %.0f %.0f %.0f\n", m[8], m[9], m[10],
+        std::fprintf(stderr, "[pose prof] per worker wave, compute + fold ticks/frame: %.0f %.0f %.0f %.0f %.0f %.0f | prologue %.0f | last wave %.0f\n", m[8], m[9], m[10],
                      m[11], m[12], m[13], m[14], m[15]);
         (void)hipFree(dprof);
     }
