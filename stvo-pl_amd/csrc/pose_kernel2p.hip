@@ -37,7 +37,9 @@ struct PointRec2 {
 constexpr bool POSE2P_PRIO = true;  // serial sections at wave priority 3 (measured: 239 -> 230 us per 512 pairs with four waves per pair)
 
 // NW waves per frame pair at 256 VGPRs (two waves per SIMD); k_lds record ordinals of every thread live in LDS
-template <int NW>
+// PROF: the developer's phase-tick instrumentation (tools/pose_probe.py) as its own instantiation — as a run-time flag its ~26
+// live counters cost the production kernel registers across the whole state machine (30 VGPRs spilled at the loop head)
+template <int NW, bool PROF>
 __global__ __launch_bounds__(NW * 64, 2) void pose2p_kernel(PoseArgs a, const int k_lds, double2* arena, const size_t arena_pair) {
     constexpr int WPE = 2;
     constexpr int BLOCK = NW * 64;
@@ -57,10 +59,13 @@ __global__ __launch_bounds__(NW * 64, 2) void pose2p_kernel(PoseArgs a, const in
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const bool w0 = wv == 0;   // the wave that also runs the serial sections (all of its lanes, redundantly)
     const bool t0 = tid == 0;  // the lane that writes results to global memory
-    const bool prof = a.prof_out != nullptr;
+    constexpr bool prof = PROF;
     long long tprof[5] = {0, 0, 0, 0, 0};
     long long wprof[3] = {0, 0, 0}, wave_busy = 0;  // developer aid: loop compute, fold, barrier + partial sums; per-wave busy ticks
-    auto tick = [&]() -> long long { return prof ? (long long)__builtin_readcyclecounter() : 0ll; };
+    auto tick = [&]() -> long long {
+        if constexpr (PROF) return (long long)__builtin_readcyclecounter();
+        else return 0ll;
+    };
     const long long t_begin = tick();
     const stvo_cam cam_f = a.cams ? a.cams[f] : a.cam;
     const pm::Cam5 cam{cam_f.fx, cam_f.fy, cam_f.cx, cam_f.cy};
@@ -607,11 +612,14 @@ int launch_pose2p_variant(hipStream_t s, const PoseArgs& a, int wgs_per_cu) {
     if (const char* e = std::getenv("STVO_POSE2P_KLDS")) k_lds = std::atoi(e);
     k_lds = k_lds < 0 ? 0 : (k_lds > PPT ? PPT : k_lds);
     const int lds = k_lds * BLOCK * 48;
-    if (lds > 48 * 1024 && !lds_opt_in(reinterpret_cast<const void*>(&pose2p_kernel<NW>), lds)) return STVO_ERR_CAPACITY;
+    const bool prof = a.prof_out != nullptr;
+    const void* kfn = prof ? reinterpret_cast<const void*>(&pose2p_kernel<NW, true>) : reinterpret_cast<const void*>(&pose2p_kernel<NW, false>);
+    if (lds > 48 * 1024 && !lds_opt_in(kfn, lds)) return STVO_ERR_CAPACITY;
     const size_t pair_d2 = (size_t)(PPT * 3 + LPT * 7) * BLOCK;
     ArenaBuf* ab = arena_buf(s, (size_t)a.B * pair_d2 * sizeof(double2));
     if (!ab) return STVO_ERR_HIP;
-    hipLaunchKernelGGL((pose2p_kernel<NW>), dim3(a.B), dim3(BLOCK), (size_t)lds, s, a, k_lds, ab->dev, pair_d2);
+    if (prof) hipLaunchKernelGGL((pose2p_kernel<NW, true>), dim3(a.B), dim3(BLOCK), (size_t)lds, s, a, k_lds, ab->dev, pair_d2);
+    else hipLaunchKernelGGL((pose2p_kernel<NW, false>), dim3(a.B), dim3(BLOCK), (size_t)lds, s, a, k_lds, ab->dev, pair_d2);
     return STVO_OK;
 }
 
@@ -621,8 +629,11 @@ int launch_pose2p(hipStream_t s, const PoseArgs& a) {
     if (a.B <= 0) return STVO_OK;
     if (a.max_pts > STVO_POSE_MAX_POINTS || a.max_lines > STVO_POSE_MAX_LINES) return STVO_ERR_CAPACITY;
     if (a.eval_only) return launch_pose2(s, a);
-    const char* env = std::getenv("STVO_POSE2P_NW");  // developer override: waves per frame pair (2: four pairs per CU, 4: two)
-    const int nw = env ? std::atoi(env) : 2;
+    // waves per frame pair: two (four pairs per CU) once the batch holds more than two pairs per CU, four (two pairs per CU,
+    // half as many records per thread) below that — with 512 pairs on 256 CUs the two-wave variant leaves half of every CU's
+    // wave slots empty (configs[3] leg, 512 streams: 701 k vs 774 k frame pairs/s).  STVO_POSE2P_NW overrides (developer).
+    const char* env = std::getenv("STVO_POSE2P_NW");
+    const int nw = env ? std::atoi(env) : (a.B > 2 * device_cu_count() ? 2 : 4);
     if (nw >= 4) return launch_pose2p_variant<4>(s, a, 2);
     return launch_pose2p_variant<2>(s, a, 4);
 }
