@@ -557,6 +557,7 @@ def main():
     ap.add_argument("--max-keylines", type=int, default=128,
                     help="key-line capacity per image of the pipeline (config_kitti.yaml: lsd_nfeatures 100; the library allows up to 512)")
     ap.add_argument("--repeats", type=int, default=5, help="the timed region (exactly --steps steps between barriers) is repeated this often; value = median")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle parity sample after the timed region (counter passes: every dispatch costs seconds)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the latency / configs[1] / correlated-descriptor legs")
     args = ap.parse_args()
@@ -658,7 +659,10 @@ def main():
         stage_ms, n_timed = pipe.get_stage_timing()
         pipe.set_stage_timing(False)
         # parity at the headline shape: 8 streams of this run (sequence ids 0-7 = all three calibrations) vs the oracle
-        parity, last_slot = parity_sample(pipe, streams, cams, mp, op, order, last_slot, list(range(min(8, B))))
+        if args.no_parity:
+            parity = {"skipped": True}
+        else:
+            parity, last_slot = parity_sample(pipe, streams, cams, mp, op, order, last_slot, list(range(min(8, B))))
         n_kp = np.array([[len(st[k]["kp_l"]) + len(st[k]["kp_r"]) for k in range(S)] for st in streams], np.float64)  # [B][S]
         pairs_l, n1_l, n2_l, np_l, nl_l = (float(np.mean(v)) for v in (pairs, n1s, n2s, nps, nls))
 

@@ -294,28 +294,11 @@ struct BlockOps {
         int kk = kth, parity = 0;
         for (int shift = BITS - 8; shift >= 0; shift -= 8) {
             int* h = hist[parity];
-            if (W && shift + 8 >= BITS) {
-                // first round: the top digit of residual norms (sign + the leading exponent bits) takes two or three values, so ~1500
-                // ds_add on two or three bins serialise in the LDS unit (~8 k cycles).  Aggregate inside the wave instead: one add
-                // per distinct digit and wave (a handful of ballots), same counts.
-#pragma unroll
-                for (int k = 0; k < N; ++k) {
-                    const bool in = (mask >> k) & 1u;
-                    const int bin = (int)((key[k] >> shift) & 255);
-                    unsigned long long todo = __builtin_amdgcn_ballot_w64(in);
-                    while (todo) {  // wave-uniform loop over the distinct digits of this trip
-                        const int leader = __builtin_ctzll(todo);
-                        const int v = __builtin_amdgcn_readlane(bin, leader);
-                        const unsigned long long same_bin = __builtin_amdgcn_ballot_w64(in && bin == v);
-                        if (lane == leader) atomicAdd(&h[v], (int)__popcll(same_bin));
-                        todo &= ~same_bin;
-                    }
-                }
-            } else if (W) {
+            if (W) {
 #pragma unroll
                 for (int k = 0; k < N; ++k) {
                     const K diff = key[k] ^ prefix;
-                    const bool same = (diff >> (shift + 8 >= BITS ? 0 : shift + 8)) == 0;
+                    const bool same = shift + 8 >= BITS ? true : (diff >> (shift + 8 >= BITS ? 0 : shift + 8)) == 0;
                     if (((mask >> k) & 1u) && same) atomicAdd(&h[(int)((key[k] >> shift) & 255)], 1);
                 }
             }

@@ -16,11 +16,11 @@ rm -rf /tmp/kt
 if [ "$2" = "pmc" ]; then
   for c in FETCH_SIZE WRITE_SIZE; do
     cd /tmp; rm -rf /tmp/pmc_$c
-    timeout 420 rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc_$c -- $BENCH --steps 1 --warmup 1 --repeats 1 > /dev/null 2>&1
+    timeout 420 rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc_$c -- $BENCH --steps 1 --warmup 1 --repeats 1 --no-parity > /dev/null 2>&1
     cd $R; python tools/rocprof_summary.py pmc $(find /tmp/pmc_$c -name "*.db" | head -1) $c > $OUT/pmc_$c.txt 2>/dev/null; rm -rf /tmp/pmc_$c
   done
   cd /tmp; rm -rf /tmp/pmc_g
-  timeout 240 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --kernel-trace -d /tmp/pmc_g -- $BENCH --steps 1 --warmup 1 --repeats 1 > /dev/null 2>&1
+  timeout 240 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --kernel-trace -d /tmp/pmc_g -- $BENCH --steps 1 --warmup 1 --repeats 1 --no-parity > /dev/null 2>&1
   cd $R; python tools/rocprof_summary.py pmc $(find /tmp/pmc_g -name "*.db" | head -1) 2>/dev/null | grep -i "hamming_knn2_mfma_kernel<2, 0>\|pose\|grid_points_fused\|counter" > $OUT/pmc_sq.txt; rm -rf /tmp/pmc_g
 fi
 ls -la $OUT; head -c 1500 $OUT/bench_default.json; echo; tail -5 $OUT/bench_default.err
