@@ -141,6 +141,37 @@ def cpu_baseline(n_pts, n_lines, budget_s=12.0):
             "ms_per_frame": t_used / done * 1e3}
 
 
+def cpu_baseline_fanout(n_pts, n_lines, budget_s=5.0):
+    """One stream at the reference's OWN thread structure: points || lines in the stereo association and in f2fTracking
+    (stereoFrame.cpp:64-72, stereoFrameHandler.cpp:115-118) and 12 || 21 inside every StVO::match (matching.cpp:69-74) — up to four
+    busy threads.  Same results as the sequential loop (tests/test_oracle_matching.py); this is the CPU latency the reference's
+    design would show on this box, next to the 1-core figure."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from concurrent.futures import ThreadPoolExecutor
+    import oracle_lib
+    import pipeline_ref
+    from stvo_amd import synth
+    from stvo_amd.ctypes_types import match_params, opt_params
+    orc = oracle_lib.load()
+    mp, op = match_params("kitti"), opt_params("kitti")
+    nf = 6
+    with ThreadPoolExecutor(6) as ex:
+        warm = synth.make_config5_sequence(0, n_frames=3, n_pts=n_pts, n_lines=n_lines, replica=980)
+        pipeline_ref.run_sequence(orc, warm, synth.config5_cam(0), mp, op, fanout=ex)
+        done, t_used, k = 0, 0.0, 0
+        while t_used < budget_s:
+            s = k % synth.CONFIG5_N_SEQUENCES
+            sq = synth.make_config5_sequence(s, n_frames=nf, n_pts=n_pts, n_lines=n_lines, replica=981 + k // 8)
+            t0 = time.perf_counter()
+            pipeline_ref.run_sequence(orc, sq, synth.config5_cam(s), mp, op, fanout=ex)
+            t_used += time.perf_counter() - t0
+            done += nf
+            k += 1
+    return {"value": done / t_used, "unit": "frame-pairs/s", "cores": 4, "kind": "port", "ms_per_frame": t_used / done * 1e3,
+            "sample": f"{k} sequences x {nf} frames, one stream, the reference's thread fan-out (points || lines, 12 || 21: up to 4 busy threads), "
+                      f"{t_used:.1f} s"}
+
+
 def cpu_baseline_threads(n_pts, n_lines, budget_s=6.0):
     """Independent sequences on many host threads (the oracle's C functions run outside the GIL): the all-cores figure
     SURVEY.md §8(d) asks for next to the 1-thread one.  Reported beside `cpu_baseline`, never instead of it."""
@@ -750,10 +781,14 @@ def main():
         out["images_to_poses"] = images_leg(local_rank)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.points, args.lines)
+        out["cpu_baseline_fanout"] = cpu_baseline_fanout(args.points, args.lines)
         out["cpu_baseline_threads"] = cpu_baseline_threads(args.points, args.lines)
         if "latency" in out:
             out["latency"]["oracle_ms_1_core"] = out["cpu_baseline"]["ms_per_frame"]
             out["latency"]["speedup_vs_oracle_1_core"] = out["cpu_baseline"]["ms_per_frame"] / out["latency"]["seq_push_ms"]["median"]
+            # the same against the reference's own thread structure (what its CPU latency would be on this box)
+            out["latency"]["oracle_ms_reference_fanout_4_threads"] = out["cpu_baseline_fanout"]["ms_per_frame"]
+            out["latency"]["speedup_vs_oracle_reference_fanout"] = out["cpu_baseline_fanout"]["ms_per_frame"] / out["latency"]["seq_push_ms"]["median"]
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

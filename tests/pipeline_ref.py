@@ -36,26 +36,62 @@ def matched_line_sigma2(sigma2, level, lsd_scale):
     return out
 
 
-def run_sequence(orc, frames, cam, mp, prm, fast=dict(adaptive=True, th0=20, mn=7, mx=30, inc=5, feat=50, err=0.5), keyframes=None):
+def match_fanout(orc, ex, d1, d2, nnr, best_lr):
+    """StVO::match with its two directions as two tasks (src/matching.cpp:69-74: matchNNR 12 || 21 through std::async when
+    lrInParallel), then the mutual check of :80-86.  Same result as orc.match(d1, d2, nnr, best_lr)."""
+    if not best_lr:
+        return orc.match(d1, d2, nnr, 0)
+    f12 = ex.submit(orc.match, d1, d2, nnr, 0)
+    f21 = ex.submit(orc.match, d2, d1, nnr, 0)
+    m12 = f12.result()[0].copy()
+    m21 = f21.result()[0]
+    has = m12 >= 0
+    keep = has & (m21[np.where(has, m12, 0)] == np.arange(len(m12)))
+    m12[~keep] = -1
+    return m12, int(keep.sum())
+
+
+def run_sequence(orc, frames, cam, mp, prm, fast=dict(adaptive=True, th0=20, mn=7, mx=30, inc=5, feat=50, err=0.5), keyframes=None, fanout=None):
     """keyframes: None, or dict(min_entropy_ratio, max_kf_t_dist, max_kf_r_dist) to run needNewKF / currFrameIsKF after every
-    optimizePose (src/stereoFrameHandler.cpp:1136-1218); every result then carries `new_kf`."""
+    optimizePose (src/stereoFrameHandler.cpp:1136-1218); every result then carries `new_kf`.
+    fanout: None, or a concurrent.futures executor with >= 4 workers — the reference's own thread structure (points || lines in
+    the stereo association and in f2fTracking, stereoFrame.cpp:64-72 / stereoFrameHandler.cpp:115-118, and 12 || 21 inside every
+    match, matching.cpp:69-74): identical results, used by bench.py to time the CPU path at the reference's fan-out."""
     has_p, has_l = bool(prm.has_points), bool(prm.has_lines)
     kf_state = orc.kf_state() if keyframes else None
-    prev = stereo_frame(orc, frames[0], cam, mp, has_p, has_l)
+    def stereo(fr):
+        if fanout is None or not (has_p and has_l):
+            return stereo_frame(orc, fr, cam, mp, has_p, has_l)
+        fp = fanout.submit(stereo_frame, orc, fr, cam, mp, True, False)   # points || lines
+        fl = fanout.submit(stereo_frame, orc, fr, cam, mp, False, True)
+        out = fp.result()
+        ln = fl.result()
+        out.update({k: ln[k] for k in ("spl", "epl", "sP", "eP", "le", "sigma2l", "llevel", "ldesc", "m12_raw_l")})
+        return out
+
+    def match(d1, d2, nnr):
+        return orc.match(d1, d2, nnr, mp.best_lr_matches) if fanout is None else match_fanout(orc, fanout, d1, d2, nnr, mp.best_lr_matches)
+
+    prev = stereo(frames[0])
     prev.update(Tfw=np.eye(4), Tfw_cov=np.eye(6))
     fast_th = fast["th0"]
     results = []
     for k in range(1, len(frames)):
-        curr = stereo_frame(orc, frames[k], cam, mp, has_p, has_l)
+        curr = stereo(frames[k])
         z3 = np.zeros((0, 3)); z2 = np.zeros((0, 2))
         rec = dict(P=z3, pl_obs=z2, sigma2p=np.zeros(0), inlier_p=np.zeros(0, np.int32), sP=z3, eP=z3, le_obs=z3, spl=z2,
                    epl=z2, sigma2l=np.zeros(0), inlier_l=np.zeros(0, np.int32))
-        if has_p and len(prev["P"]) and len(curr["P"]):
-            m12, _ = orc.match(prev["pdesc"], curr["pdesc"], mp.min_ratio_12_p, mp.best_lr_matches)
+        do_p = has_p and len(prev["P"]) and len(curr["P"])
+        do_l = has_l and len(prev["sP"]) and len(curr["sP"])
+        fut_l = None
+        if fanout is not None and do_p and do_l:   # f2fTracking: the line matching runs beside the point matching
+            fut_l = fanout.submit(match, prev["ldesc"], curr["ldesc"], mp.min_ratio_12_l)
+        if do_p:
+            m12, _ = match(prev["pdesc"], curr["pdesc"], mp.min_ratio_12_p)
             sel = np.nonzero(m12 >= 0)[0]
             rec.update(P=prev["P"][sel], pl_obs=curr["pl"][m12[sel]], sigma2p=prev["sigma2p"][sel], inlier_p=np.ones(len(sel), np.int32))
-        if has_l and len(prev["sP"]) and len(curr["sP"]):
-            m12, _ = orc.match(prev["ldesc"], curr["ldesc"], mp.min_ratio_12_l, mp.best_lr_matches)
+        if do_l:
+            m12, _ = fut_l.result() if fut_l is not None else match(prev["ldesc"], curr["ldesc"], mp.min_ratio_12_l)
             sel = np.nonzero(m12 >= 0)[0]
             rec.update(sP=prev["sP"][sel], eP=prev["eP"][sel], le_obs=curr["le"][m12[sel]], spl=prev["spl"][sel],
                        epl=prev["epl"][sel], sigma2l=matched_line_sigma2(prev["sigma2l"][sel], prev["llevel"][sel], mp.lsd_scale),

@@ -175,3 +175,22 @@ def test_match_grid_lines_vs_numpy(oracle):  # A.4, A.11, A.12
         ref = np_model.match_grid(cands, d1, d2, 0.75, bool(best_lr), gate)
         assert np.array_equal(m, ref)
     assert (m[:10] >= -1).all()
+
+
+def test_pipeline_reference_thread_fanout_gives_identical_results(oracle):
+    """tests/pipeline_ref.run_sequence with the reference's thread structure (points || lines, 12 || 21; what bench.py times as the
+    CPU path at the reference's fan-out) is the same computation as the sequential one: identical matches, inliers and poses."""
+    from concurrent.futures import ThreadPoolExecutor
+    import pipeline_ref
+    from stvo_amd import synth
+    from stvo_amd.ctypes_types import match_params, opt_params
+    cam = synth.KITTI_CAM
+    seq = synth.make_stereo_sequence(4242, n_frames=4, n_pts=300, n_lines=40, cam=cam)
+    mp = match_params("kitti"); op = opt_params("kitti")
+    a = pipeline_ref.run_sequence(oracle, seq, cam, mp, op)
+    with ThreadPoolExecutor(6) as ex:
+        b = pipeline_ref.run_sequence(oracle, seq, cam, mp, op, fanout=ex)
+    for x, y in zip(a, b):
+        for k in ("status", "path", "iters", "n_matched_pt", "n_matched_ls", "n_inliers_pt", "n_inliers_ls", "n_stereo_pt", "n_stereo_ls"):
+            assert x[k] == y[k], k
+        assert np.array_equal(x["T"], y["T"]) and np.array_equal(x["inlier_p"], y["inlier_p"]) and np.array_equal(x["inlier_l"], y["inlier_l"])
