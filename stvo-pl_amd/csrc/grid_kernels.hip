@@ -409,14 +409,20 @@ __global__ __launch_bounds__(256) void grid_finalize_kernel(GridBatch g) {
 // registers (bitonic network, 16 slots) and takes the strict prefix minima — the eligible pairs; the last one is matches_21
 // (:148).  Eligible pairs meet their left rows through LDS: atomic min of (d << 16 | position) = best (:151-154), then one more
 // look at every eligible pair that is not the best for the ratio test (:160, pairwise as in the scan formulation), then one
-// thread per left row applies the mutual check (:166-174).  A right feature with more than 16 candidates (rare) is taken by
-// its whole wave, lane = candidate, keys in LDS.  Frames with more such keys than the LDS holds are flagged and run the scan
-// formulation above by the same workgroup after its last frame (fused_misfit_frame).
-constexpr int FUSED_T = 1024, FUSED_ROWS = 2048, FUSED_REG = 16;
+// thread per left row applies the mutual check (:166-174).  A right feature with more than 16 candidates (rare, ~8 per frame)
+// is queued in LDS and taken by a whole wave after the barrier, lane = candidate, keys in LDS (handled inline by its own wave
+// it made that wave the straggler of the phase: every other wave waited 13 k of a frame's 78 k cycles at the barrier).  Of a
+// thread's sorted keys only the eligible ones outlive the phase (four in registers, more in LDS): with the 16 keys of both
+// features live across the barrier the prefetched rows of the next frame were spilled — and the spill waited for them.
+// Frames with more wide features or keys than the LDS holds are flagged and run the scan formulation above by the same
+// workgroup after its last frame (fused_misfit_frame).  Round 3: 0.172 -> 0.133 ms per 1024 frames.
+constexpr int FUSED_T = 1024, FUSED_ROWS = 2048, FUSED_REG = 16, FUSED_R = FUSED_ROWS / FUSED_T;
 constexpr int FUSED_LW = GRID_LW;  // left key-points up to 16 columns right of the grid still have candidates
 constexpr int FUSED_PADDED = FUSED_ROWS + FUSED_REG;          // the unrolled walks read up to 15 rows past a range
 constexpr int FUSED_KEY_CAP = 8192;                           // keys of the right features with more than 16 candidates, whole frame
-constexpr size_t FUSED_LDS = (size_t)FUSED_PADDED * (16 + 16 + 2) + (size_t)FUSED_ROWS * (4 + 2 + 1) + (size_t)FUSED_KEY_CAP * 4;
+constexpr int FUSED_WQ = 256, FUSED_WQ_WORDS = 12;              // queue of the right features with more than 16 candidates: p, la, cnt, xoff, row
+constexpr size_t FUSED_LDS = (size_t)FUSED_PADDED * (16 + 16 + 2) + (size_t)FUSED_ROWS * (4 + 2 + 2 + 1) + (size_t)FUSED_KEY_CAP * 4 +
+                             (size_t)FUSED_WQ * FUSED_WQ_WORDS * 4;
 
 // the scan formulation for a frame the fused kernel flagged (run by the same workgroup after its last frame): 16 waves over the
 // blocks of 64 scan positions
@@ -477,117 +483,167 @@ __device__ __forceinline__ void sort16(uint32_t (&k)[FUSED_REG]) {
     }
 }
 
+constexpr int FUSED_EK = 4;
 constexpr uint32_t FUSED_NOKEY = 0xFFFFFFFFu, FUSED_FLAG = 1u << 30;  // key = left row << 9 | distance (0..256)
 
 // what a workgroup fetches ahead for its next frame while it works on the current one (all 256 workgroups of a launch run
 // in step, so without this the HBM sits idle during the compute phases and every frame start waits for a burst)
 struct FusedNext {
-    int i1[2], i2[2], rc[2];   // level 1: left row at this thread's two cell-order positions, right feature and its cell at its two scan positions
-    uint4 l0[2], l1[2];        // level 2: the left descriptor rows,
-    uint4 q0[2], q1[2];        //          the right descriptor rows,
-    int la[2], lb[2];          //          the candidate range [la, lb) of the right features in cell-order positions
+    int i1[FUSED_R], i2[FUSED_R], rc[FUSED_R];   // level 1: left row at this thread's two cell-order positions, right feature and its cell at its two scan positions
+    uint4 l0[FUSED_R], l1[FUSED_R];        // level 2: the left descriptor rows,
+    uint4 q0[FUSED_R], q1[FUSED_R];        //          the right descriptor rows,
+    int la[FUSED_R], lb[FUSED_R];          //          the candidate range [la, lb) of the right features in cell-order positions
 };
 
+// level 0: the counts of a frame, fetched one frame earlier still (fused_fetch1 used to load them itself and wait a round trip)
+struct FusedHdr {
+    int n_placed, n2, n1;
+};
+__device__ __forceinline__ FusedHdr fused_hdr(const GridBatch& g, const int f) {
+    FusedHdr h;
+    h.n_placed = (int)g.lstart[(size_t)f * GRID_LSTART_STRIDE + GRID_LCELLS];
+    h.n2 = g.n2[f];
+    h.n1 = g.n1[f];
+    return h;
+}
+
+// Both levels load unpredicated from clamped positions and keep the RAW values; validity (position < the frame's counts, which are
+// scalars) is applied where a value is consumed.  Straight-line loads keep the compiler's count of the loads in flight exact
+// (behind a predicated load it waits for everything), and a select right after a load would wait for it.
 __device__ __forceinline__ void fused_fetch1(const GridBatch& g, const int f, FusedNext& n) {
     const int tid = threadIdx.x;
     const int32_t* __restrict__ cell2 = g.cell2 + (size_t)f * g.stride2;
     const int32_t* __restrict__ lperm = g.lperm + (size_t)f * g.stride1;
     const int32_t* __restrict__ perm = g.perm + (size_t)f * g.stride2;
-    const int n_placed = (int)g.lstart[(size_t)f * GRID_LSTART_STRIDE + GRID_LCELLS], n2 = g.n2[f];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < FUSED_R; ++r) {
         const int pos = tid + r * FUSED_T;
-        n.i1[r] = pos < n_placed ? lperm[pos] : -1;
-        n.i2[r] = pos < n2 ? perm[pos] : -1;
-        n.rc[r] = pos < n2 ? cell2[pos] : -1;
+        const int p1 = pos < g.stride1 ? pos : g.stride1 - 1, p2 = pos < g.stride2 ? pos : g.stride2 - 1;
+        n.i1[r] = lperm[p1];
+        n.i2[r] = perm[p2];
+        n.rc[r] = cell2[p2];
     }
 }
 
-__device__ __forceinline__ void fused_fetch2(const GridBatch& g, const int f, FusedNext& n) {
+__device__ __forceinline__ void fused_fetch2(const GridBatch& g, const int f, const FusedHdr& h, FusedNext& n) {
+    const int tid = threadIdx.x;
     const uint4* __restrict__ D1 = reinterpret_cast<const uint4*>(g.d1) + (size_t)f * g.stride1 * 2;
     const uint4* __restrict__ D2 = reinterpret_cast<const uint4*>(g.d2) + (size_t)f * g.stride2 * 2;
     const uint32_t* __restrict__ lstart = g.lstart + (size_t)f * GRID_LSTART_STRIDE;
-    const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        n.l0[r] = n.l1[r] = n.q0[r] = n.q1[r] = z4;
-        n.la[r] = n.lb[r] = 0;
-        if (n.i1[r] >= 0) {
-            n.l0[r] = D1[2 * n.i1[r]];
-            n.l1[r] = D1[2 * n.i1[r] + 1];
-        }
-        if (n.i2[r] >= 0) {
-            n.q0[r] = D2[2 * n.i2[r]];
-            n.q1[r] = D2[2 * n.i2[r] + 1];
-        }
-        if (n.rc[r] >= 0) {  // GridStructure::get seen from the right feature: left cells x .. x + w_lo of its row (the window is clamped, :67-71)
-            const int y = n.rc[r] >> 6, x = n.rc[r] & (STVO_GRID_COLS - 1);
-            n.la[r] = (int)lstart[y * FUSED_LW + x];
-            n.lb[r] = (int)lstart[y * FUSED_LW + x + g.w.w_lo + 1];
-        }
+    for (int r = 0; r < FUSED_R; ++r) {
+        const int pos = tid + r * FUSED_T;
+        // invalid positions read row 0 / cell 0 of the frame and nobody uses the result
+        const int i1 = pos < h.n_placed ? n.i1[r] : 0, i2 = pos < h.n2 ? n.i2[r] : 0, rc = pos < h.n2 ? n.rc[r] : 0;
+        n.l0[r] = D1[2 * i1];
+        n.l1[r] = D1[2 * i1 + 1];
+        n.q0[r] = D2[2 * i2];
+        n.q1[r] = D2[2 * i2 + 1];
+        // GridStructure::get seen from the right feature: left cells x .. x + w_lo of its row (the window is clamped, :67-71)
+        const int y = rc >> 6, x = rc & (STVO_GRID_COLS - 1);
+        n.la[r] = (int)lstart[y * FUSED_LW + x];
+        n.lb[r] = (int)lstart[y * FUSED_LW + x + g.w.w_lo + 1];
     }
 }
 
 // Persistent: workgroup w takes frames w, w + gridDim.x, ...
 __global__ __launch_bounds__(FUSED_T) void grid_points_fused_kernel(GridBatch g, const int key_cap) {
     extern __shared__ uint4 s_fused[];
-    __shared__ int s_ctl[2];  // [0] bump allocator of the key slots, [1] the frame misfits
+    __shared__ int s_ctl[3];  // [0] bump allocator of the key slots, [1] the frame misfits, [2] entries in the queue of wide right features
     uint4* s_llo = s_fused;                                                              // [pos] first / second half of the left rows,
     uint4* s_lhi = s_llo + FUSED_PADDED;                                                 //       cell order
     uint32_t* s_best = reinterpret_cast<uint32_t*>(s_lhi + FUSED_PADDED);                // [left row] min (d << 16 | scan position)
     uint32_t* s_keys = s_best + FUSED_ROWS;                                              // keys of the wide right features
     unsigned short* s_lperm = reinterpret_cast<unsigned short*>(s_keys + FUSED_KEY_CAP); // [pos] -> left row
     unsigned short* s_owner = s_lperm + FUSED_PADDED;                                    // [scan position] matches_21 (:148)
-    unsigned char* s_blocked = reinterpret_cast<unsigned char*>(s_owner + FUSED_ROWS);   // [left row] ratio test failed
+    unsigned short* s_rperm = s_owner + FUSED_ROWS;                                      // [scan position] -> right row
+    unsigned char* s_blocked = reinterpret_cast<unsigned char*>(s_rperm + FUSED_ROWS);   // [left row] ratio test failed
+    uint32_t* s_wq = reinterpret_cast<uint32_t*>(s_blocked + FUSED_ROWS);                // [entry][12] wide right features
     const int tid = threadIdx.x;
     FusedNext nx;
     int f = blockIdx.x;
     if (f >= g.B) return;
     unsigned long long misfit_mask = 0ull;  // bit i: the i-th frame of this workgroup is left to the scan formulation (block-uniform)
     int trip = 0;
+    FusedHdr hn = fused_hdr(g, f);
     fused_fetch1(g, f, nx);
-    fused_fetch2(g, f, nx);
-    for (; f < g.B; f += gridDim.x) {
-        const GridArgs a = frame_view(g, f);
-        // ---- commit the fetched frame: left rows into LDS in cell order, this thread's two right rows stay in registers
-        uint4 q0[2], q1[2];
-        int la[2], cnt[2], xoff[2] = {0, 0};
+    FusedHdr hc;  // the header of the frame being worked on, in scalar registers
+    hc.n_placed = __builtin_amdgcn_readfirstlane(hn.n_placed);
+    hc.n2 = __builtin_amdgcn_readfirstlane(hn.n2);
+    hc.n1 = __builtin_amdgcn_readfirstlane(hn.n1);
+    fused_fetch2(g, f, hc, nx);
+    if (f + (int)gridDim.x < g.B) hn = fused_hdr(g, f + gridDim.x);
+    const bool mutual = g.mutual != 0;
+    const double ratio = g.ratio;
+    auto commit_rows = [&]() {
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < FUSED_R; ++r) {
             const int pos = tid + r * FUSED_T;
-            if (nx.i1[r] >= 0) {
+            if (pos < hc.n_placed) {
                 s_llo[pos] = nx.l0[r];
                 s_lhi[pos] = nx.l1[r];
                 s_lperm[pos] = (unsigned short)nx.i1[r];
             }
+        }
+    };
+    for (; f < g.B; f += gridDim.x) {
+        // the header of the NEXT frame, fetched a frame ago, into scalar registers here: one unconditional wait that also covers the
+        // fetched rows (the counter is in order), so that neither the commit nor the level-1 loads below wait again — predicated
+        // loads make the compiler's own count pessimistic, it waited a full round trip between two level-1 loads
+        FusedHdr hs;
+        hs.n_placed = __builtin_amdgcn_readfirstlane(hn.n_placed);
+        hs.n2 = __builtin_amdgcn_readfirstlane(hn.n2);
+        hs.n1 = __builtin_amdgcn_readfirstlane(hn.n1);
+        // ---- commit the fetched frame: left rows into LDS in cell order, this thread's two right rows stay in registers
+        commit_rows();
+        uint4 q0[FUSED_R], q1[FUSED_R];
+        int la[FUSED_R], cnt[FUSED_R], xoff[FUSED_R] = {};
+#pragma unroll
+        for (int r = 0; r < FUSED_R; ++r) {
+            const int pos = tid + r * FUSED_T;
+            if (pos < hc.n2) s_rperm[pos] = (unsigned short)nx.i2[r];
             s_best[pos] = 0xFFFFFFFFu;
             s_blocked[pos] = 0;
             q0[r] = nx.q0[r];
             q1[r] = nx.q1[r];
-            la[r] = nx.la[r];
-            cnt[r] = nx.lb[r] - nx.la[r];
+            la[r] = pos < hc.n2 ? nx.la[r] : 0;
+            cnt[r] = pos < hc.n2 ? nx.lb[r] - nx.la[r] : 0;
         }
         if (tid == 0) {
             s_ctl[0] = 0;
             s_ctl[1] = key_cap < 0;
+            s_ctl[2] = 0;
         }
         const int fn = f + gridDim.x;
         const bool more = fn < g.B;  // block-uniform
-        if (more) fused_fetch1(g, fn, nx);
+        if (more) {
+            fused_fetch1(g, fn, nx);
+            if (fn + (int)gridDim.x < g.B) hn = fused_hdr(g, fn + gridDim.x);
+        }
         __syncthreads();
         // ---- distances, eligible chains, best per left row
-        uint32_t key[2][FUSED_REG];
-        uint32_t elig[2] = {0u, 0u};
+        // what the ratio tests after the barrier need of a right feature: its eligible keys — the first FUSED_EK stay in registers, further
+        // ones (4 % of the features) go to the key slots of LDS; the 16 sorted keys themselves live for one r only
+        uint32_t ek[FUSED_R][FUSED_EK];
+        int eoff[FUSED_R] = {}, extra[FUSED_R] = {};
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < FUSED_R; ++r) {
             const int p = tid + r * FUSED_T;
+            uint32_t key[FUSED_REG];
+            uint32_t elig = 0u;
             bool wide = cnt[r] > FUSED_REG;
             if (wide) {  // slots for its keys; a frame with more of them than the LDS holds is left to the scan formulation
                 xoff[r] = atomicAdd(&s_ctl[0], cnt[r]);
-                if (xoff[r] + cnt[r] > key_cap) {
+                const int slot = atomicAdd(&s_ctl[2], 1);
+                if (xoff[r] + cnt[r] > key_cap || slot >= FUSED_WQ) {
                     s_ctl[1] = 1;
                     wide = false;
                     cnt[r] = 0;
+                } else {  // taken after the barrier, spread over the waves (inline they made their wave the straggler of the phase)
+                    uint32_t* e = s_wq + slot * FUSED_WQ_WORDS;
+                    e[0] = (uint32_t)p; e[1] = (uint32_t)la[r]; e[2] = (uint32_t)cnt[r]; e[3] = (uint32_t)xoff[r];
+                    e[4] = q0[r].x; e[5] = q0[r].y; e[6] = q0[r].z; e[7] = q0[r].w;
+                    e[8] = q1[r].x; e[9] = q1[r].y; e[10] = q1[r].z; e[11] = q1[r].w;
                 }
             }
             const int c16 = wide ? 0 : cnt[r];
@@ -598,7 +654,7 @@ __global__ __launch_bounds__(FUSED_T) void grid_points_fused_kernel(GridBatch g,
             for (int k4 = 0; k4 < FUSED_REG; k4 += 4) {
                 if (!__any(c16 > k4)) {  // wave-uniform
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) key[r][k4 + j] = FUSED_NOKEY;
+                    for (int j = 0; j < 4; ++j) key[k4 + j] = FUSED_NOKEY;
                     continue;
                 }
 #pragma unroll
@@ -606,42 +662,63 @@ __global__ __launch_bounds__(FUSED_T) void grid_points_fused_kernel(GridBatch g,
                     // past the range: a neighbour's row or padding, result masked
                     const uint32_t dd = hamming256(lds_row(lo_row + k4 + j), lds_row(hi_row + k4 + j), q0[r], q1[r]);
                     const uint32_t i1 = perm_row[k4 + j];
-                    key[r][k4 + j] = k4 + j < c16 ? ((i1 << 9) | dd) : FUSED_NOKEY;
+                    key[k4 + j] = k4 + j < c16 ? ((i1 << 9) | dd) : FUSED_NOKEY;
                 }
             }
             uint32_t owner = 0xFFFFu;
-            if (a.mutual) {  // :145-150 — ascending left row, strict running minimum
-                sort16(key[r]);
+            if (mutual) {  // :145-150 — ascending left row, strict running minimum
+                sort16(key);
                 uint32_t thr = 512u;
 #pragma unroll
                 for (int k = 0; k < FUSED_REG; ++k) {
-                    const uint32_t dd = key[r][k] & 511u;
-                    if (key[r][k] != FUSED_NOKEY && dd < thr) {
+                    const uint32_t dd = key[k] & 511u;
+                    if (key[k] != FUSED_NOKEY && dd < thr) {
                         thr = dd;
-                        owner = key[r][k] >> 9;
-                        elig[r] |= 1u << k;
+                        owner = key[k] >> 9;
+                        elig |= 1u << k;
                     }
                 }
             } else {
-                elig[r] = (1u << c16) - 1u;
+                elig = (1u << c16) - 1u;
+            }
+            extra[r] = __builtin_popcount(elig) - FUSED_EK;
+            if (extra[r] > 0) {
+                eoff[r] = atomicAdd(&s_ctl[0], extra[r]);
+                if (eoff[r] + extra[r] > key_cap) {
+                    s_ctl[1] = 1;
+                    extra[r] = 0;
+                }
             }
 #pragma unroll
+            for (int j = 0; j < FUSED_EK; ++j) ek[r][j] = FUSED_NOKEY;
+            int ne = 0;
+#pragma unroll
             for (int k = 0; k < FUSED_REG; ++k)
-                if (elig[r] & (1u << k)) atomicMin(&s_best[key[r][k] >> 9], ((key[r][k] & 511u) << 16) | (uint32_t)p);
+                if (elig & (1u << k)) {
+                    atomicMin(&s_best[key[k] >> 9], ((key[k] & 511u) << 16) | (uint32_t)p);
+#pragma unroll
+                    for (int j = 0; j < FUSED_EK; ++j) ek[r][j] = ne == j ? key[k] : ek[r][j];
+                    if (k >= FUSED_EK && ne >= FUSED_EK && ne - FUSED_EK < extra[r]) s_keys[eoff[r] + ne - FUSED_EK] = key[k];
+                    ++ne;
+                }
             if (!wide) s_owner[p] = (unsigned short)owner;
-            // right features with more than 16 candidates (rare): the whole wave takes them one at a time — keys to LDS (lane =
-            // candidate), then every lane decides its candidates against all the others: eligible unless an earlier left row is
-            // at least as close (:145-150), matches_21 = the eligible one no later row beats
-            for (unsigned long long wm = __ballot(wide); wm; wm &= wm - 1ull) {
-                const int L = __builtin_ctzll(wm);
-                const int w_la = __builtin_amdgcn_readlane(la[r], L), w_cnt = __builtin_amdgcn_readlane(cnt[r], L);
-                const int w_xoff = __builtin_amdgcn_readlane(xoff[r], L);
-                const uint32_t w_p = (uint32_t)((tid & ~63) + L + r * FUSED_T);
-                uint4 wq0, wq1;
-                wq0.x = __builtin_amdgcn_readlane(q0[r].x, L); wq0.y = __builtin_amdgcn_readlane(q0[r].y, L);
-                wq0.z = __builtin_amdgcn_readlane(q0[r].z, L); wq0.w = __builtin_amdgcn_readlane(q0[r].w, L);
-                wq1.x = __builtin_amdgcn_readlane(q1[r].x, L); wq1.y = __builtin_amdgcn_readlane(q1[r].y, L);
-                wq1.z = __builtin_amdgcn_readlane(q1[r].z, L); wq1.w = __builtin_amdgcn_readlane(q1[r].w, L);
+            if (wide && !mutual) s_owner[p] = 0xFFFFu;
+            cnt[r] = wide ? cnt[r] : 0;  // from here on: the number of keys this thread's feature has in LDS
+        }
+        if (more) fused_fetch2(g, fn, hs, nx);  // lands during the two phases below
+        __syncthreads();
+        const bool misfit = s_ctl[1] != 0;  // block-uniform
+        // right features with more than 16 candidates (rare, ~8 per frame): one wave each — keys to LDS (lane = candidate), then
+        // every lane decides its candidates against all the others: eligible unless an earlier left row is at least as close
+        // (:145-150), matches_21 = the eligible one no later row beats
+        const int n_wide = s_ctl[2];  // block-uniform
+        if (!misfit && n_wide > 0) {
+            for (int ent = tid >> 6; ent < n_wide; ent += FUSED_T / 64) {
+                const uint32_t* e = s_wq + ent * FUSED_WQ_WORDS;
+                const uint32_t w_p = (uint32_t)__builtin_amdgcn_readfirstlane((int)e[0]);
+                const int w_la = __builtin_amdgcn_readfirstlane((int)e[1]), w_cnt = __builtin_amdgcn_readfirstlane((int)e[2]);
+                const int w_xoff = __builtin_amdgcn_readfirstlane((int)e[3]);
+                const uint4 wq0 = make_uint4(e[4], e[5], e[6], e[7]), wq1 = make_uint4(e[8], e[9], e[10], e[11]);
                 uint32_t* kk = s_keys + w_xoff;
                 for (int k = tid & 63; k < w_cnt; k += 64) {
                     const int pos = w_la + k;
@@ -658,42 +735,35 @@ __global__ __launch_bounds__(FUSED_T) void grid_points_fused_kernel(GridBatch g,
                         dominated |= vi < i1 && vd <= dd;
                         later_better |= vi > i1 && vd < dd;
                     }
-                    if (!a.mutual || !dominated) {
+                    if (!mutual || !dominated) {
                         kk[k] = mine | FUSED_FLAG;
                         atomicMin(&s_best[i1], (dd << 16) | w_p);
-                        if (a.mutual && !later_better) s_owner[w_p] = (unsigned short)i1;
+                        if (mutual && !later_better) s_owner[w_p] = (unsigned short)i1;
                     }
                 }
             }
-            if (wide && !a.mutual) s_owner[p] = 0xFFFFu;
-            cnt[r] = wide ? cnt[r] : 0;  // from here on: the number of keys this thread's feature has in LDS
+            __syncthreads();
         }
-        if (more) fused_fetch2(g, fn, nx);  // lands during the two phases below
-        __syncthreads();
-        const bool misfit = s_ctl[1] != 0;  // block-uniform
         if (tid == 0) g.misfit[f] = misfit;
         if (misfit && trip < 64) misfit_mask |= 1ull << trip;
         ++trip;
         if (!misfit) {
             // ---- :160 for every eligible pair that is not its left row's best: best_d < d * minRatio12P in DOUBLE, else the row is out
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
+            for (int r = 0; r < FUSED_R; ++r) {
                 const uint32_t p = (uint32_t)(tid + r * FUSED_T);
                 auto judge = [&](uint32_t k, uint32_t pos) {
                     const uint32_t i1 = (k >> 9) & 2047u, dd = k & 511u;
                     const uint32_t bk = s_best[i1];
                     if (bk != ((dd << 16) | pos)) {
                         const double best_d = (double)(int)(bk >> 16), d2 = (double)(int)dd;
-                        if (!(best_d < d2 * a.ratio)) s_blocked[i1] = 1;
+                        if (!(best_d < d2 * ratio)) s_blocked[i1] = 1;
                     }
                 };
 #pragma unroll
-                for (int k4 = 0; k4 < FUSED_REG; k4 += 4) {
-                    if (!__any((elig[r] >> k4) & 0xFu)) continue;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (elig[r] & (1u << (k4 + j))) judge(key[r][k4 + j], p);
-                }
+                for (int j = 0; j < FUSED_EK; ++j)
+                    if (ek[r][j] != FUSED_NOKEY) judge(ek[r][j], p);
+                for (int j = 0; j < extra[r]; ++j) judge(s_keys[eoff[r] + j], p);
                 for (unsigned long long wm = __ballot(cnt[r] > 0); wm; wm &= wm - 1ull) {  // the wide ones, lane = candidate
                     const int L = __builtin_ctzll(wm);
                     const int w_cnt = __builtin_amdgcn_readlane(cnt[r], L), w_xoff = __builtin_amdgcn_readlane(xoff[r], L);
@@ -709,19 +779,20 @@ __global__ __launch_bounds__(FUSED_T) void grid_points_fused_kernel(GridBatch g,
         // ---- one thread per left row: accept unless blocked, mutual check (:166-174)
         if (!misfit) {
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
+            for (int r = 0; r < FUSED_R; ++r) {
                 const int i1 = tid + r * FUSED_T;
                 if (i1 >= g.stride1) continue;
                 const uint32_t bk = s_best[i1];
                 int mm = -1;
-                if (i1 < a.n1 && bk != 0xFFFFFFFFu && !s_blocked[i1] && (double)(int)(bk >> 16) < 2147483647.0 * a.ratio) {
+                if (i1 < hc.n1 && bk != 0xFFFFFFFFu && !s_blocked[i1] && (double)(int)(bk >> 16) < 2147483647.0 * ratio) {
                     const int pb = (int)(bk & 0xFFFFu);
-                    if (!a.mutual || (int)s_owner[pb] == i1) mm = a.perm[pb];
+                    if (!mutual || (int)s_owner[pb] == i1) mm = (int)s_rperm[pb];
                 }
-                a.m12[i1] = mm;
+                g.m12[(size_t)f * g.stride1 + i1] = mm;
             }
         }
         if (more) __syncthreads();  // the next frame's commit overwrites what the phase above reads
+        hc = hs;
     }
     // frames that did not fit (rare): the scan formulation, by the workgroup that flagged them — no second launch
     if (misfit_mask != 0ull || trip > 64) {

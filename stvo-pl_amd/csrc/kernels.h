@@ -142,6 +142,14 @@ int launch_pose2(hipStream_t s, const PoseArgs& a);  // pose_kernel2.hip: every 
 int launch_pose2_list(hipStream_t s, const PoseArgs& a, const int* list, const int* count);
 int launch_pose2p(hipStream_t s, const PoseArgs& a); // pose_kernel2p.hip: thread-private records (LDS planes + global arena), four frame pairs per CU
 int launch_pose3(hipStream_t s, const PoseArgs& a);  // pose_kernel3.hip: two frame pairs per workgroup, owner + evaluator waves
+// the per-(device, stream) scratch of the batch kernels (record arena, misfit list) is freed when its stream goes away; the
+// caller has synchronised the stream and made its device current
+void pose2p_release_stream(hipStream_t s);
+void pose3_release_stream(hipStream_t s);
+inline void pose_release_stream(hipStream_t s) {
+    pose2p_release_stream(s);
+    pose3_release_stream(s);
+}
 
 // ---- K3: grid-windowed stereo matchers, batched over frame pairs (blockIdx.y) ----------------------
 constexpr int GRID_LW = STVO_GRID_COLS + 16, GRID_LCELLS = STVO_GRID_ROWS * GRID_LW, GRID_LSTART_STRIDE = GRID_LCELLS + 4;

@@ -18,6 +18,7 @@
 
 #include <map>
 #include <mutex>
+#include <vector>
 
 #include "pose_block.h"
 
@@ -573,23 +574,22 @@ __global__ __launch_bounds__(NW * 64, 2) void pose2p_kernel(PoseArgs a, const in
 struct ArenaBuf {
     double2* dev = nullptr;
     size_t bytes = 0;
+    std::vector<void*> retired;  // superseded blocks: kept until the stream is released (a captured step graph may hold the address)
 };
 
-// the record arena of a (device, stream): grown on demand, never shrunk (B pairs x ~152 KB)
+std::mutex g_arena_mu;
+std::map<std::pair<int, hipStream_t>, ArenaBuf> g_arenas;
+
+// the record arena of a (device, stream): grown on demand, never shrunk (B pairs x ~152 KB); pose2p_release_stream frees it
 ArenaBuf* arena_buf(hipStream_t s, size_t bytes) {
-    static std::mutex mu;
-    static std::map<std::pair<int, hipStream_t>, ArenaBuf> bufs;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> lk(mu);
-    ArenaBuf& b = bufs[std::make_pair(dev, s)];
+    std::lock_guard<std::mutex> lk(g_arena_mu);
+    ArenaBuf& b = g_arenas[std::make_pair(dev, s)];
     if (b.bytes < bytes) {
-        if (b.dev) {
-            (void)hipStreamSynchronize(s);
-            (void)hipFree(b.dev);
-            b.dev = nullptr;
-            b.bytes = 0;
-        }
+        if (b.dev) b.retired.push_back(b.dev);
+        b.dev = nullptr;
+        b.bytes = 0;
         if (hipMalloc((void**)&b.dev, bytes) != hipSuccess) return nullptr;
         b.bytes = bytes;
     }
@@ -624,6 +624,17 @@ int launch_pose2p_variant(hipStream_t s, const PoseArgs& a, int wgs_per_cu) {
 }
 
 }  // namespace
+
+void pose2p_release_stream(hipStream_t s) {  // the caller has synchronised the stream
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    std::lock_guard<std::mutex> lk(g_arena_mu);
+    const auto it = g_arenas.find(std::make_pair(dev, s));
+    if (it == g_arenas.end()) return;
+    if (it->second.dev) (void)hipFree(it->second.dev);
+    for (void* p : it->second.retired) (void)hipFree(p);
+    g_arenas.erase(it);
+}
 
 int launch_pose2p(hipStream_t s, const PoseArgs& a) {
     if (a.B <= 0) return STVO_OK;

@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <map>
 #include <mutex>
+#include <vector>
 
 #include "pose_block.h"
 
@@ -818,24 +819,24 @@ struct MisfitBuf {
     int* dev = nullptr;  // [2] counters (alternating between launches), then the list
     int cap = 0;
     unsigned launches = 0;
+    std::vector<void*> retired;  // superseded blocks: kept until the stream is released (a captured step graph may hold the address)
 };
 
+std::mutex g_misfit_mu;
+std::map<std::pair<int, hipStream_t>, MisfitBuf> g_misfits;
+
 MisfitBuf* misfit_buf(hipStream_t s, int B) {
-    static std::mutex mu;
-    static std::map<std::pair<int, hipStream_t>, MisfitBuf> bufs;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> lk(mu);
-    MisfitBuf& b = bufs[std::make_pair(dev, s)];
+    std::lock_guard<std::mutex> lk(g_misfit_mu);
+    MisfitBuf& b = g_misfits[std::make_pair(dev, s)];
     if (b.cap < B) {
-        if (b.dev) {
-            (void)hipStreamSynchronize(s);
-            (void)hipFree(b.dev);
-            b.dev = nullptr;
-        }
+        if (b.dev) b.retired.push_back(b.dev);
+        b.dev = nullptr;
+        b.cap = 0;
         const int cap = B < 4096 ? 4096 : B;
         if (hipMalloc((void**)&b.dev, (size_t)(cap + 4) * sizeof(int)) != hipSuccess) return nullptr;
-        if (hipMemset(b.dev, 0, (size_t)(cap + 4) * sizeof(int)) != hipSuccess) return nullptr;
+        if (hipMemsetAsync(b.dev, 0, (size_t)(cap + 4) * sizeof(int), s) != hipSuccess) return nullptr;
         b.cap = cap;
         b.launches = 0;
     }
@@ -864,6 +865,17 @@ int launch_pose3_variant(hipStream_t s, const PoseArgs& a, MisfitBuf* mb) {
 }
 
 }  // namespace
+
+void pose3_release_stream(hipStream_t s) {  // the caller has synchronised the stream
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    std::lock_guard<std::mutex> lk(g_misfit_mu);
+    const auto it = g_misfits.find(std::make_pair(dev, s));
+    if (it == g_misfits.end()) return;
+    if (it->second.dev) (void)hipFree(it->second.dev);
+    for (void* p : it->second.retired) (void)hipFree(p);
+    g_misfits.erase(it);
+}
 
 int launch_pose3(hipStream_t s, const PoseArgs& a) {
     if (a.B <= 0) return STVO_OK;

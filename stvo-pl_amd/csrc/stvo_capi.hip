@@ -86,8 +86,10 @@ int stvo_ctx_destroy(stvo_ctx* ctx) {
     if (ctx->arena_host) (void)hipHostFree(ctx->arena_host);
     if (ctx->probe_sink) (void)hipFree(ctx->probe_sink);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
+    if (ctx->stream) stvo::pose_release_stream(ctx->stream);
     if (ctx->aux_stream) {
         (void)hipStreamSynchronize(ctx->aux_stream);
+        stvo::pose_release_stream(ctx->aux_stream);
         (void)hipStreamDestroy(ctx->aux_stream);
         (void)hipEventDestroy(ctx->ev_match_done);
         (void)hipEventDestroy(ctx->ev_pose_done);
@@ -99,9 +101,11 @@ int stvo_ctx_destroy(stvo_ctx* ctx) {
 
 int stvo_ctx_set_stream(stvo_ctx* ctx, void* hip_stream) {
     if (!ctx) return STVO_ERR_INVALID_ARG;
-    if (ctx->own_stream && ctx->stream) {
+    if (ctx->stream) {
+        (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
-        (void)hipStreamDestroy(ctx->stream);
+        stvo::pose_release_stream(ctx->stream);
+        if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     }
     ctx->own_stream = false;
     ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
