@@ -431,6 +431,36 @@ __device__ __forceinline__ void fused_misfit_frame(const GridBatch& g, const int
     const int stride1 = g.stride1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int blocks = (a.n2 + 63) >> 6;
+    if (g.lean_cells) {  // what the lean point_cells_kernel leaves out: empty top-2 records, the candidate range of every left row
+        const int32_t* cs = g.cell_start + (size_t)f * (STVO_GRID_CELLS + 1);
+        const uint32_t* ls = g.lstart + (size_t)f * GRID_LSTART_STRIDE;
+        const int32_t* lp = g.lperm + (size_t)f * g.stride1;
+        int32_t* rg = const_cast<int32_t*>(g.range1) + (size_t)f * g.stride1 * 2;
+        for (int i = tid; i < stride1; i += FUSED_T) {
+            a.top2[i] = kTop2Empty;
+            rg[2 * i] = 0;  // not placed on the extended grid: no candidates
+            rg[2 * i + 1] = 0;
+        }
+        if (tid == 0 && a.ovf) *a.ovf = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const int n_in = cs[STVO_GRID_CELLS];
+        for (int c = tid; c < GRID_LCELLS; c += FUSED_T) {  // GridStructure::get of a left key-point of extended cell c (src/gridStructure.cpp:65-76)
+            const int y = c / GRID_LW, x = c - y * GRID_LW;
+            const int min_x = min(max(0, x - g.w.w_lo), STVO_GRID_COLS), max_x = max(min(STVO_GRID_COLS, x + 1), min_x);
+            const int c0 = y * STVO_GRID_COLS + min_x, c1 = y * STVO_GRID_COLS + max_x;
+            const int lo = c0 < STVO_GRID_CELLS ? cs[c0] : n_in, hi = c1 < STVO_GRID_CELLS ? cs[c1] : n_in;
+            for (uint32_t pos = ls[c]; pos < ls[c + 1]; ++pos) {
+                const int i1 = lp[pos];
+                rg[2 * i1] = lo;
+                rg[2 * i1 + 1] = hi;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
     for (int w = wave; w < blocks; w += FUSED_T / 64) grid_scan_body<false, 1, true>(a, w * 64 + lane);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
@@ -809,6 +839,15 @@ __global__ __launch_bounds__(FUSED_T) void grid_points_fused_kernel(GridBatch g,
 
 }  // namespace
 
+bool grid_points_fused_ok(const GridBatch& g) {
+    const bool range = g.range_points && g.range1 != nullptr;
+    // STVO_GRID_FUSED=0: the scan formulation for every batch
+    const char* ef = std::getenv("STVO_GRID_FUSED");
+    const bool fused = range && g.misfit && g.cell2 && g.lperm && g.lstart && g.stride1 <= FUSED_ROWS && g.stride2 <= FUSED_ROWS && g.w.w_lo >= 0 &&
+                       g.w.w_lo <= FUSED_LW - STVO_GRID_COLS && g.w.w_hi == 0 && g.w.h_lo == 0 && g.w.h_hi == 0 && !(ef && ef[0] == '0');
+    return fused && lds_opt_in(reinterpret_cast<const void*>(grid_points_fused_kernel), (int)FUSED_LDS);
+}
+
 // cover (zeroed here) -> scan -> finalize for a batch of frame pairs
 void launch_grid_batch(hipStream_t s, const GridBatch& g, bool lines, hipEvent_t* scan_events) {
     if (g.B <= 0 || g.stride1 <= 0 || g.stride2 <= 0) return;
@@ -828,22 +867,16 @@ void launch_grid_batch(hipStream_t s, const GridBatch& g, bool lines, hipEvent_t
         if (scan_events) (void)hipEventRecord(scan_events[1], s);
     } else {
         const bool range = g.range_points && g.range1 != nullptr;
-        // STVO_GRID_FUSED=0: the scan formulation for every batch; STVO_GRID_FUSED_CAP: capacity for the keys of right features with more than 16 candidates (tests force the misfit path with -1)
-        const char* ef = std::getenv("STVO_GRID_FUSED");
-        const bool fused = range && g.misfit && g.cell2 && g.lperm && g.lstart && g.stride1 <= FUSED_ROWS && g.stride2 <= FUSED_ROWS && g.w.w_lo >= 0 &&
-                           g.w.w_lo <= FUSED_LW - STVO_GRID_COLS && g.w.w_hi == 0 && g.w.h_lo == 0 && g.w.h_hi == 0 && !(ef && ef[0] == '0');
-        if (fused) {
-            const bool attr_ok = lds_opt_in(reinterpret_cast<const void*>(grid_points_fused_kernel), (int)FUSED_LDS);
+        if (grid_points_fused_ok(g)) {
+            // STVO_GRID_FUSED_CAP: capacity for the keys of right features with more than 16 candidates (tests force the misfit path with -1)
             const char* ec = std::getenv("STVO_GRID_FUSED_CAP");
             int cap = ec ? std::atoi(ec) : FUSED_KEY_CAP;
             if (cap > FUSED_KEY_CAP) cap = FUSED_KEY_CAP;  // negative: every frame misfits
             const int fused_wgs = device_cu_count();  // one persistent workgroup per CU (its LDS and registers fill one)
-            if (attr_ok) {
-                if (scan_events) (void)hipEventRecord(scan_events[0], s);
-                hipLaunchKernelGGL(grid_points_fused_kernel, dim3(g.B < fused_wgs ? g.B : fused_wgs), dim3(FUSED_T), FUSED_LDS, s, g, cap);
-                if (scan_events) (void)hipEventRecord(scan_events[1], s);
-                return;
-            }
+            if (scan_events) (void)hipEventRecord(scan_events[0], s);
+            hipLaunchKernelGGL(grid_points_fused_kernel, dim3(g.B < fused_wgs ? g.B : fused_wgs), dim3(FUSED_T), FUSED_LDS, s, g, cap);
+            if (scan_events) (void)hipEventRecord(scan_events[1], s);
+            return;
         }
         if (range) {
             if (scan_events) (void)hipEventRecord(scan_events[0], s);

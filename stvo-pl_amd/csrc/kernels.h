@@ -192,10 +192,15 @@ struct GridBatch {
     int32_t* elig_cnt;         // [B][stride2]
     int32_t* ovf;              // [B] set when some right feature of the frame met more than GRID_ELIG eligible pairs
     int32_t* misfit;           // [B] or nullptr: written by the one-workgroup-per-frame point matcher (1: frame left to the scan formulation)
+    // != 0: the caller left range1 / top2 / ovf uninitialised because grid_points_fused_ok() holds; the one-workgroup matcher
+    // derives them from cell_start / lstart / lperm for the frames it hands to the scan formulation
+    int lean_cells;
 };
 constexpr int GRID_ELIG = 16;
 // scan_events (optional): [0] / [1] are recorded on `s` before / after the two grid_scan passes
 void launch_grid_batch(hipStream_t s, const GridBatch& g, bool lines, hipEvent_t* scan_events = nullptr);
+// true when launch_grid_batch(.., lines = false) will run the one-workgroup-per-frame point matcher for this batch
+bool grid_points_fused_ok(const GridBatch& g);
 void launch_grid_range_debug(hipStream_t s, const GridBatch& g);  // test hook, see stvo_seq_debug_grid
 
 }  // namespace stvo

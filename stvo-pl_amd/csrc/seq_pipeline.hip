@@ -141,6 +141,11 @@ __device__ __forceinline__ void scan_cells(int* hist, int* s_wave, int32_t* star
 }
 
 // ---- 1: points — cells + CSR of the right key-points -----------------------------------------------
+// LEAN (the one-workgroup point matcher will run, grid_points_fused_ok): only what that matcher reads — the cell-sorted left
+// indices and their starts, the scan order of the right key-points and their cells, the CSR starts.  The integer cells and
+// candidate ranges of the left key-points, the CSR items / ranks and the empty top-2 records (64 of 125 KB per frame) are inputs
+// of the scan formulation only; the matcher rebuilds them for the rare frame it hands to it (fused_misfit_frame).
+template <bool LEAN>
 __global__ __launch_bounds__(256) void point_cells_kernel(SeqDev s) {
     __shared__ int hist[STVO_GRID_CELLS];
     __shared__ int fill[STVO_GRID_CELLS];
@@ -153,18 +158,20 @@ __global__ __launch_bounds__(256) void point_cells_kernel(SeqDev s) {
     const int nl = s.n_kp_l[b], nr = s.n_kp_r[b];
     const size_t off = (size_t)b * s.K;
     const double inv_w = s.inv_wh[2 * b], inv_h = s.inv_wh[2 * b + 1];
-    for (int i = tid; i < nl; i += 256) {  // float * double -> int truncation (stereoFrame.cpp:132)
-        s.pxy_l[(off + i) * 2 + 0] = (int)((double)s.kp_l[(off + i) * 2 + 0] * inv_w);
-        s.pxy_l[(off + i) * 2 + 1] = (int)((double)s.kp_l[(off + i) * 2 + 1] * inv_h);
-    }
+    if (!LEAN)
+        for (int i = tid; i < nl; i += 256) {  // float * double -> int truncation (stereoFrame.cpp:132)
+            s.pxy_l[(off + i) * 2 + 0] = (int)((double)s.kp_l[(off + i) * 2 + 0] * inv_w);
+            s.pxy_l[(off + i) * 2 + 1] = (int)((double)s.kp_l[(off + i) * 2 + 1] * inv_h);
+        }
     for (int c = tid; c < STVO_GRID_CELLS; c += 256) {
         hist[c] = 0;
         fill[c] = 0;
     }
     for (int c = tid; c < GRID_LCELLS; c += 256) lhist[c] = 0;
-    for (int i = tid; i < s.K; i += 256) s.top2_p[off + i] = 0x00000000FFFFFFFFull;  // grid matcher: no eligible candidate yet
+    if (!LEAN)
+        for (int i = tid; i < s.K; i += 256) s.top2_p[off + i] = 0x00000000FFFFFFFFull;  // grid matcher: no eligible candidate yet
     if (tid == 0) {
-        s.govf_p[b] = 0;
+        if (!LEAN) s.govf_p[b] = 0;
         s_extra = 0;
     }
     __syncthreads();
@@ -203,18 +210,19 @@ __global__ __launch_bounds__(256) void point_cells_kernel(SeqDev s) {
     const int n_in = s.pstart[(size_t)b * (STVO_GRID_CELLS + 1) + STVO_GRID_CELLS];
     // GridStructure::get with the stereo window (matching_s_ws cells to the left, same row; src/gridStructure.cpp:65-76,
     // src/stereoFrame.cpp:141-143): cells x - ws .. x of row y are contiguous in the CSR => candidates = positions [lo, hi)
-    for (int i = tid; i < nl; i += 256) {
-        const int x = s.pxy_l[(off + i) * 2 + 0], y = s.pxy_l[(off + i) * 2 + 1];
-        int lo = 0, hi = 0;
-        if (y >= 0 && y < STVO_GRID_ROWS) {
-            const int min_x = min(max(0, x - s.mp.matching_s_ws), STVO_GRID_COLS), max_x = max(min(STVO_GRID_COLS, x + 1), min_x);
-            const int c0 = y * STVO_GRID_COLS + min_x, c1 = y * STVO_GRID_COLS + max_x;
-            lo = hist[c0];
-            hi = c1 < STVO_GRID_CELLS ? hist[c1] : n_in;
+    if (!LEAN)
+        for (int i = tid; i < nl; i += 256) {
+            const int x = s.pxy_l[(off + i) * 2 + 0], y = s.pxy_l[(off + i) * 2 + 1];
+            int lo = 0, hi = 0;
+            if (y >= 0 && y < STVO_GRID_ROWS) {
+                const int min_x = min(max(0, x - s.mp.matching_s_ws), STVO_GRID_COLS), max_x = max(min(STVO_GRID_COLS, x + 1), min_x);
+                const int c0 = y * STVO_GRID_COLS + min_x, c1 = y * STVO_GRID_COLS + max_x;
+                lo = c0 < STVO_GRID_CELLS ? hist[c0] : n_in;
+                hi = c1 < STVO_GRID_CELLS ? hist[c1] : n_in;
+            }
+            s.prange[(off + i) * 2 + 0] = lo;
+            s.prange[(off + i) * 2 + 1] = hi;
         }
-        s.prange[(off + i) * 2 + 0] = lo;
-        s.prange[(off + i) * 2 + 1] = hi;
-    }
     __syncthreads();  // hist (the cell starts) is read above and advanced by nobody: fill[] takes the scatter counters
     for (int i = tid; i < nr; i += 256) {
         const int x = (int)((double)s.kp_r[(off + i) * 2 + 0] * inv_w);
@@ -223,13 +231,13 @@ __global__ __launch_bounds__(256) void point_cells_kernel(SeqDev s) {
         if (in_grid(x, y)) {
             const int c = y * STVO_GRID_COLS + x;
             pos = hist[c] + atomicAdd(&fill[c], 1);
-            s.pitems[off + pos] = i;
+            if (!LEAN) s.pitems[off + pos] = i;
         } else {  // the reference's out_of_bounds sink: never a candidate, scanned last
             pos = n_in + atomicAdd(&s_extra, 1);
         }
         s.pperm[off + pos] = i;  // scan order = CSR (spatial) order
         s.pcell[off + pos] = in_grid(x, y) ? y * STVO_GRID_COLS + x : -1;
-        s.prank[off + i] = pos;
+        if (!LEAN) s.prank[off + i] = pos;
     }
 }
 
@@ -982,7 +990,6 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl) {
     if (s->pev[0]) (void)hipEventRecord(s->pev[1], st);  // pev[0] was recorded before the ingest
     if (s->op.has_points) {
         mark(0, st);
-        hipLaunchKernelGGL(stvo::point_cells_kernel, dim3(B), dim3(256), 0, st, d);
         stvo::GridBatch g;
         std::memset(&g, 0, sizeof(g));
         g.B = B; g.stride1 = K; g.stride2 = K; g.xy_width = 2; g.items_stride = K; g.words64 = K / 64; g.n1p = K;
@@ -997,6 +1004,11 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl) {
         g.range1 = d.prange;
         g.cell2 = d.pcell;
         g.lstart = d.plstart; g.lperm = d.plperm;
+        g.lean_cells = stvo::grid_points_fused_ok(g) ? 1 : 0;
+        if (g.lean_cells)
+            hipLaunchKernelGGL(stvo::point_cells_kernel<true>, dim3(B), dim3(256), 0, st, d);
+        else
+            hipLaunchKernelGGL(stvo::point_cells_kernel<false>, dim3(B), dim3(256), 0, st, d);
         s->last_point_grid = g;
         stvo::launch_grid_batch(st, g, false, tev ? tev + 2 : nullptr);
         hipLaunchKernelGGL(stvo::point_tail_kernel, dim3(B), dim3(stvo::TAIL_BLOCK), 0, st, d);
@@ -1261,6 +1273,12 @@ int stvo_seq_debug_grid(stvo_seq* s, int b, int lines, int32_t* cell_start, int3
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(s->line_stream));
     const stvo::SeqDev& d = s->d;
+    if (!lines && s->last_point_grid.lean_cells) {  // the step ran the lean cells kernel: produce the full set of grid arrays for the hook
+        stvo::SeqDev full = d;
+        bind_raw(s, full, s->last_slot);
+        hipLaunchKernelGGL(stvo::point_cells_kernel<false>, dim3(s->B), dim3(256), 0, ctx->stream, full);
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
     const int R = lines ? s->M : s->K, xyw = lines ? 4 : 2;
     const size_t items_stride = lines ? (size_t)s->M * stvo::LENT : (size_t)s->K;
     // counts of the slot the last step ran on are not tracked per slot: read them through the last bound raw block
