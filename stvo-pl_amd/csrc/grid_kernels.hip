@@ -520,8 +520,8 @@ constexpr uint32_t FUSED_NOKEY = 0xFFFFFFFFu, FUSED_FLAG = 1u << 30;  // key = l
 // in step, so without this the HBM sits idle during the compute phases and every frame start waits for a burst)
 struct FusedNext {
     int i1[FUSED_R], i2[FUSED_R], rc[FUSED_R];   // level 1: left row at this thread's two cell-order positions, right feature and its cell at its two scan positions
-    uint4 l0[FUSED_R], l1[FUSED_R];        // level 2: the left descriptor rows,
-    uint4 q0[FUSED_R], q1[FUSED_R];        //          the right descriptor rows,
+    u32x4 l0[FUSED_R], l1[FUSED_R];        // level 2: the left descriptor rows (native vectors: a uint4 member is copied with memcpy
+    u32x4 q0[FUSED_R], q1[FUSED_R];        //          and one of them stayed in scratch), the right descriptor rows,
     int la[FUSED_R], lb[FUSED_R];          //          the candidate range [la, lb) of the right features in cell-order positions
 };
 
@@ -537,11 +537,18 @@ __device__ __forceinline__ FusedHdr fused_hdr(const GridBatch& g, const int f) {
     return h;
 }
 
+// an opaque copy of a value: address arithmetic that starts from it is redone where it is used instead of being hoisted out of the
+// frame loop (hoisted, the allocator spilled it — and every scratch reload waits for ALL memory operations in flight)
+__device__ __forceinline__ int fresh(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 // Both levels load unpredicated from clamped positions and keep the RAW values; validity (position < the frame's counts, which are
 // scalars) is applied where a value is consumed.  Straight-line loads keep the compiler's count of the loads in flight exact
 // (behind a predicated load it waits for everything), and a select right after a load would wait for it.
 __device__ __forceinline__ void fused_fetch1(const GridBatch& g, const int f, FusedNext& n) {
-    const int tid = threadIdx.x;
+    const int tid = fresh(threadIdx.x);
     const int32_t* __restrict__ cell2 = g.cell2 + (size_t)f * g.stride2;
     const int32_t* __restrict__ lperm = g.lperm + (size_t)f * g.stride1;
     const int32_t* __restrict__ perm = g.perm + (size_t)f * g.stride2;
@@ -556,9 +563,9 @@ __device__ __forceinline__ void fused_fetch1(const GridBatch& g, const int f, Fu
 }
 
 __device__ __forceinline__ void fused_fetch2(const GridBatch& g, const int f, const FusedHdr& h, FusedNext& n) {
-    const int tid = threadIdx.x;
-    const uint4* __restrict__ D1 = reinterpret_cast<const uint4*>(g.d1) + (size_t)f * g.stride1 * 2;
-    const uint4* __restrict__ D2 = reinterpret_cast<const uint4*>(g.d2) + (size_t)f * g.stride2 * 2;
+    const int tid = fresh(threadIdx.x);
+    const u32x4* __restrict__ D1 = reinterpret_cast<const u32x4*>(g.d1) + (size_t)f * g.stride1 * 2;
+    const u32x4* __restrict__ D2 = reinterpret_cast<const u32x4*>(g.d2) + (size_t)f * g.stride2 * 2;
     const uint32_t* __restrict__ lstart = g.lstart + (size_t)f * GRID_LSTART_STRIDE;
 #pragma unroll
     for (int r = 0; r < FUSED_R; ++r) {
@@ -576,9 +583,53 @@ __device__ __forceinline__ void fused_fetch2(const GridBatch& g, const int f, co
     }
 }
 
+// The tail of the stereo association for frame f, one thread per left row (rows tid, tid + 1024): mm[r] = its stereo match.  Kept
+// rows keep ascending left index (stereoFrame.cpp:161-172): ballot ranks within a wave, wave counts through LDS.  The caller
+// separates two calls by a barrier (s_cnt).
+__device__ __forceinline__ void fused_tail(const GridBatch& g, const int f, const int n1, const int (&mm)[FUSED_R], int* s_cnt) {
+    const PointTail& t = g.tail;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));  // the addresses below are computed here, per frame: hoisted out of the frame loop they were spilled
+                                   // (and pushed a prefetched row into scratch, whose store waits for the row)
+    const int lane = tid & 63, wv = tid >> 6;
+    const size_t off = (size_t)f * g.stride1;
+    bool ok[FUSED_R];
+    double disp[FUSED_R];
+    int before[FUSED_R];
+#pragma unroll
+    for (int r = 0; r < FUSED_R; ++r) {
+        const int i = tid + r * FUSED_T;
+        ok[r] = false;
+        disp[r] = 0.0;
+        if (i < n1 && mm[r] >= 0) ok[r] = point_tail_filter(t, off, i, mm[r], disp[r]);
+        const unsigned long long bal = __ballot(ok[r]);
+        before[r] = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) s_cnt[r * (FUSED_T / 64) + wv] = __popcll(bal);
+    }
+    __syncthreads();
+    const stvo_cam cam = t.cams[f];
+    int base = 0;
+#pragma unroll
+    for (int r = 0; r < FUSED_R; ++r) {
+        int wbase = base;
+        for (int w = 0; w < FUSED_T / 64; ++w) {
+            const int c = s_cnt[r * (FUSED_T / 64) + w];
+            wbase += w < wv ? c : 0;
+            base += c;
+        }
+        if (ok[r]) point_tail_write(t, cam, off, tid + r * FUSED_T, off + (size_t)(wbase + before[r]), disp[r]);
+    }
+    if (tid == 0) {
+        t.n[f] = base;
+        if (t.host_n) t.host_n[f] = base;
+        if (t.zero_nl) t.nl[f] = 0;
+    }
+}
+
 // Persistent: workgroup w takes frames w, w + gridDim.x, ...
 __global__ __launch_bounds__(FUSED_T) void grid_points_fused_kernel(GridBatch g, const int key_cap) {
     extern __shared__ uint4 s_fused[];
+    __shared__ int s_cnt[FUSED_R * (FUSED_T / 64)];  // fused_tail: kept rows per wave
     __shared__ int s_ctl[3];  // [0] bump allocator of the key slots, [1] the frame misfits, [2] entries in the queue of wide right features
     uint4* s_llo = s_fused;                                                              // [pos] first / second half of the left rows,
     uint4* s_lhi = s_llo + FUSED_PADDED;                                                 //       cell order
@@ -605,37 +656,41 @@ __global__ __launch_bounds__(FUSED_T) void grid_points_fused_kernel(GridBatch g,
     if (f + (int)gridDim.x < g.B) hn = fused_hdr(g, f + gridDim.x);
     const bool mutual = g.mutual != 0;
     const double ratio = g.ratio;
-    auto commit_rows = [&]() {
+    // Left rows of the fetched frame into LDS (cell order), and the header of the frame after it into scalar registers: ONE
+    // unconditional wait for everything in flight.  Inside the loop this sits between the ratio tests and the last phase of the
+    // frame before — nothing reads the rows then, the fetched data has long arrived, and no store is in flight yet: behind the
+    // stores of the last phase (loads and stores return out of order with respect to each other, so the compiler can only wait
+    // for ALL of them) the same wait cost the write latency of the whole tail at every frame start.
+    FusedHdr hs = hc;
+    auto commit_rows = [&](const FusedHdr& h) {
+        const int t0 = fresh(tid);
 #pragma unroll
         for (int r = 0; r < FUSED_R; ++r) {
-            const int pos = tid + r * FUSED_T;
-            if (pos < hc.n_placed) {
-                s_llo[pos] = nx.l0[r];
-                s_lhi[pos] = nx.l1[r];
+            const int pos = t0 + r * FUSED_T;
+            if (pos < h.n_placed) {
+                *reinterpret_cast<u32x4*>(s_llo + pos) = nx.l0[r];
+                *reinterpret_cast<u32x4*>(s_lhi + pos) = nx.l1[r];
                 s_lperm[pos] = (unsigned short)nx.i1[r];
             }
         }
-    };
-    for (; f < g.B; f += gridDim.x) {
-        // the header of the NEXT frame, fetched a frame ago, into scalar registers here: one unconditional wait that also covers the
-        // fetched rows (the counter is in order), so that neither the commit nor the level-1 loads below wait again — predicated
-        // loads make the compiler's own count pessimistic, it waited a full round trip between two level-1 loads
-        FusedHdr hs;
         hs.n_placed = __builtin_amdgcn_readfirstlane(hn.n_placed);
         hs.n2 = __builtin_amdgcn_readfirstlane(hn.n2);
         hs.n1 = __builtin_amdgcn_readfirstlane(hn.n1);
-        // ---- commit the fetched frame: left rows into LDS in cell order, this thread's two right rows stay in registers
-        commit_rows();
+    };
+    commit_rows(hc);  // afterwards hs = header of frame f + gridDim.x (if any)
+    for (; f < g.B; f += gridDim.x) {
+        // ---- commit the fetched frame, right side: this thread's two right rows stay in registers
         uint4 q0[FUSED_R], q1[FUSED_R];
-        int la[FUSED_R], cnt[FUSED_R], xoff[FUSED_R] = {};
+        int la[FUSED_R], cnt[FUSED_R];
+        const int t1 = fresh(tid);
 #pragma unroll
         for (int r = 0; r < FUSED_R; ++r) {
-            const int pos = tid + r * FUSED_T;
+            const int pos = t1 + r * FUSED_T;
             if (pos < hc.n2) s_rperm[pos] = (unsigned short)nx.i2[r];
             s_best[pos] = 0xFFFFFFFFu;
             s_blocked[pos] = 0;
-            q0[r] = nx.q0[r];
-            q1[r] = nx.q1[r];
+            q0[r] = make_uint4(nx.q0[r].x, nx.q0[r].y, nx.q0[r].z, nx.q0[r].w);
+            q1[r] = make_uint4(nx.q1[r].x, nx.q1[r].y, nx.q1[r].z, nx.q1[r].w);
             la[r] = pos < hc.n2 ? nx.la[r] : 0;
             cnt[r] = pos < hc.n2 ? nx.lb[r] - nx.la[r] : 0;
         }
@@ -655,7 +710,9 @@ __global__ __launch_bounds__(FUSED_T) void grid_points_fused_kernel(GridBatch g,
         // what the ratio tests after the barrier need of a right feature: its eligible keys — the first FUSED_EK stay in registers, further
         // ones (4 % of the features) go to the key slots of LDS; the 16 sorted keys themselves live for one r only
         uint32_t ek[FUSED_R][FUSED_EK];
-        int eoff[FUSED_R] = {}, extra[FUSED_R] = {};
+        // its keys in the key slots of LDS, one word: count | offset << 12 | wide << 31 (wide: all its keys, flagged where eligible;
+        // otherwise: the eligible keys beyond the FUSED_EK in registers)
+        uint32_t kinfo[FUSED_R] = {};
 #pragma unroll
         for (int r = 0; r < FUSED_R; ++r) {
             const int p = tid + r * FUSED_T;
@@ -663,15 +720,16 @@ __global__ __launch_bounds__(FUSED_T) void grid_points_fused_kernel(GridBatch g,
             uint32_t elig = 0u;
             bool wide = cnt[r] > FUSED_REG;
             if (wide) {  // slots for its keys; a frame with more of them than the LDS holds is left to the scan formulation
-                xoff[r] = atomicAdd(&s_ctl[0], cnt[r]);
+                const int xoff = atomicAdd(&s_ctl[0], cnt[r]);
                 const int slot = atomicAdd(&s_ctl[2], 1);
-                if (xoff[r] + cnt[r] > key_cap || slot >= FUSED_WQ) {
+                if (xoff + cnt[r] > key_cap || slot >= FUSED_WQ) {
                     s_ctl[1] = 1;
                     wide = false;
                     cnt[r] = 0;
                 } else {  // taken after the barrier, spread over the waves (inline they made their wave the straggler of the phase)
+                    kinfo[r] = (uint32_t)cnt[r] | ((uint32_t)xoff << 12) | 0x80000000u;
                     uint32_t* e = s_wq + slot * FUSED_WQ_WORDS;
-                    e[0] = (uint32_t)p; e[1] = (uint32_t)la[r]; e[2] = (uint32_t)cnt[r]; e[3] = (uint32_t)xoff[r];
+                    e[0] = (uint32_t)p; e[1] = (uint32_t)la[r]; e[2] = (uint32_t)cnt[r]; e[3] = (uint32_t)xoff;
                     e[4] = q0[r].x; e[5] = q0[r].y; e[6] = q0[r].z; e[7] = q0[r].w;
                     e[8] = q1[r].x; e[9] = q1[r].y; e[10] = q1[r].z; e[11] = q1[r].w;
                 }
@@ -711,12 +769,14 @@ __global__ __launch_bounds__(FUSED_T) void grid_points_fused_kernel(GridBatch g,
             } else {
                 elig = (1u << c16) - 1u;
             }
-            extra[r] = __builtin_popcount(elig) - FUSED_EK;
-            if (extra[r] > 0) {
-                eoff[r] = atomicAdd(&s_ctl[0], extra[r]);
-                if (eoff[r] + extra[r] > key_cap) {
+            int extra = __builtin_popcount(elig) - FUSED_EK, eoff = 0;
+            if (extra > 0) {
+                eoff = atomicAdd(&s_ctl[0], extra);
+                if (eoff + extra > key_cap) {
                     s_ctl[1] = 1;
-                    extra[r] = 0;
+                    extra = 0;
+                } else {
+                    kinfo[r] = (uint32_t)extra | ((uint32_t)eoff << 12);
                 }
             }
 #pragma unroll
@@ -728,12 +788,11 @@ __global__ __launch_bounds__(FUSED_T) void grid_points_fused_kernel(GridBatch g,
                     atomicMin(&s_best[key[k] >> 9], ((key[k] & 511u) << 16) | (uint32_t)p);
 #pragma unroll
                     for (int j = 0; j < FUSED_EK; ++j) ek[r][j] = ne == j ? key[k] : ek[r][j];
-                    if (k >= FUSED_EK && ne >= FUSED_EK && ne - FUSED_EK < extra[r]) s_keys[eoff[r] + ne - FUSED_EK] = key[k];
+                    if (k >= FUSED_EK && ne >= FUSED_EK && ne - FUSED_EK < extra) s_keys[eoff + ne - FUSED_EK] = key[k];
                     ++ne;
                 }
             if (!wide) s_owner[p] = (unsigned short)owner;
             if (wide && !mutual) s_owner[p] = 0xFFFFu;
-            cnt[r] = wide ? cnt[r] : 0;  // from here on: the number of keys this thread's feature has in LDS
         }
         if (more) fused_fetch2(g, fn, hs, nx);  // lands during the two phases below
         __syncthreads();
@@ -793,10 +852,12 @@ __global__ __launch_bounds__(FUSED_T) void grid_points_fused_kernel(GridBatch g,
 #pragma unroll
                 for (int j = 0; j < FUSED_EK; ++j)
                     if (ek[r][j] != FUSED_NOKEY) judge(ek[r][j], p);
-                for (int j = 0; j < extra[r]; ++j) judge(s_keys[eoff[r] + j], p);
-                for (unsigned long long wm = __ballot(cnt[r] > 0); wm; wm &= wm - 1ull) {  // the wide ones, lane = candidate
+                if (!(kinfo[r] >> 31))
+                    for (uint32_t j = 0; j < (kinfo[r] & 4095u); ++j) judge(s_keys[((kinfo[r] >> 12) & 0x3FFFFu) + j], p);
+                for (unsigned long long wm = __ballot((kinfo[r] >> 31) != 0u); wm; wm &= wm - 1ull) {  // the wide ones, lane = candidate
                     const int L = __builtin_ctzll(wm);
-                    const int w_cnt = __builtin_amdgcn_readlane(cnt[r], L), w_xoff = __builtin_amdgcn_readlane(xoff[r], L);
+                    const uint32_t w_info = (uint32_t)__builtin_amdgcn_readlane((int)kinfo[r], L);
+                    const int w_cnt = (int)(w_info & 4095u), w_xoff = (int)((w_info >> 12) & 0x3FFFFu);
                     const uint32_t w_p = (uint32_t)((tid & ~63) + L + r * FUSED_T);
                     for (int k = tid & 63; k < w_cnt; k += 64) {
                         const uint32_t v = s_keys[w_xoff + k];
@@ -805,24 +866,28 @@ __global__ __launch_bounds__(FUSED_T) void grid_points_fused_kernel(GridBatch g,
                 }
             }
         }
+        const FusedHdr hfn = hs;  // header of frame fn: fused_fetch2 above used it, the next iteration works on it
+        if (more) commit_rows(hfn);  // hs becomes the header of frame fn + gridDim.x
         __syncthreads();
-        // ---- one thread per left row: accept unless blocked, mutual check (:166-174)
+        // ---- one thread per left row: accept unless blocked, mutual check (:166-174); then the tail of the association
         if (!misfit) {
+            int mm[FUSED_R];
 #pragma unroll
             for (int r = 0; r < FUSED_R; ++r) {
                 const int i1 = tid + r * FUSED_T;
+                mm[r] = -1;
                 if (i1 >= g.stride1) continue;
                 const uint32_t bk = s_best[i1];
-                int mm = -1;
                 if (i1 < hc.n1 && bk != 0xFFFFFFFFu && !s_blocked[i1] && (double)(int)(bk >> 16) < 2147483647.0 * ratio) {
                     const int pb = (int)(bk & 0xFFFFu);
-                    if (!mutual || (int)s_owner[pb] == i1) mm = (int)s_rperm[pb];
+                    if (!mutual || (int)s_owner[pb] == i1) mm[r] = (int)s_rperm[pb];
                 }
-                g.m12[(size_t)f * g.stride1 + i1] = mm;
+                g.m12[(size_t)f * g.stride1 + i1] = mm[r];
             }
+            if (g.has_tail) fused_tail(g, f, hc.n1, mm, s_cnt);
         }
         if (more) __syncthreads();  // the next frame's commit overwrites what the phase above reads
-        hc = hs;
+        hc = hfn;
     }
     // frames that did not fit (rare): the scan formulation, by the workgroup that flagged them — no second launch
     if (misfit_mask != 0ull || trip > 64) {
@@ -832,6 +897,18 @@ __global__ __launch_bounds__(FUSED_T) void grid_points_fused_kernel(GridBatch g,
             if (todo) {
                 __syncthreads();
                 fused_misfit_frame(g, fm);
+                if (g.has_tail) {  // its matches come back through global memory
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    __syncthreads();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    int mm[FUSED_R];
+#pragma unroll
+                    for (int r = 0; r < FUSED_R; ++r) {
+                        const int i1 = threadIdx.x + r * FUSED_T;
+                        mm[r] = i1 < g.stride1 ? g.m12[(size_t)fm * g.stride1 + i1] : -1;
+                    }
+                    fused_tail(g, fm, g.n1[fm], mm, s_cnt);
+                }
             }
         }
     }

@@ -10,6 +10,7 @@
 #include <utility>
 
 #include "../../include/stvo_hip.h"
+#include "point_tail.h"
 
 namespace stvo {
 
@@ -93,6 +94,10 @@ void launch_match_mutual_lazy(hipStream_t s, int B, int row_stride, const uint8_
 // the verification pass alone, on the claims left by the last launch_match_mutual_lazy (timing tools)
 void launch_hamming_verify(hipStream_t s, int B, int row_stride, const uint8_t* d1, const int32_t* n1, const uint8_t* d2,
                            float nnr, const LazyScratch& w, int lds_pad_bytes, int nseg);
+// StVO::match of B frame pairs with at most 512 rows per set (key-lines): one workgroup per frame pair, both sets in LDS
+bool match_small_ok(int row_stride);
+void launch_match_small(hipStream_t s, int B, int row_stride, const uint8_t* d1, const int32_t* n1, const uint8_t* d2,
+                        const int32_t* n2, float nnr, int mutual, int32_t* m12, int cap = 0 /* rows per set the LDS is sized for; 0: row_stride */);
 void launch_nnr_mutual(hipStream_t s, int B, int row_stride, const uint2* knn12, const uint2* knn21, const int32_t* n1,
                        const int32_t* n2, float nnr, int mutual, int32_t* m12, int nseg = KNN_MIN_NSEG);
 void launch_valu_probe(hipStream_t s, int blocks, int iters, uint32_t* sink);
@@ -195,6 +200,11 @@ struct GridBatch {
     // != 0: the caller left range1 / top2 / ovf uninitialised because grid_points_fused_ok() holds; the one-workgroup matcher
     // derives them from cell_start / lstart / lperm for the frames it hands to the scan formulation
     int lean_cells;
+    // has_tail != 0 (only with grid_points_fused_ok): the one-workgroup matcher also runs the tail of the stereo association on the
+    // frame it just matched (filters, back-projection, ordered compaction, point_tail.h) — no point_tail_kernel launch, no second
+    // pass over the matches
+    int has_tail;
+    PointTail tail;
 };
 constexpr int GRID_ELIG = 16;
 // scan_events (optional): [0] / [1] are recorded on `s` before / after the two grid_scan passes

@@ -707,4 +707,85 @@ void launch_valu_probe(hipStream_t s, int blocks, int iters, uint32_t* sink) {
     hipLaunchKernelGGL(valu_probe_kernel, dim3(blocks), dim3(256), 0, s, iters, sink);
 }
 
+// ---- small sets (key-lines): StVO::match of one frame pair in ONE workgroup -------------------------------------------
+// The key-line sets of a frame hold ~100 rows (config: lsd_nfeatures = 100 / 300).  Through the general machinery (matrix-core scan,
+// forward plan, two reverse scans, final check: five launches whose workgroups spend their lives in prologues) the f2f line match
+// of 1024 frames took ~70 us alone and, sharing the CUs with the key-point scan on the other stream, stretched that scan by ~15 %.
+// Here a WAVE takes 64 query rows of one direction and scans the other set exactly like K1 above (lane = query row in registers,
+// train rows wave-uniform through the scalar cache: no vector-memory or LDS instruction in the loop), keeping the two smallest
+// packed keys (distance << 16 | index: lowest index among equal distances = knnMatch's tie order); the top-2 of both directions
+// meet in LDS for the float ratio test (src/matching.cpp:53-58) and the mutual check (:80-86) of nnr_mutual_kernel, verbatim.
+// `cap` (<= row_stride, <= 512): rows per set the LDS arrays are sized for — the caller knows that no set of the batch holds more.
+__global__ __launch_bounds__(256) void match_small_kernel(int row_stride, int cap, const uint8_t* __restrict__ d1,
+                                                          const int32_t* __restrict__ n1, const uint8_t* __restrict__ d2,
+                                                          const int32_t* __restrict__ n2, float nnr, int mutual,
+                                                          int32_t* __restrict__ m12) {
+    extern __shared__ uint2 s_knn[];  // knn12[cap], knn21[cap]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int na = min(n1[b], cap), nb = min(n2[b], cap);
+    const size_t off = (size_t)b * row_stride;
+    uint2* k12 = s_knn;
+    uint2* k21 = s_knn + cap;
+    const int tiles_a = (na + 63) >> 6, tiles_b = mutual ? (nb + 63) >> 6 : 0;
+    for (int item = tid >> 6; item < tiles_a + tiles_b; item += 4) {  // wave-uniform
+        const int it = __builtin_amdgcn_readfirstlane(item);
+        const bool fwd = it < tiles_a;
+        const int q = (fwd ? it : it - tiles_a) * 64 + lane;
+        const int nq = fwd ? na : nb, nt = fwd ? nb : na;
+        const uint8_t* Q = (fwd ? d1 : d2) + off * STVO_DESC_BYTES;
+        const uint32_t* __restrict__ T = reinterpret_cast<const uint32_t*>((fwd ? d2 : d1) + off * STVO_DESC_BYTES);
+        const int qc = q < nq ? q : nq - 1;  // tail lanes scan a valid row and discard the result
+        const uint4 q0 = reinterpret_cast<const uint4*>(Q)[2 * qc];
+        const uint4 q1 = reinterpret_cast<const uint4*>(Q)[2 * qc + 1];
+        uint32_t best = 0xFFFFFFFFu, second = 0xFFFFFFFFu;
+        auto update = [&](uint32_t d, uint32_t jj) {
+            const uint32_t key = pack_key(d, jj);
+            second = med3_u32(best, second, key);
+            best = best < key ? best : key;
+        };
+        int j = 0;
+        for (; j + 4 <= nt; j += 4) {
+            uint32_t t[32];
+#pragma unroll
+            for (int k = 0; k < 32; ++k) t[k] = T[8 * j + k];
+            uint32_t d[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) d[u] = hamming256(q0, q1, t + 8 * u);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) update(d[u], (uint32_t)(j + u));
+        }
+        for (; j < nt; ++j) update(hamming256(q0, q1, T + 8 * j), (uint32_t)j);
+        if (q < nq) (fwd ? k12 : k21)[q] = make_uint2(best, second);
+    }
+    __syncthreads();
+    for (int i = tid; i < row_stride; i += 256) {
+        int m = -1;
+        if (i < na && nb >= 2) {
+            const uint2 fk = k12[i];
+            const float f0 = (float)(fk.x >> 16), f1 = (float)(fk.y >> 16);
+            if (f0 < f1 * nnr) m = (int)(fk.x & 0xFFFFu);
+            if (mutual && m >= 0) {
+                bool keep = false;
+                if (na >= 2) {
+                    const uint2 rk = k21[m];
+                    const float r0 = (float)(rk.x >> 16), r1 = (float)(rk.y >> 16);
+                    keep = (r0 < r1 * nnr) && ((int)(rk.x & 0xFFFFu) == i);
+                }
+                if (!keep) m = -1;
+            }
+        }
+        m12[off + i] = m;
+    }
+}
+
+bool match_small_ok(int row_stride) { return row_stride > 0 && row_stride <= 512; }
+
+void launch_match_small(hipStream_t s, int B, int row_stride, const uint8_t* d1, const int32_t* n1, const uint8_t* d2,
+                        const int32_t* n2, float nnr, int mutual, int32_t* m12, int cap) {
+    if (B <= 0 || !match_small_ok(row_stride)) return;
+    if (cap <= 0 || cap > row_stride) cap = row_stride;
+    const size_t lds = (size_t)cap * 2 * sizeof(uint2);
+    hipLaunchKernelGGL(match_small_kernel, dim3(B), dim3(256), lds, s, row_stride, cap, d1, n1, d2, n2, nnr, mutual, m12);
+}
+
 }  // namespace stvo

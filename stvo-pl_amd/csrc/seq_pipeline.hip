@@ -245,6 +245,13 @@ __global__ __launch_bounds__(256) void point_cells_kernel(SeqDev s) {
 // 1024 threads per frame: the compaction offset is carried from chunk to chunk (three barriers each), so fewer, larger
 // chunks shorten the chain — 2 chunks instead of 8 for ~2000 key-points.
 constexpr int TAIL_BLOCK = 1024;
+__host__ __device__ __forceinline__ PointTail point_tail_args(const SeqDev& s) {
+    PointTail t;
+    t.kp_l = s.kp_l; t.kp_r = s.kp_r; t.oct_l = s.oct_l; t.desc_l = s.desc_l; t.cams = s.cams;
+    t.max_dist_epip = s.mp.max_dist_epip; t.min_disp = s.mp.min_disp; t.orb_scale_factor = s.mp.orb_scale_factor;
+    t.pl = s.pl; t.P = s.P; t.s2 = s.s2; t.desc = s.desc; t.n = s.n; t.host_n = s.host_n; t.nl = s.nl; t.zero_nl = s.zero_nl;
+    return t;
+}
 __global__ __launch_bounds__(TAIL_BLOCK) void point_tail_kernel(SeqDev s) {
     __shared__ int s_wave[TAIL_BLOCK / 64];
     __shared__ int s_run;
@@ -252,6 +259,7 @@ __global__ __launch_bounds__(TAIL_BLOCK) void point_tail_kernel(SeqDev s) {
     const int nl = s.n_kp_l[b];
     const size_t off = (size_t)b * s.K;
     const stvo_cam cam = s.cams[b];
+    const PointTail t = point_tail_args(s);
     if (tid == 0) s_run = 0;
     __syncthreads();
     for (int base = 0; base < nl; base += TAIL_BLOCK) {
@@ -260,13 +268,7 @@ __global__ __launch_bounds__(TAIL_BLOCK) void point_tail_kernel(SeqDev s) {
         double disp = 0.0;
         if (i < nl) {
             const int i2 = s.m12s_p[off + i];
-            if (i2 >= 0) {
-                const float yl = s.kp_l[(off + i) * 2 + 1], yr = s.kp_r[(off + i2) * 2 + 1];
-                if ((double)fabsf(yl - yr) <= s.mp.max_dist_epip) {  // float difference (:157)
-                    disp = (double)(s.kp_l[(off + i) * 2 + 0] - s.kp_r[(off + i2) * 2 + 0]);  // float difference (:159)
-                    ok = disp >= s.mp.min_disp;
-                }
-            }
+            if (i2 >= 0) ok = point_tail_filter(t, off, i, i2, disp);
         }
         // ordered compaction: stereo_pt / pdesc_l keep ascending left index (:161-172)
         const unsigned long long bal = __ballot(ok);
@@ -275,29 +277,12 @@ __global__ __launch_bounds__(TAIL_BLOCK) void point_tail_kernel(SeqDev s) {
         __syncthreads();
         int wbase = s_run;
         for (int w = 0; w < wv; ++w) wbase += s_wave[w];
-        if (ok) {
-            const size_t k = off + (size_t)(wbase + before);
-            const double u = (double)s.kp_l[(off + i) * 2 + 0], v = (double)s.kp_l[(off + i) * 2 + 1];
-            const double bd = cam.b / disp;  // backProjection (src/pinholeStereoCamera.cpp:221-229)
-            s.pl[k * 2 + 0] = u;
-            s.pl[k * 2 + 1] = v;
-            s.P[k * 3 + 0] = bd * (u - cam.cx);
-            s.P[k * 3 + 1] = bd * (v - cam.cy);
-            s.P[k * 3 + 2] = bd * cam.fx;
-            double sg = 1.0;  // PointFeature ctor: sigma2 = 1 / scale^(2 level) (src/stereoFeatures.cpp:41-47)
-            const int level = s.oct_l[off + i];
-            for (int t = 0; t < level; ++t) sg *= s.mp.orb_scale_factor;
-            s.s2[k] = 1.0 / (sg * sg);
-            const uint4* src = reinterpret_cast<const uint4*>(s.desc_l + (off + i) * STVO_DESC_BYTES);
-            uint4* dst = reinterpret_cast<uint4*>(s.desc + k * STVO_DESC_BYTES);
-            dst[0] = src[0];
-            dst[1] = src[1];
-        }
+        if (ok) point_tail_write(t, cam, off, i, off + (size_t)(wbase + before), disp);
         __syncthreads();
         if (tid == 0) {
-            int t = 0;
-            for (int w = 0; w < TAIL_BLOCK / 64; ++w) t += s_wave[w];
-            s_run += t;
+            int q = 0;
+            for (int w = 0; w < TAIL_BLOCK / 64; ++w) q += s_wave[w];
+            s_run += q;
         }
         __syncthreads();
     }
@@ -388,21 +373,20 @@ __global__ __launch_bounds__(256) void line_cells_kernel(SeqDev s) {
 }
 
 // ---- 6: lines — geometry filters, back-projection, ordered compaction --------------------------------
-__global__ __launch_bounds__(256) void line_tail_kernel(SeqDev s) {
-    __shared__ int s_wave[4];
-    __shared__ int s_run;
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+// the tail of frame b by a workgroup of 256 threads; match_of(i) = stereo match of left line i (the caller has put a barrier
+// after s_run = 0 and after whatever match_of reads)
+template <typename MatchOf>
+__device__ __forceinline__ void line_tail_frame(const SeqDev& s, const int b, MatchOf match_of, int* s_wave, int* s_run) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nl = s.n_kl_l[b];
     const size_t off = (size_t)b * s.M;
     const stvo_cam cam = s.cams[b];
-    if (tid == 0) s_run = 0;
-    __syncthreads();
     for (int base = 0; base < nl; base += 256) {
         const int i = base + tid;
         bool ok = false;
         double sp_l[2] = {0, 0}, ep_l[2] = {0, 0}, le_l[3] = {0, 0, 0}, disp_s = 0.0, disp_e = 0.0;
         if (i < nl) {
-            const int i2 = s.m12s_l[off + i];
+            const int i2 = match_of(i);
             if (i2 >= 0) {
                 const float* l = s.kl_l + (off + i) * 4;
                 const float* r = s.kl_r + (off + i2) * 4;
@@ -430,7 +414,7 @@ __global__ __launch_bounds__(256) void line_tail_kernel(SeqDev s) {
         const int before = __popcll(bal & ((1ull << lane) - 1ull));
         if (lane == 0) s_wave[wv] = __popcll(bal);
         __syncthreads();
-        int wbase = s_run;
+        int wbase = (*s_run);
         for (int w = 0; w < wv; ++w) wbase += s_wave[w];
         if (ok) {
             const size_t k = off + (size_t)(wbase + before);
@@ -458,13 +442,198 @@ __global__ __launch_bounds__(256) void line_tail_kernel(SeqDev s) {
             dst[1] = src[1];
         }
         __syncthreads();
-        if (tid == 0) s_run += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        if (tid == 0) (*s_run) += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
         __syncthreads();
     }
     if (tid == 0) {
-        s.nl[b] = s_run;
-        if (s.host_nl) s.host_nl[b] = s_run;
+        s.nl[b] = *s_run;
+        if (s.host_nl) s.host_nl[b] = *s_run;
     }
+}
+
+__global__ __launch_bounds__(256) void line_tail_kernel(SeqDev s) {
+    __shared__ int s_wave[4];
+    __shared__ int s_run;
+    const int b = blockIdx.x;
+    const size_t off = (size_t)b * s.M;
+    if (threadIdx.x == 0) s_run = 0;
+    __syncthreads();
+    line_tail_frame(s, b, [&](int i) { return s.m12s_l[off + i]; }, s_wave, &s_run);
+}
+
+// ---- 4 + 5 + 6 in one workgroup per frame: the whole stereo association of the key-lines --------------------------------------
+// A frame holds ~100 key-lines (lsd_nfeatures 100 / 300).  Through the general grid machinery (CSR of the rasterised right lines,
+// candidate bit-matrix, scan / elig / scan / finalize, tail: seven launches, a thread or a wave per line) the stage took ~290 us
+// per 1024 frames on an idle GPU and, sharing the CUs with the key-point stage, stretched that stage and the key-point scan by
+// ~0.1 ms.  Here thread j owns RIGHT line j: it rasterises the line once into per-grid-row column intervals in LDS (a Bresenham
+// line covers one contiguous run of columns in every row it crosses), and the candidates of left line i1 — the right lines with a
+// cell in the window of either END-POINT cell of i1 (src/matching.cpp:213-215; window = matching_s_ws columns to the left, same
+// row, stereoFrame.cpp:340-342) — become two interval tests.  matchGrid's order dependence (:145-150: a pair takes part only if it
+// strictly improves on every earlier left line that met the same right line) is local to thread j, which walks i1 in ascending
+// order; the best of a left line is an LDS atomic min over (distance << 16 | j), the ratio test (:241, DOUBLE) a second walk, the
+// mutual check (:247-255) one thread per left line.  Left lines, directions and descriptors are read through wave-uniform LDS
+// addresses (broadcasts).  Ties: the best of two equal distances fails the ratio test for ratios <= 1 whichever is "first".
+constexpr int LSF_ROW_EMPTY = 0x00FF;  // cmin = 255 > cmax = 0
+constexpr int LSF_MAX_LINES = 512, LSF_BYTES_PER_LINE = 32 + 16 + 16 + 4 + 2 * STVO_GRID_ROWS + 2 + 2 + 1;
+// Mk (<= s.M): lines per image the LDS arrays are sized for — the host knows that no image of the batch holds more.
+__global__ __launch_bounds__(256) void line_stereo_fused_kernel(SeqDev s, const int Mk, const int mutual, const double ratio) {
+    extern __shared__ uint4 s_dyn[];
+    __shared__ int s_wave[4];
+    __shared__ int s_run;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const int M = Mk, b = blockIdx.x, tid = threadIdx.x;
+    u32x4* dl = reinterpret_cast<u32x4*>(s_dyn);                                      // [M][2] left descriptor rows
+    int4* cxy = reinterpret_cast<int4*>(dl + 2 * M);                                  // [M] end-point cells of the left lines
+    double2* vdir = reinterpret_cast<double2*>(cxy + M);                              // [M] their unit directions (integer cell differences)
+    uint32_t* best = reinterpret_cast<uint32_t*>(vdir + M);                           // [M] min (d << 16 | j) over the eligible pairs
+    unsigned short* rows = reinterpret_cast<unsigned short*>(best + M);               // [48][M] cmin | cmax << 8 of right line j in grid row y
+    unsigned short* owner = rows + (size_t)STVO_GRID_ROWS * M;                        // [M] matches_21
+    short* mm = reinterpret_cast<short*>(owner + M);                                  // [M] the stereo match of left line i
+    unsigned char* blocked = reinterpret_cast<unsigned char*>(mm + M);                // [M] ratio test failed
+    uint32_t* cand = reinterpret_cast<uint32_t*>(blocked + M + ((4 - (M & 3)) & 3));  // [M / 32][M] bit k of word (w, j): left line 32 w + k has right line j as a candidate
+    const int nl = min(s.n_kl_l[b], M), nr = min(s.n_kl_r[b], M);
+    const size_t off = (size_t)b * s.M;
+    const double inv_w = s.inv_wh[2 * b], inv_h = s.inv_wh[2 * b + 1];
+    const int ws = s.mp.matching_s_ws;
+    const double sim_th = s.mp.line_sim_th;
+    if (tid == 0) s_run = 0;
+    for (int i = tid; i < nl; i += 256) {  // :318-322, include/matching.h:48-53
+        const float* kl = s.kl_l + (off + i) * 4;
+        int4 c;
+        c.x = (int)((double)kl[0] * inv_w);
+        c.y = (int)((double)kl[1] * inv_h);
+        c.z = (int)((double)kl[2] * inv_w);
+        c.w = (int)((double)kl[3] * inv_h);
+        cxy[i] = c;
+        const double vx = (double)(c.z - c.x), vy = (double)(c.w - c.y);
+        const double mag = sqrt(vx * vx + vy * vy);
+        vdir[i] = make_double2(vx / mag, vy / mag);  // 0 / 0 = NaN never skips a candidate (:207-222)
+        const u32x4* g = reinterpret_cast<const u32x4*>(s.ldesc_l + (off + i) * STVO_DESC_BYTES);
+        dl[2 * i] = g[0];
+        dl[2 * i + 1] = g[1];
+        best[i] = 0xFFFFFFFFu;
+        blocked[i] = 0;
+    }
+    for (int j = tid; j < nr; j += 256) {  // :325-338
+        for (int y = 0; y < STVO_GRID_ROWS; ++y) rows[y * M + j] = (unsigned short)LSF_ROW_EMPTY;
+        const float* kl = s.kl_r + (off + j) * 4;
+        // the cells come row by row (the minor coordinate of a Bresenham walk is monotone): the run of the current row stays in
+        // registers and is written once — no read-modify-write chain through LDS
+        int cy = -1, cmn = 255, cmx = 0;
+        auto flush = [&]() {
+            if (cy >= 0 && cy < STVO_GRID_ROWS && cmn <= cmx) rows[cy * M + j] = (unsigned short)(cmn | (cmx << 8));
+        };
+        bresenham((double)kl[0] * inv_w, (double)kl[1] * inv_h, (double)kl[2] * inv_w, (double)kl[3] * inv_h, [&](int x, int y) {
+            if (y != cy) {
+                flush();
+                cy = y;
+                cmn = 255;
+                cmx = 0;
+            }
+            if (x >= 0 && x < STVO_GRID_COLS) {
+                cmn = min(cmn, x);
+                cmx = max(cmx, x);
+            }
+        });
+        flush();
+    }
+    __syncthreads();
+    // GridStructure::get(x, y, {ws, 0, 0, 0}) seen from right line j: has it a cell in columns max(x - ws, 0) .. min(x, 63) of row y?
+    auto in_window = [&](int j, int x, int y) -> bool {
+        const bool row_ok = y >= 0 && y < STVO_GRID_ROWS;
+        const int lo = max(x - ws, 0), hi = min(x, STVO_GRID_COLS - 1);
+        const int v = rows[(row_ok ? y : 0) * M + j];
+        return row_ok && lo <= hi && (v & 0xFF) <= hi && (v >> 8) >= lo;
+    };
+    // candidate bit-matrix, all threads: word (w, j) = left lines 32 w .. 32 w + 31 that have right line j as a candidate.  The
+    // pairs are independent (the loads of one trip do not wait for the trip before), and the walks below then visit the few
+    // candidates of a right line instead of testing every left line in a chain of dependent LDS reads.
+    const int words = (nl + 31) >> 5;
+    for (int e = tid; e < words * M; e += 256) {
+        const int w = e / M, j = e - w * M;
+        uint32_t bits = 0u;
+        if (j < nr) {
+            const int i_end = min(32, nl - 32 * w);
+#pragma unroll 4
+            for (int k = 0; k < i_end; ++k) {
+                const int4 c = cxy[32 * w + k];
+                if (in_window(j, c.x, c.y) || in_window(j, c.z, c.w)) bits |= 1u << k;
+            }
+        }
+        cand[e] = bits;
+    }
+    __syncthreads();
+    // the walk of thread j over its candidates in ascending left index; f(i1, d) is called for every eligible pair
+    auto walk = [&](int j, const u32x4 t0, const u32x4 t1, const double dirx, const double diry, auto f) {
+        int run_min = 0x7FFFFFFF;
+        for (int w = 0; w < words; ++w) {
+            for (uint32_t bits = cand[w * M + j]; bits; bits &= bits - 1u) {
+                const int i1 = 32 * w + __builtin_ctz(bits);
+                const double2 v = vdir[i1];
+                const double dot = v.x * dirx + v.y * diry;
+                if (fabs(dot) < sim_th) continue;  // :221-222
+                const u32x4 q0 = dl[2 * i1], q1 = dl[2 * i1 + 1];
+                const int d = __builtin_popcount(q0.x ^ t0.x) + __builtin_popcount(q0.y ^ t0.y) + __builtin_popcount(q0.z ^ t0.z) +
+                              __builtin_popcount(q0.w ^ t0.w) + __builtin_popcount(q1.x ^ t1.x) + __builtin_popcount(q1.y ^ t1.y) +
+                              __builtin_popcount(q1.z ^ t1.z) + __builtin_popcount(q1.w ^ t1.w);
+                if (mutual) {  // :145-150 running strict minimum per right line
+                    if (d >= run_min) continue;
+                    run_min = d;
+                }
+                f(i1, d);
+            }
+        }
+    };
+    auto right_line = [&](int j, u32x4& t0, u32x4& t1, double& dirx, double& diry) {
+        const float* kl = s.kl_r + (off + j) * 4;
+        const double vx = (double)(kl[2] - kl[0]) * inv_w;  // float difference, then * double (:331)
+        const double vy = (double)(kl[3] - kl[1]) * inv_h;
+        const double mag = sqrt(vx * vx + vy * vy);
+        dirx = vx / mag;
+        diry = vy / mag;
+        const u32x4* g = reinterpret_cast<const u32x4*>(s.ldesc_r + (off + j) * STVO_DESC_BYTES);
+        t0 = g[0];
+        t1 = g[1];
+    };
+    for (int j = tid; j < nr; j += 256) {
+        u32x4 t0, t1;
+        double dirx, diry;
+        right_line(j, t0, t1, dirx, diry);
+        int own = 0xFFFF;
+        walk(j, t0, t1, dirx, diry, [&](int i1, int d) {
+            own = i1;
+            atomicMin(&best[i1], ((uint32_t)d << 16) | (uint32_t)j);
+        });
+        owner[j] = (unsigned short)own;
+    }
+    __syncthreads();
+    for (int j = tid; j < nr; j += 256) {  // :241 for every eligible pair that is not its left line's best
+        u32x4 t0, t1;
+        double dirx, diry;
+        right_line(j, t0, t1, dirx, diry);
+        walk(j, t0, t1, dirx, diry, [&](int i1, int d) {
+            const uint32_t bk = best[i1];
+            if (bk != (((uint32_t)d << 16) | (uint32_t)j)) {
+                const double best_d = (double)(int)(bk >> 16), d2 = (double)d;
+                if (!(best_d < d2 * ratio)) blocked[i1] = 1;
+            }
+        });
+    }
+    __syncthreads();
+    for (int i1 = tid; i1 < s.M; i1 += 256) {  // accept, mutual check (:247-255)
+        int m = -1;
+        if (i1 < nl) {
+            const uint32_t bk = best[i1];
+            if (bk != 0xFFFFFFFFu && !blocked[i1] && (double)(int)(bk >> 16) < 2147483647.0 * ratio) {
+                const int j = (int)(bk & 0xFFFFu);
+                if (!mutual || (int)owner[j] == i1) m = j;
+            }
+        }
+        if (i1 < M) mm[i1] = (short)m;
+        const_cast<int32_t*>(s.m12s_l)[off + i1] = m;
+    }
+    __syncthreads();
+    line_tail_frame(s, b, [&](int i) { return (int)mm[i]; }, s_wave, &s_run);
 }
 
 }  // namespace
@@ -534,10 +703,14 @@ struct stvo_seq {
     size_t tev_used = 0;
     bool zero_copy = false;    // small batches: kernels write results / counts straight into out_host
     std::vector<char> raw_lines;  // slot holds at least one left and one right key-line
+    std::vector<int> raw_max_lines;  // most key-lines of one image in the slot, as far as the host knows (device ingests: M)
+    int set_lines_cap[2] = {0, 0};   // the same bound for the stereo line sets (set[0], set[1])
     bool set_lines[2] = {false, false};  // stereo set was built from a frame with key-lines
     bool last_lines = false;             // the last step ran the line stage
     int last_slot = 0;                   // raw slot of the last step
     stvo::GridBatch last_point_grid{};   // arguments of the last point grid match (test hook)
+    stvo::GridBatch last_line_grid{};    // the general matcher's arguments for the key-lines of the last step (test hook)
+    bool last_line_fused = false;        // the last step ran line_stereo_fused_kernel: the hook rebuilds the grid arrays
     size_t off_kp_l, off_oct_l, off_desc_l, off_nkl, off_kp_r, off_desc_r, off_nkr, off_kl_l, off_oct_ll, off_ldesc_l,
         off_nll, off_kl_r, off_ldesc_r, off_nlr;
 };
@@ -710,6 +883,7 @@ int stvo_seq_create_multi(stvo_ctx* ctx, int B, int max_keypoints, int max_keyli
     char* D = s->dev;
     s->raw_dev = {D + o_raw, D + o_raw1};
     s->raw_lines.assign(2, 0);
+    s->raw_max_lines.assign(2, 0);
     s->d_cams = (stvo_cam*)(D + o_cams);
     s->d_inv_wh = (double*)(D + o_invwh);
     {
@@ -789,12 +963,14 @@ int stvo_seq_set_slots(stvo_seq* s, int n_slots) {
     }
     s->raw_dev.resize(2);
     s->raw_lines.resize(2);
+    s->raw_max_lines.resize(2);
     if (n_slots > 2) {
         HIP_TRY(ctx, hipMalloc((void**)&s->extra_raw, (size_t)(n_slots - 2) * s->raw_bytes));
         HIP_TRY(ctx, hipMemset(s->extra_raw, 0, (size_t)(n_slots - 2) * s->raw_bytes));
         for (int k = 2; k < n_slots; ++k) {
             s->raw_dev.push_back(s->extra_raw + (size_t)(k - 2) * s->raw_bytes);
             s->raw_lines.push_back(0);
+            s->raw_max_lines.push_back(0);
         }
     }
     return STVO_OK;
@@ -868,6 +1044,7 @@ int stvo_seq_upload(stvo_seq* s, int slot, const stvo_frame_features* f) {
     int32_t* nkr = (int32_t*)(H + s->off_nkr);
     int32_t* nll = (int32_t*)(H + s->off_nll);
     int32_t* nlr = (int32_t*)(H + s->off_nlr);
+    int max_lines = 0;
     for (int b = 0; b < B; ++b) {
         const int a = f->n_kp_l ? f->n_kp_l[b] : 0, r = f->n_kp_r ? f->n_kp_r[b] : 0;
         const int la = (f->n_kl_l && s->op.has_lines) ? f->n_kl_l[b] : 0, lr = (f->n_kl_r && s->op.has_lines) ? f->n_kl_r[b] : 0;
@@ -878,6 +1055,7 @@ int stvo_seq_upload(stvo_seq* s, int slot, const stvo_frame_features* f) {
         nkr[b] = s->op.has_points ? r : 0;
         nll[b] = la;
         nlr[b] = lr;
+        max_lines = std::max(max_lines, std::max(la, lr));
         const size_t so = (size_t)b * f->stride_kp, dof = (size_t)b * K;
         if (nkl[b]) {
             std::memcpy(H + s->off_kp_l + dof * 8, f->kp_l + so * 2, (size_t)a * 8);
@@ -902,6 +1080,7 @@ int stvo_seq_upload(stvo_seq* s, int slot, const stvo_frame_features* f) {
     bool any_lines = false;
     for (int b = 0; b < B; ++b) any_lines = any_lines || (nll[b] > 0 && nlr[b] > 0);
     s->raw_lines[slot] = any_lines;
+    s->raw_max_lines[slot] = max_lines;
     if (s->raw_bytes <= (size_t)4 << 20) {
         // copy kernel instead of the DMA engine: ~5 us less latency for the ~200 KB of one frame
         stvo::launch_copy16(ctx->stream, H, s->raw_dev[slot], s->raw_bytes);
@@ -933,6 +1112,7 @@ int stvo_seq_upload_dev(stvo_seq* s, int slot, const stvo_frame_features* f) {
     a.ldesc_l = (uint8_t*)(Rw + s->off_ldesc_l); a.n_kl_l = (int32_t*)(Rw + s->off_nll); a.kl_r = (float*)(Rw + s->off_kl_r);
     a.ldesc_r = (uint8_t*)(Rw + s->off_ldesc_r); a.n_kl_r = (int32_t*)(Rw + s->off_nlr);
     hipLaunchKernelGGL(seq_ingest_kernel, dim3(s->B), dim3(256), 0, ctx->stream, a);
+    s->raw_max_lines[slot] = s->M;
     s->raw_lines[slot] = lns;  // the line stage runs whenever line arrays were given (empty sets cost two small launches)
     return check_launch(ctx);
 }
@@ -1004,20 +1184,23 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl) {
         g.range1 = d.prange;
         g.cell2 = d.pcell;
         g.lstart = d.plstart; g.lperm = d.plperm;
+        // the one-workgroup matcher: lean cells kernel in front, the tail of the association as its last phase
         g.lean_cells = stvo::grid_points_fused_ok(g) ? 1 : 0;
+        g.has_tail = g.lean_cells;
+        if (const char* e = std::getenv("STVO_GRID_TAIL")) g.has_tail = g.has_tail && e[0] != '0';  // developer: 0 = point_tail_kernel as its own launch
+        if (g.has_tail) g.tail = stvo::point_tail_args(d);
         if (g.lean_cells)
             hipLaunchKernelGGL(stvo::point_cells_kernel<true>, dim3(B), dim3(256), 0, st, d);
         else
             hipLaunchKernelGGL(stvo::point_cells_kernel<false>, dim3(B), dim3(256), 0, st, d);
         s->last_point_grid = g;
         stvo::launch_grid_batch(st, g, false, tev ? tev + 2 : nullptr);
-        hipLaunchKernelGGL(stvo::point_tail_kernel, dim3(B), dim3(stvo::TAIL_BLOCK), 0, st, d);
+        if (!g.has_tail) hipLaunchKernelGGL(stvo::point_tail_kernel, dim3(B), dim3(stvo::TAIL_BLOCK), 0, st, d);
         mark(1, st);
     } else {
         HIP_TRY(ctx, hipMemsetAsync(cs.n, 0, (size_t)B * 4, st));
     }
     if (lines_now) {
-        hipLaunchKernelGGL(stvo::line_cells_kernel, dim3(B), dim3(256), 0, sl, d);
         stvo::GridBatch g;
         std::memset(&g, 0, sizeof(g));
         g.B = B; g.stride1 = M; g.stride2 = M; g.xy_width = 4; g.items_stride = M * stvo::LENT; g.words64 = M / 64; g.n1p = M;
@@ -1028,8 +1211,21 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl) {
         g.mutual = s->mp.best_lr_matches;
         g.cover = s->cover_l; g.rank = d.lrank; g.perm = d.lperm; g.top2 = s->top2_l; g.owner2 = s->owner2_l; g.m12 = s->m12s_l;
         if (g.mutual) { g.elig = s->elig_l; g.elig_cnt = s->elig_cnt_l; g.ovf = s->govf_l; }
-        stvo::launch_grid_batch(sl, g, true);
-        hipLaunchKernelGGL(stvo::line_tail_kernel, dim3(B), dim3(256), 0, sl, d);
+        s->last_line_grid = g;
+        // few key-lines per frame: the whole association in one workgroup per frame (STVO_LINE_FUSED=0: the general grid matcher)
+        const int Mk = std::min(M, std::max(64, (s->raw_max_lines[slot] + 63) & ~63));  // LDS for the lines the slot holds, not for the capacity
+        s->set_lines_cap[s->cur] = Mk;
+        const size_t lds = (size_t)Mk * stvo::LSF_BYTES_PER_LINE + 4 + (size_t)Mk * (Mk / 32) * 4;
+        const char* ef = std::getenv("STVO_LINE_FUSED");
+        s->last_line_fused = M <= stvo::LSF_MAX_LINES && !(ef && ef[0] == '0') &&
+                             (lds <= (48u << 10) || stvo::lds_opt_in(reinterpret_cast<const void*>(stvo::line_stereo_fused_kernel), (int)lds));
+        if (s->last_line_fused) {
+            hipLaunchKernelGGL(stvo::line_stereo_fused_kernel, dim3(B), dim3(256), lds, sl, d, Mk, (int)s->mp.best_lr_matches, s->ratio_grid);
+        } else {
+            hipLaunchKernelGGL(stvo::line_cells_kernel, dim3(B), dim3(256), 0, sl, d);
+            stvo::launch_grid_batch(sl, g, true);
+            hipLaunchKernelGGL(stvo::line_tail_kernel, dim3(B), dim3(256), 0, sl, d);
+        }
     } else if (!d.zero_nl) {
         HIP_TRY(ctx, hipMemsetAsync(cs.nl, 0, (size_t)B * 4, st));
     }
@@ -1038,9 +1234,14 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl) {
     if (track) {
         // ---- f2fTracking: prev stereo sets vs curr stereo sets
         const stvo::LazyScratch w{ctx->knn12, ctx->knn21, ctx->cand, ctx->need, ctx->qsel, ctx->nsel, ctx->knn_capacity};
+        const char* esm = std::getenv("STVO_MATCH_SMALL");  // developer: 0 = the general machinery for the key-line sets too
+        const bool small_sets = !(esm && esm[0] == '0');
+        int small_cap = 0;  // rows per set the small-set kernel sizes its LDS for (0: the stride)
         auto match_set = [&](hipStream_t q, const stvo::LazyScratch& ws, int stride, const uint8_t* da, const int32_t* na,
                              const uint8_t* db, const int32_t* nb, float nnr, int32_t* m12, hipEvent_t* mev) {
-            if (s->mp.best_lr_matches) {
+            if (stvo::match_small_ok(stride) && small_sets && !mev) {  // (mev: the stage timers want the general launches)
+                stvo::launch_match_small(q, B, stride, da, na, db, nb, nnr, s->mp.best_lr_matches, m12, small_cap);
+            } else if (s->mp.best_lr_matches) {
                 stvo::launch_match_mutual_lazy(q, B, stride, da, na, db, nb, nnr, ws, m12, 0, nullptr, mev);
             } else {
                 const int nseg = stvo::knn_pick_nseg(B, stride, ws.knn_capacity);
@@ -1049,6 +1250,7 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl) {
             }
         };
         if (s->op.has_points) match_set(st, w, K, ps.desc, ps.n, cs.desc, cs.n, s->mp.min_ratio_12_p, s->m12p, tev ? tev + 4 : nullptr);
+        small_cap = std::max(s->set_lines_cap[0], s->set_lines_cap[1]);
         if (lines_prev && lines_now)
             match_set(sl, s->lazy_l, M, ps.ldesc, ps.nl, cs.ldesc, cs.nl, s->mp.min_ratio_12_l, s->m12l, nullptr);
         else if (lines_prev)  // nothing to match against: every prev line is unmatched
@@ -1277,6 +1479,13 @@ int stvo_seq_debug_grid(stvo_seq* s, int b, int lines, int32_t* cell_start, int3
         stvo::SeqDev full = d;
         bind_raw(s, full, s->last_slot);
         hipLaunchKernelGGL(stvo::point_cells_kernel<false>, dim3(s->B), dim3(256), 0, ctx->stream, full);
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    if (lines && s->last_line_fused) {  // the step ran the fused line kernel: the general matcher's kernels produce the grid arrays
+        stvo::SeqDev full = d;
+        bind_raw(s, full, s->last_slot);
+        hipLaunchKernelGGL(stvo::line_cells_kernel, dim3(s->B), dim3(256), 0, ctx->stream, full);
+        stvo::launch_grid_batch(ctx->stream, s->last_line_grid, true);
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
     const int R = lines ? s->M : s->K, xyw = lines ? 4 : 2;

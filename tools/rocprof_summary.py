@@ -7,6 +7,9 @@
                                                                     total / average / min / max (us): a kernel that is launched on
                                                                     problems of different sizes (K1m: key-points and key-lines) gets
                                                                     one line per shape, so the dominant launch can be read off alone
+    python tools/rocprof_summary.py timeline <trace.db> [N]      -> the last N dispatches in start order: start (us, relative), duration,
+                                                                    queue, launch shape, kernel — which launches overlap on the two
+                                                                    streams of a step, and which one the next stage waits for
 """
 import sqlite3
 import sys
@@ -69,9 +72,31 @@ def split(db, pattern=None):
         print(f"{n:6d} {g:10d} {w:5d} {tot:12.1f} {avg:10.2f} {lo:10.2f} {hi:10.2f}  {k[:100]}")
 
 
+def timeline(db, n=60):
+    con = sqlite3.connect(db)
+    view = _table_like(con, "kernels")
+    cols = [r[1] for r in con.execute(f"pragma table_info('{view}')")]
+
+    def pick(*cands):
+        for c in cands:
+            if c in cols:
+                return c
+        return None
+    name, start, end = pick("name", "kernel_name"), pick("start", "start_timestamp"), pick("end", "end_timestamp")
+    gx, wx = pick("grid_size_x", "grid_x", "grid_size"), pick("workgroup_size_x", "workgroup_x", "workgroup_size")
+    queue = pick("queue_id", "queue", "stream_id", "stream") or "0"
+    rows = con.execute(f"select {start}, {end}, {queue}, {gx}, {wx}, {name} from {view} order by {start} desc limit {int(n)}").fetchall()[::-1]
+    t0 = rows[0][0]
+    print(f"{'start_us':>10} {'end_us':>10} {'dur_us':>9} {'queue':>6} {'grid_x':>9} {'wg':>5}  kernel")
+    for st, en, q, g, w, k in rows:
+        print(f"{(st - t0) / 1e3:10.1f} {(en - t0) / 1e3:10.1f} {(en - st) / 1e3:9.1f} {str(q):>6} {g:9d} {w:5d}  {k[:90]}")
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2])
+    elif sys.argv[1] == "timeline":
+        timeline(sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else 60)
     elif sys.argv[1] == "split":
         split(sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else None)
     else:
