@@ -373,15 +373,15 @@ __global__ __launch_bounds__(256) void line_cells_kernel(SeqDev s) {
 }
 
 // ---- 6: lines — geometry filters, back-projection, ordered compaction --------------------------------
-// the tail of frame b by a workgroup of 256 threads; match_of(i) = stereo match of left line i (the caller has put a barrier
+// the tail of frame b by a workgroup of T threads; match_of(i) = stereo match of left line i (the caller has put a barrier
 // after s_run = 0 and after whatever match_of reads)
-template <typename MatchOf>
+template <int T, typename MatchOf>
 __device__ __forceinline__ void line_tail_frame(const SeqDev& s, const int b, MatchOf match_of, int* s_wave, int* s_run) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nl = s.n_kl_l[b];
     const size_t off = (size_t)b * s.M;
     const stvo_cam cam = s.cams[b];
-    for (int base = 0; base < nl; base += 256) {
+    for (int base = 0; base < nl; base += T) {
         const int i = base + tid;
         bool ok = false;
         double sp_l[2] = {0, 0}, ep_l[2] = {0, 0}, le_l[3] = {0, 0, 0}, disp_s = 0.0, disp_e = 0.0;
@@ -442,7 +442,8 @@ __device__ __forceinline__ void line_tail_frame(const SeqDev& s, const int b, Ma
             dst[1] = src[1];
         }
         __syncthreads();
-        if (tid == 0) (*s_run) += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        if (tid == 0)
+            for (int w = 0; w < T / 64; ++w) (*s_run) += s_wave[w];
         __syncthreads();
     }
     if (tid == 0) {
@@ -458,7 +459,7 @@ __global__ __launch_bounds__(256) void line_tail_kernel(SeqDev s) {
     const size_t off = (size_t)b * s.M;
     if (threadIdx.x == 0) s_run = 0;
     __syncthreads();
-    line_tail_frame(s, b, [&](int i) { return s.m12s_l[off + i]; }, s_wave, &s_run);
+    line_tail_frame<256>(s, b, [&](int i) { return s.m12s_l[off + i]; }, s_wave, &s_run);
 }
 
 // ---- 4 + 5 + 6 in one workgroup per frame: the whole stereo association of the key-lines --------------------------------------
@@ -476,7 +477,9 @@ __global__ __launch_bounds__(256) void line_tail_kernel(SeqDev s) {
 constexpr int LSF_ROW_EMPTY = 0x00FF;  // cmin = 255 > cmax = 0
 constexpr int LSF_MAX_LINES = 512, LSF_BYTES_PER_LINE = 32 + 16 + 16 + 4 + 2 * STVO_GRID_ROWS + 2 + 2 + 1;
 // Mk (<= s.M): lines per image the LDS arrays are sized for — the host knows that no image of the batch holds more.
-__global__ __launch_bounds__(256) void line_stereo_fused_kernel(SeqDev s, const int Mk, const int mutual, const double ratio) {
+// T: threads per frame (256; a single wave per frame was tried to hold fewer wave slots, and was slower).
+template <int T>
+__global__ __launch_bounds__(T) void line_stereo_fused_kernel(SeqDev s, const int Mk, const int mutual, const double ratio) {
     extern __shared__ uint4 s_dyn[];
     __shared__ int s_wave[4];
     __shared__ int s_run;
@@ -497,7 +500,7 @@ __global__ __launch_bounds__(256) void line_stereo_fused_kernel(SeqDev s, const 
     const int ws = s.mp.matching_s_ws;
     const double sim_th = s.mp.line_sim_th;
     if (tid == 0) s_run = 0;
-    for (int i = tid; i < nl; i += 256) {  // :318-322, include/matching.h:48-53
+    for (int i = tid; i < nl; i += T) {  // :318-322, include/matching.h:48-53
         const float* kl = s.kl_l + (off + i) * 4;
         int4 c;
         c.x = (int)((double)kl[0] * inv_w);
@@ -514,7 +517,7 @@ __global__ __launch_bounds__(256) void line_stereo_fused_kernel(SeqDev s, const 
         best[i] = 0xFFFFFFFFu;
         blocked[i] = 0;
     }
-    for (int j = tid; j < nr; j += 256) {  // :325-338
+    for (int j = tid; j < nr; j += T) {  // :325-338
         for (int y = 0; y < STVO_GRID_ROWS; ++y) rows[y * M + j] = (unsigned short)LSF_ROW_EMPTY;
         const float* kl = s.kl_r + (off + j) * 4;
         // the cells come row by row (the minor coordinate of a Bresenham walk is monotone): the run of the current row stays in
@@ -549,7 +552,7 @@ __global__ __launch_bounds__(256) void line_stereo_fused_kernel(SeqDev s, const 
     // pairs are independent (the loads of one trip do not wait for the trip before), and the walks below then visit the few
     // candidates of a right line instead of testing every left line in a chain of dependent LDS reads.
     const int words = (nl + 31) >> 5;
-    for (int e = tid; e < words * M; e += 256) {
+    for (int e = tid; e < words * M; e += T) {
         const int w = e / M, j = e - w * M;
         uint32_t bits = 0u;
         if (j < nr) {
@@ -595,7 +598,7 @@ __global__ __launch_bounds__(256) void line_stereo_fused_kernel(SeqDev s, const 
         t0 = g[0];
         t1 = g[1];
     };
-    for (int j = tid; j < nr; j += 256) {
+    for (int j = tid; j < nr; j += T) {
         u32x4 t0, t1;
         double dirx, diry;
         right_line(j, t0, t1, dirx, diry);
@@ -607,7 +610,7 @@ __global__ __launch_bounds__(256) void line_stereo_fused_kernel(SeqDev s, const 
         owner[j] = (unsigned short)own;
     }
     __syncthreads();
-    for (int j = tid; j < nr; j += 256) {  // :241 for every eligible pair that is not its left line's best
+    for (int j = tid; j < nr; j += T) {  // :241 for every eligible pair that is not its left line's best
         u32x4 t0, t1;
         double dirx, diry;
         right_line(j, t0, t1, dirx, diry);
@@ -620,7 +623,7 @@ __global__ __launch_bounds__(256) void line_stereo_fused_kernel(SeqDev s, const 
         });
     }
     __syncthreads();
-    for (int i1 = tid; i1 < s.M; i1 += 256) {  // accept, mutual check (:247-255)
+    for (int i1 = tid; i1 < s.M; i1 += T) {  // accept, mutual check (:247-255)
         int m = -1;
         if (i1 < nl) {
             const uint32_t bk = best[i1];
@@ -633,7 +636,7 @@ __global__ __launch_bounds__(256) void line_stereo_fused_kernel(SeqDev s, const 
         const_cast<int32_t*>(s.m12s_l)[off + i1] = m;
     }
     __syncthreads();
-    line_tail_frame(s, b, [&](int i) { return (int)mm[i]; }, s_wave, &s_run);
+    line_tail_frame<T>(s, b, [&](int i) { return (int)mm[i]; }, s_wave, &s_run);
 }
 
 }  // namespace
@@ -1162,7 +1165,14 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl) {
     // fork: everything enqueued so far (ingest, the previous step) happens-before the line stream's work
     const bool par = lines_now && s->op.has_points;
     hipStream_t sl = par ? s->line_stream : st;
-    if (par) {
+    // Where the line stream forks off.  Every big kernel of the point stream fills the register file of the CUs it runs on (the
+    // one-workgroup point matcher even holds every CU for its whole life), so work of the line stream never runs BESIDE it, only
+    // instead of it: forked at the start of the step, the line workgroups took CUs from the persistent point matcher, whose
+    // workgroups then started late (0.158 -> 0.198 ms).  Forked after the point stage, the line kernels share the GPU with the
+    // key-point scan, whose many short workgroups interleave with them at dispatch granularity.  STVO_LINE_FORK=early: the old order.
+    const char* efk = std::getenv("STVO_LINE_FORK");
+    const bool late_fork = par && !(efk && efk[0] == 'e');
+    if (par && !late_fork) {
         HIP_TRY(ctx, hipEventRecord(s->ev_fork, st));
         HIP_TRY(ctx, hipStreamWaitEvent(sl, s->ev_fork, 0));
     }
@@ -1200,6 +1210,10 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl) {
     } else {
         HIP_TRY(ctx, hipMemsetAsync(cs.n, 0, (size_t)B * 4, st));
     }
+    if (late_fork) {
+        HIP_TRY(ctx, hipEventRecord(s->ev_fork, st));
+        HIP_TRY(ctx, hipStreamWaitEvent(sl, s->ev_fork, 0));
+    }
     if (lines_now) {
         stvo::GridBatch g;
         std::memset(&g, 0, sizeof(g));
@@ -1218,9 +1232,10 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl) {
         const size_t lds = (size_t)Mk * stvo::LSF_BYTES_PER_LINE + 4 + (size_t)Mk * (Mk / 32) * 4;
         const char* ef = std::getenv("STVO_LINE_FUSED");
         s->last_line_fused = M <= stvo::LSF_MAX_LINES && !(ef && ef[0] == '0') &&
-                             (lds <= (48u << 10) || stvo::lds_opt_in(reinterpret_cast<const void*>(stvo::line_stereo_fused_kernel), (int)lds));
+                             (lds <= (48u << 10) || stvo::lds_opt_in(reinterpret_cast<const void*>(stvo::line_stereo_fused_kernel<256>), (int)lds));
         if (s->last_line_fused) {
-            hipLaunchKernelGGL(stvo::line_stereo_fused_kernel, dim3(B), dim3(256), lds, sl, d, Mk, (int)s->mp.best_lr_matches, s->ratio_grid);
+            // (one wave per frame, <64>: 185 instead of 150 us beside the key-point scan, which it stretched by 15 us more)
+            hipLaunchKernelGGL(stvo::line_stereo_fused_kernel<256>, dim3(B), dim3(256), lds, sl, d, Mk, (int)s->mp.best_lr_matches, s->ratio_grid);
         } else {
             hipLaunchKernelGGL(stvo::line_cells_kernel, dim3(B), dim3(256), 0, sl, d);
             stvo::launch_grid_batch(sl, g, true);
