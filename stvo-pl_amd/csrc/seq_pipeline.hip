@@ -1169,9 +1169,12 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl) {
     // one-workgroup point matcher even holds every CU for its whole life), so work of the line stream never runs BESIDE it, only
     // instead of it: forked at the start of the step, the line workgroups took CUs from the persistent point matcher, whose
     // workgroups then started late (0.158 -> 0.198 ms).  Forked after the point stage, the line kernels share the GPU with the
-    // key-point scan, whose many short workgroups interleave with them at dispatch granularity.  STVO_LINE_FORK=early: the old order.
+    // key-point scan, whose many short workgroups interleave with them at dispatch granularity.
+    // Only for batches that keep the point matcher's workgroups busy for several frames each (more than two per CU): measured
+    // 1024 KITTI-shaped streams 929 k (early) vs 935 k (late) frame pairs/s, 512 EuRoC-shaped streams 857 k vs 777 k, one
+    // stream 0.252 vs 0.280 ms per frame.  STVO_LINE_FORK=early / late overrides.
     const char* efk = std::getenv("STVO_LINE_FORK");
-    const bool late_fork = par && !(efk && efk[0] == 'e');
+    const bool late_fork = par && (efk ? efk[0] == 'l' : B > 2 * stvo::device_cu_count());
     if (par && !late_fork) {
         HIP_TRY(ctx, hipEventRecord(s->ev_fork, st));
         HIP_TRY(ctx, hipStreamWaitEvent(sl, s->ev_fork, 0));
@@ -1231,7 +1234,9 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl) {
         s->set_lines_cap[s->cur] = Mk;
         const size_t lds = (size_t)Mk * stvo::LSF_BYTES_PER_LINE + 4 + (size_t)Mk * (Mk / 32) * 4;
         const char* ef = std::getenv("STVO_LINE_FUSED");
-        s->last_line_fused = M <= stvo::LSF_MAX_LINES && !(ef && ef[0] == '0') &&
+        // (a single stream with hundreds of key-lines is better off with the general matcher's many small workgroups: EuRoC-shaped,
+        // 300 key-lines, one stream 0.310 vs 0.360 ms per frame; 102 key-lines 0.257 vs 0.252)
+        s->last_line_fused = M <= stvo::LSF_MAX_LINES && (ef ? ef[0] != '0' : (B >= 16 || Mk <= 128)) &&
                              (lds <= (48u << 10) || stvo::lds_opt_in(reinterpret_cast<const void*>(stvo::line_stereo_fused_kernel<256>), (int)lds));
         if (s->last_line_fused) {
             // (one wave per frame, <64>: 185 instead of 150 us beside the key-point scan, which it stretched by 15 us more)
@@ -1250,7 +1255,8 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl) {
         // ---- f2fTracking: prev stereo sets vs curr stereo sets
         const stvo::LazyScratch w{ctx->knn12, ctx->knn21, ctx->cand, ctx->need, ctx->qsel, ctx->nsel, ctx->knn_capacity};
         const char* esm = std::getenv("STVO_MATCH_SMALL");  // developer: 0 = the general machinery for the key-line sets too
-        const bool small_sets = !(esm && esm[0] == '0');
+        const int lines_cap = std::max(s->set_lines_cap[0], s->set_lines_cap[1]);
+        const bool small_sets = esm ? esm[0] != '0' : (B >= 16 || lines_cap <= 128);  // (as for the fused line kernel above)
         int small_cap = 0;  // rows per set the small-set kernel sizes its LDS for (0: the stride)
         auto match_set = [&](hipStream_t q, const stvo::LazyScratch& ws, int stride, const uint8_t* da, const int32_t* na,
                              const uint8_t* db, const int32_t* nb, float nnr, int32_t* m12, hipEvent_t* mev) {
@@ -1265,7 +1271,7 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl) {
             }
         };
         if (s->op.has_points) match_set(st, w, K, ps.desc, ps.n, cs.desc, cs.n, s->mp.min_ratio_12_p, s->m12p, tev ? tev + 4 : nullptr);
-        small_cap = std::max(s->set_lines_cap[0], s->set_lines_cap[1]);
+        small_cap = lines_cap;
         if (lines_prev && lines_now)
             match_set(sl, s->lazy_l, M, ps.ldesc, ps.nl, cs.ldesc, cs.nl, s->mp.min_ratio_12_l, s->m12l, nullptr);
         else if (lines_prev)  // nothing to match against: every prev line is unmatched
