@@ -1165,16 +1165,14 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl) {
     // fork: everything enqueued so far (ingest, the previous step) happens-before the line stream's work
     const bool par = lines_now && s->op.has_points;
     hipStream_t sl = par ? s->line_stream : st;
-    // Where the line stream forks off.  Every big kernel of the point stream fills the register file of the CUs it runs on (the
-    // one-workgroup point matcher even holds every CU for its whole life), so work of the line stream never runs BESIDE it, only
-    // instead of it: forked at the start of the step, the line workgroups took CUs from the persistent point matcher, whose
-    // workgroups then started late (0.158 -> 0.198 ms).  Forked after the point stage, the line kernels share the GPU with the
-    // key-point scan, whose many short workgroups interleave with them at dispatch granularity.
-    // Only for batches that keep the point matcher's workgroups busy for several frames each (more than two per CU): measured
-    // 1024 KITTI-shaped streams 929 k (early) vs 935 k (late) frame pairs/s, 512 EuRoC-shaped streams 857 k vs 777 k, one
-    // stream 0.252 vs 0.280 ms per frame.  STVO_LINE_FORK=early / late overrides.
+    // Where the line stream forks off.  Every big kernel of the point stream fills the register file of the CUs it runs on, so work
+    // of the line stream never runs BESIDE it, only instead of it.  Forked at the start of the step (default) the line kernels share
+    // the GPU with point_cells_kernel and delay the start of some of the persistent point matcher's workgroups (0.158 -> 0.198 ms
+    // per 1024 frames) but leave the key-point scan alone (0.467 ms); forked after the point stage (STVO_LINE_FORK=late) they
+    // stretch the scan instead (0.510 ms).  Measured: 1024 KITTI-shaped streams 929 k (early) vs 935 k (late) frame pairs/s, 512
+    // EuRoC-shaped streams 857 k vs 777 k, one stream 0.252 vs 0.280 ms per frame.
     const char* efk = std::getenv("STVO_LINE_FORK");
-    const bool late_fork = par && (efk ? efk[0] == 'l' : B > 2 * stvo::device_cu_count());
+    const bool late_fork = par && efk && efk[0] == 'l';
     if (par && !late_fork) {
         HIP_TRY(ctx, hipEventRecord(s->ev_fork, st));
         HIP_TRY(ctx, hipStreamWaitEvent(sl, s->ev_fork, 0));
@@ -1257,11 +1255,19 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl) {
         const char* esm = std::getenv("STVO_MATCH_SMALL");  // developer: 0 = the general machinery for the key-line sets too
         const int lines_cap = std::max(s->set_lines_cap[0], s->set_lines_cap[1]);
         const bool small_sets = esm ? esm[0] != '0' : (B >= 16 || lines_cap <= 128);  // (as for the fused line kernel above)
+        const char* elz = std::getenv("STVO_MATCH_LAZY");  // developer: 1 = the lazy formulation for small batches too
         int small_cap = 0;  // rows per set the small-set kernel sizes its LDS for (0: the stride)
         auto match_set = [&](hipStream_t q, const stvo::LazyScratch& ws, int stride, const uint8_t* da, const int32_t* na,
                              const uint8_t* db, const int32_t* nb, float nnr, int32_t* m12, hipEvent_t* mev) {
             if (stvo::match_small_ok(stride) && small_sets && !mev) {  // (mev: the stage timers want the general launches)
                 stvo::launch_match_small(q, B, stride, da, na, db, nb, nnr, s->mp.best_lr_matches, m12, small_cap);
+            } else if (s->mp.best_lr_matches && B <= 4 && !mev && !(elz && elz[0] == '1')) {
+                // a few frame pairs leave most of the GPU idle: the reverse direction as a full scan in the SAME launch and one
+                // ratio / mutual kernel, instead of the plan + two selective reverse scans + final check of the lazy formulation
+                // (five dependent launches: 42 -> ~18 us of a single stream's 230 us)
+                const int nseg = stvo::knn_pick_nseg(B, stride, ws.knn_capacity);
+                stvo::launch_hamming_knn2(q, B, stride, stride, da, na, db, nb, ws.knn12, ws.knn21, 1, 0, 0, nullptr, nullptr, nseg);
+                stvo::launch_nnr_mutual(q, B, stride, ws.knn12, ws.knn21, na, nb, nnr, 1, m12, nseg);
             } else if (s->mp.best_lr_matches) {
                 stvo::launch_match_mutual_lazy(q, B, stride, da, na, db, nb, nnr, ws, m12, 0, nullptr, mev);
             } else {
