@@ -738,14 +738,19 @@ def main():
         scan_ms = stage_ms["grid_scan"]
         n_kp_step = float(n_kp.mean(axis=1).sum())   # left + right key-points of one step, all streams
         scan_bytes = 32.0 * n_kp_step + 12.0 * n_kp_step / 2 + 4.0 * (3073.0 * B + n_kp_step / 2)
+        fused_tail = os.environ.get("STVO_GRID_FUSED", "1") != "0" and os.environ.get("STVO_GRID_TAIL", "1") != "0"
+        if fused_tail:  # the matcher launch also runs the tail of the association: key-point coordinates and octaves in, stereo set out
+            scan_bytes += 8.0 * n_kp_step + 4.0 * n_kp_step / 2 + (16.0 + 24.0 + 8.0 + 32.0) * n2_l
         scan_gbs = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
         fused = os.environ.get("STVO_GRID_FUSED", "1") != "0"
         scan_name = "grid_points_fused_kernel" if fused else "grid_scan_kernel<false"
         roofline_grid = {"kernel": scan_name if fused else "grid_scan_kernel<false, 1> + <false, 2>", "bound": "hbm", "achieved": scan_gbs, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": scan_gbs / HBM_PEAK_GBS, "traffic": committed_traffic(scan_name), "traffic_source": TRAFFIC_SRC,
                          "algorithmic_bytes_per_launch": scan_bytes, "avg_launch_ms": scan_ms, "timing": timing,
-                         "note": "matchGrid (points), all frames in one launch: 32 (N1 + N2) + 8 N1 + 4 (3073 + N2) + 4 N1 bytes per frame; "
-                                 "~16 k candidate pairs per frame — bound by LDS gathers and the issue of the per-thread sort / chain code "
+                         "note": "matchGrid (points), all frames in one launch: 32 (N1 + N2) + 8 N1 + 4 (3073 + N2) + 4 N1 bytes per frame"
+                                 + (", and as its last phase the tail of the stereo association (filters, back-projection, ordered compaction: "
+                                    "8 (N1 + N2) + 4 N1 bytes in, 80 bytes per stereo point out)" if fused_tail else "") +
+                                 "; ~16 k candidate pairs per frame — bound by LDS gathers and the issue of the per-thread sort / chain code "
                                  "at 4 waves per SIMD (one workgroup per CU), not by HBM"}
         resident_mb = S * B * (2 * 2048 * (8 + 32) + 2048 * 4 + 2 * 512 * (16 + 32) + 512 * 4) / 1e6
         out = {
@@ -767,8 +772,10 @@ def main():
                        "parallelism": f"seq-shard x{world}", "committed_pose_fraction": ok_frac},
             "roofline": roofline, "roofline_pose": roofline_pose, "roofline_grid_scan": roofline_grid,
             "stage_ms": dict(stage_ms, steps_timed=n_timed,
-                             note="stereo_points_stage = cells + grid matcher + tail of the key-points (contains grid_scan = the matcher launch); "
-                                  "the key-line stage runs concurrently on a second stream and is not on the critical path"),
+                             note="stereo_points_stage = cells + grid matcher (with the tail of the association as its last phase) of the "
+                                  "key-points (contains grid_scan = the matcher launch); the key-line stage (line_stereo_fused_kernel, "
+                                  "match_small_kernel) runs on a second stream forked at the start of the step: it shares the GPU with this "
+                                  "stage and delays the start of the persistent matcher's workgroups (0.16 ms alone)"),
         }
     pipe.close()
     ctx.close()
