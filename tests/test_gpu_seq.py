@@ -184,6 +184,33 @@ def test_seq_point_grid_other_formulations(oracle, monkeypatch, env):
     run_and_compare(oracle, seqs, cam, "kitti")
 
 
+@pytest.mark.parametrize("env", [
+    {"STVO_LINE_FUSED": "1", "STVO_MATCH_SMALL": "1"},    # one workgroup per frame for 200 key-lines (LDS sized for 256, opt-in above 48 KB at 320)
+    {"STVO_LINE_FUSED": "0", "STVO_MATCH_SMALL": "0"},    # the general grid matcher and match machinery for the key-lines
+    {"STVO_LINE_FUSED": "1", "STVO_LINE_FORK": "late"},   # line stream forked after the point stage
+    {"STVO_GRID_TAIL": "0"},                              # point_tail_kernel as its own launch behind the lean cells kernel
+    {"STVO_MATCH_LAZY": "1"},                             # lazy reverse check for a tiny batch (default there: both directions in one scan)
+], ids=["lines-fused", "lines-general", "late-fork", "tail-kernel", "lazy-reverse"])
+def test_seq_step_variants_line_heavy(oracle, monkeypatch, env):
+    """Every launch plan the step can choose (by batch size / line count, or by a developer switch) gives the oracle's results:
+    EuRoC-shaped frames with ~240 key-lines per image, two streams."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    cam = synth.EUROC_CAM
+    seqs = [synth.make_stereo_sequence(740 + b, n_frames=4, n_pts=500, n_lines=200, cam=cam, depth=(1.0, 8.0),
+                                       octave_probs=[.5, .25, .15, .1], outlier_frac=0.2) for b in range(2)]
+    run_and_compare(oracle, seqs, cam, "euroc", max_kl=512 if env.get("STVO_LINE_FORK") else 320)
+
+
+def test_seq_batch_line_heavy_default_plan(oracle):
+    """16 streams (the size from which the fused line kernel and the small-set match are the default for any line count) with
+    150-260 key-lines per image and a stream without any."""
+    cam = synth.EUROC_CAM
+    seqs = [synth.make_stereo_sequence(7600 + b, n_frames=3, n_pts=260 + 10 * b, n_lines=0 if b == 5 else 130 + 6 * b, cam=cam, depth=(1.0, 8.0),
+                                       octave_probs=[.5, .25, .15, .1], outlier_frac=0.2) for b in range(16)]
+    run_and_compare(oracle, seqs, cam, "euroc")
+
+
 def crowd(fr, rng, frac, box):
     """Moves a fraction of the key-points of both images into a small box (left / right keep their disparity): many candidates
     per window, long eligibility chains, near-duplicate descriptors."""
