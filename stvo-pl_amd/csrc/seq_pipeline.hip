@@ -104,8 +104,15 @@ __device__ __forceinline__ bool in_grid(int x, int y) {
 }
 
 // exclusive scan of hist[0..256 * PER) in LDS by 256 threads (PER cells each); writes start[0..256 * PER]
-template <int PER>
-__device__ __forceinline__ void scan_cells_n(int* hist, int* s_wave, int32_t* start_out) {
+// 16-bit LDS counters (a frame holds at most 2048 features of a kind): half the LDS of the cells kernels, so that workgroups of the
+// line stage fit beside them.  LDS has 16-bit loads and stores but only 32-bit atomics: increment the half of the containing word.
+__device__ __forceinline__ int lds_inc16(unsigned short* a, int c) {
+    const unsigned old = atomicAdd(reinterpret_cast<unsigned*>(a) + (c >> 1), 1u << (16 * (c & 1)));
+    return (int)((old >> (16 * (c & 1))) & 0xFFFFu);
+}
+
+template <int PER, typename T>
+__device__ __forceinline__ void scan_cells_n(T* hist, int* s_wave, int32_t* start_out) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int local[PER];
     int sum = 0;
@@ -129,14 +136,15 @@ __device__ __forceinline__ void scan_cells_n(int* hist, int* s_wave, int32_t* st
     int run = base + incl - sum;
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
-        hist[tid * PER + k] = run;  // hist becomes the exclusive start
+        hist[tid * PER + k] = (T)run;  // hist becomes the exclusive start
         start_out[tid * PER + k] = run;
         run += local[k];
     }
     if (tid == 255) start_out[256 * PER] = run;
     __syncthreads();
 }
-__device__ __forceinline__ void scan_cells(int* hist, int* s_wave, int32_t* start_out) {
+template <typename T>
+__device__ __forceinline__ void scan_cells(T* hist, int* s_wave, int32_t* start_out) {
     scan_cells_n<STVO_GRID_CELLS / 256>(hist, s_wave, start_out);
 }
 
@@ -147,9 +155,9 @@ __device__ __forceinline__ void scan_cells(int* hist, int* s_wave, int32_t* star
 // of the scan formulation only; the matcher rebuilds them for the rare frame it hands to it (fused_misfit_frame).
 template <bool LEAN>
 __global__ __launch_bounds__(256) void point_cells_kernel(SeqDev s) {
-    __shared__ int hist[STVO_GRID_CELLS];
-    __shared__ int fill[STVO_GRID_CELLS];
-    __shared__ int lhist[GRID_LCELLS];
+    __shared__ __attribute__((aligned(4))) unsigned short hist[STVO_GRID_CELLS];
+    __shared__ __attribute__((aligned(4))) unsigned short fill[STVO_GRID_CELLS];
+    __shared__ __attribute__((aligned(4))) unsigned short lhist[GRID_LCELLS];
     __shared__ int s_wave[4];
     __shared__ int s_extra;
     static_assert(GRID_LCELLS % 256 == 0, "scan_cells_n");
@@ -178,7 +186,7 @@ __global__ __launch_bounds__(256) void point_cells_kernel(SeqDev s) {
     for (int i = tid; i < nr; i += 256) {
         const int x = (int)((double)s.kp_r[(off + i) * 2 + 0] * inv_w);
         const int y = (int)((double)s.kp_r[(off + i) * 2 + 1] * inv_h);
-        if (in_grid(x, y)) atomicAdd(&hist[y * STVO_GRID_COLS + x], 1);
+        if (in_grid(x, y)) (void)lds_inc16(hist, y * STVO_GRID_COLS + x);
     }
     // counting sort of the LEFT key-points by cell, for the matcher that walks the candidates of a right key-point: the window
     // is clamped, not the cell (src/gridStructure.cpp:67-71), so columns up to 63 + ws still see the last grid columns
@@ -194,7 +202,7 @@ __global__ __launch_bounds__(256) void point_cells_kernel(SeqDev s) {
                 const int y = (int)((double)s.kp_l[(off + i) * 2 + 1] * inv_h);
                 if (y >= 0 && y < STVO_GRID_ROWS && x >= 0 && x <= STVO_GRID_COLS - 1 + s.mp.matching_s_ws) {
                     lcel[k] = y * GRID_LW + x;
-                    lrnk[k] = atomicAdd(&lhist[lcel[k]], 1);
+                    lrnk[k] = lds_inc16(lhist, lcel[k]);
                 }
             }
         }
@@ -230,7 +238,7 @@ __global__ __launch_bounds__(256) void point_cells_kernel(SeqDev s) {
         int pos;
         if (in_grid(x, y)) {
             const int c = y * STVO_GRID_COLS + x;
-            pos = hist[c] + atomicAdd(&fill[c], 1);
+            pos = (int)hist[c] + lds_inc16(fill, c);
             if (!LEAN) s.pitems[off + pos] = i;
         } else {  // the reference's out_of_bounds sink: never a candidate, scanned last
             pos = n_in + atomicAdd(&s_extra, 1);
@@ -1179,74 +1187,89 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl) {
     }
     d.zero_nl = (!lines_now && s->op.has_points) ? 1 : 0;
     if (s->pev[0]) (void)hipEventRecord(s->pev[1], st);  // pev[0] was recorded before the ingest
-    if (s->op.has_points) {
-        mark(0, st);
-        stvo::GridBatch g;
-        std::memset(&g, 0, sizeof(g));
-        g.B = B; g.stride1 = K; g.stride2 = K; g.xy_width = 2; g.items_stride = K; g.words64 = K / 64; g.n1p = K;
-        g.cell_xy1 = d.pxy_l; g.d1 = d.desc_l; g.n1 = d.n_kp_l; g.cell_start = d.pstart; g.cell_items = d.pitems;
-        g.d2 = d.desc_r; g.n2 = d.n_kp_r; g.dir2 = nullptr;
-        g.w = stvo_grid_window{s->mp.matching_s_ws, 0, 0, 0};  // stereoFrame.cpp:141-143
-        g.ratio = s->ratio_grid; g.line_sim_th = 0.0; g.mutual = s->mp.best_lr_matches;
-        g.cover = s->cover; g.rank = d.prank; g.perm = d.pperm; g.top2 = s->top2; g.owner2 = s->owner2; g.m12 = s->m12s_p;
-        if (g.mutual) { g.elig = s->elig; g.elig_cnt = s->elig_cnt; g.ovf = s->govf; }
-        g.misfit = s->govf + s->B;
-        g.range_points = 1;  // device CSR: right key-points are numbered in cell order, one grid row per window
-        g.range1 = d.prange;
-        g.cell2 = d.pcell;
-        g.lstart = d.plstart; g.lperm = d.plperm;
-        // the one-workgroup matcher: lean cells kernel in front, the tail of the association as its last phase
-        g.lean_cells = stvo::grid_points_fused_ok(g) ? 1 : 0;
-        g.has_tail = g.lean_cells;
-        if (const char* e = std::getenv("STVO_GRID_TAIL")) g.has_tail = g.has_tail && e[0] != '0';  // developer: 0 = point_tail_kernel as its own launch
-        if (g.has_tail) g.tail = stvo::point_tail_args(d);
-        if (g.lean_cells)
-            hipLaunchKernelGGL(stvo::point_cells_kernel<true>, dim3(B), dim3(256), 0, st, d);
-        else
-            hipLaunchKernelGGL(stvo::point_cells_kernel<false>, dim3(B), dim3(256), 0, st, d);
-        s->last_point_grid = g;
-        stvo::launch_grid_batch(st, g, false, tev ? tev + 2 : nullptr);
-        if (!g.has_tail) hipLaunchKernelGGL(stvo::point_tail_kernel, dim3(B), dim3(stvo::TAIL_BLOCK), 0, st, d);
-        mark(1, st);
-    } else {
-        HIP_TRY(ctx, hipMemsetAsync(cs.n, 0, (size_t)B * 4, st));
-    }
+    int stage_rc = STVO_OK;
+    auto point_stage = [&]() -> int {
+        if (s->op.has_points) {
+            mark(0, st);
+            stvo::GridBatch g;
+            std::memset(&g, 0, sizeof(g));
+            g.B = B; g.stride1 = K; g.stride2 = K; g.xy_width = 2; g.items_stride = K; g.words64 = K / 64; g.n1p = K;
+            g.cell_xy1 = d.pxy_l; g.d1 = d.desc_l; g.n1 = d.n_kp_l; g.cell_start = d.pstart; g.cell_items = d.pitems;
+            g.d2 = d.desc_r; g.n2 = d.n_kp_r; g.dir2 = nullptr;
+            g.w = stvo_grid_window{s->mp.matching_s_ws, 0, 0, 0};  // stereoFrame.cpp:141-143
+            g.ratio = s->ratio_grid; g.line_sim_th = 0.0; g.mutual = s->mp.best_lr_matches;
+            g.cover = s->cover; g.rank = d.prank; g.perm = d.pperm; g.top2 = s->top2; g.owner2 = s->owner2; g.m12 = s->m12s_p;
+            if (g.mutual) { g.elig = s->elig; g.elig_cnt = s->elig_cnt; g.ovf = s->govf; }
+            g.misfit = s->govf + s->B;
+            g.range_points = 1;  // device CSR: right key-points are numbered in cell order, one grid row per window
+            g.range1 = d.prange;
+            g.cell2 = d.pcell;
+            g.lstart = d.plstart; g.lperm = d.plperm;
+            // the one-workgroup matcher: lean cells kernel in front, the tail of the association as its last phase
+            g.lean_cells = stvo::grid_points_fused_ok(g) ? 1 : 0;
+            g.has_tail = g.lean_cells;
+            if (const char* e = std::getenv("STVO_GRID_TAIL")) g.has_tail = g.has_tail && e[0] != '0';  // developer: 0 = point_tail_kernel as its own launch
+            if (g.has_tail) g.tail = stvo::point_tail_args(d);
+            if (g.lean_cells)
+                hipLaunchKernelGGL(stvo::point_cells_kernel<true>, dim3(B), dim3(256), 0, st, d);
+            else
+                hipLaunchKernelGGL(stvo::point_cells_kernel<false>, dim3(B), dim3(256), 0, st, d);
+            s->last_point_grid = g;
+            stvo::launch_grid_batch(st, g, false, tev ? tev + 2 : nullptr);
+            if (!g.has_tail) hipLaunchKernelGGL(stvo::point_tail_kernel, dim3(B), dim3(stvo::TAIL_BLOCK), 0, st, d);
+            mark(1, st);
+        } else {
+            HIP_TRY(ctx, hipMemsetAsync(cs.n, 0, (size_t)B * 4, st));
+        }
+        return STVO_OK;
+    };
+    auto line_stage = [&]() -> int {
+        if (lines_now) {
+            stvo::GridBatch g;
+            std::memset(&g, 0, sizeof(g));
+            g.B = B; g.stride1 = M; g.stride2 = M; g.xy_width = 4; g.items_stride = M * stvo::LENT; g.words64 = M / 64; g.n1p = M;
+            g.cell_xy1 = d.lxy_l; g.d1 = d.ldesc_l; g.n1 = d.n_kl_l; g.cell_start = d.lstart; g.cell_items = d.litems;
+            g.d2 = d.ldesc_r; g.n2 = d.n_kl_r; g.dir2 = d.ldir;
+            g.w = stvo_grid_window{s->mp.matching_s_ws, 0, 0, 0};  // :340-342
+            g.ratio = s->ratio_grid /* sic, minRatio12P: matching.cpp:241 */; g.line_sim_th = s->mp.line_sim_th;
+            g.mutual = s->mp.best_lr_matches;
+            g.cover = s->cover_l; g.rank = d.lrank; g.perm = d.lperm; g.top2 = s->top2_l; g.owner2 = s->owner2_l; g.m12 = s->m12s_l;
+            if (g.mutual) { g.elig = s->elig_l; g.elig_cnt = s->elig_cnt_l; g.ovf = s->govf_l; }
+            s->last_line_grid = g;
+            // few key-lines per frame: the whole association in one workgroup per frame (STVO_LINE_FUSED=0: the general grid matcher)
+            const int Mk = std::min(M, std::max(64, (s->raw_max_lines[slot] + 63) & ~63));  // LDS for the lines the slot holds, not for the capacity
+            s->set_lines_cap[s->cur] = Mk;
+            const size_t lds = (size_t)Mk * stvo::LSF_BYTES_PER_LINE + 4 + (size_t)Mk * (Mk / 32) * 4;
+            const char* ef = std::getenv("STVO_LINE_FUSED");
+            // (a single stream with hundreds of key-lines is better off with the general matcher's many small workgroups: EuRoC-shaped,
+            // 300 key-lines, one stream 0.310 vs 0.360 ms per frame; 102 key-lines 0.257 vs 0.252)
+            s->last_line_fused = M <= stvo::LSF_MAX_LINES && (ef ? ef[0] != '0' : (B >= 16 || Mk <= 128)) &&
+                                 (lds <= (48u << 10) || stvo::lds_opt_in(reinterpret_cast<const void*>(stvo::line_stereo_fused_kernel<256>), (int)lds));
+            if (s->last_line_fused) {
+                // (one wave per frame, <64>: 185 instead of 150 us beside the key-point scan, which it stretched by 15 us more)
+                hipLaunchKernelGGL(stvo::line_stereo_fused_kernel<256>, dim3(B), dim3(256), lds, sl, d, Mk, (int)s->mp.best_lr_matches, s->ratio_grid);
+            } else {
+                hipLaunchKernelGGL(stvo::line_cells_kernel, dim3(B), dim3(256), 0, sl, d);
+                stvo::launch_grid_batch(sl, g, true);
+                hipLaunchKernelGGL(stvo::line_tail_kernel, dim3(B), dim3(256), 0, sl, d);
+            }
+        } else if (!d.zero_nl) {
+            HIP_TRY(ctx, hipMemsetAsync(cs.nl, 0, (size_t)B * 4, st));
+        }
+        return STVO_OK;
+    };
+    // enqueue order: with the early fork the line kernel goes first — its workgroups then sit beside those of point_cells_kernel
+    // (16-bit LDS counters: three of them fit next to four line workgroups) and are gone when the persistent point matcher wants
+    // whole CUs (matcher 0.186 -> 0.166 ms, the cells kernel a little slower: stage 0.239 -> 0.231).  STVO_LINE_FIRST=0: point stage first
+    const char* elf = std::getenv("STVO_LINE_FIRST");
+    const bool line_first = par && !late_fork && !(elf && elf[0] == '0');
+    if (line_first && (stage_rc = line_stage()) != STVO_OK) return stage_rc;
+    if ((stage_rc = point_stage()) != STVO_OK) return stage_rc;
     if (late_fork) {
         HIP_TRY(ctx, hipEventRecord(s->ev_fork, st));
         HIP_TRY(ctx, hipStreamWaitEvent(sl, s->ev_fork, 0));
     }
-    if (lines_now) {
-        stvo::GridBatch g;
-        std::memset(&g, 0, sizeof(g));
-        g.B = B; g.stride1 = M; g.stride2 = M; g.xy_width = 4; g.items_stride = M * stvo::LENT; g.words64 = M / 64; g.n1p = M;
-        g.cell_xy1 = d.lxy_l; g.d1 = d.ldesc_l; g.n1 = d.n_kl_l; g.cell_start = d.lstart; g.cell_items = d.litems;
-        g.d2 = d.ldesc_r; g.n2 = d.n_kl_r; g.dir2 = d.ldir;
-        g.w = stvo_grid_window{s->mp.matching_s_ws, 0, 0, 0};  // :340-342
-        g.ratio = s->ratio_grid /* sic, minRatio12P: matching.cpp:241 */; g.line_sim_th = s->mp.line_sim_th;
-        g.mutual = s->mp.best_lr_matches;
-        g.cover = s->cover_l; g.rank = d.lrank; g.perm = d.lperm; g.top2 = s->top2_l; g.owner2 = s->owner2_l; g.m12 = s->m12s_l;
-        if (g.mutual) { g.elig = s->elig_l; g.elig_cnt = s->elig_cnt_l; g.ovf = s->govf_l; }
-        s->last_line_grid = g;
-        // few key-lines per frame: the whole association in one workgroup per frame (STVO_LINE_FUSED=0: the general grid matcher)
-        const int Mk = std::min(M, std::max(64, (s->raw_max_lines[slot] + 63) & ~63));  // LDS for the lines the slot holds, not for the capacity
-        s->set_lines_cap[s->cur] = Mk;
-        const size_t lds = (size_t)Mk * stvo::LSF_BYTES_PER_LINE + 4 + (size_t)Mk * (Mk / 32) * 4;
-        const char* ef = std::getenv("STVO_LINE_FUSED");
-        // (a single stream with hundreds of key-lines is better off with the general matcher's many small workgroups: EuRoC-shaped,
-        // 300 key-lines, one stream 0.310 vs 0.360 ms per frame; 102 key-lines 0.257 vs 0.252)
-        s->last_line_fused = M <= stvo::LSF_MAX_LINES && (ef ? ef[0] != '0' : (B >= 16 || Mk <= 128)) &&
-                             (lds <= (48u << 10) || stvo::lds_opt_in(reinterpret_cast<const void*>(stvo::line_stereo_fused_kernel<256>), (int)lds));
-        if (s->last_line_fused) {
-            // (one wave per frame, <64>: 185 instead of 150 us beside the key-point scan, which it stretched by 15 us more)
-            hipLaunchKernelGGL(stvo::line_stereo_fused_kernel<256>, dim3(B), dim3(256), lds, sl, d, Mk, (int)s->mp.best_lr_matches, s->ratio_grid);
-        } else {
-            hipLaunchKernelGGL(stvo::line_cells_kernel, dim3(B), dim3(256), 0, sl, d);
-            stvo::launch_grid_batch(sl, g, true);
-            hipLaunchKernelGGL(stvo::line_tail_kernel, dim3(B), dim3(256), 0, sl, d);
-        }
-    } else if (!d.zero_nl) {
-        HIP_TRY(ctx, hipMemsetAsync(cs.nl, 0, (size_t)B * 4, st));
-    }
+    if (!line_first && (stage_rc = line_stage()) != STVO_OK) return stage_rc;
     if (s->pev[0]) (void)hipEventRecord(s->pev[2], st);
     const bool track = fl.track;
     if (track) {

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--preset", default="kitti", choices=["kitti", "euroc"],
                     help="euroc: BASELINE configs[3] shape (752x480, 800 points over 4 octaves, 300 lines, 40 %% outliers)")
     ap.add_argument("--mode", type=int, default=0, help="0 GN, 1 robust GN, 2 LM")
+    ap.add_argument("--no-point-stage", action="store_true", help="has_points = 0: only the key-line kernels run (their standalone durations under rocprofv3)")
     a = ap.parse_args()
     import torch  # noqa: F401  (one HIP runtime per process, see capi.load)
     from stvo_amd import capi, synth
@@ -37,7 +38,7 @@ def main():
     euroc = a.preset == "euroc"
     cam = synth.EUROC_CAM if euroc else synth.KITTI_CAM
     mp = match_params(a.preset)
-    op = opt_params(a.preset, has_lines=1 if a.lines > 0 else 0, mode=a.mode)
+    op = opt_params(a.preset, has_lines=1 if a.lines > 0 else 0, mode=a.mode, has_points=0 if a.no_point_stage else 1)
     B = a.batch
     extra = dict(depth=(0.5, 8.0), octave_probs=[.5, .25, .15, .1], outlier_frac=0.4) if euroc else {}
     seqs = [synth.make_stereo_sequence(synth.frame_seed(b, 0), n_frames=2, n_pts=a.points, n_lines=a.lines, cam=cam, **extra)
