@@ -1315,7 +1315,7 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl) {
             HIP_TRY(ctx, hipEventRecord(s->ev_fetch, st));
         }
         // ---- optimizePose
-        stvo::PoseArgs a;
+        stvo::PoseArgs a{};
         std::memset(&a, 0, sizeof(a));
         a.B = B; a.max_pts = K; a.max_lines = M;
         a.n_prev_pts = s->op.has_points ? ps.n : nullptr;

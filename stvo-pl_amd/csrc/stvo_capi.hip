@@ -252,7 +252,7 @@ int stvo_normal_eq(stvo_ctx* ctx, const double T[16], const stvo_cam* cam, const
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->arena_off = 0;
     ctx->upload_hi = 0;
-    stvo::PoseArgs a;
+    stvo::PoseArgs a{};
     int32_t *dip, *dil;
     TRY(stage_records(ctx, m, T, &a, &dip, &dil));
     a.cam = *cam;
@@ -283,7 +283,7 @@ int stvo_optimize_pose(stvo_ctx* ctx, const double init_T[16], const stvo_cam* c
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->arena_off = 0;
     ctx->upload_hi = 0;
-    stvo::PoseArgs a;
+    stvo::PoseArgs a{};
     int32_t *dip, *dil;
     TRY(stage_records(ctx, m, init_T, &a, &dip, &dil));
     a.cam = *cam;
@@ -406,7 +406,7 @@ int stvo_track_batched_dev(stvo_ctx* ctx, const stvo_track_batch_dev* b, const s
     if (params->has_lines && b->max_lines > 0)
         match_set(b->max_lines, b->prev_ldesc, b->n_prev_lines, b->curr_ldesc, b->n_curr_lines, nnr_lines, b->m12_lines);
     if (prev_pose) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, prev_pose, 0));  // also when nothing was matched
-    stvo::PoseArgs a;
+    stvo::PoseArgs a{};
     fill_pose_args(b, cam, params, false, &a);
     // a feature kind that is switched off is never matched => matched_pt / matched_ls stay empty (:137,160)
     if (!params->has_points) a.n_prev_pts = nullptr;
@@ -430,7 +430,7 @@ int stvo_optimize_pose_batched_dev(stvo_ctx* ctx, const stvo_track_batch_dev* b,
     if (!cam || !params) return STVO_ERR_INVALID_ARG;
     TRY(check_batch(ctx, b, false));
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    stvo::PoseArgs a;
+    stvo::PoseArgs a{};
     fill_pose_args(b, cam, params, true, &a);
     TRY(stvo::launch_pose(ctx->stream, a));
     return check_launch(ctx);
@@ -444,7 +444,7 @@ int stvo_time_stage_dev(stvo_ctx* ctx, const stvo_track_batch_dev* b, const stvo
     hipEvent_t e0, e1;
     HIP_TRY(ctx, hipEventCreate(&e0));
     HIP_TRY(ctx, hipEventCreate(&e1));
-    stvo::PoseArgs a;
+    stvo::PoseArgs a{};
     fill_pose_args(b, cam, params, false, &a);
     HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
     const stvo::LazyScratch lw{ctx->knn12, ctx->knn21, ctx->cand, ctx->need, ctx->qsel, ctx->nsel, ctx->knn_capacity};
