@@ -1262,7 +1262,7 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl) {
     // (16-bit LDS counters: three of them fit next to four line workgroups) and are gone when the persistent point matcher wants
     // whole CUs (matcher 0.186 -> 0.166 ms, the cells kernel a little slower: stage 0.239 -> 0.231).  STVO_LINE_FIRST=0: point stage first
     const char* elf = std::getenv("STVO_LINE_FIRST");
-    const bool line_first = par && !late_fork && !(elf && elf[0] == '0');
+    const bool line_first = par && !late_fork && (elf ? elf[0] != '0' : B >= 16);  // (a single stream: the point stage is the critical path)
     if (line_first && (stage_rc = line_stage()) != STVO_OK) return stage_rc;
     if ((stage_rc = point_stage()) != STVO_OK) return stage_rc;
     if (late_fork) {
@@ -1288,7 +1288,9 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl) {
                 // a few frame pairs leave most of the GPU idle: the reverse direction as a full scan in the SAME launch and one
                 // ratio / mutual kernel, instead of the plan + two selective reverse scans + final check of the lazy formulation
                 // (five dependent launches: 42 -> ~18 us of a single stream's 230 us)
-                const int nseg = stvo::knn_pick_nseg(B, stride, ws.knn_capacity);
+                // (four train segments, not the 16 a single direction gets: both directions already double the workgroups, and the
+                // ratio / mutual kernel merges 2 x nseg partial keys per row — one stream 0.2465 -> 0.2357 ms)
+                const int nseg = std::min(4, stvo::knn_pick_nseg(B, stride, ws.knn_capacity));
                 stvo::launch_hamming_knn2(q, B, stride, stride, da, na, db, nb, ws.knn12, ws.knn21, 1, 0, 0, nullptr, nullptr, nseg);
                 stvo::launch_nnr_mutual(q, B, stride, ws.knn12, ws.knn21, na, nb, nnr, 1, m12, nseg);
             } else if (s->mp.best_lr_matches) {
