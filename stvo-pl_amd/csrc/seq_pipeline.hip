@@ -104,13 +104,6 @@ __device__ __forceinline__ bool in_grid(int x, int y) {
 }
 
 // exclusive scan of hist[0..256 * PER) in LDS by 256 threads (PER cells each); writes start[0..256 * PER]
-// 16-bit LDS counters (a frame holds at most 2048 features of a kind): half the LDS of the cells kernels, so that workgroups of the
-// line stage fit beside them.  LDS has 16-bit loads and stores but only 32-bit atomics: increment the half of the containing word.
-__device__ __forceinline__ int lds_inc16(unsigned short* a, int c) {
-    const unsigned old = atomicAdd(reinterpret_cast<unsigned*>(a) + (c >> 1), 1u << (16 * (c & 1)));
-    return (int)((old >> (16 * (c & 1))) & 0xFFFFu);
-}
-
 template <int PER, typename T>
 __device__ __forceinline__ void scan_cells_n(T* hist, int* s_wave, int32_t* start_out) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -155,9 +148,11 @@ __device__ __forceinline__ void scan_cells(T* hist, int* s_wave, int32_t* start_
 // of the scan formulation only; the matcher rebuilds them for the rare frame it hands to it (fused_misfit_frame).
 template <bool LEAN>
 __global__ __launch_bounds__(256) void point_cells_kernel(SeqDev s) {
-    __shared__ __attribute__((aligned(4))) unsigned short hist[STVO_GRID_CELLS];
-    __shared__ __attribute__((aligned(4))) unsigned short fill[STVO_GRID_CELLS];
-    __shared__ __attribute__((aligned(4))) unsigned short lhist[GRID_LCELLS];
+    // (16-bit counters — half the LDS, so that line workgroups fit beside this kernel's — gained 0.7 % on 1024 KITTI-shaped streams and
+    // lost 10 % on 512 EuRoC-shaped ones, where the line stream is the longer one and every speed-up of the point stream takes CUs from it)
+    __shared__ int hist[STVO_GRID_CELLS];
+    __shared__ int fill[STVO_GRID_CELLS];
+    __shared__ int lhist[GRID_LCELLS];
     __shared__ int s_wave[4];
     __shared__ int s_extra;
     static_assert(GRID_LCELLS % 256 == 0, "scan_cells_n");
@@ -186,7 +181,7 @@ __global__ __launch_bounds__(256) void point_cells_kernel(SeqDev s) {
     for (int i = tid; i < nr; i += 256) {
         const int x = (int)((double)s.kp_r[(off + i) * 2 + 0] * inv_w);
         const int y = (int)((double)s.kp_r[(off + i) * 2 + 1] * inv_h);
-        if (in_grid(x, y)) (void)lds_inc16(hist, y * STVO_GRID_COLS + x);
+        if (in_grid(x, y)) atomicAdd(&hist[y * STVO_GRID_COLS + x], 1);
     }
     // counting sort of the LEFT key-points by cell, for the matcher that walks the candidates of a right key-point: the window
     // is clamped, not the cell (src/gridStructure.cpp:67-71), so columns up to 63 + ws still see the last grid columns
@@ -202,7 +197,7 @@ __global__ __launch_bounds__(256) void point_cells_kernel(SeqDev s) {
                 const int y = (int)((double)s.kp_l[(off + i) * 2 + 1] * inv_h);
                 if (y >= 0 && y < STVO_GRID_ROWS && x >= 0 && x <= STVO_GRID_COLS - 1 + s.mp.matching_s_ws) {
                     lcel[k] = y * GRID_LW + x;
-                    lrnk[k] = lds_inc16(lhist, lcel[k]);
+                    lrnk[k] = atomicAdd(&lhist[lcel[k]], 1);
                 }
             }
         }
@@ -238,7 +233,7 @@ __global__ __launch_bounds__(256) void point_cells_kernel(SeqDev s) {
         int pos;
         if (in_grid(x, y)) {
             const int c = y * STVO_GRID_COLS + x;
-            pos = (int)hist[c] + lds_inc16(fill, c);
+            pos = hist[c] + atomicAdd(&fill[c], 1);
             if (!LEAN) s.pitems[off + pos] = i;
         } else {  // the reference's out_of_bounds sink: never a candidate, scanned last
             pos = n_in + atomicAdd(&s_extra, 1);
@@ -1258,11 +1253,10 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl) {
         }
         return STVO_OK;
     };
-    // enqueue order: with the early fork the line kernel goes first — its workgroups then sit beside those of point_cells_kernel
-    // (16-bit LDS counters: three of them fit next to four line workgroups) and are gone when the persistent point matcher wants
-    // whole CUs (matcher 0.186 -> 0.166 ms, the cells kernel a little slower: stage 0.239 -> 0.231).  STVO_LINE_FIRST=0: point stage first
+    // enqueue order: STVO_LINE_FIRST=1 puts the line kernel in front of the point stage (experiment: the point matcher then starts on
+    // free CUs, the cells kernel shares them — same step time on 1024 KITTI-shaped streams, slower with hundreds of lines per image)
     const char* elf = std::getenv("STVO_LINE_FIRST");
-    const bool line_first = par && !late_fork && (elf ? elf[0] != '0' : B >= 16);  // (a single stream: the point stage is the critical path)
+    const bool line_first = par && !late_fork && elf && elf[0] == '1';
     if (line_first && (stage_rc = line_stage()) != STVO_OK) return stage_rc;
     if ((stage_rc = point_stage()) != STVO_OK) return stage_rc;
     if (late_fork) {
