@@ -452,7 +452,7 @@ __device__ __forceinline__ uint32_t block_threshold(uint32_t d0, float nnr) {
 //   3. picks the cut tau and writes the LIGHT / HEAVY column lists and the row list S.
 // out: cand[i], claim[j], blocked[j], qsel (LIGHT columns from the front, HEAVY from the back of the frame's slot), tsel,
 // nsel[0][b] = claimed columns, [1] = light, [2] = heavy, [3] = |S|, [4] = tau.  knn12 segment 0 is left holding the merged top-2.
-constexpr int PLAN_BLOCK = 1024;
+constexpr int PLAN_BLOCK = 512;  // (1024: two rounds of two workgroups per CU for 1024 frames, 34 us; 512: one round, 29 us; 320: 32 us)
 __global__ __launch_bounds__(PLAN_BLOCK) void forward_plan_kernel(int B, int nseg, int row_stride, uint2* __restrict__ knn12,
                                                                   const int32_t* __restrict__ n1,
                                                                   const int32_t* __restrict__ n2, float nnr,
