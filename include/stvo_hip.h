@@ -303,6 +303,10 @@ int stvo_last_reverse_plan(stvo_ctx* ctx, int B, int32_t* plan);
  * 32-bit lane-ops/s of this device, the empirical roof K1 is priced against. */
 int stvo_valu_peak_probe(stvo_ctx* ctx, double* lane_ops_per_s);
 
+/* Developer switches (csrc/debug_switches.h lists every STVO_* environment variable the library knows): they are parsed once,
+ * on first use; this re-reads the environment so that one test process can drive several kernel variants. */
+void stvo_debug_reparse_env(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,6 +12,7 @@ struct stvo_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    bool stream_retained = false;  // this context holds a reference on the stream's pose-record arena (kernels.h)
     int max_rows = 0, max_batch = 0;
     // persistent scratch for the batched path
     uint2* knn12 = nullptr;

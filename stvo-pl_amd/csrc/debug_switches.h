@@ -1,0 +1,34 @@
+// debug_switches.h — every developer switch of the library in ONE place.  The STVO_* environment variables are parsed once, on
+// first use, into this struct; nothing else in csrc/ calls getenv.  stvo_debug_reparse_env() (C-ABI, tests and tools only) reads
+// them again, so that a parity test can drive several variants from one process.  DBG_UNSET = not set: the library's own choice.
+#pragma once
+
+#include <climits>
+
+namespace stvo {
+
+constexpr int DBG_UNSET = INT_MIN;
+
+struct DebugSwitches {
+    int pose_kernel;     // STVO_POSE_KERNEL     1: pose_kernel.hip for every batch size, 4: pose_kernel2p.hip for every batch size
+    int pose2p_nw;       // STVO_POSE2P_NW       waves per frame pair of the batch kernel (2 or 4)
+    int pose_prof;       // STVO_POSE_PROF       in-kernel phase ticks (tools/pose_probe.py)
+    int pose_lds_t;      // STVO_POSE_LDS_T      0: pose_kernel.hip's throughput variant without its partial LDS record cache
+    int knn_mfma;        // STVO_KNN_MFMA        0: VALU matcher (K1 + K1v), else query blocks per wave of K1m
+    int knn_nseg;        // STVO_KNN_NSEG        train segments per query tile
+    int seq_graph;       // STVO_SEQ_GRAPH       1: hipGraph replay of the per-frame chain
+    int seq_prof;        // STVO_SEQ_PROF        host-side phase times of stvo_seq_push
+    int line_fork_late;  // STVO_LINE_FORK=late  1: the key-line stream forks after the stereo point stage instead of at the start of the step
+    int line_first;      // STVO_LINE_FIRST      1: key-line kernels enqueued before the point-cells kernel
+    int line_fused;      // STVO_LINE_FUSED      0 / 1: general / one-workgroup stereo line matcher
+    int match_small;     // STVO_MATCH_SMALL     0: the general f2f machinery for the key-line sets too
+    int match_lazy;      // STVO_MATCH_LAZY      1: the lazy reverse check for small batches too
+    int grid_tail;       // STVO_GRID_TAIL       0: point_tail_kernel as its own launch
+    int grid_fused;      // STVO_GRID_FUSED      0: scan formulation of the stereo point matcher
+    int grid_fused_cap;  // STVO_GRID_FUSED_CAP  capacity override of the one-workgroup point matcher (tests of the misfit path)
+};
+
+const DebugSwitches& dbg();  // parsed on first use (stvo_capi.hip)
+void dbg_reparse();
+
+}  // namespace stvo

@@ -607,7 +607,6 @@ __device__ __forceinline__ void fused_tail(const GridBatch& g, const int f, cons
         if (lane == 0) s_cnt[r * (FUSED_T / 64) + wv] = __popcll(bal);
     }
     __syncthreads();
-    const stvo_cam cam = t.cams[f];
     int base = 0;
 #pragma unroll
     for (int r = 0; r < FUSED_R; ++r) {
@@ -617,7 +616,7 @@ __device__ __forceinline__ void fused_tail(const GridBatch& g, const int f, cons
             wbase += w < wv ? c : 0;
             base += c;
         }
-        if (ok[r]) point_tail_write(t, cam, off, tid + r * FUSED_T, off + (size_t)(wbase + before[r]), disp[r]);
+        if (ok[r]) point_tail_write(t, off, tid + r * FUSED_T, off + (size_t)(wbase + before[r]), disp[r]);
     }
     if (tid == 0) {
         t.n[f] = base;
@@ -919,9 +918,8 @@ __global__ __launch_bounds__(FUSED_T) void grid_points_fused_kernel(GridBatch g,
 bool grid_points_fused_ok(const GridBatch& g) {
     const bool range = g.range_points && g.range1 != nullptr;
     // STVO_GRID_FUSED=0: the scan formulation for every batch
-    const char* ef = std::getenv("STVO_GRID_FUSED");
     const bool fused = range && g.misfit && g.cell2 && g.lperm && g.lstart && g.stride1 <= FUSED_ROWS && g.stride2 <= FUSED_ROWS && g.w.w_lo >= 0 &&
-                       g.w.w_lo <= FUSED_LW - STVO_GRID_COLS && g.w.w_hi == 0 && g.w.h_lo == 0 && g.w.h_hi == 0 && !(ef && ef[0] == '0');
+                       g.w.w_lo <= FUSED_LW - STVO_GRID_COLS && g.w.w_hi == 0 && g.w.h_lo == 0 && g.w.h_hi == 0 && dbg().grid_fused != 0;
     return fused && lds_opt_in(reinterpret_cast<const void*>(grid_points_fused_kernel), (int)FUSED_LDS);
 }
 
@@ -946,8 +944,7 @@ void launch_grid_batch(hipStream_t s, const GridBatch& g, bool lines, hipEvent_t
         const bool range = g.range_points && g.range1 != nullptr;
         if (grid_points_fused_ok(g)) {
             // STVO_GRID_FUSED_CAP: capacity for the keys of right features with more than 16 candidates (tests force the misfit path with -1)
-            const char* ec = std::getenv("STVO_GRID_FUSED_CAP");
-            int cap = ec ? std::atoi(ec) : FUSED_KEY_CAP;
+            int cap = dbg().grid_fused_cap != DBG_UNSET ? dbg().grid_fused_cap : FUSED_KEY_CAP;
             if (cap > FUSED_KEY_CAP) cap = FUSED_KEY_CAP;  // negative: every frame misfits
             const int fused_wgs = device_cu_count();  // one persistent workgroup per CU (its LDS and registers fill one)
             if (scan_events) (void)hipEventRecord(scan_events[0], s);

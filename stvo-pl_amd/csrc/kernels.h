@@ -10,23 +10,26 @@
 #include <utility>
 
 #include "../../include/stvo_hip.h"
+#include "debug_switches.h"
 #include "point_tail.h"
 
 namespace stvo {
 
 // More than 64 KB of dynamic LDS per workgroup needs an explicit opt-in, and hipFuncSetAttribute applies to the CURRENT device
-// only: the verdict is cached per (kernel, device), so contexts on several devices of one process each get their opt-in.
+// only: the largest size granted so far is remembered per (kernel, device) — a later, larger request raises the attribute again
+// (a kernel whose dynamic LDS depends on the problem, e.g. the fused line matcher, must not run on a stale smaller opt-in).
 inline bool lds_opt_in(const void* kernel, int bytes) {
     static std::mutex mu;
-    static std::map<std::pair<const void*, int>, bool> done;
+    static std::map<std::pair<const void*, int>, int> granted;  // bytes granted, -1: the runtime refused
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return false;
     std::lock_guard<std::mutex> lk(mu);
     const auto key = std::make_pair(kernel, dev);
-    const auto it = done.find(key);
-    if (it != done.end()) return it->second;
+    const auto it = granted.find(key);
+    if (it != granted.end() && (it->second >= bytes || it->second < 0)) return it->second >= bytes;
     const bool ok = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
-    done[key] = ok;
+    if (ok) granted[key] = bytes;
+    else if (it == granted.end()) granted[key] = -1;
     return ok;
 }
 
@@ -40,7 +43,7 @@ inline int knn_pick_nseg(int B, int max_n, size_t capacity) {
     nseg = nseg < KNN_MIN_NSEG ? KNN_MIN_NSEG : (nseg > KNN_MAX_NSEG ? KNN_MAX_NSEG : nseg);
     if ((long long)B * tiles >= 4096) nseg = 1;  // >= 5 dispatch rounds even unsegmented: a workgroup's fixed cost is paid once per query tile
                                                  // (1024 frames: K1m 0.562 -> 0.551 ms, reverse check 0.054 -> 0.050 ms)
-    if (const char* e = std::getenv("STVO_KNN_NSEG")) nseg = std::atoi(e) > 0 ? std::atoi(e) : nseg;  // developer override
+    if (dbg().knn_nseg != DBG_UNSET && dbg().knn_nseg > 0) nseg = dbg().knn_nseg;  // developer override
     const size_t per_seg = (size_t)(B > 0 ? B : 1) * (size_t)(max_n > 0 ? max_n : 1);
     while (nseg > 1 && (size_t)nseg * per_seg > capacity) --nseg;
     return nseg;
@@ -138,23 +141,26 @@ struct PoseArgs {
     int eval_robust;
     double* eval_out;    // [B][44]: H(36) g(6) e n
     long long* prof_out; // optional [B][16] phase ticks (tools only)
-    int obs_f32;         // hint: every curr_pl value is exactly a float (key-point coordinates): pose_kernel3 keeps them as floats in LDS
-                         // (verified per frame pair on the device; pairs that fail take the full-width path)
+    // compact records of the device-resident pipeline (seq_pipeline.hip), or nullptr: a stereo point is {u, v, disparity as
+    // floats, pyramid level} — exactly what the reference's PointFeature is built from (src/stereoFrame.cpp:152-167: float
+    // key-point coordinates, a float difference, backProjection of the three) — so P, sigma2 and the observation are recomputed
+    // on chip instead of being stored and re-read as seven doubles.  prev_rc[i] gives P and sigma2 of prev point i, curr_rc[j]
+    // the observation; prev_P / prev_s2p / curr_pl are ignored then.
+    const float4* prev_rc;  // [B][max_pts]
+    const float4* curr_rc;  // [B][max_pts]
+    const double* q_tab;    // [STVO_POSE_QTAB] sqrt(sigma2) of pyramid level l (device memory; levels beyond the table are computed)
+    double level_scale;     // orbScaleFactor: sigma2 = 1 / scale^(2 level) (src/stereoFeatures.cpp:41-47)
 };
-int launch_pose(hipStream_t s, const PoseArgs& a);   // dispatches to pose_kernel2.hip (default) or pose_kernel.hip (STVO_POSE_KERNEL=1)
-int launch_pose2(hipStream_t s, const PoseArgs& a);  // pose_kernel2.hip: every wave a worker, 128 VGPRs, records in LDS
-// pose_kernel2's batch kernel on the frame pairs list[0 .. *count - 1] (device memory; a.B = capacity of the list)
-int launch_pose2_list(hipStream_t s, const PoseArgs& a, const int* list, const int* count);
-int launch_pose2p(hipStream_t s, const PoseArgs& a); // pose_kernel2p.hip: thread-private records (LDS planes + global arena), four frame pairs per CU
-int launch_pose3(hipStream_t s, const PoseArgs& a);  // pose_kernel3.hip: two frame pairs per workgroup, owner + evaluator waves
-// the per-(device, stream) scratch of the batch kernels (record arena, misfit list) is freed when its stream goes away; the
-// caller has synchronised the stream and made its device current
+constexpr int STVO_POSE_QTAB = 16;
+// dispatch: pose_kernel.hip's latency variant up to 256 frame pairs (and for single evaluations), pose_kernel2p.hip beyond
+int launch_pose(hipStream_t s, const PoseArgs& a);
+int launch_pose2p(hipStream_t s, const PoseArgs& a);  // pose_kernel2p.hip: thread-private records, four frame pairs per CU
+// the per-(device, stream) record arena of the batch kernel: every context that holds a stream retains it, the last release frees
+// it (the releasing caller has synchronised the stream and made its device current)
+void pose2p_retain_stream(hipStream_t s);
 void pose2p_release_stream(hipStream_t s);
-void pose3_release_stream(hipStream_t s);
-inline void pose_release_stream(hipStream_t s) {
-    pose2p_release_stream(s);
-    pose3_release_stream(s);
-}
+inline void pose_retain_stream(hipStream_t s) { pose2p_retain_stream(s); }
+inline void pose_release_stream(hipStream_t s) { pose2p_release_stream(s); }
 
 // ---- K3: grid-windowed stereo matchers, batched over frame pairs (blockIdx.y) ----------------------
 constexpr int GRID_LW = STVO_GRID_COLS + 16, GRID_LCELLS = STVO_GRID_ROWS * GRID_LW, GRID_LSTART_STRIDE = GRID_LCELLS + 4;

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(KNN_BLOCK) void hamming_knn2_kernel(int B, int tile
 // Query blocks per wave of the matrix-core scan (match_mfma.hip), 0 = use the VALU scan: train indices must fit the
 // 13 index bits of its keys.  STVO_KNN_MFMA=0 selects the VALU kernels (K1 + K1v) for comparison runs.
 int knn_mfma_qb(int max_n) {
-    static const int qb = [] { const char* e = getenv("STVO_KNN_MFMA"); return e ? atoi(e) : 2; }();
+    const int qb = dbg().knn_mfma != DBG_UNSET ? dbg().knn_mfma : 2;
     return max_n <= 8192 ? qb : 0;
 }
 

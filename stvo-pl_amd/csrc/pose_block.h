@@ -1,6 +1,6 @@
-// pose_block.h — building blocks shared by the two pose kernels (pose_kernel.hip: worker waves + a solver wave, 256 VGPRs;
-// pose_kernel2.hip: every wave a worker, 128 VGPRs, row-distributed 6x6 algebra): the per-problem state in LDS, the
-// workgroup-wide reductions / selections, and the serial sections of the optimizePose state machine
+// pose_block.h — building blocks shared by the two pose kernels (pose_kernel.hip: worker waves + a solver wave, the latency
+// formulation; pose_kernel2p.hip: every wave a worker, thread-private records, the batch formulation): the per-problem state
+// in LDS, the workgroup-wide reductions / selections, and the serial sections of the optimizePose state machine
 // (/root/reference/src/stereoFrameHandler.cpp:307-547).
 #pragma once
 #include "kernels.h"
@@ -172,111 +172,8 @@ struct BlockOps {
         return t;
     }
 
-    // exclusive scan of per-thread counts (worker thread order); returns this thread's offset
-    template <bool W>
-    static __device__ __forceinline__ int excl_scan(int count, int* ired, int* total) {
-        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        int incl = count;
-        if (W) {
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int o = __shfl_up(incl, off, 64);
-                if (lane >= off) incl += o;
-            }
-            if (lane == 63) ired[wv] = incl;
-        }
-        __syncthreads();
-        int base = 0, tot = 0;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) {
-            const int c = ired[w];
-            if (w < wv) base += c;
-            tot += c;
-        }
-        __syncthreads();
-        *total = tot;
-        return base + incl - count;
-    }
-
-    // workgroup-wide totals of three per-wave counts (wave-uniform c[0..2]); double-buffered partials => ONE barrier per call
-    template <bool W>
-    static __device__ __forceinline__ void count3_db(int* c, int (*ibuf)[3 * NW], int parity) {
-        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        if (W && lane == 0) {
-            ibuf[parity][wv] = c[0];
-            ibuf[parity][NW + wv] = c[1];
-            ibuf[parity][2 * NW + wv] = c[2];
-        }
-        __syncthreads();
-        int t0 = 0, t1 = 0, t2 = 0;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) {
-            t0 += ibuf[parity][w];
-            t1 += ibuf[parity][NW + w];
-            t2 += ibuf[parity][2 * NW + w];
-        }
-        c[0] = t0;
-        c[1] = t1;
-        c[2] = t2;
-    }
-
-    // k-th smallest (0-based) of the n keys {key[k] : bit k of mask} held in REGISTERS across the workgroup:
-    // most-significant-first radix search on two bits per round — three thresholds, three workgroup-wide counts (per-wave
-    // counts from ballots + s_bcnt1, no cross-lane data movement), one barrier.  lo / hi bracket the number of keys
-    // below the current prefix and below its upper end; as soon as exactly one key is left in the bracket it IS the
-    // answer and is fetched directly — with n ~ 1500 distinct values that happens after ~13 of the 32 (or ~9 of the 16)
-    // rounds.  Equal keys simply keep the search going to the last bit.  Same result as sorting.
-    template <int N, bool W, typename K, int BITS>
-    static __device__ __forceinline__ K select_kth(const K* key, unsigned mask, int n, int kth, int (*ibuf)[3 * NW], K* xchg) {
-        static_assert(BITS % 2 == 0, "two bits per round");
-        K res = 0;
-        int lo = 0, hi = n, parity = 0;
-        for (int bit = BITS - 2; bit >= 0; bit -= 2) {
-            const K t1 = res | ((K)1 << bit), t2 = res | ((K)2 << bit), t3 = res | ((K)3 << bit);
-            int c[3] = {0, 0, 0};
-            if (W) {
-#pragma unroll
-                for (int k = 0; k < N; ++k) {
-                    const bool in = (mask >> k) & 1u;
-                    c[0] += __popcll(__builtin_amdgcn_ballot_w64(in && key[k] < t1));
-                    c[1] += __popcll(__builtin_amdgcn_ballot_w64(in && key[k] < t2));
-                    c[2] += __popcll(__builtin_amdgcn_ballot_w64(in && key[k] < t3));
-                }
-            }
-            count3_db<W>(c, ibuf, parity);
-            parity ^= 1;
-            // the largest threshold with at most kth keys below it becomes the new prefix
-            if (c[2] <= kth) {
-                res = t3;
-                lo = c[2];
-            } else if (c[1] <= kth) {
-                res = t2;
-                lo = c[1];
-                hi = c[2];
-            } else if (c[0] <= kth) {
-                res = t1;
-                lo = c[0];
-                hi = c[1];
-            } else {
-                hi = c[0];
-            }
-            if (hi - lo == 1 && bit > 0) {  // block-uniform: the single key in [res, res + 2^bit)
-                const K top = res + (((K)1 << bit) - 1);
-                if (W) {
-#pragma unroll
-                    for (int k = 0; k < N; ++k)
-                        if (((mask >> k) & 1u) && key[k] >= res && key[k] <= top) *xchg = key[k];
-                }
-                __syncthreads();
-                res = *xchg;
-                break;
-            }
-        }
-        __syncthreads();  // ibuf / xchg are reused by the caller
-        return res;
-    }
-
-    // The same selection on EIGHT bits per round: the keys that still carry the current prefix are counted into a 256-bin LDS
+    // k-th smallest (0-based) of the keys {key[k] : bit k of mask} held in REGISTERS across the workgroup, most significant
+    // byte first: the keys that still carry the current prefix are counted into a 256-bin LDS
     // histogram (no-return ds_add), wave 0 scans the bins (4 per lane) for the one that holds the kth key while the other
     // waves clear the histogram of the next round, everybody adopts bin and rank.  ~1300 doubles take 3 rounds + the fetch of
     // the last key instead of ~11 two-bit rounds of 24 ballots each (the outlier removal of a frame pair: 70 k -> ~35 k
@@ -375,169 +272,11 @@ struct BlockOps {
 
 __device__ __forceinline__ double norm3(const double* v) { return sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
 
-// ---- row-distributed 6x6 algebra for ONE wave (pose_kernel2.hip) -------------------------------------------------------
-// Lane i (0..5) of the calling wave holds row i of the matrix in 6 registers; a pivot row is broadcast with v_readlane (the
-// lane index is a compile-time constant, so the values land in SGPRs and feed the other lanes' FMAs as scalar operands).
-// Every lane of the wave executes the code (lanes >= 6 carry a copy of row 0 and are never read).  Same certification as
-// pm::ldl6: unpivoted elimination is accepted only while every pivot is > 1e-10 of the largest diagonal entry — callers
-// then fall back to the pivoted serial routines, so degenerate systems behave exactly as in pose_kernel.hip.
-template <int L>
-__device__ __forceinline__ double rl(double v) {
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_readlane((int)(b & 0xFFFFFFFFll), L), hi = __builtin_amdgcn_readlane((int)(b >> 32), L);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned long long)(unsigned)lo);
-}
-__device__ __forceinline__ double own_diag(const double* h, int lane) {  // h[lane] without a dynamic register index
-    double d = h[0];
-#pragma unroll
-    for (int j = 1; j < 6; ++j) d = (lane == j) ? h[j] : d;
-    return d;
-}
-template <int K>
-struct RowStep {  // elimination step K on rows i != K (below only when !JORDAN)
-    template <bool JORDAN, int NE>
-    static __device__ __forceinline__ void run(double* h, double* e, int lane, double tol, bool& ok, double* piv, double* rinv) {
-        double pk[6], ek[NE > 0 ? NE : 1];
-#pragma unroll
-        for (int j = K; j < 6; ++j) pk[j] = rl<K>(h[j]);
-#pragma unroll
-        for (int j = 0; j < NE; ++j) ek[j] = rl<K>(e[j]);
-        ok = ok && (pk[K] > tol);
-        const double ri = 1.0 / pk[K];
-        piv[K] = pk[K];
-        rinv[K] = ri;
-        const bool upd = JORDAN ? (lane != K) : (lane > K);
-        const double fcol = h[K];
-        const double f = upd ? fcol * ri : 0.0;
-#pragma unroll
-        for (int j = K + 1; j < 6; ++j) h[j] -= f * pk[j];
-#pragma unroll
-        for (int j = 0; j < NE; ++j) e[j] -= f * ek[j];
-        if (JORDAN) {  // the pivot row itself is normalised at the end (by rinv), keep it untouched here
-        }
-    }
-};
-
-// H x = b.  h: row `lane` of H (lanes 0..5), b: its right-hand side.  x (uniform) and log|det H|; false => not certified.
-__device__ __forceinline__ bool row_solve_spd(const double* h_in, double b_in, double* x, double* log_abs_det) {
-    const int lane = threadIdx.x & 63;
-    double h[6], e[1] = {b_in}, piv[6], rinv[6];
-#pragma unroll
-    for (int j = 0; j < 6; ++j) h[j] = h_in[j];
-    const double dg = fabs(own_diag(h, lane));
-    double maxd = rl<0>(dg);
-    maxd = fmax(maxd, rl<1>(dg)); maxd = fmax(maxd, rl<2>(dg)); maxd = fmax(maxd, rl<3>(dg));
-    maxd = fmax(maxd, rl<4>(dg)); maxd = fmax(maxd, rl<5>(dg));
-    const double d0 = rl<0>(dg), d1 = rl<1>(dg), d2 = rl<2>(dg), d3 = rl<3>(dg), d4 = rl<4>(dg), d5 = rl<5>(dg);
-    const bool finite = (d0 == d0) && (d1 == d1) && (d2 == d2) && (d3 == d3) && (d4 == d4) && (d5 == d5);  // fmax drops NaNs
-    const double tol = 1e-10 * maxd;
-    bool ok = finite && maxd > 0.0 && maxd < 1.0e300;
-    RowStep<0>::run<false, 1>(h, e, lane, tol, ok, piv, rinv);
-    RowStep<1>::run<false, 1>(h, e, lane, tol, ok, piv, rinv);
-    RowStep<2>::run<false, 1>(h, e, lane, tol, ok, piv, rinv);
-    RowStep<3>::run<false, 1>(h, e, lane, tol, ok, piv, rinv);
-    RowStep<4>::run<false, 1>(h, e, lane, tol, ok, piv, rinv);
-    RowStep<5>::run<false, 1>(h, e, lane, tol, ok, piv, rinv);
-    // back substitution on the upper-triangular rows: lane k owns row k
-    double t;
-    x[5] = rl<5>(e[0]) * rinv[5];
-    t = e[0] - h[5] * x[5];
-    x[4] = rl<4>(t) * rinv[4];
-    t = e[0] - h[5] * x[5] - h[4] * x[4];
-    x[3] = rl<3>(t) * rinv[3];
-    t = e[0] - h[5] * x[5] - h[4] * x[4] - h[3] * x[3];
-    x[2] = rl<2>(t) * rinv[2];
-    t = e[0] - h[5] * x[5] - h[4] * x[4] - h[3] * x[3] - h[2] * x[2];
-    x[1] = rl<1>(t) * rinv[1];
-    t = e[0] - h[5] * x[5] - h[4] * x[4] - h[3] * x[3] - h[2] * x[2] - h[1] * x[1];
-    x[0] = rl<0>(t) * rinv[0];
-    if (log_abs_det) *log_abs_det = log(piv[0] * piv[1] * piv[2]) + log(piv[3] * piv[4] * piv[5]);
-    return ok;
-}
-
-// Row `lane` of A^-1 (lower triangle mirrored, i.e. exactly symmetric) by Gauss-Jordan on [A | I]; false => not certified.
-__device__ __forceinline__ bool row_inverse_spd(const double* h_in, double* inv_row) {
-    const int lane = threadIdx.x & 63;
-    double h[6], e[6], piv[6], rinv[6];
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        h[j] = h_in[j];
-        e[j] = (lane == j) ? 1.0 : 0.0;
-    }
-    const double dg = fabs(own_diag(h, lane));
-    const double d0 = rl<0>(dg), d1 = rl<1>(dg), d2 = rl<2>(dg), d3 = rl<3>(dg), d4 = rl<4>(dg), d5 = rl<5>(dg);
-    const double maxd = fmax(fmax(fmax(d0, d1), fmax(d2, d3)), fmax(d4, d5));
-    const bool finite = (d0 == d0) && (d1 == d1) && (d2 == d2) && (d3 == d3) && (d4 == d4) && (d5 == d5);
-    const double tol = 1e-10 * maxd;
-    bool ok = finite && maxd > 0.0 && maxd < 1.0e300;
-    RowStep<0>::run<true, 6>(h, e, lane, tol, ok, piv, rinv);
-    RowStep<1>::run<true, 6>(h, e, lane, tol, ok, piv, rinv);
-    RowStep<2>::run<true, 6>(h, e, lane, tol, ok, piv, rinv);
-    RowStep<3>::run<true, 6>(h, e, lane, tol, ok, piv, rinv);
-    RowStep<4>::run<true, 6>(h, e, lane, tol, ok, piv, rinv);
-    RowStep<5>::run<true, 6>(h, e, lane, tol, ok, piv, rinv);
-    double ri = rinv[0];  // the row's own pivot reciprocal
-#pragma unroll
-    for (int j = 1; j < 6; ++j) ri = (lane == j) ? rinv[j] : ri;
-#pragma unroll
-    for (int j = 0; j < 6; ++j) e[j] *= ri;
-    // mirror the lower triangle: element (i, j), j > i, := element (j, i) held by lane j
-    const double m01 = rl<1>(e[0]), m02 = rl<2>(e[0]), m03 = rl<3>(e[0]), m04 = rl<4>(e[0]), m05 = rl<5>(e[0]);
-    const double m12 = rl<2>(e[1]), m13 = rl<3>(e[1]), m14 = rl<4>(e[1]), m15 = rl<5>(e[1]);
-    const double m23 = rl<3>(e[2]), m24 = rl<4>(e[2]), m25 = rl<5>(e[2]);
-    const double m34 = rl<4>(e[3]), m35 = rl<5>(e[3]);
-    const double m45 = rl<5>(e[4]);
-    if (lane == 0) { e[1] = m01; e[2] = m02; e[3] = m03; e[4] = m04; e[5] = m05; }
-    if (lane == 1) { e[2] = m12; e[3] = m13; e[4] = m14; e[5] = m15; }
-    if (lane == 2) { e[3] = m23; e[4] = m24; e[5] = m25; }
-    if (lane == 3) { e[4] = m34; e[5] = m35; }
-    if (lane == 4) { e[5] = m45; }
-#pragma unroll
-    for (int j = 0; j < 6; ++j) inv_row[j] = e[j];
-    return ok;
-}
-
-// pm::spd_unit_certificate on rows: s = row `lane` of the symmetric matrix given by the LOWER triangle of C.
-__device__ __forceinline__ int row_spd_unit_certificate(const double* s_in) {
-    const int lane = threadIdx.x & 63;
-    double h[6], e[1] = {0.0}, piv[6], rinv[6];
-    double rs = 0.0;
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        h[j] = s_in[j];
-        rs += fabs(h[j]);
-    }
-    const double dgs = own_diag(h, lane);
-    double rmax = 0.0, dmax_ = 0.0;
-    {
-        const double r0 = rl<0>(rs), r1 = rl<1>(rs), r2 = rl<2>(rs), r3 = rl<3>(rs), r4 = rl<4>(rs), r5 = rl<5>(rs);
-        const double g0 = rl<0>(dgs), g1 = rl<1>(dgs), g2 = rl<2>(dgs), g3 = rl<3>(dgs), g4 = rl<4>(dgs), g5 = rl<5>(dgs);
-        const double rr[6] = {r0, r1, r2, r3, r4, r5}, gg[6] = {g0, g1, g2, g3, g4, g5};
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {  // the comparison chain of pm::spd_unit_certificate (NaN stays out of the maxima)
-            rmax = rr[i] > rmax ? rr[i] : rmax;
-            dmax_ = gg[i] > dmax_ ? gg[i] : dmax_;
-        }
-        bool nan = false;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) nan = nan || !(rr[i] == rr[i]);
-        if (nan) return 0;
-    }
-    if (!(rmax <= 1.0)) return 0;
-    const double tol = 1e-10 * dmax_;
-    bool ok = dmax_ > 0.0;
-    RowStep<0>::run<false, 0>(h, e, lane, tol, ok, piv, rinv);
-    RowStep<1>::run<false, 0>(h, e, lane, tol, ok, piv, rinv);
-    RowStep<2>::run<false, 0>(h, e, lane, tol, ok, piv, rinv);
-    RowStep<3>::run<false, 0>(h, e, lane, tol, ok, piv, rinv);
-    RowStep<4>::run<false, 0>(h, e, lane, tol, ok, piv, rinv);
-    RowStep<5>::run<false, 0>(h, e, lane, tol, ok, piv, rinv);
-    return ok ? 1 : 0;
-}
-
-// ---- solver sections.  ROW == false: executed by ONE lane (the solver lane of pose_kernel.hip).  ROW == true: executed by
-// EVERY lane of one wave with identical data (pose_kernel2.hip): the scalar logic runs redundantly, the 6x6 systems are
-// solved on rows; LDS stores of identical values from all lanes are benign. ----
+// ---- solver sections: the serial 6x6 routines of pose_math.h.  Executed by ONE lane (the solver lane of pose_kernel.hip) or
+// redundantly by every lane of one wave with identical data (pose_kernel2p.hip: same cost as one lane, every lane then holds the
+// decisions; LDS stores of identical values from all lanes are benign).  A row-distributed variant (lane i = row i, pivot rows
+// through v_readlane) was built for 128-VGPR kernels in round 2 and measured slower (88 k vs 80 k cycles of solver time per
+// frame pair); it went with those kernels in round 4. ----
 
 __device__ __forceinline__ void t0_unpack(PoseSh* sh) {
     int k = 0;
@@ -556,25 +295,16 @@ __device__ __forceinline__ void t0_unpack(PoseSh* sh) {
 
 // H inc = g (ColPivHouseholderQR::solve at :417-418 and siblings): LDL^T when H is certified positive definite
 // (the normal case), the pivoted QR otherwise — see pose_math.h.
-template <bool ROW>
 __device__ __forceinline__ void solve_normal_eq(PoseSh* sh, double* inc, double* log_abs_det) {
-    if (ROW) {
-        const int lane = threadIdx.x & 63, r = lane < 6 ? lane : 0;
-        double h[6];
-#pragma unroll
-        for (int j = 0; j < 6; ++j) h[j] = sh->H[r * 6 + j];
-        if (row_solve_spd(h, sh->g[r], inc, log_abs_det)) return;  // wave-uniform verdict
-    }
     double H[36], g[6];
 #pragma unroll
     for (int i = 0; i < 36; ++i) H[i] = sh->H[i];
 #pragma unroll
     for (int i = 0; i < 6; ++i) g[i] = sh->g[i];
-    if (ROW || !pm::solve6_spd(H, g, inc, log_abs_det)) pm::solve6(H, g, inc, log_abs_det);
+    if (!pm::solve6_spd(H, g, inc, log_abs_det)) pm::solve6(H, g, inc, log_abs_det);
 }
 
 // body of gaussNewtonOptimization after optimizeFunctions (:405-428)
-template <bool ROW>
 __device__ __forceinline__ void t0_gn_iter(PoseSh* sh, double min_error, double min_error_change, int it) {
     t0_unpack(sh);
     const double err = sh->err;
@@ -587,7 +317,7 @@ __device__ __forceinline__ void t0_gn_iter(PoseSh* sh, double min_error, double 
         return;
     }
     double inc[6], DT[16];
-    solve_normal_eq<ROW>(sh, inc, nullptr);
+    solve_normal_eq(sh, inc, nullptr);
 #pragma unroll
     for (int i = 0; i < 16; ++i) DT[i] = sh->DT[i];
     pm::step_pose(DT, inc);
@@ -602,7 +332,6 @@ __device__ __forceinline__ void t0_gn_iter(PoseSh* sh, double min_error, double 
 }
 
 // body of gaussNewtonOptimizationRobust after optimizeFunctionsRobust (:449-467)
-template <bool ROW>
 __device__ __forceinline__ void t0_gnr_iter(PoseSh* sh, double min_error, double min_error_change) {
     t0_unpack(sh);
     const double err = sh->err;
@@ -611,7 +340,7 @@ __device__ __forceinline__ void t0_gnr_iter(PoseSh* sh, double min_error, double
         return;
     }
     double inc[6], DT[16], lad;
-    solve_normal_eq<ROW>(sh, inc, &lad);
+    solve_normal_eq(sh, inc, &lad);
     if (lad < 0.0) {
         sh->good = 0;
         sh->action = ACT_BREAK;
@@ -634,7 +363,6 @@ __device__ __forceinline__ void t0_gnr_iter(PoseSh* sh, double min_error, double
 }
 
 // LM first iteration (:486-510) and loop body (:518-542)
-template <bool ROW>
 __device__ __forceinline__ void t0_lm_iter(PoseSh* sh, double min_error, double min_error_change, int first) {
     t0_unpack(sh);
     const double err = sh->err;
@@ -649,7 +377,7 @@ __device__ __forceinline__ void t0_lm_iter(PoseSh* sh, double min_error, double 
         sh->lambda = 0.000000001 * Hmax;
 #pragma unroll
         for (int i = 0; i < 6; ++i) sh->H[i * 7] += sh->lambda;
-        solve_normal_eq<ROW>(sh, inc, nullptr);
+        solve_normal_eq(sh, inc, nullptr);
 #pragma unroll
         for (int i = 0; i < 16; ++i) DT[i] = sh->DT[i];
         pm::step_pose(DT, inc);
@@ -665,7 +393,7 @@ __device__ __forceinline__ void t0_lm_iter(PoseSh* sh, double min_error, double 
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) sh->H[i * 7] += sh->lambda;
-    solve_normal_eq<ROW>(sh, inc, nullptr);
+    solve_normal_eq(sh, inc, nullptr);
     if (err > sh->err_prev)
         sh->lambda /= 4.0;
     else {
@@ -684,28 +412,11 @@ __device__ __forceinline__ void t0_lm_iter(PoseSh* sh, double min_error, double 
     sh->action = ACT_CONTINUE;
 }
 
-template <bool ROW>
 __device__ __forceinline__ void t0_cov_from_H(PoseSh* sh) {
-    if (ROW) {
-        const int lane = threadIdx.x & 63, r = lane < 6 ? lane : 0;
-        double h[6], ir[6];
-#pragma unroll
-        for (int j = 0; j < 6; ++j) h[j] = sh->H[r * 6 + j];
-        if (row_inverse_spd(h, ir)) {  // wave-uniform verdict
-            if (lane < 6) {
-#pragma unroll
-                for (int j = 0; j < 6; ++j) sh->cov[lane * 6 + j] = ir[j];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            return;
-        }
-    }
     double H[36], Hi[36];
 #pragma unroll
     for (int i = 0; i < 36; ++i) H[i] = sh->H[i];
-    if (ROW || !pm::inverse6_spd(H, Hi)) pm::inverse6(H, Hi);  // Matrix6d::inverse(), :429 / :470 / :545
+    if (!pm::inverse6_spd(H, Hi)) pm::inverse6(H, Hi);  // Matrix6d::inverse(), :429 / :470 / :545
 #pragma unroll
     for (int i = 0; i < 36; ++i) sh->cov[i] = Hi[i];
 }
@@ -724,22 +435,9 @@ __device__ __forceinline__ void t0_is_good(PoseSh* sh, const double* DT, double 
 // Same decision without the eigenvalues (the stage-1 test of :341 only needs the verdict): positive
 // definiteness by LDL^T pivots and lambda_max <= ||.||_inf <= 1 certify the two eigenvalue conditions; anything
 // not certified falls back to the eigen-decomposition the reference performs.
-template <bool ROW>
 __device__ __forceinline__ void t0_is_good_fast(PoseSh* sh, const double* DT, double err) {
     if (err < 0.0 || err > 1.0 || !pm::all_finite16(DT)) {
         sh->good = 0;
-        return;
-    }
-    if (ROW) {
-        const int lane = threadIdx.x & 63, r = lane < 6 ? lane : 0;
-        double srow[6];
-#pragma unroll
-        for (int j = 0; j < 6; ++j) srow[j] = (j <= r) ? sh->cov[r * 6 + j] : sh->cov[j * 6 + r];
-        if (row_spd_unit_certificate(srow) == 1) {
-            sh->good = 1;
-            return;
-        }
-        t0_is_good(sh, DT, err);
         return;
     }
     double C[36];

@@ -119,6 +119,16 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_hist)[Block
             j = a.m12p ? pbase + (size_t)a.m12p[i] : i;
         }
         PointRec r;
+        if (a.prev_rc) {  // compact stereo points of the device-resident pipeline: one 16-byte load per side (kernels.h)
+            const float4 p = a.prev_rc[i], c = a.curr_rc[j];
+            double P[3];
+            pm::back_project(cam_f.b, cam_f.fx, cam_f.cx, cam_f.cy, (double)p.x, (double)p.y, (double)p.z, P);
+            r.X = P[0]; r.Y = P[1]; r.Z = P[2];
+            r.s2 = sqrt(pm::level_sigma2((int)p.w, a.level_scale));
+            r.ox = (double)c.x;
+            r.oy = (double)c.y;
+            return r;
+        }
         r.X = a.prev_P[i * 3 + 0];
         r.Y = a.prev_P[i * 3 + 1];
         r.Z = a.prev_P[i * 3 + 2];
@@ -420,9 +430,9 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_hist)[Block
                 tq = tick();
                 ++evals;
                 if (t0) {
-                    if (alg == 0) t0_gn_iter<false>(sh, prm.min_error, prm.min_error_change, it);
-                    else if (alg == 1) t0_gnr_iter<false>(sh, prm.min_error, prm.min_error_change);
-                    else t0_lm_iter<false>(sh, prm.min_error, prm.min_error_change, it == 0 ? 1 : 0);
+                    if (alg == 0) t0_gn_iter(sh, prm.min_error, prm.min_error_change, it);
+                    else if (alg == 1) t0_gnr_iter(sh, prm.min_error, prm.min_error_change);
+                    else t0_lm_iter(sh, prm.min_error, prm.min_error_change, it == 0 ? 1 : 0);
                 }
                 __syncthreads();
                 tprof[1] += tick() - tq;
@@ -440,7 +450,7 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_hist)[Block
 #pragma unroll
                     for (int i = 0; i < 36; ++i) sh->cov[i] = (i % 7 == 0) ? 1.0 : 0.0;
                 } else {
-                    t0_cov_from_H<false>(sh);  // :429 / :470 / :545 — H of the last evaluation (damped for LM)
+                    t0_cov_from_H(sh);  // :429 / :470 / :545 — H of the last evaluation (damped for LM)
                     sh->err_out = evals > 0 ? sh->err : 0.0;
                 }
             }
@@ -455,7 +465,7 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_hist)[Block
             if (t0) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) sh->DT1[i] = sh->DT[i];
-                t0_is_good_fast<false>(sh, sh->DT1, sh->err_out);
+                t0_is_good_fast(sh, sh->DT1, sh->err_out);
             }
             __syncthreads();
             tprof[2] += tick() - tq2;
@@ -589,27 +599,19 @@ static bool pose_ldsrec_available() {
 
 int launch_pose(hipStream_t s, const PoseArgs& a) {
     if (a.B <= 0) return STVO_OK;
-    // the occupancy-oriented formulation (pose_kernel2.hip) is the default; STVO_POSE_KERNEL=1 selects this file's kernels
-    // (kept as the measured comparison point and exercised by the same parity tests)
-    const char* env = std::getenv("STVO_POSE_KERNEL");  // read per call: the parity tests switch between the two kernels
-    const int which = env ? std::atoi(env) : 0;
-    // default: up to 256 frame pairs this file's latency variant (121 vs 176 us for one pair); larger batches take
-    // pose_kernel2.hip with four waves per pair at 256 VGPRs — every wave a worker, all records in the workgroup's LDS half:
-    // 465 vs 568 us per 1024 points-only pairs, 0.53 vs 0.57 ms inside the pipeline (profiles/r02_pose_variants.txt).
-    // STVO_POSE_KERNEL = 1 / 2 forces one of the two for every batch size.
-    // STVO_POSE_KERNEL = 3: pose_kernel3.hip (two frame pairs per workgroup, owner + evaluator waves) — until it is the measured
-    // default for batches it is opt-in
-    if (which == 3 && !a.eval_only) return launch_pose3(s, a);
-    // batches beyond one frame pair per CU: pose_kernel2p.hip — thread-private records (LDS planes + a coalesced global arena), two
-    // waves per pair at 256 VGPRs, FOUR pairs per CU: 0.43 -> 0.33 ms per 1024 pairs inside the pipeline against pose_kernel2.hip's
-    // four-wave kernel (profiles/r03_pose_variants.txt).  STVO_POSE_KERNEL = 2 / 4 force either for every batch size.
-    if ((which == 4 || (which == 0 && a.B > POSE_LATENCY_MAX_B)) && !a.eval_only) return launch_pose2p(s, a);
-    if (which == 2 || (which == 0 && a.B > POSE_LATENCY_MAX_B)) return launch_pose2(s, a);
+    // Two formulations (round 4: the 128-VGPR / compacted-LDS kernel of round 2 and the owner + evaluator experiment of round 3
+    // are gone — both measured slower than what is here, NOTES.md):
+    //   * up to 256 frame pairs, and for single evaluations (stvo_normal_eq): this file's latency variant — one workgroup per CU,
+    //     seven worker waves + a solver wave, every record resident in LDS (121 us for one pair);
+    //   * larger batches: pose_kernel2p.hip — thread-private records, two waves per pair at 256 VGPRs, four pairs per CU.
+    // STVO_POSE_KERNEL = 1 / 4 (debug_switches.h) force either for every batch size: the parity tests run both everywhere.
+    const int which = dbg().pose_kernel;
+    if (!a.eval_only && (which == 4 || (which != 1 && a.B > POSE_LATENCY_MAX_B))) return launch_pose2p(s, a);
     if (a.max_pts > STVO_POSE_MAX_POINTS || a.max_lines > STVO_POSE_MAX_LINES) return STVO_ERR_CAPACITY;
     const size_t rec_bytes = ((size_t)a.max_pts * 6 + (size_t)a.max_lines * 14) * sizeof(double);
     // throughput variant: two workgroups per CU, each with half of the CU's LDS as record cache — most records are then read
     // from HBM once instead of at every evaluation (the gathers of ~64 co-resident pairs overflow an XCD's 4 MB L2)
-    static const bool lds_t = std::getenv("STVO_POSE_LDS_T") ? std::atoi(std::getenv("STVO_POSE_LDS_T")) != 0 : true;
+    const bool lds_t = dbg().pose_lds_t != 0;  // (unset: on)
     if (a.B <= POSE_LATENCY_MAX_B && rec_bytes <= POSE_LDSREC_MAX_BYTES && pose_ldsrec_available<POSE_BLOCK_L>())
         launch_pose_variant<POSE_BLOCK_L, true>(s, a, POSE_LDSREC_MAX_BYTES);   // one workgroup per CU: records resident in LDS
     else if (a.B <= POSE_LATENCY_MAX_B)

@@ -1,23 +1,27 @@
 // pose_kernel2p.hip — K4/K5/K6, the batch formulation with THREAD-PRIVATE record storage: the whole of
 // StereoFrameHandler::optimizePose (/root/reference/src/stereoFrameHandler.cpp:307-392) in one launch, one workgroup per
-// frame pair, built so that FOUR frame pairs share a CU.
+// frame pair, built so that FOUR frame pairs share a CU (two waves per pair at 256 VGPRs, a 40 KB LDS share).
 //
-// pose_kernel2.hip keeps the matched records of a pair compacted in LDS (80 KB per pair: two pairs per CU).  A pair is a
-// chain of ~13.7 evaluate -> solve rounds with serial sections in which its other waves idle (NOTES.md), so what the CU's FP64
-// pipes do depends on how many independent chains it holds.  Here a thread owns its matched records privately:
-//   * its first K_lds records live in LDS planes [record ordinal][thread] (16-byte parts of neighbouring threads are
-//     neighbours: conflict-free b128 accesses, and no cross-thread compaction — the two block-wide scans of the prologue go);
-//   * the others live in a global arena with the SAME plane layout ([ordinal][part][thread]: a wave's load of one part is one
-//     contiguous 1 KB run) written once at staging and read with a three-deep register ring, the first three requested at the
-//     start of an evaluation and consumed after the LDS-resident records;
-//   * key-lines (~75 per pair, at most one per thread in practice) live in the arena only.
-// With two waves per pair at 256 VGPRs and a 40 KB LDS share, four workgroups fit a CU.  Same contract, same PoseArgs, same
-// arithmetic and association order as pose_kernel2.hip's kernel of the same wave count (thread t owns prev points t + k BLOCK
-// and accumulates them in index order), so the results are bit-identical to it.
+// A pair is a chain of ~13.7 evaluate -> solve rounds with serial sections in which its other waves idle (NOTES.md), so what
+// the CU's FP64 pipes do depends on how many independent chains it holds.  A thread owns prev points t + k BLOCK and numbers
+// its matched records 0, 1, ... in that order (the ORDINAL); record r of thread t lives in LDS planes [r][part][t] — 16-byte
+// parts of neighbouring threads are neighbours: conflict-free wide accesses, no cross-thread compaction, no barrier between
+// staging and use.  Two kernels share the state machine below:
+//   * pose2c_kernel (round 4) — COMPACT records, the device-resident pipeline's format (kernels.h: PoseArgs::prev_rc): a stereo
+//     point is {u, v, disparity, level}; the LDS record is {u, v, ox, oy} as floats + b / disparity as a double = 24 bytes, P is
+//     rebuilt with 2 subtractions + 3 products per use and sqrt(sigma2) comes from a 16-entry table.  TWELVE ordinals fit the
+//     40 KB share (one more stays in registers): every record of the bench shape (~11.6 per thread) is on chip, nothing is
+//     staged through HBM, and a record costs one 16-byte load per side (52 -> 36 bytes of gather per prev point);
+//   * pose2p_kernel (round 3) — the general form for callers that hand over P / sigma2 / observations as doubles
+//     (stvo_track_batched_dev): 48-byte records, the first K_lds ordinals in LDS, the others in a global arena with the same
+//     plane layout, read with a three-deep register ring.
+// Key-lines (~75 per pair, at most one per thread in practice) live in the arena in both.  Same arithmetic and association
+// order in both (a thread accumulates its records in ascending ordinal), so the results agree bit for bit.
 #include <cstdlib>
 
 #include <map>
 #include <mutex>
+#include <utility>
 #include <vector>
 
 #include "pose_block.h"
@@ -37,17 +41,120 @@ struct PointRec2 {
 
 constexpr bool POSE2P_PRIO = true;  // serial sections at wave priority 3 (measured: 239 -> 230 us per 512 pairs with four waves per pair)
 
+// ---------------- the optimizePose state machine (:332-370), shared by both kernels ----------------
+// evaluate(robust): optimizeFunctions[Robust] at sh->DT -> sh->tot (wave 0 holds the totals); remove_outliers(): :988-1067 at
+// sh->DT1.  Every decision is block-uniform (read from LDS after a barrier); wave 0 runs the serial sections.
+struct PoseFlow {
+    int status, path, it0, it1;
+};
+template <typename Eval, typename Rem, typename Tick>
+__device__ __forceinline__ PoseFlow optimize_pose_flow(PoseSh* sh, const stvo_opt_params& prm, const bool w0, Eval&& evaluate,
+                                                       Rem&& remove_outliers, Tick&& tick, long long* tprof) {
+    int status = STVO_POSE_OK, path = 0, it0 = 0, it1 = 0;
+    if (sh->n_inl_p + sh->n_inl_l >= prm.min_features) {
+        int stage = 0;        // 0 = first optimisation (:335-338), 1 = refinement (:345-350), 2 = robust fallback (:359)
+        int alg = prm.mode;   // 0 GN, 1 robust GN, 2 LM
+        int max_it = prm.max_iters;
+        for (;;) {
+            if (w0) {
+                sh->err_prev = 999999999.9;
+                sh->good = 1;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sh->DTr[i] = sh->DT[i];  // robust GN's entry pose (:441)
+            }
+            const int n_it = (alg == 2 && max_it < 1) ? 1 : max_it;  // LM always evaluates once (:493)
+            int evals = 0, action = ACT_BREAK;
+            for (int it = 0; it < n_it; ++it) {
+                long long tq = tick();
+                evaluate(alg == 1);
+                tprof[0] += tick() - tq;
+                tq = tick();
+                ++evals;
+                if (w0) {
+                    // the serial section is one wave's dependent chain while the co-resident workgroup's waves evaluate on the
+                    // same SIMD: let it win the issue arbitration
+                    if (POSE2P_PRIO) __builtin_amdgcn_s_setprio(3);
+                    if (alg == 0) t0_gn_iter(sh, prm.min_error, prm.min_error_change, it);
+                    else if (alg == 1) t0_gnr_iter(sh, prm.min_error, prm.min_error_change);
+                    else t0_lm_iter(sh, prm.min_error, prm.min_error_change, it == 0 ? 1 : 0);
+                    if (POSE2P_PRIO) __builtin_amdgcn_s_setprio(0);
+                }
+                __syncthreads();
+                tprof[1] += tick() - tq;
+                action = sh->action;
+                if (action != ACT_CONTINUE) break;
+            }
+            long long tq2 = tick();
+            if (w0) {
+                if (alg == 0 && action == ACT_FAIL) {
+                    sh->err_out = -1.0;  // :408-409, covariance left untouched
+                } else if (alg == 1 && !sh->good) {  // :473-478
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) sh->DT[i] = sh->DTr[i];
+                    sh->err_out = -1.0;
+#pragma unroll
+                    for (int i = 0; i < 36; ++i) sh->cov[i] = (i % 7 == 0) ? 1.0 : 0.0;
+                } else {
+                    t0_cov_from_H(sh);  // :429 / :470 / :545 — H of the last evaluation (damped for LM)
+                    sh->err_out = evals > 0 ? sh->err : 0.0;
+                }
+            }
+            __syncthreads();
+            tprof[2] += tick() - tq2;
+            if (stage != 0) {
+                it1 = evals;
+                break;
+            }
+            it0 = evals;
+            tq2 = tick();
+            if (w0) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sh->DT1[i] = sh->DT[i];
+                t0_is_good_fast(sh, sh->DT1, sh->err_out);
+            }
+            __syncthreads();
+            tprof[2] += tick() - tq2;
+            if (sh->good) {  // :341
+                path |= STVO_PATH_STAGE1_GOOD;
+                tq2 = tick();
+                remove_outliers();
+                tprof[3] += tick() - tq2;
+                if (sh->n_inl_p + sh->n_inl_l >= prm.min_features) {  // :345 — restart from the INITIAL DT
+                    path |= STVO_PATH_REFINED;
+                    stage = 1;
+                } else {
+                    if (w0) pm::identity4(sh->DT);
+                    status = STVO_POSE_FEW_INLIERS_AFTER;
+                    __syncthreads();
+                    break;
+                }
+            } else {  // :357-362 robust GN on everything, from the initial DT
+                path |= STVO_PATH_ROBUST_FALLBACK;
+                stage = 2;
+                alg = 1;
+            }
+            max_it = prm.max_iters_ref;
+            if (w0) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sh->DT[i] = sh->DT0[i];
+            }
+            __syncthreads();
+        }
+    } else {
+        if (w0) pm::identity4(sh->DT);
+        status = STVO_POSE_FEW_INLIERS_BEFORE;
+        __syncthreads();
+    }
+
+    return PoseFlow{status, path, it0, it1};
+}
+
 // NW waves per frame pair at 256 VGPRs (two waves per SIMD); k_lds record ordinals of every thread live in LDS
 // PROF: the developer's phase-tick instrumentation (tools/pose_probe.py) as its own instantiation — as a run-time flag its ~26
 // live counters cost the production kernel registers across the whole state machine (30 VGPRs spilled at the loop head)
 template <int NW, bool PROF>
 __global__ __launch_bounds__(NW * 64, 2) void pose2p_kernel(PoseArgs a, const int k_lds, double2* arena, const size_t arena_pair) {
-    constexpr int WPE = 2;
     constexpr int BLOCK = NW * 64;
-    // 6x6 systems: on ROWS (row_solve_spd & co., no 36-element arrays per lane) in the 128-VGPR variants; with the serial
-    // routines of pose_math.h, executed redundantly by every lane of wave 0, in the 256-VGPR variant, where the arrays fit and
-    // the serial form is the faster one (80 k vs 88 k cycles of solver time per frame pair)
-    constexpr bool POSE2_ROW = WPE >= 4;
     constexpr int PPT = (STVO_POSE_MAX_POINTS + BLOCK - 1) / BLOCK;
     constexpr int LPT = (STVO_POSE_MAX_LINES + BLOCK - 1) / BLOCK;
     using Ops = BlockOps<NW>;
@@ -442,102 +549,8 @@ __global__ __launch_bounds__(NW * 64, 2) void pose2p_kernel(PoseArgs a, const in
         __syncthreads();
     };
 
-    // ---------------- optimizePose state machine (:332-370), as in pose_kernel.hip ----------------
-    int status = STVO_POSE_OK, path = 0, it0 = 0, it1 = 0;
-    if (sh->n_inl_p + sh->n_inl_l >= prm.min_features) {
-        int stage = 0;        // 0 = first optimisation (:335-338), 1 = refinement (:345-350), 2 = robust fallback (:359)
-        int alg = prm.mode;   // 0 GN, 1 robust GN, 2 LM
-        int max_it = prm.max_iters;
-        for (;;) {
-            if (w0) {
-                sh->err_prev = 999999999.9;
-                sh->good = 1;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) sh->DTr[i] = sh->DT[i];  // robust GN's entry pose (:441)
-            }
-            const int n_it = (alg == 2 && max_it < 1) ? 1 : max_it;  // LM always evaluates once (:493)
-            int evals = 0, action = ACT_BREAK;
-            for (int it = 0; it < n_it; ++it) {
-                long long tq = tick();
-                evaluate(alg == 1);
-                tprof[0] += tick() - tq;
-                tq = tick();
-                ++evals;
-                if (w0) {
-                    // the serial section is one wave's dependent chain while the co-resident workgroup's waves evaluate on the
-                    // same SIMD: let it win the issue arbitration
-                    if (POSE2P_PRIO) __builtin_amdgcn_s_setprio(3);
-                    if (alg == 0) t0_gn_iter<POSE2_ROW>(sh, prm.min_error, prm.min_error_change, it);
-                    else if (alg == 1) t0_gnr_iter<POSE2_ROW>(sh, prm.min_error, prm.min_error_change);
-                    else t0_lm_iter<POSE2_ROW>(sh, prm.min_error, prm.min_error_change, it == 0 ? 1 : 0);
-                    if (POSE2P_PRIO) __builtin_amdgcn_s_setprio(0);
-                }
-                __syncthreads();
-                tprof[1] += tick() - tq;
-                action = sh->action;
-                if (action != ACT_CONTINUE) break;
-            }
-            long long tq2 = tick();
-            if (w0) {
-                if (alg == 0 && action == ACT_FAIL) {
-                    sh->err_out = -1.0;  // :408-409, covariance left untouched
-                } else if (alg == 1 && !sh->good) {  // :473-478
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) sh->DT[i] = sh->DTr[i];
-                    sh->err_out = -1.0;
-#pragma unroll
-                    for (int i = 0; i < 36; ++i) sh->cov[i] = (i % 7 == 0) ? 1.0 : 0.0;
-                } else {
-                    t0_cov_from_H<POSE2_ROW>(sh);  // :429 / :470 / :545 — H of the last evaluation (damped for LM)
-                    sh->err_out = evals > 0 ? sh->err : 0.0;
-                }
-            }
-            __syncthreads();
-            tprof[2] += tick() - tq2;
-            if (stage != 0) {
-                it1 = evals;
-                break;
-            }
-            it0 = evals;
-            tq2 = tick();
-            if (w0) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) sh->DT1[i] = sh->DT[i];
-                t0_is_good_fast<POSE2_ROW>(sh, sh->DT1, sh->err_out);
-            }
-            __syncthreads();
-            tprof[2] += tick() - tq2;
-            if (sh->good) {  // :341
-                path |= STVO_PATH_STAGE1_GOOD;
-                tq2 = tick();
-                remove_outliers();
-                tprof[3] += tick() - tq2;
-                if (sh->n_inl_p + sh->n_inl_l >= prm.min_features) {  // :345 — restart from the INITIAL DT
-                    path |= STVO_PATH_REFINED;
-                    stage = 1;
-                } else {
-                    if (w0) pm::identity4(sh->DT);
-                    status = STVO_POSE_FEW_INLIERS_AFTER;
-                    __syncthreads();
-                    break;
-                }
-            } else {  // :357-362 robust GN on everything, from the initial DT
-                path |= STVO_PATH_ROBUST_FALLBACK;
-                stage = 2;
-                alg = 1;
-            }
-            max_it = prm.max_iters_ref;
-            if (w0) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) sh->DT[i] = sh->DT0[i];
-            }
-            __syncthreads();
-        }
-    } else {
-        if (w0) pm::identity4(sh->DT);
-        status = STVO_POSE_FEW_INLIERS_BEFORE;
-        __syncthreads();
-    }
+    const PoseFlow fl = optimize_pose_flow(sh, prm, w0, evaluate, remove_outliers, tick, tprof);
+    const int status = fl.status, path = fl.path, it0 = fl.it0, it1 = fl.it1;
 
     {
         const long long tq3 = tick();
@@ -571,29 +584,514 @@ __global__ __launch_bounds__(NW * 64, 2) void pose2p_kernel(PoseArgs a, const in
     }
 }
 
+// ======================================================================================================================
+// pose2c_kernel — compact records (PoseArgs::prev_rc / curr_rc).  Thread state: pmatched (bit k: prev point tid + k BLOCK is
+// matched — only for the mask written at the end) and, in ORDINAL space (bit r: the thread's r-th matched record), inl_o
+// (inliers), lv (4-bit pyramid level per ordinal), slow_o (records that are not on chip: ordinals beyond the planes + the one
+// register-resident record, or a level the 16-entry sigma table does not hold — re-gathered at every use, rare by
+// construction: the bench shape has none).
+// ======================================================================================================================
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {  // f(integral_constant<int, I>) for I in [I, N): compile-time ordinals
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+template <int NW>
+constexpr int pose2c_planes() {  // record ordinals per thread in LDS: 12 x 128 x 24 bytes = 36 KB of the 40 KB share (two waves);
+                                 // everything (PPT = 8) with four waves and two pairs per CU
+    return NW == 2 ? 12 : STVO_POSE_MAX_POINTS / (NW * 64);
+}
+
+struct CompactRec {
+    float4 a;   // u, v of the prev stereo point; ox, oy: the matched key-point of the current frame
+    double bd;  // b / disparity
+    double q;   // sqrt(sigma2)
+};
+
+// a record that is not on chip: find the slot of ordinal r, follow the match index, gather both sides
+__device__ __noinline__ CompactRec pose2c_fetch_slow(const float4* prev_rc, const float4* curr_rc, const int32_t* m12p, size_t pbase,
+                                                     int tid, int block, unsigned pmatched, int r, double cam_b, double level_scale) {
+    unsigned m = pmatched;
+    for (int i = 0; i < r; ++i) m &= m - 1u;
+    const size_t i = pbase + (size_t)(tid + __builtin_ctz(m) * block);
+    const size_t j = m12p ? pbase + (size_t)m12p[i] : i;
+    const float4 p = prev_rc[i], c = curr_rc[j];
+    CompactRec rec;
+    rec.a = make_float4(p.x, p.y, c.x, c.y);
+    rec.bd = cam_b / (double)p.z;
+    rec.q = sqrt(pm::level_sigma2((int)p.w, level_scale));
+    return rec;
+}
+
+template <int NW, bool PROF>
+__global__ __launch_bounds__(NW * 64, 2) void pose2c_kernel(PoseArgs a, double2* arena, const size_t arena_pair) {
+    constexpr int BLOCK = NW * 64;
+    constexpr int PPT = (STVO_POSE_MAX_POINTS + BLOCK - 1) / BLOCK;
+    constexpr int LPT = (STVO_POSE_MAX_LINES + BLOCK - 1) / BLOCK;
+    constexpr int KL = pose2c_planes<NW>();
+    constexpr bool HAS_REG = KL < PPT;  // ordinal KL lives in registers
+    static_assert(KL <= PPT && PPT <= 16, "4-bit levels of 16 ordinals in one 64-bit word");
+    using Ops = BlockOps<NW>;
+    extern __shared__ float4 s_ra[];                               // [KL][BLOCK] {u, v, ox, oy}
+    double* const s_rb = reinterpret_cast<double*>(s_ra + KL * BLOCK);  // [KL][BLOCK] b / disparity
+    __shared__ int s_hist[2][Ops::HIST_W];
+    __shared__ double s_red[NW][28];
+    __shared__ int s_ired[NW];
+    __shared__ PoseSh s_sh;
+    PoseSh* sh = &s_sh;
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const bool w0 = wv == 0, t0 = tid == 0;
+    long long tprof[5] = {0, 0, 0, 0, 0};
+    long long wprof[3] = {0, 0, 0}, wave_busy = 0;
+    auto tick = [&]() -> long long {
+        if constexpr (PROF) return (long long)__builtin_readcyclecounter();
+        else return 0ll;
+    };
+    const long long t_begin = tick();
+    const stvo_cam cam_f = a.cams ? a.cams[f] : a.cam;
+    const pm::Cam5 cam{cam_f.fx, cam_f.fy, cam_f.cx, cam_f.cy};
+    const double cam_b = cam_f.b;
+    const stvo_opt_params prm = a.prm;
+
+    // ---------------- ownership (as pose2p_kernel): thread t owns prev points t + k BLOCK and prev line BLOCK - 1 - t ----------------
+    unsigned pmatched = 0u, pinl = 0u;
+    const int n_prev_p = a.n_prev_pts != nullptr ? min(a.n_prev_pts[f], a.max_pts) : 0;
+    const size_t pbase = (size_t)f * a.max_pts;
+    int jj[PPT];
+    {
+        int init[PPT];
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int i = tid + k * BLOCK;
+            const int ic = i < n_prev_p ? i : 0;
+            jj[k] = a.m12p ? a.m12p[pbase + ic] : ic;
+            init[k] = a.init_inl_p ? a.init_inl_p[pbase + ic] : 1;
+        }
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int i = tid + k * BLOCK;
+            if (i < n_prev_p && jj[k] >= 0) {
+                pmatched |= 1u << k;
+                if (init[k] != 0) pinl |= 1u << k;
+            } else {
+                jj[k] = 0;
+            }
+        }
+    }
+    unsigned lmatched = 0u, linl = 0u;
+    const int n_prev_l = (a.n_prev_lines != nullptr && a.max_lines > 0) ? a.n_prev_lines[f] : 0;
+    const size_t lbase = (size_t)f * a.max_lines;
+    const int li0 = BLOCK - 1 - tid;
+    int jl[LPT];
+    {
+        int initl[LPT];
+#pragma unroll
+        for (int k = 0; k < LPT; ++k) {
+            const int li = li0 + k * BLOCK;
+            const int lc = (li < n_prev_l && li < a.max_lines) ? li : 0;
+            jl[k] = (a.m12l && a.max_lines > 0) ? a.m12l[lbase + lc] : lc;
+            initl[k] = (a.init_inl_l && a.max_lines > 0) ? a.init_inl_l[lbase + lc] : 1;
+        }
+#pragma unroll
+        for (int k = 0; k < LPT; ++k) {
+            const int li = li0 + k * BLOCK;
+            if (li < n_prev_l && li < a.max_lines && jl[k] >= 0) {
+                lmatched |= 1u << k;
+                if (initl[k] != 0) linl |= 1u << k;
+            } else {
+                jl[k] = 0;
+            }
+        }
+    }
+    const int n_mine = __popc(pmatched);
+    const int n_m_p = Ops::template sum_int<true>(n_mine, s_ired);
+    const int n_m_l = Ops::template sum_int<true>(__popc(lmatched), s_ired);
+
+    // ---------------- staging: every matched record of the thread, once, ordinal by ordinal ----------------
+    const unsigned m_o = n_mine >= 32 ? 0xFFFFFFFFu : ((1u << n_mine) - 1u);
+    unsigned inl_o = 0u, slow_o = 0u;
+    unsigned long long lv = 0ull;
+    float4 xa = make_float4(0.f, 0.f, 0.f, 0.f);
+    double xb = 1.0;
+    {
+        int r = 0;
+        constexpr int STAGE_CH = PPT < 8 ? PPT : 8;
+#pragma unroll
+        for (int k0 = 0; k0 < PPT; k0 += STAGE_CH) {
+            float4 pv[STAGE_CH], cv[STAGE_CH];
+#pragma unroll
+            for (int c = 0; c < STAGE_CH; ++c) {  // unconditional loads from clamped (valid) addresses: all in flight at once
+                const int k = k0 + c;
+                if (k >= PPT) continue;
+                const int ik = tid + k * BLOCK;
+                pv[c] = a.prev_rc[pbase + (size_t)(ik < n_prev_p ? ik : 0)];
+                cv[c] = a.curr_rc[pbase + (size_t)jj[k]];
+            }
+#pragma unroll
+            for (int c = 0; c < STAGE_CH; ++c) {
+                const int k = k0 + c;
+                if (k >= PPT) continue;
+                if ((pmatched >> k) & 1u) {
+                    const int level = (int)pv[c].w;
+                    const bool in_tab = level >= 0 && level < STVO_POSE_QTAB - 1;
+                    const float4 av = make_float4(pv[c].x, pv[c].y, cv[c].x, cv[c].y);
+                    const double bd = cam_b / (double)pv[c].z;  // backProjection's quotient (src/pinholeStereoCamera.cpp:224)
+                    if (r < KL) {
+                        s_ra[r * BLOCK + tid] = av;
+                        s_rb[r * BLOCK + tid] = bd;
+                    } else if (HAS_REG && r == KL) {
+                        xa = av;
+                        xb = bd;
+                    }
+                    lv |= (unsigned long long)(in_tab ? level : STVO_POSE_QTAB - 1) << (4 * r);
+                    if (r > (HAS_REG ? KL : KL - 1) || !in_tab) slow_o |= 1u << r;
+                    if ((pinl >> k) & 1u) inl_o |= 1u << r;
+                    ++r;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // the number of LDS planes any lane of this WAVE uses: the trip count of the evaluation loops (wave-uniform, an SGPR)
+    int n_trip = n_mine < KL ? n_mine : KL;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) n_trip = max(n_trip, __shfl_xor(n_trip, off, 64));
+    n_trip = __builtin_amdgcn_readfirstlane(n_trip);
+
+    // key-lines: the arena, plane layout [ordinal][7 parts][thread] (as pose2p_kernel)
+    double2* ar_l = arena + (size_t)f * arena_pair;
+    auto load_line = [&](int k) -> pm::LineRec {
+        int r = __popc(lmatched & ((1u << k) - 1u));
+        asm volatile("" : "+v"(r));  // no hoisted 64-bit addresses across the iteration loop
+        const double2* q = ar_l + (size_t)(r * 7) * BLOCK + tid;
+        pm::LineRec L;
+        const double2 v0 = q[0], v1 = q[BLOCK], v2 = q[2 * BLOCK], v3 = q[3 * BLOCK], v4 = q[4 * BLOCK], v5 = q[5 * BLOCK], v6 = q[6 * BLOCK];
+        L.sP[0] = v0.x; L.sP[1] = v0.y; L.sP[2] = v1.x; L.eP[0] = v1.y; L.eP[1] = v2.x; L.eP[2] = v2.y;
+        L.le[0] = v3.x; L.le[1] = v3.y; L.le[2] = v4.x; L.spl[0] = v4.y; L.spl[1] = v5.x; L.epl[0] = v5.y; L.epl[1] = v6.x;
+        L.sigma2 = v6.y;
+        return L;
+    };
+#pragma unroll
+    for (int k = 0; k < LPT; ++k)
+        if ((lmatched >> k) & 1u) {
+            const size_t i = lbase + (size_t)(li0 + k * BLOCK);
+            const size_t j = lbase + (size_t)jl[k];
+            const int r = __popc(lmatched & ((1u << k) - 1u));
+            double2* q = ar_l + (size_t)(r * 7) * BLOCK + tid;
+            q[0] = make_double2(a.prev_sP[i * 3 + 0], a.prev_sP[i * 3 + 1]);
+            q[BLOCK] = make_double2(a.prev_sP[i * 3 + 2], a.prev_eP[i * 3 + 0]);
+            q[2 * BLOCK] = make_double2(a.prev_eP[i * 3 + 1], a.prev_eP[i * 3 + 2]);
+            q[3 * BLOCK] = make_double2(a.curr_le[j * 3 + 0], a.curr_le[j * 3 + 1]);
+            q[4 * BLOCK] = make_double2(a.curr_le[j * 3 + 2], a.prev_spl[i * 2 + 0]);
+            q[5 * BLOCK] = make_double2(a.prev_spl[i * 2 + 1], a.prev_epl[i * 2 + 0]);
+            q[6 * BLOCK] = make_double2(a.prev_epl[i * 2 + 1], sqrt(a.prev_s2l[i]));  // the record carries sqrt(sigma2) (pm::line_term_q)
+        }
+    // (a thread reads back only what it wrote itself: program order is enough, no fence)
+
+    {
+        const int nip = Ops::template sum_int<true>(__popc(inl_o), s_ired);
+        const int nil = Ops::template sum_int<true>(__popc(linl), s_ired);
+        if (w0) {
+            sh->n_m_p = n_m_p;
+            sh->n_m_l = n_m_l;
+            sh->n_inl_p = nip;
+            sh->n_inl_l = nil;
+            sh->good = 1;
+            sh->err_out = -1.0;  // :313
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const double v = a.init_T ? a.init_T[(size_t)f * 16 + i] : ((i % 5 == 0) ? 1.0 : 0.0);
+                sh->DT[i] = v;
+                sh->DT0[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < 36; ++i) {
+                sh->cov[i] = 0.0;
+                sh->H[i] = 0.0;
+            }
+        }
+        __syncthreads();
+    }
+    const long long t_prologue = tick() - t_begin;
+
+    // ---------------- record access ----------------
+    // P = backProjection(u, v, disparity) from the record: the two subtractions and three products of
+    // src/pinholeStereoCamera.cpp:225-227 on the stored quotient — what point_tail_write computed when the pair was built
+    auto rebuild = [&](const float4& av, double bd, double* X, double* Y, double* Z, double* ox, double* oy) {
+#pragma clang fp contract(off)
+        *X = bd * ((double)av.x - cam_f.cx);
+        *Y = bd * ((double)av.y - cam_f.cy);
+        *Z = bd * cam_f.fx;
+        *ox = (double)av.z;
+        *oy = (double)av.w;
+    };
+    auto q_of = [&](unsigned nib) -> double { return a.q_tab[nib]; };
+    auto fetch_slow = [&](int r) -> CompactRec {
+        return pose2c_fetch_slow(a.prev_rc, a.curr_rc, a.m12p, pbase, tid, BLOCK, pmatched, r, cam_b, a.level_scale);
+    };
+    // record ordinal R (compile-time) of this thread, wherever it lives
+    auto fetch = [&](auto rc) -> CompactRec {
+        constexpr int R = decltype(rc)::value;
+        CompactRec rec;
+        if ((slow_o >> R) & 1u) return fetch_slow(R);
+        if constexpr (R < KL) {
+            rec.a = s_ra[R * BLOCK + tid];
+            rec.bd = s_rb[R * BLOCK + tid];
+        } else {
+            rec.a = xa;
+            rec.bd = xb;
+        }
+        rec.q = q_of((unsigned)(lv >> (4 * R)) & 15u);
+        return rec;
+    };
+    auto residual_of = [&](const double* DT, const CompactRec& rec) -> double {
+        double X, Y, Z, ox, oy;
+        rebuild(rec.a, rec.bd, &X, &Y, &Z, &ox, &oy);
+        return pm::point_residual(DT, cam, X, Y, Z, ox, oy);
+    };
+    // residual norms of the records in `mask` (ordinal space), by ordinal; scaled by sqrt(sigma2) when `weighted`
+    auto residuals = [&](const double* DT, unsigned mask, bool weighted, double* res) {
+        auto one = [&](auto rc) {
+            constexpr int R = decltype(rc)::value;
+            res[R] = 0.0;
+            if ((mask >> R) & 1u) {
+                const CompactRec rec = fetch(rc);
+                const double n = residual_of(DT, rec);
+                res[R] = weighted ? n * rec.q : n;
+            }
+        };
+        static_for<0, PPT>(one);
+    };
+
+    // ---------------- optimizeFunctions / optimizeFunctionsRobust at sh->DT ----------------
+    auto pose_sgpr = [&](const double* src, double* DT) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) DT[i] = uni(src[i]);
+    };
+    auto evaluate = [&](bool robust) {
+        double DT[12];
+        pose_sgpr(sh->DT, DT);
+        double sp = 1.0, sl = 1.0;
+        if (robust) {  // pre-pass :710-781: MAD scale of the inlier residual norms
+            double rp[PPT];
+            residuals(DT, inl_o, false, rp);
+            sp = pm::clamp_scale(Ops::template mad_sigma<PPT, true>(rp, inl_o, sh->n_inl_p, s_hist, &sh->xchg));
+            double rlv[LPT];
+#pragma unroll
+            for (int k = 0; k < LPT; ++k) {
+                rlv[k] = 0.0;
+                if ((linl >> k) & 1u) rlv[k] = pm::line_residual(DT, cam, load_line(k));
+            }
+            sl = pm::clamp_scale(Ops::template mad_sigma<LPT, true>(rlv, linl, sh->n_inl_l, s_hist, &sh->xchg));
+        }
+        const long long tw0 = tick();
+        double acc[28];
+#pragma unroll
+        for (int i = 0; i < 28; ++i) acc[i] = 0.0;
+        auto term = [&](const float4& av, double bd, double q) {
+            double X, Y, Z, ox, oy;
+            rebuild(av, bd, &X, &Y, &Z, &ox, &oy);
+            pm::point_term_q(acc, DT, cam, prm.homog_th, X, Y, Z, ox, oy, q, robust, sp);
+        };
+        {
+            // the thread's first inlier line is requested first (global memory), the points run while it is in flight
+            pm::LineRec L0{};
+            int kl0 = -1;
+            if (linl) {
+                kl0 = __builtin_ctz(linl);
+                L0 = load_line(kl0);
+            }
+            // LDS planes, ascending ordinal, one record ahead; the plane pointers advance by a constant
+            const unsigned hot = inl_o & ~slow_o;
+            const float4* pa = s_ra + tid;
+            const double* pb = s_rb + tid;
+            float4 av = pa[0];
+            double bd = pb[0], q = q_of((unsigned)lv & 15u);
+            unsigned long long lvr = lv >> 4;
+            for (int r = 0; r < n_trip; ++r) {
+                const int rn = r + 1 < KL ? r + 1 : r;
+                const float4 avn = pa[rn * BLOCK];
+                const double bdn = pb[rn * BLOCK], qn = q_of((unsigned)lvr & 15u);
+                lvr >>= 4;
+                if ((hot >> r) & 1u) term(av, bd, q);
+                av = avn;
+                bd = bdn;
+                q = qn;
+            }
+            if constexpr (HAS_REG) {
+                if ((hot >> KL) & 1u) term(xa, xb, q_of((unsigned)(lv >> (4 * KL)) & 15u));
+            }
+            unsigned slow = inl_o & slow_o;  // off-chip records (none in the usual shapes), still in ascending ordinal
+            while (slow) {
+                const int r = __builtin_ctz(slow);
+                slow &= slow - 1u;
+                const CompactRec rec = fetch_slow(r);
+                term(rec.a, rec.bd, rec.q);
+            }
+            if (kl0 >= 0) pm::line_term_q(acc, DT, cam, prm.homog_th, L0, robust, sl);
+#pragma unroll 1
+            for (int k = 0; k < LPT; ++k)
+                if (((linl >> k) & 1u) && k != kl0) {
+                    const pm::LineRec L = load_line(k);
+                    pm::line_term_q(acc, DT, cam, prm.homog_th, L, robust, sl);
+                }
+        }
+        const long long tw1 = tick();
+        Ops::template sum28_fold<true>(acc, s_red);
+        const long long tw2 = tick();
+        wave_busy += tw2 - tw0;
+        __syncthreads();
+        if (w0) {  // wave partials summed in wave order => bit-reproducible
+            if (lane < 28) {
+                double sum = s_red[0][lane];
+#pragma unroll
+                for (int w = 1; w < NW; ++w) sum += s_red[w][lane];
+                sh->tot[lane] = sum;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        wprof[0] += tw1 - tw0;
+        wprof[1] += tw2 - tw1;
+        wprof[2] += tick() - tw2;
+    };
+
+    // ---------------- removeOutliers at pose DT1 (:988-1067) ----------------
+    auto remove_outliers = [&]() {
+        double DT[12];
+        pose_sgpr(sh->DT1, DT);
+        if (prm.has_points) {
+            double res[PPT];
+            const int tot = sh->n_m_p;
+            residuals(DT, m_o, true, res);  // ALL matches, current outliers included (:998-1005)
+            const double stdv = Ops::template mad_sigma<PPT, true>(res, m_o, tot, s_hist, &sh->xchg);
+            double v[3] = {0.0, 0.0, 0.0};  // mean of the samples below 2 sigma, or of all samples (src/auxiliar.cpp:405-427)
+#pragma unroll
+            for (int r = 0; r < PPT; ++r)
+                if ((m_o >> r) & 1u) {
+                    if (res[r] < 2.0 * stdv) {
+                        v[0] += res[r];
+                        v[1] += 1.0;
+                    }
+                    v[2] += res[r];
+                }
+            double t[3];
+            Ops::template sum_small<3, true>(v, s_red, t);
+            double mean = 0.0;
+            if (tot != 0) {
+                const int ksel = (int)t[1];
+                mean = (ksel >= (int)(0.2 * (double)tot)) ? t[0] / (double)ksel : t[2] / (double)tot;
+            }
+            const double th = prm.inlier_k * stdv;
+#pragma unroll
+            for (int r = 0; r < PPT; ++r)
+                if (((inl_o >> r) & 1u) && fabs(res[r] - mean) > th) inl_o &= ~(1u << r);
+            const int nip = Ops::template sum_int<true>(__popc(inl_o), s_ired);
+            if (w0) sh->n_inl_p = nip;
+        }
+        if (prm.has_lines) {
+            double res[LPT];
+            const int tot = sh->n_m_l;
+#pragma unroll
+            for (int k = 0; k < LPT; ++k) {
+                res[k] = 0.0;
+                if ((lmatched >> k) & 1u) {
+                    const pm::LineRec L = load_line(k);
+                    res[k] = pm::line_residual(DT, cam, L) * L.sigma2;  // L.sigma2 = sqrt(sigma2)
+                }
+            }
+            const double stdv = Ops::template mad_sigma<LPT, true>(res, lmatched, tot, s_hist, &sh->xchg);
+            double v[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+            for (int k = 0; k < LPT; ++k)
+                if ((lmatched >> k) & 1u) {
+                    if (res[k] < 2.0 * stdv) {
+                        v[0] += res[k];
+                        v[1] += 1.0;
+                    }
+                    v[2] += res[k];
+                }
+            double t[3];
+            Ops::template sum_small<3, true>(v, s_red, t);
+            double mean = 0.0;
+            if (tot != 0) {
+                const int ksel = (int)t[1];
+                mean = (ksel >= (int)(0.2 * (double)tot)) ? t[0] / (double)ksel : t[2] / (double)tot;
+            }
+            const double th = prm.inlier_k * stdv;
+#pragma unroll
+            for (int k = 0; k < LPT; ++k)
+                if (((linl >> k) & 1u) && fabs(res[k] - mean) > th) linl &= ~(1u << k);
+            const int nil = Ops::template sum_int<true>(__popc(linl), s_ired);
+            if (w0) sh->n_inl_l = nil;
+        }
+        __syncthreads();
+    };
+
+    const PoseFlow fl = optimize_pose_flow(sh, prm, w0, evaluate, remove_outliers, tick, tprof);
+
+    {
+        const long long tq3 = tick();
+        if (t0) t0_commit(sh, a.results + f, fl.status, fl.path, fl.it0, fl.it1);
+        tprof[2] += tick() - tq3;
+    }
+    if (PROF && t0) {
+        tprof[4] = tick() - t_begin;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) a.prof_out[(size_t)f * 16 + i] = tprof[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) a.prof_out[(size_t)f * 16 + 5 + i] = wprof[i];
+        a.prof_out[(size_t)f * 16 + 14] = t_prologue;
+    }
+    if (PROF && lane == 0 && (wv < 6 || wv == NW - 1)) a.prof_out[(size_t)f * 16 + 8 + (wv < 6 ? wv : 7)] = wave_busy;
+
+    if (a.inl_p_out) {  // back to slots: prev point tid + k BLOCK is the thread's popc(pmatched below k)-th record
+        const size_t base = (size_t)f * a.max_pts;
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int i = tid + k * BLOCK;
+            const int r = __popc(pmatched & ((1u << k) - 1u));
+            if (i < a.max_pts) a.inl_p_out[base + i] = ((pmatched >> k) & 1u) ? (int)((inl_o >> r) & 1u) : -1;
+        }
+    }
+    if (a.inl_l_out && a.max_lines > 0) {
+#pragma unroll
+        for (int k = 0; k < LPT; ++k) {
+            const int li = li0 + k * BLOCK;
+            if (li < a.max_lines) a.inl_l_out[(size_t)f * a.max_lines + li] = ((lmatched >> k) & 1u) ? (int)((linl >> k) & 1u) : -1;
+        }
+    }
+}
+
 struct ArenaBuf {
     double2* dev = nullptr;
     size_t bytes = 0;
+    int users = 0;               // contexts that hold the stream (pose2p_retain_stream); the buffer goes with the last one
     std::vector<void*> retired;  // superseded blocks: kept until the stream is released (a captured step graph may hold the address)
 };
 
 std::mutex g_arena_mu;
 std::map<std::pair<int, hipStream_t>, ArenaBuf> g_arenas;
 
-// the record arena of a (device, stream): grown on demand, never shrunk (B pairs x ~152 KB); pose2p_release_stream frees it
-ArenaBuf* arena_buf(hipStream_t s, size_t bytes) {
+// the record arena of a (device, stream): grown on demand, never shrunk; the last pose2p_release_stream frees it.  Returns the
+// block itself (read under the lock): callers never hold a pointer into the map.
+double2* arena_ptr(hipStream_t s, size_t bytes) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     std::lock_guard<std::mutex> lk(g_arena_mu);
     ArenaBuf& b = g_arenas[std::make_pair(dev, s)];
-    if (b.bytes < bytes) {
+    if (b.bytes < bytes || !b.dev) {
         if (b.dev) b.retired.push_back(b.dev);
         b.dev = nullptr;
         b.bytes = 0;
-        if (hipMalloc((void**)&b.dev, bytes) != hipSuccess) return nullptr;
+        if (hipMalloc((void**)&b.dev, bytes > 256 ? bytes : 256) != hipSuccess) return nullptr;
         b.bytes = bytes;
     }
-    return &b;
+    return b.dev;
 }
 
 template <int NW>
@@ -606,31 +1104,60 @@ int launch_pose2p_variant(hipStream_t s, const PoseArgs& a, int wgs_per_cu) {
     constexpr int BLOCK = NW * 64;
     constexpr int PPT = (STVO_POSE_MAX_POINTS + BLOCK - 1) / BLOCK, LPT = (STVO_POSE_MAX_LINES + BLOCK - 1) / BLOCK;
     // LDS planes: as many record ordinals per thread as the workgroup's share of the CU's 160 KB holds (a plane of one ordinal
-    // is BLOCK x 48 bytes); STVO_POSE2P_KLDS overrides (developer)
+    // is BLOCK x 48 bytes)
     const int share = (160 * 1024) / wgs_per_cu - pose2p_static_lds<NW>();
     int k_lds = share / (BLOCK * 48);
-    if (const char* e = std::getenv("STVO_POSE2P_KLDS")) k_lds = std::atoi(e);
     k_lds = k_lds < 0 ? 0 : (k_lds > PPT ? PPT : k_lds);
     const int lds = k_lds * BLOCK * 48;
     const bool prof = a.prof_out != nullptr;
     const void* kfn = prof ? reinterpret_cast<const void*>(&pose2p_kernel<NW, true>) : reinterpret_cast<const void*>(&pose2p_kernel<NW, false>);
     if (lds > 48 * 1024 && !lds_opt_in(kfn, lds)) return STVO_ERR_CAPACITY;
     const size_t pair_d2 = (size_t)(PPT * 3 + LPT * 7) * BLOCK;
-    ArenaBuf* ab = arena_buf(s, (size_t)a.B * pair_d2 * sizeof(double2));
+    double2* ab = arena_ptr(s, (size_t)a.B * pair_d2 * sizeof(double2));
     if (!ab) return STVO_ERR_HIP;
-    if (prof) hipLaunchKernelGGL((pose2p_kernel<NW, true>), dim3(a.B), dim3(BLOCK), (size_t)lds, s, a, k_lds, ab->dev, pair_d2);
-    else hipLaunchKernelGGL((pose2p_kernel<NW, false>), dim3(a.B), dim3(BLOCK), (size_t)lds, s, a, k_lds, ab->dev, pair_d2);
+    if (prof) hipLaunchKernelGGL((pose2p_kernel<NW, true>), dim3(a.B), dim3(BLOCK), (size_t)lds, s, a, k_lds, ab, pair_d2);
+    else hipLaunchKernelGGL((pose2p_kernel<NW, false>), dim3(a.B), dim3(BLOCK), (size_t)lds, s, a, k_lds, ab, pair_d2);
+    return STVO_OK;
+}
+
+// the compact-record kernel: KL planes of BLOCK x 24 bytes; the arena holds the key-lines only
+template <int NW>
+int launch_pose2c_variant(hipStream_t s, const PoseArgs& a, int wgs_per_cu) {
+    constexpr int BLOCK = NW * 64;
+    constexpr int LPT = (STVO_POSE_MAX_LINES + BLOCK - 1) / BLOCK;
+    constexpr int lds = pose2c_planes<NW>() * BLOCK * 24;
+    static_assert(lds + pose2p_static_lds<NW>() <= (160 * 1024) / (NW == 2 ? 4 : 2), "the planes must leave room for the co-resident pairs");
+    (void)wgs_per_cu;
+    const bool prof = a.prof_out != nullptr;
+    const void* kfn = prof ? reinterpret_cast<const void*>(&pose2c_kernel<NW, true>) : reinterpret_cast<const void*>(&pose2c_kernel<NW, false>);
+    if (lds > 48 * 1024 && !lds_opt_in(kfn, lds)) return STVO_ERR_CAPACITY;
+    const size_t pair_d2 = (size_t)(LPT * 7) * BLOCK;
+    double2* ab = arena_ptr(s, (size_t)a.B * pair_d2 * sizeof(double2));
+    if (!ab) return STVO_ERR_HIP;
+    if (prof) hipLaunchKernelGGL((pose2c_kernel<NW, true>), dim3(a.B), dim3(BLOCK), (size_t)lds, s, a, ab, pair_d2);
+    else hipLaunchKernelGGL((pose2c_kernel<NW, false>), dim3(a.B), dim3(BLOCK), (size_t)lds, s, a, ab, pair_d2);
     return STVO_OK;
 }
 
 }  // namespace
 
-void pose2p_release_stream(hipStream_t s) {  // the caller has synchronised the stream
+// A context that adopts a stream (its own, a borrowed one, the NULL stream) retains the stream's arena and releases it when it
+// lets go; the blocks are freed with the LAST holder, so contexts that share a user stream (bench.py: torch's current stream) do
+// not free each other's scratch.  The releasing caller has synchronised the stream and made its device current.
+void pose2p_retain_stream(hipStream_t s) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    std::lock_guard<std::mutex> lk(g_arena_mu);
+    ++g_arenas[std::make_pair(dev, s)].users;
+}
+
+void pose2p_release_stream(hipStream_t s) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return;
     std::lock_guard<std::mutex> lk(g_arena_mu);
     const auto it = g_arenas.find(std::make_pair(dev, s));
     if (it == g_arenas.end()) return;
+    if (--it->second.users > 0) return;
     if (it->second.dev) (void)hipFree(it->second.dev);
     for (void* p : it->second.retired) (void)hipFree(p);
     g_arenas.erase(it);
@@ -638,15 +1165,14 @@ void pose2p_release_stream(hipStream_t s) {  // the caller has synchronised the 
 
 int launch_pose2p(hipStream_t s, const PoseArgs& a) {
     if (a.B <= 0) return STVO_OK;
-    if (a.max_pts > STVO_POSE_MAX_POINTS || a.max_lines > STVO_POSE_MAX_LINES) return STVO_ERR_CAPACITY;
-    if (a.eval_only) return launch_pose2(s, a);
+    if (a.max_pts > STVO_POSE_MAX_POINTS || a.max_lines > STVO_POSE_MAX_LINES || a.eval_only) return STVO_ERR_CAPACITY;
+    if (a.prev_rc && (!a.curr_rc || !a.q_tab)) return STVO_ERR_INVALID_ARG;
     // waves per frame pair: two (four pairs per CU) once the batch holds more than two pairs per CU, four (two pairs per CU,
     // half as many records per thread) below that — with 512 pairs on 256 CUs the two-wave variant leaves half of every CU's
     // wave slots empty (configs[3] leg, 512 streams: 701 k vs 774 k frame pairs/s).  STVO_POSE2P_NW overrides (developer).
-    const char* env = std::getenv("STVO_POSE2P_NW");
-    const int nw = env ? std::atoi(env) : (a.B > 2 * device_cu_count() ? 2 : 4);
-    if (nw >= 4) return launch_pose2p_variant<4>(s, a, 2);
-    return launch_pose2p_variant<2>(s, a, 4);
+    const int nw = dbg().pose2p_nw != DBG_UNSET && dbg().pose2p_nw > 0 ? dbg().pose2p_nw : (a.B > 2 * device_cu_count() ? 2 : 4);
+    if (a.prev_rc) return nw >= 4 ? launch_pose2c_variant<4>(s, a, 2) : launch_pose2c_variant<2>(s, a, 4);
+    return nw >= 4 ? launch_pose2p_variant<4>(s, a, 2) : launch_pose2p_variant<2>(s, a, 4);
 }
 
 }  // namespace stvo

@@ -925,6 +925,23 @@ PM_HD double point_residual(const double* DT, const Cam5& cam, double X, double 
     return sqrt(dx * dx + dy * dy);
 }
 
+// ---- compact stereo points of the device-resident pipeline: {u, v, disparity as floats, pyramid level} ----
+// The reference builds a PointFeature from exactly these (src/stereoFrame.cpp:152-167: float key-point coordinates, a float
+// difference, backProjection of the three, sigma2 from the octave), so P and sigma2 are functions of 13 bytes; the pipeline
+// stores those and the pose kernels recompute.  Operations and their order are the reference's (src/pinholeStereoCamera.cpp:
+// 221-229, src/stereoFeatures.cpp:41-47); none of them can contract into an FMA.
+PM_HD void back_project(double b, double fx, double cx, double cy, double u, double v, double disp, double* P) {
+    const double bd = b / disp;
+    P[0] = bd * (u - cx);
+    P[1] = bd * (v - cy);
+    P[2] = bd * fx;
+}
+PM_HD double level_sigma2(int level, double scale) {
+    double sg = 1.0;
+    for (int q = 0; q < level; ++q) sg *= scale;
+    return 1.0 / (sg * sg);
+}
+
 // One point of optimizeFunctions (robust == false: r = |e| sqrt(sigma2), w = Cauchy(r);
 // robust == true: r = |e|, w = Cauchy(r / s_p)).
 PM_HD void point_term(double* acc, const double* DT, const Cam5& cam, double homog_th, double X, double Y, double Z,

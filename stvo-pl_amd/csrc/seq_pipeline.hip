@@ -72,9 +72,7 @@ struct SeqDev {
     const int32_t* m12s_p;  // [B][K] stereo matches of the left points
     const int32_t* m12s_l;  // [B][M]
     // stereo set being built (curr)
-    double* pl;     // [B][K][2]
-    double* P;      // [B][K][3]
-    double* s2;     // [B][K]
+    float4* rc;     // [B][K] {u, v, disparity, level}: the stereo point (point_tail.h)
     uint8_t* desc;  // [B][K][32]
     int32_t* n;     // [B]
     double* spl;    // [B][M][2]
@@ -251,8 +249,8 @@ constexpr int TAIL_BLOCK = 1024;
 __host__ __device__ __forceinline__ PointTail point_tail_args(const SeqDev& s) {
     PointTail t;
     t.kp_l = s.kp_l; t.kp_r = s.kp_r; t.oct_l = s.oct_l; t.desc_l = s.desc_l; t.cams = s.cams;
-    t.max_dist_epip = s.mp.max_dist_epip; t.min_disp = s.mp.min_disp; t.orb_scale_factor = s.mp.orb_scale_factor;
-    t.pl = s.pl; t.P = s.P; t.s2 = s.s2; t.desc = s.desc; t.n = s.n; t.host_n = s.host_n; t.nl = s.nl; t.zero_nl = s.zero_nl;
+    t.max_dist_epip = s.mp.max_dist_epip; t.min_disp = s.mp.min_disp;
+    t.rc = s.rc; t.desc = s.desc; t.n = s.n; t.host_n = s.host_n; t.nl = s.nl; t.zero_nl = s.zero_nl;
     return t;
 }
 __global__ __launch_bounds__(TAIL_BLOCK) void point_tail_kernel(SeqDev s) {
@@ -261,7 +259,6 @@ __global__ __launch_bounds__(TAIL_BLOCK) void point_tail_kernel(SeqDev s) {
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nl = s.n_kp_l[b];
     const size_t off = (size_t)b * s.K;
-    const stvo_cam cam = s.cams[b];
     const PointTail t = point_tail_args(s);
     if (tid == 0) s_run = 0;
     __syncthreads();
@@ -280,7 +277,7 @@ __global__ __launch_bounds__(TAIL_BLOCK) void point_tail_kernel(SeqDev s) {
         __syncthreads();
         int wbase = s_run;
         for (int w = 0; w < wv; ++w) wbase += s_wave[w];
-        if (ok) point_tail_write(t, cam, off, i, off + (size_t)(wbase + before), disp);
+        if (ok) point_tail_write(t, off, i, off + (size_t)(wbase + before), disp);
         __syncthreads();
         if (tid == 0) {
             int q = 0;
@@ -639,7 +636,9 @@ __global__ __launch_bounds__(T) void line_stereo_fused_kernel(SeqDev s, const in
         const_cast<int32_t*>(s.m12s_l)[off + i1] = m;
     }
     __syncthreads();
-    line_tail_frame<T>(s, b, [&](int i) { return (int)mm[i]; }, s_wave, &s_run);
+    // (left lines beyond the LDS arrays — only possible if the launch was sized for fewer lines than the slot holds — are unmatched,
+    //  never read out of bounds)
+    line_tail_frame<T>(s, b, [&](int i) { return i < M ? (int)mm[i] : -1; }, s_wave, &s_run);
 }
 
 }  // namespace
@@ -654,6 +653,7 @@ struct stvo_seq {
     double ratio_grid = 0;         // Config::minRatio12P() as the DOUBLE matchGrid compares with (matching.cpp:160,241)
     stvo_cam* d_cams = nullptr;    // [B] per-sequence calibration (device)
     double* d_inv_wh = nullptr;    // [B][2] per-sequence grid scale (device)
+    double* d_qtab = nullptr;      // [STVO_POSE_QTAB] sqrt(sigma2) of pyramid level l (kernels.h: PoseArgs::q_tab)
     char* dev = nullptr;     // one allocation, carved below
     size_t dev_bytes = 0;
     // pinned mirrors of the raw-feature block: two, used alternately, each guarded by the event of the copy that last
@@ -670,7 +670,7 @@ struct stvo_seq {
     std::vector<char*> raw_dev;
     char* extra_raw = nullptr;
     struct Set {
-        double *pl, *P, *s2;
+        float4* rc;
         uint8_t* desc;
         int32_t* n;
         double *spl, *epl, *sP, *eP, *le, *s2l, *s2lm;
@@ -825,7 +825,7 @@ int stvo_seq_create_multi(stvo_ctx* ctx, int B, int max_keypoints, int max_keyli
     // ---- everything else
     Carver c;
     const size_t o_raw = c.take(s->raw_bytes), o_raw1 = c.take(s->raw_bytes);
-    const size_t o_cams = c.take(nb * sizeof(stvo_cam)), o_invwh = c.take(nb * 2 * 8);
+    const size_t o_cams = c.take(nb * sizeof(stvo_cam)), o_invwh = c.take(nb * 2 * 8), o_qtab = c.take(stvo::STVO_POSE_QTAB * 8);
     const size_t o_pxy = c.take(nb * K * 2 * 4), o_pstart = c.take(nb * (STVO_GRID_CELLS + 1) * 4), o_pitems = c.take(nb * K * 4),
                  o_prank = c.take(nb * K * 4), o_pperm = c.take(nb * K * 4), o_prange = c.take(nb * K * 2 * 4), o_pcell = c.take(nb * K * 4);
     const bool lsort = K <= 2048 && mp->matching_s_ws >= 0 && mp->matching_s_ws <= stvo::GRID_LW - STVO_GRID_COLS;
@@ -846,9 +846,8 @@ int stvo_seq_create_multi(stvo_ctx* ctx, int B, int max_keypoints, int max_keyli
                  o_need_l = c.take(nb * M * 4), o_qsel_l = c.take(nb * M * 4), o_nsel_l = c.take(nb * 4 * 5);
     size_t o_set[2][14];
     for (int t = 0; t < 2; ++t) {
-        o_set[t][0] = c.take(nb * K * 2 * 8);
-        o_set[t][1] = c.take(nb * K * 3 * 8);
-        o_set[t][2] = c.take(nb * K * 8);
+        o_set[t][0] = c.take(nb * K * 16);
+        o_set[t][1] = o_set[t][2] = 0;
         o_set[t][3] = c.take(nb * K * 32);
         o_set[t][4] = c.take(nb * 4);
         o_set[t][5] = c.take(nb * M * 2 * 8);
@@ -877,8 +876,7 @@ int stvo_seq_create_multi(stvo_ctx* ctx, int B, int max_keypoints, int max_keyli
     {   // graph replay of the step chain: opt-in (STVO_SEQ_GRAPH=1).  Measured on ROCm 7.2 / MI355X for one sequence: 0.290 vs
         // 0.282 ms per frame points-only and 0.477 vs 0.310 ms with the line stage on its second stream — the graph executor
         // adds more per-node latency than the host-side launches cost (profiles/r02_single_stream_latency.txt)
-        const char* e = std::getenv("STVO_SEQ_GRAPH");
-        s->graph_mode = e ? std::atoi(e) != 0 : false;
+        s->graph_mode = stvo::dbg().seq_graph != stvo::DBG_UNSET && stvo::dbg().seq_graph != 0;
     }
     if (!ok) {
         stvo_seq_destroy(s);
@@ -892,13 +890,17 @@ int stvo_seq_create_multi(stvo_ctx* ctx, int B, int max_keypoints, int max_keyli
     s->raw_max_lines.assign(2, 0);
     s->d_cams = (stvo_cam*)(D + o_cams);
     s->d_inv_wh = (double*)(D + o_invwh);
+    s->d_qtab = (double*)(D + o_qtab);
     {
         std::vector<double> iw(2 * nb);
         for (int b = 0; b < B; ++b) {
             iw[2 * b + 0] = STVO_GRID_COLS / (double)img_cols[b];  // stereoFrame.cpp:47-48
             iw[2 * b + 1] = STVO_GRID_ROWS / (double)img_rows[b];
         }
-        ok = hip_ok(ctx, hipMemcpy(s->d_cams, cams, nb * sizeof(stvo_cam), hipMemcpyHostToDevice), "hipMemcpy cams") &&
+        double qtab[stvo::STVO_POSE_QTAB];  // sqrt(sigma2) per pyramid level: the same operations as the kernels' own computation
+        for (int l = 0; l < stvo::STVO_POSE_QTAB; ++l) qtab[l] = std::sqrt(pm::level_sigma2(l, s->mp.orb_scale_factor));
+        ok = hip_ok(ctx, hipMemcpy(s->d_qtab, qtab, sizeof(qtab), hipMemcpyHostToDevice), "hipMemcpy qtab") &&
+             hip_ok(ctx, hipMemcpy(s->d_cams, cams, nb * sizeof(stvo_cam), hipMemcpyHostToDevice), "hipMemcpy cams") &&
              hip_ok(ctx, hipMemcpy(s->d_inv_wh, iw.data(), iw.size() * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy inv_wh");
         if (!ok) {
             stvo_seq_destroy(s);
@@ -934,7 +936,7 @@ int stvo_seq_create_multi(stvo_ctx* ctx, int B, int max_keypoints, int max_keyli
     }
     for (int t = 0; t < 2; ++t) {
         stvo_seq::Set& q = s->set[t];
-        q.pl = (double*)(D + o_set[t][0]); q.P = (double*)(D + o_set[t][1]); q.s2 = (double*)(D + o_set[t][2]);
+        q.rc = (float4*)(D + o_set[t][0]);
         q.desc = (uint8_t*)(D + o_set[t][3]); q.n = (int32_t*)(D + o_set[t][4]);
         q.spl = (double*)(D + o_set[t][5]); q.epl = (double*)(D + o_set[t][6]); q.sP = (double*)(D + o_set[t][7]);
         q.eP = (double*)(D + o_set[t][8]); q.le = (double*)(D + o_set[t][9]); q.s2l = (double*)(D + o_set[t][10]);
@@ -1157,7 +1159,7 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl) {
     stvo_seq::Set& ps = s->set[s->cur ^ 1];
     stvo::SeqDev d = s->d;
     bind_raw(s, d, slot);
-    d.pl = cs.pl; d.P = cs.P; d.s2 = cs.s2; d.desc = cs.desc; d.n = cs.n;
+    d.rc = cs.rc; d.desc = cs.desc; d.n = cs.n;
     d.spl = cs.spl; d.epl = cs.epl; d.sP = cs.sP; d.eP = cs.eP; d.le = cs.le; d.s2l = cs.s2l; d.s2lm = cs.s2lm;
     d.ldesc = cs.ldesc; d.nl = cs.nl;
     const size_t res_bytes = (size_t)B * sizeof(stvo_pose_result);
@@ -1174,8 +1176,7 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl) {
     // per 1024 frames) but leave the key-point scan alone (0.467 ms); forked after the point stage (STVO_LINE_FORK=late) they
     // stretch the scan instead (0.510 ms).  Measured: 1024 KITTI-shaped streams 929 k (early) vs 935 k (late) frame pairs/s, 512
     // EuRoC-shaped streams 857 k vs 777 k, one stream 0.252 vs 0.280 ms per frame.
-    const char* efk = std::getenv("STVO_LINE_FORK");
-    const bool late_fork = par && efk && efk[0] == 'l';
+    const bool late_fork = par && stvo::dbg().line_fork_late == 1;
     if (par && !late_fork) {
         HIP_TRY(ctx, hipEventRecord(s->ev_fork, st));
         HIP_TRY(ctx, hipStreamWaitEvent(sl, s->ev_fork, 0));
@@ -1203,7 +1204,7 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl) {
             // the one-workgroup matcher: lean cells kernel in front, the tail of the association as its last phase
             g.lean_cells = stvo::grid_points_fused_ok(g) ? 1 : 0;
             g.has_tail = g.lean_cells;
-            if (const char* e = std::getenv("STVO_GRID_TAIL")) g.has_tail = g.has_tail && e[0] != '0';  // developer: 0 = point_tail_kernel as its own launch
+            if (stvo::dbg().grid_tail == 0) g.has_tail = 0;  // developer: point_tail_kernel as its own launch
             if (g.has_tail) g.tail = stvo::point_tail_args(d);
             if (g.lean_cells)
                 hipLaunchKernelGGL(stvo::point_cells_kernel<true>, dim3(B), dim3(256), 0, st, d);
@@ -1232,13 +1233,16 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl) {
             if (g.mutual) { g.elig = s->elig_l; g.elig_cnt = s->elig_cnt_l; g.ovf = s->govf_l; }
             s->last_line_grid = g;
             // few key-lines per frame: the whole association in one workgroup per frame (STVO_LINE_FUSED=0: the general grid matcher)
-            const int Mk = std::min(M, std::max(64, (s->raw_max_lines[slot] + 63) & ~63));  // LDS for the lines the slot holds, not for the capacity
+            // LDS for the lines the slot holds, not for the capacity — except under graph replay: a captured step is replayed for
+            // later uploads into the slot, whose line counts the capture cannot know, so it is sized for the capacity (and so are
+            // the caps derived from set_lines_cap below)
+            const int Mk = s->graph_mode ? M : std::min(M, std::max(64, (s->raw_max_lines[slot] + 63) & ~63));
             s->set_lines_cap[s->cur] = Mk;
             const size_t lds = (size_t)Mk * stvo::LSF_BYTES_PER_LINE + 4 + (size_t)Mk * (Mk / 32) * 4;
-            const char* ef = std::getenv("STVO_LINE_FUSED");
+            const int ef = stvo::dbg().line_fused;
             // (a single stream with hundreds of key-lines is better off with the general matcher's many small workgroups: EuRoC-shaped,
             // 300 key-lines, one stream 0.310 vs 0.360 ms per frame; 102 key-lines 0.257 vs 0.252)
-            s->last_line_fused = M <= stvo::LSF_MAX_LINES && (ef ? ef[0] != '0' : (B >= 16 || Mk <= 128)) &&
+            s->last_line_fused = M <= stvo::LSF_MAX_LINES && (ef != stvo::DBG_UNSET ? ef != 0 : (B >= 16 || Mk <= 128)) &&
                                  (lds <= (48u << 10) || stvo::lds_opt_in(reinterpret_cast<const void*>(stvo::line_stereo_fused_kernel<256>), (int)lds));
             if (s->last_line_fused) {
                 // (one wave per frame, <64>: 185 instead of 150 us beside the key-point scan, which it stretched by 15 us more)
@@ -1255,8 +1259,7 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl) {
     };
     // enqueue order: STVO_LINE_FIRST=1 puts the line kernel in front of the point stage (experiment: the point matcher then starts on
     // free CUs, the cells kernel shares them — same step time on 1024 KITTI-shaped streams, slower with hundreds of lines per image)
-    const char* elf = std::getenv("STVO_LINE_FIRST");
-    const bool line_first = par && !late_fork && elf && elf[0] == '1';
+    const bool line_first = par && !late_fork && stvo::dbg().line_first == 1;
     if (line_first && (stage_rc = line_stage()) != STVO_OK) return stage_rc;
     if ((stage_rc = point_stage()) != STVO_OK) return stage_rc;
     if (late_fork) {
@@ -1269,16 +1272,16 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl) {
     if (track) {
         // ---- f2fTracking: prev stereo sets vs curr stereo sets
         const stvo::LazyScratch w{ctx->knn12, ctx->knn21, ctx->cand, ctx->need, ctx->qsel, ctx->nsel, ctx->knn_capacity};
-        const char* esm = std::getenv("STVO_MATCH_SMALL");  // developer: 0 = the general machinery for the key-line sets too
+        const int esm = stvo::dbg().match_small;  // developer: 0 = the general machinery for the key-line sets too
         const int lines_cap = std::max(s->set_lines_cap[0], s->set_lines_cap[1]);
-        const bool small_sets = esm ? esm[0] != '0' : (B >= 16 || lines_cap <= 128);  // (as for the fused line kernel above)
-        const char* elz = std::getenv("STVO_MATCH_LAZY");  // developer: 1 = the lazy formulation for small batches too
+        const bool small_sets = esm != stvo::DBG_UNSET ? esm != 0 : (B >= 16 || lines_cap <= 128);  // (as for the fused line kernel above)
+        const bool elz = stvo::dbg().match_lazy == 1;  // developer: the lazy formulation for small batches too
         int small_cap = 0;  // rows per set the small-set kernel sizes its LDS for (0: the stride)
         auto match_set = [&](hipStream_t q, const stvo::LazyScratch& ws, int stride, const uint8_t* da, const int32_t* na,
                              const uint8_t* db, const int32_t* nb, float nnr, int32_t* m12, hipEvent_t* mev) {
             if (stvo::match_small_ok(stride) && small_sets && !mev) {  // (mev: the stage timers want the general launches)
                 stvo::launch_match_small(q, B, stride, da, na, db, nb, nnr, s->mp.best_lr_matches, m12, small_cap);
-            } else if (s->mp.best_lr_matches && B <= 4 && !mev && !(elz && elz[0] == '1')) {
+            } else if (s->mp.best_lr_matches && B <= 4 && !mev && !elz) {
                 // a few frame pairs leave most of the GPU idle: the reverse direction as a full scan in the SAME launch and one
                 // ratio / mutual kernel, instead of the plan + two selective reverse scans + final check of the lazy formulation
                 // (five dependent launches: 42 -> ~18 us of a single stream's 230 us)
@@ -1315,12 +1318,11 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl) {
         std::memset(&a, 0, sizeof(a));
         a.B = B; a.max_pts = K; a.max_lines = M;
         a.n_prev_pts = s->op.has_points ? ps.n : nullptr;
-        a.prev_P = ps.P; a.prev_s2p = ps.s2; a.curr_pl = cs.pl; a.m12p = s->m12p;
+        a.prev_rc = ps.rc; a.curr_rc = cs.rc; a.q_tab = s->d_qtab; a.level_scale = s->mp.orb_scale_factor; a.m12p = s->m12p;
         a.n_prev_lines = s->op.has_lines ? ps.nl : nullptr;
         a.prev_sP = ps.sP; a.prev_eP = ps.eP; a.prev_spl = ps.spl; a.prev_epl = ps.epl; a.prev_s2l = ps.s2lm;
         a.curr_le = cs.le; a.m12l = s->m12l;
         a.cams = s->d_cams; a.prm = s->op;
-        a.obs_f32 = 1;  // curr_pl holds key-point coordinates widened from float (point_tail_kernel)
         a.results = s->zero_copy ? reinterpret_cast<stvo_pose_result*>(s->out_host) : s->results;
         a.inl_p_out = s->inlp; a.inl_l_out = s->inll;
         mark(8, st);
@@ -1585,7 +1587,7 @@ int stvo_seq_debug_grid(stvo_seq* s, int b, int lines, int32_t* cell_start, int3
 int stvo_seq_push(stvo_seq* s, const stvo_frame_features* f, stvo_pose_result* results, int32_t* counts) {
     if (!s || !f) return STVO_ERR_INVALID_ARG;
     const int slot = s->frame_idx & 1;  // (slots beyond the first two belong to callers of upload / step_dev)
-    static const bool prof = std::getenv("STVO_SEQ_PROF") != nullptr;  // developer aid: host-side phase times
+    const bool prof = stvo::dbg().seq_prof != stvo::DBG_UNSET;  // developer aid: host-side phase times
     if (!prof) {
         TRY(stvo_seq_upload(s, slot, f));
         TRY(stvo_seq_step_dev(s, slot));

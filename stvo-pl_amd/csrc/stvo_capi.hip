@@ -11,8 +11,49 @@
 
 #include "ctx_internal.h"
 
+namespace stvo {
+namespace {
+
+int env_int(const char* name) {
+    const char* e = std::getenv(name);
+    return (e && *e) ? std::atoi(e) : DBG_UNSET;
+}
+DebugSwitches parse_switches() {
+    DebugSwitches d;
+    d.pose_kernel = env_int("STVO_POSE_KERNEL");
+    d.pose2p_nw = env_int("STVO_POSE2P_NW");
+    d.pose_prof = env_int("STVO_POSE_PROF");
+    d.pose_lds_t = env_int("STVO_POSE_LDS_T");
+    d.knn_mfma = env_int("STVO_KNN_MFMA");
+    d.knn_nseg = env_int("STVO_KNN_NSEG");
+    d.seq_graph = env_int("STVO_SEQ_GRAPH");
+    d.seq_prof = env_int("STVO_SEQ_PROF");
+    const char* lf = std::getenv("STVO_LINE_FORK");
+    d.line_fork_late = lf ? (lf[0] == 'l' ? 1 : 0) : DBG_UNSET;
+    d.line_first = env_int("STVO_LINE_FIRST");
+    d.line_fused = env_int("STVO_LINE_FUSED");
+    d.match_small = env_int("STVO_MATCH_SMALL");
+    d.match_lazy = env_int("STVO_MATCH_LAZY");
+    d.grid_tail = env_int("STVO_GRID_TAIL");
+    d.grid_fused = env_int("STVO_GRID_FUSED");
+    d.grid_fused_cap = env_int("STVO_GRID_FUSED_CAP");
+    return d;
+}
+DebugSwitches& switches() {
+    static DebugSwitches d = parse_switches();
+    return d;
+}
+
+}  // namespace
+
+const DebugSwitches& dbg() { return switches(); }
+void dbg_reparse() { switches() = parse_switches(); }
+
+}  // namespace stvo
 
 extern "C" {
+
+void stvo_debug_reparse_env(void) { stvo::dbg_reparse(); }
 
 const char* stvo_backend_name(void) { return "hip-gfx950"; }
 int stvo_abi_version(void) { return STVO_ABI_VERSION; }
@@ -48,6 +89,10 @@ int stvo_ctx_create(int device_id, int max_rows, int max_batch, stvo_ctx** out) 
     bool ok = hip_ok(ctx, hipSetDevice(device_id), "hipSetDevice") &&
               hip_ok(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking), "hipStreamCreate");
     ctx->own_stream = ok;
+    if (ok) {
+        stvo::pose_retain_stream(ctx->stream);
+        ctx->stream_retained = true;
+    }
     const size_t knn_elems = (size_t)max_rows * (size_t)max_batch;
     // [nseg][B][rows] with nseg = 2 for full batches, up to KNN_MAX_NSEG for a single problem (knn_pick_nseg)
     const size_t knn_seg_elems =
@@ -86,7 +131,7 @@ int stvo_ctx_destroy(stvo_ctx* ctx) {
     if (ctx->arena_host) (void)hipHostFree(ctx->arena_host);
     if (ctx->probe_sink) (void)hipFree(ctx->probe_sink);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
-    if (ctx->stream) stvo::pose_release_stream(ctx->stream);
+    if (ctx->stream_retained) stvo::pose_release_stream(ctx->stream);
     if (ctx->aux_stream) {
         (void)hipStreamSynchronize(ctx->aux_stream);
         stvo::pose_release_stream(ctx->aux_stream);
@@ -101,14 +146,14 @@ int stvo_ctx_destroy(stvo_ctx* ctx) {
 
 int stvo_ctx_set_stream(stvo_ctx* ctx, void* hip_stream) {
     if (!ctx) return STVO_ERR_INVALID_ARG;
-    if (ctx->stream) {
-        (void)hipSetDevice(ctx->device);
-        (void)hipStreamSynchronize(ctx->stream);
-        stvo::pose_release_stream(ctx->stream);
-        if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
-    }
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream_retained) stvo::pose_release_stream(ctx->stream);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     ctx->own_stream = false;
-    ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);  // may be the NULL stream
+    stvo::pose_retain_stream(ctx->stream);
+    ctx->stream_retained = true;
     return STVO_OK;
 }
 
@@ -125,6 +170,7 @@ int stvo_ctx_set_overlap(stvo_ctx* ctx, int enable) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (enable && !ctx->aux_stream) {
         HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+        stvo::pose_retain_stream(ctx->aux_stream);
         HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_match_done, hipEventDisableTiming));
         HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_pose_done, hipEventDisableTiming));
     }
@@ -470,7 +516,7 @@ int stvo_time_stage_dev(stvo_ctx* ctx, const stvo_track_batch_dev* b, const stvo
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     *avg_ms = ms / (float)iters;
-    if (stage == 1 && std::getenv("STVO_POSE_PROF")) {  // developer aid: per-phase ticks of the solver lane
+    if (stage == 1 && stvo::dbg().pose_prof != stvo::DBG_UNSET) {  // developer aid: per-phase ticks of the solver lane
         long long* dprof = nullptr;
         HIP_TRY(ctx, hipMalloc((void**)&dprof, (size_t)b->B * 16 * sizeof(long long)));
         a.prof_out = dprof;
@@ -480,11 +526,6 @@ int stvo_time_stage_dev(stvo_ctx* ctx, const stvo_track_batch_dev* b, const stvo
         double m[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         for (int f = 0; f < b->B; ++f)
             for (int i = 0; i < 16; ++i) m[i] += (double)h[(size_t)f * 16 + i] / b->B;
-        if (std::getenv("STVO_POSE_KERNEL") && std::atoi(std::getenv("STVO_POSE_KERNEL")) == 3)
-            std::fprintf(stderr, "[pose3 prof] mean ticks/pair: chain %.0f = stage %.0f + eval-wait %.0f + iter-algebra %.0f + cov/isgood %.0f + "
-                                 "remove_outliers %.0f + commit %.0f + out %.0f + post %.0f + sum %.0f + robust-pre %.0f; jobs (cumulative per owner) %.1f\n",
-                         m[0], m[2], m[1], m[5], m[6], m[7], m[8], m[3], m[10], m[11], m[9], m[4]);
-        else
         std::fprintf(stderr, "[pose prof] mean ticks/frame: evaluate %.0f  iter-algebra %.0f  cov+isgood+commit %.0f  "
                              "remove_outliers %.0f  total %.0f | worker: eval-compute %.0f  barrier+solver-sum %.0f  prefetch+fold %.0f\n", m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7]);
         std::fprintf(stderr, "[pose prof] per worker wave, compute + fold ticks/frame: %.0f %.0f %.0f %.0f %.0f %.0f | prologue %.0f | last wave %.0f\n", m[8], m[9], m[10],

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <future>
 #include <iostream>
@@ -77,6 +78,8 @@ FrameFeatures StereoFrameHandler::detectStereoFeatures(const GrayImage& img_l, c
     feat.img_rows = img_l.rows;
     if (!Config::hasPoints()) return feat;  // src/stereoFrame.cpp:106
     const int K = 4096;  // capacity per image: orb_nfeatures plus the ties at the cut
+    // fast_th == 0 means "the configured threshold" (src/stereoFrame.cpp:109-112), otherwise the adaptive one; cv::FAST's range
+    const int fast_th = std::min(254, std::max(1, orb_fast_th == 0 ? Config::orbFastTh() : orb_fast_th));
     if (orb && (orb_cols != img_l.cols || orb_rows != img_l.rows)) {
         stvo_orb_destroy(orb);
         orb = nullptr;
@@ -84,7 +87,7 @@ FrameFeatures StereoFrameHandler::detectStereoFeatures(const GrayImage& img_l, c
     if (!orb) {
         stvo_orb_params prm{};
         prm.nfeatures = Config::orbNFeatures();
-        prm.fast_threshold = std::min(254, std::max(1, orb_fast_th));
+        prm.fast_threshold = fast_th;
         prm.edge_threshold = Config::orbEdgeTh();
         prm.nlevels = Config::orbNLevels();
         prm.scale_factor = Config::orbScaleFactor();
@@ -92,7 +95,7 @@ FrameFeatures StereoFrameHandler::detectStereoFeatures(const GrayImage& img_l, c
         orb_cols = img_l.cols;
         orb_rows = img_l.rows;
     }
-    check(stvo_orb_set_fast_threshold(orb, std::min(254, std::max(1, orb_fast_th))), "stvo_orb_set_fast_threshold", ctx);
+    check(stvo_orb_set_fast_threshold(orb, fast_th), "stvo_orb_set_fast_threshold", ctx);
     const size_t px = (size_t)img_l.rows * img_l.cols;
     std::vector<uint8_t> pair(2 * px);
     const GrayImage* im[2] = {&img_l, &img_r};
@@ -106,6 +109,9 @@ FrameFeatures StereoFrameHandler::detectStereoFeatures(const GrayImage& img_l, c
     int32_t n[2] = {0, 0}, nt[2] = {0, 0};
     check(stvo_orb_detect_levels(orb, pair.data(), kp.data(), resp.data(), ang.data(), oct.data(), desc.data(), n, nt), "stvo_orb_detect_levels", ctx);
     for (int s = 0; s < 2; ++s) {
+        if (nt[s] > n[s])  // more key-points qualified than the front-end's per-image capacity: not silently
+            std::fprintf(stderr, "[StVO-HIP] detectStereoFeatures: %d of %d key-points of the %s image dropped at the capacity of %d\n",
+                         nt[s] - n[s], nt[s], s ? "right" : "left", K);
         std::vector<KeyPoint>& pts = s ? feat.points_r : feat.points_l;
         DescMat& dm = s ? feat.pdesc_r : feat.pdesc_l;
         pts.reserve(n[s]);

@@ -23,7 +23,7 @@ EXPORTS = ["stvo_backend_name", "stvo_abi_version", "stvo_error_string", "stvo_c
            "stvo_seq_set_stage_timing", "stvo_seq_get_stage_timing", "stvo_seq_debug_grid", "stvo_orb_create", "stvo_orb_destroy",
            "stvo_orb_set_pattern", "stvo_orb_get_pattern", "stvo_orb_detect", "stvo_orb_detect_dev", "stvo_orb_detect_levels",
            "stvo_orb_detect_levels_dev", "stvo_orb_set_fast_threshold", "stvo_seq_upload_dev", "stvo_lbd_create", "stvo_lbd_destroy",
-           "stvo_lbd_compute", "stvo_lbd_compute_dev"]
+           "stvo_lbd_compute", "stvo_lbd_compute_dev", "stvo_debug_reparse_env"]
 
 SEQ_NSTAGE = 5  # include/stvo_hip.h: STVO_SEQ_NSTAGE
 SEQ_STAGE_NAMES = ("stereo_points_stage", "grid_scan", "hamming_knn2", "reverse_check", "pose")

@@ -26,3 +26,20 @@ def hip():
     ctx = capi.Context(device_id=0, max_rows=4096, max_batch=64)
     yield ctx
     ctx.close()
+
+
+@pytest.fixture
+def switches(monkeypatch):
+    """Developer switches of the library (stvo-pl_amd/csrc/debug_switches.h): the STVO_* variables are parsed once, so a test
+    that drives a variant sets them through this fixture, which makes the library read the environment again — and once more
+    after the test has restored it."""
+    from stvo_amd import capi
+
+    def set_env(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        capi.load().stvo_debug_reparse_env()
+
+    yield set_env
+    monkeypatch.undo()
+    capi.load().stvo_debug_reparse_env()

@@ -13,33 +13,19 @@ pytestmark = pytest.mark.gpu
 CAM = synth.KITTI_CAM
 
 
-@pytest.fixture(autouse=True, params=["default", "1", "2:16", "2:8", "2:4", "2:2", "2:40", "3:16", "3:8", "4:2", "4:4"])
-def pose_kernel_variant(request):
-    """Every test of this module runs against both pose kernels: pose_kernel.hip (worker waves + solver wave, "1") and
-    pose_kernel2.hip (every wave a worker, row-distributed algebra, records compacted in LDS) with 16 / 8 / 4 / 2 waves per
-    frame pair at 128 VGPRs, or 4 at 256 VGPRs ("2:40", the default for big batches), and pose_kernel3.hip (two frame pairs per
-    workgroup, owner + evaluator waves) with 16 waves at 128 VGPRs / 8 waves at 256 VGPRs ("3:16", "3:8"; problems whose
-    records do not fit its LDS share are handed to pose_kernel2's kernel by the library); "default" is the library's own
-    choice.  The library reads the variables at every launch."""
-    import os
-    old = {k: os.environ.get(k) for k in ("STVO_POSE_KERNEL", "STVO_POSE2_NW", "STVO_POSE3_NW", "STVO_POSE2P_NW")}
-    if request.param == "default":
-        for k in old:
-            os.environ.pop(k, None)
-    else:
+@pytest.fixture(autouse=True, params=["default", "1", "4:2", "4:4"])
+def pose_kernel_variant(request, switches):
+    """Every test of this module runs against both optimizePose formulations of the library: pose_kernel.hip (worker waves + a
+    solver wave, every record in LDS: "1", the default up to 256 frame pairs) and pose_kernel2p.hip (every wave a worker,
+    thread-private records, two or four waves per frame pair: "4:2" / "4:4", the default for larger batches); "default" is the
+    library's own choice.  (The round-2 kernel with compacted LDS records and the round-3 owner / evaluator experiment were
+    removed in round 4 — both measured slower.)"""
+    if request.param != "default":
         k, _, nw = request.param.partition(":")
-        os.environ["STVO_POSE_KERNEL"] = k
-        var = {"3": "STVO_POSE3_NW", "4": "STVO_POSE2P_NW"}.get(k, "STVO_POSE2_NW")   # "4": pose_kernel2p.hip (thread-private records)
-        for v in ("STVO_POSE2_NW", "STVO_POSE3_NW", "STVO_POSE2P_NW"):
-            os.environ.pop(v, None)
-        if nw:
-            os.environ[var] = nw
+        switches(dict({"STVO_POSE_KERNEL": k}, **({"STVO_POSE2P_NW": nw} if nw else {})))
     yield request.param
-    for k, v in old.items():
-        if v is None:
-            os.environ.pop(k, None)
-        else:
-            os.environ[k] = v
+
+
 ROT_TOL, TRANS_TOL = 1e-4, 1e-3  # BASELINE.json north_star
 
 

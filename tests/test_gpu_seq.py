@@ -174,11 +174,10 @@ def test_seq_fetch_by_products(oracle):
 
 
 @pytest.mark.parametrize("env", [{"STVO_GRID_FUSED": "0"}, {"STVO_GRID_FUSED_CAP": "-1"}], ids=["scan", "misfit"])
-def test_seq_point_grid_other_formulations(oracle, monkeypatch, env):
+def test_seq_point_grid_other_formulations(oracle, switches, env):
     """The stereo point matcher runs as one workgroup per frame by default; the scan formulation (separate launches) and the
     scan formulation inside the fused launch (frames whose pairs do not fit the LDS) must give the same pipeline results."""
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
+    switches(env)
     cam = synth.KITTI_CAM
     seqs = [synth.make_stereo_sequence(520 + b, n_frames=4, n_pts=500 + 500 * b, n_lines=30, cam=cam) for b in range(3)]
     run_and_compare(oracle, seqs, cam, "kitti")
@@ -191,11 +190,10 @@ def test_seq_point_grid_other_formulations(oracle, monkeypatch, env):
     {"STVO_GRID_TAIL": "0"},                              # point_tail_kernel as its own launch behind the lean cells kernel
     {"STVO_MATCH_LAZY": "1"},                             # lazy reverse check for a tiny batch (default there: both directions in one scan)
 ], ids=["lines-fused", "lines-general", "late-fork", "tail-kernel", "lazy-reverse"])
-def test_seq_step_variants_line_heavy(oracle, monkeypatch, env):
+def test_seq_step_variants_line_heavy(oracle, switches, env):
     """Every launch plan the step can choose (by batch size / line count, or by a developer switch) gives the oracle's results:
     EuRoC-shaped frames with ~240 key-lines per image, two streams."""
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
+    switches(env)
     cam = synth.EUROC_CAM
     seqs = [synth.make_stereo_sequence(740 + b, n_frames=4, n_pts=500, n_lines=200, cam=cam, depth=(1.0, 8.0),
                                        octave_probs=[.5, .25, .15, .1], outlier_frac=0.2) for b in range(2)]
@@ -240,13 +238,12 @@ def crowd(fr, rng, frac, box):
                                       (0.12, (200, 80, 600, 30)), (0.1, (200, 80, 500, 24))],
                          ids=["half-in-strip", "all-in-one-window", "top-row", "mild-crowd", "mild-crowd-wide-rows"])
 @pytest.mark.parametrize("env", [{}, {"STVO_GRID_FUSED": "0"}], ids=["fused", "scan"])
-def test_seq_point_grid_crowded_frames(oracle, monkeypatch, frac, box, env):
+def test_seq_point_grid_crowded_frames(oracle, switches, frac, box, env):
     """Raw matchGrid output (stereoFrame.cpp:145) on frames whose key-points crowd into a few grid cells: rows with more than
     64 candidates and frames with more pairs than the one-workgroup formulation holds (it must then take the scan
     formulation on its own), chains of equal distances — index for index against the oracle."""
     from stvo_amd import capi
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
+    switches(env)
     cam = synth.KITTI_CAM
     rng = np.random.default_rng(77)
     seq = synth.make_stereo_sequence(4321, n_frames=2, n_pts=1600, n_lines=0, cam=cam)
@@ -268,7 +265,7 @@ def test_seq_point_grid_crowded_frames(oracle, monkeypatch, frac, box, env):
         ctx.close()
 
 
-def test_seq_point_grid_persistent_workgroups_many_frames(oracle, monkeypatch):
+def test_seq_point_grid_persistent_workgroups_many_frames(oracle, switches):
     """More frames than CUs: every persistent workgroup of the one-workgroup-per-frame matcher takes several frames and
     prefetches the next one while it works — the raw stereo matches and the pose blocks of 600 small sequences must equal the
     scan formulation's, and sequence 0 / 599 the oracle's."""
@@ -294,7 +291,7 @@ def test_seq_point_grid_persistent_workgroups_many_frames(oracle, monkeypatch):
             ctx.close()
 
     fused = run()
-    monkeypatch.setenv("STVO_GRID_FUSED", "0")
+    switches({"STVO_GRID_FUSED": "0"})
     scan = run()
     for k in range(2):
         assert np.array_equal(fused[k][0], scan[k][0]) and np.array_equal(fused[k][1], scan[k][1])
@@ -305,17 +302,17 @@ def test_seq_point_grid_persistent_workgroups_many_frames(oracle, monkeypatch):
         assert np.array_equal(fused[1][0][b, :len(seqs[b][1]["kp_l"])], ref["m12_raw_p"])
 
 
-@pytest.mark.parametrize("pose", ["default", "3:16", "3:8", "4:2", "4:4"])
-def test_seq_pipeline_headline_shape_every_stream_vs_oracle(oracle, monkeypatch, pose):
+@pytest.mark.parametrize("pose", ["default", "1", "4:2", "4:4"])
+def test_seq_pipeline_headline_shape_every_stream_vs_oracle(oracle, switches, pose):
     """The shape bench.py's `value` is quoted on — hundreds of streams x (1650 landmarks ~ 2000 key-points + 85 segments ~ 100
     key-lines), the eight sequence ids / three KITTI calibrations of configs[4], resident frame slots advanced with
     upload / step_dev in ping-pong order, the batch-size default of the pose kernel — with EVERY stream compared with the
     oracle-driven per-frame loop on every transition (forward and backward), not with another formulation of itself."""
     from concurrent.futures import ThreadPoolExecutor
     from stvo_amd import capi
-    if pose != "default":   # pose_kernel3.hip (two frame pairs per workgroup) with 16 / 8 waves
-        monkeypatch.setenv("STVO_POSE_KERNEL", pose.split(":")[0])
-        monkeypatch.setenv("STVO_POSE3_NW" if pose[0] == "3" else "STVO_POSE2P_NW", pose.split(":")[1])
+    if pose != "default":   # "1": pose_kernel.hip (worker waves + solver wave), "4:n": pose_kernel2p.hip with n waves per frame pair
+        k, _, nw = pose.partition(":")
+        switches(dict({"STVO_POSE_KERNEL": k}, **({"STVO_POSE2P_NW": nw} if nw else {})))
     B, S = 320, 3
     ids = np.arange(B) % synth.CONFIG5_N_SEQUENCES
     streams = [synth.make_config5_sequence(int(s), n_frames=S, n_pts=1650, n_lines=85, replica=400 + b // 8) for b, s in enumerate(ids)]
