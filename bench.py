@@ -131,18 +131,21 @@ def gpu_clocks_under_load(run_some_work, card=0):
         p.kill()
         return {"error": "rocm-smi timed out"}
     try:
-        d = json.loads(txt)
+        d = json.loads(txt[txt.index("{"):])   # (a low-power warning line may precede the JSON)
         c = d.get(f"card{card}", next(iter(d.values())))
     except (ValueError, StopIteration, AttributeError):
         return {"error": "rocm-smi output not parsed", "raw": txt[:300]}
     out = {"source": "rocm-smi -c -P --showmaxpower --showperflevel --json, one sample while bench steps were running"}
+    def mhz(v):
+        m = re.search(r"([0-9.]+)\s*mhz", str(v), re.I)
+        return float(m.group(1)) if m else v
     for k, v in c.items():
         kl = k.lower()
-        if "sclk" in kl: out["sclk"] = v
-        elif "mclk" in kl: out["mclk"] = v
-        elif "fclk" in kl: out["fclk"] = v
-        elif "max graphics package power" in kl or "max power" in kl: out["power_cap_w"] = v
-        elif "power" in kl and "socket" in kl or "average graphics package power" in kl or "current socket" in kl: out["power_w"] = v
+        if "clock speed" in kl:
+            for name in ("sclk", "mclk", "fclk", "socclk"):
+                if kl.startswith(name): out[name + "_mhz"] = mhz(v)
+        elif "max graphics package power" in kl: out["power_cap_w"] = float(v)
+        elif "graphics package power" in kl: out["power_w"] = float(v)
         elif "performance level" in kl: out["perf_level"] = v
     return out
 

@@ -3,6 +3,8 @@
 // in LDS, the workgroup-wide reductions / selections, and the serial sections of the optimizePose state machine
 // (/root/reference/src/stereoFrameHandler.cpp:307-547).
 #pragma once
+#include <type_traits>
+
 #include "kernels.h"
 #include "pose_math.h"
 
@@ -180,23 +182,85 @@ struct BlockOps {
     // cycles).  Integer counts only: the result is the one a sort would give.  hist: [2][HIST_W] ints (HIST_W - 256 mailbox
     // words); zeroed here, so callers need not preserve anything.
     static constexpr int HIST_W = 260;
+    // Round 4: the search starts at the most significant bit in which the keys DIFFER (block-wide AND / OR of the keys, one extra
+    // exchange through the second histogram's words before the first barrier).  The keys of a selection are residual norms: doubles
+    // between ~0.01 and ~100 share sign and the top exponent bits, so the first 8-bit round of a search from bit 63 put ~1500
+    // ds_add on two or three bins (they serialise in the LDS unit) and decided nothing; from the first differing bit the first
+    // round already spreads the keys over most of the 256 bins and the second usually isolates the answer.
     template <int N, bool W, typename K, int BITS>
     static __device__ __forceinline__ K select_kth_hist(const K* key, unsigned mask, int kth, int (*hist)[HIST_W], K* xchg) {
-        static_assert(BITS % 8 == 0, "eight bits per round");
+        static_assert(BITS == 32 || BITS == 64, "32- or 64-bit keys");
         const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-        if (W)
+        // (only where it pays: the 64-bit keys of a thread with many of them — the key-points of the batch kernels.  The float keys
+        //  of the MAD spread over ~15 top bytes by themselves, and with a handful of keys per thread the exchange costs more than the
+        //  degenerate round: the robust mode of the latency kernel, which selects at every evaluation, lost 8 % to it.)
+        constexpr bool PREFIX = BITS == 64 && N >= 8;
+        K k_and = 0, k_or = ~(K)0;  // !PREFIX: every bit counts as differing
+        if (PREFIX) {
+            k_and = ~(K)0;
+            k_or = 0;
+        }
+        if (W) {
+            if (PREFIX) {
+#pragma unroll
+                for (int k = 0; k < N; ++k)
+                    if ((mask >> k) & 1u) {
+                        k_and &= key[k];
+                        k_or |= key[k];
+                    }
+                // wave AND / OR on DPP moves (lanes without a source keep their own value: the identity of both), result in lane 63
+                auto dpp_step = [&](auto ctrl_c, auto rmask_c) {
+                    constexpr int CTRL = decltype(ctrl_c)::value, RM = decltype(rmask_c)::value;
+                    const unsigned alo = (unsigned)k_and, ahi = (unsigned)((unsigned long long)k_and >> 32);
+                    const unsigned olo = (unsigned)k_or, ohi = (unsigned)((unsigned long long)k_or >> 32);
+                    const unsigned a0 = (unsigned)__builtin_amdgcn_update_dpp((int)alo, (int)alo, CTRL, RM, 0xf, false);
+                    const unsigned a1 = (unsigned)__builtin_amdgcn_update_dpp((int)ahi, (int)ahi, CTRL, RM, 0xf, false);
+                    const unsigned o0 = (unsigned)__builtin_amdgcn_update_dpp((int)olo, (int)olo, CTRL, RM, 0xf, false);
+                    const unsigned o1 = (unsigned)__builtin_amdgcn_update_dpp((int)ohi, (int)ohi, CTRL, RM, 0xf, false);
+                    k_and &= (K)(((unsigned long long)a1 << 32) | a0);
+                    k_or |= (K)(((unsigned long long)o1 << 32) | o0);
+                };
+                using std::integral_constant;
+                dpp_step(integral_constant<int, 0x111>{}, integral_constant<int, 0xf>{});  // row_shr:1
+                dpp_step(integral_constant<int, 0x112>{}, integral_constant<int, 0xf>{});  // row_shr:2
+                dpp_step(integral_constant<int, 0x114>{}, integral_constant<int, 0xf>{});  // row_shr:4
+                dpp_step(integral_constant<int, 0x118>{}, integral_constant<int, 0xf>{});  // row_shr:8
+                dpp_step(integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{});  // row_bcast:15 -> rows 1 and 3
+                dpp_step(integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{});  // row_bcast:31 -> rows 2 and 3
+                unsigned long long* part = reinterpret_cast<unsigned long long*>(&hist[1][0]);  // [NWORK][2]
+                if (lane == 63) {
+                    part[2 * wv] = (unsigned long long)k_and;
+                    part[2 * wv + 1] = (unsigned long long)k_or;
+                }
+            }
             for (int i = tid; i < 256; i += WTHREADS) hist[0][i] = 0;
+        }
         __syncthreads();
-        K prefix = 0;
+        if (PREFIX) {
+            const unsigned long long* part = reinterpret_cast<const unsigned long long*>(&hist[1][0]);
+            unsigned long long a = ~0ull, o = 0ull;
+#pragma unroll
+            for (int w = 0; w < NWORK; ++w) {
+                a &= part[2 * w];
+                o |= part[2 * w + 1];
+            }
+            k_and = (K)a;
+            k_or = (K)o;
+        }
+        const K differ = k_and ^ k_or;
+        K prefix = k_and;  // the common high bits (and zeros below them, as far as the search is concerned)
         int kk = kth, parity = 0;
-        for (int shift = BITS - 8; shift >= 0; shift -= 8) {
+        // hi = the most significant undecided bit; a round decides bits hi .. lo = max(0, hi - 7)
+        int hi = differ == 0 ? -1 : (BITS - 1) - (BITS == 64 ? __clzll((unsigned long long)differ) : __clz((unsigned)differ));
+        while (hi >= 0) {
+            const int lo = hi >= 7 ? hi - 7 : 0;
             int* h = hist[parity];
             if (W) {
 #pragma unroll
                 for (int k = 0; k < N; ++k) {
                     const K diff = key[k] ^ prefix;
-                    const bool same = shift + 8 >= BITS ? true : (diff >> (shift + 8 >= BITS ? 0 : shift + 8)) == 0;
-                    if (((mask >> k) & 1u) && same) atomicAdd(&h[(int)((key[k] >> shift) & 255)], 1);
+                    const bool same = hi + 1 >= BITS ? true : (diff >> (hi + 1 >= BITS ? 0 : hi + 1)) == 0;
+                    if (((mask >> k) & 1u) && same) atomicAdd(&h[(int)((key[k] >> lo) & 255)], 1);
                 }
             }
             __syncthreads();
@@ -226,19 +290,20 @@ struct BlockOps {
             }
             __syncthreads();
             const int bin = h[256], below = h[257], cnt = h[258];
-            prefix |= (K)bin << shift;
+            prefix = (prefix & ~((K)255 << lo)) | ((K)bin << lo);  // (the window may reach into decided bits: they are the same)
             kk -= below;
             parity ^= 1;
-            if (cnt == 1 && shift > 0) {  // block-uniform: the single key under the prefix
+            if (cnt == 1 && lo > 0) {  // block-uniform: the single key under the prefix
                 if (W) {
 #pragma unroll
                     for (int k = 0; k < N; ++k)
-                        if (((mask >> k) & 1u) && ((key[k] ^ prefix) >> shift) == 0) *xchg = key[k];
+                        if (((mask >> k) & 1u) && ((key[k] ^ prefix) >> lo) == 0) *xchg = key[k];
                 }
                 __syncthreads();
                 prefix = *xchg;
                 break;
             }
+            hi = lo - 1;
         }
         __syncthreads();  // hist / xchg are reused by the caller
         return prefix;

@@ -47,6 +47,7 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_hist)[Block
     const stvo_cam cam_f = a.cams ? a.cams[f] : a.cam;  // per-sequence calibration (stvo_seq_create_multi) or one for the batch
     const pm::Cam5 cam{cam_f.fx, cam_f.fy, cam_f.cx, cam_f.cy};
     const stvo_opt_params prm = a.prm;
+    const double inv_homog = 1.0 / prm.homog_th;
 
     // ---------------- which records does this thread own?  (bitmasks only) ----------------
     // Thread t of the worker waves owns prev features i = t + k*BLOCK, k < PPT.  Only two bitmasks
@@ -264,36 +265,65 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_hist)[Block
             }
             sl = pm::clamp_scale(Ops::template mad_sigma<LPT, W>(rl, linl, sh->n_inl_l, s_hist, &sh->xchg));
         }
+        const double isp = 1.0 / sp, isl = 1.0 / sl;  // reciprocals of the robust scales: one division per evaluation, not per feature
         const long long tw0 = tick();
         double acc[28];
 #pragma unroll
         for (int i = 0; i < 28; ++i) acc[i] = 0.0;
         {
-            // software pipeline over this thread's inlier points: the record of the NEXT inlier is in flight
-            // (L2 latency) while the current one is evaluated; the FIRST record of an evaluation was requested at the
-            // end of the previous one (or by prefetch_first), i.e. while the workgroup waited for the solver wave
+            // this thread's inlier points, TWO per trip (pm::point_term_t<d2>: every operation on both records, adjacent in the
+            // instruction stream): a term is a chain of ~60 dependent FP64 instructions and a wave retires one of those every
+            // ~8 cycles — the second record fills the gaps (latency variant: 3.3 records per thread, two waves per SIMD; the pipe
+            // was ~40 % busy with one record per trip).
+            // The records of the NEXT trip are in flight while this one is evaluated; the FIRST record of an evaluation was
+            // requested at the end of the previous one (or by prefetch_first), i.e. while the workgroup waited for the solver wave.
+            // An odd count ends with the last record evaluated twice, the second time with weight 0: an exact no-op.
             unsigned todo = pinl;
-            PointRec cur{1.0, 1.0, 1.0, 0.0, 0.0, 1.0};
-            if (todo) {
-                if (first_k == __builtin_ctz(todo)) {
-                    cur.X = fX; cur.Y = fY; cur.Z = fZ; cur.ox = fox; cur.oy = foy; cur.s2 = fs2;
+            auto next_k = [&]() -> int {
+                const int k = __builtin_ctz(todo);
+                todo &= todo - 1u;
+                return k;
+            };
+            PointRec c0{1.0, 1.0, 1.0, 0.0, 0.0, 1.0}, c1 = c0;
+            double m1 = 0.0;
+            bool go = todo != 0u;
+            if (go) {
+                const int k0 = next_k();
+                if (first_k == k0) {
+                    c0.X = fX; c0.Y = fY; c0.Z = fZ; c0.ox = fox; c0.oy = foy; c0.s2 = fs2;
                 } else {
-                    cur = load_point(__builtin_ctz(todo));
+                    c0 = load_point(k0);
+                }
+                c1 = c0;
+                if (todo) {
+                    c1 = load_point(next_k());
+                    m1 = 1.0;
                 }
             }
-            while (todo) {
-                todo &= todo - 1u;
-                PointRec nxt = cur;
-                if (todo) nxt = load_point(__builtin_ctz(todo));
-                pm::point_term_q(acc, DT, cam, prm.homog_th, cur.X, cur.Y, cur.Z, cur.ox, cur.oy, cur.s2, robust, sp);
-                cur = nxt;
+            while (go) {
+                PointRec n0 = c1, n1 = c1;
+                double mn = 0.0;
+                go = todo != 0u;
+                if (go) {
+                    n0 = load_point(next_k());
+                    n1 = n0;
+                    if (todo) {
+                        n1 = load_point(next_k());
+                        mn = 1.0;
+                    }
+                }
+                pm::point_term_t<pm::d2>(acc, DT, cam, prm.homog_th, inv_homog, pm::d2{c0.X, c1.X}, pm::d2{c0.Y, c1.Y}, pm::d2{c0.Z, c1.Z},
+                                         pm::d2{c0.ox, c1.ox}, pm::d2{c0.oy, c1.oy}, pm::d2{c0.s2, c1.s2}, robust, isp, pm::d2{1.0, m1});
+                c0 = n0;
+                c1 = n1;
+                m1 = mn;
             }
         }
 #pragma unroll 1
         for (int k = 0; k < LPT; ++k)
             if ((linl >> k) & 1u) {
                 const pm::LineRec L = load_line(k);
-                pm::line_term_q(acc, DT, cam, prm.homog_th, L, robust, sl);
+                pm::line_term_q(acc, DT, cam, prm.homog_th, inv_homog, L, robust, isl);
             }
         const long long tw1 = tick();
         prefetch_first();  // for the next evaluation; completes while this one is reduced and solved

@@ -47,14 +47,15 @@ constexpr bool POSE2P_PRIO = true;  // serial sections at wave priority 3 (measu
 struct PoseFlow {
     int status, path, it0, it1;
 };
-template <typename Eval, typename Rem, typename Tick>
-__device__ __forceinline__ PoseFlow optimize_pose_flow(PoseSh* sh, const stvo_opt_params& prm, const bool w0, Eval&& evaluate,
+// prm(): the optimizer parameters, fetched where they are used (pose2c_kernel reads them from the kernel-argument segment)
+template <typename Prm, typename Eval, typename Rem, typename Tick>
+__device__ __forceinline__ PoseFlow optimize_pose_flow(PoseSh* sh, Prm&& prm, const bool w0, Eval&& evaluate,
                                                        Rem&& remove_outliers, Tick&& tick, long long* tprof) {
     int status = STVO_POSE_OK, path = 0, it0 = 0, it1 = 0;
-    if (sh->n_inl_p + sh->n_inl_l >= prm.min_features) {
+    if (sh->n_inl_p + sh->n_inl_l >= prm().min_features) {
         int stage = 0;        // 0 = first optimisation (:335-338), 1 = refinement (:345-350), 2 = robust fallback (:359)
-        int alg = prm.mode;   // 0 GN, 1 robust GN, 2 LM
-        int max_it = prm.max_iters;
+        int alg = prm().mode;   // 0 GN, 1 robust GN, 2 LM
+        int max_it = prm().max_iters;
         for (;;) {
             if (w0) {
                 sh->err_prev = 999999999.9;
@@ -74,9 +75,9 @@ __device__ __forceinline__ PoseFlow optimize_pose_flow(PoseSh* sh, const stvo_op
                     // the serial section is one wave's dependent chain while the co-resident workgroup's waves evaluate on the
                     // same SIMD: let it win the issue arbitration
                     if (POSE2P_PRIO) __builtin_amdgcn_s_setprio(3);
-                    if (alg == 0) t0_gn_iter(sh, prm.min_error, prm.min_error_change, it);
-                    else if (alg == 1) t0_gnr_iter(sh, prm.min_error, prm.min_error_change);
-                    else t0_lm_iter(sh, prm.min_error, prm.min_error_change, it == 0 ? 1 : 0);
+                    if (alg == 0) t0_gn_iter(sh, prm().min_error, prm().min_error_change, it);
+                    else if (alg == 1) t0_gnr_iter(sh, prm().min_error, prm().min_error_change);
+                    else t0_lm_iter(sh, prm().min_error, prm().min_error_change, it == 0 ? 1 : 0);
                     if (POSE2P_PRIO) __builtin_amdgcn_s_setprio(0);
                 }
                 __syncthreads();
@@ -119,7 +120,7 @@ __device__ __forceinline__ PoseFlow optimize_pose_flow(PoseSh* sh, const stvo_op
                 tq2 = tick();
                 remove_outliers();
                 tprof[3] += tick() - tq2;
-                if (sh->n_inl_p + sh->n_inl_l >= prm.min_features) {  // :345 — restart from the INITIAL DT
+                if (sh->n_inl_p + sh->n_inl_l >= prm().min_features) {  // :345 — restart from the INITIAL DT
                     path |= STVO_PATH_REFINED;
                     stage = 1;
                 } else {
@@ -133,7 +134,7 @@ __device__ __forceinline__ PoseFlow optimize_pose_flow(PoseSh* sh, const stvo_op
                 stage = 2;
                 alg = 1;
             }
-            max_it = prm.max_iters_ref;
+            max_it = prm().max_iters_ref;
             if (w0) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) sh->DT[i] = sh->DT0[i];
@@ -178,6 +179,7 @@ __global__ __launch_bounds__(NW * 64, 2) void pose2p_kernel(PoseArgs a, const in
     const stvo_cam cam_f = a.cams ? a.cams[f] : a.cam;
     const pm::Cam5 cam{cam_f.fx, cam_f.fy, cam_f.cx, cam_f.cy};
     const stvo_opt_params prm = a.prm;
+    const double inv_homog = 1.0 / prm.homog_th;
 
     // ---------------- ownership: thread t owns prev points t + k BLOCK and prev line BLOCK - 1 - t ----------------
     // (lines are handed out from the top: the last threads own the fewest points, a line term costs about two points)
@@ -378,6 +380,7 @@ __global__ __launch_bounds__(NW * 64, 2) void pose2p_kernel(PoseArgs a, const in
             }
             sl = pm::clamp_scale(Ops::template mad_sigma<LPT, true>(rlv, linl, sh->n_inl_l, s_hist, &sh->xchg));
         }
+        const double isp = 1.0 / sp, isl = 1.0 / sl;  // reciprocals of the robust scales: one division per evaluation, not per feature
         const long long tw0 = tick();
         double acc[28];
 #pragma unroll
@@ -410,26 +413,26 @@ __global__ __launch_bounds__(NW * 64, 2) void pose2p_kernel(PoseArgs a, const in
                 todo &= todo - 1u;
                 PointRec2 nxt = cur;
                 if (todo) nxt = load_point_lds(__builtin_ctz(todo));
-                pm::point_term_q(acc, DT, cam, prm.homog_th, cur.X, cur.Y, cur.Z, cur.ox, cur.oy, cur.q, robust, sp);
+                pm::point_term_q(acc, DT, cam, prm.homog_th, inv_homog, cur.X, cur.Y, cur.Z, cur.ox, cur.oy, cur.q, robust, isp);
                 cur = nxt;
             }
             for (;;) {
                 if (!v0) break;
-                pm::point_term_q(acc, DT, cam, prm.homog_th, r0.X, r0.Y, r0.Z, r0.ox, r0.oy, r0.q, robust, sp);
+                pm::point_term_q(acc, DT, cam, prm.homog_th, inv_homog, r0.X, r0.Y, r0.Z, r0.ox, r0.oy, r0.q, robust, isp);
                 v0 = req(r0);
                 if (!v1) break;
-                pm::point_term_q(acc, DT, cam, prm.homog_th, r1.X, r1.Y, r1.Z, r1.ox, r1.oy, r1.q, robust, sp);
+                pm::point_term_q(acc, DT, cam, prm.homog_th, inv_homog, r1.X, r1.Y, r1.Z, r1.ox, r1.oy, r1.q, robust, isp);
                 v1 = req(r1);
                 if (!v2) break;
-                pm::point_term_q(acc, DT, cam, prm.homog_th, r2.X, r2.Y, r2.Z, r2.ox, r2.oy, r2.q, robust, sp);
+                pm::point_term_q(acc, DT, cam, prm.homog_th, inv_homog, r2.X, r2.Y, r2.Z, r2.ox, r2.oy, r2.q, robust, isp);
                 v2 = req(r2);
             }
-            if (kl0 >= 0) pm::line_term_q(acc, DT, cam, prm.homog_th, L0, robust, sl);
+            if (kl0 >= 0) pm::line_term_q(acc, DT, cam, prm.homog_th, inv_homog, L0, robust, isl);
 #pragma unroll 1
             for (int k = 0; k < LPT; ++k)
                 if (((linl >> k) & 1u) && k != kl0) {
                     const pm::LineRec L = load_line(k);
-                    pm::line_term_q(acc, DT, cam, prm.homog_th, L, robust, sl);
+                    pm::line_term_q(acc, DT, cam, prm.homog_th, inv_homog, L, robust, isl);
                 }
         }
         const long long tw1 = tick();
@@ -549,7 +552,7 @@ __global__ __launch_bounds__(NW * 64, 2) void pose2p_kernel(PoseArgs a, const in
         __syncthreads();
     };
 
-    const PoseFlow fl = optimize_pose_flow(sh, prm, w0, evaluate, remove_outliers, tick, tprof);
+    const PoseFlow fl = optimize_pose_flow(sh, [&]() -> const stvo_opt_params& { return prm; }, w0, evaluate, remove_outliers, tick, tprof);
     const int status = fl.status, path = fl.path, it0 = fl.it0, it1 = fl.it1;
 
     {
@@ -606,7 +609,7 @@ constexpr int pose2c_planes() {  // record ordinals per thread in LDS: 12 x 128 
 }
 
 struct CompactRec {
-    float4 a;   // u, v of the prev stereo point; ox, oy: the matched key-point of the current frame
+    float4 uvo; // u, v of the prev stereo point; ox, oy: the matched key-point of the current frame
     double bd;  // b / disparity
     double q;   // sqrt(sigma2)
 };
@@ -620,14 +623,27 @@ __device__ __noinline__ CompactRec pose2c_fetch_slow(const float4* prev_rc, cons
     const size_t j = m12p ? pbase + (size_t)m12p[i] : i;
     const float4 p = prev_rc[i], c = curr_rc[j];
     CompactRec rec;
-    rec.a = make_float4(p.x, p.y, c.x, c.y);
+    rec.uvo = make_float4(p.x, p.y, c.x, c.y);
     rec.bd = cam_b / (double)p.z;
     rec.q = sqrt(pm::level_sigma2((int)p.w, level_scale));
     return rec;
 }
 
 template <int NW, bool PROF>
-__global__ __launch_bounds__(NW * 64, 2) void pose2c_kernel(PoseArgs a, double2* arena, const size_t arena_pair) {
+__global__ __launch_bounds__(NW * 64, 2) void pose2c_kernel(PoseArgs a_by_value, double2* arena, const size_t arena_pair) {
+    // The ~35 pointers and scalars of PoseArgs are read from the kernel-argument segment WHERE THEY ARE USED, through a pointer the
+    // compiler cannot see through: as ordinary by-value arguments they are all loaded at the top of the kernel and stay live — most
+    // of them until the epilogue — in SGPRs the evaluation loop needs (it then reloads spilled scalars with v_readlane on every
+    // trip: 9 of its 137 vector instructions).  PoseArgs is the first kernel argument: offset 0 of the segment.
+    (void)a_by_value;
+    typedef const PoseArgs __attribute__((address_space(4))) KArgs;
+    KArgs* const kargs = (KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    auto ka = [&]() -> KArgs& {
+        KArgs* p = kargs;
+        asm volatile("" : "+s"(p));
+        return *p;
+    };
+
     constexpr int BLOCK = NW * 64;
     constexpr int PPT = (STVO_POSE_MAX_POINTS + BLOCK - 1) / BLOCK;
     constexpr int LPT = (STVO_POSE_MAX_LINES + BLOCK - 1) / BLOCK;
@@ -651,24 +667,30 @@ __global__ __launch_bounds__(NW * 64, 2) void pose2c_kernel(PoseArgs a, double2*
         else return 0ll;
     };
     const long long t_begin = tick();
-    const stvo_cam cam_f = a.cams ? a.cams[f] : a.cam;
+    stvo_cam cam_f;
+    if (ka().cams) {
+        cam_f = ka().cams[f];
+    } else {
+        cam_f.fx = ka().cam.fx; cam_f.fy = ka().cam.fy; cam_f.cx = ka().cam.cx; cam_f.cy = ka().cam.cy; cam_f.b = ka().cam.b;
+    }
     const pm::Cam5 cam{cam_f.fx, cam_f.fy, cam_f.cx, cam_f.cy};
     const double cam_b = cam_f.b;
-    const stvo_opt_params prm = a.prm;
+    const double homog_th = ka().prm.homog_th, inv_homog = 1.0 / homog_th;
 
     // ---------------- ownership (as pose2p_kernel): thread t owns prev points t + k BLOCK and prev line BLOCK - 1 - t ----------------
     unsigned pmatched = 0u, pinl = 0u;
-    const int n_prev_p = a.n_prev_pts != nullptr ? min(a.n_prev_pts[f], a.max_pts) : 0;
-    const size_t pbase = (size_t)f * a.max_pts;
+    const int n_prev_p = ka().n_prev_pts != nullptr ? min(ka().n_prev_pts[f], ka().max_pts) : 0;
+    const size_t pbase = (size_t)f * ka().max_pts;
     int jj[PPT];
     {
         int init[PPT];
+        const int last = ka().max_pts - 1;
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) {
+        for (int k = 0; k < PPT; ++k) {  // (addresses clamped to the pair's slot, not to its count: the loads do not wait for n_prev_pts)
             const int i = tid + k * BLOCK;
-            const int ic = i < n_prev_p ? i : 0;
-            jj[k] = a.m12p ? a.m12p[pbase + ic] : ic;
-            init[k] = a.init_inl_p ? a.init_inl_p[pbase + ic] : 1;
+            const int ic = i < last ? i : last;
+            jj[k] = ka().m12p ? ka().m12p[pbase + ic] : ic;
+            init[k] = ka().init_inl_p ? ka().init_inl_p[pbase + ic] : 1;
         }
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
@@ -682,8 +704,8 @@ __global__ __launch_bounds__(NW * 64, 2) void pose2c_kernel(PoseArgs a, double2*
         }
     }
     unsigned lmatched = 0u, linl = 0u;
-    const int n_prev_l = (a.n_prev_lines != nullptr && a.max_lines > 0) ? a.n_prev_lines[f] : 0;
-    const size_t lbase = (size_t)f * a.max_lines;
+    const int n_prev_l = (ka().n_prev_lines != nullptr && ka().max_lines > 0) ? ka().n_prev_lines[f] : 0;
+    const size_t lbase = (size_t)f * ka().max_lines;
     const int li0 = BLOCK - 1 - tid;
     int jl[LPT];
     {
@@ -691,14 +713,14 @@ __global__ __launch_bounds__(NW * 64, 2) void pose2c_kernel(PoseArgs a, double2*
 #pragma unroll
         for (int k = 0; k < LPT; ++k) {
             const int li = li0 + k * BLOCK;
-            const int lc = (li < n_prev_l && li < a.max_lines) ? li : 0;
-            jl[k] = (a.m12l && a.max_lines > 0) ? a.m12l[lbase + lc] : lc;
-            initl[k] = (a.init_inl_l && a.max_lines > 0) ? a.init_inl_l[lbase + lc] : 1;
+            const int lc = (li < n_prev_l && li < ka().max_lines) ? li : 0;
+            jl[k] = (ka().m12l && ka().max_lines > 0) ? ka().m12l[lbase + lc] : lc;
+            initl[k] = (ka().init_inl_l && ka().max_lines > 0) ? ka().init_inl_l[lbase + lc] : 1;
         }
 #pragma unroll
         for (int k = 0; k < LPT; ++k) {
             const int li = li0 + k * BLOCK;
-            if (li < n_prev_l && li < a.max_lines && jl[k] >= 0) {
+            if (li < n_prev_l && li < ka().max_lines && jl[k] >= 0) {
                 lmatched |= 1u << k;
                 if (initl[k] != 0) linl |= 1u << k;
             } else {
@@ -718,7 +740,7 @@ __global__ __launch_bounds__(NW * 64, 2) void pose2c_kernel(PoseArgs a, double2*
     double xb = 1.0;
     {
         int r = 0;
-        constexpr int STAGE_CH = PPT < 8 ? PPT : 8;
+        constexpr int STAGE_CH = PPT;  // both records of every slot in flight at once: one round trip (32 x 16 bytes per thread)
 #pragma unroll
         for (int k0 = 0; k0 < PPT; k0 += STAGE_CH) {
             float4 pv[STAGE_CH], cv[STAGE_CH];
@@ -727,8 +749,8 @@ __global__ __launch_bounds__(NW * 64, 2) void pose2c_kernel(PoseArgs a, double2*
                 const int k = k0 + c;
                 if (k >= PPT) continue;
                 const int ik = tid + k * BLOCK;
-                pv[c] = a.prev_rc[pbase + (size_t)(ik < n_prev_p ? ik : 0)];
-                cv[c] = a.curr_rc[pbase + (size_t)jj[k]];
+                pv[c] = ka().prev_rc[pbase + (size_t)(ik < n_prev_p ? ik : 0)];  // (index 0 for the slots past the count: one cache line)
+                cv[c] = ka().curr_rc[pbase + (size_t)jj[k]];
             }
 #pragma unroll
             for (int c = 0; c < STAGE_CH; ++c) {
@@ -760,6 +782,11 @@ __global__ __launch_bounds__(NW * 64, 2) void pose2c_kernel(PoseArgs a, double2*
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) n_trip = max(n_trip, __shfl_xor(n_trip, off, 64));
     n_trip = __builtin_amdgcn_readfirstlane(n_trip);
+    // After removeOutliers the inliers are re-dealt to the threads (compact_inliers below): `dealt` (block-uniform) says that the
+    // LDS planes hold ONLY inliers, in a dense layout the owner-space masks no longer describe — inl_w are then the plane ordinals
+    // this thread holds.  inl_o / pmatched keep describing the thread's own prev points (the mask written at the end).
+    bool dealt = false;
+    unsigned inl_w = 0u;
 
     // key-lines: the arena, plane layout [ordinal][7 parts][thread] (as pose2p_kernel)
     double2* ar_l = arena + (size_t)f * arena_pair;
@@ -781,13 +808,13 @@ __global__ __launch_bounds__(NW * 64, 2) void pose2c_kernel(PoseArgs a, double2*
             const size_t j = lbase + (size_t)jl[k];
             const int r = __popc(lmatched & ((1u << k) - 1u));
             double2* q = ar_l + (size_t)(r * 7) * BLOCK + tid;
-            q[0] = make_double2(a.prev_sP[i * 3 + 0], a.prev_sP[i * 3 + 1]);
-            q[BLOCK] = make_double2(a.prev_sP[i * 3 + 2], a.prev_eP[i * 3 + 0]);
-            q[2 * BLOCK] = make_double2(a.prev_eP[i * 3 + 1], a.prev_eP[i * 3 + 2]);
-            q[3 * BLOCK] = make_double2(a.curr_le[j * 3 + 0], a.curr_le[j * 3 + 1]);
-            q[4 * BLOCK] = make_double2(a.curr_le[j * 3 + 2], a.prev_spl[i * 2 + 0]);
-            q[5 * BLOCK] = make_double2(a.prev_spl[i * 2 + 1], a.prev_epl[i * 2 + 0]);
-            q[6 * BLOCK] = make_double2(a.prev_epl[i * 2 + 1], sqrt(a.prev_s2l[i]));  // the record carries sqrt(sigma2) (pm::line_term_q)
+            q[0] = make_double2(ka().prev_sP[i * 3 + 0], ka().prev_sP[i * 3 + 1]);
+            q[BLOCK] = make_double2(ka().prev_sP[i * 3 + 2], ka().prev_eP[i * 3 + 0]);
+            q[2 * BLOCK] = make_double2(ka().prev_eP[i * 3 + 1], ka().prev_eP[i * 3 + 2]);
+            q[3 * BLOCK] = make_double2(ka().curr_le[j * 3 + 0], ka().curr_le[j * 3 + 1]);
+            q[4 * BLOCK] = make_double2(ka().curr_le[j * 3 + 2], ka().prev_spl[i * 2 + 0]);
+            q[5 * BLOCK] = make_double2(ka().prev_spl[i * 2 + 1], ka().prev_epl[i * 2 + 0]);
+            q[6 * BLOCK] = make_double2(ka().prev_epl[i * 2 + 1], sqrt(ka().prev_s2l[i]));  // the record carries sqrt(sigma2) (pm::line_term_q)
         }
     // (a thread reads back only what it wrote itself: program order is enough, no fence)
 
@@ -803,7 +830,7 @@ __global__ __launch_bounds__(NW * 64, 2) void pose2c_kernel(PoseArgs a, double2*
             sh->err_out = -1.0;  // :313
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const double v = a.init_T ? a.init_T[(size_t)f * 16 + i] : ((i % 5 == 0) ? 1.0 : 0.0);
+                const double v = ka().init_T ? ka().init_T[(size_t)f * 16 + i] : ((i % 5 == 0) ? 1.0 : 0.0);
                 sh->DT[i] = v;
                 sh->DT0[i] = v;
             }
@@ -828,20 +855,21 @@ __global__ __launch_bounds__(NW * 64, 2) void pose2c_kernel(PoseArgs a, double2*
         *ox = (double)av.z;
         *oy = (double)av.w;
     };
-    auto q_of = [&](unsigned nib) -> double { return a.q_tab[nib]; };
+    const double* const qtab = ka().q_tab;  // (hot: stays in two SGPRs)
+    auto q_of = [&](unsigned nib) -> double { return qtab[nib]; };
     auto fetch_slow = [&](int r) -> CompactRec {
-        return pose2c_fetch_slow(a.prev_rc, a.curr_rc, a.m12p, pbase, tid, BLOCK, pmatched, r, cam_b, a.level_scale);
+        return pose2c_fetch_slow(ka().prev_rc, ka().curr_rc, ka().m12p, pbase, tid, BLOCK, pmatched, r, cam_b, ka().level_scale);
     };
     // record ordinal R (compile-time) of this thread, wherever it lives
     auto fetch = [&](auto rc) -> CompactRec {
         constexpr int R = decltype(rc)::value;
         CompactRec rec;
-        if ((slow_o >> R) & 1u) return fetch_slow(R);
+        if (!dealt && ((slow_o >> R) & 1u)) return fetch_slow(R);
         if constexpr (R < KL) {
-            rec.a = s_ra[R * BLOCK + tid];
+            rec.uvo = s_ra[R * BLOCK + tid];
             rec.bd = s_rb[R * BLOCK + tid];
         } else {
-            rec.a = xa;
+            rec.uvo = xa;
             rec.bd = xb;
         }
         rec.q = q_of((unsigned)(lv >> (4 * R)) & 15u);
@@ -849,7 +877,7 @@ __global__ __launch_bounds__(NW * 64, 2) void pose2c_kernel(PoseArgs a, double2*
     };
     auto residual_of = [&](const double* DT, const CompactRec& rec) -> double {
         double X, Y, Z, ox, oy;
-        rebuild(rec.a, rec.bd, &X, &Y, &Z, &ox, &oy);
+        rebuild(rec.uvo, rec.bd, &X, &Y, &Z, &ox, &oy);
         return pm::point_residual(DT, cam, X, Y, Z, ox, oy);
     };
     // residual norms of the records in `mask` (ordinal space), by ordinal; scaled by sqrt(sigma2) when `weighted`
@@ -877,8 +905,9 @@ __global__ __launch_bounds__(NW * 64, 2) void pose2c_kernel(PoseArgs a, double2*
         double sp = 1.0, sl = 1.0;
         if (robust) {  // pre-pass :710-781: MAD scale of the inlier residual norms
             double rp[PPT];
-            residuals(DT, inl_o, false, rp);
-            sp = pm::clamp_scale(Ops::template mad_sigma<PPT, true>(rp, inl_o, sh->n_inl_p, s_hist, &sh->xchg));
+            const unsigned pre = dealt ? inl_w : inl_o;
+            residuals(DT, pre, false, rp);
+            sp = pm::clamp_scale(Ops::template mad_sigma<PPT, true>(rp, pre, sh->n_inl_p, s_hist, &sh->xchg));
             double rlv[LPT];
 #pragma unroll
             for (int k = 0; k < LPT; ++k) {
@@ -887,6 +916,7 @@ __global__ __launch_bounds__(NW * 64, 2) void pose2c_kernel(PoseArgs a, double2*
             }
             sl = pm::clamp_scale(Ops::template mad_sigma<LPT, true>(rlv, linl, sh->n_inl_l, s_hist, &sh->xchg));
         }
+        const double isp = 1.0 / sp, isl = 1.0 / sl;  // reciprocals of the robust scales: one division per evaluation, not per feature
         const long long tw0 = tick();
         double acc[28];
 #pragma unroll
@@ -894,7 +924,7 @@ __global__ __launch_bounds__(NW * 64, 2) void pose2c_kernel(PoseArgs a, double2*
         auto term = [&](const float4& av, double bd, double q) {
             double X, Y, Z, ox, oy;
             rebuild(av, bd, &X, &Y, &Z, &ox, &oy);
-            pm::point_term_q(acc, DT, cam, prm.homog_th, X, Y, Z, ox, oy, q, robust, sp);
+            pm::point_term_q(acc, DT, cam, homog_th, inv_homog, X, Y, Z, ox, oy, q, robust, isp);
         };
         {
             // the thread's first inlier line is requested first (global memory), the points run while it is in flight
@@ -905,7 +935,7 @@ __global__ __launch_bounds__(NW * 64, 2) void pose2c_kernel(PoseArgs a, double2*
                 L0 = load_line(kl0);
             }
             // LDS planes, ascending ordinal, one record ahead; the plane pointers advance by a constant
-            const unsigned hot = inl_o & ~slow_o;
+            const unsigned hot = dealt ? inl_w : (inl_o & ~slow_o);
             const float4* pa = s_ra + tid;
             const double* pb = s_rb + tid;
             float4 av = pa[0];
@@ -924,19 +954,19 @@ __global__ __launch_bounds__(NW * 64, 2) void pose2c_kernel(PoseArgs a, double2*
             if constexpr (HAS_REG) {
                 if ((hot >> KL) & 1u) term(xa, xb, q_of((unsigned)(lv >> (4 * KL)) & 15u));
             }
-            unsigned slow = inl_o & slow_o;  // off-chip records (none in the usual shapes), still in ascending ordinal
+            unsigned slow = dealt ? 0u : (inl_o & slow_o);  // off-chip records (none in the usual shapes), still in ascending ordinal
             while (slow) {
                 const int r = __builtin_ctz(slow);
                 slow &= slow - 1u;
                 const CompactRec rec = fetch_slow(r);
-                term(rec.a, rec.bd, rec.q);
+                term(rec.uvo, rec.bd, rec.q);
             }
-            if (kl0 >= 0) pm::line_term_q(acc, DT, cam, prm.homog_th, L0, robust, sl);
+            if (kl0 >= 0) pm::line_term_q(acc, DT, cam, homog_th, inv_homog, L0, robust, isl);
 #pragma unroll 1
             for (int k = 0; k < LPT; ++k)
                 if (((linl >> k) & 1u) && k != kl0) {
                     const pm::LineRec L = load_line(k);
-                    pm::line_term_q(acc, DT, cam, prm.homog_th, L, robust, sl);
+                    pm::line_term_q(acc, DT, cam, homog_th, inv_homog, L, robust, isl);
                 }
         }
         const long long tw1 = tick();
@@ -960,11 +990,86 @@ __global__ __launch_bounds__(NW * 64, 2) void pose2c_kernel(PoseArgs a, double2*
         wprof[2] += tick() - tw2;
     };
 
+    // ---------------- the refinement's working set: the inliers, dealt evenly to the threads ----------------
+    // A thread owns the matches of ITS prev points (binomial: ~11.6 +- 1.1 of 13 at the bench shape, 13 trips per evaluation for
+    // the wave) and after removeOutliers ~70 % of them are inliers, scattered over its ordinals — the refinement (8.6 of the 13.6
+    // evaluations of a pair) would keep walking 13 planes for ~8 records per thread.  So the inliers are re-dealt: inlier number g
+    // of the pair (threads in order, ordinals ascending) goes to plane g / BLOCK of thread g % BLOCK — every thread reads its
+    // inlier records into registers, barrier, writes them to their new slots (the planes are big enough: at most KL + 1 records per
+    // thread came from them), the 4-bit levels travel through the selection histogram's LDS (free between selections).  The
+    // refinement then runs ceil(inliers / BLOCK) trips (~9) with every lane busy.  Skipped (block-uniform) when some inlier is
+    // off chip or the dense layout would not fit the planes; the sums are then formed in a different order than pose_kernel.hip's
+    // (a few roundings), the inlier masks / counts / iteration logic are untouched.
+    auto compact_inliers = [&]() {
+        unsigned char* const s_lvb = reinterpret_cast<unsigned char*>(&s_hist[0][0]);  // [KL * BLOCK] level nibbles
+        static_assert(sizeof(s_hist) >= (size_t)KL * BLOCK, "the level bytes of a full set of planes fit the histogram scratch");
+        const unsigned mov = inl_o & ~slow_o;
+        const int c = __popc(mov);
+        // exclusive scan of c over the threads + the number of off-chip inliers of the pair
+        int incl = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        const int n_slow = Ops::template sum_int<true>(__popc(inl_o & slow_o), s_ired);
+        if (lane == 63) s_ired[wv] = incl;
+        __syncthreads();
+        int base = incl - c, total = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const int cw = s_ired[w];
+            if (w < wv) base += cw;
+            total += cw;
+        }
+        __syncthreads();
+        if (n_slow != 0 || total > KL * BLOCK) return;  // block-uniform: keep the owner layout
+        float4 ra[KL + 1];
+        double rb[KL + 1];
+        auto take = [&](auto rc) {
+            constexpr int R = decltype(rc)::value;
+            if constexpr (R < KL) {
+                ra[R] = s_ra[R * BLOCK + tid];
+                rb[R] = s_rb[R * BLOCK + tid];
+            } else {
+                ra[R] = xa;
+                rb[R] = xb;
+            }
+        };
+        static_for<0, HAS_REG ? KL + 1 : KL>(take);
+        __syncthreads();  // every record has been read: the planes can be overwritten
+        {
+            int g = base;
+            auto put = [&](auto rc) {
+                constexpr int R = decltype(rc)::value;
+                if ((mov >> R) & 1u) {
+                    s_ra[g] = ra[R];
+                    s_rb[g] = rb[R];
+                    s_lvb[g] = (unsigned char)((lv >> (4 * R)) & 15u);
+                    ++g;
+                }
+            };
+            static_for<0, HAS_REG ? KL + 1 : KL>(put);
+        }
+        __syncthreads();
+        const int n_hold = tid < total ? (total - tid + BLOCK - 1) / BLOCK : 0;  // slots g = r BLOCK + tid below total
+        unsigned long long lvn = 0ull;
+#pragma unroll
+        for (int r = 0; r < KL; ++r)
+            if (r < n_hold) lvn |= (unsigned long long)s_lvb[r * BLOCK + tid] << (4 * r);
+        lv = lvn;
+        inl_w = n_hold > 0 ? ((1u << n_hold) - 1u) : 0u;
+        dealt = true;
+        const int first = wv * 64;  // the wave's first thread holds the most
+        n_trip = first < total ? (total - first + BLOCK - 1) / BLOCK : 0;
+        __syncthreads();  // s_lvb (the selection scratch) is free again
+    };
+
     // ---------------- removeOutliers at pose DT1 (:988-1067) ----------------
     auto remove_outliers = [&]() {
         double DT[12];
         pose_sgpr(sh->DT1, DT);
-        if (prm.has_points) {
+        if (ka().prm.has_points) {
             double res[PPT];
             const int tot = sh->n_m_p;
             residuals(DT, m_o, true, res);  // ALL matches, current outliers included (:998-1005)
@@ -986,14 +1091,14 @@ __global__ __launch_bounds__(NW * 64, 2) void pose2c_kernel(PoseArgs a, double2*
                 const int ksel = (int)t[1];
                 mean = (ksel >= (int)(0.2 * (double)tot)) ? t[0] / (double)ksel : t[2] / (double)tot;
             }
-            const double th = prm.inlier_k * stdv;
+            const double th = ka().prm.inlier_k * stdv;
 #pragma unroll
             for (int r = 0; r < PPT; ++r)
                 if (((inl_o >> r) & 1u) && fabs(res[r] - mean) > th) inl_o &= ~(1u << r);
             const int nip = Ops::template sum_int<true>(__popc(inl_o), s_ired);
             if (w0) sh->n_inl_p = nip;
         }
-        if (prm.has_lines) {
+        if (ka().prm.has_lines) {
             double res[LPT];
             const int tot = sh->n_m_l;
 #pragma unroll
@@ -1022,7 +1127,7 @@ __global__ __launch_bounds__(NW * 64, 2) void pose2c_kernel(PoseArgs a, double2*
                 const int ksel = (int)t[1];
                 mean = (ksel >= (int)(0.2 * (double)tot)) ? t[0] / (double)ksel : t[2] / (double)tot;
             }
-            const double th = prm.inlier_k * stdv;
+            const double th = ka().prm.inlier_k * stdv;
 #pragma unroll
             for (int k = 0; k < LPT; ++k)
                 if (((linl >> k) & 1u) && fabs(res[k] - mean) > th) linl &= ~(1u << k);
@@ -1030,39 +1135,41 @@ __global__ __launch_bounds__(NW * 64, 2) void pose2c_kernel(PoseArgs a, double2*
             if (w0) sh->n_inl_l = nil;
         }
         __syncthreads();
+        compact_inliers();
     };
 
-    const PoseFlow fl = optimize_pose_flow(sh, prm, w0, evaluate, remove_outliers, tick, tprof);
+    const PoseFlow fl = optimize_pose_flow(sh, [&]() -> const stvo_opt_params __attribute__((address_space(4)))& { return ka().prm; }, w0, evaluate,
+                                           remove_outliers, tick, tprof);
 
     {
         const long long tq3 = tick();
-        if (t0) t0_commit(sh, a.results + f, fl.status, fl.path, fl.it0, fl.it1);
+        if (t0) t0_commit(sh, ka().results + f, fl.status, fl.path, fl.it0, fl.it1);
         tprof[2] += tick() - tq3;
     }
     if (PROF && t0) {
         tprof[4] = tick() - t_begin;
 #pragma unroll
-        for (int i = 0; i < 5; ++i) a.prof_out[(size_t)f * 16 + i] = tprof[i];
+        for (int i = 0; i < 5; ++i) ka().prof_out[(size_t)f * 16 + i] = tprof[i];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) a.prof_out[(size_t)f * 16 + 5 + i] = wprof[i];
-        a.prof_out[(size_t)f * 16 + 14] = t_prologue;
+        for (int i = 0; i < 3; ++i) ka().prof_out[(size_t)f * 16 + 5 + i] = wprof[i];
+        ka().prof_out[(size_t)f * 16 + 14] = t_prologue;
     }
-    if (PROF && lane == 0 && (wv < 6 || wv == NW - 1)) a.prof_out[(size_t)f * 16 + 8 + (wv < 6 ? wv : 7)] = wave_busy;
+    if (PROF && lane == 0 && (wv < 6 || wv == NW - 1)) ka().prof_out[(size_t)f * 16 + 8 + (wv < 6 ? wv : 7)] = wave_busy;
 
-    if (a.inl_p_out) {  // back to slots: prev point tid + k BLOCK is the thread's popc(pmatched below k)-th record
-        const size_t base = (size_t)f * a.max_pts;
+    if (ka().inl_p_out) {  // back to slots: prev point tid + k BLOCK is the thread's popc(pmatched below k)-th record
+        const size_t base = (size_t)f * ka().max_pts;
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
             const int i = tid + k * BLOCK;
             const int r = __popc(pmatched & ((1u << k) - 1u));
-            if (i < a.max_pts) a.inl_p_out[base + i] = ((pmatched >> k) & 1u) ? (int)((inl_o >> r) & 1u) : -1;
+            if (i < ka().max_pts) ka().inl_p_out[base + i] = ((pmatched >> k) & 1u) ? (int)((inl_o >> r) & 1u) : -1;
         }
     }
-    if (a.inl_l_out && a.max_lines > 0) {
+    if (ka().inl_l_out && ka().max_lines > 0) {
 #pragma unroll
         for (int k = 0; k < LPT; ++k) {
             const int li = li0 + k * BLOCK;
-            if (li < a.max_lines) a.inl_l_out[(size_t)f * a.max_lines + li] = ((lmatched >> k) & 1u) ? (int)((linl >> k) & 1u) : -1;
+            if (li < ka().max_lines) ka().inl_l_out[(size_t)f * ka().max_lines + li] = ((lmatched >> k) & 1u) ? (int)((linl >> k) & 1u) : -1;
         }
     }
 }

@@ -1012,47 +1012,120 @@ PM_HD void accumulate28w(double* acc, const double* J, double r, double w) {
     acc[27] += (r * r) * w;
 }
 
-// point_term with sqrt(sigma2) supplied by the caller (computed once per record instead of once per evaluation).
-PM_HD void transform_project_fast(const double* DT, double X, double Y, double Z, const Cam5& cam, double* Pc, double* uv) {
-    Pc[0] = DT[0] * X + DT[1] * Y + DT[2] * Z + DT[3];
-    Pc[1] = DT[4] * X + DT[5] * Y + DT[6] * Z + DT[7];
-    Pc[2] = DT[8] * X + DT[9] * Y + DT[10] * Z + DT[11];
-    const double iz = fast_rcp(Pc[2]);
-    uv[0] = cam.cx + cam.fx * Pc[0] * iz;
-    uv[1] = cam.cy + cam.fy * Pc[1] * iz;
+// ---- the per-feature term of the kernels, written ONCE for one record (T = double) and for two records side by side
+// (T = d2, device only): every operation of the pair form is the scalar operation on both components, adjacent in the instruction
+// stream.  A term is a chain of ~60 dependent FP64 instructions and a wave retires one of those every ~8 cycles: the pair form
+// fills the gaps with the other record (the compiler does NOT interleave two inlined scalar terms on its own — it schedules them
+// one after the other).  Same expression trees, hence the same contractions and the same values as the scalar form.
+#if defined(__HIPCC__)
+typedef double d2 __attribute__((ext_vector_type(2)));
+PM_HD d2 t_rcp(d2 x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    d2 y = {__builtin_amdgcn_rcp(x.x), __builtin_amdgcn_rcp(x.y)};
+    d2 e = {fma(-x.x, y.x, 1.0), fma(-x.y, y.y, 1.0)};
+    y = d2{fma(y.x, e.x, y.x), fma(y.y, e.y, y.y)};
+    e = d2{fma(-x.x, y.x, 1.0), fma(-x.y, y.y, 1.0)};
+    return d2{fma(y.x, e.x, y.x), fma(y.y, e.y, y.y)};
+#else
+    return d2{fast_rcp(x.x), fast_rcp(x.y)};  // (the host pass only parses the kernels)
+#endif
 }
-PM_HD void grad6_fast(const double* Pc, double dx, double dy, double fx, double homog_th, double* J) {
-    const double gx = Pc[0], gy = Pc[1], gz = Pc[2];
-    const double gz2 = gz * gz;
-    const double fgz2 = fx * fast_rcp(dmax(homog_th, gz2));
-    J[0] = +fgz2 * dx * gz;
-    J[1] = +fgz2 * dy * gz;
-    J[2] = -fgz2 * (gx * dx + gy * dy);
-    J[3] = -fgz2 * (gx * gy * dx + gy * gy * dy + gz * gz * dy);
-    J[4] = +fgz2 * (gx * gx * dx + gz * gz * dx + gx * gy * dy);
-    J[5] = +fgz2 * (gx * gz * dy - gy * gz * dx);
+PM_HD d2 t_sqrt(d2 x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const d2 y = {__builtin_amdgcn_rsq(x.x), __builtin_amdgcn_rsq(x.y)};
+    d2 g = x * y, h = 0.5 * y;
+    const d2 r = {fma(-h.x, g.x, 0.5), fma(-h.y, g.y, 0.5)};
+    g = d2{fma(g.x, r.x, g.x), fma(g.y, r.y, g.y)};
+    h = d2{fma(h.x, r.x, h.x), fma(h.y, r.y, h.y)};
+    const d2 d = {fma(-g.x, g.x, x.x), fma(-g.y, g.y, x.y)};
+    g = d2{fma(d.x, h.x, g.x), fma(d.y, h.y, g.y)};
+    return d2{x.x > 0.0 ? g.x : x.x, x.y > 0.0 ? g.y : x.y};
+#else
+    return d2{fast_sqrt(x.x), fast_sqrt(x.y)};
+#endif
+}
+PM_HD d2 t_sel_gt(d2 a, double b, d2 x, double y) { return d2{a.x > b ? x.x : y, a.y > b ? x.y : y}; }  // a > b ? x : y
+PM_HD void t_acc(double& acc, d2 a, d2 b) {  // acc += a b, component 0 first: the order of two consecutive scalar terms
+    acc += a.x * b.x;
+    acc += a.y * b.y;
+}
+#endif
+PM_HD double t_rcp(double x) { return fast_rcp(x); }
+PM_HD double t_sqrt(double x) { return fast_sqrt(x); }
+PM_HD double t_sel_gt(double a, double b, double x, double y) { return a > b ? x : y; }
+PM_HD void t_acc(double& acc, double a, double b) { acc += a * b; }
+
+// One point of optimizeFunctions[Robust] (or two).  Against the reference's formulas (point_term above, src/stereoFrameHandler.cpp:
+// 563-606): one reciprocal per division by a common denominator; fx / max(homogTh, gz^2) from the reciprocal depth the projection
+// already has (iz^2 when gz^2 exceeds the threshold — every point in front of the camera — 1 / homogTh otherwise, a select);
+// the gradient with the common sub-expression t = gx dx + gy dy factored out and the scale a = fgz2 / max(homogTh, |e|) applied
+// once (J3 = -a (gy t + gz^2 dy), J4 = a (gx t + gz^2 dx) are the reference's terms re-associated: 15 operations instead of 32);
+// the sums weight-first (Jw = J w, one FMA per entry).  Same values up to a few roundings; the kernels are bound by FP64 issue.
+// sqrt_sigma2 comes with the record; robust == true takes the RECIPROCAL of the MAD scale (one division per evaluation); the two
+// variants differ by two selects of block-uniform values, not by a branch: r = |e| sqrt(sigma2), w = Cauchy(r) or r = |e|,
+// w = Cauchy(r / s_p).  wmask (1 or 0) multiplies the weight: 0 makes a (finite) record an exact no-op.  inv_homog = 1 / homogTh.
+template <typename T>
+PM_HD void point_term_t(double* acc, const double* DT, const Cam5& cam, double homog_th, double inv_homog, T X, T Y, T Z, T ox, T oy,
+                        T sqrt_sigma2, bool robust, double inv_s_p, T wmask) {
+    const T gx = DT[0] * X + DT[1] * Y + DT[2] * Z + DT[3];
+    const T gy = DT[4] * X + DT[5] * Y + DT[6] * Z + DT[7];
+    const T gz = DT[8] * X + DT[9] * Y + DT[10] * Z + DT[11];
+    const T iz = t_rcp(gz);
+    const T dx = (cam.cx + cam.fx * gx * iz) - ox, dy = (cam.cy + cam.fy * gy * iz) - oy;
+    const T nrm = t_sqrt(dx * dx + dy * dy);
+    const T gz2 = gz * gz;
+    const T a = (cam.fx * t_sel_gt(gz2, homog_th, iz * iz, inv_homog)) * t_sel_gt(nrm, homog_th, t_rcp(nrm), inv_homog);
+    const T t = gx * dx + gy * dy;
+    const T ag = a * gz;
+    T J[6];
+    J[0] = ag * dx;
+    J[1] = ag * dy;
+    J[2] = -a * t;
+    J[3] = -a * (gy * t + gz2 * dy);
+    J[4] = a * (gx * t + gz2 * dx);
+    J[5] = ag * (gx * dy - gy * dx);
+    const T r = nrm * (robust ? T(1.0) : sqrt_sigma2);
+    const T xx = r * (robust ? inv_s_p : 1.0);
+    const T w = t_rcp(1.0 + xx * xx) * wmask;
+    T Jw[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) Jw[i] = J[i] * w;
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = i; j < 6; ++j) t_acc(acc[k++], Jw[i], J[j]);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) t_acc(acc[21 + i], Jw[i], r);
+    t_acc(acc[27], r * r, w);
+}
+PM_HD void point_term_q(double* acc, const double* DT, const Cam5& cam, double homog_th, double inv_homog, double X, double Y, double Z,
+                        double ox, double oy, double sqrt_sigma2, bool robust, double inv_s_p, double wmask = 1.0) {
+    point_term_t<double>(acc, DT, cam, homog_th, inv_homog, X, Y, Z, ox, oy, sqrt_sigma2, robust, inv_s_p, wmask);
 }
 
-PM_HD void point_term_q(double* acc, const double* DT, const Cam5& cam, double homog_th, double X, double Y, double Z,
-                        double ox, double oy, double sqrt_sigma2, bool robust, double s_p) {
-    double Pc[3], uv[2], J[6];
-    transform_project_fast(DT, X, Y, Z, cam, Pc, uv);
-    const double dx = uv[0] - ox, dy = uv[1] - oy;
-    const double nrm = fast_sqrt(dx * dx + dy * dy);
-    grad6_fast(Pc, dx, dy, cam.fx, homog_th, J);
-    const double iden = fast_rcp(dmax(homog_th, nrm));
-#pragma unroll
-    for (int i = 0; i < 6; ++i) J[i] = J[i] * iden;
-    double r, w;
-    if (!robust) {
-        r = nrm * sqrt_sigma2;
-        w = fast_rcp(1.0 + r * r);
-    } else {
-        r = nrm;
-        const double xx = r / s_p;
-        w = fast_rcp(1.0 + xx * xx);
-    }
-    accumulate28w(acc, J, r, w);
+// the gradient of a line end-point: grad6 scaled by `a`, factored as in point_term_t
+PM_HD void grad6_scaled(const double* Pc, double dx, double dy, double a, double gz2, double* J) {
+    const double gx = Pc[0], gy = Pc[1], gz = Pc[2];
+    const double t = gx * dx + gy * dy;
+    const double ag = a * gz;
+    J[0] = ag * dx;
+    J[1] = ag * dy;
+    J[2] = -a * t;
+    J[3] = -a * (gy * t + gz2 * dy);
+    J[4] = a * (gx * t + gz2 * dx);
+    J[5] = ag * (gx * dy - gy * dx);
+}
+PM_HD double fgz2_of(double fx, double homog_th, double inv_homog, double gz2, double iz) {
+    return fx * (gz2 > homog_th ? iz * iz : inv_homog);
+}
+PM_HD double inv_clamped(double homog_th, double inv_homog, double x) {  // 1 / max(homog_th, x)
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double y = fast_rcp(x);  // (not selected for x == 0)
+    return x > homog_th ? y : inv_homog;
+#else
+    return 1.0 / dmax(homog_th, x);
+#endif
 }
 
 struct LineRec {
@@ -1094,30 +1167,33 @@ PM_HD void line_term(double* acc, const double* DT, const Cam5& cam, double homo
     accumulate28(acc, J, r, w);
 }
 
-// line_term with L.sigma2 already holding sqrt(sigma2), weight-folded accumulation (pose_kernel2.hip)
-PM_HD void line_term_q(double* acc, const double* DT, const Cam5& cam, double homog_th, const LineRec& L, bool robust,
-                       double s_l) {
-    double sPc[3], ePc[3], s[2], t[2], Js[6], Je[6], J[6];
-    transform_project(DT, L.sP[0], L.sP[1], L.sP[2], cam, sPc, s);
-    transform_project(DT, L.eP[0], L.eP[1], L.eP[2], cam, ePc, t);
-    const double ds = L.le[0] * s[0] + L.le[1] * s[1] + L.le[2];
-    const double de = L.le[0] * t[0] + L.le[1] * t[1] + L.le[2];
-    const double nrm = sqrt(ds * ds + de * de);
-    grad6(sPc, L.le[0], L.le[1], cam.fx, homog_th, Js);
-    grad6(ePc, L.le[0], L.le[1], cam.fx, homog_th, Je);
-    const double iden = 1.0 / dmax(homog_th, nrm);
+// line_term with L.sigma2 already holding sqrt(sigma2), weight-folded accumulation, the reciprocals / square root of the point
+// term, and J = (Js ds + Je de) / max(homogTh, |err|) with the two scale factors folded into the end-point gradients
+// (inv_s_l: reciprocal of the robust scale, as for the points).  The overlap weight is the reference's, operation for operation.
+PM_HD void line_term_q(double* acc, const double* DT, const Cam5& cam, double homog_th, double inv_homog, const LineRec& L, bool robust,
+                       double inv_s_l) {
+    double sPc[3], ePc[3], Js[6], Je[6], J[6];
+    sPc[0] = DT[0] * L.sP[0] + DT[1] * L.sP[1] + DT[2] * L.sP[2] + DT[3];
+    sPc[1] = DT[4] * L.sP[0] + DT[5] * L.sP[1] + DT[6] * L.sP[2] + DT[7];
+    sPc[2] = DT[8] * L.sP[0] + DT[9] * L.sP[1] + DT[10] * L.sP[2] + DT[11];
+    ePc[0] = DT[0] * L.eP[0] + DT[1] * L.eP[1] + DT[2] * L.eP[2] + DT[3];
+    ePc[1] = DT[4] * L.eP[0] + DT[5] * L.eP[1] + DT[6] * L.eP[2] + DT[7];
+    ePc[2] = DT[8] * L.eP[0] + DT[9] * L.eP[1] + DT[10] * L.eP[2] + DT[11];
+    const double izs = fast_rcp(sPc[2]), ize = fast_rcp(ePc[2]);
+    const double s0 = cam.cx + cam.fx * sPc[0] * izs, s1 = cam.cy + cam.fy * sPc[1] * izs;
+    const double t0 = cam.cx + cam.fx * ePc[0] * ize, t1 = cam.cy + cam.fy * ePc[1] * ize;
+    const double ds = L.le[0] * s0 + L.le[1] * s1 + L.le[2];
+    const double de = L.le[0] * t0 + L.le[1] * t1 + L.le[2];
+    const double nrm = fast_sqrt(ds * ds + de * de);
+    const double iden = inv_clamped(homog_th, inv_homog, nrm);
+    const double gs2 = sPc[2] * sPc[2], ge2 = ePc[2] * ePc[2];
+    grad6_scaled(sPc, L.le[0], L.le[1], fgz2_of(cam.fx, homog_th, inv_homog, gs2, izs) * (ds * iden), gs2, Js);
+    grad6_scaled(ePc, L.le[0], L.le[1], fgz2_of(cam.fx, homog_th, inv_homog, ge2, ize) * (de * iden), ge2, Je);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) J[i] = (Js[i] * ds + Je[i] * de) * iden;
-    double r, w;
-    if (!robust) {
-        r = nrm * L.sigma2;
-        w = 1.0 / (1.0 + r * r);
-    } else {
-        r = nrm;
-        const double xx = r / s_l;
-        w = 1.0 / (1.0 + xx * xx);
-    }
-    w *= line_overlap(L.spl[0], L.spl[1], L.epl[0], L.epl[1], s[0], s[1], t[0], t[1]);
+    for (int i = 0; i < 6; ++i) J[i] = Js[i] + Je[i];
+    const double r = nrm * (robust ? 1.0 : L.sigma2);
+    const double xx = r * (robust ? inv_s_l : 1.0);
+    const double w = fast_rcp(1.0 + xx * xx) * line_overlap(L.spl[0], L.spl[1], L.epl[0], L.epl[1], s0, s1, t0, t1);
     accumulate28w(acc, J, r, w);
 }
 

@@ -654,6 +654,7 @@ struct stvo_seq {
     stvo_cam* d_cams = nullptr;    // [B] per-sequence calibration (device)
     double* d_inv_wh = nullptr;    // [B][2] per-sequence grid scale (device)
     double* d_qtab = nullptr;      // [STVO_POSE_QTAB] sqrt(sigma2) of pyramid level l (kernels.h: PoseArgs::q_tab)
+    long long* d_prof = nullptr;   // STVO_POSE_PROF (developer aid): [B][16] phase ticks of the last pose launch, printed by stvo_seq_read
     char* dev = nullptr;     // one allocation, carved below
     size_t dev_bytes = 0;
     // pinned mirrors of the raw-feature block: two, used alternately, each guarded by the event of the copy that last
@@ -989,6 +990,7 @@ int stvo_seq_destroy(stvo_seq* s) {
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
     if (s->ctx->aux_stream) (void)hipStreamSynchronize(s->ctx->aux_stream);
+    if (s->d_prof) (void)hipFree(s->d_prof);
     if (s->line_stream) {
         (void)hipStreamSynchronize(s->line_stream);
         (void)hipStreamDestroy(s->line_stream);
@@ -1325,11 +1327,22 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl) {
         a.cams = s->d_cams; a.prm = s->op;
         a.results = s->zero_copy ? reinterpret_cast<stvo_pose_result*>(s->out_host) : s->results;
         a.inl_p_out = s->inlp; a.inl_l_out = s->inll;
+        // small batches with the by-product fetch on (the StereoFrameHandler mirror): the pose kernel writes the inlier masks straight
+        // into the pinned block — like its result — instead of a copy kernel behind it (one launch less on the single-stream chain)
+        const bool inl_zero_copy = s->fetch && s->zero_copy;
+        if (inl_zero_copy) {
+            a.inl_p_out = reinterpret_cast<int32_t*>(s->fetch_host + s->m12_span);
+            a.inl_l_out = reinterpret_cast<int32_t*>(s->fetch_host + s->m12_span + (reinterpret_cast<const char*>(s->inll) - reinterpret_cast<const char*>(s->inlp)));
+        }
+        if (stvo::dbg().pose_prof != stvo::DBG_UNSET) {
+            if (!s->d_prof) HIP_TRY(ctx, hipMalloc((void**)&s->d_prof, (size_t)B * 16 * sizeof(long long)));
+            a.prof_out = s->d_prof;
+        }
         mark(8, st);
         TRY(stvo::launch_pose(st, a));
         mark(9, st);
         if (s->pev[0]) (void)hipEventRecord(s->pev[4], st);
-        if (s->fetch) stvo::launch_copy16(st, s->inlp, s->fetch_host + s->m12_span, s->inl_span);
+        if (s->fetch && !inl_zero_copy) stvo::launch_copy16(st, s->inlp, s->fetch_host + s->m12_span, s->inl_span);
     } else {
         if (par) {  // first frame: nothing to track, but the main stream must still see the line stage's results
             HIP_TRY(ctx, hipEventRecord(s->ev_join, sl));
@@ -1403,6 +1416,17 @@ int stvo_seq_read(stvo_seq* s, stvo_pose_result* results, int32_t* counts) {
     const int B = s->B;
     hipStream_t st = ctx->stream;
     const stvo_seq::Set& ls = s->set[s->cur ^ 1];  // the set built by the last step (cur was flipped)
+    if (s->d_prof && s->frame_idx > 1) {  // STVO_POSE_PROF: mean phase ticks of the last pose launch (as stvo_time_stage_dev prints them)
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        std::vector<long long> h((size_t)B * 16);
+        HIP_TRY(ctx, hipMemcpy(h.data(), s->d_prof, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+        double m[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int f = 0; f < B; ++f)
+            for (int i = 0; i < 16; ++i) m[i] += (double)h[(size_t)f * 16 + i] / B;
+        std::fprintf(stderr, "[pose prof] mean ticks/pair: evaluate %.0f  iter-algebra %.0f  cov+isgood+commit %.0f  remove_outliers %.0f  total %.0f | "
+                             "eval-compute %.0f  fold %.0f  barrier+sum %.0f | prologue %.0f | wave busy %.0f %.0f\n",
+                     m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7], m[14], m[8], m[9]);
+    }
     const bool track = s->frame_idx > 1;
     char* OH = s->out_host;
     const size_t res_bytes = (size_t)B * sizeof(stvo_pose_result);

@@ -12,7 +12,7 @@ import numpy as np
 from .ctypes_types import Cam, GridWindow, MatchParams, OptParams, PoseResult, POSE_RESULT_DTYPE
 
 PKG_DIR = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # stvo-pl_amd/
-LIB_PATH = os.path.join(PKG_DIR, "libstvo_hip.so")
+LIB_PATH = os.environ.get("STVO_LIB") or os.path.join(PKG_DIR, "libstvo_hip.so")   # STVO_LIB: A/B runs of two builds (developer)
 
 EXPORTS = ["stvo_backend_name", "stvo_abi_version", "stvo_error_string", "stvo_ctx_last_error", "stvo_ctx_create",
            "stvo_ctx_destroy", "stvo_ctx_set_stream", "stvo_ctx_synchronize", "stvo_ctx_set_overlap", "stvo_match_nnr_mutual",
