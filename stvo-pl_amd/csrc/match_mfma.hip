@@ -24,12 +24,27 @@
 //     (4 hf + d) + 8 p of that word.  Any mapping works as long as both operands use the same one (a sum over k).
 //     This one costs shift + and + or per four elements: ((w << (7 - s)) & 0x80808080) | 0x40404040 (a single
 //     v_and_or_b32 with the mask in an SGPR was measured: no difference, the kernel is not bound by the VALU count).
+//
+// Round 4 — FP4 operands (template flag FP4, the default): gfx950's block-scaled v_mfma_scale_f32_32x32x64_f8f6f4 takes e2m1
+// elements, and +-4 is one of them (0b0110 / 0b1110): a bit becomes a NIBBLE, a 256-bit row four K = 64 steps instead of eight
+// K = 32 steps, each at the duration of an i8 step — the matrix pipe needs half the time per tile (tools/fp4_probe.hip on
+// MI355X: 151 cycles per 32 x 32 tile of 256-bit distances against 265 - 330 for i8, 16 - 17 T pairs/s register-only against
+// 9 - 10; the probe also checks the operand convention used here against a CPU product, entry for entry).  With both block
+// scales at 2^4 the products are +-16 * 2^8 = +-4096 and the f32 accumulator holds the SAME key as the i8 form,
+// 8192 h + j - 2^20, exactly (|key| < 2^22 even after every rebasing); the C operand carries the row index as before; the fold is
+// v_med3_f32 + v_min_f32.  The query fragments shrink from 64 to 32 VGPRs per wave, the LDS tile from 8 to 4 KB, the fragment
+// reads from 8 to 4 per tile.  Expansion: dword d of a word's fragment holds bits d, d + 4, ..., d + 28 as nibbles:
+// ((w << (3 - d)) & 0x88888888) | 0x66666666 — shift + and-or per eight elements.
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace stvo {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v8i __attribute__((ext_vector_type(8)));
 typedef int v16i __attribute__((ext_vector_type(16)));
+typedef float v16f __attribute__((ext_vector_type(16)));
 
 constexpr int MF_BLOCK = 256;        // 4 waves
 constexpr int MF_TILE = 32;          // train rows per tile
@@ -68,6 +83,29 @@ __device__ __forceinline__ int med3_i32(int a, int b, int c) {
     asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
+// FP4: the 32 bits of a descriptor word as 32 e2m1 nibbles, 0b0110 (+4) for a clear bit, 0b1110 (-4) for a set one
+__device__ __forceinline__ v4i expand_fp4(uint32_t w) {
+    v4i r;
+    r.x = (int)(((w << 3) & 0x88888888u) | 0x66666666u);
+    r.y = (int)(((w << 2) & 0x88888888u) | 0x66666666u);
+    r.z = (int)(((w << 1) & 0x88888888u) | 0x66666666u);
+    r.w = (int)((w & 0x88888888u) | 0x66666666u);
+    return r;
+}
+__device__ __forceinline__ float med3_f32(float a, float b, float c) {
+    float r;
+    asm("v_med3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float min_f32(float a, float b) {  // (no canonicalisation of the operands: they are exact integers)
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+constexpr float MF_NO_KEY_F = 1.0e30f;      // the float form's sentinel: rebasing by -32 never changes it
+constexpr float MF_NO_KEY_MIN_F = 1.0e29f;
+constexpr int MF_SCALE_2_4 = 127 + 4;       // E8M0 block scale 2^4 on both operands: (+-4 * 16)^2 = 4096
+
 // tile-relative key -> K1's (distance << 16) | train index; base = first train row of the tile the key is relative to
 __device__ __forceinline__ uint32_t key_to_knn(int key, int base) {
     if (key >= MF_NO_KEY_MIN) return 0xFFFFFFFFu;
@@ -79,7 +117,9 @@ __device__ __forceinline__ uint32_t key_to_knn(int key, int base) {
 // MODE 1: the query rows listed in qsel (front of the per-frame list, or its back when qsel_from_back) against every train row.
 // MODE 2: as 1, and the train rows are the ones listed in tsel; the indices in the keys are then positions in tsel.
 // (the reverse check of the claimed columns, match_kernels.hip; separate instantiations also keep the uses apart in traces)
-template <int QB, int MODE>
+// FP4: e2m1 operands on the block-scaled matrix instruction (four K = 64 steps per tile, f32 keys); false: the i8 form (eight
+// K = 32 steps, i32 keys) — kept as the measured comparison point (STVO_KNN_I8=1 selects it).
+template <int QB, int MODE, bool FP4>
 __global__ __launch_bounds__(MF_BLOCK, (QB == 1 ? 4 : QB == 2 ? 3 : 1)) void hamming_knn2_mfma_kernel(int B, int tiles, int ndir, int dir0, int nseg, int row_stride,
                                                                       const uint8_t* __restrict__ d1,
                                                                       const int32_t* __restrict__ n1,
@@ -93,7 +133,11 @@ __global__ __launch_bounds__(MF_BLOCK, (QB == 1 ? 4 : QB == 2 ? 3 : 1)) void ham
                                                                       const int32_t* __restrict__ ntsel) {
     constexpr bool GATHER = MODE >= 1, TGATHER = MODE == 2;
     constexpr int ROWS = 4 * QB * 32;  // query rows per workgroup
-    __shared__ v4i s_tile[2][16 * 32];  // [tile parity][(kk * 2 + hf) * 32 + train row] = one 16-byte fragment
+    constexpr int KSTEPS = FP4 ? 4 : 8;  // matrix instructions per 32 x 32 tile of 256-bit distances
+    using key_t = typename std::conditional<FP4, float, int>::type;
+    using acc_t = typename std::conditional<FP4, v16f, v16i>::type;
+    // one 16-byte fragment per (K step, wave half, train row): [tile parity][(kk * 2 + hf) * 32 + train row]
+    __shared__ v4i s_tile[2][KSTEPS * 2 * 32];
     // XCD-aware block -> (frame pair, direction, tile, segment) mapping: as hamming_knn2_kernel
     const int per_frame = tiles * ndir * nseg;
     const int L = blockIdx.x;
@@ -148,7 +192,7 @@ __global__ __launch_bounds__(MF_BLOCK, (QB == 1 ? 4 : QB == 2 ? 3 : 1)) void ham
 
     // query fragments: block qb of this wave = rows q_base + (wv * QB + qb) * 32 + col, kept for the whole scan
     const bool wave_active = q_base + wv * QB * 32 < nq;
-    v4i qf[QB][8];
+    v4i qf[QB][KSTEPS];
     auto query_row = [&](int qb) {  // recomputed for the final store rather than kept live across the scan
         const int q = q_base + (wv * QB + qb) * 32 + col;
         const int qc = q < nq ? q : nq - 1;  // tail lanes scan a valid row and discard the result
@@ -165,20 +209,26 @@ __global__ __launch_bounds__(MF_BLOCK, (QB == 1 ? 4 : QB == 2 ? 3 : 1)) void ham
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         const uint32_t w[8] = {qw[qb][0].x, qw[qb][0].y, qw[qb][0].z, qw[qb][0].w, qw[qb][1].x, qw[qb][1].y, qw[qb][1].z, qw[qb][1].w};
+        if constexpr (FP4) {  // K step kk covers words 2 kk and 2 kk + 1: the lower wave half takes the first, the upper the second
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) qf[qb][kk] = expand_half_lane(~w[kk], hf);
+            for (int kk = 0; kk < 4; ++kk) qf[qb][kk] = expand_fp4(~(hf ? w[2 * kk + 1] : w[2 * kk]));
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) qf[qb][kk] = expand_half_lane(~w[kk], hf);
+        }
     }
     // The train index enters through the C operand of the first matrix instruction of a tile: accumulator register r of
     // this lane belongs to tile row (r & 3) + 8 (r >> 2) + 4 hf.  Keys are therefore TILE-RELATIVE (index - first row of
     // the tile) and the running (best, second) are rebased by -32 per tile: 2 VALU ops per tile and query block instead
     // of a ninth matrix instruction per block.
-    v16i cidx;
+    acc_t cidx;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) cidx[r] = (r & 3) + 8 * (r >> 2) + 4 * hf;
+    for (int r = 0; r < 16; ++r) cidx[r] = (key_t)((r & 3) + 8 * (r >> 2) + 4 * hf);
 
-    int best[QB], second[QB];
+    const key_t no_key = FP4 ? (key_t)MF_NO_KEY_F : (key_t)MF_NO_KEY;
+    key_t best[QB], second[QB];
 #pragma unroll
-    for (int qb = 0; qb < QB; ++qb) best[qb] = second[qb] = MF_NO_KEY;
+    for (int qb = 0; qb < QB; ++qb) best[qb] = second[qb] = no_key;
 
     // staging role of this thread: word xk of train row xr of the tile
     const int xr = tid & 31, xk = tid >> 5;
@@ -190,8 +240,12 @@ __global__ __launch_bounds__(MF_BLOCK, (QB == 1 ? 4 : QB == 2 ? 3 : 1)) void ham
         return T[(size_t)row * 8 + xk];
     };
     auto stage = [&](int t, uint32_t w) {
-        s_tile[t & 1][(xk * 2 + 0) * 32 + xr] = expand_half(w, 0);
-        s_tile[t & 1][(xk * 2 + 1) * 32 + xr] = expand_half(w, 1);
+        if constexpr (FP4) {
+            s_tile[t & 1][xk * 32 + xr] = expand_fp4(w);  // word xk = K step xk / 2, wave half xk & 1
+        } else {
+            s_tile[t & 1][(xk * 2 + 0) * 32 + xr] = expand_half(w, 0);
+            s_tile[t & 1][(xk * 2 + 1) * 32 + xr] = expand_half(w, 1);
+        }
     };
     if (ntiles > 0) stage(0, fetch(0));
     __syncthreads();
@@ -201,49 +255,61 @@ __global__ __launch_bounds__(MF_BLOCK, (QB == 1 ? 4 : QB == 2 ? 3 : 1)) void ham
     auto rebase = [&]() {  // (best, second) relative to the next tile; the no-key sentinel stays far above any key
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
-            best[qb] -= MF_TILE;
-            second[qb] -= MF_TILE;
+            best[qb] -= (key_t)MF_TILE;
+            second[qb] -= (key_t)MF_TILE;
         }
     };
-    auto fold = [&](int qb, int key) {
-        second[qb] = med3_i32(best[qb], second[qb], key);
-        best[qb] = min(best[qb], key);
+    auto fold = [&](int qb, key_t key) {
+        if constexpr (FP4) {
+            second[qb] = med3_f32(best[qb], second[qb], key);
+            best[qb] = min_f32(best[qb], key);
+        } else {
+            second[qb] = med3_i32(best[qb], second[qb], key);
+            best[qb] = min(best[qb], key);
+        }
     };
-    auto mma_fold = [&](v16i (&cur)[QB], const v16i (&prev)[QB], int t) {
+    auto mma = [&](const v4i& tf, const v4i& q, const acc_t& c) -> acc_t {
+        if constexpr (FP4) {
+            const v8i a8 = {tf.x, tf.y, tf.z, tf.w, 0, 0, 0, 0}, b8 = {q.x, q.y, q.z, q.w, 0, 0, 0, 0};  // (FP4 reads four dwords)
+            return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, c, 4, 4, 0, MF_SCALE_2_4, 0, MF_SCALE_2_4);
+        } else {
+            return __builtin_amdgcn_mfma_i32_32x32x32_i8(tf, q, c, 0, 0, 0);
+        }
+    };
+    constexpr int FOLD_PER_STEP = 16 / KSTEPS;  // accumulator registers of the previous tile folded in the shadow of one K step
+    auto mma_fold = [&](acc_t (&cur)[QB], const acc_t (&prev)[QB], int t) {
         if (wave_active) {
             const v4i* frag = s_tile[t & 1];
             const bool fold_prev = t > 0;  // tile t - 1 is a full tile here
             if (fold_prev) rebase();
             v4i tf = frag[lane];
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk) {
+            for (int kk = 0; kk < KSTEPS; ++kk) {
                 v4i tf_ahead = tf;
-                if (kk < 7) tf_ahead = frag[(kk + 1) * 64 + lane];  // one K step ahead of its use
+                if (kk < KSTEPS - 1) tf_ahead = frag[(kk + 1) * 64 + lane];  // one K step ahead of its use
 #pragma unroll
-                for (int qb = 0; qb < QB; ++qb)
-                    cur[qb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(tf, qf[qb][kk], kk == 0 ? cidx : cur[qb], 0, 0, 0);
+                for (int qb = 0; qb < QB; ++qb) cur[qb] = mma(tf, qf[qb][kk], kk == 0 ? cidx : cur[qb]);
                 if (fold_prev) {
 #pragma unroll
-                    for (int qb = 0; qb < QB; ++qb) {
-                        fold(qb, prev[qb][2 * kk]);
-                        fold(qb, prev[qb][2 * kk + 1]);
-                    }
+                    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                        for (int f = 0; f < FOLD_PER_STEP; ++f) fold(qb, prev[qb][FOLD_PER_STEP * kk + f]);
                 }
-                if (kk < 7) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 LDS read (the next step's fragment)
-                __builtin_amdgcn_sched_group_barrier(0x008, QB, 0);             // QB matrix instructions
-                __builtin_amdgcn_sched_group_barrier(0x002, 4 * QB, 0);         // their shadow: 4 * QB VALU ops
+                if (kk < KSTEPS - 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       // 1 LDS read (the next step's fragment)
+                __builtin_amdgcn_sched_group_barrier(0x008, QB, 0);                            // QB matrix instructions
+                __builtin_amdgcn_sched_group_barrier(0x002, 2 * FOLD_PER_STEP * QB, 0);        // their shadow: the fold's VALU ops
                 tf = tf_ahead;
             }
         }
     };
-    auto step = [&](v16i (&cur)[QB], const v16i (&prev)[QB], int t) {
+    auto step = [&](acc_t (&cur)[QB], const acc_t (&prev)[QB], int t) {
         uint32_t w_next = 0;
         if (t + 1 < ntiles) w_next = fetch(t + 1);
         mma_fold(cur, prev, t);
         if (t + 1 < ntiles) stage(t + 1, w_next);
         __syncthreads();
     };
-    v16i accA[QB], accB[QB];
+    acc_t accA[QB], accB[QB];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
@@ -256,24 +322,27 @@ __global__ __launch_bounds__(MF_BLOCK, (QB == 1 ? 4 : QB == 2 ? 3 : 1)) void ham
     if (t < ntiles) step(accA, accB, t);
     if (wave_active && ntiles > 0) {  // drain: the last tile, rows past the segment end carry no key
         const int jt = j0 + (ntiles - 1) * MF_TILE;
-        const v16i(&last)[QB] = (ntiles & 1) ? accA : accB;
+        const acc_t(&last)[QB] = (ntiles & 1) ? accA : accB;
         rebase();
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int jr = jt + (r & 3) + 8 * (r >> 2) + 4 * hf;
-                fold(qb, jr < nt ? last[qb][r] : MF_NO_KEY);
+                fold(qb, jr < nt ? last[qb][r] : no_key);
             }
     }
     if (!wave_active) return;
     // the two wave halves hold the same query columns over different train rows: merge, lower half writes
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
-        const int ob = __shfl_xor(best[qb], 32), os = __shfl_xor(second[qb], 32);
-        const int hi = max(best[qb], ob);
-        const int sec = min(min(second[qb], os), hi);
-        const int bst = min(best[qb], ob);
+        // (the f32 keys are exact integers below 2^23: from here on as int)
+        const int bi = FP4 ? (best[qb] >= (key_t)MF_NO_KEY_MIN_F ? MF_NO_KEY : (int)best[qb]) : (int)best[qb];
+        const int si = FP4 ? (second[qb] >= (key_t)MF_NO_KEY_MIN_F ? MF_NO_KEY : (int)second[qb]) : (int)second[qb];
+        const int ob = __shfl_xor(bi, 32), os = __shfl_xor(si, 32);
+        const int hi = max(bi, ob);
+        const int sec = min(min(si, os), hi);
+        const int bst = min(bi, ob);
         const int q = q_base + (wv * QB + qb) * 32 + col;
         const int base = j0 + (ntiles - 1) * MF_TILE;  // the frame of the last rebasing
         if (hf == 0 && q < nq) out[query_row(qb)] = make_uint2(key_to_knn(bst, base), key_to_knn(sec, base));
@@ -281,6 +350,18 @@ __global__ __launch_bounds__(MF_BLOCK, (QB == 1 ? 4 : QB == 2 ? 3 : 1)) void ham
 }
 
 int mfma_rows_per_block(int qb) { return 4 * qb * 32; }
+
+template <int QB, int MODE>
+static void launch_mf(bool fp4, dim3 grid, hipStream_t s, int B, int tiles, int ndir, int dir0, int nseg, int row_stride, const uint8_t* d1,
+                      const int32_t* n1, const uint8_t* d2, const int32_t* n2, uint2* knn12, uint2* knn21, const int32_t* qsel,
+                      const int32_t* nsel, uint32_t* claim_init, int qsel_from_back, const int32_t* tsel, const int32_t* ntsel) {
+    if (fp4)
+        hipLaunchKernelGGL((hamming_knn2_mfma_kernel<QB, MODE, true>), grid, dim3(MF_BLOCK), 0, s, B, tiles, ndir, dir0, nseg, row_stride, d1, n1,
+                           d2, n2, knn12, knn21, qsel, nsel, claim_init, qsel_from_back, tsel, ntsel);
+    else
+        hipLaunchKernelGGL((hamming_knn2_mfma_kernel<QB, MODE, false>), grid, dim3(MF_BLOCK), 0, s, B, tiles, ndir, dir0, nseg, row_stride, d1, n1,
+                           d2, n2, knn12, knn21, qsel, nsel, claim_init, qsel_from_back, tsel, ntsel);
+}
 
 void launch_hamming_knn2_mfma(hipStream_t s, int B, int row_stride, int max_n, const uint8_t* d1, const int32_t* n1,
                               const uint8_t* d2, const int32_t* n2, uint2* knn12, uint2* knn21, int both_directions,
@@ -290,19 +371,24 @@ void launch_hamming_knn2_mfma(hipStream_t s, int B, int row_stride, int max_n, c
     const int rows = mfma_rows_per_block(qb);
     const int tiles = (max_n + rows - 1) / rows, ndir = both_directions ? 2 : 1;
     const int groups = (B + 7) / 8;
-    dim3 grid((unsigned)(groups * 8 * tiles * ndir * nseg));
-#define STVO_MF_LAUNCH(QBV, M)                                                                                               \
-    hipLaunchKernelGGL((hamming_knn2_mfma_kernel<QBV, M>), grid, dim3(MF_BLOCK), 0, s, B, tiles, ndir, dir0, nseg, row_stride, \
-                       d1, n1, d2, n2, knn12, knn21, qsel, nsel, claim_init, qsel_from_back, tsel, ntsel)
-#define STVO_MF_LAUNCH_QB(M)            \
-    if (qb == 1) STVO_MF_LAUNCH(1, M);  \
-    else if (qb == 2) STVO_MF_LAUNCH(2, M); \
-    else STVO_MF_LAUNCH(4, M)
-    if (!qsel) { STVO_MF_LAUNCH_QB(0); }
-    else if (!tsel) { STVO_MF_LAUNCH_QB(1); }
-    else { STVO_MF_LAUNCH_QB(2); }
-#undef STVO_MF_LAUNCH_QB
-#undef STVO_MF_LAUNCH
+    const dim3 grid((unsigned)(groups * 8 * tiles * ndir * nseg));
+    const bool fp4 = dbg().knn_i8 != 1;  // STVO_KNN_I8=1: the i8 form (comparison runs)
+#define STVO_MF_ARGS fp4, grid, s, B, tiles, ndir, dir0, nseg, row_stride, d1, n1, d2, n2, knn12, knn21, qsel, nsel, claim_init, qsel_from_back, tsel, ntsel
+    const int mode = !qsel ? 0 : (!tsel ? 1 : 2);
+    if (qb == 1) {
+        if (mode == 0) launch_mf<1, 0>(STVO_MF_ARGS);
+        else if (mode == 1) launch_mf<1, 1>(STVO_MF_ARGS);
+        else launch_mf<1, 2>(STVO_MF_ARGS);
+    } else if (qb == 2) {
+        if (mode == 0) launch_mf<2, 0>(STVO_MF_ARGS);
+        else if (mode == 1) launch_mf<2, 1>(STVO_MF_ARGS);
+        else launch_mf<2, 2>(STVO_MF_ARGS);
+    } else {
+        if (mode == 0) launch_mf<4, 0>(STVO_MF_ARGS);
+        else if (mode == 1) launch_mf<4, 1>(STVO_MF_ARGS);
+        else launch_mf<4, 2>(STVO_MF_ARGS);
+    }
+#undef STVO_MF_ARGS
 }
 
 }  // namespace stvo
