@@ -46,6 +46,12 @@ typedef int v8i __attribute__((ext_vector_type(8)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
+#ifndef MF_TPB
+#define MF_TPB 2  // train tiles per workgroup barrier
+#endif
+#ifndef MF_OCC_QB2_FP4
+#define MF_OCC_QB2_FP4 3  // waves per SIMD of the FP4 scan with two query blocks per wave (138 VGPRs as written)
+#endif
 constexpr int MF_BLOCK = 256;        // 4 waves
 constexpr int MF_TILE = 32;          // train rows per tile
 constexpr int MF_KEY_SHIFT = 13;     // key = (h << 13) + j - MF_KEY_BIAS, j < 8192
@@ -120,7 +126,7 @@ __device__ __forceinline__ uint32_t key_to_knn(int key, int base) {
 // FP4: e2m1 operands on the block-scaled matrix instruction (four K = 64 steps per tile, f32 keys); false: the i8 form (eight
 // K = 32 steps, i32 keys) — kept as the measured comparison point (STVO_KNN_I8=1 selects it).
 template <int QB, int MODE, bool FP4>
-__global__ __launch_bounds__(MF_BLOCK, (QB == 1 ? 4 : QB == 2 ? 3 : 1)) void hamming_knn2_mfma_kernel(int B, int tiles, int ndir, int dir0, int nseg, int row_stride,
+__global__ __launch_bounds__(MF_BLOCK, (QB == 1 ? 4 : QB == 2 ? (FP4 ? MF_OCC_QB2_FP4 : 3) : 1)) void hamming_knn2_mfma_kernel(int B, int tiles, int ndir, int dir0, int nseg, int row_stride,
                                                                       const uint8_t* __restrict__ d1,
                                                                       const int32_t* __restrict__ n1,
                                                                       const uint8_t* __restrict__ d2,
@@ -137,7 +143,8 @@ __global__ __launch_bounds__(MF_BLOCK, (QB == 1 ? 4 : QB == 2 ? 3 : 1)) void ham
     using key_t = typename std::conditional<FP4, float, int>::type;
     using acc_t = typename std::conditional<FP4, v16f, v16i>::type;
     // one 16-byte fragment per (K step, wave half, train row): [tile parity][(kk * 2 + hf) * 32 + train row]
-    __shared__ v4i s_tile[2][KSTEPS * 2 * 32];
+    constexpr int NBUF = 2 * MF_TPB;
+    __shared__ v4i s_tile[NBUF][KSTEPS * 2 * 32];
     // XCD-aware block -> (frame pair, direction, tile, segment) mapping: as hamming_knn2_kernel
     const int per_frame = tiles * ndir * nseg;
     const int L = blockIdx.x;
@@ -210,8 +217,11 @@ __global__ __launch_bounds__(MF_BLOCK, (QB == 1 ? 4 : QB == 2 ? 3 : 1)) void ham
     for (int qb = 0; qb < QB; ++qb) {
         const uint32_t w[8] = {qw[qb][0].x, qw[qb][0].y, qw[qb][0].z, qw[qb][0].w, qw[qb][1].x, qw[qb][1].y, qw[qb][1].z, qw[qb][1].w};
         if constexpr (FP4) {  // K step kk covers words 2 kk and 2 kk + 1: the lower wave half takes the first, the upper the second
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) qf[qb][kk] = expand_fp4(~(hf ? w[2 * kk + 1] : w[2 * kk]));
+            const bool up = hf != 0;  // (selects, not an indexed array: that one went through scratch)
+            qf[qb][0] = expand_fp4(~(up ? w[1] : w[0]));
+            qf[qb][1] = expand_fp4(~(up ? w[3] : w[2]));
+            qf[qb][2] = expand_fp4(~(up ? w[5] : w[4]));
+            qf[qb][3] = expand_fp4(~(up ? w[7] : w[6]));
         } else {
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk) qf[qb][kk] = expand_half_lane(~w[kk], hf);
@@ -241,13 +251,15 @@ __global__ __launch_bounds__(MF_BLOCK, (QB == 1 ? 4 : QB == 2 ? 3 : 1)) void ham
     };
     auto stage = [&](int t, uint32_t w) {
         if constexpr (FP4) {
-            s_tile[t & 1][xk * 32 + xr] = expand_fp4(w);  // word xk = K step xk / 2, wave half xk & 1
+            s_tile[t & (NBUF - 1)][xk * 32 + xr] = expand_fp4(w);  // word xk = K step xk / 2, wave half xk & 1
         } else {
-            s_tile[t & 1][(xk * 2 + 0) * 32 + xr] = expand_half(w, 0);
-            s_tile[t & 1][(xk * 2 + 1) * 32 + xr] = expand_half(w, 1);
+            s_tile[t & (NBUF - 1)][(xk * 2 + 0) * 32 + xr] = expand_half(w, 0);
+            s_tile[t & (NBUF - 1)][(xk * 2 + 1) * 32 + xr] = expand_half(w, 1);
         }
     };
-    if (ntiles > 0) stage(0, fetch(0));
+#pragma unroll
+    for (int i = 0; i < MF_TPB; ++i)
+        if (i < ntiles) stage(i, fetch(i));
     __syncthreads();
     // Software pipeline, depth one tile: step t issues the matrix instructions of tile t and, in their shadow, folds the
     // accumulators of tile t - 1 into (best, second) — a v_mfma occupies the matrix pipe for 8 passes while the wave's
@@ -279,7 +291,7 @@ __global__ __launch_bounds__(MF_BLOCK, (QB == 1 ? 4 : QB == 2 ? 3 : 1)) void ham
     constexpr int FOLD_PER_STEP = 16 / KSTEPS;  // accumulator registers of the previous tile folded in the shadow of one K step
     auto mma_fold = [&](acc_t (&cur)[QB], const acc_t (&prev)[QB], int t) {
         if (wave_active) {
-            const v4i* frag = s_tile[t & 1];
+            const v4i* frag = s_tile[t & (NBUF - 1)];
             const bool fold_prev = t > 0;  // tile t - 1 is a full tile here
             if (fold_prev) rebase();
             v4i tf = frag[lane];
@@ -291,35 +303,56 @@ __global__ __launch_bounds__(MF_BLOCK, (QB == 1 ? 4 : QB == 2 ? 3 : 1)) void ham
                 for (int qb = 0; qb < QB; ++qb) cur[qb] = mma(tf, qf[qb][kk], kk == 0 ? cidx : cur[qb]);
                 if (fold_prev) {
 #pragma unroll
-                    for (int qb = 0; qb < QB; ++qb)
+                    for (int qb = 0; qb < QB; ++qb) {
 #pragma unroll
                         for (int f = 0; f < FOLD_PER_STEP; ++f) fold(qb, prev[qb][FOLD_PER_STEP * kk + f]);
+                    }
                 }
                 if (kk < KSTEPS - 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       // 1 LDS read (the next step's fragment)
-                __builtin_amdgcn_sched_group_barrier(0x008, QB, 0);                            // QB matrix instructions
-                __builtin_amdgcn_sched_group_barrier(0x002, 2 * FOLD_PER_STEP * QB, 0);        // their shadow: the fold's VALU ops
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) {  // (one instruction, then its share of the fold: with FP4 operands a matrix instruction
+                                                   //  lasts about as long as the 8 fold operations of one block take to issue — 0.418 ->
+                                                   //  0.401 ms per 1024 frames against QB instructions followed by all of the fold)
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                         // one matrix instruction
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2 * FOLD_PER_STEP, 0);         // its shadow: one block's share of the fold
+                }
                 tf = tf_ahead;
             }
         }
-    };
-    auto step = [&](acc_t (&cur)[QB], const acc_t (&prev)[QB], int t) {
-        uint32_t w_next = 0;
-        if (t + 1 < ntiles) w_next = fetch(t + 1);
-        mma_fold(cur, prev, t);
-        if (t + 1 < ntiles) stage(t + 1, w_next);
-        __syncthreads();
     };
     acc_t accA[QB], accB[QB];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) accA[qb][r] = accB[qb][r] = 0;
+    // MF_TPB tiles per workgroup barrier: while tiles t .. t + MF_TPB - 1 are multiplied (2 MF_TPB LDS buffers), the next MF_TPB are
+    // fetched and staged.  With FP4 operands a tile is short (4 matrix instructions per block) and the four waves of a workgroup
+    // met at a barrier every ~400 cycles: two tiles per barrier 0.402 -> 0.364 ms per 1024 frames.
+    static_assert(MF_TPB % 2 == 0, "the accumulator sets alternate tile by tile");
     int t = 0;
-    for (; t + 2 <= ntiles; t += 2) {
-        step(accA, accB, t);
-        step(accB, accA, t + 1);
+    for (; t + MF_TPB <= ntiles; t += MF_TPB) {
+        uint32_t w_next[MF_TPB];
+#pragma unroll
+        for (int i = 0; i < MF_TPB; ++i) {
+            w_next[i] = 0;
+            if (t + MF_TPB + i < ntiles) w_next[i] = fetch(t + MF_TPB + i);
+        }
+#pragma unroll
+        for (int i = 0; i < MF_TPB; ++i) {
+            if ((i & 1) == 0) mma_fold(accA, accB, t + i);
+            else mma_fold(accB, accA, t + i);
+        }
+#pragma unroll
+        for (int i = 0; i < MF_TPB; ++i)
+            if (t + MF_TPB + i < ntiles) stage(t + MF_TPB + i, w_next[i]);
+        __syncthreads();
     }
-    if (t < ntiles) step(accA, accB, t);
+#pragma unroll
+    for (int i = 0; i < MF_TPB - 1; ++i)  // the last, partly filled group: its tiles are staged already (t is even here)
+        if (t + i < ntiles) {
+            if ((i & 1) == 0) mma_fold(accA, accB, t + i);
+            else mma_fold(accB, accA, t + i);
+        }
     if (wave_active && ntiles > 0) {  // drain: the last tile, rows past the segment end carry no key
         const int jt = j0 + (ntiles - 1) * MF_TILE;
         const acc_t(&last)[QB] = (ntiles & 1) ? accA : accB;
