@@ -15,7 +15,6 @@ struct DebugSwitches {
     int pose_prof;       // STVO_POSE_PROF       in-kernel phase ticks (tools/pose_probe.py)
     int pose_lds_t;      // STVO_POSE_LDS_T      0: pose_kernel.hip's throughput variant without its partial LDS record cache
     int knn_mfma;        // STVO_KNN_MFMA        0: VALU matcher (K1 + K1v), else query blocks per wave of K1m
-    int knn_i8;          // STVO_KNN_I8          1: K1m on i8 operands (round 1-3) instead of FP4
     int knn_nseg;        // STVO_KNN_NSEG        train segments per query tile
     int seq_graph;       // STVO_SEQ_GRAPH       1: hipGraph replay of the per-frame chain
     int seq_prof;        // STVO_SEQ_PROF        host-side phase times of stvo_seq_push

@@ -6,35 +6,28 @@
 // order, lowest train index first among equal distances — and the same output ([nseg][B][row_stride] packed keys).
 //
 // Why this is a matrix product and not a reshaping trick: the all-pairs Hamming distance of bit rows IS a Gram
-// matrix.  With bits mapped to x = +-64 (query: +64 for a set bit) and y = -+64 (train: -64 for a set bit),
-//       sum_k x_k * y_k = 4096 * (#differing - #equal) = 8192 * h - 2^20,
-// exact in the i32 accumulator of v_mfma_i32_32x32x32_i8.  The C operand of a tile's first matrix instruction
-// carries the (tile-relative) train index, so the accumulator leaves the matrix pipe already as the packed key
-// 8192 * h + j - 2^20 whose signed order is the (distance, train index) order knnMatch uses.  The VALU work
-// per (query, train) pair drops from 16 + ~2 ops (K1) to 2: v_med3_i32 + v_min_i32.
+// matrix.  With bits mapped to x = -+a (query: -a for a set bit) and y = +-a (train: +a for a set bit),
+//       sum_k x_k * y_k = a^2 * (#differing - #equal) = 2 a^2 * h - 256 a^2.
+// Operands are FP4 (e2m1) on gfx950's block-scaled v_mfma_scale_f32_32x32x64_f8f6f4 (round 4; rounds 1-3 used i8 on
+// v_mfma_i32_32x32x32_i8): +-4 is an e2m1 value (0b0110 / 0b1110), so a bit becomes a NIBBLE and a 256-bit row four K = 64
+// steps, each as long as one of the eight i8 steps it replaces — the matrix pipe needs half the time per tile
+// (tools/fp4_probe.hip on MI355X: 151 cycles per 32 x 32 tile of 256-bit distances against 265 - 330 for i8, 16 - 17 T pairs/s
+// register-only against 9 - 10; the probe also checks the operand convention used here against a CPU product, entry for
+// entry).  With both block scales at 2^4, a = 64 and the f32 accumulator holds 8192 h - 2^20 exactly; the C operand of a
+// tile's first matrix instruction carries the (tile-relative) train index, so the accumulator leaves the matrix pipe already
+// as the packed key 8192 h + j - 2^20 (|key| < 2^22 after every rebasing: exact in f32) whose order is the (distance, train
+// index) order knnMatch uses.  The VALU work per (query, train) pair drops from 16 + ~2 ops (K1) to 2: v_med3_f32 + v_min_f32.
 //
 // Mapping (wave64, 32x32 tiles):
-//   * MFMA "A" operand = 32 TRAIN rows, expanded from bits to i8 once per workgroup into LDS (double-buffered,
-//     one barrier per tile) and read back as ready-made fragments (one contiguous ds_read_b128 per K step);
-//   * MFMA "B" operand = 32 QUERY rows per block, expanded once and kept in VGPRs for the whole scan
-//     (QB blocks per wave -> every train fragment read from LDS feeds QB matrix instructions);
+//   * MFMA "A" operand = 32 TRAIN rows, expanded from bits to nibbles once per workgroup into LDS (4 KB per tile, 2 MF_TPB
+//     buffers, one barrier per MF_TPB tiles) and read back as ready-made fragments (one contiguous ds_read_b128 per K step);
+//   * MFMA "B" operand = 32 QUERY rows per block, expanded once and kept in VGPRs for the whole scan (16 per block;
+//     QB blocks per wave -> every train fragment read from LDS feeds QB matrix instructions);
 //   * D[train][query]: a lane owns ONE query column and 16 train rows of the tile, so the running (best, second)
 //     of a query is two VGPRs per lane and the final cross-lane merge is a single swap of the wave halves.
-//   * bit -> K element mapping: K step kk covers descriptor word kk; wave half hf, dword d, byte p holds bit
-//     (4 hf + d) + 8 p of that word.  Any mapping works as long as both operands use the same one (a sum over k).
-//     This one costs shift + and + or per four elements: ((w << (7 - s)) & 0x80808080) | 0x40404040 (a single
-//     v_and_or_b32 with the mask in an SGPR was measured: no difference, the kernel is not bound by the VALU count).
-//
-// Round 4 — FP4 operands (template flag FP4, the default): gfx950's block-scaled v_mfma_scale_f32_32x32x64_f8f6f4 takes e2m1
-// elements, and +-4 is one of them (0b0110 / 0b1110): a bit becomes a NIBBLE, a 256-bit row four K = 64 steps instead of eight
-// K = 32 steps, each at the duration of an i8 step — the matrix pipe needs half the time per tile (tools/fp4_probe.hip on
-// MI355X: 151 cycles per 32 x 32 tile of 256-bit distances against 265 - 330 for i8, 16 - 17 T pairs/s register-only against
-// 9 - 10; the probe also checks the operand convention used here against a CPU product, entry for entry).  With both block
-// scales at 2^4 the products are +-16 * 2^8 = +-4096 and the f32 accumulator holds the SAME key as the i8 form,
-// 8192 h + j - 2^20, exactly (|key| < 2^22 even after every rebasing); the C operand carries the row index as before; the fold is
-// v_med3_f32 + v_min_f32.  The query fragments shrink from 64 to 32 VGPRs per wave, the LDS tile from 8 to 4 KB, the fragment
-// reads from 8 to 4 per tile.  Expansion: dword d of a word's fragment holds bits d, d + 4, ..., d + 28 as nibbles:
-// ((w << (3 - d)) & 0x88888888) | 0x66666666 — shift + and-or per eight elements.
+//   * bit -> K element mapping: K step kk covers descriptor words 2 kk (lower wave half) and 2 kk + 1 (upper); dword d of a
+//     lane's fragment holds bits d, d + 4, ..., d + 28 of its word as nibbles: ((w << (3 - d)) & 0x88888888) | 0x66666666 —
+//     shift + and-or per eight elements.  Any mapping works as long as both operands use the same one (a sum over k).
 #include <type_traits>
 
 #include "kernels.h"
@@ -49,9 +42,6 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 #ifndef MF_TPB
 #define MF_TPB 2  // train tiles per workgroup barrier
 #endif
-#ifndef MF_OCC_QB2_FP4
-#define MF_OCC_QB2_FP4 3  // waves per SIMD of the FP4 scan with two query blocks per wave (138 VGPRs as written)
-#endif
 constexpr int MF_BLOCK = 256;        // 4 waves
 constexpr int MF_TILE = 32;          // train rows per tile
 constexpr int MF_KEY_SHIFT = 13;     // key = (h << 13) + j - MF_KEY_BIAS, j < 8192
@@ -59,36 +49,6 @@ constexpr int MF_KEY_BIAS = 1 << 20;
 constexpr int MF_NO_KEY = 0x7FFFFFFF;
 constexpr int MF_NO_KEY_MIN = 0x40000000;  // the sentinel after any number of per-tile rebasings (<= 256 x 32)
 
-// four K elements (bytes) from bits s, s+8, s+16, s+24 of w: byte = 0x40 | bit << 7  (+64 clear, -64 set)
-template <int S>
-__device__ __forceinline__ int expand4(uint32_t w) {
-    const uint32_t sh = S == 7 ? w : (w << (7 - S));
-    return (int)((sh & 0x80808080u) | 0x40404040u);
-}
-__device__ __forceinline__ v4i expand_half(uint32_t w, int hf) {
-    v4i r;
-    if (hf == 0) {
-        r.x = expand4<0>(w); r.y = expand4<1>(w); r.z = expand4<2>(w); r.w = expand4<3>(w);
-    } else {
-        r.x = expand4<4>(w); r.y = expand4<5>(w); r.z = expand4<6>(w); r.w = expand4<7>(w);
-    }
-    return r;
-}
-// the same with a PER-LANE half (the two halves of a wave expand their own four bit positions; no divergent branch)
-__device__ __forceinline__ v4i expand_half_lane(uint32_t w, int hf) {
-    const int sh = 7 - 4 * hf;  // shift of dword 0; dword d uses sh - d >= 0
-    v4i r;
-    r.x = (int)(((w << sh) & 0x80808080u) | 0x40404040u);
-    r.y = (int)(((w << (sh - 1)) & 0x80808080u) | 0x40404040u);
-    r.z = (int)(((w << (sh - 2)) & 0x80808080u) | 0x40404040u);
-    r.w = (int)(((w << (sh - 3)) & 0x80808080u) | 0x40404040u);
-    return r;
-}
-__device__ __forceinline__ int med3_i32(int a, int b, int c) {
-    int r;
-    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
 // FP4: the 32 bits of a descriptor word as 32 e2m1 nibbles, 0b0110 (+4) for a clear bit, 0b1110 (-4) for a set one
 __device__ __forceinline__ v4i expand_fp4(uint32_t w) {
     v4i r;
@@ -123,10 +83,8 @@ __device__ __forceinline__ uint32_t key_to_knn(int key, int base) {
 // MODE 1: the query rows listed in qsel (front of the per-frame list, or its back when qsel_from_back) against every train row.
 // MODE 2: as 1, and the train rows are the ones listed in tsel; the indices in the keys are then positions in tsel.
 // (the reverse check of the claimed columns, match_kernels.hip; separate instantiations also keep the uses apart in traces)
-// FP4: e2m1 operands on the block-scaled matrix instruction (four K = 64 steps per tile, f32 keys); false: the i8 form (eight
-// K = 32 steps, i32 keys) — kept as the measured comparison point (STVO_KNN_I8=1 selects it).
-template <int QB, int MODE, bool FP4>
-__global__ __launch_bounds__(MF_BLOCK, (QB == 1 ? 4 : QB == 2 ? (FP4 ? MF_OCC_QB2_FP4 : 3) : 1)) void hamming_knn2_mfma_kernel(int B, int tiles, int ndir, int dir0, int nseg, int row_stride,
+template <int QB, int MODE>
+__global__ __launch_bounds__(MF_BLOCK, (QB == 1 ? 4 : QB == 2 ? 3 : 1)) void hamming_knn2_mfma_kernel(int B, int tiles, int ndir, int dir0, int nseg, int row_stride,
                                                                       const uint8_t* __restrict__ d1,
                                                                       const int32_t* __restrict__ n1,
                                                                       const uint8_t* __restrict__ d2,
@@ -139,9 +97,9 @@ __global__ __launch_bounds__(MF_BLOCK, (QB == 1 ? 4 : QB == 2 ? (FP4 ? MF_OCC_QB
                                                                       const int32_t* __restrict__ ntsel) {
     constexpr bool GATHER = MODE >= 1, TGATHER = MODE == 2;
     constexpr int ROWS = 4 * QB * 32;  // query rows per workgroup
-    constexpr int KSTEPS = FP4 ? 4 : 8;  // matrix instructions per 32 x 32 tile of 256-bit distances
-    using key_t = typename std::conditional<FP4, float, int>::type;
-    using acc_t = typename std::conditional<FP4, v16f, v16i>::type;
+    constexpr int KSTEPS = 4;  // matrix instructions (K = 64) per 32 x 32 tile of 256-bit distances
+    using key_t = float;
+    using acc_t = v16f;
     // one 16-byte fragment per (K step, wave half, train row): [tile parity][(kk * 2 + hf) * 32 + train row]
     constexpr int NBUF = 2 * MF_TPB;
     __shared__ v4i s_tile[NBUF][KSTEPS * 2 * 32];
@@ -216,16 +174,12 @@ __global__ __launch_bounds__(MF_BLOCK, (QB == 1 ? 4 : QB == 2 ? (FP4 ? MF_OCC_QB
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         const uint32_t w[8] = {qw[qb][0].x, qw[qb][0].y, qw[qb][0].z, qw[qb][0].w, qw[qb][1].x, qw[qb][1].y, qw[qb][1].z, qw[qb][1].w};
-        if constexpr (FP4) {  // K step kk covers words 2 kk and 2 kk + 1: the lower wave half takes the first, the upper the second
-            const bool up = hf != 0;  // (selects, not an indexed array: that one went through scratch)
-            qf[qb][0] = expand_fp4(~(up ? w[1] : w[0]));
-            qf[qb][1] = expand_fp4(~(up ? w[3] : w[2]));
-            qf[qb][2] = expand_fp4(~(up ? w[5] : w[4]));
-            qf[qb][3] = expand_fp4(~(up ? w[7] : w[6]));
-        } else {
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk) qf[qb][kk] = expand_half_lane(~w[kk], hf);
-        }
+        // K step kk covers words 2 kk and 2 kk + 1: the lower wave half takes the first, the upper the second
+        const bool up = hf != 0;  // (selects, not an indexed array: that one went through scratch)
+        qf[qb][0] = expand_fp4(~(up ? w[1] : w[0]));
+        qf[qb][1] = expand_fp4(~(up ? w[3] : w[2]));
+        qf[qb][2] = expand_fp4(~(up ? w[5] : w[4]));
+        qf[qb][3] = expand_fp4(~(up ? w[7] : w[6]));
     }
     // The train index enters through the C operand of the first matrix instruction of a tile: accumulator register r of
     // this lane belongs to tile row (r & 3) + 8 (r >> 2) + 4 hf.  Keys are therefore TILE-RELATIVE (index - first row of
@@ -235,7 +189,7 @@ __global__ __launch_bounds__(MF_BLOCK, (QB == 1 ? 4 : QB == 2 ? (FP4 ? MF_OCC_QB
 #pragma unroll
     for (int r = 0; r < 16; ++r) cidx[r] = (key_t)((r & 3) + 8 * (r >> 2) + 4 * hf);
 
-    const key_t no_key = FP4 ? (key_t)MF_NO_KEY_F : (key_t)MF_NO_KEY;
+    const key_t no_key = MF_NO_KEY_F;
     key_t best[QB], second[QB];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) best[qb] = second[qb] = no_key;
@@ -250,12 +204,7 @@ __global__ __launch_bounds__(MF_BLOCK, (QB == 1 ? 4 : QB == 2 ? (FP4 ? MF_OCC_QB
         return T[(size_t)row * 8 + xk];
     };
     auto stage = [&](int t, uint32_t w) {
-        if constexpr (FP4) {
-            s_tile[t & (NBUF - 1)][xk * 32 + xr] = expand_fp4(w);  // word xk = K step xk / 2, wave half xk & 1
-        } else {
-            s_tile[t & (NBUF - 1)][(xk * 2 + 0) * 32 + xr] = expand_half(w, 0);
-            s_tile[t & (NBUF - 1)][(xk * 2 + 1) * 32 + xr] = expand_half(w, 1);
-        }
+        s_tile[t & (NBUF - 1)][xk * 32 + xr] = expand_fp4(w);  // word xk = K step xk / 2, wave half xk & 1
     };
 #pragma unroll
     for (int i = 0; i < MF_TPB; ++i)
@@ -272,21 +221,12 @@ __global__ __launch_bounds__(MF_BLOCK, (QB == 1 ? 4 : QB == 2 ? (FP4 ? MF_OCC_QB
         }
     };
     auto fold = [&](int qb, key_t key) {
-        if constexpr (FP4) {
-            second[qb] = med3_f32(best[qb], second[qb], key);
-            best[qb] = min_f32(best[qb], key);
-        } else {
-            second[qb] = med3_i32(best[qb], second[qb], key);
-            best[qb] = min(best[qb], key);
-        }
+        second[qb] = med3_f32(best[qb], second[qb], key);
+        best[qb] = min_f32(best[qb], key);
     };
     auto mma = [&](const v4i& tf, const v4i& q, const acc_t& c) -> acc_t {
-        if constexpr (FP4) {
-            const v8i a8 = {tf.x, tf.y, tf.z, tf.w, 0, 0, 0, 0}, b8 = {q.x, q.y, q.z, q.w, 0, 0, 0, 0};  // (FP4 reads four dwords)
-            return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, c, 4, 4, 0, MF_SCALE_2_4, 0, MF_SCALE_2_4);
-        } else {
-            return __builtin_amdgcn_mfma_i32_32x32x32_i8(tf, q, c, 0, 0, 0);
-        }
+        const v8i a8 = {tf.x, tf.y, tf.z, tf.w, 0, 0, 0, 0}, b8 = {q.x, q.y, q.z, q.w, 0, 0, 0, 0};  // (FP4 reads four dwords)
+        return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, c, 4, 4, 0, MF_SCALE_2_4, 0, MF_SCALE_2_4);
     };
     constexpr int FOLD_PER_STEP = 16 / KSTEPS;  // accumulator registers of the previous tile folded in the shadow of one K step
     auto mma_fold = [&](acc_t (&cur)[QB], const acc_t (&prev)[QB], int t) {
@@ -370,8 +310,8 @@ __global__ __launch_bounds__(MF_BLOCK, (QB == 1 ? 4 : QB == 2 ? (FP4 ? MF_OCC_QB
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         // (the f32 keys are exact integers below 2^23: from here on as int)
-        const int bi = FP4 ? (best[qb] >= (key_t)MF_NO_KEY_MIN_F ? MF_NO_KEY : (int)best[qb]) : (int)best[qb];
-        const int si = FP4 ? (second[qb] >= (key_t)MF_NO_KEY_MIN_F ? MF_NO_KEY : (int)second[qb]) : (int)second[qb];
+        const int bi = best[qb] >= MF_NO_KEY_MIN_F ? MF_NO_KEY : (int)best[qb];
+        const int si = second[qb] >= MF_NO_KEY_MIN_F ? MF_NO_KEY : (int)second[qb];
         const int ob = __shfl_xor(bi, 32), os = __shfl_xor(si, 32);
         const int hi = max(bi, ob);
         const int sec = min(min(si, os), hi);
@@ -385,15 +325,11 @@ __global__ __launch_bounds__(MF_BLOCK, (QB == 1 ? 4 : QB == 2 ? (FP4 ? MF_OCC_QB
 int mfma_rows_per_block(int qb) { return 4 * qb * 32; }
 
 template <int QB, int MODE>
-static void launch_mf(bool fp4, dim3 grid, hipStream_t s, int B, int tiles, int ndir, int dir0, int nseg, int row_stride, const uint8_t* d1,
+static void launch_mf(dim3 grid, hipStream_t s, int B, int tiles, int ndir, int dir0, int nseg, int row_stride, const uint8_t* d1,
                       const int32_t* n1, const uint8_t* d2, const int32_t* n2, uint2* knn12, uint2* knn21, const int32_t* qsel,
                       const int32_t* nsel, uint32_t* claim_init, int qsel_from_back, const int32_t* tsel, const int32_t* ntsel) {
-    if (fp4)
-        hipLaunchKernelGGL((hamming_knn2_mfma_kernel<QB, MODE, true>), grid, dim3(MF_BLOCK), 0, s, B, tiles, ndir, dir0, nseg, row_stride, d1, n1,
-                           d2, n2, knn12, knn21, qsel, nsel, claim_init, qsel_from_back, tsel, ntsel);
-    else
-        hipLaunchKernelGGL((hamming_knn2_mfma_kernel<QB, MODE, false>), grid, dim3(MF_BLOCK), 0, s, B, tiles, ndir, dir0, nseg, row_stride, d1, n1,
-                           d2, n2, knn12, knn21, qsel, nsel, claim_init, qsel_from_back, tsel, ntsel);
+    hipLaunchKernelGGL((hamming_knn2_mfma_kernel<QB, MODE>), grid, dim3(MF_BLOCK), 0, s, B, tiles, ndir, dir0, nseg, row_stride, d1, n1, d2, n2,
+                       knn12, knn21, qsel, nsel, claim_init, qsel_from_back, tsel, ntsel);
 }
 
 void launch_hamming_knn2_mfma(hipStream_t s, int B, int row_stride, int max_n, const uint8_t* d1, const int32_t* n1,
@@ -405,8 +341,7 @@ void launch_hamming_knn2_mfma(hipStream_t s, int B, int row_stride, int max_n, c
     const int tiles = (max_n + rows - 1) / rows, ndir = both_directions ? 2 : 1;
     const int groups = (B + 7) / 8;
     const dim3 grid((unsigned)(groups * 8 * tiles * ndir * nseg));
-    const bool fp4 = dbg().knn_i8 != 1;  // STVO_KNN_I8=1: the i8 form (comparison runs)
-#define STVO_MF_ARGS fp4, grid, s, B, tiles, ndir, dir0, nseg, row_stride, d1, n1, d2, n2, knn12, knn21, qsel, nsel, claim_init, qsel_from_back, tsel, ntsel
+#define STVO_MF_ARGS grid, s, B, tiles, ndir, dir0, nseg, row_stride, d1, n1, d2, n2, knn12, knn21, qsel, nsel, claim_init, qsel_from_back, tsel, ntsel
     const int mode = !qsel ? 0 : (!tsel ? 1 : 2);
     if (qb == 1) {
         if (mode == 0) launch_mf<1, 0>(STVO_MF_ARGS);

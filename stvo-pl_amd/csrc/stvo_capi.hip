@@ -25,7 +25,6 @@ DebugSwitches parse_switches() {
     d.pose_prof = env_int("STVO_POSE_PROF");
     d.pose_lds_t = env_int("STVO_POSE_LDS_T");
     d.knn_mfma = env_int("STVO_KNN_MFMA");
-    d.knn_i8 = env_int("STVO_KNN_I8");
     d.knn_nseg = env_int("STVO_KNN_NSEG");
     d.seq_graph = env_int("STVO_SEQ_GRAPH");
     d.seq_prof = env_int("STVO_SEQ_PROF");
