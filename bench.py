@@ -631,6 +631,7 @@ def main():
     ap.add_argument("--repeats", type=int, default=5, help="the timed region (exactly --steps steps between barriers) is repeated this often; value = median")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle parity sample after the timed region (counter passes: every dispatch costs seconds)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-clocks", action="store_true", help="skip the rocm-smi clock sample (it keeps enqueueing steps until rocm-smi answers: counter passes, where every dispatch costs seconds)")
     ap.add_argument("--no-extras", action="store_true", help="skip the latency / configs[1] / correlated-descriptor legs")
     args = ap.parse_args()
 
@@ -709,7 +710,7 @@ def main():
     dt = float(np.median(rep_dt))
 
     clocks = None
-    if rank == 0:   # outside the timed region: a few hundred more steps while rocm-smi takes its sample
+    if rank == 0 and not args.no_clocks:   # outside the timed region: a few hundred more steps while rocm-smi takes its sample
         def _work():
             nonlocal last_slot
             for _ in range(8):

@@ -578,9 +578,17 @@ constexpr int DESC_PW = 10, DESC_PH = 2 * DESC_R + 1;  // blurred patch: 39 rows
 constexpr int IC_PW = 8, IC_PH = 2 * ORB_HP + 1;       // image patch: 31 rows of 8 words = bytes x - 16 .. x + 15
 __global__ __launch_bounds__(256) void orb_describe_kernel(OrbDev o, Umax um) {
     __shared__ uint32_t s_patch[DESC_KP_PER_WG][DESC_PH * DESC_PW];  // the image patch first (31 x 8 words), then the blurred one
-    const int b = blockIdx.y, lane = threadIdx.x & 63, l = lane & 15;
+    // XCD-aware 1-D grid: workgroup L runs on XCD L mod 8 (round-robin dispatch), so image = 8 (L / 8 / blocks per image) + L mod 8
+    // keeps every workgroup of an image on ONE XCD — the patches of neighbouring key-points overlap (2000 key-points read 11 x the
+    // image), and with the image's workgroups dealt over all eight private L2s each of them fetched the image from HBM again
+    // (FETCH_SIZE 6.6 x the image bytes in round 3)
+    const int xcd = blockIdx.x & 7, kq = blockIdx.x >> 3;
+    const int bpi = (o.K + DESC_KP_PER_WG - 1) / DESC_KP_PER_WG;  // workgroups per image
+    const int b = (kq / bpi) * 8 + xcd, kb = kq % bpi;
+    if (b >= o.B) return;
+    const int lane = threadIdx.x & 63, l = lane & 15;
     const int n = o.n_kp[b];
-    const int k_first = blockIdx.x * DESC_KP_PER_WG + (threadIdx.x >> 6) * 4;
+    const int k_first = kb * DESC_KP_PER_WG + (threadIdx.x >> 6) * 4;
     if (k_first >= n) return;  // wave-uniform
     const int slot = (threadIdx.x >> 6) * 4 + (lane >> 4);
     const int k_own = k_first + (lane >> 4);
@@ -895,7 +903,8 @@ int stvo_orb_detect_levels_dev(stvo_orb* o, const uint8_t* images, float* kp_xy,
                            dim3(256), 0, s, d);
         hipLaunchKernelGGL(stvo::orb_blur_kernel, tiles, tb, 0, s, d, o->blur_k);
         hipLaunchKernelGGL(stvo::orb_order_kernel, dim3(d.B), dim3(1024), 0, s, d);
-        hipLaunchKernelGGL(stvo::orb_describe_kernel, dim3((d.K + stvo::DESC_KP_PER_WG - 1) / stvo::DESC_KP_PER_WG, d.B), dim3(256), 0, s, d, o->umax);
+        hipLaunchKernelGGL(stvo::orb_describe_kernel, dim3((unsigned)(((d.K + stvo::DESC_KP_PER_WG - 1) / stvo::DESC_KP_PER_WG) * ((d.B + 7) / 8) * 8)), dim3(256),
+                           0, s, d, o->umax);
     }
     if (multi) {
         stvo::ConcatArgs c{};

@@ -1276,7 +1276,11 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl) {
         const stvo::LazyScratch w{ctx->knn12, ctx->knn21, ctx->cand, ctx->need, ctx->qsel, ctx->nsel, ctx->knn_capacity};
         const int esm = stvo::dbg().match_small;  // developer: 0 = the general machinery for the key-line sets too
         const int lines_cap = std::max(s->set_lines_cap[0], s->set_lines_cap[1]);
-        const bool small_sets = esm != stvo::DBG_UNSET ? esm != 0 : (B >= 16 || lines_cap <= 128);  // (as for the fused line kernel above)
+        // one workgroup per frame pair (match_small_kernel) up to 128 key-lines per image; beyond that its row-by-row scan is the
+        // longest thing on the key-line stream and the general machinery (K1m + planned reverse check, five launches) wins for every
+        // batch size: 512 EuRoC-shaped streams with ~250 key-lines 844 k -> 913 k frame pairs/s (both directions in one K1m launch +
+        // one ratio / mutual kernel: 895 k), one such stream 0.360 -> 0.310 ms (round 3)
+        const bool small_sets = esm != stvo::DBG_UNSET ? esm != 0 : lines_cap <= 128;
         const bool elz = stvo::dbg().match_lazy == 1;  // developer: the lazy formulation for small batches too
         int small_cap = 0;  // rows per set the small-set kernel sizes its LDS for (0: the stride)
         auto match_set = [&](hipStream_t q, const stvo::LazyScratch& ws, int stride, const uint8_t* da, const int32_t* na,
