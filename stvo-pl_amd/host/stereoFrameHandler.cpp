@@ -56,7 +56,9 @@ void StereoFrameHandler::initialize(const FrameFeatures& feat, const int idx_) {
         stvo_seq_destroy(seq);
         seq = nullptr;
     }
-    if (!(use_pipeline && !Config::useMotionModel() && pipelineStep(feat, prev_frame))) {
+    if (use_pipeline && !Config::useMotionModel() && pipelineEnqueue(feat)) {
+        pipelineCollect(prev_frame);
+    } else {
         use_pipeline = false;
         prev_frame->extractStereoFeatures(llength_th, orb_fast_th);
     }
@@ -137,17 +139,19 @@ void StereoFrameHandler::insertStereoPair(const GrayImage& img_l, const GrayImag
 void StereoFrameHandler::insertStereoPair(const FrameFeatures& feat, const int idx_) {
     using clk = std::chrono::high_resolution_clock;
     const auto t0 = clk::now();
+    // device pipeline: the kernel chain of the frame is enqueued BEFORE the host-side frame object (a copy of ~180 KB of features)
+    // is built — the copy then overlaps the GPU's stereo stage instead of delaying its start
+    const bool enqueued = use_pipeline && pipelineEnqueue(feat);
     curr_frame = new StereoFrame(feat, idx_, cam, ctx, ctx_lines);
-    if (use_pipeline) {
-        if (pipelineStep(feat, curr_frame)) {
-            t_stereo_ms = std::chrono::duration<double, std::milli>(clk::now() - t0).count();
-            t_f2f_ms = 0.0;
-            return;
-        }
-        // the frame exceeds the pipeline's capacity: the host-side lists are complete, so the per-call path can take over
-        // from here (and keeps the sequence: the device-side state would be stale after this frame)
-        use_pipeline = false;
+    if (enqueued) {
+        pipelineCollect(curr_frame);
+        t_stereo_ms = std::chrono::duration<double, std::milli>(clk::now() - t0).count();
+        t_f2f_ms = 0.0;
+        return;
     }
+    // the frame exceeds the pipeline's capacity: the host-side lists are complete, so the per-call path can take over
+    // from here (and keeps the sequence: the device-side state would be stale after this frame)
+    use_pipeline = false;
     curr_frame->extractStereoFeatures(llength_th, orb_fast_th);
     const auto t1 = clk::now();
     f2fTracking();
@@ -404,7 +408,9 @@ void StereoFrameHandler::publishPose() {
 
 // One frame through the device-resident pipeline: upload, enqueue stereo association -> f2f -> pose, then rebuild the
 // host-side lists from the fetched match indices while the pose kernel runs.  false = the frame does not fit.
-bool StereoFrameHandler::pipelineStep(const FrameFeatures& feat, StereoFrame* frame) {
+// first half of a frame on the device-resident pipeline: features -> pinned staging -> the whole kernel chain enqueued.  Nothing here
+// needs the StereoFrame object: the caller builds it (it copies ~180 KB of features) while the GPU already works
+bool StereoFrameHandler::pipelineEnqueue(const FrameFeatures& feat) {
     const int n0 = (int)feat.points_l.size(), n1 = (int)feat.points_r.size(), n2 = (int)feat.lines_l.size(),
               n3 = (int)feat.lines_r.size();
     if (n0 > STVO_POSE_MAX_POINTS || n1 > STVO_POSE_MAX_POINTS || n2 > STVO_POSE_MAX_LINES || n3 > STVO_POSE_MAX_LINES) return false;
@@ -453,11 +459,16 @@ bool StereoFrameHandler::pipelineStep(const FrameFeatures& feat, StereoFrame* fr
     ff.n_kp_l = &n[0]; ff.n_kp_r = &n[1]; ff.n_kl_l = &n[2]; ff.n_kl_r = &n[3];
     ff.kp_l = kpl.data(); ff.oct_l = ol.data(); ff.desc_l = feat.pdesc_l.ptr(); ff.kp_r = kpr.data(); ff.desc_r = feat.pdesc_r.ptr();
     ff.kl_l = kll.data(); ff.oct_ll = oll.data(); ff.ldesc_l = feat.ldesc_l.ptr(); ff.kl_r = klr.data(); ff.ldesc_r = feat.ldesc_r.ptr();
-    const bool first = (frame == prev_frame);
     check(stvo_seq_upload(seq, pipe_slot, &ff), "stvo_seq_upload", ctx);
     check(stvo_seq_step_dev(seq, pipe_slot), "stvo_seq_step_dev", ctx);
     pipe_slot ^= 1;
-    // GPU: stereo association + f2f done => match indices in pinned memory; the pose kernel is still running
+    return true;
+}
+
+// second half: the host-side lists of the frame the GPU is working on (stereo_pt / stereo_ls, matched_pt / matched_ls) from the
+// match indices, which reach pinned memory right after the f2f stage — the pose kernel is still running
+void StereoFrameHandler::pipelineCollect(StereoFrame* frame) {
+    const bool first = (frame == prev_frame);
     const int32_t *ms_p = nullptr, *ms_l = nullptr, *m_p = nullptr, *m_l = nullptr;
     check(stvo_seq_fetch_matches(seq, &ms_p, &ms_l, &m_p, &m_l), "stvo_seq_fetch_matches", ctx);
     frame->adoptStereoMatches(ms_p, ms_l);
@@ -465,7 +476,7 @@ bool StereoFrameHandler::pipelineStep(const FrameFeatures& feat, StereoFrame* fr
         int32_t counts[4];
         stvo_pose_result dummy;
         check(stvo_seq_read(seq, &dummy, counts), "stvo_seq_read", ctx);  // nothing to track on the first frame
-        return true;
+        return;
     }
     // f2fTracking (:106-129) from the fetched f2f matches
     for (auto pt : matched_pt) delete pt;
@@ -480,7 +491,6 @@ bool StereoFrameHandler::pipelineStep(const FrameFeatures& feat, StereoFrame* fr
     n_inliers_ls = (int)matched_ls.size();
     n_inliers = n_inliers_pt + n_inliers_ls;
     pose_pending = true;
-    return true;
 }
 
 void StereoFrameHandler::resetOutliers() {

@@ -72,7 +72,8 @@ public:
     bool use_pipeline = true;
 
 private:
-    bool pipelineStep(const FrameFeatures& feat, StereoFrame* frame);  // false: frame does not fit -> legacy path
+    bool pipelineEnqueue(const FrameFeatures& feat);  // false: frame does not fit -> legacy path
+    void pipelineCollect(StereoFrame* frame);
     void buildMatchedPoints(const int32_t* matches_12, size_t n);
     void buildMatchedLines(const int32_t* matches_12, size_t n);
     void publishPose();

@@ -64,6 +64,21 @@ def test_seq_pipeline_euroc_line_heavy(oracle, mode):
     run_and_compare(oracle, seqs, cam, "euroc", mode=mode)
 
 
+@pytest.mark.parametrize("nw", ["2", "4"])
+def test_seq_pipeline_compact_pose_kernel_full_frames_and_high_levels(oracle, switches, nw):
+    """The batch pose kernel on compact records (pose2c_kernel, forced here for a small batch) away from its comfortable shape:
+    frames with ~2000 stereo points (a thread owns up to 16 prev points: the 12 LDS planes AND the register-resident record AND
+    the off-chip path are all in use, and the inliers do not fit the planes' dense re-deal), and pyramid levels beyond the 15
+    the sigma table holds (those records are gathered at every use).  Everything against the oracle-driven loop."""
+    switches({"STVO_POSE_KERNEL": "4", "STVO_POSE2P_NW": nw})
+    cam = synth.KITTI_CAM
+    full = [synth.make_stereo_sequence(1900 + b, n_frames=4, n_pts=1690, n_lines=40, cam=cam) for b in range(2)]
+    run_and_compare(oracle, full, cam, "kitti")
+    probs = [0.4, 0.2, 0.1, 0.05] + [0.0] * 10 + [0.1, 0.1, 0.05]   # levels 14, 15, 16 occur
+    deep = [synth.make_stereo_sequence(1950 + b, n_frames=4, n_pts=700, n_lines=30, cam=cam, octave_probs=probs) for b in range(2)]
+    run_and_compare(oracle, deep, cam, "kitti")
+
+
 def test_seq_pipeline_empty_and_tiny_frames(oracle):
     """Frames with no right features, no lines, or too few features: in-band failures, no crashes."""
     cam = synth.KITTI_CAM
