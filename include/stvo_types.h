@@ -79,8 +79,8 @@ enum {
     STVO_POSE_FEW_INLIERS_BEFORE = 1,  /* n_inliers < minFeatures before optimisation    (:364-368) */
     STVO_POSE_FEW_INLIERS_AFTER = 2,   /* n_inliers < minFeatures after removeOutliers   (:351-355) */
     STVO_POSE_REJECTED = 3,            /* isGoodSolution false or DT == I at commit      (:382-391) */
-    STVO_POSE_INTERNAL = 4             /* device-side failure of the batched pose kernel's wave hand-over (never expected;
-                                          no reference counterpart): the pose of this frame pair was NOT computed */
+    STVO_POSE_INTERNAL = 4             /* reserved (a round-3 experimental kernel could report a device-side failure; removed in
+                                          round 4): no kernel of the library returns it */
 };
 
 /* Flags describing the path taken through the state machine. */
