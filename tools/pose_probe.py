@@ -13,7 +13,7 @@ ap.add_argument("--batch", type=int, default=512)
 ap.add_argument("--points", type=int, default=2000)
 ap.add_argument("--lines", type=int, default=0)
 ap.add_argument("--iters", type=int, default=10)
-ap.add_argument("--f32-obs", action="store_true", help="round the observations to float (what the per-frame pipeline feeds): pose_kernel3's compact format applies")
+ap.add_argument("--f32-obs", action="store_true", help="round the observations to float (what the per-frame pipeline feeds)")
 a = ap.parse_args()
 import torch  # noqa: E402
 from stvo_amd import capi, synth  # noqa: E402
