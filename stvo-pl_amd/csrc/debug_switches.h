@@ -26,6 +26,7 @@ struct DebugSwitches {
     int grid_tail;       // STVO_GRID_TAIL       0: point_tail_kernel as its own launch
     int grid_fused;      // STVO_GRID_FUSED      0: scan formulation of the stereo point matcher
     int grid_fused_cap;  // STVO_GRID_FUSED_CAP  capacity override of the one-workgroup point matcher (tests of the misfit path)
+    int grid_cells;      // STVO_GRID_CELLS      0: point_cells_kernel as its own launch for small batches too, 1: in the matcher whenever it fits
 };
 
 const DebugSwitches& dbg();  // parsed on first use (stvo_capi.hip)

@@ -36,6 +36,7 @@
 #include <vector>
 
 #include "ctx_internal.h"
+#include "point_cells.h"
 
 namespace stvo {
 namespace {
@@ -626,8 +627,19 @@ __device__ __forceinline__ void fused_tail(const GridBatch& g, const int f, cons
 }
 
 // Persistent: workgroup w takes frames w, w + gridDim.x, ...
+// CELLS (host: one frame per workgroup, g.fused_cells): the workgroup first builds the grid of its frame (point_cells.h) in the LDS
+// the matcher uses afterwards; the matcher then reads the cell tables back through L2 like those of a point_cells_kernel launch.
+template <bool CELLS>
 __global__ __launch_bounds__(FUSED_T) void grid_points_fused_kernel(GridBatch g, const int key_cap) {
     extern __shared__ uint4 s_fused[];
+    static_assert(sizeof(PointCellsLds<FUSED_T>) <= FUSED_LDS, "the cells phase borrows the matcher's LDS");
+    if (CELLS) {
+        if ((int)blockIdx.x >= g.B) return;
+        point_cells_frame<FUSED_T, true>(g.cells, blockIdx.x, reinterpret_cast<PointCellsLds<FUSED_T>*>(s_fused));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
     __shared__ int s_cnt[FUSED_R * (FUSED_T / 64)];  // fused_tail: kept rows per wave
     __shared__ int s_ctl[3];  // [0] bump allocator of the key slots, [1] the frame misfits, [2] entries in the queue of wide right features
     uint4* s_llo = s_fused;                                                              // [pos] first / second half of the left rows,
@@ -920,7 +932,8 @@ bool grid_points_fused_ok(const GridBatch& g) {
     // STVO_GRID_FUSED=0: the scan formulation for every batch
     const bool fused = range && g.misfit && g.cell2 && g.lperm && g.lstart && g.stride1 <= FUSED_ROWS && g.stride2 <= FUSED_ROWS && g.w.w_lo >= 0 &&
                        g.w.w_lo <= FUSED_LW - STVO_GRID_COLS && g.w.w_hi == 0 && g.w.h_lo == 0 && g.w.h_hi == 0 && dbg().grid_fused != 0;
-    return fused && lds_opt_in(reinterpret_cast<const void*>(grid_points_fused_kernel), (int)FUSED_LDS);
+    return fused && lds_opt_in(reinterpret_cast<const void*>(grid_points_fused_kernel<false>), (int)FUSED_LDS) &&
+           lds_opt_in(reinterpret_cast<const void*>(grid_points_fused_kernel<true>), (int)FUSED_LDS);
 }
 
 // cover (zeroed here) -> scan -> finalize for a batch of frame pairs
@@ -948,7 +961,10 @@ void launch_grid_batch(hipStream_t s, const GridBatch& g, bool lines, hipEvent_t
             if (cap > FUSED_KEY_CAP) cap = FUSED_KEY_CAP;  // negative: every frame misfits
             const int fused_wgs = device_cu_count();  // one persistent workgroup per CU (its LDS and registers fill one)
             if (scan_events) (void)hipEventRecord(scan_events[0], s);
-            hipLaunchKernelGGL(grid_points_fused_kernel, dim3(g.B < fused_wgs ? g.B : fused_wgs), dim3(FUSED_T), FUSED_LDS, s, g, cap);
+            if (g.fused_cells && g.B <= fused_wgs)
+                hipLaunchKernelGGL(grid_points_fused_kernel<true>, dim3(g.B), dim3(FUSED_T), FUSED_LDS, s, g, cap);
+            else
+                hipLaunchKernelGGL(grid_points_fused_kernel<false>, dim3(g.B < fused_wgs ? g.B : fused_wgs), dim3(FUSED_T), FUSED_LDS, s, g, cap);
             if (scan_events) (void)hipEventRecord(scan_events[1], s);
             return;
         }

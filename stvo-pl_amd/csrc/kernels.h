@@ -164,6 +164,28 @@ inline void pose_release_stream(hipStream_t s) { pose2p_release_stream(s); }
 
 // ---- K3: grid-windowed stereo matchers, batched over frame pairs (blockIdx.y) ----------------------
 constexpr int GRID_LW = STVO_GRID_COLS + 16, GRID_LCELLS = STVO_GRID_ROWS * GRID_LW, GRID_LSTART_STRIDE = GRID_LCELLS + 4;
+// the cells phase of the key-points of a frame (point_cells.h): what it reads and writes
+struct PointCells {
+    int K, ws;               // rows per frame of every array below; matching_s_ws (stereoFrame.cpp:141-143)
+    const float* kp_l;       // [B][K][2]
+    const float* kp_r;       // [B][K][2]
+    const int32_t* n_kp_l;   // [B]
+    const int32_t* n_kp_r;   // [B]
+    const double* inv_wh;    // [B][2] 64 / cols, 48 / rows (stereoFrame.cpp:47-48)
+    int32_t* pstart;         // [B][3073] out: exclusive cell starts of the right key-points
+    uint32_t* plstart;       // [B][GRID_LSTART_STRIDE] out: cell starts of the left key-points (nullptr: not sorted)
+    int32_t* plperm;         // [B][K] out: position -> left key-point
+    int32_t* pperm;          // [B][K] out: scan position -> right key-point
+    int32_t* pcell;          // [B][K] out: cell (y * 64 + x) of the right key-point at each scan position, -1: outside the grid
+    // inputs of the scan formulation only (LEAN == false)
+    int32_t* pxy_l;              // [B][K][2]
+    unsigned long long* top2_p;  // [B][K]
+    int32_t* govf_p;             // [B]
+    int32_t* prange;             // [B][K][2]
+    int32_t* pitems;             // [B][K]
+    int32_t* prank;              // [B][K]
+};
+
 struct GridBatch {
     int B, stride1, stride2;   // frame pairs; rows per frame of the left / right feature arrays
     int xy_width;              // 2 (points: cx, cy) or 4 (lines: sx, sy, ex, ey)
@@ -211,6 +233,10 @@ struct GridBatch {
     // pass over the matches
     int has_tail;
     PointTail tail;
+    // fused_cells != 0 (only with grid_points_fused_ok and B <= the number of workgroups of the launch, i.e. one frame per workgroup):
+    // the one-workgroup matcher builds the grid of its frame itself as its first phase — no point_cells_kernel launch
+    int fused_cells;
+    PointCells cells;
 };
 constexpr int GRID_ELIG = 16;
 // scan_events (optional): [0] / [1] are recorded on `s` before / after the two grid_scan passes

@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "ctx_internal.h"
+#include "point_cells.h"
 #include "pose_math.h"
 
 // The geometry filters of the tail kernels decide on thresholds (min_disp, ls_min_disp_ratio, stereo_overlap_th): no
@@ -139,107 +140,21 @@ __device__ __forceinline__ void scan_cells(T* hist, int* s_wave, int32_t* start_
     scan_cells_n<STVO_GRID_CELLS / 256>(hist, s_wave, start_out);
 }
 
-// ---- 1: points — cells + CSR of the right key-points -----------------------------------------------
-// LEAN (the one-workgroup point matcher will run, grid_points_fused_ok): only what that matcher reads — the cell-sorted left
-// indices and their starts, the scan order of the right key-points and their cells, the CSR starts.  The integer cells and
-// candidate ranges of the left key-points, the CSR items / ranks and the empty top-2 records (64 of 125 KB per frame) are inputs
-// of the scan formulation only; the matcher rebuilds them for the rare frame it hands to it (fused_misfit_frame).
+// ---- 1: points — cells + CSR of the right key-points (point_cells.h) -------------------------------
+__host__ __device__ __forceinline__ PointCells point_cells_args(const SeqDev& s) {
+    PointCells c;
+    c.K = s.K; c.ws = s.mp.matching_s_ws;
+    c.kp_l = s.kp_l; c.kp_r = s.kp_r; c.n_kp_l = s.n_kp_l; c.n_kp_r = s.n_kp_r; c.inv_wh = s.inv_wh;
+    c.pstart = s.pstart; c.plstart = s.plstart; c.plperm = s.plperm; c.pperm = s.pperm; c.pcell = s.pcell;
+    c.pxy_l = s.pxy_l; c.top2_p = s.top2_p; c.govf_p = s.govf_p; c.prange = s.prange; c.pitems = s.pitems; c.prank = s.prank;
+    return c;
+}
+// (16-bit counters — half the LDS, so that line workgroups fit beside this kernel's — gained 0.7 % on 1024 KITTI-shaped streams and
+// lost 10 % on 512 EuRoC-shaped ones, where the line stream is the longer one and every speed-up of the point stream takes CUs from it)
 template <bool LEAN>
 __global__ __launch_bounds__(256) void point_cells_kernel(SeqDev s) {
-    // (16-bit counters — half the LDS, so that line workgroups fit beside this kernel's — gained 0.7 % on 1024 KITTI-shaped streams and
-    // lost 10 % on 512 EuRoC-shaped ones, where the line stream is the longer one and every speed-up of the point stream takes CUs from it)
-    __shared__ int hist[STVO_GRID_CELLS];
-    __shared__ int fill[STVO_GRID_CELLS];
-    __shared__ int lhist[GRID_LCELLS];
-    __shared__ int s_wave[4];
-    __shared__ int s_extra;
-    static_assert(GRID_LCELLS % 256 == 0, "scan_cells_n");
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const bool lsort = s.plperm != nullptr;  // host: K <= 2048 (8 key-points per thread), window within GRID_LW
-    const int nl = s.n_kp_l[b], nr = s.n_kp_r[b];
-    const size_t off = (size_t)b * s.K;
-    const double inv_w = s.inv_wh[2 * b], inv_h = s.inv_wh[2 * b + 1];
-    if (!LEAN)
-        for (int i = tid; i < nl; i += 256) {  // float * double -> int truncation (stereoFrame.cpp:132)
-            s.pxy_l[(off + i) * 2 + 0] = (int)((double)s.kp_l[(off + i) * 2 + 0] * inv_w);
-            s.pxy_l[(off + i) * 2 + 1] = (int)((double)s.kp_l[(off + i) * 2 + 1] * inv_h);
-        }
-    for (int c = tid; c < STVO_GRID_CELLS; c += 256) {
-        hist[c] = 0;
-        fill[c] = 0;
-    }
-    for (int c = tid; c < GRID_LCELLS; c += 256) lhist[c] = 0;
-    if (!LEAN)
-        for (int i = tid; i < s.K; i += 256) s.top2_p[off + i] = 0x00000000FFFFFFFFull;  // grid matcher: no eligible candidate yet
-    if (tid == 0) {
-        if (!LEAN) s.govf_p[b] = 0;
-        s_extra = 0;
-    }
-    __syncthreads();
-    for (int i = tid; i < nr; i += 256) {
-        const int x = (int)((double)s.kp_r[(off + i) * 2 + 0] * inv_w);
-        const int y = (int)((double)s.kp_r[(off + i) * 2 + 1] * inv_h);
-        if (in_grid(x, y)) atomicAdd(&hist[y * STVO_GRID_COLS + x], 1);
-    }
-    // counting sort of the LEFT key-points by cell, for the matcher that walks the candidates of a right key-point: the window
-    // is clamped, not the cell (src/gridStructure.cpp:67-71), so columns up to 63 + ws still see the last grid columns
-    int lcel[8], lrnk[8];
-    if (lsort) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int i = tid + 256 * k;
-            lcel[k] = -1;
-            lrnk[k] = 0;
-            if (i < nl) {
-                const int x = (int)((double)s.kp_l[(off + i) * 2 + 0] * inv_w);
-                const int y = (int)((double)s.kp_l[(off + i) * 2 + 1] * inv_h);
-                if (y >= 0 && y < STVO_GRID_ROWS && x >= 0 && x <= STVO_GRID_COLS - 1 + s.mp.matching_s_ws) {
-                    lcel[k] = y * GRID_LW + x;
-                    lrnk[k] = atomicAdd(&lhist[lcel[k]], 1);
-                }
-            }
-        }
-    }
-    __syncthreads();
-    scan_cells(hist, s_wave, s.pstart + (size_t)b * (STVO_GRID_CELLS + 1));
-    if (lsort) {
-        scan_cells_n<GRID_LCELLS / 256>(lhist, s_wave, reinterpret_cast<int32_t*>(s.plstart) + (size_t)b * GRID_LSTART_STRIDE);
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-            if (lcel[k] >= 0) s.plperm[off + lhist[lcel[k]] + lrnk[k]] = tid + 256 * k;
-    }
-    const int n_in = s.pstart[(size_t)b * (STVO_GRID_CELLS + 1) + STVO_GRID_CELLS];
-    // GridStructure::get with the stereo window (matching_s_ws cells to the left, same row; src/gridStructure.cpp:65-76,
-    // src/stereoFrame.cpp:141-143): cells x - ws .. x of row y are contiguous in the CSR => candidates = positions [lo, hi)
-    if (!LEAN)
-        for (int i = tid; i < nl; i += 256) {
-            const int x = s.pxy_l[(off + i) * 2 + 0], y = s.pxy_l[(off + i) * 2 + 1];
-            int lo = 0, hi = 0;
-            if (y >= 0 && y < STVO_GRID_ROWS) {
-                const int min_x = min(max(0, x - s.mp.matching_s_ws), STVO_GRID_COLS), max_x = max(min(STVO_GRID_COLS, x + 1), min_x);
-                const int c0 = y * STVO_GRID_COLS + min_x, c1 = y * STVO_GRID_COLS + max_x;
-                lo = c0 < STVO_GRID_CELLS ? hist[c0] : n_in;
-                hi = c1 < STVO_GRID_CELLS ? hist[c1] : n_in;
-            }
-            s.prange[(off + i) * 2 + 0] = lo;
-            s.prange[(off + i) * 2 + 1] = hi;
-        }
-    __syncthreads();  // hist (the cell starts) is read above and advanced by nobody: fill[] takes the scatter counters
-    for (int i = tid; i < nr; i += 256) {
-        const int x = (int)((double)s.kp_r[(off + i) * 2 + 0] * inv_w);
-        const int y = (int)((double)s.kp_r[(off + i) * 2 + 1] * inv_h);
-        int pos;
-        if (in_grid(x, y)) {
-            const int c = y * STVO_GRID_COLS + x;
-            pos = hist[c] + atomicAdd(&fill[c], 1);
-            if (!LEAN) s.pitems[off + pos] = i;
-        } else {  // the reference's out_of_bounds sink: never a candidate, scanned last
-            pos = n_in + atomicAdd(&s_extra, 1);
-        }
-        s.pperm[off + pos] = i;  // scan order = CSR (spatial) order
-        s.pcell[off + pos] = in_grid(x, y) ? y * STVO_GRID_COLS + x : -1;
-        if (!LEAN) s.prank[off + i] = pos;
-    }
+    __shared__ PointCellsLds<256> lds;
+    point_cells_frame<256, LEAN>(point_cells_args(s), blockIdx.x, &lds);
 }
 
 // ---- 3: points — filters, back-projection, ordered compaction ---------------------------------------
@@ -657,12 +572,22 @@ struct stvo_seq {
     long long* d_prof = nullptr;   // STVO_POSE_PROF (developer aid): [B][16] phase ticks of the last pose launch, printed by stvo_seq_read
     char* dev = nullptr;     // one allocation, carved below
     size_t dev_bytes = 0;
-    // pinned mirrors of the raw-feature block: two, used alternately, each guarded by the event of the copy that last
-    // read it — packing frame k + 1 on the host overlaps the device work of frame k (no stream synchronisation per upload)
+    // pinned mirrors of the raw-feature block: two, used alternately — packing frame k + 1 on the host overlaps the device work
+    // of frame k.  A block may be written again once the copy that last read it has completed.  The usual caller synchronises the
+    // stream once per frame anyway (stvo_seq_read), so the uploads are numbered and the read remembers the last one it has
+    // waited for: no event behind the copy (on this runtime a recorded event delays the next kernel of the stream by several
+    // microseconds).  Only a caller that uploads a third frame without a read in between pays for an event, at that upload.
     char* raw_host[2] = {nullptr, nullptr};
     hipEvent_t ev_stage[2] = {nullptr, nullptr};
-    bool stage_busy[2] = {false, false};
+    unsigned long long stage_upload[2] = {0, 0};  // number of the upload that last read the block (0: none)
+    unsigned long long uploads = 0, uploads_done = 0;
     int stage_next = 0;
+    // The key-line kernels of a step run on their own stream, which must see the frame's key-line arrays.  When the point stream
+    // has been idle since the last read (single-stream operation: upload, step, read per frame) stvo_seq_upload copies the key-line
+    // part of the block ON the line stream and the step forks without an event; st_dirty = something the line stream would have to
+    // wait for has been enqueued on the point stream since the last synchronisation.
+    bool st_dirty = false;
+    std::vector<char> raw_split;  // per slot: its key-line arrays were copied on the line stream
     size_t raw_bytes = 0;
     stvo::SeqDev d{};          // pointers into `dev` (set = current)
     // carve results
@@ -889,6 +814,7 @@ int stvo_seq_create_multi(stvo_ctx* ctx, int B, int max_keypoints, int max_keyli
     s->raw_dev = {D + o_raw, D + o_raw1};
     s->raw_lines.assign(2, 0);
     s->raw_max_lines.assign(2, 0);
+    s->raw_split.assign(2, 0);
     s->d_cams = (stvo_cam*)(D + o_cams);
     s->d_inv_wh = (double*)(D + o_invwh);
     s->d_qtab = (double*)(D + o_qtab);
@@ -973,6 +899,7 @@ int stvo_seq_set_slots(stvo_seq* s, int n_slots) {
     s->raw_dev.resize(2);
     s->raw_lines.resize(2);
     s->raw_max_lines.resize(2);
+    s->raw_split.assign(2, 0);
     if (n_slots > 2) {
         HIP_TRY(ctx, hipMalloc((void**)&s->extra_raw, (size_t)(n_slots - 2) * s->raw_bytes));
         HIP_TRY(ctx, hipMemset(s->extra_raw, 0, (size_t)(n_slots - 2) * s->raw_bytes));
@@ -980,6 +907,7 @@ int stvo_seq_set_slots(stvo_seq* s, int n_slots) {
             s->raw_dev.push_back(s->extra_raw + (size_t)(k - 2) * s->raw_bytes);
             s->raw_lines.push_back(0);
             s->raw_max_lines.push_back(0);
+            s->raw_split.push_back(0);
         }
     }
     return STVO_OK;
@@ -1048,7 +976,11 @@ int stvo_seq_upload(stvo_seq* s, int slot, const stvo_frame_features* f) {
     // two pinned staging blocks used alternately: only wait for the copy that last read THIS block (two uploads ago)
     const int sb = s->stage_next;
     s->stage_next ^= 1;
-    if (s->stage_busy[sb]) HIP_TRY(ctx, hipEventSynchronize(s->ev_stage[sb]));
+    if (s->stage_upload[sb] > s->uploads_done) {  // everything enqueued so far covers that copy
+        HIP_TRY(ctx, hipEventRecord(s->ev_stage[sb], ctx->stream));
+        HIP_TRY(ctx, hipEventSynchronize(s->ev_stage[sb]));
+        s->uploads_done = s->uploads;
+    }
     char* H = s->raw_host[sb];
     int32_t* nkl = (int32_t*)(H + s->off_nkl);
     int32_t* nkr = (int32_t*)(H + s->off_nkr);
@@ -1091,14 +1023,20 @@ int stvo_seq_upload(stvo_seq* s, int slot, const stvo_frame_features* f) {
     for (int b = 0; b < B; ++b) any_lines = any_lines || (nll[b] > 0 && nlr[b] > 0);
     s->raw_lines[slot] = any_lines;
     s->raw_max_lines[slot] = max_lines;
+    s->raw_split[slot] = 0;
     if (s->raw_bytes <= (size_t)4 << 20) {
         // copy kernel instead of the DMA engine: ~5 us less latency for the ~200 KB of one frame
-        stvo::launch_copy16(ctx->stream, H, s->raw_dev[slot], s->raw_bytes);
+        if (any_lines && s->op.has_points && !s->st_dirty && !s->graph_mode && s->line_stream) {
+            stvo::launch_copy16(ctx->stream, H, s->raw_dev[slot], s->off_kl_l);
+            stvo::launch_copy16(s->line_stream, H + s->off_kl_l, s->raw_dev[slot] + s->off_kl_l, s->raw_bytes - s->off_kl_l);
+            s->raw_split[slot] = 1;
+        } else {
+            stvo::launch_copy16(ctx->stream, H, s->raw_dev[slot], s->raw_bytes);
+        }
     } else {
         HIP_TRY(ctx, hipMemcpyAsync(s->raw_dev[slot], H, s->raw_bytes, hipMemcpyHostToDevice, ctx->stream));
     }
-    HIP_TRY(ctx, hipEventRecord(s->ev_stage[sb], ctx->stream));
-    s->stage_busy[sb] = true;
+    s->stage_upload[sb] = ++s->uploads;
     return STVO_OK;
 }
 
@@ -1122,6 +1060,8 @@ int stvo_seq_upload_dev(stvo_seq* s, int slot, const stvo_frame_features* f) {
     a.ldesc_l = (uint8_t*)(Rw + s->off_ldesc_l); a.n_kl_l = (int32_t*)(Rw + s->off_nll); a.kl_r = (float*)(Rw + s->off_kl_r);
     a.ldesc_r = (uint8_t*)(Rw + s->off_ldesc_r); a.n_kl_r = (int32_t*)(Rw + s->off_nlr);
     hipLaunchKernelGGL(seq_ingest_kernel, dim3(s->B), dim3(256), 0, ctx->stream, a);
+    s->st_dirty = true;
+    s->raw_split[slot] = 0;
     s->raw_max_lines[slot] = s->M;
     s->raw_lines[slot] = lns;  // the line stage runs whenever line arrays were given (empty sets cost two small launches)
     return check_launch(ctx);
@@ -1179,7 +1119,8 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl) {
     // stretch the scan instead (0.510 ms).  Measured: 1024 KITTI-shaped streams 929 k (early) vs 935 k (late) frame pairs/s, 512
     // EuRoC-shaped streams 857 k vs 777 k, one stream 0.252 vs 0.280 ms per frame.
     const bool late_fork = par && stvo::dbg().line_fork_late == 1;
-    if (par && !late_fork) {
+    const bool fork_free = par && s->raw_split[slot] && !s->st_dirty && !s->graph_mode;  // see stvo_seq::st_dirty
+    if (par && !late_fork && !fork_free) {
         HIP_TRY(ctx, hipEventRecord(s->ev_fork, st));
         HIP_TRY(ctx, hipStreamWaitEvent(sl, s->ev_fork, 0));
     }
@@ -1208,7 +1149,12 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl) {
             g.has_tail = g.lean_cells;
             if (stvo::dbg().grid_tail == 0) g.has_tail = 0;  // developer: point_tail_kernel as its own launch
             if (g.has_tail) g.tail = stvo::point_tail_args(d);
-            if (g.lean_cells)
+            // one frame per workgroup of the matcher (single-stream operation, small batches): the grid of the frame is the matcher's
+            // first phase — one dependent launch less in the chain of a frame
+            g.fused_cells = g.lean_cells && B <= stvo::device_cu_count() && stvo::dbg().grid_cells != 0;
+            if (g.fused_cells)
+                g.cells = stvo::point_cells_args(d);
+            else if (g.lean_cells)
                 hipLaunchKernelGGL(stvo::point_cells_kernel<true>, dim3(B), dim3(256), 0, st, d);
             else
                 hipLaunchKernelGGL(stvo::point_cells_kernel<false>, dim3(B), dim3(256), 0, st, d);
@@ -1403,6 +1349,7 @@ int stvo_seq_step_dev(stvo_seq* s, int slot) {
     } else {
         TRY(seq_enqueue_step(s, slot, fl));
     }
+    s->st_dirty = true;
     s->set_lines[s->cur] = fl.lines_now;
     s->last_lines = fl.lines_now;
     s->last_slot = slot;
@@ -1440,6 +1387,8 @@ int stvo_seq_read(stvo_seq* s, stvo_pose_result* results, int32_t* counts) {
         HIP_TRY(ctx, hipMemcpyAsync(OH + res_bytes + (size_t)B * 4, ls.nl, (size_t)B * 4, hipMemcpyDeviceToHost, st));
     }
     HIP_TRY(ctx, hipStreamSynchronize(st));
+    s->uploads_done = s->uploads;  // every staging copy enqueued so far has read its block
+    s->st_dirty = false;           // (the line stream's work of every step was joined into this stream before its pose kernel)
     const stvo_pose_result* hr = reinterpret_cast<const stvo_pose_result*>(OH);
     const int32_t* hn = reinterpret_cast<const int32_t*>(OH + res_bytes);
     for (int b = 0; b < B; ++b) {

@@ -37,6 +37,7 @@ DebugSwitches parse_switches() {
     d.grid_tail = env_int("STVO_GRID_TAIL");
     d.grid_fused = env_int("STVO_GRID_FUSED");
     d.grid_fused_cap = env_int("STVO_GRID_FUSED_CAP");
+    d.grid_cells = env_int("STVO_GRID_CELLS");
     return d;
 }
 DebugSwitches& switches() {

@@ -188,10 +188,13 @@ def test_seq_fetch_by_products(oracle):
         ctx.close()
 
 
-@pytest.mark.parametrize("env", [{"STVO_GRID_FUSED": "0"}, {"STVO_GRID_FUSED_CAP": "-1"}], ids=["scan", "misfit"])
+@pytest.mark.parametrize("env", [{"STVO_GRID_FUSED": "0"}, {"STVO_GRID_FUSED_CAP": "-1"}, {"STVO_GRID_CELLS": "0"},
+                                 {"STVO_GRID_CELLS": "0", "STVO_GRID_FUSED_CAP": "-1"}],
+                         ids=["scan", "misfit", "cells-launch", "cells-launch-misfit"])
 def test_seq_point_grid_other_formulations(oracle, switches, env):
-    """The stereo point matcher runs as one workgroup per frame by default; the scan formulation (separate launches) and the
-    scan formulation inside the fused launch (frames whose pairs do not fit the LDS) must give the same pipeline results."""
+    """The stereo point matcher runs as one workgroup per frame by default — for a batch this small it also builds the grid of
+    its frame (point_cells.h); the scan formulation (separate launches), the scan formulation inside the fused launch (frames
+    whose pairs do not fit the LDS) and point_cells_kernel as its own launch must give the same pipeline results."""
     switches(env)
     cam = synth.KITTI_CAM
     seqs = [synth.make_stereo_sequence(520 + b, n_frames=4, n_pts=500 + 500 * b, n_lines=30, cam=cam) for b in range(3)]
@@ -252,7 +255,7 @@ def crowd(fr, rng, frac, box):
 @pytest.mark.parametrize("frac,box", [(0.5, (300, 100, 200, 12)), (0.95, (500, 200, 60, 7)), (0.3, (0, 0, 1241, 8)),
                                       (0.12, (200, 80, 600, 30)), (0.1, (200, 80, 500, 24))],
                          ids=["half-in-strip", "all-in-one-window", "top-row", "mild-crowd", "mild-crowd-wide-rows"])
-@pytest.mark.parametrize("env", [{}, {"STVO_GRID_FUSED": "0"}], ids=["fused", "scan"])
+@pytest.mark.parametrize("env", [{}, {"STVO_GRID_FUSED": "0"}, {"STVO_GRID_CELLS": "0"}], ids=["fused", "scan", "cells-launch"])
 def test_seq_point_grid_crowded_frames(oracle, switches, frac, box, env):
     """Raw matchGrid output (stereoFrame.cpp:145) on frames whose key-points crowd into a few grid cells: rows with more than
     64 candidates and frames with more pairs than the one-workgroup formulation holds (it must then take the scan
