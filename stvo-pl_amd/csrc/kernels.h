@@ -150,8 +150,25 @@ struct PoseArgs {
     const float4* curr_rc;  // [B][max_pts]
     const double* q_tab;    // [STVO_POSE_QTAB] sqrt(sigma2) of pyramid level l (device memory; levels beyond the table are computed)
     double level_scale;     // orbScaleFactor: sigma2 = 1 / scale^(2 level) (src/stereoFeatures.cpp:41-47)
+    // In-kernel ordering for single-stream operation (pose_inline_sync_ok; the latency kernel only), instead of events between
+    // streams — on this runtime every recorded / awaited event delays the next kernel of its stream by ~6 us:
+    //   wait_flag   the kernel starts by waiting until *wait_flag has reached wait_value (device memory, set by
+    //               launch_stream_signal behind the last kernel of another stream whose results this launch reads);
+    //   fetch_*     the solver wave of workgroup 0 copies fetch_n16 16-byte words (by-products the host wants while this kernel
+    //               runs) to pinned host memory and then publishes fetch_value in *fetch_flag (pinned, system scope).
+    const unsigned* wait_flag;
+    unsigned wait_value;
+    const uint4* fetch_src;
+    uint4* fetch_dst;
+    unsigned fetch_n16;
+    unsigned* fetch_flag;
+    unsigned fetch_value;
 };
 constexpr int STVO_POSE_QTAB = 16;
+// may launch_pose honour wait_flag / fetch_* for a batch of B frame pairs?  (few workgroups: the kernels they wait for always find CUs)
+bool pose_inline_sync_ok(int B);
+// *flag = value (release, device scope) once everything enqueued on `s` so far has completed
+void launch_stream_signal(hipStream_t s, unsigned* flag, unsigned value);
 // dispatch: pose_kernel.hip's latency variant up to 256 frame pairs (and for single evaluations), pose_kernel2p.hip beyond
 int launch_pose(hipStream_t s, const PoseArgs& a);
 int launch_pose2p(hipStream_t s, const PoseArgs& a);  // pose_kernel2p.hip: thread-private records, four frame pairs per CU

@@ -577,6 +577,18 @@ __global__ __launch_bounds__(BLOCK + 64, 2) void pose_kernel(PoseArgs a) {  // >
     // the VALU-saturating matching kernel of the next batch (stvo_ctx_set_overlap): give its waves issue
     // priority so its critical path is not stretched by the co-resident popcount waves.
     __builtin_amdgcn_s_setprio(3);
+    if (a.wait_flag) {  // results of another stream (PoseArgs::wait_flag): normally long there — one L2 round trip
+        if (threadIdx.x == 0)
+            while ((int)(__hip_atomic_load(a.wait_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - a.wait_value) < 0) __builtin_amdgcn_s_sleep(8);
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    if (a.fetch_dst && blockIdx.x == 0 && threadIdx.x >= BLOCK) {  // the solver wave has nothing to do until the first reduction
+        const int lane = threadIdx.x - BLOCK;
+        for (unsigned i = lane; i < a.fetch_n16; i += 64) a.fetch_dst[i] = a.fetch_src[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // the wave's stores have reached the host
+        if (lane == 0) __hip_atomic_store(a.fetch_flag, a.fetch_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     if (threadIdx.x < BLOCK)
         pose_body<BLOCK, PPT, LPT, true, LDSREC>(a, s_hist, s_red, s_ired, &s_sh, s_rec);   // worker waves
     else
@@ -627,8 +639,19 @@ static bool pose_ldsrec_available() {
     return lds_opt_in(reinterpret_cast<const void*>(&pose_kernel<BLK, PPT, LPT, true>), (int)POSE_LDSREC_MAX_BYTES);
 }
 
+namespace {
+__global__ void stream_signal_kernel(unsigned* flag, unsigned value) {
+    __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+}  // namespace
+void launch_stream_signal(hipStream_t s, unsigned* flag, unsigned value) {
+    hipLaunchKernelGGL(stream_signal_kernel, dim3(1), dim3(1), 0, s, flag, value);
+}
+bool pose_inline_sync_ok(int B) { return B >= 1 && B <= 16 && dbg().pose_kernel != 4; }
+
 int launch_pose(hipStream_t s, const PoseArgs& a) {
     if (a.B <= 0) return STVO_OK;
+    if ((a.wait_flag || a.fetch_dst) && !pose_inline_sync_ok(a.B)) return STVO_ERR_INVALID_ARG;
     // Two formulations (round 4: the 128-VGPR / compacted-LDS kernel of round 2 and the owner + evaluator experiment of round 3
     // are gone — both measured slower than what is here, NOTES.md):
     //   * up to 256 frame pairs, and for single evaluations (stvo_normal_eq): this file's latency variant — one workgroup per CU,

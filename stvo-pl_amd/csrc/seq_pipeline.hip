@@ -18,6 +18,7 @@
 //   then the two stereo-set buffers swap roles (updateFrame, :89-100).  One upload, one small download
 //   (B pose results + counters) and one synchronisation per frame.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -587,6 +588,11 @@ struct stvo_seq {
     // part of the block ON the line stream and the step forks without an event; st_dirty = something the line stream would have to
     // wait for has been enqueued on the point stream since the last synchronisation.
     bool st_dirty = false;
+    // ordering inside the pose kernel instead of events (kernels.h: PoseArgs::wait_flag / fetch_*), small batches only
+    unsigned* d_join_flag = nullptr;     // device word the line stream's last launch of a step is followed by a signal on
+    unsigned join_epoch = 0;
+    unsigned fetch_epoch = 0;            // value the pose kernel publishes in the pinned flag once the match indices are in fetch_host
+    bool fetch_by_pose = false;          // the last step's by-products come that way (stvo_seq_fetch_matches polls the flag)
     std::vector<char> raw_split;  // per slot: its key-line arrays were copied on the line stream
     size_t raw_bytes = 0;
     stvo::SeqDev d{};          // pointers into `dev` (set = current)
@@ -751,7 +757,8 @@ int stvo_seq_create_multi(stvo_ctx* ctx, int B, int max_keypoints, int max_keyli
     // ---- everything else
     Carver c;
     const size_t o_raw = c.take(s->raw_bytes), o_raw1 = c.take(s->raw_bytes);
-    const size_t o_cams = c.take(nb * sizeof(stvo_cam)), o_invwh = c.take(nb * 2 * 8), o_qtab = c.take(stvo::STVO_POSE_QTAB * 8);
+    const size_t o_cams = c.take(nb * sizeof(stvo_cam)), o_invwh = c.take(nb * 2 * 8), o_qtab = c.take(stvo::STVO_POSE_QTAB * 8),
+                 o_joinflag = c.take(64);
     const size_t o_pxy = c.take(nb * K * 2 * 4), o_pstart = c.take(nb * (STVO_GRID_CELLS + 1) * 4), o_pitems = c.take(nb * K * 4),
                  o_prank = c.take(nb * K * 4), o_pperm = c.take(nb * K * 4), o_prange = c.take(nb * K * 2 * 4), o_pcell = c.take(nb * K * 4);
     const bool lsort = K <= 2048 && mp->matching_s_ws >= 0 && mp->matching_s_ws <= stvo::GRID_LW - STVO_GRID_COLS;
@@ -818,6 +825,7 @@ int stvo_seq_create_multi(stvo_ctx* ctx, int B, int max_keypoints, int max_keyli
     s->d_cams = (stvo_cam*)(D + o_cams);
     s->d_inv_wh = (double*)(D + o_invwh);
     s->d_qtab = (double*)(D + o_qtab);
+    s->d_join_flag = (unsigned*)(D + o_joinflag);
     {
         std::vector<double> iw(2 * nb);
         for (int b = 0; b < B; ++b) {
@@ -1256,12 +1264,19 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl) {
             match_set(sl, s->lazy_l, M, ps.ldesc, ps.nl, cs.ldesc, cs.nl, s->mp.min_ratio_12_l, s->m12l, nullptr);
         else if (lines_prev)  // nothing to match against: every prev line is unmatched
             HIP_TRY(ctx, hipMemsetAsync(s->m12l, 0xFF, (size_t)B * M * sizeof(int32_t), st));
-        if (par) {  // join before optimizePose
+        // Small batches (single-stream operation): the pose kernel itself waits for the line stream and hands the match indices to
+        // the host — an event awaited or recorded in front of it delays its start by ~6 us each on this runtime.
+        const bool inline_sync = stvo::pose_inline_sync_ok(B) && stvo::dbg().seq_inline != 0 && !s->graph_mode && !tev && !s->pev[0] &&
+                                 (!s->fetch || (B == 1 && s->zero_copy));
+        if (par && inline_sync) {
+            stvo::launch_stream_signal(sl, s->d_join_flag, ++s->join_epoch);
+        } else if (par) {  // join before optimizePose
             HIP_TRY(ctx, hipEventRecord(s->ev_join, sl));
             HIP_TRY(ctx, hipStreamWaitEvent(st, s->ev_join, 0));
         }
         if (s->pev[0]) (void)hipEventRecord(s->pev[3], st);
-        if (s->fetch) {
+        s->fetch_by_pose = s->fetch && inline_sync;
+        if (s->fetch && !inline_sync) {
             stvo::launch_copy16(st, s->m12s_p, s->fetch_host, s->m12_span);
             HIP_TRY(ctx, hipEventRecord(s->ev_fetch, st));
         }
@@ -1288,6 +1303,17 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl) {
             if (!s->d_prof) HIP_TRY(ctx, hipMalloc((void**)&s->d_prof, (size_t)B * 16 * sizeof(long long)));
             a.prof_out = s->d_prof;
         }
+        if (par && inline_sync) {
+            a.wait_flag = s->d_join_flag;
+            a.wait_value = s->join_epoch;
+        }
+        if (s->fetch_by_pose) {
+            a.fetch_src = reinterpret_cast<const uint4*>(s->m12s_p);
+            a.fetch_dst = reinterpret_cast<uint4*>(s->fetch_host);
+            a.fetch_n16 = (unsigned)(s->m12_span / 16);
+            a.fetch_flag = reinterpret_cast<unsigned*>(s->fetch_host + s->m12_span + s->inl_span);
+            a.fetch_value = ++s->fetch_epoch;
+        }
         mark(8, st);
         TRY(stvo::launch_pose(st, a));
         mark(9, st);
@@ -1298,6 +1324,7 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl) {
             HIP_TRY(ctx, hipEventRecord(s->ev_join, sl));
             HIP_TRY(ctx, hipStreamWaitEvent(st, s->ev_join, 0));
         }
+        s->fetch_by_pose = false;
         if (s->fetch) {
             stvo::launch_copy16(st, s->m12s_p, s->fetch_host, s->m12_span);
             HIP_TRY(ctx, hipEventRecord(s->ev_fetch, st));
@@ -1420,7 +1447,8 @@ int stvo_seq_enable_fetch(stvo_seq* s, int enable) {
     stvo_ctx* ctx = s->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (enable && !s->fetch_host) {
-        HIP_TRY(ctx, hipHostMalloc((void**)&s->fetch_host, s->m12_span + s->inl_span, hipHostMallocDefault));
+        HIP_TRY(ctx, hipHostMalloc((void**)&s->fetch_host, s->m12_span + s->inl_span + 64, hipHostMallocDefault));
+        *reinterpret_cast<volatile unsigned*>(s->fetch_host + s->m12_span + s->inl_span) = 0u;  // the pose kernel's flag (fetch_by_pose)
         HIP_TRY(ctx, hipEventCreateWithFlags(&s->ev_fetch, hipEventDisableTiming));
     }
     s->fetch = enable != 0;
@@ -1432,7 +1460,19 @@ int stvo_seq_fetch_matches(stvo_seq* s, const int32_t** m12_stereo_pts, const in
     if (!s || !s->fetch || s->frame_idx == 0) return STVO_ERR_INVALID_ARG;
     stvo_ctx* ctx = s->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipEventSynchronize(s->ev_fetch));  // the f2f stage of the last step; its pose kernel may still run
+    if (s->fetch_by_pose) {
+        // the pose kernel of the last step copies the indices and then publishes its number; it may still run.  Bounded poll of the
+        // pinned word, then the stream (a launch that failed never publishes)
+        const volatile unsigned* flag = reinterpret_cast<const volatile unsigned*>(s->fetch_host + s->m12_span + s->inl_span);
+        const auto t0 = std::chrono::steady_clock::now();
+        bool seen = false;
+        for (unsigned spin = 0; !(seen = (*flag == s->fetch_epoch)); ++spin)
+            if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+        std::atomic_thread_fence(std::memory_order_acquire);
+        if (!seen) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    } else {
+        HIP_TRY(ctx, hipEventSynchronize(s->ev_fetch));  // the f2f stage of the last step; its pose kernel may still run
+    }
     const char* H = s->fetch_host;
     const char* D0 = reinterpret_cast<const char*>(s->m12s_p);
     if (m12_stereo_pts) *m12_stereo_pts = reinterpret_cast<const int32_t*>(H);

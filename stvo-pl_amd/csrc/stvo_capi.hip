@@ -28,6 +28,7 @@ DebugSwitches parse_switches() {
     d.knn_nseg = env_int("STVO_KNN_NSEG");
     d.seq_graph = env_int("STVO_SEQ_GRAPH");
     d.seq_prof = env_int("STVO_SEQ_PROF");
+    d.seq_inline = env_int("STVO_SEQ_INLINE");
     const char* lf = std::getenv("STVO_LINE_FORK");
     d.line_fork_late = lf ? (lf[0] == 'l' ? 1 : 0) : DBG_UNSET;
     d.line_first = env_int("STVO_LINE_FIRST");

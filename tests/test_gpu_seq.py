@@ -188,6 +188,42 @@ def test_seq_fetch_by_products(oracle):
         ctx.close()
 
 
+@pytest.mark.parametrize("env", [{}, {"STVO_SEQ_INLINE": "0"}], ids=["in-kernel", "events"])
+@pytest.mark.parametrize("n_lines", [40, 0])
+def test_seq_fetch_before_read_single_stream(oracle, switches, env, n_lines):
+    """The StereoFrameHandler mirror's order of calls — upload, step, fetch_matches WHILE the pose kernel runs, then read: for one
+    stream the pose kernel itself waits for the key-line stream and publishes the match indices (kernels.h: PoseArgs::wait_flag /
+    fetch_*); STVO_SEQ_INLINE=0 keeps the events.  Same by-products and bit-identical results either way, equal to push + fetch."""
+    from stvo_amd import capi
+    switches(env)
+    cam = synth.KITTI_CAM
+    seq = synth.make_stereo_sequence(4242, n_frames=5, n_pts=900, n_lines=n_lines, cam=cam)
+    mp = match_params("kitti"); op = opt_params("kitti", has_lines=1 if n_lines else 0)
+    ctx = capi.Context(device_id=0, max_rows=2048, max_batch=1)
+    a = capi.Sequences(ctx, 1, 1024, 64, cam, mp, op)
+    b = capi.Sequences(ctx, 1, 1024, 64, cam, mp, op)
+    try:
+        a.enable_fetch(True); b.enable_fetch(True)
+        for k, fr in enumerate(seq):
+            a.upload(k & 1, [fr]); a.step_dev(k & 1)
+            fa = a.fetch_matches()          # before the read: the pose kernel may still be running
+            ra, ca = a.read()
+            rb, cb = b.push([fr])
+            fb = b.fetch_matches()
+            ref = pipeline_ref.stereo_frame(oracle, fr, cam, mp, True, n_lines > 0)
+            assert np.array_equal(fa[0][0, :len(fr["kp_l"])], ref["m12_raw_p"])
+            for x, y in zip(fa, fb):
+                assert np.array_equal(x, y)
+            assert np.array_equal(ca, cb) and ra.tobytes() == rb.tobytes()
+            if k > 0:
+                ia, ib = a.fetch_inliers(), b.fetch_inliers()
+                assert np.array_equal(ia[0], ib[0]) and np.array_equal(ia[1], ib[1])
+                assert ra[0]["n_matched_pt"] > 100
+    finally:
+        a.close(); b.close()
+        ctx.close()
+
+
 @pytest.mark.parametrize("env", [{"STVO_GRID_FUSED": "0"}, {"STVO_GRID_FUSED_CAP": "-1"}, {"STVO_GRID_CELLS": "0"},
                                  {"STVO_GRID_CELLS": "0", "STVO_GRID_FUSED_CAP": "-1"}],
                          ids=["scan", "misfit", "cells-launch", "cells-launch-misfit"])

@@ -5,7 +5,7 @@ set -e
 R=$PWD; OUT=$R/$1; L=${2:-0}; mkdir -p $OUT
 python tools/make_sequence.py /tmp/seq.bin --frames 31 --lines $L > /dev/null
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace -d /tmp/lat_kt -o lat -- $R/stvo-pl_amd/bin/imagesStVO_synth /tmp/seq.bin /tmp/res.bin --preset kitti --device-pipeline > $OUT/run_l$L.txt 2>&1 || true
+rocprofv3 --kernel-trace -d /tmp/lat_kt -o lat -- $R/stvo-pl_amd/bin/imagesStVO_synth /tmp/seq.bin /tmp/res.bin --preset kitti ${TRACE_MODE---device-pipeline} > $OUT/run_l$L.txt 2>&1 || true
 cd $R
 DB=$(find /tmp/lat_kt -name "*.db" | head -1)
 python - "$DB" > $OUT/trace_l$L.txt <<'PY'
