@@ -200,8 +200,8 @@ def test_seq_fetch_before_read_single_stream(oracle, switches, env, n_lines):
     seq = synth.make_stereo_sequence(4242, n_frames=5, n_pts=900, n_lines=n_lines, cam=cam)
     mp = match_params("kitti"); op = opt_params("kitti", has_lines=1 if n_lines else 0)
     ctx = capi.Context(device_id=0, max_rows=2048, max_batch=1)
-    a = capi.Sequences(ctx, 1, 1024, 64, cam, mp, op)
-    b = capi.Sequences(ctx, 1, 1024, 64, cam, mp, op)
+    a = capi.Sequences(ctx, 1, 2048, 64, cam, mp, op)
+    b = capi.Sequences(ctx, 1, 2048, 64, cam, mp, op)
     try:
         a.enable_fetch(True); b.enable_fetch(True)
         for k, fr in enumerate(seq):
