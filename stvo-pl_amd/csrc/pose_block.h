@@ -25,9 +25,8 @@ struct PoseSh {
     double H[36];
     double g[6];
     double err, err_prev, err_out, lambda;
-    double stat[4];  // scratch scalars broadcast by thread 0 (median, stdv, mean, ...)
     double s_p, s_l;
-    unsigned long long xchg;  // select_kth's one-word mailbox
+    unsigned long long xchg[2];  // select2's mailboxes
     int action, good, n_inl_p, n_inl_l, n_m_p, n_m_l, evals, itmp;
 };
 
@@ -174,164 +173,288 @@ struct BlockOps {
         return t;
     }
 
-    // k-th smallest (0-based) of the keys {key[k] : bit k of mask} held in REGISTERS across the workgroup, most significant
-    // byte first: the keys that still carry the current prefix are counted into a 256-bin LDS
-    // histogram (no-return ds_add), wave 0 scans the bins (4 per lane) for the one that holds the kth key while the other
-    // waves clear the histogram of the next round, everybody adopts bin and rank.  ~1300 doubles take 3 rounds + the fetch of
-    // the last key instead of ~11 two-bit rounds of 24 ballots each (the outlier removal of a frame pair: 70 k -> ~35 k
-    // cycles).  Integer counts only: the result is the one a sort would give.  hist: [2][HIST_W] ints (HIST_W - 256 mailbox
-    // words); zeroed here, so callers need not preserve anything.
+    // ---- exact k-th element selection on register-resident keys, TWO independent key sets in lockstep -------------------------
+    // (the key-points and the key-lines of removeOutliers / of the robust pre-pass: the same barriers serve both.)
+    // Radix search from the most significant bit in which the keys of a set DIFFER (block-wide AND / OR; 64-bit keys of threads
+    // with many keys only — residual norms share sign and top exponent bits, so a first round from bit 63 decided nothing while
+    // ~1500 ds_add hit two or three bins), 7 bits per round: the keys that still carry the prefix are counted into a 128-bin
+    // histogram of 16-bit counters (64 words; a set has at most 2048 keys), EVERY wave scans it (one word per lane, DPP prefix
+    // sum, the lane that holds rank kk found by ballot) and so knows bin and rank without a second barrier.  Three histograms per
+    // set are used in rotation — round r counts into r mod 3 and, after its barrier, clears (r + 2) mod 3, which every wave
+    // finished scanning before it arrived at that barrier — so a round costs ONE barrier (round 3: clear / count / barrier / scan
+    // by wave 0 / barrier / read back = two).  The rotation carries over from call to call (`rot`, block-uniform): the scratch
+    // must be zero before the first call and whenever somebody else has used it.  Integer counts only: the result is the one a
+    // sort would give.
+    // Scratch S (HIST_W * 2 words): [set][rot][64] histograms, then the AND / OR words of the waves.
     static constexpr int HIST_W = 260;
-    // Round 4: the search starts at the most significant bit in which the keys DIFFER (block-wide AND / OR of the keys, one extra
-    // exchange through the second histogram's words before the first barrier).  The keys of a selection are residual norms: doubles
-    // between ~0.01 and ~100 share sign and the top exponent bits, so the first 8-bit round of a search from bit 63 put ~1500
-    // ds_add on two or three bins (they serialise in the LDS unit) and decided nothing; from the first differing bit the first
-    // round already spreads the keys over most of the 256 bins and the second usually isolates the answer.
-    template <int N, bool W, typename K, int BITS>
-    static __device__ __forceinline__ K select_kth_hist(const K* key, unsigned mask, int kth, int (*hist)[HIST_W], K* xchg) {
-        static_assert(BITS == 32 || BITS == 64, "32- or 64-bit keys");
-        const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-        // (only where it pays: the 64-bit keys of a thread with many of them — the key-points of the batch kernels.  The float keys
-        //  of the MAD spread over ~15 top bytes by themselves, and with a handful of keys per thread the exchange costs more than the
-        //  degenerate round: the robust mode of the latency kernel, which selects at every evaluation, lost 8 % to it.)
-        constexpr bool PREFIX = BITS == 64 && N >= 8;
-        K k_and = 0, k_or = ~(K)0;  // !PREFIX: every bit counts as differing
-        if (PREFIX) {
-            k_and = ~(K)0;
-            k_or = 0;
-        }
-        if (W) {
-            if (PREFIX) {
+    static constexpr int SEL_HW = 64, SEL_PART = 6 * SEL_HW;  // words per histogram; word offset of the AND / OR exchange
+    static_assert(SEL_PART * 4 % 8 == 0 && SEL_PART + 8 * NWORK <= 2 * HIST_W, "selection scratch");
+
+    static __device__ __forceinline__ int wave_incl_scan_i(int v) {
+        v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);  // row_shr:1
+        v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);  // row_shr:2
+        v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);  // row_shr:4
+        v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);  // row_shr:8
+        v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);  // row_bcast:15 -> rows 1 and 3
+        v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);  // row_bcast:31 -> rows 2 and 3
+        return v;
+    }
+    // which bin of histogram h holds the key of rank kk (0 <= kk < keys counted), how many keys lie below that bin, how many in it
+    static __device__ __forceinline__ void sel_scan(const unsigned* h, int kk, int& bin, int& below, int& cnt) {
+        const int lane = threadIdx.x & 63;
+        const unsigned w = h[lane];
+        const int c0 = (int)(w & 0xFFFFu), c1 = (int)(w >> 16), sum = c0 + c1;
+        const int incl = wave_incl_scan_i(sum), excl = incl - sum;
+        const unsigned long long hit = __ballot(excl <= kk && kk < incl);  // exactly one lane
+        const int L = hit ? __builtin_ctzll(hit) : 0;
+        const bool up = kk >= excl + c0;
+        bin = __builtin_amdgcn_readlane(2 * lane + (up ? 1 : 0), L);
+        below = __builtin_amdgcn_readlane(excl + (up ? c0 : 0), L);
+        cnt = __builtin_amdgcn_readlane(up ? c1 : c0, L);
+    }
+    // wave AND / OR of the keys in `mask` on DPP moves (lanes without a source keep their own value: the identity of both); lane 63
+    // of worker wave wv leaves them in part[0], part[1]
+    template <int N, typename K>
+    static __device__ __forceinline__ void sel_and_or(const K* key, unsigned mask, unsigned long long* part) {
+        K k_and = ~(K)0, k_or = 0;
 #pragma unroll
-                for (int k = 0; k < N; ++k)
-                    if ((mask >> k) & 1u) {
-                        k_and &= key[k];
-                        k_or |= key[k];
-                    }
-                // wave AND / OR on DPP moves (lanes without a source keep their own value: the identity of both), result in lane 63
-                auto dpp_step = [&](auto ctrl_c, auto rmask_c) {
-                    constexpr int CTRL = decltype(ctrl_c)::value, RM = decltype(rmask_c)::value;
-                    const unsigned alo = (unsigned)k_and, ahi = (unsigned)((unsigned long long)k_and >> 32);
-                    const unsigned olo = (unsigned)k_or, ohi = (unsigned)((unsigned long long)k_or >> 32);
-                    const unsigned a0 = (unsigned)__builtin_amdgcn_update_dpp((int)alo, (int)alo, CTRL, RM, 0xf, false);
-                    const unsigned a1 = (unsigned)__builtin_amdgcn_update_dpp((int)ahi, (int)ahi, CTRL, RM, 0xf, false);
-                    const unsigned o0 = (unsigned)__builtin_amdgcn_update_dpp((int)olo, (int)olo, CTRL, RM, 0xf, false);
-                    const unsigned o1 = (unsigned)__builtin_amdgcn_update_dpp((int)ohi, (int)ohi, CTRL, RM, 0xf, false);
-                    k_and &= (K)(((unsigned long long)a1 << 32) | a0);
-                    k_or |= (K)(((unsigned long long)o1 << 32) | o0);
-                };
-                using std::integral_constant;
-                dpp_step(integral_constant<int, 0x111>{}, integral_constant<int, 0xf>{});  // row_shr:1
-                dpp_step(integral_constant<int, 0x112>{}, integral_constant<int, 0xf>{});  // row_shr:2
-                dpp_step(integral_constant<int, 0x114>{}, integral_constant<int, 0xf>{});  // row_shr:4
-                dpp_step(integral_constant<int, 0x118>{}, integral_constant<int, 0xf>{});  // row_shr:8
-                dpp_step(integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{});  // row_bcast:15 -> rows 1 and 3
-                dpp_step(integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{});  // row_bcast:31 -> rows 2 and 3
-                unsigned long long* part = reinterpret_cast<unsigned long long*>(&hist[1][0]);  // [NWORK][2]
-                if (lane == 63) {
-                    part[2 * wv] = (unsigned long long)k_and;
-                    part[2 * wv + 1] = (unsigned long long)k_or;
-                }
+        for (int k = 0; k < N; ++k)
+            if ((mask >> k) & 1u) {
+                k_and &= key[k];
+                k_or |= key[k];
             }
-            for (int i = tid; i < 256; i += WTHREADS) hist[0][i] = 0;
+        auto dpp_step = [&](auto ctrl_c, auto rmask_c) {
+            constexpr int CTRL = decltype(ctrl_c)::value, RM = decltype(rmask_c)::value;
+            const unsigned alo = (unsigned)k_and, ahi = (unsigned)((unsigned long long)k_and >> 32);
+            const unsigned olo = (unsigned)k_or, ohi = (unsigned)((unsigned long long)k_or >> 32);
+            const unsigned a0 = (unsigned)__builtin_amdgcn_update_dpp((int)alo, (int)alo, CTRL, RM, 0xf, false);
+            const unsigned a1 = (unsigned)__builtin_amdgcn_update_dpp((int)ahi, (int)ahi, CTRL, RM, 0xf, false);
+            const unsigned o0 = (unsigned)__builtin_amdgcn_update_dpp((int)olo, (int)olo, CTRL, RM, 0xf, false);
+            const unsigned o1 = (unsigned)__builtin_amdgcn_update_dpp((int)ohi, (int)ohi, CTRL, RM, 0xf, false);
+            k_and &= (K)(((unsigned long long)a1 << 32) | a0);
+            k_or |= (K)(((unsigned long long)o1 << 32) | o0);
+        };
+        using std::integral_constant;
+        dpp_step(integral_constant<int, 0x111>{}, integral_constant<int, 0xf>{});  // row_shr:1
+        dpp_step(integral_constant<int, 0x112>{}, integral_constant<int, 0xf>{});  // row_shr:2
+        dpp_step(integral_constant<int, 0x114>{}, integral_constant<int, 0xf>{});  // row_shr:4
+        dpp_step(integral_constant<int, 0x118>{}, integral_constant<int, 0xf>{});  // row_shr:8
+        dpp_step(integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{});  // row_bcast:15 -> rows 1 and 3
+        dpp_step(integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{});  // row_bcast:31 -> rows 2 and 3
+        if ((threadIdx.x & 63) == 63) {
+            part[0] = (unsigned long long)k_and;
+            part[1] = (unsigned long long)k_or;
         }
-        __syncthreads();
-        if (PREFIX) {
-            const unsigned long long* part = reinterpret_cast<const unsigned long long*>(&hist[1][0]);
-            unsigned long long a = ~0ull, o = 0ull;
+    }
+
+    // outa / outb = the ktha-th / kthb-th smallest (0-based) of {ka[k] : bit k of ma} / {kb[k] : bit k of mb}; acta / actb
+    // (block-uniform): the set is not empty — an inactive set costs nothing and leaves its output alone.  xchg: two LDS words.
+    template <int NA, int NB, bool W, typename K, int BITS>
+    static __device__ __forceinline__ void select2(const K* ka, unsigned ma, int ktha, bool acta, const K* kb, unsigned mb, int kthb, bool actb,
+                                                   unsigned* S, unsigned long long* xchg, int& rot, K& outa, K& outb) {
+        static_assert(BITS == 32 || BITS == 64, "32- or 64-bit keys");
+        const int tid = threadIdx.x, wv = tid >> 6;
+        // (the AND / OR exchange only where it pays: the float keys of the MAD spread over ~15 top bytes by themselves, and with a
+        //  handful of keys per thread it costs more than the degenerate round — the robust mode of the latency kernel, which
+        //  selects at every evaluation, lost 8 % to it)
+        constexpr bool PFA = BITS == 64 && NA >= 8, PFB = BITS == 64 && NB >= 8;
+        K anda = 0, ora = ~(K)0, andb = 0, orb = ~(K)0;  // no exchange: every bit counts as differing
+        if (PFA || PFB) {
+            unsigned long long* part = reinterpret_cast<unsigned long long*>(S + SEL_PART);  // [NWORK][4]
+            if (W) {
+                if (PFA) sel_and_or<NA, K>(ka, ma, part + 4 * wv);
+                if (PFB) sel_and_or<NB, K>(kb, mb, part + 4 * wv + 2);
+            }
+            __syncthreads();
+            unsigned long long a0 = ~0ull, o0 = 0ull, a1 = ~0ull, o1 = 0ull;
 #pragma unroll
             for (int w = 0; w < NWORK; ++w) {
-                a &= part[2 * w];
-                o |= part[2 * w + 1];
+                if (PFA) { a0 &= part[4 * w]; o0 |= part[4 * w + 1]; }
+                if (PFB) { a1 &= part[4 * w + 2]; o1 |= part[4 * w + 3]; }
             }
-            k_and = (K)a;
-            k_or = (K)o;
+            if (PFA) { anda = (K)a0; ora = (K)o0; }
+            if (PFB) { andb = (K)a1; orb = (K)o1; }
         }
-        const K differ = k_and ^ k_or;
-        K prefix = k_and;  // the common high bits (and zeros below them, as far as the search is concerned)
-        int kk = kth, parity = 0;
-        // hi = the most significant undecided bit; a round decides bits hi .. lo = max(0, hi - 7)
-        int hi = differ == 0 ? -1 : (BITS - 1) - (BITS == 64 ? __clzll((unsigned long long)differ) : __clz((unsigned)differ));
-        while (hi >= 0) {
-            const int lo = hi >= 7 ? hi - 7 : 0;
-            int* h = hist[parity];
-            if (W) {
+        auto top_bit = [](K differ) -> int {
+            return differ == 0 ? -1 : (BITS - 1) - (BITS == 64 ? __clzll((unsigned long long)differ) : __clz((unsigned)differ));
+        };
+        K pa = anda, pb = andb;  // the common high bits (and zeros below them, as far as the search is concerned)
+        int kka = ktha, kkb = kthb;
+        // hi = the most significant undecided bit of the set (-1: done); a round decides bits hi .. lo = max(0, hi - 6)
+        int hia = acta ? top_bit(anda ^ ora) : -1, hib = actb ? top_bit(andb ^ orb) : -1;
+        bool penda = false, pendb = false;  // the result comes from the single key left under the prefix, through xchg
+        auto count = [&](auto n_c, const K* key, unsigned mask, K prefix, int hi, int lo, unsigned* h) {
+            constexpr int N = decltype(n_c)::value;
 #pragma unroll
-                for (int k = 0; k < N; ++k) {
-                    const K diff = key[k] ^ prefix;
-                    const bool same = hi + 1 >= BITS ? true : (diff >> (hi + 1 >= BITS ? 0 : hi + 1)) == 0;
-                    if (((mask >> k) & 1u) && same) atomicAdd(&h[(int)((key[k] >> lo) & 255)], 1);
-                }
+            for (int k = 0; k < N; ++k) {
+                const K diff = key[k] ^ prefix;
+                const bool same = hi + 1 >= BITS ? true : (diff >> (hi + 1 >= BITS ? 0 : hi + 1)) == 0;
+                const unsigned bin = (unsigned)((key[k] >> lo) & 127);
+                if (((mask >> k) & 1u) && same) atomicAdd(&h[bin >> 1], 1u << (16 * (bin & 1u)));
             }
-            __syncthreads();
-            if (W && wv == 0) {
-                const int c0 = h[4 * lane], c1 = h[4 * lane + 1], c2 = h[4 * lane + 2], c3 = h[4 * lane + 3];
-                const int sum = c0 + c1 + c2 + c3;
-                int incl = sum;
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const int o = __shfl_up(incl, off, 64);
-                    if (lane >= off) incl += o;
-                }
-                const int excl = incl - sum;
-                if (excl <= kk && kk < incl) {  // exactly one lane: 0 <= kk < number of keys under the prefix
-                    int bin = 4 * lane, below = excl, cnt = c0;
-                    if (kk >= below + cnt) { below += cnt; cnt = c1; bin += 1;
-                        if (kk >= below + cnt) { below += cnt; cnt = c2; bin += 1;
-                            if (kk >= below + cnt) { below += cnt; cnt = c3; bin += 1; } } }
-                    h[256] = bin;
-                    h[257] = below;
-                    h[258] = cnt;
-                }
-            }
-            if (W && (NWORK == 1 || wv != 0)) {  // the next round's histogram
-                const int first = NWORK == 1 ? 0 : 64, step = NWORK == 1 ? 64 : WTHREADS - 64;
-                for (int i = tid - first; i < 256; i += step) hist[parity ^ 1][i] = 0;
-            }
-            __syncthreads();
-            const int bin = h[256], below = h[257], cnt = h[258];
-            prefix = (prefix & ~((K)255 << lo)) | ((K)bin << lo);  // (the window may reach into decided bits: they are the same)
+        };
+        auto decide = [&](auto n_c, const K* key, unsigned mask, const unsigned* h, K& prefix, int& kk, int& hi, int lo, bool& pend,
+                          unsigned long long* mail) {
+            constexpr int N = decltype(n_c)::value;
+            int bin, below, cnt;
+            sel_scan(h, kk, bin, below, cnt);
+            prefix = (prefix & ~((K)127 << lo)) | ((K)bin << lo);  // (the window may reach into decided bits: they are the same)
             kk -= below;
-            parity ^= 1;
-            if (cnt == 1 && lo > 0) {  // block-uniform: the single key under the prefix
+            hi = lo - 1;
+            if (cnt == 1 && lo > 0) {  // block-uniform: the single key under the prefix; visible after the next barrier
                 if (W) {
 #pragma unroll
                     for (int k = 0; k < N; ++k)
-                        if (((mask >> k) & 1u) && ((key[k] ^ prefix) >> lo) == 0) *xchg = key[k];
+                        if (((mask >> k) & 1u) && ((key[k] ^ prefix) >> lo) == 0) *mail = (unsigned long long)key[k];
                 }
-                __syncthreads();
-                prefix = *xchg;
-                break;
+                pend = true;
+                hi = -1;
             }
-            hi = lo - 1;
+        };
+        using std::integral_constant;
+        while (hia >= 0 || hib >= 0) {
+            const int loa = hia >= 6 ? hia - 6 : 0, lob = hib >= 6 ? hib - 6 : 0;
+            unsigned* const ha = S + rot * SEL_HW;
+            unsigned* const hb = S + (3 + rot) * SEL_HW;
+            if (W) {
+                if (hia >= 0) count(integral_constant<int, NA>{}, ka, ma, pa, hia, loa, ha);
+                if (hib >= 0) count(integral_constant<int, NB>{}, kb, mb, pb, hib, lob, hb);
+            }
+            __syncthreads();
+            if (W && tid < 2 * SEL_HW) {  // the histograms of the round after the next (worker threads 0 .. 127)
+                const int rc = rot == 0 ? 2 : rot - 1;
+                S[((tid >> 6) * 3 + rc) * SEL_HW + (tid & 63)] = 0u;
+            }
+            if (hia >= 0) decide(integral_constant<int, NA>{}, ka, ma, ha, pa, kka, hia, loa, penda, xchg);
+            if (hib >= 0) decide(integral_constant<int, NB>{}, kb, mb, hb, pb, kkb, hib, lob, pendb, xchg + 1);
+            rot = rot == 2 ? 0 : rot + 1;
         }
-        __syncthreads();  // hist / xchg are reused by the caller
-        return prefix;
+        __syncthreads();  // the mailboxes; and the AND / OR words are free for the next call
+        if (penda) pa = (K)xchg[0];
+        if (pendb) pb = (K)xchg[1];
+        if (acta) outa = pa;
+        if (actb) outb = pb;
     }
 
-    // 1.4826 * MAD of the n values {v[k] : bit k of mask}.  Follows vector_stdv_mad / the first half of
-    // vector_mean_stdv_mad (src/auxiliar.cpp:395-404, 447-457): median = sorted[n/2]; dev = fabsf(x - median)
-    // (FLOAT truncation); MAD = sorted dev[n/2].  The two std::sort calls are replaced by exact k-th-element
-    // selection on the order-preserving integer images of the values.  n == 0 -> 0.
+    // 1.4826 * MAD of the na values {va[k] : bit k of ma} and of the nb values {vb[k] : bit k of mb}.  Follows vector_stdv_mad /
+    // the first half of vector_mean_stdv_mad (src/auxiliar.cpp:395-404, 447-457): median = sorted[n/2]; dev = fabsf(x - median)
+    // (FLOAT truncation); MAD = sorted dev[n/2].  The two std::sort calls are replaced by exact k-th-element selection on the
+    // order-preserving integer images of the values.  n == 0 -> 0.
+    template <int NA, int NB, bool W>
+    static __device__ __forceinline__ void mad_sigma2(const double* va, unsigned ma, int na, const double* vb, unsigned mb, int nb, unsigned* S,
+                                                      unsigned long long* xchg, int& rot, double& sa, double& sb) {
+        sa = 0.0;
+        sb = 0.0;
+        const bool acta = na != 0, actb = nb != 0;  // block-uniform
+        if (!acta && !actb) return;
+        auto image = [](double v) -> unsigned long long {  // total order of IEEE doubles
+            const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+            return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+        };
+        auto value = [](unsigned long long k) -> double {
+            return __longlong_as_double((long long)((k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k));
+        };
+        unsigned long long ka[NA], kb[NB];
+#pragma unroll
+        for (int k = 0; k < NA; ++k) ka[k] = image(va[k]);
+#pragma unroll
+        for (int k = 0; k < NB; ++k) kb[k] = image(vb[k]);
+        unsigned long long ra = 0ull, rb = 0ull;
+        select2<NA, NB, W, unsigned long long, 64>(ka, ma, na / 2, acta, kb, mb, nb / 2, actb, S, xchg, rot, ra, rb);
+        const double meda = value(ra), medb = value(rb);
+        unsigned fa[NA], fb[NB];
+#pragma unroll
+        for (int k = 0; k < NA; ++k) fa[k] = __float_as_uint(fabsf((float)(va[k] - meda)));  // >= 0 (or NaN)
+#pragma unroll
+        for (int k = 0; k < NB; ++k) fb[k] = __float_as_uint(fabsf((float)(vb[k] - medb)));
+        unsigned qa = 0u, qb = 0u;
+        select2<NA, NB, W, unsigned, 32>(fa, ma, na / 2, acta, fb, mb, nb / 2, actb, S, xchg, rot, qa, qb);
+        if (acta) sa = 1.4826 * (double)__uint_as_float(qa);
+        if (actb) sb = 1.4826 * (double)__uint_as_float(qb);
+    }
+
+    // block sums of N doubles to every thread through red[.][slot0 .. slot0 + N): ONE barrier.  The caller keeps a barrier between
+    // two uses of the same slots (and of sum28_fold, which uses all of them).
     template <int N, bool W>
-    static __device__ __forceinline__ double mad_sigma(const double* v, unsigned mask, int n, int (*hist)[HIST_W],
-                                                       unsigned long long* xchg) {
-        if (n == 0) return 0.0;  // block-uniform
-        const int kth = n / 2;
-        unsigned long long key[N];
+    static __device__ __forceinline__ void sum_at(const double* v, double (*red)[28], int slot0, double* out) {
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        if (W) {
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                const double s = wave_sum_lane63(v[k]);
+                if (lane == 63) red[wv][slot0 + k] = s;
+            }
+        }
+        __syncthreads();
 #pragma unroll
         for (int k = 0; k < N; ++k) {
-            const unsigned long long b = (unsigned long long)__double_as_longlong(v[k]);
-            key[k] = (b >> 63) ? ~b : (b | 0x8000000000000000ull);  // total order of IEEE doubles
-        }
-        const unsigned long long res = select_kth_hist<N, W, unsigned long long, 64>(key, mask, kth, hist, xchg);
-        const unsigned long long mb = (res >> 63) ? (res & 0x7FFFFFFFFFFFFFFFull) : ~res;
-        const double median = __longlong_as_double((long long)mb);
-        unsigned fkey[N];
+            double s = red[0][slot0 + k];
 #pragma unroll
-        for (int k = 0; k < N; ++k) fkey[k] = __float_as_uint(fabsf((float)(v[k] - median)));  // >= 0 (or NaN)
-        const unsigned fres = select_kth_hist<N, W, unsigned, 32>(fkey, mask, kth, hist, reinterpret_cast<unsigned*>(xchg));
-        return 1.4826 * (double)__uint_as_float(fres);
+            for (int w = 1; w < NW; ++w) s += red[w][slot0 + k];
+            out[k] = s;
+        }
+    }
+
+    // removeOutliers (:988-1067) for both kinds of features at once, given the weighted residual norms of ALL matches (ra / rb by
+    // slot, matched masks ma / mb, na / nb matches in the block): robust scale (mad_sigma2), the mean of the samples below two
+    // sigma or of all samples (src/auxiliar.cpp:405-427), then every inlier further than inlier_k sigma from the mean goes.
+    // do_a / do_b = has_points / has_lines (:991, :1026).  inla / inlb are updated; cnt[0], cnt[1] = the new inlier counts of the
+    // block (meaningful for the kinds that were processed).  Ends WITHOUT a barrier: the caller has one before red is used again.
+    template <int NA, int NB, bool W>
+    static __device__ __forceinline__ void outlier_cut(const double* ra, unsigned ma, int na, bool do_a, const double* rb, unsigned mb, int nb,
+                                                       bool do_b, double inlier_k, unsigned& inla, unsigned& inlb, unsigned* S,
+                                                       unsigned long long* xchg, int& rot, double (*red)[28], int* cnt) {
+        double sa, sb;
+        mad_sigma2<NA, NB, W>(ra, do_a ? ma : 0u, do_a ? na : 0, rb, do_b ? mb : 0u, do_b ? nb : 0, S, xchg, rot, sa, sb);
+        double v[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        if (W) {
+#pragma unroll
+            for (int k = 0; k < NA; ++k)
+                if (do_a && ((ma >> k) & 1u)) {
+                    if (ra[k] < 2.0 * sa) {
+                        v[0] += ra[k];
+                        v[1] += 1.0;
+                    }
+                    v[2] += ra[k];
+                }
+#pragma unroll
+            for (int k = 0; k < NB; ++k)
+                if (do_b && ((mb >> k) & 1u)) {
+                    if (rb[k] < 2.0 * sb) {
+                        v[3] += rb[k];
+                        v[4] += 1.0;
+                    }
+                    v[5] += rb[k];
+                }
+        }
+        double t[6];
+        sum_at<6, W>(v, red, 0, t);
+        auto mean_of = [](int tot, const double* t3) -> double {
+            if (tot == 0) return 0.0;
+            const int ksel = (int)t3[1];
+            return (ksel >= (int)(0.2 * (double)tot)) ? t3[0] / (double)ksel : t3[2] / (double)tot;
+        };
+        const double mean_a = mean_of(na, t), mean_b = mean_of(nb, t + 3);
+        const double tha = inlier_k * sa, thb = inlier_k * sb;
+        double c[2] = {0.0, 0.0};
+        if (W) {
+            if (do_a) {
+#pragma unroll
+                for (int k = 0; k < NA; ++k)
+                    if (((inla >> k) & 1u) && fabs(ra[k] - mean_a) > tha) inla &= ~(1u << k);
+            }
+            if (do_b) {
+#pragma unroll
+                for (int k = 0; k < NB; ++k)
+                    if (((inlb >> k) & 1u) && fabs(rb[k] - mean_b) > thb) inlb &= ~(1u << k);
+            }
+            c[0] = (double)__popc(inla);
+            c[1] = (double)__popc(inlb);
+        }
+        double ct[2];
+        sum_at<2, W>(c, red, 8, ct);
+        cnt[0] = (int)ct[0];
+        cnt[1] = (int)ct[1];
     }
 };
 

@@ -56,6 +56,10 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_hist)[Block
     // from HBM the first time and from L2 afterwards: the working set of the workgroups resident on
     // one XCD is < 4 MiB.  Keeping the records out of the VGPR file is what lets three workgroups
     // share a CU, so one pair's serial 6x6 algebra overlaps the parallel phases of the others.
+    unsigned* const sel = reinterpret_cast<unsigned*>(&s_hist[0][0]);  // BlockOps::select2's scratch: zero before its first use
+    int sel_rot = 0;
+    if (W)
+        for (int i = tid; i < 2 * Ops::HIST_W; i += BLOCK) sel[i] = 0u;  // (the barriers of the counts below come first)
     unsigned pmatched = 0u, pinl = 0u;
     // like the reference, optimizeFunctions sums whatever is in matched_pt / matched_ls; has_points /
     // has_lines only gate the matching (caller) and the two blocks of removeOutliers (:991,1026)
@@ -244,7 +248,7 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_hist)[Block
 #pragma unroll
         for (int i = 0; i < 16; ++i) DT[i] = sh->DT[i];
         double sp = 1.0, sl = 1.0;
-        if (robust) {  // pre-pass :710-781: MAD scale of the inlier residual norms
+        if (robust) {  // pre-pass :710-781: MAD scale of the inlier residual norms, both kinds of features in the same rounds
             double rp[PPT];
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
@@ -255,7 +259,6 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_hist)[Block
                 }
                 __builtin_amdgcn_sched_barrier(0);  // keep one record in flight, not PPT of them
             }
-            sp = pm::clamp_scale(Ops::template mad_sigma<PPT, W>(rp, pinl, sh->n_inl_p, s_hist, &sh->xchg));
             double rl[LPT];
 #pragma unroll
             for (int k = 0; k < LPT; ++k) {
@@ -263,7 +266,9 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_hist)[Block
                 if ((linl >> k) & 1u) rl[k] = pm::line_residual(DT, cam, load_line(k));
                 __builtin_amdgcn_sched_barrier(0);
             }
-            sl = pm::clamp_scale(Ops::template mad_sigma<LPT, W>(rl, linl, sh->n_inl_l, s_hist, &sh->xchg));
+            Ops::template mad_sigma2<PPT, LPT, W>(rp, pinl, sh->n_inl_p, rl, linl, sh->n_inl_l, sel, sh->xchg, sel_rot, sp, sl);
+            sp = pm::clamp_scale(sp);
+            sl = pm::clamp_scale(sl);
         }
         const double isp = 1.0 / sp, isl = 1.0 / sl;  // reciprocals of the robust scales: one division per evaluation, not per feature
         const long long tw0 = tick();
@@ -356,80 +361,31 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_hist)[Block
         double DT[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) DT[i] = sh->DT1[i];
-        if (prm.has_points) {
-            double res[PPT];
-            const int tot = sh->n_m_p;
+        double resp[PPT], resl[LPT];
 #pragma unroll
-            for (int k = 0; k < PPT; ++k) {  // ALL matches, current outliers included (:998-1005)
-                res[k] = 0.0;
-                if ((pmatched >> k) & 1u) {
-                    const PointRec r = load_point(k);
-                    res[k] = pm::point_residual(DT, cam, r.X, r.Y, r.Z, r.ox, r.oy) * r.s2;  // r.s2 = sqrt(sigma2)
-                }
-                __builtin_amdgcn_sched_barrier(0);
+        for (int k = 0; k < PPT; ++k) {  // ALL matches, current outliers included (:998-1005)
+            resp[k] = 0.0;
+            if (prm.has_points && ((pmatched >> k) & 1u)) {
+                const PointRec r = load_point(k);
+                resp[k] = pm::point_residual(DT, cam, r.X, r.Y, r.Z, r.ox, r.oy) * r.s2;  // r.s2 = sqrt(sigma2)
             }
-            const double stdv = Ops::template mad_sigma<PPT, W>(res, pmatched, tot, s_hist, &sh->xchg);
-            // mean of the samples below 2 sigma, or of all samples (src/auxiliar.cpp:405-427)
-            double v[3] = {0.0, 0.0, 0.0};
-#pragma unroll
-            for (int k = 0; k < PPT; ++k)
-                if ((pmatched >> k) & 1u) {
-                    if (res[k] < 2.0 * stdv) {
-                        v[0] += res[k];
-                        v[1] += 1.0;
-                    }
-                    v[2] += res[k];
-                }
-            double t[3];
-            Ops::template sum_small<3, W>(v, s_red, t);
-            double mean = 0.0;
-            if (tot != 0) {
-                const int ksel = (int)t[1];
-                mean = (ksel >= (int)(0.2 * (double)tot)) ? t[0] / (double)ksel : t[2] / (double)tot;
-            }
-            const double th = prm.inlier_k * stdv;
-#pragma unroll
-            for (int k = 0; k < PPT; ++k)
-                if (((pinl >> k) & 1u) && fabs(res[k] - mean) > th) pinl &= ~(1u << k);
-            const int nip = Ops::template sum_int<W>(__popc(pinl), s_ired);
-            if (t0) sh->n_inl_p = nip;
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (prm.has_lines) {
-            double res[LPT];
-            const int tot = sh->n_m_l;
 #pragma unroll
-            for (int k = 0; k < LPT; ++k) {
-                res[k] = 0.0;
-                if ((lmatched >> k) & 1u) {
-                    const pm::LineRec L = load_line(k);
-                    res[k] = pm::line_residual(DT, cam, L) * L.sigma2;  // sqrt(sigma2)
-                }
-                __builtin_amdgcn_sched_barrier(0);
+        for (int k = 0; k < LPT; ++k) {
+            resl[k] = 0.0;
+            if (prm.has_lines && ((lmatched >> k) & 1u)) {
+                const pm::LineRec L = load_line(k);
+                resl[k] = pm::line_residual(DT, cam, L) * L.sigma2;  // sqrt(sigma2)
             }
-            const double stdv = Ops::template mad_sigma<LPT, W>(res, lmatched, tot, s_hist, &sh->xchg);
-            double v[3] = {0.0, 0.0, 0.0};
-#pragma unroll
-            for (int k = 0; k < LPT; ++k)
-                if ((lmatched >> k) & 1u) {
-                    if (res[k] < 2.0 * stdv) {
-                        v[0] += res[k];
-                        v[1] += 1.0;
-                    }
-                    v[2] += res[k];
-                }
-            double t[3];
-            Ops::template sum_small<3, W>(v, s_red, t);
-            double mean = 0.0;
-            if (tot != 0) {
-                const int ksel = (int)t[1];
-                mean = (ksel >= (int)(0.2 * (double)tot)) ? t[0] / (double)ksel : t[2] / (double)tot;
-            }
-            const double th = prm.inlier_k * stdv;
-#pragma unroll
-            for (int k = 0; k < LPT; ++k)
-                if (((linl >> k) & 1u) && fabs(res[k] - mean) > th) linl &= ~(1u << k);
-            const int nil = Ops::template sum_int<W>(__popc(linl), s_ired);
-            if (t0) sh->n_inl_l = nil;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        int cnt[2];
+        Ops::template outlier_cut<PPT, LPT, W>(resp, pmatched, sh->n_m_p, prm.has_points != 0, resl, lmatched, sh->n_m_l, prm.has_lines != 0,
+                                               prm.inlier_k, pinl, linl, sel, sh->xchg, sel_rot, s_red, cnt);
+        if (t0) {
+            if (prm.has_points) sh->n_inl_p = cnt[0];
+            if (prm.has_lines) sh->n_inl_l = cnt[1];
         }
         prefetch_first();  // the inlier set changed
         __syncthreads();
@@ -569,7 +525,7 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_hist)[Block
 template <int BLOCK, int PPT, int LPT, bool LDSREC>
 __global__ __launch_bounds__(BLOCK + 64, 2) void pose_kernel(PoseArgs a) {  // >= 2 waves/SIMD => <= 256 VGPRs, 2 workgroups per CU
     extern __shared__ double s_rec[];  // LDSREC: [max_pts][6] + [max_lines][14] doubles (dynamic, sized at launch)
-    __shared__ int s_hist[2][BlockOps<BLOCK / 64>::HIST_W];  // select_kth_hist
+    __shared__ __align__(16) int s_hist[2][BlockOps<BLOCK / 64>::HIST_W];  // BlockOps::select2
     __shared__ double s_red[BLOCK / 64][28];
     __shared__ int s_ired[BLOCK / 64];
     __shared__ PoseSh s_sh;

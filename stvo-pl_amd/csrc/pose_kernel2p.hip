@@ -160,7 +160,7 @@ __global__ __launch_bounds__(NW * 64, 2) void pose2p_kernel(PoseArgs a, const in
     constexpr int LPT = (STVO_POSE_MAX_LINES + BLOCK - 1) / BLOCK;
     using Ops = BlockOps<NW>;
     extern __shared__ double2 s_pl[];  // [k_lds][3][BLOCK]: 16-byte part `part` of this thread's record ordinal r at (r * 3 + part) * BLOCK + tid
-    __shared__ int s_hist[2][Ops::HIST_W];  // select_kth_hist
+    __shared__ __align__(16) int s_hist[2][Ops::HIST_W];  // BlockOps::select2
     __shared__ double s_red[NW][28];
     __shared__ int s_ired[NW];
     __shared__ PoseSh s_sh;
@@ -236,6 +236,9 @@ __global__ __launch_bounds__(NW * 64, 2) void pose2p_kernel(PoseArgs a, const in
     }
 
     // ---------------- thread-private records: LDS planes for the first k_lds ordinals, the global arena for the rest ----------------
+    unsigned* const sel = reinterpret_cast<unsigned*>(&s_hist[0][0]);  // BlockOps::select2's scratch: zero before its first use
+    int sel_rot = 0;
+    for (int i = tid; i < 2 * Ops::HIST_W; i += BLOCK) sel[i] = 0u;  // (the barriers of the counts below come first)
     const int n_m_p = Ops::template sum_int<true>(__popc(pmatched), s_ired);
     const int n_m_l = Ops::template sum_int<true>(__popc(lmatched), s_ired);
     // (the index of a record is laundered through an empty asm at every use: otherwise the compiler hoists the 64-bit addresses
@@ -371,14 +374,15 @@ __global__ __launch_bounds__(NW * 64, 2) void pose2p_kernel(PoseArgs a, const in
                     rp[k] = pm::point_residual(DT, cam, r.X, r.Y, r.Z, r.ox, r.oy);
                 }
             }
-            sp = pm::clamp_scale(Ops::template mad_sigma<PPT, true>(rp, pinl, sh->n_inl_p, s_hist, &sh->xchg));
             double rlv[LPT];
 #pragma unroll
             for (int k = 0; k < LPT; ++k) {
                 rlv[k] = 0.0;
                 if ((linl >> k) & 1u) rlv[k] = pm::line_residual(DT, cam, load_line(k));
             }
-            sl = pm::clamp_scale(Ops::template mad_sigma<LPT, true>(rlv, linl, sh->n_inl_l, s_hist, &sh->xchg));
+            Ops::template mad_sigma2<PPT, LPT, true>(rp, pinl, sh->n_inl_p, rlv, linl, sh->n_inl_l, sel, sh->xchg, sel_rot, sp, sl);
+            sp = pm::clamp_scale(sp);
+            sl = pm::clamp_scale(sl);
         }
         const double isp = 1.0 / sp, isl = 1.0 / sl;  // reciprocals of the robust scales: one division per evaluation, not per feature
         const long long tw0 = tick();
@@ -477,77 +481,29 @@ __global__ __launch_bounds__(NW * 64, 2) void pose2p_kernel(PoseArgs a, const in
     auto remove_outliers = [&]() {
         double DT[12];
         pose_sgpr(sh->DT1, DT);
-        if (prm.has_points) {
-            double res[PPT];
-            const int tot = sh->n_m_p;
+        double resp[PPT], resl[LPT];
 #pragma unroll
-            for (int k = 0; k < PPT; ++k) {  // ALL matches, current outliers included (:998-1005)
-                res[k] = 0.0;
-                if ((pmatched >> k) & 1u) {
-                    const PointRec2 r = load_point(k);
-                    res[k] = pm::point_residual(DT, cam, r.X, r.Y, r.Z, r.ox, r.oy) * r.q;
-                }
+        for (int k = 0; k < PPT; ++k) {  // ALL matches, current outliers included (:998-1005)
+            resp[k] = 0.0;
+            if (prm.has_points && ((pmatched >> k) & 1u)) {
+                const PointRec2 r = load_point(k);
+                resp[k] = pm::point_residual(DT, cam, r.X, r.Y, r.Z, r.ox, r.oy) * r.q;
             }
-            const double stdv = Ops::template mad_sigma<PPT, true>(res, pmatched, tot, s_hist, &sh->xchg);
-            double v[3] = {0.0, 0.0, 0.0};  // mean of the samples below 2 sigma, or of all samples (src/auxiliar.cpp:405-427)
-#pragma unroll
-            for (int k = 0; k < PPT; ++k)
-                if ((pmatched >> k) & 1u) {
-                    if (res[k] < 2.0 * stdv) {
-                        v[0] += res[k];
-                        v[1] += 1.0;
-                    }
-                    v[2] += res[k];
-                }
-            double t[3];
-            Ops::template sum_small<3, true>(v, s_red, t);
-            double mean = 0.0;
-            if (tot != 0) {
-                const int ksel = (int)t[1];
-                mean = (ksel >= (int)(0.2 * (double)tot)) ? t[0] / (double)ksel : t[2] / (double)tot;
-            }
-            const double th = prm.inlier_k * stdv;
-#pragma unroll
-            for (int k = 0; k < PPT; ++k)
-                if (((pinl >> k) & 1u) && fabs(res[k] - mean) > th) pinl &= ~(1u << k);
-            const int nip = Ops::template sum_int<true>(__popc(pinl), s_ired);
-            if (w0) sh->n_inl_p = nip;
         }
-        if (prm.has_lines) {
-            double res[LPT];
-            const int tot = sh->n_m_l;
 #pragma unroll
-            for (int k = 0; k < LPT; ++k) {
-                res[k] = 0.0;
-                if ((lmatched >> k) & 1u) {
-                    const pm::LineRec L = load_line(k);
-                    res[k] = pm::line_residual(DT, cam, L) * L.sigma2;  // L.sigma2 = sqrt(sigma2)
-                }
+        for (int k = 0; k < LPT; ++k) {
+            resl[k] = 0.0;
+            if (prm.has_lines && ((lmatched >> k) & 1u)) {
+                const pm::LineRec L = load_line(k);
+                resl[k] = pm::line_residual(DT, cam, L) * L.sigma2;  // L.sigma2 = sqrt(sigma2)
             }
-            const double stdv = Ops::template mad_sigma<LPT, true>(res, lmatched, tot, s_hist, &sh->xchg);
-            double v[3] = {0.0, 0.0, 0.0};
-#pragma unroll
-            for (int k = 0; k < LPT; ++k)
-                if ((lmatched >> k) & 1u) {
-                    if (res[k] < 2.0 * stdv) {
-                        v[0] += res[k];
-                        v[1] += 1.0;
-                    }
-                    v[2] += res[k];
-                }
-            double t[3];
-            Ops::template sum_small<3, true>(v, s_red, t);
-            double mean = 0.0;
-            if (tot != 0) {
-                const int ksel = (int)t[1];
-                mean = (ksel >= (int)(0.2 * (double)tot)) ? t[0] / (double)ksel : t[2] / (double)tot;
-            }
-            const double th = prm.inlier_k * stdv;
-#pragma unroll
-            for (int k = 0; k < LPT; ++k)
-                if (((linl >> k) & 1u) && fabs(res[k] - mean) > th) linl &= ~(1u << k);
-            const int nil = Ops::template sum_int<true>(__popc(linl), s_ired);
-            if (w0) sh->n_inl_l = nil;
+        }
+        int cnt[2];
+        Ops::template outlier_cut<PPT, LPT, true>(resp, pmatched, sh->n_m_p, prm.has_points != 0, resl, lmatched, sh->n_m_l, prm.has_lines != 0,
+                                                  prm.inlier_k, pinl, linl, sel, sh->xchg, sel_rot, s_red, cnt);
+        if (w0) {
+            if (prm.has_points) sh->n_inl_p = cnt[0];
+            if (prm.has_lines) sh->n_inl_l = cnt[1];
         }
         __syncthreads();
     };
@@ -653,13 +609,14 @@ __global__ __launch_bounds__(NW * 64, 2) void pose2c_kernel(PoseArgs a_by_value,
     using Ops = BlockOps<NW>;
     extern __shared__ float4 s_ra[];                               // [KL][BLOCK] {u, v, ox, oy}
     double* const s_rb = reinterpret_cast<double*>(s_ra + KL * BLOCK);  // [KL][BLOCK] b / disparity
-    __shared__ int s_hist[2][Ops::HIST_W];
+    __shared__ __align__(16) int s_hist[2][Ops::HIST_W];  // BlockOps::select2
     __shared__ double s_red[NW][28];
     __shared__ int s_ired[NW];
     __shared__ PoseSh s_sh;
     PoseSh* sh = &s_sh;
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const bool w0 = wv == 0, t0 = tid == 0;
+    long long rprof[3] = {0, 0, 0};
     long long tprof[5] = {0, 0, 0, 0, 0};
     long long wprof[3] = {0, 0, 0}, wave_busy = 0;
     auto tick = [&]() -> long long {
@@ -729,6 +686,9 @@ __global__ __launch_bounds__(NW * 64, 2) void pose2c_kernel(PoseArgs a_by_value,
         }
     }
     const int n_mine = __popc(pmatched);
+    unsigned* const sel = reinterpret_cast<unsigned*>(&s_hist[0][0]);  // BlockOps::select2's scratch: zero before its first use
+    int sel_rot = 0;
+    for (int i = tid; i < 2 * Ops::HIST_W; i += BLOCK) sel[i] = 0u;  // (the barriers of the counts below come first)
     const int n_m_p = Ops::template sum_int<true>(n_mine, s_ired);
     const int n_m_l = Ops::template sum_int<true>(__popc(lmatched), s_ired);
 
@@ -907,14 +867,15 @@ __global__ __launch_bounds__(NW * 64, 2) void pose2c_kernel(PoseArgs a_by_value,
             double rp[PPT];
             const unsigned pre = dealt ? inl_w : inl_o;
             residuals(DT, pre, false, rp);
-            sp = pm::clamp_scale(Ops::template mad_sigma<PPT, true>(rp, pre, sh->n_inl_p, s_hist, &sh->xchg));
             double rlv[LPT];
 #pragma unroll
             for (int k = 0; k < LPT; ++k) {
                 rlv[k] = 0.0;
                 if ((linl >> k) & 1u) rlv[k] = pm::line_residual(DT, cam, load_line(k));
             }
-            sl = pm::clamp_scale(Ops::template mad_sigma<LPT, true>(rlv, linl, sh->n_inl_l, s_hist, &sh->xchg));
+            Ops::template mad_sigma2<PPT, LPT, true>(rp, pre, sh->n_inl_p, rlv, linl, sh->n_inl_l, sel, sh->xchg, sel_rot, sp, sl);
+            sp = pm::clamp_scale(sp);
+            sl = pm::clamp_scale(sl);
         }
         const double isp = 1.0 / sp, isl = 1.0 / sl;  // reciprocals of the robust scales: one division per evaluation, not per feature
         const long long tw0 = tick();
@@ -1062,80 +1023,41 @@ __global__ __launch_bounds__(NW * 64, 2) void pose2c_kernel(PoseArgs a_by_value,
         dealt = true;
         const int first = wv * 64;  // the wave's first thread holds the most
         n_trip = first < total ? (total - first + BLOCK - 1) / BLOCK : 0;
-        __syncthreads();  // s_lvb (the selection scratch) is free again
+        __syncthreads();  // every level byte has been read
+        for (int i = tid; i < 2 * Ops::HIST_W; i += BLOCK) sel[i] = 0u;  // the selection scratch as BlockOps::select2 expects it
+        __syncthreads();
     };
 
     // ---------------- removeOutliers at pose DT1 (:988-1067) ----------------
     auto remove_outliers = [&]() {
         double DT[12];
         pose_sgpr(sh->DT1, DT);
-        if (ka().prm.has_points) {
-            double res[PPT];
-            const int tot = sh->n_m_p;
-            residuals(DT, m_o, true, res);  // ALL matches, current outliers included (:998-1005)
-            const double stdv = Ops::template mad_sigma<PPT, true>(res, m_o, tot, s_hist, &sh->xchg);
-            double v[3] = {0.0, 0.0, 0.0};  // mean of the samples below 2 sigma, or of all samples (src/auxiliar.cpp:405-427)
+        const bool do_p = ka().prm.has_points != 0, do_l = ka().prm.has_lines != 0;
+        const long long tr0 = tick();
+        double resp[PPT], resl[LPT];
+        residuals(DT, do_p ? m_o : 0u, true, resp);  // ALL matches, current outliers included (:998-1005)
 #pragma unroll
-            for (int r = 0; r < PPT; ++r)
-                if ((m_o >> r) & 1u) {
-                    if (res[r] < 2.0 * stdv) {
-                        v[0] += res[r];
-                        v[1] += 1.0;
-                    }
-                    v[2] += res[r];
-                }
-            double t[3];
-            Ops::template sum_small<3, true>(v, s_red, t);
-            double mean = 0.0;
-            if (tot != 0) {
-                const int ksel = (int)t[1];
-                mean = (ksel >= (int)(0.2 * (double)tot)) ? t[0] / (double)ksel : t[2] / (double)tot;
+        for (int k = 0; k < LPT; ++k) {
+            resl[k] = 0.0;
+            if (do_l && ((lmatched >> k) & 1u)) {
+                const pm::LineRec L = load_line(k);
+                resl[k] = pm::line_residual(DT, cam, L) * L.sigma2;  // L.sigma2 = sqrt(sigma2)
             }
-            const double th = ka().prm.inlier_k * stdv;
-#pragma unroll
-            for (int r = 0; r < PPT; ++r)
-                if (((inl_o >> r) & 1u) && fabs(res[r] - mean) > th) inl_o &= ~(1u << r);
-            const int nip = Ops::template sum_int<true>(__popc(inl_o), s_ired);
-            if (w0) sh->n_inl_p = nip;
         }
-        if (ka().prm.has_lines) {
-            double res[LPT];
-            const int tot = sh->n_m_l;
-#pragma unroll
-            for (int k = 0; k < LPT; ++k) {
-                res[k] = 0.0;
-                if ((lmatched >> k) & 1u) {
-                    const pm::LineRec L = load_line(k);
-                    res[k] = pm::line_residual(DT, cam, L) * L.sigma2;  // L.sigma2 = sqrt(sigma2)
-                }
-            }
-            const double stdv = Ops::template mad_sigma<LPT, true>(res, lmatched, tot, s_hist, &sh->xchg);
-            double v[3] = {0.0, 0.0, 0.0};
-#pragma unroll
-            for (int k = 0; k < LPT; ++k)
-                if ((lmatched >> k) & 1u) {
-                    if (res[k] < 2.0 * stdv) {
-                        v[0] += res[k];
-                        v[1] += 1.0;
-                    }
-                    v[2] += res[k];
-                }
-            double t[3];
-            Ops::template sum_small<3, true>(v, s_red, t);
-            double mean = 0.0;
-            if (tot != 0) {
-                const int ksel = (int)t[1];
-                mean = (ksel >= (int)(0.2 * (double)tot)) ? t[0] / (double)ksel : t[2] / (double)tot;
-            }
-            const double th = ka().prm.inlier_k * stdv;
-#pragma unroll
-            for (int k = 0; k < LPT; ++k)
-                if (((linl >> k) & 1u) && fabs(res[k] - mean) > th) linl &= ~(1u << k);
-            const int nil = Ops::template sum_int<true>(__popc(linl), s_ired);
-            if (w0) sh->n_inl_l = nil;
+        const long long tr1 = tick();
+        int cnt[2];
+        Ops::template outlier_cut<PPT, LPT, true>(resp, m_o, sh->n_m_p, do_p, resl, lmatched, sh->n_m_l, do_l, ka().prm.inlier_k, inl_o, linl, sel,
+                                                  sh->xchg, sel_rot, s_red, cnt);
+        if (w0) {
+            if (do_p) sh->n_inl_p = cnt[0];
+            if (do_l) sh->n_inl_l = cnt[1];
         }
         __syncthreads();
+        const long long tr2 = tick();
         compact_inliers();
+        rprof[0] += tr1 - tr0;
+        rprof[1] += tr2 - tr1;
+        rprof[2] += tick() - tr2;
     };
 
     const PoseFlow fl = optimize_pose_flow(sh, [&]() -> const stvo_opt_params __attribute__((address_space(4)))& { return ka().prm; }, w0, evaluate,
@@ -1153,6 +1075,8 @@ __global__ __launch_bounds__(NW * 64, 2) void pose2c_kernel(PoseArgs a_by_value,
 #pragma unroll
         for (int i = 0; i < 3; ++i) ka().prof_out[(size_t)f * 16 + 5 + i] = wprof[i];
         ka().prof_out[(size_t)f * 16 + 14] = t_prologue;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) ka().prof_out[(size_t)f * 16 + 10 + i] = rprof[i];  // removeOutliers: residuals, statistics, re-deal
     }
     if (PROF && lane == 0 && (wv < 6 || wv == NW - 1)) ka().prof_out[(size_t)f * 16 + 8 + (wv < 6 ? wv : 7)] = wave_busy;
 

@@ -1402,8 +1402,8 @@ int stvo_seq_read(stvo_seq* s, stvo_pose_result* results, int32_t* counts) {
         for (int f = 0; f < B; ++f)
             for (int i = 0; i < 16; ++i) m[i] += (double)h[(size_t)f * 16 + i] / B;
         std::fprintf(stderr, "[pose prof] mean ticks/pair: evaluate %.0f  iter-algebra %.0f  cov+isgood+commit %.0f  remove_outliers %.0f  total %.0f | "
-                             "eval-compute %.0f  fold %.0f  barrier+sum %.0f | prologue %.0f | wave busy %.0f %.0f\n",
-                     m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7], m[14], m[8], m[9]);
+                             "eval-compute %.0f  fold %.0f  barrier+sum %.0f | prologue %.0f | wave busy %.0f %.0f | removeOutliers: residuals %.0f  statistics %.0f  re-deal %.0f\n",
+                     m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7], m[14], m[8], m[9], m[10], m[11], m[12]);
     }
     const bool track = s->frame_idx > 1;
     char* OH = s->out_host;
