@@ -284,6 +284,45 @@ class Oracle:
                                  npx if n else np.zeros(1, np.int32), desc.reshape(-1), df.ctypes.data_as(C.c_void_p))
         return (desc[:n], df[:n]) if want_float else desc[:n]
 
+    # ---- LSD line detector (oracle/stvo_lsd_oracle.c) ----
+    class LsdOpts(C.Structure):
+        _fields_ = [("refine", C.c_int), ("scale", C.c_double), ("sigma_scale", C.c_double), ("quant", C.c_double), ("ang_th", C.c_double),
+                    ("log_eps", C.c_double), ("density_th", C.c_double), ("n_bins", C.c_int), ("min_length", C.c_double), ("nfeatures", C.c_int)]
+
+    KEYLINE_DT = np.dtype([("sx", np.float32), ("sy", np.float32), ("ex", np.float32), ("ey", np.float32), ("length", np.float32),
+                           ("response", np.float32), ("angle", np.float32), ("num_pixels", np.int32)])
+
+    def lsd_opts(self, min_length=0.0, nfeatures=0, refine=0, scale=1.2, sigma_scale=0.6, quant=2.0, ang_th=22.5, n_bins=1024):
+        return self.LsdOpts(refine, scale, sigma_scale, quant, ang_th, 1.0, 0.6, n_bins, min_length, nfeatures)  # src/config.cpp:104-112
+
+    def lsd_segments(self, img, opts, cap=65536):
+        """cv::LineSegmentDetector::detect restated: [n, 4] float32 (x1, y1, x2, y2) in detection order."""
+        self.lib.orc_lsd_segments.argtypes = [u8p, C.c_int, C.c_int, C.POINTER(self.LsdOpts), f32p, C.c_int]
+        self.lib.orc_lsd_segments.restype = C.c_int
+        img = np.ascontiguousarray(img, np.uint8)
+        seg = np.zeros((cap, 4), np.float32)
+        n = self.lib.orc_lsd_segments(img.reshape(-1), img.shape[1], img.shape[0], C.byref(opts), seg.reshape(-1), cap)
+        if n < 0:
+            raise RuntimeError(f"orc_lsd_segments: {n}")
+        return seg[:min(n, cap)].copy()
+
+    def lsd_detect(self, img, opts, cap=4096):
+        """LSDDetectorC::detect + the top-N cut of detectLineFeatures: structured array (KEYLINE_DT)."""
+        self.lib.orc_lsd_detect.argtypes = [u8p, C.c_int, C.c_int, C.POINTER(self.LsdOpts), C.c_void_p, C.c_int]
+        self.lib.orc_lsd_detect.restype = C.c_int
+        img = np.ascontiguousarray(img, np.uint8)
+        out = np.zeros(cap, self.KEYLINE_DT)
+        n = self.lib.orc_lsd_detect(img.reshape(-1), img.shape[1], img.shape[0], C.byref(opts), out.ctypes.data_as(C.c_void_p), cap)
+        if n < 0:
+            raise RuntimeError(f"orc_lsd_detect: {n}")
+        return out[:n].copy()
+
+    def sincos_det(self, x):
+        self.lib.orc_sincos_det.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]; self.lib.orc_sincos_det.restype = None
+        s, c = C.c_double(), C.c_double()
+        self.lib.orc_sincos_det(float(x), C.byref(s), C.byref(c))
+        return s.value, c.value
+
     def gaussian_blur5(self, img):
         self.lib.orc_gaussian_blur5.argtypes = [u8p, C.c_int, C.c_int, u8p]; self.lib.orc_gaussian_blur5.restype = None
         img = np.ascontiguousarray(img, np.uint8)
