@@ -273,6 +273,42 @@ int stvo_lbd_compute(stvo_lbd* lbd, const uint8_t* images, const stvo_keyline* l
 int stvo_lbd_compute_dev(stvo_lbd* lbd, const uint8_t* images, const stvo_keyline* lines, const int32_t* n_lines, uint8_t* desc,
                          float* desc_float);
 
+/* ---- LSD line detector (second half) -------------------------------------------------------- */
+
+/* Replaces  lsd->detect(img, lines, Config::lsdScale(), 1, opts)  + the top-N cut by response of StereoFrame::detectLineFeatures
+ * (src/stereoFrame.cpp:219-240; LSDDetectorC::detectImpl, 3rdparty/line_descriptor/src/LSDDetector_custom.cpp:227-325, one
+ * octave) for B images of cols x rows bytes: cv::LineSegmentDetector — third-party code the reference does not hold — as restated
+ * in oracle/stvo_lsd_oracle.c from the published algorithm (parity unpinned), lsd_refine = 0 only (what every shipped
+ * configuration uses; other values: STVO_ERR_UNSUPPORTED), images up to 2^20 pixels after scaling.  Blur, resize, gradient /
+ * level-line angles and the pseudo-ordering are data-parallel kernels; region growing is inherently sequential per image (a
+ * pixel joins a region depending on the running region angle and on what every earlier region took) and runs as ONE wavefront
+ * per image, the images of the batch side by side. */
+typedef struct stvo_lsd_params {
+    int32_t refine;        /* Config::lsdRefine()      0 */
+    int32_t n_bins;        /* Config::lsdNBins()       1024 */
+    double scale;          /* Config::lsdScale()       1.2 */
+    double sigma_scale;    /* Config::lsdSigmaScale()  0.6 */
+    double quant;          /* Config::lsdQuant()       2.0 */
+    double ang_th;         /* Config::lsdAngTh()       22.5 */
+    double log_eps;        /* Config::lsdLogEps()      (unused with refine 0) */
+    double density_th;     /* Config::lsdDensityTh()   (unused with refine 0) */
+    double min_length;     /* LSDOptions::min_length = min_line_length x min(cols, rows) (stereoFrame.cpp:78) */
+    int32_t nfeatures;     /* Config::lsdNFeatures()   300, 0: keep all */
+    int32_t reserved;
+} stvo_lsd_params;
+typedef struct stvo_lsd stvo_lsd;
+int stvo_lsd_create(stvo_ctx* ctx, int B, int cols, int rows, int max_keylines, const stvo_lsd_params* prm, stvo_lsd** out);
+int stvo_lsd_destroy(stvo_lsd* lsd);
+/* Host buffers in / out, synchronises.  images [B][rows][cols]; lines [B][max_keylines] (what stvo_lbd_compute consumes: in-octave
+ * end points, angle, LineIterator count), response (may be NULL) [B][max_keylines] = KeyLine::response, n_lines [B]; lines come
+ * in detection order, or by descending response when the top-N cut applied. */
+int stvo_lsd_detect(stvo_lsd* lsd, const uint8_t* images, stvo_keyline* lines, float* response, int32_t* n_lines);
+/* The same with DEVICE pointers, enqueued on the context's stream (no synchronisation). */
+int stvo_lsd_detect_dev(stvo_lsd* lsd, const uint8_t* images, stvo_keyline* lines, float* response, int32_t* n_lines);
+/* test hook: the raw segments of the detector core (cv::LineSegmentDetector::detect), host buffers, synchronises:
+ * segments [B][cap][4], n_segments [B] (all found; at most cap stored) */
+int stvo_lsd_segments(stvo_lsd* lsd, const uint8_t* images, float* segments, int cap, int32_t* n_segments);
+
 /* ---- measurement helpers --------------------------------------------------------------------- */
 /* Times `iters` launches of the named kernel stage on the context's stream with hipEvents and
  * returns the average milliseconds per launch (used by bench.py for the roofline line).

@@ -191,6 +191,10 @@ typedef struct {
     double x1, y1, x2, y2, width;
 } lsd_rect;
 
+/* developer aid (tools/lsd_probe.py): when set, 8 doubles per segment — cx, cy, Ixx, Iyy, Ixy, theta, l_min, l_max */
+double* orc_lsd_debug_out = NULL;
+void orc_lsd_set_debug(double* p) { orc_lsd_debug_out = p; }
+
 static int is_aligned(const double* angles, int w, int h, int x, int y, double theta, double prec) {
     if (x < 0 || y < 0 || x >= w || y >= h) return 0;
     const double a = angles[(size_t)y * w + x];
@@ -353,6 +357,10 @@ int orc_lsd_segments(const uint8_t* img, int cols, int rows, const orc_lsd_opts*
         rec.x1 += 0.5; rec.y1 += 0.5; rec.x2 += 0.5; rec.y2 += 0.5;
         if (o->scale != 1) {
             rec.x1 /= o->scale; rec.y1 /= o->scale; rec.x2 /= o->scale; rec.y2 /= o->scale;
+        }
+        if (orc_lsd_debug_out && n_seg < cap) {
+            double* q = orc_lsd_debug_out + 8 * (size_t)n_seg;
+            q[0] = x; q[1] = y; q[2] = Ixx; q[3] = Iyy; q[4] = Ixy; q[5] = theta; q[6] = l_min; q[7] = l_max;
         }
         if (n_seg < cap) {
             seg[4 * n_seg + 0] = (float)rec.x1;

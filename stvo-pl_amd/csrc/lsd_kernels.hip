@@ -1,0 +1,608 @@
+// lsd_kernels.hip — the LSD key-line detector on gfx950: what the reference obtains from
+//     lsd->detect(img, lines, Config::lsdScale(), 1, opts)  + the top-N cut by response   (/root/reference/src/stereoFrame.cpp:219-240)
+// through LSDDetectorC::detectImpl (3rdparty/line_descriptor/src/LSDDetector_custom.cpp:227-325) and cv::LineSegmentDetector.
+// The detector core is third-party code that is not under /root/reference: the semantics are those of oracle/stvo_lsd_oracle.c
+// (restated from the published algorithm, parity unpinned), against which these kernels are bit-exact (tests/test_gpu_lsd.py).
+//
+//   blur + resize        the scaled image (cv::GaussianBlur 7 x 7 + cv::resize on 8-bit data): orb_kernels.hip's kernels
+//   lsd_gradient_kernel  ll_angle: 2 x 2 gradient, norm, level-line angle (fastAtan2, degrees), the float cos / sin a pixel
+//                        contributes to a region angle, the largest squared gradient of the image (integer atomic max)
+//   lsd_keys_kernel      pseudo-ordering as a sort key: (highest bin first) << 20 | pixel index; undefined pixels last
+//   hipcub segmented radix sort (rocPRIM): keys per image — the index in the key makes the order total, so the sort is
+//                        deterministic and pixels of a bin keep row-major order (oracle note (1))
+//   lsd_grow_kernel      the search: region_grow + region2rect for every unused seed in that order.  Inherently sequential
+//                        per image — whether a pixel joins depends on the running region angle, which changes with every pixel
+//                        added, and on what all earlier regions took — so ONE wavefront walks an image and the batch supplies
+//                        the parallelism.  Inside the wave the work of one step is spread over the lanes: the 9 neighbours of
+//                        7 consecutive region points are fetched by 63 lanes at once (one memory round trip per 7 points) and
+//                        then resolved in order with ballots; the sums of region2rect are accumulated strictly in region
+//                        order (lane-parallel products, serial additions through v_readlane), so every rounding is the oracle's
+//   lsd_keylines_kernel  the wrapper: checkLineExtremes, length, min_length, KeyLine fields, top-N by response (stable)
+// Byte / integer work except where the source computes in floating point; no fused multiply-adds outside the two of the sine /
+// cosine reduction, which the oracle has too.
+#include <hipcub/hipcub.hpp>
+
+#include <cmath>
+#include <new>
+#include <vector>
+
+#include "ctx_internal.h"
+#include "fast_atan2.h"
+
+#pragma clang fp contract(off)
+
+namespace stvo {
+namespace {
+
+constexpr double LSD_PI = 3.14159265358979323846;
+constexpr double LSD_DEG2RAD = LSD_PI / 180;
+constexpr double LSD_3_2_PI = (3 * LSD_PI) / 2;
+constexpr double LSD_2_PI = 2 * LSD_PI;
+constexpr uint32_t LSD_NOKEY = 0xFFFFFFFFu;
+constexpr int LSD_IDX_BITS = 20;  // pixel index inside a sort key: scaled images up to 2^20 pixels
+
+// orc_sincos_det (oracle/stvo_lsd_oracle.c), operation for operation
+__device__ __forceinline__ void sincos_det(double x, double& s, double& c) {
+    const double PIO2_HI = 1.57079632679489655800e+00, PIO2_LO = 6.12323399573676603587e-17, TWO_OVER_PI = 6.36619772367581382433e-01;
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double k = __builtin_rint(x * TWO_OVER_PI);
+    double r = __builtin_fma(-k, PIO2_HI, x);
+    r = __builtin_fma(-k, PIO2_LO, r);
+    const double z = r * r;
+    const double ps = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+    const double sn = r + (z * r) * (S1 + z * ps);
+    const double pc = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+    const double cs = 1.0 - (0.5 * z - z * pc);
+    const int q = (int)((long long)k & 3);
+    s = q == 0 ? sn : (q == 1 ? cs : (q == 2 ? -sn : -cs));
+    c = q == 0 ? cs : (q == 1 ? -sn : (q == 2 ? -cs : sn));
+}
+
+struct LsdDev {
+    int B, w, h;               // the scaled image
+    int cols, rows;            // the input image
+    int n_bins, min_reg_size, seg_cap, K, nfeatures;
+    double rho, prec, scale, min_length;
+    const uint8_t* scaled;     // [B][h][w]
+    float* ang;                // [B][w h] level-line angle in degrees, < 0: undefined
+    float2* csn;               // [B][w h] (cos, sin) of float(angle) as floats
+    double* mod;               // [B][w h] gradient norm
+    int32_t* used;             // [B][w h]
+    uint32_t* keys;            // [B][w h]
+    uint32_t* order;           // [B][w h] sorted keys
+    int32_t* reg;              // [B][w h] the region being grown: x | y << 16
+    int32_t* kmax;             // [B] largest gx^2 + gy^2 among the defined pixels, -1: none
+    float4* seg;               // [B][seg_cap] (x1, y1, x2, y2) in detection order
+    int32_t* n_seg;            // [B]
+    double* dbg;               // developer aid (stvo_lsd_debug): [B][seg_cap][8] cx, cy, Ixx, Iyy, Ixy, theta, l_min, l_max, or nullptr
+    // outputs of the wrapper
+    stvo_keyline* lines;       // [B][K]
+    float* response;           // [B][K] or nullptr
+    int32_t* n_lines;          // [B]
+};
+
+// ll_angle: one thread per pixel of the scaled image
+__global__ __launch_bounds__(256) void lsd_gradient_kernel(LsdDev d) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+    if (x >= d.w) return;
+    const size_t base = (size_t)b * d.w * d.h, q = base + (size_t)y * d.w + x;
+    float ang = -1.f;
+    float2 cs = make_float2(0.f, 0.f);
+    double norm = 0.0;
+    if (x < d.w - 1 && y < d.h - 1) {
+        const uint8_t* r0 = d.scaled + base + (size_t)y * d.w + x;
+        const uint8_t* r1 = r0 + d.w;
+        const int DA = (int)r1[1] - (int)r0[0], BC = (int)r0[1] - (int)r1[0];
+        const int gx = DA + BC, gy = DA - BC;
+        const int k = gx * gx + gy * gy;
+        norm = sqrt((double)k / 4.0);
+        if (!(norm <= d.rho)) {
+            ang = fast_atan2_deg((float)gx, (float)-gy);
+            const double a = (double)ang * LSD_DEG2RAD;
+            double s, c;
+            sincos_det((double)(float)a, s, c);
+            cs = make_float2((float)c, (float)s);
+            atomicMax(&d.kmax[b], k);
+        }
+    }
+    d.ang[q] = ang;
+    d.csn[q] = cs;
+    d.mod[q] = norm;
+    d.used[q] = 0;
+}
+
+__global__ __launch_bounds__(256) void lsd_keys_kernel(LsdDev d) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+    if (x >= d.w) return;
+    const size_t base = (size_t)b * d.w * d.h;
+    const uint32_t idx = (uint32_t)(y * d.w + x);
+    const int km = d.kmax[b];
+    const double max_grad = km >= 0 ? sqrt((double)km / 4.0) : -1.0;
+    const double bin_coef = max_grad > 0 ? (double)(d.n_bins - 1) / max_grad : 0.0;
+    uint32_t key = LSD_NOKEY;
+    if (d.ang[base + idx] >= 0.f) {  // undefined pixels never seed a region: they sort to the end
+        int bin = (int)(d.mod[base + idx] * bin_coef);
+        bin = bin < 0 ? 0 : (bin >= d.n_bins ? d.n_bins - 1 : bin);
+        key = ((uint32_t)(d.n_bins - 1 - bin) << LSD_IDX_BITS) | idx;
+    }
+    d.keys[base + idx] = key;
+}
+
+constexpr int LSD_RING = 4096;  // the most recent region points, in LDS
+
+// coherent accesses to the flags / the region list the wave itself writes (lane 0 stores, all lanes load later): past the L1
+__device__ __forceinline__ int ld_coherent(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_coherent(int32_t* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ float readlane_f32(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+// stores of this wave have reached the L2 / later loads of this wave come from the L2
+__device__ __forceinline__ void wave_publish() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+__global__ __launch_bounds__(64) void lsd_grow_kernel(LsdDev d) {
+    __shared__ int s_ring[LSD_RING];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int w = d.w, h = d.h, npx = w * h;
+    const size_t base = (size_t)b * npx;
+    const float* __restrict__ ang = d.ang + base;
+    const float2* __restrict__ csn = d.csn + base;
+    const double* __restrict__ mod = d.mod + base;
+    int32_t* used = d.used + base;
+    const uint32_t* __restrict__ order = d.order + base;
+    int32_t* reg = d.reg + base;
+    const double prec = d.prec;
+    int n_seg = 0;
+    for (int o0 = 0; o0 < npx; o0 += 64) {
+        const uint32_t key = o0 + lane < npx ? order[o0 + lane] : LSD_NOKEY;
+        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)key) == LSD_NOKEY) break;  // sorted: only undefined pixels from here on
+        const int q_l = (int)(key & ((1u << LSD_IDX_BITS) - 1u));
+        const bool key_ok = key != LSD_NOKEY;
+        unsigned long long todo = __ballot(key_ok && ld_coherent(used + (key_ok ? q_l : 0)) == 0);
+        bool dirty = false;  // a region was grown since the flags of this batch were read
+        while (todo) {
+            if (dirty) {
+                wave_publish();
+                todo &= __ballot(key_ok && ld_coherent(used + (key_ok ? q_l : 0)) == 0);
+                dirty = false;
+                if (!todo) break;
+            }
+            const int j = __builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            const int seed = __builtin_amdgcn_readlane(q_l, j);
+            // ---------------- region_grow ----------------
+            const int sx0 = seed % w, sy0 = seed / w;
+            double reg_angle = (double)ang[seed] * LSD_DEG2RAD;
+            double sn0, cs0;
+            sincos_det(reg_angle, sn0, cs0);
+            float sumdx = (float)cs0, sumdy = (float)sn0;
+            int n_reg = 1;
+            if (lane == 0) {
+                st_coherent(used + seed, 1);
+                st_coherent(reg, sx0 | (sy0 << 16));
+                s_ring[0] = sx0 | (sy0 << 16);
+            }
+            for (int i = 0; i < n_reg;) {
+                wave_publish();  // the flags and the list as the earlier groups left them
+                const int cnt = n_reg - i < 7 ? n_reg - i : 7;  // uniform
+                const int slot = lane / 9, nb = lane - slot * 9;
+                bool valid = slot < cnt;
+                int pxy = 0;
+                if (valid) pxy = (n_reg - (i + slot) <= LSD_RING) ? s_ring[(i + slot) & (LSD_RING - 1)] : ld_coherent(reg + i + slot);
+                const int xx = (pxy & 0xFFFF) + (nb % 3) - 1, yy = (pxy >> 16) + nb / 3 - 1;  // neighbours row by row
+                valid = valid && xx >= 0 && xx < w && yy >= 0 && yy < h;
+                const int qq = valid ? yy * w + xx : 0;
+                int u = 1;
+                float a = -1.f;
+                float2 cs = make_float2(0.f, 0.f);
+                if (valid) {
+                    u = ld_coherent(used + qq);
+                    a = ang[qq];
+                    cs = csn[qq];
+                }
+                bool cand = valid && u == 0 && a >= 0.f;
+                const double ad = (double)a * LSD_DEG2RAD;
+                int next = 0;  // lanes below `next` have had their turn
+                for (;;) {
+                    double n_theta = reg_angle - ad;  // isAligned
+                    if (n_theta < 0) n_theta = -n_theta;
+                    if (n_theta > LSD_3_2_PI) {
+                        n_theta -= LSD_2_PI;
+                        if (n_theta < 0) n_theta = -n_theta;
+                    }
+                    const unsigned long long m = __ballot(cand && lane >= next && n_theta <= prec);
+                    if (!m || n_reg >= npx) break;  // (the bound can only bind if a flag were lost: never write past the list)
+                    const int L = __builtin_ctzll(m);
+                    const int qL = __builtin_amdgcn_readlane(qq, L), xyL = __builtin_amdgcn_readlane(xx | (yy << 16), L);
+                    const float cL = readlane_f32(cs.x, L), sL = readlane_f32(cs.y, L);
+                    if (lane == 0) {
+                        st_coherent(used + qL, 1);
+                        st_coherent(reg + n_reg, xyL);
+                        s_ring[n_reg & (LSD_RING - 1)] = xyL;
+                    }
+                    ++n_reg;
+                    cand = cand && qq != qL;  // the same pixel seen from another region point of the group
+                    sumdx += cL;
+                    sumdy += sL;
+                    reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * LSD_DEG2RAD;
+                    next = L + 1;
+                }
+                i += cnt;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // s_ring: lane 0's writes before the next group's reads
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+            dirty = true;
+            if (n_reg < d.min_reg_size) continue;
+            // ---------------- region2rect ----------------
+            wave_publish();
+            double X = 0.0, Y = 0.0, S = 0.0;
+            for (int c0 = 0; c0 < n_reg; c0 += 64) {
+                const int t = c0 + lane, cn = n_reg - c0 < 64 ? n_reg - c0 : 64;
+                int pxy = 0;
+                double wgt = 0.0;
+                if (t < n_reg) {
+                    pxy = ld_coherent(reg + t);
+                    wgt = mod[(pxy >> 16) * w + (pxy & 0xFFFF)];
+                }
+                const double px = (double)(pxy & 0xFFFF) * wgt, py = (double)(pxy >> 16) * wgt;
+                for (int k = 0; k < cn; ++k) {  // strictly in region order: every addition rounds as the oracle's
+                    X += readlane_f64(px, k);
+                    Y += readlane_f64(py, k);
+                    S += readlane_f64(wgt, k);
+                }
+            }
+            const double cx = X / S, cy = Y / S;
+            double Ixx = 0.0, Iyy = 0.0, Ixy = 0.0;
+            for (int c0 = 0; c0 < n_reg; c0 += 64) {
+                const int t = c0 + lane, cn = n_reg - c0 < 64 ? n_reg - c0 : 64;
+                double t_xx = 0.0, t_yy = 0.0, t_xy = 0.0;
+                if (t < n_reg) {
+                    const int pxy = ld_coherent(reg + t);
+                    const double wgt = mod[(pxy >> 16) * w + (pxy & 0xFFFF)];
+                    const double ddx = (double)(pxy & 0xFFFF) - cx, ddy = (double)(pxy >> 16) - cy;
+                    t_xx = ddy * ddy * wgt;
+                    t_yy = ddx * ddx * wgt;
+                    t_xy = ddx * ddy * wgt;
+                }
+                for (int k = 0; k < cn; ++k) {
+                    Ixx += readlane_f64(t_xx, k);
+                    Iyy += readlane_f64(t_yy, k);
+                    Ixy -= readlane_f64(t_xy, k);
+                }
+            }
+            const double lambda = 0.5 * (Ixx + Iyy - sqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
+            double theta = (fabs(Ixx) > fabs(Iyy)) ? (double)fast_atan2_deg((float)(lambda - Ixx), (float)Ixy)
+                                                   : (double)fast_atan2_deg((float)Ixy, (float)(lambda - Iyy));
+            theta *= LSD_DEG2RAD;
+            {
+                double diff = theta - reg_angle;  // angle_diff
+                while (diff <= -LSD_PI) diff += LSD_2_PI;
+                while (diff > LSD_PI) diff -= LSD_2_PI;
+                if (fabs(diff) > prec) theta += LSD_PI;
+            }
+            double dx, dy;
+            sincos_det(theta, dy, dx);
+            double l_min = 0.0, l_max = 0.0;  // (the width of the rectangle is not part of the segment)
+            for (int t = lane; t < n_reg; t += 64) {
+                const int pxy = ld_coherent(reg + t);
+                const double rdx = (double)(pxy & 0xFFFF) - cx, rdy = (double)(pxy >> 16) - cy;
+                const double l = rdx * dx + rdy * dy;
+                l_max = l > l_max ? l : l_max;
+                l_min = l < l_min ? l : l_min;
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {  // maxima / minima: any order
+                const double om = __shfl_xor(l_max, off, 64), on = __shfl_xor(l_min, off, 64);
+                l_max = om > l_max ? om : l_max;
+                l_min = on < l_min ? on : l_min;
+            }
+            double x1 = cx + l_min * dx, y1 = cy + l_min * dy, x2 = cx + l_max * dx, y2 = cy + l_max * dy;
+            x1 += 0.5; y1 += 0.5; x2 += 0.5; y2 += 0.5;
+            if (d.scale != 1) {
+                x1 /= d.scale; y1 /= d.scale; x2 /= d.scale; y2 /= d.scale;
+            }
+            if (lane == 0 && n_seg < d.seg_cap) d.seg[(size_t)b * d.seg_cap + n_seg] = make_float4((float)x1, (float)y1, (float)x2, (float)y2);
+            if (d.dbg && lane == 0 && n_seg < d.seg_cap) {
+                double* q = d.dbg + ((size_t)b * d.seg_cap + n_seg) * 8;
+                q[0] = cx; q[1] = cy; q[2] = Ixx; q[3] = Iyy; q[4] = Ixy; q[5] = theta; q[6] = l_min; q[7] = l_max;
+            }
+            ++n_seg;
+        }
+    }
+    if (lane == 0) d.n_seg[b] = n_seg;
+}
+
+// LSDDetectorC::detectImpl's loop over the segments of the (single) octave (:254-303) and the cut of stereoFrame.cpp:231-240
+constexpr int KL_T = 256;
+__global__ __launch_bounds__(KL_T) void lsd_keylines_kernel(LsdDev d) {
+    extern __shared__ float s_resp[];  // [seg_cap] responses of the kept lines, detection order
+    __shared__ int s_wave[KL_T / 64];
+    __shared__ int s_run;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n = min(d.n_seg[b], d.seg_cap);
+    const float4* seg = d.seg + (size_t)b * d.seg_cap;
+    int* s_src = reinterpret_cast<int*>(s_resp + d.seg_cap);  // [seg_cap] segment of kept line k
+    if (tid == 0) s_run = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < n; c0 += KL_T) {  // the lines that pass min_length, in detection order
+        const int k = c0 + tid;
+        bool keep = false;
+        float len = 0.f;
+        if (k < n) {
+            float4 e = seg[k];
+            if (e.x < 0) e.x = 0;  // checkLineExtremes
+            if (e.x >= d.cols) e.x = (float)d.cols - 1.0f;
+            if (e.z < 0) e.z = 0;
+            if (e.z >= d.cols) e.z = (float)d.cols - 1.0f;
+            if (e.y < 0) e.y = 0;
+            if (e.y >= d.rows) e.y = (float)d.rows - 1.0f;
+            if (e.w < 0) e.w = 0;
+            if (e.w >= d.rows) e.w = (float)d.rows - 1.0f;
+            const double d0 = (double)(e.x - e.z), d1 = (double)(e.y - e.w);
+            const double length = (double)(float)sqrt(d0 * d0 + d1 * d1);
+            keep = length > d.min_length;
+            len = (float)length;
+        }
+        const unsigned long long bal = __ballot(keep);
+        if (lane == 0) s_wave[wv] = __popcll(bal);
+        __syncthreads();
+        int pos = s_run + __popcll(bal & ((1ull << lane) - 1ull));
+        for (int v = 0; v < wv; ++v) pos += s_wave[v];
+        if (keep) {
+            s_resp[pos] = __fdiv_rn(len, (float)(d.cols > d.rows ? d.cols : d.rows));
+            s_src[pos] = k;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int q = 0;
+            for (int v = 0; v < KL_T / 64; ++v) q += s_wave[v];
+            s_run += q;
+        }
+        __syncthreads();
+    }
+    const int m = s_run;
+    const bool cut = d.nfeatures != 0 && m > d.nfeatures;
+    const int n_out = min(cut ? d.nfeatures : m, d.K);
+    for (int i = tid; i < m; i += KL_T) {
+        int rank = i;
+        if (cut) {  // position in the stable descending order of the responses
+            const float r = s_resp[i];
+            rank = 0;
+            for (int j = 0; j < m; ++j) {
+                const float q = s_resp[j];
+                rank += (q > r || (q == r && j < i)) ? 1 : 0;
+            }
+        }
+        if (rank >= n_out) continue;
+        float4 e = seg[s_src[i]];
+        if (e.x < 0) e.x = 0;
+        if (e.x >= d.cols) e.x = (float)d.cols - 1.0f;
+        if (e.z < 0) e.z = 0;
+        if (e.z >= d.cols) e.z = (float)d.cols - 1.0f;
+        if (e.y < 0) e.y = 0;
+        if (e.y >= d.rows) e.y = (float)d.rows - 1.0f;
+        if (e.w < 0) e.w = 0;
+        if (e.w >= d.rows) e.w = (float)d.rows - 1.0f;
+        stvo_keyline kl;
+        kl.sx = e.x; kl.sy = e.y; kl.ex = e.z; kl.ey = e.w;
+        kl.angle = (float)atan2((double)(e.w - e.y), (double)(e.z - e.x));
+        // cv::LineIterator count: end points rounded to pixels (inside the image after checkLineExtremes), 8-connected raster
+        const int ix0 = __float2int_rn(e.x), iy0 = __float2int_rn(e.y), ix1 = __float2int_rn(e.z), iy1 = __float2int_rn(e.w);
+        const int adx = abs(ix1 - ix0), ady = abs(iy1 - iy0);
+        kl.num_pixels = (adx > ady ? adx : ady) + 1;
+        d.lines[(size_t)b * d.K + rank] = kl;
+        if (d.response) d.response[(size_t)b * d.K + rank] = s_resp[i];
+    }
+    if (tid == 0) d.n_lines[b] = n_out;
+}
+
+}  // namespace
+}  // namespace stvo
+
+struct stvo_lsd {
+    stvo_ctx* ctx = nullptr;
+    stvo::LsdDev d{};
+    stvo_lsd_params prm{};
+    int k7[7] = {0, 0, 0, 0, 0, 0, 0};
+    char* dev = nullptr;
+    uint8_t *img = nullptr, *blur = nullptr, *scaled = nullptr;
+    int32_t* seg_off = nullptr;   // [B + 1] segment offsets of the sort
+    void* sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0;
+    stvo_keyline* lines = nullptr;  // device buffers of the host-pointer entry points
+    float* response = nullptr;
+    int32_t* n_lines = nullptr;
+    double* dbg = nullptr;
+};
+
+namespace {
+
+int lsd_enqueue(stvo_lsd* o, const uint8_t* images, stvo_keyline* lines, float* response, int32_t* n_lines) {
+    stvo_ctx* ctx = o->ctx;
+    hipStream_t s = ctx->stream;
+    stvo::LsdDev d = o->d;
+    const uint8_t* src = images;
+    if (d.scale != 1) {
+        stvo::launch_blur7_u8(s, d.B, d.cols, d.rows, images, o->blur, o->k7);
+        stvo::launch_resize_linear_u8(s, d.B, d.cols, d.rows, d.w, d.h, o->blur, o->scaled);
+        src = o->scaled;
+    }
+    d.scaled = src;
+    d.lines = lines; d.response = response; d.n_lines = n_lines;
+    HIP_TRY(ctx, hipMemsetAsync(d.kmax, 0xFF, (size_t)d.B * 4, s));
+    const dim3 grid((d.w + 255) / 256, d.h, d.B);
+    hipLaunchKernelGGL(stvo::lsd_gradient_kernel, grid, dim3(256), 0, s, d);
+    hipLaunchKernelGGL(stvo::lsd_keys_kernel, grid, dim3(256), 0, s, d);
+    size_t tb = o->sort_tmp_bytes;
+    HIP_TRY(ctx, hipcub::DeviceSegmentedRadixSort::SortKeys(o->sort_tmp, tb, d.keys, d.order, d.B * d.w * d.h, d.B, o->seg_off, o->seg_off + 1, 0, 32, s));
+    hipLaunchKernelGGL(stvo::lsd_grow_kernel, dim3(d.B), dim3(64), 0, s, d);
+    const size_t lds = (size_t)d.seg_cap * 8;
+    hipLaunchKernelGGL(stvo::lsd_keylines_kernel, dim3(d.B), dim3(stvo::KL_T), lds, s, d);
+    return check_launch(ctx);
+}
+
+}  // namespace
+
+extern "C" {
+
+int stvo_lsd_create(stvo_ctx* ctx, int B, int cols, int rows, int max_keylines, const stvo_lsd_params* prm, stvo_lsd** out) {
+    if (!ctx || !prm || !out || B < 1 || cols < 8 || rows < 8 || max_keylines < 1) return STVO_ERR_INVALID_ARG;
+    if (prm->refine != 0) return STVO_ERR_UNSUPPORTED;  // the refinement / NFA branches are not built (no shipped configuration uses them)
+    if (!(prm->scale > 0) || !(prm->ang_th > 0 && prm->ang_th < 180) || prm->n_bins < 1 || prm->n_bins > 4096 || prm->nfeatures < 0)
+        return STVO_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    stvo_lsd* o = new (std::nothrow) stvo_lsd();
+    if (!o) return STVO_ERR_HIP;
+    o->ctx = ctx;
+    o->prm = *prm;
+    stvo::LsdDev& d = o->d;
+    d.B = B; d.cols = cols; d.rows = rows; d.w = cols; d.h = rows;
+    d.scale = prm->scale;
+    if (prm->scale != 1) {
+        const double sigma = prm->scale < 1 ? prm->sigma_scale / prm->scale : prm->sigma_scale;
+        const unsigned hk = (unsigned)std::ceil(sigma * std::sqrt(2 * 3.0 * std::log(10.0)));
+        if (hk != 3) {  // only the 7 x 7 blur is built (sigma between 0.54 and 0.80: scale 1.2 / sigma_scale 0.6 and OpenCV's own 0.8 / 0.6)
+            delete o;
+            return STVO_ERR_UNSUPPORTED;
+        }
+        double k[7], sum = 0.0;  // orc_lsd_kernel7
+        for (int i = 0; i < 7; ++i) {
+            const double x = i - 3;
+            k[i] = std::exp(-x * x / (2.0 * sigma * sigma));
+            sum += k[i];
+        }
+        for (int i = 0; i < 7; ++i) o->k7[i] = (int)std::lrint((float)(k[i] / sum) * 256.0);
+        d.w = (int)std::lrint((double)cols * prm->scale);  // resize(..., Size(), scale, scale): cvRound
+        d.h = (int)std::lrint((double)rows * prm->scale);
+    }
+    if ((long long)d.w * d.h > (1ll << stvo::LSD_IDX_BITS) || d.w >= 65536 || d.h >= 32768) {
+        delete o;
+        return STVO_ERR_CAPACITY;
+    }
+    d.n_bins = prm->n_bins;
+    d.rho = prm->quant / std::sin(stvo::LSD_PI * prm->ang_th / 180);
+    d.prec = stvo::LSD_PI * prm->ang_th / 180;
+    {
+        const double p = prm->ang_th / 180;
+        const double log_nt = 5 * (std::log10((double)d.w) + std::log10((double)d.h)) / 2 + std::log10(11.0);
+        d.min_reg_size = (int)(size_t)(-log_nt / std::log10(p));
+    }
+    d.min_length = prm->min_length;
+    d.nfeatures = prm->nfeatures;
+    d.K = max_keylines;
+    d.seg_cap = 8192;  // segments per image the wrapper ranks (its LDS: 8 bytes each); more are counted, not stored
+    const size_t npx = (size_t)d.w * d.h, nb = (size_t)B;
+    struct {
+        size_t off = 0;
+        size_t take(size_t bytes) {
+            const size_t o = off;
+            off += (bytes + 255) & ~size_t(255);
+            return o;
+        }
+    } c;
+    const size_t o_blur = c.take(nb * cols * rows), o_scaled = c.take(nb * npx), o_img = c.take(nb * cols * rows), o_ang = c.take(nb * npx * 4),
+                 o_csn = c.take(nb * npx * 8), o_mod = c.take(nb * npx * 8), o_used = c.take(nb * npx * 4), o_keys = c.take(nb * npx * 4),
+                 o_order = c.take(nb * npx * 4), o_reg = c.take(nb * npx * 4), o_kmax = c.take(nb * 4), o_seg = c.take(nb * d.seg_cap * 16),
+                 o_nseg = c.take(nb * 4), o_off = c.take((nb + 1) * 4), o_lines = c.take(nb * d.K * sizeof(stvo_keyline)),
+                 o_resp = c.take(nb * d.K * 4), o_nl = c.take(nb * 4);
+    bool ok = hip_ok(ctx, hipMalloc((void**)&o->dev, c.off), "hipMalloc lsd") && hip_ok(ctx, hipMemset(o->dev, 0, c.off), "hipMemset lsd");
+    if (ok) {
+        char* D = o->dev;
+        o->blur = (uint8_t*)(D + o_blur); o->scaled = (uint8_t*)(D + o_scaled); o->img = (uint8_t*)(D + o_img);
+        d.ang = (float*)(D + o_ang); d.csn = (float2*)(D + o_csn); d.mod = (double*)(D + o_mod); d.used = (int32_t*)(D + o_used);
+        d.keys = (uint32_t*)(D + o_keys); d.order = (uint32_t*)(D + o_order); d.reg = (int32_t*)(D + o_reg); d.kmax = (int32_t*)(D + o_kmax);
+        d.seg = (float4*)(D + o_seg); d.n_seg = (int32_t*)(D + o_nseg);
+        o->seg_off = (int32_t*)(D + o_off);
+        o->lines = (stvo_keyline*)(D + o_lines); o->response = (float*)(D + o_resp); o->n_lines = (int32_t*)(D + o_nl);
+        std::vector<int32_t> off(nb + 1);
+        for (size_t i = 0; i <= nb; ++i) off[i] = (int32_t)(i * npx);
+        ok = nb * npx < (1ull << 31) && hip_ok(ctx, hipMemcpy(o->seg_off, off.data(), off.size() * 4, hipMemcpyHostToDevice), "hipMemcpy lsd offsets");
+    }
+    if (ok) {
+        size_t tb = 0;
+        ok = hip_ok(ctx, hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, tb, (const uint32_t*)d.keys, d.order, (int)(nb * npx), B, o->seg_off,
+                                                                    o->seg_off + 1, 0, 32, ctx->stream), "segmented sort (size)") &&
+             hip_ok(ctx, hipMalloc(&o->sort_tmp, tb > 0 ? tb : 16), "hipMalloc lsd sort");
+        o->sort_tmp_bytes = tb;
+    }
+    if (ok && (size_t)d.seg_cap * 8 > 48 * 1024)
+        ok = stvo::lds_opt_in(reinterpret_cast<const void*>(stvo::lsd_keylines_kernel), d.seg_cap * 8);
+    if (!ok) {
+        stvo_lsd_destroy(o);
+        return STVO_ERR_HIP;
+    }
+    *out = o;
+    return STVO_OK;
+}
+
+int stvo_lsd_destroy(stvo_lsd* o) {
+    if (!o) return STVO_OK;
+    if (o->ctx) {
+        (void)hipSetDevice(o->ctx->device);
+        (void)hipStreamSynchronize(o->ctx->stream);
+    }
+    if (o->dbg) (void)hipFree(o->dbg);
+    if (o->sort_tmp) (void)hipFree(o->sort_tmp);
+    if (o->dev) (void)hipFree(o->dev);
+    delete o;
+    return STVO_OK;
+}
+
+int stvo_lsd_detect_dev(stvo_lsd* o, const uint8_t* images, stvo_keyline* lines, float* response, int32_t* n_lines) {
+    if (!o || !images || !lines || !n_lines) return STVO_ERR_INVALID_ARG;
+    stvo_ctx* ctx = o->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return lsd_enqueue(o, images, lines, response, n_lines);
+}
+
+int stvo_lsd_detect(stvo_lsd* o, const uint8_t* images, stvo_keyline* lines, float* response, int32_t* n_lines) {
+    if (!o || !images || !lines || !n_lines) return STVO_ERR_INVALID_ARG;
+    stvo_ctx* ctx = o->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const stvo::LsdDev& d = o->d;
+    const size_t img_bytes = (size_t)d.B * d.cols * d.rows;
+    HIP_TRY(ctx, hipMemcpyAsync(o->img, images, img_bytes, hipMemcpyHostToDevice, ctx->stream));
+    TRY(lsd_enqueue(o, o->img, o->lines, o->response, o->n_lines));
+    HIP_TRY(ctx, hipMemcpyAsync(lines, o->lines, (size_t)d.B * d.K * sizeof(stvo_keyline), hipMemcpyDeviceToHost, ctx->stream));
+    if (response) HIP_TRY(ctx, hipMemcpyAsync(response, o->response, (size_t)d.B * d.K * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(n_lines, o->n_lines, (size_t)d.B * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return STVO_OK;
+}
+
+// developer aid, not part of include/: the rectangle intermediates of the last stvo_lsd_segments call's first image
+extern "C" int stvo_lsd_debug(stvo_lsd* o, int enable, double* out /* [seg_cap][8] or NULL */) {
+    if (!o) return STVO_ERR_INVALID_ARG;
+    stvo_ctx* ctx = o->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (enable && !o->dbg) HIP_TRY(ctx, hipMalloc((void**)&o->dbg, (size_t)o->d.B * o->d.seg_cap * 64));
+    o->d.dbg = enable ? o->dbg : nullptr;
+    if (out && o->dbg) HIP_TRY(ctx, hipMemcpy(out, o->dbg, (size_t)o->d.seg_cap * 64, hipMemcpyDeviceToHost));
+    return STVO_OK;
+}
+
+int stvo_lsd_segments(stvo_lsd* o, const uint8_t* images, float* segments, int cap, int32_t* n_segments) {
+    if (!o || !images || !segments || !n_segments || cap < 1) return STVO_ERR_INVALID_ARG;
+    stvo_ctx* ctx = o->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const stvo::LsdDev& d = o->d;
+    HIP_TRY(ctx, hipMemcpyAsync(o->img, images, (size_t)d.B * d.cols * d.rows, hipMemcpyHostToDevice, ctx->stream));
+    TRY(lsd_enqueue(o, o->img, o->lines, o->response, o->n_lines));
+    HIP_TRY(ctx, hipMemcpyAsync(n_segments, d.n_seg, (size_t)d.B * 4, hipMemcpyDeviceToHost, ctx->stream));
+    const int take = cap < d.seg_cap ? cap : d.seg_cap;
+    HIP_TRY(ctx, hipMemcpy2DAsync(segments, (size_t)cap * 16, d.seg, (size_t)d.seg_cap * 16, (size_t)take * 16, d.B, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return STVO_OK;
+}
+
+}  // extern "C"

@@ -19,6 +19,7 @@
 #include <new>
 
 #include "ctx_internal.h"
+#include "fast_atan2.h"
 
 #pragma clang fp contract(off)
 
@@ -541,27 +542,6 @@ __global__ __launch_bounds__(BL_T) void orb_blur_kernel(OrbDev o, BlurK kk) {
     }
 }
 
-// OpenCV fastAtan2 (degrees): 7th-order odd polynomial on [0, 1], octant folding
-__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
-    const float scale = (float)(180.0 / 3.14159265358979323846);
-    const float p1 = 0.9997878412794807f * scale, p3 = -0.3258083974640975f * scale, p5 = 0.1555786518463281f * scale,
-                p7 = -0.04432655554792128f * scale;
-    const float ax = fabsf(x), ay = fabsf(y);
-    float a, c, c2;
-    if (ax >= ay) {
-        c = __fdiv_rn(ay, ax + (float)2.2204460492503131e-16);
-        c2 = c * c;
-        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
-    } else {
-        c = __fdiv_rn(ax, ay + (float)2.2204460492503131e-16);
-        c2 = c * c;
-        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
-    }
-    if (x < 0) a = 180.f - a;
-    if (y < 0) a = 360.f - a;
-    return a;
-}
-
 struct Umax {
     int u[ORB_HP + 2];
 };
@@ -681,6 +661,24 @@ __global__ __launch_bounds__(256) void orb_describe_kernel(OrbDev o, Umax um) {
 }
 
 }  // namespace
+
+// the two 8-bit image operations other front-ends share (lsd_kernels.hip: the scaled image of the line detector)
+void launch_blur7_u8(hipStream_t s, int B, int cols, int rows, const uint8_t* src, uint8_t* dst, const int* k7) {
+    OrbDev o{};
+    o.B = B; o.cols = cols; o.rows = rows; o.img = src; o.blur = dst;
+    BlurK kk{};
+    for (int i = 0; i < 7; ++i) kk.k[i] = k7[i];
+    const dim3 tiles((cols + 4 * BL_T - 1) / (4 * BL_T), (rows + BL_R - 1) / BL_R, B);
+    hipLaunchKernelGGL(orb_blur_kernel, tiles, dim3(BL_T), 0, s, o, kk);
+}
+void launch_resize_linear_u8(hipStream_t s, int B, int scols, int srows, int dcols, int drows, const uint8_t* src, uint8_t* dst) {
+    ResizeArgs r{};
+    r.B = B; r.scols = scols; r.srows = srows; r.dcols = dcols; r.drows = drows;
+    r.scale_x = 1.0 / ((double)dcols / scols);
+    r.scale_y = 1.0 / ((double)drows / srows);
+    r.src = src; r.dst = dst;
+    hipLaunchKernelGGL(orb_resize_kernel, dim3((dcols + 255) / 256, drows, B), dim3(256), 0, s, r);
+}
 }  // namespace stvo
 
 struct stvo_orb {

@@ -23,7 +23,8 @@ EXPORTS = ["stvo_backend_name", "stvo_abi_version", "stvo_error_string", "stvo_c
            "stvo_seq_set_stage_timing", "stvo_seq_get_stage_timing", "stvo_seq_debug_grid", "stvo_orb_create", "stvo_orb_destroy",
            "stvo_orb_set_pattern", "stvo_orb_get_pattern", "stvo_orb_detect", "stvo_orb_detect_dev", "stvo_orb_detect_levels",
            "stvo_orb_detect_levels_dev", "stvo_orb_set_fast_threshold", "stvo_seq_upload_dev", "stvo_lbd_create", "stvo_lbd_destroy",
-           "stvo_lbd_compute", "stvo_lbd_compute_dev", "stvo_debug_reparse_env"]
+           "stvo_lbd_compute", "stvo_lbd_compute_dev", "stvo_debug_reparse_env", "stvo_lsd_create", "stvo_lsd_destroy", "stvo_lsd_detect",
+           "stvo_lsd_detect_dev", "stvo_lsd_segments"]
 
 SEQ_NSTAGE = 5  # include/stvo_hip.h: STVO_SEQ_NSTAGE
 SEQ_STAGE_NAMES = ("stereo_points_stage", "grid_scan", "hamming_knn2", "reverse_check", "pose")
@@ -141,6 +142,11 @@ def load():
     L.stvo_lbd_destroy.argtypes = [C.c_void_p]
     L.stvo_lbd_compute.argtypes = [C.c_void_p, u8p, C.c_void_p, i32p, u8p, C.c_void_p]
     L.stvo_lbd_compute_dev.argtypes = [C.c_void_p] + [C.c_void_p] * 5
+    L.stvo_lsd_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(LsdParams), C.POINTER(C.c_void_p)]
+    L.stvo_lsd_destroy.argtypes = [C.c_void_p]
+    L.stvo_lsd_detect.argtypes = [C.c_void_p, u8p, C.c_void_p, C.c_void_p, i32p]
+    L.stvo_lsd_detect_dev.argtypes = [C.c_void_p] + [C.c_void_p] * 4
+    L.stvo_lsd_segments.argtypes = [C.c_void_p, u8p, f32p, C.c_int, i32p]
     L.stvo_seq_destroy.argtypes = [C.c_void_p]
     L.stvo_seq_push.argtypes = [C.c_void_p, C.POINTER(FrameFeatures), C.c_void_p, i32p]
     L.stvo_seq_upload.argtypes = [C.c_void_p, C.c_int, C.POINTER(FrameFeatures)]
@@ -357,6 +363,48 @@ class Orb:
 
 
 KEYLINE_DTYPE = np.dtype([("sx", "<f4"), ("sy", "<f4"), ("ex", "<f4"), ("ey", "<f4"), ("angle", "<f4"), ("num_pixels", "<i4")])  # stvo_keyline
+
+
+class LsdParams(C.Structure):  # stvo_lsd_params
+    _fields_ = [("refine", C.c_int32), ("n_bins", C.c_int32), ("scale", C.c_double), ("sigma_scale", C.c_double), ("quant", C.c_double),
+                ("ang_th", C.c_double), ("log_eps", C.c_double), ("density_th", C.c_double), ("min_length", C.c_double),
+                ("nfeatures", C.c_int32), ("reserved", C.c_int32)]
+
+
+def lsd_params(min_length=0.0, nfeatures=300, refine=0, scale=1.2, sigma_scale=0.6, quant=2.0, ang_th=22.5, n_bins=1024):
+    """src/config.cpp:104-112 (every shipped yaml has the same values)."""
+    return LsdParams(refine, n_bins, scale, sigma_scale, quant, ang_th, 1.0, 0.6, min_length, nfeatures, 0)
+
+
+class Lsd:
+    """The LSD key-line detector for B images of one size (stvo_lsd_*)."""
+
+    def __init__(self, ctx, B, cols, rows, prm, max_keylines=512):
+        self.ctx, self.B, self.cols, self.rows, self.M = ctx, B, cols, rows, max_keylines
+        self.h = C.c_void_p()
+        ctx._chk(ctx.lib.stvo_lsd_create(ctx.h, B, cols, rows, max_keylines, C.byref(prm), C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.stvo_lsd_destroy(self.h)
+            self.h = None
+
+    def detect(self, images):
+        """images uint8 [B, rows, cols] -> list of B (key-lines as KEYLINE_DTYPE records, responses float32)."""
+        images = np.ascontiguousarray(images, np.uint8).reshape(self.B, self.rows, self.cols)
+        rec = np.zeros((self.B, self.M), KEYLINE_DTYPE)
+        resp = np.zeros((self.B, self.M), np.float32)
+        n = np.zeros(self.B, np.int32)
+        self.ctx._chk(self.ctx.lib.stvo_lsd_detect(self.h, images.reshape(-1), rec.ctypes.data_as(C.c_void_p), resp.ctypes.data_as(C.c_void_p), n))
+        return [(rec[b, :n[b]].copy(), resp[b, :n[b]].copy()) for b in range(self.B)]
+
+    def segments(self, images, cap=8192):
+        """The raw segments of the detector core: list of B float32 [n_b, 4] (detection order)."""
+        images = np.ascontiguousarray(images, np.uint8).reshape(self.B, self.rows, self.cols)
+        seg = np.zeros((self.B, cap, 4), np.float32)
+        n = np.zeros(self.B, np.int32)
+        self.ctx._chk(self.ctx.lib.stvo_lsd_segments(self.h, images.reshape(-1), seg.reshape(-1), cap, n))
+        return [seg[b, :min(n[b], cap)].copy() for b in range(self.B)], n
 
 
 class Lbd:
