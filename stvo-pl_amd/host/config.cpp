@@ -35,6 +35,8 @@ void Config::setDefaults() {
     c.matching_strategy = 0; c.matching_s_ws = 10; c.matching_f2f_ws = 3;
     c.orb_nfeatures = 1200; c.orb_scale_factor = 1.2; c.orb_nlevels = 4; c.orb_fast_th = 20; c.orb_edge_th = 19;  // src/config.cpp:95-102
     c.lsd_nfeatures = 300; c.lsd_scale = 1.2;
+    c.lsd_refine = 0; c.lsd_sigma_scale = 0.6; c.lsd_quant = 2.0; c.lsd_ang_th = 22.5; c.lsd_log_eps = 1.0; c.lsd_density_th = 0.6;
+    c.lsd_n_bins = 1024;  // src/config.cpp:105-112
 }
 
 // config/config/config_kitti.yaml
@@ -94,6 +96,8 @@ void Config::loadFromFile(const std::string& path) {
     I("matching_s_ws", matching_s_ws) I("matching_f2f_ws", matching_f2f_ws)
     I("orb_nfeatures", orb_nfeatures) D("orb_scale_factor", orb_scale_factor) I("orb_nlevels", orb_nlevels)
     I("orb_fast_th", orb_fast_th) I("orb_edge_th", orb_edge_th) I("lsd_nfeatures", lsd_nfeatures) D("lsd_scale", lsd_scale)
+    I("lsd_refine", lsd_refine) D("lsd_sigma_scale", lsd_sigma_scale) D("lsd_quant", lsd_quant) D("lsd_ang_th", lsd_ang_th)
+    D("lsd_log_eps", lsd_log_eps) D("lsd_density_th", lsd_density_th) I("lsd_n_bins", lsd_n_bins)
     D("min_entropy_ratio", min_entropy_ratio) D("max_kf_t_dist", max_kf_t_dist) D("max_kf_r_dist", max_kf_r_dist)
 #undef B
 #undef D

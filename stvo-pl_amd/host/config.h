@@ -35,6 +35,9 @@ public:
     STVO_CFG(int, orbNFeatures, orb_nfeatures) STVO_CFG(double, orbScaleFactor, orb_scale_factor)
     STVO_CFG(int, orbNLevels, orb_nlevels) STVO_CFG(int, orbFastTh, orb_fast_th) STVO_CFG(int, orbEdgeTh, orb_edge_th)
     STVO_CFG(int, lsdNFeatures, lsd_nfeatures) STVO_CFG(double, lsdScale, lsd_scale)
+    STVO_CFG(int, lsdRefine, lsd_refine) STVO_CFG(double, lsdSigmaScale, lsd_sigma_scale) STVO_CFG(double, lsdQuant, lsd_quant)
+    STVO_CFG(double, lsdAngTh, lsd_ang_th) STVO_CFG(double, lsdLogEps, lsd_log_eps) STVO_CFG(double, lsdDensityTh, lsd_density_th)
+    STVO_CFG(int, lsdNBins, lsd_n_bins)
     STVO_CFG(double, minEntropyRatio, min_entropy_ratio) STVO_CFG(double, maxKFTDist, max_kf_t_dist)
     STVO_CFG(double, maxKFRDist, max_kf_r_dist)
 #undef STVO_CFG
@@ -54,6 +57,8 @@ public:
     int orb_nlevels, orb_fast_th, orb_edge_th;
     int lsd_nfeatures;
     double lsd_scale;
+    int lsd_refine, lsd_n_bins;  // src/config.cpp:105-112
+    double lsd_sigma_scale, lsd_quant, lsd_ang_th, lsd_log_eps, lsd_density_th;
     double min_entropy_ratio, max_kf_t_dist, max_kf_r_dist;
 
 private:

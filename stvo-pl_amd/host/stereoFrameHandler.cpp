@@ -42,6 +42,8 @@ StereoFrameHandler::~StereoFrameHandler() {
     delete prev_frame;
     if (seq) stvo_seq_destroy(seq);
     if (orb) stvo_orb_destroy(orb);
+    if (lsd) stvo_lsd_destroy(lsd);
+    if (lbd) stvo_lbd_destroy(lbd);
     if (ctx_lines) stvo_ctx_destroy(ctx_lines);
     stvo_ctx_destroy(ctx);
 }
@@ -78,6 +80,14 @@ FrameFeatures StereoFrameHandler::detectStereoFeatures(const GrayImage& img_l, c
     FrameFeatures feat;
     feat.img_cols = img_l.cols;
     feat.img_rows = img_l.rows;
+    const size_t px = (size_t)img_l.rows * img_l.cols;
+    std::vector<uint8_t> pair(2 * px);
+    const GrayImage* im[2] = {&img_l, &img_r};
+    for (int s = 0; s < 2; ++s) {
+        const size_t step = im[s]->step ? im[s]->step : (size_t)im[s]->cols;
+        for (int r = 0; r < im[s]->rows; ++r) std::memcpy(pair.data() + s * px + (size_t)r * im[s]->cols, im[s]->data + r * step, (size_t)im[s]->cols);
+    }
+    if (Config::hasLines()) detectStereoLines(pair.data(), img_l.cols, img_l.rows, feat);  // src/stereoFrame.cpp:191-203
     if (!Config::hasPoints()) return feat;  // src/stereoFrame.cpp:106
     const int K = 4096;  // capacity per image: orb_nfeatures plus the ties at the cut
     // fast_th == 0 means "the configured threshold" (src/stereoFrame.cpp:109-112), otherwise the adaptive one; cv::FAST's range
@@ -98,13 +108,6 @@ FrameFeatures StereoFrameHandler::detectStereoFeatures(const GrayImage& img_l, c
         orb_rows = img_l.rows;
     }
     check(stvo_orb_set_fast_threshold(orb, fast_th), "stvo_orb_set_fast_threshold", ctx);
-    const size_t px = (size_t)img_l.rows * img_l.cols;
-    std::vector<uint8_t> pair(2 * px);
-    const GrayImage* im[2] = {&img_l, &img_r};
-    for (int s = 0; s < 2; ++s) {
-        const size_t step = im[s]->step ? im[s]->step : (size_t)im[s]->cols;
-        for (int r = 0; r < im[s]->rows; ++r) std::memcpy(pair.data() + s * px + (size_t)r * im[s]->cols, im[s]->data + r * step, (size_t)im[s]->cols);
-    }
     std::vector<float> kp((size_t)2 * K * 2), resp((size_t)2 * K), ang((size_t)2 * K);
     std::vector<int32_t> oct((size_t)2 * K);
     std::vector<uint8_t> desc((size_t)2 * K * 32);
@@ -124,6 +127,46 @@ FrameFeatures StereoFrameHandler::detectStereoFeatures(const GrayImage& img_l, c
         }
     }
     return feat;
+}
+
+// StereoFrame::detectStereoLineSegments (src/stereoFrame.cpp:191-203) -> detectLineFeatures (:207-243) for both images of the
+// pair in one batch: the LSD detector with Config's lsd_* options and min_line_length x min(cols, rows) (stvo_lsd_*, oracle/
+// stvo_lsd_oracle.c), the top-N cut by response, then the LBD descriptors (stvo_lbd_*).  The FLD branch (:245-303,
+// cv::ximgproc::FastLineDetector) is not built: use_fld_lines = true is refused.
+void StereoFrameHandler::detectStereoLines(const uint8_t* pair, int cols, int rows, FrameFeatures& feat) {
+    if (Config::useFLDLines()) throw std::runtime_error("[StVO-HIP] use_fld_lines: the FLD detector is not built (LSD only)");
+    const int M = STVO_POSE_MAX_LINES;  // the pipeline's capacity per image; lsd_nfeatures (300 / 100) lies below it
+    if (lsd && (line_cols != cols || line_rows != rows)) {
+        stvo_lsd_destroy(lsd); lsd = nullptr;
+        stvo_lbd_destroy(lbd); lbd = nullptr;
+    }
+    if (!lsd) {
+        stvo_lsd_params prm{};
+        prm.refine = Config::lsdRefine(); prm.n_bins = Config::lsdNBins(); prm.scale = Config::lsdScale();
+        prm.sigma_scale = Config::lsdSigmaScale(); prm.quant = Config::lsdQuant(); prm.ang_th = Config::lsdAngTh();
+        prm.log_eps = Config::lsdLogEps(); prm.density_th = Config::lsdDensityTh();
+        prm.min_length = Config::minLineLength() * std::min(cols, rows);  // llength_th (:52) for this image size
+        prm.nfeatures = Config::lsdNFeatures();
+        check(stvo_lsd_create(ctx, 2, cols, rows, M, &prm, &lsd), "stvo_lsd_create", ctx);
+        check(stvo_lbd_create(ctx, 2, cols, rows, M, &lbd), "stvo_lbd_create", ctx);
+        line_cols = cols;
+        line_rows = rows;
+    }
+    std::vector<stvo_keyline> kl((size_t)2 * M);
+    std::vector<uint8_t> desc((size_t)2 * M * 32);
+    int32_t n[2] = {0, 0};
+    check(stvo_lsd_detect(lsd, pair, kl.data(), nullptr, n), "stvo_lsd_detect", ctx);
+    check(stvo_lbd_compute(lbd, pair, kl.data(), n, desc.data(), nullptr), "stvo_lbd_compute", ctx);
+    for (int s = 0; s < 2; ++s) {
+        std::vector<KeyLine>& ls = s ? feat.lines_r : feat.lines_l;
+        DescMat& dm = s ? feat.ldesc_r : feat.ldesc_l;
+        ls.reserve(n[s]);
+        for (int i = 0; i < n[s]; ++i) {
+            const stvo_keyline& q = kl[(size_t)s * M + i];
+            ls.push_back(KeyLine{q.sx, q.sy, q.ex, q.ey, q.angle, 0});  // one octave: octaveScale = 1 (LSDDetector_custom.cpp:257)
+            dm.push_back_row(desc.data() + ((size_t)s * M + i) * 32);
+        }
+    }
 }
 
 void StereoFrameHandler::initialize(const GrayImage& img_l, const GrayImage& img_r, const int idx_) {

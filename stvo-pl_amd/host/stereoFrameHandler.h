@@ -27,6 +27,7 @@ public:
     // honoured by the rest of the path; it simply finds empty sets).
     void initialize(const GrayImage& img_l, const GrayImage& img_r, const int idx_);
     void insertStereoPair(const GrayImage& img_l, const GrayImage& img_r, const int idx_);
+    void detectStereoLines(const uint8_t* pair, int cols, int rows, FrameFeatures& feat);
     FrameFeatures detectStereoFeatures(const GrayImage& img_l, const GrayImage& img_r);
     void updateFrame();
 
@@ -79,6 +80,9 @@ private:
     void publishPose();
     stvo_orb* orb = nullptr;  // created at the first image pair (image size, Config's orb_* values)
     int orb_cols = 0, orb_rows = 0;
+    stvo_lsd* lsd = nullptr;  // the line front-end of the image entry points: LSD detector + LBD descriptor, both images per call
+    stvo_lbd* lbd = nullptr;
+    int line_cols = 0, line_rows = 0;
     stvo_seq* seq = nullptr;
     int seq_K = 0, seq_M = 0, pipe_slot = 0;
     bool pose_pending = false;

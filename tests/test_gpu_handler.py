@@ -154,3 +154,45 @@ def test_image_entry_points_of_the_handler(tmp_path, oracle, preset, nlevels):
             th = ref[-1]["fast"]   # updateFrame's threshold for the NEXT detection
     compare(res, ref)
     assert sum(r["ints"][1] == 0 for r in res) >= 2 and "FAST:" in p.stdout
+
+
+@pytest.mark.parametrize("preset,nlevels", [("kitti", 1), ("euroc", 4)])
+def test_image_entry_points_points_and_lines(tmp_path, oracle, preset, nlevels):
+    """The same with Config::hasLines(): insertStereoPair(img_l, img_r, idx) detects key-points (ORB) AND key-lines — the LSD detector
+    with Config's lsd_* options and min_line_length x min(cols, rows), the top-N cut by response, LBD descriptors
+    (src/stereoFrame.cpp:191-243) — on the GPU and runs points + lines through the usual path; against the CPU chain: ORB / LSD / LBD
+    oracles on every image, their features through the oracle-driven per-frame loop."""
+    cam = dict(synth.KITTI_CAM if preset == "kitti" else synth.EUROC_CAM, width=640, height=240)
+    pairs = synth.make_stereo_image_sequence(91, 4, cam)
+    seq = str(tmp_path / "img.bin"); res_path = str(tmp_path / "res.bin")
+    synth.write_image_sequence(seq, pairs, cam)
+    p = subprocess.run([APP, seq, res_path, "--preset", preset], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr + p.stdout
+    res = synth.read_results(res_path)
+    mp = match_params(preset); op = opt_params(preset, has_lines=1)
+    nfeat = {"kitti": 2000, "euroc": 800}[preset]; nlines = {"kitti": 100, "euroc": 300}[preset]
+    fast = dict(adaptive=True, th0=20, mn=7, mx=30, inc=5, feat=50, err=0.5) if preset == "kitti" else \
+        dict(adaptive=True, th0=20, mn=5, mx=50, inc=5, feat=50, err=0.5)
+    pattern = oracle.orb_default_pattern()
+    lopts = oracle.lsd_opts(min_length=0.025 * min(cam["width"], cam["height"]), nfeatures=nlines)
+
+    def lines_of(img):
+        kl = oracle.lsd_detect(img, lopts)
+        rec = np.stack([kl["sx"], kl["sy"], kl["ex"], kl["ey"], kl["angle"]], axis=1).astype(np.float32)
+        desc = oracle.lbd_compute(img, rec, kl["num_pixels"])
+        return np.ascontiguousarray(rec[:, :4]), np.ascontiguousarray(rec[:, 4]), desc
+
+    frames, th, ref = [], fast["th0"], []
+    for k, (left, right) in enumerate(pairs):
+        l = oracle.orb_detect_levels(left, nfeatures=nfeat, nlevels=nlevels, fast_th=th, pattern=pattern)
+        r = oracle.orb_detect_levels(right, nfeatures=nfeat, nlevels=nlevels, fast_th=th, pattern=pattern)
+        kl_l, ang_l, ld_l = lines_of(left)
+        kl_r, _, ld_r = lines_of(right)
+        assert len(kl_l) > 20 and len(kl_r) > 20
+        frames.append(dict(kp_l=l["kp"], oct_l=l["octave"], desc_l=l["desc"], kp_r=r["kp"], desc_r=r["desc"], kl_l=kl_l,
+                           oct_ll=np.zeros(len(kl_l), np.int32), ldesc_l=ld_l, kl_r=kl_r, ldesc_r=ld_r, ang_l=ang_l))
+        if k:
+            ref = pipeline_ref.run_sequence(oracle, frames, cam, mp, op, fast=fast)
+            th = ref[-1]["fast"]
+    compare(res, ref)
+    assert any(r["ints"][7] > 0 for r in res[1:])  # matched key-lines took part
