@@ -133,20 +133,23 @@ __global__ __launch_bounds__(256) void lsd_keys_kernel(LsdDev d) {
 
 constexpr int LSD_RING = 4096;  // the most recent region points, in LDS
 
-// coherent accesses to the flags / the region list the wave itself writes (lane 0 stores, all lanes load later): past the L1
-__device__ __forceinline__ int ld_coherent(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_coherent(int32_t* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// The flags / the region list are written by lane 0 and read by all lanes of the SAME wave later: workgroup-scope ordering is
+// what is needed — the vector L1 is write-through and shared by the CU, so such accesses are ordinary loads / stores with a wait
+// for the stores in between.  (Device-scope atomics were the first version: on this part they bypass the XCD's L2, ~2 us each,
+// and 512 images took 0.5 s.)
+__device__ __forceinline__ int ld_coherent(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void st_coherent(int32_t* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ double readlane_f64(double v, int l) {
     const unsigned long long b = (unsigned long long)__double_as_longlong(v);
     const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 __device__ __forceinline__ float readlane_f32(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
-// stores of this wave have reached the L2 / later loads of this wave come from the L2
+// stores of this wave are complete / later loads of this wave see them
 __device__ __forceinline__ void wave_publish() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
 __global__ __launch_bounds__(64) void lsd_grow_kernel(LsdDev d) {
@@ -192,7 +195,7 @@ __global__ __launch_bounds__(64) void lsd_grow_kernel(LsdDev d) {
                 s_ring[0] = sx0 | (sy0 << 16);
             }
             for (int i = 0; i < n_reg;) {
-                wave_publish();  // the flags and the list as the earlier groups left them
+                wave_publish();  // lane 0's stores of the earlier groups before the flag / list loads below
                 const int cnt = n_reg - i < 7 ? n_reg - i : 7;  // uniform
                 const int slot = lane / 9, nb = lane - slot * 9;
                 bool valid = slot < cnt;
