@@ -132,6 +132,7 @@ __global__ __launch_bounds__(256) void lsd_keys_kernel(LsdDev d) {
 }
 
 constexpr int LSD_RING = 4096;  // the most recent region points, in LDS
+constexpr int LSD_GR = 2;       // sub-groups of 7 region points (63 lanes) fetched per round of the region growing
 
 // The flags / the region list are written by lane 0 and read by all lanes of the SAME wave later: workgroup-scope ordering is
 // what is needed — the vector L1 is write-through and shared by the CU, so such accesses are ordinary loads / stores with a wait
@@ -170,21 +171,17 @@ __global__ __launch_bounds__(64) void lsd_grow_kernel(LsdDev d) {
         if ((uint32_t)__builtin_amdgcn_readfirstlane((int)key) == LSD_NOKEY) break;  // sorted: only undefined pixels from here on
         const int q_l = (int)(key & ((1u << LSD_IDX_BITS) - 1u));
         const bool key_ok = key != LSD_NOKEY;
+        const float ang_l = key_ok ? ang[q_l] : -1.f;  // the seeds' angles, fetched with the batch
         unsigned long long todo = __ballot(key_ok && ld_coherent(used + (key_ok ? q_l : 0)) == 0);
-        bool dirty = false;  // a region was grown since the flags of this batch were read
+        // seeds of this batch that a region grown from an earlier seed of the batch takes are struck off as they are taken (one
+        // compare + ballot per pixel added) — re-reading the flags after every region cost a memory round trip per region
         while (todo) {
-            if (dirty) {
-                wave_publish();
-                todo &= __ballot(key_ok && ld_coherent(used + (key_ok ? q_l : 0)) == 0);
-                dirty = false;
-                if (!todo) break;
-            }
             const int j = __builtin_ctzll(todo);
             todo &= todo - 1ull;
             const int seed = __builtin_amdgcn_readlane(q_l, j);
             // ---------------- region_grow ----------------
             const int sx0 = seed % w, sy0 = seed / w;
-            double reg_angle = (double)ang[seed] * LSD_DEG2RAD;
+            double reg_angle = (double)readlane_f32(ang_l, j) * LSD_DEG2RAD;
             double sn0, cs0;
             sincos_det(reg_angle, sn0, cs0);
             float sumdx = (float)cs0, sumdy = (float)sn0;
@@ -195,56 +192,72 @@ __global__ __launch_bounds__(64) void lsd_grow_kernel(LsdDev d) {
                 s_ring[0] = sx0 | (sy0 << 16);
             }
             for (int i = 0; i < n_reg;) {
-                wave_publish();  // lane 0's stores of the earlier groups before the flag / list loads below
-                const int cnt = n_reg - i < 7 ? n_reg - i : 7;  // uniform
-                const int slot = lane / 9, nb = lane - slot * 9;
-                bool valid = slot < cnt;
-                int pxy = 0;
-                if (valid) pxy = (n_reg - (i + slot) <= LSD_RING) ? s_ring[(i + slot) & (LSD_RING - 1)] : ld_coherent(reg + i + slot);
-                const int xx = (pxy & 0xFFFF) + (nb % 3) - 1, yy = (pxy >> 16) + nb / 3 - 1;  // neighbours row by row
-                valid = valid && xx >= 0 && xx < w && yy >= 0 && yy < h;
-                const int qq = valid ? yy * w + xx : 0;
-                int u = 1;
-                float a = -1.f;
-                float2 cs = make_float2(0.f, 0.f);
-                if (valid) {
-                    u = ld_coherent(used + qq);
-                    a = ang[qq];
-                    cs = csn[qq];
+                wave_publish();  // lane 0's stores of the earlier rounds before the flag / list loads below
+                // one round: the next (up to) 7 LSD_GR region points — sub-group r holds points i + 7 r .. i + 7 r + 6, lane = 9 x point
+                // + neighbour — fetched together, then resolved sub-group after sub-group, lane after lane: the oracle's order
+                const int cnt = n_reg - i < 7 * LSD_GR ? n_reg - i : 7 * LSD_GR;  // uniform
+                const int slot0 = lane / 9, nb = lane - slot0 * 9;
+                int qq[LSD_GR], xy[LSD_GR];
+                float2 cs[LSD_GR];
+                double ad[LSD_GR];
+                bool cand[LSD_GR];
+#pragma unroll
+                for (int r = 0; r < LSD_GR; ++r) {
+                    const int slot = 7 * r + slot0;
+                    bool valid = lane < 63 && slot < cnt && nb != 4;  // (the centre is the region point itself)
+                    int pxy = 0;
+                    if (valid) pxy = (n_reg - (i + slot) <= LSD_RING) ? s_ring[(i + slot) & (LSD_RING - 1)] : ld_coherent(reg + i + slot);
+                    const int xx = (pxy & 0xFFFF) + (nb % 3) - 1, yy = (pxy >> 16) + nb / 3 - 1;  // neighbours row by row
+                    valid = valid && xx >= 0 && xx < w && yy >= 0 && yy < h;
+                    qq[r] = valid ? yy * w + xx : 0;
+                    xy[r] = xx | (yy << 16);
+                    int u = 1;
+                    float a = -1.f;
+                    cs[r] = make_float2(0.f, 0.f);
+                    if (valid) {
+                        u = ld_coherent(used + qq[r]);
+                        a = ang[qq[r]];
+                        cs[r] = csn[qq[r]];
+                    }
+                    cand[r] = valid && u == 0 && a >= 0.f;
+                    ad[r] = (double)a * LSD_DEG2RAD;
                 }
-                bool cand = valid && u == 0 && a >= 0.f;
-                const double ad = (double)a * LSD_DEG2RAD;
-                int next = 0;  // lanes below `next` have had their turn
-                for (;;) {
-                    double n_theta = reg_angle - ad;  // isAligned
-                    if (n_theta < 0) n_theta = -n_theta;
-                    if (n_theta > LSD_3_2_PI) {
-                        n_theta -= LSD_2_PI;
+#pragma unroll
+                for (int r = 0; r < LSD_GR; ++r) {
+                    if (7 * r >= cnt) break;  // uniform
+                    int next = 0;  // lanes below `next` have had their turn
+                    for (;;) {
+                        double n_theta = reg_angle - ad[r];  // isAligned
                         if (n_theta < 0) n_theta = -n_theta;
+                        if (n_theta > LSD_3_2_PI) {
+                            n_theta -= LSD_2_PI;
+                            if (n_theta < 0) n_theta = -n_theta;
+                        }
+                        const unsigned long long m = __ballot(cand[r] && lane >= next && n_theta <= prec);
+                        if (!m || n_reg >= npx) break;  // (the bound can only bind if a flag were lost: never write past the list)
+                        const int L = __builtin_ctzll(m);
+                        const int qL = __builtin_amdgcn_readlane(qq[r], L), xyL = __builtin_amdgcn_readlane(xy[r], L);
+                        const float cL = readlane_f32(cs[r].x, L), sL = readlane_f32(cs[r].y, L);
+                        if (lane == 0) {
+                            st_coherent(used + qL, 1);
+                            st_coherent(reg + n_reg, xyL);
+                            s_ring[n_reg & (LSD_RING - 1)] = xyL;
+                        }
+                        ++n_reg;
+#pragma unroll
+                        for (int r2 = 0; r2 < LSD_GR; ++r2) cand[r2] = cand[r2] && qq[r2] != qL;  // the same pixel seen from another point of the round
+                        todo &= ~__ballot(key_ok && q_l == qL);
+                        sumdx += cL;
+                        sumdy += sL;
+                        reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * LSD_DEG2RAD;
+                        next = L + 1;
                     }
-                    const unsigned long long m = __ballot(cand && lane >= next && n_theta <= prec);
-                    if (!m || n_reg >= npx) break;  // (the bound can only bind if a flag were lost: never write past the list)
-                    const int L = __builtin_ctzll(m);
-                    const int qL = __builtin_amdgcn_readlane(qq, L), xyL = __builtin_amdgcn_readlane(xx | (yy << 16), L);
-                    const float cL = readlane_f32(cs.x, L), sL = readlane_f32(cs.y, L);
-                    if (lane == 0) {
-                        st_coherent(used + qL, 1);
-                        st_coherent(reg + n_reg, xyL);
-                        s_ring[n_reg & (LSD_RING - 1)] = xyL;
-                    }
-                    ++n_reg;
-                    cand = cand && qq != qL;  // the same pixel seen from another region point of the group
-                    sumdx += cL;
-                    sumdy += sL;
-                    reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * LSD_DEG2RAD;
-                    next = L + 1;
                 }
                 i += cnt;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // s_ring: lane 0's writes before the next group's reads
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // s_ring: lane 0's writes before the next round's reads
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
-            dirty = true;
             if (n_reg < d.min_reg_size) continue;
             // ---------------- region2rect ----------------
             wave_publish();
