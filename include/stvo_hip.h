@@ -305,6 +305,10 @@ int stvo_lsd_destroy(stvo_lsd* lsd);
 int stvo_lsd_detect(stvo_lsd* lsd, const uint8_t* images, stvo_keyline* lines, float* response, int32_t* n_lines);
 /* The same with DEVICE pointers, enqueued on the context's stream (no synchronisation). */
 int stvo_lsd_detect_dev(stvo_lsd* lsd, const uint8_t* images, stvo_keyline* lines, float* response, int32_t* n_lines);
+/* Device helper between stvo_lsd_detect_dev / stvo_lbd_compute_dev and stvo_seq_upload_dev: the end points (sx, sy, ex, ey) of
+ * the key-line records [B][stride] as the float rows [B][stride][4] that stvo_frame_features::kl_l / kl_r take (device pointers,
+ * enqueued on the context's stream; rows beyond n_lines[b] are zeroed). */
+int stvo_keylines_xy_dev(stvo_ctx* ctx, int B, int stride, const stvo_keyline* lines, const int32_t* n_lines, float* kl_xy);
 /* test hook: the raw segments of the detector core (cv::LineSegmentDetector::detect), host buffers, synchronises:
  * segments [B][cap][4], n_segments [B] (all found; at most cap stored) */
 int stvo_lsd_segments(stvo_lsd* lsd, const uint8_t* images, float* segments, int cap, int32_t* n_segments);

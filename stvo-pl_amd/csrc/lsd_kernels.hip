@@ -422,6 +422,14 @@ __global__ __launch_bounds__(KL_T) void lsd_keylines_kernel(LsdDev d) {
     if (tid == 0) d.n_lines[b] = n_out;
 }
 
+// the end points of key-line records as the rows stvo_frame_features::kl_l / kl_r take (unused rows zeroed)
+__global__ __launch_bounds__(256) void keylines_xy_kernel(int stride, const stvo_keyline* lines, const int32_t* n_lines, float4* xy) {
+    const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (i >= stride) return;
+    const stvo_keyline q = lines[(size_t)b * stride + i];
+    xy[(size_t)b * stride + i] = i < n_lines[b] ? make_float4(q.sx, q.sy, q.ex, q.ey) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 }  // namespace
 }  // namespace stvo
 
@@ -605,6 +613,14 @@ extern "C" int stvo_lsd_debug(stvo_lsd* o, int enable, double* out /* [seg_cap][
     o->d.dbg = enable ? o->dbg : nullptr;
     if (out && o->dbg) HIP_TRY(ctx, hipMemcpy(out, o->dbg, (size_t)o->d.seg_cap * 64, hipMemcpyDeviceToHost));
     return STVO_OK;
+}
+
+int stvo_keylines_xy_dev(stvo_ctx* ctx, int B, int stride, const stvo_keyline* lines, const int32_t* n_lines, float* kl_xy) {
+    if (!ctx || B < 1 || stride < 1 || !lines || !n_lines || !kl_xy) return STVO_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(stvo::keylines_xy_kernel, dim3((stride + 255) / 256, B), dim3(256), 0, ctx->stream, stride, lines, n_lines,
+                       reinterpret_cast<float4*>(kl_xy));
+    return check_launch(ctx);
 }
 
 int stvo_lsd_segments(stvo_lsd* o, const uint8_t* images, float* segments, int cap, int32_t* n_segments) {

@@ -24,7 +24,7 @@ EXPORTS = ["stvo_backend_name", "stvo_abi_version", "stvo_error_string", "stvo_c
            "stvo_orb_set_pattern", "stvo_orb_get_pattern", "stvo_orb_detect", "stvo_orb_detect_dev", "stvo_orb_detect_levels",
            "stvo_orb_detect_levels_dev", "stvo_orb_set_fast_threshold", "stvo_seq_upload_dev", "stvo_lbd_create", "stvo_lbd_destroy",
            "stvo_lbd_compute", "stvo_lbd_compute_dev", "stvo_debug_reparse_env", "stvo_lsd_create", "stvo_lsd_destroy", "stvo_lsd_detect",
-           "stvo_lsd_detect_dev", "stvo_lsd_segments"]
+           "stvo_lsd_detect_dev", "stvo_lsd_segments", "stvo_keylines_xy_dev"]
 
 SEQ_NSTAGE = 5  # include/stvo_hip.h: STVO_SEQ_NSTAGE
 SEQ_STAGE_NAMES = ("stereo_points_stage", "grid_scan", "hamming_knn2", "reverse_check", "pose")
@@ -147,6 +147,7 @@ def load():
     L.stvo_lsd_detect.argtypes = [C.c_void_p, u8p, C.c_void_p, C.c_void_p, i32p]
     L.stvo_lsd_detect_dev.argtypes = [C.c_void_p] + [C.c_void_p] * 4
     L.stvo_lsd_segments.argtypes = [C.c_void_p, u8p, f32p, C.c_int, i32p]
+    L.stvo_keylines_xy_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.stvo_seq_destroy.argtypes = [C.c_void_p]
     L.stvo_seq_push.argtypes = [C.c_void_p, C.POINTER(FrameFeatures), C.c_void_p, i32p]
     L.stvo_seq_upload.argtypes = [C.c_void_p, C.c_int, C.POINTER(FrameFeatures)]
@@ -398,6 +399,10 @@ class Lsd:
         self.ctx._chk(self.ctx.lib.stvo_lsd_detect(self.h, images.reshape(-1), rec.ctypes.data_as(C.c_void_p), resp.ctypes.data_as(C.c_void_p), n))
         return [(rec[b, :n[b]].copy(), resp[b, :n[b]].copy()) for b in range(self.B)]
 
+    def detect_dev(self, img_ptr, lines_ptr, resp_ptr, n_ptr):
+        """Device pointers (uint8 [B, rows, cols]; stvo_keyline [B, M]; float32 [B, M] or None; int32 [B]); asynchronous."""
+        self.ctx._chk(self.ctx.lib.stvo_lsd_detect_dev(self.h, img_ptr, lines_ptr, resp_ptr, n_ptr))
+
     def segments(self, images, cap=8192):
         """The raw segments of the detector core: list of B float32 [n_b, 4] (detection order)."""
         images = np.ascontiguousarray(images, np.uint8).reshape(self.B, self.rows, self.cols)
@@ -419,6 +424,10 @@ class Lbd:
         if self.h:
             self.ctx.lib.stvo_lbd_destroy(self.h)
             self.h = None
+
+    def compute_dev(self, img_ptr, lines_ptr, n_ptr, desc_ptr, desc_float_ptr=None):
+        """Device pointers (uint8 [B, rows, cols]; stvo_keyline [B, M]; int32 [B]; uint8 [B, M, 32]; float32 [B, M, 72] or None)."""
+        self.ctx._chk(self.ctx.lib.stvo_lbd_compute_dev(self.h, img_ptr, lines_ptr, n_ptr, desc_ptr, desc_float_ptr))
 
     def compute(self, images, lines, num_pixels, want_float=False):
         """images uint8 [B, rows, cols]; lines: list of B arrays [n_b, 5] (sx, sy, ex, ey, angle); num_pixels: list of B int arrays.

@@ -61,3 +61,49 @@ def test_images_to_poses_two_streams(oracle, nlevels):
     finally:
         pipe.close()
         ctx.close()
+
+
+def test_images_to_poses_points_and_lines(oracle):
+    """Key-points AND key-lines on the device: ORB, LSD (+ top-N cut), LBD, the end points handed to stvo_seq_upload_dev, then the
+    per-frame pipeline with has_lines — against the CPU chain (ORB / LSD / LBD oracles -> oracle pipeline), pose for pose."""
+    from stvo_amd import capi, images
+    cam = dict(synth.KITTI_CAM, width=640, height=240)
+    mp = match_params("kitti"); op = opt_params("kitti", has_lines=1)
+    B, nf, nlines = 2, 3, 100
+    min_len = 0.025 * min(cam["width"], cam["height"])
+    seqs = [synth.make_stereo_image_sequence(60 + b, nf, cam, shift_per_disp=0.3 - 0.05 * b) for b in range(B)]
+    ctx = capi.Context(device_id=0, max_rows=2048, max_batch=B)
+    pipe = images.ImagePipeline(ctx, B, cam, mp, op, max_kp=2048, lsd=capi.lsd_params(min_length=min_len, nfeatures=nlines), max_kl=128)
+    lopts = oracle.lsd_opts(min_length=min_len, nfeatures=nlines)
+    try:
+        pattern = pipe.orb.pattern()
+        frames = [oracle_frames(oracle, seqs[b], pattern) for b in range(B)]
+        for b in range(B):
+            for fr, (left, right) in zip(frames[b], seqs[b]):
+                for side, img in (("l", left), ("r", right)):
+                    kl = oracle.lsd_detect(img, lopts)
+                    rec = np.stack([kl["sx"], kl["sy"], kl["ex"], kl["ey"], kl["angle"]], axis=1).astype(np.float32)
+                    fr["kl_" + side] = np.ascontiguousarray(rec[:, :4])
+                    fr["ldesc_" + side] = oracle.lbd_compute(img, rec, kl["num_pixels"])
+                    if side == "l":
+                        fr["ang_l"] = np.ascontiguousarray(rec[:, 4]); fr["oct_ll"] = np.zeros(len(rec), np.int32)
+        refs = [pipeline_ref.run_sequence(oracle, frames[b], cam, mp, op) for b in range(B)]
+        n_lines_used = 0
+        for k in range(nf):
+            res, counts = pipe.push_images(np.stack([seqs[b][k][0] for b in range(B)]), np.stack([seqs[b][k][1] for b in range(B)]))
+            if k == 0:
+                continue
+            for b in range(B):
+                o, r = refs[b][k - 1], res[b]
+                assert counts[b, 0] == o["n_stereo_pt"] and counts[b, 1] == o["n_stereo_ls"], (b, k, counts[b], o["n_stereo_pt"], o["n_stereo_ls"])
+                assert r["n_matched_pt"] == o["n_matched_pt"] and r["n_matched_ls"] == o["n_matched_ls"]
+                assert r["status"] == o["status"] and r["path"] == o["path"] and tuple(r["iters"]) == o["iters"]
+                assert r["n_inliers_pt"] == o["n_inliers_pt"] and r["n_inliers_ls"] == o["n_inliers_ls"]
+                T = r["T"].reshape(4, 4)
+                assert np_model.rot_angle(T[:3, :3], o["T"][:3, :3]) < 1e-4 and np.linalg.norm(T[:3, 3] - o["T"][:3, 3]) < 1e-3
+                assert np.allclose(T, o["T"], atol=1e-8)
+                n_lines_used += r["n_matched_ls"]
+        assert n_lines_used > 0
+    finally:
+        pipe.close()
+        ctx.close()
