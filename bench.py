@@ -380,10 +380,61 @@ def orb_leg(local_rank, B=256):
     return out
 
 
-def images_leg(local_rank, B=128, steps=8):
-    """SURVEY 8(f) rank 3 joined to the hot path: stereo IMAGES in, poses out, nothing through the host — the ORB point
-    front-end on 2 B KITTI-size images, its key-points ingested on the device (stvo_seq_upload_dev), then the per-frame pipeline
-    (grid stereo association, f2f, optimizePose) for B streams.  Key-points only: the LSD / LBD line front-end is not built."""
+def lsd_leg(local_rank, B=1024):
+    """SURVEY 8(f) rank 4, measured beside the hot path: the LSD key-line detector (stvo_lsd_detect_dev) on B synthetic KITTI-size
+    images resident in HBM — blur + 1.2x resize, level-line angles, pseudo-ordering (segmented radix sort), region growing +
+    rectangles (one wavefront per image), wrapper + top-N cut — and the LBD descriptors of its key-lines (stvo_lbd_compute_dev)."""
+    import torch
+    from stvo_amd import capi, synth
+    import oracle_lib
+    cols, rows, M = 1241, 376, 128
+    dev = f"cuda:{local_rank}"
+    base = [synth.make_image(500 + k, cols=cols, rows=rows) for k in range(8)]
+    imgs = np.stack([np.roll(base[b % 8], 7 * (b // 8), axis=1) for b in range(B)])
+    min_len = 0.025 * rows
+    ctx = capi.Context(device_id=local_rank, max_rows=2048, max_batch=4)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    lsd = capi.Lsd(ctx, B, cols, rows, capi.lsd_params(min_length=min_len, nfeatures=100), max_keylines=M)
+    lbd = capi.Lbd(ctx, B, cols, rows, max_keylines=M)
+    d = dict(img=torch.from_numpy(imgs).to(dev), kl=torch.zeros(B, M, 6, device=dev), resp=torch.zeros(B, M, device=dev),
+             n=torch.zeros(B, dtype=torch.int32, device=dev), desc=torch.zeros(B, M, 32, dtype=torch.uint8, device=dev))
+    try:
+        def run(with_lbd):
+            lsd.detect_dev(d["img"].data_ptr(), d["kl"].data_ptr(), d["resp"].data_ptr(), d["n"].data_ptr())
+            if with_lbd:
+                lbd.compute_dev(d["img"].data_ptr(), d["kl"].data_ptr(), d["n"].data_ptr(), d["desc"].data_ptr())
+        out = {}
+        for name, with_lbd in (("lsd", False), ("lsd_lbd", True)):
+            run(with_lbd)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                run(with_lbd)
+            torch.cuda.synchronize()
+            out[name] = (time.perf_counter() - t0) / 3
+        nl = d["n"].cpu().numpy()
+        kl = d["kl"].cpu().numpy().view(np.float32)
+        # parity of the run's own output, after the timed region: the first two images against the oracle
+        o = oracle_lib.load()
+        ok = True
+        t0 = time.perf_counter()
+        for b in (0, 1):
+            ref = o.lsd_detect(imgs[b], o.lsd_opts(min_length=min_len, nfeatures=100))
+            got = kl[b, :nl[b], :4]
+            ok = ok and len(ref) == nl[b] and np.array_equal(got, np.stack([ref["sx"], ref["sy"], ref["ex"], ref["ey"]], axis=1))
+        cpu_ms = (time.perf_counter() - t0) / 2 * 1e3
+    finally:
+        lsd.close(); lbd.close(); ctx.close()
+    return {"workload": f"{B} synthetic {cols} x {rows} images, lsd_scale 1.2, lsd_refine 0, min_line_length 0.025, lsd_nfeatures 100 (config_kitti.yaml)",
+            "images_per_s": B / out["lsd"], "ms_per_launch": out["lsd"] * 1e3, "with_lbd_images_per_s": B / out["lsd_lbd"],
+            "mean_keylines": float(nl.mean()), "parity_first_two_images": bool(ok), "oracle_ms_per_image_1_core": cpu_ms,
+            "note": "region growing is sequential per image (one wavefront each; ~0.1 s for one image): the batch is the parallelism"}
+
+
+def images_leg(local_rank, B=128, steps=8, lines=False):
+    """SURVEY 8(f) ranks 3 / 4 joined to the hot path: stereo IMAGES in, poses out, nothing through the host — the ORB point
+    front-end on 2 B KITTI-size images (lines = True: also the LSD detector + LBD descriptors), the features ingested on the device
+    (stvo_seq_upload_dev), then the per-frame pipeline (grid stereo association, f2f, optimizePose) for B streams."""
     import torch
     from stvo_amd import capi, images, synth
     from stvo_amd.ctypes_types import match_params, opt_params
@@ -398,7 +449,9 @@ def images_leg(local_rank, B=128, steps=8):
                 frames[k, side * B + b] = torch.from_numpy(np.roll(base[b % 2][k][side], 11 * (b // 2), axis=1))
     ctx = capi.Context(device_id=local_rank, max_rows=2048, max_batch=B)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    pipe = images.ImagePipeline(ctx, B, cam, match_params("kitti"), opt_params("kitti", has_lines=0), max_kp=2048, device=dev)
+    lsd_prm = capi.lsd_params(min_length=0.025 * cam["height"], nfeatures=100) if lines else None
+    pipe = images.ImagePipeline(ctx, B, cam, match_params("kitti"), opt_params("kitti", has_lines=1 if lines else 0), max_kp=2048, device=dev,
+                                lsd=lsd_prm, max_kl=128)
     order = [0, 1, 2, 3, 2, 1]  # consecutive views are always neighbours of the same scene
     try:
         for k in (0, 1):
@@ -417,10 +470,12 @@ def images_leg(local_rank, B=128, steps=8):
     finally:
         pipe.close(); ctx.close()
     return {"workload": f"{B} stereo streams of 1241 x 376 image pairs resident in HBM (two synthetic layered scenes, rolled per stream), "
-                        "orb_nfeatures 2000, one pyramid level, key-points only; per step: ORB on 2 B images -> device ingest -> grid stereo "
+                        "orb_nfeatures 2000, one pyramid level" + (", LSD key-lines (lsd_nfeatures 100) with LBD descriptors" if lines else ", key-points only") +
+                        "; per step: ORB" + (" + LSD + LBD" if lines else "") + " on 2 B images -> device ingest -> grid stereo "
                         "association -> f2f -> optimizePose", "stereo_pairs_per_s": B / dt, "ms_per_step": dt * 1e3, "streams": B,
             "mean_keypoints_per_image": nk, "committed_pose_fraction_last_step": ok, "mean_stereo_points_last_step": float(counts[:, 0].mean()),
-            "mean_matched_points_last_step": float(counts[:, 2].mean())}
+            "mean_matched_points_last_step": float(counts[:, 2].mean()), "mean_stereo_lines_last_step": float(counts[:, 1].mean()),
+            "mean_matched_lines_last_step": float(counts[:, 3].mean())}
 
 
 CORRELATED_MODELS = {
@@ -844,6 +899,8 @@ def main():
         out["reverse_check_correlated"] = correlated_leg(dev_name, rank)
         out["orb_front_end"] = orb_leg(local_rank)
         out["images_to_poses"] = images_leg(local_rank)
+        out["lsd_front_end"] = lsd_leg(local_rank)
+        out["images_to_poses_with_lines"] = images_leg(local_rank, B=256, steps=3, lines=True)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.points, args.lines)
         out["cpu_baseline_fanout"] = cpu_baseline_fanout(args.points, args.lines)
