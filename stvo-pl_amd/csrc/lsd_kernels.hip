@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void lsd_keys_kernel(LsdDev d) {
     d.keys[base + idx] = key;
 }
 
-constexpr int LSD_RING = 4096;  // the most recent region points, in LDS
+constexpr int LSD_RING = 1024;  // the most recent region points, in LDS (4 KB: the LDS must not limit the images in flight per CU)
 constexpr int LSD_GR = 2;       // sub-groups of 7 region points (63 lanes) fetched per round of the region growing
 
 // The flags / the region list are written by lane 0 and read by all lanes of the SAME wave later: workgroup-scope ordering is
