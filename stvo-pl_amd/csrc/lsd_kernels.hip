@@ -166,7 +166,12 @@ __global__ __launch_bounds__(64) void lsd_grow_kernel(LsdDev d) {
     int32_t* reg = d.reg + base;
     const double prec = d.prec;
     int n_seg = 0;
+    const bool prof = d.dbg != nullptr;
+    long long t_grow = 0, t_res = 0, t_rect = 0, n_rounds = 0, n_add = 0, n_regions = 0, n_batches = 0;
+    auto tick = [&]() -> long long { return prof ? (long long)__builtin_readcyclecounter() : 0ll; };
+    const long long t_begin = tick();
     for (int o0 = 0; o0 < npx; o0 += 64) {
+        ++n_batches;
         const uint32_t key = o0 + lane < npx ? order[o0 + lane] : LSD_NOKEY;
         if ((uint32_t)__builtin_amdgcn_readfirstlane((int)key) == LSD_NOKEY) break;  // sorted: only undefined pixels from here on
         const int q_l = (int)(key & ((1u << LSD_IDX_BITS) - 1u));
@@ -180,6 +185,8 @@ __global__ __launch_bounds__(64) void lsd_grow_kernel(LsdDev d) {
             todo &= todo - 1ull;
             const int seed = __builtin_amdgcn_readlane(q_l, j);
             // ---------------- region_grow ----------------
+            const long long tg0 = tick();
+            ++n_regions;
             const int sx0 = seed % w, sy0 = seed / w;
             double reg_angle = (double)readlane_f32(ang_l, j) * LSD_DEG2RAD;
             double sn0, cs0;
@@ -222,6 +229,8 @@ __global__ __launch_bounds__(64) void lsd_grow_kernel(LsdDev d) {
                     cand[r] = valid && u == 0 && a >= 0.f;
                     ad[r] = (double)a * LSD_DEG2RAD;
                 }
+                const long long tr0 = tick();
+                ++n_rounds;
 #pragma unroll
                 for (int r = 0; r < LSD_GR; ++r) {
                     if (7 * r >= cnt) break;  // uniform
@@ -253,13 +262,17 @@ __global__ __launch_bounds__(64) void lsd_grow_kernel(LsdDev d) {
                         next = L + 1;
                     }
                 }
+                t_res += tick() - tr0;
                 i += cnt;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // s_ring: lane 0's writes before the next round's reads
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
+            t_grow += tick() - tg0;
+            n_add += n_reg;
             if (n_reg < d.min_reg_size) continue;
             // ---------------- region2rect ----------------
+            const long long tq0 = tick();
             wave_publish();
             double X = 0.0, Y = 0.0, S = 0.0;
             for (int c0 = 0; c0 < n_reg; c0 += 64) {
@@ -333,9 +346,15 @@ __global__ __launch_bounds__(64) void lsd_grow_kernel(LsdDev d) {
                 q[0] = cx; q[1] = cy; q[2] = Ixx; q[3] = Iyy; q[4] = Ixy; q[5] = theta; q[6] = l_min; q[7] = l_max;
             }
             ++n_seg;
+            t_rect += tick() - tq0;
         }
     }
     if (lane == 0) d.n_seg[b] = n_seg;
+    if (prof && lane == 0 && b == 0) {  // tools/lsd_probe.py: the last 16 doubles of image 0's block
+        double* q = d.dbg + ((size_t)d.seg_cap - 2) * 8;
+        q[0] = (double)(tick() - t_begin); q[1] = (double)t_grow; q[2] = (double)t_res; q[3] = (double)t_rect; q[4] = (double)n_rounds;
+        q[5] = (double)n_add; q[6] = (double)n_regions; q[7] = (double)n_batches;
+    }
 }
 
 // LSDDetectorC::detectImpl's loop over the segments of the (single) octave (:254-303) and the cut of stereoFrame.cpp:231-240

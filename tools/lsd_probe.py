@@ -34,6 +34,8 @@ for b in range(min(B, 2)):
         for c, name in enumerate(("cx", "cy", "Ixx", "Iyy", "Ixy", "theta", "l_min", "l_max")):
             print(f"   {name}: {int((gd[:m2, c] != od[:m2, c]).sum())} of {m2} differ")
         o.lib.orc_lsd_set_debug(None)
+        q = gd[8190]
+        print(f"   image 0, cycles: total {q[0]:.0f}  grow {q[1]:.0f} (of which resolving {q[2]:.0f})  rect {q[3]:.0f} | rounds {q[4]:.0f}  pixels added {q[5]:.0f}  regions {q[6]:.0f}  batches {q[7]:.0f}")
 t0 = time.perf_counter()
 for _ in range(a.iters):
     lsd.detect(imgs)
