@@ -534,8 +534,9 @@ __global__ __launch_bounds__(BLOCK + 64, 2) void pose_kernel(PoseArgs a) {  // >
     // priority so its critical path is not stretched by the co-resident popcount waves.
     __builtin_amdgcn_s_setprio(3);
     if (a.wait_flag) {  // results of another stream (PoseArgs::wait_flag): normally long there — one L2 round trip
-        if (threadIdx.x == 0)
-            while ((int)(__hip_atomic_load(a.wait_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - a.wait_value) < 0) __builtin_amdgcn_s_sleep(8);
+        if (threadIdx.x == 0)  // bounded (~2 s): a signal that never comes (a failed launch on the other stream) must not hang the device
+            for (int spin = 0; spin < (1 << 23) && (int)(__hip_atomic_load(a.wait_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - a.wait_value) < 0; ++spin)
+                __builtin_amdgcn_s_sleep(8);
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
