@@ -83,9 +83,30 @@ PM_HD void inverse_se3(const double* T, double* Ti) {
 struct SinCos {
     double s, c;
 };
+// theta = |w| of a pose increment: a fraction of a radian in practice.  Up to 64 rad: Cody-Waite reduction by pi / 2 (two FMAs) + the
+// fdlibm kernel polynomials, ~45 instructions, within an ulp of libm's result (the pose tolerance is 1e-4 rad; the same routine
+// restated in oracle/stvo_lsd_oracle.c: orc_sincos_det) — the library call behind it costs ~200 and runs at every iteration of the
+// serial section.  Beyond 64 rad (diverged iterations) the library call, for its exact argument reduction.
 static __device__ __noinline__ SinCos sincos_call(double x) {
     SinCos r;
-    sincos(x, &r.s, &r.c);
+    if (!(fabs(x) <= 64.0)) {
+        sincos(x, &r.s, &r.c);
+        return r;
+    }
+    const double PIO2_HI = 1.57079632679489655800e+00, PIO2_LO = 6.12323399573676603587e-17, TWO_OVER_PI = 6.36619772367581382433e-01;
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double k = __builtin_rint(x * TWO_OVER_PI);
+    double t = __builtin_fma(-k, PIO2_HI, x);
+    t = __builtin_fma(-k, PIO2_LO, t);
+    const double z = t * t;
+    const double sn = t + (z * t) * (S1 + z * (S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)))));
+    const double cs = 1.0 - (0.5 * z - z * (z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))))));
+    const int q = (int)k & 3;
+    r.s = q == 0 ? sn : (q == 1 ? cs : (q == 2 ? -sn : -cs));
+    r.c = q == 0 ? cs : (q == 1 ? -sn : (q == 2 ? -cs : sn));
     return r;
 }
 static __device__ __noinline__ double acos_call(double x) { return acos(x); }
