@@ -158,6 +158,9 @@ struct PoseArgs {
     //               runs) to pinned host memory and then publishes fetch_value in *fetch_flag (pinned, system scope).
     const unsigned* wait_flag;
     unsigned wait_value;
+    // lazy_eig != 0 (latency kernel only; the caller reads the results through stvo_seq_read): cov_eig is left to the reader, flagged in
+    // stvo_pose_result::path (pose_block.h: PATH_EIG_PENDING)
+    int lazy_eig;
     const uint4* fetch_src;
     uint4* fetch_dst;
     unsigned fetch_n16;
@@ -165,6 +168,8 @@ struct PoseArgs {
     unsigned fetch_value;
 };
 constexpr int STVO_POSE_QTAB = 16;
+// internal flag in stvo_pose_result::path (never leaves the library): the eigenvalues of `cov` are still to be computed by the reader
+constexpr int PATH_EIG_PENDING = 1 << 30;
 // may launch_pose honour wait_flag / fetch_* for a batch of B frame pairs?  (few workgroups: the kernels they wait for always find CUs)
 bool pose_inline_sync_ok(int B);
 // *flag = value (release, device scope) once everything enqueued on `s` so far has completed

@@ -638,9 +638,28 @@ __device__ __forceinline__ void t0_is_good_fast(PoseSh* sh, const double* DT, do
     t0_is_good(sh, DT, err);
 }
 
-__device__ __forceinline__ void t0_commit(PoseSh* sh, stvo_pose_result* out, int status, int path, int it0, int it1) {
+// lazy_eig (single-stream operation, results read by stvo_seq_read): the verdict of :372 comes from the certificate (exact when it
+// says "good"; anything it cannot certify takes the eigen-decomposition here), and DT_cov_eig — an output, not an input of anything on
+// the path — is left to the host, which runs the same routine in ~2 us: the decomposition is ~3.5 k dependent instructions, 8 us on
+// one lane at the very end of the frame's chain.
+__device__ __forceinline__ void t0_commit(PoseSh* sh, stvo_pose_result* out, int status, int path, int it0, int it1, bool lazy_eig = false) {
     // :372-391
-    t0_is_good(sh, sh->DT, sh->err_out);
+    bool eig_pending = false;
+    if (lazy_eig) {
+        double C[36];
+#pragma unroll
+        for (int i = 0; i < 36; ++i) C[i] = sh->cov[i];
+        if (sh->err_out < 0.0 || sh->err_out > 1.0 || !pm::all_finite16(sh->DT)) {
+            sh->good = 0;  // (the eigenvalues do not matter: the outputs of a rejected solution are zeros)
+        } else if (pm::spd_unit_certificate(C) == 1) {
+            sh->good = 1;
+            eig_pending = true;
+        } else {
+            t0_is_good(sh, sh->DT, sh->err_out);
+        }
+    } else {
+        t0_is_good(sh, sh->DT, sh->err_out);
+    }
     double DT[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -658,7 +677,8 @@ __device__ __forceinline__ void t0_commit(PoseSh* sh, stvo_pose_result* out, int
 #pragma unroll
         for (int i = 0; i < 36; ++i) out->cov[i] = sh->cov[i];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) out->cov_eig[i] = sh->eig[i];
+        for (int i = 0; i < 6; ++i) out->cov_eig[i] = eig_pending ? 0.0 : sh->eig[i];
+        if (eig_pending) path |= PATH_EIG_PENDING;
         out->err = sh->err_out;
     } else {
 #pragma unroll

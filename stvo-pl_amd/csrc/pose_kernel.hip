@@ -490,7 +490,7 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_hist)[Block
 
     {
         const long long tq3 = tick();
-        if (t0) t0_commit(sh, a.results + f, status, path, it0, it1);
+        if (t0) t0_commit(sh, a.results + f, status, path, it0, it1, a.lazy_eig != 0);
         tprof[2] += tick() - tq3;
     }
     if (prof && t0) {

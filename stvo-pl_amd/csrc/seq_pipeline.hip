@@ -1307,6 +1307,8 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl) {
             a.wait_flag = s->d_join_flag;
             a.wait_value = s->join_epoch;
         }
+        // single-stream operation: the eigenvalues of the committed covariance (an output only) are computed by stvo_seq_read
+        a.lazy_eig = (inline_sync && s->zero_copy && stvo::dbg().pose_kernel != 4) ? 1 : 0;
         if (s->fetch_by_pose) {
             a.fetch_src = reinterpret_cast<const uint4*>(s->m12s_p);
             a.fetch_dst = reinterpret_cast<uint4*>(s->fetch_host);
@@ -1420,8 +1422,13 @@ int stvo_seq_read(stvo_seq* s, stvo_pose_result* results, int32_t* counts) {
     const int32_t* hn = reinterpret_cast<const int32_t*>(OH + res_bytes);
     for (int b = 0; b < B; ++b) {
         if (results) {
-            if (track)
+            if (track) {
                 results[b] = hr[b];
+                if (results[b].path & stvo::PATH_EIG_PENDING) {  // PoseArgs::lazy_eig: SelfAdjointEigenSolver(DT_cov).eigenvalues(), :379-380
+                    pm::eig6_ql(results[b].cov, results[b].cov_eig);
+                    results[b].path &= ~stvo::PATH_EIG_PENDING;
+                }
+            }
             else
                 std::memset(&results[b], 0, sizeof(stvo_pose_result));
         }
