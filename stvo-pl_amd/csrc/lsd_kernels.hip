@@ -40,6 +40,7 @@ constexpr double LSD_3_2_PI = (3 * LSD_PI) / 2;
 constexpr double LSD_2_PI = 2 * LSD_PI;
 constexpr uint32_t LSD_NOKEY = 0xFFFFFFFFu;
 constexpr int LSD_IDX_BITS = 20;  // pixel index inside a sort key: scaled images up to 2^20 pixels
+constexpr int LSD_ROWS = 16;      // image rows per workgroup of the per-pixel kernels
 
 // orc_sincos_det (oracle/stvo_lsd_oracle.c), operation for operation
 __device__ __forceinline__ void sincos_det(double x, double& s, double& c) {
@@ -86,12 +87,17 @@ struct LsdDev {
 
 // ll_angle: one thread per pixel of the scaled image
 __global__ __launch_bounds__(256) void lsd_gradient_kernel(LsdDev d) {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
-    if (x >= d.w) return;
-    const size_t base = (size_t)b * d.w * d.h, q = base + (size_t)y * d.w + x;
+    const int x = blockIdx.x * 256 + threadIdx.x, b = blockIdx.z;
+    const bool in_row = x < d.w;  // (no early return: the whole wave takes part in the reduction below)
+    const size_t base = (size_t)b * d.w * d.h;
+    int kw = -1;
+    // LSD_ROWS rows per workgroup: one row each made 2.8 M workgroups per 1024 images and the launch dispatch-bound (25 ms)
+    for (int y = blockIdx.y * LSD_ROWS; y < min((int)(blockIdx.y + 1) * LSD_ROWS, d.h); ++y) {
+    const size_t q = base + (size_t)y * d.w + (in_row ? x : 0);
     float ang = -1.f;
     float2 cs = make_float2(0.f, 0.f);
     double norm = 0.0;
+    int kdef = -1;
     if (x < d.w - 1 && y < d.h - 1) {
         const uint8_t* r0 = d.scaled + base + (size_t)y * d.w + x;
         const uint8_t* r1 = r0 + d.w;
@@ -105,30 +111,40 @@ __global__ __launch_bounds__(256) void lsd_gradient_kernel(LsdDev d) {
             double s, c;
             sincos_det((double)(float)a, s, c);
             cs = make_float2((float)c, (float)s);
-            atomicMax(&d.kmax[b], k);
+            kdef = k;
         }
     }
-    d.ang[q] = ang;
-    d.csn[q] = cs;
-    d.mod[q] = norm;
-    d.used[q] = 0;
+    kw = max(kw, kdef);
+    if (in_row) {
+        d.ang[q] = ang;
+        d.csn[q] = cs;
+        d.mod[q] = norm;
+        d.used[q] = 0;
+    }
+    }
+    // the image's largest squared gradient: one atomic per wave, and only when it can raise the value
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) kw = max(kw, __shfl_xor(kw, off, 64));
+    if ((threadIdx.x & 63) == 0 && kw >= 0 && kw > __hip_atomic_load(&d.kmax[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&d.kmax[b], kw);
 }
 
 __global__ __launch_bounds__(256) void lsd_keys_kernel(LsdDev d) {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+    const int x = blockIdx.x * 256 + threadIdx.x, b = blockIdx.z;
     if (x >= d.w) return;
     const size_t base = (size_t)b * d.w * d.h;
-    const uint32_t idx = (uint32_t)(y * d.w + x);
     const int km = d.kmax[b];
     const double max_grad = km >= 0 ? sqrt((double)km / 4.0) : -1.0;
     const double bin_coef = max_grad > 0 ? (double)(d.n_bins - 1) / max_grad : 0.0;
-    uint32_t key = LSD_NOKEY;
-    if (d.ang[base + idx] >= 0.f) {  // undefined pixels never seed a region: they sort to the end
-        int bin = (int)(d.mod[base + idx] * bin_coef);
-        bin = bin < 0 ? 0 : (bin >= d.n_bins ? d.n_bins - 1 : bin);
-        key = ((uint32_t)(d.n_bins - 1 - bin) << LSD_IDX_BITS) | idx;
+    for (int y = blockIdx.y * LSD_ROWS; y < min((int)(blockIdx.y + 1) * LSD_ROWS, d.h); ++y) {
+        const uint32_t idx = (uint32_t)(y * d.w + x);
+        uint32_t key = LSD_NOKEY;
+        if (d.ang[base + idx] >= 0.f) {  // undefined pixels never seed a region: they sort to the end
+            int bin = (int)(d.mod[base + idx] * bin_coef);
+            bin = bin < 0 ? 0 : (bin >= d.n_bins ? d.n_bins - 1 : bin);
+            key = ((uint32_t)(d.n_bins - 1 - bin) << LSD_IDX_BITS) | idx;
+        }
+        d.keys[base + idx] = key;
     }
-    d.keys[base + idx] = key;
 }
 
 constexpr int LSD_RING = 1024;  // the most recent region points, in LDS (4 KB: the LDS must not limit the images in flight per CU)
@@ -483,7 +499,7 @@ int lsd_enqueue(stvo_lsd* o, const uint8_t* images, stvo_keyline* lines, float* 
     d.scaled = src;
     d.lines = lines; d.response = response; d.n_lines = n_lines;
     HIP_TRY(ctx, hipMemsetAsync(d.kmax, 0xFF, (size_t)d.B * 4, s));
-    const dim3 grid((d.w + 255) / 256, d.h, d.B);
+    const dim3 grid((d.w + 255) / 256, (d.h + stvo::LSD_ROWS - 1) / stvo::LSD_ROWS, d.B);
     hipLaunchKernelGGL(stvo::lsd_gradient_kernel, grid, dim3(256), 0, s, d);
     hipLaunchKernelGGL(stvo::lsd_keys_kernel, grid, dim3(256), 0, s, d);
     size_t tb = o->sort_tmp_bytes;
