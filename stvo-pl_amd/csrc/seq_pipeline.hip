@@ -987,6 +987,7 @@ int stvo_seq_upload(stvo_seq* s, int slot, const stvo_frame_features* f) {
     if (s->stage_upload[sb] > s->uploads_done) {  // everything enqueued so far covers that copy
         HIP_TRY(ctx, hipEventRecord(s->ev_stage[sb], ctx->stream));
         HIP_TRY(ctx, hipEventSynchronize(s->ev_stage[sb]));
+        if (s->line_stream) HIP_TRY(ctx, hipStreamSynchronize(s->line_stream));  // (its share of a split copy reads the same block)
         s->uploads_done = s->uploads;
     }
     char* H = s->raw_host[sb];
