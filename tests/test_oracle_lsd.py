@@ -1,0 +1,87 @@
+"""CPU checks of the LSD oracle (oracle/stvo_lsd_oracle.c) — the restatement of cv::LineSegmentDetector + LSDDetectorC::detectImpl + the
+top-N cut of StereoFrame::detectLineFeatures that the HIP detector is compared with on the GPU (tests/test_gpu_lsd.py).  Parity with
+OpenCV itself is unpinned (no OpenCV here, no vector in the reference); what can be checked on the CPU is that the restatement behaves
+like a line-segment detector with the wrapper's contract."""
+import numpy as np
+
+from stvo_amd import synth
+
+
+def test_sincos_det_is_within_an_ulp(oracle):
+    xs = np.concatenate([np.linspace(-7.0, 10.0, 3001), [0.0, np.pi / 2, np.pi, 3 * np.pi / 2, 2 * np.pi, 1e-9, -1e-9]])
+    for x in xs:
+        s, c = oracle.sincos_det(x)
+        assert abs(s - np.sin(x)) <= 2.3e-16 and abs(c - np.cos(x)) <= 2.3e-16
+
+
+def test_rectangle_edges_are_found(oracle):
+    """A bright rectangle on a flat background: exactly its four edges, each within a pixel of where it was drawn, end points ordered
+    so that the brighter side lies to the same hand (the level-line direction), lengths close to the sides."""
+    img = np.full((200, 320), 100, np.uint8)
+    img[50:150, 80:240] = 200
+    seg = oracle.lsd_segments(img, oracle.lsd_opts())
+    assert len(seg) == 4
+    horiz = sorted([s for s in seg if abs(s[1] - s[3]) < 1.0], key=lambda s: s[1])
+    vert = sorted([s for s in seg if abs(s[0] - s[2]) < 1.0], key=lambda s: s[0])
+    assert len(horiz) == 2 and len(vert) == 2
+    assert abs(horiz[0][1] - 49.5) < 1.0 and abs(horiz[1][1] - 149.5) < 1.0
+    assert abs(vert[0][0] - 79.5) < 1.0 and abs(vert[1][0] - 239.5) < 1.0
+    for s in horiz:
+        assert abs(abs(s[0] - s[2]) - 160) < 4
+    for s in vert:
+        assert abs(abs(s[1] - s[3]) - 100) < 4
+    # opposite edges run in opposite directions
+    assert (horiz[0][2] - horiz[0][0]) * (horiz[1][2] - horiz[1][0]) < 0 and (vert[0][3] - vert[0][1]) * (vert[1][3] - vert[1][1]) < 0
+
+
+def test_flat_and_scale_one(oracle):
+    assert len(oracle.lsd_segments(np.full((120, 160), 77, np.uint8), oracle.lsd_opts())) == 0
+    img = np.full((120, 160), 60, np.uint8)
+    img[30:90, 40:120] = 180
+    for scale in (1.0, 0.8, 1.2):
+        seg = oracle.lsd_segments(img, oracle.lsd_opts(scale=scale))
+        assert len(seg) == 4, scale
+
+
+def test_wrapper_fields_and_top_n(oracle):
+    """min_length, response = length / max(cols, rows), LineIterator count, angle = atan2 of the end points, and the cut: the
+    lsd_nfeatures longest lines by descending response, ties in detection order; without the cut: detection order."""
+    img = synth.make_image(321, 400, 240, n_rects=120, n_discs=30)
+    cols, rows = 400, 240
+    full = oracle.lsd_detect(img, oracle.lsd_opts(min_length=0.0, nfeatures=0))
+    assert len(full) > 60
+    d = np.hypot((full["sx"] - full["ex"]).astype(np.float64), (full["sy"] - full["ey"]).astype(np.float64)).astype(np.float32)
+    assert np.array_equal(full["length"], d)
+    assert np.array_equal(full["response"], full["length"] / np.float32(max(cols, rows)))
+    assert np.allclose(full["angle"], np.arctan2((full["ey"] - full["sy"]).astype(np.float64), (full["ex"] - full["sx"]).astype(np.float64)), atol=1e-6)
+    ix0, iy0, ix1, iy1 = (np.rint(full[k]).astype(int) for k in ("sx", "sy", "ex", "ey"))   # numpy rounds half to even like cvRound
+    assert np.array_equal(full["num_pixels"], np.maximum(abs(ix1 - ix0), abs(iy1 - iy0)) + 1)
+    assert (full["sx"] >= 0).all() and (full["ex"] <= cols - 1).all() and (full["sy"] >= 0).all() and (full["ey"] <= rows - 1).all()
+    # min_length: exactly the lines longer than it, same order
+    kept = oracle.lsd_detect(img, oracle.lsd_opts(min_length=12.0, nfeatures=0))
+    sel = full[full["length"].astype(np.float64) > 12.0]
+    assert kept.tobytes() == sel.tobytes()
+    # the cut
+    n = 25
+    top = oracle.lsd_detect(img, oracle.lsd_opts(min_length=0.0, nfeatures=n))
+    order = np.argsort(-full["response"], kind="stable")[:n]
+    assert top.tobytes() == full[order].tobytes()
+    assert np.all(np.diff(top["response"]) <= 0)
+
+
+def test_segments_lie_on_edges(oracle):
+    """The long segments of a synthetic scene lie on intensity edges: the gradient magnitude next to them is several times the image's
+    MEDIAN gradient (the background is smooth; the rectangles' borders are the edges)."""
+    img = synth.make_image(77, 320, 200, n_rects=60, n_discs=0, noise=1.0)
+    seg = oracle.lsd_segments(img, oracle.lsd_opts())
+    gy, gx = np.gradient(img.astype(np.float64))
+    mag = np.hypot(gx, gy)
+    long_ones = [s for s in seg if np.hypot(s[0] - s[2], s[1] - s[3]) > 15]
+    assert len(long_ones) > 20
+    hits = 0
+    for s in long_ones:
+        t = np.linspace(0.1, 0.9, 20)
+        xs = np.clip(np.rint(s[0] + t * (s[2] - s[0])).astype(int), 1, 318); ys = np.clip(np.rint(s[1] + t * (s[3] - s[1])).astype(int), 1, 198)
+        nb = np.max([mag[ys + dy, xs + dx] for dy in (-1, 0, 1) for dx in (-1, 0, 1)], axis=0)
+        hits += np.median(nb) > 5 * np.median(mag)
+    assert hits >= 0.95 * len(long_ones)
