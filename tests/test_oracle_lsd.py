@@ -85,3 +85,13 @@ def test_segments_lie_on_edges(oracle):
         nb = np.max([mag[ys + dy, xs + dx] for dy in (-1, 0, 1) for dx in (-1, 0, 1)], axis=0)
         hits += np.median(nb) > 5 * np.median(mag)
     assert hits >= 0.95 * len(long_ones)
+
+
+def test_oracle_output_is_pinned(oracle):
+    """The restatement against its own committed output (tests/golden/make_lsd_golden.py): a regression pin, not a reference vector."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lsd_oracle_320x200.npz"))
+    seg = oracle.lsd_segments(g["img"], oracle.lsd_opts())
+    assert np.array_equal(seg, g["segments"])
+    kl = oracle.lsd_detect(g["img"], oracle.lsd_opts(min_length=0.025 * 200, nfeatures=50))
+    assert kl.tobytes() == g["keylines"].tobytes()
