@@ -542,6 +542,25 @@ __global__ __launch_bounds__(BL_T) void orb_blur_kernel(OrbDev o, BlurK kk) {
     }
 }
 
+// sine and cosine of a float angle in [0, 2 pi] in double precision (the routine of lsd_kernels.hip / oracle/stvo_lsd_oracle.c)
+__device__ __forceinline__ void orb_sincos(float xf, double& s, double& c) {
+    const double x = (double)xf;
+    const double PIO2_HI = 1.57079632679489655800e+00, PIO2_LO = 6.12323399573676603587e-17, TWO_OVER_PI = 6.36619772367581382433e-01;
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double k = __builtin_rint(x * TWO_OVER_PI);
+    double r = __builtin_fma(-k, PIO2_HI, x);
+    r = __builtin_fma(-k, PIO2_LO, r);
+    const double z = r * r;
+    const double sn = r + (z * r) * (S1 + z * (S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)))));
+    const double cs = 1.0 - (0.5 * z - z * (z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))))));
+    const int q = (int)k & 3;
+    s = q == 0 ? sn : (q == 1 ? cs : (q == 2 ? -sn : -cs));
+    c = q == 0 ? cs : (q == 1 ? -sn : (q == 2 ? -cs : sn));
+}
+
 struct Umax {
     int u[ORB_HP + 2];
 };
@@ -567,6 +586,19 @@ __global__ __launch_bounds__(256) void orb_describe_kernel(OrbDev o, Umax um) {
     const int b = (kq / bpi) * 8 + xcd, kb = kq % bpi;
     if (b >= o.B) return;
     const int lane = threadIdx.x & 63, l = lane & 15;
+    // the circular patch as byte masks of the row words: row |dy| keeps columns |u| <= umax[|dy|] (byte k of word w is column 4 w + k - 16)
+    __shared__ uint32_t s_mask[ORB_HP + 1][IC_PW];
+    if (threadIdx.x < (ORB_HP + 1) * IC_PW) {
+        const int v = threadIdx.x >> 3, w = threadIdx.x & 7;
+        uint32_t m = 0u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int u = 4 * w + k - 16;
+            if ((u < 0 ? -u : u) <= um.u[v]) m |= 0xFFu << (8 * k);
+        }
+        s_mask[v][w] = m;
+    }
+    __syncthreads();
     const int n = o.n_kp[b];
     const int k_first = kb * DESC_KP_PER_WG + (threadIdx.x >> 6) * 4;
     if (k_first >= n) return;  // wave-uniform
@@ -595,26 +627,44 @@ __global__ __launch_bounds__(256) void orb_describe_kernel(OrbDev o, Umax um) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // ICAngles: lane l owns columns l - 15 and l + 1 of the circular patch; integer moments, so the summation order is free
+    // the blurred patch is requested NOW, into registers (25 words per lane), and stored to LDS behind the moments: its memory round
+    // trip runs beside the computation instead of after it
+    constexpr int BW_N = (DESC_PH * DESC_PW + 15) / 16;
+    uint32_t bw[BW_N];
+    {
+        const uint8_t* blur_lo = o.blur + base;
+        const uint8_t* blur_hi = o.blur + base + (size_t)o.rows * o.cols - 4;
+        const uint8_t* org = o.blur + base + (size_t)(y - DESC_R) * o.cols + (x - 20);
+#pragma unroll
+        for (int j = 0; j < BW_N; ++j) {
+            const int i = l + 16 * j;
+            const int r = i / DESC_PW, w = i - r * DESC_PW;
+            const uint8_t* p = org + (size_t)r * o.cols + 4 * w;
+            p = p < blur_lo ? blur_lo : (p > blur_hi ? blur_hi : p);  // (i beyond the patch: a clamped, unused word)
+            bw[j] = *reinterpret_cast<const u32_unaligned*>(p);
+        }
+    }
+    // ICAngles: lane l owns ROWS l and l + 16 of the patch (dy = row - 15).  Integer moments, so the summation order is free: a row is 8
+    // words — masked to the disc, then m10 += sum u I and the row sum for m01 come from byte dot products (v_dot4_u32_u8: weights u + 16
+    // and 1) instead of 31 byte loads per column (~70 instead of ~300 instructions per lane)
     int m10 = 0, m01 = 0;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        const int u_raw = h == 0 ? l - ORB_HP : l + 1;
-        const bool col_ok = u_raw <= ORB_HP;
-        const int u = col_ok ? u_raw : ORB_HP;
-        const int au = u < 0 ? -u : u;
-        const uint8_t* c = patch8 + ORB_HP * (IC_PW * 4) + (16 + u);  // centre row, column x + u
-        int s10 = c[0], s01 = 0;
+        const int r = l + 16 * h;
+        const bool row_ok = r < IC_PH;
+        const int dy = r - ORB_HP, ady = dy < 0 ? -dy : dy;
+        const uint32_t* row = patch + (row_ok ? r : 0) * IC_PW;
+        const uint32_t* msk = s_mask[row_ok ? ady : 0];
+        uint32_t s1 = 0u, su = 0u;
 #pragma unroll
-        for (int v = 1; v <= ORB_HP; ++v) {
-            const int vp = c[v * (IC_PW * 4)], vm = c[-v * (IC_PW * 4)];
-            const bool in = au <= um.u[v];
-            s10 += in ? vp + vm : 0;
-            s01 += in ? v * (vp - vm) : 0;
+        for (int w = 0; w < IC_PW; ++w) {
+            const uint32_t W = row[w] & msk[w];
+            s1 = __builtin_amdgcn_udot4(W, 0x01010101u, s1, false);
+            su = __builtin_amdgcn_udot4(W, 0x03020100u + 0x04040404u * (uint32_t)w, su, false);
         }
-        if (col_ok) {
-            m10 += u * s10;
-            m01 += s01;
+        if (row_ok) {
+            m10 += (int)su - 16 * (int)s1;
+            m01 += dy * (int)s1;
         }
     }
 #pragma unroll
@@ -627,20 +677,18 @@ __global__ __launch_bounds__(256) void orb_describe_kernel(OrbDev o, Umax um) {
     // the blurred patch replaces the image patch (every lane of the group is past its reads: the shuffles above synchronise)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    {
-        const uint8_t* blur_lo = o.blur + base;
-        const uint8_t* blur_hi = o.blur + base + (size_t)o.rows * o.cols - 4;
-        const uint8_t* org = o.blur + base + (size_t)(y - DESC_R) * o.cols + (x - 20);
-        for (int i = l; i < DESC_PH * DESC_PW; i += 16) {
-            const int r = i / DESC_PW, w = i - r * DESC_PW;
-            const uint8_t* p = org + (size_t)r * o.cols + 4 * w;
-            p = p < blur_lo ? blur_lo : (p > blur_hi ? blur_hi : p);
-            patch[i] = *reinterpret_cast<const u32_unaligned*>(p);
-        }
+#pragma unroll
+    for (int j = 0; j < BW_N; ++j) {
+        const int i = l + 16 * j;
+        if (i < DESC_PH * DESC_PW) patch[i] = bw[j];
     }
     // computeOrbDescriptors, WTA_K = 2: lane l evaluates tests 16 l .. 16 l + 15 = bytes 2 l, 2 l + 1 of the descriptor
     const float rad = ang * (float)(3.14159265358979323846 / 180.0);
-    const float a = (float)cos((double)rad), sb = (float)sin((double)rad);
+    // (float)cos((double)rad), (float)sin((double)rad): one Cody-Waite + kernel-polynomial evaluation (within an ulp of the library's
+    // double results, i.e. the same floats except on rounding ties) instead of two library calls of ~100 instructions each
+    double sd, cd;
+    orb_sincos(rad, sd, cd);
+    const float a = (float)cd, sb = (float)sd;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
