@@ -95,3 +95,27 @@ def test_oracle_output_is_pinned(oracle):
     assert np.array_equal(seg, g["segments"])
     kl = oracle.lsd_detect(g["img"], oracle.lsd_opts(min_length=0.025 * 200, nfeatures=50))
     assert kl.tobytes() == g["keylines"].tobytes()
+
+
+def test_detector_core_against_the_numpy_restatement(oracle):
+    """tests/np_lsd.py — an independent statement of the detector core written from the published algorithm — gives the same segments,
+    bit for bit and in the same order, as oracle/stvo_lsd_oracle.c at scale 1 (small images: it runs plain Python loops)."""
+    import np_lsd
+    rng = np.random.default_rng(5)
+    total = 0
+    for k in range(4):
+        img = np.full((72, 104), 90.0)
+        for _ in range(6):
+            w, h = rng.integers(10, 50), rng.integers(8, 40)
+            x0, y0 = rng.integers(-5, 95), rng.integers(-5, 65)
+            img[max(y0, 0):max(y0 + h, 0), max(x0, 0):max(x0 + w, 0)] = rng.uniform(20, 235)
+        if k >= 2:   # slanted edges and texture: regions whose angle drifts while they grow
+            yy, xx = np.mgrid[0:72, 0:104]
+            img[(xx * 0.6 + yy * 0.8) % 37 < 11] += 55
+            img += rng.normal(0, 2.5, img.shape)
+        img = np.clip(np.rint(img), 0, 255).astype(np.uint8)
+        ref = oracle.lsd_segments(img, oracle.lsd_opts(scale=1.0))
+        got = np_lsd.segments(img)
+        assert got.shape == ref.shape and np.array_equal(got, ref), k
+        total += len(ref)
+    assert total > 30
