@@ -14,6 +14,7 @@ struct DebugSwitches {
     int pose2p_nw;       // STVO_POSE2P_NW       waves per frame pair of the batch kernel (2 or 4)
     int pose_prof;       // STVO_POSE_PROF       in-kernel phase ticks (tools/pose_probe.py)
     int pose_lds_t;      // STVO_POSE_LDS_T      0: pose_kernel.hip's throughput variant without its partial LDS record cache
+    int pose_los;        // STVO_POSE_LOS        0: the key-lines of pose_kernel.hip always with the worker waves (never the solver wave)
     int knn_mfma;        // STVO_KNN_MFMA        0: VALU matcher (K1 + K1v), else query blocks per wave of K1m
     int knn_nseg;        // STVO_KNN_NSEG        train segments per query tile
     int seq_graph;       // STVO_SEQ_GRAPH       1: hipGraph replay of the per-frame chain

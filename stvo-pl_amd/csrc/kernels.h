@@ -161,6 +161,9 @@ struct PoseArgs {
     // lazy_eig != 0 (latency kernel only; the caller reads the results through stvo_seq_read): cov_eig is left to the reader, flagged in
     // stvo_pose_result::path (pose_block.h: PATH_EIG_PENDING)
     int lazy_eig;
+    // lines_on_solver != 0 (set by launch_pose for the latency kernel; STVO_POSE_LOS=0 clears it): frame pairs with at most 64 LPT
+    // key-lines have them evaluated by the solver wave (pose_kernel.hip)
+    int lines_on_solver;
     const uint4* fetch_src;
     uint4* fetch_dst;
     unsigned fetch_n16;

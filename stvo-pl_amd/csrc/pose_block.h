@@ -97,10 +97,12 @@ struct BlockOps {
     // Inside a wave: 28 values -> 14 (fold32) -> 7 (fold16) per lane, then a 16-lane row scan of those 7; row r
     // ends up with the wave totals of values 7r .. 7r+6 in its last lane.  147 VALU ops instead of the 504 of 28
     // independent 64-lane scans; fixed association order => bit-reproducible.
+    // sc ("the solver contributes", block-uniform; pose_kernel.hip only): the solver wave owns features too — the key-lines of a
+    // frame pair with few of them — and leaves its partial results in row NW of `red` / `ired`, which then have NW + 1 rows.
     template <bool W>
-    static __device__ __forceinline__ void sum28_fold(double* acc, double (*red)[28]) {
-        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        if (W) {
+    static __device__ __forceinline__ void sum28_fold(double* acc, double (*red)[28], bool sc = false) {
+        const int lane = threadIdx.x & 63, wv = W ? (int)(threadIdx.x >> 6) : NW;
+        if (W || sc) {
             double s14[14], s7[7];
 #pragma unroll
             for (int k = 0; k < 14; ++k) s14[k] = fold32(acc[k], acc[14 + k]);
@@ -118,7 +120,7 @@ struct BlockOps {
         }
     }
     template <bool W>
-    static __device__ __forceinline__ void sum28_finish(double (*red)[28], PoseSh* sh) {
+    static __device__ __forceinline__ void sum28_finish(double (*red)[28], PoseSh* sh, bool sc = false) {
         const int lane = threadIdx.x & 63;
         __syncthreads();
         if (!W) {
@@ -126,6 +128,7 @@ struct BlockOps {
                 double s = red[0][lane];
 #pragma unroll
                 for (int w = 1; w < NW; ++w) s += red[w][lane];
+                if (sc) s += red[NW][lane];
                 sh->tot[lane] = s;
             }
             // tot[] is consumed by lane 0 of THIS wave only (t0_unpack), so a wave-level fence is enough; the
@@ -159,9 +162,9 @@ struct BlockOps {
     }
 
     template <bool W>
-    static __device__ __forceinline__ int sum_int(int v, int* ired) {
-        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        if (W) {
+    static __device__ __forceinline__ int sum_int(int v, int* ired, bool sc = false) {
+        const int lane = threadIdx.x & 63, wv = W ? (int)(threadIdx.x >> 6) : NW;
+        if (W || sc) {
             const int s = wave_sum_i(v);
             if (lane == 0) ired[wv] = s;
         }
@@ -169,6 +172,7 @@ struct BlockOps {
         int t = 0;
 #pragma unroll
         for (int w = 0; w < NW; ++w) t += ired[w];
+        if (sc) t += ired[NW];
         __syncthreads();
         return t;
     }
@@ -188,7 +192,7 @@ struct BlockOps {
     // Scratch S (HIST_W * 2 words): [set][rot][64] histograms, then the AND / OR words of the waves.
     static constexpr int HIST_W = 260;
     static constexpr int SEL_HW = 64, SEL_PART = 6 * SEL_HW;  // words per histogram; word offset of the AND / OR exchange
-    static_assert(SEL_PART * 4 % 8 == 0 && SEL_PART + 8 * NWORK <= 2 * HIST_W, "selection scratch");
+    static_assert(SEL_PART * 4 % 8 == 0 && SEL_PART + 8 * (NWORK + 1) <= 2 * HIST_W, "selection scratch");
 
     static __device__ __forceinline__ int wave_incl_scan_i(int v) {
         v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);  // row_shr:1
@@ -251,9 +255,10 @@ struct BlockOps {
     // (block-uniform): the set is not empty — an inactive set costs nothing and leaves its output alone.  xchg: two LDS words.
     template <int NA, int NB, bool W, typename K, int BITS>
     static __device__ __forceinline__ void select2(const K* ka, unsigned ma, int ktha, bool acta, const K* kb, unsigned mb, int kthb, bool actb,
-                                                   unsigned* S, unsigned long long* xchg, int& rot, K& outa, K& outb) {
+                                                   unsigned* S, unsigned long long* xchg, int& rot, K& outa, K& outb, bool sc = false) {
         static_assert(BITS == 32 || BITS == 64, "32- or 64-bit keys");
         const int tid = threadIdx.x, wv = tid >> 6;
+        const bool own_b = W ? !sc : sc;  // who holds the keys of set B (sc: the solver wave, see sum28_fold)
         // (the AND / OR exchange only where it pays: the float keys of the MAD spread over ~15 top bytes by themselves, and with a
         //  handful of keys per thread it costs more than the degenerate round — the robust mode of the latency kernel, which
         //  selects at every evaluation, lost 8 % to it)
@@ -263,7 +268,7 @@ struct BlockOps {
             unsigned long long* part = reinterpret_cast<unsigned long long*>(S + SEL_PART);  // [NWORK][4]
             if (W) {
                 if (PFA) sel_and_or<NA, K>(ka, ma, part + 4 * wv);
-                if (PFB) sel_and_or<NB, K>(kb, mb, part + 4 * wv + 2);
+                if (PFB && !sc) sel_and_or<NB, K>(kb, mb, part + 4 * wv + 2);
             }
             __syncthreads();
             unsigned long long a0 = ~0ull, o0 = 0ull, a1 = ~0ull, o1 = 0ull;
@@ -273,7 +278,7 @@ struct BlockOps {
                 if (PFB) { a1 &= part[4 * w + 2]; o1 |= part[4 * w + 3]; }
             }
             if (PFA) { anda = (K)a0; ora = (K)o0; }
-            if (PFB) { andb = (K)a1; orb = (K)o1; }
+            if (PFB && !sc) { andb = (K)a1; orb = (K)o1; }  // (sc: the solver's few keys search from the top bit)
         }
         auto top_bit = [](K differ) -> int {
             return differ == 0 ? -1 : (BITS - 1) - (BITS == 64 ? __clzll((unsigned long long)differ) : __clz((unsigned)differ));
@@ -293,7 +298,7 @@ struct BlockOps {
                 if (((mask >> k) & 1u) && same) atomicAdd(&h[bin >> 1], 1u << (16 * (bin & 1u)));
             }
         };
-        auto decide = [&](auto n_c, const K* key, unsigned mask, const unsigned* h, K& prefix, int& kk, int& hi, int lo, bool& pend,
+        auto decide = [&](auto n_c, bool own, const K* key, unsigned mask, const unsigned* h, K& prefix, int& kk, int& hi, int lo, bool& pend,
                           unsigned long long* mail) {
             constexpr int N = decltype(n_c)::value;
             int bin, below, cnt;
@@ -302,7 +307,7 @@ struct BlockOps {
             kk -= below;
             hi = lo - 1;
             if (cnt == 1 && lo > 0) {  // block-uniform: the single key under the prefix; visible after the next barrier
-                if (W) {
+                if (own) {
 #pragma unroll
                     for (int k = 0; k < N; ++k)
                         if (((mask >> k) & 1u) && ((key[k] ^ prefix) >> lo) == 0) *mail = (unsigned long long)key[k];
@@ -316,17 +321,15 @@ struct BlockOps {
             const int loa = hia >= 6 ? hia - 6 : 0, lob = hib >= 6 ? hib - 6 : 0;
             unsigned* const ha = S + rot * SEL_HW;
             unsigned* const hb = S + (3 + rot) * SEL_HW;
-            if (W) {
-                if (hia >= 0) count(integral_constant<int, NA>{}, ka, ma, pa, hia, loa, ha);
-                if (hib >= 0) count(integral_constant<int, NB>{}, kb, mb, pb, hib, lob, hb);
-            }
+            if (W && hia >= 0) count(integral_constant<int, NA>{}, ka, ma, pa, hia, loa, ha);
+            if (own_b && hib >= 0) count(integral_constant<int, NB>{}, kb, mb, pb, hib, lob, hb);
             __syncthreads();
             if (W && tid < 2 * SEL_HW) {  // the histograms of the round after the next (worker threads 0 .. 127)
                 const int rc = rot == 0 ? 2 : rot - 1;
                 S[((tid >> 6) * 3 + rc) * SEL_HW + (tid & 63)] = 0u;
             }
-            if (hia >= 0) decide(integral_constant<int, NA>{}, ka, ma, ha, pa, kka, hia, loa, penda, xchg);
-            if (hib >= 0) decide(integral_constant<int, NB>{}, kb, mb, hb, pb, kkb, hib, lob, pendb, xchg + 1);
+            if (hia >= 0) decide(integral_constant<int, NA>{}, W, ka, ma, ha, pa, kka, hia, loa, penda, xchg);
+            if (hib >= 0) decide(integral_constant<int, NB>{}, own_b, kb, mb, hb, pb, kkb, hib, lob, pendb, xchg + 1);
             rot = rot == 2 ? 0 : rot + 1;
         }
         __syncthreads();  // the mailboxes; and the AND / OR words are free for the next call
@@ -342,7 +345,7 @@ struct BlockOps {
     // order-preserving integer images of the values.  n == 0 -> 0.
     template <int NA, int NB, bool W>
     static __device__ __forceinline__ void mad_sigma2(const double* va, unsigned ma, int na, const double* vb, unsigned mb, int nb, unsigned* S,
-                                                      unsigned long long* xchg, int& rot, double& sa, double& sb) {
+                                                      unsigned long long* xchg, int& rot, double& sa, double& sb, bool sc = false) {
         sa = 0.0;
         sb = 0.0;
         const bool acta = na != 0, actb = nb != 0;  // block-uniform
@@ -360,7 +363,7 @@ struct BlockOps {
 #pragma unroll
         for (int k = 0; k < NB; ++k) kb[k] = image(vb[k]);
         unsigned long long ra = 0ull, rb = 0ull;
-        select2<NA, NB, W, unsigned long long, 64>(ka, ma, na / 2, acta, kb, mb, nb / 2, actb, S, xchg, rot, ra, rb);
+        select2<NA, NB, W, unsigned long long, 64>(ka, ma, na / 2, acta, kb, mb, nb / 2, actb, S, xchg, rot, ra, rb, sc);
         const double meda = value(ra), medb = value(rb);
         unsigned fa[NA], fb[NB];
 #pragma unroll
@@ -368,7 +371,7 @@ struct BlockOps {
 #pragma unroll
         for (int k = 0; k < NB; ++k) fb[k] = __float_as_uint(fabsf((float)(vb[k] - medb)));
         unsigned qa = 0u, qb = 0u;
-        select2<NA, NB, W, unsigned, 32>(fa, ma, na / 2, acta, fb, mb, nb / 2, actb, S, xchg, rot, qa, qb);
+        select2<NA, NB, W, unsigned, 32>(fa, ma, na / 2, acta, fb, mb, nb / 2, actb, S, xchg, rot, qa, qb, sc);
         if (acta) sa = 1.4826 * (double)__uint_as_float(qa);
         if (actb) sb = 1.4826 * (double)__uint_as_float(qb);
     }
@@ -376,9 +379,9 @@ struct BlockOps {
     // block sums of N doubles to every thread through red[.][slot0 .. slot0 + N): ONE barrier.  The caller keeps a barrier between
     // two uses of the same slots (and of sum28_fold, which uses all of them).
     template <int N, bool W>
-    static __device__ __forceinline__ void sum_at(const double* v, double (*red)[28], int slot0, double* out) {
-        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        if (W) {
+    static __device__ __forceinline__ void sum_at(const double* v, double (*red)[28], int slot0, double* out, bool sc = false) {
+        const int lane = threadIdx.x & 63, wv = W ? (int)(threadIdx.x >> 6) : NW;
+        if (W || sc) {
 #pragma unroll
             for (int k = 0; k < N; ++k) {
                 const double s = wave_sum_lane63(v[k]);
@@ -391,6 +394,7 @@ struct BlockOps {
             double s = red[0][slot0 + k];
 #pragma unroll
             for (int w = 1; w < NW; ++w) s += red[w][slot0 + k];
+            if (sc) s += red[NW][slot0 + k];
             out[k] = s;
         }
     }
@@ -403,9 +407,10 @@ struct BlockOps {
     template <int NA, int NB, bool W>
     static __device__ __forceinline__ void outlier_cut(const double* ra, unsigned ma, int na, bool do_a, const double* rb, unsigned mb, int nb,
                                                        bool do_b, double inlier_k, unsigned& inla, unsigned& inlb, unsigned* S,
-                                                       unsigned long long* xchg, int& rot, double (*red)[28], int* cnt) {
+                                                       unsigned long long* xchg, int& rot, double (*red)[28], int* cnt, bool sc = false) {
+        const bool own_b = W ? !sc : sc;
         double sa, sb;
-        mad_sigma2<NA, NB, W>(ra, do_a ? ma : 0u, do_a ? na : 0, rb, do_b ? mb : 0u, do_b ? nb : 0, S, xchg, rot, sa, sb);
+        mad_sigma2<NA, NB, W>(ra, do_a ? ma : 0u, do_a ? na : 0, rb, do_b ? mb : 0u, do_b ? nb : 0, S, xchg, rot, sa, sb, sc);
         double v[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         if (W) {
 #pragma unroll
@@ -417,6 +422,8 @@ struct BlockOps {
                     }
                     v[2] += ra[k];
                 }
+        }
+        if (own_b) {
 #pragma unroll
             for (int k = 0; k < NB; ++k)
                 if (do_b && ((mb >> k) & 1u)) {
@@ -428,7 +435,7 @@ struct BlockOps {
                 }
         }
         double t[6];
-        sum_at<6, W>(v, red, 0, t);
+        sum_at<6, W>(v, red, 0, t, sc);
         auto mean_of = [](int tot, const double* t3) -> double {
             if (tot == 0) return 0.0;
             const int ksel = (int)t3[1];
@@ -443,16 +450,18 @@ struct BlockOps {
                 for (int k = 0; k < NA; ++k)
                     if (((inla >> k) & 1u) && fabs(ra[k] - mean_a) > tha) inla &= ~(1u << k);
             }
+            c[0] = (double)__popc(inla);
+        }
+        if (own_b) {
             if (do_b) {
 #pragma unroll
                 for (int k = 0; k < NB; ++k)
                     if (((inlb >> k) & 1u) && fabs(rb[k] - mean_b) > thb) inlb &= ~(1u << k);
             }
-            c[0] = (double)__popc(inla);
             c[1] = (double)__popc(inlb);
         }
         double ct[2];
-        sum_at<2, W>(c, red, 8, ct);
+        sum_at<2, W>(c, red, 8, ct, sc);
         cnt[0] = (int)ct[0];
         cnt[1] = (int)ct[1];
     }

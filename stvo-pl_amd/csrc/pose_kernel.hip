@@ -76,12 +76,20 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_hist)[Block
             }
         }
     }
+    // Key-lines: with few of them (<= 64 LPT, the KITTI configuration's ~80) they belong to the SOLVER wave, lane = line: it has
+    // nothing else to do while the workers evaluate their points, and the two worker waves that used to carry a line term on top of
+    // their point trips were what every evaluation waited for (~4 k of 17 k cycles).  Otherwise (hundreds of key-lines) to the
+    // workers as before, one or two each.  los is block-uniform; BlockOps' `sc` arguments carry it.
     unsigned lmatched = 0u, linl = 0u;
-    const int n_prev_l = (W && a.n_prev_lines != nullptr && a.max_lines > 0) ? a.n_prev_lines[f] : 0;
+    const int n_l_all = (a.n_prev_lines != nullptr && a.max_lines > 0) ? a.n_prev_lines[f] : 0;
+    const bool los = a.lines_on_solver != 0 && n_l_all <= 64 * LPT;
+    const bool own_l = W ? !los : los;
+    const int ltid = W ? tid : tid - BLOCK, lstride = W ? BLOCK : 64;
+    const int n_prev_l = own_l ? n_l_all : 0;
     const size_t lbase = (size_t)f * a.max_lines;
 #pragma unroll
     for (int k = 0; k < LPT; ++k) {
-        const int i = tid + k * BLOCK;
+        const int i = ltid + k * lstride;
         if (i < n_prev_l) {
             const int j = a.m12l ? a.m12l[lbase + i] : i;
             if (j >= 0) {
@@ -151,7 +159,7 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_hist)[Block
         return r;
     };
     auto load_line_global = [&](int k) -> pm::LineRec {
-        const size_t i = lbase + (size_t)(tid + k * BLOCK);
+        const size_t i = lbase + (size_t)(ltid + k * lstride);
         const size_t j = a.m12l ? lbase + (size_t)a.m12l[i] : i;
         pm::LineRec L;
 #pragma unroll
@@ -169,8 +177,8 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_hist)[Block
         return L;
     };
     auto load_line = [&](int k) -> pm::LineRec {
-        if (!LDSREC || (PARTIAL && tid + k * BLOCK >= cap_l)) return load_line_global(k);
-        const double2* q = reinterpret_cast<const double2*>(s_lns + (size_t)(tid + k * BLOCK) * 14);
+        if (!LDSREC || (PARTIAL && ltid + k * lstride >= cap_l)) return load_line_global(k);
+        const double2* q = reinterpret_cast<const double2*>(s_lns + (size_t)(ltid + k * lstride) * 14);
         pm::LineRec L;
         const double2 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3], v4 = q[4], v5 = q[5], v6 = q[6];
         L.sP[0] = v0.x; L.sP[1] = v0.y; L.sP[2] = v1.x; L.eP[0] = v1.y; L.eP[1] = v2.x; L.eP[2] = v2.y;
@@ -188,11 +196,13 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_hist)[Block
                 q[1] = make_double2(r.Z, r.ox);
                 q[2] = make_double2(r.oy, r.s2);
             }
+    }
+    if (LDSREC && own_l) {
 #pragma unroll
         for (int k = 0; k < LPT; ++k)
-            if (((lmatched >> k) & 1u) && (!PARTIAL || tid + k * BLOCK < cap_l)) {
+            if (((lmatched >> k) & 1u) && (!PARTIAL || ltid + k * lstride < cap_l)) {
                 const pm::LineRec L = load_line_global(k);
-                double2* q = reinterpret_cast<double2*>(s_lns + (size_t)(tid + k * BLOCK) * 14);
+                double2* q = reinterpret_cast<double2*>(s_lns + (size_t)(ltid + k * lstride) * 14);
                 q[0] = make_double2(L.sP[0], L.sP[1]);
                 q[1] = make_double2(L.sP[2], L.eP[0]);
                 q[2] = make_double2(L.eP[1], L.eP[2]);
@@ -205,9 +215,9 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_hist)[Block
 
     {
         const int nmp = Ops::template sum_int<W>(__popc(pmatched), s_ired);
-        const int nml = Ops::template sum_int<W>(__popc(lmatched), s_ired);
+        const int nml = Ops::template sum_int<W>(__popc(lmatched), s_ired, los);
         const int nip = Ops::template sum_int<W>(__popc(pinl), s_ired);
-        const int nil = Ops::template sum_int<W>(__popc(linl), s_ired);
+        const int nil = Ops::template sum_int<W>(__popc(linl), s_ired, los);
         if (t0) {
             sh->n_m_p = nmp;
             sh->n_m_l = nml;
@@ -266,7 +276,7 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_hist)[Block
                 if ((linl >> k) & 1u) rl[k] = pm::line_residual(DT, cam, load_line(k));
                 __builtin_amdgcn_sched_barrier(0);
             }
-            Ops::template mad_sigma2<PPT, LPT, W>(rp, pinl, sh->n_inl_p, rl, linl, sh->n_inl_l, sel, sh->xchg, sel_rot, sp, sl);
+            Ops::template mad_sigma2<PPT, LPT, W>(rp, pinl, sh->n_inl_p, rl, linl, sh->n_inl_l, sel, sh->xchg, sel_rot, sp, sl, los);
             sp = pm::clamp_scale(sp);
             sl = pm::clamp_scale(sl);
         }
@@ -332,9 +342,9 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_hist)[Block
             }
         const long long tw1 = tick();
         prefetch_first();  // for the next evaluation; completes while this one is reduced and solved
-        Ops::template sum28_fold<W>(acc, s_red);
+        Ops::template sum28_fold<W>(acc, s_red, los);
         const long long tw2 = tick();
-        Ops::template sum28_finish<W>(s_red, sh);
+        Ops::template sum28_finish<W>(s_red, sh, los);
         wprof[0] += tw1 - tw0;
         wprof[1] += tick() - tw2;
         wprof[2] += tw2 - tw1;
@@ -382,7 +392,7 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_hist)[Block
         }
         int cnt[2];
         Ops::template outlier_cut<PPT, LPT, W>(resp, pmatched, sh->n_m_p, prm.has_points != 0, resl, lmatched, sh->n_m_l, prm.has_lines != 0,
-                                               prm.inlier_k, pinl, linl, sel, sh->xchg, sel_rot, s_red, cnt);
+                                               prm.inlier_k, pinl, linl, sel, sh->xchg, sel_rot, s_red, cnt, los);
         if (t0) {
             if (prm.has_points) sh->n_inl_p = cnt[0];
             if (prm.has_lines) sh->n_inl_l = cnt[1];
@@ -512,22 +522,24 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_hist)[Block
             if (i < a.max_pts) a.inl_p_out[base + i] = ((pmatched >> k) & 1u) ? (int)((pinl >> k) & 1u) : -1;
         }
     }
-    if (W && a.inl_l_out && a.max_lines > 0) {
+    if (own_l && a.inl_l_out && a.max_lines > 0) {
         const size_t base = (size_t)f * a.max_lines;
 #pragma unroll
         for (int k = 0; k < LPT; ++k) {
-            const int i = tid + k * BLOCK;
+            const int i = ltid + k * lstride;
             if (i < a.max_lines) a.inl_l_out[base + i] = ((lmatched >> k) & 1u) ? (int)((linl >> k) & 1u) : -1;
         }
     }
+    if (W && los && a.inl_l_out)  // the solver's lanes cover lines 0 .. 64 LPT - 1: nothing is matched beyond them
+        for (int i = 64 * LPT + tid; i < a.max_lines; i += BLOCK) a.inl_l_out[(size_t)f * a.max_lines + i] = -1;
 }
 
 template <int BLOCK, int PPT, int LPT, bool LDSREC>
 __global__ __launch_bounds__(BLOCK + 64, 2) void pose_kernel(PoseArgs a) {  // >= 2 waves/SIMD => <= 256 VGPRs, 2 workgroups per CU
     extern __shared__ double s_rec[];  // LDSREC: [max_pts][6] + [max_lines][14] doubles (dynamic, sized at launch)
     __shared__ __align__(16) int s_hist[2][BlockOps<BLOCK / 64>::HIST_W];  // BlockOps::select2
-    __shared__ double s_red[BLOCK / 64][28];
-    __shared__ int s_ired[BLOCK / 64];
+    __shared__ double s_red[BLOCK / 64 + 1][28];  // (+ 1: the solver wave's partial sums when it owns the key-lines)
+    __shared__ int s_ired[BLOCK / 64 + 1];
     __shared__ PoseSh s_sh;
     // This kernel is latency-bound (dependent FP64 chains, barriers) and is meant to run CONCURRENTLY with
     // the VALU-saturating matching kernel of the next batch (stvo_ctx_set_overlap): give its waves issue
@@ -572,6 +584,7 @@ static void launch_pose_variant(hipStream_t s, const PoseArgs& a_in, size_t lds_
     constexpr int LPT = (STVO_POSE_MAX_LINES + BLK - 1) / BLK;
     PoseArgs a = a_in;
     a.lds_cap_pts = a.lds_cap_lines = 0;
+    a.lines_on_solver = dbg().pose_los != 0 ? 1 : 0;
     size_t lds = 0;
     if (LDSREC) {
         const size_t lb = 14 * sizeof(double), pb = 6 * sizeof(double);

@@ -24,6 +24,7 @@ DebugSwitches parse_switches() {
     d.pose2p_nw = env_int("STVO_POSE2P_NW");
     d.pose_prof = env_int("STVO_POSE_PROF");
     d.pose_lds_t = env_int("STVO_POSE_LDS_T");
+    d.pose_los = env_int("STVO_POSE_LOS");
     d.knn_mfma = env_int("STVO_KNN_MFMA");
     d.knn_nseg = env_int("STVO_KNN_NSEG");
     d.seq_graph = env_int("STVO_SEQ_GRAPH");

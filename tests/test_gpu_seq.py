@@ -44,7 +44,11 @@ def run_and_compare(oracle, seqs, cam, preset, mode=0, has_lines=1, max_kp=2048,
         ctx.close()
 
 
-def test_seq_pipeline_kitti_points_and_lines(oracle):
+@pytest.mark.parametrize("env", [{}, {"STVO_POSE_LOS": "0"}], ids=["lines-on-solver-wave", "lines-on-worker-waves"])
+def test_seq_pipeline_kitti_points_and_lines(oracle, switches, env):
+    """Few frame pairs: the latency pose kernel.  Its key-lines (60-80 here) are evaluated by the solver wave by default, by the worker
+    waves with STVO_POSE_LOS=0 (and whenever a pair has more than 128): the same results either way."""
+    switches(env)
     cam = synth.KITTI_CAM
     seqs = [synth.make_stereo_sequence(500 + b, n_frames=5, n_pts=600 + 150 * b, n_lines=60 + 10 * b, cam=cam) for b in range(3)]
     run_and_compare(oracle, seqs, cam, "kitti")
