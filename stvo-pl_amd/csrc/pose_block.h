@@ -177,6 +177,28 @@ struct BlockOps {
         return t;
     }
 
+    // four integer block sums at once through the (idle) rows of `red`: ONE barrier; the caller keeps a barrier before `red` is used again
+    template <bool W>
+    static __device__ __forceinline__ void sum_int4(const int* v, double (*red)[28], int* out, bool sc = false) {
+        const int lane = threadIdx.x & 63, wv = W ? (int)(threadIdx.x >> 6) : NW;
+        if (W || sc) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int t = wave_sum_i(v[k]);
+                if (lane == 0) reinterpret_cast<int*>(&red[wv][0])[k] = t;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int t = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) t += reinterpret_cast<const int*>(&red[w][0])[k];
+            if (sc) t += reinterpret_cast<const int*>(&red[NW][0])[k];
+            out[k] = t;
+        }
+    }
+
     // ---- exact k-th element selection on register-resident keys, TWO independent key sets in lockstep -------------------------
     // (the key-points and the key-lines of removeOutliers / of the robust pre-pass: the same barriers serve both.)
     // Radix search from the most significant bit in which the keys of a set DIFFER (block-wide AND / OR; 64-bit keys of threads

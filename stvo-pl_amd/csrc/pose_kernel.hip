@@ -214,10 +214,11 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_hist)[Block
     }
 
     {
-        const int nmp = Ops::template sum_int<W>(__popc(pmatched), s_ired);
-        const int nml = Ops::template sum_int<W>(__popc(lmatched), s_ired, los);
-        const int nip = Ops::template sum_int<W>(__popc(pinl), s_ired);
-        const int nil = Ops::template sum_int<W>(__popc(linl), s_ired, los);
+        // matched / inlier counts of both kinds in one reduction (the solver wave's points are none: its zeros do not matter)
+        const int cnt4[4] = {(int)__popc(pmatched), (int)__popc(lmatched), (int)__popc(pinl), (int)__popc(linl)};
+        int tot4[4];
+        Ops::template sum_int4<W>(cnt4, s_red, tot4, los);
+        const int nmp = tot4[0], nml = tot4[1], nip = tot4[2], nil = tot4[3];
         if (t0) {
             sh->n_m_p = nmp;
             sh->n_m_l = nml;
