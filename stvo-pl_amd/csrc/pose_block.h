@@ -15,7 +15,6 @@ namespace {
 constexpr int ACT_CONTINUE = 0, ACT_BREAK = 1, ACT_FAIL = 2;
 
 struct PoseSh {
-    double tot[28];
     double DT[16];   // optimiser variable
     double DT0[16];  // initial DT of optimizePose (:317-326)
     double DT1[16];  // stage-1 result DT_ (:335)
@@ -29,6 +28,21 @@ struct PoseSh {
     unsigned long long xchg[2];  // select2's mailboxes
     int action, good, n_inl_p, n_inl_l, n_m_p, n_m_l, evals, itmp;
 };
+
+// Total k of the 28-vector block sum (21 upper-triangular H entries row by row, 6 g, 1 e) goes straight to where the serial routines
+// read it — H (both triangles), g, err = e / inliers (:692; 0 / 0 -> NaN) — by the lane that holds it: 28 lanes, two stores each,
+// instead of one lane (or sixty-four redundant ones) copying 28 values through a staging array at every iteration.
+__device__ __forceinline__ void store_total(PoseSh* sh, int k, double s) {
+    if (k < 21) {
+        const int i = (k >= 6) + (k >= 11) + (k >= 15) + (k >= 18) + (k >= 20), j = k - (i * (13 - i)) / 2 + i;
+        sh->H[i * 6 + j] = s;
+        sh->H[j * 6 + i] = s;
+    } else if (k < 27) {
+        sh->g[k - 21] = s;
+    } else {
+        sh->err = s / (double)(sh->n_inl_l + sh->n_inl_p);
+    }
+}
 
 // Block-wide primitives.  The workgroup has NWORK worker waves (threads 0 .. 64*NWORK-1, they own
 // the feature records) plus ONE solver wave (the last 64 threads: 6x6 algebra, SE(3), every
@@ -93,7 +107,7 @@ struct BlockOps {
                __longlong_as_double((long long)(((unsigned long long)hi[1] << 32) | lo[1]));
     }
 
-    // 28-vector block sum -> sh->tot[0..27] (wave partials summed in wave order by the solver wave).
+    // 28-vector block sum -> sh->H / g / err (store_total; wave partials summed in wave order by the solver wave).
     // Inside a wave: 28 values -> 14 (fold32) -> 7 (fold16) per lane, then a 16-lane row scan of those 7; row r
     // ends up with the wave totals of values 7r .. 7r+6 in its last lane.  147 VALU ops instead of the 504 of 28
     // independent 64-lane scans; fixed association order => bit-reproducible.
@@ -129,9 +143,9 @@ struct BlockOps {
 #pragma unroll
                 for (int w = 1; w < NW; ++w) s += red[w][lane];
                 if (sc) s += red[NW][lane];
-                sh->tot[lane] = s;
+                store_total(sh, lane, s);
             }
-            // tot[] is consumed by lane 0 of THIS wave only (t0_unpack), so a wave-level fence is enough; the
+            // the totals are consumed by lane 0 of THIS wave only (the serial routines), so a wave-level fence is enough; the
             // worker waves run ahead to the barrier that follows the solver's algebra, which also keeps them from
             // overwriting `red` before it has been read here.
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -497,21 +511,6 @@ __device__ __forceinline__ double norm3(const double* v) { return sqrt(v[0] * v[
 // through v_readlane) was built for 128-VGPR kernels in round 2 and measured slower (88 k vs 80 k cycles of solver time per
 // frame pair); it went with those kernels in round 4. ----
 
-__device__ __forceinline__ void t0_unpack(PoseSh* sh) {
-    int k = 0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int j = i; j < 6; ++j) {
-            const double v = sh->tot[k++];
-            sh->H[i * 6 + j] = v;
-            sh->H[j * 6 + i] = v;
-        }
-#pragma unroll
-    for (int i = 0; i < 6; ++i) sh->g[i] = sh->tot[21 + i];
-    sh->err = sh->tot[27] / (double)(sh->n_inl_l + sh->n_inl_p);  // :692  (0/0 -> NaN)
-}
-
 // H inc = g (ColPivHouseholderQR::solve at :417-418 and siblings): LDL^T when H is certified positive definite
 // (the normal case), the pivoted QR otherwise — see pose_math.h.
 __device__ __forceinline__ void solve_normal_eq(PoseSh* sh, double* inc, double* log_abs_det) {
@@ -525,7 +524,6 @@ __device__ __forceinline__ void solve_normal_eq(PoseSh* sh, double* inc, double*
 
 // body of gaussNewtonOptimization after optimizeFunctions (:405-428)
 __device__ __forceinline__ void t0_gn_iter(PoseSh* sh, double min_error, double min_error_change, int it) {
-    t0_unpack(sh);
     const double err = sh->err;
     if (err > sh->err_prev) {
         sh->action = it > 0 ? ACT_BREAK : ACT_FAIL;
@@ -552,7 +550,6 @@ __device__ __forceinline__ void t0_gn_iter(PoseSh* sh, double min_error, double 
 
 // body of gaussNewtonOptimizationRobust after optimizeFunctionsRobust (:449-467)
 __device__ __forceinline__ void t0_gnr_iter(PoseSh* sh, double min_error, double min_error_change) {
-    t0_unpack(sh);
     const double err = sh->err;
     if (fabs(err - sh->err_prev) < min_error_change || err < min_error) {
         sh->action = ACT_BREAK;
@@ -583,7 +580,6 @@ __device__ __forceinline__ void t0_gnr_iter(PoseSh* sh, double min_error, double
 
 // LM first iteration (:486-510) and loop body (:518-542)
 __device__ __forceinline__ void t0_lm_iter(PoseSh* sh, double min_error, double min_error_change, int first) {
-    t0_unpack(sh);
     const double err = sh->err;
     double inc[6], DT[16];
     if (first) {

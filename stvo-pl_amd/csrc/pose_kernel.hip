@@ -355,7 +355,6 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_hist)[Block
     if (a.eval_only) {
         evaluate(a.eval_robust != 0);
         if (t0) {
-            t0_unpack(sh);
             double* o = a.eval_out + (size_t)f * 44;
 #pragma unroll
             for (int i = 0; i < 36; ++i) o[i] = sh->H[i];

@@ -42,7 +42,7 @@ struct PointRec2 {
 constexpr bool POSE2P_PRIO = true;  // serial sections at wave priority 3 (measured: 239 -> 230 us per 512 pairs with four waves per pair)
 
 // ---------------- the optimizePose state machine (:332-370), shared by both kernels ----------------
-// evaluate(robust): optimizeFunctions[Robust] at sh->DT -> sh->tot (wave 0 holds the totals); remove_outliers(): :988-1067 at
+// evaluate(robust): optimizeFunctions[Robust] at sh->DT -> sh->H / g / err (store_total); remove_outliers(): :988-1067 at
 // sh->DT1.  Every decision is block-uniform (read from LDS after a barrier); wave 0 runs the serial sections.
 struct PoseFlow {
     int status, path, it0, it1;
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(NW * 64, 2) void pose2p_kernel(PoseArgs a, const in
                 double s = s_red[0][lane];
 #pragma unroll
                 for (int w = 1; w < NW; ++w) s += s_red[w][lane];
-                sh->tot[lane] = s;
+                store_total(sh, lane, s);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -463,7 +463,6 @@ __global__ __launch_bounds__(NW * 64, 2) void pose2p_kernel(PoseArgs a, const in
     if (a.eval_only) {
         evaluate(a.eval_robust != 0);
         if (w0) {
-            t0_unpack(sh);
             if (t0) {
                 double* o = a.eval_out + (size_t)f * 44;
 #pragma unroll
@@ -940,7 +939,7 @@ __global__ __launch_bounds__(NW * 64, 2) void pose2c_kernel(PoseArgs a_by_value,
                 double sum = s_red[0][lane];
 #pragma unroll
                 for (int w = 1; w < NW; ++w) sum += s_red[w][lane];
-                sh->tot[lane] = sum;
+                store_total(sh, lane, sum);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
