@@ -254,14 +254,15 @@ struct BlockOps {
     }
     // wave AND / OR of the keys in `mask` on DPP moves (lanes without a source keep their own value: the identity of both); lane 63
     // of worker wave wv leaves them in part[0], part[1]
-    template <int N, typename K>
-    static __device__ __forceinline__ void sel_and_or(const K* key, unsigned mask, unsigned long long* part) {
+    template <int N, typename K, typename KeyFn>
+    static __device__ __forceinline__ void sel_and_or(KeyFn&& key, unsigned mask, unsigned long long* part) {
         K k_and = ~(K)0, k_or = 0;
 #pragma unroll
         for (int k = 0; k < N; ++k)
             if ((mask >> k) & 1u) {
-                k_and &= key[k];
-                k_or |= key[k];
+                const K kv = key(k);
+                k_and &= kv;
+                k_or |= kv;
             }
         auto dpp_step = [&](auto ctrl_c, auto rmask_c) {
             constexpr int CTRL = decltype(ctrl_c)::value, RM = decltype(rmask_c)::value;
@@ -287,10 +288,12 @@ struct BlockOps {
         }
     }
 
-    // outa / outb = the ktha-th / kthb-th smallest (0-based) of {ka[k] : bit k of ma} / {kb[k] : bit k of mb}; acta / actb
+    // outa / outb = the ktha-th / kthb-th smallest (0-based) of {ka(k) : bit k of ma} / {kb(k) : bit k of mb}; acta / actb
     // (block-uniform): the set is not empty — an inactive set costs nothing and leaves its output alone.  xchg: two LDS words.
-    template <int NA, int NB, bool W, typename K, int BITS>
-    static __device__ __forceinline__ void select2(const K* ka, unsigned ma, int ktha, bool acta, const K* kb, unsigned mb, int kthb, bool actb,
+    // The keys are FUNCTIONS of the slot (the order-preserving image of a value the caller holds anyway, two or three operations):
+    // as arrays they were 39 more live registers per lane through every round, in kernels that spill at 256.
+    template <int NA, int NB, bool W, typename K, int BITS, typename KeyA, typename KeyB>
+    static __device__ __forceinline__ void select2(KeyA&& ka, unsigned ma, int ktha, bool acta, KeyB&& kb, unsigned mb, int kthb, bool actb,
                                                    unsigned* S, unsigned long long* xchg, int& rot, K& outa, K& outb, bool sc = false) {
         static_assert(BITS == 32 || BITS == 64, "32- or 64-bit keys");
         const int tid = threadIdx.x, wv = tid >> 6;
@@ -324,17 +327,18 @@ struct BlockOps {
         // hi = the most significant undecided bit of the set (-1: done); a round decides bits hi .. lo = max(0, hi - 6)
         int hia = acta ? top_bit(anda ^ ora) : -1, hib = actb ? top_bit(andb ^ orb) : -1;
         bool penda = false, pendb = false;  // the result comes from the single key left under the prefix, through xchg
-        auto count = [&](auto n_c, const K* key, unsigned mask, K prefix, int hi, int lo, unsigned* h) {
+        auto count = [&](auto n_c, auto&& key, unsigned mask, K prefix, int hi, int lo, unsigned* h) {
             constexpr int N = decltype(n_c)::value;
 #pragma unroll
             for (int k = 0; k < N; ++k) {
-                const K diff = key[k] ^ prefix;
+                const K kv = key(k);
+                const K diff = kv ^ prefix;
                 const bool same = hi + 1 >= BITS ? true : (diff >> (hi + 1 >= BITS ? 0 : hi + 1)) == 0;
-                const unsigned bin = (unsigned)((key[k] >> lo) & 127);
+                const unsigned bin = (unsigned)((kv >> lo) & 127);
                 if (((mask >> k) & 1u) && same) atomicAdd(&h[bin >> 1], 1u << (16 * (bin & 1u)));
             }
         };
-        auto decide = [&](auto n_c, bool own, const K* key, unsigned mask, const unsigned* h, K& prefix, int& kk, int& hi, int lo, bool& pend,
+        auto decide = [&](auto n_c, bool own, auto&& key, unsigned mask, const unsigned* h, K& prefix, int& kk, int& hi, int lo, bool& pend,
                           unsigned long long* mail) {
             constexpr int N = decltype(n_c)::value;
             int bin, below, cnt;
@@ -345,8 +349,10 @@ struct BlockOps {
             if (cnt == 1 && lo > 0) {  // block-uniform: the single key under the prefix; visible after the next barrier
                 if (own) {
 #pragma unroll
-                    for (int k = 0; k < N; ++k)
-                        if (((mask >> k) & 1u) && ((key[k] ^ prefix) >> lo) == 0) *mail = (unsigned long long)key[k];
+                    for (int k = 0; k < N; ++k) {
+                        const K kv = key(k);
+                        if (((mask >> k) & 1u) && ((kv ^ prefix) >> lo) == 0) *mail = (unsigned long long)kv;
+                    }
                 }
                 pend = true;
                 hi = -1;
@@ -393,21 +399,13 @@ struct BlockOps {
         auto value = [](unsigned long long k) -> double {
             return __longlong_as_double((long long)((k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k));
         };
-        unsigned long long ka[NA], kb[NB];
-#pragma unroll
-        for (int k = 0; k < NA; ++k) ka[k] = image(va[k]);
-#pragma unroll
-        for (int k = 0; k < NB; ++k) kb[k] = image(vb[k]);
         unsigned long long ra = 0ull, rb = 0ull;
-        select2<NA, NB, W, unsigned long long, 64>(ka, ma, na / 2, acta, kb, mb, nb / 2, actb, S, xchg, rot, ra, rb, sc);
+        select2<NA, NB, W, unsigned long long, 64>([&](int k) { return image(va[k]); }, ma, na / 2, acta, [&](int k) { return image(vb[k]); }, mb,
+                                                   nb / 2, actb, S, xchg, rot, ra, rb, sc);
         const double meda = value(ra), medb = value(rb);
-        unsigned fa[NA], fb[NB];
-#pragma unroll
-        for (int k = 0; k < NA; ++k) fa[k] = __float_as_uint(fabsf((float)(va[k] - meda)));  // >= 0 (or NaN)
-#pragma unroll
-        for (int k = 0; k < NB; ++k) fb[k] = __float_as_uint(fabsf((float)(vb[k] - medb)));
-        unsigned qa = 0u, qb = 0u;
-        select2<NA, NB, W, unsigned, 32>(fa, ma, na / 2, acta, fb, mb, nb / 2, actb, S, xchg, rot, qa, qb, sc);
+        unsigned qa = 0u, qb = 0u;  // |x - median| as a FLOAT (fabsf: >= 0 or NaN), whose bits order like the values
+        select2<NA, NB, W, unsigned, 32>([&](int k) { return __float_as_uint(fabsf((float)(va[k] - meda))); }, ma, na / 2, acta,
+                                         [&](int k) { return __float_as_uint(fabsf((float)(vb[k] - medb))); }, mb, nb / 2, actb, S, xchg, rot, qa, qb, sc);
         if (acta) sa = 1.4826 * (double)__uint_as_float(qa);
         if (actb) sb = 1.4826 * (double)__uint_as_float(qb);
     }
