@@ -106,25 +106,26 @@ int main(int argc, char** argv) {
       for (int i = 0; i < npx; ++i) if (ang[i] != NOTDEF) { order[start[1023 - (int)(mod[i] * bc)]++] = i; ++n_order; }
       free(start); }
     const int Ks[] = {1, 4, 16, 64, 256};
-    const int min_sep[] = {0, 24};  /* 0: the next K unused seeds; 24: additionally at least 24 px apart (Chebyshev) from the round's earlier picks */
+    const int min_sep[] = {0, 24, 24};  /* 0: the next K unused seeds; 24: additionally at least 24 px apart (Chebyshev) from the round's earlier picks; third pass: separation 24 with the STRICT (exact) commit rule */
     uint8_t* used = malloc(npx); int32_t* mine = malloc(sizeof(int32_t) * npx); int32_t* claimed = malloc(sizeof(int32_t) * npx);
     int32_t** regs = malloc(sizeof(int32_t*) * 256); for (int k = 0; k < 256; ++k) regs[k] = malloc(sizeof(int32_t) * npx / 4 + 4096);
     printf("%d defined pixels\n", n_order);
-    for (int ms = 0; ms < 2; ++ms)
+    for (int ms = 0; ms < 3; ++ms)
     for (int ki = 0; ki < 5; ++ki) {
         const int K = Ks[ki], sep = min_sep[ms];
+        const int strict = ms == 2;
         if (K == 1 && ms) continue;
         memset(used, 0, npx); memset(mine, 0xFF, sizeof(int32_t) * npx); memset(claimed, 0xFF, sizeof(int32_t) * npx);
         long long rounds = 0, crit = 0, work = 0, useful = 0, regions = 0; int32_t id = 0; int ptr = 0;
         while (1) {
             while (ptr < n_order && used[order[ptr]]) ++ptr;
             if (ptr >= n_order) break;
-            int seeds[256], sz[256], ns = 0;
+            int seeds[256], sz[256], rank[256], ns = 0;
             for (int p = ptr; p < n_order && ns < K; ++p) {
                 const int q = order[p]; if (used[q]) continue;
                 int ok = 1;
                 if (sep) for (int j = 0; j < ns; ++j) { int dx = abs(q % W - seeds[j] % W), dy = abs(q / W - seeds[j] / W); if ((dx > dy ? dx : dy) < sep) { ok = 0; break; } }
-                if (ok) seeds[ns++] = q;
+                if (ok) { rank[ns] = p; seeds[ns++] = q; }
                 if (p - ptr > 4096) break; /* look-ahead window */
             }
             int big = 0;
@@ -132,7 +133,12 @@ int main(int argc, char** argv) {
             /* commit in rank order; with min_sep the picks are NOT the next seeds in order, so only the first pick is certainly in turn:
              * a later pick commits if no skipped earlier seed could touch it — approximated optimistically here by the conflict test alone */
             const int32_t round_id = (int32_t)rounds;
+            int scan = ptr;  /* strict: every seed of rank < rank[j] must be used before pick j may commit */
             for (int j = 0; j < ns; ++j) {
+                if (strict) {
+                    while (scan < rank[j] && used[order[scan]]) ++scan;
+                    if (scan < rank[j]) break;  /* an unresolved seed of lower rank: the rest of the picks wait (here: are thrown away) */
+                }
                 if (used[seeds[j]]) continue;  /* taken by a region committed in this round: nothing to commit */
                 int conflict = 0;
                 for (int t = 0; t < sz[j] && !conflict; ++t) conflict = claimed[regs[j][t]] == round_id;
@@ -142,8 +148,8 @@ int main(int argc, char** argv) {
             }
             crit += big; ++rounds;
         }
-        printf("K %3d  separation %2d : rounds %7lld  critical path %8lld pixel steps (%.1fx shorter than sequential)  work %9lld (%.2fx the useful %lld)  regions %lld\n",
-               K, sep, rounds, crit, (double)useful / (double)crit, work, (double)work / (double)useful, useful, regions);
+        printf("%sK %3d  separation %2d : rounds %7lld  critical path %8lld pixel steps (%.1fx shorter than sequential)  work %9lld (%.2fx the useful %lld)  regions %lld\n",
+               strict ? "strict " : "", K, sep, rounds, crit, (double)useful / (double)crit, work, (double)work / (double)useful, useful, regions);
     }
     return 0;
 }
