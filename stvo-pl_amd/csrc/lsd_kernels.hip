@@ -169,8 +169,12 @@ __device__ __forceinline__ void wave_publish() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// V (developer switch STVO_LSD_GROW, debug_switches.h) — bit 0: a sub-group's candidates are resolved by guess + verification instead
+// of one after the other; bit 1: region2rect's ordered sums read their terms from LDS instead of through v_readlane.  Same results.
+template <int V>
 __global__ __launch_bounds__(64) void lsd_grow_kernel(LsdDev d) {
     __shared__ int s_ring[LSD_RING];
+    __shared__ double s_term[3][64];  // region2rect (V & 2): the terms of one chunk, lane l < 3 adds row l in order
     const int b = blockIdx.x, lane = threadIdx.x;
     const int w = d.w, h = d.h, npx = w * h;
     const size_t base = (size_t)b * npx;
@@ -247,6 +251,7 @@ __global__ __launch_bounds__(64) void lsd_grow_kernel(LsdDev d) {
                 }
                 const long long tr0 = tick();
                 ++n_rounds;
+                if constexpr ((V & 1) == 0) {
 #pragma unroll
                 for (int r = 0; r < LSD_GR; ++r) {
                     if (7 * r >= cnt) break;  // uniform
@@ -278,6 +283,89 @@ __global__ __launch_bounds__(64) void lsd_grow_kernel(LsdDev d) {
                         next = L + 1;
                     }
                 }
+                } else {
+                // Guess + verification (tools/experiments/lsd_resolve_model.c has the CPU model and the argument).  Only the two float
+                // additions per pixel depend on the order; the ~30 operations of the angle update run for all lanes at once:
+                //   A   = the lanes aligned with the angle at the start of the sub-group, the first lane of every pixel only
+                //   lane k: sums_k = start sums + (cos, sin) of A's lanes below k, added in lane order; angle_k = fastAtan2(sums_k), or
+                //           the start angle if A has no lane below k;  dup_k = a lane of A below k holds the same pixel
+                //   D   = the lanes aligned with their angle_k and not dup.  D == A: A is what the sequential loop accepts (induction
+                //         over the lanes); else the lanes below the first difference m are final, lane m's decision is D[m]: again
+                //         with A = A below m | D from m on (2 % of the sub-groups of a KITTI-size scene).
+#pragma unroll
+                for (int r = 0; r < LSD_GR; ++r) {
+                    if (7 * r >= cnt) break;  // uniform
+                    unsigned long long A;
+                    {
+                        double n_theta = reg_angle - ad[r];  // isAligned
+                        if (n_theta < 0) n_theta = -n_theta;
+                        if (n_theta > LSD_3_2_PI) {
+                            n_theta -= LSD_2_PI;
+                            if (n_theta < 0) n_theta = -n_theta;
+                        }
+                        A = __ballot(cand[r] && n_theta <= prec);
+                    }
+                    if (!A || n_reg + 64 > npx) continue;  // (the bound can only bind if a flag were lost: never write past the list)
+                    unsigned long long acc, kill;
+                    float sx, sy;
+                    double th;
+                    bool hit[LSD_GR];  // this lane's candidate of a LATER sub-group is a pixel accepted here
+                    for (;;) {
+                        unsigned long long rem = A;
+                        acc = 0ull;
+                        kill = 0ull;
+                        sx = sumdx;
+                        sy = sumdy;
+                        bool any = false, dup = false;
+#pragma unroll
+                        for (int r2 = 0; r2 < LSD_GR; ++r2) hit[r2] = false;
+                        while (rem) {  // uniform: the lanes of the guess, lowest first
+                            const int j = __builtin_ctzll(rem);
+                            const int qj = __builtin_amdgcn_readlane(qq[r], j);
+                            const float cj = readlane_f32(cs[r].x, j), sj = readlane_f32(cs[r].y, j);
+                            acc |= 1ull << j;
+                            const bool same = qq[r] == qj;
+                            rem &= ~__ballot(same);  // lane j itself and the later lanes that hold the same pixel
+                            if (lane > j) {
+                                sx += cj;
+                                sy += sj;
+                                any = true;
+                                dup = dup || same;
+                            }
+                            kill |= __ballot(key_ok && q_l == qj);
+#pragma unroll
+                            for (int r2 = 0; r2 < LSD_GR; ++r2)
+                                if (r2 > r) hit[r2] = hit[r2] || qq[r2] == qj;
+                        }
+                        th = any ? (double)fast_atan2_deg(sy, sx) * LSD_DEG2RAD : reg_angle;
+                        double n_theta = th - ad[r];
+                        if (n_theta < 0) n_theta = -n_theta;
+                        if (n_theta > LSD_3_2_PI) {
+                            n_theta -= LSD_2_PI;
+                            if (n_theta < 0) n_theta = -n_theta;
+                        }
+                        const unsigned long long D = __ballot(cand[r] && !dup && n_theta <= prec);
+                        if (D == acc) break;
+                        const unsigned long long below = (1ull << __builtin_ctzll(D ^ acc)) - 1ull;
+                        A = (acc & below) | (D & ~below);  // (never empty: the lowest lane of a guess sees the start angle, as the guess did)
+                    }
+                    // acc is the sequential result: every accepted lane stores its own pixel, in lane order
+                    if ((acc >> lane) & 1ull) {
+                        const int idx = n_reg + __builtin_popcountll(acc & ((1ull << lane) - 1ull));
+                        st_coherent(used + qq[r], 1);
+                        st_coherent(reg + idx, xy[r]);
+                        s_ring[idx & (LSD_RING - 1)] = xy[r];
+                    }
+                    n_reg += __builtin_popcountll(acc);
+                    sumdx = readlane_f32(sx, 63);  // lane 63 is never a candidate: its sums are the sums over all of acc
+                    sumdy = readlane_f32(sy, 63);
+                    reg_angle = readlane_f64(th, 63);
+                    todo &= ~kill;
+#pragma unroll
+                    for (int r2 = 0; r2 < LSD_GR; ++r2)
+                        if (r2 > r) cand[r2] = cand[r2] && !hit[r2];
+                }
+                }
                 t_res += tick() - tr0;
                 i += cnt;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // s_ring: lane 0's writes before the next round's reads
@@ -291,6 +379,25 @@ __global__ __launch_bounds__(64) void lsd_grow_kernel(LsdDev d) {
             const long long tq0 = tick();
             wave_publish();
             double X = 0.0, Y = 0.0, S = 0.0;
+            // V & 2: the three ordered sums of a pass are three independent chains — lane l < 3 adds row l of s_term term by term
+            // (one LDS read + one addition per region point instead of six v_readlane + three additions)
+            double chain = 0.0;
+            auto add_ordered = [&](double t0, double t1, double t2, int cn) {
+                s_term[0][lane] = t0;
+                s_term[1][lane] = t1;
+                s_term[2][lane] = t2;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (lane < 3) {
+                    const double* row = s_term[lane];
+#pragma unroll 8
+                    for (int k = 0; k < cn; ++k) chain += row[k];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the reads before the next chunk's writes
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            };
             for (int c0 = 0; c0 < n_reg; c0 += 64) {
                 const int t = c0 + lane, cn = n_reg - c0 < 64 ? n_reg - c0 : 64;
                 int pxy = 0;
@@ -300,11 +407,21 @@ __global__ __launch_bounds__(64) void lsd_grow_kernel(LsdDev d) {
                     wgt = mod[(pxy >> 16) * w + (pxy & 0xFFFF)];
                 }
                 const double px = (double)(pxy & 0xFFFF) * wgt, py = (double)(pxy >> 16) * wgt;
-                for (int k = 0; k < cn; ++k) {  // strictly in region order: every addition rounds as the oracle's
-                    X += readlane_f64(px, k);
-                    Y += readlane_f64(py, k);
-                    S += readlane_f64(wgt, k);
+                if constexpr ((V & 2) != 0) {
+                    add_ordered(px, py, wgt, cn);
+                } else {
+                    for (int k = 0; k < cn; ++k) {  // strictly in region order: every addition rounds as the oracle's
+                        X += readlane_f64(px, k);
+                        Y += readlane_f64(py, k);
+                        S += readlane_f64(wgt, k);
+                    }
                 }
+            }
+            if constexpr ((V & 2) != 0) {
+                X = readlane_f64(chain, 0);
+                Y = readlane_f64(chain, 1);
+                S = readlane_f64(chain, 2);
+                chain = 0.0;
             }
             const double cx = X / S, cy = Y / S;
             double Ixx = 0.0, Iyy = 0.0, Ixy = 0.0;
@@ -319,11 +436,20 @@ __global__ __launch_bounds__(64) void lsd_grow_kernel(LsdDev d) {
                     t_yy = ddx * ddx * wgt;
                     t_xy = ddx * ddy * wgt;
                 }
-                for (int k = 0; k < cn; ++k) {
-                    Ixx += readlane_f64(t_xx, k);
-                    Iyy += readlane_f64(t_yy, k);
-                    Ixy -= readlane_f64(t_xy, k);
+                if constexpr ((V & 2) != 0) {
+                    add_ordered(t_xx, t_yy, -t_xy, cn);  // (a - b and a + (-b) round alike)
+                } else {
+                    for (int k = 0; k < cn; ++k) {
+                        Ixx += readlane_f64(t_xx, k);
+                        Iyy += readlane_f64(t_yy, k);
+                        Ixy -= readlane_f64(t_xy, k);
+                    }
                 }
+            }
+            if constexpr ((V & 2) != 0) {
+                Ixx = readlane_f64(chain, 0);
+                Iyy = readlane_f64(chain, 1);
+                Ixy = readlane_f64(chain, 2);
             }
             const double lambda = 0.5 * (Ixx + Iyy - sqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
             double theta = (fabs(Ixx) > fabs(Iyy)) ? (double)fast_atan2_deg((float)(lambda - Ixx), (float)Ixy)
@@ -504,7 +630,12 @@ int lsd_enqueue(stvo_lsd* o, const uint8_t* images, stvo_keyline* lines, float* 
     hipLaunchKernelGGL(stvo::lsd_keys_kernel, grid, dim3(256), 0, s, d);
     size_t tb = o->sort_tmp_bytes;
     HIP_TRY(ctx, hipcub::DeviceSegmentedRadixSort::SortKeys(o->sort_tmp, tb, d.keys, d.order, d.B * d.w * d.h, d.B, o->seg_off, o->seg_off + 1, 0, 32, s));
-    hipLaunchKernelGGL(stvo::lsd_grow_kernel, dim3(d.B), dim3(64), 0, s, d);
+    switch (stvo::dbg().lsd_grow == stvo::DBG_UNSET ? 0 : stvo::dbg().lsd_grow & 3) {
+        case 1: hipLaunchKernelGGL(stvo::lsd_grow_kernel<1>, dim3(d.B), dim3(64), 0, s, d); break;
+        case 2: hipLaunchKernelGGL(stvo::lsd_grow_kernel<2>, dim3(d.B), dim3(64), 0, s, d); break;
+        case 3: hipLaunchKernelGGL(stvo::lsd_grow_kernel<3>, dim3(d.B), dim3(64), 0, s, d); break;
+        default: hipLaunchKernelGGL(stvo::lsd_grow_kernel<0>, dim3(d.B), dim3(64), 0, s, d); break;
+    }
     const size_t lds = (size_t)d.seg_cap * 8;
     hipLaunchKernelGGL(stvo::lsd_keylines_kernel, dim3(d.B), dim3(stvo::KL_T), lds, s, d);
     return check_launch(ctx);

@@ -40,6 +40,7 @@ DebugSwitches parse_switches() {
     d.grid_fused = env_int("STVO_GRID_FUSED");
     d.grid_fused_cap = env_int("STVO_GRID_FUSED_CAP");
     d.grid_cells = env_int("STVO_GRID_CELLS");
+    d.lsd_grow = env_int("STVO_LSD_GROW");
     return d;
 }
 DebugSwitches& switches() {

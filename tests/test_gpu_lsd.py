@@ -3,6 +3,8 @@ what StereoFrame::detectLineFeatures gets from LSDDetectorC::detect + its top-N 
 3rdparty/line_descriptor/src/LSDDetector_custom.cpp:227-325).  The detector core (cv::LineSegmentDetector) is third-party code
 the reference does not hold: the oracle restates the published algorithm, parity unpinned — what is pinned here is
 that the HIP path reproduces the oracle bit for bit: every segment, in detection order."""
+import os
+
 import numpy as np
 import pytest
 
@@ -49,6 +51,30 @@ def test_lsd_segments_bit_exact(hip, oracle, cols, rows, seed):
             check_keylines(dets[b], kl, cols, rows)
     finally:
         lsd.close()
+
+
+@pytest.mark.skipif(not os.environ.get("STVO_TEST_CANDIDATES"), reason="candidate kernels (set STVO_TEST_CANDIDATES=1): written at the end of "
+                    "round 4 without GPU time left; checked against tools/experiments/lsd_resolve_model.c on the CPU only")
+@pytest.mark.parametrize("variant", [1, 2, 3])
+def test_lsd_grow_candidates_bit_exact(hip, oracle, switches, variant):
+    """STVO_LSD_GROW (debug_switches.h): guess + verification of a sub-group's candidates (bit 0), region2rect's ordered sums
+    from LDS (bit 1) — the same segments, rectangle by rectangle, on a scene, a clean image, noise and a flat image."""
+    from stvo_amd import capi
+    switches({"STVO_LSD_GROW": str(variant)})
+    cols, rows = 752, 480
+    rng = np.random.default_rng(41)
+    imgs = np.stack([synth.make_image(610, cols, rows), clean_image(cols, rows, 611), rng.integers(0, 255, (rows, cols), dtype=np.uint8),
+                     np.full((rows, cols), 77, np.uint8)])
+    for scale in (1.2, 1.0):
+        lsd = capi.Lsd(hip, 4, cols, rows, capi.lsd_params(min_length=4.0, nfeatures=0, scale=scale), max_keylines=2048)
+        try:
+            segs, n = lsd.segments(imgs)
+            for b in range(4):
+                ref = oracle.lsd_segments(imgs[b], oracle.lsd_opts(scale=scale))
+                assert n[b] == len(ref)
+                assert np.array_equal(segs[b], ref)
+        finally:
+            lsd.close()
 
 
 def test_lsd_keep_all_flat_and_unscaled(hip, oracle):
