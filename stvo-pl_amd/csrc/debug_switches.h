@@ -28,7 +28,7 @@ struct DebugSwitches {
     int grid_tail;       // STVO_GRID_TAIL       0: point_tail_kernel as its own launch
     int grid_fused;      // STVO_GRID_FUSED      0: scan formulation of the stereo point matcher
     int grid_fused_cap;  // STVO_GRID_FUSED_CAP  capacity override of the one-workgroup point matcher (tests of the misfit path)
-    int lsd_grow;        // STVO_LSD_GROW        bit 0: guess + verification of a sub-group's candidates, bit 1: region2rect's ordered sums from LDS (lsd_kernels.hip)
+    int lsd_grow;        // STVO_LSD_GROW        variants of lsd_grow_kernel, a bit mask (lsd_kernels.hip: template parameter V)
     int grid_cells;      // STVO_GRID_CELLS      0: point_cells_kernel as its own launch for small batches too, 1: in the matcher whenever it fits
 };
 

@@ -15,16 +15,12 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     const float p1 = 0.9997878412794807f * scale, p3 = -0.3258083974640975f * scale, p5 = 0.1555786518463281f * scale,
                 p7 = -0.04432655554792128f * scale;
     const float ax = fabsf(x), ay = fabsf(y);
-    float a, c, c2;
-    if (ax >= ay) {
-        c = __fdiv_rn(ay, ax + (float)2.2204460492503131e-16);
-        c2 = c * c;
-        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
-    } else {
-        c = __fdiv_rn(ax, ay + (float)2.2204460492503131e-16);
-        c2 = c * c;
-        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
-    }
+    // one division for both octant cases (lanes of a wave take both: as two branches every lane paid for two divisions)
+    const bool x_major = ax >= ay;
+    const float c = __fdiv_rn(x_major ? ay : ax, (x_major ? ax : ay) + (float)2.2204460492503131e-16);
+    const float c2 = c * c;
+    float a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    if (!x_major) a = 90.f - a;
     if (x < 0) a = 180.f - a;
     if (y < 0) a = 360.f - a;
     return a;

@@ -149,6 +149,7 @@ __global__ __launch_bounds__(256) void lsd_keys_kernel(LsdDev d) {
 
 constexpr int LSD_RING = 1024;  // the most recent region points, in LDS (4 KB: the LDS must not limit the images in flight per CU)
 constexpr int LSD_GR = 2;       // sub-groups of 7 region points (63 lanes) fetched per round of the region growing
+constexpr int LSD_GROW_DEFAULT = 7;  // variant of lsd_grow_kernel when STVO_LSD_GROW is not set (its template parameter V)
 
 // The flags / the region list are written by lane 0 and read by all lanes of the SAME wave later: workgroup-scope ordering is
 // what is needed — the vector L1 is write-through and shared by the CU, so such accesses are ordinary loads / stores with a wait
@@ -169,8 +170,9 @@ __device__ __forceinline__ void wave_publish() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-// V (developer switch STVO_LSD_GROW, debug_switches.h) — bit 0: a sub-group's candidates are resolved by guess + verification instead
-// of one after the other; bit 1: region2rect's ordered sums read their terms from LDS instead of through v_readlane.  Same results.
+// V (developer switch STVO_LSD_GROW, debug_switches.h; unset = LSD_GROW_DEFAULT) — bit 0: a sub-group's candidates are resolved by
+// guess + verification instead of one after the other; bit 1: region2rect's ordered sums read their terms from LDS instead of through
+// v_readlane; bit 2: the loads of all sub-groups of a round are issued before the first is consumed.  Same results.
 template <int V>
 __global__ __launch_bounds__(64) void lsd_grow_kernel(LsdDev d) {
     __shared__ int s_ring[LSD_RING];
@@ -188,6 +190,7 @@ __global__ __launch_bounds__(64) void lsd_grow_kernel(LsdDev d) {
     int n_seg = 0;
     const bool prof = d.dbg != nullptr;
     long long t_grow = 0, t_res = 0, t_rect = 0, n_rounds = 0, n_add = 0, n_regions = 0, n_batches = 0;
+    long long t_pub = 0, t_issue = 0, t_wait = 0, t_seed = 0;  // phases of a round (profiling only: explicit waits make them attributable)
     auto tick = [&]() -> long long { return prof ? (long long)__builtin_readcyclecounter() : 0ll; };
     const long long t_begin = tick();
     for (int o0 = 0; o0 < npx; o0 += 64) {
@@ -218,8 +221,13 @@ __global__ __launch_bounds__(64) void lsd_grow_kernel(LsdDev d) {
                 st_coherent(reg, sx0 | (sy0 << 16));
                 s_ring[0] = sx0 | (sy0 << 16);
             }
+            t_seed += tick() - tg0;
             for (int i = 0; i < n_reg;) {
+                const long long tp0 = tick();
                 wave_publish();  // lane 0's stores of the earlier rounds before the flag / list loads below
+                if (prof) __builtin_amdgcn_s_waitcnt(0);
+                const long long tp1 = tick();
+                t_pub += tp1 - tp0;
                 // one round: the next (up to) 7 LSD_GR region points — sub-group r holds points i + 7 r .. i + 7 r + 6, lane = 9 x point
                 // + neighbour — fetched together, then resolved sub-group after sub-group, lane after lane: the oracle's order
                 const int cnt = n_reg - i < 7 * LSD_GR ? n_reg - i : 7 * LSD_GR;  // uniform
@@ -228,6 +236,37 @@ __global__ __launch_bounds__(64) void lsd_grow_kernel(LsdDev d) {
                 float2 cs[LSD_GR];
                 double ad[LSD_GR];
                 bool cand[LSD_GR];
+                if constexpr ((V & 4) != 0) {
+                    // every sub-group's region point first, then every load, then the uses: the flag / angle / (cos, sin) loads of
+                    // the sub-groups overlap (one after the other they were two memory round trips per round).  Lanes without a
+                    // neighbour load pixel 0 and drop the values
+                    int pxyv[LSD_GR], u[LSD_GR];
+                    float a[LSD_GR];
+                    bool val[LSD_GR];
+                    const bool in_ring = n_reg - i <= LSD_RING;  // uniform: the round's oldest point is still in the LDS ring
+#pragma unroll
+                    for (int r = 0; r < LSD_GR; ++r) {
+                        const int slot = 7 * r + slot0;
+                        val[r] = lane < 63 && slot < cnt && nb != 4;
+                        const int at = val[r] ? i + slot : i;
+                        pxyv[r] = in_ring ? s_ring[at & (LSD_RING - 1)] : ld_coherent(reg + at);
+                    }
+#pragma unroll
+                    for (int r = 0; r < LSD_GR; ++r) {
+                        const int xx = (pxyv[r] & 0xFFFF) + (nb % 3) - 1, yy = (pxyv[r] >> 16) + nb / 3 - 1;
+                        val[r] = val[r] && xx >= 0 && xx < w && yy >= 0 && yy < h;
+                        qq[r] = val[r] ? yy * w + xx : 0;
+                        xy[r] = xx | (yy << 16);
+                        u[r] = ld_coherent(used + qq[r]);
+                        a[r] = ang[qq[r]];
+                        cs[r] = csn[qq[r]];
+                    }
+#pragma unroll
+                    for (int r = 0; r < LSD_GR; ++r) {
+                        cand[r] = val[r] && u[r] == 0 && a[r] >= 0.f;
+                        ad[r] = (double)a[r] * LSD_DEG2RAD;
+                    }
+                } else {
 #pragma unroll
                 for (int r = 0; r < LSD_GR; ++r) {
                     const int slot = 7 * r + slot0;
@@ -249,7 +288,12 @@ __global__ __launch_bounds__(64) void lsd_grow_kernel(LsdDev d) {
                     cand[r] = valid && u == 0 && a >= 0.f;
                     ad[r] = (double)a * LSD_DEG2RAD;
                 }
-                const long long tr0 = tick();
+                }
+                const long long ti1 = tick();  // the loads are issued ...
+                if (prof) __builtin_amdgcn_s_waitcnt(0);
+                const long long tr0 = tick();  // ... and have arrived
+                t_issue += ti1 - tp1;
+                t_wait += tr0 - ti1;
                 ++n_rounds;
                 if constexpr ((V & 1) == 0) {
 #pragma unroll
@@ -286,12 +330,18 @@ __global__ __launch_bounds__(64) void lsd_grow_kernel(LsdDev d) {
                 } else {
                 // Guess + verification (tools/experiments/lsd_resolve_model.c has the CPU model and the argument).  Only the two float
                 // additions per pixel depend on the order; the ~30 operations of the angle update run for all lanes at once:
-                //   A   = the lanes aligned with the angle at the start of the sub-group, the first lane of every pixel only
+                //   A   = the lanes aligned with the angle at the start of the sub-group
+                //   A'  = A walked from the lowest lane: a lane taken removes the later lanes that hold the same pixel
                 //   lane k: sums_k = start sums + (cos, sin) of A's lanes below k, added in lane order; angle_k = fastAtan2(sums_k), or
-                //           the start angle if A has no lane below k;  dup_k = a lane of A below k holds the same pixel
-                //   D   = the lanes aligned with their angle_k and not dup.  D == A: A is what the sequential loop accepts (induction
-                //         over the lanes); else the lanes below the first difference m are final, lane m's decision is D[m]: again
-                //         with A = A below m | D from m on (2 % of the sub-groups of a KITTI-size scene).
+                //           the start angle if A' has no lane below k;  dup_k = a lane of A' below k holds the same pixel
+                //   D   = the lanes aligned with their angle_k and not dup.  D == A': A' is what the sequential loop accepts
+                //         (induction over the lanes); else the lanes below the first difference m are final, lane m's decision is
+                //         D[m]: again with A = A' below m | D from m on (2 % of the sub-groups of a KITTI-size scene).
+                // Every per-lane flag is kept as a 64-bit lane mask in scalar registers (they are compare results to begin with).
+                unsigned long long cand_m[LSD_GR];
+#pragma unroll
+                for (int r = 0; r < LSD_GR; ++r) cand_m[r] = __ballot(cand[r]);
+                const unsigned long long key_m = __ballot(key_ok);
 #pragma unroll
                 for (int r = 0; r < LSD_GR; ++r) {
                     if (7 * r >= cnt) break;  // uniform
@@ -303,40 +353,39 @@ __global__ __launch_bounds__(64) void lsd_grow_kernel(LsdDev d) {
                             n_theta -= LSD_2_PI;
                             if (n_theta < 0) n_theta = -n_theta;
                         }
-                        A = __ballot(cand[r] && n_theta <= prec);
+                        A = __ballot(n_theta <= prec) & cand_m[r];
                     }
                     if (!A || n_reg + 64 > npx) continue;  // (the bound can only bind if a flag were lost: never write past the list)
-                    unsigned long long acc, kill;
+                    unsigned long long acc, kill, hit_m[LSD_GR];
                     float sx, sy;
                     double th;
-                    bool hit[LSD_GR];  // this lane's candidate of a LATER sub-group is a pixel accepted here
                     for (;;) {
-                        unsigned long long rem = A;
+                        unsigned long long rem = A, dup_m = 0ull;
                         acc = 0ull;
                         kill = 0ull;
+#pragma unroll
+                        for (int r2 = 0; r2 < LSD_GR; ++r2) hit_m[r2] = 0ull;
                         sx = sumdx;
                         sy = sumdy;
-                        bool any = false, dup = false;
-#pragma unroll
-                        for (int r2 = 0; r2 < LSD_GR; ++r2) hit[r2] = false;
                         while (rem) {  // uniform: the lanes of the guess, lowest first
                             const int j = __builtin_ctzll(rem);
                             const int qj = __builtin_amdgcn_readlane(qq[r], j);
                             const float cj = readlane_f32(cs[r].x, j), sj = readlane_f32(cs[r].y, j);
+                            const unsigned long long later = j == 63 ? 0ull : ~0ull << (j + 1);
+                            const unsigned long long same = __ballot(qq[r] == qj);
                             acc |= 1ull << j;
-                            const bool same = qq[r] == qj;
-                            rem &= ~__ballot(same);  // lane j itself and the later lanes that hold the same pixel
-                            if (lane > j) {
-                                sx += cj;
-                                sy += sj;
-                                any = true;
-                                dup = dup || same;
-                            }
-                            kill |= __ballot(key_ok && q_l == qj);
+                            rem &= ~same;  // lane j itself and the later lanes that hold the same pixel
+                            dup_m |= same & later;
+                            const float nx = sx + cj, ny = sy + sj;  // (a select, not a masked addition of zero: x + 0 is not x for x = -0)
+                            const bool is_later = lane > j;
+                            sx = is_later ? nx : sx;
+                            sy = is_later ? ny : sy;
+                            kill |= __ballot(q_l == qj);
 #pragma unroll
                             for (int r2 = 0; r2 < LSD_GR; ++r2)
-                                if (r2 > r) hit[r2] = hit[r2] || qq[r2] == qj;
+                                if (r2 > r) hit_m[r2] |= __ballot(qq[r2] == qj);
                         }
+                        const bool any = lane > __builtin_ctzll(acc);
                         th = any ? (double)fast_atan2_deg(sy, sx) * LSD_DEG2RAD : reg_angle;
                         double n_theta = th - ad[r];
                         if (n_theta < 0) n_theta = -n_theta;
@@ -344,14 +393,14 @@ __global__ __launch_bounds__(64) void lsd_grow_kernel(LsdDev d) {
                             n_theta -= LSD_2_PI;
                             if (n_theta < 0) n_theta = -n_theta;
                         }
-                        const unsigned long long D = __ballot(cand[r] && !dup && n_theta <= prec);
+                        const unsigned long long D = __ballot(n_theta <= prec) & cand_m[r] & ~dup_m;
                         if (D == acc) break;
                         const unsigned long long below = (1ull << __builtin_ctzll(D ^ acc)) - 1ull;
                         A = (acc & below) | (D & ~below);  // (never empty: the lowest lane of a guess sees the start angle, as the guess did)
                     }
                     // acc is the sequential result: every accepted lane stores its own pixel, in lane order
                     if ((acc >> lane) & 1ull) {
-                        const int idx = n_reg + __builtin_popcountll(acc & ((1ull << lane) - 1ull));
+                        const int idx = n_reg + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(acc >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)acc, 0u));
                         st_coherent(used + qq[r], 1);
                         st_coherent(reg + idx, xy[r]);
                         s_ring[idx & (LSD_RING - 1)] = xy[r];
@@ -360,10 +409,10 @@ __global__ __launch_bounds__(64) void lsd_grow_kernel(LsdDev d) {
                     sumdx = readlane_f32(sx, 63);  // lane 63 is never a candidate: its sums are the sums over all of acc
                     sumdy = readlane_f32(sy, 63);
                     reg_angle = readlane_f64(th, 63);
-                    todo &= ~kill;
+                    todo &= ~(kill & key_m);
 #pragma unroll
                     for (int r2 = 0; r2 < LSD_GR; ++r2)
-                        if (r2 > r) cand[r2] = cand[r2] && !hit[r2];
+                        if (r2 > r) cand_m[r2] &= ~hit_m[r2];
                 }
                 }
                 t_res += tick() - tr0;
@@ -496,6 +545,7 @@ __global__ __launch_bounds__(64) void lsd_grow_kernel(LsdDev d) {
         double* q = d.dbg + ((size_t)d.seg_cap - 2) * 8;
         q[0] = (double)(tick() - t_begin); q[1] = (double)t_grow; q[2] = (double)t_res; q[3] = (double)t_rect; q[4] = (double)n_rounds;
         q[5] = (double)n_add; q[6] = (double)n_regions; q[7] = (double)n_batches;
+        q[8] = (double)t_pub; q[9] = (double)t_issue; q[10] = (double)t_wait; q[11] = (double)t_seed;
     }
 }
 
@@ -630,11 +680,11 @@ int lsd_enqueue(stvo_lsd* o, const uint8_t* images, stvo_keyline* lines, float* 
     hipLaunchKernelGGL(stvo::lsd_keys_kernel, grid, dim3(256), 0, s, d);
     size_t tb = o->sort_tmp_bytes;
     HIP_TRY(ctx, hipcub::DeviceSegmentedRadixSort::SortKeys(o->sort_tmp, tb, d.keys, d.order, d.B * d.w * d.h, d.B, o->seg_off, o->seg_off + 1, 0, 32, s));
-    switch (stvo::dbg().lsd_grow == stvo::DBG_UNSET ? 0 : stvo::dbg().lsd_grow & 3) {
-        case 1: hipLaunchKernelGGL(stvo::lsd_grow_kernel<1>, dim3(d.B), dim3(64), 0, s, d); break;
-        case 2: hipLaunchKernelGGL(stvo::lsd_grow_kernel<2>, dim3(d.B), dim3(64), 0, s, d); break;
-        case 3: hipLaunchKernelGGL(stvo::lsd_grow_kernel<3>, dim3(d.B), dim3(64), 0, s, d); break;
-        default: hipLaunchKernelGGL(stvo::lsd_grow_kernel<0>, dim3(d.B), dim3(64), 0, s, d); break;
+    switch (stvo::dbg().lsd_grow == stvo::DBG_UNSET ? stvo::LSD_GROW_DEFAULT : stvo::dbg().lsd_grow & 7) {
+#define LSD_GROW_CASE(v) case v: hipLaunchKernelGGL(stvo::lsd_grow_kernel<v>, dim3(d.B), dim3(64), 0, s, d); break;
+        LSD_GROW_CASE(0) LSD_GROW_CASE(1) LSD_GROW_CASE(2) LSD_GROW_CASE(3) LSD_GROW_CASE(6)
+#undef LSD_GROW_CASE
+        default: hipLaunchKernelGGL(stvo::lsd_grow_kernel<7>, dim3(d.B), dim3(64), 0, s, d); break;
     }
     const size_t lds = (size_t)d.seg_cap * 8;
     hipLaunchKernelGGL(stvo::lsd_keylines_kernel, dim3(d.B), dim3(stvo::KL_T), lds, s, d);

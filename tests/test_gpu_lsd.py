@@ -55,7 +55,7 @@ def test_lsd_segments_bit_exact(hip, oracle, cols, rows, seed):
 
 @pytest.mark.skipif(not os.environ.get("STVO_TEST_CANDIDATES"), reason="candidate kernels (set STVO_TEST_CANDIDATES=1): written at the end of "
                     "round 4 without GPU time left; checked against tools/experiments/lsd_resolve_model.c on the CPU only")
-@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 6])
 def test_lsd_grow_candidates_bit_exact(hip, oracle, switches, variant):
     """STVO_LSD_GROW (debug_switches.h): guess + verification of a sub-group's candidates (bit 0), region2rect's ordered sums
     from LDS (bit 1) — the same segments, rectangle by rectangle, on a scene, a clean image, noise and a flat image."""

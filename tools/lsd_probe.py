@@ -35,6 +35,8 @@ for b in range(min(B, 2)):
             print(f"   {name}: {int((gd[:m2, c] != od[:m2, c]).sum())} of {m2} differ")
         o.lib.orc_lsd_set_debug(None)
         q = gd[8190]
+        q2 = gd[8191]
+        print(f"   rounds: publish {q2[0]:.0f}  list read + address + issue {q2[1]:.0f}  wait for the loads {q2[2]:.0f}  | seed set-up {q2[3]:.0f}")
         print(f"   image 0, cycles: total {q[0]:.0f}  grow {q[1]:.0f} (of which resolving {q[2]:.0f})  rect {q[3]:.0f} | rounds {q[4]:.0f}  pixels added {q[5]:.0f}  regions {q[6]:.0f}  batches {q[7]:.0f}")
 t0 = time.perf_counter()
 for _ in range(a.iters):
