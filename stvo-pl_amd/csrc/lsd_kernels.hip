@@ -679,7 +679,10 @@ int lsd_enqueue(stvo_lsd* o, const uint8_t* images, stvo_keyline* lines, float* 
     hipLaunchKernelGGL(stvo::lsd_gradient_kernel, grid, dim3(256), 0, s, d);
     hipLaunchKernelGGL(stvo::lsd_keys_kernel, grid, dim3(256), 0, s, d);
     size_t tb = o->sort_tmp_bytes;
-    HIP_TRY(ctx, hipcub::DeviceSegmentedRadixSort::SortKeys(o->sort_tmp, tb, d.keys, d.order, d.B * d.w * d.h, d.B, o->seg_off, o->seg_off + 1, 0, 32, s));
+    // the radix sort is stable and the keys come in index order: sorting by the bin bits alone leaves every bin in row-major order
+    // (STVO_LSD_SORT_FULL=1: all 32 bits, the index bits included — the same order, more digit passes)
+    const int begin_bit = stvo::dbg().lsd_sort_full == 1 ? 0 : stvo::LSD_IDX_BITS;
+    HIP_TRY(ctx, hipcub::DeviceSegmentedRadixSort::SortKeys(o->sort_tmp, tb, d.keys, d.order, d.B * d.w * d.h, d.B, o->seg_off, o->seg_off + 1, begin_bit, 32, s));
     switch (stvo::dbg().lsd_grow == stvo::DBG_UNSET ? stvo::LSD_GROW_DEFAULT : stvo::dbg().lsd_grow & 7) {
 #define LSD_GROW_CASE(v) case v: hipLaunchKernelGGL(stvo::lsd_grow_kernel<v>, dim3(d.B), dim3(64), 0, s, d); break;
         LSD_GROW_CASE(0) LSD_GROW_CASE(1) LSD_GROW_CASE(2) LSD_GROW_CASE(3) LSD_GROW_CASE(6)

@@ -41,6 +41,7 @@ DebugSwitches parse_switches() {
     d.grid_fused_cap = env_int("STVO_GRID_FUSED_CAP");
     d.grid_cells = env_int("STVO_GRID_CELLS");
     d.lsd_grow = env_int("STVO_LSD_GROW");
+    d.lsd_sort_full = env_int("STVO_LSD_SORT_FULL");
     return d;
 }
 DebugSwitches& switches() {

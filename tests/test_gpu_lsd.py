@@ -77,6 +77,25 @@ def test_lsd_grow_candidates_bit_exact(hip, oracle, switches, variant):
             lsd.close()
 
 
+def test_lsd_sort_by_all_key_bits_is_the_same(hip, oracle, switches):
+    """The pseudo-ordering sorts the bin bits only and relies on the stability of the radix sort for the row-major order inside a
+    bin (STVO_LSD_SORT_FULL=1 sorts the index bits too): the same segments either way."""
+    from stvo_amd import capi
+    cols, rows = 640, 480
+    imgs = np.stack([synth.make_image(700, cols, rows), clean_image(cols, rows, 701)])
+    out = []
+    for full in ("0", "1"):
+        switches({"STVO_LSD_SORT_FULL": full})
+        lsd = capi.Lsd(hip, 2, cols, rows, capi.lsd_params(min_length=4.0, nfeatures=0), max_keylines=2048)
+        try:
+            out.append(lsd.segments(imgs))
+        finally:
+            lsd.close()
+    for b in range(2):
+        assert out[0][1][b] == out[1][1][b] and np.array_equal(out[0][0][b], out[1][0][b])
+        assert np.array_equal(out[0][0][b], oracle.lsd_segments(imgs[b], oracle.lsd_opts()))
+
+
 def test_lsd_keep_all_flat_and_unscaled(hip, oracle):
     """nfeatures = 0 keeps every line in detection order; a flat image and pure noise give none / few; scale 1 skips the blur."""
     from stvo_amd import capi
