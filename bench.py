@@ -428,8 +428,8 @@ def lsd_leg(local_rank, B=2048):
     return {"workload": f"{B} synthetic {cols} x {rows} images, lsd_scale 1.2, lsd_refine 0, min_line_length 0.025, lsd_nfeatures 100 (config_kitti.yaml)",
             "images_per_s": B / out["lsd"], "ms_per_launch": out["lsd"] * 1e3, "with_lbd_images_per_s": B / out["lsd_lbd"],
             "mean_keylines": float(nl.mean()), "parity_first_two_images": bool(ok), "oracle_ms_per_image_1_core": cpu_ms,
-            "note": "region growing is sequential per image (one wavefront each; ~0.1 s for one image: ~150 k pixels added one after the other, "
-                    "~700 cycles of dependent instructions each): the batch is the parallelism — throughput grows with the images in flight"}
+            "note": "region growing is sequential per image (one wavefront each; ~65 ms for one image: ~44 k rounds of ~3.4 region points, one L2 "
+                    "round trip + ~1500 cycles of dependent instructions each): the batch is the parallelism — throughput grows with the images in flight"}
 
 
 def images_leg(local_rank, B=128, steps=8, lines=False):
