@@ -133,19 +133,35 @@ __global__ __launch_bounds__(256) void orb_fast_nms_kernel(OrbDev o) {
     const uint8_t* img = o.img + (size_t)b * o.rows * o.cols;
     const uint8_t* tile8 = reinterpret_cast<const uint8_t*>(&tile[0][0]);
     uint8_t* sc = reinterpret_cast<uint8_t*>(&sc_w[0][0]);
-    for (int i = tid; i < IM_H * IM_DW; i += 256) {
-        const int ty = i / IM_DW, td = i - ty * IM_DW;
-        const int gx = x0 - 5 + 4 * td, gy = min(max(y0 + ty - 4, 0), o.rows - 1);
-        const uint8_t* row = img + (size_t)gy * o.cols;
-        uint32_t w;
-        if (gx >= 0 && gx + 4 <= o.cols) {
-            w = *reinterpret_cast<const u32_unaligned*>(row + gx);
-        } else {  // image border: replicate (those pixels never pass the border test below, their values only have to exist)
-            w = 0u;
+    {
+        // every word of the tile is requested before the first is used (as a loop of load -> wait -> LDS store the workgroup began
+        // its life with six memory round trips one after the other).  Words that cross the image border are re-read byte by byte
+        // afterwards; the first pass reads them from a clamped address so that it needs no branch
+        constexpr int ST_TRIPS = (IM_H * IM_DW + 255) / 256;
+        uint32_t wv[ST_TRIPS];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) w |= (uint32_t)row[min(max(gx + k, 0), o.cols - 1)] << (8 * k);
+        for (int k = 0; k < ST_TRIPS; ++k) {
+            const int i = min(tid + 256 * k, IM_H * IM_DW - 1);
+            const int ty = i / IM_DW, td = i - ty * IM_DW;
+            const int gx = x0 - 5 + 4 * td, gy = min(max(y0 + ty - 4, 0), o.rows - 1);
+            wv[k] = *reinterpret_cast<const u32_unaligned*>(img + (size_t)gy * o.cols + min(max(gx, 0), o.cols - 4));
         }
-        tile[ty][td] = w;
+#pragma unroll
+        for (int k = 0; k < ST_TRIPS; ++k) {
+            const int i = tid + 256 * k;
+            if (i < IM_H * IM_DW) {
+                const int ty = i / IM_DW, td = i - ty * IM_DW;
+                const int gx = x0 - 5 + 4 * td, gy = min(max(y0 + ty - 4, 0), o.rows - 1);
+                uint32_t w = wv[k];
+                if (gx < 0 || gx + 4 > o.cols) {  // image border: replicate (those pixels never pass the border test below, their values only have to exist)
+                    const uint8_t* row = img + (size_t)gy * o.cols;
+                    w = 0u;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) w |= (uint32_t)row[min(max(gx + c, 0), o.cols - 1)] << (8 * c);
+                }
+                tile[ty][td] = w;
+            }
+        }
     }
     for (int i = tid; i < SC_H * (SC_PITCH / 4); i += 256) (&sc_w[0][0])[i] = 0u;
     if (tid == 0) {
