@@ -592,7 +592,8 @@ constexpr int DESC_R = 19;                        // |rotated pattern coordinate
 constexpr int DESC_PW = 10, DESC_PH = 2 * DESC_R + 1;  // blurred patch: 39 rows of 10 words = bytes x - 20 .. x + 19
 constexpr int IC_PW = 8, IC_PH = 2 * ORB_HP + 1;       // image patch: 31 rows of 8 words = bytes x - 16 .. x + 15
 __global__ __launch_bounds__(256) void orb_describe_kernel(OrbDev o, Umax um) {
-    __shared__ uint32_t s_patch[DESC_KP_PER_WG][DESC_PH * DESC_PW];  // the image patch first (31 x 8 words), then the blurred one
+    constexpr int PATCH_W = ((DESC_PH * DESC_PW + 15) / 16) * 16;  // rounded up to the 16 lanes of a group: every lane stores every word it loaded
+    __shared__ uint32_t s_patch[DESC_KP_PER_WG][PATCH_W];  // the image patch first (31 x 8 words), then the blurred one
     // XCD-aware 1-D grid: workgroup L runs on XCD L mod 8 (round-robin dispatch), so image = 8 (L / 8 / blocks per image) + L mod 8
     // keeps every workgroup of an image on ONE XCD — the patches of neighbouring key-points overlap (2000 key-points read 11 x the
     // image), and with the image's workgroups dealt over all eight private L2s each of them fetched the image from HBM again
@@ -632,13 +633,21 @@ __global__ __launch_bounds__(256) void orb_describe_kernel(OrbDev o, Umax um) {
     const uint8_t* img_lo = o.img + base;
     const uint8_t* img_hi = o.img + base + (size_t)o.rows * o.cols - 4;
     {
+        // all 16 words of a lane's share are requested before the first is stored (as a loop the compiler made four groups of four
+        // loads with a wait after each: four memory round trips one after the other at the start of every wave)
+        constexpr int IW_N = (IC_PH * IC_PW + 15) / 16;
+        uint32_t iw[IW_N];
         const uint8_t* org = o.img + base + (size_t)(y - ORB_HP) * o.cols + (x - 16);
-        for (int i = l; i < IC_PH * IC_PW; i += 16) {
+#pragma unroll
+        for (int j = 0; j < IW_N; ++j) {
+            const int i = l + 16 * j;
             const int r = i >> 3, w = i & 7;
             const uint8_t* p = org + (size_t)r * o.cols + 4 * w;
-            p = p < img_lo ? img_lo : (p > img_hi ? img_hi : p);
-            patch[i] = *reinterpret_cast<const u32_unaligned*>(p);
+            p = p < img_lo ? img_lo : (p > img_hi ? img_hi : p);  // (i beyond the patch: a clamped, unused word)
+            iw[j] = *reinterpret_cast<const u32_unaligned*>(p);
         }
+#pragma unroll
+        for (int j = 0; j < IW_N; ++j) patch[l + 16 * j] = iw[j];  // (unconditional: a store under `i < 248` took its load along, into a round trip of its own)
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -694,10 +703,7 @@ __global__ __launch_bounds__(256) void orb_describe_kernel(OrbDev o, Umax um) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int j = 0; j < BW_N; ++j) {
-        const int i = l + 16 * j;
-        if (i < DESC_PH * DESC_PW) patch[i] = bw[j];
-    }
+    for (int j = 0; j < BW_N; ++j) patch[l + 16 * j] = bw[j];  // (unconditional: the row is padded to 16 x BW_N words)
     // computeOrbDescriptors, WTA_K = 2: lane l evaluates tests 16 l .. 16 l + 15 = bytes 2 l, 2 l + 1 of the descriptor
     const float rad = ang * (float)(3.14159265358979323846 / 180.0);
     // (float)cos((double)rad), (float)sin((double)rad): one Cody-Waite + kernel-polynomial evaluation (within an ulp of the library's
