@@ -149,7 +149,6 @@ __global__ __launch_bounds__(256) void lsd_keys_kernel(LsdDev d) {
 
 constexpr int LSD_RING = 1024;  // the most recent region points, in LDS (4 KB: the LDS must not limit the images in flight per CU)
 constexpr int LSD_GR = 2;       // sub-groups of 7 region points (63 lanes) fetched per round of the region growing
-constexpr int LSD_GROW_DEFAULT = 7;  // variant of lsd_grow_kernel when STVO_LSD_GROW is not set (its template parameter V)
 
 // The flags / the region list are written by lane 0 and read by all lanes of the SAME wave later: workgroup-scope ordering is
 // what is needed — the vector L1 is write-through and shared by the CU, so such accesses are ordinary loads / stores with a wait
@@ -170,13 +169,15 @@ __device__ __forceinline__ void wave_publish() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-// V (developer switch STVO_LSD_GROW, debug_switches.h; unset = LSD_GROW_DEFAULT) — bit 0: a sub-group's candidates are resolved by
-// guess + verification instead of one after the other; bit 1: region2rect's ordered sums read their terms from LDS instead of through
-// v_readlane; bit 2: the loads of all sub-groups of a round are issued before the first is consumed.  Same results.
-template <int V>
+// FAST (the default; STVO_LSD_GROW=0 selects the plain form, debug_switches.h): a sub-group's candidates are resolved by guess +
+// verification instead of one after the other, region2rect's ordered sums read their terms from LDS instead of through v_readlane,
+// the loads of all sub-groups of a round are issued before the first is used.  Same results: the plain form is the direct statement
+// of the oracle's loops and stays as the in-library cross-check (tests/test_gpu_lsd.py runs both).  Round 4, one KITTI-size image:
+// 233 M cycles plain, 155 M fast (NOTES.md has the table of the steps in between).
+template <bool FAST>
 __global__ __launch_bounds__(64) void lsd_grow_kernel(LsdDev d) {
     __shared__ int s_ring[LSD_RING];
-    __shared__ double s_term[3][64];  // region2rect (V & 2): the terms of one chunk, lane l < 3 adds row l in order
+    __shared__ double s_term[3][64];  // region2rect (FAST): the terms of one chunk, lane l < 3 adds row l in order
     const int b = blockIdx.x, lane = threadIdx.x;
     const int w = d.w, h = d.h, npx = w * h;
     const size_t base = (size_t)b * npx;
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(64) void lsd_grow_kernel(LsdDev d) {
                 float2 cs[LSD_GR];
                 double ad[LSD_GR];
                 bool cand[LSD_GR];
-                if constexpr ((V & 4) != 0) {
+                if constexpr (FAST) {
                     // every sub-group's region point first, then every load, then the uses: the flag / angle / (cos, sin) loads of
                     // the sub-groups overlap (one after the other they were two memory round trips per round).  Lanes without a
                     // neighbour load pixel 0 and drop the values
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(64) void lsd_grow_kernel(LsdDev d) {
                 t_issue += ti1 - tp1;
                 t_wait += tr0 - ti1;
                 ++n_rounds;
-                if constexpr ((V & 1) == 0) {
+                if constexpr (!FAST) {
 #pragma unroll
                 for (int r = 0; r < LSD_GR; ++r) {
                     if (7 * r >= cnt) break;  // uniform
@@ -428,7 +429,7 @@ __global__ __launch_bounds__(64) void lsd_grow_kernel(LsdDev d) {
             const long long tq0 = tick();
             wave_publish();
             double X = 0.0, Y = 0.0, S = 0.0;
-            // V & 2: the three ordered sums of a pass are three independent chains — lane l < 3 adds row l of s_term term by term
+            // FAST: the three ordered sums of a pass are three independent chains — lane l < 3 adds row l of s_term term by term
             // (one LDS read + one addition per region point instead of six v_readlane + three additions)
             double chain = 0.0;
             auto add_ordered = [&](double t0, double t1, double t2, int cn) {
@@ -456,7 +457,7 @@ __global__ __launch_bounds__(64) void lsd_grow_kernel(LsdDev d) {
                     wgt = mod[(pxy >> 16) * w + (pxy & 0xFFFF)];
                 }
                 const double px = (double)(pxy & 0xFFFF) * wgt, py = (double)(pxy >> 16) * wgt;
-                if constexpr ((V & 2) != 0) {
+                if constexpr (FAST) {
                     add_ordered(px, py, wgt, cn);
                 } else {
                     for (int k = 0; k < cn; ++k) {  // strictly in region order: every addition rounds as the oracle's
@@ -466,7 +467,7 @@ __global__ __launch_bounds__(64) void lsd_grow_kernel(LsdDev d) {
                     }
                 }
             }
-            if constexpr ((V & 2) != 0) {
+            if constexpr (FAST) {
                 X = readlane_f64(chain, 0);
                 Y = readlane_f64(chain, 1);
                 S = readlane_f64(chain, 2);
@@ -485,7 +486,7 @@ __global__ __launch_bounds__(64) void lsd_grow_kernel(LsdDev d) {
                     t_yy = ddx * ddx * wgt;
                     t_xy = ddx * ddy * wgt;
                 }
-                if constexpr ((V & 2) != 0) {
+                if constexpr (FAST) {
                     add_ordered(t_xx, t_yy, -t_xy, cn);  // (a - b and a + (-b) round alike)
                 } else {
                     for (int k = 0; k < cn; ++k) {
@@ -495,7 +496,7 @@ __global__ __launch_bounds__(64) void lsd_grow_kernel(LsdDev d) {
                     }
                 }
             }
-            if constexpr ((V & 2) != 0) {
+            if constexpr (FAST) {
                 Ixx = readlane_f64(chain, 0);
                 Iyy = readlane_f64(chain, 1);
                 Ixy = readlane_f64(chain, 2);
@@ -683,12 +684,8 @@ int lsd_enqueue(stvo_lsd* o, const uint8_t* images, stvo_keyline* lines, float* 
     // (STVO_LSD_SORT_FULL=1: all 32 bits, the index bits included — the same order, more digit passes)
     const int begin_bit = stvo::dbg().lsd_sort_full == 1 ? 0 : stvo::LSD_IDX_BITS;
     HIP_TRY(ctx, hipcub::DeviceSegmentedRadixSort::SortKeys(o->sort_tmp, tb, d.keys, d.order, d.B * d.w * d.h, d.B, o->seg_off, o->seg_off + 1, begin_bit, 32, s));
-    switch (stvo::dbg().lsd_grow == stvo::DBG_UNSET ? stvo::LSD_GROW_DEFAULT : stvo::dbg().lsd_grow & 7) {
-#define LSD_GROW_CASE(v) case v: hipLaunchKernelGGL(stvo::lsd_grow_kernel<v>, dim3(d.B), dim3(64), 0, s, d); break;
-        LSD_GROW_CASE(0) LSD_GROW_CASE(1) LSD_GROW_CASE(2) LSD_GROW_CASE(3) LSD_GROW_CASE(6)
-#undef LSD_GROW_CASE
-        default: hipLaunchKernelGGL(stvo::lsd_grow_kernel<7>, dim3(d.B), dim3(64), 0, s, d); break;
-    }
+    if (stvo::dbg().lsd_grow == 0) hipLaunchKernelGGL(stvo::lsd_grow_kernel<false>, dim3(d.B), dim3(64), 0, s, d);
+    else hipLaunchKernelGGL(stvo::lsd_grow_kernel<true>, dim3(d.B), dim3(64), 0, s, d);
     const size_t lds = (size_t)d.seg_cap * 8;
     hipLaunchKernelGGL(stvo::lsd_keylines_kernel, dim3(d.B), dim3(stvo::KL_T), lds, s, d);
     return check_launch(ctx);
