@@ -550,6 +550,437 @@ __global__ __launch_bounds__(64) void lsd_grow_kernel(LsdDev d) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// ONE image by a workgroup of LSD_NW waves — an EXACT asynchronous form of the search for small batches (developer switch
+// STVO_LSD_WAVES=1; written at the end of round 4 WITHOUT GPU time left: it compiles, its scheme is replayed on the CPU by
+// tools/experiments/lsd_waves_sim.c — 6.75 x for one KITTI-size image with 16 waves — but it has not run on hardware yet.  The default
+// path does not touch it).
+//   wave 0 commits in seed order.  A seed with a finished PENDING region takes it if every pixel of it is still free (flag stores,
+//   lane-parallel; the segment was computed by the wave that grew it), a seed another wave is growing right now is waited for
+//   (bounded), any other seed — and any pending region that lost a pixel — is grown by wave 0 itself, flags set as it goes.
+//   waves 1 .. LSD_NW - 1 speculate: the first seed after the committer's position (LSD_LOOK ranks) that is free, not pending, not in
+//   flight and >= LSD_SEP px (Chebyshev) from every seed in flight is grown against the flags committed so far; the wave marks ITS
+//   pixels in a stamp array of its own and leaves the flags alone.
+// Exactness: flags only turn on.  A region grown against an older state of the flags made the sequential decisions at every pixel it
+// examined unless it ACCEPTED a pixel that was taken before its turn — then the validation at its turn fails and the seed is grown again.
+// Output order = commit order = seed order.
+constexpr int LSD_NW = 16;
+constexpr int LSD_WRING = 256;       // per wave: the most recent region points in LDS
+constexpr int LSD_SEP = 24;
+constexpr int LSD_LOOK = 2048;
+constexpr int LSD_REC_CAP = 32768;   // regions a speculating wave can hold (it stops speculating when full)
+constexpr int LSD_WAVES_MAX_B = 8;   // the scratch below is ~130 B per pixel and wave-pair: small batches only
+
+struct LsdRec {
+    int off, n;   // pixel list at wlist[wave] + off; n = 0: the growth was abandoned (out of room)
+    float x1, y1, x2, y2;
+};
+struct LsdWaves {
+    int32_t* stamp;  // [B][LSD_NW][w h] region id of the wave that holds the pixel in its CURRENT region (zeroed per call)
+    int32_t* wlist;  // [B][LSD_NW][w h] pixel lists, region after region
+    LsdRec* rec;     // [B][LSD_NW][LSD_REC_CAP]
+    int32_t* pend;   // [B][w h] by RANK in the pseudo-ordering: 0 or ((wave << 20) | record) + 1 (zeroed per call)
+};
+
+__device__ __forceinline__ int lds_ld(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_st(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// region_grow from `seed`, the fast form of lsd_grow_kernel.  MARK (the committer): a pixel is taken by setting its flag.  !MARK (a
+// speculating wave): the flags are only read; the wave's own pixels carry `id` in `stamp`.  The list goes to `list` (at most `cap`
+// entries: -1 if it does not fit), the final region angle to `angle_out`.
+template <bool MARK>
+__device__ __forceinline__ int grow_region_w(const float* __restrict__ ang, const float2* __restrict__ csn, int32_t* used, int32_t* stamp, int id,
+                                             int32_t* list, int cap, int* ring, int seed, float seed_ang, int w, int h, double prec,
+                                             double& angle_out) {
+    const int lane = threadIdx.x & 63;
+    const int sx0 = seed % w, sy0 = seed / w;
+    double reg_angle = (double)seed_ang * LSD_DEG2RAD;
+    double sn0, cs0;
+    sincos_det(reg_angle, sn0, cs0);
+    float sumdx = (float)cs0, sumdy = (float)sn0;
+    int n_reg = 1;
+    if (lane == 0) {
+        if (MARK) st_coherent(used + seed, 1);
+        else st_coherent(stamp + seed, id);
+        st_coherent(list, sx0 | (sy0 << 16));
+        ring[0] = sx0 | (sy0 << 16);
+    }
+    for (int i = 0; i < n_reg;) {
+        wave_publish();
+        const int cnt = n_reg - i < 7 * LSD_GR ? n_reg - i : 7 * LSD_GR;  // uniform
+        const int slot0 = lane / 9, nb = lane - slot0 * 9;
+        int qq[LSD_GR], xy[LSD_GR], pxyv[LSD_GR], u[LSD_GR], own[LSD_GR];
+        float2 cs[LSD_GR];
+        float a[LSD_GR];
+        double ad[LSD_GR];
+        bool val[LSD_GR];
+        const bool in_ring = n_reg - i <= LSD_WRING;  // uniform
+#pragma unroll
+        for (int r = 0; r < LSD_GR; ++r) {
+            const int slot = 7 * r + slot0;
+            val[r] = lane < 63 && slot < cnt && nb != 4;
+            const int at = val[r] ? i + slot : i;
+            pxyv[r] = in_ring ? ring[at & (LSD_WRING - 1)] : ld_coherent(list + at);
+        }
+#pragma unroll
+        for (int r = 0; r < LSD_GR; ++r) {
+            const int xx = (pxyv[r] & 0xFFFF) + (nb % 3) - 1, yy = (pxyv[r] >> 16) + nb / 3 - 1;
+            val[r] = val[r] && xx >= 0 && xx < w && yy >= 0 && yy < h;
+            qq[r] = val[r] ? yy * w + xx : 0;
+            xy[r] = xx | (yy << 16);
+            u[r] = ld_coherent(used + qq[r]);
+            own[r] = MARK ? 0 : ld_coherent(stamp + qq[r]);
+            a[r] = ang[qq[r]];
+            cs[r] = csn[qq[r]];
+        }
+        unsigned long long cand_m[LSD_GR];
+#pragma unroll
+        for (int r = 0; r < LSD_GR; ++r) {
+            cand_m[r] = __ballot(val[r] && u[r] == 0 && (MARK || own[r] != id) && a[r] >= 0.f);
+            ad[r] = (double)a[r] * LSD_DEG2RAD;
+        }
+        // guess + verification of a sub-group: lsd_grow_kernel<true> has the explanation
+#pragma unroll
+        for (int r = 0; r < LSD_GR; ++r) {
+            if (7 * r >= cnt) break;  // uniform
+            unsigned long long A;
+            {
+                double n_theta = reg_angle - ad[r];
+                if (n_theta < 0) n_theta = -n_theta;
+                if (n_theta > LSD_3_2_PI) {
+                    n_theta -= LSD_2_PI;
+                    if (n_theta < 0) n_theta = -n_theta;
+                }
+                A = __ballot(n_theta <= prec) & cand_m[r];
+            }
+            if (!A) continue;
+            if (n_reg + 64 > cap) return -1;  // uniform
+            unsigned long long acc, hit_m[LSD_GR];
+            float sx, sy;
+            double th;
+            for (;;) {
+                unsigned long long rem = A, dup_m = 0ull;
+                acc = 0ull;
+#pragma unroll
+                for (int r2 = 0; r2 < LSD_GR; ++r2) hit_m[r2] = 0ull;
+                sx = sumdx;
+                sy = sumdy;
+                while (rem) {
+                    const int j = __builtin_ctzll(rem);
+                    const int qj = __builtin_amdgcn_readlane(qq[r], j);
+                    const float cj = readlane_f32(cs[r].x, j), sj = readlane_f32(cs[r].y, j);
+                    const unsigned long long later = j == 63 ? 0ull : ~0ull << (j + 1);
+                    const unsigned long long same = __ballot(qq[r] == qj);
+                    acc |= 1ull << j;
+                    rem &= ~same;
+                    dup_m |= same & later;
+                    const float nx = sx + cj, ny = sy + sj;
+                    const bool is_later = lane > j;
+                    sx = is_later ? nx : sx;
+                    sy = is_later ? ny : sy;
+#pragma unroll
+                    for (int r2 = 0; r2 < LSD_GR; ++r2)
+                        if (r2 > r) hit_m[r2] |= __ballot(qq[r2] == qj);
+                }
+                const bool any = lane > __builtin_ctzll(acc);
+                th = any ? (double)fast_atan2_deg(sy, sx) * LSD_DEG2RAD : reg_angle;
+                double n_theta = th - ad[r];
+                if (n_theta < 0) n_theta = -n_theta;
+                if (n_theta > LSD_3_2_PI) {
+                    n_theta -= LSD_2_PI;
+                    if (n_theta < 0) n_theta = -n_theta;
+                }
+                const unsigned long long D = __ballot(n_theta <= prec) & cand_m[r] & ~dup_m;
+                if (D == acc) break;
+                const unsigned long long below = (1ull << __builtin_ctzll(D ^ acc)) - 1ull;
+                A = (acc & below) | (D & ~below);
+            }
+            if ((acc >> lane) & 1ull) {
+                const int idx = n_reg + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(acc >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)acc, 0u));
+                if (MARK) st_coherent(used + qq[r], 1);
+                else st_coherent(stamp + qq[r], id);
+                st_coherent(list + idx, xy[r]);
+                ring[idx & (LSD_WRING - 1)] = xy[r];
+            }
+            n_reg += __builtin_popcountll(acc);
+            sumdx = readlane_f32(sx, 63);
+            sumdy = readlane_f32(sy, 63);
+            reg_angle = readlane_f64(th, 63);
+#pragma unroll
+            for (int r2 = 0; r2 < LSD_GR; ++r2)
+                if (r2 > r) cand_m[r2] &= ~hit_m[r2];
+        }
+        i += cnt;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the ring: this round's writes before the next round's reads
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    angle_out = reg_angle;
+    return n_reg;
+}
+
+// region2rect + the segment of a region of n >= min_reg_size pixels (the fast form of lsd_grow_kernel); term: [3][64] doubles of LDS
+__device__ __forceinline__ float4 region_segment_w(const LsdDev& d, const int32_t* list, int n_reg, const double* __restrict__ mod, double reg_angle,
+                                                   double (*term)[64]) {
+    const int lane = threadIdx.x & 63, w = d.w;
+    wave_publish();
+    double chain = 0.0;
+    auto add_ordered = [&](double t0, double t1, double t2, int cn) {
+        term[0][lane] = t0;
+        term[1][lane] = t1;
+        term[2][lane] = t2;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < 3) {
+            const double* row = term[lane];
+#pragma unroll 8
+            for (int k = 0; k < cn; ++k) chain += row[k];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    for (int c0 = 0; c0 < n_reg; c0 += 64) {
+        const int t = c0 + lane, cn = n_reg - c0 < 64 ? n_reg - c0 : 64;
+        int pxy = 0;
+        double wgt = 0.0;
+        if (t < n_reg) {
+            pxy = ld_coherent(list + t);
+            wgt = mod[(pxy >> 16) * w + (pxy & 0xFFFF)];
+        }
+        add_ordered((double)(pxy & 0xFFFF) * wgt, (double)(pxy >> 16) * wgt, wgt, cn);
+    }
+    const double X = readlane_f64(chain, 0), Y = readlane_f64(chain, 1), S = readlane_f64(chain, 2);
+    chain = 0.0;
+    const double cx = X / S, cy = Y / S;
+    for (int c0 = 0; c0 < n_reg; c0 += 64) {
+        const int t = c0 + lane, cn = n_reg - c0 < 64 ? n_reg - c0 : 64;
+        double t_xx = 0.0, t_yy = 0.0, t_xy = 0.0;
+        if (t < n_reg) {
+            const int pxy = ld_coherent(list + t);
+            const double wgt = mod[(pxy >> 16) * w + (pxy & 0xFFFF)];
+            const double ddx = (double)(pxy & 0xFFFF) - cx, ddy = (double)(pxy >> 16) - cy;
+            t_xx = ddy * ddy * wgt;
+            t_yy = ddx * ddx * wgt;
+            t_xy = ddx * ddy * wgt;
+        }
+        add_ordered(t_xx, t_yy, -t_xy, cn);
+    }
+    const double Ixx = readlane_f64(chain, 0), Iyy = readlane_f64(chain, 1), Ixy = readlane_f64(chain, 2);
+    const double lambda = 0.5 * (Ixx + Iyy - sqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
+    double theta = (fabs(Ixx) > fabs(Iyy)) ? (double)fast_atan2_deg((float)(lambda - Ixx), (float)Ixy)
+                                           : (double)fast_atan2_deg((float)Ixy, (float)(lambda - Iyy));
+    theta *= LSD_DEG2RAD;
+    {
+        double diff = theta - reg_angle;
+        while (diff <= -LSD_PI) diff += LSD_2_PI;
+        while (diff > LSD_PI) diff -= LSD_2_PI;
+        if (fabs(diff) > d.prec) theta += LSD_PI;
+    }
+    double dx, dy;
+    sincos_det(theta, dy, dx);
+    double l_min = 0.0, l_max = 0.0;
+    for (int t = lane; t < n_reg; t += 64) {
+        const int pxy = ld_coherent(list + t);
+        const double rdx = (double)(pxy & 0xFFFF) - cx, rdy = (double)(pxy >> 16) - cy;
+        const double l = rdx * dx + rdy * dy;
+        l_max = l > l_max ? l : l_max;
+        l_min = l < l_min ? l : l_min;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double om = __shfl_xor(l_max, off, 64), on = __shfl_xor(l_min, off, 64);
+        l_max = om > l_max ? om : l_max;
+        l_min = on < l_min ? on : l_min;
+    }
+    double x1 = cx + l_min * dx, y1 = cy + l_min * dy, x2 = cx + l_max * dx, y2 = cy + l_max * dy;
+    x1 += 0.5; y1 += 0.5; x2 += 0.5; y2 += 0.5;
+    if (d.scale != 1) {
+        x1 /= d.scale; y1 /= d.scale; x2 /= d.scale; y2 /= d.scale;
+    }
+    return make_float4((float)x1, (float)y1, (float)x2, (float)y2);
+}
+
+__global__ __launch_bounds__(LSD_NW * 64) void lsd_grow_waves_kernel(LsdDev d, LsdWaves x) {
+    __shared__ int s_ring[LSD_NW][LSD_WRING];
+    __shared__ double s_term[LSD_NW][3][64];
+    __shared__ int s_scan, s_done, s_lock, s_if_rank[LSD_NW], s_if_seed[LSD_NW];
+    const int b = blockIdx.x, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int w = d.w, h = d.h, npx = w * h;
+    const size_t base = (size_t)b * npx;
+    const float* __restrict__ ang = d.ang + base;
+    const float2* __restrict__ csn = d.csn + base;
+    const double* __restrict__ mod = d.mod + base;
+    int32_t* used = d.used + base;
+    const uint32_t* __restrict__ order = d.order + base;
+    int32_t* pend = x.pend + base;
+    int32_t* wlist = x.wlist + ((size_t)b * LSD_NW + wv) * npx;
+    if (threadIdx.x == 0) {
+        s_scan = -1;
+        s_done = 0;
+        s_lock = 0;
+    }
+    if (threadIdx.x < LSD_NW) {
+        s_if_rank[threadIdx.x] = -1;
+        s_if_seed[threadIdx.x] = -1;
+    }
+    __syncthreads();
+    if (wv == 0) {
+        // ---------------- the committer ----------------
+        int n_seg = 0;
+        for (int o0 = 0; o0 < npx; o0 += 64) {
+            const uint32_t key = o0 + lane < npx ? order[o0 + lane] : LSD_NOKEY;
+            if ((uint32_t)__builtin_amdgcn_readfirstlane((int)key) == LSD_NOKEY) break;
+            const int q_l = (int)(key & ((1u << LSD_IDX_BITS) - 1u));
+            const bool key_ok = key != LSD_NOKEY;
+            const float ang_l = key_ok ? ang[q_l] : -1.f;
+            unsigned long long todo = __ballot(key_ok && ld_coherent(used + (key_ok ? q_l : 0)) == 0);
+            while (todo) {
+                const int j = __builtin_ctzll(todo);
+                todo &= todo - 1ull;
+                const int seed = __builtin_amdgcn_readlane(q_l, j), rank = o0 + j;
+                if (lane == 0) {
+                    lds_st(&s_scan, rank);
+                    lds_st(&s_if_seed[0], seed);
+                }
+                int p = ld_coherent(pend + rank);
+                if (!p) {
+                    bool in_flight = false;
+                    for (int v = 1; v < LSD_NW; ++v) in_flight = in_flight || lds_ld(&s_if_rank[v]) == rank;
+                    if (in_flight)  // another wave is growing this very seed: its work is the work this wave would do (bounded wait)
+                        for (int spin = 0; spin < (1 << 20) && !(p = ld_coherent(pend + rank)); ++spin) __builtin_amdgcn_s_sleep(8);
+                    else
+                        p = ld_coherent(pend + rank);  // (published between the two looks)
+                }
+                bool took = false;
+                if (p) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    const int pw = (p - 1) >> 20, ri = (p - 1) & ((1 << 20) - 1);
+                    const LsdRec* rc = x.rec + ((size_t)b * LSD_NW + pw) * LSD_REC_CAP + ri;
+                    const int n = ld_coherent(&rc->n), off = ld_coherent(&rc->off);
+                    if (n > 0) {
+                        const int32_t* pl = x.wlist + ((size_t)b * LSD_NW + pw) * npx + off;
+                        bool bad = false;
+                        for (int t = lane; t < n; t += 64) {
+                            const int pxy = ld_coherent(pl + t);
+                            bad = bad || ld_coherent(used + (pxy >> 16) * w + (pxy & 0xFFFF)) != 0;
+                        }
+                        if (!__ballot(bad)) {  // every pixel still free: this IS the region of the sequential search
+                            for (int t = lane; t < n; t += 64) {
+                                const int pxy = ld_coherent(pl + t);
+                                st_coherent(used + (pxy >> 16) * w + (pxy & 0xFFFF), 1);
+                            }
+                            took = true;
+                            if (n >= d.min_reg_size) {
+                                if (lane == 0 && n_seg < d.seg_cap) {  // (vector loads: another wave wrote the record during this launch)
+                                    auto fld = [](const float* f) { return __int_as_float(ld_coherent(reinterpret_cast<const int32_t*>(f))); };
+                                    d.seg[(size_t)b * d.seg_cap + n_seg] = make_float4(fld(&rc->x1), fld(&rc->y1), fld(&rc->x2), fld(&rc->y2));
+                                }
+                                ++n_seg;
+                            }
+                        }
+                    }
+                }
+                if (!took) {
+                    double reg_angle;
+                    const int n = grow_region_w<true>(ang, csn, used, nullptr, 0, wlist, npx, s_ring[0], seed, readlane_f32(ang_l, j), w, h, d.prec,
+                                                      reg_angle);
+                    if (n >= d.min_reg_size) {
+                        const float4 sg = region_segment_w(d, wlist, n, mod, reg_angle, s_term[0]);
+                        if (lane == 0 && n_seg < d.seg_cap) d.seg[(size_t)b * d.seg_cap + n_seg] = sg;
+                        ++n_seg;
+                    }
+                }
+                wave_publish();
+                todo &= __ballot(key_ok && ld_coherent(used + (key_ok ? q_l : 0)) == 0);  // seeds of the batch taken meanwhile
+            }
+        }
+        if (lane == 0) {
+            d.n_seg[b] = n_seg;
+            lds_st(&s_done, 1);
+        }
+    } else {
+        // ---------------- a speculating wave ----------------
+        int32_t* stamp = x.stamp + ((size_t)b * LSD_NW + wv) * npx;
+        LsdRec* rec = x.rec + ((size_t)b * LSD_NW + wv) * LSD_REC_CAP;
+        int id = 0, off = 0, nrec = 0;
+        for (int idle = 0; idle < (1 << 22);) {  // (bounded: a wave that finds nothing for this long gives up)
+            if (lds_ld(&s_done)) break;
+            int got = 0;
+            if (lane == 0) got = atomicCAS(&s_lock, 0, 1) == 0;
+            got = __builtin_amdgcn_readfirstlane(got);
+            if (!got) {
+                __builtin_amdgcn_s_sleep(2);
+                ++idle;
+                continue;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const int scan = lds_ld(&s_scan);
+            int pick_r = -1, pick_q = 0;
+            for (int c = 0; c < LSD_LOOK && pick_r < 0; c += 64) {
+                const int r = scan + 1 + c + lane;
+                const uint32_t key = r < npx ? order[r] : LSD_NOKEY;
+                if ((uint32_t)__builtin_amdgcn_readfirstlane((int)key) == LSD_NOKEY) break;
+                const bool ok = key != LSD_NOKEY;
+                const int q = (int)(key & ((1u << LSD_IDX_BITS) - 1u));
+                bool fr = ok && ld_coherent(used + (ok ? q : 0)) == 0 && ld_coherent(pend + (ok ? r : 0)) == 0;
+                const int qx = q % w, qy = q / w;
+                for (int v = 0; v < LSD_NW; ++v) {
+                    const int sv = lds_ld(&s_if_seed[v]);  // uniform
+                    if (sv >= 0) {
+                        const int ddx = qx - sv % w, ddy = qy - sv / w;
+                        const int adx = ddx < 0 ? -ddx : ddx, ady = ddy < 0 ? -ddy : ddy;
+                        fr = fr && (adx > ady ? adx : ady) >= LSD_SEP;
+                    }
+                }
+                const unsigned long long m = __ballot(fr);
+                if (m) {
+                    const int L = __builtin_ctzll(m);
+                    pick_r = __builtin_amdgcn_readlane(r, L);
+                    pick_q = __builtin_amdgcn_readlane(q, L);
+                }
+            }
+            if (pick_r >= 0 && lane == 0) {
+                lds_st(&s_if_rank[wv], pick_r);
+                lds_st(&s_if_seed[wv], pick_q);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the in-flight entry before the lock opens
+            if (lane == 0) lds_st(&s_lock, 0);
+            if (pick_r < 0) {
+                __builtin_amdgcn_s_sleep(32);
+                ++idle;
+                continue;
+            }
+            ++id;
+            double reg_angle = 0.0;
+            const int n = grow_region_w<false>(ang, csn, used, stamp, id, wlist + off, npx - off, s_ring[wv], pick_q, ang[pick_q], w, h, d.prec,
+                                               reg_angle);
+            float4 sg = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (n >= d.min_reg_size) sg = region_segment_w(d, wlist + off, n, mod, reg_angle, s_term[wv]);
+            if (lane == 0) {
+                LsdRec R;
+                R.off = off; R.n = n > 0 ? n : 0; R.x1 = sg.x; R.y1 = sg.y; R.x2 = sg.z; R.y2 = sg.w;
+                rec[nrec] = R;
+            }
+            wave_publish();  // the list and the record before the table entry
+            if (lane == 0) st_coherent(pend + pick_r, ((wv << 20) | nrec) + 1);
+            wave_publish();  // the table entry before the seed leaves the in-flight set
+            if (lane == 0) {
+                lds_st(&s_if_rank[wv], -1);
+                lds_st(&s_if_seed[wv], -1);
+            }
+            if (n > 0) off += n;
+            ++nrec;
+            if (nrec >= LSD_REC_CAP || npx - off < 4096) break;  // out of room: this wave stops speculating
+        }
+        if (lane == 0) {  // (whatever ended the loop: nothing of this wave is in flight any more)
+            lds_st(&s_if_rank[wv], -1);
+            lds_st(&s_if_seed[wv], -1);
+        }
+    }
+}
+
 // LSDDetectorC::detectImpl's loop over the segments of the (single) octave (:254-303) and the cut of stereoFrame.cpp:231-240
 constexpr int KL_T = 256;
 __global__ __launch_bounds__(KL_T) void lsd_keylines_kernel(LsdDev d) {
@@ -659,6 +1090,9 @@ struct stvo_lsd {
     float* response = nullptr;
     int32_t* n_lines = nullptr;
     double* dbg = nullptr;
+    stvo::LsdWaves xw{};      // scratch of lsd_grow_waves_kernel (STVO_LSD_WAVES=1, small batches), or null
+    char* wdev = nullptr;
+    size_t stamp_bytes = 0, pend_bytes = 0;
 };
 
 namespace {
@@ -684,8 +1118,15 @@ int lsd_enqueue(stvo_lsd* o, const uint8_t* images, stvo_keyline* lines, float* 
     // (STVO_LSD_SORT_FULL=1: all 32 bits, the index bits included — the same order, more digit passes)
     const int begin_bit = stvo::dbg().lsd_sort_full == 1 ? 0 : stvo::LSD_IDX_BITS;
     HIP_TRY(ctx, hipcub::DeviceSegmentedRadixSort::SortKeys(o->sort_tmp, tb, d.keys, d.order, d.B * d.w * d.h, d.B, o->seg_off, o->seg_off + 1, begin_bit, 32, s));
-    if (stvo::dbg().lsd_grow == 0) hipLaunchKernelGGL(stvo::lsd_grow_kernel<false>, dim3(d.B), dim3(64), 0, s, d);
-    else hipLaunchKernelGGL(stvo::lsd_grow_kernel<true>, dim3(d.B), dim3(64), 0, s, d);
+    if (o->wdev) {  // one workgroup of LSD_NW waves per image (opt-in, see lsd_grow_waves_kernel)
+        HIP_TRY(ctx, hipMemsetAsync(o->xw.stamp, 0, o->stamp_bytes, s));
+        HIP_TRY(ctx, hipMemsetAsync(o->xw.pend, 0, o->pend_bytes, s));
+        hipLaunchKernelGGL(stvo::lsd_grow_waves_kernel, dim3(d.B), dim3(stvo::LSD_NW * 64), 0, s, d, o->xw);
+    } else if (stvo::dbg().lsd_grow == 0) {
+        hipLaunchKernelGGL(stvo::lsd_grow_kernel<false>, dim3(d.B), dim3(64), 0, s, d);
+    } else {
+        hipLaunchKernelGGL(stvo::lsd_grow_kernel<true>, dim3(d.B), dim3(64), 0, s, d);
+    }
     const size_t lds = (size_t)d.seg_cap * 8;
     hipLaunchKernelGGL(stvo::lsd_keylines_kernel, dim3(d.B), dim3(stvo::KL_T), lds, s, d);
     return check_launch(ctx);
@@ -777,6 +1218,18 @@ int stvo_lsd_create(stvo_ctx* ctx, int B, int cols, int rows, int max_keylines, 
     }
     if (ok && (size_t)d.seg_cap * 8 > 48 * 1024)
         ok = stvo::lds_opt_in(reinterpret_cast<const void*>(stvo::lsd_keylines_kernel), d.seg_cap * 8);
+    if (ok && stvo::dbg().lsd_waves == 1 && B <= stvo::LSD_WAVES_MAX_B) {
+        decltype(c) cw;
+        const size_t w_stamp = cw.take(nb * stvo::LSD_NW * npx * 4), w_list = cw.take(nb * stvo::LSD_NW * npx * 4),
+                     w_rec = cw.take(nb * stvo::LSD_NW * stvo::LSD_REC_CAP * sizeof(stvo::LsdRec)), w_pend = cw.take(nb * npx * 4);
+        ok = hip_ok(ctx, hipMalloc((void**)&o->wdev, cw.off), "hipMalloc lsd waves");
+        if (ok) {
+            o->xw.stamp = (int32_t*)(o->wdev + w_stamp); o->xw.wlist = (int32_t*)(o->wdev + w_list);
+            o->xw.rec = (stvo::LsdRec*)(o->wdev + w_rec); o->xw.pend = (int32_t*)(o->wdev + w_pend);
+            o->stamp_bytes = nb * stvo::LSD_NW * npx * 4;
+            o->pend_bytes = nb * npx * 4;
+        }
+    }
     if (!ok) {
         stvo_lsd_destroy(o);
         return STVO_ERR_HIP;
@@ -793,6 +1246,7 @@ int stvo_lsd_destroy(stvo_lsd* o) {
     }
     if (o->dbg) (void)hipFree(o->dbg);
     if (o->sort_tmp) (void)hipFree(o->sort_tmp);
+    if (o->wdev) (void)hipFree(o->wdev);
     if (o->dev) (void)hipFree(o->dev);
     delete o;
     return STVO_OK;

@@ -42,6 +42,7 @@ DebugSwitches parse_switches() {
     d.grid_cells = env_int("STVO_GRID_CELLS");
     d.lsd_grow = env_int("STVO_LSD_GROW");
     d.lsd_sort_full = env_int("STVO_LSD_SORT_FULL");
+    d.lsd_waves = env_int("STVO_LSD_WAVES");
     return d;
 }
 DebugSwitches& switches() {
