@@ -844,21 +844,23 @@ __global__ __launch_bounds__(LSD_NW * 64) void lsd_grow_waves_kernel(LsdDev d, L
                     lds_st(&s_scan, rank);
                     lds_st(&s_if_seed[0], seed);
                 }
-                int p = ld_coherent(pend + rank);
+                auto table = [&]() { return __builtin_amdgcn_readfirstlane(ld_coherent(pend + rank)); };  // (one address: a scalar result)
+                int p = table();
                 if (!p) {
                     bool in_flight = false;
                     for (int v = 1; v < LSD_NW; ++v) in_flight = in_flight || lds_ld(&s_if_rank[v]) == rank;
+                    in_flight = __builtin_amdgcn_readfirstlane((int)in_flight) != 0;
                     if (in_flight)  // another wave is growing this very seed: its work is the work this wave would do (bounded wait)
-                        for (int spin = 0; spin < (1 << 20) && !(p = ld_coherent(pend + rank)); ++spin) __builtin_amdgcn_s_sleep(8);
+                        for (int spin = 0; spin < (1 << 20) && !(p = table()); ++spin) __builtin_amdgcn_s_sleep(8);
                     else
-                        p = ld_coherent(pend + rank);  // (published between the two looks)
+                        p = table();  // (published between the two looks)
                 }
                 bool took = false;
                 if (p) {
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                     const int pw = (p - 1) >> 20, ri = (p - 1) & ((1 << 20) - 1);
                     const LsdRec* rc = x.rec + ((size_t)b * LSD_NW + pw) * LSD_REC_CAP + ri;
-                    const int n = ld_coherent(&rc->n), off = ld_coherent(&rc->off);
+                    const int n = __builtin_amdgcn_readfirstlane(ld_coherent(&rc->n)), off = __builtin_amdgcn_readfirstlane(ld_coherent(&rc->off));
                     if (n > 0) {
                         const int32_t* pl = x.wlist + ((size_t)b * LSD_NW + pw) * npx + off;
                         bool bad = false;
@@ -907,6 +909,42 @@ __global__ __launch_bounds__(LSD_NW * 64) void lsd_grow_waves_kernel(LsdDev d, L
         int id = 0, off = 0, nrec = 0;
         for (int idle = 0; idle < (1 << 22);) {  // (bounded: a wave that finds nothing for this long gives up)
             if (lds_ld(&s_done)) break;
+            // the scan for a candidate runs WITHOUT the lock (up to LSD_LOOK ranks, three loads per 64); under the lock only the
+            // candidate is looked at again — the lock is held for one memory round trip
+            auto separated = [&](int q) {
+                const int qx = q % w, qy = q / w;
+                bool far = true;
+                for (int v = 0; v < LSD_NW; ++v) {
+                    const int sv = lds_ld(&s_if_seed[v]);  // uniform
+                    if (sv >= 0) {
+                        const int ddx = qx - sv % w, ddy = qy - sv / w;
+                        const int adx = ddx < 0 ? -ddx : ddx, ady = ddy < 0 ? -ddy : ddy;
+                        far = far && (adx > ady ? adx : ady) >= LSD_SEP;
+                    }
+                }
+                return far;
+            };
+            const int scan = lds_ld(&s_scan);
+            int pick_r = -1, pick_q = 0;
+            for (int c = 0; c < LSD_LOOK && pick_r < 0; c += 64) {
+                const int r = scan + 1 + c + lane;
+                const uint32_t key = r < npx ? order[r] : LSD_NOKEY;
+                if ((uint32_t)__builtin_amdgcn_readfirstlane((int)key) == LSD_NOKEY) break;
+                const bool ok = key != LSD_NOKEY;
+                const int q = (int)(key & ((1u << LSD_IDX_BITS) - 1u));
+                const bool fr = ok && ld_coherent(used + (ok ? q : 0)) == 0 && ld_coherent(pend + (ok ? r : 0)) == 0 && separated(q);
+                const unsigned long long m = __ballot(fr);
+                if (m) {
+                    const int L = __builtin_ctzll(m);
+                    pick_r = __builtin_amdgcn_readlane(r, L);
+                    pick_q = __builtin_amdgcn_readlane(q, L);
+                }
+            }
+            if (pick_r < 0) {
+                __builtin_amdgcn_s_sleep(32);
+                ++idle;
+                continue;
+            }
             int got = 0;
             if (lane == 0) got = atomicCAS(&s_lock, 0, 1) == 0;
             got = __builtin_amdgcn_readfirstlane(got);
@@ -916,39 +954,15 @@ __global__ __launch_bounds__(LSD_NW * 64) void lsd_grow_waves_kernel(LsdDev d, L
                 continue;
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            const int scan = lds_ld(&s_scan);
-            int pick_r = -1, pick_q = 0;
-            for (int c = 0; c < LSD_LOOK && pick_r < 0; c += 64) {
-                const int r = scan + 1 + c + lane;
-                const uint32_t key = r < npx ? order[r] : LSD_NOKEY;
-                if ((uint32_t)__builtin_amdgcn_readfirstlane((int)key) == LSD_NOKEY) break;
-                const bool ok = key != LSD_NOKEY;
-                const int q = (int)(key & ((1u << LSD_IDX_BITS) - 1u));
-                bool fr = ok && ld_coherent(used + (ok ? q : 0)) == 0 && ld_coherent(pend + (ok ? r : 0)) == 0;
-                const int qx = q % w, qy = q / w;
-                for (int v = 0; v < LSD_NW; ++v) {
-                    const int sv = lds_ld(&s_if_seed[v]);  // uniform
-                    if (sv >= 0) {
-                        const int ddx = qx - sv % w, ddy = qy - sv / w;
-                        const int adx = ddx < 0 ? -ddx : ddx, ady = ddy < 0 ? -ddy : ddy;
-                        fr = fr && (adx > ady ? adx : ady) >= LSD_SEP;
-                    }
-                }
-                const unsigned long long m = __ballot(fr);
-                if (m) {
-                    const int L = __builtin_ctzll(m);
-                    pick_r = __builtin_amdgcn_readlane(r, L);
-                    pick_q = __builtin_amdgcn_readlane(q, L);
-                }
-            }
-            if (pick_r >= 0 && lane == 0) {
+            const bool still = __builtin_amdgcn_readfirstlane(  // (every lane computed the same: make it a scalar for the branches below)
+                (int)(pick_r > lds_ld(&s_scan) && ld_coherent(used + pick_q) == 0 && ld_coherent(pend + pick_r) == 0 && separated(pick_q))) != 0;
+            if (still && lane == 0) {
                 lds_st(&s_if_rank[wv], pick_r);
                 lds_st(&s_if_seed[wv], pick_q);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the in-flight entry before the lock opens
             if (lane == 0) lds_st(&s_lock, 0);
-            if (pick_r < 0) {
-                __builtin_amdgcn_s_sleep(32);
+            if (!still) {
                 ++idle;
                 continue;
             }
