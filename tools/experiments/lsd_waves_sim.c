@@ -6,7 +6,8 @@
  * seed being grown, and grows it against the flags committed so far (a snapshot at its start: the validation at commit makes that exact).
  * Time unit: one pixel added by one wave (the sequential chain of the kernel); a region costs n + C0 units.  Output: makespan against the
  * sequential sum, for W, SEP, LOOK.  The committed regions are the sequential ones (count and total size are checked).
- *   gcc -O2 -o /tmp/lsd_waves tools/experiments/lsd_waves_sim.c oracle/stvo_lsd_oracle.c oracle/stvo_orb_oracle.c -lm && /tmp/lsd_waves [noise] */
+ *   gcc -O2 -o /tmp/lsd_waves tools/experiments/lsd_waves_sim.c oracle/stvo_lsd_oracle.c oracle/stvo_orb_oracle.c -lm && /tmp/lsd_waves [noise [image.raw]]
+ * (image.raw: 1241 x 376 bytes instead of the built-in scene, e.g. python -c "import sys; sys.path[:0]=['stvo-pl_amd/python']; from stvo_amd import synth; synth.make_image(500).tofile('/tmp/img500.raw')") */
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -72,6 +73,7 @@ int main(int argc, char** argv) {
         for (int y = y0 < 0 ? 0 : y0; y < y0 + h && y < H0; ++y) for (int x = x0 < 0 ? 0 : x0; x < x0 + w && x < W0; ++x) f[y * W0 + x] = v;
     }
     for (int i = 0; i < npx0; ++i) { double n = -6; for (int t = 0; t < 12; ++t) n += (RND() % 10000) / 10000.0; double v = f[i] + noise * n; img0[i] = v < 0 ? 0 : v > 255 ? 255 : (uint8_t)lrint(v); }
+    if (argc > 2) { FILE* fp = fopen(argv[2], "rb"); if (!fp || fread(img0, 1, npx0, fp) != (size_t)npx0) { printf("cannot read %s\n", argv[2]); return 1; } fclose(fp); }
     { int32_t ki[7]; orc_lsd_kernel7(0.6, ki); int32_t* tmp = malloc(sizeof(int32_t) * npx0); uint8_t* bl = malloc(npx0);
 #define R101(p, n) ((p) < 0 ? -(p) : ((p) >= (n) ? 2 * (n) - 2 - (p) : (p)))
       for (int y = 0; y < H0; ++y) for (int x = 0; x < W0; ++x) { int a = 0; for (int i = 0; i < 7; ++i) a += ki[i] * img0[y * W0 + R101(x + i - 3, W0)]; tmp[y * W0 + x] = a; }
