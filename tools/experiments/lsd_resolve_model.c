@@ -57,6 +57,7 @@ static int grow_seq(int seed, int32_t* reg, double prec, double* angle_out) {
     *angle_out = ra;
     return n;
 }
+static long long g_rounds, g_pred_ok;
 static long long g_passes, g_subgroups, g_flips, g_accepts;
 /* the lane model (marks `used`) */
 static int grow_model(int seed, int32_t* reg, double prec, double* angle_out) {
@@ -81,6 +82,14 @@ static int grow_model(int seed, int32_t* reg, double prec, double* angle_out) {
             cand[r][lane] = valid && u == 0 && a >= 0.f;
             ad[r][lane] = (double)a * DEG2RAD;
         }
+        /* could the NEXT round's loads be issued before this round is resolved?  prediction from the state at the start of the round: the
+         * first lane of every pixel aligned with the start angle, sub-group after sub-group */
+        int pred[128], n_pred = 0;
+        for (int r = 0; r < GR && 7 * r < cnt; ++r) for (int l = 0; l < 64; ++l) if (cand[r][l] && aligned_d(reg_angle, ad[r][l], prec)) {
+            int dupe = 0; for (int t = 0; t < n_pred; ++t) dupe |= pred[t] == qq[r][l];
+            if (!dupe) pred[n_pred++] = qq[r][l];
+        }
+        const int n_before = n_reg;
         for (int r = 0; r < GR; ++r) {
             if (7 * r >= cnt) break;
             uint64_t A = 0, acc = 0;
@@ -121,6 +130,8 @@ static int grow_model(int seed, int32_t* reg, double prec, double* angle_out) {
             }
             if (A) reg_angle = (double)orc_fast_atan2(sumdy, sumdx) * DEG2RAD;
         }
+        ++g_rounds;
+        { int same = n_reg - n_before == n_pred; for (int t = 0; t < n_pred && same; ++t) same = reg[n_before + t] == pred[t]; g_pred_ok += same; }
         i += cnt;
     }
     *angle_out = reg_angle;
@@ -179,5 +190,6 @@ int main(int argc, char** argv) {
     printf("%lld regions, %lld differ; flags equal: %d\n", regions, bad, !memcmp(used_a, used_b, npx));
     printf("sub-groups %lld, with candidates accepted at the first guess or later: verification passes %lld, passes that ended in a flip %lld, pixels accepted %lld\n",
            g_subgroups, g_passes, g_flips, g_accepts);
+    printf("rounds %lld, of which the accepted pixels (in order) equal the prediction made at the start of the round: %lld (%.1f %%)\n", g_rounds, g_pred_ok, 100.0 * g_pred_ok / g_rounds);
     return bad != 0;
 }
