@@ -57,7 +57,7 @@ static int grow_seq(int seed, int32_t* reg, double prec, double* angle_out) {
     *angle_out = ra;
     return n;
 }
-static long long g_rounds, g_pred_ok;
+static long long g_rounds, g_pred_ok, g_pref_used, g_pref_bad;
 static long long g_passes, g_subgroups, g_flips, g_accepts;
 /* the lane model (marks `used`) */
 static int grow_model(int seed, int32_t* reg, double prec, double* angle_out) {
@@ -67,9 +67,11 @@ static int grow_model(int seed, int32_t* reg, double prec, double* angle_out) {
     orc_sincos_det(reg_angle, &s0, &c0);
     float sumdx = (float)c0, sumdy = (float)s0;
     reg[0] = seed; used[seed] = 1;
+    /* early loads for the NEXT round (issued right after the prediction, before this round is resolved): pixel and flag per lane */
+    int have_pref = 0, pref_i = 0, pref_cnt = 0, pref_q[GR][64], pref_u[GR][64];
     for (int i = 0; i < n_reg;) {
         const int cnt = n_reg - i < 7 * GR ? n_reg - i : 7 * GR;
-        int qq[GR][64]; float cx[GR][64], cy[GR][64]; double ad[GR][64]; int cand[GR][64];
+        int qq[GR][64]; float cx[GR][64], cy[GR][64]; double ad[GR][64]; int cand[GR][64], uu[GR][64];
         for (int r = 0; r < GR; ++r) for (int lane = 0; lane < 64; ++lane) {
             const int slot0 = lane / 9, nb = lane - slot0 * 9, slot = 7 * r + slot0;
             int valid = lane < 63 && slot < cnt && nb != 4;
@@ -79,8 +81,15 @@ static int grow_model(int seed, int32_t* reg, double prec, double* angle_out) {
             qq[r][lane] = valid ? yy * W + xx : -1;
             int u = 1; float a = -1.f; cx[r][lane] = cy[r][lane] = 0.f;
             if (valid) { u = used[qq[r][lane]]; a = angd[qq[r][lane]]; cx[r][lane] = csn[2 * qq[r][lane]]; cy[r][lane] = csn[2 * qq[r][lane] + 1]; }
+            uu[r][lane] = u;
             cand[r][lane] = valid && u == 0 && a >= 0.f;
             ad[r][lane] = (double)a * DEG2RAD;
+        }
+        if (have_pref) {  /* what the early loads + the correction hold must be what the fetch of this round reads */
+            ++g_pref_used;
+            int bad = pref_i != i || pref_cnt != cnt;
+            for (int r = 0; r < GR && !bad; ++r) for (int l = 0; l < 64; ++l) if (pref_q[r][l] != qq[r][l] || (qq[r][l] >= 0 && pref_u[r][l] != uu[r][l])) bad = 1;
+            g_pref_bad += bad;
         }
         /* could the NEXT round's loads be issued before this round is resolved?  prediction from the state at the start of the round: the
          * first lane of every pixel aligned with the start angle, sub-group after sub-group */
@@ -90,6 +99,18 @@ static int grow_model(int seed, int32_t* reg, double prec, double* angle_out) {
             if (!dupe) pred[n_pred++] = qq[r][l];
         }
         const int n_before = n_reg;
+        int early_q[GR][64], early_u[GR][64];
+        const int next_i = i + cnt, next_n = n_reg + n_pred, next_cnt = next_n - next_i < 7 * GR ? next_n - next_i : 7 * GR;
+        for (int r = 0; r < GR; ++r) for (int lane = 0; lane < 64; ++lane) {  /* the points of the next round: queued list entries, then the prediction */
+            const int slot0 = lane / 9, nb = lane - slot0 * 9, slot = 7 * r + slot0;
+            int valid = lane < 63 && slot < next_cnt && nb != 4;
+            const int idx = next_i + slot;
+            const int pq = valid ? (idx < n_reg ? reg[idx] : pred[idx - n_reg]) : 0;
+            const int xx = pq % W + (nb % 3) - 1, yy = pq / W + nb / 3 - 1;
+            valid = valid && xx >= 0 && xx < W && yy >= 0 && yy < H;
+            early_q[r][lane] = valid ? yy * W + xx : -1;
+            early_u[r][lane] = valid ? used[early_q[r][lane]] : 1;   /* the flags as they are NOW: this round's acceptances are not in them */
+        }
         for (int r = 0; r < GR; ++r) {
             if (7 * r >= cnt) break;
             uint64_t A = 0, acc = 0;
@@ -131,7 +152,15 @@ static int grow_model(int seed, int32_t* reg, double prec, double* angle_out) {
             if (A) reg_angle = (double)orc_fast_atan2(sumdy, sumdx) * DEG2RAD;
         }
         ++g_rounds;
-        { int same = n_reg - n_before == n_pred; for (int t = 0; t < n_pred && same; ++t) same = reg[n_before + t] == pred[t]; g_pred_ok += same; }
+        { int same = n_reg - n_before == n_pred; for (int t = 0; t < n_pred && same; ++t) same = reg[n_before + t] == pred[t]; g_pred_ok += same;
+          have_pref = same && next_cnt > 0;
+          if (have_pref) {
+              pref_i = next_i; pref_cnt = next_cnt;
+              for (int r = 0; r < GR; ++r) for (int l = 0; l < 64; ++l) {
+                  pref_q[r][l] = early_q[r][l]; pref_u[r][l] = early_u[r][l];
+                  for (int t = 0; t < n_pred; ++t) if (early_q[r][l] == pred[t]) pref_u[r][l] = 1;  /* the correction: pixels this round took */
+              }
+          } }
         i += cnt;
     }
     *angle_out = reg_angle;
@@ -191,5 +220,6 @@ int main(int argc, char** argv) {
     printf("sub-groups %lld, with candidates accepted at the first guess or later: verification passes %lld, passes that ended in a flip %lld, pixels accepted %lld\n",
            g_subgroups, g_passes, g_flips, g_accepts);
     printf("rounds %lld, of which the accepted pixels (in order) equal the prediction made at the start of the round: %lld (%.1f %%)\n", g_rounds, g_pred_ok, 100.0 * g_pred_ok / g_rounds);
-    return bad != 0;
+    printf("rounds that could run on loads issued one round early (+ the correction for the pixels taken meanwhile): %lld, of which the data differ from a fetch at the round's start: %lld\n", g_pref_used, g_pref_bad);
+    return bad != 0 || g_pref_bad != 0;
 }
