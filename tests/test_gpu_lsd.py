@@ -75,6 +75,29 @@ def test_lsd_plain_growth_is_the_same(hip, oracle, switches):
             lsd.close()
 
 
+@pytest.mark.skipif(not os.environ.get("STVO_TEST_LSD_PIPE"), reason="lsd_grow_pipe_kernel (STVO_LSD_GROW=2) was written at the end of round 4 "
+                    "without GPU time left: opt-in until it has run on hardware (set STVO_TEST_LSD_PIPE=1, under a timeout)")
+def test_lsd_early_loads_of_the_next_round_is_the_same(hip, oracle, switches):
+    """STVO_LSD_GROW=2: one wave per image with the next round's neighbour data requested from a prediction of what the round accepts
+    (lsd_kernels.hip: grow_region_w<.., PIPE>; CPU model: tools/experiments/lsd_resolve_model.c) — the oracle's segments in order."""
+    from stvo_amd import capi
+    switches({"STVO_LSD_GROW": "2"})
+    cols, rows = 752, 480
+    rng = np.random.default_rng(47)
+    imgs = np.stack([synth.make_image(630, cols, rows), clean_image(cols, rows, 631), rng.integers(0, 255, (rows, cols), dtype=np.uint8),
+                     np.full((rows, cols), 77, np.uint8)])
+    for scale in (1.2, 1.0):
+        lsd = capi.Lsd(hip, 4, cols, rows, capi.lsd_params(min_length=4.0, nfeatures=0, scale=scale), max_keylines=2048)
+        try:
+            segs, n = lsd.segments(imgs)
+            for b in range(4):
+                ref = oracle.lsd_segments(imgs[b], oracle.lsd_opts(scale=scale))
+                assert n[b] == len(ref)
+                assert np.array_equal(segs[b], ref)
+        finally:
+            lsd.close()
+
+
 @pytest.mark.skipif(not os.environ.get("STVO_TEST_LSD_WAVES"), reason="lsd_grow_waves_kernel (STVO_LSD_WAVES=1) was written at the end of round 4 "
                     "without GPU time left: opt-in until it has run on hardware (set STVO_TEST_LSD_WAVES=1, under a timeout)")
 def test_lsd_sixteen_waves_per_image_is_the_same(hip, oracle, switches):
