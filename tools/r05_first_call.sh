@@ -8,6 +8,9 @@
 R=$PWD; OUT=$R/gpurun_out/r05_first; mkdir -p $OUT
 bash tools/lsd_check.sh > $OUT/lsd_check.txt 2>&1
 timeout 30 python tools/orb_probe.py > $OUT/orb_probe.txt 2>&1
+# the blur that requests rows ahead (never run): parity, then the same probe with it
+STVO_TEST_BLUR_AHEAD=1 timeout 60 python -m pytest tests/test_gpu_orb.py -x -q -k rows_ahead > $OUT/blur_ahead_test.txt 2>&1
+STVO_BLUR_AHEAD=1 timeout 30 python tools/orb_probe.py > $OUT/orb_probe_blur_ahead.txt 2>&1
 for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_BUSY_CU_CYCLES SQ_WAVES"; do
     tag=$(echo $grp | tr ' ' '_')
     cd /tmp && export TMPDIR=/tmp; rm -rf /tmp/pmc_o
@@ -15,4 +18,4 @@ for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_BUSY_CU_CYCLES SQ_WAVE
     cd $R; python tools/rocprof_summary.py pmc $(find /tmp/pmc_o -name "*.db" 2>/dev/null | head -1) > $OUT/pmc_$tag.txt 2>/dev/null; rm -rf /tmp/pmc_o
 done
 timeout 150 python bench.py --no-extras --no-cpu-baseline > $OUT/bench_quick.json 2> $OUT/bench_quick.err
-tail -12 $OUT/lsd_check.txt; cat $OUT/orb_probe.txt; grep -h "orb_" $OUT/pmc_*.txt | cut -c1-150 | head -16; cut -c1-300 $OUT/bench_quick.json
+tail -12 $OUT/lsd_check.txt; cat $OUT/orb_probe.txt; tail -1 $OUT/blur_ahead_test.txt; cat $OUT/orb_probe_blur_ahead.txt; grep -h "orb_" $OUT/pmc_*.txt | cut -c1-150 | head -16; cut -c1-300 $OUT/bench_quick.json
