@@ -285,7 +285,7 @@ int stvo_lbd_compute_dev(stvo_lbd* lbd, const uint8_t* images, const stvo_keylin
  * per image, the images of the batch side by side. */
 typedef struct stvo_lsd_params {
     int32_t refine;        /* Config::lsdRefine()      0 */
-    int32_t n_bins;        /* Config::lsdNBins()       1024 */
+    int32_t n_bins;        /* Config::lsdNBins()       1024 (1 .. 2048; more: STVO_ERR_UNSUPPORTED) */
     double scale;          /* Config::lsdScale()       1.2 */
     double sigma_scale;    /* Config::lsdSigmaScale()  0.6 */
     double quant;          /* Config::lsdQuant()       2.0 */

@@ -42,7 +42,7 @@
 #include "../include/stvo_types.h"
 
 float orc_fast_atan2(float y, float x);                                                        /* stvo_orb_oracle.c */
-void orc_resize_linear(const uint8_t* src, int scols, int srows, uint8_t* dst, int dcols, int drows); /* stvo_orb_oracle.c */
+void orc_resize_linear_fxy(const uint8_t* src, int scols, int srows, uint8_t* dst, int dcols, int drows, double inv_x, double inv_y); /* stvo_orb_oracle.c */
 
 #define LSD_NOTDEF (-1024.0)
 #define LSD_PI 3.14159265358979323846
@@ -230,7 +230,7 @@ int orc_lsd_segments(const uint8_t* img, int cols, int rows, const orc_lsd_opts*
         gaussian_blur7_sigma(img, cols, rows, sigma, blur);
         orc_lsd_scaled_size(cols, rows, o->scale, &w, &h);
         scaled = (uint8_t*)malloc((size_t)w * h);
-        orc_resize_linear(blur, cols, rows, scaled, w, h);
+        orc_resize_linear_fxy(blur, cols, rows, scaled, w, h, o->scale, o->scale); /* resize(.., Size(), scale, scale): positions from 1 / scale */
         free(blur);
     } else {
         scaled = (uint8_t*)malloc((size_t)w * h);

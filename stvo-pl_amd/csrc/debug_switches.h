@@ -28,9 +28,8 @@ struct DebugSwitches {
     int grid_tail;       // STVO_GRID_TAIL       0: point_tail_kernel as its own launch
     int grid_fused;      // STVO_GRID_FUSED      0: scan formulation of the stereo point matcher
     int grid_fused_cap;  // STVO_GRID_FUSED_CAP  capacity override of the one-workgroup point matcher (tests of the misfit path)
-    int lsd_grow;        // STVO_LSD_GROW        0: the plain form of lsd_grow_kernel (candidates one after the other, sums through v_readlane), 2: lsd_grow_pipe_kernel (NOT verified on hardware yet)
-    int blur_ahead;      // STVO_BLUR_AHEAD      1: orb_blur_kernel requests input row r + 2 before it works on row r (NOT verified on hardware yet)
-    int lsd_waves;       // STVO_LSD_WAVES       1: batches of <= 8 images by lsd_grow_waves_kernel, 16 waves per image (NOT verified on hardware yet)
+    int lsd_grow;        // STVO_LSD_GROW        0: the plain form of lsd_grow_kernel (candidates one after the other, sums through v_readlane)
+    int lsd_waves;       // STVO_LSD_WAVES       0: batches of <= 8 images by lsd_grow_kernel (one wave per image) instead of lsd_grow_waves_kernel (16 waves per image)
     int lsd_sort_full;   // STVO_LSD_SORT_FULL   1: the pseudo-ordering sorts all 32 key bits instead of the bin bits only (lsd_kernels.hip)
     int grid_cells;      // STVO_GRID_CELLS      0: point_cells_kernel as its own launch for small batches too, 1: in the matcher whenever it fits
 };

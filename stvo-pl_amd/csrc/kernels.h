@@ -190,8 +190,10 @@ inline void pose_release_stream(hipStream_t s) { pose2p_release_stream(s); }
 // ---- 8-bit image operations of the ORB front-end that the line detector reuses (orb_kernels.hip) ----
 // cv::GaussianBlur(7 x 7) in 8-bit fixed point with the integer kernel k7 (weights x 2^8), BORDER_REFLECT_101
 void launch_blur7_u8(hipStream_t s, int B, int cols, int rows, const uint8_t* src, uint8_t* dst, const int* k7);
-// cv::resize(INTER_LINEAR) for 8-bit images, 11-bit fixed point
-void launch_resize_linear_u8(hipStream_t s, int B, int scols, int srows, int dcols, int drows, const uint8_t* src, uint8_t* dst);
+// cv::resize(INTER_LINEAR) for 8-bit images, 11-bit fixed point; fx = fy = 0: resize to a given dsize (sample step ssize / dsize),
+// fx, fy > 0: resize(src, dst, Size(), fx, fy) with dsize = cvRound(ssize f) — the sample step stays 1 / f (LSD's scaled image)
+void launch_resize_linear_u8(hipStream_t s, int B, int scols, int srows, int dcols, int drows, const uint8_t* src, uint8_t* dst, double fx = 0.0,
+                             double fy = 0.0);
 
 // ---- K3: grid-windowed stereo matchers, batched over frame pairs (blockIdx.y) ----------------------
 constexpr int GRID_LW = STVO_GRID_COLS + 16, GRID_LCELLS = STVO_GRID_ROWS * GRID_LW, GRID_LSTART_STRIDE = GRID_LCELLS + 4;

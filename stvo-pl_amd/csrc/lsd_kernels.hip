@@ -551,10 +551,9 @@ __global__ __launch_bounds__(64) void lsd_grow_kernel(LsdDev d) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// ONE image by a workgroup of LSD_NW waves — an EXACT asynchronous form of the search for small batches (developer switch
-// STVO_LSD_WAVES=1; written at the end of round 4 WITHOUT GPU time left: it compiles, its scheme is replayed on the CPU by
-// tools/experiments/lsd_waves_sim.c — 6.75 x for one KITTI-size image with 16 waves — but it has not run on hardware yet.  The default
-// path does not touch it).
+// ONE image by a workgroup of LSD_NW waves — an EXACT asynchronous form of the search, the default for batches of <= LSD_WAVES_MAX_B
+// images (STVO_LSD_WAVES=0: one wave per image there too).  Its scheme is replayed on the CPU by tools/experiments/lsd_waves_sim.c; on
+// hardware (round 5) two KITTI-size images take 37 ms per call against 70 ms with one wave each, segments identical in detection order.
 //   wave 0 commits in seed order.  A seed with a finished PENDING region takes it if every pixel of it is still free (flag stores,
 //   lane-parallel; the segment was computed by the wave that grew it), a seed another wave is growing right now is waited for
 //   (bounded), any other seed — and any pending region that lost a pixel — is grown by wave 0 itself, flags set as it goes.
@@ -588,9 +587,9 @@ __device__ __forceinline__ void lds_st(int* p, int v) { __hip_atomic_store(p, v,
 // region_grow from `seed`, the fast form of lsd_grow_kernel.  MARK (the committer): a pixel is taken by setting its flag.  !MARK (a
 // speculating wave): the flags are only read; the wave's own pixels carry `id` in `stamp`.  The list goes to `list` (at most `cap`
 // entries: -1 if it does not fit), the final region angle to `angle_out`.
-template <bool MARK, bool PIPE>
+template <bool MARK>
 __device__ __forceinline__ int grow_region_w(const float* __restrict__ ang, const float2* __restrict__ csn, int32_t* used, int32_t* stamp, int id,
-                                             int32_t* list, int cap, int* ring, int* pred, int seed, float seed_ang, int w, int h, double prec,
+                                             int32_t* list, int cap, int* ring, int seed, float seed_ang, int w, int h, double prec,
                                              double& angle_out) {
     const int lane = threadIdx.x & 63;
     const int sx0 = seed % w, sy0 = seed / w;
@@ -605,24 +604,6 @@ __device__ __forceinline__ int grow_region_w(const float* __restrict__ ang, cons
         st_coherent(list, sx0 | (sy0 << 16));
         ring[0] = sx0 | (sy0 << 16);
     }
-    // PIPE: the neighbour data of the NEXT round are requested right after a prediction of what this round will accept (the first lane of
-    // every pixel aligned with the angle at the START of the round — right in 98 % of the rounds, tools/experiments/lsd_resolve_model.c),
-    // so that their memory round trip runs beside the verification of this round instead of after it.  If the round accepts exactly the
-    // prediction, the next round takes the early data, corrected for the pixels taken meanwhile (their flags were read too early).
-    bool have_pref = false;
-    int e_q[LSD_GR], e_xy[LSD_GR], e_u[LSD_GR], e_own[LSD_GR], p_qq[LSD_GR];
-    float e_a[LSD_GR];
-    float2 e_cs[LSD_GR];
-    bool e_val[LSD_GR];
-    unsigned long long p_acc[LSD_GR];
-#pragma unroll
-    for (int r = 0; r < LSD_GR; ++r) {
-        e_q[r] = e_xy[r] = e_u[r] = e_own[r] = p_qq[r] = 0;
-        e_a[r] = 0.f;
-        e_cs[r] = make_float2(0.f, 0.f);
-        e_val[r] = false;
-        p_acc[r] = 0ull;
-    }
     for (int i = 0; i < n_reg;) {
         const int cnt = n_reg - i < 7 * LSD_GR ? n_reg - i : 7 * LSD_GR;  // uniform
         const int slot0 = lane / 9, nb = lane - slot0 * 9;
@@ -631,24 +612,6 @@ __device__ __forceinline__ int grow_region_w(const float* __restrict__ ang, cons
         float a[LSD_GR];
         double ad[LSD_GR];
         bool val[LSD_GR];
-        if (PIPE && have_pref) {  // uniform
-#pragma unroll
-            for (int r = 0; r < LSD_GR; ++r) {
-                qq[r] = e_q[r]; xy[r] = e_xy[r]; u[r] = e_u[r]; own[r] = e_own[r]; a[r] = e_a[r]; cs[r] = e_cs[r]; val[r] = e_val[r];
-            }
-            // the correction: a pixel the previous round took was still free when the early loads read its flag
-#pragma unroll
-            for (int r2 = 0; r2 < LSD_GR; ++r2) {
-                unsigned long long rem = p_acc[r2];
-                while (rem) {
-                    const int j = __builtin_ctzll(rem);
-                    rem &= rem - 1ull;
-                    const int qj = __builtin_amdgcn_readlane(p_qq[r2], j);
-#pragma unroll
-                    for (int r = 0; r < LSD_GR; ++r) u[r] = qq[r] == qj ? 1 : u[r];
-                }
-            }
-        } else {
         wave_publish();
         const bool in_ring = n_reg - i <= LSD_WRING;  // uniform
 #pragma unroll
@@ -669,67 +632,11 @@ __device__ __forceinline__ int grow_region_w(const float* __restrict__ ang, cons
             a[r] = ang[qq[r]];
             cs[r] = csn[qq[r]];
         }
-        }
         unsigned long long cand_m[LSD_GR];
 #pragma unroll
         for (int r = 0; r < LSD_GR; ++r) {
             cand_m[r] = __ballot(val[r] && u[r] == 0 && (MARK || own[r] != id) && a[r] >= 0.f);
             ad[r] = (double)a[r] * LSD_DEG2RAD;
-        }
-        unsigned long long G[LSD_GR], accv[LSD_GR];
-#pragma unroll
-        for (int r = 0; r < LSD_GR; ++r) G[r] = accv[r] = 0ull;
-        int next_cnt = 0;
-        if constexpr (PIPE) {
-            // the prediction, sub-group after sub-group: the first lane of every pixel aligned with the angle the round starts with (a pixel
-            // predicted for sub-group 0 is no candidate of sub-group 1); the predicted pixels in order go to `pred` (LDS, this wave's)
-            unsigned long long struck1 = 0ull;
-            int n_pred = 0;
-#pragma unroll
-            for (int r = 0; r < LSD_GR; ++r) {
-                if (7 * r >= cnt) break;  // uniform
-                double n_theta = reg_angle - ad[r];
-                if (n_theta < 0) n_theta = -n_theta;
-                if (n_theta > LSD_3_2_PI) {
-                    n_theta -= LSD_2_PI;
-                    if (n_theta < 0) n_theta = -n_theta;
-                }
-                unsigned long long rem = __ballot(n_theta <= prec) & cand_m[r] & (r == 0 ? ~0ull : ~struck1);
-                while (rem) {
-                    const int j = __builtin_ctzll(rem);
-                    const int qj = __builtin_amdgcn_readlane(qq[r], j), xyj = __builtin_amdgcn_readlane(xy[r], j);
-                    G[r] |= 1ull << j;
-                    rem &= ~__ballot(qq[r] == qj);
-                    if (r == 0) struck1 |= __ballot(qq[LSD_GR > 1 ? 1 : 0] == qj);
-                    if (lane == 0 && n_pred < 16) pred[n_pred] = xyj;
-                    ++n_pred;
-                }
-            }
-            const int next_i = i + cnt, next_n = n_reg + n_pred;
-            next_cnt = next_n - next_i < 7 * LSD_GR ? next_n - next_i : 7 * LSD_GR;  // (>= the first 14 of them: pred holds 16)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // pred: lane 0's writes before the reads below (and the earlier rounds' stores
-            __builtin_amdgcn_wave_barrier();                        // of this wave before the early loads: same-wave program order suffices)
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const bool nin_ring = n_reg - next_i <= LSD_WRING;  // uniform
-#pragma unroll
-            for (int r = 0; r < LSD_GR; ++r) {
-                const int slot = 7 * r + slot0, idx = next_i + slot;
-                bool v = lane < 63 && slot < next_cnt && nb != 4;
-                int pxy = 0;
-                if (v) pxy = idx < n_reg ? (nin_ring ? ring[idx & (LSD_WRING - 1)] : ld_coherent(list + idx)) : pred[idx - n_reg];
-                const int xx = (pxy & 0xFFFF) + (nb % 3) - 1, yy = (pxy >> 16) + nb / 3 - 1;
-                v = v && xx >= 0 && xx < w && yy >= 0 && yy < h;
-                e_val[r] = v;
-                e_q[r] = v ? yy * w + xx : 0;
-                e_xy[r] = xx | (yy << 16);
-            }
-#pragma unroll
-            for (int r = 0; r < LSD_GR; ++r) {
-                e_u[r] = ld_coherent(used + e_q[r]);
-                e_own[r] = MARK ? 0 : ld_coherent(stamp + e_q[r]);
-                e_a[r] = ang[e_q[r]];
-                e_cs[r] = csn[e_q[r]];
-            }
         }
         // guess + verification of a sub-group: lsd_grow_kernel<true> has the explanation
 #pragma unroll
@@ -794,7 +701,6 @@ __device__ __forceinline__ int grow_region_w(const float* __restrict__ ang, cons
                 st_coherent(list + idx, xy[r]);
                 ring[idx & (LSD_WRING - 1)] = xy[r];
             }
-            accv[r] = acc;
             n_reg += __builtin_popcountll(acc);
             sumdx = readlane_f32(sx, 63);
             sumdy = readlane_f32(sy, 63);
@@ -802,16 +708,6 @@ __device__ __forceinline__ int grow_region_w(const float* __restrict__ ang, cons
 #pragma unroll
             for (int r2 = 0; r2 < LSD_GR; ++r2)
                 if (r2 > r) cand_m[r2] &= ~hit_m[r2];
-        }
-        if constexpr (PIPE) {
-            bool same = next_cnt > 0;
-#pragma unroll
-            for (int r = 0; r < LSD_GR; ++r) {
-                same = same && accv[r] == G[r];
-                p_acc[r] = accv[r];
-                p_qq[r] = qq[r];
-            }
-            have_pref = same;
         }
         i += cnt;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the ring: this round's writes before the next round's reads
@@ -905,49 +801,6 @@ __device__ __forceinline__ float4 region_segment_w(const LsdDev& d, const int32_
     return make_float4((float)x1, (float)y1, (float)x2, (float)y2);
 }
 
-// One wave per image like lsd_grow_kernel<true>, with the NEXT round's loads requested early (grow_region_w<.., PIPE>): developer switch
-// STVO_LSD_GROW=2.  Written at the end of round 4 without GPU time left — the logic is modelled on the CPU (lsd_resolve_model.c: early
-// loads + correction = a fresh fetch, lane by lane), the kernel itself has not run.
-__global__ __launch_bounds__(64) void lsd_grow_pipe_kernel(LsdDev d) {
-    __shared__ int s_ring[LSD_WRING];
-    __shared__ int s_pred[16];
-    __shared__ double s_term[3][64];
-    const int b = blockIdx.x, lane = threadIdx.x;
-    const int w = d.w, h = d.h, npx = w * h;
-    const size_t base = (size_t)b * npx;
-    const float* __restrict__ ang = d.ang + base;
-    const float2* __restrict__ csn = d.csn + base;
-    const double* __restrict__ mod = d.mod + base;
-    int32_t* used = d.used + base;
-    const uint32_t* __restrict__ order = d.order + base;
-    int32_t* list = d.reg + base;
-    int n_seg = 0;
-    for (int o0 = 0; o0 < npx; o0 += 64) {
-        const uint32_t key = o0 + lane < npx ? order[o0 + lane] : LSD_NOKEY;
-        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)key) == LSD_NOKEY) break;
-        const int q_l = (int)(key & ((1u << LSD_IDX_BITS) - 1u));
-        const bool key_ok = key != LSD_NOKEY;
-        const float ang_l = key_ok ? ang[q_l] : -1.f;
-        unsigned long long todo = __ballot(key_ok && ld_coherent(used + (key_ok ? q_l : 0)) == 0);
-        while (todo) {
-            const int j = __builtin_ctzll(todo);
-            todo &= todo - 1ull;
-            const int seed = __builtin_amdgcn_readlane(q_l, j);
-            double reg_angle;
-            const int n = grow_region_w<true, true>(ang, csn, used, nullptr, 0, list, npx, s_ring, s_pred, seed, readlane_f32(ang_l, j), w, h, d.prec,
-                                                    reg_angle);
-            if (n >= d.min_reg_size) {
-                const float4 sg = region_segment_w(d, list, n, mod, reg_angle, s_term);
-                if (lane == 0 && n_seg < d.seg_cap) d.seg[(size_t)b * d.seg_cap + n_seg] = sg;
-                ++n_seg;
-            }
-            wave_publish();
-            todo &= __ballot(key_ok && ld_coherent(used + (key_ok ? q_l : 0)) == 0);  // seeds of the batch the region took
-        }
-    }
-    if (lane == 0) d.n_seg[b] = n_seg;
-}
-
 __global__ __launch_bounds__(LSD_NW * 64) void lsd_grow_waves_kernel(LsdDev d, LsdWaves x) {
     __shared__ int s_ring[LSD_NW][LSD_WRING];
     __shared__ double s_term[LSD_NW][3][64];
@@ -1032,7 +885,7 @@ __global__ __launch_bounds__(LSD_NW * 64) void lsd_grow_waves_kernel(LsdDev d, L
                 }
                 if (!took) {
                     double reg_angle;
-                    const int n = grow_region_w<true, false>(ang, csn, used, nullptr, 0, wlist, npx, s_ring[0], nullptr, seed, readlane_f32(ang_l, j), w, h, d.prec,
+                    const int n = grow_region_w<true>(ang, csn, used, nullptr, 0, wlist, npx, s_ring[0], seed, readlane_f32(ang_l, j), w, h, d.prec,
                                                       reg_angle);
                     if (n >= d.min_reg_size) {
                         const float4 sg = region_segment_w(d, wlist, n, mod, reg_angle, s_term[0]);
@@ -1114,7 +967,7 @@ __global__ __launch_bounds__(LSD_NW * 64) void lsd_grow_waves_kernel(LsdDev d, L
             }
             ++id;
             double reg_angle = 0.0;
-            const int n = grow_region_w<false, false>(ang, csn, used, stamp, id, wlist + off, npx - off, s_ring[wv], nullptr, pick_q, ang[pick_q], w, h, d.prec,
+            const int n = grow_region_w<false>(ang, csn, used, stamp, id, wlist + off, npx - off, s_ring[wv], pick_q, ang[pick_q], w, h, d.prec,
                                                reg_angle);
             float4 sg = make_float4(0.f, 0.f, 0.f, 0.f);
             if (n >= d.min_reg_size) sg = region_segment_w(d, wlist + off, n, mod, reg_angle, s_term[wv]);
@@ -1250,7 +1103,7 @@ struct stvo_lsd {
     float* response = nullptr;
     int32_t* n_lines = nullptr;
     double* dbg = nullptr;
-    stvo::LsdWaves xw{};      // scratch of lsd_grow_waves_kernel (STVO_LSD_WAVES=1, small batches), or null
+    stvo::LsdWaves xw{};      // scratch of lsd_grow_waves_kernel (small batches), or null
     char* wdev = nullptr;
     size_t stamp_bytes = 0, pend_bytes = 0;
 };
@@ -1264,7 +1117,7 @@ int lsd_enqueue(stvo_lsd* o, const uint8_t* images, stvo_keyline* lines, float* 
     const uint8_t* src = images;
     if (d.scale != 1) {
         stvo::launch_blur7_u8(s, d.B, d.cols, d.rows, images, o->blur, o->k7);
-        stvo::launch_resize_linear_u8(s, d.B, d.cols, d.rows, d.w, d.h, o->blur, o->scaled);
+        stvo::launch_resize_linear_u8(s, d.B, d.cols, d.rows, d.w, d.h, o->blur, o->scaled, d.scale, d.scale);
         src = o->scaled;
     }
     d.scaled = src;
@@ -1278,12 +1131,10 @@ int lsd_enqueue(stvo_lsd* o, const uint8_t* images, stvo_keyline* lines, float* 
     // (STVO_LSD_SORT_FULL=1: all 32 bits, the index bits included — the same order, more digit passes)
     const int begin_bit = stvo::dbg().lsd_sort_full == 1 ? 0 : stvo::LSD_IDX_BITS;
     HIP_TRY(ctx, hipcub::DeviceSegmentedRadixSort::SortKeys(o->sort_tmp, tb, d.keys, d.order, d.B * d.w * d.h, d.B, o->seg_off, o->seg_off + 1, begin_bit, 32, s));
-    if (o->wdev) {  // one workgroup of LSD_NW waves per image (opt-in, see lsd_grow_waves_kernel)
+    if (o->wdev) {  // small batches: one workgroup of LSD_NW waves per image (lsd_grow_waves_kernel)
         HIP_TRY(ctx, hipMemsetAsync(o->xw.stamp, 0, o->stamp_bytes, s));
         HIP_TRY(ctx, hipMemsetAsync(o->xw.pend, 0, o->pend_bytes, s));
         hipLaunchKernelGGL(stvo::lsd_grow_waves_kernel, dim3(d.B), dim3(stvo::LSD_NW * 64), 0, s, d, o->xw);
-    } else if (stvo::dbg().lsd_grow == 2) {  // (opt-in: early loads of the next round, not verified on hardware yet)
-        hipLaunchKernelGGL(stvo::lsd_grow_pipe_kernel, dim3(d.B), dim3(64), 0, s, d);
     } else if (stvo::dbg().lsd_grow == 0) {
         hipLaunchKernelGGL(stvo::lsd_grow_kernel<false>, dim3(d.B), dim3(64), 0, s, d);
     } else {
@@ -1303,6 +1154,9 @@ int stvo_lsd_create(stvo_ctx* ctx, int B, int cols, int rows, int max_keylines, 
     if (prm->refine != 0) return STVO_ERR_UNSUPPORTED;  // the refinement / NFA branches are not built (no shipped configuration uses them)
     if (!(prm->scale > 0) || !(prm->ang_th > 0 && prm->ang_th < 180) || prm->n_bins < 1 || prm->n_bins > 4096 || prm->nfeatures < 0)
         return STVO_ERR_INVALID_ARG;
+    // sort key = (n_bins - 1 - bin) << LSD_IDX_BITS | index, LSD_NOKEY = all ones: with 4096 bins the keys of bin 0 would share their
+    // top 12 bits with the undefined pixels' key and the bin-bits-only sort would interleave them
+    if (prm->n_bins > 2048) return STVO_ERR_UNSUPPORTED;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     stvo_lsd* o = new (std::nothrow) stvo_lsd();
     if (!o) return STVO_ERR_HIP;
@@ -1380,7 +1234,7 @@ int stvo_lsd_create(stvo_ctx* ctx, int B, int cols, int rows, int max_keylines, 
     }
     if (ok && (size_t)d.seg_cap * 8 > 48 * 1024)
         ok = stvo::lds_opt_in(reinterpret_cast<const void*>(stvo::lsd_keylines_kernel), d.seg_cap * 8);
-    if (ok && stvo::dbg().lsd_waves == 1 && B <= stvo::LSD_WAVES_MAX_B) {
+    if (ok && stvo::dbg().lsd_waves != 0 && B <= stvo::LSD_WAVES_MAX_B) {  // STVO_LSD_WAVES=0: one wave per image for small batches too
         decltype(c) cw;
         const size_t w_stamp = cw.take(nb * stvo::LSD_NW * npx * 4), w_list = cw.take(nb * stvo::LSD_NW * npx * 4),
                      w_rec = cw.take(nb * stvo::LSD_NW * stvo::LSD_REC_CAP * sizeof(stvo::LsdRec)), w_pend = cw.take(nb * npx * 4);

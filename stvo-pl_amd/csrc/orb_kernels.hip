@@ -385,7 +385,7 @@ __global__ __launch_bounds__(1024) void orb_order_kernel(OrbDev o) {
 // orc_resize_linear).  One thread per output pixel; the coefficient arithmetic is a few FP ops next to four byte loads.
 struct ResizeArgs {
     int B, scols, srows, dcols, drows;
-    double scale_x, scale_y;  // 1 / (dcols / scols), 1 / (drows / srows) as OpenCV forms them
+    double scale_x, scale_y;  // 1 / inv_scale as OpenCV forms them: inv_scale = dsize / ssize for a given dsize, = fx, fy for Size()
     const uint8_t* src;
     uint8_t* dst;
 };
@@ -554,105 +554,6 @@ __global__ __launch_bounds__(BL_T) void orb_blur_kernel(OrbDev o, BlurK kk) {
             } else {
                 for (int i = 0; x + i < o.cols; ++i) dst[i] = (uint8_t)(px >> (8 * i));
             }
-        }
-    }
-}
-
-// The same filter with the words of a later input row requested before row r is worked on (developer switch STVO_BLUR_AHEAD=1; written at
-// the end of round 4, NOT yet run on hardware).  In orb_blur_kernel the uniform exit for rows below the image sits between the unrolled
-// rows and the compiler keeps every row's load behind the previous row's arithmetic and store: from the eighth row on its ISA is load ->
-// vmcnt(0) -> arithmetic -> store, 16 memory round trips one after the other per thread (NOTES.md).  Here a wave whose lanes are all
-// interior (no reflected column) requests row r + 4 before it works on row r; a wave that touches the left / right border runs the rows as before
-// (a per-lane choice between word and byte loads would put vmcnt(0) at every join).
-__global__ __launch_bounds__(BL_T) void orb_blur_ahead_kernel(OrbDev o, BlurK kk) {
-    const int b = blockIdx.z, x = (blockIdx.x * BL_T + threadIdx.x) * 4, y0 = blockIdx.y * BL_R;
-    const uint8_t* img = o.img + (size_t)b * o.rows * o.cols;
-    uint8_t* out = o.blur + (size_t)b * o.rows * o.cols;
-    const uint32_t k03 = (uint32_t)kk.k[0] | ((uint32_t)kk.k[1] << 8) | ((uint32_t)kk.k[2] << 16) | ((uint32_t)kk.k[3] << 24);
-    const uint32_t k46 = (uint32_t)kk.k[4] | ((uint32_t)kk.k[5] << 8) | ((uint32_t)kk.k[6] << 16);
-    const bool active = x < o.cols;
-    const bool interior = x >= 4 && x + 8 <= o.cols;
-    const bool wave_interior = __ballot(active && !interior) == 0ull;  // uniform
-    if (!active) return;
-    uint32_t h[7][4];
-#pragma unroll
-    for (int j = 0; j < 7; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) h[j][i] = 0u;
-    // one input row: horizontal sums into the ring, and (from the seventh on) the output row it completes
-    auto work = [&](int r, uint32_t w0, uint32_t w1, uint32_t w2) {
-        uint32_t hs[4];
-        hs[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 1), k03, 0u, false);
-        hs[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 1), k46, hs[0], false);
-        hs[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 2), k03, 0u, false);
-        hs[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 2), k46, hs[1], false);
-        hs[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 3), k03, 0u, false);
-        hs[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 3), k46, hs[2], false);
-        hs[3] = __builtin_amdgcn_udot4(w1, k03, 0u, false);
-        hs[3] = __builtin_amdgcn_udot4(w2, k46, hs[3], false);
-#pragma unroll
-        for (int j = 0; j < 6; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) h[j][i] = h[j + 1][i];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) h[6][i] = hs[i];
-        if (r >= 6) {
-            const int yo = y0 + r - 6;
-            uint32_t px = 0u;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                uint32_t sv = 1u << 15;
-#pragma unroll
-                for (int j = 0; j < 7; ++j) sv += (uint32_t)kk.k[j] * h[j][i];
-                px |= min(sv >> 16, 255u) << (8 * i);
-            }
-            uint8_t* dst = out + (size_t)yo * o.cols + x;
-            if (x + 4 <= o.cols) {
-                *reinterpret_cast<u32_unaligned*>(dst) = px;
-            } else {
-                for (int i = 0; x + i < o.cols; ++i) dst[i] = (uint8_t)(px >> (8 * i));
-            }
-        }
-    };
-    if (wave_interior) {
-        auto words = [&](int r, uint32_t (&w)[3]) {  // row r of the tile, always a row of the image (requested ahead of the exit test)
-            const uint8_t* row = img + (size_t)min(reflect101(y0 + r - 3, o.rows), o.rows - 1) * o.cols;
-            w[0] = *reinterpret_cast<const u32_unaligned*>(row + x - 4);
-            w[1] = *reinterpret_cast<const u32_unaligned*>(row + x);
-            w[2] = *reinterpret_cast<const u32_unaligned*>(row + x + 4);
-        };
-        // (the stores of the finished rows count in vmcnt like the loads and the compiler assumes in-order completion: a row is waited
-        // for AH - 1 rows after its request, not AH)
-        constexpr int AH = 4;
-        uint32_t ahead[AH + 1][3];
-#pragma unroll
-        for (int r = 0; r < AH; ++r) words(r, ahead[r]);
-#pragma unroll
-        for (int r = 0; r < BL_R + 6; ++r) {
-            if (r >= 6 && y0 + r - 6 >= o.rows) break;  // uniform over the workgroup
-            if (r + AH < BL_R + 6) words(r + AH, ahead[(r + AH) % (AH + 1)]);
-            work(r, ahead[r % (AH + 1)][0], ahead[r % (AH + 1)][1], ahead[r % (AH + 1)][2]);
-        }
-    } else {
-#pragma unroll 1
-        for (int r = 0; r < BL_R + 6; ++r) {
-            if (r >= 6 && y0 + r - 6 >= o.rows) break;
-            const uint8_t* row = img + (size_t)reflect101(y0 + r - 3, o.rows) * o.cols;
-            uint32_t w0, w1, w2;
-            if (interior) {
-                w0 = *reinterpret_cast<const u32_unaligned*>(row + x - 4);
-                w1 = *reinterpret_cast<const u32_unaligned*>(row + x);
-                w2 = *reinterpret_cast<const u32_unaligned*>(row + x + 4);
-            } else {  // image border: BORDER_REFLECT_101 byte by byte
-                w0 = w1 = w2 = 0u;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    w0 |= (uint32_t)row[reflect101(x - 4 + i, o.cols)] << (8 * i);
-                    w1 |= (uint32_t)row[reflect101(x + i, o.cols)] << (8 * i);
-                    w2 |= (uint32_t)row[reflect101(x + 4 + i, o.cols)] << (8 * i);
-                }
-            }
-            work(r, w0, w1, w2);
         }
     }
 }
@@ -838,14 +739,14 @@ void launch_blur7_u8(hipStream_t s, int B, int cols, int rows, const uint8_t* sr
     BlurK kk{};
     for (int i = 0; i < 7; ++i) kk.k[i] = k7[i];
     const dim3 tiles((cols + 4 * BL_T - 1) / (4 * BL_T), (rows + BL_R - 1) / BL_R, B);
-    if (dbg().blur_ahead == 1) hipLaunchKernelGGL(orb_blur_ahead_kernel, tiles, dim3(BL_T), 0, s, o, kk);
-    else hipLaunchKernelGGL(orb_blur_kernel, tiles, dim3(BL_T), 0, s, o, kk);
+    hipLaunchKernelGGL(orb_blur_kernel, tiles, dim3(BL_T), 0, s, o, kk);
 }
-void launch_resize_linear_u8(hipStream_t s, int B, int scols, int srows, int dcols, int drows, const uint8_t* src, uint8_t* dst) {
+void launch_resize_linear_u8(hipStream_t s, int B, int scols, int srows, int dcols, int drows, const uint8_t* src, uint8_t* dst, double fx, double fy) {
     ResizeArgs r{};
     r.B = B; r.scols = scols; r.srows = srows; r.dcols = dcols; r.drows = drows;
-    r.scale_x = 1.0 / ((double)dcols / scols);
-    r.scale_y = 1.0 / ((double)drows / srows);
+    // fx, fy > 0: resize(src, dst, Size(), fx, fy) — cv::resize keeps inv_scale = fx and rounds only the output size; 0: a given dsize
+    r.scale_x = 1.0 / (fx > 0 ? fx : (double)dcols / scols);
+    r.scale_y = 1.0 / (fy > 0 ? fy : (double)drows / srows);
     r.src = src; r.dst = dst;
     hipLaunchKernelGGL(orb_resize_kernel, dim3((dcols + 255) / 256, drows, B), dim3(256), 0, s, r);
 }
@@ -1069,8 +970,7 @@ int stvo_orb_detect_levels_dev(stvo_orb* o, const uint8_t* images, float* kp_xy,
         const dim3 tiles((d.cols + 4 * stvo::BL_T - 1) / (4 * stvo::BL_T), (d.rows + stvo::BL_R - 1) / stvo::BL_R, d.B), tb(stvo::BL_T);
         hipLaunchKernelGGL(stvo::orb_fast_nms_kernel, dim3((d.cols + stvo::FT_W - 1) / stvo::FT_W, (d.rows + stvo::FT_H - 1) / stvo::FT_H, d.B),
                            dim3(256), 0, s, d);
-        if (stvo::dbg().blur_ahead == 1) hipLaunchKernelGGL(stvo::orb_blur_ahead_kernel, tiles, tb, 0, s, d, o->blur_k);
-        else hipLaunchKernelGGL(stvo::orb_blur_kernel, tiles, tb, 0, s, d, o->blur_k);
+        hipLaunchKernelGGL(stvo::orb_blur_kernel, tiles, tb, 0, s, d, o->blur_k);
         hipLaunchKernelGGL(stvo::orb_order_kernel, dim3(d.B), dim3(1024), 0, s, d);
         hipLaunchKernelGGL(stvo::orb_describe_kernel, dim3((unsigned)(((d.K + stvo::DESC_KP_PER_WG - 1) / stvo::DESC_KP_PER_WG) * ((d.B + 7) / 8) * 8)), dim3(256),
                            0, s, d, o->umax);

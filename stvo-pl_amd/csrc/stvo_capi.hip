@@ -43,7 +43,6 @@ DebugSwitches parse_switches() {
     d.lsd_grow = env_int("STVO_LSD_GROW");
     d.lsd_sort_full = env_int("STVO_LSD_SORT_FULL");
     d.lsd_waves = env_int("STVO_LSD_WAVES");
-    d.blur_ahead = env_int("STVO_BLUR_AHEAD");
     return d;
 }
 DebugSwitches& switches() {

@@ -262,6 +262,16 @@ class Oracle:
         self.lib.orc_resize_linear(img.reshape(-1), img.shape[1], img.shape[0], out.reshape(-1), dcols, drows)
         return out
 
+    def resize_linear_fxy(self, img, fx, fy):
+        """resize(img, Size(), fx, fy): the output size is cvRound(size f), the sample step stays 1 / f."""
+        self.lib.orc_resize_linear_fxy.argtypes = [u8p, C.c_int, C.c_int, u8p, C.c_int, C.c_int, C.c_double, C.c_double]
+        self.lib.orc_resize_linear_fxy.restype = None
+        img = np.ascontiguousarray(img, np.uint8)
+        dcols, drows = int(np.rint(img.shape[1] * fx)), int(np.rint(img.shape[0] * fy))
+        out = np.zeros((drows, dcols), np.uint8)
+        self.lib.orc_resize_linear_fxy(img.reshape(-1), img.shape[1], img.shape[0], out.reshape(-1), dcols, drows, fx, fy)
+        return out
+
     def orb_levels(self, cols, rows, nfeatures, nlevels, scale_factor):
         f32p_ = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
         self.lib.orc_orb_levels.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, f32p_, i32p, i32p, i32p]

@@ -58,7 +58,7 @@ def test_lsd_plain_growth_is_the_same(hip, oracle, switches):
     sums through v_readlane — against the oracle on a scene, a clean image, noise and a flat image; the default form (guess +
     verification, sums from LDS) is what every other test of this file runs."""
     from stvo_amd import capi
-    switches({"STVO_LSD_GROW": "0"})
+    switches({"STVO_LSD_GROW": "0", "STVO_LSD_WAVES": "0"})
     cols, rows = 752, 480
     rng = np.random.default_rng(41)
     imgs = np.stack([synth.make_image(610, cols, rows), clean_image(cols, rows, 611), rng.integers(0, 255, (rows, cols), dtype=np.uint8),
@@ -75,37 +75,14 @@ def test_lsd_plain_growth_is_the_same(hip, oracle, switches):
             lsd.close()
 
 
-@pytest.mark.skipif(not os.environ.get("STVO_TEST_LSD_PIPE"), reason="lsd_grow_pipe_kernel (STVO_LSD_GROW=2) was written at the end of round 4 "
-                    "without GPU time left: opt-in until it has run on hardware (set STVO_TEST_LSD_PIPE=1, under a timeout)")
-def test_lsd_early_loads_of_the_next_round_is_the_same(hip, oracle, switches):
-    """STVO_LSD_GROW=2: one wave per image with the next round's neighbour data requested from a prediction of what the round accepts
-    (lsd_kernels.hip: grow_region_w<.., PIPE>; CPU model: tools/experiments/lsd_resolve_model.c) — the oracle's segments in order."""
+@pytest.mark.parametrize("waves", ["1", "0"])
+def test_lsd_sixteen_waves_and_one_wave_per_image_are_the_same(hip, oracle, switches, waves):
+    """Batches of <= 8 images run one workgroup of 16 waves per image by default — a committing wave and 15 speculating ones, pending
+    regions validated at their seed's turn (lsd_kernels.hip: lsd_grow_waves_kernel; CPU replay: tools/experiments/lsd_waves_sim.c);
+    STVO_LSD_WAVES=0 runs such a batch on the one-wave kernel of the large batches.  Both must give the oracle's segments in the
+    oracle's order."""
     from stvo_amd import capi
-    switches({"STVO_LSD_GROW": "2"})
-    cols, rows = 752, 480
-    rng = np.random.default_rng(47)
-    imgs = np.stack([synth.make_image(630, cols, rows), clean_image(cols, rows, 631), rng.integers(0, 255, (rows, cols), dtype=np.uint8),
-                     np.full((rows, cols), 77, np.uint8)])
-    for scale in (1.2, 1.0):
-        lsd = capi.Lsd(hip, 4, cols, rows, capi.lsd_params(min_length=4.0, nfeatures=0, scale=scale), max_keylines=2048)
-        try:
-            segs, n = lsd.segments(imgs)
-            for b in range(4):
-                ref = oracle.lsd_segments(imgs[b], oracle.lsd_opts(scale=scale))
-                assert n[b] == len(ref)
-                assert np.array_equal(segs[b], ref)
-        finally:
-            lsd.close()
-
-
-@pytest.mark.skipif(not os.environ.get("STVO_TEST_LSD_WAVES"), reason="lsd_grow_waves_kernel (STVO_LSD_WAVES=1) was written at the end of round 4 "
-                    "without GPU time left: opt-in until it has run on hardware (set STVO_TEST_LSD_WAVES=1, under a timeout)")
-def test_lsd_sixteen_waves_per_image_is_the_same(hip, oracle, switches):
-    """STVO_LSD_WAVES=1: one workgroup of 16 waves per image — a committing wave and 15 speculating ones, pending regions validated at
-    their seed's turn (lsd_kernels.hip: lsd_grow_waves_kernel; CPU replay: tools/experiments/lsd_waves_sim.c) — must give the oracle's
-    segments in the oracle's order, like the one-wave kernels."""
-    from stvo_amd import capi
-    switches({"STVO_LSD_WAVES": "1"})
+    switches({"STVO_LSD_WAVES": waves})
     cols, rows = 752, 480
     rng = np.random.default_rng(43)
     imgs = np.stack([synth.make_image(620, cols, rows), clean_image(cols, rows, 621), rng.integers(0, 255, (rows, cols), dtype=np.uint8),

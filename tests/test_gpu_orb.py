@@ -40,23 +40,6 @@ def test_orb_kitti_size_batch_bit_exact(hip, oracle):
         orb.close()
 
 
-@pytest.mark.skipif(not os.environ.get("STVO_TEST_BLUR_AHEAD"), reason="orb_blur_ahead_kernel (STVO_BLUR_AHEAD=1) was written at the end of round 4 "
-                    "without GPU time left: opt-in until it has run on hardware (set STVO_TEST_BLUR_AHEAD=1)")
-@pytest.mark.parametrize("cols,rows", [(1241, 376), (640, 200), (333, 45)])
-def test_orb_with_the_blur_that_requests_rows_ahead(hip, oracle, switches, cols, rows):
-    """STVO_BLUR_AHEAD=1: the 7 x 7 blur with input rows requested four rows ahead (interior waves) — the descriptors are taken on the
-    blurred image, so the ORB output against the oracle checks every pixel the tests read; widths that are no multiple of 256 and a
-    height that is no multiple of 16 exercise the border waves and the early exit."""
-    from stvo_amd import capi
-    switches({"STVO_BLUR_AHEAD": "1"})
-    img = synth.make_image(900 + cols, cols=cols, rows=rows, n_rects=60, n_discs=20)
-    orb = capi.Orb(hip, 1, cols, rows, max_keypoints=2048, nfeatures=2000, fast_threshold=20)
-    try:
-        same(orb.detect(img[None])[0], oracle.orb_detect(img, nfeatures=2000, fast_th=20, cap=2048))
-    finally:
-        orb.close()
-
-
 @pytest.mark.parametrize("nf,th,cap", [(300, 12, 512), (5000, 35, 1024), (50, 60, 64), (700, 5, 700)])
 def test_orb_thresholds_cuts_and_capacity(hip, oracle, nf, th, cap):
     """retainBest cut with ties, fewer corners than requested, and truncation at the capacity (row-major order)."""

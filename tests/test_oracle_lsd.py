@@ -119,3 +119,47 @@ def test_detector_core_against_the_numpy_restatement(oracle):
         assert got.shape == ref.shape and np.array_equal(got, ref), k
         total += len(ref)
     assert total > 30
+
+
+def test_scaled_image_sample_positions_follow_the_scale_not_the_rounded_size(oracle):
+    """LSD scales with resize(img, Size(), scale, scale): cv::resize rounds only the OUTPUT size (cvRound(1241 * 1.2) = 1489) and keeps
+    inv_scale = 1.2, so output column d samples source position (d + 0.5) / 1.2 - 0.5 — not (d + 0.5) * 1241 / 1489 - 0.5 (up to
+    0.17 px apart at the right edge).  An independent numpy statement of the fixed-point bilinear pins both forms; sizes that scale
+    to integers (640 x 200) give the same image either way."""
+    cols, rows = 1241, 376
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (rows, cols), dtype=np.uint8)
+    out = oracle.resize_linear_fxy(img, 1.2, 1.2)
+    assert out.shape == (451, 1489)
+
+    def model(img, dcols, drows, sx_, sy_):
+        sc, sr = img.shape[1], img.shape[0]
+        fx = (((np.arange(dcols) + 0.5) * sx_) - 0.5).astype(np.float32)
+        x0 = np.floor(fx).astype(np.int64)
+        fx = (fx - x0.astype(np.float32)).astype(np.float32)
+        lo, hi = x0 < 0, x0 >= sc - 1
+        fx[lo | hi] = 0
+        x0[lo] = 0
+        x0[hi] = sc - 1
+        a0 = np.rint((np.float32(1) - fx) * np.float32(2048)).astype(np.int64)
+        a1 = np.rint(fx * np.float32(2048)).astype(np.int64)
+        x1 = np.minimum(x0 + 1, sc - 1)
+        a0[hi], a1[hi] = 2048, 0
+        fy = (((np.arange(drows) + 0.5) * sy_) - 0.5).astype(np.float32)
+        y0 = np.floor(fy).astype(np.int64)
+        fy = (fy - y0.astype(np.float32)).astype(np.float32)
+        b0 = np.rint((np.float32(1) - fy) * np.float32(2048)).astype(np.int64)
+        b1 = np.rint(fy * np.float32(2048)).astype(np.int64)
+        r0, r1 = np.clip(y0, 0, sr - 1), np.clip(y0 + 1, 0, sr - 1)
+        I = img.astype(np.int64)
+        S0 = I[r0][:, x0] * a0 + I[r0][:, x1] * a1
+        S1 = I[r1][:, x0] * a0 + I[r1][:, x1] * a1
+        v = (((b0[:, None] * (S0 >> 4)) >> 16) + ((b1[:, None] * (S1 >> 4)) >> 16) + 2) >> 2
+        return np.clip(v, 0, 255).astype(np.uint8)
+
+    assert np.array_equal(out, model(img, 1489, 451, 1.0 / 1.2, 1.0 / 1.2))
+    ratio = oracle.resize_linear(img, 1489, 451)
+    assert np.array_equal(ratio, model(img, 1489, 451, 1.0 / (1489 / 1241), 1.0 / (451 / 376)))
+    assert np.count_nonzero(ratio != out) > 1000  # the two forms are different images at this size
+    img2 = rng.integers(0, 256, (200, 640), dtype=np.uint8)
+    assert np.array_equal(oracle.resize_linear_fxy(img2, 1.2, 1.2), oracle.resize_linear(img2, 768, 240))
