@@ -695,7 +695,9 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         import torch
         n_vis = torch.cuda.device_count()
-        if n_vis < args.gpus:
+        # STVO_BENCH_BACKEND=gloo (tests on a 1-GPU box): the ranks share the visible GPU(s), the barrier and the two scalar
+        # all-reduces run over gloo with CPU tensors — everything else of the N > 1 branch is the code an 8-GPU node executes
+        if n_vis < args.gpus and os.environ.get("STVO_BENCH_BACKEND", "nccl") != "gloo":
             raise SystemExit(f"bench.py --gpus {args.gpus}: only {n_vis} GPU(s) visible")
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
@@ -721,13 +723,19 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X: the product path has no CPU fallback")
+    backend = os.environ.get("STVO_BENCH_BACKEND", "nccl") if world > 1 else None
+    if backend == "gloo":      # ranks may outnumber the GPUs: rank r runs on GPU r mod (visible GPUs)
+        local_rank = local_rank % torch.cuda.device_count()
+        dist.init_process_group("gloo")
+    elif world > 1:            # "nccl" IS RCCL on ROCm
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
     if args.gpus != world and rank == 0:
         print(f"bench.py: --gpus {args.gpus} but the torch.distributed world has {world} rank(s); reporting n_gpus = {world}", file=sys.stderr)
     torch.cuda.set_device(local_rank)
     dev_name = f"cuda:{local_rank}"
+    agg_dev = "cpu" if backend == "gloo" else dev_name   # where the two scalars of shard.aggregate live
 
     cams = [synth.config5_cam(int(s)) for s in seq_ids]
     mp, op = match_params("kitti"), opt_params("kitti")
@@ -761,7 +769,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         dt_r = time.perf_counter() - t0
-        frames_total, dt_r = shard.aggregate(dist, B * args.steps, dt_r, device=dev_name)   # sum of frame pairs, max of seconds
+        frames_total, dt_r = shard.aggregate(dist, B * args.steps, dt_r, device=agg_dev)   # sum of frame pairs, max of seconds
         rep_dt.append(dt_r)
     dt = float(np.median(rep_dt))
 
@@ -869,7 +877,7 @@ def main():
         resident_mb = S * B * (2 * 2048 * (8 + 32) + 2048 * 4 + 2 * 512 * (16 + 32) + 512 * 4) / 1e6
         out = {
             "metric": "stereo frames/s (match+optimizePose)", "value": frames_total / dt, "unit": "frame-pairs/s",
-            "n_gpus": world, "rccl_ranks": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "n_gpus": world, "rccl_ranks": world, "collective_backend": ("rccl" if backend == "nccl" else backend), "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "repeats": {"n": len(rep_dt), "statistic": "median", "value_min": frames_total / max(rep_dt), "value_max": frames_total / min(rep_dt),
                         "ms_per_step_all": [d / args.steps * 1e3 for d in rep_dt]},
             "parity_sampled": parity,

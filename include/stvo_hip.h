@@ -149,7 +149,7 @@ int stvo_optimize_pose_batched_dev(stvo_ctx* ctx, const stvo_track_batch_dev* ba
  * (src/stereoFrameHandler.cpp:35-60, 307-392, 89-100): stereo association on the 64x48 grid
  * (src/stereoFrame.cpp:120-173, 309-415), f2f tracking, pose optimisation.  The Tfw composition (:377-378) and the
  * adaptive FAST threshold (:66-86, a front-end knob) stay with the caller.  init_T is the identity
- * (use_motion_model = false, as in every shipped configuration). */
+ * (use_motion_model = false, as in every shipped configuration) unless stvo_seq_set_motion_model turns the motion model on. */
 typedef struct stvo_seq stvo_seq;
 int stvo_seq_create(stvo_ctx* ctx, int B, int max_keypoints, int max_keylines, int img_cols, int img_rows,
                     const stvo_cam* cam, const stvo_match_params* mp, const stvo_opt_params* op, stvo_seq** out);
@@ -162,6 +162,11 @@ int stvo_seq_create_multi(stvo_ctx* ctx, int B, int max_keypoints, int max_keyli
                           const int32_t* img_rows, const stvo_cam* cams, const stvo_match_params* mp,
                           const stvo_opt_params* op, stvo_seq** out);
 int stvo_seq_destroy(stvo_seq* seq);
+/* Config::useMotionModel() for every sequence of the pipeline (src/stereoFrameHandler.cpp:317-324): the initial DT of a frame pair is
+ * prev_frame->DT (the increment COMMITTED for the previous pair, i.e. after :374's inverse) unless !isGoodSolution(prev_frame->DT,
+ * prev_frame->DT_cov, prev_frame->err_norm), then the identity.  The decision is taken on the device by the previous step's commit —
+ * the result never leaves HBM.  Enabling (again) restarts every sequence from prev_frame->DT = I (:45); synchronises. */
+int stvo_seq_set_motion_model(stvo_seq* seq, int enable);
 /* Number of raw frame slots (2 .. STVO_SEQ_MAX_SLOTS; 2 after create).  A throughput caller uploads several consecutive
  * frames of every sequence once (stvo_seq_upload) and rotates stvo_seq_step_dev through the slots. */
 #define STVO_SEQ_MAX_SLOTS 16

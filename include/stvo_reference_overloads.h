@@ -177,7 +177,7 @@ inline void optimizePose(StereoFrameHandler& h, PinholeStereoCamera* cam, int mo
     const stvo_cam c{cam->getFx(), cam->getFy(), cam->getCx(), cam->getCy(), cam->getB()};
     /* :317-326 — identity, or the previous increment under the motion model */
     double init[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
-    if (Config::useMotionModel())
+    if (Config::useMotionModel() && h.isGoodSolution(h.prev_frame->DT, h.prev_frame->DT_cov, h.prev_frame->err_norm)) /* :322-323 */
         for (int i = 0; i < 4; ++i)
             for (int j = 0; j < 4; ++j) init[i * 4 + j] = h.prev_frame->DT(i, j);
     stvo_pose_result r{};

@@ -129,6 +129,7 @@ struct PoseArgs {
     const int32_t* m12l;
     const int32_t* init_inl_l;
     const double* init_T;  // [B][16] or nullptr
+    double* next_T;        // [B][16] or nullptr: the next frame pair's init_T under use_motion_model (pose_block.h: t0_commit); may alias init_T
     stvo_cam cam;
     const stvo_cam* cams;  // [B] per-frame-pair calibration (device) or nullptr: `cam` for every pair
     // set by launch_pose: prev points / lines with an index below these live in the workgroup's LDS record cache

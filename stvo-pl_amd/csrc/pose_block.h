@@ -667,7 +667,11 @@ __device__ __forceinline__ void t0_is_good_fast(PoseSh* sh, const double* DT, do
 // says "good"; anything it cannot certify takes the eigen-decomposition here), and DT_cov_eig — an output, not an input of anything on
 // the path — is left to the host, which runs the same routine in ~2 us: the decomposition is ~3.5 k dependent instructions, 8 us on
 // one lane at the very end of the frame's chain.
-__device__ __forceinline__ void t0_commit(PoseSh* sh, stvo_pose_result* out, int status, int path, int it0, int it1, bool lazy_eig = false) {
+// next_T (the device-resident pipeline under use_motion_model, or nullptr): the NEXT frame pair's initial DT by the rule of :317-324 —
+// prev_frame->DT unless !isGoodSolution(prev DT, prev DT_cov, prev err_norm).  For a committed solution DT_cov and err_norm just
+// passed that very test, so only is_finite(committed DT) is left to check; a rejected one has DT = I either way.
+__device__ __forceinline__ void t0_commit(PoseSh* sh, stvo_pose_result* out, int status, int path, int it0, int it1, bool lazy_eig = false,
+                                          double* next_T = nullptr) {
     // :372-391
     bool eig_pending = false;
     if (lazy_eig) {
@@ -699,6 +703,11 @@ __device__ __forceinline__ void t0_commit(PoseSh* sh, stvo_pose_result* out, int
         pm::expmap_se3(x, T);
 #pragma unroll
         for (int i = 0; i < 16; ++i) out->T[i] = T[i];
+        if (next_T) {
+            const bool fin = pm::all_finite16(T);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) next_T[i] = fin ? T[i] : ((i % 5 == 0) ? 1.0 : 0.0);
+        }
 #pragma unroll
         for (int i = 0; i < 36; ++i) out->cov[i] = sh->cov[i];
 #pragma unroll
@@ -708,6 +717,10 @@ __device__ __forceinline__ void t0_commit(PoseSh* sh, stvo_pose_result* out, int
     } else {
 #pragma unroll
         for (int i = 0; i < 16; ++i) out->T[i] = (i % 5 == 0) ? 1.0 : 0.0;
+        if (next_T) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) next_T[i] = (i % 5 == 0) ? 1.0 : 0.0;
+        }
 #pragma unroll
         for (int i = 0; i < 36; ++i) out->cov[i] = 0.0;
 #pragma unroll

@@ -500,7 +500,7 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_hist)[Block
 
     {
         const long long tq3 = tick();
-        if (t0) t0_commit(sh, a.results + f, status, path, it0, it1, a.lazy_eig != 0);
+        if (t0) t0_commit(sh, a.results + f, status, path, it0, it1, a.lazy_eig != 0, a.next_T ? a.next_T + (size_t)f * 16 : nullptr);
         tprof[2] += tick() - tq3;
     }
     if (prof && t0) {

@@ -512,7 +512,7 @@ __global__ __launch_bounds__(NW * 64, 2) void pose2p_kernel(PoseArgs a, const in
 
     {
         const long long tq3 = tick();
-        if (t0) t0_commit(sh, a.results + f, status, path, it0, it1);
+        if (t0) t0_commit(sh, a.results + f, status, path, it0, it1, false, a.next_T ? a.next_T + (size_t)f * 16 : nullptr);
         tprof[2] += tick() - tq3;
     }
     if (prof && t0) {
@@ -1064,7 +1064,7 @@ __global__ __launch_bounds__(NW * 64, 2) void pose2c_kernel(PoseArgs a_by_value,
 
     {
         const long long tq3 = tick();
-        if (t0) t0_commit(sh, ka().results + f, fl.status, fl.path, fl.it0, fl.it1);
+        if (t0) t0_commit(sh, ka().results + f, fl.status, fl.path, fl.it0, fl.it1, false, ka().next_T ? ka().next_T + (size_t)f * 16 : nullptr);
         tprof[2] += tick() - tq3;
     }
     if (PROF && t0) {

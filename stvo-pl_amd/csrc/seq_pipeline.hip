@@ -570,6 +570,7 @@ struct stvo_seq {
     stvo_cam* d_cams = nullptr;    // [B] per-sequence calibration (device)
     double* d_inv_wh = nullptr;    // [B][2] per-sequence grid scale (device)
     double* d_qtab = nullptr;      // [STVO_POSE_QTAB] sqrt(sigma2) of pyramid level l (kernels.h: PoseArgs::q_tab)
+    double* d_motion_T = nullptr;  // [B][16] use_motion_model: the next step's initial DT per sequence, written by the pose kernel's commit (stvo_seq_set_motion_model)
     long long* d_prof = nullptr;   // STVO_POSE_PROF (developer aid): [B][16] phase ticks of the last pose launch, printed by stvo_seq_read
     char* dev = nullptr;     // one allocation, carved below
     size_t dev_bytes = 0;
@@ -927,6 +928,7 @@ int stvo_seq_destroy(stvo_seq* s) {
     (void)hipStreamSynchronize(s->ctx->stream);
     if (s->ctx->aux_stream) (void)hipStreamSynchronize(s->ctx->aux_stream);
     if (s->d_prof) (void)hipFree(s->d_prof);
+    if (s->d_motion_T) (void)hipFree(s->d_motion_T);
     if (s->line_stream) {
         (void)hipStreamSynchronize(s->line_stream);
         (void)hipStreamDestroy(s->line_stream);
@@ -1291,6 +1293,7 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl) {
         a.prev_sP = ps.sP; a.prev_eP = ps.eP; a.prev_spl = ps.spl; a.prev_epl = ps.epl; a.prev_s2l = ps.s2lm;
         a.curr_le = cs.le; a.m12l = s->m12l;
         a.cams = s->d_cams; a.prm = s->op;
+        a.init_T = s->d_motion_T; a.next_T = s->d_motion_T;  // (nullptr: DT = I, use_motion_model = false)
         a.results = s->zero_copy ? reinterpret_cast<stvo_pose_result*>(s->out_host) : s->results;
         a.inl_p_out = s->inlp; a.inl_l_out = s->inll;
         // small batches with the by-product fetch on (the StereoFrameHandler mirror): the pose kernel writes the inlier masks straight
@@ -1498,6 +1501,28 @@ int stvo_seq_fetch_inliers(stvo_seq* s, const int32_t** inl_pts, const int32_t**
     const char* H = s->fetch_host + s->m12_span;
     if (inl_pts) *inl_pts = reinterpret_cast<const int32_t*>(H);
     if (inl_lines) *inl_lines = reinterpret_cast<const int32_t*>(H + (reinterpret_cast<const char*>(s->inll) - reinterpret_cast<const char*>(s->inlp)));
+    return STVO_OK;
+}
+
+// Config::useMotionModel() (src/stereoFrameHandler.cpp:317-324) for every sequence of the pipeline: the rule is applied ON THE DEVICE
+// by the commit of the previous step (pose_block.h: t0_commit), the first tracked frame starts from prev_frame->DT = I (:45).
+int stvo_seq_set_motion_model(stvo_seq* s, int enable) {
+    if (!s) return STVO_ERR_INVALID_ARG;
+    stvo_ctx* ctx = s->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (!enable) {
+        if (s->d_motion_T) (void)hipFree(s->d_motion_T);
+        s->d_motion_T = nullptr;
+    } else {
+        if (!s->d_motion_T) HIP_TRY(ctx, hipMalloc((void**)&s->d_motion_T, (size_t)s->B * 16 * sizeof(double)));
+        std::vector<double> I((size_t)s->B * 16, 0.0);
+        for (int b = 0; b < s->B; ++b)
+            for (int i = 0; i < 4; ++i) I[(size_t)b * 16 + i * 5] = 1.0;
+        HIP_TRY(ctx, hipMemcpy(s->d_motion_T, I.data(), I.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    for (auto& g : s->graphs) (void)hipGraphExecDestroy(g.second);  // captured steps hold the old init_T pointer
+    s->graphs.clear();
     return STVO_OK;
 }
 

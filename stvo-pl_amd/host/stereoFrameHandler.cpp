@@ -58,7 +58,7 @@ void StereoFrameHandler::initialize(const FrameFeatures& feat, const int idx_) {
         stvo_seq_destroy(seq);
         seq = nullptr;
     }
-    if (use_pipeline && !Config::useMotionModel() && pipelineEnqueue(feat)) {
+    if (use_pipeline && pipelineEnqueue(feat)) {
         pipelineCollect(prev_frame);
     } else {
         use_pipeline = false;
@@ -336,6 +336,9 @@ void StereoFrameHandler::optimizePose() {
         // the optimisation was enqueued by insertStereoPair right behind the f2f matching; collect it
         if (!pose_pending) throw std::runtime_error("[StVO-HIP] optimizePose() without a preceding insertStereoPair()");
         pose_pending = false;
+        // :317-324 — the device took this decision when it committed the previous pair; the host repeats the test for the
+        // reference's console line only (isGoodSolution prints the eigenvalues of a rejected prior), while the GPU still works
+        if (Config::useMotionModel()) (void)isGoodSolution(prev_frame->DT, prev_frame->DT_cov, prev_frame->err_norm);
         int32_t counts[4];
         check(stvo_seq_read(seq, &last_result, counts), "stvo_seq_read", ctx);
         const int32_t *ip = nullptr, *il = nullptr;
@@ -475,6 +478,8 @@ bool StereoFrameHandler::pipelineEnqueue(const FrameFeatures& feat) {
         check(stvo_seq_create(ctx, 1, STVO_POSE_MAX_POINTS, STVO_POSE_MAX_LINES, feat.img_cols, feat.img_rows, &c, &mp, &op, &seq),
               "stvo_seq_create", ctx);
         check(stvo_seq_enable_fetch(seq, 1), "stvo_seq_enable_fetch", ctx);
+        // :317-324 — under the motion model the device keeps the committed increment and applies the isGoodSolution rule itself
+        if (Config::useMotionModel()) check(stvo_seq_set_motion_model(seq, 1), "stvo_seq_set_motion_model", ctx);
         int32_t K = 0, M = 0;
         check(stvo_seq_strides(seq, &K, &M), "stvo_seq_strides", ctx);
         seq_K = K; seq_M = M;

@@ -20,7 +20,7 @@ EXPORTS = ["stvo_backend_name", "stvo_abi_version", "stvo_error_string", "stvo_c
            "stvo_track_batched_dev", "stvo_match_nnr_mutual_batched_dev", "stvo_optimize_pose_batched_dev",
            "stvo_time_stage_dev", "stvo_valu_peak_probe", "stvo_last_reverse_counts", "stvo_last_reverse_plan", "stvo_ctx_set_kernel_timing", "stvo_ctx_get_kernel_timing", "stvo_seq_create", "stvo_seq_destroy", "stvo_seq_enable_fetch", "stvo_seq_fetch_matches", "stvo_seq_fetch_inliers", "stvo_seq_strides",
            "stvo_seq_push", "stvo_seq_upload", "stvo_seq_step_dev", "stvo_seq_read", "stvo_seq_create_multi", "stvo_seq_set_slots",
-           "stvo_seq_set_stage_timing", "stvo_seq_get_stage_timing", "stvo_seq_debug_grid", "stvo_orb_create", "stvo_orb_destroy",
+           "stvo_seq_set_stage_timing", "stvo_seq_get_stage_timing", "stvo_seq_set_motion_model", "stvo_seq_debug_grid", "stvo_orb_create", "stvo_orb_destroy",
            "stvo_orb_set_pattern", "stvo_orb_get_pattern", "stvo_orb_detect", "stvo_orb_detect_dev", "stvo_orb_detect_levels",
            "stvo_orb_detect_levels_dev", "stvo_orb_set_fast_threshold", "stvo_seq_upload_dev", "stvo_lbd_create", "stvo_lbd_destroy",
            "stvo_lbd_compute", "stvo_lbd_compute_dev", "stvo_debug_reparse_env", "stvo_lsd_create", "stvo_lsd_destroy", "stvo_lsd_detect",
@@ -124,6 +124,7 @@ def load():
                                         C.POINTER(OptParams), C.POINTER(C.c_void_p)]
     L.stvo_seq_set_slots.argtypes = [C.c_void_p, C.c_int]
     L.stvo_seq_set_stage_timing.argtypes = [C.c_void_p, C.c_int]
+    L.stvo_seq_set_motion_model.argtypes = [C.c_void_p, C.c_int]
     L.stvo_seq_get_stage_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
     L.stvo_seq_debug_grid.argtypes = [C.c_void_p, C.c_int, C.c_int, i32p, i32p, C.c_int32, i32p, i32p, i32p, C.c_int32,
                                       C.POINTER(C.c_int32)]
@@ -470,6 +471,10 @@ class Sequences:
 
     def set_slots(self, n):
         self.ctx._chk(self.ctx.lib.stvo_seq_set_slots(self.h, n))
+
+    def set_motion_model(self, on=True):
+        """Config::useMotionModel(): the initial DT of a frame pair = the increment committed for the previous pair if it was good."""
+        self.ctx._chk(self.ctx.lib.stvo_seq_set_motion_model(self.h, 1 if on else 0))
 
     def set_stage_timing(self, on=True):
         self.ctx._chk(self.ctx.lib.stvo_seq_set_stage_timing(self.h, 1 if on else 0))

@@ -51,8 +51,11 @@ def match_fanout(orc, ex, d1, d2, nnr, best_lr):
     return m12, int(keep.sum())
 
 
-def run_sequence(orc, frames, cam, mp, prm, fast=dict(adaptive=True, th0=20, mn=7, mx=30, inc=5, feat=50, err=0.5), keyframes=None, fanout=None):
-    """keyframes: None, or dict(min_entropy_ratio, max_kf_t_dist, max_kf_r_dist) to run needNewKF / currFrameIsKF after every
+def run_sequence(orc, frames, cam, mp, prm, fast=dict(adaptive=True, th0=20, mn=7, mx=30, inc=5, feat=50, err=0.5), keyframes=None, fanout=None, motion_model=False):
+    """motion_model: Config::useMotionModel() — the initial DT of optimizePose is prev_frame->DT (the increment COMMITTED for the previous
+    pair) unless !isGoodSolution(prev_frame->DT, prev_frame->DT_cov, prev_frame->err_norm) (src/stereoFrameHandler.cpp:317-324).  After
+    initialize prev_frame->DT = I (:45) while DT_cov / err_norm are uninitialised memory in the reference: either verdict gives I.
+    keyframes: None, or dict(min_entropy_ratio, max_kf_t_dist, max_kf_r_dist) to run needNewKF / currFrameIsKF after every
     optimizePose (src/stereoFrameHandler.cpp:1136-1218); every result then carries `new_kf`.
     fanout: None, or a concurrent.futures executor with >= 4 workers — the reference's own thread structure (points || lines in
     the stereo association and in f2fTracking, stereoFrame.cpp:64-72 / stereoFrameHandler.cpp:115-118, and 12 || 21 inside every
@@ -73,7 +76,7 @@ def run_sequence(orc, frames, cam, mp, prm, fast=dict(adaptive=True, th0=20, mn=
         return orc.match(d1, d2, nnr, mp.best_lr_matches) if fanout is None else match_fanout(orc, fanout, d1, d2, nnr, mp.best_lr_matches)
 
     prev = stereo(frames[0])
-    prev.update(Tfw=np.eye(4), Tfw_cov=np.eye(6))
+    prev.update(Tfw=np.eye(4), Tfw_cov=np.eye(6), DT=np.eye(4), DT_cov=np.zeros((6, 6)), err_norm=-1.0)
     fast_th = fast["th0"]
     results = []
     for k in range(1, len(frames)):
@@ -96,7 +99,11 @@ def run_sequence(orc, frames, cam, mp, prm, fast=dict(adaptive=True, th0=20, mn=
             rec.update(sP=prev["sP"][sel], eP=prev["eP"][sel], le_obs=curr["le"][m12[sel]], spl=prev["spl"][sel],
                        epl=prev["epl"][sel], sigma2l=matched_line_sigma2(prev["sigma2l"][sel], prev["llevel"][sel], mp.lsd_scale),
                        inlier_l=np.ones(len(sel), np.int32))
-        out = orc.optimize_pose(np.eye(4), cam, prm, rec)
+        init_T = np.eye(4)
+        if motion_model and orc.is_good(prev["DT"], prev["DT_cov"], prev["err_norm"]):   # :317-324
+            init_T = prev["DT"]
+        out = orc.optimize_pose(init_T, cam, prm, rec)
+        curr.update(DT=np.array(out["T"], float).reshape(4, 4), DT_cov=np.array(out["cov"], float).reshape(6, 6), err_norm=float(out["err"]))
         if out["status"] == 0:
             curr["Tfw"] = orc.expmap(orc.logmap(prev["Tfw"] @ out["T"]))
             curr["Tfw_cov"] = orc.unccomp(prev["Tfw"], prev["Tfw_cov"], out["cov"])

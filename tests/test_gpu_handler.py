@@ -102,6 +102,27 @@ def test_oversized_frame_falls_back_to_the_per_call_path(tmp_path, oracle):
     compare(res, ref)
 
 
+@pytest.mark.parametrize("pipeline", [True, False])
+def test_motion_model_through_the_handler(tmp_path, oracle, pipeline):
+    """use_motion_model : true (Config::useMotionModel, src/stereoFrameHandler.cpp:317-324): the initial DT of optimizePose is the
+    increment committed for the previous pair unless !isGoodSolution(prev) — on the device-resident pipeline the rule is applied ON
+    the device by the previous step's commit (stvo_seq_set_motion_model), on the per-call path by the handler; both against the
+    oracle pipeline with the same rule.  One frame without right-camera features makes two pairs fail: the pair after a rejected one
+    starts from the identity again."""
+    cam = synth.KITTI_CAM
+    frames = synth.make_stereo_sequence(3131, n_frames=9, n_pts=600, n_lines=50, cam=cam)
+    z2 = np.zeros((0, 2), np.float32); zd = np.zeros((0, 32), np.uint8); z4 = np.zeros((0, 4), np.float32)
+    frames[4] = dict(frames[4], kp_r=z2, desc_r=zd, kl_r=z4, ldesc_r=zd)
+    cfg = tmp_path / "cfg.yaml"
+    cfg.write_text("use_motion_model : true\n")
+    res, _ = run_app(tmp_path, frames, cam, "kitti", extra=("-c", str(cfg)), pipeline=pipeline)
+    ref = pipeline_ref.run_sequence(oracle, frames, cam, match_params("kitti"), opt_params("kitti"), motion_model=True)
+    compare(res, ref)
+    assert [r["ints"][1] == 0 for r in res] == [True, True, True, False, False, True, True, True]
+    plain = pipeline_ref.run_sequence(oracle, frames, cam, match_params("kitti"), opt_params("kitti"))
+    assert any(a["iters"] != b["iters"] for a, b in zip(ref, plain))   # the prior changes the optimisation's course
+
+
 def test_keyframe_decisions_and_cli_offset_step(tmp_path, oracle):
     """--keyframes: needNewKF / currFrameIsKF (src/stereoFrameHandler.cpp:1136-1218) after every optimizePose of the handler,
     against the oracle's restatement — same decisions, and the poses after a key-frame are expressed in the restarted map

@@ -12,7 +12,7 @@ from stvo_amd.ctypes_types import match_params, opt_params
 pytestmark = pytest.mark.gpu
 
 
-def run_and_compare(oracle, seqs, cam, preset, mode=0, has_lines=1, max_kp=2048, max_kl=320):
+def run_and_compare(oracle, seqs, cam, preset, mode=0, has_lines=1, max_kp=2048, max_kl=320, motion_model=False):
     from stvo_amd import capi
     B, nf = len(seqs), len(seqs[0])
     mp = match_params(preset)
@@ -21,7 +21,9 @@ def run_and_compare(oracle, seqs, cam, preset, mode=0, has_lines=1, max_kp=2048,
     ctx = capi.Context(device_id=0, max_rows=2048, max_batch=max(B, 1))
     dev = capi.Sequences(ctx, B, max_kp, max_kl, cam, mp, op)
     try:
-        refs = [pipeline_ref.run_sequence(oracle, seqs[b], cams[b], mp, op) for b in range(B)]
+        if motion_model:
+            dev.set_motion_model(True)
+        refs = [pipeline_ref.run_sequence(oracle, seqs[b], cams[b], mp, op, motion_model=motion_model) for b in range(B)]
         ref0 = [pipeline_ref.stereo_frame(oracle, seqs[b][0], cams[b], mp, True, bool(has_lines)) for b in range(B)]
         for k in range(nf):
             res, counts = dev.push([seqs[b][k] for b in range(B)])
@@ -58,6 +60,27 @@ def test_seq_pipeline_kitti_points_only_2000(oracle):
     cam = synth.KITTI_CAM
     seqs = [synth.make_stereo_sequence(600 + b, n_frames=4, n_pts=1650, n_lines=0, cam=cam) for b in range(2)]
     run_and_compare(oracle, seqs, cam, "kitti", has_lines=0)
+
+
+@pytest.mark.parametrize("B,pose", [(3, None), (40, "4"), (40, "1")], ids=["latency-kernel", "batch-kernel", "latency-kernel-40"])
+def test_seq_pipeline_motion_model(oracle, switches, B, pose):
+    """use_motion_model = true (stvo_seq_set_motion_model): the initial DT of a pair is the increment committed for the previous pair
+    — the rule of src/stereoFrameHandler.cpp:317-324 applied on the device by the previous step's commit — against the oracle
+    pipeline with the same rule, for both pose kernels.  The committed increment is the INVERSE of the optimiser's variable (:374), so
+    under forward motion the reference starts every pair about two increments away from the answer: iteration counts and paths differ
+    from the identity start, and the one sequence whose second frame carries no features exercises 'previous pair rejected -> I'."""
+    if pose:
+        switches({"STVO_POSE_KERNEL": pose})
+    cam = synth.KITTI_CAM
+    seqs = [synth.make_stereo_sequence(900 + b, n_frames=5, n_pts=300 + 40 * (b % 7), n_lines=30 + 5 * (b % 4), cam=cam) for b in range(B)]
+    z2 = np.zeros((0, 2), np.float32); zd = np.zeros((0, 32), np.uint8); z4 = np.zeros((0, 4), np.float32)
+    seqs[1][2] = dict(seqs[1][2], kp_r=z2, desc_r=zd, kl_r=z4, ldesc_r=zd)   # right camera dropped out: pairs 2 and 3 are rejected
+    run_and_compare(oracle, seqs, cam, "kitti", max_kp=1024, max_kl=128, motion_model=True)
+    # the motion model really changes the computation: some pair takes a different number of evaluations than from the identity
+    mp, op = match_params("kitti"), opt_params("kitti")
+    a = pipeline_ref.run_sequence(oracle, seqs[0], cam, mp, op, motion_model=True)
+    b = pipeline_ref.run_sequence(oracle, seqs[0], cam, mp, op, motion_model=False)
+    assert any(x["iters"] != y["iters"] for x, y in zip(a, b))
 
 
 @pytest.mark.parametrize("mode", [0, 2])

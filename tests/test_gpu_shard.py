@@ -31,3 +31,25 @@ def test_two_rank_config5_equals_one_rank(tmp_path):
         got = z[f"poses_{r}"].reshape(len(ids), n_frames - 1, 16)
         assert got.tobytes() == one_p[ids].tobytes(), f"rank {r}: pose blocks differ from the 1-rank run"
         assert np.array_equal(z[f"status_{r}"].reshape(len(ids), -1).astype(np.int32), one_s[ids])
+
+
+def test_bench_two_ranks_runs_its_multi_gpu_branch(tmp_path):
+    """`python bench.py --gpus 2` end to end: the self-spawn under torch.distributed.run, one process per rank, sequence s on rank
+    s mod 2, barrier + synchronize around the timed region, max-over-ranks time and the summed frame count — the code an 8-GPU node
+    executes, here with STVO_BENCH_BACKEND=gloo because both ranks share this box's one GPU (RCCL refuses two ranks on one device).
+    One JSON line from rank 0 with n_gpus == rccl_ranks == 2 and value = all ranks' frame pairs / the slowest rank's time."""
+    import json
+    env = dict(os.environ, STVO_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "64", "--steps", "2", "--warmup", "1", "--repeats", "1",
+           "--no-extras", "--no-cpu-baseline", "--no-clocks"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["collective_backend"] == "gloo"
+    assert out["steps"] == 2 and out["scaling"] == "weak"
+    # whole-job aggregate: 2 ranks x 64 streams x 2 steps over the max-over-ranks time
+    frames = 2 * 64 * 2
+    assert abs(out["value"] - frames / (out["ms_per_step"] * 1e-3 * 2)) / out["value"] < 1e-6
+    assert out["parity_sampled"] is None or out["parity_sampled"].get("ok", True)
