@@ -91,12 +91,13 @@ def stream_ids(rank, world, B):
 
 def _gen_stream(args):
     from stvo_amd import synth
-    s, rep, n_frames, n_pts, n_lines = args
-    return synth.make_config5_sequence(int(s), n_frames=n_frames, n_pts=n_pts, n_lines=n_lines, replica=int(rep))
+    s, rep, n_frames, n_pts, n_lines = args[:5]
+    return synth.make_config5_sequence(int(s), n_frames=n_frames, n_pts=n_pts, n_lines=n_lines, replica=int(rep),
+                                       cluster_kw=args[5] if len(args) > 5 else None)
 
 
-def generate_streams(seq_ids, replicas, n_frames, n_pts, n_lines):
-    jobs = [(s, r, n_frames, n_pts, n_lines) for s, r in zip(seq_ids, replicas)]
+def generate_streams(seq_ids, replicas, n_frames, n_pts, n_lines, cluster_kw=None):
+    jobs = [(s, r, n_frames, n_pts, n_lines, cluster_kw) for s, r in zip(seq_ids, replicas)]
     nproc = min(16, os.cpu_count() or 1, max(1, len(jobs) // 8))
     if nproc <= 1:
         return [_gen_stream(j) for j in jobs]
@@ -528,9 +529,53 @@ def correlated_leg(ctx_dev, rank, B=512, n=2000, steps=8):
                          "accepted_matches": float(res["n_matched_pt"].mean()), "committed_pose_fraction": float((res["status"] == 0).mean())}
         finally:
             ctx.close()
-    out["note"] = ("reverse check = forward_plan kernel + two sparse scans of K1m (light columns against the rows of S, heavy columns against all "
-                   "rows, DESIGN.md section 5); the plan of a frame of near-duplicates degrades towards the full reverse scan")
+    out["note"] = ("reverse check = forward_plan kernel + ONE launch of the sparse reverse scans (hamming_knn2_mfma_reverse_kernel: light columns against "
+                   "the rows of S, heavy columns against all rows, the train side of an item resident in LDS; DESIGN.md section 5); the plan of a "
+                   "frame of near-duplicates degrades towards the full reverse scan")
     return out
+
+
+def clustered_headline_leg(local_rank, streams, cams, S, steps, warmup, repeats, max_keylines):
+    """The HEADLINE workload — same pipeline, same stream count, same slot rotation — on streams whose landmark descriptors are
+    clustered (CORRELATED_MODELS["clustered"]: 60 % of the rows in groups of ~8 near-duplicates) instead of i.i.d. bits: the mutual
+    check of StVO::match then needs its reverse scans (the i.i.d. rows need none), and the grid matcher sees close second bests.
+    value_clustered = frame pairs / s exactly as `value` is formed (median of `repeats` timed regions of `steps` steps)."""
+    from stvo_amd import capi
+    from stvo_amd.ctypes_types import match_params, opt_params
+    B = len(streams)
+    mp, op = match_params("kitti"), opt_params("kitti")
+    ctx = capi.Context(device_id=local_rank, max_rows=2048, max_batch=B)
+    pipe = capi.Sequences(ctx, B, 2048, max_keylines, cams, mp, op)
+    try:
+        pipe.set_slots(S)
+        for k in range(S):
+            pipe.upload(k, [st[k] for st in streams])
+        ctx.synchronize()
+        order = ping_pong(S)
+        for _ in range(warmup):
+            pipe.step_dev(next(order))
+        ctx.synchronize()
+        rep = []
+        for _ in range(max(1, repeats)):
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                pipe.step_dev(next(order))
+            ctx.synchronize()
+            rep.append(time.perf_counter() - t0)
+        dt = float(np.median(rep))
+        pipe.set_stage_timing(True)
+        for _ in range(steps):
+            pipe.step_dev(next(order))
+        stage_ms, n_timed = pipe.get_stage_timing()
+        pipe.set_stage_timing(False)
+        res, counts = pipe.read()
+        return {"descriptor_model": CORRELATED_MODELS["clustered"], "value": B * steps / dt, "unit": "frame-pairs/s", "ms_per_step": dt / steps * 1e3,
+                "streams": B, "steps": steps, "repeats": len(rep), "stage_ms": stage_ms,
+                "committed_pose_fraction": float((res["status"] == 0).mean()), "mean_stereo_points": float(counts[:, 0].mean()),
+                "mean_matched_points": float(counts[:, 2].mean())}
+    finally:
+        pipe.close()
+        ctx.close()
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -710,6 +755,9 @@ def main():
     B, S = args.batch, max(2, min(args.slots, 16))
     seq_ids, replicas = stream_ids(rank, world, B)
     streams = generate_streams(seq_ids, replicas, S, args.points, args.lines)
+    streams_cl = None
+    if rank == 0 and world == 1 and not args.no_extras:   # the same streams with clustered landmark descriptors (value_clustered)
+        streams_cl = generate_streams(seq_ids, replicas, S, args.points, args.lines, cluster_kw=CORRELATED_MODELS["clustered"])
     c3_seqs = None
     if rank == 0 and world == 1 and not args.no_extras:   # configs[3] sequences, also before the GPU is touched (fork)
         import multiprocessing as mp_
@@ -909,6 +957,14 @@ def main():
                 out[name] = leg(*a, **kw)
             except Exception as e:  # noqa: BLE001 — whatever a leg raises (HIP error codes arrive as StvoError, allocation as RuntimeError)
                 out[name] = {"error": f"{type(e).__name__}: {e}"}
+        extra("headline_clustered", clustered_headline_leg, local_rank, streams_cl, cams, S, args.steps, args.warmup, args.repeats, args.max_keylines)
+        hc = out["headline_clustered"]
+        if "error" not in hc:   # beside `value`, inside the object the driver keeps whole
+            out["config"]["value_clustered"] = hc["value"]
+            out["config"]["value_clustered_over_value"] = hc["value"] / out["value"]
+            out["config"]["value_clustered_note"] = ("the same pipeline and stream count on streams whose landmark descriptors are clustered "
+                                                     "(60 % of the rows in groups of ~8 near-duplicates, spread 6 % of the bits): the i.i.d. "
+                                                     "rows of `value` need no reverse distance evaluation in the mutual check, these do")
         extra("latency", single_stream_latency, local_rank, args.points, args.lines)
         extra("configs1", configs1_leg, dev_name, rank)
         extra("configs3", configs3_leg, local_rank, c3_seqs)

@@ -73,6 +73,16 @@ void launch_hamming_knn2(hipStream_t s, int B, int row_stride, int max_n, const 
                          const int32_t* nsel = nullptr, int nseg = KNN_MIN_NSEG, uint32_t* claim_init = nullptr);
 // K1m: the same scan with the distances taken from the matrix cores (match_mfma.hip); qb = query blocks of 32 rows per
 // wave (1, 2 or 4; a workgroup covers 128 * qb query rows).  Train indices must fit 13 bits (max_n <= 8192).
+// the reverse check of the claimed columns in one launch (match_mfma.hip): light columns against S, heavy columns against all rows,
+// the train side of an item resident in LDS; `slots` workgroups per frame pair walk the frame's items; results in
+// knn21 [rev_segments(rows)][B][row_stride]
+constexpr int REV_MAX_SEG = 8;
+__host__ __device__ inline int rev_segments(int train_rows) {  // train segments of an item list with this many train rows
+    const int s = (train_rows + 255) / 256;
+    return s < 1 ? 1 : (s > REV_MAX_SEG ? REV_MAX_SEG : s);
+}
+void launch_hamming_knn2_mfma_reverse(hipStream_t s, int B, int row_stride, const uint8_t* d1, const int32_t* n1, const uint8_t* d2, uint2* knn21,
+                                      const int32_t* qsel, const int32_t* nsel, const int32_t* tsel, int slots);
 void launch_hamming_knn2_mfma(hipStream_t s, int B, int row_stride, int max_n, const uint8_t* d1, const int32_t* n1,
                               const uint8_t* d2, const int32_t* n2, uint2* knn12, uint2* knn21, int both_directions,
                               int dir0, const int32_t* qsel, const int32_t* nsel, int nseg, uint32_t* claim_init, int qb,
@@ -90,6 +100,7 @@ struct LazyScratch {
     int32_t* qsel;  // [B][row_stride] compacted flagged columns
     int32_t* nsel;  // [5][B]: claimed columns; light, heavy, |S|, tau of the matrix-core reverse check (reverse_plan_kernel)
     size_t knn_capacity;  // elements of knn12 / knn21
+    size_t knn21_capacity = 0;  // elements of knn21 when it is the larger one (the reverse check's segments), 0: knn_capacity
 };
 void launch_match_mutual_lazy(hipStream_t s, int B, int row_stride, const uint8_t* d1, const int32_t* n1,
                               const uint8_t* d2, const int32_t* n2, float nnr, const LazyScratch& w, int32_t* m12,

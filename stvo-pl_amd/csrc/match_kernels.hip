@@ -77,6 +77,23 @@ __device__ __forceinline__ uint2 merged_knn(const uint2* __restrict__ knn, size_
     return r;
 }
 
+// the same for at most 8 segments with every load in flight at once (the reverse check's final pass: a dependent gather per column)
+__device__ __forceinline__ uint2 merged_knn8(const uint2* __restrict__ knn, size_t seg_stride, size_t idx, int nseg) {
+    uint2 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = k < nseg ? knn[(size_t)k * seg_stride + idx] : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+    uint2 r = v[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+        const uint32_t hi = r.x > v[k].x ? r.x : v[k].x;
+        uint32_t sec = r.y < v[k].y ? r.y : v[k].y;
+        sec = sec < hi ? sec : hi;
+        r.x = r.x < v[k].x ? r.x : v[k].x;
+        r.y = sec;
+    }
+    return r;
+}
+
 // qsel / nsel (optional): scan only the listed query rows of this direction (not used by the product path any more:
 // the mutual check is hamming_verify below); qsel = nullptr scans every row.
 // nseg: the train range of every query tile is split into nseg segments scanned by different workgroups
@@ -575,7 +592,9 @@ __global__ __launch_bounds__(256) void nnr_reverse_final_kernel(int nseg, int ro
             const bool light = (int)T <= nsel[4 * (size_t)B + b];
             // (a light column of a frame with an empty S was not scanned at all: nothing can block it any more)
             const bool scanned = !light || nsel[3 * (size_t)B + b] > 0;
-            const uint2 r = scanned ? merged_knn(knn21, (size_t)B * row_stride, off + m, nseg) : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+            // (a light column was scanned against S, a heavy one against all prev rows: rev_segments(.) segments each)
+            const uint2 r = scanned ? merged_knn8(knn21, (size_t)B * row_stride, off + m, rev_segments(light ? nsel[3 * (size_t)B + b] : n1[b]))
+                                    : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
             bool blk = false;
             if (r.x != 0xFFFFFFFFu) {
                 const int pos = (int)(r.x & 0xFFFFu);
@@ -596,24 +615,20 @@ struct ReversePlan {
     int32_t* tsel;
     int nseg;
 };
-static ReversePlan reverse_plan(const LazyScratch& w, int B, int row_stride, int nseg_forward) {
+constexpr int KNN_REV_SLOTS = 4;  // workgroups per frame pair walking the frame's reverse-check items
+static ReversePlan reverse_plan(const LazyScratch& w, int B, int row_stride, int /*nseg_forward*/) {
     const size_t per = (size_t)B * row_stride;
+    const size_t cap = w.knn21_capacity ? w.knn21_capacity : w.knn_capacity;
     ReversePlan p;
-    p.blocked = reinterpret_cast<int32_t*>(w.knn21 + (w.knn_capacity - per));
+    p.blocked = reinterpret_cast<int32_t*>(w.knn21 + (cap - per));
     p.tsel = p.blocked + per;
-    const size_t fit = (w.knn_capacity - per) / per;
-    p.nseg = (int)(fit < (size_t)nseg_forward ? fit : (size_t)nseg_forward);
-    if (p.nseg < 1) p.nseg = 1;
+    p.nseg = REV_MAX_SEG;  // [REV_MAX_SEG][B][row_stride] in front of the lists (stvo_ctx_create sizes knn21 for it)
     return p;
 }
-
 static void launch_reverse_scans(hipStream_t s, int B, int row_stride, const uint8_t* d1, const int32_t* n1, const uint8_t* d2,
-                                 const LazyScratch& w, const ReversePlan& rp, int mfma_qb) {
-    // light columns against the rows of S (positions in tsel), heavy columns against every row; disjoint column sets
-    launch_hamming_knn2_mfma(s, B, row_stride, row_stride, d1, n1, d2, n1, w.knn12, w.knn21, 0, 1, w.qsel, w.nsel + B, rp.nseg,
-                             nullptr, mfma_qb, 0, rp.tsel, w.nsel + 3 * (size_t)B);
-    launch_hamming_knn2_mfma(s, B, row_stride, row_stride, d1, n1, d2, n1, w.knn12, w.knn21, 0, 1, w.qsel, w.nsel + 2 * (size_t)B,
-                             rp.nseg, nullptr, mfma_qb, 1, nullptr, nullptr);
+                                 const LazyScratch& w, const ReversePlan& rp, int /*mfma_qb*/) {
+    // light columns against the rows of S (positions in tsel), heavy columns against every row; disjoint column sets, one launch
+    launch_hamming_knn2_mfma_reverse(s, B, row_stride, d1, n1, d2, w.knn21, w.qsel, w.nsel, rp.tsel, KNN_REV_SLOTS);
 }
 
 void launch_hamming_verify(hipStream_t s, int B, int row_stride, const uint8_t* d1, const int32_t* n1, const uint8_t* d2,

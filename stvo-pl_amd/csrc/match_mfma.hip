@@ -352,6 +352,226 @@ __global__ __launch_bounds__(MF_BLOCK, (QB == 1 ? 4 : QB == 2 ? 3 : 1)) void ham
     }
 }
 
+// ---- the reverse check of the claimed columns (match_kernels.hip: forward_plan_kernel) in ONE launch -------------------------------
+// A frame pair's work items:
+//   light item (lt, seg)   light columns [lt REV_ROWS, (lt + 1) REV_ROWS) of the frame's list against segment seg of the rows of S (tsel);
+//   heavy item (ht, seg)   heavy columns (back of the list) against segment seg of ALL prev rows.
+// An item of the old form — the general scan above with its one global fetch per barrier — ran at the latency of that fetch: a
+// handful of tiles per item, nothing else on the CU in the same phase (round 5, 512 clustered frames: 97 heavy columns per frame took
+// 113 us as one 2000-row item per frame, the 1340 light ones 48 us against |S| = 178 rows).  Here the train side of an item is
+// RESIDENT: at most REV_CHUNK = 256 rows, requested in one go (eight words per thread in flight behind their list entries), expanded
+// into LDS once, one barrier, then the waves run their tiles without meeting again.  The query rows are requested in the same breath,
+// so an item costs two dependent round trips (list entry -> row) and a few hundred cycles per tile.  Train ranges beyond 256 rows are
+// cut into segments (at most REV_MAX_SEG; a segment longer than a chunk takes several chunks, one after the other).
+// `slots` workgroups per frame pair walk the items slot, slot + slots, ...: a frame whose plan left nothing to scan (i.i.d. rows: S is
+// empty) costs `slots` workgroups that read four counters and leave.
+// Results: knn21 [seg][B][row_stride] for the listed columns; nnr_reverse_final_kernel merges rev_segments(.) segments.
+constexpr int REV_QB = 1, REV_ROWS = 4 * REV_QB * 32;  // query rows per item: 4 waves x 32
+constexpr int REV_CHUNK_TILES = 8, REV_CHUNK = REV_CHUNK_TILES * MF_TILE;
+
+__global__ __launch_bounds__(MF_BLOCK, 4) void hamming_knn2_mfma_reverse_kernel(int B, int slots, int row_stride, const uint8_t* __restrict__ d1,
+                                                                                const int32_t* __restrict__ n1, const uint8_t* __restrict__ d2,
+                                                                                uint2* __restrict__ knn21, const int32_t* __restrict__ qsel,
+                                                                                const int32_t* __restrict__ nsel, const int32_t* __restrict__ tsel) {
+    constexpr int KSTEPS = 4;
+    using key_t = float;
+    using acc_t = v16f;
+    __shared__ v4i s_tile[REV_CHUNK_TILES][KSTEPS * 2 * 32];  // 32 KB: every tile of the chunk
+    const int L = blockIdx.x;
+    const int xcd = L & 7, k = L >> 3;
+    const int b = (k / slots) * 8 + xcd, slot = k % slots;
+    if (b >= B) return;
+    const int na = n1[b];
+    const int nl = nsel[(size_t)B + b], nh = nsel[2 * (size_t)B + b], ns = nsel[3 * (size_t)B + b];
+    const int lseg = rev_segments(ns), hseg = rev_segments(na);
+    const int lt = ns > 0 ? (nl + REV_ROWS - 1) / REV_ROWS : 0;  // (an empty S: nothing can block a light column any more)
+    const int n_light = lt * lseg, n_items = n_light + ((nh + REV_ROWS - 1) / REV_ROWS) * hseg;
+    if (slot >= n_items) return;
+    const size_t frame_off = (size_t)b * row_stride;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, col = lane & 31, hf = lane >> 5;
+    const int xr = tid & 31, xk = tid >> 5;  // staging role: word xk of train row xr of a tile
+    const uint32_t* __restrict__ Q = reinterpret_cast<const uint32_t*>(d2 + frame_off * STVO_DESC_BYTES);  // the columns: curr rows
+    const uint32_t* __restrict__ T = reinterpret_cast<const uint32_t*>(d1 + frame_off * STVO_DESC_BYTES);  // against prev rows
+    acc_t cidx;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cidx[r] = (key_t)((r & 3) + 8 * (r >> 2) + 4 * hf);
+    auto mma = [&](const v4i& tf, const v4i& q, const acc_t& c) -> acc_t {
+        const v8i a8 = {tf.x, tf.y, tf.z, tf.w, 0, 0, 0, 0}, b8 = {q.x, q.y, q.z, q.w, 0, 0, 0, 0};
+        return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, c, 4, 4, 0, MF_SCALE_2_4, 0, MF_SCALE_2_4);
+    };
+    struct Item {
+        bool light;
+        int seg, nq, j0, nt, q_base;
+    };
+    auto item_of = [&](int item) -> Item {  // (workgroup-uniform scalars)
+        Item m;
+        m.light = item < n_light;
+        const int nseg = m.light ? lseg : hseg, it = m.light ? item : item - n_light;
+        m.seg = it % nseg;
+        m.q_base = (it / nseg) * REV_ROWS;
+        m.nq = m.light ? nl : nh;
+        const int nt_all = m.light ? ns : na;
+        const int seg_len = (((nt_all + nseg - 1) / nseg) + MF_TILE - 1) & ~(MF_TILE - 1);
+        m.j0 = min(m.seg * seg_len, nt_all);
+        m.nt = min(m.j0 + seg_len, nt_all);
+        return m;
+    };
+    // The requests of a unit of work (an item's chunk): eight train words per thread behind their list entries and — for the item's first
+    // chunk — the query row behind its list entry.  They are issued one unit AHEAD: while the waves multiply the resident chunk, the next
+    // unit's two dependent round trips are under way (an item is ~4 k cycles of tiles against ~6 k of round trips).
+    uint32_t w[REV_CHUNK_TILES];
+    int qi = 0;
+    uint4 qw0 = make_uint4(0u, 0u, 0u, 0u), qw1 = qw0;
+    auto request_train = [&](const Item& m, int c0) {
+#pragma unroll
+        for (int t = 0; t < REV_CHUNK_TILES; ++t) {
+            const int j = c0 + t * MF_TILE + xr;
+            uint32_t v = 0u;
+            if (j < m.nt) v = T[(size_t)(m.light ? tsel[frame_off + j] : j) * 8 + xk];
+            w[t] = v;
+        }
+    };
+    auto request_query = [&](const Item& m) {
+        const int q = m.q_base + wv * 32 + col;
+        const int qc = q < m.nq ? q : m.nq - 1;  // tail lanes scan a valid row and discard the result
+        qi = qsel[frame_off + (m.light ? qc : row_stride - 1 - qc)];
+        qw0 = reinterpret_cast<const uint4*>(Q)[2 * qi];
+        qw1 = reinterpret_cast<const uint4*>(Q)[2 * qi + 1];
+    };
+
+    int item = slot;
+    Item m = item_of(item);
+    int c0 = m.j0;
+    bool first = true;
+    request_train(m, c0);
+    request_query(m);
+    v4i qf[KSTEPS];
+    key_t best = MF_NO_KEY_F, second = MF_NO_KEY_F;
+    int out_row = 0, last_base = 0;
+    auto fold = [&](key_t key) {
+        second = med3_f32(best, second, key);
+        best = min_f32(best, key);
+    };
+    for (;;) {
+        if (first) {  // the item's query rows: expanded once, kept for all its chunks
+            const bool up = hf != 0;
+            qf[0] = expand_fp4(~(up ? qw0.y : qw0.x));
+            qf[1] = expand_fp4(~(up ? qw0.w : qw0.z));
+            qf[2] = expand_fp4(~(up ? qw1.y : qw1.x));
+            qf[3] = expand_fp4(~(up ? qw1.w : qw1.z));
+            best = second = MF_NO_KEY_F;
+            out_row = qi;
+            last_base = m.j0;
+        }
+        const int ntc = min((m.nt - c0 + MF_TILE - 1) / MF_TILE, REV_CHUNK_TILES);  // (0 for an empty segment)
+#pragma unroll
+        for (int t = 0; t < REV_CHUNK_TILES; ++t)
+            if (t < ntc) s_tile[t][xk * 32 + xr] = expand_fp4(w[t]);
+        __syncthreads();
+        // the next unit: the item's next chunk, or the first chunk of this workgroup's next item
+        const bool more_chunks = c0 + REV_CHUNK < m.nt;
+        const int n_item = more_chunks ? item : item + slots;
+        const bool has_next = more_chunks || n_item < n_items;
+        const Item nm = (!more_chunks && has_next) ? item_of(n_item) : m;
+        const int n_c0 = more_chunks ? c0 + REV_CHUNK : nm.j0;
+        if (has_next) {
+            request_train(nm, n_c0);
+            if (!more_chunks) request_query(nm);
+        }
+        const bool wave_active = m.q_base + wv * 32 < m.nq;
+        if (wave_active && ntc > 0) {
+            // software pipeline, depth one tile (as the general scan): tile t's matrix instructions are issued, tile t - 1's keys are
+            // folded in their shadow — three keys at a time (5 operations per 3 keys); the chunk's last tile is folded after the loop
+            auto fold3 = [&](const acc_t& p, int f) {
+                const key_t k0 = p[f], k1 = p[f + 1], k2 = p[f + 2];
+                const key_t lo = min3_f32(k0, k1, k2), mid = med3_f32(k0, k1, k2);
+                second = min3_f32(max_f32(best, lo), second, mid);
+                best = min_f32(best, lo);
+            };
+            auto do_tile = [&](acc_t& cur, acc_t& prev, int t) {
+                const v4i* frag = s_tile[t];
+                const bool fold_prev = t > 0;
+                if (fold_prev) {
+                    best -= (key_t)MF_TILE;
+                    second -= (key_t)MF_TILE;
+                }
+                v4i tf = frag[lane];
+#pragma unroll
+                for (int kk = 0; kk < KSTEPS; ++kk) {
+                    v4i tf_ahead = tf;
+                    if (kk < KSTEPS - 1) tf_ahead = frag[(kk + 1) * 64 + lane];
+                    cur = mma(tf, qf[kk], kk == 0 ? cidx : cur);
+                    if (fold_prev) {
+                        if (kk == 0) {
+                            // The folds read tile t - 1's accumulators through inline asm (v_min3 / v_med3 without canonicalisation),
+                            // which the compiler's hazard recogniser does not cover: nothing stops it from scheduling them right behind
+                            // the matrix instruction that writes them, and the hardware does not interlock that read (round 5: one
+                            // wrong top-2 in the adversarial test with a single instruction between the two).  The wait states of a
+                            // 16-pass XDL write -> VALU read (19), tied to the registers, in the shadow of this tile's first instruction.
+                            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 2" : "+v"(prev));
+                            fold3(prev, 0);
+                            fold3(prev, 3);
+                        } else if (kk == 1) {
+                            fold3(prev, 6);
+                            fold(prev[15]);
+                        } else if (kk == 2) {
+                            fold3(prev, 9);
+                        } else {
+                            fold3(prev, 12);
+                        }
+                    }
+                    if (kk < KSTEPS - 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+                    tf = tf_ahead;
+                }
+            };
+            acc_t accA, accB;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accA[r] = accB[r] = 0;
+            int t = 0;
+            for (; t + 2 <= ntc; t += 2) {
+                do_tile(accA, accB, t);
+                do_tile(accB, accA, t + 1);
+            }
+            if (t < ntc) do_tile(accA, accB, t);
+            acc_t& last = (ntc & 1) ? accA : accB;
+            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 2" : "+v"(last));  // (as above: the last tile's accumulators are read by asm folds)
+            best -= (key_t)MF_TILE;
+            second -= (key_t)MF_TILE;
+            last_base = c0 + (ntc - 1) * MF_TILE;  // first train row of the tile the keys are relative to
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int jr = last_base + (r & 3) + 8 * (r >> 2) + 4 * hf;
+                fold(jr < m.nt ? last[r] : MF_NO_KEY_F);
+            }
+        }
+        __syncthreads();  // the tile buffers are staged again by the next unit
+        if (!more_chunks && wave_active) {  // the item is complete: the two wave halves hold the same columns over different train rows
+            const int bi = best >= MF_NO_KEY_MIN_F ? MF_NO_KEY : (int)best;
+            const int si = second >= MF_NO_KEY_MIN_F ? MF_NO_KEY : (int)second;
+            const int ob = __shfl_xor(bi, 32), os = __shfl_xor(si, 32);
+            const int hi = max(bi, ob);
+            const int sec = min(min(si, os), hi);
+            const int bst = min(bi, ob);
+            if (hf == 0 && m.q_base + wv * 32 + col < m.nq)
+                knn21[(size_t)m.seg * B * row_stride + frame_off + out_row] = make_uint2(key_to_knn(bst, last_base), key_to_knn(sec, last_base));
+        }
+        if (!has_next) break;
+        first = !more_chunks;
+        item = n_item;
+        m = nm;
+        c0 = n_c0;
+    }
+}
+
+void launch_hamming_knn2_mfma_reverse(hipStream_t s, int B, int row_stride, const uint8_t* d1, const int32_t* n1, const uint8_t* d2, uint2* knn21,
+                                      const int32_t* qsel, const int32_t* nsel, const int32_t* tsel, int slots) {
+    if (B <= 0 || row_stride <= 0) return;
+    const dim3 grid((unsigned)(((B + 7) / 8) * 8 * slots));
+    hipLaunchKernelGGL(hamming_knn2_mfma_reverse_kernel, grid, dim3(MF_BLOCK), 0, s, B, slots, row_stride, d1, n1, d2, knn21, qsel, nsel, tsel);
+}
+
 int mfma_rows_per_block(int qb) { return 4 * qb * 32; }
 
 template <int QB, int MODE>

@@ -207,13 +207,34 @@ def make_matched_records(seed, n_pts=1200, n_lines=60, cam=KITTI_CAM, outlier_fr
 # Stereo feature SEQUENCES (what the out-of-scope ORB / LSD+LBD front-end would hand to the hot path)
 # ------------------------------------------------------------------------------------------------
 def make_stereo_sequence(seed, n_frames=6, n_pts=600, n_lines=60, cam=KITTI_CAM, distract=0.2, flip_p=0.03,
-                         noise_px=0.3, depth=(4.0, 60.0), octave_probs=None, outlier_frac=0.05):
+                         noise_px=0.3, depth=(4.0, 60.0), octave_probs=None, outlier_frac=0.05, cluster_kw=None):
     """A persistent 3-D landmark world observed by a forward-moving rectified stereo rig.
     Returns a list of per-frame dicts: kp_l/kp_r (float32 [n,2]), oct_l, desc_l/desc_r (uint8 [n,32]),
-    kl_l/kl_r (float32 [n,4] sx,sy,ex,ey), ang_l, oct_ll, ldesc_l/ldesc_r, plus T_true (prev->curr)."""
+    kl_l/kl_r (float32 [n,4] sx,sy,ex,ey), ang_l, oct_ll, ldesc_l/ldesc_r, plus T_true (prev->curr).
+    cluster_kw (None: i.i.d. descriptor bits): dict(cluster_frac, cluster_size, spread_p) — the landmark descriptors (points and
+    lines) come in groups of near-duplicates around a fixed set of centres, as clustered_desc describes: repeated structure, so that
+    ratio tests and the mutual check are decided by close calls in BOTH matchers (stereo grid and f2f)."""
     rng = np.random.default_rng(seed)
     W, Hh = cam["width"], cam["height"]
     edge = 19.0
+    if cluster_kw is None:
+        land_desc_p = land_desc_l = lambda n: random_desc(rng, n)
+    else:
+        frac, size, sp = cluster_kw["cluster_frac"], cluster_kw["cluster_size"], cluster_kw["spread_p"]
+
+        def make_model(n_total):
+            centres = random_desc(rng, max(1, int(round(frac * n_total)) // size))
+
+            def draw(n):
+                d = random_desc(rng, n)
+                if n:
+                    cl = rng.random(n) < frac
+                    k = int(cl.sum())
+                    if k:
+                        d[cl] = flip_bits(rng, centres[rng.integers(0, len(centres), k)], sp)
+                return d
+            return draw
+        land_desc_p, land_desc_l = make_model(n_pts), make_model(max(n_lines, 1))
 
     def new_points(n, Tcw):
         u = rng.uniform(edge, W - edge, n); v = rng.uniform(edge, Hh - edge, n); z = rng.uniform(depth[0], depth[1], n)
@@ -230,11 +251,11 @@ def make_stereo_sequence(seed, n_frames=6, n_pts=600, n_lines=60, cam=KITTI_CAM,
 
     Tcw = np.eye(4)
     Pw = new_points(n_pts, Tcw)
-    pdesc = random_desc(rng, n_pts)
+    pdesc = land_desc_p(n_pts)
     plevel = (np.zeros(n_pts, np.int32) if octave_probs is None
               else rng.choice(len(octave_probs), size=n_pts, p=octave_probs).astype(np.int32))
     Ls, Le = new_lines(n_lines, Tcw) if n_lines else (np.zeros((0, 3)), np.zeros((0, 3)))
-    ldesc = random_desc(rng, n_lines)
+    ldesc = land_desc_l(n_lines)
     frames = []
     for k in range(n_frames):
         T_step = np.eye(4)
@@ -248,7 +269,7 @@ def make_stereo_sequence(seed, n_frames=6, n_pts=600, n_lines=60, cam=KITTI_CAM,
         nb = int((~vis).sum())
         if nb:
             Pw[~vis] = new_points(nb, Tcw)
-            pdesc[~vis] = random_desc(rng, nb)
+            pdesc[~vis] = land_desc_p(nb)
             Pc = Pw @ Tcw[:3, :3].T + Tcw[:3, 3]
             uv = project(cam, Pc)
         if n_lines:
@@ -262,7 +283,7 @@ def make_stereo_sequence(seed, n_frames=6, n_pts=600, n_lines=60, cam=KITTI_CAM,
             if nb:
                 s_new, e_new = new_lines(nb, Tcw)
                 Ls[~lvis] = s_new; Le[~lvis] = e_new
-                ldesc[~lvis] = random_desc(rng, nb)
+                ldesc[~lvis] = land_desc_l(nb)
                 sc = Ls @ Tcw[:3, :3].T + Tcw[:3, 3]; ec = Le @ Tcw[:3, :3].T + Tcw[:3, 3]
                 su = project(cam, sc); eu = project(cam, ec)
         # ---- points: left observation, right = same row shifted by the disparity
