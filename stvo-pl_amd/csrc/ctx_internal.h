@@ -17,8 +17,7 @@ struct stvo_ctx {
     // persistent scratch for the batched path
     uint2* knn12 = nullptr;
     uint2* knn21 = nullptr;
-    size_t knn_capacity = 0;  // elements of knn12 (knn21 holds at least as many)
-    size_t knn21_capacity = 0;  // elements of knn21: the reverse check keeps up to 8 train segments per column + its lists there
+    size_t knn_capacity = 0;  // elements in each of knn12 / knn21
     int32_t *cand = nullptr, *need = nullptr, *qsel = nullptr, *nsel = nullptr;  // lazy reverse pass
     // bump arena for the host-buffer entry points
     char* arena = nullptr;

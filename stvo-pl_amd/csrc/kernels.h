@@ -74,15 +74,15 @@ void launch_hamming_knn2(hipStream_t s, int B, int row_stride, int max_n, const 
 // K1m: the same scan with the distances taken from the matrix cores (match_mfma.hip); qb = query blocks of 32 rows per
 // wave (1, 2 or 4; a workgroup covers 128 * qb query rows).  Train indices must fit 13 bits (max_n <= 8192).
 // the reverse check of the claimed columns in one launch (match_mfma.hip): light columns against S, heavy columns against all rows,
-// the train side of an item resident in LDS; `slots` workgroups per frame pair walk the frame's items; results in
-// knn21 [rev_segments(rows)][B][row_stride]
+// the train side of a unit resident in LDS; `slots` workgroups per frame pair share the frame's units; blocked[column] = 1 for every
+// listed column whose claim another row blocks
 constexpr int REV_MAX_SEG = 8;
-__host__ __device__ inline int rev_segments(int train_rows) {  // train segments of an item list with this many train rows
+__host__ __device__ inline int rev_segments(int train_rows) {  // train segments of a column list with this many train rows
     const int s = (train_rows + 255) / 256;
     return s < 1 ? 1 : (s > REV_MAX_SEG ? REV_MAX_SEG : s);
 }
-void launch_hamming_knn2_mfma_reverse(hipStream_t s, int B, int row_stride, const uint8_t* d1, const int32_t* n1, const uint8_t* d2, uint2* knn21,
-                                      const int32_t* qsel, const int32_t* nsel, const int32_t* tsel, int slots);
+void launch_hamming_knn2_mfma_reverse(hipStream_t s, int B, int row_stride, const uint8_t* d1, const int32_t* n1, const uint8_t* d2, const int32_t* qsel,
+                                      const int32_t* nsel, const int32_t* tsel, const uint32_t* claim, float nnr, int32_t* blocked, int slots);
 void launch_hamming_knn2_mfma(hipStream_t s, int B, int row_stride, int max_n, const uint8_t* d1, const int32_t* n1,
                               const uint8_t* d2, const int32_t* n2, uint2* knn12, uint2* knn21, int both_directions,
                               int dir0, const int32_t* qsel, const int32_t* nsel, int nseg, uint32_t* claim_init, int qb,
@@ -93,14 +93,13 @@ int knn_mfma_qb(int max_n);  // query blocks per wave of K1m for this problem si
 // (> 8192 rows, STVO_KNN_MFMA=0) by a range query with early exit
 struct LazyScratch {
     uint2* knn12;
-    uint2* knn21;   // VALU path: reused as int32 blocked[B][row_stride].  Matrix-core path: [nseg_r][B][row_stride] reverse top-2
-                    // of the scanned columns in front, blocked[] and tsel[] (B * row_stride int32 each) in the last B * row_stride entries
+    uint2* knn21;   // VALU path: reused as int32 blocked[B][row_stride].  Matrix-core path: blocked[] and tsel[] (B * row_stride int32
+                    // each) in the last B * row_stride entries
     int32_t* cand;  // [B][row_stride] forward ratio-tested best
     int32_t* need;  // [B][row_stride] per-column claim (d0 << 16 | claimant), 0xFFFFFFFF = unclaimed
     int32_t* qsel;  // [B][row_stride] compacted flagged columns
     int32_t* nsel;  // [5][B]: claimed columns; light, heavy, |S|, tau of the matrix-core reverse check (reverse_plan_kernel)
     size_t knn_capacity;  // elements of knn12 / knn21
-    size_t knn21_capacity = 0;  // elements of knn21 when it is the larger one (the reverse check's segments), 0: knn_capacity
 };
 void launch_match_mutual_lazy(hipStream_t s, int B, int row_stride, const uint8_t* d1, const int32_t* n1,
                               const uint8_t* d2, const int32_t* n2, float nnr, const LazyScratch& w, int32_t* m12,

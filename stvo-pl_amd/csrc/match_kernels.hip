@@ -77,23 +77,6 @@ __device__ __forceinline__ uint2 merged_knn(const uint2* __restrict__ knn, size_
     return r;
 }
 
-// the same for at most 8 segments with every load in flight at once (the reverse check's final pass: a dependent gather per column)
-__device__ __forceinline__ uint2 merged_knn8(const uint2* __restrict__ knn, size_t seg_stride, size_t idx, int nseg) {
-    uint2 v[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = k < nseg ? knn[(size_t)k * seg_stride + idx] : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
-    uint2 r = v[0];
-#pragma unroll
-    for (int k = 1; k < 8; ++k) {
-        const uint32_t hi = r.x > v[k].x ? r.x : v[k].x;
-        uint32_t sec = r.y < v[k].y ? r.y : v[k].y;
-        sec = sec < hi ? sec : hi;
-        r.x = r.x < v[k].x ? r.x : v[k].x;
-        r.y = sec;
-    }
-    return r;
-}
-
 // qsel / nsel (optional): scan only the listed query rows of this direction (not used by the product path any more:
 // the mutual check is hamming_verify below); qsel = nullptr scans every row.
 // nseg: the train range of every query tile is split into nseg segments scanned by different workgroups
@@ -531,18 +514,48 @@ __global__ __launch_bounds__(PLAN_BLOCK) void forward_plan_kernel(int B, int nse
             if (k.y != 0xFFFFFFFFu) atomicAdd(&hS[min(k.y >> 16, 256u)], 1);
         }
     __syncthreads();
-    if (tid < 256) {  // candidate cut tau = tid - 1 (thresholds above 254 are always heavy: they would need S = every row)
-        int cT = 0, cS = 0, C = 0;
-        for (int t = 0; t < 257; ++t) {
-            C += hT[t];
-            if (t < tid) {
-                cT += hT[t];
-                cS += hS[t];
+    // candidate cut tau = t - 1 for t = 0 .. 255 (thresholds above 254 are always heavy: they would need S = every row): exclusive
+    // prefix sums of the two histograms (in place, by the first wave: five values per lane + a wave scan), then one cost per thread
+    if (tid < 64) {
+        int vT[5], vS[5], sT = 0, sS = 0;
+#pragma unroll
+        for (int e = 0; e < 5; ++e) {
+            const int t = tid * 5 + e;
+            vT[e] = t < 257 ? hT[t] : 0;
+            vS[e] = t < 257 ? hS[t] : 0;
+            sT += vT[e];
+            sS += vS[e];
+        }
+        int iT = sT, iS = sS;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int a = __shfl_up(iT, o, 64), c = __shfl_up(iS, o, 64);
+            if (tid >= o) {
+                iT += a;
+                iS += c;
             }
         }
+        int eT = iT - sT, eS = iS - sS;  // exclusive
+#pragma unroll
+        for (int e = 0; e < 5; ++e) {
+            const int t = tid * 5 + e;
+            if (t < 257) {
+                hT[t] = eT;
+                hS[t] = eS;
+            }
+            eT += vT[e];
+            eS += vS[e];
+        }
+        if (tid == 63) s_cnt[0] = iT;  // C = all claimed columns (s_cnt[0] is reset below)
+    }
+    __syncthreads();
+    if (tid < 256) {
+        const int C = s_cnt[0], cT = hT[tid], cS = hS[tid];
         const unsigned long long cost = (unsigned long long)(C - cT) * (unsigned)na + (unsigned long long)cT * (unsigned)cS;
         atomicMin(&s_best, (cost << 9) | (unsigned)tid);
     }
+    __syncthreads();
+    if (tid == 0) s_cnt[0] = 0;
     __syncthreads();
     const int tau = (int)(s_best & 511ull) - 1;
     for (int j = tid; j < row_stride; j += PLAN_BLOCK) {
@@ -568,67 +581,26 @@ __global__ __launch_bounds__(PLAN_BLOCK) void forward_plan_kernel(int B, int nse
     }
 }
 
-// m12[i] = cand[i] iff i holds the claim on that column, no row was found within T from knn12 alone, and the reverse
-// top-2 of the column (over S for a light column, over all rows for a heavy one) holds no OTHER row within T.
-// Fewer than two prev rows => no match (the reference's knnMatch(k = 2) row would have one entry; :54 is UB).
-__global__ __launch_bounds__(256) void nnr_reverse_final_kernel(int nseg, int row_stride, const int32_t* __restrict__ cand,
-                                                                const uint32_t* __restrict__ claim,
-                                                                const int32_t* __restrict__ blocked,
-                                                                const uint2* __restrict__ knn21,
-                                                                const int32_t* __restrict__ tsel,
-                                                                const int32_t* __restrict__ nsel,
-                                                                const int32_t* __restrict__ n1, float nnr,
-                                                                int32_t* __restrict__ m12) {
-    const int b = blockIdx.y, B = gridDim.y;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= row_stride) return;
-    const size_t off = (size_t)b * row_stride;
-    int m = cand[off + i];
-    if (m >= 0) {
-        bool keep = false;
-        const uint32_t c = claim[off + m];
-        if (n1[b] >= 2 && (c & 0xFFFFu) == (uint32_t)i && blocked[off + m] == 0) {
-            const uint32_t T = block_threshold(c >> 16, nnr);
-            const bool light = (int)T <= nsel[4 * (size_t)B + b];
-            // (a light column of a frame with an empty S was not scanned at all: nothing can block it any more)
-            const bool scanned = !light || nsel[3 * (size_t)B + b] > 0;
-            // (a light column was scanned against S, a heavy one against all prev rows: rev_segments(.) segments each)
-            const uint2 r = scanned ? merged_knn8(knn21, (size_t)B * row_stride, off + m, rev_segments(light ? nsel[3 * (size_t)B + b] : n1[b]))
-                                    : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
-            bool blk = false;
-            if (r.x != 0xFFFFFFFFu) {
-                const int pos = (int)(r.x & 0xFFFFu);
-                const int row = light ? tsel[off + pos] : pos;
-                blk = row != i ? (r.x >> 16) <= T : (r.y != 0xFFFFFFFFu && (r.y >> 16) <= T);
-            }
-            keep = !blk;
-        }
-        if (!keep) m = -1;
-    }
-    m12[off + i] = m;
-}
-
-// scratch of the matrix-core reverse check: the last B * row_stride uint2 of knn21 hold blocked[] and tsel[]; the reverse
-// top-2 arrays in front of them get as many train segments as fit
+// scratch of the matrix-core reverse check: the last B * row_stride uint2 of knn21 hold blocked[] and tsel[] (the reverse top-2 array of
+// the non-lazy path is not needed here)
 struct ReversePlan {
     int32_t* blocked;
     int32_t* tsel;
-    int nseg;
 };
-constexpr int KNN_REV_SLOTS = 4;  // workgroups per frame pair walking the frame's reverse-check items
-static ReversePlan reverse_plan(const LazyScratch& w, int B, int row_stride, int /*nseg_forward*/) {
+constexpr int KNN_REV_SLOTS = 4;  // workgroups per frame pair sharing the frame's reverse-check units (match_mfma.hip)
+static ReversePlan reverse_plan(const LazyScratch& w, int B, int row_stride) {
     const size_t per = (size_t)B * row_stride;
-    const size_t cap = w.knn21_capacity ? w.knn21_capacity : w.knn_capacity;
     ReversePlan p;
-    p.blocked = reinterpret_cast<int32_t*>(w.knn21 + (cap - per));
+    p.blocked = reinterpret_cast<int32_t*>(w.knn21 + (w.knn_capacity - per));
     p.tsel = p.blocked + per;
-    p.nseg = REV_MAX_SEG;  // [REV_MAX_SEG][B][row_stride] in front of the lists (stvo_ctx_create sizes knn21 for it)
     return p;
 }
-static void launch_reverse_scans(hipStream_t s, int B, int row_stride, const uint8_t* d1, const int32_t* n1, const uint8_t* d2,
-                                 const LazyScratch& w, const ReversePlan& rp, int /*mfma_qb*/) {
-    // light columns against the rows of S (positions in tsel), heavy columns against every row; disjoint column sets, one launch
-    launch_hamming_knn2_mfma_reverse(s, B, row_stride, d1, n1, d2, w.knn21, w.qsel, w.nsel, rp.tsel, KNN_REV_SLOTS);
+
+// light columns against the rows of S (positions in tsel), heavy columns against every row — one launch; blocked[] gains the verdicts
+static void launch_reverse_scans(hipStream_t s, int B, int row_stride, const uint8_t* d1, const int32_t* n1, const uint8_t* d2, float nnr,
+                                 const LazyScratch& w, const ReversePlan& rp) {
+    launch_hamming_knn2_mfma_reverse(s, B, row_stride, d1, n1, d2, w.qsel, w.nsel, rp.tsel, reinterpret_cast<const uint32_t*>(w.need), nnr, rp.blocked,
+                                     KNN_REV_SLOTS);
 }
 
 void launch_hamming_verify(hipStream_t s, int B, int row_stride, const uint8_t* d1, const int32_t* n1, const uint8_t* d2,
@@ -636,7 +608,7 @@ void launch_hamming_verify(hipStream_t s, int B, int row_stride, const uint8_t* 
     if (B <= 0 || row_stride <= 0) return;
     const int mfma_qb = knn_mfma_qb(row_stride);
     if (mfma_qb > 0) {  // the two reverse scans on the lists left by the last reverse_plan_kernel
-        launch_reverse_scans(s, B, row_stride, d1, n1, d2, w, reverse_plan(w, B, row_stride, nseg), mfma_qb);
+        launch_reverse_scans(s, B, row_stride, d1, n1, d2, nnr, w, reverse_plan(w, B, row_stride));
         return;
     }
     const int tiles = (row_stride + KNN_BLOCK - 1) / KNN_BLOCK, groups = (B + 7) / 8;
@@ -660,15 +632,14 @@ void launch_match_mutual_lazy(hipStream_t s, int B, int row_stride, const uint8_
     if (tev) (void)hipEventRecord(tev[1], s);
     const int mfma_qb = knn_mfma_qb(row_stride);
     if (mfma_qb > 0) {
-        const ReversePlan rp = reverse_plan(w, B, row_stride, nseg);
+        const ReversePlan rp = reverse_plan(w, B, row_stride);
         if (tev) (void)hipEventRecord(tev[2], s);
         hipLaunchKernelGGL(forward_plan_kernel, dim3(B), dim3(PLAN_BLOCK), (size_t)row_stride * 7, s, B, nseg, row_stride, w.knn12,
                            n1, n2, nnr, w.cand, claim, rp.blocked, w.qsel, rp.tsel, w.nsel);
-        launch_reverse_scans(s, B, row_stride, d1, n1, d2, w, rp, mfma_qb);
+        launch_reverse_scans(s, B, row_stride, d1, n1, d2, nnr, w, rp);
         if (tev) (void)hipEventRecord(tev[3], s);
         if (wait_before_m12_write) (void)hipStreamWaitEvent(s, wait_before_m12_write, 0);
-        hipLaunchKernelGGL(nnr_reverse_final_kernel, grid2, dim3(256), 0, s, rp.nseg, row_stride, w.cand, claim, rp.blocked, w.knn21,
-                           rp.tsel, w.nsel, n1, nnr, m12);
+        hipLaunchKernelGGL(nnr_reverse_check_kernel, grid2, dim3(256), 0, s, row_stride, w.cand, claim, rp.blocked, n1, m12);
         return;
     }
     hipLaunchKernelGGL(nnr_forward_kernel, grid2, dim3(256), 0, s, nseg, row_stride, w.knn12, n1, n2, nnr, w.cand, claim);

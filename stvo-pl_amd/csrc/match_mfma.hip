@@ -353,40 +353,45 @@ __global__ __launch_bounds__(MF_BLOCK, (QB == 1 ? 4 : QB == 2 ? 3 : 1)) void ham
 }
 
 // ---- the reverse check of the claimed columns (match_kernels.hip: forward_plan_kernel) in ONE launch -------------------------------
-// A frame pair's work items:
-//   light item (lt, seg)   light columns [lt REV_ROWS, (lt + 1) REV_ROWS) of the frame's list against segment seg of the rows of S (tsel);
-//   heavy item (ht, seg)   heavy columns (back of the list) against segment seg of ALL prev rows.
-// An item of the old form — the general scan above with its one global fetch per barrier — ran at the latency of that fetch: a
-// handful of tiles per item, nothing else on the CU in the same phase (round 5, 512 clustered frames: 97 heavy columns per frame took
-// 113 us as one 2000-row item per frame, the 1340 light ones 48 us against |S| = 178 rows).  Here the train side of an item is
-// RESIDENT: at most REV_CHUNK = 256 rows, requested in one go (eight words per thread in flight behind their list entries), expanded
-// into LDS once, one barrier, then the waves run their tiles without meeting again.  The query rows are requested in the same breath,
-// so an item costs two dependent round trips (list entry -> row) and a few hundred cycles per tile.  Train ranges beyond 256 rows are
-// cut into segments (at most REV_MAX_SEG; a segment longer than a chunk takes several chunks, one after the other).
-// `slots` workgroups per frame pair walk the items slot, slot + slots, ...: a frame whose plan left nothing to scan (i.i.d. rows: S is
-// empty) costs `slots` workgroups that read four counters and leave.
-// Results: knn21 [seg][B][row_stride] for the listed columns; nnr_reverse_final_kernel merges rev_segments(.) segments.
-constexpr int REV_QB = 1, REV_ROWS = 4 * REV_QB * 32;  // query rows per item: 4 waves x 32
+// Two lists per frame pair: the LIGHT columns, to be compared with the rows of S (tsel), and the HEAVY columns (back of the list), to
+// be compared with ALL prev rows.  A list's train side is cut into rev_segments(rows) segments of at most ~256 rows; a UNIT of work is
+// (list, segment): its train rows are made RESIDENT — requested in one go (eight words per thread in flight behind their list entries),
+// expanded into LDS once, ONE barrier — and then every wave runs ITS column blocks (32 columns each) against the resident tiles without
+// meeting the others again: the next block's rows are requested (list entries two blocks ahead, rows one block ahead) while the
+// current block is multiplied.  The general scan above, used for this in rounds 3 - 4 (one launch per list), pays one global fetch per
+// barrier and per two tiles and ran at the latency of that fetch (round 5, 512 clustered frames: 97 heavy columns per frame took
+// 113 us as one 2000-row scan per frame, the 1340 light ones 48 us against |S| = 178 rows; 0.186 ms for the whole check).
+// `slots` workgroups per frame pair share the units: column group g (4 blocks, one per wave) of segment seg belongs to slot
+// (g + seg) mod slots — the groups of a long light list spread over the slots, and so do the segments of a short heavy list.  A frame
+// whose plan left nothing to scan (i.i.d. rows: S is empty) costs `slots` workgroups that read four counters and leave.
+// A segment longer than a chunk (more than 2048 train rows) takes several chunks, one after the other.
+// Result: blocked[column] = 1 for every listed column whose claim some other row blocks (each train range decides for itself: the
+// question is a union over ranges); nnr_reverse_check_kernel then keeps the unblocked claims — no top-2 array leaves the kernel.
 constexpr int REV_CHUNK_TILES = 8, REV_CHUNK = REV_CHUNK_TILES * MF_TILE;
 
 __global__ __launch_bounds__(MF_BLOCK, 4) void hamming_knn2_mfma_reverse_kernel(int B, int slots, int row_stride, const uint8_t* __restrict__ d1,
                                                                                 const int32_t* __restrict__ n1, const uint8_t* __restrict__ d2,
-                                                                                uint2* __restrict__ knn21, const int32_t* __restrict__ qsel,
-                                                                                const int32_t* __restrict__ nsel, const int32_t* __restrict__ tsel) {
+                                                                                const int32_t* __restrict__ qsel, const int32_t* __restrict__ nsel,
+                                                                                const int32_t* __restrict__ tsel, const uint32_t* __restrict__ claim,
+                                                                                float nnr, int32_t* __restrict__ blocked) {
     constexpr int KSTEPS = 4;
     using key_t = float;
     using acc_t = v16f;
     __shared__ v4i s_tile[REV_CHUNK_TILES][KSTEPS * 2 * 32];  // 32 KB: every tile of the chunk
+    __shared__ uint16_t s_thr[256];                           // block_threshold(d0): the largest distance that still blocks a claim at d0
     const int L = blockIdx.x;
     const int xcd = L & 7, k = L >> 3;
     const int b = (k / slots) * 8 + xcd, slot = k % slots;
     if (b >= B) return;
     const int na = n1[b];
     const int nl = nsel[(size_t)B + b], nh = nsel[2 * (size_t)B + b], ns = nsel[3 * (size_t)B + b];
-    const int lseg = rev_segments(ns), hseg = rev_segments(na);
-    const int lt = ns > 0 ? (nl + REV_ROWS - 1) / REV_ROWS : 0;  // (an empty S: nothing can block a light column any more)
-    const int n_light = lt * lseg, n_items = n_light + ((nh + REV_ROWS - 1) / REV_ROWS) * hseg;
-    if (slot >= n_items) return;
+    if ((ns == 0 || nl == 0) && nh == 0) return;  // (an empty S: nothing can block a light column any more)
+    {   // match_kernels.hip: block_threshold — the largest d' for which float(d0) < float(d') * nnr is false
+        const float f0 = (float)threadIdx.x;
+        uint32_t thr = threadIdx.x;
+        while (thr < 256u && !(f0 < (float)(thr + 1u) * nnr)) ++thr;
+        s_thr[threadIdx.x] = (uint16_t)thr;
+    }   // (read after the first barrier below)
     const size_t frame_off = (size_t)b * row_stride;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, col = lane & 31, hf = lane >> 5;
     const int xr = tid & 31, xk = tid >> 5;  // staging role: word xk of train row xr of a tile
@@ -399,177 +404,173 @@ __global__ __launch_bounds__(MF_BLOCK, 4) void hamming_knn2_mfma_reverse_kernel(
         const v8i a8 = {tf.x, tf.y, tf.z, tf.w, 0, 0, 0, 0}, b8 = {q.x, q.y, q.z, q.w, 0, 0, 0, 0};
         return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, c, 4, 4, 0, MF_SCALE_2_4, 0, MF_SCALE_2_4);
     };
-    struct Item {
-        bool light;
-        int seg, nq, j0, nt, q_base;
-    };
-    auto item_of = [&](int item) -> Item {  // (workgroup-uniform scalars)
-        Item m;
-        m.light = item < n_light;
-        const int nseg = m.light ? lseg : hseg, it = m.light ? item : item - n_light;
-        m.seg = it % nseg;
-        m.q_base = (it / nseg) * REV_ROWS;
-        m.nq = m.light ? nl : nh;
-        const int nt_all = m.light ? ns : na;
-        const int seg_len = (((nt_all + nseg - 1) / nseg) + MF_TILE - 1) & ~(MF_TILE - 1);
-        m.j0 = min(m.seg * seg_len, nt_all);
-        m.nt = min(m.j0 + seg_len, nt_all);
-        return m;
-    };
-    // The requests of a unit of work (an item's chunk): eight train words per thread behind their list entries and — for the item's first
-    // chunk — the query row behind its list entry.  They are issued one unit AHEAD: while the waves multiply the resident chunk, the next
-    // unit's two dependent round trips are under way (an item is ~4 k cycles of tiles against ~6 k of round trips).
-    uint32_t w[REV_CHUNK_TILES];
-    int qi = 0;
-    uint4 qw0 = make_uint4(0u, 0u, 0u, 0u), qw1 = qw0;
-    auto request_train = [&](const Item& m, int c0) {
-#pragma unroll
-        for (int t = 0; t < REV_CHUNK_TILES; ++t) {
-            const int j = c0 + t * MF_TILE + xr;
-            uint32_t v = 0u;
-            if (j < m.nt) v = T[(size_t)(m.light ? tsel[frame_off + j] : j) * 8 + xk];
-            w[t] = v;
-        }
-    };
-    auto request_query = [&](const Item& m) {
-        const int q = m.q_base + wv * 32 + col;
-        const int qc = q < m.nq ? q : m.nq - 1;  // tail lanes scan a valid row and discard the result
-        qi = qsel[frame_off + (m.light ? qc : row_stride - 1 - qc)];
-        qw0 = reinterpret_cast<const uint4*>(Q)[2 * qi];
-        qw1 = reinterpret_cast<const uint4*>(Q)[2 * qi + 1];
-    };
 
-    int item = slot;
-    Item m = item_of(item);
-    int c0 = m.j0;
-    bool first = true;
-    request_train(m, c0);
-    request_query(m);
-    v4i qf[KSTEPS];
-    key_t best = MF_NO_KEY_F, second = MF_NO_KEY_F;
-    int out_row = 0, last_base = 0;
-    auto fold = [&](key_t key) {
-        second = med3_f32(best, second, key);
-        best = min_f32(best, key);
-    };
-    for (;;) {
-        if (first) {  // the item's query rows: expanded once, kept for all its chunks
-            const bool up = hf != 0;
-            qf[0] = expand_fp4(~(up ? qw0.y : qw0.x));
-            qf[1] = expand_fp4(~(up ? qw0.w : qw0.z));
-            qf[2] = expand_fp4(~(up ? qw1.y : qw1.x));
-            qf[3] = expand_fp4(~(up ? qw1.w : qw1.z));
-            best = second = MF_NO_KEY_F;
-            out_row = qi;
-            last_base = m.j0;
-        }
-        const int ntc = min((m.nt - c0 + MF_TILE - 1) / MF_TILE, REV_CHUNK_TILES);  // (0 for an empty segment)
+    for (int list = 0; list < 2; ++list) {
+        const bool light = list == 0;
+        const int nq = light ? (ns > 0 ? nl : 0) : nh, nt_all = light ? ns : na;
+        if (nq == 0) continue;
+        const int nseg = rev_segments(nt_all);
+        const int n_groups = (nq + 127) / 128;  // 4 blocks of 32 columns, one per wave
+        const int seg_len = (((nt_all + nseg - 1) / nseg) + MF_TILE - 1) & ~(MF_TILE - 1);
+        auto column_of = [&](int g) -> int {  // this lane's column (a position in the list) of group g; tail lanes take a valid one
+            const int q = (g * 4 + wv) * 32 + col;
+            return q < nq ? q : nq - 1;
+        };
+        auto list_entry = [&](int g) -> int { return qsel[frame_off + (light ? column_of(g) : row_stride - 1 - column_of(g))]; };
+        for (int seg = 0; seg < nseg; ++seg) {
+            // this workgroup's groups of the unit: g = g_first, g_first + slots, ...
+            const int g_first = ((slot - seg) % slots + slots) % slots;
+            if (g_first >= n_groups) continue;  // (workgroup-uniform)
+            const int j0 = min(seg * seg_len, nt_all), nt = min(j0 + seg_len, nt_all);
+            for (int c0 = j0; c0 < nt || c0 == j0; c0 += REV_CHUNK) {  // (an empty segment still writes "no key" for its columns)
+                // ---- the chunk's train rows -> LDS
+                uint32_t w[REV_CHUNK_TILES];
 #pragma unroll
-        for (int t = 0; t < REV_CHUNK_TILES; ++t)
-            if (t < ntc) s_tile[t][xk * 32 + xr] = expand_fp4(w[t]);
-        __syncthreads();
-        // the next unit: the item's next chunk, or the first chunk of this workgroup's next item
-        const bool more_chunks = c0 + REV_CHUNK < m.nt;
-        const int n_item = more_chunks ? item : item + slots;
-        const bool has_next = more_chunks || n_item < n_items;
-        const Item nm = (!more_chunks && has_next) ? item_of(n_item) : m;
-        const int n_c0 = more_chunks ? c0 + REV_CHUNK : nm.j0;
-        if (has_next) {
-            request_train(nm, n_c0);
-            if (!more_chunks) request_query(nm);
-        }
-        const bool wave_active = m.q_base + wv * 32 < m.nq;
-        if (wave_active && ntc > 0) {
-            // software pipeline, depth one tile (as the general scan): tile t's matrix instructions are issued, tile t - 1's keys are
-            // folded in their shadow — three keys at a time (5 operations per 3 keys); the chunk's last tile is folded after the loop
-            auto fold3 = [&](const acc_t& p, int f) {
-                const key_t k0 = p[f], k1 = p[f + 1], k2 = p[f + 2];
-                const key_t lo = min3_f32(k0, k1, k2), mid = med3_f32(k0, k1, k2);
-                second = min3_f32(max_f32(best, lo), second, mid);
-                best = min_f32(best, lo);
-            };
-            auto do_tile = [&](acc_t& cur, acc_t& prev, int t) {
-                const v4i* frag = s_tile[t];
-                const bool fold_prev = t > 0;
-                if (fold_prev) {
-                    best -= (key_t)MF_TILE;
-                    second -= (key_t)MF_TILE;
+                for (int t = 0; t < REV_CHUNK_TILES; ++t) {
+                    const int j = c0 + t * MF_TILE + xr;
+                    uint32_t v = 0u;
+                    if (j < nt) v = T[(size_t)(light ? tsel[frame_off + j] : j) * 8 + xk];
+                    w[t] = v;
                 }
-                v4i tf = frag[lane];
+                // (the first two groups' list entries travel with them)
+                int e_cur = list_entry(g_first);
+                int e_next = g_first + slots < n_groups ? list_entry(g_first + slots) : 0;
+                const int ntc = min((nt - c0 + MF_TILE - 1) / MF_TILE, REV_CHUNK_TILES);
 #pragma unroll
-                for (int kk = 0; kk < KSTEPS; ++kk) {
-                    v4i tf_ahead = tf;
-                    if (kk < KSTEPS - 1) tf_ahead = frag[(kk + 1) * 64 + lane];
-                    cur = mma(tf, qf[kk], kk == 0 ? cidx : cur);
-                    if (fold_prev) {
-                        if (kk == 0) {
-                            // The folds read tile t - 1's accumulators through inline asm (v_min3 / v_med3 without canonicalisation),
-                            // which the compiler's hazard recogniser does not cover: nothing stops it from scheduling them right behind
-                            // the matrix instruction that writes them, and the hardware does not interlock that read (round 5: one
-                            // wrong top-2 in the adversarial test with a single instruction between the two).  The wait states of a
-                            // 16-pass XDL write -> VALU read (19), tied to the registers, in the shadow of this tile's first instruction.
-                            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 2" : "+v"(prev));
-                            fold3(prev, 0);
-                            fold3(prev, 3);
-                        } else if (kk == 1) {
-                            fold3(prev, 6);
-                            fold(prev[15]);
-                        } else if (kk == 2) {
-                            fold3(prev, 9);
-                        } else {
-                            fold3(prev, 12);
+                for (int t = 0; t < REV_CHUNK_TILES; ++t)
+                    if (t < ntc) s_tile[t][xk * 32 + xr] = expand_fp4(w[t]);
+                uint4 qw0 = reinterpret_cast<const uint4*>(Q)[2 * e_cur], qw1 = reinterpret_cast<const uint4*>(Q)[2 * e_cur + 1];
+                uint32_t cw = claim[frame_off + e_cur];  // (d0 << 16) | claimant of the lane's column
+                __syncthreads();
+                // ---- every wave: its blocks against the resident tiles
+                for (int g = g_first; g < n_groups; g += slots) {
+                    const bool up = hf != 0;
+                    v4i qf[KSTEPS];
+                    qf[0] = expand_fp4(~(up ? qw0.y : qw0.x));
+                    qf[1] = expand_fp4(~(up ? qw0.w : qw0.z));
+                    qf[2] = expand_fp4(~(up ? qw1.y : qw1.x));
+                    qf[3] = expand_fp4(~(up ? qw1.w : qw1.z));
+                    const int out_col = e_cur;
+                    const uint32_t c_claim = cw;
+                    const bool block_active = (g * 4 + wv) * 32 < nq;
+                    // requests one block ahead (rows) and two ahead (list entry): under way while this block is multiplied
+                    if (g + slots < n_groups) {
+                        qw0 = reinterpret_cast<const uint4*>(Q)[2 * e_next];
+                        qw1 = reinterpret_cast<const uint4*>(Q)[2 * e_next + 1];
+                        cw = claim[frame_off + e_next];
+                        e_cur = e_next;
+                        if (g + 2 * slots < n_groups) e_next = list_entry(g + 2 * slots);
+                    }
+                    if (!block_active) continue;
+                    key_t best = MF_NO_KEY_F, second = MF_NO_KEY_F;
+                    auto fold = [&](key_t key) {
+                        second = med3_f32(best, second, key);
+                        best = min_f32(best, key);
+                    };
+                    int last_base = c0;
+                    if (ntc > 0) {
+                        // software pipeline, depth one tile (as the general scan): tile t's matrix instructions are issued, tile t - 1's
+                        // keys are folded in their shadow — three keys at a time; the chunk's last tile is folded after the loop
+                        auto fold3 = [&](const acc_t& p, int f) {
+                            const key_t k0 = p[f], k1 = p[f + 1], k2 = p[f + 2];
+                            const key_t lo = min3_f32(k0, k1, k2), mid = med3_f32(k0, k1, k2);
+                            second = min3_f32(max_f32(best, lo), second, mid);
+                            best = min_f32(best, lo);
+                        };
+                        auto do_tile = [&](acc_t& cur, acc_t& prev, int t) {
+                            const v4i* frag = s_tile[t];
+                            const bool fold_prev = t > 0;
+                            if (fold_prev) {
+                                best -= (key_t)MF_TILE;
+                                second -= (key_t)MF_TILE;
+                            }
+                            v4i tf = frag[lane];
+#pragma unroll
+                            for (int kk = 0; kk < KSTEPS; ++kk) {
+                                v4i tf_ahead = tf;
+                                if (kk < KSTEPS - 1) tf_ahead = frag[(kk + 1) * 64 + lane];
+                                cur = mma(tf, qf[kk], kk == 0 ? cidx : cur);
+                                if (fold_prev) {
+                                    if (kk == 0) {
+                                        // The folds read tile t - 1's accumulators through inline asm (v_min3 / v_med3 without
+                                        // canonicalisation), which the compiler's hazard recogniser does not cover: nothing stops it from
+                                        // scheduling them right behind the matrix instruction that writes them, and the hardware does not
+                                        // interlock that read (round 5: one wrong top-2 in the adversarial test with a single instruction
+                                        // between the two).  The wait states of a 16-pass XDL write -> VALU read (19), tied to the
+                                        // registers, in the shadow of this tile's first matrix instruction.
+                                        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 2" : "+v"(prev));
+                                        fold3(prev, 0);
+                                        fold3(prev, 3);
+                                    } else if (kk == 1) {
+                                        fold3(prev, 6);
+                                        fold(prev[15]);
+                                    } else if (kk == 2) {
+                                        fold3(prev, 9);
+                                    } else {
+                                        fold3(prev, 12);
+                                    }
+                                }
+                                if (kk < KSTEPS - 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+                                tf = tf_ahead;
+                            }
+                        };
+                        acc_t accA, accB;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) accA[r] = accB[r] = 0;
+                        int t = 0;
+                        for (; t + 2 <= ntc; t += 2) {
+                            do_tile(accA, accB, t);
+                            do_tile(accB, accA, t + 1);
+                        }
+                        if (t < ntc) do_tile(accA, accB, t);
+                        acc_t& last = (ntc & 1) ? accA : accB;
+                        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 2" : "+v"(last));  // (as above: read by asm folds)
+                        best -= (key_t)MF_TILE;
+                        second -= (key_t)MF_TILE;
+                        last_base = c0 + (ntc - 1) * MF_TILE;  // first train row of the tile the keys are relative to
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int jr = last_base + (r & 3) + 8 * (r >> 2) + 4 * hf;
+                            fold(jr < nt ? last[r] : MF_NO_KEY_F);
                         }
                     }
-                    if (kk < KSTEPS - 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
-                    tf = tf_ahead;
+                    // the two wave halves hold the same columns over different train rows: merge, lower half writes
+                    const int bi = best >= MF_NO_KEY_MIN_F ? MF_NO_KEY : (int)best;
+                    const int si = second >= MF_NO_KEY_MIN_F ? MF_NO_KEY : (int)second;
+                    const int ob = __shfl_xor(bi, 32), os = __shfl_xor(si, 32);
+                    const int hi = max(bi, ob);
+                    const int sec = min(min(si, os), hi);
+                    const int bst = min(bi, ob);
+                    // The verdict of this train range: the claim (row i*, distance d0) on the column is BLOCKED iff some other row lies within
+                    // T = block_threshold(d0) — a union over segments and chunks, so every range decides for itself from its own top-2
+                    // (the nearest row if it is not the claimant, else the second) and blocked columns are flagged; writers only store 1.
+                    if (hf == 0 && (g * 4 + wv) * 32 + col < nq) {
+                        const uint32_t x = key_to_knn(bst, last_base), y = key_to_knn(sec, last_base);
+                        if (x != 0xFFFFFFFFu) {
+                            const uint32_t T = s_thr[c_claim >> 16], istar = c_claim & 0xFFFFu;
+                            bool blk = false;
+                            if ((x >> 16) <= T) {  // (else nothing of the range is within T)
+                                const uint32_t pos = x & 0xFFFFu;
+                                const uint32_t row = light ? (uint32_t)tsel[frame_off + pos] : pos;
+                                blk = row != istar || (y != 0xFFFFFFFFu && (y >> 16) <= T);
+                            }
+                            if (blk) blocked[frame_off + out_col] = 1;
+                        }
+                    }
                 }
-            };
-            acc_t accA, accB;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) accA[r] = accB[r] = 0;
-            int t = 0;
-            for (; t + 2 <= ntc; t += 2) {
-                do_tile(accA, accB, t);
-                do_tile(accB, accA, t + 1);
-            }
-            if (t < ntc) do_tile(accA, accB, t);
-            acc_t& last = (ntc & 1) ? accA : accB;
-            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 2" : "+v"(last));  // (as above: the last tile's accumulators are read by asm folds)
-            best -= (key_t)MF_TILE;
-            second -= (key_t)MF_TILE;
-            last_base = c0 + (ntc - 1) * MF_TILE;  // first train row of the tile the keys are relative to
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int jr = last_base + (r & 3) + 8 * (r >> 2) + 4 * hf;
-                fold(jr < m.nt ? last[r] : MF_NO_KEY_F);
+                __syncthreads();  // the tile buffers are staged again (next chunk, next unit)
             }
         }
-        __syncthreads();  // the tile buffers are staged again by the next unit
-        if (!more_chunks && wave_active) {  // the item is complete: the two wave halves hold the same columns over different train rows
-            const int bi = best >= MF_NO_KEY_MIN_F ? MF_NO_KEY : (int)best;
-            const int si = second >= MF_NO_KEY_MIN_F ? MF_NO_KEY : (int)second;
-            const int ob = __shfl_xor(bi, 32), os = __shfl_xor(si, 32);
-            const int hi = max(bi, ob);
-            const int sec = min(min(si, os), hi);
-            const int bst = min(bi, ob);
-            if (hf == 0 && m.q_base + wv * 32 + col < m.nq)
-                knn21[(size_t)m.seg * B * row_stride + frame_off + out_row] = make_uint2(key_to_knn(bst, last_base), key_to_knn(sec, last_base));
-        }
-        if (!has_next) break;
-        first = !more_chunks;
-        item = n_item;
-        m = nm;
-        c0 = n_c0;
     }
 }
 
-void launch_hamming_knn2_mfma_reverse(hipStream_t s, int B, int row_stride, const uint8_t* d1, const int32_t* n1, const uint8_t* d2, uint2* knn21,
-                                      const int32_t* qsel, const int32_t* nsel, const int32_t* tsel, int slots) {
+void launch_hamming_knn2_mfma_reverse(hipStream_t s, int B, int row_stride, const uint8_t* d1, const int32_t* n1, const uint8_t* d2, const int32_t* qsel,
+                                      const int32_t* nsel, const int32_t* tsel, const uint32_t* claim, float nnr, int32_t* blocked, int slots) {
     if (B <= 0 || row_stride <= 0) return;
     const dim3 grid((unsigned)(((B + 7) / 8) * 8 * slots));
-    hipLaunchKernelGGL(hamming_knn2_mfma_reverse_kernel, grid, dim3(MF_BLOCK), 0, s, B, slots, row_stride, d1, n1, d2, knn21, qsel, nsel, tsel);
+    hipLaunchKernelGGL(hamming_knn2_mfma_reverse_kernel, grid, dim3(MF_BLOCK), 0, s, B, slots, row_stride, d1, n1, d2, qsel, nsel, tsel, claim, nnr, blocked);
 }
 
 int mfma_rows_per_block(int qb) { return 4 * qb * 32; }

@@ -1230,7 +1230,7 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl) {
     const bool track = fl.track;
     if (track) {
         // ---- f2fTracking: prev stereo sets vs curr stereo sets
-        const stvo::LazyScratch w{ctx->knn12, ctx->knn21, ctx->cand, ctx->need, ctx->qsel, ctx->nsel, ctx->knn_capacity, ctx->knn21_capacity};
+        const stvo::LazyScratch w{ctx->knn12, ctx->knn21, ctx->cand, ctx->need, ctx->qsel, ctx->nsel, ctx->knn_capacity};
         const int esm = stvo::dbg().match_small;  // developer: 0 = the general machinery for the key-line sets too
         const int lines_cap = std::max(s->set_lines_cap[0], s->set_lines_cap[1]);
         // one workgroup per frame pair (match_small_kernel) up to 128 key-lines per image; beyond that its row-by-row scan is the

@@ -104,14 +104,10 @@ int stvo_ctx_create(int device_id, int max_rows, int max_batch, stvo_ctx** out) 
     const size_t knn_seg_elems =
         (size_t)max_rows * (size_t)(2 * max_batch > stvo::KNN_MAX_NSEG ? 2 * max_batch : stvo::KNN_MAX_NSEG);
     ctx->knn_capacity = knn_seg_elems;
-    // knn21: the reverse check of the claimed columns scans a heavy column in 8 train segments ([8][B][rows]) and keeps its two
-    // per-column lists behind them (match_kernels.hip: reverse_plan) — 9 x max_batch x max_rows entries (151 MB for 1024 x 2048)
-    const size_t knn21_elems = std::max(knn_seg_elems, (size_t)max_rows * (size_t)max_batch * 9);
-    ctx->knn21_capacity = knn21_elems;
     // arena: descriptors + records + per-row scratch of one host-buffer call, with slack
     ctx->arena_size = (size_t)max_rows * 1024 + ((size_t)4 << 20);
     ok = ok && hip_ok(ctx, hipMalloc((void**)&ctx->knn12, knn_seg_elems * sizeof(uint2)), "hipMalloc knn12") &&
-         hip_ok(ctx, hipMalloc((void**)&ctx->knn21, knn21_elems * sizeof(uint2)), "hipMalloc knn21") &&
+         hip_ok(ctx, hipMalloc((void**)&ctx->knn21, knn_seg_elems * sizeof(uint2)), "hipMalloc knn21") &&
          hip_ok(ctx, hipMalloc((void**)&ctx->cand, knn_elems * sizeof(int32_t)), "hipMalloc cand") &&
          hip_ok(ctx, hipMalloc((void**)&ctx->need, knn_elems * sizeof(int32_t)), "hipMalloc need") &&
          hip_ok(ctx, hipMalloc((void**)&ctx->qsel, knn_elems * sizeof(int32_t)), "hipMalloc qsel") &&
@@ -210,7 +206,7 @@ int stvo_match_nnr_mutual(stvo_ctx* ctx, const uint8_t* d1, int n1, const uint8_
     TRY(flush_uploads(ctx));
     TRY(upload(ctx, &dm12, (const int32_t*)nullptr, (size_t)stride));
     if (mutual) {
-        const stvo::LazyScratch w{ctx->knn12, ctx->knn21, ctx->cand, ctx->need, ctx->qsel, ctx->nsel, ctx->knn_capacity, ctx->knn21_capacity};
+        const stvo::LazyScratch w{ctx->knn12, ctx->knn21, ctx->cand, ctx->need, ctx->qsel, ctx->nsel, ctx->knn_capacity};
         stvo::launch_match_mutual_lazy(ctx->stream, 1, stride, dd1, dn1, dd2, dn2, nnr, w, dm12, 0, nullptr);
     } else {
         const int nseg = stvo::knn_pick_nseg(1, stride, ctx->knn_capacity);
@@ -241,7 +237,7 @@ int stvo_match_nnr_mutual_batched_dev(stvo_ctx* ctx, int B, int row_stride, cons
         return STVO_ERR_CAPACITY;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (mutual) {
-        const stvo::LazyScratch w{ctx->knn12, ctx->knn21, ctx->cand, ctx->need, ctx->qsel, ctx->nsel, ctx->knn_capacity, ctx->knn21_capacity};
+        const stvo::LazyScratch w{ctx->knn12, ctx->knn21, ctx->cand, ctx->need, ctx->qsel, ctx->nsel, ctx->knn_capacity};
         stvo::launch_match_mutual_lazy(ctx->stream, B, row_stride, d1, n1, d2, n2, nnr, w, m12, 0, nullptr);
     } else {
         const int nseg = stvo::knn_pick_nseg(B, row_stride, ctx->knn_capacity);
@@ -430,7 +426,7 @@ int stvo_track_batched_dev(stvo_ctx* ctx, const stvo_track_batch_dev* b, const s
     // kernel); K2 rewrites m12, which the previous pose kernel may still be reading => K2 waits for it.
     const int pad = ctx->overlap ? kOverlapLdsPad : 0;
     hipEvent_t prev_pose = (ctx->overlap && ctx->pose_pending) ? ctx->ev_pose_done : nullptr;
-    const stvo::LazyScratch w{ctx->knn12, ctx->knn21, ctx->cand, ctx->need, ctx->qsel, ctx->nsel, ctx->knn_capacity, ctx->knn21_capacity};
+    const stvo::LazyScratch w{ctx->knn12, ctx->knn21, ctx->cand, ctx->need, ctx->qsel, ctx->nsel, ctx->knn_capacity};
     auto match_set = [&](int stride, const uint8_t* da, const int32_t* na, const uint8_t* db, const int32_t* nb,
                          float nnr, int32_t* m12) {
         if (mutual) {
@@ -503,7 +499,7 @@ int stvo_time_stage_dev(stvo_ctx* ctx, const stvo_track_batch_dev* b, const stvo
     stvo::PoseArgs a{};
     fill_pose_args(b, cam, params, false, &a);
     HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
-    const stvo::LazyScratch lw{ctx->knn12, ctx->knn21, ctx->cand, ctx->need, ctx->qsel, ctx->nsel, ctx->knn_capacity, ctx->knn21_capacity};
+    const stvo::LazyScratch lw{ctx->knn12, ctx->knn21, ctx->cand, ctx->need, ctx->qsel, ctx->nsel, ctx->knn_capacity};
     for (int it = 0; it < iters; ++it) {
         const int pad = ctx->overlap ? kOverlapLdsPad : 0;
         const int nseg = stvo::knn_pick_nseg(b->B, b->max_pts, ctx->knn_capacity);
