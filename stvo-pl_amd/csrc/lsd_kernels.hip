@@ -557,9 +557,11 @@ __global__ __launch_bounds__(64) void lsd_grow_kernel(LsdDev d) {
 //   wave 0 commits in seed order.  A seed with a finished PENDING region takes it if every pixel of it is still free (flag stores,
 //   lane-parallel; the segment was computed by the wave that grew it), a seed another wave is growing right now is waited for
 //   (bounded), any other seed — and any pending region that lost a pixel — is grown by wave 0 itself, flags set as it goes.
-//   waves 1 .. LSD_NW - 1 speculate: the first seed after the committer's position (LSD_LOOK ranks) that is free, not pending, not in
-//   flight and >= LSD_SEP px (Chebyshev) from every seed in flight is grown against the flags committed so far; the wave marks ITS
-//   pixels in a stamp array of its own and leaves the flags alone.
+//   waves 1 .. LSD_NW - 1 speculate: the first seed after the committer's position (LSD_LOOK ranks) that is free, not pending, not
+//   claimed and >= LSD_SEP px (Chebyshev) from every seed in flight is CLAIMED — one compare-and-swap on its table entry, no lock
+//   (round 5: with a workgroup lock held for a memory round trip per pick the fifteen speculators produced a region per ~5 k cycles
+//   and the committer spent half its time waiting at seeds just picked) — and grown against the flags committed so far; the wave
+//   marks ITS pixels in a stamp array of its own and leaves the flags alone.
 // Exactness: flags only turn on.  A region grown against an older state of the flags made the sequential decisions at every pixel it
 // examined unless it ACCEPTED a pixel that was taken before its turn — then the validation at its turn fails and the seed is grown again.
 // Output order = commit order = seed order.
@@ -568,6 +570,7 @@ constexpr int LSD_WRING = 256;       // per wave: the most recent region points 
 constexpr int LSD_SEP = 24;
 constexpr int LSD_LOOK = 2048;
 constexpr int LSD_REC_CAP = 32768;   // regions a speculating wave can hold (it stops speculating when full)
+constexpr int LSD_CLAIM = (int)0x80000000;  // table entry of a seed a speculating wave is growing: LSD_CLAIM | wave
 constexpr int LSD_WAVES_MAX_B = 8;   // the scratch below is ~130 B per pixel and wave-pair: small batches only
 
 struct LsdRec {
@@ -804,7 +807,7 @@ __device__ __forceinline__ float4 region_segment_w(const LsdDev& d, const int32_
 __global__ __launch_bounds__(LSD_NW * 64) void lsd_grow_waves_kernel(LsdDev d, LsdWaves x) {
     __shared__ int s_ring[LSD_NW][LSD_WRING];
     __shared__ double s_term[LSD_NW][3][64];
-    __shared__ int s_scan, s_done, s_lock, s_if_rank[LSD_NW], s_if_seed[LSD_NW];
+    __shared__ int s_scan, s_done, s_if_seed[LSD_NW];
     const int b = blockIdx.x, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int w = d.w, h = d.h, npx = w * h;
     const size_t base = (size_t)b * npx;
@@ -818,16 +821,18 @@ __global__ __launch_bounds__(LSD_NW * 64) void lsd_grow_waves_kernel(LsdDev d, L
     if (threadIdx.x == 0) {
         s_scan = -1;
         s_done = 0;
-        s_lock = 0;
     }
-    if (threadIdx.x < LSD_NW) {
-        s_if_rank[threadIdx.x] = -1;
-        s_if_seed[threadIdx.x] = -1;
-    }
+    if (threadIdx.x < LSD_NW) s_if_seed[threadIdx.x] = -1;
     __syncthreads();
     if (wv == 0) {
         // ---------------- the committer ----------------
+        __builtin_amdgcn_s_setprio(3);  // the one wave everything waits for: ahead of the three speculators of its SIMD
         int n_seg = 0;
+        const bool prof = d.dbg != nullptr && b == 0;  // tools/lsd_probe.py: where the committer's time goes
+        auto tick = [&]() -> long long { return prof ? (long long)__builtin_readcyclecounter() : 0ll; };
+        const long long t_begin = tick();
+        long long t_self = 0, t_wait = 0, t_take = 0;
+        int n_took = 0, n_self = 0, n_bad = 0, n_waited = 0;
         for (int o0 = 0; o0 < npx; o0 += 64) {
             const uint32_t key = o0 + lane < npx ? order[o0 + lane] : LSD_NOKEY;
             if ((uint32_t)__builtin_amdgcn_readfirstlane((int)key) == LSD_NOKEY) break;
@@ -845,16 +850,15 @@ __global__ __launch_bounds__(LSD_NW * 64) void lsd_grow_waves_kernel(LsdDev d, L
                 }
                 auto table = [&]() { return __builtin_amdgcn_readfirstlane(ld_coherent(pend + rank)); };  // (one address: a scalar result)
                 int p = table();
-                if (!p) {
-                    bool in_flight = false;
-                    for (int v = 1; v < LSD_NW; ++v) in_flight = in_flight || lds_ld(&s_if_rank[v]) == rank;
-                    in_flight = __builtin_amdgcn_readfirstlane((int)in_flight) != 0;
-                    if (in_flight)  // another wave is growing this very seed: its work is the work this wave would do (bounded wait)
-                        for (int spin = 0; spin < (1 << 20) && !(p = table()); ++spin) __builtin_amdgcn_s_sleep(8);
-                    else
-                        p = table();  // (published between the two looks)
+                if (p < 0) {  // a speculating wave holds the claim on this very seed: its work is the work this wave would do (bounded wait)
+                    const long long tw = tick();
+                    for (int spin = 0; spin < (1 << 20) && (p = table()) < 0; ++spin) __builtin_amdgcn_s_sleep(4);
+                    if (p < 0) p = 0;  // (gave up: this wave grows the seed itself, whatever the other one publishes later is never read)
+                    t_wait += tick() - tw;
+                    ++n_waited;
                 }
                 bool took = false;
+                const long long tk = tick();
                 if (p) {
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                     const int pw = (p - 1) >> 20, ri = (p - 1) & ((1 << 20) - 1);
@@ -883,6 +887,11 @@ __global__ __launch_bounds__(LSD_NW * 64) void lsd_grow_waves_kernel(LsdDev d, L
                         }
                     }
                 }
+                const long long ts = tick();
+                t_take += ts - tk;
+                if (took) ++n_took;
+                else if (p) ++n_bad;
+                else ++n_self;
                 if (!took) {
                     double reg_angle;
                     const int n = grow_region_w<true>(ang, csn, used, nullptr, 0, wlist, npx, s_ring[0], seed, readlane_f32(ang_l, j), w, h, d.prec,
@@ -892,6 +901,7 @@ __global__ __launch_bounds__(LSD_NW * 64) void lsd_grow_waves_kernel(LsdDev d, L
                         if (lane == 0 && n_seg < d.seg_cap) d.seg[(size_t)b * d.seg_cap + n_seg] = sg;
                         ++n_seg;
                     }
+                    t_self += tick() - ts;
                 }
                 wave_publish();
                 todo &= __ballot(key_ok && ld_coherent(used + (key_ok ? q_l : 0)) == 0);  // seeds of the batch taken meanwhile
@@ -900,6 +910,12 @@ __global__ __launch_bounds__(LSD_NW * 64) void lsd_grow_waves_kernel(LsdDev d, L
         if (lane == 0) {
             d.n_seg[b] = n_seg;
             lds_st(&s_done, 1);
+        }
+        if (prof && lane == 0) {  // the last 16 doubles of image 0's block (row seg_cap - 1: marker -1 = this kernel)
+            double* q = d.dbg + ((size_t)d.seg_cap - 2) * 8;
+            q[0] = (double)(tick() - t_begin); q[1] = (double)t_self; q[2] = (double)t_wait; q[3] = (double)t_take;
+            q[4] = (double)n_took; q[5] = (double)n_self; q[6] = (double)n_bad; q[7] = (double)n_waited;
+            q[8] = -1.0;
         }
     } else {
         // ---------------- a speculating wave ----------------
@@ -944,27 +960,30 @@ __global__ __launch_bounds__(LSD_NW * 64) void lsd_grow_waves_kernel(LsdDev d, L
                 ++idle;
                 continue;
             }
+            // the claim: one compare-and-swap on the seed's table entry (0 -> "in flight, wave wv") — no lock, every wave claims on its
+            // own; the committer that finds the claim waits for the record, the one that came first grows the seed itself
             int got = 0;
-            if (lane == 0) got = atomicCAS(&s_lock, 0, 1) == 0;
+            if (lane == 0) got = atomicCAS(pend + pick_r, 0, LSD_CLAIM | wv) == 0;
             got = __builtin_amdgcn_readfirstlane(got);
             if (!got) {
-                __builtin_amdgcn_s_sleep(2);
                 ++idle;
                 continue;
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            const bool still = __builtin_amdgcn_readfirstlane(  // (every lane computed the same: make it a scalar for the branches below)
-                (int)(pick_r > lds_ld(&s_scan) && ld_coherent(used + pick_q) == 0 && ld_coherent(pend + pick_r) == 0 && separated(pick_q))) != 0;
-            if (still && lane == 0) {
-                lds_st(&s_if_rank[wv], pick_r);
-                lds_st(&s_if_seed[wv], pick_q);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the in-flight entry before the lock opens
-            if (lane == 0) lds_st(&s_lock, 0);
-            if (!still) {
+            const bool still = __builtin_amdgcn_readfirstlane((int)(pick_r > lds_ld(&s_scan) && ld_coherent(used + pick_q) == 0)) != 0;
+            if (!still) {  // the committer reached the seed, or a committed region took it meanwhile: an empty record releases the claim
+                if (lane == 0) {
+                    LsdRec R;
+                    R.off = off; R.n = 0; R.x1 = R.y1 = R.x2 = R.y2 = 0.f;
+                    rec[nrec] = R;
+                }
+                wave_publish();
+                if (lane == 0) st_coherent(pend + pick_r, ((wv << 20) | nrec) + 1);
+                ++nrec;
+                if (nrec >= LSD_REC_CAP) break;
                 ++idle;
                 continue;
             }
+            if (lane == 0) lds_st(&s_if_seed[wv], pick_q);  // (advisory: keeps the other waves' picks LSD_SEP away from this growth)
             ++id;
             double reg_angle = 0.0;
             const int n = grow_region_w<false>(ang, csn, used, stamp, id, wlist + off, npx - off, s_ring[wv], pick_q, ang[pick_q], w, h, d.prec,
@@ -978,19 +997,12 @@ __global__ __launch_bounds__(LSD_NW * 64) void lsd_grow_waves_kernel(LsdDev d, L
             }
             wave_publish();  // the list and the record before the table entry
             if (lane == 0) st_coherent(pend + pick_r, ((wv << 20) | nrec) + 1);
-            wave_publish();  // the table entry before the seed leaves the in-flight set
-            if (lane == 0) {
-                lds_st(&s_if_rank[wv], -1);
-                lds_st(&s_if_seed[wv], -1);
-            }
+            if (lane == 0) lds_st(&s_if_seed[wv], -1);
             if (n > 0) off += n;
             ++nrec;
             if (nrec >= LSD_REC_CAP || npx - off < 4096) break;  // out of room: this wave stops speculating
         }
-        if (lane == 0) {  // (whatever ended the loop: nothing of this wave is in flight any more)
-            lds_st(&s_if_rank[wv], -1);
-            lds_st(&s_if_seed[wv], -1);
-        }
+        if (lane == 0) lds_st(&s_if_seed[wv], -1);  // (whatever ended the loop: nothing of this wave is in flight any more)
     }
 }
 
@@ -1130,7 +1142,15 @@ int lsd_enqueue(stvo_lsd* o, const uint8_t* images, stvo_keyline* lines, float* 
     // the radix sort is stable and the keys come in index order: sorting by the bin bits alone leaves every bin in row-major order
     // (STVO_LSD_SORT_FULL=1: all 32 bits, the index bits included — the same order, more digit passes)
     const int begin_bit = stvo::dbg().lsd_sort_full == 1 ? 0 : stvo::LSD_IDX_BITS;
-    HIP_TRY(ctx, hipcub::DeviceSegmentedRadixSort::SortKeys(o->sort_tmp, tb, d.keys, d.order, d.B * d.w * d.h, d.B, o->seg_off, o->seg_off + 1, begin_bit, 32, s));
+    if (o->wdev) {  // small batches: the device-wide sort per image (the segmented sort gives a segment ONE workgroup: 3.5 ms for a KITTI-size
+                    // image) — over ALL key bits: the keys are distinct, so the order does not lean on the stability of the sort (over the
+                    // bin bits alone this sort returned another order than the segmented one, round 5)
+        const int npx = d.w * d.h;
+        for (int b = 0; b < d.B; ++b)
+            HIP_TRY(ctx, hipcub::DeviceRadixSort::SortKeys(o->sort_tmp, tb, d.keys + (size_t)b * npx, d.order + (size_t)b * npx, npx, 0, 32, s));
+    } else {
+        HIP_TRY(ctx, hipcub::DeviceSegmentedRadixSort::SortKeys(o->sort_tmp, tb, d.keys, d.order, d.B * d.w * d.h, d.B, o->seg_off, o->seg_off + 1, begin_bit, 32, s));
+    }
     if (o->wdev) {  // small batches: one workgroup of LSD_NW waves per image (lsd_grow_waves_kernel)
         HIP_TRY(ctx, hipMemsetAsync(o->xw.stamp, 0, o->stamp_bytes, s));
         HIP_TRY(ctx, hipMemsetAsync(o->xw.pend, 0, o->pend_bytes, s));
@@ -1226,10 +1246,12 @@ int stvo_lsd_create(stvo_ctx* ctx, int B, int cols, int rows, int max_keylines, 
         ok = nb * npx < (1ull << 31) && hip_ok(ctx, hipMemcpy(o->seg_off, off.data(), off.size() * 4, hipMemcpyHostToDevice), "hipMemcpy lsd offsets");
     }
     if (ok) {
-        size_t tb = 0;
+        size_t tb = 0, tb1 = 0;
         ok = hip_ok(ctx, hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, tb, (const uint32_t*)d.keys, d.order, (int)(nb * npx), B, o->seg_off,
                                                                     o->seg_off + 1, 0, 32, ctx->stream), "segmented sort (size)") &&
-             hip_ok(ctx, hipMalloc(&o->sort_tmp, tb > 0 ? tb : 16), "hipMalloc lsd sort");
+             hip_ok(ctx, hipcub::DeviceRadixSort::SortKeys(nullptr, tb1, (const uint32_t*)d.keys, d.order, (int)npx, 0, 32, ctx->stream), "device sort (size)");
+        if (tb1 > tb) tb = tb1;  // (the per-image device-wide sort of the small batches)
+        ok = ok && hip_ok(ctx, hipMalloc(&o->sort_tmp, tb > 0 ? tb : 16), "hipMalloc lsd sort");
         o->sort_tmp_bytes = tb;
     }
     if (ok && (size_t)d.seg_cap * 8 > 48 * 1024)

@@ -36,6 +36,10 @@ for b in range(min(B, 2)):
         o.lib.orc_lsd_set_debug(None)
         q = gd[8190]
         q2 = gd[8191]
+        if q2[0] == -1.0:
+            print(f"   16-waves kernel, committer cycles: total {q[0]:.0f}  growing itself {q[1]:.0f}  waiting for an in-flight seed {q[2]:.0f}  validating + taking pending {q[3]:.0f} | "
+                  f"regions taken {q[4]:.0f}  grown by the committer {q[5]:.0f}  failed validation {q[6]:.0f}  waited for {q[7]:.0f}")
+            continue
         print(f"   rounds: publish {q2[0]:.0f}  list read + address + issue {q2[1]:.0f}  wait for the loads {q2[2]:.0f}  | seed set-up {q2[3]:.0f}")
         print(f"   image 0, cycles: total {q[0]:.0f}  grow {q[1]:.0f} (of which resolving {q[2]:.0f})  rect {q[3]:.0f} | rounds {q[4]:.0f}  pixels added {q[5]:.0f}  regions {q[6]:.0f}  batches {q[7]:.0f}")
 t0 = time.perf_counter()
