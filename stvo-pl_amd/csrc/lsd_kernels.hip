@@ -568,20 +568,32 @@ __global__ __launch_bounds__(64) void lsd_grow_kernel(LsdDev d) {
 constexpr int LSD_NW = 16;
 constexpr int LSD_WRING = 256;       // per wave: the most recent region points in LDS
 constexpr int LSD_SEP = 24;
-constexpr int LSD_LOOK = 2048;
+constexpr int LSD_LOOK = 2048;       // ranks a speculating wave examines per pick, from the front
+constexpr int LSD_AHEAD = 16384;     // the front's lead over the committer (ranks; ~200 seeds of a KITTI-size scene)
 constexpr int LSD_REC_CAP = 32768;   // regions a speculating wave can hold (it stops speculating when full)
-constexpr int LSD_CLAIM = (int)0x80000000;  // table entry of a seed a speculating wave is growing: LSD_CLAIM | wave
+// Table entry of a seed: 0 = nobody's; LSD_CLAIM | wave = a speculating wave is growing it; else a finished region — everything the
+// committer needs to find it in ONE load: list offset (21 bits), size (21), record (16), wave (4), bit 62 set.
+constexpr long long LSD_CLAIM = (long long)0x8000000000000000ull;
+__device__ __forceinline__ long long lsd_entry(int wave, int record, int n, int off) {
+    return (1ll << 62) | ((long long)wave << 58) | ((long long)record << 42) | ((long long)n << 21) | (long long)off;
+}
+__device__ __forceinline__ long long ld_coherent64(const long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void st_coherent64(long long* p, long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ long long readfirstlane64(long long v) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)v);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)v >> 32));
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
 constexpr int LSD_WAVES_MAX_B = 8;   // the scratch below is ~130 B per pixel and wave-pair: small batches only
 
 struct LsdRec {
-    int off, n;   // pixel list at wlist[wave] + off; n = 0: the growth was abandoned (out of room)
-    float x1, y1, x2, y2;
+    float x1, y1, x2, y2;  // the segment of a finished region of >= min_reg_size pixels
 };
 struct LsdWaves {
     int32_t* stamp;  // [B][LSD_NW][w h] region id of the wave that holds the pixel in its CURRENT region (zeroed per call)
     int32_t* wlist;  // [B][LSD_NW][w h] pixel lists, region after region
     LsdRec* rec;     // [B][LSD_NW][LSD_REC_CAP]
-    int32_t* pend;   // [B][w h] by RANK in the pseudo-ordering: 0 or ((wave << 20) | record) + 1 (zeroed per call)
+    long long* pend; // [B][w h] by RANK in the pseudo-ordering: 0 free, a claim (sign bit | wave) or a finished region (lsd_entry), zeroed per call
 };
 
 __device__ __forceinline__ int lds_ld(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -807,7 +819,7 @@ __device__ __forceinline__ float4 region_segment_w(const LsdDev& d, const int32_
 __global__ __launch_bounds__(LSD_NW * 64) void lsd_grow_waves_kernel(LsdDev d, LsdWaves x) {
     __shared__ int s_ring[LSD_NW][LSD_WRING];
     __shared__ double s_term[LSD_NW][3][64];
-    __shared__ int s_scan, s_done, s_if_seed[LSD_NW];
+    __shared__ int s_scan, s_done, s_front, s_if_seed[LSD_NW];
     const int b = blockIdx.x, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int w = d.w, h = d.h, npx = w * h;
     const size_t base = (size_t)b * npx;
@@ -816,11 +828,12 @@ __global__ __launch_bounds__(LSD_NW * 64) void lsd_grow_waves_kernel(LsdDev d, L
     const double* __restrict__ mod = d.mod + base;
     int32_t* used = d.used + base;
     const uint32_t* __restrict__ order = d.order + base;
-    int32_t* pend = x.pend + base;
+    long long* pend = x.pend + base;
     int32_t* wlist = x.wlist + ((size_t)b * LSD_NW + wv) * npx;
     if (threadIdx.x == 0) {
         s_scan = -1;
         s_done = 0;
+        s_front = 0;
     }
     if (threadIdx.x < LSD_NW) s_if_seed[threadIdx.x] = -1;
     __syncthreads();
@@ -840,6 +853,8 @@ __global__ __launch_bounds__(LSD_NW * 64) void lsd_grow_waves_kernel(LsdDev d, L
             const bool key_ok = key != LSD_NOKEY;
             const float ang_l = key_ok ? ang[q_l] : -1.f;
             unsigned long long todo = __ballot(key_ok && ld_coherent(used + (key_ok ? q_l : 0)) == 0);
+            int ahead_j = -1;
+            long long ahead_p = 0;
             while (todo) {
                 const int j = __builtin_ctzll(todo);
                 todo &= todo - 1ull;
@@ -848,8 +863,9 @@ __global__ __launch_bounds__(LSD_NW * 64) void lsd_grow_waves_kernel(LsdDev d, L
                     lds_st(&s_scan, rank);
                     lds_st(&s_if_seed[0], seed);
                 }
-                auto table = [&]() { return __builtin_amdgcn_readfirstlane(ld_coherent(pend + rank)); };  // (one address: a scalar result)
-                int p = table();
+                auto table = [&]() { return readfirstlane64(ld_coherent64(pend + rank)); };  // (one address: a scalar result)
+                // the entry read ahead at the end of the previous seed is final if it shows a finished region (those never change)
+                long long p = (j == ahead_j && (ahead_p & (1ll << 62))) ? ahead_p : table();
                 if (p < 0) {  // a speculating wave holds the claim on this very seed: its work is the work this wave would do (bounded wait)
                     const long long tw = tick();
                     for (int spin = 0; spin < (1 << 20) && (p = table()) < 0; ++spin) __builtin_amdgcn_s_sleep(4);
@@ -861,11 +877,13 @@ __global__ __launch_bounds__(LSD_NW * 64) void lsd_grow_waves_kernel(LsdDev d, L
                 const long long tk = tick();
                 if (p) {
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                    const int pw = (p - 1) >> 20, ri = (p - 1) & ((1 << 20) - 1);
-                    const LsdRec* rc = x.rec + ((size_t)b * LSD_NW + pw) * LSD_REC_CAP + ri;
-                    const int n = __builtin_amdgcn_readfirstlane(ld_coherent(&rc->n)), off = __builtin_amdgcn_readfirstlane(ld_coherent(&rc->off));
+                    const int off = (int)(p & 0x1FFFFF), n = (int)((p >> 21) & 0x1FFFFF), ri = (int)((p >> 42) & 0xFFFF), pw = (int)((p >> 58) & 0xF);
                     if (n > 0) {
                         const int32_t* pl = x.wlist + ((size_t)b * LSD_NW + pw) * npx + off;
+                        // the segment travels with the first pixels (vector loads: another wave wrote the record during this launch)
+                        const LsdRec* rc = x.rec + ((size_t)b * LSD_NW + pw) * LSD_REC_CAP + ri;
+                        float sgv = 0.f;
+                        if (n >= d.min_reg_size && lane < 4) sgv = __int_as_float(ld_coherent(reinterpret_cast<const int32_t*>(rc) + lane));
                         bool bad = false;
                         for (int t = lane; t < n; t += 64) {
                             const int pxy = ld_coherent(pl + t);
@@ -878,10 +896,8 @@ __global__ __launch_bounds__(LSD_NW * 64) void lsd_grow_waves_kernel(LsdDev d, L
                             }
                             took = true;
                             if (n >= d.min_reg_size) {
-                                if (lane == 0 && n_seg < d.seg_cap) {  // (vector loads: another wave wrote the record during this launch)
-                                    auto fld = [](const float* f) { return __int_as_float(ld_coherent(reinterpret_cast<const int32_t*>(f))); };
-                                    d.seg[(size_t)b * d.seg_cap + n_seg] = make_float4(fld(&rc->x1), fld(&rc->y1), fld(&rc->x2), fld(&rc->y2));
-                                }
+                                const float4 sg = make_float4(readlane_f32(sgv, 0), readlane_f32(sgv, 1), readlane_f32(sgv, 2), readlane_f32(sgv, 3));
+                                if (lane == 0 && n_seg < d.seg_cap) d.seg[(size_t)b * d.seg_cap + n_seg] = sg;
                                 ++n_seg;
                             }
                         }
@@ -904,7 +920,14 @@ __global__ __launch_bounds__(LSD_NW * 64) void lsd_grow_waves_kernel(LsdDev d, L
                     t_self += tick() - ts;
                 }
                 wave_publish();
-                todo &= __ballot(key_ok && ld_coherent(used + (key_ok ? q_l : 0)) == 0);  // seeds of the batch taken meanwhile
+                // seeds of the batch taken meanwhile — and, in the same round trip, the table entry of the seed that comes next if it is
+                // still free (a finished region found there is final; anything else is read again at the seed's turn)
+                ahead_j = todo ? __builtin_ctzll(todo) : -1;
+                const bool free_l = key_ok && ld_coherent(used + (key_ok ? q_l : 0)) == 0;
+                long long pa = 0;
+                if (ahead_j >= 0) pa = ld_coherent64(pend + o0 + ahead_j);
+                todo &= __ballot(free_l);
+                ahead_p = readfirstlane64(pa);
             }
         }
         if (lane == 0) {
@@ -939,22 +962,36 @@ __global__ __launch_bounds__(LSD_NW * 64) void lsd_grow_waves_kernel(LsdDev d, L
                 }
                 return far;
             };
+            // The scan starts at the FRONT: every rank below it is used, pending or claimed — for good (flags and table entries only turn
+            // on), so no wave looks at those ranks again; the waves push the front together (LDS, atomic max).  Without it the window
+            // began at the committer's position, and 2048 ranks are ~26 seeds: with 15 regions in flight and the finished ones waiting
+            // for their turn the window held nothing to pick and the speculators slept (round 5).  The front may run at most
+            // LSD_AHEAD ranks ahead of the committer: regions grown further ahead see flags that are too stale to survive validation.
             const int scan = lds_ld(&s_scan);
-            int pick_r = -1, pick_q = 0;
-            for (int c = 0; c < LSD_LOOK && pick_r < 0; c += 64) {
-                const int r = scan + 1 + c + lane;
-                const uint32_t key = r < npx ? order[r] : LSD_NOKEY;
-                if ((uint32_t)__builtin_amdgcn_readfirstlane((int)key) == LSD_NOKEY) break;
-                const bool ok = key != LSD_NOKEY;
-                const int q = (int)(key & ((1u << LSD_IDX_BITS) - 1u));
-                const bool fr = ok && ld_coherent(used + (ok ? q : 0)) == 0 && ld_coherent(pend + (ok ? r : 0)) == 0 && separated(q);
-                const unsigned long long m = __ballot(fr);
-                if (m) {
-                    const int L = __builtin_ctzll(m);
-                    pick_r = __builtin_amdgcn_readlane(r, L);
-                    pick_q = __builtin_amdgcn_readlane(q, L);
+            const int front0 = lds_ld(&s_front);
+            const int start = front0 > scan + 1 ? front0 : scan + 1;
+            int pick_r = -1, pick_q = 0, solid = start;  // [start, solid): nothing free, whatever the separation says
+            bool contiguous = true;
+            if (start - scan <= LSD_AHEAD)
+                for (int c = 0; c < LSD_LOOK && pick_r < 0; c += 64) {
+                    const int r = start + c + lane;
+                    const uint32_t key = r < npx ? order[r] : LSD_NOKEY;
+                    if ((uint32_t)__builtin_amdgcn_readfirstlane((int)key) == LSD_NOKEY) break;
+                    const bool ok = key != LSD_NOKEY;
+                    const int q = (int)(key & ((1u << LSD_IDX_BITS) - 1u));
+                    const bool open = ok && ld_coherent(used + (ok ? q : 0)) == 0 && ld_coherent64(pend + (ok ? r : 0)) == 0;
+                    const unsigned long long m_open = __ballot(open), m = __ballot(open && separated(q));
+                    if (contiguous) {  // the ranks of this chunk in front of its first open one join the solid part
+                        solid = start + c + (m_open ? __builtin_ctzll(m_open) : 64);
+                        contiguous = m_open == 0ull;
+                    }
+                    if (m) {
+                        const int L = __builtin_ctzll(m);
+                        pick_r = __builtin_amdgcn_readlane(r, L);
+                        pick_q = __builtin_amdgcn_readlane(q, L);
+                    }
                 }
-            }
+            if (solid > front0 && lane == 0) atomicMax(&s_front, solid);
             if (pick_r < 0) {
                 __builtin_amdgcn_s_sleep(32);
                 ++idle;
@@ -963,7 +1000,7 @@ __global__ __launch_bounds__(LSD_NW * 64) void lsd_grow_waves_kernel(LsdDev d, L
             // the claim: one compare-and-swap on the seed's table entry (0 -> "in flight, wave wv") — no lock, every wave claims on its
             // own; the committer that finds the claim waits for the record, the one that came first grows the seed itself
             int got = 0;
-            if (lane == 0) got = atomicCAS(pend + pick_r, 0, LSD_CLAIM | wv) == 0;
+            if (lane == 0) got = atomicCAS(reinterpret_cast<unsigned long long*>(pend + pick_r), 0ull, (unsigned long long)(LSD_CLAIM | wv)) == 0ull;
             got = __builtin_amdgcn_readfirstlane(got);
             if (!got) {
                 ++idle;
@@ -971,15 +1008,7 @@ __global__ __launch_bounds__(LSD_NW * 64) void lsd_grow_waves_kernel(LsdDev d, L
             }
             const bool still = __builtin_amdgcn_readfirstlane((int)(pick_r > lds_ld(&s_scan) && ld_coherent(used + pick_q) == 0)) != 0;
             if (!still) {  // the committer reached the seed, or a committed region took it meanwhile: an empty record releases the claim
-                if (lane == 0) {
-                    LsdRec R;
-                    R.off = off; R.n = 0; R.x1 = R.y1 = R.x2 = R.y2 = 0.f;
-                    rec[nrec] = R;
-                }
-                wave_publish();
-                if (lane == 0) st_coherent(pend + pick_r, ((wv << 20) | nrec) + 1);
-                ++nrec;
-                if (nrec >= LSD_REC_CAP) break;
+                if (lane == 0) st_coherent64(pend + pick_r, lsd_entry(wv, 0, 0, 0));  // (size 0: the committer grows the seed itself)
                 ++idle;
                 continue;
             }
@@ -992,11 +1021,11 @@ __global__ __launch_bounds__(LSD_NW * 64) void lsd_grow_waves_kernel(LsdDev d, L
             if (n >= d.min_reg_size) sg = region_segment_w(d, wlist + off, n, mod, reg_angle, s_term[wv]);
             if (lane == 0) {
                 LsdRec R;
-                R.off = off; R.n = n > 0 ? n : 0; R.x1 = sg.x; R.y1 = sg.y; R.x2 = sg.z; R.y2 = sg.w;
+                R.x1 = sg.x; R.y1 = sg.y; R.x2 = sg.z; R.y2 = sg.w;
                 rec[nrec] = R;
             }
             wave_publish();  // the list and the record before the table entry
-            if (lane == 0) st_coherent(pend + pick_r, ((wv << 20) | nrec) + 1);
+            if (lane == 0) st_coherent64(pend + pick_r, lsd_entry(wv, nrec, n > 0 ? n : 0, off));
             if (lane == 0) lds_st(&s_if_seed[wv], -1);
             if (n > 0) off += n;
             ++nrec;
@@ -1259,13 +1288,13 @@ int stvo_lsd_create(stvo_ctx* ctx, int B, int cols, int rows, int max_keylines, 
     if (ok && stvo::dbg().lsd_waves != 0 && B <= stvo::LSD_WAVES_MAX_B) {  // STVO_LSD_WAVES=0: one wave per image for small batches too
         decltype(c) cw;
         const size_t w_stamp = cw.take(nb * stvo::LSD_NW * npx * 4), w_list = cw.take(nb * stvo::LSD_NW * npx * 4),
-                     w_rec = cw.take(nb * stvo::LSD_NW * stvo::LSD_REC_CAP * sizeof(stvo::LsdRec)), w_pend = cw.take(nb * npx * 4);
+                     w_rec = cw.take(nb * stvo::LSD_NW * stvo::LSD_REC_CAP * sizeof(stvo::LsdRec)), w_pend = cw.take(nb * npx * 8);
         ok = hip_ok(ctx, hipMalloc((void**)&o->wdev, cw.off), "hipMalloc lsd waves");
         if (ok) {
             o->xw.stamp = (int32_t*)(o->wdev + w_stamp); o->xw.wlist = (int32_t*)(o->wdev + w_list);
-            o->xw.rec = (stvo::LsdRec*)(o->wdev + w_rec); o->xw.pend = (int32_t*)(o->wdev + w_pend);
+            o->xw.rec = (stvo::LsdRec*)(o->wdev + w_rec); o->xw.pend = (long long*)(o->wdev + w_pend);
             o->stamp_bytes = nb * stvo::LSD_NW * npx * 4;
-            o->pend_bytes = nb * npx * 4;
+            o->pend_bytes = nb * npx * 8;
         }
     }
     if (!ok) {
