@@ -43,35 +43,53 @@ I8_MFMA_PEAK_TOPS = 5000.0
 I8_MFMA_MEASURED_FLOOR_TOPS = 4404.0
 FP4_MFMA_PEAK_TOPS = 10000.0
 K1M_OPS_PER_PAIR = 2 * 256
-PREV_PROFILE_TAG = "r03"
-PROFILE_TAG = "r04"          # committed rocprofv3 PMC passes the `traffic` figures are read from
+PREV_PROFILE_TAG = "r04"
+PROFILE_TAG = "r05"          # committed rocprofv3 PMC passes the `traffic` figures are read from
 FP64_PEAK_TFLOPS = 78.6      # MI355X_MICROARCH.md: vector FP64 (the matrix FP64 rate is the same on gfx950)
 TOL_RAD, TOL_M = 1e-4, 1e-3  # BASELINE.json north_star: pose within 1e-4 rad / 1e-3 m of the reference CPU path per frame
 
 
+def counter_calibration(path):
+    """(FETCH_SIZE factor, WRITE_SIZE factor) a committed counter file states in its line '# calibration: FETCH_SIZE x <f> WRITE_SIZE x <w>'
+    (measured by tools/hbm_calib on known byte counts: on gfx950 FETCH_SIZE tallies its 128-byte requests at 64 bytes).  (1, 1) if absent."""
+    try:
+        for line in open(path):
+            if line.startswith("# calibration:"):
+                f = line.replace(",", " ").split()
+                return float(f[f.index("FETCH_SIZE") + 2]), float(f[f.index("WRITE_SIZE") + 2])
+    except (OSError, ValueError, IndexError):
+        pass
+    return 1.0, 1.0
+
+
 def committed_traffic(kernel, col=1):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, separate
-    `--pmc` runs summarised by tools/rocprof_summary.py; values there are KB per dispatch: n, avg, min, max).  `col`: 1 = the
-    average over the launches, 3 = the largest launch (a kernel that also runs on the small key-line problems).  The newest
-    committed pass that lists the kernel is used (this round's, else the previous round's).  None if unavailable."""
+    `--pmc` runs summarised by tools/rocprof_summary.py; values there are KB per dispatch: n, avg, min, max), each counter times the
+    calibration factor its file states.  `col`: 1 = the average over the launches, 3 = the largest launch (a kernel that also runs on
+    the small key-line problems).  The newest committed pass that lists the kernel is used (this round's, else the previous
+    round's).  None if unavailable."""
     for tag in (PROFILE_TAG, PREV_PROFILE_TAG):
         path = os.path.join(ROOT, "profiles", f"{tag}_hbm_counters.txt")
         try:
+            cal_f, cal_w = counter_calibration(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_hbm_counters.txt"))  # (a property of the counters)
             tot = {}
             for line in open(path):
                 f = line.split()
                 if len(f) >= 6 and f[4] in ("FETCH_SIZE", "WRITE_SIZE") and kernel in line and f[4] not in tot:
                     tot[f[4]] = float(f[col]) * 1024.0
             if len(tot) == 2:
-                return tot["FETCH_SIZE"] + tot["WRITE_SIZE"]
+                return tot["FETCH_SIZE"] * cal_f + tot["WRITE_SIZE"] * cal_w
         except (OSError, ValueError, KeyError):
             pass
     return None
 
 
-TRAFFIC_SRC = (f"bytes per launch = FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes over this command, read from the "
-               f"committed profiles/{PROFILE_TAG}_hbm_counters.txt (profiles/{PREV_PROFILE_TAG}_hbm_counters.txt for kernels that file "
-               f"does not list; not re-measured by this run); null when neither lists the kernel")
+_CAL = counter_calibration(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_hbm_counters.txt"))
+TRAFFIC_SRC = (f"bytes per launch = {_CAL[0]:g} x FETCH_SIZE + {_CAL[1]:g} x WRITE_SIZE of separate rocprofv3 --pmc passes over this command, read "
+               f"from the committed profiles/{PROFILE_TAG}_hbm_counters.txt (profiles/{PREV_PROFILE_TAG}_hbm_counters.txt for kernels that file "
+               f"does not list; not re-measured by this run); the factors are the calibration that file states (tools/hbm_calib: 2 GiB streamed "
+               f"with 4- and 16-byte loads / stores and a 16-of-64-byte gather — FETCH_SIZE reports half the bytes read, WRITE_SIZE the bytes "
+               f"written); null when neither file lists the kernel")
 
 
 def free_port():
@@ -878,6 +896,13 @@ def main():
                     "algorithmic_ops_per_launch": ops, "algorithmic_bytes_per_launch": k1_bytes, "avg_launch_ms": k1_ms,
                     "timing": timing, "frac_of_measured_mfma_floor": k1_tops / 9099.0,  # register-only FP4 floor of the guide
                     "hbm_view_frac": k1_bytes / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if k1_ms > 0 else 0.0,
+                    # SURVEY.md section 8(d)'s own units for match_bf: unique (query, train) distances per second, and the integer-VALU
+                    # work the reference formulation would need for them (8 x (v_xor + v_bcnt) = 16 lane-ops per pair) against the
+                    # 39.3 T lane-ops/s VALU roof the survey prices the path on — above 1 because the distances come from the matrix
+                    # cores (the bit-exact parity tests are the evidence that they are all computed)
+                    "pairs_per_s": pairs_l / (k1_ms * 1e-3) if k1_ms > 0 else 0.0,
+                    "valu_roof_equivalent": {"lane_ops_per_pair": 16, "peak_lane_ops_per_s": 3.93e13,
+                                             "frac": 16.0 * pairs_l / (k1_ms * 1e-3) / 3.93e13 if k1_ms > 0 else 0.0},
                     "note": "dominant kernel: all-pairs Hamming distances of the f2f point match as a Gram matrix of +-4 FP4 elements on the "
                             "matrix cores (v_mfma_scale_f32_32x32x64_f8f6f4), top-2 fold in the shadow of the matrix instructions; ~56 k "
                             "bit-operations per compulsory byte, so HBM is idle by construction (hbm_view_frac)"}
