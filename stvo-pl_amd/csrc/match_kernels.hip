@@ -410,21 +410,21 @@ __global__ __launch_bounds__(KNN_BLOCK) void hamming_verify_kernel(int B, int ti
 
 // m12[i] = cand[i] iff i holds the claim on that column and the verification found no blocking row.
 // Fewer than two prev rows => no match (the reference's knnMatch(k = 2) row would have one entry; :54 is UB).
-__global__ __launch_bounds__(256) void nnr_reverse_check_kernel(int row_stride, const int32_t* __restrict__ cand,
-                                                                const uint32_t* __restrict__ claim,
-                                                                const int32_t* __restrict__ blocked,
-                                                                const int32_t* __restrict__ n1,
-                                                                int32_t* __restrict__ m12) {
-    const int b = blockIdx.y;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= row_stride) return;
+// Column by column: the claimant i of column j has cand[i] = j (that is how it came to claim it), a row claims at most one column, and
+// every other row ends without a match — so the pass reads claim[] and blocked[] in order and scatters the survivors, instead of two
+// dependent gathers per row (round 5: 18.7 -> us per 1024 frames, 99 -> MB of calibrated fetch).  One workgroup per frame pair.
+__global__ __launch_bounds__(1024) void nnr_reverse_check_kernel(int row_stride, const uint32_t* __restrict__ claim,
+                                                                 const int32_t* __restrict__ blocked, const int32_t* __restrict__ n1,
+                                                                 int32_t* __restrict__ m12) {
+    const int b = blockIdx.x;
     const size_t off = (size_t)b * row_stride;
-    int m = cand[off + i];
-    if (m >= 0) {
-        const bool keep = n1[b] >= 2 && (claim[off + m] & 0xFFFFu) == (uint32_t)i && blocked[off + m] == 0;
-        if (!keep) m = -1;
+    for (int i = threadIdx.x; i < row_stride; i += 1024) m12[off + i] = -1;
+    __syncthreads();  // (the survivors below overwrite entries other threads just cleared)
+    if (n1[b] < 2) return;
+    for (int j = threadIdx.x; j < row_stride; j += 1024) {
+        const uint32_t c = claim[off + j];
+        if (c != 0xFFFFFFFFu && blocked[off + j] == 0) m12[off + (c & 0xFFFFu)] = j;
     }
-    m12[off + i] = m;
 }
 
 // ---- reverse check on the matrix cores: which (column, row) pairs still have to be looked at ------------------
@@ -639,7 +639,7 @@ void launch_match_mutual_lazy(hipStream_t s, int B, int row_stride, const uint8_
         launch_reverse_scans(s, B, row_stride, d1, n1, d2, nnr, w, rp);
         if (tev) (void)hipEventRecord(tev[3], s);
         if (wait_before_m12_write) (void)hipStreamWaitEvent(s, wait_before_m12_write, 0);
-        hipLaunchKernelGGL(nnr_reverse_check_kernel, grid2, dim3(256), 0, s, row_stride, w.cand, claim, rp.blocked, n1, m12);
+        hipLaunchKernelGGL(nnr_reverse_check_kernel, dim3(B), dim3(1024), 0, s, row_stride, claim, rp.blocked, n1, m12);
         return;
     }
     hipLaunchKernelGGL(nnr_forward_kernel, grid2, dim3(256), 0, s, nseg, row_stride, w.knn12, n1, n2, nnr, w.cand, claim);
@@ -648,7 +648,7 @@ void launch_match_mutual_lazy(hipStream_t s, int B, int row_stride, const uint8_
     launch_hamming_verify(s, B, row_stride, d1, n1, d2, nnr, w, lds_pad_bytes, nseg);
     if (tev) (void)hipEventRecord(tev[3], s);
     if (wait_before_m12_write) (void)hipStreamWaitEvent(s, wait_before_m12_write, 0);
-    hipLaunchKernelGGL(nnr_reverse_check_kernel, grid2, dim3(256), 0, s, row_stride, w.cand, claim, blocked, n1, m12);
+    hipLaunchKernelGGL(nnr_reverse_check_kernel, dim3(B), dim3(1024), 0, s, row_stride, claim, blocked, n1, m12);
 }
 
 // Integer-VALU roof probe: the same instruction mix as K1's inner loop (xor, bcnt-accumulate,
