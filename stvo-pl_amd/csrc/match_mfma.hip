@@ -300,12 +300,21 @@ __global__ __launch_bounds__(MF_BLOCK, (QB == 1 ? 4 : QB == 2 ? 3 : 1)) void ham
     // met at a barrier every ~400 cycles: two tiles per barrier 0.402 -> 0.364 ms per 1024 frames.
     static_assert(MF_TPB % 2 == 0, "the accumulator sets alternate tile by tile");
     int t = 0;
+    // the train words travel TWO barrier groups ahead of their tiles (registers only: the LDS buffers are staged as before; round 5:
+    // 0.3256 -> 0.3227 ms per 1024 frames — the fetch was not what the kernel waits for, nor is the LDS read of a K step: with the
+    // reads truly one step ahead (lgkmcnt(1) instead of (0) in front of every matrix instruction pair) the time did not move)
+    uint32_t w_near[MF_TPB];
+#pragma unroll
+    for (int i = 0; i < MF_TPB; ++i) {
+        w_near[i] = 0;
+        if (MF_TPB + i < ntiles) w_near[i] = fetch(MF_TPB + i);
+    }
     for (; t + MF_TPB <= ntiles; t += MF_TPB) {
-        uint32_t w_next[MF_TPB];
+        uint32_t w_far[MF_TPB];
 #pragma unroll
         for (int i = 0; i < MF_TPB; ++i) {
-            w_next[i] = 0;
-            if (t + MF_TPB + i < ntiles) w_next[i] = fetch(t + MF_TPB + i);
+            w_far[i] = 0;
+            if (t + 2 * MF_TPB + i < ntiles) w_far[i] = fetch(t + 2 * MF_TPB + i);
         }
 #pragma unroll
         for (int i = 0; i < MF_TPB; ++i) {
@@ -313,8 +322,10 @@ __global__ __launch_bounds__(MF_BLOCK, (QB == 1 ? 4 : QB == 2 ? 3 : 1)) void ham
             else mma_fold(accB, accA, t + i);
         }
 #pragma unroll
-        for (int i = 0; i < MF_TPB; ++i)
-            if (t + MF_TPB + i < ntiles) stage(t + MF_TPB + i, w_next[i]);
+        for (int i = 0; i < MF_TPB; ++i) {
+            if (t + MF_TPB + i < ntiles) stage(t + MF_TPB + i, w_near[i]);
+            w_near[i] = w_far[i];
+        }
         __syncthreads();
     }
 #pragma unroll
