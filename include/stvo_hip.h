@@ -306,8 +306,12 @@ int stvo_lsd_create(stvo_ctx* ctx, int B, int cols, int rows, int max_keylines, 
 int stvo_lsd_destroy(stvo_lsd* lsd);
 /* Host buffers in / out, synchronises.  images [B][rows][cols]; lines [B][max_keylines] (what stvo_lbd_compute consumes: in-octave
  * end points, angle, LineIterator count), response (may be NULL) [B][max_keylines] = KeyLine::response, n_lines [B]; lines come
- * in detection order, or by descending response when the top-N cut applied. */
+ * in detection order, or by descending response when the top-N cut applied — also when max_keylines is what cuts (nfeatures 0 or
+ * above the capacity): the strongest max_keylines lines are kept, and stvo_lsd_counts tells that a cut happened. */
 int stvo_lsd_detect(stvo_lsd* lsd, const uint8_t* images, stvo_keyline* lines, float* response, int32_t* n_lines);
+/* Counts of the last detection before its cuts, host arrays [B] (either may be NULL), synchronises: n_segments = segments the
+ * detector core found (the first 8192 are ranked), n_passing = those longer than min_length. */
+int stvo_lsd_counts(stvo_lsd* lsd, int32_t* n_segments, int32_t* n_passing);
 /* The same with DEVICE pointers, enqueued on the context's stream (no synchronisation). */
 int stvo_lsd_detect_dev(stvo_lsd* lsd, const uint8_t* images, stvo_keyline* lines, float* response, int32_t* n_lines);
 /* Device helper between stvo_lsd_detect_dev / stvo_lbd_compute_dev and stvo_seq_upload_dev: the end points (sx, sy, ex, ey) of

@@ -79,8 +79,8 @@ enum {
     STVO_POSE_FEW_INLIERS_BEFORE = 1,  /* n_inliers < minFeatures before optimisation    (:364-368) */
     STVO_POSE_FEW_INLIERS_AFTER = 2,   /* n_inliers < minFeatures after removeOutliers   (:351-355) */
     STVO_POSE_REJECTED = 3,            /* isGoodSolution false or DT == I at commit      (:382-391) */
-    STVO_POSE_INTERNAL = 4             /* reserved (a round-3 experimental kernel could report a device-side failure; removed in
-                                          round 4): no kernel of the library returns it */
+    STVO_POSE_INTERNAL = 4             /* device-side failure: the single-stream pose kernel waited ~2 s for the key-line stream's
+                                          signal and did not get it (a failed launch there); pose held, no by-products published */
 };
 
 /* Flags describing the path taken through the state machine. */

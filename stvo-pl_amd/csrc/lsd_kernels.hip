@@ -78,6 +78,7 @@ struct LsdDev {
     int32_t* kmax;             // [B] largest gx^2 + gy^2 among the defined pixels, -1: none
     float4* seg;               // [B][seg_cap] (x1, y1, x2, y2) in detection order
     int32_t* n_seg;            // [B]
+    int32_t* n_pass;           // [B] segments longer than min_length, before the top-N / capacity cut (stvo_lsd_counts)
     double* dbg;               // developer aid (stvo_lsd_debug): [B][seg_cap][8] cx, cy, Ixx, Iyy, Ixy, theta, l_min, l_max, or nullptr
     // outputs of the wrapper
     stvo_keyline* lines;       // [B][K]
@@ -1084,8 +1085,10 @@ __global__ __launch_bounds__(KL_T) void lsd_keylines_kernel(LsdDev d) {
         __syncthreads();
     }
     const int m = s_run;
-    const bool cut = d.nfeatures != 0 && m > d.nfeatures;
-    const int n_out = min(cut ? d.nfeatures : m, d.K);
+    // the top-N cut of stereoFrame.cpp:231-240 — and when the CAPACITY binds (lsd_nfeatures = 0 or above max_keylines) the same
+    // selection for K lines: the K strongest, not the first K in detection order (the uncut count goes to n_pass: stvo_lsd_counts)
+    const int n_out = min(d.nfeatures != 0 ? min(d.nfeatures, m) : m, d.K);
+    const bool cut = m > n_out;
     for (int i = tid; i < m; i += KL_T) {
         int rank = i;
         if (cut) {  // position in the stable descending order of the responses
@@ -1116,7 +1119,10 @@ __global__ __launch_bounds__(KL_T) void lsd_keylines_kernel(LsdDev d) {
         d.lines[(size_t)b * d.K + rank] = kl;
         if (d.response) d.response[(size_t)b * d.K + rank] = s_resp[i];
     }
-    if (tid == 0) d.n_lines[b] = n_out;
+    if (tid == 0) {
+        d.n_lines[b] = n_out;
+        d.n_pass[b] = m;
+    }
 }
 
 // the end points of key-line records as the rows stvo_frame_features::kl_l / kl_r take (unused rows zeroed)
@@ -1260,14 +1266,14 @@ int stvo_lsd_create(stvo_ctx* ctx, int B, int cols, int rows, int max_keylines, 
                  o_csn = c.take(nb * npx * 8), o_mod = c.take(nb * npx * 8), o_used = c.take(nb * npx * 4), o_keys = c.take(nb * npx * 4),
                  o_order = c.take(nb * npx * 4), o_reg = c.take(nb * npx * 4), o_kmax = c.take(nb * 4), o_seg = c.take(nb * d.seg_cap * 16),
                  o_nseg = c.take(nb * 4), o_off = c.take((nb + 1) * 4), o_lines = c.take(nb * d.K * sizeof(stvo_keyline)),
-                 o_resp = c.take(nb * d.K * 4), o_nl = c.take(nb * 4);
+                 o_resp = c.take(nb * d.K * 4), o_nl = c.take(nb * 4), o_np = c.take(nb * 4);
     bool ok = hip_ok(ctx, hipMalloc((void**)&o->dev, c.off), "hipMalloc lsd") && hip_ok(ctx, hipMemset(o->dev, 0, c.off), "hipMemset lsd");
     if (ok) {
         char* D = o->dev;
         o->blur = (uint8_t*)(D + o_blur); o->scaled = (uint8_t*)(D + o_scaled); o->img = (uint8_t*)(D + o_img);
         d.ang = (float*)(D + o_ang); d.csn = (float2*)(D + o_csn); d.mod = (double*)(D + o_mod); d.used = (int32_t*)(D + o_used);
         d.keys = (uint32_t*)(D + o_keys); d.order = (uint32_t*)(D + o_order); d.reg = (int32_t*)(D + o_reg); d.kmax = (int32_t*)(D + o_kmax);
-        d.seg = (float4*)(D + o_seg); d.n_seg = (int32_t*)(D + o_nseg);
+        d.seg = (float4*)(D + o_seg); d.n_seg = (int32_t*)(D + o_nseg); d.n_pass = (int32_t*)(D + o_np);
         o->seg_off = (int32_t*)(D + o_off);
         o->lines = (stvo_keyline*)(D + o_lines); o->response = (float*)(D + o_resp); o->n_lines = (int32_t*)(D + o_nl);
         std::vector<int32_t> off(nb + 1);
@@ -1358,6 +1364,20 @@ int stvo_keylines_xy_dev(stvo_ctx* ctx, int B, int stride, const stvo_keyline* l
     hipLaunchKernelGGL(stvo::keylines_xy_kernel, dim3((stride + 255) / 256, B), dim3(256), 0, ctx->stream, stride, lines, n_lines,
                        reinterpret_cast<float4*>(kl_xy));
     return check_launch(ctx);
+}
+
+// What the last detection found BEFORE its cuts, per image: n_segments = segments of the detector core (at most 8192 are ranked),
+// n_passing = those longer than min_length (n_lines = min(n_passing, nfeatures if set, max_keylines)).  A caller that asked for
+// "keep all" (lsd_nfeatures = 0) learns here whether the capacity cut its lines.  Host arrays [B]; synchronises.
+int stvo_lsd_counts(stvo_lsd* o, int32_t* n_segments, int32_t* n_passing) {
+    if (!o || (!n_segments && !n_passing)) return STVO_ERR_INVALID_ARG;
+    stvo_ctx* ctx = o->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const stvo::LsdDev& d = o->d;
+    if (n_segments) HIP_TRY(ctx, hipMemcpyAsync(n_segments, d.n_seg, (size_t)d.B * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (n_passing) HIP_TRY(ctx, hipMemcpyAsync(n_passing, d.n_pass, (size_t)d.B * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return STVO_OK;
 }
 
 int stvo_lsd_segments(stvo_lsd* o, const uint8_t* images, float* segments, int cap, int32_t* n_segments) {

@@ -546,11 +546,34 @@ __global__ __launch_bounds__(BLOCK + 64, 2) void pose_kernel(PoseArgs a) {  // >
     // priority so its critical path is not stretched by the co-resident popcount waves.
     __builtin_amdgcn_s_setprio(3);
     if (a.wait_flag) {  // results of another stream (PoseArgs::wait_flag): normally long there — one L2 round trip
-        if (threadIdx.x == 0)  // bounded (~2 s): a signal that never comes (a failed launch on the other stream) must not hang the device
-            for (int spin = 0; spin < (1 << 23) && (int)(__hip_atomic_load(a.wait_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - a.wait_value) < 0; ++spin)
+        __shared__ int s_timed_out;
+        if (threadIdx.x == 0) {  // bounded (~2 s): a signal that never comes (a failed launch on the other stream) must not hang the device
+            int spin = 0;
+            for (; spin < (1 << 23) && (int)(__hip_atomic_load(a.wait_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - a.wait_value) < 0; ++spin)
                 __builtin_amdgcn_s_sleep(8);
+            s_timed_out = spin >= (1 << 23);
+        }
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (s_timed_out) {
+            // The key-line stream never signalled: its match indices and line set are not to be trusted.  No pose from half the
+            // input — the pair reports STVO_POSE_INTERNAL in band (pose held: DT = I, err = -1, like a rejected solution) and the
+            // by-product fetch is NOT published, so stvo_seq_fetch_matches times out on the host side instead of handing over indices.
+            if (threadIdx.x == 0) {
+                stvo_pose_result* out = a.results + blockIdx.x;
+                for (int i = 0; i < 16; ++i) out->T[i] = out->T_opt[i] = (i % 5 == 0) ? 1.0 : 0.0;
+                for (int i = 0; i < 36; ++i) out->cov[i] = 0.0;
+                for (int i = 0; i < 6; ++i) out->cov_eig[i] = 0.0;
+                out->err = out->err_opt = -1.0;
+                out->status = STVO_POSE_INTERNAL;
+                out->path = 0;
+                out->iters[0] = out->iters[1] = 0;
+                out->n_matched_pt = out->n_matched_ls = out->n_inliers_pt = out->n_inliers_ls = 0;
+                if (a.next_T)
+                    for (int i = 0; i < 16; ++i) a.next_T[(size_t)blockIdx.x * 16 + i] = (i % 5 == 0) ? 1.0 : 0.0;
+            }
+            return;
+        }
     }
     if (a.fetch_dst && blockIdx.x == 0 && threadIdx.x >= BLOCK) {  // the solver wave has nothing to do until the first reduction
         const int lane = threadIdx.x - BLOCK;

@@ -1480,7 +1480,13 @@ int stvo_seq_fetch_matches(stvo_seq* s, const int32_t** m12_stereo_pts, const in
         for (unsigned spin = 0; !(seen = (*flag == s->fetch_epoch)); ++spin)
             if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
         std::atomic_thread_fence(std::memory_order_acquire);
-        if (!seen) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (!seen) {
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            if (*flag != s->fetch_epoch) {  // the kernel ended without publishing: it gave up waiting for the key-line stream (STVO_POSE_INTERNAL)
+                std::snprintf(ctx->last_error, sizeof(ctx->last_error), "%s", "the pose kernel did not publish the match indices of the last step (no signal from the key-line stream)");
+                return STVO_ERR_HIP;
+            }
+        }
     } else {
         HIP_TRY(ctx, hipEventSynchronize(s->ev_fetch));  // the f2f stage of the last step; its pose kernel may still run
     }

@@ -156,6 +156,16 @@ void StereoFrameHandler::detectStereoLines(const uint8_t* pair, int cols, int ro
     std::vector<uint8_t> desc((size_t)2 * M * 32);
     int32_t n[2] = {0, 0};
     check(stvo_lsd_detect(lsd, pair, kl.data(), nullptr, n), "stvo_lsd_detect", ctx);
+    {   // "keep all" (lsd_nfeatures = 0) or a budget above the pipeline's capacity: say so when the capacity cut the lines
+        int32_t n_seg[2] = {0, 0}, n_pass[2] = {0, 0};
+        check(stvo_lsd_counts(lsd, n_seg, n_pass), "stvo_lsd_counts", ctx);
+        const int want = Config::lsdNFeatures();
+        for (int s = 0; s < 2; ++s)
+            if (n_seg[s] > 8192 || (n_pass[s] > M && (want == 0 || want > M)))
+                std::cout << "[StVO-HIP] " << (s ? "right" : "left") << " image: " << n_seg[s] << " segments, " << n_pass[s]
+                          << " longer than min_line_length; the strongest " << n[s] << " are kept (capacity " << M << " key-lines, 8192 ranked segments)"
+                          << std::endl;
+    }
     check(stvo_lbd_compute(lbd, pair, kl.data(), n, desc.data(), nullptr), "stvo_lbd_compute", ctx);
     for (int s = 0; s < 2; ++s) {
         std::vector<KeyLine>& ls = s ? feat.lines_r : feat.lines_l;

@@ -24,7 +24,7 @@ EXPORTS = ["stvo_backend_name", "stvo_abi_version", "stvo_error_string", "stvo_c
            "stvo_orb_set_pattern", "stvo_orb_get_pattern", "stvo_orb_detect", "stvo_orb_detect_dev", "stvo_orb_detect_levels",
            "stvo_orb_detect_levels_dev", "stvo_orb_set_fast_threshold", "stvo_seq_upload_dev", "stvo_lbd_create", "stvo_lbd_destroy",
            "stvo_lbd_compute", "stvo_lbd_compute_dev", "stvo_debug_reparse_env", "stvo_lsd_create", "stvo_lsd_destroy", "stvo_lsd_detect",
-           "stvo_lsd_detect_dev", "stvo_lsd_segments", "stvo_keylines_xy_dev"]
+           "stvo_lsd_detect_dev", "stvo_lsd_segments", "stvo_lsd_counts", "stvo_keylines_xy_dev"]
 
 SEQ_NSTAGE = 5  # include/stvo_hip.h: STVO_SEQ_NSTAGE
 SEQ_STAGE_NAMES = ("stereo_points_stage", "grid_scan", "hamming_knn2", "reverse_check", "pose")
@@ -148,6 +148,7 @@ def load():
     L.stvo_lsd_detect.argtypes = [C.c_void_p, u8p, C.c_void_p, C.c_void_p, i32p]
     L.stvo_lsd_detect_dev.argtypes = [C.c_void_p] + [C.c_void_p] * 4
     L.stvo_lsd_segments.argtypes = [C.c_void_p, u8p, f32p, C.c_int, i32p]
+    L.stvo_lsd_counts.argtypes = [C.c_void_p, i32p, i32p]
     L.stvo_keylines_xy_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.stvo_seq_destroy.argtypes = [C.c_void_p]
     L.stvo_seq_push.argtypes = [C.c_void_p, C.POINTER(FrameFeatures), C.c_void_p, i32p]
@@ -403,6 +404,12 @@ class Lsd:
     def detect_dev(self, img_ptr, lines_ptr, resp_ptr, n_ptr):
         """Device pointers (uint8 [B, rows, cols]; stvo_keyline [B, M]; float32 [B, M] or None; int32 [B]); asynchronous."""
         self.ctx._chk(self.ctx.lib.stvo_lsd_detect_dev(self.h, img_ptr, lines_ptr, resp_ptr, n_ptr))
+
+    def counts(self):
+        """(segments found, segments longer than min_length) per image of the last detection, before the top-N / capacity cut."""
+        ns = np.zeros(self.B, np.int32); npass = np.zeros(self.B, np.int32)
+        self.ctx._chk(self.ctx.lib.stvo_lsd_counts(self.h, ns, npass))
+        return ns, npass
 
     def segments(self, images, cap=8192):
         """The raw segments of the detector core: list of B float32 [n_b, 4] (detection order)."""

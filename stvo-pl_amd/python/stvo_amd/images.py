@@ -23,6 +23,9 @@ class ImagePipeline:
         self.ctx, self.B, self.K, self.M = ctx, B, max_kp, max_kl
         self.cols, self.rows = cam["width"], cam["height"]
         self.orb = capi.Orb(ctx, 2 * B, self.cols, self.rows, max_kp, nfeatures, fast_threshold, edge_threshold, nlevels, scale_factor)  # left images, then right
+        if lsd is not None and (lsd.nfeatures == 0 or lsd.nfeatures > max_kl):
+            import warnings
+            warnings.warn(f"ImagePipeline: lsd nfeatures = {lsd.nfeatures} against a capacity of {max_kl} key-lines per image: the strongest {max_kl} are kept")
         self.lsd = capi.Lsd(ctx, 2 * B, self.cols, self.rows, lsd, max_keylines=max_kl) if lsd is not None else None
         self.lbd = capi.Lbd(ctx, 2 * B, self.cols, self.rows, max_keylines=max_kl) if lsd is not None else None
         self.seq = capi.Sequences(ctx, B, max_kp, max_kl if lsd is not None else 64, cam, mp, op)

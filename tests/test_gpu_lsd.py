@@ -146,3 +146,22 @@ def test_lsd_rejects_what_is_not_built(hip):
         capi.Lsd(hip, 1, 320, 200, capi.lsd_params(refine=1))          # refinement / NFA: not built
     with pytest.raises(StvoError):
         capi.Lsd(hip, 1, 2000, 1000, capi.lsd_params())                # more than 2^20 pixels after scaling
+
+
+def test_lsd_capacity_cut_keeps_the_strongest_and_is_reported(hip, oracle):
+    """lsd_nfeatures = 0 ("keep all") against a capacity of 40 key-lines: the 40 lines of highest response come back in the order of the
+    top-N cut (what nfeatures = 40 gives), not the first 40 in detection order, and stvo_lsd_counts reports how many passed min_length."""
+    from stvo_amd import capi
+    cols, rows = 640, 240
+    img = synth.make_image(950, cols=cols, rows=rows, n_rects=80, n_discs=10)
+    full = oracle.lsd_detect(img, oracle.lsd_opts(min_length=8.0, nfeatures=0))
+    want = oracle.lsd_detect(img, oracle.lsd_opts(min_length=8.0, nfeatures=40))
+    assert len(full) > 60
+    lsd = capi.Lsd(hip, 1, cols, rows, capi.lsd_params(min_length=8.0, nfeatures=0), max_keylines=40)
+    try:
+        det = lsd.detect(img[None])[0]
+        check_keylines(det, want, cols, rows)
+        n_seg, n_pass = lsd.counts()
+        assert n_pass[0] == len(full) and n_seg[0] >= n_pass[0]
+    finally:
+        lsd.close()

@@ -83,6 +83,18 @@ def test_seq_pipeline_motion_model(oracle, switches, B, pose):
     assert any(x["iters"] != y["iters"] for x, y in zip(a, b))
 
 
+@pytest.mark.parametrize("B", [2, 24])
+def test_seq_pipeline_clustered_descriptors(oracle, B):
+    """The streams behind bench.py's value_clustered: landmark descriptors in groups of near-duplicates (60 % of the rows, ~8 per group,
+    6 % of the bits spread), so that the ratio tests of BOTH matchers and the mutual check are decided by close calls and the reverse
+    check runs its light and heavy scans (hamming_knn2_mfma_reverse_kernel) — the whole pipeline against the oracle, frame by frame,
+    on the latency kernels (B = 2) and on the batch machinery (B = 24: K1m forward scan + plan + reverse scans + batch pose kernel)."""
+    kw = dict(cluster_frac=0.6, cluster_size=8, spread_p=0.06)
+    seqs = [synth.make_config5_sequence(b % 8, n_frames=4, n_pts=900 + 90 * (b % 5), n_lines=60, cluster_kw=kw) for b in range(B)]
+    cams = [synth.config5_cam(b % 8) for b in range(B)]
+    run_and_compare(oracle, seqs, cams, "kitti", max_kp=2048, max_kl=128)
+
+
 @pytest.mark.parametrize("mode", [0, 2])
 def test_seq_pipeline_euroc_line_heavy(oracle, mode):
     cam = synth.EUROC_CAM
