@@ -301,8 +301,11 @@ __global__ __launch_bounds__(MF_BLOCK, (QB == 1 ? 4 : QB == 2 ? 3 : 1)) void ham
     static_assert(MF_TPB % 2 == 0, "the accumulator sets alternate tile by tile");
     int t = 0;
     // the train words travel TWO barrier groups ahead of their tiles (registers only: the LDS buffers are staged as before; round 5:
-    // 0.3256 -> 0.3227 ms per 1024 frames — the fetch was not what the kernel waits for, nor is the LDS read of a K step: with the
-    // reads truly one step ahead (lgkmcnt(1) instead of (0) in front of every matrix instruction pair) the time did not move)
+    // 0.3256 -> 0.3227 ms per 1024 frames).  What else round 5 measured on this loop, all without effect or worse: LDS reads truly one K
+    // step ahead (lgkmcnt(1) instead of (0) in front of every pair of matrix instructions): no change; no barrier: no change; no fetch /
+    // stage / barrier at all: 0.289; (almost) no fold: 0.273 — the matrix pipe's own 0.17 is not within reach of this skeleton; workgroups
+    // persistent over the query tiles of a frame, next tile's rows requested under the drain: 0.40 (168 VGPRs, address reloads in the loop),
+    // and as slow with ONE tile per workgroup, i.e. the per-workgroup prologue is not what is missing either.
     uint32_t w_near[MF_TPB];
 #pragma unroll
     for (int i = 0; i < MF_TPB; ++i) {
@@ -604,20 +607,12 @@ void launch_hamming_knn2_mfma(hipStream_t s, int B, int row_stride, int max_n, c
     const int groups = (B + 7) / 8;
     const dim3 grid((unsigned)(groups * 8 * tiles * ndir * nseg));
 #define STVO_MF_ARGS grid, s, B, tiles, ndir, dir0, nseg, row_stride, d1, n1, d2, n2, knn12, knn21, qsel, nsel, claim_init, qsel_from_back, tsel, ntsel
-    const int mode = !qsel ? 0 : (!tsel ? 1 : 2);
-    if (qb == 1) {
-        if (mode == 0) launch_mf<1, 0>(STVO_MF_ARGS);
-        else if (mode == 1) launch_mf<1, 1>(STVO_MF_ARGS);
-        else launch_mf<1, 2>(STVO_MF_ARGS);
-    } else if (qb == 2) {
-        if (mode == 0) launch_mf<2, 0>(STVO_MF_ARGS);
-        else if (mode == 1) launch_mf<2, 1>(STVO_MF_ARGS);
-        else launch_mf<2, 2>(STVO_MF_ARGS);
-    } else {
-        if (mode == 0) launch_mf<4, 0>(STVO_MF_ARGS);
-        else if (mode == 1) launch_mf<4, 1>(STVO_MF_ARGS);
-        else launch_mf<4, 2>(STVO_MF_ARGS);
-    }
+    // (MODE 1 / 2 — listed query rows / listed train rows — served the reverse check until round 5, which has its own kernel above;
+    //  no caller passes a list any more and only the forward form is instantiated)
+    if (qsel || tsel) return;
+    if (qb == 1) launch_mf<1, 0>(STVO_MF_ARGS);
+    else if (qb == 2) launch_mf<2, 0>(STVO_MF_ARGS);
+    else launch_mf<4, 0>(STVO_MF_ARGS);
 #undef STVO_MF_ARGS
 }
 
