@@ -1153,6 +1153,7 @@ struct stvo_lsd {
     stvo::LsdWaves xw{};      // scratch of lsd_grow_waves_kernel (small batches), or null
     char* wdev = nullptr;
     size_t stamp_bytes = 0, pend_bytes = 0;
+    int sort_chunk = 1;       // images per call of the segmented sort (its item count is an int)
 };
 
 namespace {
@@ -1184,7 +1185,13 @@ int lsd_enqueue(stvo_lsd* o, const uint8_t* images, stvo_keyline* lines, float* 
         for (int b = 0; b < d.B; ++b)
             HIP_TRY(ctx, hipcub::DeviceRadixSort::SortKeys(o->sort_tmp, tb, d.keys + (size_t)b * npx, d.order + (size_t)b * npx, npx, 0, 32, s));
     } else {
-        HIP_TRY(ctx, hipcub::DeviceSegmentedRadixSort::SortKeys(o->sort_tmp, tb, d.keys, d.order, d.B * d.w * d.h, d.B, o->seg_off, o->seg_off + 1, begin_bit, 32, s));
+        // (the sort counts its items in an int: batches beyond 2^31 pixels go in chunks of whole images)
+        const size_t npx = (size_t)d.w * d.h;
+        for (int b0 = 0; b0 < d.B; b0 += o->sort_chunk) {
+            const int nb_c = d.B - b0 < o->sort_chunk ? d.B - b0 : o->sort_chunk;
+            HIP_TRY(ctx, hipcub::DeviceSegmentedRadixSort::SortKeys(o->sort_tmp, tb, d.keys + b0 * npx, d.order + b0 * npx, (int)(nb_c * npx), nb_c, o->seg_off,
+                                                                    o->seg_off + 1, begin_bit, 32, s));
+        }
     }
     if (o->wdev) {  // small batches: one workgroup of LSD_NW waves per image (lsd_grow_waves_kernel)
         HIP_TRY(ctx, hipMemsetAsync(o->xw.stamp, 0, o->stamp_bytes, s));
@@ -1276,13 +1283,14 @@ int stvo_lsd_create(stvo_ctx* ctx, int B, int cols, int rows, int max_keylines, 
         d.seg = (float4*)(D + o_seg); d.n_seg = (int32_t*)(D + o_nseg); d.n_pass = (int32_t*)(D + o_np);
         o->seg_off = (int32_t*)(D + o_off);
         o->lines = (stvo_keyline*)(D + o_lines); o->response = (float*)(D + o_resp); o->n_lines = (int32_t*)(D + o_nl);
-        std::vector<int32_t> off(nb + 1);
-        for (size_t i = 0; i <= nb; ++i) off[i] = (int32_t)(i * npx);
-        ok = nb * npx < (1ull << 31) && hip_ok(ctx, hipMemcpy(o->seg_off, off.data(), off.size() * 4, hipMemcpyHostToDevice), "hipMemcpy lsd offsets");
+        o->sort_chunk = (int)std::min<size_t>(nb, ((1ull << 31) - 1) / npx);  // images per call of the segmented sort
+        std::vector<int32_t> off((size_t)o->sort_chunk + 1);
+        for (size_t i = 0; i < off.size(); ++i) off[i] = (int32_t)(i * npx);
+        ok = o->sort_chunk >= 1 && hip_ok(ctx, hipMemcpy(o->seg_off, off.data(), ((size_t)o->sort_chunk + 1) * 4, hipMemcpyHostToDevice), "hipMemcpy lsd offsets");
     }
     if (ok) {
         size_t tb = 0, tb1 = 0;
-        ok = hip_ok(ctx, hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, tb, (const uint32_t*)d.keys, d.order, (int)(nb * npx), B, o->seg_off,
+        ok = hip_ok(ctx, hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, tb, (const uint32_t*)d.keys, d.order, (int)((size_t)o->sort_chunk * npx), o->sort_chunk, o->seg_off,
                                                                     o->seg_off + 1, 0, 32, ctx->stream), "segmented sort (size)") &&
              hip_ok(ctx, hipcub::DeviceRadixSort::SortKeys(nullptr, tb1, (const uint32_t*)d.keys, d.order, (int)npx, 0, 32, ctx->stream), "device sort (size)");
         if (tb1 > tb) tb = tb1;  // (the per-image device-wide sort of the small batches)
