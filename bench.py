@@ -1017,7 +1017,7 @@ def main():
         extra("configs3", configs3_leg, local_rank, c3_seqs)
         extra("reverse_check_correlated", correlated_leg, dev_name, rank)
         extra("orb_front_end", orb_leg, local_rank)
-        extra("images_to_poses", images_leg, local_rank)
+        extra("images_to_poses", images_leg, local_rank, B=512)
         extra("lsd_front_end", lsd_leg, local_rank)
         extra("images_to_poses_with_lines", images_leg, local_rank, B=2048, steps=3, lines=True)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
