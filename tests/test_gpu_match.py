@@ -317,3 +317,33 @@ def test_match_clustered_descriptors_2000x2000(hip, oracle, kw):
         plan = hip.last_reverse_plan(1)[:, 0]
         assert plan[0] > 0 and plan[3] > 0, plan          # claimed columns, rows in S
         assert plan[1] > 0 and plan[2] > 0, plan          # both light and heavy columns
+
+
+@pytest.mark.parametrize("n", [5000, 8192])
+def test_match_clustered_descriptors_beyond_2048_rows(oracle, n):
+    """The reverse check's units beyond their comfortable size: with more than 2048 train rows a heavy column's segment is longer than one
+    LDS-resident chunk (8 segments of n / 8 rows: several chunks one after the other), and with heavy clustering the row list S exceeds
+    256 rows (several light segments).  Clustered rows on both sides, both ratios; bit-exact against the oracle."""
+    from stvo_amd import capi
+    ctx = capi.Context(device_id=0, max_rows=8192, max_batch=1)
+    try:
+        rng = np.random.default_rng(n)
+        kw = dict(cluster_frac=0.8, cluster_size=12, spread_p=0.05)
+        d2 = synth.clustered_desc(rng, n, **kw)
+        d1 = synth.flip_bits(rng, d2[rng.permutation(n)], 0.06)
+        d1[: n // 5] = synth.clustered_desc(rng, n // 5, **kw)      # rows without a partner
+        # 600 query rows that sit between TWIN train rows (2 bits apart): no claim (the ratio test fails), but a second-best distance
+        # of a few bits puts every one of them into the row list S of any useful cut — |S| > 256, several light segments
+        tw = rand_desc(rng, 600)
+        d2[0:1200:2] = tw
+        d2[1:1200:2] = synth.flip_bits(rng, tw, 2.0 / 256)
+        d1[n // 5:n // 5 + 600] = synth.flip_bits(rng, tw, 3.0 / 256)
+        for nnr in (0.75, 0.95):
+            got, cnt = ctx.match(d1, d2, nnr, 1)
+            exp, en = oracle.match(d1, d2, nnr, 1)
+            assert np.array_equal(got, exp) and cnt == en
+            plan = ctx.last_reverse_plan(1)[:, 0]
+            assert plan[2] > 0 and plan[1] > 0, plan                 # heavy and light columns
+        assert plan[3] > 256, plan                                   # more rows in S than one LDS-resident chunk holds
+    finally:
+        ctx.close()
