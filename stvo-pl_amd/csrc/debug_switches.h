@@ -20,7 +20,7 @@ struct DebugSwitches {
     int seq_graph;       // STVO_SEQ_GRAPH       1: hipGraph replay of the per-frame chain
     int seq_prof;        // STVO_SEQ_PROF        host-side phase times of stvo_seq_push
     int seq_inline;      // STVO_SEQ_INLINE      0: events between the streams of a step for small batches too (kernels.h: PoseArgs::wait_flag)
-    int line_fork_late;  // STVO_LINE_FORK=late  1: the key-line stream forks after the stereo point stage instead of at the start of the step
+    int line_fork_late;  // STVO_LINE_FORK       start (0) / late (1) / mid (2): where the key-line stream forks off — at the start of the step, after the stereo point stage, behind the cells kernel (unset: mid for batches of >= 64, start below)
     int line_first;      // STVO_LINE_FIRST      1: key-line kernels enqueued before the point-cells kernel
     int line_fused;      // STVO_LINE_FUSED      0 / 1: general / one-workgroup stereo line matcher
     int match_small;     // STVO_MATCH_SMALL     0: the general f2f machinery for the key-line sets too

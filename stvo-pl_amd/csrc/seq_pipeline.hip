@@ -1129,9 +1129,16 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl) {
     // per 1024 frames) but leave the key-point scan alone (0.467 ms); forked after the point stage (STVO_LINE_FORK=late) they
     // stretch the scan instead (0.510 ms).  Measured: 1024 KITTI-shaped streams 929 k (early) vs 935 k (late) frame pairs/s, 512
     // EuRoC-shaped streams 857 k vs 777 k, one stream 0.252 vs 0.280 ms per frame.
-    const bool late_fork = par && stvo::dbg().line_fork_late == 1;
+    // Round 5: a third point — behind the cells kernel (STVO_LINE_FORK=mid), the default for batches: the line kernels then become
+    // ready together with the persistent point matcher, whose workgroups (already queued) take their CUs first, instead of finding four
+    // line workgroups per CU in their way.  1024 KITTI-shaped streams 0.872 -> 0.853 ms per step, 512 EuRoC-shaped 1.036 -> 1.105 M
+    // frame pairs/s; one stream is SLOWER that way (0.205 -> 0.211 ms: its line kernels lose their head start), so small batches keep
+    // the fork at the start.  STVO_LINE_FORK=start / mid / late forces one of the three.
+    const int fork_sw = stvo::dbg().line_fork_late;  // DBG_UNSET: by batch size
+    const bool late_fork = par && fork_sw == 1;
+    const bool mid_fork = par && s->op.has_points && (fork_sw == 2 || (fork_sw == stvo::DBG_UNSET && B >= 64));
     const bool fork_free = par && s->raw_split[slot] && !s->st_dirty && !s->graph_mode;  // see stvo_seq::st_dirty
-    if (par && !late_fork && !fork_free) {
+    if (par && !late_fork && !mid_fork && !fork_free) {
         HIP_TRY(ctx, hipEventRecord(s->ev_fork, st));
         HIP_TRY(ctx, hipStreamWaitEvent(sl, s->ev_fork, 0));
     }
@@ -1169,6 +1176,10 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl) {
                 hipLaunchKernelGGL(stvo::point_cells_kernel<true>, dim3(B), dim3(256), 0, st, d);
             else
                 hipLaunchKernelGGL(stvo::point_cells_kernel<false>, dim3(B), dim3(256), 0, st, d);
+            if (mid_fork) {
+                HIP_TRY(ctx, hipEventRecord(s->ev_fork, st));
+                HIP_TRY(ctx, hipStreamWaitEvent(sl, s->ev_fork, 0));
+            }
             s->last_point_grid = g;
             stvo::launch_grid_batch(st, g, false, tev ? tev + 2 : nullptr);
             if (!g.has_tail) hipLaunchKernelGGL(stvo::point_tail_kernel, dim3(B), dim3(stvo::TAIL_BLOCK), 0, st, d);

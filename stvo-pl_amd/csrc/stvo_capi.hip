@@ -31,7 +31,7 @@ DebugSwitches parse_switches() {
     d.seq_prof = env_int("STVO_SEQ_PROF");
     d.seq_inline = env_int("STVO_SEQ_INLINE");
     const char* lf = std::getenv("STVO_LINE_FORK");
-    d.line_fork_late = lf ? (lf[0] == 'l' ? 1 : 0) : DBG_UNSET;
+    d.line_fork_late = lf ? (lf[0] == 'l' ? 1 : (lf[0] == 'm' ? 2 : 0)) : DBG_UNSET;
     d.line_first = env_int("STVO_LINE_FIRST");
     d.line_fused = env_int("STVO_LINE_FUSED");
     d.match_small = env_int("STVO_MATCH_SMALL");
