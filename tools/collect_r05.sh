@@ -22,7 +22,7 @@ cd $R
 rm -rf /tmp/kt
 bash tools/hbm_calib.sh > $OUT/hbm_calib.txt 2>&1
 PMCB="$BENCH --no-parity --no-clocks --steps 1 --warmup 1 --repeats 1"
-for c in FETCH_SIZE WRITE_SIZE; do
+for c in ${PMC_PASSES:-FETCH_SIZE WRITE_SIZE}; do   # (PMC_PASSES=WRITE_SIZE: skip a pass that keeps hanging)
   cd /tmp; rm -rf /tmp/pmc_$c
   timeout 150 rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc_$c -- $PMCB > $OUT/pmc_$c.bench.json 2>/dev/null; echo "$c pass: exit $?"
   cd $R; python tools/rocprof_summary.py pmc $(find /tmp/pmc_$c -name "*.db" | head -1) $c > $OUT/pmc_$c.txt 2>/dev/null; rm -rf /tmp/pmc_$c
