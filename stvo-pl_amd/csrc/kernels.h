@@ -74,7 +74,7 @@ void launch_hamming_knn2(hipStream_t s, int B, int row_stride, int max_n, const 
 // K1m: the same scan with the distances taken from the matrix cores (match_mfma.hip); qb = query blocks of 32 rows per
 // wave (1, 2 or 4; a workgroup covers 128 * qb query rows).  Train indices must fit 13 bits (max_n <= 8192).
 // the reverse check of the claimed columns in one launch (match_mfma.hip): light columns against S, heavy columns against all rows,
-// the train side of a unit resident in LDS; `slots` workgroups per frame pair share the frame's units; blocked[column] = 1 for every
+// the train side of a unit resident in LDS; `slots` workgroups per frame pair share the frame's units; m12[claimant] = -1 for every
 // listed column whose claim another row blocks
 constexpr int REV_MAX_SEG = 8;
 __host__ __device__ inline int rev_segments(int train_rows) {  // train segments of a column list with this many train rows
@@ -82,20 +82,20 @@ __host__ __device__ inline int rev_segments(int train_rows) {  // train segments
     return s < 1 ? 1 : (s > REV_MAX_SEG ? REV_MAX_SEG : s);
 }
 void launch_hamming_knn2_mfma_reverse(hipStream_t s, int B, int row_stride, const uint8_t* d1, const int32_t* n1, const uint8_t* d2, const int32_t* qsel,
-                                      const int32_t* nsel, const int32_t* tsel, const uint32_t* claim, float nnr, int32_t* blocked, int slots);
+                                      const int32_t* nsel, const int32_t* tsel, const uint32_t* claim, float nnr, int32_t* m12, int slots);
 void launch_hamming_knn2_mfma(hipStream_t s, int B, int row_stride, int max_n, const uint8_t* d1, const int32_t* n1,
                               const uint8_t* d2, const int32_t* n2, uint2* knn12, uint2* knn21, int both_directions,
                               int dir0, const int32_t* qsel, const int32_t* nsel, int nseg, uint32_t* claim_init, int qb,
                               int qsel_from_back = 0, const int32_t* tsel = nullptr, const int32_t* ntsel = nullptr);
 int knn_mfma_qb(int max_n);  // query blocks per wave of K1m for this problem size, 0 = VALU kernels
 // mutual matching with a lazy reverse pass: only the columns claimed by an accepted forward match are examined
-// (match_kernels.hip) — on the matrix-core path by a per-frame plan + two sparse scans of K1m, on the VALU path
+// (match_kernels.hip) — on the matrix-core path by a per-frame plan + one launch of sparse reverse scans, on the VALU path
 // (> 8192 rows, STVO_KNN_MFMA=0) by a range query with early exit
 struct LazyScratch {
     uint2* knn12;
-    uint2* knn21;   // VALU path: reused as int32 blocked[B][row_stride].  Matrix-core path: blocked[] and tsel[] (B * row_stride int32
-                    // each) in the last B * row_stride entries
-    int32_t* cand;  // [B][row_stride] forward ratio-tested best
+    uint2* knn21;   // VALU path: reused as int32 blocked[B][row_stride].  Matrix-core path: tsel[] (B * row_stride int32) in the last
+                    // B * row_stride / 2 entries
+    int32_t* cand;  // [B][row_stride] forward ratio-tested best (VALU path)
     int32_t* need;  // [B][row_stride] per-column claim (d0 << 16 | claimant), 0xFFFFFFFF = unclaimed
     int32_t* qsel;  // [B][row_stride] compacted flagged columns
     int32_t* nsel;  // [5][B]: claimed columns; light, heavy, |S|, tau of the matrix-core reverse check (reverse_plan_kernel)
@@ -106,7 +106,7 @@ void launch_match_mutual_lazy(hipStream_t s, int B, int row_stride, const uint8_
                               int lds_pad_bytes, hipEvent_t wait_before_m12_write, hipEvent_t* timing_events = nullptr);
 // the verification pass alone, on the claims left by the last launch_match_mutual_lazy (timing tools)
 void launch_hamming_verify(hipStream_t s, int B, int row_stride, const uint8_t* d1, const int32_t* n1, const uint8_t* d2,
-                           float nnr, const LazyScratch& w, int lds_pad_bytes, int nseg);
+                           float nnr, const LazyScratch& w, int lds_pad_bytes, int nseg, int32_t* m12);
 // StVO::match of B frame pairs with at most 512 rows per set (key-lines): one workgroup per frame pair, both sets in LDS
 bool match_small_ok(int row_stride);
 void launch_match_small(hipStream_t s, int B, int row_stride, const uint8_t* d1, const int32_t* n1, const uint8_t* d2,

@@ -450,15 +450,16 @@ __device__ __forceinline__ uint32_t block_threshold(uint32_t d0, float nnr) {
 //      resolves the column claims with LDS atomics (one claim per column: the smallest (d0, row));
 //   2. judges from the forward top-2 alone every (row, column) pair where the column is one of the row's two entries;
 //   3. picks the cut tau and writes the LIGHT / HEAVY column lists and the row list S.
-// out: cand[i], claim[j], blocked[j], qsel (LIGHT columns from the front, HEAVY from the back of the frame's slot), tsel,
+// out: m12[i] (the claimants whose claim the forward top-2 does not already block; the reverse scans clear more), claim[j], qsel
+// (LIGHT columns from the front, HEAVY from the back of the frame's slot), tsel,
 // nsel[0][b] = claimed columns, [1] = light, [2] = heavy, [3] = |S|, [4] = tau.  knn12 segment 0 is left holding the merged top-2.
 constexpr int PLAN_BLOCK = 512;  // (1024: two rounds of two workgroups per CU for 1024 frames, 34 us; 512: one round, 29 us; 320: 32 us)
 __global__ __launch_bounds__(PLAN_BLOCK) void forward_plan_kernel(int B, int nseg, int row_stride, uint2* __restrict__ knn12,
                                                                   const int32_t* __restrict__ n1,
                                                                   const int32_t* __restrict__ n2, float nnr,
-                                                                  int32_t* __restrict__ cand, uint32_t* __restrict__ claim_g,
-                                                                  int32_t* __restrict__ blocked_g, int32_t* __restrict__ qsel,
-                                                                  int32_t* __restrict__ tsel, int32_t* __restrict__ nsel) {
+                                                                  int32_t* __restrict__ m12, uint32_t* __restrict__ claim_g,
+                                                                  int32_t* __restrict__ qsel, int32_t* __restrict__ tsel,
+                                                                  int32_t* __restrict__ nsel) {
     extern __shared__ uint32_t plan_lds[];  // claim u32[stride] | T u16[stride] | verdict u8[stride]
     uint32_t* claim = plan_lds;
     uint16_t* Tc = reinterpret_cast<uint16_t*>(claim + row_stride);
@@ -478,17 +479,13 @@ __global__ __launch_bounds__(PLAN_BLOCK) void forward_plan_kernel(int B, int nse
     __syncthreads();
     const bool active = nb >= 2 && na >= 1;
     for (int i = tid; i < row_stride; i += PLAN_BLOCK) {  // forward ratio test + claims
-        int m = -1;
         if (active && i < na) {
             const uint2 k = merged_knn(knn12, (size_t)B * row_stride, off + i, nseg);
             if (nseg > 1) knn12[off + i] = k;
             const float f0 = (float)(k.x >> 16), f1 = (float)(k.y >> 16);
-            if (f0 < f1 * nnr) {
-                m = (int)(k.x & 0xFFFFu);
-                atomicMin(&claim[m], (k.x & 0xFFFF0000u) | (uint32_t)i);  // (d0 << 16) | claimant
-            }
+            if (f0 < f1 * nnr) atomicMin(&claim[k.x & 0xFFFFu], (k.x & 0xFFFF0000u) | (uint32_t)i);  // (d0 << 16) | claimant
         }
-        cand[off + i] = m;
+        m12[off + i] = -1;  // (the claimants that survive are written by the last loop, barriers later)
     }
     __syncthreads();
     for (int j = tid; j < row_stride; j += PLAN_BLOCK) {  // thresholds of the claimed columns
@@ -559,8 +556,11 @@ __global__ __launch_bounds__(PLAN_BLOCK) void forward_plan_kernel(int B, int nse
     __syncthreads();
     const int tau = (int)(s_best & 511ull) - 1;
     for (int j = tid; j < row_stride; j += PLAN_BLOCK) {
-        blocked_g[off + j] = blk[j];
-        if (claim[j] == 0xFFFFFFFFu) continue;
+        const uint32_t c = claim[j];
+        if (c == 0xFFFFFFFFu) continue;
+        // the match as far as the forward top-2 can tell; the reverse scans clear the entries whose claim a scanned row blocks.
+        // Fewer than two prev rows => no match (the reference's knnMatch(k = 2) row would have one entry; :54 is UB).
+        if (!blk[j] && na >= 2) m12[off + (c & 0xFFFFu)] = j;
         if ((int)Tc[j] <= tau)
             qsel[off + atomicAdd(&s_cnt[0], 1)] = j;
         else
@@ -581,34 +581,33 @@ __global__ __launch_bounds__(PLAN_BLOCK) void forward_plan_kernel(int B, int nse
     }
 }
 
-// scratch of the matrix-core reverse check: the last B * row_stride uint2 of knn21 hold blocked[] and tsel[] (the reverse top-2 array of
-// the non-lazy path is not needed here)
+// scratch of the matrix-core reverse check: the last B * row_stride int32 of knn21 hold tsel[] (the reverse top-2 array of the non-lazy
+// path is not needed here)
 struct ReversePlan {
-    int32_t* blocked;
     int32_t* tsel;
 };
 constexpr int KNN_REV_SLOTS = 4;  // workgroups per frame pair sharing the frame's reverse-check units (match_mfma.hip)
 static ReversePlan reverse_plan(const LazyScratch& w, int B, int row_stride) {
     const size_t per = (size_t)B * row_stride;
     ReversePlan p;
-    p.blocked = reinterpret_cast<int32_t*>(w.knn21 + (w.knn_capacity - per));
-    p.tsel = p.blocked + per;
+    p.tsel = reinterpret_cast<int32_t*>(w.knn21 + (w.knn_capacity - per)) + per;  // (the place it had beside the flags of round 5's first form)
     return p;
 }
 
-// light columns against the rows of S (positions in tsel), heavy columns against every row — one launch; blocked[] gains the verdicts
+// light columns against the rows of S (positions in tsel), heavy columns against every row — one launch; m12 loses the claimants whose
+// column some scanned row blocks
 static void launch_reverse_scans(hipStream_t s, int B, int row_stride, const uint8_t* d1, const int32_t* n1, const uint8_t* d2, float nnr,
-                                 const LazyScratch& w, const ReversePlan& rp) {
-    launch_hamming_knn2_mfma_reverse(s, B, row_stride, d1, n1, d2, w.qsel, w.nsel, rp.tsel, reinterpret_cast<const uint32_t*>(w.need), nnr, rp.blocked,
+                                 const LazyScratch& w, const ReversePlan& rp, int32_t* m12) {
+    launch_hamming_knn2_mfma_reverse(s, B, row_stride, d1, n1, d2, w.qsel, w.nsel, rp.tsel, reinterpret_cast<const uint32_t*>(w.need), nnr, m12,
                                      KNN_REV_SLOTS);
 }
 
 void launch_hamming_verify(hipStream_t s, int B, int row_stride, const uint8_t* d1, const int32_t* n1, const uint8_t* d2,
-                           float nnr, const LazyScratch& w, int lds_pad_bytes, int nseg) {
+                           float nnr, const LazyScratch& w, int lds_pad_bytes, int nseg, int32_t* m12) {
     if (B <= 0 || row_stride <= 0) return;
     const int mfma_qb = knn_mfma_qb(row_stride);
-    if (mfma_qb > 0) {  // the two reverse scans on the lists left by the last reverse_plan_kernel
-        launch_reverse_scans(s, B, row_stride, d1, n1, d2, nnr, w, reverse_plan(w, B, row_stride));
+    if (mfma_qb > 0) {  // the reverse scans on the lists left by the last forward_plan_kernel (they clear the same entries of m12 again)
+        launch_reverse_scans(s, B, row_stride, d1, n1, d2, nnr, w, reverse_plan(w, B, row_stride), m12);
         return;
     }
     const int tiles = (row_stride + KNN_BLOCK - 1) / KNN_BLOCK, groups = (B + 7) / 8;
@@ -632,20 +631,21 @@ void launch_match_mutual_lazy(hipStream_t s, int B, int row_stride, const uint8_
     if (tev) (void)hipEventRecord(tev[1], s);
     const int mfma_qb = knn_mfma_qb(row_stride);
     if (mfma_qb > 0) {
+        // Two launches behind the forward scan (three until the end of round 5: a last pass turned claim[] and per-column flags into
+        // m12): the plan writes m12 as far as the forward top-2 decides it, the reverse scans clear the claimants they find blocked.
         const ReversePlan rp = reverse_plan(w, B, row_stride);
+        if (wait_before_m12_write) (void)hipStreamWaitEvent(s, wait_before_m12_write, 0);
         if (tev) (void)hipEventRecord(tev[2], s);
         hipLaunchKernelGGL(forward_plan_kernel, dim3(B), dim3(PLAN_BLOCK), (size_t)row_stride * 7, s, B, nseg, row_stride, w.knn12,
-                           n1, n2, nnr, w.cand, claim, rp.blocked, w.qsel, rp.tsel, w.nsel);
-        launch_reverse_scans(s, B, row_stride, d1, n1, d2, nnr, w, rp);
+                           n1, n2, nnr, m12, claim, w.qsel, rp.tsel, w.nsel);
+        launch_reverse_scans(s, B, row_stride, d1, n1, d2, nnr, w, rp, m12);
         if (tev) (void)hipEventRecord(tev[3], s);
-        if (wait_before_m12_write) (void)hipStreamWaitEvent(s, wait_before_m12_write, 0);
-        hipLaunchKernelGGL(nnr_reverse_check_kernel, dim3(B), dim3(1024), 0, s, row_stride, claim, rp.blocked, n1, m12);
         return;
     }
     hipLaunchKernelGGL(nnr_forward_kernel, grid2, dim3(256), 0, s, nseg, row_stride, w.knn12, n1, n2, nnr, w.cand, claim);
     hipLaunchKernelGGL(compact_need_kernel, dim3(B), dim3(256), 0, s, row_stride, claim, n2, w.qsel, w.nsel, blocked);
     if (tev) (void)hipEventRecord(tev[2], s);
-    launch_hamming_verify(s, B, row_stride, d1, n1, d2, nnr, w, lds_pad_bytes, nseg);
+    launch_hamming_verify(s, B, row_stride, d1, n1, d2, nnr, w, lds_pad_bytes, nseg, m12);
     if (tev) (void)hipEventRecord(tev[3], s);
     if (wait_before_m12_write) (void)hipStreamWaitEvent(s, wait_before_m12_write, 0);
     hipLaunchKernelGGL(nnr_reverse_check_kernel, dim3(B), dim3(1024), 0, s, row_stride, claim, blocked, n1, m12);

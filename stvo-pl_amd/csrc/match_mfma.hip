@@ -379,15 +379,15 @@ __global__ __launch_bounds__(MF_BLOCK, (QB == 1 ? 4 : QB == 2 ? 3 : 1)) void ham
 // (g + seg) mod slots — the groups of a long light list spread over the slots, and so do the segments of a short heavy list.  A frame
 // whose plan left nothing to scan (i.i.d. rows: S is empty) costs `slots` workgroups that read four counters and leave.
 // A segment longer than a chunk (more than 2048 train rows) takes several chunks, one after the other.
-// Result: blocked[column] = 1 for every listed column whose claim some other row blocks (each train range decides for itself: the
-// question is a union over ranges); nnr_reverse_check_kernel then keeps the unblocked claims — no top-2 array leaves the kernel.
+// Result: m12[claimant] = -1 for every listed column whose claim some other row blocks (each train range decides for itself: the
+// question is a union over ranges; forward_plan_kernel wrote m12[claimant] = column before) — no top-2 array leaves the kernel.
 constexpr int REV_CHUNK_TILES = 8, REV_CHUNK = REV_CHUNK_TILES * MF_TILE;
 
 __global__ __launch_bounds__(MF_BLOCK, 4) void hamming_knn2_mfma_reverse_kernel(int B, int slots, int row_stride, const uint8_t* __restrict__ d1,
                                                                                 const int32_t* __restrict__ n1, const uint8_t* __restrict__ d2,
                                                                                 const int32_t* __restrict__ qsel, const int32_t* __restrict__ nsel,
                                                                                 const int32_t* __restrict__ tsel, const uint32_t* __restrict__ claim,
-                                                                                float nnr, int32_t* __restrict__ blocked) {
+                                                                                float nnr, int32_t* __restrict__ m12) {
     constexpr int KSTEPS = 4;
     using key_t = float;
     using acc_t = v16f;
@@ -464,7 +464,6 @@ __global__ __launch_bounds__(MF_BLOCK, 4) void hamming_knn2_mfma_reverse_kernel(
                     qf[1] = expand_fp4(~(up ? qw0.w : qw0.z));
                     qf[2] = expand_fp4(~(up ? qw1.y : qw1.x));
                     qf[3] = expand_fp4(~(up ? qw1.w : qw1.z));
-                    const int out_col = e_cur;
                     const uint32_t c_claim = cw;
                     const bool block_active = (g * 4 + wv) * 32 < nq;
                     // requests one block ahead (rows) and two ahead (list entry): under way while this block is multiplied
@@ -559,7 +558,7 @@ __global__ __launch_bounds__(MF_BLOCK, 4) void hamming_knn2_mfma_reverse_kernel(
                     const int bst = min(bi, ob);
                     // The verdict of this train range: the claim (row i*, distance d0) on the column is BLOCKED iff some other row lies within
                     // T = block_threshold(d0) — a union over segments and chunks, so every range decides for itself from its own top-2
-                    // (the nearest row if it is not the claimant, else the second) and blocked columns are flagged; writers only store 1.
+                    // (the nearest row if it is not the claimant, else the second) and the claimant of a blocked column loses its match; writers only store -1.
                     if (hf == 0 && (g * 4 + wv) * 32 + col < nq) {
                         const uint32_t x = key_to_knn(bst, last_base), y = key_to_knn(sec, last_base);
                         if (x != 0xFFFFFFFFu) {
@@ -570,7 +569,7 @@ __global__ __launch_bounds__(MF_BLOCK, 4) void hamming_knn2_mfma_reverse_kernel(
                                 const uint32_t row = light ? (uint32_t)tsel[frame_off + pos] : pos;
                                 blk = row != istar || (y != 0xFFFFFFFFu && (y >> 16) <= T);
                             }
-                            if (blk) blocked[frame_off + out_col] = 1;
+                            if (blk) m12[frame_off + istar] = -1;
                         }
                     }
                 }
@@ -581,10 +580,10 @@ __global__ __launch_bounds__(MF_BLOCK, 4) void hamming_knn2_mfma_reverse_kernel(
 }
 
 void launch_hamming_knn2_mfma_reverse(hipStream_t s, int B, int row_stride, const uint8_t* d1, const int32_t* n1, const uint8_t* d2, const int32_t* qsel,
-                                      const int32_t* nsel, const int32_t* tsel, const uint32_t* claim, float nnr, int32_t* blocked, int slots) {
+                                      const int32_t* nsel, const int32_t* tsel, const uint32_t* claim, float nnr, int32_t* m12, int slots) {
     if (B <= 0 || row_stride <= 0) return;
     const dim3 grid((unsigned)(((B + 7) / 8) * 8 * slots));
-    hipLaunchKernelGGL(hamming_knn2_mfma_reverse_kernel, grid, dim3(MF_BLOCK), 0, s, B, slots, row_stride, d1, n1, d2, qsel, nsel, tsel, claim, nnr, blocked);
+    hipLaunchKernelGGL(hamming_knn2_mfma_reverse_kernel, grid, dim3(MF_BLOCK), 0, s, B, slots, row_stride, d1, n1, d2, qsel, nsel, tsel, claim, nnr, m12);
 }
 
 int mfma_rows_per_block(int qb) { return 4 * qb * 32; }

@@ -508,7 +508,7 @@ int stvo_time_stage_dev(stvo_ctx* ctx, const stvo_track_batch_dev* b, const stvo
                                       b->curr_pdesc, b->n_curr_pts, ctx->knn12, ctx->knn21, 0, pad, 0, nullptr, nullptr, nseg);
         } else if (stage == 3) {  // hamming_verify on the claims of the LAST stvo_track_batched_dev call
             stvo::launch_hamming_verify(ctx->stream, b->B, b->max_pts, b->prev_pdesc, b->n_prev_pts, b->curr_pdesc, nnr, lw,
-                                        pad, nseg);
+                                        pad, nseg, b->m12_pts);
         } else if (stage == 4) {  // developer probe: both directions as full top-2 scans (the pre-lazy formulation)
             stvo::launch_hamming_knn2(ctx->stream, b->B, b->max_pts, b->max_pts, b->prev_pdesc, b->n_prev_pts,
                                       b->curr_pdesc, b->n_curr_pts, ctx->knn12, ctx->knn21, 1, pad, 0, nullptr, nullptr, nseg);
