@@ -83,6 +83,13 @@ __device__ __forceinline__ void point_cells_frame(const PointCells& s, const int
     const bool lsort = s.plperm != nullptr;  // host: K <= 2048, window within GRID_LW
     const int nl = s.n_kp_l[b], nr = s.n_kp_r[b];
     const size_t off = (size_t)b * s.K;
+    // the key-points of this thread (i = tid + T k), left and right: requested before anything else, together with the counts
+    float2 rxy[LPT], lxy[LPT];
+#pragma unroll
+    for (int k = 0; k < LPT; ++k) rxy[k] = reinterpret_cast<const float2*>(s.kp_r)[off + min(tid + T * k, s.K - 1)];
+#pragma unroll
+    for (int k = 0; k < LPT; ++k) lxy[k] = reinterpret_cast<const float2*>(s.kp_l)[off + min(tid + T * k, s.K - 1)];  // (also without lsort: no branch)
+    __builtin_amdgcn_sched_barrier(0);  // (the conversions of the first coordinates were scheduled between the loads, with a wait)
     const double inv_w = s.inv_wh[2 * b], inv_h = s.inv_wh[2 * b + 1];
     if (!LEAN)
         for (int i = tid; i < nl; i += T) {  // float * double -> int truncation (stereoFrame.cpp:132)
@@ -100,8 +107,23 @@ __device__ __forceinline__ void point_cells_frame(const PointCells& s, const int
         if (!LEAN) s.govf_p[b] = 0;
         lds->extra = 0;
     }
+    // The cells of the right key-points of this thread, kept for the scatter below; the coordinates were requested all at once above: as loops `for (i = tid; i < nr; i += T)` the histogram and the scatter each were a chain of load -> wait -> LDS
+    // atomic per trip (tools/isa_scan.py --waits: every load waited for at once; eight trips each with 256 threads).  Rows past nr
+    // are read from a clamped index (inside the frame's slot) and ignored.
+    int rcel[LPT];  // cell, -1: outside the grid (the reference's out_of_bounds sink), -2: no key-point
+    {
+#pragma unroll
+        for (int k = 0; k < LPT; ++k) {
+            const int x = (int)((double)rxy[k].x * inv_w);
+            const int y = (int)((double)rxy[k].y * inv_h);
+            rcel[k] = tid + T * k < nr ? (point_in_grid(x, y) ? y * STVO_GRID_COLS + x : -1) : -2;
+        }
+    }
     __syncthreads();
-    for (int i = tid; i < nr; i += T) {
+#pragma unroll
+    for (int k = 0; k < LPT; ++k)
+        if (rcel[k] >= 0) atomicAdd(&hist[rcel[k]], 1);
+    for (int i = tid + T * LPT; i < nr; i += T) {  // (capacities beyond 2048 key-points per image: trip by trip)
         const int x = (int)((double)s.kp_r[(off + i) * 2 + 0] * inv_w);
         const int y = (int)((double)s.kp_r[(off + i) * 2 + 1] * inv_h);
         if (point_in_grid(x, y)) atomicAdd(&hist[y * STVO_GRID_COLS + x], 1);
@@ -110,19 +132,18 @@ __device__ __forceinline__ void point_cells_frame(const PointCells& s, const int
     // is clamped, not the cell (src/gridStructure.cpp:67-71), so columns up to 63 + ws still see the last grid columns
     int lcel[LPT], lrnk[LPT];
     if (lsort) {
+        // (coordinates first, from a clamped index, as for the right key-points: a load under `if (i < nl)` stayed in its branch and
+        //  was waited for there — eight memory round trips one after the other)
 #pragma unroll
         for (int k = 0; k < LPT; ++k) {
-            const int i = tid + T * k;
-            lcel[k] = -1;
+            const int x = (int)((double)lxy[k].x * inv_w);
+            const int y = (int)((double)lxy[k].y * inv_h);
+            lcel[k] = (tid + T * k < nl && y >= 0 && y < STVO_GRID_ROWS && x >= 0 && x <= STVO_GRID_COLS - 1 + s.ws) ? y * GRID_LW + x : -1;
+        }
+#pragma unroll
+        for (int k = 0; k < LPT; ++k) {
             lrnk[k] = 0;
-            if (i < nl) {
-                const int x = (int)((double)s.kp_l[(off + i) * 2 + 0] * inv_w);
-                const int y = (int)((double)s.kp_l[(off + i) * 2 + 1] * inv_h);
-                if (y >= 0 && y < STVO_GRID_ROWS && x >= 0 && x <= STVO_GRID_COLS - 1 + s.ws) {
-                    lcel[k] = y * GRID_LW + x;
-                    lrnk[k] = atomicAdd(&lhist[lcel[k]], 1);
-                }
-            }
+            if (lcel[k] >= 0) lrnk[k] = atomicAdd(&lhist[lcel[k]], 1);
         }
     }
     __syncthreads();
@@ -149,19 +170,34 @@ __device__ __forceinline__ void point_cells_frame(const PointCells& s, const int
             s.prange[(off + i) * 2 + 1] = hi;
         }
     __syncthreads();  // hist (the cell starts) is read above and advanced by nobody: fill[] takes the scatter counters
-    for (int i = tid; i < nr; i += T) {
-        const int x = (int)((double)s.kp_r[(off + i) * 2 + 0] * inv_w);
-        const int y = (int)((double)s.kp_r[(off + i) * 2 + 1] * inv_h);
+#pragma unroll
+    for (int k = 0; k < LPT; ++k) {
+        const int i = tid + T * k, c = rcel[k];
+        if (c == -2) continue;
         int pos;
-        if (point_in_grid(x, y)) {
-            const int c = y * STVO_GRID_COLS + x;
+        if (c >= 0) {
             pos = hist[c] + atomicAdd(&fill[c], 1);
             if (!LEAN) s.pitems[off + pos] = i;
         } else {  // the reference's out_of_bounds sink: never a candidate, scanned last
             pos = n_in + atomicAdd(&lds->extra, 1);
         }
         s.pperm[off + pos] = i;  // scan order = CSR (spatial) order
-        s.pcell[off + pos] = point_in_grid(x, y) ? y * STVO_GRID_COLS + x : -1;
+        s.pcell[off + pos] = c;
+        if (!LEAN) s.prank[off + i] = pos;
+    }
+    for (int i = tid + T * LPT; i < nr; i += T) {
+        const int x = (int)((double)s.kp_r[(off + i) * 2 + 0] * inv_w);
+        const int y = (int)((double)s.kp_r[(off + i) * 2 + 1] * inv_h);
+        const int c = point_in_grid(x, y) ? y * STVO_GRID_COLS + x : -1;
+        int pos;
+        if (c >= 0) {
+            pos = hist[c] + atomicAdd(&fill[c], 1);
+            if (!LEAN) s.pitems[off + pos] = i;
+        } else {
+            pos = n_in + atomicAdd(&lds->extra, 1);
+        }
+        s.pperm[off + pos] = i;
+        s.pcell[off + pos] = c;
         if (!LEAN) s.prank[off + i] = pos;
     }
 }

@@ -72,7 +72,7 @@ def split(db, pattern=None):
         print(f"{n:6d} {g:10d} {w:5d} {tot:12.1f} {avg:10.2f} {lo:10.2f} {hi:10.2f}  {k[:100]}")
 
 
-def timeline(db, n=60):
+def timeline(db, n=60, skip=0):  # the n dispatches in front of the last `skip`, in start order
     con = sqlite3.connect(db)
     view = _table_like(con, "kernels")
     cols = [r[1] for r in con.execute(f"pragma table_info('{view}')")]
@@ -85,7 +85,7 @@ def timeline(db, n=60):
     name, start, end = pick("name", "kernel_name"), pick("start", "start_timestamp"), pick("end", "end_timestamp")
     gx, wx = pick("grid_size_x", "grid_x", "grid_size"), pick("workgroup_size_x", "workgroup_x", "workgroup_size")
     queue = pick("queue_id", "queue", "stream_id", "stream") or "0"
-    rows = con.execute(f"select {start}, {end}, {queue}, {gx}, {wx}, {name} from {view} order by {start} desc limit {int(n)}").fetchall()[::-1]
+    rows = con.execute(f"select {start}, {end}, {queue}, {gx}, {wx}, {name} from {view} order by {start} desc limit {int(n)} offset {int(skip)}").fetchall()[::-1]
     t0 = rows[0][0]
     print(f"{'start_us':>10} {'end_us':>10} {'dur_us':>9} {'queue':>6} {'grid_x':>9} {'wg':>5}  kernel")
     for st, en, q, g, w, k in rows:
@@ -96,7 +96,7 @@ if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2])
     elif sys.argv[1] == "timeline":
-        timeline(sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else 60)
+        timeline(sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else 60, sys.argv[4] if len(sys.argv) > 4 else 0)
     elif sys.argv[1] == "split":
         split(sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else None)
     else:
