@@ -42,6 +42,9 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 #ifndef MF_TPB
 #define MF_TPB 2  // train tiles per workgroup barrier
 #endif
+#ifndef MF_FOLD_SLOTS
+#define MF_FOLD_SLOTS 5  // vector instructions scheduled behind each matrix instruction of the forward scan
+#endif
 constexpr int MF_BLOCK = 256;        // 4 waves
 constexpr int MF_TILE = 32;          // train rows per tile
 constexpr int MF_KEY_SHIFT = 13;     // key = (h << 13) + j - MF_KEY_BIAS, j < 8192
@@ -243,6 +246,7 @@ __global__ __launch_bounds__(MF_BLOCK, (QB == 1 ? 4 : QB == 2 ? 3 : 1)) void ham
             const v4i* frag = s_tile[t & (NBUF - 1)];
             const bool fold_prev = t > 0;  // tile t - 1 is a full tile here
             if (fold_prev) rebase();
+            key_t node[QB][5];
             v4i tf = frag[lane];
 #pragma unroll
             for (int kk = 0; kk < KSTEPS; ++kk) {
@@ -251,30 +255,37 @@ __global__ __launch_bounds__(MF_BLOCK, (QB == 1 ? 4 : QB == 2 ? 3 : 1)) void ham
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb) cur[qb] = mma(tf, qf[qb][kk], kk == 0 ? cidx : cur[qb]);
                 if (fold_prev) {
-                    // Three keys at a time: their two smallest (v_min3 + v_med3), merged into the running pair with
-                    // second' = min3(max(best, lo), second, mid), best' = min(best, lo) — 5 operations per 3 keys instead of 6.  The
-                    // kernel is bound by VALU issue once the matrix instructions are FP4 (the fold is 2/3 of its vector work):
-                    // 0.386 -> 0.336 ms per 1024 frames with 3 of the 16 keys of a block folded this way, all 15 + 1 below.
-                    // The previous tile's 16 accumulator registers per block are complete, so their order is free: K steps 0 .. 3
-                    // take 6 + 4 + 3 + 3 of them.
+                    // The fold as a TOURNAMENT of three-input nodes (round 5, last change).  The 16 keys of the previous tile and the
+                    // running best are the 17 leaves of a tree of eight nodes; a node forms the smallest of its three inputs (v_min3,
+                    // passed up) and their median (v_med3).  The root's minimum is the new best, and the new second is the smallest of
+                    // the old second and the eight medians: a median is the minimum of a subtree that does not hold the overall
+                    // minimum, so none is below the true second; and the true second — the smallest key that lost DIRECTLY to the
+                    // winner, or the old second — is among them.  16 + 4 operations per block and tile instead of the 27 of merging
+                    // three keys at a time into the pair (5 per 3 keys); the kernel is bound by vector + matrix ISSUE (rocprofv3:
+                    // SQ_ACTIVE_INST_ANY of the three waves of a SIMD = 1.08 of a wave's life) and the fold is most of its vector work.
+                    // The previous tile's 16 accumulator registers per block are complete, so their order is free: five operations
+                    // behind each of the four matrix instructions of a block.
 #pragma unroll
                     for (int qb = 0; qb < QB; ++qb) {
-                        auto fold3 = [&](int f) {
-                            const key_t k0 = prev[qb][f], k1 = prev[qb][f + 1], k2 = prev[qb][f + 2];
-                            const key_t lo = min3_f32(k0, k1, k2), mid = med3_f32(k0, k1, k2);
-                            second[qb] = min3_f32(max_f32(best[qb], lo), second[qb], mid);
-                            best[qb] = min_f32(best[qb], lo);
-                        };
+                        const acc_t& p = prev[qb];
+                        key_t(&a)[5] = node[qb];
                         if (kk == 0) {
-                            fold3(0);
-                            fold3(3);
+                            a[0] = min3_f32(p[0], p[1], p[2]);
+                            a[1] = min3_f32(p[3], p[4], p[5]);
+                            second[qb] = min3_f32(second[qb], med3_f32(p[0], p[1], p[2]), med3_f32(p[3], p[4], p[5]));
                         } else if (kk == 1) {
-                            fold3(6);
-                            fold(qb, prev[qb][15]);
+                            a[2] = min3_f32(p[6], p[7], p[8]);
+                            a[3] = min3_f32(p[9], p[10], p[11]);
+                            second[qb] = min3_f32(second[qb], med3_f32(p[6], p[7], p[8]), med3_f32(p[9], p[10], p[11]));
                         } else if (kk == 2) {
-                            fold3(9);
+                            a[4] = min3_f32(p[12], p[13], p[14]);
+                            const key_t b0 = min3_f32(a[0], a[1], a[2]);
+                            second[qb] = min3_f32(second[qb], med3_f32(p[12], p[13], p[14]), med3_f32(a[0], a[1], a[2]));
+                            a[0] = b0;
                         } else {
-                            fold3(12);
+                            const key_t b1 = min3_f32(a[3], a[4], p[15]), n1 = med3_f32(a[3], a[4], p[15]);
+                            second[qb] = min3_f32(second[qb], n1, med3_f32(a[0], b1, best[qb]));
+                            best[qb] = min3_f32(a[0], b1, best[qb]);
                         }
                     }
                 }
@@ -284,7 +295,7 @@ __global__ __launch_bounds__(MF_BLOCK, (QB == 1 ? 4 : QB == 2 ? 3 : 1)) void ham
                                                    //  lasts about as long as the 8 fold operations of one block take to issue — 0.418 ->
                                                    //  0.401 ms per 1024 frames against QB instructions followed by all of the fold)
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                         // one matrix instruction
-                    __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);                         // its shadow: a block's share of the fold (27 ops)
+                    __builtin_amdgcn_sched_group_barrier(0x002, MF_FOLD_SLOTS, 0);             // its shadow: a block's share of the fold (20 ops + rebasing)
                 }
                 tf = tf_ahead;
             }
