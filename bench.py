@@ -570,8 +570,8 @@ def correlated_leg(ctx_dev, rank, B=512, n=2000, steps=8):
         finally:
             ctx.close()
     out["note"] = ("reverse check = forward_plan kernel + ONE launch of the sparse reverse scans (hamming_knn2_mfma_reverse_kernel: light columns against "
-                   "the rows of S, heavy columns against all rows, the train side of an item resident in LDS; DESIGN.md section 5); the plan of a "
-                   "frame of near-duplicates degrades towards the full reverse scan")
+                   "the rows of S, heavy columns against all rows, the train side of an item resident in LDS; the plan writes m12 as far as the forward top-2 decides it, the scans clear the "
+                   "claimants they find blocked; DESIGN.md section 5); the plan of a frame of near-duplicates degrades towards the full reverse scan")
     return out
 
 
@@ -991,8 +991,11 @@ def main():
             "stage_ms": dict(stage_ms, steps_timed=n_timed,
                              note="stereo_points_stage = cells + grid matcher (with the tail of the association as its last phase) of the "
                                   "key-points (contains grid_scan = the matcher launch); the key-line stage (line_stereo_fused_kernel, "
-                                  "match_small_kernel) runs on a second stream forked at the start of the step: it shares the GPU with this "
-                                  "stage and delays the start of the persistent matcher's workgroups (0.16 ms alone)"),
+                                  "match_small_kernel) runs on a second stream.  These figures come from a SECOND pass over the same steps with an event "
+                                  "pair around every kernel; the markers change what runs beside what (the key-line kernels then share the GPU "
+                                  "with the point matcher: 0.14 ms alone, while in the timed region — fork behind the cells kernel, no markers — "
+                                  "they run beside the forward scan and stretch IT), so the stages do not add up to ms_per_step: "
+                                  "profiles/r05_step_timeline.txt has the dispatches of the timed region itself"),
         }
     pipe.close()
     ctx.close()

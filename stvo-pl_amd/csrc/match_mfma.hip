@@ -494,14 +494,9 @@ __global__ __launch_bounds__(MF_BLOCK, 4) void hamming_knn2_mfma_reverse_kernel(
                     int last_base = c0;
                     if (ntc > 0) {
                         // software pipeline, depth one tile (as the general scan): tile t's matrix instructions are issued, tile t - 1's
-                        // keys are folded in their shadow — three keys at a time; the chunk's last tile is folded after the loop
-                        auto fold3 = [&](const acc_t& p, int f) {
-                            const key_t k0 = p[f], k1 = p[f + 1], k2 = p[f + 2];
-                            const key_t lo = min3_f32(k0, k1, k2), mid = med3_f32(k0, k1, k2);
-                            second = min3_f32(max_f32(best, lo), second, mid);
-                            best = min_f32(best, lo);
-                        };
+                        // keys are folded in their shadow; the chunk's last tile is folded after the loop
                         auto do_tile = [&](acc_t& cur, acc_t& prev, int t) {
+                            key_t nd[5];
                             const v4i* frag = s_tile[t];
                             const bool fold_prev = t > 0;
                             if (fold_prev) {
@@ -523,20 +518,28 @@ __global__ __launch_bounds__(MF_BLOCK, 4) void hamming_knn2_mfma_reverse_kernel(
                                         // between the two).  The wait states of a 16-pass XDL write -> VALU read (19), tied to the
                                         // registers, in the shadow of this tile's first matrix instruction.
                                         asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 2" : "+v"(prev));
-                                        fold3(prev, 0);
-                                        fold3(prev, 3);
+                                        // (the fold as a tournament of v_min3 / v_med3 nodes, as in the forward scan above)
+                                        nd[0] = min3_f32(prev[0], prev[1], prev[2]);
+                                        nd[1] = min3_f32(prev[3], prev[4], prev[5]);
+                                        second = min3_f32(second, med3_f32(prev[0], prev[1], prev[2]), med3_f32(prev[3], prev[4], prev[5]));
                                     } else if (kk == 1) {
-                                        fold3(prev, 6);
-                                        fold(prev[15]);
+                                        nd[2] = min3_f32(prev[6], prev[7], prev[8]);
+                                        nd[3] = min3_f32(prev[9], prev[10], prev[11]);
+                                        second = min3_f32(second, med3_f32(prev[6], prev[7], prev[8]), med3_f32(prev[9], prev[10], prev[11]));
                                     } else if (kk == 2) {
-                                        fold3(prev, 9);
+                                        nd[4] = min3_f32(prev[12], prev[13], prev[14]);
+                                        const key_t b0 = min3_f32(nd[0], nd[1], nd[2]);
+                                        second = min3_f32(second, med3_f32(prev[12], prev[13], prev[14]), med3_f32(nd[0], nd[1], nd[2]));
+                                        nd[0] = b0;
                                     } else {
-                                        fold3(prev, 12);
+                                        const key_t b1 = min3_f32(nd[3], nd[4], prev[15]), n1 = med3_f32(nd[3], nd[4], prev[15]);
+                                        second = min3_f32(second, n1, med3_f32(nd[0], b1, best));
+                                        best = min3_f32(nd[0], b1, best);
                                     }
                                 }
                                 if (kk < KSTEPS - 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                                __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x002, MF_FOLD_SLOTS, 0);
                                 tf = tf_ahead;
                             }
                         };

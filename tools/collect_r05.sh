@@ -16,9 +16,12 @@ cd $R
 { echo "# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-extras (tools/collect_r05.sh); bench line of the profiled run:"; cat $OUT/bench_profiled.json; echo;
   python tools/rocprof_summary.py stats $DB; echo; echo "# the same dispatches split by launch shape (grid_x in work-items x workgroup size): one line per problem size of a kernel";
   python tools/rocprof_summary.py split $DB; } > $OUT/kernel_stats.txt
-{ echo "# The last steps of 'python bench.py --no-cpu-baseline --no-extras' under rocprofv3 --kernel-trace (tools/collect_r05.sh): every dispatch in start order,";
-  echo "# queue = HIP stream (the point stream and the key-line stream forked at the start of a step)";
-  python tools/rocprof_summary.py timeline $DB 60; } > $OUT/timeline.txt
+{ echo "# 'python bench.py --no-cpu-baseline --no-extras' under rocprofv3 --kernel-trace (tools/collect_r05.sh): every dispatch in start order, queue = HIP stream";
+  echo "# (1 = the point stream, 3 = the key-line stream, forked behind the cells kernel).  (a) steps of the TIMED region (dispatches 400 .. 447 of the run: steps back";
+  echo "# to back, no markers, no reads):";
+  python tools/rocprof_summary.py timeline $DB 48 -400;
+  echo; echo "# (b) the last dispatches of the run (the pass with an event pair around every kernel, then the parity sample): the markers change what runs beside what";
+  python tools/rocprof_summary.py timeline $DB 36; } > $OUT/timeline.txt
 rm -rf /tmp/kt
 bash tools/hbm_calib.sh > $OUT/hbm_calib.txt 2>&1
 PMCB="$BENCH --no-parity --no-clocks --steps 1 --warmup 1 --repeats 1"
@@ -30,6 +33,10 @@ done
 cd /tmp; rm -rf /tmp/pmc_g
 timeout 150 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --kernel-trace -d /tmp/pmc_g -- $PMCB > /dev/null 2>&1
 cd $R; python tools/rocprof_summary.py pmc $(find /tmp/pmc_g -name "*.db" | head -1) 2>/dev/null | grep -i "hamming_knn2_mfma\|pose\|grid_points_fused\|counter" > $OUT/pmc_sq.txt; rm -rf /tmp/pmc_g
+# where a wave's cycles go (quad-cycles: active / issue-stalled / parked), the forward scan and the pose kernel
+cd /tmp; rm -rf /tmp/pmc_w
+timeout 60 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_ACTIVE_INST_LDS --kernel-trace -d /tmp/pmc_w -- $PMCB > /dev/null 2>&1; echo "wave-cycle pass: exit $?"
+cd $R; python tools/rocprof_summary.py pmc $(find /tmp/pmc_w -name "*.db" | head -1) 2>/dev/null | grep -i "hamming_knn2_mfma_kernel\|pose2c\|counter" > $OUT/pmc_wave_cycles.txt; rm -rf /tmp/pmc_w
 bash tools/corr_prof.sh > $OUT/clustered_match.txt 2>&1; cp gpurun_out/corr/kernel_stats.txt $OUT/clustered_match_kernel_stats.txt 2>/dev/null
 tools/latency.sh gpurun_out/$T/latency.txt > /dev/null 2>&1
 cd /tmp; rm -rf /tmp/kt; timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/kt -- python $R/tools/lsd_probe.py --batch 1024 --iters 2 > $OUT/lsd_probe.txt 2>/dev/null

@@ -72,7 +72,7 @@ def split(db, pattern=None):
         print(f"{n:6d} {g:10d} {w:5d} {tot:12.1f} {avg:10.2f} {lo:10.2f} {hi:10.2f}  {k[:100]}")
 
 
-def timeline(db, n=60, skip=0):  # the n dispatches in front of the last `skip`, in start order
+def timeline(db, n=60, skip=0):  # the n dispatches in front of the last `skip`, in start order; skip < 0: the n dispatches behind the first -skip
     con = sqlite3.connect(db)
     view = _table_like(con, "kernels")
     cols = [r[1] for r in con.execute(f"pragma table_info('{view}')")]
@@ -85,7 +85,10 @@ def timeline(db, n=60, skip=0):  # the n dispatches in front of the last `skip`,
     name, start, end = pick("name", "kernel_name"), pick("start", "start_timestamp"), pick("end", "end_timestamp")
     gx, wx = pick("grid_size_x", "grid_x", "grid_size"), pick("workgroup_size_x", "workgroup_x", "workgroup_size")
     queue = pick("queue_id", "queue", "stream_id", "stream") or "0"
-    rows = con.execute(f"select {start}, {end}, {queue}, {gx}, {wx}, {name} from {view} order by {start} desc limit {int(n)} offset {int(skip)}").fetchall()[::-1]
+    if int(skip) < 0:
+        rows = con.execute(f"select {start}, {end}, {queue}, {gx}, {wx}, {name} from {view} order by {start} asc limit {int(n)} offset {-int(skip)}").fetchall()
+    else:
+        rows = con.execute(f"select {start}, {end}, {queue}, {gx}, {wx}, {name} from {view} order by {start} desc limit {int(n)} offset {int(skip)}").fetchall()[::-1]
     t0 = rows[0][0]
     print(f"{'start_us':>10} {'end_us':>10} {'dur_us':>9} {'queue':>6} {'grid_x':>9} {'wg':>5}  kernel")
     for st, en, q, g, w, k in rows:
