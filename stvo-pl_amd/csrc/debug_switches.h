@@ -31,6 +31,7 @@ struct DebugSwitches {
     int lsd_grow;        // STVO_LSD_GROW        0: the plain form of lsd_grow_kernel (candidates one after the other, sums through v_readlane)
     int lsd_waves;       // STVO_LSD_WAVES       0: batches of <= 8 images by lsd_grow_kernel (one wave per image) instead of lsd_grow_waves_kernel (16 waves per image)
     int lsd_sort_full;   // STVO_LSD_SORT_FULL   1: the pseudo-ordering sorts all 32 key bits instead of the bin bits only (lsd_kernels.hip)
+    int cells_ahead;     // STVO_CELLS_AHEAD     0: point_cells_kernel of a batch in the point stream (unset: on the line stream, ahead of the point stream's step)
     int grid_cells;      // STVO_GRID_CELLS      0: point_cells_kernel as its own launch for small batches too, 1: in the matcher whenever it fits
 };
 

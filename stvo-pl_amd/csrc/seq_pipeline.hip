@@ -639,6 +639,17 @@ struct stvo_seq {
     // 115-118) and its kernels are far too small to fill the GPU, so it runs concurrently on its own scratch
     hipStream_t line_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // Batches: the grid of frame k + 1 (point_cells_kernel) is enqueued on the LINE stream, which is idle from ~0.2 ms into step k on, and
+    // the point stream only waits for it in front of its matcher — 38 us less in the chain of a step (see seq_enqueue_step).  The kernel's
+    // outputs are double-buffered by the parity of the step (cells_buf[cur]): the grid of frame k + 1 may be built while the matcher
+    // of frame k still reads its own.
+    hipEvent_t ev_cells = nullptr, ev_upload = nullptr;
+    unsigned long long upload_seq = 0, upload_seen = 0;  // uploads enqueued on the point stream / the last one the line stream has been made to wait for
+    long long sl_forked_frame = -2;                      // the last step in which the line stream waited for an event of the point stream
+    struct CellsBuf {
+        int32_t *pstart, *pperm, *pcell, *plperm;
+        uint32_t* plstart;
+    } cells_buf[2] = {};
     unsigned long long *cover_l = nullptr, *top2_l = nullptr;
     int32_t* owner2_l = nullptr;
     stvo::LazyScratch lazy_l{};
@@ -781,6 +792,11 @@ int stvo_seq_create_multi(stvo_ctx* ctx, int B, int max_keypoints, int max_keyli
                  o_prank = c.take(nb * K * 4), o_pperm = c.take(nb * K * 4), o_prange = c.take(nb * K * 2 * 4), o_pcell = c.take(nb * K * 4);
     const bool lsort = K <= 2048 && mp->matching_s_ws >= 0 && mp->matching_s_ws <= stvo::GRID_LW - STVO_GRID_COLS;
     const size_t o_plstart = c.take(lsort ? nb * stvo::GRID_LSTART_STRIDE * 4 : 0), o_plperm = c.take(lsort ? nb * K * 4 : 0);
+    // second copy of what the lean point_cells_kernel writes (batches only: stvo_seq::cells_buf)
+    const bool cells2 = lsort && B >= 64;
+    const size_t o_pstart2 = c.take(cells2 ? nb * (STVO_GRID_CELLS + 1) * 4 : 0), o_pperm2 = c.take(cells2 ? nb * K * 4 : 0),
+                 o_pcell2 = c.take(cells2 ? nb * K * 4 : 0), o_plstart2 = c.take(cells2 ? nb * stvo::GRID_LSTART_STRIDE * 4 : 0),
+                 o_plperm2 = c.take(cells2 ? nb * K * 4 : 0);
     const size_t o_lxy = c.take(nb * M * 4 * 4), o_lstart = c.take(nb * (STVO_GRID_CELLS + 1) * 4),
                  o_litems = c.take(nb * M * stvo::LENT * 4), o_lrank = c.take(nb * M * 4), o_lperm = c.take(nb * M * 4),
                  o_ldir = c.take(nb * M * 2 * 8);
@@ -821,6 +837,8 @@ int stvo_seq_create_multi(stvo_ctx* ctx, int B, int max_keypoints, int max_keyli
               hip_ok(ctx, hipStreamCreateWithFlags(&s->line_stream, hipStreamNonBlocking), "hipStreamCreate seq") &&
               hip_ok(ctx, hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming), "hipEventCreate seq") &&
               hip_ok(ctx, hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming), "hipEventCreate seq") &&
+              hip_ok(ctx, hipEventCreateWithFlags(&s->ev_cells, hipEventDisableTiming), "hipEventCreate seq") &&
+              hip_ok(ctx, hipEventCreateWithFlags(&s->ev_upload, hipEventDisableTiming), "hipEventCreate seq") &&
               hip_ok(ctx, hipEventCreateWithFlags(&s->ev_stage[0], hipEventDisableTiming), "hipEventCreate seq") &&
               hip_ok(ctx, hipEventCreateWithFlags(&s->ev_stage[1], hipEventDisableTiming), "hipEventCreate seq");
     s->zero_copy = B <= 16;
@@ -887,6 +905,11 @@ int stvo_seq_create_multi(stvo_ctx* ctx, int B, int max_keypoints, int max_keyli
     if (lsort) {
         d.plstart = (uint32_t*)(D + o_plstart); d.plperm = (int32_t*)(D + o_plperm);
     }
+    s->cells_buf[0] = {d.pstart, d.pperm, d.pcell, d.plperm, d.plstart};
+    s->cells_buf[1] = s->cells_buf[0];
+    if (cells2)
+        s->cells_buf[1] = {(int32_t*)(D + o_pstart2), (int32_t*)(D + o_pperm2), (int32_t*)(D + o_pcell2), (int32_t*)(D + o_plperm2),
+                           (uint32_t*)(D + o_plstart2)};
     for (int t = 0; t < 2; ++t) {
         stvo_seq::Set& q = s->set[t];
         q.rc = (float4*)(D + o_set[t][0]);
@@ -952,6 +975,8 @@ int stvo_seq_destroy(stvo_seq* s) {
     }
     if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
     if (s->ev_join) (void)hipEventDestroy(s->ev_join);
+    if (s->ev_cells) (void)hipEventDestroy(s->ev_cells);
+    if (s->ev_upload) (void)hipEventDestroy(s->ev_upload);
     for (auto e : s->ev_stage)
         if (e) (void)hipEventDestroy(e);
     for (auto e : s->pev)
@@ -1065,6 +1090,10 @@ int stvo_seq_upload(stvo_seq* s, int slot, const stvo_frame_features* f) {
         HIP_TRY(ctx, hipMemcpyAsync(s->raw_dev[slot], H, s->raw_bytes, hipMemcpyHostToDevice, ctx->stream));
     }
     s->stage_upload[sb] = ++s->uploads;
+    if (s->B >= 64 && s->line_stream) {  // batches: the line stream may read a slot first (stvo_seq::ev_cells); no event in single-stream operation
+        HIP_TRY(ctx, hipEventRecord(s->ev_upload, ctx->stream));
+        ++s->upload_seq;
+    }
     return STVO_OK;
 }
 
@@ -1088,6 +1117,10 @@ int stvo_seq_upload_dev(stvo_seq* s, int slot, const stvo_frame_features* f) {
     a.ldesc_l = (uint8_t*)(Rw + s->off_ldesc_l); a.n_kl_l = (int32_t*)(Rw + s->off_nll); a.kl_r = (float*)(Rw + s->off_kl_r);
     a.ldesc_r = (uint8_t*)(Rw + s->off_ldesc_r); a.n_kl_r = (int32_t*)(Rw + s->off_nlr);
     hipLaunchKernelGGL(seq_ingest_kernel, dim3(s->B), dim3(256), 0, ctx->stream, a);
+    if (s->B >= 64 && s->line_stream) {
+        HIP_TRY(ctx, hipEventRecord(s->ev_upload, ctx->stream));
+        ++s->upload_seq;
+    }
     s->st_dirty = true;
     s->raw_split[slot] = 0;
     s->raw_max_lines[slot] = s->M;
@@ -1104,7 +1137,7 @@ struct StepFlags {
 
 // Enqueues the kernel chain of one step on the context's stream (and the line stream).  No state of `s` changes here, so
 // the same code serves direct launches and stream capture into a hipGraph.
-int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl) {
+int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl, bool* forked_by_event = nullptr) {
     stvo_ctx* ctx = s->ctx;
     const int B = s->B, K = s->K, M = s->M;
     hipStream_t st = ctx->stream;
@@ -1155,6 +1188,7 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl) {
     const bool late_fork = par && fork_sw == 1;
     const bool mid_fork = par && s->op.has_points && (fork_sw == 2 || (fork_sw == stvo::DBG_UNSET && B >= 64));
     const bool fork_free = par && s->raw_split[slot] && !s->st_dirty && !s->graph_mode;  // see stvo_seq::st_dirty
+    if (forked_by_event) *forked_by_event = par && (late_fork || mid_fork || !fork_free);
     if (par && !late_fork && !mid_fork && !fork_free) {
         HIP_TRY(ctx, hipEventRecord(s->ev_fork, st));
         HIP_TRY(ctx, hipStreamWaitEvent(sl, s->ev_fork, 0));
@@ -1187,12 +1221,26 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl) {
             // one frame per workgroup of the matcher (single-stream operation, small batches): the grid of the frame is the matcher's
             // first phase — one dependent launch less in the chain of a frame
             g.fused_cells = g.lean_cells && B <= stvo::device_cu_count() && stvo::dbg().grid_cells != 0;
+            // Batches: the grid of this frame on the LINE stream, which has been idle since ~0.2 ms into the previous step — the kernel (38 us
+            // per 1024 frames; few instructions, mostly waiting) then runs beside the previous step's forward scan or pose kernel and
+            // the point stream meets it with one awaited event in front of the matcher.  Safe because (a) its outputs are double-buffered
+            // by the parity of the step (the matcher of the previous frame may still read the other copy; the copy written here was
+            // last read two steps ago, and the line stream's work of the previous step waited for an event the point stream recorded
+            // after that: sl_forked_frame), (b) the line stream has been made to wait for every upload enqueued on the point stream
+            // (stvo_seq_step_dev), (c) everything else the kernel reads is the resident slot.  STVO_CELLS_AHEAD=0: in the point stream.
+            const bool cells_ahead = par && mid_fork && g.lean_cells && !g.fused_cells && !tev && !s->pev[0] && !s->graph_mode &&
+                                     s->cells_buf[0].pstart != s->cells_buf[1].pstart && s->sl_forked_frame == (long long)s->frame_idx - 1 &&
+                                     stvo::dbg().cells_ahead != 0;
             if (g.fused_cells)
                 g.cells = stvo::point_cells_args(d);
             else if (g.lean_cells)
-                hipLaunchKernelGGL(stvo::point_cells_kernel<true>, dim3(B), dim3(256), 0, st, d);
+                hipLaunchKernelGGL(stvo::point_cells_kernel<true>, dim3(B), dim3(256), 0, cells_ahead ? sl : st, d);
             else
                 hipLaunchKernelGGL(stvo::point_cells_kernel<false>, dim3(B), dim3(256), 0, st, d);
+            if (cells_ahead) {
+                HIP_TRY(ctx, hipEventRecord(s->ev_cells, sl));
+                HIP_TRY(ctx, hipStreamWaitEvent(st, s->ev_cells, 0));
+            }
             if (mid_fork) {
                 HIP_TRY(ctx, hipEventRecord(s->ev_fork, st));
                 HIP_TRY(ctx, hipStreamWaitEvent(sl, s->ev_fork, 0));
@@ -1380,6 +1428,15 @@ int stvo_seq_step_dev(stvo_seq* s, int slot) {
     fl.lines_now = s->op.has_lines && s->raw_lines[slot];
     fl.lines_prev = s->op.has_lines && s->set_lines[s->cur ^ 1];
     fl.track = s->frame_idx > 0;
+    {   // the grid buffers of this step (stvo_seq::cells_buf), and the line stream behind every upload the point stream holds
+        const stvo_seq::CellsBuf& cb = s->cells_buf[s->cur];
+        s->d.pstart = cb.pstart; s->d.pperm = cb.pperm; s->d.pcell = cb.pcell; s->d.plperm = cb.plperm; s->d.plstart = cb.plstart;
+        if (s->line_stream && s->upload_seen != s->upload_seq) {
+            HIP_TRY(ctx, hipStreamWaitEvent(s->line_stream, s->ev_upload, 0));
+            s->upload_seen = s->upload_seq;
+        }
+    }
+    bool forked = false;
     // the first steps run directly (lazy one-time initialisations must not happen inside a capture); timing / fetch /
     // profiling modes record events the host waits on, which a captured graph cannot provide
     const bool use_graph = s->graph_mode && s->frame_idx >= 2 && !s->timing && !s->fetch && !s->pev[0] && !ctx->overlap;
@@ -1393,7 +1450,7 @@ int stvo_seq_step_dev(stvo_seq* s, int slot) {
             bool ok = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
             int rc = STVO_ERR_HIP;
             if (ok) {
-                rc = seq_enqueue_step(s, slot, fl);
+                rc = seq_enqueue_step(s, slot, fl, &forked);
                 ok = hipStreamEndCapture(ctx->stream, &graph) == hipSuccess && rc == STVO_OK && graph != nullptr;
             }
             if (ok) ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
@@ -1401,15 +1458,16 @@ int stvo_seq_step_dev(stvo_seq* s, int slot) {
             if (!ok) {  // capture unsupported for some node: fall back to direct launches for good
                 (void)hipGetLastError();
                 s->graph_mode = false;
-                TRY(seq_enqueue_step(s, slot, fl));
+                TRY(seq_enqueue_step(s, slot, fl, &forked));
             } else {
                 it = s->graphs.emplace(key, exec).first;
             }
         }
         if (s->graph_mode) HIP_TRY(ctx, hipGraphLaunch(it->second, ctx->stream));
     } else {
-        TRY(seq_enqueue_step(s, slot, fl));
+        TRY(seq_enqueue_step(s, slot, fl, &forked));
     }
+    if (forked && !s->graph_mode) s->sl_forked_frame = s->frame_idx;
     s->st_dirty = true;
     s->set_lines[s->cur] = fl.lines_now;
     s->last_lines = fl.lines_now;

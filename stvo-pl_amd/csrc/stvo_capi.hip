@@ -33,6 +33,7 @@ DebugSwitches parse_switches() {
     const char* lf = std::getenv("STVO_LINE_FORK");
     d.line_fork_late = lf ? (lf[0] == 'l' ? 1 : (lf[0] == 'm' ? 2 : 0)) : DBG_UNSET;
     d.line_first = env_int("STVO_LINE_FIRST");
+    d.cells_ahead = env_int("STVO_CELLS_AHEAD");
     d.line_fused = env_int("STVO_LINE_FUSED");
     d.match_small = env_int("STVO_MATCH_SMALL");
     d.match_lazy = env_int("STVO_MATCH_LAZY");
