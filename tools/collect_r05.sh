@@ -17,7 +17,7 @@ cd $R
   python tools/rocprof_summary.py stats $DB; echo; echo "# the same dispatches split by launch shape (grid_x in work-items x workgroup size): one line per problem size of a kernel";
   python tools/rocprof_summary.py split $DB; } > $OUT/kernel_stats.txt
 { echo "# 'python bench.py --no-cpu-baseline --no-extras' under rocprofv3 --kernel-trace (tools/collect_r05.sh): every dispatch in start order, queue = HIP stream";
-  echo "# (1 = the point stream, 3 = the key-line stream, forked behind the cells kernel).  (a) steps of the TIMED region (dispatches 400 .. 447 of the run: steps back";
+  echo "# (1 = the point stream, 3 = the key-line stream: forked in front of the point matcher, and the builder of the NEXT frame's grid — point_cells_kernel — once its key-line work is done).  (a) steps of the TIMED region (dispatches 400 .. 447 of the run: steps back";
   echo "# to back, no markers, no reads):";
   python tools/rocprof_summary.py timeline $DB 48 -400;
   echo; echo "# (b) the last dispatches of the run (the pass with an event pair around every kernel, then the parity sample): the markers change what runs beside what";
