@@ -207,13 +207,17 @@ def test_match_at_the_matrix_core_index_limit(oracle):
         ctx.close()
 
 
-def test_match_valu_kernels_still_agree():
+@pytest.mark.parametrize("qb", ["0", "1", "4"])
+def test_match_other_kernel_forms_still_agree(qb):
     """The VALU matcher (K1 + K1v, STVO_KNN_MFMA=0) is kept for sizes K1m cannot index and as the comparison point of
-    the profiles: run this file's parity cases against it in a child process (the switch is read once per process)."""
+    the profiles; K1m's instantiations with one and with four query blocks per wave (STVO_KNN_MFMA=1 / 4; the library's choice is
+    2) share the forward kernel's text — the top-2 fold reads matrix-core accumulators through inline asm, one matrix instruction
+    behind their last write when a wave holds a single block.  Run this file's parity cases against each in a child process (the
+    switch is read once per process)."""
     import os, subprocess, sys
-    if os.environ.get("STVO_KNN_MFMA") == "0":
+    if os.environ.get("STVO_KNN_MFMA") is not None:
         pytest.skip("already the child run")
-    env = dict(os.environ, STVO_KNN_MFMA="0")
+    env = dict(os.environ, STVO_KNN_MFMA=qb)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q",
                         "-k", "bit_exact or adversarial or key_edges or many_ties or fuzz"], env=env, capture_output=True, text=True,
                        timeout=900)
