@@ -757,6 +757,110 @@ def configs3_leg(local_rank, seqs, B=512, steps=10):
                    "only as the fallback of :359")
     return out
 
+SHORT_LINE_MAX = 6000   # bytes: the driver keeps a bounded tail of stdout — round 5's 20 KB line was recorded as "parsed": null
+
+
+def _num(v, nd=6):
+    """Numbers of the short line to `nd` significant digits (every digit beyond is noise of the run)."""
+    if isinstance(v, bool) or v is None or isinstance(v, (int, str)):
+        return v
+    if isinstance(v, float):
+        return float(f"{v:.{nd}g}")
+    if isinstance(v, dict):
+        return {k: _num(x, nd) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_num(x, nd) for x in v]
+    return v
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def short_line(full):
+    """The ONE stdout line of the driver contract, <= SHORT_LINE_MAX bytes: the contract's keys, the three roofline objects (numbers only),
+    cpu_baseline and a number per extra leg.  Every note, every `what` and every extra leg in full goes to bench_extras.json."""
+    roof_keys = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_ops_per_launch", "algorithmic_bytes_per_launch",
+                 "avg_launch_ms", "launches_timed", "pairs_per_s", "hbm_view_frac")
+    out = _pick(full, ("metric", "value", "unit", "n_gpus", "rccl_ranks", "collective_backend", "steps", "warmup", "ms_per_step", "higher_is_better",
+                       "scaling", "vs_baseline", "dtype", "data"))
+    rep = full.get("repeats") or {}
+    out["repeats"] = _pick(rep, ("n", "value_min", "value_max"))
+    cfg = full.get("config") or {}
+    out["config"] = _pick(cfg, ("workload", "streams_per_gpu", "resident_frames_per_stream", "keypoints_per_image", "keylines_per_image",
+                                "mean_stereo_points", "mean_matched_points", "mean_matched_lines", "parallelism", "committed_pose_fraction",
+                                "value_clustered", "value_clustered_over_value"))
+    par = full.get("parity_sampled")
+    out["parity_sampled"] = _pick(par, ("ok", "skipped", "frame_pairs_checked", "max_rot_err_rad", "max_trans_err_m")) if isinstance(par, dict) else par
+    for k in ("roofline", "roofline_pose", "roofline_grid_scan"):
+        if isinstance(full.get(k), dict):
+            out[k] = _pick(full[k], roof_keys)
+            if isinstance(full[k].get("fp64_view"), dict):
+                out[k]["fp64_frac"] = full[k]["fp64_view"].get("frac")
+    if "roofline" in out:
+        out["roofline"]["timing"] = "hipEvent pairs, light pass (see bench_extras.json)"
+    for k in ("per_rank_frame_pairs_per_s", "scaling_efficiency_vs_n1"):
+        if full.get(k) is not None:
+            out[k] = full[k]
+    cb = full.get("cpu_baseline")
+    if isinstance(cb, dict):
+        out["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "sample", "ms_per_frame", "ms_per_frame_reference_fanout_4_threads",
+                                         "speedup_vs_1_core", "speedup_vs_reference_fanout"))
+        ss = cb.get("single_stream_ms")
+        if isinstance(ss, dict):
+            out["cpu_baseline"]["single_stream_ms"] = _pick(ss, ("seq_push", "handler"))
+    # one number per extra leg (the legs in full: bench_extras.json)
+    legs = {}
+
+    def leg(name, *path):
+        v = full.get(path[0])
+        for k in path[1:]:
+            v = v.get(k) if isinstance(v, dict) else None
+        if isinstance(full.get(path[0]), dict) and "error" in full[path[0]]:
+            legs[name] = "error"
+        elif v is not None:
+            legs[name] = v
+    leg("configs1_frame_pairs_per_s", "configs1", "value")
+    for m in ("gn", "robust_gn", "lm"):
+        leg(f"configs3_{m}_frame_pairs_per_s", "configs3", m, "value")
+    leg("configs3_single_stream_ms", "configs3", "gn", "single_stream_push_ms_median")
+    leg("configs3_single_stream_vs_oracle_1_core", "configs3", "gn", "single_stream_speedup_vs_oracle_1_core")
+    leg("orb_images_per_s", "orb_front_end", "kitti_1_level", "images_per_s")
+    leg("images_to_poses_pairs_per_s", "images_to_poses", "stereo_pairs_per_s")
+    leg("lsd_images_per_s", "lsd_front_end", "images_per_s")
+    leg("lsd_one_image_ms", "lsd_front_end", "one_image_ms")
+    leg("lsd_one_image_vs_oracle_1_core", "lsd_front_end", "one_image_vs_oracle_1_core")
+    leg("images_to_poses_with_lines_pairs_per_s", "images_to_poses_with_lines", "stereo_pairs_per_s")
+    leg("clustered_reverse_check_ms", "reverse_check_correlated", "clustered", "reverse_check_ms")
+    if legs:
+        out["legs"] = legs
+    out["extras_file"] = full.get("extras_file")
+    out = _num(out)
+    line = json.dumps(out, separators=(",", ":"))
+    if len(line) > SHORT_LINE_MAX:   # never again: drop the optional parts in order until it fits
+        for k in ("legs", "roofline_grid_scan", "roofline_pose"):
+            out.pop(k, None)
+            line = json.dumps(out, separators=(",", ":"))
+            if len(line) <= SHORT_LINE_MAX:
+                break
+    return line
+
+
+def write_extras(full, path=None):
+    """Everything the run measured, with every note: bench_extras.json beside bench.py (and in gpurun_out/ when that exists)."""
+    paths = [path or os.path.join(ROOT, "bench_extras.json")]
+    if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        paths.append(os.path.join(ROOT, "gpurun_out", "bench_extras.json"))
+    written = None
+    for q in paths:
+        try:
+            with open(q, "w") as f:
+                json.dump(full, f, indent=1)
+            written = written or os.path.relpath(q, ROOT)
+        except OSError:
+            pass
+    return written
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -774,6 +878,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-clocks", action="store_true", help="skip the rocm-smi clock sample (it keeps enqueueing steps until rocm-smi answers: counter passes, where every dispatch costs seconds)")
     ap.add_argument("--no-extras", action="store_true", help="skip the latency / configs[1] / correlated-descriptor legs")
+    ap.add_argument("--print-extras", action="store_true", help="also print the full record (bench_extras.json) on stderr")
     args = ap.parse_args()
 
     # ---- `--gpus N` from a plain `python bench.py`: spawn N ranks (one process per GPU) under torch.distributed.run
@@ -841,7 +946,7 @@ def main():
     ctx.synchronize()
     # ---- the timed region: EXACTLY --steps steps between barrier + synchronize on both sides, max over ranks; repeated
     # --repeats times back to back, `value` = the median repeat (min / max beside it)
-    rep_dt = []
+    rep_dt, rep_dt_local = [], []
     frames_total = B * args.steps * world
     for _ in range(max(1, args.repeats)):
         torch.cuda.synchronize()
@@ -857,9 +962,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         dt_r = time.perf_counter() - t0
+        rep_dt_local.append(dt_r)
         frames_total, dt_r = shard.aggregate(dist, B * args.steps, dt_r, device=agg_dev)   # sum of frame pairs, max of seconds
         rep_dt.append(dt_r)
     dt = float(np.median(rep_dt))
+    # reporting only: every rank's own rate (its frame pairs / its own median time), gathered to rank 0
+    per_rank = shard.gather_scalars(dist, B * args.steps / float(np.median(rep_dt_local)), device=agg_dev)
 
     clocks = None
     if rank == 0 and not args.no_clocks:   # outside the timed region: a few hundred more steps while rocm-smi takes its sample
@@ -875,23 +983,45 @@ def main():
 
     out = None
     if rank == 0:
-        # ---- per-kernel figures, measured LIVE in a second pass over the same steps (same streams, same slot order): hipEvent pairs
-        # around the kernels on the stream they run on.  Separate from the pass that produced `value` because every marker is a
-        # barrier packet that keeps a kernel from starting under the tail of the previous one.
+        # ---- per-kernel figures, measured LIVE behind the timed region, same streams, same slot order, hipEvent pairs on the stream the
+        # kernels run on.  Two passes.  (B) counting pass: an event pair around EVERY stage and a read after every step -> `stage_ms`
+        # (bench_extras.json only: the markers change what runs beside what) and the set sizes / match counts / evaluations of every slot
+        # transition, which depend on the transition alone.  (A) light pass: the steps back to back exactly as in the timed region —
+        # key-line stream unmarked, next frame's grid built ahead on it — with pairs around the three big kernels of the point stream
+        # only (stvo_seq_set_stage_timing(.., 2)) -> `roofline*`: each kernel keeps the neighbours it has in the region that produced
+        # `value` (profiles/<tag>_kernel_stats.txt is the rocprofv3 view of the same command).
         pipe.set_stage_timing(True)
-        pairs, n1s, n2s, nps, nls, grid_b = [], [], [], [], [], []
-        prev_counts = counts
-        evals = []
+        per_tr = {}   # (prev slot, slot) -> (pairs, n1, n2, matched points, matched lines, evaluations)
+        n_by_slot = {}
+        prev_counts, prev_slot = counts, last_slot
         for _ in range(args.steps):
             last_slot = next(order); pipe.step_dev(last_slot)
             r_k, c_k = pipe.read()
-            evals.append(float(r_k["iters"].sum()))
             n_prev, n_curr = prev_counts[:, 0].astype(np.int64), c_k[:, 0].astype(np.int64)
-            pairs.append(float((n_prev * n_curr).sum())); n1s.append(float(n_prev.sum())); n2s.append(float(n_curr.sum()))
-            nps.append(float(c_k[:, 2].sum())); nls.append(float(c_k[:, 3].sum()))
-            prev_counts = c_k
+            per_tr[(prev_slot, last_slot)] = (float((n_prev * n_curr).sum()), float(n_prev.sum()), float(n_curr.sum()),
+                                              float(c_k[:, 2].sum()), float(c_k[:, 3].sum()), float(r_k["iters"].sum()))
+            n_by_slot[last_slot] = float(n_curr.sum())
+            prev_counts, prev_slot = c_k, last_slot
+        stage_ms_full, n_timed_full = pipe.get_stage_timing()
+        pipe.set_stage_timing(2)
+        tr_seq = []
+        for _ in range(args.steps):
+            prev_slot, last_slot = last_slot, next(order)
+            pipe.step_dev(last_slot)
+            tr_seq.append((prev_slot, last_slot))
+        ctx.synchronize()
         stage_ms, n_timed = pipe.get_stage_timing()
         pipe.set_stage_timing(False)
+        missing = [t for t in tr_seq if t not in per_tr]
+        if missing:   # (fewer steps than the slot period: count the transitions the counting pass did not see)
+            for t in dict.fromkeys(missing):
+                pipe.step_dev(t[0]); _, c_a = pipe.read()
+                pipe.step_dev(t[1]); r_k, c_k = pipe.read()
+                n_prev, n_curr = c_a[:, 0].astype(np.int64), c_k[:, 0].astype(np.int64)
+                per_tr[t] = (float((n_prev * n_curr).sum()), float(n_prev.sum()), float(n_curr.sum()),
+                             float(c_k[:, 2].sum()), float(c_k[:, 3].sum()), float(r_k["iters"].sum()))
+            last_slot = missing[-1][1]
+        pairs, n1s, n2s, nps, nls, evals = (list(v) for v in zip(*[per_tr[t] for t in tr_seq]))
         # parity at the headline shape: 8 streams of this run (sequence ids 0-7 = all three calibrations) vs the oracle
         if args.no_parity:
             parity = {"skipped": True}
@@ -905,7 +1035,8 @@ def main():
         ops = pairs_l * K1M_OPS_PER_PAIR
         k1_bytes = 32.0 * (n1_l + n2_l) + 8.0 * n1_l      # descriptors in once, one packed top-2 per prev row out
         k1_tops = ops / (k1_ms * 1e-3) / 1e12 if k1_ms > 0 else 0.0
-        timing = "hipEvent pairs around the launch(es), on the launch stream, over a second pass of the same K steps"
+        timing = ("hipEvent pairs around the launch on its stream, over K more steps enqueued back to back as in the timed region "
+                  "(markers on these three kernels only; key-line stream unmarked)")
         k1_name = "hamming_knn2_mfma_kernel<2, 0>"
         roofline = {"kernel": k1_name, "bound": "mfma", "achieved": k1_tops, "peak": FP4_MFMA_PEAK_TOPS, "unit": "TFLOP/s",
                     "unit_note": "multiply-accumulate ops (TOP/s), 2 x 256 per 256-bit Hamming distance, on FP4 (e2m1) operands: peak = the dense "
@@ -915,7 +1046,7 @@ def main():
                                         "note": "the same launch against the dense int8 peak the kernel was priced on while it used i8 operands "
                                                 "(rounds 1-3: 0.57 - 0.60)"}, "traffic": committed_traffic(k1_name, col=3),  # the key-point launch (the key-line launch of the same kernel is ~20x smaller)
                     "traffic_source": TRAFFIC_SRC,
-                    "algorithmic_ops_per_launch": ops, "algorithmic_bytes_per_launch": k1_bytes, "avg_launch_ms": k1_ms,
+                    "algorithmic_ops_per_launch": ops, "algorithmic_bytes_per_launch": k1_bytes, "avg_launch_ms": k1_ms, "launches_timed": n_timed,
                     "timing": timing, "frac_of_measured_mfma_floor": k1_tops / 9099.0,  # register-only FP4 floor of the guide
                     "hbm_view_frac": k1_bytes / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if k1_ms > 0 else 0.0,
                     # SURVEY.md section 8(d)'s own units for match_bf: unique (query, train) distances per second, and the integer-VALU
@@ -944,7 +1075,7 @@ def main():
         pose_tf = pose_flops / (pose_ms * 1e-3) / 1e12 if pose_ms > 0 else 0.0
         roofline_pose = {"kernel": pose_name, "bound": "hbm", "achieved": pose_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": pose_gbs / HBM_PEAK_GBS, "traffic": committed_traffic(pose_name), "traffic_source": TRAFFIC_SRC,
-                         "algorithmic_bytes_per_launch": pose_bytes, "avg_launch_ms": pose_ms, "timing": timing,
+                         "algorithmic_bytes_per_launch": pose_bytes, "avg_launch_ms": pose_ms, "launches_timed": n_timed, "timing": timing,
                          "fp64_view": {"achieved": pose_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": pose_tf / FP64_PEAK_TFLOPS,
                                        "algorithmic_flops_per_launch": pose_flops, "mean_evaluations_per_pair": evals_l,
                                        "note": "(150 Np + 400 Nl) flop per evaluation x evaluations per frame pair (SURVEY.md 8d)"},
@@ -963,7 +1094,7 @@ def main():
         scan_name = "grid_points_fused_kernel" if fused else "grid_scan_kernel<false"
         roofline_grid = {"kernel": scan_name if fused else "grid_scan_kernel<false, 1> + <false, 2>", "bound": "hbm", "achieved": scan_gbs, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": scan_gbs / HBM_PEAK_GBS, "traffic": committed_traffic(scan_name), "traffic_source": TRAFFIC_SRC,
-                         "algorithmic_bytes_per_launch": scan_bytes, "avg_launch_ms": scan_ms, "timing": timing,
+                         "algorithmic_bytes_per_launch": scan_bytes, "avg_launch_ms": scan_ms, "launches_timed": n_timed, "timing": timing,
                          "note": "matchGrid (points), all frames in one launch: 32 (N1 + N2) + 8 N1 + 4 (3073 + N2) + 4 N1 bytes per frame"
                                  + (", and as its last phase the tail of the stereo association (filters, back-projection, ordered compaction: "
                                     "8 (N1 + N2) + 4 N1 bytes in, 48 bytes per stereo point out: a 16-byte compact record + the descriptor row)" if fused_tail else "") +
@@ -987,15 +1118,19 @@ def main():
                        "mean_stereo_points": n2_l / B, "mean_matched_points": np_l / B, "mean_matched_lines": nl_l / B,
                        "cameras": "kitti00-02 (seq 0-2), kitti03 (seq 3), kitti04-10 (seq 4-7)",
                        "parallelism": f"seq-shard x{world}", "committed_pose_fraction": ok_frac},
+            "per_rank_frame_pairs_per_s": per_rank if world > 1 else None,
+            # (the driver computes scaling efficiency itself; this is a convenience when the N = 1 value of the same box is handed in)
+            "scaling_efficiency_vs_n1": (frames_total / dt / (world * float(os.environ["STVO_N1_VALUE"]))
+                                         if world > 1 and os.environ.get("STVO_N1_VALUE") else None),
             "roofline": roofline, "roofline_pose": roofline_pose, "roofline_grid_scan": roofline_grid, "gpu_clocks": clocks,
-            "stage_ms": dict(stage_ms, steps_timed=n_timed,
+            "stage_ms": dict(stage_ms_full, steps_timed=n_timed_full,
                              note="stereo_points_stage = cells + grid matcher (with the tail of the association as its last phase) of the "
                                   "key-points (contains grid_scan = the matcher launch); the key-line stage (line_stereo_fused_kernel, "
-                                  "match_small_kernel) runs on a second stream.  These figures come from a SECOND pass over the same steps with an event "
-                                  "pair around every kernel; the markers change what runs beside what (the key-line kernels then share the GPU "
+                                  "match_small_kernel) runs on a second stream.  These figures come from the COUNTING pass (an event pair around every "
+                                  "stage, a read after every step; the roofline objects come from the light pass instead); the markers change what runs beside what (the key-line kernels then share the GPU "
                                   "with the point matcher: 0.14 ms alone, while in the timed region — fork behind the cells kernel, no markers — "
                                   "they run beside the forward scan and stretch IT), so the stages do not add up to ms_per_step: "
-                                  "profiles/r05_step_timeline.txt has the dispatches of the timed region itself"),
+                                  "profiles/<tag>_step_timeline.txt has the dispatches of the timed region itself"),
         }
     pipe.close()
     ctx.close()
@@ -1050,7 +1185,10 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        out["extras_file"] = write_extras(out)
+        if args.print_extras:   # the full record on an EARLIER line of stderr; stdout carries the one short line only
+            print("bench_extras: " + json.dumps(out), file=sys.stderr)
+        print(short_line(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -207,7 +207,10 @@ int stvo_seq_strides(const stvo_seq* seq, int32_t* stride_pts, int32_t* stride_l
  * the stream the kernels run on, stage 0 = the whole stereo point stage (cells + grid matcher + tail), 1 = the two
  * grid_scan passes of the point grid matcher alone, 2 = the forward top-2 scan of the point f2f match (K1m), 3 = plan +
  * reverse scans of its mutual check, 4 = the pose kernel.  get synchronises, returns the average milliseconds per stage over
- * the steps measured since the last get / set (n_steps = the largest number of samples any stage has) and resets. */
+ * the steps measured since the last get / set (n_steps = the largest number of samples any stage has) and resets.
+ * enable = 2 ("light"): pairs around stages 1, 2 and 4 only — the three big kernels of the point stream — and the step is otherwise
+ * enqueued exactly as an untimed one (key-line stream unmarked, the next frame's grid built ahead on it), so the kernels keep the
+ * neighbours they have in the timed region; stages 0 and 3 report 0. */
 #define STVO_SEQ_NSTAGE 5
 int stvo_seq_set_stage_timing(stvo_seq* seq, int enable);
 int stvo_seq_get_stage_timing(stvo_seq* seq, float avg_ms[STVO_SEQ_NSTAGE], int32_t* n_steps);

@@ -635,18 +635,18 @@ void launch_match_mutual_lazy(hipStream_t s, int B, int row_stride, const uint8_
         // m12): the plan writes m12 as far as the forward top-2 decides it, the reverse scans clear the claimants they find blocked.
         const ReversePlan rp = reverse_plan(w, B, row_stride);
         if (wait_before_m12_write) (void)hipStreamWaitEvent(s, wait_before_m12_write, 0);
-        if (tev) (void)hipEventRecord(tev[2], s);
+        if (tev && tev[2]) (void)hipEventRecord(tev[2], s);
         hipLaunchKernelGGL(forward_plan_kernel, dim3(B), dim3(PLAN_BLOCK), (size_t)row_stride * 7, s, B, nseg, row_stride, w.knn12,
                            n1, n2, nnr, m12, claim, w.qsel, rp.tsel, w.nsel);
         launch_reverse_scans(s, B, row_stride, d1, n1, d2, nnr, w, rp, m12);
-        if (tev) (void)hipEventRecord(tev[3], s);
+        if (tev && tev[3]) (void)hipEventRecord(tev[3], s);
         return;
     }
     hipLaunchKernelGGL(nnr_forward_kernel, grid2, dim3(256), 0, s, nseg, row_stride, w.knn12, n1, n2, nnr, w.cand, claim);
     hipLaunchKernelGGL(compact_need_kernel, dim3(B), dim3(256), 0, s, row_stride, claim, n2, w.qsel, w.nsel, blocked);
-    if (tev) (void)hipEventRecord(tev[2], s);
+    if (tev && tev[2]) (void)hipEventRecord(tev[2], s);
     launch_hamming_verify(s, B, row_stride, d1, n1, d2, nnr, w, lds_pad_bytes, nseg, m12);
-    if (tev) (void)hipEventRecord(tev[3], s);
+    if (tev && tev[3]) (void)hipEventRecord(tev[3], s);
     if (wait_before_m12_write) (void)hipStreamWaitEvent(s, wait_before_m12_write, 0);
     hipLaunchKernelGGL(nnr_reverse_check_kernel, dim3(B), dim3(1024), 0, s, row_stride, claim, blocked, n1, m12);
 }

@@ -241,7 +241,7 @@ __global__ __launch_bounds__(MF_BLOCK, (QB == 1 ? 4 : QB == 2 ? 3 : 1)) void ham
         const v8i a8 = {tf.x, tf.y, tf.z, tf.w, 0, 0, 0, 0}, b8 = {q.x, q.y, q.z, q.w, 0, 0, 0, 0};  // (FP4 reads four dwords)
         return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, c, 4, 4, 0, MF_SCALE_2_4, 0, MF_SCALE_2_4);
     };
-    auto mma_fold = [&](acc_t (&cur)[QB], const acc_t (&prev)[QB], int t) {
+    auto mma_fold = [&](acc_t (&cur)[QB], acc_t (&prev)[QB], int t) {
         if (wave_active) {
             const v4i* frag = s_tile[t & (NBUF - 1)];
             const bool fold_prev = t > 0;  // tile t - 1 is a full tile here
@@ -265,6 +265,14 @@ __global__ __launch_bounds__(MF_BLOCK, (QB == 1 ? 4 : QB == 2 ? 3 : 1)) void ham
                     // SQ_ACTIVE_INST_ANY of the three waves of a SIMD = 1.08 of a wave's life) and the fold is most of its vector work.
                     // The previous tile's 16 accumulator registers per block are complete, so their order is free: five operations
                     // behind each of the four matrix instructions of a block.
+                    // HAZARD (tools/mfma_hazard_check.py, run by tests/test_isa_mfma_hazard.py on every build): these reads
+                    // are inline asm, so the compiler inserts none of the 12 wait states an 8-pass XDL write needs before a vector read
+                    // of its destination.  With QB >= 2 the distance is structural — behind the last matrix instruction of a block's
+                    // previous tile come its share of the fold, the other blocks' matrix instructions and folds, the rebasing and this
+                    // tile's first matrix instruction (>= 14 counted conservatively; the ISA check fails the CPU suite below 12).  With one
+                    // block per wave (developer switch) only five fold operations and the rebasing lie between: an explicit fence, tied to
+                    // the registers, as in the reverse kernel.
+                    if (QB == 1 && kk == 0) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 2" : "+v"(prev[0]));
 #pragma unroll
                     for (int qb = 0; qb < QB; ++qb) {
                         const acc_t& p = prev[qb];
@@ -403,7 +411,7 @@ __global__ __launch_bounds__(MF_BLOCK, 4) void hamming_knn2_mfma_reverse_kernel(
     using key_t = float;
     using acc_t = v16f;
     __shared__ v4i s_tile[REV_CHUNK_TILES][KSTEPS * 2 * 32];  // 32 KB: every tile of the chunk
-    __shared__ uint16_t s_thr[256];                           // block_threshold(d0): the largest distance that still blocks a claim at d0
+    __shared__ uint16_t s_thr[257];                           // block_threshold(d0), d0 = 0 .. 256: the largest distance that still blocks a claim at d0
     const int L = blockIdx.x;
     const int xcd = L & 7, k = L >> 3;
     const int b = (k / slots) * 8 + xcd, slot = k % slots;
@@ -416,6 +424,7 @@ __global__ __launch_bounds__(MF_BLOCK, 4) void hamming_knn2_mfma_reverse_kernel(
         uint32_t thr = threadIdx.x;
         while (thr < 256u && !(f0 < (float)(thr + 1u) * nnr)) ++thr;
         s_thr[threadIdx.x] = (uint16_t)thr;
+        if (threadIdx.x == 0) s_thr[256] = 256;  // (a claim at distance 256 — possible with nnr > 1 only — is blocked by any other row: nothing is farther)
     }   // (read after the first barrier below)
     const size_t frame_off = (size_t)b * row_stride;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, col = lane & 31, hf = lane >> 5;

@@ -572,6 +572,12 @@ __global__ __launch_bounds__(BLOCK + 64, 2) void pose_kernel(PoseArgs a) {  // >
                 if (a.next_T)
                     for (int i = 0; i < 16; ++i) a.next_T[(size_t)blockIdx.x * 16 + i] = (i % 5 == 0) ? 1.0 : 0.0;
             }
+            // the by-products of this pair: nothing matched, nothing an inlier — stvo_seq_fetch_inliers / the counts of stvo_seq_read
+            // must not hand the PREVIOUS step's flags over as this step's
+            if (a.inl_p_out)
+                for (int i = threadIdx.x; i < a.max_pts; i += blockDim.x) a.inl_p_out[(size_t)blockIdx.x * a.max_pts + i] = -1;
+            if (a.inl_l_out)
+                for (int i = threadIdx.x; i < a.max_lines; i += blockDim.x) a.inl_l_out[(size_t)blockIdx.x * a.max_lines + i] = -1;
             return;
         }
     }

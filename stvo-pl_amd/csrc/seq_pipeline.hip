@@ -665,7 +665,7 @@ struct stvo_seq {
     bool graph_mode = false;
     std::unordered_map<unsigned, hipGraphExec_t> graphs;
     // optional live stage timing (bench.py): event pairs around the kernels of every step, on the stream they run on
-    bool timing = false;
+    int timing = 0;  // 1: every stage; 2: "light" — only the three big kernels of the point stream, the step otherwise as untimed
     std::vector<hipEvent_t> tev;  // STVO_SEQ_NSTAGE start/stop pairs per step, grown on demand
     size_t tev_used = 0;
     bool zero_copy = false;    // small batches: kernels write results / counts straight into out_host
@@ -1154,8 +1154,12 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl, bool* forked_by
             s->tev_used += 2 * STVO_SEQ_NSTAGE;
         }
     }
+    // light timing (stvo_seq_set_stage_timing(.., 2)): event pairs around the grid matcher, the forward scan and the pose kernel only, on
+    // the point stream; the key-line stream runs unmarked and the next frame's grid is still built ahead on it, so the three kernels
+    // keep the neighbours they have in an untimed step (bench.py: `roofline` must come from the region that produced `value`)
+    const bool light = tev && s->timing == 2;
     auto mark = [&](int k, hipStream_t q) {
-        if (tev) (void)hipEventRecord(tev[k], q);
+        if (tev && !(light && k < 2)) (void)hipEventRecord(tev[k], q);
     };
     // ---- stereo association of the new frame into set[cur]
     stvo_seq::Set& cs = s->set[s->cur];
@@ -1228,7 +1232,7 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl, bool* forked_by
             // last read two steps ago, and the line stream's work of the previous step waited for an event the point stream recorded
             // after that: sl_forked_frame), (b) the line stream has been made to wait for every upload enqueued on the point stream
             // (stvo_seq_step_dev), (c) everything else the kernel reads is the resident slot.  STVO_CELLS_AHEAD=0: in the point stream.
-            const bool cells_ahead = par && mid_fork && g.lean_cells && !g.fused_cells && !tev && !s->pev[0] && !s->graph_mode &&
+            const bool cells_ahead = par && mid_fork && g.lean_cells && !g.fused_cells && (!tev || light) && !s->pev[0] && !s->graph_mode &&
                                      s->cells_buf[0].pstart != s->cells_buf[1].pstart && s->sl_forked_frame == (long long)s->frame_idx - 1 &&
                                      stvo::dbg().cells_ahead != 0;
             if (g.fused_cells)
@@ -1337,7 +1341,8 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl, bool* forked_by
                 stvo::launch_nnr_mutual(q, B, stride, ws.knn12, ws.knn21, na, nb, nnr, 0, m12, nseg);
             }
         };
-        if (s->op.has_points) match_set(st, w, K, ps.desc, ps.n, cs.desc, cs.n, s->mp.min_ratio_12_p, s->m12p, tev ? tev + 4 : nullptr);
+        hipEvent_t mev_light[4] = {tev ? tev[4] : nullptr, tev ? tev[5] : nullptr, nullptr, nullptr};  // (light: no pair around plan + reverse scans)
+        if (s->op.has_points) match_set(st, w, K, ps.desc, ps.n, cs.desc, cs.n, s->mp.min_ratio_12_p, s->m12p, tev ? (light ? mev_light : tev + 4) : nullptr);
         small_cap = lines_cap;
         if (lines_prev && lines_now)
             match_set(sl, s->lazy_l, M, ps.ldesc, ps.nl, cs.ldesc, cs.nl, s->mp.min_ratio_12_l, s->m12l, nullptr);
@@ -1603,6 +1608,9 @@ int stvo_seq_set_motion_model(stvo_seq* s, int enable) {
     stvo_ctx* ctx = s->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    // (every stream a pose kernel or a captured step may still hold init_T / next_T on — the set stvo_seq_destroy waits for)
+    if (ctx->aux_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->aux_stream));
+    if (s->line_stream) HIP_TRY(ctx, hipStreamSynchronize(s->line_stream));
     if (!enable) {
         if (s->d_motion_T) (void)hipFree(s->d_motion_T);
         s->d_motion_T = nullptr;
@@ -1620,7 +1628,7 @@ int stvo_seq_set_motion_model(stvo_seq* s, int enable) {
 
 int stvo_seq_set_stage_timing(stvo_seq* s, int enable) {
     if (!s) return STVO_ERR_INVALID_ARG;
-    s->timing = enable != 0;
+    s->timing = enable == 2 ? 2 : (enable != 0);
     s->tev_used = 0;
     return STVO_OK;
 }
@@ -1634,6 +1642,7 @@ int stvo_seq_get_stage_timing(stvo_seq* s, float avg_ms[STVO_SEQ_NSTAGE], int32_
     int cnt[STVO_SEQ_NSTAGE] = {0};
     for (size_t k = 0; k + 2 * STVO_SEQ_NSTAGE <= s->tev_used; k += 2 * STVO_SEQ_NSTAGE)
         for (int st = 0; st < STVO_SEQ_NSTAGE; ++st) {
+            if (s->timing == 2 && (st == 0 || st == 3)) continue;  // light: these pairs were not recorded (their events may hold older stamps)
             float ms = 0.f;  // a stage that did not run in this step (first frame: no f2f, no pose) left its events unrecorded
             if (hipEventElapsedTime(&ms, s->tev[k + 2 * st], s->tev[k + 2 * st + 1]) == hipSuccess) {
                 acc[st] += ms;

@@ -484,7 +484,9 @@ class Sequences:
         self.ctx._chk(self.ctx.lib.stvo_seq_set_motion_model(self.h, 1 if on else 0))
 
     def set_stage_timing(self, on=True):
-        self.ctx._chk(self.ctx.lib.stvo_seq_set_stage_timing(self.h, 1 if on else 0))
+        """True / 1: an event pair around every stage; 2: "light" — only the grid matcher, the forward scan and the pose kernel (the
+        step otherwise as untimed); False: off."""
+        self.ctx._chk(self.ctx.lib.stvo_seq_set_stage_timing(self.h, int(on)))
 
     def get_stage_timing(self):
         """({stage name: average ms per step}, number of steps measured) since the last call."""

@@ -26,6 +26,17 @@ def aggregate(dist, frames_local: int, seconds_local: float, device="cpu"):
     return int(round(n.item())), float(t.item())
 
 
+def gather_scalars(dist, x_local: float, device="cpu"):
+    """[x of rank 0, x of rank 1, ...] on every rank (reporting: per-rank frame pairs/s next to the whole-job value)."""
+    if dist is None:
+        return [float(x_local)]
+    import torch
+    t = torch.tensor([float(x_local)], dtype=torch.float64, device=device)
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
+
+
 def gather_poses(dist, poses_local, device="cpu"):
     """All-gather per-rank [n,16] pose blocks to every rank (optional reporting path)."""
     import torch
