@@ -948,7 +948,7 @@ void launch_grid_batch(hipStream_t s, const GridBatch& g, bool lines, hipEvent_t
             hipLaunchKernelGGL((grid_cover_kernel<true, true>), gc, blk, lds, s, g);
         else
             hipLaunchKernelGGL((grid_cover_kernel<true, false>), gc, blk, 0, s, g);
-        if (scan_events) (void)hipEventRecord(scan_events[0], s);
+        if (scan_events && scan_events[0]) (void)hipEventRecord(scan_events[0], s);
         hipLaunchKernelGGL((grid_scan_kernel<true, 1, false>), g2, blk, 0, s, g);
         if (g.elig) hipLaunchKernelGGL(grid_elig_kernel, g2, blk, 0, s, g);
         hipLaunchKernelGGL((grid_scan_kernel<true, 2, false>), g2, blk, 0, s, g);
@@ -960,7 +960,7 @@ void launch_grid_batch(hipStream_t s, const GridBatch& g, bool lines, hipEvent_t
             int cap = dbg().grid_fused_cap != DBG_UNSET ? dbg().grid_fused_cap : FUSED_KEY_CAP;
             if (cap > FUSED_KEY_CAP) cap = FUSED_KEY_CAP;  // negative: every frame misfits
             const int fused_wgs = device_cu_count();  // one persistent workgroup per CU (its LDS and registers fill one)
-            if (scan_events) (void)hipEventRecord(scan_events[0], s);
+            if (scan_events && scan_events[0]) (void)hipEventRecord(scan_events[0], s);
             if (g.fused_cells && g.B <= fused_wgs)
                 hipLaunchKernelGGL(grid_points_fused_kernel<true>, dim3(g.B), dim3(FUSED_T), FUSED_LDS, s, g, cap);
             else
@@ -969,7 +969,7 @@ void launch_grid_batch(hipStream_t s, const GridBatch& g, bool lines, hipEvent_t
             return;
         }
         if (range) {
-            if (scan_events) (void)hipEventRecord(scan_events[0], s);
+            if (scan_events && scan_events[0]) (void)hipEventRecord(scan_events[0], s);
             hipLaunchKernelGGL((grid_scan_kernel<false, 1, true>), g2, blk, 0, s, g);
             if (g.elig) hipLaunchKernelGGL(grid_elig_kernel, g2, blk, 0, s, g);
             hipLaunchKernelGGL((grid_scan_kernel<false, 2, true>), g2, blk, 0, s, g);
@@ -978,7 +978,7 @@ void launch_grid_batch(hipStream_t s, const GridBatch& g, bool lines, hipEvent_t
                 hipLaunchKernelGGL((grid_cover_kernel<false, true>), gc, blk, lds, s, g);
             else
                 hipLaunchKernelGGL((grid_cover_kernel<false, false>), gc, blk, 0, s, g);
-            if (scan_events) (void)hipEventRecord(scan_events[0], s);
+            if (scan_events && scan_events[0]) (void)hipEventRecord(scan_events[0], s);
             hipLaunchKernelGGL((grid_scan_kernel<false, 1, false>), g2, blk, 0, s, g);
             if (g.elig) hipLaunchKernelGGL(grid_elig_kernel, g2, blk, 0, s, g);
             hipLaunchKernelGGL((grid_scan_kernel<false, 2, false>), g2, blk, 0, s, g);
