@@ -43,8 +43,8 @@ I8_MFMA_PEAK_TOPS = 5000.0
 I8_MFMA_MEASURED_FLOOR_TOPS = 4404.0
 FP4_MFMA_PEAK_TOPS = 10000.0
 K1M_OPS_PER_PAIR = 2 * 256
-PREV_PROFILE_TAG = "r04"
-PROFILE_TAG = "r05"          # committed rocprofv3 PMC passes the `traffic` figures are read from
+PREV_PROFILE_TAG = "r05"
+PROFILE_TAG = "r06"          # committed rocprofv3 PMC passes the `traffic` figures are read from
 FP64_PEAK_TFLOPS = 78.6      # MI355X_MICROARCH.md: vector FP64 (the matrix FP64 rate is the same on gfx950)
 TOL_RAD, TOL_M = 1e-4, 1e-3  # BASELINE.json north_star: pose within 1e-4 rad / 1e-3 m of the reference CPU path per frame
 
