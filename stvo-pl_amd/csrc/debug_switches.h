@@ -32,6 +32,9 @@ struct DebugSwitches {
     int lsd_waves;       // STVO_LSD_WAVES       0: batches of <= 8 images by lsd_grow_kernel (one wave per image) instead of lsd_grow_waves_kernel (16 waves per image)
     int lsd_sort_full;   // STVO_LSD_SORT_FULL   1: the pseudo-ordering sorts all 32 key bits instead of the bin bits only (lsd_kernels.hip)
     int cells_ahead;     // STVO_CELLS_AHEAD     0: point_cells_kernel of a batch in the point stream (unset: on the line stream, ahead of the point stream's step)
+    int seq_pipe;        // STVO_SEQ_PIPE        1: pipelined steps (optimizePose(k) on the aux stream beside the stereo association of step k + 1; built and measured in round 6, no gain), 2: the same without the gate kernel
+    int lines_ahead;     // STVO_LINES_AHEAD     0: the key-line stream waits for its own step's fork event (until round 5); unset: for batches it runs one step ahead, behind the dispatch of the previous pose kernel
+    int grid_dyn;        // STVO_GRID_DYN        0: the persistent point matcher takes its frames by a static stride (unset: from a counter, when the step is pipelined)
     int grid_cells;      // STVO_GRID_CELLS      0: point_cells_kernel as its own launch for small batches too, 1: in the matcher whenever it fits
 };
 

@@ -653,7 +653,23 @@ __global__ __launch_bounds__(FUSED_T) void grid_points_fused_kernel(GridBatch g,
     uint32_t* s_wq = reinterpret_cast<uint32_t*>(s_blocked + FUSED_ROWS);                // [entry][12] wide right features
     const int tid = threadIdx.x;
     FusedNext nx;
-    int f = blockIdx.x;
+    // frames of this workgroup: a static stride, or (GridBatch::dyn_ctr) tickets from a counter — three drawn at the start (the frame
+    // worked on, the one being fetched, the one whose header is requested), one more per frame
+    const bool dyn = !CELLS && g.dyn_ctr != nullptr;
+    __shared__ int s_ticket;
+    int f = blockIdx.x, f_n1 = f + (int)gridDim.x, f_n2 = f + 2 * (int)gridDim.x;
+    if (dyn) {
+        int32_t* ctr = g.dyn_ctr + g.dyn_par;
+        if (tid == 0) {
+            if (blockIdx.x == 0) g.dyn_ctr[g.dyn_par ^ 1] = 0;  // the next launch's counter (the previous launch is complete: stream order)
+            s_ticket = atomicAdd(ctr, 3);
+        }
+        __syncthreads();
+        f = __builtin_amdgcn_readfirstlane(s_ticket);
+        f_n1 = f + 1;
+        f_n2 = f + 2;
+        __syncthreads();  // (s_ticket is written again inside the loop)
+    }
     if (f >= g.B) return;
     unsigned long long misfit_mask = 0ull;  // bit i: the i-th frame of this workgroup is left to the scan formulation (block-uniform)
     int trip = 0;
@@ -664,7 +680,7 @@ __global__ __launch_bounds__(FUSED_T) void grid_points_fused_kernel(GridBatch g,
     hc.n2 = __builtin_amdgcn_readfirstlane(hn.n2);
     hc.n1 = __builtin_amdgcn_readfirstlane(hn.n1);
     fused_fetch2(g, f, hc, nx);
-    if (f + (int)gridDim.x < g.B) hn = fused_hdr(g, f + gridDim.x);
+    if (f_n1 < g.B) hn = fused_hdr(g, f_n1);
     const bool mutual = g.mutual != 0;
     const double ratio = g.ratio;
     // Left rows of the fetched frame into LDS (cell order), and the header of the frame after it into scalar registers: ONE
@@ -688,8 +704,10 @@ __global__ __launch_bounds__(FUSED_T) void grid_points_fused_kernel(GridBatch g,
         hs.n2 = __builtin_amdgcn_readfirstlane(hn.n2);
         hs.n1 = __builtin_amdgcn_readfirstlane(hn.n1);
     };
-    commit_rows(hc);  // afterwards hs = header of frame f + gridDim.x (if any)
-    for (; f < g.B; f += gridDim.x) {
+    commit_rows(hc);  // afterwards hs = header of the workgroup's next frame (if any)
+    bool any_misfit = false;
+    int tk = 0;  // the ticket drawn during this iteration (read behind its first barrier; the next iteration's draw is two barriers later)
+    for (; f < g.B; f = f_n1, f_n1 = f_n2, f_n2 = dyn ? tk : f_n2 + (int)gridDim.x) {
         // ---- commit the fetched frame, right side: this thread's two right rows stay in registers
         uint4 q0[FUSED_R], q1[FUSED_R];
         int la[FUSED_R], cnt[FUSED_R];
@@ -709,14 +727,19 @@ __global__ __launch_bounds__(FUSED_T) void grid_points_fused_kernel(GridBatch g,
             s_ctl[0] = 0;
             s_ctl[1] = key_cap < 0;
             s_ctl[2] = 0;
+            if (dyn) {  // (read at the loop's step expression, behind this iteration's barriers)
+                s_ticket = atomicAdd(g.dyn_ctr + g.dyn_par, 1);
+                g.dyn_owner[f] = (int)blockIdx.x;
+            }
         }
-        const int fn = f + gridDim.x;
+        const int fn = f_n1;
         const bool more = fn < g.B;  // block-uniform
         if (more) {
             fused_fetch1(g, fn, nx);
-            if (fn + (int)gridDim.x < g.B) hn = fused_hdr(g, fn + gridDim.x);
+            if (f_n2 < g.B) hn = fused_hdr(g, f_n2);
         }
         __syncthreads();
+        if (dyn) tk = __builtin_amdgcn_readfirstlane(s_ticket);
         // ---- distances, eligible chains, best per left row
         // what the ratio tests after the barrier need of a right feature: its eligible keys — the first FUSED_EK stay in registers, further
         // ones (4 % of the features) go to the key slots of LDS; the 16 sorted keys themselves live for one r only
@@ -846,6 +869,7 @@ __global__ __launch_bounds__(FUSED_T) void grid_points_fused_kernel(GridBatch g,
         }
         if (tid == 0) g.misfit[f] = misfit;
         if (misfit && trip < 64) misfit_mask |= 1ull << trip;
+        any_misfit |= misfit;
         ++trip;
         if (!misfit) {
             // ---- :160 for every eligible pair that is not its left row's best: best_d < d * minRatio12P in DOUBLE, else the row is out
@@ -901,10 +925,16 @@ __global__ __launch_bounds__(FUSED_T) void grid_points_fused_kernel(GridBatch g,
         hc = hfn;
     }
     // frames that did not fit (rare): the scan formulation, by the workgroup that flagged them — no second launch
-    if (misfit_mask != 0ull || trip > 64) {
+    if (dyn ? any_misfit : (misfit_mask != 0ull || trip > 64)) {
         int i = 0;
-        for (int fm = blockIdx.x; fm < g.B; fm += gridDim.x, ++i) {
-            const bool todo = i < 64 ? ((misfit_mask >> i) & 1ull) != 0ull : g.misfit[fm] != 0;  // (beyond 64 frames per workgroup: the flag it stored)
+        if (dyn) {  // the frames this workgroup took are the ones it signed (its own stores, made visible to all its threads)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        for (int fm = dyn ? 0 : (int)blockIdx.x; fm < g.B; fm += dyn ? 1 : (int)gridDim.x, ++i) {
+            const bool todo = dyn ? (g.dyn_owner[fm] == (int)blockIdx.x && g.misfit[fm] != 0)
+                                  : (i < 64 ? ((misfit_mask >> i) & 1ull) != 0ull : g.misfit[fm] != 0);  // (beyond 64 frames per workgroup: the flag it stored)
             if (todo) {
                 __syncthreads();
                 fused_misfit_frame(g, fm);

@@ -180,7 +180,16 @@ struct PoseArgs {
     unsigned fetch_n16;
     unsigned* fetch_flag;
     unsigned fetch_value;
+    // start_flag (batch kernel pose2c only; nullptr otherwise): the LAST workgroup of the launch publishes start_value there when it
+    // starts — every workgroup of the launch has then been dispatched.  The pipelined steps of seq_pipeline.hip hold the NEXT step's
+    // point matcher behind it (launch_stream_gate), so that the matcher's one-per-CU workgroups do not take the CUs first.
+    unsigned* start_flag;
+    unsigned start_value;
 };
+// the batch kernel honours PoseArgs::start_flag for this launch (same selection as launch_pose)
+bool pose_start_flag_ok(const PoseArgs& a);
+// one thread that leaves when *flag has reached value, or after ~0.5 ms (a scheduling hint, never a dependence)
+void launch_stream_gate(hipStream_t s, const unsigned* flag, unsigned value);
 constexpr int STVO_POSE_QTAB = 16;
 // internal flag in stvo_pose_result::path (never leaves the library): the eigenvalues of `cov` are still to be computed by the reader
 constexpr int PATH_EIG_PENDING = 1 << 30;
@@ -281,6 +290,13 @@ struct GridBatch {
     // the one-workgroup matcher builds the grid of its frame itself as its first phase — no point_cells_kernel launch
     int fused_cells;
     PointCells cells;
+    // dyn_ctr != nullptr (persistent point matcher, pipelined steps of seq_pipeline.hip): the workgroups take their frames from the counter
+    // dyn_ctr[dyn_par] instead of by a static stride — the launch then starts beside the previous step's pose kernel, its workgroups come
+    // to their CUs one by one as that kernel's frame pairs finish, and the ones that start early take more frames.  The launch resets
+    // dyn_ctr[dyn_par ^ 1] for the next one; dyn_owner [B] remembers who took a frame (for the workgroup's own pass over misfits).
+    int32_t* dyn_ctr;
+    int32_t* dyn_owner;
+    int dyn_par;
 };
 constexpr int GRID_ELIG = 16;
 // scan_events (optional): [0] / [1] are recorded on `s` before / after the two grid_scan passes

@@ -642,9 +642,23 @@ namespace {
 __global__ void stream_signal_kernel(unsigned* flag, unsigned value) {
     __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
+// one thread: leaves when *flag has reached `value` (wrap-safe) or after ~0.5 ms — a scheduling hint (kernels.h: launch_stream_gate)
+__global__ void stream_gate_kernel(const unsigned* flag, unsigned value) {
+    for (int spin = 0; spin < 2500; ++spin) {
+        if ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - value) >= 0) break;
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
 }  // namespace
 void launch_stream_signal(hipStream_t s, unsigned* flag, unsigned value) {
     hipLaunchKernelGGL(stream_signal_kernel, dim3(1), dim3(1), 0, s, flag, value);
+}
+void launch_stream_gate(hipStream_t s, const unsigned* flag, unsigned value) {
+    hipLaunchKernelGGL(stream_gate_kernel, dim3(1), dim3(1), 0, s, flag, value);
+}
+bool pose_start_flag_ok(const PoseArgs& a) {  // launch_pose below takes the batch kernel on compact records (pose2c_kernel)
+    const int which = dbg().pose_kernel;
+    return a.B > 0 && !a.eval_only && a.prev_rc != nullptr && (which == 4 || (which != 1 && a.B > POSE_LATENCY_MAX_B));
 }
 bool pose_inline_sync_ok(int B) { return B >= 1 && B <= 16 && dbg().pose_kernel != 4; }
 

@@ -626,12 +626,39 @@ struct stvo_seq {
         double *spl, *epl, *sP, *eP, *le, *s2l, *s2lm;
         uint8_t* ldesc;
         int32_t* nl;
-    } set[2];
+    } set[3];  // THREE stereo sets (round 6): step k writes set k mod 3 and reads set (k - 1) mod 3, so that the association of step k + 1
+               // (which writes set (k + 1) mod 3) may run while the pose kernel of step k still reads sets k - 1 and k (pipelined steps below)
     int cur = 0;
+    int prev_set() const { return (cur + 2) % 3; }
     unsigned long long *cover, *top2;
     uint32_t *elig = nullptr, *elig_l = nullptr;         // eligible pairs of the grid scans (points / lines), see GridBatch
     int32_t *elig_cnt = nullptr, *elig_cnt_l = nullptr, *govf = nullptr, *govf_l = nullptr;
     int32_t *owner2, *m12s_p, *m12s_l, *m12p, *m12l, *inlp, *inll, *counts;
+    // ---- pipelined steps (batches; STVO_SEQ_PIPE=0 switches them off): optimizePose(k) runs on the context's aux stream, and the point
+    // stream goes straight on to the stereo association of step k + 1, whose workgroups take the CUs the pose kernel's one residency round
+    // frees as its frame pairs finish (the pairs with the most evaluations are a ~20 % tail: profiles/r05_sq_counters.txt).  What makes the
+    // two independent: the third stereo set (above), a second copy of the f2f match indices (odd steps write m12p_alt / m12l_alt), and the
+    // events ev_match (point stream -> pose: the indices are complete) / ev_pose[k & 1] (pose -> the step that overwrites what it read).
+    // The ORDER in which the two become ready matters for speed only: the pose kernel's workgroups must be dispatched before the matcher's
+    // (one per CU, most of its LDS), so the point stream passes a one-thread gate kernel that leaves when the pose kernel's last workgroup
+    // has started (PoseArgs::start_flag) — bounded, a hint: every data dependence is carried by the events.
+    int32_t *m12p_alt = nullptr, *m12l_alt = nullptr;
+    hipEvent_t ev_match = nullptr, ev_pose[2] = {nullptr, nullptr};
+    unsigned* d_pose_flag = nullptr;
+    unsigned pose_epoch = 0;
+    int32_t *d_dyn_ctr = nullptr, *d_dyn_owner = nullptr;  // GridBatch::dyn_ctr [2] / dyn_owner [B]: frame tickets of the persistent point matcher
+    long long dyn_last_frame = -2;                         // the last step whose matcher took tickets (it reset the other counter)
+    bool pose_pending[2] = {false, false};  // ev_pose[i] has been recorded and not yet waited for by the point stream
+    bool piped_last = false;                // the last step put its pose kernel on the aux stream (stvo_seq_read waits for it)
+    // ---- key-line stage AHEAD (the default for batches, round 6; STVO_LINES_AHEAD=0 switches it off): the key-line kernels of step k + 1
+    // (stereo association + f2f of ~100 rows per image: 1024 small workgroups each) do not depend on anything the point stream does in
+    // step k + 1, so the line stream no longer waits for that step's fork event.  It waits for the fork event of step k — recorded behind
+    // optimizePose(k - 1), the last reader of the line set and of the match-index copy step k + 1 overwrites (three sets, two copies) —
+    // and passes a gate that opens when optimizePose(k) has been dispatched: the small workgroups then fill the slots that kernel's one
+    // residency round frees as its frame pairs finish, instead of sharing the issue ports with the forward scan K1m(k + 1), which they
+    // stretched by ~40 us per step.
+    long long fork_rec_frame = -2;   // the last step that recorded ev_fork on the point stream
+    long long pose_flag_frame = -2;  // the last step whose pose kernel publishes its start (d_pose_flag == pose_epoch)
     stvo_pose_result* results;
     char* out_host = nullptr;  // pinned: results + counts
     // second stream: the line stage (stereo association + f2f of the key-lines) is independent of the point stage
@@ -671,8 +698,8 @@ struct stvo_seq {
     bool zero_copy = false;    // small batches: kernels write results / counts straight into out_host
     std::vector<char> raw_lines;  // slot holds at least one left and one right key-line
     std::vector<int> raw_max_lines;  // most key-lines of one image in the slot, as far as the host knows (device ingests: M)
-    int set_lines_cap[2] = {0, 0};   // the same bound for the stereo line sets (set[0], set[1])
-    bool set_lines[2] = {false, false};  // stereo set was built from a frame with key-lines
+    int set_lines_cap[3] = {0, 0, 0};   // the same bound for the stereo line sets
+    bool set_lines[3] = {false, false, false};  // stereo set was built from a frame with key-lines
     bool last_lines = false;             // the last step ran the line stage
     int last_slot = 0;                   // raw slot of the last step
     stvo::GridBatch last_point_grid{};   // arguments of the last point grid match (test hook)
@@ -787,7 +814,7 @@ int stvo_seq_create_multi(stvo_ctx* ctx, int B, int max_keypoints, int max_keyli
     Carver c;
     const size_t o_raw = c.take(s->raw_bytes), o_raw1 = c.take(s->raw_bytes);
     const size_t o_cams = c.take(nb * sizeof(stvo_cam)), o_invwh = c.take(nb * 2 * 8), o_qtab = c.take(stvo::STVO_POSE_QTAB * 8),
-                 o_joinflag = c.take(64);
+                 o_joinflag = c.take(64), o_poseflag = c.take(64);
     const size_t o_pxy = c.take(nb * K * 2 * 4), o_pstart = c.take(nb * (STVO_GRID_CELLS + 1) * 4), o_pitems = c.take(nb * K * 4),
                  o_prank = c.take(nb * K * 4), o_pperm = c.take(nb * K * 4), o_prange = c.take(nb * K * 2 * 4), o_pcell = c.take(nb * K * 4);
     const bool lsort = K <= 2048 && mp->matching_s_ws >= 0 && mp->matching_s_ws <= stvo::GRID_LW - STVO_GRID_COLS;
@@ -807,12 +834,15 @@ int stvo_seq_create_multi(stvo_ctx* ctx, int B, int max_keypoints, int max_keyli
     const size_t o_m12sp = c.take(nb * K * 4), o_m12sl = c.take(nb * M * 4), o_m12p = c.take(nb * K * 4), o_m12l = c.take(nb * M * 4),
                  o_inlp = c.take(nb * K * 4), o_inll = c.take(nb * M * 4), o_res = c.take(nb * sizeof(stvo_pose_result)),
                  o_counts = c.take(nb * 4 * 4);
+    const bool pipe_ok = B >= 64;  // (pipelined steps: batches only)
+    const size_t o_m12p_alt = c.take(pipe_ok ? nb * K * 4 : 0), o_m12l_alt = c.take(pipe_ok ? nb * M * 4 : 0);
+    const size_t o_dyn_ctr = c.take(64), o_dyn_owner = c.take(nb * 4);
     const size_t cap_l = nb * (size_t)M * 4;  // line f2f: up to 4 train segments
     const size_t o_cover_l = c.take(nb * (size_t)(M / 64) * M * 8), o_top2_l = c.take(nb * M * 8), o_owner_l = c.take(nb * M * 4),
                  o_knn12_l = c.take(cap_l * 8), o_knn21_l = c.take(cap_l * 8), o_cand_l = c.take(nb * M * 4),
                  o_need_l = c.take(nb * M * 4), o_qsel_l = c.take(nb * M * 4), o_nsel_l = c.take(nb * 4 * 5);
-    size_t o_set[2][14];
-    for (int t = 0; t < 2; ++t) {
+    size_t o_set[3][14];
+    for (int t = 0; t < 3; ++t) {
         o_set[t][0] = c.take(nb * K * 16);
         o_set[t][1] = o_set[t][2] = 0;
         o_set[t][3] = c.take(nb * K * 32);
@@ -839,9 +869,16 @@ int stvo_seq_create_multi(stvo_ctx* ctx, int B, int max_keypoints, int max_keyli
               hip_ok(ctx, hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming), "hipEventCreate seq") &&
               hip_ok(ctx, hipEventCreateWithFlags(&s->ev_cells, hipEventDisableTiming), "hipEventCreate seq") &&
               hip_ok(ctx, hipEventCreateWithFlags(&s->ev_upload, hipEventDisableTiming), "hipEventCreate seq") &&
+              hip_ok(ctx, hipEventCreateWithFlags(&s->ev_match, hipEventDisableTiming), "hipEventCreate seq") &&
+              hip_ok(ctx, hipEventCreateWithFlags(&s->ev_pose[0], hipEventDisableTiming), "hipEventCreate seq") &&
+              hip_ok(ctx, hipEventCreateWithFlags(&s->ev_pose[1], hipEventDisableTiming), "hipEventCreate seq") &&
               hip_ok(ctx, hipEventCreateWithFlags(&s->ev_stage[0], hipEventDisableTiming), "hipEventCreate seq") &&
               hip_ok(ctx, hipEventCreateWithFlags(&s->ev_stage[1], hipEventDisableTiming), "hipEventCreate seq");
     s->zero_copy = B <= 16;
+    if (ok && pipe_ok && !ctx->aux_stream) {  // pipelined steps: optimizePose on the context's aux stream (with its record arena)
+        ok = hip_ok(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking), "hipStreamCreate aux");
+        if (ok) stvo::pose_retain_stream(ctx->aux_stream);
+    }
     {   // graph replay of the step chain: opt-in (STVO_SEQ_GRAPH=1).  Measured on ROCm 7.2 / MI355X for one sequence: 0.290 vs
         // 0.282 ms per frame points-only and 0.477 vs 0.310 ms with the line stage on its second stream — the graph executor
         // adds more per-node latency than the host-side launches cost (profiles/r02_single_stream_latency.txt)
@@ -862,6 +899,13 @@ int stvo_seq_create_multi(stvo_ctx* ctx, int B, int max_keypoints, int max_keyli
     s->d_inv_wh = (double*)(D + o_invwh);
     s->d_qtab = (double*)(D + o_qtab);
     s->d_join_flag = (unsigned*)(D + o_joinflag);
+    s->d_pose_flag = (unsigned*)(D + o_poseflag);
+    s->d_dyn_ctr = (int32_t*)(D + o_dyn_ctr);
+    s->d_dyn_owner = (int32_t*)(D + o_dyn_owner);
+    if (pipe_ok) {
+        s->m12p_alt = (int32_t*)(D + o_m12p_alt);
+        s->m12l_alt = (int32_t*)(D + o_m12l_alt);
+    }
     {
         std::vector<double> iw(2 * nb);
         for (int b = 0; b < B; ++b) {
@@ -910,7 +954,7 @@ int stvo_seq_create_multi(stvo_ctx* ctx, int B, int max_keypoints, int max_keyli
     if (cells2)
         s->cells_buf[1] = {(int32_t*)(D + o_pstart2), (int32_t*)(D + o_pperm2), (int32_t*)(D + o_pcell2), (int32_t*)(D + o_plperm2),
                            (uint32_t*)(D + o_plstart2)};
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < 3; ++t) {
         stvo_seq::Set& q = s->set[t];
         q.rc = (float4*)(D + o_set[t][0]);
         q.desc = (uint8_t*)(D + o_set[t][3]); q.n = (int32_t*)(D + o_set[t][4]);
@@ -938,6 +982,7 @@ int stvo_seq_set_slots(stvo_seq* s, int n_slots) {
     stvo_ctx* ctx = s->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->aux_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->aux_stream));
     // captured step graphs (STVO_SEQ_GRAPH=1) hold the raw-slot addresses of the slots they were captured for
     for (auto& g : s->graphs) (void)hipGraphExecDestroy(g.second);
     s->graphs.clear();
@@ -976,6 +1021,9 @@ int stvo_seq_destroy(stvo_seq* s) {
     if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
     if (s->ev_join) (void)hipEventDestroy(s->ev_join);
     if (s->ev_cells) (void)hipEventDestroy(s->ev_cells);
+    if (s->ev_match) (void)hipEventDestroy(s->ev_match);
+    for (auto e : s->ev_pose)
+        if (e) (void)hipEventDestroy(e);
     if (s->ev_upload) (void)hipEventDestroy(s->ev_upload);
     for (auto e : s->ev_stage)
         if (e) (void)hipEventDestroy(e);
@@ -995,6 +1043,16 @@ int stvo_seq_destroy(stvo_seq* s) {
 }
 
 namespace {
+
+// pipelined steps: pose kernels still in flight on the aux stream (everything they depend on was enqueued before them)
+int seq_wait_pose_stream(stvo_seq* s) {
+    stvo_ctx* ctx = s->ctx;
+    if ((s->pose_pending[0] || s->pose_pending[1] || s->piped_last) && ctx->aux_stream) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->aux_stream));
+        s->pose_pending[0] = s->pose_pending[1] = false;
+    }
+    return STVO_OK;
+}
 
 void bind_raw(stvo_seq* s, stvo::SeqDev& d, int slot) {
     char* Rw = s->raw_dev[slot];
@@ -1161,9 +1219,35 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl, bool* forked_by
     auto mark = [&](int k, hipStream_t q) {
         if (tev && !(light && k < 2)) (void)hipEventRecord(tev[k], q);
     };
+    // ---- pipelined step (stvo_seq: "pipelined steps"): this step's pose kernel goes to the aux stream and the NEXT step's association may
+    // start beside it.  Batches on the compact-record batch kernel only; not with the by-product fetch (its copies follow the pose kernel in
+    // the point stream), the full stage timers, the host-side profile markers or graph replay.
+    // (round 6: built, parity-green, measured — no gain: the matcher's workgroups need whole CUs, which the pose kernel frees only at its very
+    //  end; profiles/r06_pipelined_steps.txt.  Opt-in: STVO_SEQ_PIPE=1, 2 = without the gate.)
+    const int pipe_sw = stvo::dbg().seq_pipe;
+    const bool piped = s->m12p_alt != nullptr && ctx->aux_stream != nullptr && !ctx->overlap && !s->fetch && !s->graph_mode && !s->pev[0] &&
+                       !(tev && !light) && !s->zero_copy && (pipe_sw == 1 || pipe_sw == 2);
+    // what a pose kernel on the aux stream still reads — the stereo set this step overwrites (it was `prev` two steps ago) and the f2f
+    // match indices of this step's parity — is free once the pose kernel of two steps ago has finished: long ago, in the steady state
+    {
+        const int par2 = s->frame_idx & 1;
+        if (s->pose_pending[par2]) {
+            HIP_TRY(ctx, hipStreamWaitEvent(st, s->ev_pose[par2], 0));
+            s->pose_pending[par2] = false;
+        }
+        if (!piped && s->pose_pending[par2 ^ 1]) {  // leaving the pipelined mode: this step's pose kernel follows the last one in stream order
+            HIP_TRY(ctx, hipStreamWaitEvent(st, s->ev_pose[par2 ^ 1], 0));
+            s->pose_pending[par2 ^ 1] = false;
+        }
+    }
+    // two copies of the f2f match indices, by the parity of the step (batches without the by-product fetch, whose copies read the first):
+    // the matches of step k + 1 may be written while optimizePose(k) reads those of step k
+    const bool alt_ok = s->m12p_alt != nullptr && !s->fetch;
+    int32_t* const m12p_use = (alt_ok && (s->frame_idx & 1)) ? s->m12p_alt : s->m12p;
+    int32_t* const m12l_use = (alt_ok && (s->frame_idx & 1)) ? s->m12l_alt : s->m12l;
     // ---- stereo association of the new frame into set[cur]
     stvo_seq::Set& cs = s->set[s->cur];
-    stvo_seq::Set& ps = s->set[s->cur ^ 1];
+    stvo_seq::Set& ps = s->set[s->prev_set()];
     stvo::SeqDev d = s->d;
     bind_raw(s, d, slot);
     d.rc = cs.rc; d.desc = cs.desc; d.n = cs.n;
@@ -1235,6 +1319,11 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl, bool* forked_by
             const bool cells_ahead = par && mid_fork && g.lean_cells && !g.fused_cells && (!tev || light) && !s->pev[0] && !s->graph_mode &&
                                      s->cells_buf[0].pstart != s->cells_buf[1].pstart && s->sl_forked_frame == (long long)s->frame_idx - 1 &&
                                      stvo::dbg().cells_ahead != 0;
+            // key-line stage ahead (stvo_seq: fork_rec_frame): the line stream waits for the PREVIOUS step's fork event — in front of the
+            // cells kernel, whose output copy the matcher of two steps ago read — and not for this step's
+            const bool lines_ahead = cells_ahead && !piped && alt_ok && s->fork_rec_frame == (long long)s->frame_idx - 1 &&
+                                     stvo::dbg().lines_ahead != 0;
+            if (lines_ahead) HIP_TRY(ctx, hipStreamWaitEvent(sl, s->ev_fork, 0));
             if (g.fused_cells)
                 g.cells = stvo::point_cells_args(d);
             else if (g.lean_cells)
@@ -1252,7 +1341,20 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl, bool* forked_by
             if (light) (void)hipEventRecord(tev[2], st);
             if (mid_fork) {
                 HIP_TRY(ctx, hipEventRecord(s->ev_fork, st));
-                HIP_TRY(ctx, hipStreamWaitEvent(sl, s->ev_fork, 0));
+                if (!s->graph_mode) s->fork_rec_frame = s->frame_idx;
+                if (!lines_ahead)
+                    HIP_TRY(ctx, hipStreamWaitEvent(sl, s->ev_fork, 0));
+                else if (s->pose_flag_frame == (long long)s->frame_idx - 1)  // the key-line kernels behind the dispatch of optimizePose(k - 1)
+                    stvo::launch_stream_gate(sl, s->d_pose_flag, s->pose_epoch);
+            }
+            // pipelined steps: the persistent matcher starts beside the previous step's pose kernel — frames by ticket (GridBatch::dyn_ctr)
+            if (piped && fl.track && g.lean_cells && !g.fused_cells && stvo::dbg().grid_dyn != 0) {
+                g.dyn_ctr = s->d_dyn_ctr;
+                g.dyn_owner = s->d_dyn_owner;
+                g.dyn_par = s->frame_idx & 1;
+                if (s->dyn_last_frame != (long long)s->frame_idx - 1)  // nobody reset this launch's counter
+                    HIP_TRY(ctx, hipMemsetAsync(s->d_dyn_ctr, 0, 2 * sizeof(int32_t), st));
+                s->dyn_last_frame = s->frame_idx;
             }
             s->last_point_grid = g;
             stvo::launch_grid_batch(st, g, false, tev ? (light ? gev_light : tev + 2) : nullptr);
@@ -1317,7 +1419,7 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl, bool* forked_by
         // ---- f2fTracking: prev stereo sets vs curr stereo sets
         const stvo::LazyScratch w{ctx->knn12, ctx->knn21, ctx->cand, ctx->need, ctx->qsel, ctx->nsel, ctx->knn_capacity};
         const int esm = stvo::dbg().match_small;  // developer: 0 = the general machinery for the key-line sets too
-        const int lines_cap = std::max(s->set_lines_cap[0], s->set_lines_cap[1]);
+        const int lines_cap = std::max(s->set_lines_cap[s->cur], s->set_lines_cap[s->prev_set()]);
         // one workgroup per frame pair (match_small_kernel) up to 128 key-lines per image; beyond that its row-by-row scan is the
         // longest thing on the key-line stream and the general machinery (K1m + planned reverse check, five launches) wins for every
         // batch size: 512 EuRoC-shaped streams with ~250 key-lines 844 k -> 913 k frame pairs/s (both directions in one K1m launch +
@@ -1347,21 +1449,26 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl, bool* forked_by
             }
         };
         hipEvent_t mev_light[4] = {tev ? tev[4] : nullptr, tev ? tev[5] : nullptr, nullptr, nullptr};  // (light: no pair around plan + reverse scans)
-        if (s->op.has_points) match_set(st, w, K, ps.desc, ps.n, cs.desc, cs.n, s->mp.min_ratio_12_p, s->m12p, tev ? (light ? mev_light : tev + 4) : nullptr);
+        if (s->op.has_points) match_set(st, w, K, ps.desc, ps.n, cs.desc, cs.n, s->mp.min_ratio_12_p, m12p_use, tev ? (light ? mev_light : tev + 4) : nullptr);
         small_cap = lines_cap;
         if (lines_prev && lines_now)
-            match_set(sl, s->lazy_l, M, ps.ldesc, ps.nl, cs.ldesc, cs.nl, s->mp.min_ratio_12_l, s->m12l, nullptr);
+            match_set(sl, s->lazy_l, M, ps.ldesc, ps.nl, cs.ldesc, cs.nl, s->mp.min_ratio_12_l, m12l_use, nullptr);
         else if (lines_prev)  // nothing to match against: every prev line is unmatched
-            HIP_TRY(ctx, hipMemsetAsync(s->m12l, 0xFF, (size_t)B * M * sizeof(int32_t), st));
+            HIP_TRY(ctx, hipMemsetAsync(m12l_use, 0xFF, (size_t)B * M * sizeof(int32_t), st));
         // Small batches (single-stream operation): the pose kernel itself waits for the line stream and hands the match indices to
         // the host — an event awaited or recorded in front of it delays its start by ~6 us each on this runtime.
         const bool inline_sync = stvo::pose_inline_sync_ok(B) && stvo::dbg().seq_inline != 0 && !s->graph_mode && !tev && !s->pev[0] &&
                                  (!s->fetch || (B == 1 && s->zero_copy));
+        hipStream_t sp = piped ? ctx->aux_stream : st;  // the stream of optimizePose
+        if (piped) {  // the pose kernel waits for both streams' matches; the point stream does not wait for the key-line stream at all
+            HIP_TRY(ctx, hipEventRecord(s->ev_match, st));
+            HIP_TRY(ctx, hipStreamWaitEvent(sp, s->ev_match, 0));
+        }
         if (par && inline_sync) {
             stvo::launch_stream_signal(sl, s->d_join_flag, ++s->join_epoch);
         } else if (par) {  // join before optimizePose
             HIP_TRY(ctx, hipEventRecord(s->ev_join, sl));
-            HIP_TRY(ctx, hipStreamWaitEvent(st, s->ev_join, 0));
+            HIP_TRY(ctx, hipStreamWaitEvent(sp, s->ev_join, 0));
         }
         if (s->pev[0]) (void)hipEventRecord(s->pev[3], st);
         s->fetch_by_pose = s->fetch && inline_sync;
@@ -1374,10 +1481,10 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl, bool* forked_by
         std::memset(&a, 0, sizeof(a));
         a.B = B; a.max_pts = K; a.max_lines = M;
         a.n_prev_pts = s->op.has_points ? ps.n : nullptr;
-        a.prev_rc = ps.rc; a.curr_rc = cs.rc; a.q_tab = s->d_qtab; a.level_scale = s->mp.orb_scale_factor; a.m12p = s->m12p;
+        a.prev_rc = ps.rc; a.curr_rc = cs.rc; a.q_tab = s->d_qtab; a.level_scale = s->mp.orb_scale_factor; a.m12p = m12p_use;
         a.n_prev_lines = s->op.has_lines ? ps.nl : nullptr;
         a.prev_sP = ps.sP; a.prev_eP = ps.eP; a.prev_spl = ps.spl; a.prev_epl = ps.epl; a.prev_s2l = ps.s2lm;
-        a.curr_le = cs.le; a.m12l = s->m12l;
+        a.curr_le = cs.le; a.m12l = m12l_use;
         a.cams = s->d_cams; a.prm = s->op;
         a.init_T = s->d_motion_T; a.next_T = s->d_motion_T;  // (nullptr: DT = I, use_motion_model = false)
         a.results = s->zero_copy ? reinterpret_cast<stvo_pose_result*>(s->out_host) : s->results;
@@ -1406,9 +1513,24 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl, bool* forked_by
             a.fetch_flag = reinterpret_cast<unsigned*>(s->fetch_host + s->m12_span + s->inl_span);
             a.fetch_value = ++s->fetch_epoch;
         }
-        mark(8, st);
-        TRY(stvo::launch_pose(st, a));
-        mark(9, st);
+        const bool flagged = s->m12p_alt != nullptr && !s->graph_mode && stvo::pose_start_flag_ok(a);  // (batches on the batch kernel)
+        const bool gated = piped && pipe_sw != 2 && flagged;
+        if (flagged) {
+            a.start_flag = s->d_pose_flag;
+            a.start_value = ++s->pose_epoch;
+            s->pose_flag_frame = s->frame_idx;
+        }
+        mark(8, sp);
+        TRY(stvo::launch_pose(sp, a));
+        mark(9, sp);
+        if (piped) {
+            const int par2 = s->frame_idx & 1;
+            HIP_TRY(ctx, hipEventRecord(s->ev_pose[par2], sp));
+            s->pose_pending[par2] = true;
+            // the point stream's next kernels (the next step's matcher) behind the dispatch of this pose kernel's last workgroup
+            if (gated) stvo::launch_stream_gate(st, s->d_pose_flag, s->pose_epoch);
+        }
+        s->piped_last = piped;
         if (s->pev[0]) (void)hipEventRecord(s->pev[4], st);
         if (s->fetch && !inl_zero_copy) stvo::launch_copy16(st, s->inlp, s->fetch_host + s->m12_span, s->inl_span);
     } else {
@@ -1436,10 +1558,10 @@ int stvo_seq_step_dev(stvo_seq* s, int slot) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     StepFlags fl;
     fl.lines_now = s->op.has_lines && s->raw_lines[slot];
-    fl.lines_prev = s->op.has_lines && s->set_lines[s->cur ^ 1];
+    fl.lines_prev = s->op.has_lines && s->set_lines[s->prev_set()];
     fl.track = s->frame_idx > 0;
     {   // the grid buffers of this step (stvo_seq::cells_buf), and the line stream behind every upload the point stream holds
-        const stvo_seq::CellsBuf& cb = s->cells_buf[s->cur];
+        const stvo_seq::CellsBuf& cb = s->cells_buf[s->frame_idx & 1];
         s->d.pstart = cb.pstart; s->d.pperm = cb.pperm; s->d.pcell = cb.pcell; s->d.plperm = cb.plperm; s->d.plstart = cb.plstart;
         if (s->line_stream && s->upload_seen != s->upload_seq) {
             HIP_TRY(ctx, hipStreamWaitEvent(s->line_stream, s->ev_upload, 0));
@@ -1451,8 +1573,8 @@ int stvo_seq_step_dev(stvo_seq* s, int slot) {
     // profiling modes record events the host waits on, which a captured graph cannot provide
     const bool use_graph = s->graph_mode && s->frame_idx >= 2 && !s->timing && !s->fetch && !s->pev[0] && !ctx->overlap;
     if (use_graph) {
-        const unsigned key = (unsigned)slot | ((unsigned)s->cur << 8) | ((unsigned)fl.lines_now << 9) | ((unsigned)fl.lines_prev << 10) |
-                             ((unsigned)fl.track << 11);
+        const unsigned key = (unsigned)slot | ((unsigned)s->cur << 8) | ((unsigned)fl.lines_now << 10) | ((unsigned)fl.lines_prev << 11) |
+                             ((unsigned)fl.track << 12) | ((unsigned)(s->frame_idx & 1) << 13);  // (set index 0..2, grid-buffer parity)
         auto it = s->graphs.find(key);
         if (it == s->graphs.end()) {
             hipGraph_t graph = nullptr;
@@ -1482,7 +1604,7 @@ int stvo_seq_step_dev(stvo_seq* s, int slot) {
     s->set_lines[s->cur] = fl.lines_now;
     s->last_lines = fl.lines_now;
     s->last_slot = slot;
-    s->cur ^= 1;  // updateFrame: curr becomes prev
+    s->cur = (s->cur + 1) % 3;  // updateFrame: curr becomes prev
     s->frame_idx++;
     return STVO_OK;
 }
@@ -1495,7 +1617,8 @@ int stvo_seq_read(stvo_seq* s, stvo_pose_result* results, int32_t* counts) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int B = s->B;
     hipStream_t st = ctx->stream;
-    const stvo_seq::Set& ls = s->set[s->cur ^ 1];  // the set built by the last step (cur was flipped)
+    const stvo_seq::Set& ls = s->set[s->prev_set()];  // the set built by the last step (cur has moved on)
+    TRY(seq_wait_pose_stream(s));  // pipelined steps: the last pose kernels run on the aux stream
     if (s->d_prof && s->frame_idx > 1) {  // STVO_POSE_PROF: mean phase ticks of the last pose launch (as stvo_time_stage_dev prints them)
         HIP_TRY(ctx, hipStreamSynchronize(st));
         std::vector<long long> h((size_t)B * 16);
@@ -1643,6 +1766,7 @@ int stvo_seq_get_stage_timing(stvo_seq* s, float avg_ms[STVO_SEQ_NSTAGE], int32_
     stvo_ctx* ctx = s->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    TRY(seq_wait_pose_stream(s));  // (pipelined steps: the pose kernel's pair is on the aux stream)
     double acc[STVO_SEQ_NSTAGE] = {0};
     int cnt[STVO_SEQ_NSTAGE] = {0};
     for (size_t k = 0; k + 2 * STVO_SEQ_NSTAGE <= s->tev_used; k += 2 * STVO_SEQ_NSTAGE)

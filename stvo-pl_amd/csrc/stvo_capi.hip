@@ -41,6 +41,9 @@ DebugSwitches parse_switches() {
     d.grid_fused = env_int("STVO_GRID_FUSED");
     d.grid_fused_cap = env_int("STVO_GRID_FUSED_CAP");
     d.grid_cells = env_int("STVO_GRID_CELLS");
+    d.seq_pipe = env_int("STVO_SEQ_PIPE");
+    d.lines_ahead = env_int("STVO_LINES_AHEAD");
+    d.grid_dyn = env_int("STVO_GRID_DYN");
     d.lsd_grow = env_int("STVO_LSD_GROW");
     d.lsd_sort_full = env_int("STVO_LSD_SORT_FULL");
     d.lsd_waves = env_int("STVO_LSD_WAVES");
@@ -143,8 +146,9 @@ int stvo_ctx_destroy(stvo_ctx* ctx) {
         (void)hipStreamSynchronize(ctx->aux_stream);
         stvo::pose_release_stream(ctx->aux_stream);
         (void)hipStreamDestroy(ctx->aux_stream);
-        (void)hipEventDestroy(ctx->ev_match_done);
-        (void)hipEventDestroy(ctx->ev_pose_done);
+        // (the aux stream may have been created by a sequence pipeline — pipelined steps — without the overlap mode's events)
+        if (ctx->ev_match_done) (void)hipEventDestroy(ctx->ev_match_done);
+        if (ctx->ev_pose_done) (void)hipEventDestroy(ctx->ev_pose_done);
     }
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -178,6 +182,8 @@ int stvo_ctx_set_overlap(stvo_ctx* ctx, int enable) {
     if (enable && !ctx->aux_stream) {
         HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
         stvo::pose_retain_stream(ctx->aux_stream);
+    }
+    if (enable && !ctx->ev_match_done) {  // (a sequence pipeline may have created the aux stream before: its pipelined steps)
         HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_match_done, hipEventDisableTiming));
         HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_pose_done, hipEventDisableTiming));
     }
