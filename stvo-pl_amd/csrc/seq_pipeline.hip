@@ -1321,9 +1321,19 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl, bool* forked_by
                                      stvo::dbg().cells_ahead != 0;
             // key-line stage ahead (stvo_seq: fork_rec_frame): the line stream waits for the PREVIOUS step's fork event — in front of the
             // cells kernel, whose output copy the matcher of two steps ago read — and not for this step's
-            const bool lines_ahead = cells_ahead && !piped && alt_ok && s->fork_rec_frame == (long long)s->frame_idx - 1 &&
-                                     stvo::dbg().lines_ahead != 0;
+            // Only where it was measured to pay: ~100 key-lines per image (their kernels are a few per cent of the step) behind a pose kernel
+            // that publishes its start, i.e. the two-waves-per-pair batch kernel.  With hundreds of key-lines per image the line kernels are
+            // long enough to hold the pose kernel's freed slots against the next matcher: 512 EuRoC-shaped streams 0.442 -> 0.520 ms per step
+            // (round 6), so those keep the fork of their own step.  STVO_LINES_AHEAD=1 forces it wherever it is safe.
+            const int la_sw = stvo::dbg().lines_ahead;
+            const bool la_pays = s->pose_flag_frame == (long long)s->frame_idx - 1 && B > 2 * stvo::device_cu_count() &&
+                                 std::max(s->raw_max_lines[slot], s->set_lines_cap[s->prev_set()]) <= 128;
+            const bool lines_ahead = cells_ahead && !piped && alt_ok && s->fork_rec_frame == (long long)s->frame_idx - 1 && la_sw != 0 &&
+                                     (la_sw == 1 || la_sw == 2 || la_pays);
+            // (STVO_LINES_AHEAD=2: the gate in front of the cells kernel too — experiment)
+            const bool gate_cells = lines_ahead && stvo::dbg().lines_ahead == 2 && s->pose_flag_frame == (long long)s->frame_idx - 1;
             if (lines_ahead) HIP_TRY(ctx, hipStreamWaitEvent(sl, s->ev_fork, 0));
+            if (gate_cells) stvo::launch_stream_gate(sl, s->d_pose_flag, s->pose_epoch);
             if (g.fused_cells)
                 g.cells = stvo::point_cells_args(d);
             else if (g.lean_cells)
@@ -1344,7 +1354,7 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl, bool* forked_by
                 if (!s->graph_mode) s->fork_rec_frame = s->frame_idx;
                 if (!lines_ahead)
                     HIP_TRY(ctx, hipStreamWaitEvent(sl, s->ev_fork, 0));
-                else if (s->pose_flag_frame == (long long)s->frame_idx - 1)  // the key-line kernels behind the dispatch of optimizePose(k - 1)
+                else if (!gate_cells && s->pose_flag_frame == (long long)s->frame_idx - 1)  // the key-line kernels behind the dispatch of optimizePose(k - 1)
                     stvo::launch_stream_gate(sl, s->d_pose_flag, s->pose_epoch);
             }
             // pipelined steps: the persistent matcher starts beside the previous step's pose kernel — frames by ticket (GridBatch::dyn_ctr)

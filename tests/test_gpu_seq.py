@@ -444,3 +444,48 @@ def test_seq_pipeline_headline_shape_every_stream_vs_oracle(oracle, switches, po
     finally:
         dev.close()
         ctx.close()
+
+
+def test_seq_steps_back_to_back_schedules_agree(switches):
+    """Round 6: three stereo sets, two copies of the f2f match indices, and two schedules built on them — the key-line stage one step
+    AHEAD (the line stream waits for the previous step's fork event and a gate behind the dispatch of the previous pose kernel: the
+    default for > 2 x CUs streams with ~100 key-lines per image) and the pipelined steps (optimizePose on the aux stream beside the next
+    step's stereo association, the persistent point matcher taking frames by ticket: opt-in).  Seven steps enqueued BACK TO BACK — only
+    then do the overlaps they are about happen — must leave exactly the poses, counts and inlier totals of the plain schedule with a read
+    after every step (the one the headline-shape test compares with the oracle stream by stream)."""
+    from stvo_amd import capi
+    B, S = 320, 3
+    ids = np.arange(B) % synth.CONFIG5_N_SEQUENCES
+    streams = [synth.make_config5_sequence(int(s), n_frames=S, n_pts=900, n_lines=60, replica=700 + b // 8) for b, s in enumerate(ids)]
+    cams = [synth.config5_cam(int(s)) for s in ids]
+    mp = match_params("kitti"); op = opt_params("kitti")
+    order = [0, 1, 2, 1, 0, 1, 2]
+
+    def run(env, read_every_step):
+        switches(env)
+        ctx = capi.Context(device_id=0, max_rows=2048, max_batch=B)
+        dev = capi.Sequences(ctx, B, 2048, 128, cams, mp, op)
+        try:
+            dev.set_slots(S)
+            for k in range(S):
+                dev.upload(k, [st[k] for st in streams])
+            for cur in order:
+                dev.step_dev(cur)
+                if read_every_step:
+                    dev.read()
+            res, counts = dev.read()
+            return res.copy(), counts.copy()
+        finally:
+            dev.close()
+            ctx.close()
+
+    base = {"STVO_LINES_AHEAD": "0", "STVO_SEQ_PIPE": "0", "STVO_GRID_DYN": "1"}
+    ref_res, ref_counts = run(base, True)
+    assert (ref_res["status"] == 0).mean() > 0.9 and ref_counts[:, 2].mean() > 500
+    for name, env in (("plain, back to back", base), ("key-line stage ahead", dict(base, STVO_LINES_AHEAD="1")),
+                      ("key-line stage ahead, gate in front of the cells kernel", dict(base, STVO_LINES_AHEAD="2")),
+                      ("pipelined steps", dict(base, STVO_SEQ_PIPE="1")), ("pipelined steps, static frames", dict(base, STVO_SEQ_PIPE="1", STVO_GRID_DYN="0")),
+                      ("pipelined steps, no gate", dict(base, STVO_SEQ_PIPE="2"))):
+        res, counts = run(env, False)
+        assert np.array_equal(counts, ref_counts), name
+        assert res.tobytes() == ref_res.tobytes(), name

