@@ -206,27 +206,46 @@ __global__ __launch_bounds__(256) void orb_fast_nms_kernel(OrbDev o) {
     }
     __syncthreads();
     const int n = s_n;
+    // 3a. the signed compass test on the dense list (circle points 0, 4, 8, 12 = south, east, north, west): at least two of them brighter, or two
+    //     darker, than the centre by more than t — what passes (~40 % of the list) is compacted ONCE MORE, into s_corner, so that the ~200
+    //     instructions of the corner score run on dense lanes too (round 6: a wave of the first list ran the score if any of its lanes passed)
     for (int j = tid; j < n; j += 256) {  // lanes of a wave carry consecutive j: lane 0 is active whenever any lane is
         const int i = s_list[j], sy = i / SC_W, sx = i - sy * SC_W;
         const uint8_t* c = tile8 + (sy + 3) * (IM_PITCH * 4) + (sx + 4);
         const int v = c[0];
-        // the signed compass test on the dense list (circle points 0, 4, 8, 12 = south, east, north, west)
         const int c0 = (int)c[3 * (IM_PITCH * 4)] - v, c4 = (int)c[3] - v, c8 = (int)c[-3 * (IM_PITCH * 4)] - v, c12 = (int)c[-3] - v;
         const int nb = (c0 > t) + (c4 > t) + (c8 > t) + (c12 > t), nd = (c0 < -t) + (c4 < -t) + (c8 < -t) + (c12 < -t);
-        int s = 0;
-        if (nb >= 2 || nd >= 2) s = fast_score_lds(tile8, sx + 4, sy + 3);
+        const bool pass = nb >= 2 || nd >= 2;
+        const unsigned long long bal = __ballot(pass);
+        int base = 0;
+        if (lane == 0 && bal) base = atomicAdd(&s_nc, __popcll(bal));
+        base = __shfl(base, 0, 64);
+        if (pass) s_corner[base + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)i;
+    }
+    __syncthreads();
+    const int n_pass = s_nc;
+    __syncthreads();  // (s_nc and s_n are counted anew below; s_list is free: the corners go there)
+    if (tid == 0) {
+        s_nc = 0;
+        s_n = 0;
+    }
+    __syncthreads();
+    // 3b. the corner score on the dense list of those; corners (score >= t) to the score tile and to s_list
+    for (int j = tid; j < n_pass; j += 256) {
+        const int i = s_corner[j], sy = i / SC_W, sx = i - sy * SC_W;
+        const int s = fast_score_lds(tile8, sx + 4, sy + 3);
         const bool corner = s >= t;  // t >= 1, so a corner's score is positive
         if (corner) sc[sy * SC_PITCH + sx] = (uint8_t)s;
         const unsigned long long bal = __ballot(corner);
         int base = 0;
         if (lane == 0 && bal) base = atomicAdd(&s_nc, __popcll(bal));
         base = __shfl(base, 0, 64);
-        if (corner) s_corner[base + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)i;
+        if (corner) s_list[base + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)i;
     }
     __syncthreads();
     const int nc = s_nc;
     for (int j = tid; j < nc; j += 256) {
-        const int i = s_corner[j], sy = i / SC_W, sx = i - sy * SC_W;
+        const int i = s_list[j], sy = i / SC_W, sx = i - sy * SC_W;
         const int x = x0 + sx - 1, y = y0 + sy - 1;
         bool kp = false;
         uint32_t s = 0u;
