@@ -90,6 +90,29 @@ __device__ __forceinline__ int fast_score_lds(const uint8_t* tile, int lx, int l
     return max(sb, sd) - 1;
 }
 
+// One side of cornerScore<16> (round 6): with the differences taken as sgn (p - v) — sgn = +1 for the bright test, -1 for the dark one —
+// both are "max over the 16 arcs of the smallest of the arc's 9 differences": half of fast_score_lds' work.  A pixel's score is the larger
+// of its two sides minus 1; a side the signed compass test ruled out cannot reach t (a 9-arc holds two compass points), so only the
+// sides that passed are evaluated (orb_fast_nms_kernel: one list entry per pixel and side).
+__device__ __forceinline__ int fast_score_side_lds(const uint8_t* tile, int lx, int ly, int sgn) {
+    const uint8_t* c = tile + ly * (IM_PITCH * 4) + lx;
+    const int v = c[0];
+    int d[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) d[k] = ((int)c[c_circle[k][1] * (IM_PITCH * 4) + c_circle[k][0]] - v) * sgn;
+    int mn2[16], mn4[16], mn8[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) mn2[k] = min(d[k], d[(k + 1) & 15]);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) mn4[k] = min(mn2[k], mn2[(k + 2) & 15]);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) mn8[k] = min(mn4[k], mn4[(k + 4) & 15]);
+    int sb = -255;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) sb = max(sb, min(mn8[k], d[(k + 8) & 15]));
+    return sb - 1;
+}
+
 // wave-aggregated append of up to four flagged items per lane: ONE LDS atomic per wave (lanes hammering one counter serialise)
 __device__ __forceinline__ void append4(const bool (&flag)[4], int* counter, int (&slot)[4]) {
     const int lane = threadIdx.x & 63;
@@ -215,25 +238,31 @@ __global__ __launch_bounds__(256) void orb_fast_nms_kernel(OrbDev o) {
         const int v = c[0];
         const int c0 = (int)c[3 * (IM_PITCH * 4)] - v, c4 = (int)c[3] - v, c8 = (int)c[-3 * (IM_PITCH * 4)] - v, c12 = (int)c[-3] - v;
         const int nb = (c0 > t) + (c4 > t) + (c8 > t) + (c12 > t), nd = (c0 < -t) + (c4 < -t) + (c8 < -t) + (c12 < -t);
-        const bool pass = nb >= 2 || nd >= 2;
+        // one entry per pixel with the side(s) that passed: bit 15 = the dark side only, bit 14 = both (a saddle: rare)
+        const bool pb = nb >= 2, pd = nd >= 2, pass = pb || pd;
         const unsigned long long bal = __ballot(pass);
         int base = 0;
         if (lane == 0 && bal) base = atomicAdd(&s_nc, __popcll(bal));
         base = __shfl(base, 0, 64);
-        if (pass) s_corner[base + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)i;
+        if (pass) s_corner[base + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)(i | (pb && pd ? 0x4000 : (pd ? 0x8000 : 0)));
     }
     __syncthreads();
     const int n_pass = s_nc;
-    __syncthreads();  // (s_nc and s_n are counted anew below; s_list is free: the corners go there)
+    __syncthreads();  // (s_nc is counted anew below; s_list is free: the corners go there)
     if (tid == 0) {
         s_nc = 0;
         s_n = 0;
     }
     __syncthreads();
-    // 3b. the corner score on the dense list of those; corners (score >= t) to the score tile and to s_list
+    // 3b. the score of the side that passed, on the dense list (both sides for the rare entries that ask for it: a uniform branch most
+    //     waves skip); a pixel whose score reaches t is a corner: score tile + corner list (s_list)
     for (int j = tid; j < n_pass; j += 256) {
-        const int i = s_corner[j], sy = i / SC_W, sx = i - sy * SC_W;
-        const int s = fast_score_lds(tile8, sx + 4, sy + 3);
+        const int e = s_corner[j], i = e & 0x3FFF, sy = i / SC_W, sx = i - sy * SC_W;
+        int s = fast_score_side_lds(tile8, sx + 4, sy + 3, (e & 0x8000) ? -1 : 1);
+        if (__any((e & 0x4000) != 0)) {
+            const int s2 = fast_score_side_lds(tile8, sx + 4, sy + 3, -1);
+            if (e & 0x4000) s = max(s, s2);
+        }
         const bool corner = s >= t;  // t >= 1, so a corner's score is positive
         if (corner) sc[sy * SC_PITCH + sx] = (uint8_t)s;
         const unsigned long long bal = __ballot(corner);
