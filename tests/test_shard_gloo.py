@@ -29,7 +29,8 @@ def _worker(rank, world, port, q):
     total, tmax = shard.aggregate(dist, frames_local, seconds_local)
     poses = np.tile(np.eye(4).reshape(1, 16) * (rank + 1), (3, 1))
     gathered = shard.gather_poses(dist, poses)
-    q.put((rank, seqs, total, tmax, [float(g[0, 0]) for g in gathered]))
+    rates = shard.gather_scalars(dist, 1000.0 * (rank + 1))   # bench.py: per_rank_frame_pairs_per_s
+    q.put((rank, seqs, total, tmax, [float(g[0, 0]) for g in gathered], rates))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -46,7 +47,8 @@ def test_two_rank_sharding_and_aggregation():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, s0, tot0, t0, g0), (r1, s1, tot1, t1, g1) = res
+    (r0, s0, tot0, t0, g0, p0), (r1, s1, tot1, t1, g1, p1) = res
+    assert p0 == p1 == [1000.0, 2000.0]                       # one rate per rank, in rank order, on every rank
     assert s0 == [0, 2, 4, 6] and s1 == [1, 3, 5, 7]          # sequence s -> rank s mod G
     assert tot0 == tot1 == 8000                               # whole-job frame pairs
     assert t0 == t1 == 1.5                                    # max over ranks
@@ -55,6 +57,7 @@ def test_two_rank_sharding_and_aggregation():
 
 def test_single_process_identity():
     assert shard.aggregate(None, 123, 4.5) == (123, 4.5)
+    assert shard.gather_scalars(None, 7.5) == [7.5]
     assert shard.sequences_for_rank(8, 1, 0) == list(range(8))
     assert sum(len(shard.sequences_for_rank(8, 4, r)) for r in range(4)) == 8
     assert shard.env_world()[0] >= 1
