@@ -116,7 +116,7 @@ def _gen_stream(args):
 
 def generate_streams(seq_ids, replicas, n_frames, n_pts, n_lines, cluster_kw=None):
     jobs = [(s, r, n_frames, n_pts, n_lines, cluster_kw) for s, r in zip(seq_ids, replicas)]
-    nproc = min(16, os.cpu_count() or 1, max(1, len(jobs) // 8))
+    nproc = min(32, os.cpu_count() or 1, max(1, len(jobs) // 8))
     if nproc <= 1:
         return [_gen_stream(j) for j in jobs]
     import multiprocessing as mp
@@ -575,7 +575,7 @@ def correlated_leg(ctx_dev, rank, B=512, n=2000, steps=8):
     return out
 
 
-def clustered_headline_leg(local_rank, streams, cams, S, steps, warmup, repeats, max_keylines):
+def clustered_headline_leg(local_rank, streams, cams, S, steps, warmup, repeats, max_keylines, model="clustered"):
     """The HEADLINE workload — same pipeline, same stream count, same slot rotation — on streams whose landmark descriptors are
     clustered (CORRELATED_MODELS["clustered"]: 60 % of the rows in groups of ~8 near-duplicates) instead of i.i.d. bits: the mutual
     check of StVO::match then needs its reverse scans (the i.i.d. rows need none), and the grid matcher sees close second bests.
@@ -609,7 +609,7 @@ def clustered_headline_leg(local_rank, streams, cams, S, steps, warmup, repeats,
         stage_ms, n_timed = pipe.get_stage_timing()
         pipe.set_stage_timing(False)
         res, counts = pipe.read()
-        return {"descriptor_model": CORRELATED_MODELS["clustered"], "value": B * steps / dt, "unit": "frame-pairs/s", "ms_per_step": dt / steps * 1e3,
+        return {"descriptor_model": CORRELATED_MODELS.get(model, model), "value": B * steps / dt, "unit": "frame-pairs/s", "ms_per_step": dt / steps * 1e3,
                 "streams": B, "steps": steps, "repeats": len(rep), "stage_ms": stage_ms,
                 "committed_pose_fraction": float((res["status"] == 0).mean()), "mean_stereo_points": float(counts[:, 0].mean()),
                 "mean_matched_points": float(counts[:, 2].mean())}
@@ -789,7 +789,7 @@ def short_line(full):
     cfg = full.get("config") or {}
     out["config"] = _pick(cfg, ("workload", "streams_per_gpu", "resident_frames_per_stream", "keypoints_per_image", "keylines_per_image",
                                 "mean_stereo_points", "mean_matched_points", "mean_matched_lines", "parallelism", "committed_pose_fraction",
-                                "value_clustered", "value_clustered_over_value"))
+                                "value_clustered", "value_clustered_over_value", "value_1024_streams"))
     par = full.get("parity_sampled")
     out["parity_sampled"] = _pick(par, ("ok", "skipped", "frame_pairs_checked", "max_rot_err_rad", "max_trans_err_m")) if isinstance(par, dict) else par
     for k in ("roofline", "roofline_pose", "roofline_grid_scan"):
@@ -867,7 +867,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=6)
-    ap.add_argument("--batch", type=int, default=1024, help="independent stereo sequences (streams) per GPU; the committed PMC passes (roofline traffic) are of this default")
+    ap.add_argument("--batch", type=int, default=3072, help="independent stereo sequences (streams) per GPU: three residency rounds of the pose kernel (round 6: 1.29 M frame pairs/s "
+                         "at 1024, 1.33 M at 2048, 1.37 M at 3072, 1.37 M at 4096 — the event gaps of a step and the pose kernel's tail are paid once per step); the committed PMC passes "
+                         "(roofline traffic) are of this default; config.value_1024_streams keeps the figure of rounds 2 - 5's batch")
     ap.add_argument("--slots", type=int, default=4, help="consecutive frames of every stream kept resident in HBM")
     ap.add_argument("--points", type=int, default=1650, help="landmarks per stream; + 20 %% distractors ~ 2000 key-points per image")
     ap.add_argument("--lines", type=int, default=85, help="3-D segments per stream; + 20 %% distractors ~ 100 key-lines per image")
@@ -1150,6 +1152,12 @@ def main():
             out["config"]["value_clustered_note"] = ("the same pipeline and stream count on streams whose landmark descriptors are clustered "
                                                      "(60 % of the rows in groups of ~8 near-duplicates, spread 6 % of the bits): the i.i.d. "
                                                      "rows of `value` need no reverse distance evaluation in the mutual check, these do")
+        if B > 1024:   # the batch of rounds 2 - 5, on the first 1024 of the same streams
+            extra("headline_1024_streams", clustered_headline_leg, local_rank, streams[:1024], cams[:1024], S, args.steps, args.warmup, args.repeats,
+                  args.max_keylines, model="i.i.d. descriptor bits (the streams of `value`)")
+            h1 = out["headline_1024_streams"]
+            if "error" not in h1:
+                out["config"]["value_1024_streams"] = h1["value"]
         extra("latency", single_stream_latency, local_rank, args.points, args.lines)
         extra("configs1", configs1_leg, dev_name, rank)
         extra("configs3", configs3_leg, local_rank, c3_seqs)

@@ -180,9 +180,13 @@ struct PoseArgs {
     unsigned fetch_n16;
     unsigned* fetch_flag;
     unsigned fetch_value;
-    // start_flag (batch kernel pose2c only; nullptr otherwise): the LAST workgroup of the launch publishes start_value there when it
-    // starts — every workgroup of the launch has then been dispatched.  The pipelined steps of seq_pipeline.hip hold the NEXT step's
-    // point matcher behind it (launch_stream_gate), so that the matcher's one-per-CU workgroups do not take the CUs first.
+    // start_flag (batch kernel pose2c only; nullptr otherwise): the FIRST workgroup of the launch publishes start_value there when it
+    // starts — the launch is taking its CUs (1024 workgroups are placed within a few microseconds).  seq_pipeline.hip holds the next
+    // step's key-line kernels behind it (launch_stream_gate), so that their workgroups do not take the CUs first.  Not the LAST
+    // workgroup: 1024 frame pairs fill every VGPR of the chip (2 waves x 256 registers per SIMD), so the SIMD that hosts the waiting
+    // gate wave has room for one pose wave only — the last workgroup could not start before the gate left, and the gate waited for the
+    // last workgroup: a circular wait that resolved only when the first frame pair of the launch finished, 160 us later (round 6: every
+    // second pipeline of a process ran 0.864 instead of 0.793 ms per step that way, depending on where the gate wave had landed).
     unsigned* start_flag;
     unsigned start_value;
 };

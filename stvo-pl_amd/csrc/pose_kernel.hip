@@ -644,9 +644,11 @@ __global__ void stream_signal_kernel(unsigned* flag, unsigned value) {
 }
 // one thread: leaves when *flag has reached `value` (wrap-safe) or after ~0.5 ms — a scheduling hint (kernels.h: launch_stream_gate)
 __global__ void stream_gate_kernel(const unsigned* flag, unsigned value) {
-    for (int spin = 0; spin < 400; ++spin) {  // (polls ~3 us apart: polling every ~0.2 us made forward_plan_kernel, which runs beside it, 7 us slower)
+    // (the wave holds a VGPR granule of its SIMD while it waits: one wave of the 256-register pose kernel does not fit beside it, so it
+    //  must leave quickly once that kernel has begun — polls ~0.4 us apart)
+    for (int spin = 0; spin < 3000; ++spin) {
         if ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - value) >= 0) break;
-        __builtin_amdgcn_s_sleep(127);
+        __builtin_amdgcn_s_sleep(16);
     }
 }
 }  // namespace

@@ -623,7 +623,7 @@ __global__ __launch_bounds__(NW * 64, 2) void pose2c_kernel(PoseArgs a_by_value,
         else return 0ll;
     };
     const long long t_begin = tick();
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0 && ka().start_flag)  // every workgroup of this launch has been dispatched (kernels.h)
+    if (blockIdx.x == 0 && threadIdx.x == 0 && ka().start_flag)  // this launch has begun to take the CUs (kernels.h)
         __hip_atomic_store(ka().start_flag, ka().start_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     stvo_cam cam_f;
     if (ka().cams) {

@@ -640,8 +640,8 @@ struct stvo_seq {
     // two independent: the third stereo set (above), a second copy of the f2f match indices (odd steps write m12p_alt / m12l_alt), and the
     // events ev_match (point stream -> pose: the indices are complete) / ev_pose[k & 1] (pose -> the step that overwrites what it read).
     // The ORDER in which the two become ready matters for speed only: the pose kernel's workgroups must be dispatched before the matcher's
-    // (one per CU, most of its LDS), so the point stream passes a one-thread gate kernel that leaves when the pose kernel's last workgroup
-    // has started (PoseArgs::start_flag) — bounded, a hint: every data dependence is carried by the events.
+    // (one per CU, most of its LDS), so the point stream passes a one-thread gate kernel that leaves when the pose kernel
+    // has begun (PoseArgs::start_flag; kernels.h says why not "has been dispatched completely") — bounded, a hint: every data dependence is carried by the events.
     int32_t *m12p_alt = nullptr, *m12l_alt = nullptr;
     hipEvent_t ev_match = nullptr, ev_pose[2] = {nullptr, nullptr};
     unsigned* d_pose_flag = nullptr;
@@ -1537,7 +1537,7 @@ int seq_enqueue_step(stvo_seq* s, int slot, const StepFlags& fl, bool* forked_by
             const int par2 = s->frame_idx & 1;
             HIP_TRY(ctx, hipEventRecord(s->ev_pose[par2], sp));
             s->pose_pending[par2] = true;
-            // the point stream's next kernels (the next step's matcher) behind the dispatch of this pose kernel's last workgroup
+            // the point stream's next kernels (the next step's matcher) behind the start of this pose kernel
             if (gated) stvo::launch_stream_gate(st, s->d_pose_flag, s->pose_epoch);
         }
         s->piped_last = piped;
