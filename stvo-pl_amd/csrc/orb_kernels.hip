@@ -545,7 +545,25 @@ __global__ __launch_bounds__(BL_T) void orb_blur_kernel(OrbDev o, BlurK kk) {
     uint8_t* out = o.blur + (size_t)b * o.rows * o.cols;
     const uint32_t k03 = (uint32_t)kk.k[0] | ((uint32_t)kk.k[1] << 8) | ((uint32_t)kk.k[2] << 16) | ((uint32_t)kk.k[3] << 24);
     const uint32_t k46 = (uint32_t)kk.k[4] | ((uint32_t)kk.k[5] << 8) | ((uint32_t)kk.k[6] << 16);
-    const bool interior = x >= 4 && x + 8 <= o.cols;
+    // The three words of a row — bytes x - 4 .. x - 1, x .. x + 3, x + 4 .. x + 7 under BORDER_REFLECT_101 — as ONE word load + ONE v_perm each,
+    // for every thread alike: four consecutive positions reflect into a window of at most four bytes, so each word is a word of the row (at
+    // a per-thread offset) with its bytes permuted (a per-thread selector; the identity away from the border).  Offsets and selectors are
+    // computed once, not per row.  (Round 6: the border threads used to take a byte-by-byte path — 12 byte loads and 12 reflections per
+    // row, inlined 22 times — and dragged their whole wave through it: two of the five waves of an image row.)
+    int woff[3];
+    uint32_t wsel[3];
+#pragma unroll
+    for (int wi = 0; wi < 3; ++wi) {
+        int q[4], lo = 0x7FFFFFFF;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            q[i] = reflect101(x - 4 + 4 * wi + i, o.cols);
+            lo = min(lo, q[i]);
+        }
+        lo = max(min(lo, o.cols - 4), 0);
+        woff[wi] = lo;
+        wsel[wi] = (uint32_t)(q[0] - lo) | ((uint32_t)(q[1] - lo) << 8) | ((uint32_t)(q[2] - lo) << 16) | ((uint32_t)(q[3] - lo) << 24);
+    }
     uint32_t h[7][4];
 #pragma unroll
     for (int j = 0; j < 7; ++j)
@@ -557,20 +575,9 @@ __global__ __launch_bounds__(BL_T) void orb_blur_kernel(OrbDev o, BlurK kk) {
         if (r >= 6 && yo >= o.rows) break;          // uniform over the workgroup
         const int gy = reflect101(y0 + r - 3, o.rows);
         const uint8_t* row = img + (size_t)gy * o.cols;
-        uint32_t w0, w1, w2;  // bytes x - 4 .. x - 1, x .. x + 3, x + 4 .. x + 7
-        if (interior) {
-            w0 = *reinterpret_cast<const u32_unaligned*>(row + x - 4);
-            w1 = *reinterpret_cast<const u32_unaligned*>(row + x);
-            w2 = *reinterpret_cast<const u32_unaligned*>(row + x + 4);
-        } else {  // image border: BORDER_REFLECT_101 byte by byte
-            w0 = w1 = w2 = 0u;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                w0 |= (uint32_t)row[reflect101(x - 4 + i, o.cols)] << (8 * i);
-                w1 |= (uint32_t)row[reflect101(x + i, o.cols)] << (8 * i);
-                w2 |= (uint32_t)row[reflect101(x + 4 + i, o.cols)] << (8 * i);
-            }
-        }
+        const uint32_t w0 = __builtin_amdgcn_perm(0u, *reinterpret_cast<const u32_unaligned*>(row + woff[0]), wsel[0]);
+        const uint32_t w1 = __builtin_amdgcn_perm(0u, *reinterpret_cast<const u32_unaligned*>(row + woff[1]), wsel[1]);
+        const uint32_t w2 = __builtin_amdgcn_perm(0u, *reinterpret_cast<const u32_unaligned*>(row + woff[2]), wsel[2]);
         // output i: taps x + i - 3 .. x + i + 3 = bytes i + 1 .. i + 7 of (w0, w1, w2)
         uint32_t hs[4];
         hs[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 1), k03, 0u, false);
@@ -593,7 +600,7 @@ __global__ __launch_bounds__(BL_T) void orb_blur_kernel(OrbDev o, BlurK kk) {
             for (int i = 0; i < 4; ++i) {
                 uint32_t sv = 1u << 15;
 #pragma unroll
-                for (int j = 0; j < 7; ++j) sv += (uint32_t)kk.k[j] * h[j][i];
+                for (int j = 0; j < 7; ++j) sv += __umul24((uint32_t)kk.k[j], h[j][i]);  // (weights <= 2^8, row sums <= 2^16: the 24-bit multiply-add is exact and full rate)
                 px |= min(sv >> 16, 255u) << (8 * i);
             }
             uint8_t* dst = out + (size_t)yo * o.cols + x;
