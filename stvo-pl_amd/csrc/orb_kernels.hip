@@ -685,21 +685,22 @@ __global__ __launch_bounds__(256) void orb_describe_kernel(OrbDev o, Umax um) {
     const uint8_t* patch8 = reinterpret_cast<const uint8_t*>(patch);
     // the patches lie inside the image (edge threshold >= 19 + 1 word of slack is NOT guaranteed on the left / right: clamp the
     // word address into the image buffer; the clamped words hold columns the disc / the pattern never reads)
-    const uint8_t* img_lo = o.img + base;
-    const uint8_t* img_hi = o.img + base + (size_t)o.rows * o.cols - 4;
+    // (round 6: 32-bit offsets into the image, clamped with one v_med3 — the clamped POINTERS cost two 64-bit compares and four selects per word,
+    //  a quarter of the kernel's vector instructions)
+    const uint8_t* img_b = o.img + base;
+    const int off_hi = o.rows * o.cols - 4;
     {
         // all 16 words of a lane's share are requested before the first is stored (as a loop the compiler made four groups of four
         // loads with a wait after each: four memory round trips one after the other at the start of every wave)
         constexpr int IW_N = (IC_PH * IC_PW + 15) / 16;
         uint32_t iw[IW_N];
-        const uint8_t* org = o.img + base + (size_t)(y - ORB_HP) * o.cols + (x - 16);
+        const int org = (y - ORB_HP) * o.cols + (x - 16);
 #pragma unroll
         for (int j = 0; j < IW_N; ++j) {
             const int i = l + 16 * j;
             const int r = i >> 3, w = i & 7;
-            const uint8_t* p = org + (size_t)r * o.cols + 4 * w;
-            p = p < img_lo ? img_lo : (p > img_hi ? img_hi : p);  // (i beyond the patch: a clamped, unused word)
-            iw[j] = *reinterpret_cast<const u32_unaligned*>(p);
+            const int off = min(max(org + (int)__umul24((unsigned)r, (unsigned)o.cols) + 4 * w, 0), off_hi);  // (i beyond the patch: a clamped, unused word)
+            iw[j] = *reinterpret_cast<const u32_unaligned*>(img_b + off);
         }
 #pragma unroll
         for (int j = 0; j < IW_N; ++j) patch[l + 16 * j] = iw[j];  // (unconditional: a store under `i < 248` took its load along, into a round trip of its own)
@@ -712,16 +713,14 @@ __global__ __launch_bounds__(256) void orb_describe_kernel(OrbDev o, Umax um) {
     constexpr int BW_N = (DESC_PH * DESC_PW + 15) / 16;
     uint32_t bw[BW_N];
     {
-        const uint8_t* blur_lo = o.blur + base;
-        const uint8_t* blur_hi = o.blur + base + (size_t)o.rows * o.cols - 4;
-        const uint8_t* org = o.blur + base + (size_t)(y - DESC_R) * o.cols + (x - 20);
+        const uint8_t* blur_b = o.blur + base;
+        const int org = (y - DESC_R) * o.cols + (x - 20);
 #pragma unroll
         for (int j = 0; j < BW_N; ++j) {
             const int i = l + 16 * j;
             const int r = i / DESC_PW, w = i - r * DESC_PW;
-            const uint8_t* p = org + (size_t)r * o.cols + 4 * w;
-            p = p < blur_lo ? blur_lo : (p > blur_hi ? blur_hi : p);  // (i beyond the patch: a clamped, unused word)
-            bw[j] = *reinterpret_cast<const u32_unaligned*>(p);
+            const int off = min(max(org + (int)__umul24((unsigned)r, (unsigned)o.cols) + 4 * w, 0), off_hi);  // (i beyond the patch: a clamped, unused word)
+            bw[j] = *reinterpret_cast<const u32_unaligned*>(blur_b + off);
         }
     }
     // ICAngles: lane l owns ROWS l and l + 16 of the patch (dy = row - 15).  Integer moments, so the summation order is free: a row is 8
