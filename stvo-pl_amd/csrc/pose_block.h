@@ -511,17 +511,33 @@ __device__ __forceinline__ double norm3(const double* v) { return sqrt(v[0] * v[
 
 // H inc = g (ColPivHouseholderQR::solve at :417-418 and siblings): LDL^T when H is certified positive definite
 // (the normal case), the pivoted QR otherwise — see pose_math.h.
-__device__ __forceinline__ void solve_normal_eq(PoseSh* sh, double* inc, double* log_abs_det) {
+// ws: >= 51 doubles of LDS nobody else touches during the serial section (the callers pass the partial-sum rows: the other waves are
+// parked at the barrier behind it).  The pivoted fallback runs there, on memory operands with run-time loops (pm::solve6_mem: the same
+// operations in the same order) — inlined with its matrices in registers it was, together with inverse6 below, what the batch kernel
+// spilled 86 registers for (round 6: with both on memory operands pose2c_kernel<2> has no scratch).
+__device__ __forceinline__ void solve_normal_eq(PoseSh* sh, double* inc, double* log_abs_det, double* ws) {
     double H[36], g[6];
 #pragma unroll
     for (int i = 0; i < 36; ++i) H[i] = sh->H[i];
 #pragma unroll
     for (int i = 0; i < 6; ++i) g[i] = sh->g[i];
-    if (!pm::solve6_spd(H, g, inc, log_abs_det)) pm::solve6(H, g, inc, log_abs_det);
+    if (!pm::solve6_spd(H, g, inc, log_abs_det)) {
+        double* A = ws;
+        double* c = ws + 36;  // right-hand side, then the solution
+        double* y = ws + 42;
+        int* perm = reinterpret_cast<int*>(ws + 48);
+#pragma unroll 1
+        for (int i = 0; i < 36; ++i) A[i] = sh->H[i];
+#pragma unroll 1
+        for (int i = 0; i < 6; ++i) c[i] = sh->g[i];
+        pm::solve6_mem(A, c, y, perm, c, log_abs_det);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) inc[i] = c[i];
+    }
 }
 
 // body of gaussNewtonOptimization after optimizeFunctions (:405-428)
-__device__ __forceinline__ void t0_gn_iter(PoseSh* sh, double min_error, double min_error_change, int it) {
+__device__ __forceinline__ void t0_gn_iter(PoseSh* sh, double min_error, double min_error_change, int it, double* ws) {
     const double err = sh->err;
     if (err > sh->err_prev) {
         sh->action = it > 0 ? ACT_BREAK : ACT_FAIL;
@@ -532,7 +548,7 @@ __device__ __forceinline__ void t0_gn_iter(PoseSh* sh, double min_error, double 
         return;
     }
     double inc[6], DT[16];
-    solve_normal_eq(sh, inc, nullptr);
+    solve_normal_eq(sh, inc, nullptr, ws);
 #pragma unroll
     for (int i = 0; i < 16; ++i) DT[i] = sh->DT[i];
     pm::step_pose(DT, inc);
@@ -547,14 +563,14 @@ __device__ __forceinline__ void t0_gn_iter(PoseSh* sh, double min_error, double 
 }
 
 // body of gaussNewtonOptimizationRobust after optimizeFunctionsRobust (:449-467)
-__device__ __forceinline__ void t0_gnr_iter(PoseSh* sh, double min_error, double min_error_change) {
+__device__ __forceinline__ void t0_gnr_iter(PoseSh* sh, double min_error, double min_error_change, double* ws) {
     const double err = sh->err;
     if (fabs(err - sh->err_prev) < min_error_change || err < min_error) {
         sh->action = ACT_BREAK;
         return;
     }
     double inc[6], DT[16], lad;
-    solve_normal_eq(sh, inc, &lad);
+    solve_normal_eq(sh, inc, &lad, ws);
     if (lad < 0.0) {
         sh->good = 0;
         sh->action = ACT_BREAK;
@@ -577,7 +593,7 @@ __device__ __forceinline__ void t0_gnr_iter(PoseSh* sh, double min_error, double
 }
 
 // LM first iteration (:486-510) and loop body (:518-542)
-__device__ __forceinline__ void t0_lm_iter(PoseSh* sh, double min_error, double min_error_change, int first) {
+__device__ __forceinline__ void t0_lm_iter(PoseSh* sh, double min_error, double min_error_change, int first, double* ws) {
     const double err = sh->err;
     double inc[6], DT[16];
     if (first) {
@@ -590,7 +606,7 @@ __device__ __forceinline__ void t0_lm_iter(PoseSh* sh, double min_error, double 
         sh->lambda = 0.000000001 * Hmax;
 #pragma unroll
         for (int i = 0; i < 6; ++i) sh->H[i * 7] += sh->lambda;
-        solve_normal_eq(sh, inc, nullptr);
+        solve_normal_eq(sh, inc, nullptr, ws);
 #pragma unroll
         for (int i = 0; i < 16; ++i) DT[i] = sh->DT[i];
         pm::step_pose(DT, inc);
@@ -606,7 +622,7 @@ __device__ __forceinline__ void t0_lm_iter(PoseSh* sh, double min_error, double 
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) sh->H[i * 7] += sh->lambda;
-    solve_normal_eq(sh, inc, nullptr);
+    solve_normal_eq(sh, inc, nullptr, ws);
     if (err > sh->err_prev)
         sh->lambda /= 4.0;
     else {
@@ -625,13 +641,18 @@ __device__ __forceinline__ void t0_lm_iter(PoseSh* sh, double min_error, double 
     sh->action = ACT_CONTINUE;
 }
 
-__device__ __forceinline__ void t0_cov_from_H(PoseSh* sh) {
+__device__ __forceinline__ void t0_cov_from_H(PoseSh* sh, double* ws) {
     double H[36], Hi[36];
 #pragma unroll
     for (int i = 0; i < 36; ++i) H[i] = sh->H[i];
-    if (!pm::inverse6_spd(H, Hi)) pm::inverse6(H, Hi);  // Matrix6d::inverse(), :429 / :470 / :545
+    if (pm::inverse6_spd(H, Hi)) {  // Matrix6d::inverse(), :429 / :470 / :545
 #pragma unroll
-    for (int i = 0; i < 36; ++i) sh->cov[i] = Hi[i];
+        for (int i = 0; i < 36; ++i) sh->cov[i] = Hi[i];
+    } else {  // the pivoted LU on memory operands (see solve_normal_eq): a copy of H in ws, the inverse straight into sh->cov
+#pragma unroll 1
+        for (int i = 0; i < 36; ++i) ws[i] = sh->H[i];
+        pm::inverse6_mem(ws, sh->cov);
+    }
 }
 
 // isGoodSolution(DT, cov, err) -> sh->good; eigenvalues left in sh->eig

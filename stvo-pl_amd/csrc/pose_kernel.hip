@@ -426,9 +426,9 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_hist)[Block
                 tq = tick();
                 ++evals;
                 if (t0) {
-                    if (alg == 0) t0_gn_iter(sh, prm.min_error, prm.min_error_change, it);
-                    else if (alg == 1) t0_gnr_iter(sh, prm.min_error, prm.min_error_change);
-                    else t0_lm_iter(sh, prm.min_error, prm.min_error_change, it == 0 ? 1 : 0);
+                    if (alg == 0) t0_gn_iter(sh, prm.min_error, prm.min_error_change, it, &s_red[0][0]);
+                    else if (alg == 1) t0_gnr_iter(sh, prm.min_error, prm.min_error_change, &s_red[0][0]);
+                    else t0_lm_iter(sh, prm.min_error, prm.min_error_change, it == 0 ? 1 : 0, &s_red[0][0]);
                 }
                 __syncthreads();
                 tprof[1] += tick() - tq;
@@ -446,7 +446,7 @@ __device__ __forceinline__ void pose_body(const PoseArgs& a, int (*s_hist)[Block
 #pragma unroll
                     for (int i = 0; i < 36; ++i) sh->cov[i] = (i % 7 == 0) ? 1.0 : 0.0;
                 } else {
-                    t0_cov_from_H(sh);  // :429 / :470 / :545 — H of the last evaluation (damped for LM)
+                    t0_cov_from_H(sh, &s_red[0][0]);  // :429 / :470 / :545 — H of the last evaluation (damped for LM)
                     sh->err_out = evals > 0 ? sh->err : 0.0;
                 }
             }

@@ -50,7 +50,7 @@ struct PoseFlow {
 // prm(): the optimizer parameters, fetched where they are used (pose2c_kernel reads them from the kernel-argument segment)
 template <typename Prm, typename Eval, typename Rem, typename Tick>
 __device__ __forceinline__ PoseFlow optimize_pose_flow(PoseSh* sh, Prm&& prm, const bool w0, Eval&& evaluate,
-                                                       Rem&& remove_outliers, Tick&& tick, long long* tprof) {
+                                                       Rem&& remove_outliers, Tick&& tick, long long* tprof, double* ws) {
     int status = STVO_POSE_OK, path = 0, it0 = 0, it1 = 0;
     if (sh->n_inl_p + sh->n_inl_l >= prm().min_features) {
         int stage = 0;        // 0 = first optimisation (:335-338), 1 = refinement (:345-350), 2 = robust fallback (:359)
@@ -75,9 +75,9 @@ __device__ __forceinline__ PoseFlow optimize_pose_flow(PoseSh* sh, Prm&& prm, co
                     // the serial section is one wave's dependent chain while the co-resident workgroup's waves evaluate on the
                     // same SIMD: let it win the issue arbitration
                     if (POSE2P_PRIO) __builtin_amdgcn_s_setprio(3);
-                    if (alg == 0) t0_gn_iter(sh, prm().min_error, prm().min_error_change, it);
-                    else if (alg == 1) t0_gnr_iter(sh, prm().min_error, prm().min_error_change);
-                    else t0_lm_iter(sh, prm().min_error, prm().min_error_change, it == 0 ? 1 : 0);
+                    if (alg == 0) t0_gn_iter(sh, prm().min_error, prm().min_error_change, it, ws);
+                    else if (alg == 1) t0_gnr_iter(sh, prm().min_error, prm().min_error_change, ws);
+                    else t0_lm_iter(sh, prm().min_error, prm().min_error_change, it == 0 ? 1 : 0, ws);
                     if (POSE2P_PRIO) __builtin_amdgcn_s_setprio(0);
                 }
                 __syncthreads();
@@ -96,7 +96,7 @@ __device__ __forceinline__ PoseFlow optimize_pose_flow(PoseSh* sh, Prm&& prm, co
 #pragma unroll
                     for (int i = 0; i < 36; ++i) sh->cov[i] = (i % 7 == 0) ? 1.0 : 0.0;
                 } else {
-                    t0_cov_from_H(sh);  // :429 / :470 / :545 — H of the last evaluation (damped for LM)
+                    t0_cov_from_H(sh, ws);  // :429 / :470 / :545 — H of the last evaluation (damped for LM)
                     sh->err_out = evals > 0 ? sh->err : 0.0;
                 }
             }
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(NW * 64, 2) void pose2p_kernel(PoseArgs a, const in
         __syncthreads();
     };
 
-    const PoseFlow fl = optimize_pose_flow(sh, [&]() -> const stvo_opt_params& { return prm; }, w0, evaluate, remove_outliers, tick, tprof);
+    const PoseFlow fl = optimize_pose_flow(sh, [&]() -> const stvo_opt_params& { return prm; }, w0, evaluate, remove_outliers, tick, tprof, &s_red[0][0]);
     const int status = fl.status, path = fl.path, it0 = fl.it0, it1 = fl.it1;
 
     {
@@ -556,6 +556,27 @@ __device__ __forceinline__ void static_for(F&& f) {  // f(integral_constant<int,
         static_for<I + 1, N>(f);
     }
 }
+
+// N records {float4, double} as named members (see compact_inliers): a<R>() / b<R>() with compile-time R
+typedef float f4_native __attribute__((ext_vector_type(4)));  // (a plain vector type: nothing for the scalar-replacement pass to trip over)
+template <int N>
+struct RecRegs {
+    f4_native a0;
+    double b0;
+    RecRegs<N - 1> rest;
+    template <int R>
+    __device__ __forceinline__ f4_native& a() {
+        if constexpr (R == 0) return a0;
+        else return rest.template a<R - 1>();
+    }
+    template <int R>
+    __device__ __forceinline__ double& b() {
+        if constexpr (R == 0) return b0;
+        else return rest.template b<R - 1>();
+    }
+};
+template <>
+struct RecRegs<0> {};
 
 template <int NW>
 constexpr int pose2c_planes() {  // record ordinals per thread in LDS: 12 x 128 x 24 bytes = 36 KB of the 40 KB share (two waves);
@@ -986,16 +1007,18 @@ __global__ __launch_bounds__(NW * 64, 2) void pose2c_kernel(PoseArgs a_by_value,
         }
         __syncthreads();
         if (n_slow != 0 || total > KL * BLOCK) return;  // block-uniform: keep the owner layout
-        float4 ra[KL + 1];
-        double rb[KL + 1];
+        // (the records in a recursive struct of NAMED members, not in arrays: as `float4 ra[KL + 1]` the compiler kept twelve of them in a
+        //  192-byte stack object — scratch_store_dwordx4 behind every ds_read_b128 — which was most of what the kernel still wrote to scratch
+        //  after round 6 took the pivoted 6 x 6 fallbacks out of its registers: 25 MB per 1024 pairs)
+        RecRegs<HAS_REG ? KL + 1 : KL> regs;
         auto take = [&](auto rc) {
             constexpr int R = decltype(rc)::value;
             if constexpr (R < KL) {
-                ra[R] = s_ra[R * BLOCK + tid];
-                rb[R] = s_rb[R * BLOCK + tid];
+                regs.template a<R>() = *reinterpret_cast<const f4_native*>(&s_ra[R * BLOCK + tid]);
+                regs.template b<R>() = s_rb[R * BLOCK + tid];
             } else {
-                ra[R] = xa;
-                rb[R] = xb;
+                regs.template a<R>() = f4_native{xa.x, xa.y, xa.z, xa.w};
+                regs.template b<R>() = xb;
             }
         };
         static_for<0, HAS_REG ? KL + 1 : KL>(take);
@@ -1005,8 +1028,8 @@ __global__ __launch_bounds__(NW * 64, 2) void pose2c_kernel(PoseArgs a_by_value,
             auto put = [&](auto rc) {
                 constexpr int R = decltype(rc)::value;
                 if ((mov >> R) & 1u) {
-                    s_ra[g] = ra[R];
-                    s_rb[g] = rb[R];
+                    *reinterpret_cast<f4_native*>(&s_ra[g]) = regs.template a<R>();
+                    s_rb[g] = regs.template b<R>();
                     s_lvb[g] = (unsigned char)((lv >> (4 * R)) & 15u);
                     ++g;
                 }
@@ -1062,7 +1085,7 @@ __global__ __launch_bounds__(NW * 64, 2) void pose2c_kernel(PoseArgs a_by_value,
     };
 
     const PoseFlow fl = optimize_pose_flow(sh, [&]() -> const stvo_opt_params __attribute__((address_space(4)))& { return ka().prm; }, w0, evaluate,
-                                           remove_outliers, tick, tprof);
+                                           remove_outliers, tick, tprof, &s_red[0][0]);
 
     {
         const long long tq3 = tick();

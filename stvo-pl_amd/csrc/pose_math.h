@@ -456,6 +456,161 @@ PM_HD void inverse6(const double* Ain, double* Ai) {
     for (int i = 0; i < 36; ++i) Ai[i] = B[i];
 }
 
+// ---- the two pivoted routines above on MEMORY operands with run-time loops (round 6) --------------------------------------------
+// solve6 / inverse6 keep a 6x6 matrix (and a second one) in registers with every index a compile-time constant and every swap a
+// predicated move: ~150 live VGPRs, which the batch pose kernel pays as spills around its serial sections although the routines
+// only run when the LDL^T fast path refuses a matrix (rank-deficient geometry).  These forms do the SAME operations in the SAME
+// order — tests/test_pose_math_host.py holds them to bit-identical results — on arrays the caller provides (LDS on the device):
+// a handful of registers, slow, rare.
+// A [36] and c [6] are destroyed; ws_y [6] and ws_perm [6] are scratch.  Returns the numerical rank.
+PM_HD int solve6_mem(double* A, double* c, double* ws_y, int* perm, double* x, double* log_abs_det) {
+    double* y = ws_y;
+#pragma unroll 1
+    for (int i = 0; i < 6; ++i) {
+        perm[i] = i;
+        y[i] = 0.0;
+    }
+    double maxnorm2 = 0.0;
+#pragma unroll 1
+    for (int j = 0; j < 6; ++j) {
+        double s = 0.0;
+#pragma unroll 1
+        for (int i = 0; i < 6; ++i) s += A[i * 6 + j] * A[i * 6 + j];
+        maxnorm2 = s > maxnorm2 ? s : maxnorm2;
+    }
+    const double eps = 2.220446049250313e-16;
+    const double thr_helper = maxnorm2 * eps * eps / 6.0;
+    int rank = 6;
+    double lad = 0.0;
+#pragma unroll 1
+    for (int k = 0; k < 6; ++k) {
+        int big = k;
+        double bigsq = -1.0;
+#pragma unroll 1
+        for (int j = k; j < 6; ++j) {
+            double s = 0.0;
+#pragma unroll 1
+            for (int i = k; i < 6; ++i) s += A[i * 6 + j] * A[i * 6 + j];
+            if (s > bigsq) {
+                bigsq = s;
+                big = j;
+            }
+        }
+        if (rank == 6 && bigsq < thr_helper * (double)(6 - k)) rank = k;
+        if (big != k) {  // column swap k <-> big (the predicated form swaps with exactly one j > k)
+#pragma unroll 1
+            for (int i = 0; i < 6; ++i) {
+                const double a = A[i * 6 + k];
+                A[i * 6 + k] = A[i * 6 + big];
+                A[i * 6 + big] = a;
+            }
+            const int pa = perm[k];
+            perm[k] = perm[big];
+            perm[big] = pa;
+        }
+        const double c0 = A[k * 6 + k];
+        double tail = 0.0;
+#pragma unroll 1
+        for (int i = k + 1; i < 6; ++i) tail += A[i * 6 + k] * A[i * 6 + k];
+        double beta, tau;
+        if (tail <= 2.2250738585072014e-308) {
+            tau = 0.0;
+            beta = c0;
+#pragma unroll 1
+            for (int i = k + 1; i < 6; ++i) A[i * 6 + k] = 0.0;
+        } else {
+            beta = sqrt(c0 * c0 + tail);
+            if (c0 >= 0.0) beta = -beta;
+            const double den = c0 - beta;
+#pragma unroll 1
+            for (int i = k + 1; i < 6; ++i) A[i * 6 + k] /= den;
+            tau = (beta - c0) / beta;
+        }
+        A[k * 6 + k] = beta;
+        lad += log(fabs(beta));
+#pragma unroll 1
+        for (int j = k + 1; j < 6; ++j) {
+            double s = A[k * 6 + j];
+#pragma unroll 1
+            for (int i = k + 1; i < 6; ++i) s += A[i * 6 + k] * A[i * 6 + j];
+            s *= tau;
+            A[k * 6 + j] -= s;
+#pragma unroll 1
+            for (int i = k + 1; i < 6; ++i) A[i * 6 + j] -= s * A[i * 6 + k];
+        }
+        {
+            double s = c[k];
+#pragma unroll 1
+            for (int i = k + 1; i < 6; ++i) s += A[i * 6 + k] * c[i];
+            s *= tau;
+            c[k] -= s;
+#pragma unroll 1
+            for (int i = k + 1; i < 6; ++i) c[i] -= s * A[i * 6 + k];
+        }
+    }
+    if (log_abs_det) *log_abs_det = lad;
+#pragma unroll 1
+    for (int i = 5; i >= 0; --i) {
+        double s = c[i];
+#pragma unroll 1
+        for (int j = i + 1; j < 6; ++j) s -= A[i * 6 + j] * y[j];  // y[j] == 0 for j >= rank
+        y[i] = (i < rank) ? s / A[i * 6 + i] : 0.0;
+    }
+#pragma unroll 1
+    for (int i = 0; i < 6; ++i) x[perm[i]] = y[i];  // (perm is a permutation: every x[j] is written exactly once)
+    return rank;
+}
+
+// A [36] is destroyed (L \ U in place), B [36] receives the inverse.
+PM_HD void inverse6_mem(double* A, double* B) {
+#pragma unroll 1
+    for (int i = 0; i < 36; ++i) B[i] = (i % 7 == 0) ? 1.0 : 0.0;
+#pragma unroll 1
+    for (int k = 0; k < 6; ++k) {
+        int p = k;
+        double best = fabs(A[k * 6 + k]);
+#pragma unroll 1
+        for (int i = k + 1; i < 6; ++i) {
+            const double v = fabs(A[i * 6 + k]);
+            if (v > best) {
+                best = v;
+                p = i;
+            }
+        }
+        if (p != k) {
+#pragma unroll 1
+            for (int j = 0; j < 6; ++j) {
+                const double a = A[k * 6 + j];
+                A[k * 6 + j] = A[p * 6 + j];
+                A[p * 6 + j] = a;
+                const double c = B[k * 6 + j];
+                B[k * 6 + j] = B[p * 6 + j];
+                B[p * 6 + j] = c;
+            }
+        }
+        const double piv = A[k * 6 + k];
+#pragma unroll 1
+        for (int i = k + 1; i < 6; ++i) {
+            const double l = A[i * 6 + k] / piv;
+            A[i * 6 + k] = l;
+#pragma unroll 1
+            for (int j = k + 1; j < 6; ++j) A[i * 6 + j] -= l * A[k * 6 + j];
+#pragma unroll 1
+            for (int j = 0; j < 6; ++j) B[i * 6 + j] -= l * B[k * 6 + j];
+        }
+    }
+#pragma unroll 1
+    for (int i = 5; i >= 0; --i) {
+#pragma unroll 1
+        for (int col = 0; col < 6; ++col) {
+            double s = B[i * 6 + col];
+#pragma unroll 1
+            for (int j = i + 1; j < 6; ++j) s -= A[i * 6 + j] * B[j * 6 + col];
+            B[i * 6 + col] = s / A[i * 6 + i];
+        }
+    }
+}
+
 // Determinant by LU with partial pivoting (what Matrix6d::determinant() does for a 6x6: PartialPivLU).
 PM_HD double det6(const double* Ain) {
     double A[36];

@@ -31,6 +31,21 @@ void pmh_adjoint(const double* T, double* A) { pm::adjoint_se3(T, A); }
 void pmh_unccomp(const double* T1, const double* c1, const double* ci, double* out) { pm::unccomp_se3(T1, c1, ci, out); }
 int pmh_solve6(const double* H, const double* g, double* x, double* lad) { return pm::solve6(H, g, x, lad); }
 void pmh_inverse6(const double* A, double* Ai) { pm::inverse6(A, Ai); }
+// the memory-operand forms of the two pivoted routines (round 6): same operations, same order
+int pmh_solve6_mem(const double* H, const double* g, double* x, double* lad) {
+    double A[36], c[6], y[6];
+    int perm[6];
+    for (int i = 0; i < 36; ++i) A[i] = H[i];
+    for (int i = 0; i < 6; ++i) c[i] = g[i];
+    const int rank = pm::solve6_mem(A, c, y, perm, c, lad);   // (the solution aliases the right-hand side, as on the device)
+    for (int i = 0; i < 6; ++i) x[i] = c[i];
+    return rank;
+}
+void pmh_inverse6_mem(const double* Ain, double* Ai) {
+    double A[36];
+    for (int i = 0; i < 36; ++i) A[i] = Ain[i];
+    pm::inverse6_mem(A, Ai);
+}
 void pmh_eig6(const double* A, double* w) { pm::eig6(A, w); }
 void pmh_eig6_ql(const double* A, double* w) { pm::eig6_ql(A, w); }
 int pmh_solve6_spd(const double* H, const double* g, double* x, double* lad) { return pm::solve6_spd(H, g, x, lad) ? 1 : 0; }

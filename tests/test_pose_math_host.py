@@ -24,12 +24,13 @@ def pmh():
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-o", so, src])
     lib = C.CDLL(so)
-    for n in ("pmh_expmap", "pmh_logmap", "pmh_inverse_se3", "pmh_adjoint", "pmh_inverse6", "pmh_eig6", "pmh_step_pose",
+    for n in ("pmh_expmap", "pmh_logmap", "pmh_inverse_se3", "pmh_adjoint", "pmh_inverse6", "pmh_inverse6_mem", "pmh_eig6", "pmh_step_pose",
               "pmh_eig6_ql"):
         getattr(lib, n).argtypes = [f64p, f64p]; getattr(lib, n).restype = None
     lib.pmh_unccomp.argtypes = [f64p] * 4
     lib.pmh_solve6.argtypes = [f64p, f64p, f64p, C.POINTER(C.c_double)]; lib.pmh_solve6.restype = C.c_int
     lib.pmh_solve6_spd.argtypes = [f64p, f64p, f64p, C.POINTER(C.c_double)]; lib.pmh_solve6_spd.restype = C.c_int
+    lib.pmh_solve6_mem.argtypes = [f64p, f64p, f64p, C.POINTER(C.c_double)]; lib.pmh_solve6_mem.restype = C.c_int
     lib.pmh_inverse6_spd.argtypes = [f64p, f64p]; lib.pmh_inverse6_spd.restype = C.c_int
     lib.pmh_line_overlap.argtypes = [f64p] * 4; lib.pmh_line_overlap.restype = C.c_double
     lib.pmh_normal_eq.argtypes = [f64p, C.POINTER(Cam), C.c_double, C.c_void_p, C.c_int, C.c_double, C.c_double, f64p]
@@ -87,6 +88,32 @@ def test_dense6_blocks(pmh, oracle):
     inc = rng.normal(0, 0.1, 6)
     pmh.pmh_step_pose(DT, inc)
     assert np.allclose(DT.reshape(4, 4), np.eye(4) @ np_model.inverse_se3(np_model.expmap_se3(inc)), atol=1e-15)
+
+
+def test_memory_operand_forms_are_bit_identical(pmh):
+    """pm::solve6_mem / pm::inverse6_mem (round 6: the pivoted fallbacks of the pose kernels on LDS operands with run-time loops, so that
+    their 6 x 6 matrices do not cost the batch kernel registers) perform the operations of pm::solve6 / pm::inverse6 in the same order:
+    identical bits, rank and log|det| on well-conditioned, ill-conditioned, rank-deficient, permuted, zero and NaN inputs."""
+    rng = np.random.default_rng(21)
+    mats = []
+    for k in range(300):
+        r = int(rng.integers(1, 7))
+        J = rng.normal(size=(r if k % 3 == 0 else 30, 6)) * np.array([1, 1, 1, 30, 30, 30.0]) * 10.0 ** rng.uniform(-3, 3)
+        H = J.T @ J
+        if k % 5 == 0:
+            H = rng.normal(size=(6, 6))                         # not symmetric: every pivot choice differs from the SPD case
+        if k % 7 == 0:
+            P = np.eye(6)[rng.permutation(6)]; H = P @ H @ P.T  # pivots away from the diagonal order
+        mats.append(H)
+    mats += [np.zeros((6, 6)), np.full((6, 6), np.nan), np.diag([1.0, 0, 2, 0, 3, 0]), np.ones((6, 6))]
+    for H in mats:
+        g = rng.normal(size=6)
+        Hc = np.ascontiguousarray(H).reshape(-1)
+        x0, x1, l0, l1 = np.empty(6), np.empty(6), C.c_double(), C.c_double()
+        r0 = pmh.pmh_solve6(Hc.copy(), g.copy(), x0, C.byref(l0))
+        r1 = pmh.pmh_solve6_mem(Hc.copy(), g.copy(), x1, C.byref(l1))
+        assert r0 == r1 and x0.tobytes() == x1.tobytes() and np.array([l0.value]).tobytes() == np.array([l1.value]).tobytes()
+        assert call(pmh, "pmh_inverse6", H, 36).tobytes() == call(pmh, "pmh_inverse6_mem", H, 36).tobytes()
 
 
 def test_spd_fast_paths(pmh, oracle):
