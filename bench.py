@@ -881,6 +881,8 @@ def main():
     ap.add_argument("--no-clocks", action="store_true", help="skip the rocm-smi clock sample (it keeps enqueueing steps until rocm-smi answers: counter passes, where every dispatch costs seconds)")
     ap.add_argument("--no-extras", action="store_true", help="skip the latency / configs[1] / correlated-descriptor legs")
     ap.add_argument("--print-extras", action="store_true", help="also print the full record (bench_extras.json) on stderr")
+    ap.add_argument("--streams-cache", default=None, help="pickle file for the synthetic streams of rank 0: written when absent, read when present — counter passes "
+                    "(rocprofv3 --pmc) then start without forking generator processes under the profiler, which is where they tend to hang on this pool")
     args = ap.parse_args()
 
     # ---- `--gpus N` from a plain `python bench.py`: spawn N ranks (one process per GPU) under torch.distributed.run
@@ -901,7 +903,19 @@ def main():
     # synthetic streams first: the generator forks worker processes, which must happen before this process touches the GPU
     B, S = args.batch, max(2, min(args.slots, 16))
     seq_ids, replicas = stream_ids(rank, world, B)
-    streams = generate_streams(seq_ids, replicas, S, args.points, args.lines)
+    cache = args.streams_cache if (args.streams_cache and world == 1) else None
+    if cache and os.path.exists(cache):
+        import pickle
+        with open(cache, "rb") as f:
+            streams = pickle.load(f)
+        if len(streams) != B or len(streams[0]) != S:
+            raise SystemExit(f"--streams-cache {cache}: holds {len(streams)} streams x {len(streams[0])} frames, this run wants {B} x {S}")
+    else:
+        streams = generate_streams(seq_ids, replicas, S, args.points, args.lines)
+        if cache:
+            import pickle
+            with open(cache, "wb") as f:
+                pickle.dump(streams, f, protocol=4)
     streams_cl = None
     if rank == 0 and world == 1 and not args.no_extras:   # the same streams with clustered landmark descriptors (value_clustered)
         streams_cl = generate_streams(seq_ids, replicas, S, args.points, args.lines, cluster_kw=CORRELATED_MODELS["clustered"])

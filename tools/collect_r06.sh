@@ -27,10 +27,10 @@ cd $R
   python tools/rocprof_summary.py timeline $DB 40; } > $OUT/timeline.txt
 rm -rf /tmp/kt
 bash tools/hbm_calib.sh > $OUT/hbm_calib.txt 2>&1
-# (STVO_LINES_AHEAD=0: the key-line stage ahead puts a gate kernel on the line stream that waits for the pose kernel's start; under --pmc, where every
-#  dispatch runs alone, passes with it hung in 8 of 10 attempts — the kernels the counters are read for are the same either way)
-export STVO_LINES_AHEAD=0
-PMCB="$BENCH --no-parity --no-clocks --steps 4 --warmup 1 --repeats 1"
+# (the streams come from a cache written by an unprofiled run: under rocprofv3 the generator's forked worker processes are what made
+#  counter passes hang on this pool — with the cache every pass of round 6's last day ran at the first attempt in 3 - 4 s)
+python $R/bench.py --no-cpu-baseline --no-extras --no-parity --no-clocks --steps 1 --warmup 1 --repeats 1 --streams-cache /tmp/streams3072.pkl > /dev/null 2>&1
+PMCB="$BENCH --no-parity --no-clocks --steps 4 --warmup 1 --repeats 1 --streams-cache /tmp/streams3072.pkl"
 pmc_pass() {  # <file tag> <grep pattern or -> <counters...>
   local tag=$1 pat=$2; shift 2
   for attempt in 1 2 3; do
@@ -50,7 +50,6 @@ pmc_pass FETCH_SIZE - FETCH_SIZE
 pmc_pass WRITE_SIZE - WRITE_SIZE
 pmc_pass sq "hamming_knn2_mfma\|pose\|grid_points_fused\|counter" SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES
 pmc_pass wave_cycles "hamming_knn2_mfma_kernel\|pose2c\|grid_points_fused\|counter" SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_ACTIVE_INST_LDS
-unset STVO_LINES_AHEAD
 bash tools/corr_prof.sh > $OUT/clustered_match.txt 2>&1; cp gpurun_out/corr/kernel_stats.txt $OUT/clustered_match_kernel_stats.txt 2>/dev/null
 tools/latency.sh gpurun_out/$T/latency.txt > /dev/null 2>&1
 bash tools/trace_latency.sh gpurun_out/$T 100 > /dev/null 2>&1
