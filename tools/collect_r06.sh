@@ -35,7 +35,7 @@ pmc_pass() {  # <file tag> <grep pattern or -> <counters...>
   local tag=$1 pat=$2; shift 2
   for attempt in 1 2 3; do
     cd /tmp; rm -rf /tmp/pmc_x; local S=$(date +%s)
-    timeout 120 rocprofv3 --pmc "$@" --kernel-trace -d /tmp/pmc_x -- $PMCB > /dev/null 2>&1; local rc=$?
+    timeout 60 rocprofv3 --pmc "$@" --kernel-trace -d /tmp/pmc_x -- $PMCB > /dev/null 2>&1; local rc=$?
     echo "$tag attempt $attempt: exit $rc, $(( $(date +%s) - S )) s"
     cd $R
     if [ $rc -eq 0 ]; then
