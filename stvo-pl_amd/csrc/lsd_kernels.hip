@@ -597,13 +597,16 @@ struct LsdWaves {
     long long* pend; // [B][w h] by RANK in the pseudo-ordering: 0 free, a claim (sign bit | wave) or a finished region (lsd_entry), zeroed per call
 };
 
+// loads that bypass the vector L1 (sc1: served by the XCD's L2) — data another CU of the same XCD stores during the launch
+__device__ __forceinline__ int ld_l2(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ long long ld_l2_64(const long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int lds_ld(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void lds_st(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 // region_grow from `seed`, the fast form of lsd_grow_kernel.  MARK (the committer): a pixel is taken by setting its flag.  !MARK (a
 // speculating wave): the flags are only read; the wave's own pixels carry `id` in `stamp`.  The list goes to `list` (at most `cap`
 // entries: -1 if it does not fit), the final region angle to `angle_out`.
-template <bool MARK>
+template <bool MARK, bool FAR = false>
 __device__ __forceinline__ int grow_region_w(const float* __restrict__ ang, const float2* __restrict__ csn, int32_t* used, int32_t* stamp, int id,
                                              int32_t* list, int cap, int* ring, int seed, float seed_ang, int w, int h, double prec,
                                              double& angle_out) {
@@ -643,7 +646,7 @@ __device__ __forceinline__ int grow_region_w(const float* __restrict__ ang, cons
             val[r] = val[r] && xx >= 0 && xx < w && yy >= 0 && yy < h;
             qq[r] = val[r] ? yy * w + xx : 0;
             xy[r] = xx | (yy << 16);
-            u[r] = ld_coherent(used + qq[r]);
+            u[r] = FAR ? ld_l2(used + qq[r]) : ld_coherent(used + qq[r]);
             own[r] = MARK ? 0 : ld_coherent(stamp + qq[r]);
             a[r] = ang[qq[r]];
             cs[r] = csn[qq[r]];
@@ -1036,6 +1039,271 @@ __global__ __launch_bounds__(LSD_NW * 64) void lsd_grow_waves_kernel(LsdDev d, L
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same protocol across the CUs of ONE XCD (round 6; STVO_LSD_WAVES=1 keeps the one-workgroup form above).  Sixteen waves of one
+// workgroup share a CU's four SIMDs: a growth round is ~1500 cycles of DEPENDENT instructions, so four waves per SIMD deliver one
+// wave's worth of rounds each (measured: fifteen speculators ~ 2.7 waves' worth of growth).  Here a workgroup is four waves, one per
+// SIMD; image b is served by the workgroups b, b + 8, b + 16, ... — the dispatcher places those on one XCD — the first of them holds
+// the committer, the others four speculating waves each.  What the waves exchange lives in HBM and meets in that XCD's L2:
+//   stores are ordinary (write-through L1, the line stays in the L2), loads of anything another CU stores during the launch bypass
+//   the vector L1 (sc1), claims are compare-and-swaps (performed in the L2);
+//   the flags (`used`) and the control words (committer's position, front, seeds in flight) are ADVISORY for a speculating wave — a
+//   stale value costs a failed validation, never a wrong region; what the committer takes on trust are the pixel list + segment of a
+//   finished region: stored, waited for (vmcnt), then the table entry.
+// Placement is never assumed: the committer publishes the id of ITS XCD (an agent-scope store), a speculating workgroup that finds
+// itself on another one leaves — the committer alone is the sequential search, so any placement gives the same segments.
+constexpr int LSD_XW = 4;          // waves per workgroup: one per SIMD
+constexpr int LSD_X_MAXW = 125;    // waves per image at most (7 bits of a table entry; 31 speculating workgroups of an XCD's 32 CUs)
+constexpr int LSD_CTL = 512;       // control words per image, zeroed per call
+constexpr int XC_ALIVE = 0;        // the committer's XCC id + 1 (0: it has not started)
+constexpr int XC_DONE = 1;
+constexpr int XC_MBOX = 64;        // [128] 64-bit mail boxes: 0 = wave v is not there, 1 = idle, else bit 62 | rank << 21 | seed pixel: grow this one
+struct LsdXcd {
+    int32_t* stamp;  // [B][nw][w h] (slot 0 unused)
+    int32_t* wlist;  // [B][nw][w h] per wave: region after region, 4 words of segment + the pixel list
+    long long* pend; // [B][w h] by rank: 0 free, LSD_CLAIM | wave, or lsd_entry_x
+    int32_t* ctl;    // [B][LSD_CTL]
+    int nsb;         // speculating workgroups per image; nw = 1 + nsb LSD_XW
+};
+__device__ __forceinline__ long long lsd_entry_x(int wave, int n, int off) { return (1ll << 62) | ((long long)wave << 42) | ((long long)n << 21) | (long long)off; }
+
+__global__ __launch_bounds__(LSD_XW * 64) void lsd_grow_xcd_kernel(LsdDev d, LsdXcd x) {
+    __shared__ int s_ring[LSD_XW][LSD_WRING];
+    __shared__ double s_term[LSD_XW][3][64];
+    __shared__ int s_scan, s_done;
+    const int b = blockIdx.x & 7, role = blockIdx.x >> 3, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (b >= d.B) return;
+    int xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+    const int w = d.w, h = d.h, npx = w * h;
+    const size_t base = (size_t)b * npx;
+    const float* __restrict__ ang = d.ang + base;
+    const float2* __restrict__ csn = d.csn + base;
+    const double* __restrict__ mod = d.mod + base;
+    int32_t* used = d.used + base;
+    const uint32_t* __restrict__ order = d.order + base;
+    long long* pend = x.pend + base;
+    int32_t* ctl = x.ctl + (size_t)b * LSD_CTL;
+    long long* mbox = reinterpret_cast<long long*>(ctl + XC_MBOX);
+    const int nw = 1 + x.nsb * LSD_XW;
+    if (role == 0) {
+        if (threadIdx.x == 0) {
+            s_scan = -1;
+            s_done = 0;
+        }
+        __syncthreads();
+    }
+    if (role == 0 && wv == 0) {
+        // ---------------- the committer ----------------
+        __builtin_amdgcn_s_setprio(3);
+        int32_t* wlist = x.wlist + (size_t)b * nw * npx;
+        if (lane == 0) __hip_atomic_store(ctl + XC_ALIVE, xcc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int n_seg = 0;
+        const bool prof = d.dbg != nullptr && b == 0;  // tools/lsd_probe.py: where the committer's time goes
+        auto tick = [&]() -> long long { return prof ? (long long)__builtin_readcyclecounter() : 0ll; };
+        const long long t_begin = tick();
+        long long t_self = 0, t_wait = 0, t_take = 0;
+        int n_took = 0, n_self = 0, n_bad = 0, n_waited = 0;
+        for (int o0 = 0; o0 < npx; o0 += 64) {
+            const uint32_t key = o0 + lane < npx ? order[o0 + lane] : LSD_NOKEY;
+            if ((uint32_t)__builtin_amdgcn_readfirstlane((int)key) == LSD_NOKEY) break;
+            const int q_l = (int)(key & ((1u << LSD_IDX_BITS) - 1u));
+            const bool key_ok = key != LSD_NOKEY;
+            const float ang_l = key_ok ? ang[q_l] : -1.f;
+            unsigned long long todo = __ballot(key_ok && ld_coherent(used + (key_ok ? q_l : 0)) == 0);
+            int ahead_j = -1;
+            long long ahead_p = 0;
+            while (todo) {
+                const int j = __builtin_ctzll(todo);
+                todo &= todo - 1ull;
+                const int seed = __builtin_amdgcn_readlane(q_l, j), rank = o0 + j;
+                if (lane == 0) lds_st(&s_scan, rank);
+                auto table = [&]() { return readfirstlane64(ld_l2_64(pend + rank)); };  // (one address: a scalar result)
+                long long p = (j == ahead_j && (ahead_p & (1ll << 62))) ? ahead_p : table();
+                if (p < 0) {  // a speculating wave holds the claim on this very seed: its work is the work this wave would do (bounded wait)
+                    const long long tw = tick();
+                    for (int spin = 0; spin < (1 << 20) && (p = table()) < 0; ++spin) __builtin_amdgcn_s_sleep(2);
+                    if (p < 0) p = 0;  // (gave up: this wave grows the seed itself, whatever the other one publishes later is never read)
+                    t_wait += tick() - tw;
+                    ++n_waited;
+                }
+                bool took = false;
+                const long long tk = tick();
+                if (p) {
+                    const int off = (int)(p & 0x1FFFFF), n = (int)((p >> 21) & 0x1FFFFF), pw = (int)((p >> 42) & 0x7F);
+                    if (n > 0) {
+                        const int32_t* pl = x.wlist + ((size_t)b * nw + pw) * npx + off;  // 4 words of segment, then the pixels
+                        float sgv = 0.f;
+                        if (n >= d.min_reg_size && lane < 4) sgv = __int_as_float(ld_l2(pl + lane));
+                        bool bad = false;
+                        for (int t = lane; t < n; t += 64) {
+                            const int pxy = ld_l2(pl + 4 + t);
+                            bad = bad || ld_coherent(used + (pxy >> 16) * w + (pxy & 0xFFFF)) != 0;
+                        }
+                        if (!__ballot(bad)) {  // every pixel still free: this IS the region of the sequential search
+                            for (int t = lane; t < n; t += 64) {
+                                const int pxy = ld_l2(pl + 4 + t);
+                                st_coherent(used + (pxy >> 16) * w + (pxy & 0xFFFF), 1);
+                            }
+                            took = true;
+                            if (n >= d.min_reg_size) {
+                                const float4 sg = make_float4(readlane_f32(sgv, 0), readlane_f32(sgv, 1), readlane_f32(sgv, 2), readlane_f32(sgv, 3));
+                                if (lane == 0 && n_seg < d.seg_cap) d.seg[(size_t)b * d.seg_cap + n_seg] = sg;
+                                ++n_seg;
+                            }
+                        }
+                    }
+                }
+                const long long ts = tick();
+                t_take += ts - tk;
+                if (took) ++n_took;
+                else if (p) ++n_bad;
+                else ++n_self;
+                if (!took) {
+                    double reg_angle;
+                    const int n = grow_region_w<true>(ang, csn, used, nullptr, 0, wlist, npx, s_ring[0], seed, readlane_f32(ang_l, j), w, h, d.prec,
+                                                      reg_angle);
+                    if (n >= d.min_reg_size) {
+                        const float4 sg = region_segment_w(d, wlist, n, mod, reg_angle, s_term[0]);
+                        if (lane == 0 && n_seg < d.seg_cap) d.seg[(size_t)b * d.seg_cap + n_seg] = sg;
+                        ++n_seg;
+                    }
+                    t_self += tick() - ts;
+                }
+                wave_publish();
+                ahead_j = todo ? __builtin_ctzll(todo) : -1;
+                const bool free_l = key_ok && ld_coherent(used + (key_ok ? q_l : 0)) == 0;
+                long long pa = 0;
+                if (ahead_j >= 0) pa = ld_l2_64(pend + o0 + ahead_j);
+                todo &= __ballot(free_l);
+                ahead_p = readfirstlane64(pa);
+            }
+        }
+        if (lane == 0) {
+            d.n_seg[b] = n_seg;
+            lds_st(&s_done, 1);
+            st_coherent(ctl + XC_DONE, 1);
+        }
+        if (prof && lane == 0) {  // the last 16 doubles of image 0's block (row seg_cap - 1: marker -1 = a committer's counters)
+            double* q = d.dbg + ((size_t)d.seg_cap - 2) * 8;
+            q[0] = (double)(tick() - t_begin); q[1] = (double)t_self; q[2] = (double)t_wait; q[3] = (double)t_take;
+            q[4] = (double)n_took; q[5] = (double)n_self; q[6] = (double)n_bad; q[7] = (double)n_waited;
+            q[8] = -1.0;
+        }
+    } else if (role == 0 && wv == 1) {
+        // ---------------- the dispatcher: hands the free seeds in front of the committer to idle speculating waves, in rank order ----------------
+        // The ONLY wave that claims: no compare-and-swap, no two waves after the same seed (with every wave scanning for itself — the
+        // one-workgroup form — all of them find the same first candidate: beyond ~8 waves the claims serialise).  Lane u stands for the
+        // speculating waves u + 1 and u + 65: idle or not (its mail box), where its seed in flight lies.
+        const int ns = nw - 1;
+        int sxy0 = -1, sxy1 = -1;  // x | y << 16 of the seed in flight, -1: none
+        int front = 0;             // every rank below is used, pending or claimed — for good
+        for (int idle = 0; idle < (1 << 24); ++idle) {  // (bounded)
+            if (lds_ld(&s_done)) break;
+            const bool idle0 = lane < ns && ld_l2_64(mbox + lane) == 1, idle1 = lane + 64 < ns && ld_l2_64(mbox + 64 + lane) == 1;  // (1: the wave is there and idle)
+            if (idle0) sxy0 = -1;
+            if (idle1) sxy1 = -1;
+            unsigned long long I0 = __ballot(idle0), I1 = __ballot(idle1);
+            if (!(I0 | I1)) {
+                __builtin_amdgcn_s_sleep(4);
+                continue;
+            }
+            const int scan = lds_ld(&s_scan);
+            const int start = front > scan + 1 ? front : scan + 1;
+            if (start - scan > LSD_AHEAD) {  // far enough ahead of the committer: regions grown beyond see flags too stale to survive
+                __builtin_amdgcn_s_sleep(8);
+                continue;
+            }
+            bool contiguous = true, end = false;
+            for (int c = 0; c < LSD_LOOK && (I0 | I1) && !end; c += 64) {
+                const int r = start + c + lane;
+                const uint32_t key = r < npx ? order[r] : LSD_NOKEY;
+                end = (uint32_t)__builtin_amdgcn_readfirstlane((int)key) == LSD_NOKEY;
+                if (end) break;
+                const bool ok = key != LSD_NOKEY;
+                const int q = (int)(key & ((1u << LSD_IDX_BITS) - 1u));
+                const bool open = ok && ld_coherent(used + (ok ? q : 0)) == 0 && ld_coherent64(pend + (ok ? r : 0)) == 0;  // (the committer's stores and this wave's own: one CU)
+                const int qx = q % w, qy = q / w;
+                const unsigned long long m_open = __ballot(open);
+                unsigned long long mm = m_open, given = 0ull;
+                while (mm && (I0 | I1)) {
+                    const int L = __builtin_ctzll(mm);
+                    mm &= mm - 1ull;
+                    const int cx = __builtin_amdgcn_readlane(qx, L), cy = __builtin_amdgcn_readlane(qy, L);
+                    auto near = [&](int sxy) {
+                        const int ddx = cx - (sxy & 0xFFFF), ddy = cy - (sxy >> 16);
+                        const int adx = ddx < 0 ? -ddx : ddx, ady = ddy < 0 ? -ddy : ddy;
+                        return sxy >= 0 && (adx > ady ? adx : ady) < LSD_SEP;
+                    };
+                    if (__ballot(near(sxy0) || near(sxy1))) continue;  // too close to a growth in flight: later (the front stays in front of it)
+                    const int u = I0 ? __builtin_ctzll(I0) : 64 + __builtin_ctzll(I1);
+                    if (u < 64) I0 &= I0 - 1ull;
+                    else I1 &= I1 - 1ull;
+                    if (lane == (u & 63)) {
+                        if (u < 64) sxy0 = cx | (cy << 16);
+                        else sxy1 = cx | (cy << 16);
+                    }
+                    if (lane == L) {
+                        st_coherent64(pend + r, LSD_CLAIM | (long long)(u + 1));
+                        st_coherent64(mbox + u, (1ll << 62) | ((long long)r << 21) | (long long)q);
+                    }
+                    given |= 1ull << L;
+                    idle = 0;
+                }
+                if (contiguous) {  // the ranks of this chunk in front of the first one still open join the solid part
+                    const unsigned long long rem = m_open & ~given;
+                    front = start + c + (rem ? __builtin_ctzll(rem) : 64);
+                    contiguous = rem == 0ull;
+                }
+            }
+        }
+    } else if (role != 0) {
+        // ---------------- a speculating wave ----------------
+        {  // on the committer's XCD, or not at all
+            int alive = 0;
+            for (int spin = 0; spin < (1 << 18) && (alive = __builtin_amdgcn_readfirstlane(ld_l2(ctl + XC_ALIVE))) == 0; ++spin) __builtin_amdgcn_s_sleep(16);
+            if (alive != xcc + 1) return;
+        }
+        const int v = 1 + (role - 1) * LSD_XW + wv;  // this wave among the image's waves
+        int32_t* stamp = x.stamp + ((size_t)b * nw + v) * npx;
+        int32_t* wl = x.wlist + ((size_t)b * nw + v) * npx;
+        int id = 0, off = 0;
+        if (lane == 0) st_coherent64(mbox + (v - 1), 1ll);  // here, and idle
+        for (int idle = 0; idle < (1 << 24); ++idle) {  // (bounded: a wave that is handed nothing for this long gives up)
+            const long long m = readfirstlane64(ld_l2_64(mbox + (v - 1)));
+            if (m <= 1) {
+                if (__builtin_amdgcn_readfirstlane(ld_l2(ctl + XC_DONE))) break;
+                __builtin_amdgcn_s_sleep(2);
+                continue;
+            }
+            idle = 0;
+            const int pick_r = (int)((m >> 21) & 0x1FFFFF), pick_q = (int)(m & 0x1FFFFF);
+            int n = 0;
+            if (npx - off >= 4096) {  // (out of room: empty records from here on — the committer grows those seeds itself)
+                ++id;
+                double reg_angle = 0.0;
+                n = grow_region_w<false, true>(ang, csn, used, stamp, id, wl + off + 4, npx - off - 4, s_ring[wv], pick_q, ang[pick_q], w, h, d.prec, reg_angle);
+                if (n >= d.min_reg_size) {
+                    const float4 sg = region_segment_w(d, wl + off + 4, n, mod, reg_angle, s_term[wv]);
+                    if (lane == 0) {
+                        st_coherent(wl + off, __float_as_int(sg.x));
+                        st_coherent(wl + off + 1, __float_as_int(sg.y));
+                        st_coherent(wl + off + 2, __float_as_int(sg.z));
+                        st_coherent(wl + off + 3, __float_as_int(sg.w));
+                    }
+                }
+            }
+            // the list and the segment have reached the L2 before the table entry leaves (a workgroup-scope release does not wait: the
+            // entry is read on ANOTHER CU)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) st_coherent64(pend + pick_r, lsd_entry_x(v, n > 0 ? n : 0, off));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) st_coherent64(mbox + (v - 1), 1ll);  // idle again
+            if (n > 0) off += 4 + n;
+        }
+    }
+}
+
 // LSDDetectorC::detectImpl's loop over the segments of the (single) octave (:254-303) and the cut of stereoFrame.cpp:231-240
 constexpr int KL_T = 256;
 __global__ __launch_bounds__(KL_T) void lsd_keylines_kernel(LsdDev d) {
@@ -1153,6 +1421,7 @@ struct stvo_lsd {
     stvo::LsdWaves xw{};      // scratch of lsd_grow_waves_kernel (small batches), or null
     char* wdev = nullptr;
     size_t stamp_bytes = 0, pend_bytes = 0;
+    stvo::LsdXcd xx{};        // scratch of lsd_grow_xcd_kernel (small batches, the default), or null
     int sort_chunk = 1;       // images per call of the segmented sort (its item count is an int)
 };
 
@@ -1193,7 +1462,11 @@ int lsd_enqueue(stvo_lsd* o, const uint8_t* images, stvo_keyline* lines, float* 
                                                                     o->seg_off + 1, begin_bit, 32, s));
         }
     }
-    if (o->wdev) {  // small batches: one workgroup of LSD_NW waves per image (lsd_grow_waves_kernel)
+    if (o->wdev && o->xx.ctl) {  // small batches: a committing wave + speculating workgroups on the CUs of one XCD per image (lsd_grow_xcd_kernel)
+        HIP_TRY(ctx, hipMemsetAsync(o->xx.stamp, 0, o->stamp_bytes, s));
+        HIP_TRY(ctx, hipMemsetAsync(o->xx.pend, 0, o->pend_bytes + (size_t)d.B * stvo::LSD_CTL * 4, s));  // (the control words lie behind the table)
+        hipLaunchKernelGGL(stvo::lsd_grow_xcd_kernel, dim3(8 * (1 + o->xx.nsb)), dim3(stvo::LSD_XW * 64), 0, s, d, o->xx);
+    } else if (o->wdev) {  // STVO_LSD_WAVES=1: one workgroup of LSD_NW waves per image (lsd_grow_waves_kernel)
         HIP_TRY(ctx, hipMemsetAsync(o->xw.stamp, 0, o->stamp_bytes, s));
         HIP_TRY(ctx, hipMemsetAsync(o->xw.pend, 0, o->pend_bytes, s));
         hipLaunchKernelGGL(stvo::lsd_grow_waves_kernel, dim3(d.B), dim3(stvo::LSD_NW * 64), 0, s, d, o->xw);
@@ -1299,7 +1572,21 @@ int stvo_lsd_create(stvo_ctx* ctx, int B, int cols, int rows, int max_keylines, 
     }
     if (ok && (size_t)d.seg_cap * 8 > 48 * 1024)
         ok = stvo::lds_opt_in(reinterpret_cast<const void*>(stvo::lsd_keylines_kernel), d.seg_cap * 8);
-    if (ok && stvo::dbg().lsd_waves != 0 && B <= stvo::LSD_WAVES_MAX_B) {  // STVO_LSD_WAVES=0: one wave per image for small batches too
+    if (ok && stvo::dbg().lsd_waves != 0 && stvo::dbg().lsd_waves != 1 && B <= stvo::LSD_WAVES_MAX_B) {  // the default for small batches
+        int nsb = stvo::dbg().lsd_xcd_blocks == stvo::DBG_UNSET ? 8 : stvo::dbg().lsd_xcd_blocks;  // STVO_LSD_XCD_BLOCKS: speculating workgroups per image
+        nsb = nsb < 0 ? 0 : (nsb > (stvo::LSD_X_MAXW - 1) / stvo::LSD_XW ? (stvo::LSD_X_MAXW - 1) / stvo::LSD_XW : nsb);
+        const size_t nw = 1 + (size_t)nsb * stvo::LSD_XW;
+        decltype(c) cw;
+        const size_t w_stamp = cw.take(nb * nw * npx * 4), w_list = cw.take(nb * nw * npx * 4), w_pend = cw.take(nb * npx * 8 + nb * stvo::LSD_CTL * 4);
+        ok = hip_ok(ctx, hipMalloc((void**)&o->wdev, cw.off), "hipMalloc lsd xcd");
+        if (ok) {
+            o->xx.stamp = (int32_t*)(o->wdev + w_stamp); o->xx.wlist = (int32_t*)(o->wdev + w_list);
+            o->xx.pend = (long long*)(o->wdev + w_pend); o->xx.ctl = (int32_t*)(o->wdev + w_pend + nb * npx * 8);
+            o->xx.nsb = nsb;
+            o->stamp_bytes = nb * nw * npx * 4;
+            o->pend_bytes = nb * npx * 8;
+        }
+    } else if (ok && stvo::dbg().lsd_waves != 0 && B <= stvo::LSD_WAVES_MAX_B) {  // STVO_LSD_WAVES=1: sixteen waves of one workgroup; 0: one wave per image for small batches too
         decltype(c) cw;
         const size_t w_stamp = cw.take(nb * stvo::LSD_NW * npx * 4), w_list = cw.take(nb * stvo::LSD_NW * npx * 4),
                      w_rec = cw.take(nb * stvo::LSD_NW * stvo::LSD_REC_CAP * sizeof(stvo::LsdRec)), w_pend = cw.take(nb * npx * 8);

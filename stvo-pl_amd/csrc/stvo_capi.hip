@@ -47,6 +47,7 @@ DebugSwitches parse_switches() {
     d.lsd_grow = env_int("STVO_LSD_GROW");
     d.lsd_sort_full = env_int("STVO_LSD_SORT_FULL");
     d.lsd_waves = env_int("STVO_LSD_WAVES");
+    d.lsd_xcd_blocks = env_int("STVO_LSD_XCD_BLOCKS");
     return d;
 }
 DebugSwitches& switches() {
