@@ -29,8 +29,11 @@ struct DebugSwitches {
     int grid_fused;      // STVO_GRID_FUSED      0: scan formulation of the stereo point matcher
     int grid_fused_cap;  // STVO_GRID_FUSED_CAP  capacity override of the one-workgroup point matcher (tests of the misfit path)
     int lsd_grow;        // STVO_LSD_GROW        0: the plain form of lsd_grow_kernel (candidates one after the other, sums through v_readlane)
-    int lsd_waves;       // STVO_LSD_WAVES       0: batches of <= 8 images by lsd_grow_kernel (one wave per image), 1: by lsd_grow_waves_kernel (16 waves of one workgroup per image; until round 5) instead of lsd_grow_xcd_kernel (workgroups on the CUs of one XCD per image)
+    int lsd_waves;       // STVO_LSD_WAVES       0: batches of <= 8 images by lsd_grow_kernel (one wave per image) instead of lsd_grow_xcd_kernel (a committer + speculating workgroups on the CUs of one XCD per image)
     int lsd_xcd_blocks;  // STVO_LSD_XCD_BLOCKS  speculating workgroups (of four waves) per image of lsd_grow_xcd_kernel (unset: 8)
+    int lsd_feed_ahead;  // STVO_LSD_FEED_AHEAD  ranks the feeder wave of lsd_grow_xcd_kernel runs ahead of the committer at most
+    int lsd_sep;         // STVO_LSD_SEP         least distance (pixels, Chebyshev) of a new seed from every seed in flight
+    int lsd_ahead;       // STVO_LSD_AHEAD       ranks the dispatcher's front runs ahead of the committer at most
     int lsd_sort_full;   // STVO_LSD_SORT_FULL   1: the pseudo-ordering sorts all 32 key bits instead of the bin bits only (lsd_kernels.hip)
     int cells_ahead;     // STVO_CELLS_AHEAD     0: point_cells_kernel of a batch in the point stream (unset: on the line stream, ahead of the point stream's step)
     int seq_pipe;        // STVO_SEQ_PIPE        1: pipelined steps (optimizePose(k) on the aux stream beside the stereo association of step k + 1; built and measured in round 6, no gain), 2: the same without the gate kernel

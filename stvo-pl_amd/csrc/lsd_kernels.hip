@@ -552,50 +552,39 @@ __global__ __launch_bounds__(64) void lsd_grow_kernel(LsdDev d) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// ONE image by a workgroup of LSD_NW waves — an EXACT asynchronous form of the search, the default for batches of <= LSD_WAVES_MAX_B
-// images (STVO_LSD_WAVES=0: one wave per image there too).  Its scheme is replayed on the CPU by tools/experiments/lsd_waves_sim.c; on
-// hardware (round 5) two KITTI-size images take 37 ms per call against 70 ms with one wave each, segments identical in detection order.
-//   wave 0 commits in seed order.  A seed with a finished PENDING region takes it if every pixel of it is still free (flag stores,
-//   lane-parallel; the segment was computed by the wave that grew it), a seed another wave is growing right now is waited for
-//   (bounded), any other seed — and any pending region that lost a pixel — is grown by wave 0 itself, flags set as it goes.
-//   waves 1 .. LSD_NW - 1 speculate: the first seed after the committer's position (LSD_LOOK ranks) that is free, not pending, not
-//   claimed and >= LSD_SEP px (Chebyshev) from every seed in flight is CLAIMED — one compare-and-swap on its table entry, no lock
-//   (round 5: with a workgroup lock held for a memory round trip per pick the fifteen speculators produced a region per ~5 k cycles
-//   and the committer spent half its time waiting at seeds just picked) — and grown against the flags committed so far; the wave
-//   marks ITS pixels in a stamp array of its own and leaves the flags alone.
+// ONE image by many waves — an EXACT asynchronous form of the search, the default for batches of <= LSD_WAVES_MAX_B images
+// (STVO_LSD_WAVES=0: one wave per image there too).  The scheme is replayed on the CPU by tools/experiments/lsd_waves_sim.c.
+//   the COMMITTER walks the seeds in order.  A seed with a finished PENDING region takes it if every pixel of it is still free (the
+//   segment was computed by the wave that grew it), a seed another wave is growing right now is waited for (bounded), any other
+//   seed — and any pending region that lost a pixel — is grown by the committer itself, flags set as it goes.
+//   the SPECULATING waves grow regions of free seeds in front of the committer against the flags committed so far; a wave marks ITS
+//   pixels in a stamp array of its own and leaves the flags alone.  Seeds are handed out in rank order, >= LSD_SEP px (Chebyshev)
+//   from every seed in flight, at most LSD_AHEAD ranks ahead of the committer.
 // Exactness: flags only turn on.  A region grown against an older state of the flags made the sequential decisions at every pixel it
 // examined unless it ACCEPTED a pixel that was taken before its turn — then the validation at its turn fails and the seed is grown again.
 // Output order = commit order = seed order.
-constexpr int LSD_NW = 16;
+// Round 5 ran this inside ONE workgroup of sixteen waves (22.8 ms per KITTI-size image: the waves share a CU's four SIMDs and a
+// growth round is ~1500 cycles of dependent instructions — fifteen speculators delivered ~2.7 waves' worth of growth); round 6
+// spreads it over the CUs of one XCD: lsd_grow_xcd_kernel below (9.9 ms; the oracle takes 17 ms on one host core).
 constexpr int LSD_WRING = 256;       // per wave: the most recent region points in LDS
-constexpr int LSD_SEP = 24;
-constexpr int LSD_LOOK = 2048;       // ranks a speculating wave examines per pick, from the front
+constexpr int LSD_SEP = 16;
+constexpr int LSD_LOOK = 2048;       // ranks the dispatcher examines per pass, from the front
 constexpr int LSD_AHEAD = 16384;     // the front's lead over the committer (ranks; ~200 seeds of a KITTI-size scene)
-constexpr int LSD_REC_CAP = 32768;   // regions a speculating wave can hold (it stops speculating when full)
-// Table entry of a seed: 0 = nobody's; LSD_CLAIM | wave = a speculating wave is growing it; else a finished region — everything the
-// committer needs to find it in ONE load: list offset (21 bits), size (21), record (16), wave (4), bit 62 set.
+// Table entry of a seed: 0 = nobody's; LSD_CLAIM | wave = a speculating wave is growing it; else a finished region (lsd_entry_x)
 constexpr long long LSD_CLAIM = (long long)0x8000000000000000ull;
-__device__ __forceinline__ long long lsd_entry(int wave, int record, int n, int off) {
-    return (1ll << 62) | ((long long)wave << 58) | ((long long)record << 42) | ((long long)n << 21) | (long long)off;
-}
 __device__ __forceinline__ long long ld_coherent64(const long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void st_coherent64(long long* p, long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ long long readlane_i64(long long v, int l) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(unsigned long long)v, l);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)v >> 32), l);
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ long long readfirstlane64(long long v) {
     const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)v);
     const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)v >> 32));
     return (long long)(((unsigned long long)hi << 32) | lo);
 }
-constexpr int LSD_WAVES_MAX_B = 8;   // the scratch below is ~130 B per pixel and wave-pair: small batches only
-
-struct LsdRec {
-    float x1, y1, x2, y2;  // the segment of a finished region of >= min_reg_size pixels
-};
-struct LsdWaves {
-    int32_t* stamp;  // [B][LSD_NW][w h] region id of the wave that holds the pixel in its CURRENT region (zeroed per call)
-    int32_t* wlist;  // [B][LSD_NW][w h] pixel lists, region after region
-    LsdRec* rec;     // [B][LSD_NW][LSD_REC_CAP]
-    long long* pend; // [B][w h] by RANK in the pseudo-ordering: 0 free, a claim (sign bit | wave) or a finished region (lsd_entry), zeroed per call
-};
+constexpr int LSD_WAVES_MAX_B = 8;   // one XCD per image (and ~270 B of scratch per pixel and speculating workgroup): small batches only
 
 // loads that bypass the vector L1 (sc1: served by the XCD's L2) — data another CU of the same XCD stores during the launch
 __device__ __forceinline__ int ld_l2(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -606,10 +595,13 @@ __device__ __forceinline__ void lds_st(int* p, int v) { __hip_atomic_store(p, v,
 // region_grow from `seed`, the fast form of lsd_grow_kernel.  MARK (the committer): a pixel is taken by setting its flag.  !MARK (a
 // speculating wave): the flags are only read; the wave's own pixels carry `id` in `stamp`.  The list goes to `list` (at most `cap`
 // entries: -1 if it does not fit), the final region angle to `angle_out`.
-template <bool MARK, bool FAR = false>
+// BITS (with MARK): the flags this wave decides on are a bitmap in LDS (`bits`); `used` is only written — for the waves of other CUs.
+__device__ __forceinline__ unsigned bit_ld(const unsigned* bits, int q) { return (__hip_atomic_load(bits + (q >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> (q & 31)) & 1u; }
+__device__ __forceinline__ void bit_set(unsigned* bits, int q) { (void)__hip_atomic_fetch_or(bits + (q >> 5), 1u << (q & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+template <bool MARK, bool FAR = false, bool BITS = false>
 __device__ __forceinline__ int grow_region_w(const float* __restrict__ ang, const float2* __restrict__ csn, int32_t* used, int32_t* stamp, int id,
                                              int32_t* list, int cap, int* ring, int seed, float seed_ang, int w, int h, double prec,
-                                             double& angle_out) {
+                                             double& angle_out, unsigned* bits = nullptr) {
     const int lane = threadIdx.x & 63;
     const int sx0 = seed % w, sy0 = seed / w;
     double reg_angle = (double)seed_ang * LSD_DEG2RAD;
@@ -620,6 +612,7 @@ __device__ __forceinline__ int grow_region_w(const float* __restrict__ ang, cons
     if (lane == 0) {
         if (MARK) st_coherent(used + seed, 1);
         else st_coherent(stamp + seed, id);
+        if (BITS) bit_set(bits, seed);
         st_coherent(list, sx0 | (sy0 << 16));
         ring[0] = sx0 | (sy0 << 16);
     }
@@ -646,7 +639,7 @@ __device__ __forceinline__ int grow_region_w(const float* __restrict__ ang, cons
             val[r] = val[r] && xx >= 0 && xx < w && yy >= 0 && yy < h;
             qq[r] = val[r] ? yy * w + xx : 0;
             xy[r] = xx | (yy << 16);
-            u[r] = FAR ? ld_l2(used + qq[r]) : ld_coherent(used + qq[r]);
+            u[r] = BITS ? (int)bit_ld(bits, qq[r]) : (FAR ? ld_l2(used + qq[r]) : ld_coherent(used + qq[r]));
             own[r] = MARK ? 0 : ld_coherent(stamp + qq[r]);
             a[r] = ang[qq[r]];
             cs[r] = csn[qq[r]];
@@ -717,6 +710,7 @@ __device__ __forceinline__ int grow_region_w(const float* __restrict__ ang, cons
                 const int idx = n_reg + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(acc >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)acc, 0u));
                 if (MARK) st_coherent(used + qq[r], 1);
                 else st_coherent(stamp + qq[r], id);
+                if (BITS) bit_set(bits, qq[r]);
                 st_coherent(list + idx, xy[r]);
                 ring[idx & (LSD_WRING - 1)] = xy[r];
             }
@@ -820,241 +814,36 @@ __device__ __forceinline__ float4 region_segment_w(const LsdDev& d, const int32_
     return make_float4((float)x1, (float)y1, (float)x2, (float)y2);
 }
 
-__global__ __launch_bounds__(LSD_NW * 64) void lsd_grow_waves_kernel(LsdDev d, LsdWaves x) {
-    __shared__ int s_ring[LSD_NW][LSD_WRING];
-    __shared__ double s_term[LSD_NW][3][64];
-    __shared__ int s_scan, s_done, s_front, s_if_seed[LSD_NW];
-    const int b = blockIdx.x, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int w = d.w, h = d.h, npx = w * h;
-    const size_t base = (size_t)b * npx;
-    const float* __restrict__ ang = d.ang + base;
-    const float2* __restrict__ csn = d.csn + base;
-    const double* __restrict__ mod = d.mod + base;
-    int32_t* used = d.used + base;
-    const uint32_t* __restrict__ order = d.order + base;
-    long long* pend = x.pend + base;
-    int32_t* wlist = x.wlist + ((size_t)b * LSD_NW + wv) * npx;
-    if (threadIdx.x == 0) {
-        s_scan = -1;
-        s_done = 0;
-        s_front = 0;
-    }
-    if (threadIdx.x < LSD_NW) s_if_seed[threadIdx.x] = -1;
-    __syncthreads();
-    if (wv == 0) {
-        // ---------------- the committer ----------------
-        __builtin_amdgcn_s_setprio(3);  // the one wave everything waits for: ahead of the three speculators of its SIMD
-        int n_seg = 0;
-        const bool prof = d.dbg != nullptr && b == 0;  // tools/lsd_probe.py: where the committer's time goes
-        auto tick = [&]() -> long long { return prof ? (long long)__builtin_readcyclecounter() : 0ll; };
-        const long long t_begin = tick();
-        long long t_self = 0, t_wait = 0, t_take = 0;
-        int n_took = 0, n_self = 0, n_bad = 0, n_waited = 0;
-        for (int o0 = 0; o0 < npx; o0 += 64) {
-            const uint32_t key = o0 + lane < npx ? order[o0 + lane] : LSD_NOKEY;
-            if ((uint32_t)__builtin_amdgcn_readfirstlane((int)key) == LSD_NOKEY) break;
-            const int q_l = (int)(key & ((1u << LSD_IDX_BITS) - 1u));
-            const bool key_ok = key != LSD_NOKEY;
-            const float ang_l = key_ok ? ang[q_l] : -1.f;
-            unsigned long long todo = __ballot(key_ok && ld_coherent(used + (key_ok ? q_l : 0)) == 0);
-            int ahead_j = -1;
-            long long ahead_p = 0;
-            while (todo) {
-                const int j = __builtin_ctzll(todo);
-                todo &= todo - 1ull;
-                const int seed = __builtin_amdgcn_readlane(q_l, j), rank = o0 + j;
-                if (lane == 0) {
-                    lds_st(&s_scan, rank);
-                    lds_st(&s_if_seed[0], seed);
-                }
-                auto table = [&]() { return readfirstlane64(ld_coherent64(pend + rank)); };  // (one address: a scalar result)
-                // the entry read ahead at the end of the previous seed is final if it shows a finished region (those never change)
-                long long p = (j == ahead_j && (ahead_p & (1ll << 62))) ? ahead_p : table();
-                if (p < 0) {  // a speculating wave holds the claim on this very seed: its work is the work this wave would do (bounded wait)
-                    const long long tw = tick();
-                    for (int spin = 0; spin < (1 << 20) && (p = table()) < 0; ++spin) __builtin_amdgcn_s_sleep(4);
-                    if (p < 0) p = 0;  // (gave up: this wave grows the seed itself, whatever the other one publishes later is never read)
-                    t_wait += tick() - tw;
-                    ++n_waited;
-                }
-                bool took = false;
-                const long long tk = tick();
-                if (p) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                    const int off = (int)(p & 0x1FFFFF), n = (int)((p >> 21) & 0x1FFFFF), ri = (int)((p >> 42) & 0xFFFF), pw = (int)((p >> 58) & 0xF);
-                    if (n > 0) {
-                        const int32_t* pl = x.wlist + ((size_t)b * LSD_NW + pw) * npx + off;
-                        // the segment travels with the first pixels (vector loads: another wave wrote the record during this launch)
-                        const LsdRec* rc = x.rec + ((size_t)b * LSD_NW + pw) * LSD_REC_CAP + ri;
-                        float sgv = 0.f;
-                        if (n >= d.min_reg_size && lane < 4) sgv = __int_as_float(ld_coherent(reinterpret_cast<const int32_t*>(rc) + lane));
-                        bool bad = false;
-                        for (int t = lane; t < n; t += 64) {
-                            const int pxy = ld_coherent(pl + t);
-                            bad = bad || ld_coherent(used + (pxy >> 16) * w + (pxy & 0xFFFF)) != 0;
-                        }
-                        if (!__ballot(bad)) {  // every pixel still free: this IS the region of the sequential search
-                            for (int t = lane; t < n; t += 64) {
-                                const int pxy = ld_coherent(pl + t);
-                                st_coherent(used + (pxy >> 16) * w + (pxy & 0xFFFF), 1);
-                            }
-                            took = true;
-                            if (n >= d.min_reg_size) {
-                                const float4 sg = make_float4(readlane_f32(sgv, 0), readlane_f32(sgv, 1), readlane_f32(sgv, 2), readlane_f32(sgv, 3));
-                                if (lane == 0 && n_seg < d.seg_cap) d.seg[(size_t)b * d.seg_cap + n_seg] = sg;
-                                ++n_seg;
-                            }
-                        }
-                    }
-                }
-                const long long ts = tick();
-                t_take += ts - tk;
-                if (took) ++n_took;
-                else if (p) ++n_bad;
-                else ++n_self;
-                if (!took) {
-                    double reg_angle;
-                    const int n = grow_region_w<true>(ang, csn, used, nullptr, 0, wlist, npx, s_ring[0], seed, readlane_f32(ang_l, j), w, h, d.prec,
-                                                      reg_angle);
-                    if (n >= d.min_reg_size) {
-                        const float4 sg = region_segment_w(d, wlist, n, mod, reg_angle, s_term[0]);
-                        if (lane == 0 && n_seg < d.seg_cap) d.seg[(size_t)b * d.seg_cap + n_seg] = sg;
-                        ++n_seg;
-                    }
-                    t_self += tick() - ts;
-                }
-                wave_publish();
-                // seeds of the batch taken meanwhile — and, in the same round trip, the table entry of the seed that comes next if it is
-                // still free (a finished region found there is final; anything else is read again at the seed's turn)
-                ahead_j = todo ? __builtin_ctzll(todo) : -1;
-                const bool free_l = key_ok && ld_coherent(used + (key_ok ? q_l : 0)) == 0;
-                long long pa = 0;
-                if (ahead_j >= 0) pa = ld_coherent64(pend + o0 + ahead_j);
-                todo &= __ballot(free_l);
-                ahead_p = readfirstlane64(pa);
-            }
-        }
-        if (lane == 0) {
-            d.n_seg[b] = n_seg;
-            lds_st(&s_done, 1);
-        }
-        if (prof && lane == 0) {  // the last 16 doubles of image 0's block (row seg_cap - 1: marker -1 = this kernel)
-            double* q = d.dbg + ((size_t)d.seg_cap - 2) * 8;
-            q[0] = (double)(tick() - t_begin); q[1] = (double)t_self; q[2] = (double)t_wait; q[3] = (double)t_take;
-            q[4] = (double)n_took; q[5] = (double)n_self; q[6] = (double)n_bad; q[7] = (double)n_waited;
-            q[8] = -1.0;
-        }
-    } else {
-        // ---------------- a speculating wave ----------------
-        int32_t* stamp = x.stamp + ((size_t)b * LSD_NW + wv) * npx;
-        LsdRec* rec = x.rec + ((size_t)b * LSD_NW + wv) * LSD_REC_CAP;
-        int id = 0, off = 0, nrec = 0;
-        for (int idle = 0; idle < (1 << 22);) {  // (bounded: a wave that finds nothing for this long gives up)
-            if (lds_ld(&s_done)) break;
-            // the scan for a candidate runs WITHOUT the lock (up to LSD_LOOK ranks, three loads per 64); under the lock only the
-            // candidate is looked at again — the lock is held for one memory round trip
-            auto separated = [&](int q) {
-                const int qx = q % w, qy = q / w;
-                bool far = true;
-                for (int v = 0; v < LSD_NW; ++v) {
-                    const int sv = lds_ld(&s_if_seed[v]);  // uniform
-                    if (sv >= 0) {
-                        const int ddx = qx - sv % w, ddy = qy - sv / w;
-                        const int adx = ddx < 0 ? -ddx : ddx, ady = ddy < 0 ? -ddy : ddy;
-                        far = far && (adx > ady ? adx : ady) >= LSD_SEP;
-                    }
-                }
-                return far;
-            };
-            // The scan starts at the FRONT: every rank below it is used, pending or claimed — for good (flags and table entries only turn
-            // on), so no wave looks at those ranks again; the waves push the front together (LDS, atomic max).  Without it the window
-            // began at the committer's position, and 2048 ranks are ~26 seeds: with 15 regions in flight and the finished ones waiting
-            // for their turn the window held nothing to pick and the speculators slept (round 5).  The front may run at most
-            // LSD_AHEAD ranks ahead of the committer: regions grown further ahead see flags that are too stale to survive validation.
-            const int scan = lds_ld(&s_scan);
-            const int front0 = lds_ld(&s_front);
-            const int start = front0 > scan + 1 ? front0 : scan + 1;
-            int pick_r = -1, pick_q = 0, solid = start;  // [start, solid): nothing free, whatever the separation says
-            bool contiguous = true;
-            if (start - scan <= LSD_AHEAD)
-                for (int c = 0; c < LSD_LOOK && pick_r < 0; c += 64) {
-                    const int r = start + c + lane;
-                    const uint32_t key = r < npx ? order[r] : LSD_NOKEY;
-                    if ((uint32_t)__builtin_amdgcn_readfirstlane((int)key) == LSD_NOKEY) break;
-                    const bool ok = key != LSD_NOKEY;
-                    const int q = (int)(key & ((1u << LSD_IDX_BITS) - 1u));
-                    const bool open = ok && ld_coherent(used + (ok ? q : 0)) == 0 && ld_coherent64(pend + (ok ? r : 0)) == 0;
-                    const unsigned long long m_open = __ballot(open), m = __ballot(open && separated(q));
-                    if (contiguous) {  // the ranks of this chunk in front of its first open one join the solid part
-                        solid = start + c + (m_open ? __builtin_ctzll(m_open) : 64);
-                        contiguous = m_open == 0ull;
-                    }
-                    if (m) {
-                        const int L = __builtin_ctzll(m);
-                        pick_r = __builtin_amdgcn_readlane(r, L);
-                        pick_q = __builtin_amdgcn_readlane(q, L);
-                    }
-                }
-            if (solid > front0 && lane == 0) atomicMax(&s_front, solid);
-            if (pick_r < 0) {
-                __builtin_amdgcn_s_sleep(32);
-                ++idle;
-                continue;
-            }
-            // the claim: one compare-and-swap on the seed's table entry (0 -> "in flight, wave wv") — no lock, every wave claims on its
-            // own; the committer that finds the claim waits for the record, the one that came first grows the seed itself
-            int got = 0;
-            if (lane == 0) got = atomicCAS(reinterpret_cast<unsigned long long*>(pend + pick_r), 0ull, (unsigned long long)(LSD_CLAIM | wv)) == 0ull;
-            got = __builtin_amdgcn_readfirstlane(got);
-            if (!got) {
-                ++idle;
-                continue;
-            }
-            const bool still = __builtin_amdgcn_readfirstlane((int)(pick_r > lds_ld(&s_scan) && ld_coherent(used + pick_q) == 0)) != 0;
-            if (!still) {  // the committer reached the seed, or a committed region took it meanwhile: an empty record releases the claim
-                if (lane == 0) st_coherent64(pend + pick_r, lsd_entry(wv, 0, 0, 0));  // (size 0: the committer grows the seed itself)
-                ++idle;
-                continue;
-            }
-            if (lane == 0) lds_st(&s_if_seed[wv], pick_q);  // (advisory: keeps the other waves' picks LSD_SEP away from this growth)
-            ++id;
-            double reg_angle = 0.0;
-            const int n = grow_region_w<false>(ang, csn, used, stamp, id, wlist + off, npx - off, s_ring[wv], pick_q, ang[pick_q], w, h, d.prec,
-                                               reg_angle);
-            float4 sg = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (n >= d.min_reg_size) sg = region_segment_w(d, wlist + off, n, mod, reg_angle, s_term[wv]);
-            if (lane == 0) {
-                LsdRec R;
-                R.x1 = sg.x; R.y1 = sg.y; R.x2 = sg.z; R.y2 = sg.w;
-                rec[nrec] = R;
-            }
-            wave_publish();  // the list and the record before the table entry
-            if (lane == 0) st_coherent64(pend + pick_r, lsd_entry(wv, nrec, n > 0 ? n : 0, off));
-            if (lane == 0) lds_st(&s_if_seed[wv], -1);
-            if (n > 0) off += n;
-            ++nrec;
-            if (nrec >= LSD_REC_CAP || npx - off < 4096) break;  // out of room: this wave stops speculating
-        }
-        if (lane == 0) lds_st(&s_if_seed[wv], -1);  // (whatever ended the loop: nothing of this wave is in flight any more)
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------------------------------
-// The same protocol across the CUs of ONE XCD (round 6; STVO_LSD_WAVES=1 keeps the one-workgroup form above).  Sixteen waves of one
-// workgroup share a CU's four SIMDs: a growth round is ~1500 cycles of DEPENDENT instructions, so four waves per SIMD deliver one
-// wave's worth of rounds each (measured: fifteen speculators ~ 2.7 waves' worth of growth).  Here a workgroup is four waves, one per
-// SIMD; image b is served by the workgroups b, b + 8, b + 16, ... — the dispatcher places those on one XCD — the first of them holds
-// the committer, the others four speculating waves each.  What the waves exchange lives in HBM and meets in that XCD's L2:
-//   stores are ordinary (write-through L1, the line stays in the L2), loads of anything another CU stores during the launch bypass
-//   the vector L1 (sc1), claims are compare-and-swaps (performed in the L2);
-//   the flags (`used`) and the control words (committer's position, front, seeds in flight) are ADVISORY for a speculating wave — a
-//   stale value costs a failed validation, never a wrong region; what the committer takes on trust are the pixel list + segment of a
-//   finished region: stored, waited for (vmcnt), then the table entry.
-// Placement is never assumed: the committer publishes the id of ITS XCD (an agent-scope store), a speculating workgroup that finds
-// itself on another one leaves — the committer alone is the sequential search, so any placement gives the same segments.
+// The protocol above across the CUs of ONE XCD.  A workgroup is four waves, one per SIMD (84 KB of LDS at least: a CU holds one).
+// Image b is served by the workgroups b, b + 8, b + 16, ... — the dispatcher of the hardware places those on one XCD:
+//   workgroup b       wave 0 the COMMITTER.  One wave on its SIMD pays its issue latency for every instruction, so it executes as
+//                            little as possible per region: its flags are a bitmap in LDS (the global flags are written behind, for the
+//                            speculating waves), the finished regions reach it through LDS records (the feeder);
+//                     wave 1 the DISPATCHER: scans the ranks in front of the committer and hands the free seeds to idle speculating
+//                            waves through their mail boxes, in rank order.  The only wave that claims — with every wave scanning for
+//                            itself they all find the same first candidate and beyond ~8 waves the claims serialise (measured: 33
+//                            waves 38 ms, 125 waves 57 ms per image; with the dispatcher 13 ms before the two items above);
+//                     wave 2 the FEEDER: for the free seeds within LSD_FEED_AHEAD ranks of the committer whose table entry shows a
+//                            finished region, segment + pixel list from the L2 into a record ring in LDS, in rank order;
+//   workgroups b + 8 k  four SPECULATING waves each: mail box -> grow_region_w against the global flags (loads that bypass the L1) ->
+//                            region_segment_w -> list + segment stored, waited for (vmcnt), table entry, mail box "idle".
+// What the workgroups exchange lives in HBM and meets in that XCD's L2: stores are ordinary (write-through L1, the line stays in the
+// L2), loads of anything another CU stores during the launch bypass the vector L1 (sc1).  The flags and the mail boxes are ADVISORY
+// for a speculating wave — a stale flag costs a failed validation, never a wrong region; what the committer (or the feeder) takes on
+// trust are the pixel list + segment of a finished region: stored, waited for, THEN the table entry (a workgroup-scope release does
+// not wait for the stores — the first version lost a segment that way in one of two images).
+// Placement is verified, never assumed: the committer publishes the id of ITS XCD (HW_REG_XCC_ID, an agent-scope store), a
+// speculating workgroup that finds itself on another one leaves without announcing itself — the committer alone is the sequential
+// search, so any placement gives the same segments, only later.
 constexpr int LSD_XW = 4;          // waves per workgroup: one per SIMD
 constexpr int LSD_X_MAXW = 125;    // waves per image at most (7 bits of a table entry; 31 speculating workgroups of an XCD's 32 CUs)
 constexpr int LSD_CTL = 512;       // control words per image, zeroed per call
+constexpr size_t LSD_XCD_MAX_PX = 3u << 18;  // the committer's bitmap (96 KB) + the feeder's ring + the per-wave scratch fit the 160 KB of a CU
+constexpr int LSD_FEED_PX = 8192;   // words of the feeder's record ring (LDS)
+constexpr int LSD_FEED_Q = 256;     // records in it at most
+constexpr int LSD_FEED_MAXW = 2048; // a record's words at most (longer lists go through the table)
+constexpr int LSD_FEED_AHEAD = 192;  // ranks the feeder runs ahead of the committer at most (further ahead most regions are still being grown: 2048: a quarter of the regions found finished, 128 - 256: 95 %)
 constexpr int XC_ALIVE = 0;        // the committer's XCC id + 1 (0: it has not started)
 constexpr int XC_DONE = 1;
 constexpr int XC_MBOX = 64;        // [128] 64-bit mail boxes: 0 = wave v is not there, 1 = idle, else bit 62 | rank << 21 | seed pixel: grow this one
@@ -1064,13 +853,14 @@ struct LsdXcd {
     long long* pend; // [B][w h] by rank: 0 free, LSD_CLAIM | wave, or lsd_entry_x
     int32_t* ctl;    // [B][LSD_CTL]
     int nsb;         // speculating workgroups per image; nw = 1 + nsb LSD_XW
+    int feed_ahead, sep, ahead;  // LSD_FEED_AHEAD, LSD_SEP, LSD_AHEAD or their developer overrides (STVO_LSD_FEED_AHEAD / _SEP / _AHEAD)
 };
 __device__ __forceinline__ long long lsd_entry_x(int wave, int n, int off) { return (1ll << 62) | ((long long)wave << 42) | ((long long)n << 21) | (long long)off; }
 
 __global__ __launch_bounds__(LSD_XW * 64) void lsd_grow_xcd_kernel(LsdDev d, LsdXcd x) {
     __shared__ int s_ring[LSD_XW][LSD_WRING];
     __shared__ double s_term[LSD_XW][3][64];
-    __shared__ int s_scan, s_done;
+    __shared__ int s_scan, s_done, s_qhead, s_qtail, s_cwords;
     const int b = blockIdx.x & 7, role = blockIdx.x >> 3, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (b >= d.B) return;
     int xcc;
@@ -1086,15 +876,59 @@ __global__ __launch_bounds__(LSD_XW * 64) void lsd_grow_xcd_kernel(LsdDev d, Lsd
     int32_t* ctl = x.ctl + (size_t)b * LSD_CTL;
     long long* mbox = reinterpret_cast<long long*>(ctl + XC_MBOX);
     const int nw = 1 + x.nsb * LSD_XW;
+    // dynamic LDS of the committer's workgroup: its flags, one bit per pixel | the feeder's record ring | the records' descriptors
+    extern __shared__ unsigned s_bits[];
+    const int nbw = (((npx + 31) / 32) + 3) & ~3;  // (whole 16-byte units: the descriptors behind are int4)
+    int* const s_px = reinterpret_cast<int*>(s_bits + nbw);  // [LSD_FEED_PX] per record: 4 words of segment, then the pixel indices
+    int4* const s_desc = reinterpret_cast<int4*>(s_px + LSD_FEED_PX);  // [LSD_FEED_Q] {rank, size, position in s_px, words fed up to its end}
     if (role == 0) {
         if (threadIdx.x == 0) {
             s_scan = -1;
             s_done = 0;
+            s_qhead = 0;
+            s_qtail = 0;
+            s_cwords = 0;
         }
+        for (int i = threadIdx.x; i < nbw; i += LSD_XW * 64) s_bits[i] = 0u;
         __syncthreads();
     }
+    // keys and table entries of LSD_SB batches per round trip, the next such span requested before this one is worked on (the
+    // committer and the feeder walk the ranks alike)
+    constexpr int LSD_SB = 4;
+    uint32_t kn[LSD_SB], kc[LSD_SB];
+    long long en[LSD_SB], ec[LSD_SB];
+    auto request = [&](int s0, bool entries) {
+#pragma unroll
+        for (int i = 0; i < LSD_SB; ++i) {
+            const int r = s0 + 64 * i + lane;
+            kn[i] = r < npx ? order[r] : LSD_NOKEY;
+            en[i] = entries && r < npx ? ld_l2_64(pend + r) : 0ll;
+        }
+    };
+    auto next_span = [&](int s0, bool entries) {
+#pragma unroll
+        for (int i = 0; i < LSD_SB; ++i) {
+            kc[i] = kn[i];
+            ec[i] = en[i];
+        }
+        request(s0 + 64 * LSD_SB, entries);
+    };
+    auto batch_regs = [&](int bi, uint32_t& key, long long& ent) {
+        key = kc[0];
+        ent = ec[0];
+#pragma unroll
+        for (int i = 1; i < LSD_SB; ++i) {
+            key = bi == i ? kc[i] : key;
+            ent = bi == i ? ec[i] : ent;
+        }
+    };
     if (role == 0 && wv == 0) {
         // ---------------- the committer ----------------
+        // One wave on its SIMD: every instruction costs its issue latency, so the wave executes as little as possible per region.
+        // Its flags are the bitmap in LDS (the global flags are written behind, for the speculating waves, and never read here); the
+        // finished regions of the seeds in front of it come through LDS too — the feeder wave (below) has read table entry, segment
+        // and pixel list from the L2 and left a record in rank order.  A seed without a record (its region was not finished when the
+        // feeder passed, or the feeder is behind) takes the path through the table.
         __builtin_amdgcn_s_setprio(3);
         int32_t* wlist = x.wlist + (size_t)b * nw * npx;
         if (lane == 0) __hip_atomic_store(ctl + XC_ALIVE, xcc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1103,53 +937,124 @@ __global__ __launch_bounds__(LSD_XW * 64) void lsd_grow_xcd_kernel(LsdDev d, Lsd
         auto tick = [&]() -> long long { return prof ? (long long)__builtin_readcyclecounter() : 0ll; };
         const long long t_begin = tick();
         long long t_self = 0, t_wait = 0, t_take = 0;
-        int n_took = 0, n_self = 0, n_bad = 0, n_waited = 0;
-        for (int o0 = 0; o0 < npx; o0 += 64) {
-            const uint32_t key = o0 + lane < npx ? order[o0 + lane] : LSD_NOKEY;
-            if ((uint32_t)__builtin_amdgcn_readfirstlane((int)key) == LSD_NOKEY) break;
+        int n_took = 0, n_self = 0, n_bad = 0, n_waited = 0, n_fast = 0, n_stale = 0, n_batch = 0;
+        int qt = 0, qh = 0;  // records consumed / known to be there
+        request(0, false);
+        bool at_end = false;
+        for (int s0 = 0; s0 < npx && !at_end; s0 += 64 * LSD_SB) {
+        next_span(s0, false);
+        for (int bi = 0; bi < LSD_SB; ++bi) {
+            const int o0 = s0 + 64 * bi;
+            uint32_t key;
+            long long ent_unused;
+            batch_regs(bi, key, ent_unused);
+            if ((uint32_t)__builtin_amdgcn_readfirstlane((int)key) == LSD_NOKEY) {
+                at_end = true;
+                break;
+            }
+            ++n_batch;
             const int q_l = (int)(key & ((1u << LSD_IDX_BITS) - 1u));
             const bool key_ok = key != LSD_NOKEY;
-            const float ang_l = key_ok ? ang[q_l] : -1.f;
-            unsigned long long todo = __ballot(key_ok && ld_coherent(used + (key_ok ? q_l : 0)) == 0);
-            int ahead_j = -1;
-            long long ahead_p = 0;
+            unsigned long long todo = __ballot(key_ok && bit_ld(s_bits, key_ok ? q_l : 0) == 0u);
             while (todo) {
                 const int j = __builtin_ctzll(todo);
                 todo &= todo - 1ull;
                 const int seed = __builtin_amdgcn_readlane(q_l, j), rank = o0 + j;
                 if (lane == 0) lds_st(&s_scan, rank);
-                auto table = [&]() { return readfirstlane64(ld_l2_64(pend + rank)); };  // (one address: a scalar result)
-                long long p = (j == ahead_j && (ahead_p & (1ll << 62))) ? ahead_p : table();
-                if (p < 0) {  // a speculating wave holds the claim on this very seed: its work is the work this wave would do (bounded wait)
-                    const long long tw = tick();
-                    for (int spin = 0; spin < (1 << 20) && (p = table()) < 0; ++spin) __builtin_amdgcn_s_sleep(2);
-                    if (p < 0) p = 0;  // (gave up: this wave grows the seed itself, whatever the other one publishes later is never read)
-                    t_wait += tick() - tw;
-                    ++n_waited;
+                // the feeder's record of this rank, if there is one (records of seeds taken meanwhile are passed over)
+                int4 dsc = make_int4(-1, 0, 0, 0);
+                bool fast = false;
+                {
+                    const int qt0 = qt;
+                    int cend = 0;
+                    for (;;) {
+                        if (qt == qh) {
+                            qh = __hip_atomic_load(&s_qhead, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (qt == qh) break;
+                        }
+                        dsc = s_desc[qt & (LSD_FEED_Q - 1)];
+                        dsc.x = __builtin_amdgcn_readfirstlane(dsc.x);
+                        if (dsc.x >= rank) break;
+                        cend = __builtin_amdgcn_readfirstlane(dsc.w);
+                        ++qt;
+                        ++n_stale;
+                    }
+                    fast = qt != qh && dsc.x == rank;
+                    if (qt != qt0 && lane == 0) {  // room for the feeder
+                        lds_st(&s_cwords, cend);
+                        lds_st(&s_qtail, qt);
+                    }
                 }
                 bool took = false;
+                long long p = 0;
                 const long long tk = tick();
-                if (p) {
-                    const int off = (int)(p & 0x1FFFFF), n = (int)((p >> 21) & 0x1FFFFF), pw = (int)((p >> 42) & 0x7F);
-                    if (n > 0) {
-                        const int32_t* pl = x.wlist + ((size_t)b * nw + pw) * npx + off;  // 4 words of segment, then the pixels
-                        float sgv = 0.f;
-                        if (n >= d.min_reg_size && lane < 4) sgv = __int_as_float(ld_l2(pl + lane));
-                        bool bad = false;
-                        for (int t = lane; t < n; t += 64) {
-                            const int pxy = ld_l2(pl + 4 + t);
-                            bad = bad || ld_coherent(used + (pxy >> 16) * w + (pxy & 0xFFFF)) != 0;
+                if (fast) {
+                    ++n_fast;
+                    const int n = __builtin_amdgcn_readfirstlane(dsc.y), pos = __builtin_amdgcn_readfirstlane(dsc.z);
+                    const int v0 = lane < n + 4 ? s_px[pos + lane] : 0;
+                    const bool has = lane >= 4 && lane < n + 4;
+                    bool bad = has && bit_ld(s_bits, v0) != 0u;
+                    for (int t = 64 + lane; t < n + 4; t += 64) bad = bad || bit_ld(s_bits, s_px[pos + t]) != 0u;
+                    if (!__ballot(bad)) {  // every pixel still free: this IS the region of the sequential search
+                        if (has) {
+                            bit_set(s_bits, v0);
+                            st_coherent(used + v0, 1);
                         }
-                        if (!__ballot(bad)) {  // every pixel still free: this IS the region of the sequential search
-                            for (int t = lane; t < n; t += 64) {
-                                const int pxy = ld_l2(pl + 4 + t);
-                                st_coherent(used + (pxy >> 16) * w + (pxy & 0xFFFF), 1);
+                        for (int t = 64 + lane; t < n + 4; t += 64) {
+                            const int q = s_px[pos + t];
+                            bit_set(s_bits, q);
+                            st_coherent(used + q, 1);
+                        }
+                        took = true;
+                        if (n >= d.min_reg_size) {
+                            if (lane < 4 && n_seg < d.seg_cap) reinterpret_cast<int*>(d.seg + (size_t)b * d.seg_cap + n_seg)[lane] = v0;
+                            ++n_seg;
+                        }
+                    }
+                    p = 1;  // (a region that fails here is grown again below, as one from the table)
+                    ++qt;
+                    if (lane == 0) {
+                        lds_st(&s_cwords, __builtin_amdgcn_readfirstlane(dsc.w));
+                        lds_st(&s_qtail, qt);
+                    }
+                } else {
+                    auto table = [&]() { return readfirstlane64(ld_l2_64(pend + rank)); };  // (one address: a scalar result)
+                    p = table();
+                    if (p < 0) {  // a speculating wave is growing this very seed: its work is the work this wave would do (bounded wait)
+                        const long long tw = tick();
+                        for (int spin = 0; spin < (1 << 20) && (p = table()) < 0; ++spin) __builtin_amdgcn_s_sleep(2);
+                        if (p < 0) p = 0;  // (gave up: this wave grows the seed itself, whatever the other one publishes later is never read)
+                        t_wait += tick() - tw;
+                        ++n_waited;
+                    }
+                    if (p) {
+                        const int off = (int)(p & 0x1FFFFF), n = (int)((p >> 21) & 0x1FFFFF), pw = (int)((p >> 42) & 0x7F);
+                        if (n > 0) {
+                            const int32_t* pl = x.wlist + ((size_t)b * nw + pw) * npx + off;  // 4 words of segment, then the pixels
+                            const int w0 = lane < n + 4 ? ld_l2(pl + lane) : 0;
+                            const bool has = lane >= 4 && lane < n + 4;
+                            const int q0 = (w0 >> 16) * w + (w0 & 0xFFFF);
+                            bool bad = has && bit_ld(s_bits, q0) != 0u;
+                            for (int t = 64 + lane; t < n + 4; t += 64) {  // (the rare long list: the rest in further round trips)
+                                const int pxy = ld_l2(pl + t);
+                                bad = bad || bit_ld(s_bits, (pxy >> 16) * w + (pxy & 0xFFFF)) != 0u;
                             }
-                            took = true;
-                            if (n >= d.min_reg_size) {
-                                const float4 sg = make_float4(readlane_f32(sgv, 0), readlane_f32(sgv, 1), readlane_f32(sgv, 2), readlane_f32(sgv, 3));
-                                if (lane == 0 && n_seg < d.seg_cap) d.seg[(size_t)b * d.seg_cap + n_seg] = sg;
-                                ++n_seg;
+                            if (!__ballot(bad)) {
+                                if (has) {
+                                    bit_set(s_bits, q0);
+                                    st_coherent(used + q0, 1);
+                                }
+                                for (int t = 64 + lane; t < n + 4; t += 64) {
+                                    const int pxy = ld_l2(pl + t);
+                                    const int q = (pxy >> 16) * w + (pxy & 0xFFFF);
+                                    bit_set(s_bits, q);
+                                    st_coherent(used + q, 1);
+                                }
+                                took = true;
+                                if (n >= d.min_reg_size) {
+                                    if (lane < 4 && n_seg < d.seg_cap) reinterpret_cast<int*>(d.seg + (size_t)b * d.seg_cap + n_seg)[lane] = w0;
+                                    ++n_seg;
+                                }
                             }
                         }
                     }
@@ -1161,8 +1066,8 @@ __global__ __launch_bounds__(LSD_XW * 64) void lsd_grow_xcd_kernel(LsdDev d, Lsd
                 else ++n_self;
                 if (!took) {
                     double reg_angle;
-                    const int n = grow_region_w<true>(ang, csn, used, nullptr, 0, wlist, npx, s_ring[0], seed, readlane_f32(ang_l, j), w, h, d.prec,
-                                                      reg_angle);
+                    const int n = grow_region_w<true, false, true>(ang, csn, used, nullptr, 0, wlist, npx, s_ring[0], seed, ang[seed], w, h, d.prec,
+                                                                   reg_angle, s_bits);
                     if (n >= d.min_reg_size) {
                         const float4 sg = region_segment_w(d, wlist, n, mod, reg_angle, s_term[0]);
                         if (lane == 0 && n_seg < d.seg_cap) d.seg[(size_t)b * d.seg_cap + n_seg] = sg;
@@ -1170,14 +1075,13 @@ __global__ __launch_bounds__(LSD_XW * 64) void lsd_grow_xcd_kernel(LsdDev d, Lsd
                     }
                     t_self += tick() - ts;
                 }
-                wave_publish();
-                ahead_j = todo ? __builtin_ctzll(todo) : -1;
-                const bool free_l = key_ok && ld_coherent(used + (key_ok ? q_l : 0)) == 0;
-                long long pa = 0;
-                if (ahead_j >= 0) pa = ld_l2_64(pend + o0 + ahead_j);
-                todo &= __ballot(free_l);
-                ahead_p = readfirstlane64(pa);
+                // seeds of the batch taken meanwhile (an LDS round trip)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                todo &= __ballot(key_ok && bit_ld(s_bits, key_ok ? q_l : 0) == 0u);
             }
+        }
         }
         if (lane == 0) {
             d.n_seg[b] = n_seg;
@@ -1189,6 +1093,84 @@ __global__ __launch_bounds__(LSD_XW * 64) void lsd_grow_xcd_kernel(LsdDev d, Lsd
             q[0] = (double)(tick() - t_begin); q[1] = (double)t_self; q[2] = (double)t_wait; q[3] = (double)t_take;
             q[4] = (double)n_took; q[5] = (double)n_self; q[6] = (double)n_bad; q[7] = (double)n_waited;
             q[8] = -1.0;
+            q[9] = (double)n_fast; q[10] = (double)n_stale; q[11] = (double)n_batch;
+        }
+    } else if (role == 0 && wv == 2) {
+        // ---------------- the feeder: the finished regions in front of the committer, from the L2 into LDS, in rank order ----------------
+        // For every seed that is free now and whose table entry shows a finished region: segment + pixel list (as pixel INDICES) into
+        // the record ring, a descriptor behind it.  Never waited for by the committer; waits itself for room in the ring and keeps
+        // within LSD_FEED_AHEAD ranks of the committer (entries further ahead are mostly still being grown).
+        constexpr int GRP = 4;
+        int wpos = 0, qhd = 0;  // words / records fed so far
+        request(0, true);
+        bool at_end = false;
+        auto gone = [&]() { return lds_ld(&s_done) != 0; };
+        for (int s0 = 0; s0 < npx && !at_end; s0 += 64 * LSD_SB) {
+        next_span(s0, true);
+        for (int bi = 0; bi < LSD_SB && !at_end; ++bi) {
+            const int o0 = s0 + 64 * bi;
+            uint32_t key;
+            long long ent;
+            batch_regs(bi, key, ent);
+            if ((uint32_t)__builtin_amdgcn_readfirstlane((int)key) == LSD_NOKEY) {
+                at_end = true;
+                break;
+            }
+            for (int spin = 0; o0 > lds_ld(&s_scan) + x.feed_ahead; ++spin) {
+                if (gone() || spin > (1 << 22)) return;
+                __builtin_amdgcn_s_sleep(8);
+            }
+            const bool key_ok = key != LSD_NOKEY;
+            const int q_l = (int)(key & ((1u << LSD_IDX_BITS) - 1u));
+            // (entries read a span ago: those of free seeds that were not finished then are read again now that their batch is near)
+            if (__ballot(key_ok && (ent >> 62) != 1ll && bit_ld(s_bits, key_ok ? q_l : 0) == 0u)) {
+                const long long e2 = ld_l2_64(pend + (o0 + lane < npx ? o0 + lane : 0));
+                ent = o0 + lane < npx ? e2 : ent;
+            }
+            const int en_n = (int)((ent >> 21) & 0x1FFFFF);
+            unsigned long long g = __ballot(key_ok && (ent >> 62) == 1ll && en_n != 0 && en_n + 4 <= LSD_FEED_MAXW && bit_ld(s_bits, key_ok ? q_l : 0) == 0u);
+            while (g) {
+                int J[GRP], W[GRP];
+                const int32_t* PL[GRP];
+#pragma unroll
+                for (int k = 0; k < GRP; ++k) {  // the loads of a group together
+                    J[k] = g ? __builtin_ctzll(g) : -1;
+                    g &= g - 1ull;
+                    W[k] = 0;
+                    PL[k] = nullptr;
+                    if (J[k] >= 0) {
+                        const long long p = readlane_i64(ent, J[k]);
+                        const int off = (int)(p & 0x1FFFFF), n = (int)((p >> 21) & 0x1FFFFF), pw = (int)((p >> 42) & 0x7F);
+                        PL[k] = x.wlist + ((size_t)b * nw + pw) * npx + off;
+                        if (lane < n + 4) W[k] = ld_l2(PL[k] + lane);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < GRP; ++k) {
+                    if (J[k] < 0) continue;
+                    const long long p = readlane_i64(ent, J[k]);
+                    const int n = (int)((p >> 21) & 0x1FFFFF), L = n + 4;
+                    int pos = wpos & (LSD_FEED_PX - 1);
+                    if (pos + L > LSD_FEED_PX) {  // (records are contiguous: the rest of the ring's end stays unused)
+                        wpos += LSD_FEED_PX - pos;
+                        pos = 0;
+                    }
+                    for (int spin = 0; wpos + L - lds_ld(&s_cwords) > LSD_FEED_PX || qhd - lds_ld(&s_qtail) >= LSD_FEED_Q; ++spin) {
+                        if (gone() || spin > (1 << 22)) return;
+                        __builtin_amdgcn_s_sleep(4);
+                    }
+                    if (lane < L) s_px[pos + lane] = lane < 4 ? W[k] : (W[k] >> 16) * w + (W[k] & 0xFFFF);
+                    for (int t = 64 + lane; t < L; t += 64) {
+                        const int pxy = ld_l2(PL[k] + t);
+                        s_px[pos + t] = (pxy >> 16) * w + (pxy & 0xFFFF);
+                    }
+                    wpos += L;
+                    if (lane == 0) s_desc[qhd & (LSD_FEED_Q - 1)] = make_int4(o0 + J[k], n, pos, wpos);
+                    ++qhd;
+                    if (lane == 0) __hip_atomic_store(&s_qhead, qhd, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);  // (the record before its count)
+                }
+            }
+        }
         }
     } else if (role == 0 && wv == 1) {
         // ---------------- the dispatcher: hands the free seeds in front of the committer to idle speculating waves, in rank order ----------------
@@ -1210,7 +1192,7 @@ __global__ __launch_bounds__(LSD_XW * 64) void lsd_grow_xcd_kernel(LsdDev d, Lsd
             }
             const int scan = lds_ld(&s_scan);
             const int start = front > scan + 1 ? front : scan + 1;
-            if (start - scan > LSD_AHEAD) {  // far enough ahead of the committer: regions grown beyond see flags too stale to survive
+            if (start - scan > x.ahead) {  // far enough ahead of the committer: regions grown beyond see flags too stale to survive
                 __builtin_amdgcn_s_sleep(8);
                 continue;
             }
@@ -1222,7 +1204,7 @@ __global__ __launch_bounds__(LSD_XW * 64) void lsd_grow_xcd_kernel(LsdDev d, Lsd
                 if (end) break;
                 const bool ok = key != LSD_NOKEY;
                 const int q = (int)(key & ((1u << LSD_IDX_BITS) - 1u));
-                const bool open = ok && ld_coherent(used + (ok ? q : 0)) == 0 && ld_coherent64(pend + (ok ? r : 0)) == 0;  // (the committer's stores and this wave's own: one CU)
+                const bool open = ok && bit_ld(s_bits, ok ? q : 0) == 0u && ld_coherent64(pend + (ok ? r : 0)) == 0;  // (the committer's bitmap; this wave's own claims: one CU)
                 const int qx = q % w, qy = q / w;
                 const unsigned long long m_open = __ballot(open);
                 unsigned long long mm = m_open, given = 0ull;
@@ -1233,7 +1215,7 @@ __global__ __launch_bounds__(LSD_XW * 64) void lsd_grow_xcd_kernel(LsdDev d, Lsd
                     auto near = [&](int sxy) {
                         const int ddx = cx - (sxy & 0xFFFF), ddy = cy - (sxy >> 16);
                         const int adx = ddx < 0 ? -ddx : ddx, ady = ddy < 0 ? -ddy : ddy;
-                        return sxy >= 0 && (adx > ady ? adx : ady) < LSD_SEP;
+                        return sxy >= 0 && (adx > ady ? adx : ady) < x.sep;
                     };
                     if (__ballot(near(sxy0) || near(sxy1))) continue;  // too close to a growth in flight: later (the front stays in front of it)
                     const int u = I0 ? __builtin_ctzll(I0) : 64 + __builtin_ctzll(I1);
@@ -1418,10 +1400,10 @@ struct stvo_lsd {
     float* response = nullptr;
     int32_t* n_lines = nullptr;
     double* dbg = nullptr;
-    stvo::LsdWaves xw{};      // scratch of lsd_grow_waves_kernel (small batches), or null
     char* wdev = nullptr;
     size_t stamp_bytes = 0, pend_bytes = 0;
     stvo::LsdXcd xx{};        // scratch of lsd_grow_xcd_kernel (small batches, the default), or null
+    int xcd_lds = 0;          // its dynamic LDS: the committer's bitmap — and at least 84 KB, so that a CU holds ONE of its workgroups (a wave per SIMD)
     int sort_chunk = 1;       // images per call of the segmented sort (its item count is an int)
 };
 
@@ -1462,14 +1444,10 @@ int lsd_enqueue(stvo_lsd* o, const uint8_t* images, stvo_keyline* lines, float* 
                                                                     o->seg_off + 1, begin_bit, 32, s));
         }
     }
-    if (o->wdev && o->xx.ctl) {  // small batches: a committing wave + speculating workgroups on the CUs of one XCD per image (lsd_grow_xcd_kernel)
+    if (o->wdev) {  // small batches: a committing wave + speculating workgroups on the CUs of one XCD per image (lsd_grow_xcd_kernel)
         HIP_TRY(ctx, hipMemsetAsync(o->xx.stamp, 0, o->stamp_bytes, s));
         HIP_TRY(ctx, hipMemsetAsync(o->xx.pend, 0, o->pend_bytes + (size_t)d.B * stvo::LSD_CTL * 4, s));  // (the control words lie behind the table)
-        hipLaunchKernelGGL(stvo::lsd_grow_xcd_kernel, dim3(8 * (1 + o->xx.nsb)), dim3(stvo::LSD_XW * 64), 0, s, d, o->xx);
-    } else if (o->wdev) {  // STVO_LSD_WAVES=1: one workgroup of LSD_NW waves per image (lsd_grow_waves_kernel)
-        HIP_TRY(ctx, hipMemsetAsync(o->xw.stamp, 0, o->stamp_bytes, s));
-        HIP_TRY(ctx, hipMemsetAsync(o->xw.pend, 0, o->pend_bytes, s));
-        hipLaunchKernelGGL(stvo::lsd_grow_waves_kernel, dim3(d.B), dim3(stvo::LSD_NW * 64), 0, s, d, o->xw);
+        hipLaunchKernelGGL(stvo::lsd_grow_xcd_kernel, dim3(8 * (1 + o->xx.nsb)), dim3(stvo::LSD_XW * 64), o->xcd_lds, s, d, o->xx);
     } else if (stvo::dbg().lsd_grow == 0) {
         hipLaunchKernelGGL(stvo::lsd_grow_kernel<false>, dim3(d.B), dim3(64), 0, s, d);
     } else {
@@ -1572,29 +1550,25 @@ int stvo_lsd_create(stvo_ctx* ctx, int B, int cols, int rows, int max_keylines, 
     }
     if (ok && (size_t)d.seg_cap * 8 > 48 * 1024)
         ok = stvo::lds_opt_in(reinterpret_cast<const void*>(stvo::lsd_keylines_kernel), d.seg_cap * 8);
-    if (ok && stvo::dbg().lsd_waves != 0 && stvo::dbg().lsd_waves != 1 && B <= stvo::LSD_WAVES_MAX_B) {  // the default for small batches
+    if (ok && stvo::dbg().lsd_waves != 0 && B <= stvo::LSD_WAVES_MAX_B && npx <= stvo::LSD_XCD_MAX_PX) {  // small batches (STVO_LSD_WAVES=0: one wave per image there too)
         int nsb = stvo::dbg().lsd_xcd_blocks == stvo::DBG_UNSET ? 8 : stvo::dbg().lsd_xcd_blocks;  // STVO_LSD_XCD_BLOCKS: speculating workgroups per image
         nsb = nsb < 0 ? 0 : (nsb > (stvo::LSD_X_MAXW - 1) / stvo::LSD_XW ? (stvo::LSD_X_MAXW - 1) / stvo::LSD_XW : nsb);
         const size_t nw = 1 + (size_t)nsb * stvo::LSD_XW;
         decltype(c) cw;
         const size_t w_stamp = cw.take(nb * nw * npx * 4), w_list = cw.take(nb * nw * npx * 4), w_pend = cw.take(nb * npx * 8 + nb * stvo::LSD_CTL * 4);
-        ok = hip_ok(ctx, hipMalloc((void**)&o->wdev, cw.off), "hipMalloc lsd xcd");
+        o->xcd_lds = (int)(((((npx + 31) / 32) + 3) & ~size_t(3)) * 4) + stvo::LSD_FEED_PX * 4 + stvo::LSD_FEED_Q * 16;
+        if (o->xcd_lds < 84 * 1024) o->xcd_lds = 84 * 1024;
+        ok = stvo::lds_opt_in(reinterpret_cast<const void*>(stvo::lsd_grow_xcd_kernel), o->xcd_lds) &&
+             hip_ok(ctx, hipMalloc((void**)&o->wdev, cw.off), "hipMalloc lsd xcd");
         if (ok) {
             o->xx.stamp = (int32_t*)(o->wdev + w_stamp); o->xx.wlist = (int32_t*)(o->wdev + w_list);
             o->xx.pend = (long long*)(o->wdev + w_pend); o->xx.ctl = (int32_t*)(o->wdev + w_pend + nb * npx * 8);
             o->xx.nsb = nsb;
+            const auto& g = stvo::dbg();
+            o->xx.feed_ahead = g.lsd_feed_ahead == stvo::DBG_UNSET ? stvo::LSD_FEED_AHEAD : g.lsd_feed_ahead;
+            o->xx.sep = g.lsd_sep == stvo::DBG_UNSET ? stvo::LSD_SEP : g.lsd_sep;
+            o->xx.ahead = g.lsd_ahead == stvo::DBG_UNSET ? stvo::LSD_AHEAD : g.lsd_ahead;
             o->stamp_bytes = nb * nw * npx * 4;
-            o->pend_bytes = nb * npx * 8;
-        }
-    } else if (ok && stvo::dbg().lsd_waves != 0 && B <= stvo::LSD_WAVES_MAX_B) {  // STVO_LSD_WAVES=1: sixteen waves of one workgroup; 0: one wave per image for small batches too
-        decltype(c) cw;
-        const size_t w_stamp = cw.take(nb * stvo::LSD_NW * npx * 4), w_list = cw.take(nb * stvo::LSD_NW * npx * 4),
-                     w_rec = cw.take(nb * stvo::LSD_NW * stvo::LSD_REC_CAP * sizeof(stvo::LsdRec)), w_pend = cw.take(nb * npx * 8);
-        ok = hip_ok(ctx, hipMalloc((void**)&o->wdev, cw.off), "hipMalloc lsd waves");
-        if (ok) {
-            o->xw.stamp = (int32_t*)(o->wdev + w_stamp); o->xw.wlist = (int32_t*)(o->wdev + w_list);
-            o->xw.rec = (stvo::LsdRec*)(o->wdev + w_rec); o->xw.pend = (long long*)(o->wdev + w_pend);
-            o->stamp_bytes = nb * stvo::LSD_NW * npx * 4;
             o->pend_bytes = nb * npx * 8;
         }
     }

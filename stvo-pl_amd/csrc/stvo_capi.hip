@@ -48,6 +48,9 @@ DebugSwitches parse_switches() {
     d.lsd_sort_full = env_int("STVO_LSD_SORT_FULL");
     d.lsd_waves = env_int("STVO_LSD_WAVES");
     d.lsd_xcd_blocks = env_int("STVO_LSD_XCD_BLOCKS");
+    d.lsd_feed_ahead = env_int("STVO_LSD_FEED_AHEAD");
+    d.lsd_sep = env_int("STVO_LSD_SEP");
+    d.lsd_ahead = env_int("STVO_LSD_AHEAD");
     return d;
 }
 DebugSwitches& switches() {

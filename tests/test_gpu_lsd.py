@@ -75,14 +75,14 @@ def test_lsd_plain_growth_is_the_same(hip, oracle, switches):
             lsd.close()
 
 
-@pytest.mark.parametrize("waves", ["1", "0"])
-def test_lsd_sixteen_waves_and_one_wave_per_image_are_the_same(hip, oracle, switches, waves):
-    """Batches of <= 8 images run one workgroup of 16 waves per image by default — a committing wave and 15 speculating ones, pending
-    regions validated at their seed's turn (lsd_kernels.hip: lsd_grow_waves_kernel; CPU replay: tools/experiments/lsd_waves_sim.c);
-    STVO_LSD_WAVES=0 runs such a batch on the one-wave kernel of the large batches.  Both must give the oracle's segments in the
-    oracle's order."""
+@pytest.mark.parametrize("waves", ["", "0"])
+def test_lsd_many_waves_and_one_wave_per_image_are_the_same(hip, oracle, switches, waves):
+    """Batches of <= 8 images run one image per XCD by default — a committing wave, a dispatcher and a feeder in one workgroup,
+    speculating workgroups of four waves on the other CUs, pending regions validated at their seed's turn (lsd_kernels.hip:
+    lsd_grow_xcd_kernel; CPU replay of the scheme: tools/experiments/lsd_waves_sim.c); STVO_LSD_WAVES=0 runs such a batch on the
+    one-wave kernel of the large batches.  Both must give the oracle's segments in the oracle's order."""
     from stvo_amd import capi
-    switches({"STVO_LSD_WAVES": waves})
+    switches({"STVO_LSD_WAVES": waves} if waves else {})
     cols, rows = 752, 480
     rng = np.random.default_rng(43)
     imgs = np.stack([synth.make_image(620, cols, rows), clean_image(cols, rows, 621), rng.integers(0, 255, (rows, cols), dtype=np.uint8),
@@ -98,6 +98,30 @@ def test_lsd_sixteen_waves_and_one_wave_per_image_are_the_same(hip, oracle, swit
                     assert np.array_equal(segs[b], ref)
         finally:
             lsd.close()
+
+
+@pytest.mark.parametrize("knobs", [{"STVO_LSD_XCD_BLOCKS": "0"}, {"STVO_LSD_XCD_BLOCKS": "1", "STVO_LSD_FEED_AHEAD": "0"},
+                                   {"STVO_LSD_XCD_BLOCKS": "31", "STVO_LSD_SEP": "4", "STVO_LSD_AHEAD": "1000000", "STVO_LSD_FEED_AHEAD": "100000"}])
+def test_lsd_xcd_kernel_under_hostile_settings(hip, oracle, switches, knobs):
+    """The many-waves form must be exact whatever the speculation does: no speculating workgroup at all (the committer grows every
+    region itself, through its LDS bitmap), a feeder that is never ahead (every region through the table), and 124 speculating waves
+    crowding each other (seeds 4 px apart, no limit on their lead: most regions fail validation and are grown again) — repeated, so
+    that different interleavings are seen."""
+    from stvo_amd import capi
+    switches(knobs)
+    cols, rows = 640, 360
+    rng = np.random.default_rng(47)
+    imgs = np.stack([synth.make_image(630, cols, rows), rng.integers(0, 255, (rows, cols), dtype=np.uint8)])
+    refs = [oracle.lsd_segments(imgs[b], oracle.lsd_opts(scale=0.8)) for b in range(2)]
+    lsd = capi.Lsd(hip, 2, cols, rows, capi.lsd_params(min_length=4.0, nfeatures=0, scale=0.8), max_keylines=2048)
+    try:
+        for _ in range(4):
+            segs, n = lsd.segments(imgs)
+            for b in range(2):
+                assert n[b] == len(refs[b])
+                assert np.array_equal(segs[b], refs[b])
+    finally:
+        lsd.close()
 
 
 def test_lsd_sort_by_all_key_bits_is_the_same(hip, oracle, switches):

@@ -37,15 +37,18 @@ for b in range(min(B, 2)):
         q = gd[8190]
         q2 = gd[8191]
         if q2[0] == -1.0:
-            print(f"   16-waves kernel, committer cycles: total {q[0]:.0f}  growing itself {q[1]:.0f}  waiting for an in-flight seed {q[2]:.0f}  validating + taking pending {q[3]:.0f} | "
+            print(f"   many-waves kernel, committer cycles: total {q[0]:.0f}  growing itself {q[1]:.0f}  waiting for an in-flight seed {q[2]:.0f}  validating + taking pending {q[3]:.0f} | "
                   f"regions taken {q[4]:.0f}  grown by the committer {q[5]:.0f}  failed validation {q[6]:.0f}  waited for {q[7]:.0f}")
+            if q2[3] > 0:
+                print(f"      regions through the feeder's records {q2[1]:.0f}  records passed over {q2[2]:.0f}  batches {q2[3]:.0f}")
             continue
         print(f"   rounds: publish {q2[0]:.0f}  list read + address + issue {q2[1]:.0f}  wait for the loads {q2[2]:.0f}  | seed set-up {q2[3]:.0f}")
         print(f"   image 0, cycles: total {q[0]:.0f}  grow {q[1]:.0f} (of which resolving {q[2]:.0f})  rect {q[3]:.0f} | rounds {q[4]:.0f}  pixels added {q[5]:.0f}  regions {q[6]:.0f}  batches {q[7]:.0f}")
-t0 = time.perf_counter()
+ts = []
 for _ in range(a.iters):
-    lsd.detect(imgs)
-dt = (time.perf_counter() - t0) / a.iters
+    t0 = time.perf_counter(); lsd.detect(imgs); ts.append(time.perf_counter() - t0)
+dt = float(np.median(ts))
+print("   per call, ms:", " ".join(f"{t * 1e3:.1f}" for t in ts))
 t0 = time.perf_counter(); o.lsd_detect(imgs[0], o.lsd_opts(min_length=0.025 * rows, nfeatures=300)); dc = time.perf_counter() - t0
 print(f"{B} images: {dt * 1e3:.1f} ms per call incl. copies = {B / dt:.0f} images/s; oracle {dc * 1e3:.1f} ms per image on one core")
 lsd.close(); ctx.close()
