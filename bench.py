@@ -444,7 +444,7 @@ def lsd_leg(local_rank, B=4096):
         cpu_ms = (time.perf_counter() - t0) / 2 * 1e3
     finally:
         lsd.close(); lbd.close(); ctx.close()
-    # ONE image (device-resident, host synchronisation included): batches of <= 8 images take the 16-waves-per-image region growing
+    # ONE image (device-resident, host synchronisation included): batches of <= 8 images take the many-waves region growing (one XCD per image)
     ctx1 = capi.Context(device_id=local_rank, max_rows=2048, max_batch=4)
     ctx1.set_stream(torch.cuda.current_stream().cuda_stream)
     lsd1 = capi.Lsd(ctx1, 1, cols, rows, capi.lsd_params(min_length=min_len, nfeatures=100), max_keylines=M)
@@ -469,8 +469,9 @@ def lsd_leg(local_rank, B=4096):
             "one_image_vs_oracle_1_core": cpu_ms / one_ms if one_ms > 0 else None,
             "note": "region growing is sequential per image by definition.  Batches: one wavefront per image (~65 ms alone: ~44 k rounds of ~3.4 "
                     "region points, one L2 round trip + ~1500 cycles of dependent instructions each) — the batch is the parallelism, throughput "
-                    "saturates near 4096 images in flight.  one_image_ms: the 16-waves-per-image form of batches <= 8 (a committing wave + 15 "
-                    "speculating ones, exact), device-resident image, host synchronisation included — still slower than ONE host core"}
+                    "saturates near 4096 images in flight.  one_image_ms: the many-waves form of batches <= 8 (lsd_grow_xcd_kernel, round 6: one XCD "
+                    "per image — a committing wave on an LDS bitmap, a dispatcher and a feeder wave beside it, 32 speculating waves on eight "
+                    "other CUs, exact), device-resident image, host synchronisation included"}
 
 
 def images_leg(local_rank, B=128, steps=8, lines=False):
