@@ -62,16 +62,30 @@ __device__ __forceinline__ void sincos_det(double x, double& s, double& c) {
     c = q == 0 ? cs : (q == 1 ? -sn : (q == 2 ? -cs : sn));
 }
 
+// A pixel as the region growing sees it.  Three arrays (angle, (cos, sin), flag) were three divergent 64-lane gathers per sub-group
+// and round, and the batches are bound by exactly that — the address path of a CU shared by its sixteen waves (SQ counters, round 6:
+// the vector port of a SIMD is 29 % taken at four images per SIMD, a round takes 3.3 x as long as alone).
+struct LsdPx {
+    float ang;     // level-line angle in degrees, < 0: undefined
+    float c, s;    // cos / sin of float(angle in radians) as floats: what the pixel adds to a region's direction sums
+    int32_t used;  // 0 / 1: taken by a region (the only field written after lsd_gradient_kernel)
+};
+typedef float lsd_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ LsdPx px_ld(const LsdPx* p) {  // one 16-byte load
+    const lsd_f4 v = *reinterpret_cast<const lsd_f4*>(p);
+    LsdPx r;
+    r.ang = v.x; r.c = v.y; r.s = v.z; r.used = __float_as_int(v.w);
+    return r;
+}
+
 struct LsdDev {
     int B, w, h;               // the scaled image
     int cols, rows;            // the input image
     int n_bins, min_reg_size, seg_cap, K, nfeatures;
     double rho, prec, scale, min_length;
     const uint8_t* scaled;     // [B][h][w]
-    float* ang;                // [B][w h] level-line angle in degrees, < 0: undefined
-    float2* csn;               // [B][w h] (cos, sin) of float(angle) as floats
+    LsdPx* px;                 // [B][w h] what the search reads of a pixel, ONE 16-byte record (one gather per neighbour instead of three)
     double* mod;               // [B][w h] gradient norm
-    int32_t* used;             // [B][w h]
     uint32_t* keys;            // [B][w h]
     uint32_t* order;           // [B][w h] sorted keys
     int32_t* reg;              // [B][w h] the region being grown: x | y << 16
@@ -117,10 +131,10 @@ __global__ __launch_bounds__(256) void lsd_gradient_kernel(LsdDev d) {
     }
     kw = max(kw, kdef);
     if (in_row) {
-        d.ang[q] = ang;
-        d.csn[q] = cs;
+        lsd_f4 rec;
+        rec.x = ang; rec.y = cs.x; rec.z = cs.y; rec.w = 0.f;  // (used = 0)
+        *reinterpret_cast<lsd_f4*>(d.px + q) = rec;
         d.mod[q] = norm;
-        d.used[q] = 0;
     }
     }
     // the image's largest squared gradient: one atomic per wave, and only when it can raise the value
@@ -139,7 +153,7 @@ __global__ __launch_bounds__(256) void lsd_keys_kernel(LsdDev d) {
     for (int y = blockIdx.y * LSD_ROWS; y < min((int)(blockIdx.y + 1) * LSD_ROWS, d.h); ++y) {
         const uint32_t idx = (uint32_t)(y * d.w + x);
         uint32_t key = LSD_NOKEY;
-        if (d.ang[base + idx] >= 0.f) {  // undefined pixels never seed a region: they sort to the end
+        if (d.px[base + idx].ang >= 0.f) {  // undefined pixels never seed a region: they sort to the end
             int bin = (int)(d.mod[base + idx] * bin_coef);
             bin = bin < 0 ? 0 : (bin >= d.n_bins ? d.n_bins - 1 : bin);
             key = ((uint32_t)(d.n_bins - 1 - bin) << LSD_IDX_BITS) | idx;
@@ -182,10 +196,8 @@ __global__ __launch_bounds__(64) void lsd_grow_kernel(LsdDev d) {
     const int b = blockIdx.x, lane = threadIdx.x;
     const int w = d.w, h = d.h, npx = w * h;
     const size_t base = (size_t)b * npx;
-    const float* __restrict__ ang = d.ang + base;
-    const float2* __restrict__ csn = d.csn + base;
+    LsdPx* px = d.px + base;
     const double* __restrict__ mod = d.mod + base;
-    int32_t* used = d.used + base;
     const uint32_t* __restrict__ order = d.order + base;
     int32_t* reg = d.reg + base;
     const double prec = d.prec;
@@ -201,8 +213,9 @@ __global__ __launch_bounds__(64) void lsd_grow_kernel(LsdDev d) {
         if ((uint32_t)__builtin_amdgcn_readfirstlane((int)key) == LSD_NOKEY) break;  // sorted: only undefined pixels from here on
         const int q_l = (int)(key & ((1u << LSD_IDX_BITS) - 1u));
         const bool key_ok = key != LSD_NOKEY;
-        const float ang_l = key_ok ? ang[q_l] : -1.f;  // the seeds' angles, fetched with the batch
-        unsigned long long todo = __ballot(key_ok && ld_coherent(used + (key_ok ? q_l : 0)) == 0);
+        const LsdPx seed_l = px_ld(px + (key_ok ? q_l : 0));  // the seeds' angles, fetched with the batch
+        const float ang_l = key_ok ? seed_l.ang : -1.f;
+        unsigned long long todo = __ballot(key_ok && seed_l.used == 0);
         // seeds of this batch that a region grown from an earlier seed of the batch takes are struck off as they are taken (one
         // compare + ballot per pixel added) — re-reading the flags after every region cost a memory round trip per region
         while (todo) {
@@ -219,7 +232,7 @@ __global__ __launch_bounds__(64) void lsd_grow_kernel(LsdDev d) {
             float sumdx = (float)cs0, sumdy = (float)sn0;
             int n_reg = 1;
             if (lane == 0) {
-                st_coherent(used + seed, 1);
+                st_coherent(&px[seed].used, 1);
                 st_coherent(reg, sx0 | (sy0 << 16));
                 s_ring[0] = sx0 | (sy0 << 16);
             }
@@ -259,9 +272,10 @@ __global__ __launch_bounds__(64) void lsd_grow_kernel(LsdDev d) {
                         val[r] = val[r] && xx >= 0 && xx < w && yy >= 0 && yy < h;
                         qq[r] = val[r] ? yy * w + xx : 0;
                         xy[r] = xx | (yy << 16);
-                        u[r] = ld_coherent(used + qq[r]);
-                        a[r] = ang[qq[r]];
-                        cs[r] = csn[qq[r]];
+                        const LsdPx t = px_ld(px + qq[r]);
+                        u[r] = t.used;
+                        a[r] = t.ang;
+                        cs[r] = make_float2(t.c, t.s);
                     }
 #pragma unroll
                     for (int r = 0; r < LSD_GR; ++r) {
@@ -283,9 +297,10 @@ __global__ __launch_bounds__(64) void lsd_grow_kernel(LsdDev d) {
                     float a = -1.f;
                     cs[r] = make_float2(0.f, 0.f);
                     if (valid) {
-                        u = ld_coherent(used + qq[r]);
-                        a = ang[qq[r]];
-                        cs[r] = csn[qq[r]];
+                        const LsdPx t = px_ld(px + qq[r]);
+                        u = t.used;
+                        a = t.ang;
+                        cs[r] = make_float2(t.c, t.s);
                     }
                     cand[r] = valid && u == 0 && a >= 0.f;
                     ad[r] = (double)a * LSD_DEG2RAD;
@@ -315,7 +330,7 @@ __global__ __launch_bounds__(64) void lsd_grow_kernel(LsdDev d) {
                         const int qL = __builtin_amdgcn_readlane(qq[r], L), xyL = __builtin_amdgcn_readlane(xy[r], L);
                         const float cL = readlane_f32(cs[r].x, L), sL = readlane_f32(cs[r].y, L);
                         if (lane == 0) {
-                            st_coherent(used + qL, 1);
+                            st_coherent(&px[qL].used, 1);
                             st_coherent(reg + n_reg, xyL);
                             s_ring[n_reg & (LSD_RING - 1)] = xyL;
                         }
@@ -403,7 +418,7 @@ __global__ __launch_bounds__(64) void lsd_grow_kernel(LsdDev d) {
                     // acc is the sequential result: every accepted lane stores its own pixel, in lane order
                     if ((acc >> lane) & 1ull) {
                         const int idx = n_reg + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(acc >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)acc, 0u));
-                        st_coherent(used + qq[r], 1);
+                        st_coherent(&px[qq[r]].used, 1);
                         st_coherent(reg + idx, xy[r]);
                         s_ring[idx & (LSD_RING - 1)] = xy[r];
                     }
@@ -599,7 +614,7 @@ __device__ __forceinline__ void lds_st(int* p, int v) { __hip_atomic_store(p, v,
 __device__ __forceinline__ unsigned bit_ld(const unsigned* bits, int q) { return (__hip_atomic_load(bits + (q >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> (q & 31)) & 1u; }
 __device__ __forceinline__ void bit_set(unsigned* bits, int q) { (void)__hip_atomic_fetch_or(bits + (q >> 5), 1u << (q & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 template <bool MARK, bool FAR = false, bool BITS = false>
-__device__ __forceinline__ int grow_region_w(const float* __restrict__ ang, const float2* __restrict__ csn, int32_t* used, int32_t* stamp, int id,
+__device__ __forceinline__ int grow_region_w(LsdPx* px, int32_t* stamp, int id,
                                              int32_t* list, int cap, int* ring, int seed, float seed_ang, int w, int h, double prec,
                                              double& angle_out, unsigned* bits = nullptr) {
     const int lane = threadIdx.x & 63;
@@ -610,7 +625,7 @@ __device__ __forceinline__ int grow_region_w(const float* __restrict__ ang, cons
     float sumdx = (float)cs0, sumdy = (float)sn0;
     int n_reg = 1;
     if (lane == 0) {
-        if (MARK) st_coherent(used + seed, 1);
+        if (MARK) st_coherent(&px[seed].used, 1);
         else st_coherent(stamp + seed, id);
         if (BITS) bit_set(bits, seed);
         st_coherent(list, sx0 | (sy0 << 16));
@@ -639,10 +654,29 @@ __device__ __forceinline__ int grow_region_w(const float* __restrict__ ang, cons
             val[r] = val[r] && xx >= 0 && xx < w && yy >= 0 && yy < h;
             qq[r] = val[r] ? yy * w + xx : 0;
             xy[r] = xx | (yy << 16);
-            u[r] = BITS ? (int)bit_ld(bits, qq[r]) : (FAR ? ld_l2(used + qq[r]) : ld_coherent(used + qq[r]));
             own[r] = MARK ? 0 : ld_coherent(stamp + qq[r]);
-            a[r] = ang[qq[r]];
-            cs[r] = csn[qq[r]];
+        }
+        {   // the records: one 16-byte gather per sub-group.  FAR: the flag in it is stored by ANOTHER CU — the load bypasses the vector L1
+            LsdPx t[LSD_GR];
+            if constexpr (FAR) {
+                static_assert(LSD_GR == 2, "two loads in one statement");
+                lsd_f4 v0, v1;
+                asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                             : "=&v"(v0), "=&v"(v1)
+                             : "v"(px + qq[0]), "v"(px + qq[1])
+                             : "memory");
+                t[0].ang = v0.x; t[0].c = v0.y; t[0].s = v0.z; t[0].used = __float_as_int(v0.w);
+                t[1].ang = v1.x; t[1].c = v1.y; t[1].s = v1.z; t[1].used = __float_as_int(v1.w);
+            } else {
+#pragma unroll
+                for (int r = 0; r < LSD_GR; ++r) t[r] = px_ld(px + qq[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < LSD_GR; ++r) {
+                u[r] = BITS ? (int)bit_ld(bits, qq[r]) : t[r].used;
+                a[r] = t[r].ang;
+                cs[r] = make_float2(t[r].c, t[r].s);
+            }
         }
         unsigned long long cand_m[LSD_GR];
 #pragma unroll
@@ -708,7 +742,7 @@ __device__ __forceinline__ int grow_region_w(const float* __restrict__ ang, cons
             }
             if ((acc >> lane) & 1ull) {
                 const int idx = n_reg + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(acc >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)acc, 0u));
-                if (MARK) st_coherent(used + qq[r], 1);
+                if (MARK) st_coherent(&px[qq[r]].used, 1);
                 else st_coherent(stamp + qq[r], id);
                 if (BITS) bit_set(bits, qq[r]);
                 st_coherent(list + idx, xy[r]);
@@ -867,10 +901,8 @@ __global__ __launch_bounds__(LSD_XW * 64) void lsd_grow_xcd_kernel(LsdDev d, Lsd
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
     const int w = d.w, h = d.h, npx = w * h;
     const size_t base = (size_t)b * npx;
-    const float* __restrict__ ang = d.ang + base;
-    const float2* __restrict__ csn = d.csn + base;
+    LsdPx* px = d.px + base;
     const double* __restrict__ mod = d.mod + base;
-    int32_t* used = d.used + base;
     const uint32_t* __restrict__ order = d.order + base;
     long long* pend = x.pend + base;
     int32_t* ctl = x.ctl + (size_t)b * LSD_CTL;
@@ -998,12 +1030,12 @@ __global__ __launch_bounds__(LSD_XW * 64) void lsd_grow_xcd_kernel(LsdDev d, Lsd
                     if (!__ballot(bad)) {  // every pixel still free: this IS the region of the sequential search
                         if (has) {
                             bit_set(s_bits, v0);
-                            st_coherent(used + v0, 1);
+                            st_coherent(&px[v0].used, 1);
                         }
                         for (int t = 64 + lane; t < n + 4; t += 64) {
                             const int q = s_px[pos + t];
                             bit_set(s_bits, q);
-                            st_coherent(used + q, 1);
+                            st_coherent(&px[q].used, 1);
                         }
                         took = true;
                         if (n >= d.min_reg_size) {
@@ -1042,13 +1074,13 @@ __global__ __launch_bounds__(LSD_XW * 64) void lsd_grow_xcd_kernel(LsdDev d, Lsd
                             if (!__ballot(bad)) {
                                 if (has) {
                                     bit_set(s_bits, q0);
-                                    st_coherent(used + q0, 1);
+                                    st_coherent(&px[q0].used, 1);
                                 }
                                 for (int t = 64 + lane; t < n + 4; t += 64) {
                                     const int pxy = ld_l2(pl + t);
                                     const int q = (pxy >> 16) * w + (pxy & 0xFFFF);
                                     bit_set(s_bits, q);
-                                    st_coherent(used + q, 1);
+                                    st_coherent(&px[q].used, 1);
                                 }
                                 took = true;
                                 if (n >= d.min_reg_size) {
@@ -1066,7 +1098,7 @@ __global__ __launch_bounds__(LSD_XW * 64) void lsd_grow_xcd_kernel(LsdDev d, Lsd
                 else ++n_self;
                 if (!took) {
                     double reg_angle;
-                    const int n = grow_region_w<true, false, true>(ang, csn, used, nullptr, 0, wlist, npx, s_ring[0], seed, ang[seed], w, h, d.prec,
+                    const int n = grow_region_w<true, false, true>(px, nullptr, 0, wlist, npx, s_ring[0], seed, px[seed].ang, w, h, d.prec,
                                                                    reg_angle, s_bits);
                     if (n >= d.min_reg_size) {
                         const float4 sg = region_segment_w(d, wlist, n, mod, reg_angle, s_term[0]);
@@ -1264,7 +1296,7 @@ __global__ __launch_bounds__(LSD_XW * 64) void lsd_grow_xcd_kernel(LsdDev d, Lsd
             if (npx - off >= 4096) {  // (out of room: empty records from here on — the committer grows those seeds itself)
                 ++id;
                 double reg_angle = 0.0;
-                n = grow_region_w<false, true>(ang, csn, used, stamp, id, wl + off + 4, npx - off - 4, s_ring[wv], pick_q, ang[pick_q], w, h, d.prec, reg_angle);
+                n = grow_region_w<false, true>(px, stamp, id, wl + off + 4, npx - off - 4, s_ring[wv], pick_q, px[pick_q].ang, w, h, d.prec, reg_angle);
                 if (n >= d.min_reg_size) {
                     const float4 sg = region_segment_w(d, wl + off + 4, n, mod, reg_angle, s_term[wv]);
                     if (lane == 0) {
@@ -1520,8 +1552,8 @@ int stvo_lsd_create(stvo_ctx* ctx, int B, int cols, int rows, int max_keylines, 
             return o;
         }
     } c;
-    const size_t o_blur = c.take(nb * cols * rows), o_scaled = c.take(nb * npx), o_img = c.take(nb * cols * rows), o_ang = c.take(nb * npx * 4),
-                 o_csn = c.take(nb * npx * 8), o_mod = c.take(nb * npx * 8), o_used = c.take(nb * npx * 4), o_keys = c.take(nb * npx * 4),
+    const size_t o_blur = c.take(nb * cols * rows), o_scaled = c.take(nb * npx), o_img = c.take(nb * cols * rows), o_px = c.take(nb * npx * sizeof(stvo::LsdPx)),
+                 o_mod = c.take(nb * npx * 8), o_keys = c.take(nb * npx * 4),
                  o_order = c.take(nb * npx * 4), o_reg = c.take(nb * npx * 4), o_kmax = c.take(nb * 4), o_seg = c.take(nb * d.seg_cap * 16),
                  o_nseg = c.take(nb * 4), o_off = c.take((nb + 1) * 4), o_lines = c.take(nb * d.K * sizeof(stvo_keyline)),
                  o_resp = c.take(nb * d.K * 4), o_nl = c.take(nb * 4), o_np = c.take(nb * 4);
@@ -1529,7 +1561,7 @@ int stvo_lsd_create(stvo_ctx* ctx, int B, int cols, int rows, int max_keylines, 
     if (ok) {
         char* D = o->dev;
         o->blur = (uint8_t*)(D + o_blur); o->scaled = (uint8_t*)(D + o_scaled); o->img = (uint8_t*)(D + o_img);
-        d.ang = (float*)(D + o_ang); d.csn = (float2*)(D + o_csn); d.mod = (double*)(D + o_mod); d.used = (int32_t*)(D + o_used);
+        d.px = (stvo::LsdPx*)(D + o_px); d.mod = (double*)(D + o_mod);
         d.keys = (uint32_t*)(D + o_keys); d.order = (uint32_t*)(D + o_order); d.reg = (int32_t*)(D + o_reg); d.kmax = (int32_t*)(D + o_kmax);
         d.seg = (float4*)(D + o_seg); d.n_seg = (int32_t*)(D + o_nseg); d.n_pass = (int32_t*)(D + o_np);
         o->seg_off = (int32_t*)(D + o_off);
