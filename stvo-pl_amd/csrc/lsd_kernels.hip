@@ -599,7 +599,8 @@ __device__ __forceinline__ long long readfirstlane64(long long v) {
     const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)v >> 32));
     return (long long)(((unsigned long long)hi << 32) | lo);
 }
-constexpr int LSD_WAVES_MAX_B = 8;   // one XCD per image (and ~270 B of scratch per pixel and speculating workgroup): small batches only
+constexpr int LSD_WAVES_MAX_B = 128; // up to 16 images per XCD, each with a committer's workgroup + at least one speculating workgroup (~40 B of scratch per pixel
+                                     // and speculating workgroup); beyond that one wave per image and the batch as the parallelism
 
 // loads that bypass the vector L1 (sc1: served by the XCD's L2) — data another CU of the same XCD stores during the launch
 __device__ __forceinline__ int ld_l2(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -895,7 +896,9 @@ __global__ __launch_bounds__(LSD_XW * 64) void lsd_grow_xcd_kernel(LsdDev d, Lsd
     __shared__ int s_ring[LSD_XW][LSD_WRING];
     __shared__ double s_term[LSD_XW][3][64];
     __shared__ int s_scan, s_done, s_qhead, s_qtail, s_cwords;
-    const int b = blockIdx.x & 7, role = blockIdx.x >> 3, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // image b = XCD (b mod 8), place (b div 8) there; its 1 + nsb workgroups are neighbours in the XCD's share of the grid
+    const int slot = blockIdx.x >> 3, role = slot % (1 + x.nsb), b = (blockIdx.x & 7) + 8 * (slot / (1 + x.nsb));
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (b >= d.B) return;
     int xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
@@ -1461,7 +1464,7 @@ int lsd_enqueue(stvo_lsd* o, const uint8_t* images, stvo_keyline* lines, float* 
     // the radix sort is stable and the keys come in index order: sorting by the bin bits alone leaves every bin in row-major order
     // (STVO_LSD_SORT_FULL=1: all 32 bits, the index bits included — the same order, more digit passes)
     const int begin_bit = stvo::dbg().lsd_sort_full == 1 ? 0 : stvo::LSD_IDX_BITS;
-    if (o->wdev) {  // small batches: the device-wide sort per image (the segmented sort gives a segment ONE workgroup: 3.5 ms for a KITTI-size
+    if (o->wdev && d.B <= 8) {  // the smallest batches: the device-wide sort per image (the segmented sort gives a segment ONE workgroup: 3.5 ms for a KITTI-size
                     // image) — over ALL key bits: the keys are distinct, so the order does not lean on the stability of the sort (over the
                     // bin bits alone this sort returned another order than the segmented one, round 5)
         const int npx = d.w * d.h;
@@ -1479,7 +1482,7 @@ int lsd_enqueue(stvo_lsd* o, const uint8_t* images, stvo_keyline* lines, float* 
     if (o->wdev) {  // small batches: a committing wave + speculating workgroups on the CUs of one XCD per image (lsd_grow_xcd_kernel)
         HIP_TRY(ctx, hipMemsetAsync(o->xx.stamp, 0, o->stamp_bytes, s));
         HIP_TRY(ctx, hipMemsetAsync(o->xx.pend, 0, o->pend_bytes + (size_t)d.B * stvo::LSD_CTL * 4, s));  // (the control words lie behind the table)
-        hipLaunchKernelGGL(stvo::lsd_grow_xcd_kernel, dim3(8 * (1 + o->xx.nsb)), dim3(stvo::LSD_XW * 64), o->xcd_lds, s, d, o->xx);
+        hipLaunchKernelGGL(stvo::lsd_grow_xcd_kernel, dim3(8 * ((d.B + 7) / 8) * (1 + o->xx.nsb)), dim3(stvo::LSD_XW * 64), o->xcd_lds, s, d, o->xx);
     } else if (stvo::dbg().lsd_grow == 0) {
         hipLaunchKernelGGL(stvo::lsd_grow_kernel<false>, dim3(d.B), dim3(64), 0, s, d);
     } else {
@@ -1583,7 +1586,9 @@ int stvo_lsd_create(stvo_ctx* ctx, int B, int cols, int rows, int max_keylines, 
     if (ok && (size_t)d.seg_cap * 8 > 48 * 1024)
         ok = stvo::lds_opt_in(reinterpret_cast<const void*>(stvo::lsd_keylines_kernel), d.seg_cap * 8);
     if (ok && stvo::dbg().lsd_waves != 0 && B <= stvo::LSD_WAVES_MAX_B && npx <= stvo::LSD_XCD_MAX_PX) {  // small batches (STVO_LSD_WAVES=0: one wave per image there too)
-        int nsb = stvo::dbg().lsd_xcd_blocks == stvo::DBG_UNSET ? 8 : stvo::dbg().lsd_xcd_blocks;  // STVO_LSD_XCD_BLOCKS: speculating workgroups per image
+        // an XCD has 32 CUs and a CU holds one of the kernel's workgroups: images per XCD x (1 + speculating workgroups) <= 32
+        const int per_xcd = (B + 7) / 8;
+        int nsb = stvo::dbg().lsd_xcd_blocks == stvo::DBG_UNSET ? (32 / per_xcd - 1 < 8 ? 32 / per_xcd - 1 : 8) : stvo::dbg().lsd_xcd_blocks;  // STVO_LSD_XCD_BLOCKS
         nsb = nsb < 0 ? 0 : (nsb > (stvo::LSD_X_MAXW - 1) / stvo::LSD_XW ? (stvo::LSD_X_MAXW - 1) / stvo::LSD_XW : nsb);
         const size_t nw = 1 + (size_t)nsb * stvo::LSD_XW;
         decltype(c) cw;

@@ -100,6 +100,25 @@ def test_lsd_many_waves_and_one_wave_per_image_are_the_same(hip, oracle, switche
             lsd.close()
 
 
+def test_lsd_mid_batch_several_images_per_xcd(hip, oracle):
+    """Batches of 9 .. 128 images: several images per XCD, each with its committer's workgroup and as many speculating workgroups as
+    the XCD's 32 CUs allow (the pseudo-ordering then comes from the segmented sort of the large batches): every image against the oracle."""
+    from stvo_amd import capi
+    cols, rows, B = 640, 360, 20
+    rng = np.random.default_rng(53)
+    imgs = np.stack([synth.make_image(640 + b, cols, rows) if b % 5 else rng.integers(0, 255, (rows, cols), dtype=np.uint8) for b in range(B)])
+    lsd = capi.Lsd(hip, B, cols, rows, capi.lsd_params(min_length=4.0, nfeatures=0, scale=0.8), max_keylines=2048)
+    try:
+        for _ in range(2):
+            segs, n = lsd.segments(imgs)
+            for b in range(B):
+                ref = oracle.lsd_segments(imgs[b], oracle.lsd_opts(scale=0.8))
+                assert n[b] == len(ref), b
+                assert np.array_equal(segs[b], ref), b
+    finally:
+        lsd.close()
+
+
 @pytest.mark.parametrize("knobs", [{"STVO_LSD_XCD_BLOCKS": "0"}, {"STVO_LSD_XCD_BLOCKS": "1", "STVO_LSD_FEED_AHEAD": "0"},
                                    {"STVO_LSD_XCD_BLOCKS": "31", "STVO_LSD_SEP": "4", "STVO_LSD_AHEAD": "1000000", "STVO_LSD_FEED_AHEAD": "100000"}])
 def test_lsd_xcd_kernel_under_hostile_settings(hip, oracle, switches, knobs):
