@@ -34,7 +34,6 @@ struct DebugSwitches {
     int lsd_feed_ahead;  // STVO_LSD_FEED_AHEAD  ranks the feeder wave of lsd_grow_xcd_kernel runs ahead of the committer at most
     int lsd_sep;         // STVO_LSD_SEP         least distance (pixels, Chebyshev) of a new seed from every seed in flight
     int lsd_ahead;       // STVO_LSD_AHEAD       ranks the dispatcher's front runs ahead of the committer at most
-    int lsd_sort_full;   // STVO_LSD_SORT_FULL   1: the pseudo-ordering sorts all 32 key bits instead of the bin bits only (lsd_kernels.hip)
     int cells_ahead;     // STVO_CELLS_AHEAD     0: point_cells_kernel of a batch in the point stream (unset: on the line stream, ahead of the point stream's step)
     int seq_pipe;        // STVO_SEQ_PIPE        1: pipelined steps (optimizePose(k) on the aux stream beside the stereo association of step k + 1; built and measured in round 6, no gain), 2: the same without the gate kernel
     int lines_ahead;     // STVO_LINES_AHEAD     0: the key-line stream waits for its own step's fork event (until round 5); unset: for batches it runs one step ahead, behind the dispatch of the previous pose kernel

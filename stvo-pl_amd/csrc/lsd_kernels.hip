@@ -7,9 +7,8 @@
 //   blur + resize        the scaled image (cv::GaussianBlur 7 x 7 + cv::resize on 8-bit data): orb_kernels.hip's kernels
 //   lsd_gradient_kernel  ll_angle: 2 x 2 gradient, norm, level-line angle (fastAtan2, degrees), the float cos / sin a pixel
 //                        contributes to a region angle, the largest squared gradient of the image (integer atomic max)
-//   lsd_keys_kernel      pseudo-ordering as a sort key: (highest bin first) << 20 | pixel index; undefined pixels last
-//   hipcub segmented radix sort (rocPRIM): keys per image — the index in the key makes the order total, so the sort is
-//                        deterministic and pixels of a bin keep row-major order (oracle note (1))
+//   lsd_hist / lsd_scan / lsd_scatter_kernel   the pseudo-ordering: the defined pixels by bin of the gradient norm, highest bin first,
+//                        row-major inside a bin (oracle note (1)) — a stable counting sort written here (until round 5: rocPRIM's radix sort)
 //   lsd_grow_kernel      the search: region_grow + region2rect for every unused seed in that order.  Inherently sequential
 //                        per image — whether a pixel joins depends on the running region angle, which changes with every pixel
 //                        added, and on what all earlier regions took — so ONE wavefront walks an image and the batch supplies
@@ -20,8 +19,6 @@
 //   lsd_keylines_kernel  the wrapper: checkLineExtremes, length, min_length, KeyLine fields, top-N by response (stable)
 // Byte / integer work except where the source computes in floating point; no fused multiply-adds outside the two of the sine /
 // cosine reduction, which the oracle has too.
-#include <hipcub/hipcub.hpp>
-
 #include <cmath>
 #include <new>
 #include <vector>
@@ -85,9 +82,9 @@ struct LsdDev {
     double rho, prec, scale, min_length;
     const uint8_t* scaled;     // [B][h][w]
     LsdPx* px;                 // [B][w h] what the search reads of a pixel, ONE 16-byte record (one gather per neighbour instead of three)
-    double* mod;               // [B][w h] gradient norm
-    uint32_t* keys;            // [B][w h]
-    uint32_t* order;           // [B][w h] sorted keys
+    int32_t* k32;              // [B][w h] gx^2 + gy^2 of the defined pixels (the gradient norm is sqrt(k / 4): recomputed where it is used), -1: undefined
+    uint32_t* cnt;             // [B][units][n_bins] the pseudo-ordering's counters: pixels per bin and unit, then the first rank of every bin in every unit
+    uint32_t* order;           // [B][w h] (highest bin first) << 20 | pixel index of the defined pixels in the pseudo-ordering, LSD_NOKEY behind them
     int32_t* reg;              // [B][w h] the region being grown: x | y << 16
     int32_t* kmax;             // [B] largest gx^2 + gy^2 among the defined pixels, -1: none
     float4* seg;               // [B][seg_cap] (x1, y1, x2, y2) in detection order
@@ -134,7 +131,7 @@ __global__ __launch_bounds__(256) void lsd_gradient_kernel(LsdDev d) {
         lsd_f4 rec;
         rec.x = ang; rec.y = cs.x; rec.z = cs.y; rec.w = 0.f;  // (used = 0)
         *reinterpret_cast<lsd_f4*>(d.px + q) = rec;
-        d.mod[q] = norm;
+        d.k32[q] = kdef;
     }
     }
     // the image's largest squared gradient: one atomic per wave, and only when it can raise the value
@@ -143,22 +140,122 @@ __global__ __launch_bounds__(256) void lsd_gradient_kernel(LsdDev d) {
     if ((threadIdx.x & 63) == 0 && kw >= 0 && kw > __hip_atomic_load(&d.kmax[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&d.kmax[b], kw);
 }
 
-__global__ __launch_bounds__(256) void lsd_keys_kernel(LsdDev d) {
-    const int x = blockIdx.x * 256 + threadIdx.x, b = blockIdx.z;
-    if (x >= d.w) return;
-    const size_t base = (size_t)b * d.w * d.h;
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The pseudo-ordering — pixels by bin of their gradient norm, highest bin first, row-major inside a bin, undefined pixels not at all
+// (src of the semantics: oracle/stvo_lsd_oracle.c note (1)) — as a stable counting sort of our own (round 6; until then a key array +
+// rocPRIM's segmented radix sort: 36 of the 188 ms of 4096 images).  A wave owns a UNIT of 64 rows of 64 consecutive pixels:
+//   lsd_hist_kernel     the pixels of every bin in the unit (LDS counters, wave-private);
+//   lsd_scan_kernel     per image: first rank of every (bin, unit) = pixels of higher bins + pixels of the bin in earlier units; LSD_NOKEY
+//                       behind the last defined pixel (the searches stop at the first batch that begins with it);
+//   lsd_scatter_kernel  the unit again, row by row: a pixel's rank = the bin's running position + the lower lanes of its row with the same
+//                       bin (the lanes with equal bins matched bit by bit with ballots) — stable by construction, no atomics on the way.
+// The bin is (int)(norm (n_bins - 1) / max norm), norm = sqrt(k / 4) in double precision from the integer k both times.
+constexpr int LSD_UNIT_ROWS = 64;
+constexpr int LSD_UNIT = 64 * LSD_UNIT_ROWS;
+constexpr int LSD_MAX_BINS = 2048;
+__device__ __forceinline__ double lsd_bin_coef(const LsdDev& d, int b) {
     const int km = d.kmax[b];
     const double max_grad = km >= 0 ? sqrt((double)km / 4.0) : -1.0;
-    const double bin_coef = max_grad > 0 ? (double)(d.n_bins - 1) / max_grad : 0.0;
-    for (int y = blockIdx.y * LSD_ROWS; y < min((int)(blockIdx.y + 1) * LSD_ROWS, d.h); ++y) {
-        const uint32_t idx = (uint32_t)(y * d.w + x);
-        uint32_t key = LSD_NOKEY;
-        if (d.px[base + idx].ang >= 0.f) {  // undefined pixels never seed a region: they sort to the end
-            int bin = (int)(d.mod[base + idx] * bin_coef);
-            bin = bin < 0 ? 0 : (bin >= d.n_bins ? d.n_bins - 1 : bin);
-            key = ((uint32_t)(d.n_bins - 1 - bin) << LSD_IDX_BITS) | idx;
+    return max_grad > 0 ? (double)(d.n_bins - 1) / max_grad : 0.0;
+}
+__device__ __forceinline__ int lsd_keybin(int k, double bin_coef, int n_bins) {
+    int bin = (int)(sqrt((double)k / 4.0) * bin_coef);
+    bin = bin < 0 ? 0 : (bin >= n_bins ? n_bins - 1 : bin);
+    return n_bins - 1 - bin;
+}
+
+__global__ __launch_bounds__(256) void lsd_hist_kernel(LsdDev d) {
+    extern __shared__ unsigned s_h[];  // [4][n_bins]
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, b = blockIdx.y;
+    const int npx = d.w * d.h, nunits = (npx + LSD_UNIT - 1) / LSD_UNIT, unit = blockIdx.x * 4 + wv;
+    if (unit >= nunits) return;
+    unsigned* h = s_h + wv * d.n_bins;
+    for (int t = lane; t < d.n_bins; t += 64) h[t] = 0u;
+    const double bin_coef = lsd_bin_coef(d, b);
+    const int32_t* k32 = d.k32 + (size_t)b * npx;
+#pragma unroll 8
+    for (int r = 0; r < LSD_UNIT_ROWS; ++r) {
+        const int i = unit * LSD_UNIT + r * 64 + lane;
+        const int k = i < npx ? k32[i] : -1;
+        if (k >= 0) atomicAdd(&h[lsd_keybin(k, bin_coef, d.n_bins)], 1u);
+    }
+    unsigned* out = d.cnt + ((size_t)b * nunits + unit) * d.n_bins;
+    for (int t = lane; t < d.n_bins; t += 64) out[t] = h[t];
+}
+
+__global__ __launch_bounds__(1024) void lsd_scan_kernel(LsdDev d) {
+    __shared__ unsigned s_w[16];
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int npx = d.w * d.h, nunits = (npx + LSD_UNIT - 1) / LSD_UNIT, nb = d.n_bins;
+    unsigned* cnt = d.cnt + (size_t)b * nunits * nb;
+    unsigned carry = 0u;  // pixels of all the bins in front
+    for (int t0 = 0; t0 < nb; t0 += 1024) {  // (n_bins <= 2048: one or two turns)
+        const int bin = t0 + t;
+        unsigned tot = 0u;
+        if (bin < nb)
+            for (int u = 0; u < nunits; ++u) tot += cnt[(size_t)u * nb + bin];
+        // exclusive scan over the 1024 threads
+        unsigned inc = tot;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned v = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += v;
         }
-        d.keys[base + idx] = key;
+        __syncthreads();  // (s_w of the previous turn has been read)
+        if (lane == 63) s_w[wv] = inc;
+        __syncthreads();
+        unsigned before = 0u, all = 0u;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const unsigned x = s_w[v];
+            before += v < wv ? x : 0u;
+            all += x;
+        }
+        unsigned run = carry + before + inc - tot;
+        if (bin < nb)
+            for (int u = 0; u < nunits; ++u) {
+                const unsigned c = cnt[(size_t)u * nb + bin];
+                cnt[(size_t)u * nb + bin] = run;
+                run += c;
+            }
+        carry += all;
+    }
+    // the end mark: every reader walks the ranks in batches of 64 and stops at the first batch whose first rank holds LSD_NOKEY
+    if (t < 128 && carry + (unsigned)t < (unsigned)npx) d.order[(size_t)b * npx + carry + t] = LSD_NOKEY;
+}
+
+__global__ __launch_bounds__(256) void lsd_scatter_kernel(LsdDev d) {
+    extern __shared__ unsigned s_h[];  // [4][n_bins] the next rank of every bin, for this wave's unit
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, b = blockIdx.y;
+    const int npx = d.w * d.h, nunits = (npx + LSD_UNIT - 1) / LSD_UNIT, unit = blockIdx.x * 4 + wv;
+    if (unit >= nunits) return;
+    unsigned* h = s_h + wv * d.n_bins;
+    const unsigned* first = d.cnt + ((size_t)b * nunits + unit) * d.n_bins;
+    for (int t = lane; t < d.n_bins; t += 64) h[t] = first[t];
+    const double bin_coef = lsd_bin_coef(d, b);
+    const int32_t* k32 = d.k32 + (size_t)b * npx;
+    uint32_t* order = d.order + (size_t)b * npx;
+    const unsigned long long lt = lane == 0 ? 0ull : ~0ull >> (64 - lane);
+#pragma unroll 4
+    for (int r = 0; r < LSD_UNIT_ROWS; ++r) {
+        const int i = unit * LSD_UNIT + r * 64 + lane;
+        const int k = i < npx ? k32[i] : -1;
+        const bool valid = k >= 0;
+        const int kb = valid ? lsd_keybin(k, bin_coef, d.n_bins) : 0;
+        unsigned long long m = __ballot(valid);  // ... the lanes of the row with this lane's bin
+        if (!m) continue;  // uniform
+#pragma unroll
+        for (int bit = 0; bit < 11; ++bit) {
+            const bool one = (kb >> bit) & 1;
+            const unsigned long long bb = __ballot(one);
+            m &= one ? bb : ~bb;
+        }
+        if (valid) {
+            const int rank = __builtin_popcountll(m & lt);
+            const unsigned pos = h[kb] + (unsigned)rank;
+            order[pos] = ((uint32_t)kb << LSD_IDX_BITS) | (uint32_t)i;
+            if (rank == 0) h[kb] = pos + (unsigned)__builtin_popcountll(m);  // (the lowest lane of every bin; the read above comes first: one wave, LDS in order)
+        }
     }
 }
 
@@ -197,7 +294,7 @@ __global__ __launch_bounds__(64) void lsd_grow_kernel(LsdDev d) {
     const int w = d.w, h = d.h, npx = w * h;
     const size_t base = (size_t)b * npx;
     LsdPx* px = d.px + base;
-    const double* __restrict__ mod = d.mod + base;
+    const int32_t* __restrict__ k32 = d.k32 + base;
     const uint32_t* __restrict__ order = d.order + base;
     int32_t* reg = d.reg + base;
     const double prec = d.prec;
@@ -470,7 +567,7 @@ __global__ __launch_bounds__(64) void lsd_grow_kernel(LsdDev d) {
                 double wgt = 0.0;
                 if (t < n_reg) {
                     pxy = ld_coherent(reg + t);
-                    wgt = mod[(pxy >> 16) * w + (pxy & 0xFFFF)];
+                    wgt = sqrt((double)k32[(pxy >> 16) * w + (pxy & 0xFFFF)] / 4.0);  // the gradient norm (ll_angle's expression)
                 }
                 const double px = (double)(pxy & 0xFFFF) * wgt, py = (double)(pxy >> 16) * wgt;
                 if constexpr (FAST) {
@@ -496,7 +593,7 @@ __global__ __launch_bounds__(64) void lsd_grow_kernel(LsdDev d) {
                 double t_xx = 0.0, t_yy = 0.0, t_xy = 0.0;
                 if (t < n_reg) {
                     const int pxy = ld_coherent(reg + t);
-                    const double wgt = mod[(pxy >> 16) * w + (pxy & 0xFFFF)];
+                    const double wgt = sqrt((double)k32[(pxy >> 16) * w + (pxy & 0xFFFF)] / 4.0);  // the gradient norm (ll_angle's expression)
                     const double ddx = (double)(pxy & 0xFFFF) - cx, ddy = (double)(pxy >> 16) - cy;
                     t_xx = ddy * ddy * wgt;
                     t_yy = ddx * ddx * wgt;
@@ -767,7 +864,7 @@ __device__ __forceinline__ int grow_region_w(LsdPx* px, int32_t* stamp, int id,
 }
 
 // region2rect + the segment of a region of n >= min_reg_size pixels (the fast form of lsd_grow_kernel); term: [3][64] doubles of LDS
-__device__ __forceinline__ float4 region_segment_w(const LsdDev& d, const int32_t* list, int n_reg, const double* __restrict__ mod, double reg_angle,
+__device__ __forceinline__ float4 region_segment_w(const LsdDev& d, const int32_t* list, int n_reg, const int32_t* __restrict__ k32, double reg_angle,
                                                    double (*term)[64]) {
     const int lane = threadIdx.x & 63, w = d.w;
     wave_publish();
@@ -794,7 +891,7 @@ __device__ __forceinline__ float4 region_segment_w(const LsdDev& d, const int32_
         double wgt = 0.0;
         if (t < n_reg) {
             pxy = ld_coherent(list + t);
-            wgt = mod[(pxy >> 16) * w + (pxy & 0xFFFF)];
+            wgt = sqrt((double)k32[(pxy >> 16) * w + (pxy & 0xFFFF)] / 4.0);  // the gradient norm (ll_angle's expression)
         }
         add_ordered((double)(pxy & 0xFFFF) * wgt, (double)(pxy >> 16) * wgt, wgt, cn);
     }
@@ -806,7 +903,7 @@ __device__ __forceinline__ float4 region_segment_w(const LsdDev& d, const int32_
         double t_xx = 0.0, t_yy = 0.0, t_xy = 0.0;
         if (t < n_reg) {
             const int pxy = ld_coherent(list + t);
-            const double wgt = mod[(pxy >> 16) * w + (pxy & 0xFFFF)];
+            const double wgt = sqrt((double)k32[(pxy >> 16) * w + (pxy & 0xFFFF)] / 4.0);  // the gradient norm (ll_angle's expression)
             const double ddx = (double)(pxy & 0xFFFF) - cx, ddy = (double)(pxy >> 16) - cy;
             t_xx = ddy * ddy * wgt;
             t_yy = ddx * ddx * wgt;
@@ -905,7 +1002,7 @@ __global__ __launch_bounds__(LSD_XW * 64) void lsd_grow_xcd_kernel(LsdDev d, Lsd
     const int w = d.w, h = d.h, npx = w * h;
     const size_t base = (size_t)b * npx;
     LsdPx* px = d.px + base;
-    const double* __restrict__ mod = d.mod + base;
+    const int32_t* __restrict__ k32 = d.k32 + base;
     const uint32_t* __restrict__ order = d.order + base;
     long long* pend = x.pend + base;
     int32_t* ctl = x.ctl + (size_t)b * LSD_CTL;
@@ -1104,7 +1201,7 @@ __global__ __launch_bounds__(LSD_XW * 64) void lsd_grow_xcd_kernel(LsdDev d, Lsd
                     const int n = grow_region_w<true, false, true>(px, nullptr, 0, wlist, npx, s_ring[0], seed, px[seed].ang, w, h, d.prec,
                                                                    reg_angle, s_bits);
                     if (n >= d.min_reg_size) {
-                        const float4 sg = region_segment_w(d, wlist, n, mod, reg_angle, s_term[0]);
+                        const float4 sg = region_segment_w(d, wlist, n, k32, reg_angle, s_term[0]);
                         if (lane == 0 && n_seg < d.seg_cap) d.seg[(size_t)b * d.seg_cap + n_seg] = sg;
                         ++n_seg;
                     }
@@ -1301,7 +1398,7 @@ __global__ __launch_bounds__(LSD_XW * 64) void lsd_grow_xcd_kernel(LsdDev d, Lsd
                 double reg_angle = 0.0;
                 n = grow_region_w<false, true>(px, stamp, id, wl + off + 4, npx - off - 4, s_ring[wv], pick_q, px[pick_q].ang, w, h, d.prec, reg_angle);
                 if (n >= d.min_reg_size) {
-                    const float4 sg = region_segment_w(d, wl + off + 4, n, mod, reg_angle, s_term[wv]);
+                    const float4 sg = region_segment_w(d, wl + off + 4, n, k32, reg_angle, s_term[wv]);
                     if (lane == 0) {
                         st_coherent(wl + off, __float_as_int(sg.x));
                         st_coherent(wl + off + 1, __float_as_int(sg.y));
@@ -1428,9 +1525,6 @@ struct stvo_lsd {
     int k7[7] = {0, 0, 0, 0, 0, 0, 0};
     char* dev = nullptr;
     uint8_t *img = nullptr, *blur = nullptr, *scaled = nullptr;
-    int32_t* seg_off = nullptr;   // [B + 1] segment offsets of the sort
-    void* sort_tmp = nullptr;
-    size_t sort_tmp_bytes = 0;
     stvo_keyline* lines = nullptr;  // device buffers of the host-pointer entry points
     float* response = nullptr;
     int32_t* n_lines = nullptr;
@@ -1439,7 +1533,6 @@ struct stvo_lsd {
     size_t stamp_bytes = 0, pend_bytes = 0;
     stvo::LsdXcd xx{};        // scratch of lsd_grow_xcd_kernel (small batches, the default), or null
     int xcd_lds = 0;          // its dynamic LDS: the committer's bitmap — and at least 84 KB, so that a CU holds ONE of its workgroups (a wave per SIMD)
-    int sort_chunk = 1;       // images per call of the segmented sort (its item count is an int)
 };
 
 namespace {
@@ -1459,25 +1552,13 @@ int lsd_enqueue(stvo_lsd* o, const uint8_t* images, stvo_keyline* lines, float* 
     HIP_TRY(ctx, hipMemsetAsync(d.kmax, 0xFF, (size_t)d.B * 4, s));
     const dim3 grid((d.w + 255) / 256, (d.h + stvo::LSD_ROWS - 1) / stvo::LSD_ROWS, d.B);
     hipLaunchKernelGGL(stvo::lsd_gradient_kernel, grid, dim3(256), 0, s, d);
-    hipLaunchKernelGGL(stvo::lsd_keys_kernel, grid, dim3(256), 0, s, d);
-    size_t tb = o->sort_tmp_bytes;
-    // the radix sort is stable and the keys come in index order: sorting by the bin bits alone leaves every bin in row-major order
-    // (STVO_LSD_SORT_FULL=1: all 32 bits, the index bits included — the same order, more digit passes)
-    const int begin_bit = stvo::dbg().lsd_sort_full == 1 ? 0 : stvo::LSD_IDX_BITS;
-    if (o->wdev && d.B <= 8) {  // the smallest batches: the device-wide sort per image (the segmented sort gives a segment ONE workgroup: 3.5 ms for a KITTI-size
-                    // image) — over ALL key bits: the keys are distinct, so the order does not lean on the stability of the sort (over the
-                    // bin bits alone this sort returned another order than the segmented one, round 5)
-        const int npx = d.w * d.h;
-        for (int b = 0; b < d.B; ++b)
-            HIP_TRY(ctx, hipcub::DeviceRadixSort::SortKeys(o->sort_tmp, tb, d.keys + (size_t)b * npx, d.order + (size_t)b * npx, npx, 0, 32, s));
-    } else {
-        // (the sort counts its items in an int: batches beyond 2^31 pixels go in chunks of whole images)
-        const size_t npx = (size_t)d.w * d.h;
-        for (int b0 = 0; b0 < d.B; b0 += o->sort_chunk) {
-            const int nb_c = d.B - b0 < o->sort_chunk ? d.B - b0 : o->sort_chunk;
-            HIP_TRY(ctx, hipcub::DeviceSegmentedRadixSort::SortKeys(o->sort_tmp, tb, d.keys + b0 * npx, d.order + b0 * npx, (int)(nb_c * npx), nb_c, o->seg_off,
-                                                                    o->seg_off + 1, begin_bit, 32, s));
-        }
+    {   // the pseudo-ordering: counting sort by bin (histogram per unit, scan per image, stable scatter)
+        const int npx = d.w * d.h, nunits = (npx + stvo::LSD_UNIT - 1) / stvo::LSD_UNIT;
+        const dim3 ug((nunits + 3) / 4, d.B);
+        const size_t lds_h = (size_t)4 * d.n_bins * 4;
+        hipLaunchKernelGGL(stvo::lsd_hist_kernel, ug, dim3(256), lds_h, s, d);
+        hipLaunchKernelGGL(stvo::lsd_scan_kernel, dim3(d.B), dim3(1024), 0, s, d);
+        hipLaunchKernelGGL(stvo::lsd_scatter_kernel, ug, dim3(256), lds_h, s, d);
     }
     if (o->wdev) {  // small batches: a committing wave + speculating workgroups on the CUs of one XCD per image (lsd_grow_xcd_kernel)
         HIP_TRY(ctx, hipMemsetAsync(o->xx.stamp, 0, o->stamp_bytes, s));
@@ -1504,7 +1585,7 @@ int stvo_lsd_create(stvo_ctx* ctx, int B, int cols, int rows, int max_keylines, 
         return STVO_ERR_INVALID_ARG;
     // sort key = (n_bins - 1 - bin) << LSD_IDX_BITS | index, LSD_NOKEY = all ones: with 4096 bins the keys of bin 0 would share their
     // top 12 bits with the undefined pixels' key and the bin-bits-only sort would interleave them
-    if (prm->n_bins > 2048) return STVO_ERR_UNSUPPORTED;
+    if (prm->n_bins > stvo::LSD_MAX_BINS) return STVO_ERR_UNSUPPORTED;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     stvo_lsd* o = new (std::nothrow) stvo_lsd();
     if (!o) return STVO_ERR_HIP;
@@ -1556,32 +1637,22 @@ int stvo_lsd_create(stvo_ctx* ctx, int B, int cols, int rows, int max_keylines, 
         }
     } c;
     const size_t o_blur = c.take(nb * cols * rows), o_scaled = c.take(nb * npx), o_img = c.take(nb * cols * rows), o_px = c.take(nb * npx * sizeof(stvo::LsdPx)),
-                 o_mod = c.take(nb * npx * 8), o_keys = c.take(nb * npx * 4),
+                 o_k32 = c.take(nb * npx * 4), o_cnt = c.take(nb * ((npx + stvo::LSD_UNIT - 1) / stvo::LSD_UNIT) * (size_t)d.n_bins * 4),
                  o_order = c.take(nb * npx * 4), o_reg = c.take(nb * npx * 4), o_kmax = c.take(nb * 4), o_seg = c.take(nb * d.seg_cap * 16),
-                 o_nseg = c.take(nb * 4), o_off = c.take((nb + 1) * 4), o_lines = c.take(nb * d.K * sizeof(stvo_keyline)),
+                 o_nseg = c.take(nb * 4), o_lines = c.take(nb * d.K * sizeof(stvo_keyline)),
                  o_resp = c.take(nb * d.K * 4), o_nl = c.take(nb * 4), o_np = c.take(nb * 4);
     bool ok = hip_ok(ctx, hipMalloc((void**)&o->dev, c.off), "hipMalloc lsd") && hip_ok(ctx, hipMemset(o->dev, 0, c.off), "hipMemset lsd");
     if (ok) {
         char* D = o->dev;
         o->blur = (uint8_t*)(D + o_blur); o->scaled = (uint8_t*)(D + o_scaled); o->img = (uint8_t*)(D + o_img);
-        d.px = (stvo::LsdPx*)(D + o_px); d.mod = (double*)(D + o_mod);
-        d.keys = (uint32_t*)(D + o_keys); d.order = (uint32_t*)(D + o_order); d.reg = (int32_t*)(D + o_reg); d.kmax = (int32_t*)(D + o_kmax);
+        d.px = (stvo::LsdPx*)(D + o_px); d.k32 = (int32_t*)(D + o_k32); d.cnt = (uint32_t*)(D + o_cnt);
+        d.order = (uint32_t*)(D + o_order); d.reg = (int32_t*)(D + o_reg); d.kmax = (int32_t*)(D + o_kmax);
         d.seg = (float4*)(D + o_seg); d.n_seg = (int32_t*)(D + o_nseg); d.n_pass = (int32_t*)(D + o_np);
-        o->seg_off = (int32_t*)(D + o_off);
         o->lines = (stvo_keyline*)(D + o_lines); o->response = (float*)(D + o_resp); o->n_lines = (int32_t*)(D + o_nl);
-        o->sort_chunk = (int)std::min<size_t>(nb, ((1ull << 31) - 1) / npx);  // images per call of the segmented sort
-        std::vector<int32_t> off((size_t)o->sort_chunk + 1);
-        for (size_t i = 0; i < off.size(); ++i) off[i] = (int32_t)(i * npx);
-        ok = o->sort_chunk >= 1 && hip_ok(ctx, hipMemcpy(o->seg_off, off.data(), ((size_t)o->sort_chunk + 1) * 4, hipMemcpyHostToDevice), "hipMemcpy lsd offsets");
     }
-    if (ok) {
-        size_t tb = 0, tb1 = 0;
-        ok = hip_ok(ctx, hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, tb, (const uint32_t*)d.keys, d.order, (int)((size_t)o->sort_chunk * npx), o->sort_chunk, o->seg_off,
-                                                                    o->seg_off + 1, 0, 32, ctx->stream), "segmented sort (size)") &&
-             hip_ok(ctx, hipcub::DeviceRadixSort::SortKeys(nullptr, tb1, (const uint32_t*)d.keys, d.order, (int)npx, 0, 32, ctx->stream), "device sort (size)");
-        if (tb1 > tb) tb = tb1;  // (the per-image device-wide sort of the small batches)
-        ok = ok && hip_ok(ctx, hipMalloc(&o->sort_tmp, tb > 0 ? tb : 16), "hipMalloc lsd sort");
-        o->sort_tmp_bytes = tb;
+    if (ok && (size_t)4 * d.n_bins * 4 > 48 * 1024) {
+        ok = stvo::lds_opt_in(reinterpret_cast<const void*>(stvo::lsd_hist_kernel), 4 * d.n_bins * 4) &&
+             stvo::lds_opt_in(reinterpret_cast<const void*>(stvo::lsd_scatter_kernel), 4 * d.n_bins * 4);
     }
     if (ok && (size_t)d.seg_cap * 8 > 48 * 1024)
         ok = stvo::lds_opt_in(reinterpret_cast<const void*>(stvo::lsd_keylines_kernel), d.seg_cap * 8);
@@ -1624,7 +1695,6 @@ int stvo_lsd_destroy(stvo_lsd* o) {
         (void)hipStreamSynchronize(o->ctx->stream);
     }
     if (o->dbg) (void)hipFree(o->dbg);
-    if (o->sort_tmp) (void)hipFree(o->sort_tmp);
     if (o->wdev) (void)hipFree(o->wdev);
     if (o->dev) (void)hipFree(o->dev);
     delete o;

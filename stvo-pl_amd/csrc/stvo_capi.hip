@@ -45,7 +45,6 @@ DebugSwitches parse_switches() {
     d.lines_ahead = env_int("STVO_LINES_AHEAD");
     d.grid_dyn = env_int("STVO_GRID_DYN");
     d.lsd_grow = env_int("STVO_LSD_GROW");
-    d.lsd_sort_full = env_int("STVO_LSD_SORT_FULL");
     d.lsd_waves = env_int("STVO_LSD_WAVES");
     d.lsd_xcd_blocks = env_int("STVO_LSD_XCD_BLOCKS");
     d.lsd_feed_ahead = env_int("STVO_LSD_FEED_AHEAD");

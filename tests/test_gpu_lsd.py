@@ -143,23 +143,26 @@ def test_lsd_xcd_kernel_under_hostile_settings(hip, oracle, switches, knobs):
         lsd.close()
 
 
-def test_lsd_sort_by_all_key_bits_is_the_same(hip, oracle, switches):
-    """The pseudo-ordering sorts the bin bits only and relies on the stability of the radix sort for the row-major order inside a
-    bin (STVO_LSD_SORT_FULL=1 sorts the index bits too): the same segments either way."""
+@pytest.mark.parametrize("n_bins", [1, 7, 1000, 2048])
+def test_lsd_pseudo_ordering_by_bin_count(hip, oracle, n_bins):
+    """The pseudo-ordering is a counting sort of the library's own (lsd_hist / lsd_scan / lsd_scatter_kernel): the defined pixels by bin
+    of the gradient norm, highest bin first, row-major inside a bin.  The order of the seeds decides every region, so the segments
+    in detection order are its test — for one bin (pure row-major order), a handful, a count that is not a power of two and the
+    largest the library takes; a flat image (no defined pixel at all) and one of noise (nearly every pixel defined) ride along."""
     from stvo_amd import capi
     cols, rows = 640, 480
-    imgs = np.stack([synth.make_image(700, cols, rows), clean_image(cols, rows, 701)])
-    out = []
-    for full in ("0", "1"):
-        switches({"STVO_LSD_SORT_FULL": full})
-        lsd = capi.Lsd(hip, 2, cols, rows, capi.lsd_params(min_length=4.0, nfeatures=0), max_keylines=2048)
-        try:
-            out.append(lsd.segments(imgs))
-        finally:
-            lsd.close()
-    for b in range(2):
-        assert out[0][1][b] == out[1][1][b] and np.array_equal(out[0][0][b], out[1][0][b])
-        assert np.array_equal(out[0][0][b], oracle.lsd_segments(imgs[b], oracle.lsd_opts()))
+    rng = np.random.default_rng(59)
+    imgs = np.stack([synth.make_image(700, cols, rows), clean_image(cols, rows, 701), np.full((rows, cols), 90, np.uint8),
+                     rng.integers(0, 255, (rows, cols), dtype=np.uint8)])
+    lsd = capi.Lsd(hip, 4, cols, rows, capi.lsd_params(min_length=4.0, nfeatures=0, n_bins=n_bins), max_keylines=2048)
+    try:
+        segs, n = lsd.segments(imgs)
+        for b in range(4):
+            ref = oracle.lsd_segments(imgs[b], oracle.lsd_opts(n_bins=n_bins))
+            assert n[b] == len(ref), b
+            assert np.array_equal(segs[b], ref), b
+    finally:
+        lsd.close()
 
 
 def test_lsd_keep_all_flat_and_unscaled(hip, oracle):
