@@ -4,6 +4,6 @@ import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "stvo-pl_amd", "python")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import bench
-r = bench.lsd_leg(0, B=int(sys.argv[1]) if len(sys.argv) > 1 else 4096)
+r = bench.lsd_leg(0, B=int(sys.argv[1]), B2=0) if len(sys.argv) > 1 else bench.lsd_leg(0)
 r.pop("note", None); r.pop("workload", None)
 print(json.dumps(r))
