@@ -847,6 +847,7 @@ def short_line(full):
     leg("lsd_one_image_ms", "lsd_front_end", "one_image_ms")
     leg("lsd_one_image_vs_oracle_1_core", "lsd_front_end", "one_image_vs_oracle_1_core")
     leg("images_to_poses_with_lines_pairs_per_s", "images_to_poses_with_lines", "stereo_pairs_per_s")
+    leg("one_stereo_pair_with_lines_ms", "one_stereo_pair_with_lines", "ms_per_step")
     leg("clustered_reverse_check_ms", "reverse_check_correlated", "clustered", "reverse_check_ms")
     if legs:
         out["legs"] = legs
@@ -1196,6 +1197,8 @@ def main():
         extra("images_to_poses", images_leg, local_rank, B=512)
         extra("lsd_front_end", lsd_leg, local_rank)
         extra("images_to_poses_with_lines", images_leg, local_rank, B=2048, steps=3, lines=True)
+        # the reference application's own case (app/imagesStVO.cpp: ONE stereo pair per step, key-points + key-lines): latency, not throughput
+        extra("one_stereo_pair_with_lines", images_leg, local_rank, B=1, steps=12, lines=True)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.points, args.lines)
         out["cpu_baseline_fanout"] = cpu_baseline_fanout(args.points, args.lines)
