@@ -33,6 +33,7 @@ struct DebugSwitches {
     int lsd_xcd_blocks;  // STVO_LSD_XCD_BLOCKS  speculating workgroups (of four waves) per image of lsd_grow_xcd_kernel (unset: 8)
     int lsd_feed_ahead;  // STVO_LSD_FEED_AHEAD  ranks the feeder wave of lsd_grow_xcd_kernel runs ahead of the committer at most
     int lsd_sep;         // STVO_LSD_SEP         least distance (pixels, Chebyshev) of a new seed from every seed in flight
+    int lsd_multi;       // STVO_LSD_MULTI       0: the committer of lsd_grow_xcd_kernel takes its seeds one by one (unset: up to four records per pass)
     int lsd_ahead;       // STVO_LSD_AHEAD       ranks the dispatcher's front runs ahead of the committer at most
     int cells_ahead;     // STVO_CELLS_AHEAD     0: point_cells_kernel of a batch in the point stream (unset: on the line stream, ahead of the point stream's step)
     int seq_pipe;        // STVO_SEQ_PIPE        1: pipelined steps (optimizePose(k) on the aux stream beside the stereo association of step k + 1; built and measured in round 6, no gain), 2: the same without the gate kernel

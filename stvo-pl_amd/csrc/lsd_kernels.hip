@@ -679,7 +679,7 @@ __global__ __launch_bounds__(64) void lsd_grow_kernel(LsdDev d) {
 // growth round is ~1500 cycles of dependent instructions — fifteen speculators delivered ~2.7 waves' worth of growth); round 6
 // spreads it over the CUs of one XCD: lsd_grow_xcd_kernel below (9.9 ms; the oracle takes 17 ms on one host core).
 constexpr int LSD_WRING = 256;       // per wave: the most recent region points in LDS
-constexpr int LSD_SEP = 16;
+constexpr int LSD_SEP = 8;            // (4 … 16 give the same ~130 failed validations per KITTI-size image, 0: 390; 24 … 32: more seeds reach the committer unclaimed)
 constexpr int LSD_LOOK = 2048;       // ranks the dispatcher examines per pass, from the front
 constexpr int LSD_AHEAD = 16384;     // the front's lead over the committer (ranks; ~200 seeds of a KITTI-size scene)
 // Table entry of a seed: 0 = nobody's; LSD_CLAIM | wave = a speculating wave is growing it; else a finished region (lsd_entry_x)
@@ -986,6 +986,7 @@ struct LsdXcd {
     int32_t* ctl;    // [B][LSD_CTL]
     int nsb;         // speculating workgroups per image; nw = 1 + nsb LSD_XW
     int feed_ahead, sep, ahead;  // LSD_FEED_AHEAD, LSD_SEP, LSD_AHEAD or their developer overrides (STVO_LSD_FEED_AHEAD / _SEP / _AHEAD)
+    int multi;       // 0: the committer takes its seeds one by one (STVO_LSD_MULTI=0)
 };
 __device__ __forceinline__ long long lsd_entry_x(int wave, int n, int off) { return (1ll << 62) | ((long long)wave << 42) | ((long long)n << 21) | (long long)off; }
 
@@ -1069,7 +1070,7 @@ __global__ __launch_bounds__(LSD_XW * 64) void lsd_grow_xcd_kernel(LsdDev d, Lsd
         auto tick = [&]() -> long long { return prof ? (long long)__builtin_readcyclecounter() : 0ll; };
         const long long t_begin = tick();
         long long t_self = 0, t_wait = 0, t_take = 0;
-        int n_took = 0, n_self = 0, n_bad = 0, n_waited = 0, n_fast = 0, n_stale = 0, n_batch = 0;
+        int n_took = 0, n_self = 0, n_bad = 0, n_waited = 0, n_fast = 0, n_stale = 0, n_batch = 0, n_multi = 0, n_multi_undo = 0;
         int qt = 0, qh = 0;  // records consumed / known to be there
         request(0, false);
         bool at_end = false;
@@ -1089,6 +1090,96 @@ __global__ __launch_bounds__(LSD_XW * 64) void lsd_grow_xcd_kernel(LsdDev d, Lsd
             const bool key_ok = key != LSD_NOKEY;
             unsigned long long todo = __ballot(key_ok && bit_ld(s_bits, key_ok ? q_l : 0) == 0u);
             while (todo) {
+                // ---- several seeds at once: the next (up to) four free seeds of the batch whose records lie one behind the other in the
+                // feeder's ring.  Descriptors, words and bit tests of all of them cost the LDS round trips of ONE; they are taken together
+                // as far as the sequential search would take them: up to the first region with a used pixel, and only if no two of them
+                // share a pixel (the returning ds_or of the take shows it: then the bits are cleared again and the seeds go one by one).
+                if (x.multi) {
+                    if (qh - qt < 4) qh = __hip_atomic_load(&s_qhead, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const int have = qh - qt < 4 ? qh - qt : 4;
+                    const int4 dl = s_desc[(qt + (lane & 3)) & (LSD_FEED_Q - 1)];  // lane j (mod 4): the j-th record from the front
+                    int k = 0, total = 0, start[5] = {0, 0, 0, 0, 0};
+                    int pos0 = 0;
+                    {
+                        unsigned long long t2 = todo;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int ri = __builtin_amdgcn_readlane(dl.x, i), ni = __builtin_amdgcn_readlane(dl.y, i), pi = __builtin_amdgcn_readlane(dl.z, i);
+                            const bool more = k == i && i < have && t2 != 0ull && ri == o0 + __builtin_ctzll(t2) && total + ni + 4 <= 128 &&
+                                              (i == 0 || pi == pos0 + total);
+                            if (i == 0) pos0 = pi;
+                            if (more) {
+                                ++k;
+                                total += ni + 4;
+                                t2 &= t2 - 1ull;
+                            }
+                            start[i + 1] = total;
+                        }
+                    }
+                    if (k >= 2) {  // (one seed alone: the path below costs the same)
+                        const int w0 = lane < total ? s_px[pos0 + lane] : 0, w1 = 64 + lane < total ? s_px[pos0 + 64 + lane] : 0;
+                        auto region_of = [&](int sl) { return (sl >= start[1]) + (sl >= start[2]) + (sl >= start[3]); };
+                        const int r0 = region_of(lane), r1 = region_of(64 + lane);
+                        auto start_of = [&](int r) { return r == 0 ? 0 : (r == 1 ? start[1] : (r == 2 ? start[2] : start[3])); };
+                        const bool px0 = lane < total && lane - start_of(r0) >= 4, px1 = 64 + lane < total && 64 + lane - start_of(r1) >= 4;
+                        const unsigned long long b0 = __ballot(px0 && bit_ld(s_bits, px0 ? w0 : 0) != 0u), b1 = __ballot(px1 && bit_ld(s_bits, px1 ? w1 : 0) != 0u);
+                        const int first_bad = b0 ? __builtin_ctzll(b0) : (b1 ? 64 + __builtin_ctzll(b1) : 128);
+                        int kk = 0;  // regions in front of the first one with a used pixel
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) kk += (i < k && start[i + 1] <= first_bad) ? 1 : 0;
+                        if (kk >= 1) {
+                            const int lim = kk == 1 ? start[1] : (kk == 2 ? start[2] : (kk == 3 ? start[3] : start[4]));
+                            const bool t0 = px0 && lane < lim, t1 = px1 && 64 + lane < lim;
+                            unsigned o0w = 0u, o1w = 0u;
+                            if (t0) o0w = __hip_atomic_fetch_or(s_bits + (w0 >> 5), 1u << (w0 & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (t1) o1w = __hip_atomic_fetch_or(s_bits + (w1 >> 5), 1u << (w1 & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            const bool c0 = t0 && ((o0w >> (w0 & 31)) & 1u), c1 = t1 && ((o1w >> (w1 & 31)) & 1u);
+                            if (__ballot(c0 || c1)) {  // two of the regions share a pixel: undo (the bits were clear before), one by one below
+                                if (t0 && !c0) (void)__hip_atomic_fetch_and(s_bits + (w0 >> 5), ~(1u << (w0 & 31)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                if (t1 && !c1) (void)__hip_atomic_fetch_and(s_bits + (w1 >> 5), ~(1u << (w1 & 31)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                ++n_multi_undo;
+                            } else {
+                                if (t0) st_coherent(&px[w0].used, 1);
+                                if (t1) st_coherent(&px[w1].used, 1);
+                                // the segments of the regions large enough, in order
+                                int last_rank = 0, last_end = 0;
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) {
+                                    if (i < kk) {
+                                        const int ni = __builtin_amdgcn_readlane(dl.y, i);
+                                        last_rank = __builtin_amdgcn_readlane(dl.x, i);
+                                        last_end = __builtin_amdgcn_readlane(dl.w, i);
+                                        if (ni >= d.min_reg_size) {
+                                            const int sl = start[i];  // the segment: the first four words of the record
+                                            const bool in0 = lane >= sl && lane < sl + 4, in1 = 64 + lane >= sl && 64 + lane < sl + 4;
+                                            if (n_seg < d.seg_cap) {
+                                                int* sg = reinterpret_cast<int*>(d.seg + (size_t)b * d.seg_cap + n_seg);
+                                                if (in0) sg[lane - sl] = w0;
+                                                if (in1) sg[64 + lane - sl] = w1;
+                                            }
+                                            ++n_seg;
+                                        }
+                                        todo &= todo - 1ull;
+                                    }
+                                }
+                                qt += kk;
+                                n_took += kk;
+                                n_fast += kk;
+                                ++n_multi;
+                                if (lane == 0) {
+                                    lds_st(&s_scan, last_rank);
+                                    lds_st(&s_cwords, last_end);
+                                    lds_st(&s_qtail, qt);
+                                }
+                                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                                __builtin_amdgcn_wave_barrier();
+                                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                                todo &= __ballot(key_ok && bit_ld(s_bits, key_ok ? q_l : 0) == 0u);
+                                continue;
+                            }
+                        }
+                    }
+                }
                 const int j = __builtin_ctzll(todo);
                 todo &= todo - 1ull;
                 const int seed = __builtin_amdgcn_readlane(q_l, j), rank = o0 + j;
@@ -1225,7 +1316,7 @@ __global__ __launch_bounds__(LSD_XW * 64) void lsd_grow_xcd_kernel(LsdDev d, Lsd
             q[0] = (double)(tick() - t_begin); q[1] = (double)t_self; q[2] = (double)t_wait; q[3] = (double)t_take;
             q[4] = (double)n_took; q[5] = (double)n_self; q[6] = (double)n_bad; q[7] = (double)n_waited;
             q[8] = -1.0;
-            q[9] = (double)n_fast; q[10] = (double)n_stale; q[11] = (double)n_batch;
+            q[9] = (double)n_fast; q[10] = (double)n_stale; q[11] = (double)n_batch; q[12] = (double)n_multi; q[13] = (double)n_multi_undo;
         }
     } else if (role == 0 && wv == 2) {
         // ---------------- the feeder: the finished regions in front of the committer, from the L2 into LDS, in rank order ----------------
@@ -1312,13 +1403,17 @@ __global__ __launch_bounds__(LSD_XW * 64) void lsd_grow_xcd_kernel(LsdDev d, Lsd
         const int ns = nw - 1;
         int sxy0 = -1, sxy1 = -1;  // x | y << 16 of the seed in flight, -1: none
         int front = 0;             // every rank below is used, pending or claimed — for good
+        const bool dprof = d.dbg != nullptr && b == 0;
+        long long dp_iter = 0, dp_chunks = 0, dp_given = 0, dp_noidle = 0, dp_blocked = 0;
         for (int idle = 0; idle < (1 << 24); ++idle) {  // (bounded)
             if (lds_ld(&s_done)) break;
             const bool idle0 = lane < ns && ld_l2_64(mbox + lane) == 1, idle1 = lane + 64 < ns && ld_l2_64(mbox + 64 + lane) == 1;  // (1: the wave is there and idle)
             if (idle0) sxy0 = -1;
             if (idle1) sxy1 = -1;
             unsigned long long I0 = __ballot(idle0), I1 = __ballot(idle1);
+            ++dp_iter;
             if (!(I0 | I1)) {
+                ++dp_noidle;
                 __builtin_amdgcn_s_sleep(4);
                 continue;
             }
@@ -1340,6 +1435,7 @@ __global__ __launch_bounds__(LSD_XW * 64) void lsd_grow_xcd_kernel(LsdDev d, Lsd
                 const int qx = q % w, qy = q / w;
                 const unsigned long long m_open = __ballot(open);
                 unsigned long long mm = m_open, given = 0ull;
+                ++dp_chunks;
                 while (mm && (I0 | I1)) {
                     const int L = __builtin_ctzll(mm);
                     mm &= mm - 1ull;
@@ -1349,7 +1445,10 @@ __global__ __launch_bounds__(LSD_XW * 64) void lsd_grow_xcd_kernel(LsdDev d, Lsd
                         const int adx = ddx < 0 ? -ddx : ddx, ady = ddy < 0 ? -ddy : ddy;
                         return sxy >= 0 && (adx > ady ? adx : ady) < x.sep;
                     };
-                    if (__ballot(near(sxy0) || near(sxy1))) continue;  // too close to a growth in flight: later (the front stays in front of it)
+                    if (__ballot(near(sxy0) || near(sxy1))) {  // too close to a growth in flight: later (the front stays in front of it)
+                        ++dp_blocked;
+                        continue;
+                    }
                     const int u = I0 ? __builtin_ctzll(I0) : 64 + __builtin_ctzll(I1);
                     if (u < 64) I0 &= I0 - 1ull;
                     else I1 &= I1 - 1ull;
@@ -1362,6 +1461,7 @@ __global__ __launch_bounds__(LSD_XW * 64) void lsd_grow_xcd_kernel(LsdDev d, Lsd
                         st_coherent64(mbox + u, (1ll << 62) | ((long long)r << 21) | (long long)q);
                     }
                     given |= 1ull << L;
+                    ++dp_given;
                     idle = 0;
                 }
                 if (contiguous) {  // the ranks of this chunk in front of the first one still open join the solid part
@@ -1370,6 +1470,10 @@ __global__ __launch_bounds__(LSD_XW * 64) void lsd_grow_xcd_kernel(LsdDev d, Lsd
                     contiguous = rem == 0ull;
                 }
             }
+        }
+        if (dprof && lane == 0) {
+            double* q = d.dbg + ((size_t)d.seg_cap - 4) * 8;
+            q[0] = (double)dp_iter; q[1] = (double)dp_chunks; q[2] = (double)dp_given; q[3] = (double)dp_noidle; q[4] = (double)dp_blocked;
         }
     } else if (role != 0) {
         // ---------------- a speculating wave ----------------
@@ -1382,6 +1486,9 @@ __global__ __launch_bounds__(LSD_XW * 64) void lsd_grow_xcd_kernel(LsdDev d, Lsd
         int32_t* stamp = x.stamp + ((size_t)b * nw + v) * npx;
         int32_t* wl = x.wlist + ((size_t)b * nw + v) * npx;
         int id = 0, off = 0;
+        const bool sprof = d.dbg != nullptr && b == 0;
+        long long sp_busy = 0, sp_n = 0, sp_grow = 0;
+        const long long sp_t0 = sprof ? (long long)__builtin_readcyclecounter() : 0ll;
         if (lane == 0) st_coherent64(mbox + (v - 1), 1ll);  // here, and idle
         for (int idle = 0; idle < (1 << 24); ++idle) {  // (bounded: a wave that is handed nothing for this long gives up)
             const long long m = readfirstlane64(ld_l2_64(mbox + (v - 1)));
@@ -1391,6 +1498,7 @@ __global__ __launch_bounds__(LSD_XW * 64) void lsd_grow_xcd_kernel(LsdDev d, Lsd
                 continue;
             }
             idle = 0;
+            const long long sp_a = sprof ? (long long)__builtin_readcyclecounter() : 0ll;
             const int pick_r = (int)((m >> 21) & 0x1FFFFF), pick_q = (int)(m & 0x1FFFFF);
             int n = 0;
             if (npx - off >= 4096) {  // (out of room: empty records from here on — the committer grows those seeds itself)
@@ -1414,6 +1522,18 @@ __global__ __launch_bounds__(LSD_XW * 64) void lsd_grow_xcd_kernel(LsdDev d, Lsd
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) st_coherent64(mbox + (v - 1), 1ll);  // idle again
             if (n > 0) off += 4 + n;
+            if (sprof) {
+                sp_busy += (long long)__builtin_readcyclecounter() - sp_a;
+                ++sp_n;
+            }
+        }
+        if (sprof && lane == 0) {  // tools/lsd_probe.py: the speculating waves together (row seg_cap - 3 of image 0's block, as integers)
+            unsigned long long* q = reinterpret_cast<unsigned long long*>(d.dbg + ((size_t)d.seg_cap - 3) * 8);
+            atomicAdd(q + 0, (unsigned long long)sp_busy);
+            atomicAdd(q + 1, (unsigned long long)((long long)__builtin_readcyclecounter() - sp_t0));
+            atomicAdd(q + 2, (unsigned long long)sp_n);
+            atomicAdd(q + 3, 1ull);
+            (void)sp_grow;
         }
     }
 }
@@ -1676,6 +1796,7 @@ int stvo_lsd_create(stvo_ctx* ctx, int B, int cols, int rows, int max_keylines, 
             o->xx.feed_ahead = g.lsd_feed_ahead == stvo::DBG_UNSET ? stvo::LSD_FEED_AHEAD : g.lsd_feed_ahead;
             o->xx.sep = g.lsd_sep == stvo::DBG_UNSET ? stvo::LSD_SEP : g.lsd_sep;
             o->xx.ahead = g.lsd_ahead == stvo::DBG_UNSET ? stvo::LSD_AHEAD : g.lsd_ahead;
+            o->xx.multi = g.lsd_multi == 0 ? 0 : 1;
             o->stamp_bytes = nb * nw * npx * 4;
             o->pend_bytes = nb * npx * 8;
         }
@@ -1728,7 +1849,10 @@ extern "C" int stvo_lsd_debug(stvo_lsd* o, int enable, double* out /* [seg_cap][
     if (!o) return STVO_ERR_INVALID_ARG;
     stvo_ctx* ctx = o->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (enable && !o->dbg) HIP_TRY(ctx, hipMalloc((void**)&o->dbg, (size_t)o->d.B * o->d.seg_cap * 64));
+    if (enable && !o->dbg) {
+        HIP_TRY(ctx, hipMalloc((void**)&o->dbg, (size_t)o->d.B * o->d.seg_cap * 64));
+        HIP_TRY(ctx, hipMemset(o->dbg, 0, (size_t)o->d.B * o->d.seg_cap * 64));
+    }
     o->d.dbg = enable ? o->dbg : nullptr;
     if (out && o->dbg) HIP_TRY(ctx, hipMemcpy(out, o->dbg, (size_t)o->d.seg_cap * 64, hipMemcpyDeviceToHost));
     return STVO_OK;

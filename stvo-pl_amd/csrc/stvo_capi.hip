@@ -50,6 +50,7 @@ DebugSwitches parse_switches() {
     d.lsd_feed_ahead = env_int("STVO_LSD_FEED_AHEAD");
     d.lsd_sep = env_int("STVO_LSD_SEP");
     d.lsd_ahead = env_int("STVO_LSD_AHEAD");
+    d.lsd_multi = env_int("STVO_LSD_MULTI");
     return d;
 }
 DebugSwitches& switches() {

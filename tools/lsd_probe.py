@@ -39,8 +39,12 @@ for b in range(min(B, 2)):
         if q2[0] == -1.0:
             print(f"   many-waves kernel, committer cycles: total {q[0]:.0f}  growing itself {q[1]:.0f}  waiting for an in-flight seed {q[2]:.0f}  validating + taking pending {q[3]:.0f} | "
                   f"regions taken {q[4]:.0f}  grown by the committer {q[5]:.0f}  failed validation {q[6]:.0f}  waited for {q[7]:.0f}")
+            sp = gd[8189].view(np.uint64); dp = gd[8188]
+            if sp[3] > 0:
+                print(f"      speculating waves {sp[3]}: busy {sp[0]} of {sp[1]} cycles ({100.0 * sp[0] / max(sp[1], 1):.0f} %), regions {sp[2]} ({sp[0] / max(sp[2], 1):.0f} cycles each)")
+                print(f"      dispatcher: passes {dp[0]:.0f} (no idle wave {dp[3]:.0f}), chunks scanned {dp[1]:.0f}, seeds handed out {dp[2]:.0f}, candidates too close to a growth in flight {dp[4]:.0f}")
             if q2[3] > 0:
-                print(f"      regions through the feeder's records {q2[1]:.0f}  records passed over {q2[2]:.0f}  batches {q2[3]:.0f}")
+                print(f"      regions through the feeder's records {q2[1]:.0f}  records passed over {q2[2]:.0f}  batches {q2[3]:.0f}  passes over several records {q2[4]:.0f} (undone {q2[5]:.0f})")
             continue
         print(f"   rounds: publish {q2[0]:.0f}  list read + address + issue {q2[1]:.0f}  wait for the loads {q2[2]:.0f}  | seed set-up {q2[3]:.0f}")
         print(f"   image 0, cycles: total {q[0]:.0f}  grow {q[1]:.0f} (of which resolving {q[2]:.0f})  rect {q[3]:.0f} | rounds {q[4]:.0f}  pixels added {q[5]:.0f}  regions {q[6]:.0f}  batches {q[7]:.0f}")

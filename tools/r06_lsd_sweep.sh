@@ -3,5 +3,5 @@
 mkdir -p gpurun_out/lsd_xcd
 for cfg in "$@"; do
   echo "== $cfg" | tee -a gpurun_out/lsd_xcd/sweep.txt
-  env $cfg timeout 60 python tools/lsd_probe.py --batch ${BATCH:-1} --iters 10 2>&1 | grep -E "rows differ|committer|images:|feeder" | tee -a gpurun_out/lsd_xcd/sweep.txt
+  env $cfg timeout 60 python tools/lsd_probe.py --batch ${BATCH:-1} --iters 10 2>&1 | grep -E "rows differ|committer|images:|feeder|speculating|dispatcher" | tee -a gpurun_out/lsd_xcd/sweep.txt
 done
