@@ -30,7 +30,7 @@ struct DebugSwitches {
     int grid_fused_cap;  // STVO_GRID_FUSED_CAP  capacity override of the one-workgroup point matcher (tests of the misfit path)
     int lsd_grow;        // STVO_LSD_GROW        0: the plain form of lsd_grow_kernel (candidates one after the other, sums through v_readlane)
     int lsd_waves;       // STVO_LSD_WAVES       0: batches of <= 8 images by lsd_grow_kernel (one wave per image) instead of lsd_grow_xcd_kernel (a committer + speculating workgroups on the CUs of one XCD per image)
-    int lsd_xcd_blocks;  // STVO_LSD_XCD_BLOCKS  speculating workgroups (of four waves) per image of lsd_grow_xcd_kernel (unset: 8)
+    int lsd_xcd_blocks;  // STVO_LSD_XCD_BLOCKS  speculating workgroups (of four waves) per image of lsd_grow_xcd_kernel (unset: 16, or what the XCD's 32 CUs leave per image)
     int lsd_feed_ahead;  // STVO_LSD_FEED_AHEAD  ranks the feeder wave of lsd_grow_xcd_kernel runs ahead of the committer at most
     int lsd_sep;         // STVO_LSD_SEP         least distance (pixels, Chebyshev) of a new seed from every seed in flight
     int lsd_multi;       // STVO_LSD_MULTI       0: the committer of lsd_grow_xcd_kernel takes its seeds one by one (unset: up to four records per pass)

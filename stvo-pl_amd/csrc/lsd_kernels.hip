@@ -1779,7 +1779,7 @@ int stvo_lsd_create(stvo_ctx* ctx, int B, int cols, int rows, int max_keylines, 
     if (ok && stvo::dbg().lsd_waves != 0 && B <= stvo::LSD_WAVES_MAX_B && npx <= stvo::LSD_XCD_MAX_PX) {  // small batches (STVO_LSD_WAVES=0: one wave per image there too)
         // an XCD has 32 CUs and a CU holds one of the kernel's workgroups: images per XCD x (1 + speculating workgroups) <= 32
         const int per_xcd = (B + 7) / 8;
-        int nsb = stvo::dbg().lsd_xcd_blocks == stvo::DBG_UNSET ? (32 / per_xcd - 1 < 8 ? 32 / per_xcd - 1 : 8) : stvo::dbg().lsd_xcd_blocks;  // STVO_LSD_XCD_BLOCKS
+        int nsb = stvo::dbg().lsd_xcd_blocks == stvo::DBG_UNSET ? (32 / per_xcd - 1 < 16 ? 32 / per_xcd - 1 : 16) : stvo::dbg().lsd_xcd_blocks;  // STVO_LSD_XCD_BLOCKS
         nsb = nsb < 0 ? 0 : (nsb > (stvo::LSD_X_MAXW - 1) / stvo::LSD_XW ? (stvo::LSD_X_MAXW - 1) / stvo::LSD_XW : nsb);
         const size_t nw = 1 + (size_t)nsb * stvo::LSD_XW;
         decltype(c) cw;
