@@ -121,7 +121,8 @@ __global__ __launch_bounds__(64 * LBD_LINES_PER_WG) void lbd_describe_kernel(Lbd
     if (hID < LBD_ROWS) {  // ---- one row of the support region (:1144-1175), sequential along the line
         float sCorX = sCorX0, sCorY = sCorY0;
         float pgdL = 0.f, ngdL = 0.f, pgdO = 0.f, ngdO = 0.f;
-        for (int wID = 0; wID < lengthOfLSP; ++wID) {
+#pragma unroll 8
+        for (int wID = 0; wID < lengthOfLSP; ++wID) {  // (unrolled: the gathers of eight steps in flight — their addresses do not depend on what is loaded; the sums stay in order)
             int t = (int)roundf(sCorX);
             const int xCor = t < 0 ? 0 : (t > imageWidth ? imageWidth : t);
             t = (int)roundf(sCorY);
