@@ -1069,8 +1069,8 @@ __global__ __launch_bounds__(LSD_XW * 64) void lsd_grow_xcd_kernel(LsdDev d, Lsd
         const bool prof = d.dbg != nullptr && b == 0;  // tools/lsd_probe.py: where the committer's time goes
         auto tick = [&]() -> long long { return prof ? (long long)__builtin_readcyclecounter() : 0ll; };
         const long long t_begin = tick();
-        long long t_self = 0, t_wait = 0, t_take = 0;
-        int n_took = 0, n_self = 0, n_bad = 0, n_waited = 0, n_fast = 0, n_stale = 0, n_batch = 0, n_multi = 0, n_multi_undo = 0;
+        long long t_self = 0, t_wait = 0, t_take = 0, t_multi = 0, t_peek = 0, t_refresh = 0;
+        int n_took = 0, n_self = 0, n_bad = 0, n_waited = 0, n_fast = 0, n_stale = 0, n_batch = 0, n_multi = 0, n_multi_undo = 0, n_multi_try = 0;
         int qt = 0, qh = 0;  // records consumed / known to be there
         request(0, false);
         bool at_end = false;
@@ -1094,7 +1094,9 @@ __global__ __launch_bounds__(LSD_XW * 64) void lsd_grow_xcd_kernel(LsdDev d, Lsd
                 // feeder's ring.  Descriptors, words and bit tests of all of them cost the LDS round trips of ONE; they are taken together
                 // as far as the sequential search would take them: up to the first region with a used pixel, and only if no two of them
                 // share a pixel (the returning ds_or of the take shows it: then the bits are cleared again and the seeds go one by one).
+                const long long tm0 = tick();
                 if (x.multi) {
+                    ++n_multi_try;
                     if (qh - qt < 4) qh = __hip_atomic_load(&s_qhead, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
                     const int have = qh - qt < 4 ? qh - qt : 4;
                     const int4 dl = s_desc[(qt + (lane & 3)) & (LSD_FEED_Q - 1)];  // lane j (mod 4): the j-th record from the front
@@ -1175,11 +1177,14 @@ __global__ __launch_bounds__(LSD_XW * 64) void lsd_grow_xcd_kernel(LsdDev d, Lsd
                                 __builtin_amdgcn_wave_barrier();
                                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                                 todo &= __ballot(key_ok && bit_ld(s_bits, key_ok ? q_l : 0) == 0u);
+                                t_multi += tick() - tm0;
                                 continue;
                             }
                         }
                     }
                 }
+                const long long tp0 = tick();
+                t_multi += tp0 - tm0;
                 const int j = __builtin_ctzll(todo);
                 todo &= todo - 1ull;
                 const int seed = __builtin_amdgcn_readlane(q_l, j), rank = o0 + j;
@@ -1211,6 +1216,7 @@ __global__ __launch_bounds__(LSD_XW * 64) void lsd_grow_xcd_kernel(LsdDev d, Lsd
                 bool took = false;
                 long long p = 0;
                 const long long tk = tick();
+                t_peek += tk - tp0;
                 if (fast) {
                     ++n_fast;
                     const int n = __builtin_amdgcn_readfirstlane(dsc.y), pos = __builtin_amdgcn_readfirstlane(dsc.z);
@@ -1299,10 +1305,12 @@ __global__ __launch_bounds__(LSD_XW * 64) void lsd_grow_xcd_kernel(LsdDev d, Lsd
                     t_self += tick() - ts;
                 }
                 // seeds of the batch taken meanwhile (an LDS round trip)
+                const long long tr0 = tick();
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 todo &= __ballot(key_ok && bit_ld(s_bits, key_ok ? q_l : 0) == 0u);
+                t_refresh += tick() - tr0;
             }
         }
         }
@@ -1317,6 +1325,8 @@ __global__ __launch_bounds__(LSD_XW * 64) void lsd_grow_xcd_kernel(LsdDev d, Lsd
             q[4] = (double)n_took; q[5] = (double)n_self; q[6] = (double)n_bad; q[7] = (double)n_waited;
             q[8] = -1.0;
             q[9] = (double)n_fast; q[10] = (double)n_stale; q[11] = (double)n_batch; q[12] = (double)n_multi; q[13] = (double)n_multi_undo;
+            d.dbg[((size_t)d.seg_cap - 5) * 8 + 0] = (double)t_multi; d.dbg[((size_t)d.seg_cap - 5) * 8 + 1] = (double)t_peek;
+            d.dbg[((size_t)d.seg_cap - 5) * 8 + 2] = (double)t_refresh; d.dbg[((size_t)d.seg_cap - 5) * 8 + 3] = (double)n_multi_try;
         }
     } else if (role == 0 && wv == 2) {
         // ---------------- the feeder: the finished regions in front of the committer, from the L2 into LDS, in rank order ----------------

@@ -43,6 +43,9 @@ for b in range(min(B, 2)):
             if sp[3] > 0:
                 print(f"      speculating waves {sp[3]}: busy {sp[0]} of {sp[1]} cycles ({100.0 * sp[0] / max(sp[1], 1):.0f} %), regions {sp[2]} ({sp[0] / max(sp[2], 1):.0f} cycles each)")
                 print(f"      dispatcher: passes {dp[0]:.0f} (no idle wave {dp[3]:.0f}), chunks scanned {dp[1]:.0f}, seeds handed out {dp[2]:.0f}, candidates too close to a growth in flight {dp[4]:.0f}")
+            t5 = gd[8187]
+            if t5[3] > 0:
+                print(f"      committer: several-records passes incl. their preamble {t5[0]:.0f} ({t5[3]:.0f} tries)  queue peek of the one-by-one path {t5[1]:.0f}  refresh {t5[2]:.0f}")
             if q2[3] > 0:
                 print(f"      regions through the feeder's records {q2[1]:.0f}  records passed over {q2[2]:.0f}  batches {q2[3]:.0f}  passes over several records {q2[4]:.0f} (undone {q2[5]:.0f})")
             continue
