@@ -424,10 +424,12 @@ def build():
 def load():
     global _cached
     if _cached is None:
-        so = os.path.join(ORACLE_DIR, "liboracle.so")
-        src = os.path.join(ORACLE_DIR, "stvo_oracle.c")
-        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-            build()
+        so = os.environ.get("STVO_ORACLE_SO")  # a build of the same sources with other flags (tools/oracle_sanitize.sh: -fsanitize=address,undefined)
+        if not so:
+            so = os.path.join(ORACLE_DIR, "liboracle.so")
+            src = os.path.join(ORACLE_DIR, "stvo_oracle.c")
+            if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+                build()
         _cached = Oracle(C.CDLL(so))
     return _cached
 
