@@ -119,6 +119,49 @@ def test_lsd_mid_batch_several_images_per_xcd(hip, oracle):
         lsd.close()
 
 
+def test_lsd_two_detectors_at_once(oracle):
+    """Two contexts (two HIP streams), each with its own small-batch detector, called from two threads at the same time: the
+    many-waves launches of both compete for the CUs of the same XCDs — a speculating workgroup may start late or next to another
+    launch's, a committer may run with fewer helpers — and every call must still return the oracle's segments (the committer alone
+    is the sequential search; every wait in the kernel is bounded)."""
+    import threading
+    from stvo_amd import capi
+    cols, rows = 640, 360
+    imgs = [np.stack([synth.make_image(660 + 2 * t, cols, rows), synth.make_image(661 + 2 * t, cols, rows)]) for t in range(2)]
+    refs = [[oracle.lsd_segments(im[b], oracle.lsd_opts(scale=0.8)) for b in range(2)] for im in imgs]
+    ctxs = [capi.Context(device_id=0, max_rows=2048, max_batch=4) for _ in range(2)]
+    lsds = [capi.Lsd(c, 2, cols, rows, capi.lsd_params(min_length=4.0, nfeatures=0, scale=0.8), max_keylines=2048) for c in ctxs]
+    out, err = [None, None], []
+
+    def work(t):
+        try:
+            res = []
+            for _ in range(6):
+                res.append(lsds[t].segments(imgs[t]))
+            out[t] = res
+        except Exception as e:  # noqa: BLE001
+            err.append(e)
+
+    try:
+        th = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join(timeout=120)
+        assert not err, err
+        for t in range(2):
+            assert out[t] is not None
+            for segs, n in out[t]:
+                for b in range(2):
+                    assert n[b] == len(refs[t][b])
+                    assert np.array_equal(segs[b], refs[t][b])
+    finally:
+        for l in lsds:
+            l.close()
+        for c in ctxs:
+            c.close()
+
+
 @pytest.mark.parametrize("knobs", [{"STVO_LSD_XCD_BLOCKS": "0"}, {"STVO_LSD_XCD_BLOCKS": "1", "STVO_LSD_FEED_AHEAD": "0"},
                                    {"STVO_LSD_XCD_BLOCKS": "31", "STVO_LSD_SEP": "4", "STVO_LSD_AHEAD": "1000000", "STVO_LSD_FEED_AHEAD": "100000"}])
 def test_lsd_xcd_kernel_under_hostile_settings(hip, oracle, switches, knobs):
