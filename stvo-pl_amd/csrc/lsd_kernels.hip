@@ -974,7 +974,7 @@ constexpr int LSD_CTL = 512;       // control words per image, zeroed per call
 constexpr size_t LSD_XCD_MAX_PX = 3u << 18;  // the committer's bitmap (96 KB) + the feeder's ring + the per-wave scratch fit the 160 KB of a CU
 constexpr int LSD_FEED_PX = 8192;   // words of the feeder's record ring (LDS)
 constexpr int LSD_FEED_Q = 256;     // records in it at most
-constexpr int LSD_FEED_MAXW = 2048; // a record's words at most (longer lists go through the table)
+constexpr int LSD_FEED_MAXW = 128;  // a record's pixels at most (the 3 % of the regions that are larger go through the table)
 constexpr int LSD_FEED_AHEAD = 192;  // ranks the feeder runs ahead of the committer at most (further ahead most regions are still being grown: 2048: a quarter of the regions found finished, 128 - 256: 95 %)
 constexpr int XC_ALIVE = 0;        // the committer's XCC id + 1 (0: it has not started)
 constexpr int XC_DONE = 1;
@@ -1012,8 +1012,9 @@ __global__ __launch_bounds__(LSD_XW * 64) void lsd_grow_xcd_kernel(LsdDev d, Lsd
     // dynamic LDS of the committer's workgroup: its flags, one bit per pixel | the feeder's record ring | the records' descriptors
     extern __shared__ unsigned s_bits[];
     const int nbw = (((npx + 31) / 32) + 3) & ~3;  // (whole 16-byte units: the descriptors behind are int4)
-    int* const s_px = reinterpret_cast<int*>(s_bits + nbw);  // [LSD_FEED_PX] per record: 4 words of segment, then the pixel indices
+    int* const s_px = reinterpret_cast<int*>(s_bits + nbw);  // [LSD_FEED_PX] per record: its pixel indices, the record's number (mod 256) in the top byte
     int4* const s_desc = reinterpret_cast<int4*>(s_px + LSD_FEED_PX);  // [LSD_FEED_Q] {rank, size, position in s_px, words fed up to its end}
+    float4* const s_dseg = reinterpret_cast<float4*>(s_desc + LSD_FEED_Q);  // [LSD_FEED_Q] the records' segments
     if (role == 0) {
         if (threadIdx.x == 0) {
             s_scan = -1;
@@ -1089,164 +1090,130 @@ __global__ __launch_bounds__(LSD_XW * 64) void lsd_grow_xcd_kernel(LsdDev d, Lsd
             const int q_l = (int)(key & ((1u << LSD_IDX_BITS) - 1u));
             const bool key_ok = key != LSD_NOKEY;
             unsigned long long todo = __ballot(key_ok && bit_ld(s_bits, key_ok ? q_l : 0) == 0u);
+            bool one_record = false;  // after a pass whose regions shared a pixel: the next pass takes the first record alone
             while (todo) {
-                // ---- several seeds at once: the next (up to) four free seeds of the batch whose records lie one behind the other in the
-                // feeder's ring.  Descriptors, words and bit tests of all of them cost the LDS round trips of ONE; they are taken together
-                // as far as the sequential search would take them: up to the first region with a used pixel, and only if no two of them
-                // share a pixel (the returning ds_or of the take shows it: then the bits are cleared again and the seeds go one by one).
+                // ---- the records at the front of the feeder's queue against the free seeds of the batch, up to eight at once.  A lane
+                // below 8 holds a descriptor, a lane of the batch that is a free seed finds "its" descriptor by its ordinal among the
+                // free seeds; the pass covers the leading seeds whose records are there, one behind the other in the ring and together
+                // at most 128 pixels.  All their pixels are tested in one LDS round trip and taken together as far as the sequential
+                // search would take them — up to the first region with a used pixel — unless two of them share a pixel (the returning
+                // ds_or of the take shows it: then the bits are cleared again and the first record goes alone).
                 const long long tm0 = tick();
-                if (x.multi) {
-                    ++n_multi_try;
-                    if (qh - qt < 4) qh = __hip_atomic_load(&s_qhead, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    const int have = qh - qt < 4 ? qh - qt : 4;
-                    const int4 dl = s_desc[(qt + (lane & 3)) & (LSD_FEED_Q - 1)];  // lane j (mod 4): the j-th record from the front
-                    int k = 0, total = 0, start[5] = {0, 0, 0, 0, 0};
-                    int pos0 = 0;
-                    {
-                        unsigned long long t2 = todo;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int ri = __builtin_amdgcn_readlane(dl.x, i), ni = __builtin_amdgcn_readlane(dl.y, i), pi = __builtin_amdgcn_readlane(dl.z, i);
-                            const bool more = k == i && i < have && t2 != 0ull && ri == o0 + __builtin_ctzll(t2) && total + ni + 4 <= 128 &&
-                                              (i == 0 || pi == pos0 + total);
-                            if (i == 0) pos0 = pi;
-                            if (more) {
-                                ++k;
-                                total += ni + 4;
-                                t2 &= t2 - 1ull;
-                            }
-                            start[i + 1] = total;
+                ++n_multi_try;
+                if (qh - qt < 8) qh = __hip_atomic_load(&s_qhead, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const int have = qh - qt < 8 ? qh - qt : 8;
+                const int4 dl = s_desc[(qt + (lane & 7)) & (LSD_FEED_Q - 1)];  // {rank, pixels, position, words fed up to its end}
+                const bool is_seed = (todo >> lane) & 1ull;
+                const int ord = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(todo >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)todo, 0u));
+                const int first_rank = o0 + __builtin_ctzll(todo);
+                int k = 0;
+                {
+                    const int drank = __shfl(dl.x, ord & 7, 64);  // the rank in the descriptor with this seed's ordinal
+                    const unsigned long long hit = __ballot(is_seed && ord < have && drank == o0 + lane);
+                    const unsigned long long miss = todo & ~hit;
+                    k = __builtin_popcountll(miss ? todo & ((1ull << __builtin_ctzll(miss)) - 1ull) : todo);
+                    // one behind the other in the ring (a wrap shows as a jump of the running word count), 128 pixels together
+                    const int base0 = __builtin_amdgcn_readfirstlane(dl.w - dl.y), pos0c = __builtin_amdgcn_readfirstlane(dl.z);
+                    const int startw = dl.w - dl.y - base0;
+                    const unsigned inrow = (unsigned)__ballot(lane < 8 && dl.z == pos0c + startw && startw + dl.y <= 128) & 0xFFu;
+                    const int kc = __builtin_ctz(~inrow);
+                    k = k < kc ? k : kc;
+                    if ((one_record || !x.multi) && k > 1) k = 1;
+                    one_record = false;
+                }
+                bool regrow_first = false;
+                if (k >= 1) {
+                    const int pos0 = __builtin_amdgcn_readfirstlane(dl.z);
+                    const int total = __builtin_amdgcn_readlane(dl.w, k - 1) - __builtin_amdgcn_readfirstlane(dl.w - dl.y);
+                    const bool a0 = lane < total, a1 = 64 + lane < total;
+                    const int w0 = a0 ? s_px[pos0 + lane] : 0, w1 = a1 ? s_px[pos0 + 64 + lane] : 0;
+                    const int q0 = w0 & 0xFFFFFF, q1 = w1 & 0xFFFFFF;
+                    const int r0 = (((unsigned)w0 >> 24) - (unsigned)qt) & 0xFFu, r1 = (((unsigned)w1 >> 24) - (unsigned)qt) & 0xFFu;  // the record of a word, from the front
+                    const unsigned long long b0 = __ballot(a0 && bit_ld(s_bits, q0) != 0u), b1 = __ballot(a1 && bit_ld(s_bits, q1) != 0u);
+                    int kk = k;  // the records in front of the first one with a used pixel
+                    if (b0) kk = __builtin_amdgcn_readlane(r0, __builtin_ctzll(b0));
+                    else if (b1) kk = __builtin_amdgcn_readlane(r1, __builtin_ctzll(b1));
+                    if (kk == 0) {  // the first record has lost a pixel: its region is grown again below
+                        regrow_first = true;
+                        ++qt;
+                        ++n_bad;
+                        if (lane == 0) {
+                            lds_st(&s_cwords, __builtin_amdgcn_readfirstlane(dl.w));
+                            lds_st(&s_qtail, qt);
                         }
+                    } else {
+                        const bool t0 = a0 && r0 < kk, t1 = a1 && r1 < kk;
+                        unsigned o0w = 0u, o1w = 0u;
+                        if (t0) o0w = __hip_atomic_fetch_or(s_bits + (q0 >> 5), 1u << (q0 & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (t1) o1w = __hip_atomic_fetch_or(s_bits + (q1 >> 5), 1u << (q1 & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        const bool c0 = t0 && ((o0w >> (q0 & 31)) & 1u), c1 = t1 && ((o1w >> (q1 & 31)) & 1u);
+                        if (__ballot(c0 || c1)) {  // two of the regions share a pixel: undo (the bits were clear before), the first record alone next
+                            if (t0 && !c0) (void)__hip_atomic_fetch_and(s_bits + (q0 >> 5), ~(1u << (q0 & 31)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (t1 && !c1) (void)__hip_atomic_fetch_and(s_bits + (q1 >> 5), ~(1u << (q1 & 31)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            ++n_multi_undo;
+                            one_record = true;
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                            t_multi += tick() - tm0;
+                            continue;
+                        }
+                        if (t0) st_coherent(&px[q0].used, 1);
+                        if (t1) st_coherent(&px[q1].used, 1);
+                        // the segments of the regions large enough, in order: a descriptor's lane each
+                        const unsigned long long big = __ballot(lane < kk && dl.y >= d.min_reg_size);
+                        if ((big >> lane) & 1ull) {
+                            const int idx = n_seg + __builtin_popcountll(big & ((1ull << lane) - 1ull));
+                            if (idx < d.seg_cap) d.seg[(size_t)b * d.seg_cap + idx] = s_dseg[(qt + lane) & (LSD_FEED_Q - 1)];
+                        }
+                        n_seg += __builtin_popcountll(big);
+                        todo &= ~__ballot(is_seed && ord < kk);
+                        const int last_rank = __builtin_amdgcn_readlane(dl.x, kk - 1), last_end = __builtin_amdgcn_readlane(dl.w, kk - 1);
+                        qt += kk;
+                        n_took += kk;
+                        n_fast += kk;
+                        ++n_multi;
+                        if (lane == 0) {
+                            lds_st(&s_scan, last_rank);
+                            lds_st(&s_cwords, last_end);
+                            lds_st(&s_qtail, qt);
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        todo &= __ballot(key_ok && bit_ld(s_bits, key_ok ? q_l : 0) == 0u);
+                        t_multi += tick() - tm0;
+                        continue;
                     }
-                    if (k >= 2) {  // (one seed alone: the path below costs the same)
-                        const int w0 = lane < total ? s_px[pos0 + lane] : 0, w1 = 64 + lane < total ? s_px[pos0 + 64 + lane] : 0;
-                        auto region_of = [&](int sl) { return (sl >= start[1]) + (sl >= start[2]) + (sl >= start[3]); };
-                        const int r0 = region_of(lane), r1 = region_of(64 + lane);
-                        auto start_of = [&](int r) { return r == 0 ? 0 : (r == 1 ? start[1] : (r == 2 ? start[2] : start[3])); };
-                        const bool px0 = lane < total && lane - start_of(r0) >= 4, px1 = 64 + lane < total && 64 + lane - start_of(r1) >= 4;
-                        const unsigned long long b0 = __ballot(px0 && bit_ld(s_bits, px0 ? w0 : 0) != 0u), b1 = __ballot(px1 && bit_ld(s_bits, px1 ? w1 : 0) != 0u);
-                        const int first_bad = b0 ? __builtin_ctzll(b0) : (b1 ? 64 + __builtin_ctzll(b1) : 128);
-                        int kk = 0;  // regions in front of the first one with a used pixel
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) kk += (i < k && start[i + 1] <= first_bad) ? 1 : 0;
-                        if (kk >= 1) {
-                            const int lim = kk == 1 ? start[1] : (kk == 2 ? start[2] : (kk == 3 ? start[3] : start[4]));
-                            const bool t0 = px0 && lane < lim, t1 = px1 && 64 + lane < lim;
-                            unsigned o0w = 0u, o1w = 0u;
-                            if (t0) o0w = __hip_atomic_fetch_or(s_bits + (w0 >> 5), 1u << (w0 & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            if (t1) o1w = __hip_atomic_fetch_or(s_bits + (w1 >> 5), 1u << (w1 & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            const bool c0 = t0 && ((o0w >> (w0 & 31)) & 1u), c1 = t1 && ((o1w >> (w1 & 31)) & 1u);
-                            if (__ballot(c0 || c1)) {  // two of the regions share a pixel: undo (the bits were clear before), one by one below
-                                if (t0 && !c0) (void)__hip_atomic_fetch_and(s_bits + (w0 >> 5), ~(1u << (w0 & 31)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                if (t1 && !c1) (void)__hip_atomic_fetch_and(s_bits + (w1 >> 5), ~(1u << (w1 & 31)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                ++n_multi_undo;
-                            } else {
-                                if (t0) st_coherent(&px[w0].used, 1);
-                                if (t1) st_coherent(&px[w1].used, 1);
-                                // the segments of the regions large enough, in order
-                                int last_rank = 0, last_end = 0;
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) {
-                                    if (i < kk) {
-                                        const int ni = __builtin_amdgcn_readlane(dl.y, i);
-                                        last_rank = __builtin_amdgcn_readlane(dl.x, i);
-                                        last_end = __builtin_amdgcn_readlane(dl.w, i);
-                                        if (ni >= d.min_reg_size) {
-                                            const int sl = start[i];  // the segment: the first four words of the record
-                                            const bool in0 = lane >= sl && lane < sl + 4, in1 = 64 + lane >= sl && 64 + lane < sl + 4;
-                                            if (n_seg < d.seg_cap) {
-                                                int* sg = reinterpret_cast<int*>(d.seg + (size_t)b * d.seg_cap + n_seg);
-                                                if (in0) sg[lane - sl] = w0;
-                                                if (in1) sg[64 + lane - sl] = w1;
-                                            }
-                                            ++n_seg;
-                                        }
-                                        todo &= todo - 1ull;
-                                    }
-                                }
-                                qt += kk;
-                                n_took += kk;
-                                n_fast += kk;
-                                ++n_multi;
-                                if (lane == 0) {
-                                    lds_st(&s_scan, last_rank);
-                                    lds_st(&s_cwords, last_end);
-                                    lds_st(&s_qtail, qt);
-                                }
-                                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                                __builtin_amdgcn_wave_barrier();
-                                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                                todo &= __ballot(key_ok && bit_ld(s_bits, key_ok ? q_l : 0) == 0u);
-                                t_multi += tick() - tm0;
-                                continue;
-                            }
+                } else {
+                    // no record for the first free seed at the front of the queue: records of seeds taken meanwhile are passed over ...
+                    const unsigned stale = (unsigned)__ballot(lane < have && dl.x < first_rank) & 0xFFu;
+                    const int ns = __builtin_ctz(~stale);
+                    if (ns > 0) {
+                        const int cend = __builtin_amdgcn_readlane(dl.w, ns - 1);
+                        qt += ns;
+                        n_stale += ns;
+                        if (lane == 0) {
+                            lds_st(&s_cwords, cend);
+                            lds_st(&s_qtail, qt);
                         }
+                        t_multi += tick() - tm0;
+                        continue;
                     }
                 }
+                // ---- ... and ONE seed goes through the table (its region was not finished when the feeder passed, is larger than a
+                // record, or the feeder is behind), or — the record's region has lost a pixel — is grown again
                 const long long tp0 = tick();
                 t_multi += tp0 - tm0;
                 const int j = __builtin_ctzll(todo);
                 todo &= todo - 1ull;
                 const int seed = __builtin_amdgcn_readlane(q_l, j), rank = o0 + j;
                 if (lane == 0) lds_st(&s_scan, rank);
-                // the feeder's record of this rank, if there is one (records of seeds taken meanwhile are passed over)
-                int4 dsc = make_int4(-1, 0, 0, 0);
-                bool fast = false;
-                {
-                    const int qt0 = qt;
-                    int cend = 0;
-                    for (;;) {
-                        if (qt == qh) {
-                            qh = __hip_atomic_load(&s_qhead, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            if (qt == qh) break;
-                        }
-                        dsc = s_desc[qt & (LSD_FEED_Q - 1)];
-                        dsc.x = __builtin_amdgcn_readfirstlane(dsc.x);
-                        if (dsc.x >= rank) break;
-                        cend = __builtin_amdgcn_readfirstlane(dsc.w);
-                        ++qt;
-                        ++n_stale;
-                    }
-                    fast = qt != qh && dsc.x == rank;
-                    if (qt != qt0 && lane == 0) {  // room for the feeder
-                        lds_st(&s_cwords, cend);
-                        lds_st(&s_qtail, qt);
-                    }
-                }
                 bool took = false;
-                long long p = 0;
+                long long p = 1;
                 const long long tk = tick();
                 t_peek += tk - tp0;
-                if (fast) {
-                    ++n_fast;
-                    const int n = __builtin_amdgcn_readfirstlane(dsc.y), pos = __builtin_amdgcn_readfirstlane(dsc.z);
-                    const int v0 = lane < n + 4 ? s_px[pos + lane] : 0;
-                    const bool has = lane >= 4 && lane < n + 4;
-                    bool bad = has && bit_ld(s_bits, v0) != 0u;
-                    for (int t = 64 + lane; t < n + 4; t += 64) bad = bad || bit_ld(s_bits, s_px[pos + t]) != 0u;
-                    if (!__ballot(bad)) {  // every pixel still free: this IS the region of the sequential search
-                        if (has) {
-                            bit_set(s_bits, v0);
-                            st_coherent(&px[v0].used, 1);
-                        }
-                        for (int t = 64 + lane; t < n + 4; t += 64) {
-                            const int q = s_px[pos + t];
-                            bit_set(s_bits, q);
-                            st_coherent(&px[q].used, 1);
-                        }
-                        took = true;
-                        if (n >= d.min_reg_size) {
-                            if (lane < 4 && n_seg < d.seg_cap) reinterpret_cast<int*>(d.seg + (size_t)b * d.seg_cap + n_seg)[lane] = v0;
-                            ++n_seg;
-                        }
-                    }
-                    p = 1;  // (a region that fails here is grown again below, as one from the table)
-                    ++qt;
-                    if (lane == 0) {
-                        lds_st(&s_cwords, __builtin_amdgcn_readfirstlane(dsc.w));
-                        lds_st(&s_qtail, qt);
-                    }
-                } else {
+                if (!regrow_first) {
                     auto table = [&]() { return readfirstlane64(ld_l2_64(pend + rank)); };  // (one address: a scalar result)
                     p = table();
                     if (p < 0) {  // a speculating wave is growing this very seed: its work is the work this wave would do (bounded wait)
@@ -1264,11 +1231,11 @@ __global__ __launch_bounds__(LSD_XW * 64) void lsd_grow_xcd_kernel(LsdDev d, Lsd
                             const bool has = lane >= 4 && lane < n + 4;
                             const int q0 = (w0 >> 16) * w + (w0 & 0xFFFF);
                             bool bad = has && bit_ld(s_bits, q0) != 0u;
-                            for (int t = 64 + lane; t < n + 4; t += 64) {  // (the rare long list: the rest in further round trips)
+                            for (int t = 64 + lane; t < n + 4; t += 64) {  // (a long list: the rest in further round trips)
                                 const int pxy = ld_l2(pl + t);
                                 bad = bad || bit_ld(s_bits, (pxy >> 16) * w + (pxy & 0xFFFF)) != 0u;
                             }
-                            if (!__ballot(bad)) {
+                            if (!__ballot(bad)) {  // every pixel still free: this IS the region of the sequential search
                                 if (has) {
                                     bit_set(s_bits, q0);
                                     st_coherent(&px[q0].used, 1);
@@ -1287,12 +1254,12 @@ __global__ __launch_bounds__(LSD_XW * 64) void lsd_grow_xcd_kernel(LsdDev d, Lsd
                             }
                         }
                     }
+                    if (took) ++n_took;
+                    else if (p) ++n_bad;
+                    else ++n_self;
                 }
                 const long long ts = tick();
                 t_take += ts - tk;
-                if (took) ++n_took;
-                else if (p) ++n_bad;
-                else ++n_self;
                 if (!took) {
                     double reg_angle;
                     const int n = grow_region_w<true, false, true>(px, nullptr, 0, wlist, npx, s_ring[0], seed, px[seed].ang, w, h, d.prec,
@@ -1361,7 +1328,7 @@ __global__ __launch_bounds__(LSD_XW * 64) void lsd_grow_xcd_kernel(LsdDev d, Lsd
                 ent = o0 + lane < npx ? e2 : ent;
             }
             const int en_n = (int)((ent >> 21) & 0x1FFFFF);
-            unsigned long long g = __ballot(key_ok && (ent >> 62) == 1ll && en_n != 0 && en_n + 4 <= LSD_FEED_MAXW && bit_ld(s_bits, key_ok ? q_l : 0) == 0u);
+            unsigned long long g = __ballot(key_ok && (ent >> 62) == 1ll && en_n != 0 && en_n <= LSD_FEED_MAXW && bit_ld(s_bits, key_ok ? q_l : 0) == 0u);
             while (g) {
                 int J[GRP], W[GRP];
                 const int32_t* PL[GRP];
@@ -1382,7 +1349,7 @@ __global__ __launch_bounds__(LSD_XW * 64) void lsd_grow_xcd_kernel(LsdDev d, Lsd
                 for (int k = 0; k < GRP; ++k) {
                     if (J[k] < 0) continue;
                     const long long p = readlane_i64(ent, J[k]);
-                    const int n = (int)((p >> 21) & 0x1FFFFF), L = n + 4;
+                    const int n = (int)((p >> 21) & 0x1FFFFF), L = n;
                     int pos = wpos & (LSD_FEED_PX - 1);
                     if (pos + L > LSD_FEED_PX) {  // (records are contiguous: the rest of the ring's end stays unused)
                         wpos += LSD_FEED_PX - pos;
@@ -1392,10 +1359,13 @@ __global__ __launch_bounds__(LSD_XW * 64) void lsd_grow_xcd_kernel(LsdDev d, Lsd
                         if (gone() || spin > (1 << 22)) return;
                         __builtin_amdgcn_s_sleep(4);
                     }
-                    if (lane < L) s_px[pos + lane] = lane < 4 ? W[k] : (W[k] >> 16) * w + (W[k] & 0xFFFF);
-                    for (int t = 64 + lane; t < L; t += 64) {
+                    // the list's words: the segment (4) to the descriptor's side, the pixels as INDICES tagged with the record's number
+                    const int tag = (qhd & 0xFF) << 24;
+                    if (lane < 4) reinterpret_cast<int*>(s_dseg + (qhd & (LSD_FEED_Q - 1)))[lane] = W[k];
+                    else if (lane < n + 4) s_px[pos + lane - 4] = ((W[k] >> 16) * w + (W[k] & 0xFFFF)) | tag;
+                    for (int t = 64 + lane; t < n + 4; t += 64) {
                         const int pxy = ld_l2(PL[k] + t);
-                        s_px[pos + t] = (pxy >> 16) * w + (pxy & 0xFFFF);
+                        s_px[pos + t - 4] = ((pxy >> 16) * w + (pxy & 0xFFFF)) | tag;
                     }
                     wpos += L;
                     if (lane == 0) s_desc[qhd & (LSD_FEED_Q - 1)] = make_int4(o0 + J[k], n, pos, wpos);
@@ -1794,7 +1764,7 @@ int stvo_lsd_create(stvo_ctx* ctx, int B, int cols, int rows, int max_keylines, 
         const size_t nw = 1 + (size_t)nsb * stvo::LSD_XW;
         decltype(c) cw;
         const size_t w_stamp = cw.take(nb * nw * npx * 4), w_list = cw.take(nb * nw * npx * 4), w_pend = cw.take(nb * npx * 8 + nb * stvo::LSD_CTL * 4);
-        o->xcd_lds = (int)(((((npx + 31) / 32) + 3) & ~size_t(3)) * 4) + stvo::LSD_FEED_PX * 4 + stvo::LSD_FEED_Q * 16;
+        o->xcd_lds = (int)(((((npx + 31) / 32) + 3) & ~size_t(3)) * 4) + stvo::LSD_FEED_PX * 4 + stvo::LSD_FEED_Q * 32;
         if (o->xcd_lds < 84 * 1024) o->xcd_lds = 84 * 1024;
         ok = stvo::lds_opt_in(reinterpret_cast<const void*>(stvo::lsd_grow_xcd_kernel), o->xcd_lds) &&
              hip_ok(ctx, hipMalloc((void**)&o->wdev, cw.off), "hipMalloc lsd xcd");
