@@ -485,7 +485,7 @@ def _lsd_leg(local_rank, B, one_image=True):
             "note": "region growing is sequential per image by definition.  Batches: one wavefront per image (~65 ms alone: ~44 k rounds of ~3.4 "
                     "region points, one L2 round trip + ~1500 cycles of dependent instructions each) — the batch is the parallelism, throughput "
                     "still grows from 4096 to 8192 images in flight.  one_image_ms: the many-waves form of batches <= 8 (lsd_grow_xcd_kernel, round 6: one XCD "
-                    "per image — a committing wave on an LDS bitmap, a dispatcher and a feeder wave beside it, 32 speculating waves on eight "
+                    "per image — a committing wave on an LDS bitmap, a dispatcher and a feeder wave beside it, 64 speculating waves on sixteen "
                     "other CUs, exact), device-resident image, host synchronisation included"}
 
 
