@@ -974,7 +974,7 @@ constexpr int LSD_CTL = 512;       // control words per image, zeroed per call
 constexpr size_t LSD_XCD_MAX_PX = 3u << 18;  // the committer's bitmap (96 KB) + the feeder's ring + the per-wave scratch fit the 160 KB of a CU
 constexpr int LSD_FEED_PX = 8192;   // words of the feeder's record ring (LDS)
 constexpr int LSD_FEED_Q = 256;     // records in it at most
-constexpr int LSD_FEED_MAXW = 128;  // a record's pixels at most (the 3 % of the regions that are larger go through the table)
+constexpr int LSD_FEED_MAXW = 2048; // a record's pixels at most (a quarter of the ring; larger regions go through the table)
 constexpr int LSD_FEED_AHEAD = 192;  // ranks the feeder runs ahead of the committer at most (further ahead most regions are still being grown: 2048: a quarter of the regions found finished, 128 - 256: 95 %)
 constexpr int XC_ALIVE = 0;        // the committer's XCC id + 1 (0: it has not started)
 constexpr int XC_DONE = 1;
@@ -1178,6 +1178,43 @@ __global__ __launch_bounds__(LSD_XW * 64) void lsd_grow_xcd_kernel(LsdDev d, Lsd
                             lds_st(&s_cwords, last_end);
                             lds_st(&s_qtail, qt);
                         }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        todo &= __ballot(key_ok && bit_ld(s_bits, key_ok ? q_l : 0) == 0u);
+                        t_multi += tick() - tm0;
+                        continue;
+                    }
+                } else if (have >= 1 && __builtin_amdgcn_readfirstlane(dl.x) == first_rank) {
+                    // the first seed's record is too large for a pass (more than 128 pixels: 3 % of the regions): alone, chunk by chunk
+                    const int n = __builtin_amdgcn_readfirstlane(dl.y), pos = __builtin_amdgcn_readfirstlane(dl.z);
+                    bool bad = false;
+                    for (int t = lane; t < n; t += 64) bad = bad || bit_ld(s_bits, s_px[pos + t] & 0xFFFFFF) != 0u;
+                    const bool ok = !__ballot(bad);
+                    if (ok) {
+                        for (int t = lane; t < n; t += 64) {
+                            const int q = s_px[pos + t] & 0xFFFFFF;
+                            bit_set(s_bits, q);
+                            st_coherent(&px[q].used, 1);
+                        }
+                        if (n >= d.min_reg_size) {
+                            if (lane == 0 && n_seg < d.seg_cap) d.seg[(size_t)b * d.seg_cap + n_seg] = s_dseg[qt & (LSD_FEED_Q - 1)];
+                            ++n_seg;
+                        }
+                        todo &= todo - 1ull;
+                        ++n_took;
+                        ++n_fast;
+                    } else {
+                        regrow_first = true;
+                        ++n_bad;
+                    }
+                    ++qt;
+                    if (lane == 0) {
+                        if (ok) lds_st(&s_scan, first_rank);
+                        lds_st(&s_cwords, __builtin_amdgcn_readfirstlane(dl.w));
+                        lds_st(&s_qtail, qt);
+                    }
+                    if (ok) {
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         __builtin_amdgcn_wave_barrier();
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
