@@ -7,7 +7,7 @@
 // against which these kernels are bit-exact (tests/test_gpu_lbd.py).  The LSD / FLD detectors that produce the key-lines are
 // not built.
 //   lbd_blur5_kernel     GaussianBlur(5 x 5, sigma 1) in OpenCV 3's 8-bit fixed point (weights x 2^8, one rounding shift by 16)
-//   lbd_sobel_kernel     Sobel 3 x 3 of the blurred image to int16 (dx, dy), BORDER_REFLECT_101
+//   lbd_sobel_kernel     Sobel 3 x 3 of the blurred image to int16 (dx, dy) in one word, BORDER_REFLECT_101
 //   lbd_describe_kernel  one wave per key-line: lane = row of the 63-row line support region.  The row sums are FLOAT sums in the
 //                        source's order (a sequential walk along the line per row — the rows are the parallelism), the 9 band
 //                        statistics are accumulated row by row in the source's order by the lane that owns the band, and the
@@ -29,8 +29,7 @@ struct LbdDev {
     int B, cols, rows, M;        // images, image size, key-line capacity per image
     const uint8_t* img;          // [B][rows][cols]
     uint8_t* blur;               // [B][rows][cols]
-    int16_t* dx;                 // [B][rows][cols]
-    int16_t* dy;
+    int32_t* dxy;                // [B][rows][cols] dx (low half) and dy (high half) of a pixel as int16 in ONE word: the support region is walked with one gather per step
     const stvo_keyline* lines;   // [B][M]
     const int32_t* n_lines;      // [B]
     uint8_t* desc;               // [B][M][32]
@@ -79,8 +78,9 @@ __global__ __launch_bounds__(256) void lbd_sobel_kernel(LbdDev o) {
     const uint8_t* r2 = img + (size_t)reflect101(y + 1, o.rows) * o.cols;
     const int xm = reflect101(x - 1, o.cols), xp = reflect101(x + 1, o.cols);
     const size_t k = ((size_t)b * o.rows + y) * o.cols + x;
-    o.dx[k] = (int16_t)(((int)r0[xp] + 2 * (int)r1[xp] + (int)r2[xp]) - ((int)r0[xm] + 2 * (int)r1[xm] + (int)r2[xm]));
-    o.dy[k] = (int16_t)(((int)r2[xm] + 2 * (int)r2[x] + (int)r2[xp]) - ((int)r0[xm] + 2 * (int)r0[x] + (int)r0[xp]));
+    const int gx = ((int)r0[xp] + 2 * (int)r1[xp] + (int)r2[xp]) - ((int)r0[xm] + 2 * (int)r1[xm] + (int)r2[xm]);
+    const int gy = ((int)r2[xm] + 2 * (int)r2[x] + (int)r2[xp]) - ((int)r0[xm] + 2 * (int)r0[x] + (int)r0[xp]);
+    o.dxy[k] = (int32_t)(((uint32_t)gx & 0xFFFFu) | ((uint32_t)gy << 16));  // (|g| <= 1020: int16 halves)
 }
 
 constexpr int LBD_LINES_PER_WG = 4;
@@ -93,8 +93,7 @@ __global__ __launch_bounds__(64 * LBD_LINES_PER_WG) void lbd_describe_kernel(Lbd
     const int n = min(max(o.n_lines[b], 0), o.M);
     if (l >= n) return;  // wave-uniform (no workgroup barrier below: every synchronisation is inside the wave)
     const stvo_keyline kl = o.lines[(size_t)b * o.M + l];
-    const int16_t* pdx = o.dx + (size_t)b * o.rows * o.cols;
-    const int16_t* pdy = o.dy + (size_t)b * o.rows * o.cols;
+    const int32_t* pdxy = o.dxy + (size_t)b * o.rows * o.cols;
     float (*row)[8] = s_row[wv];
     float* des = s_des[wv];
     auto wave_sync = [] {
@@ -127,7 +126,8 @@ __global__ __launch_bounds__(64 * LBD_LINES_PER_WG) void lbd_describe_kernel(Lbd
             const int xCor = t < 0 ? 0 : (t > imageWidth ? imageWidth : t);
             t = (int)roundf(sCorY);
             const int yCor = t < 0 ? 0 : (t > imageHeight ? imageHeight : t);
-            const float dx = (float)pdx[yCor * realWidth + xCor], dy = (float)pdy[yCor * realWidth + xCor];
+            const int g = pdxy[yCor * realWidth + xCor];
+            const float dx = (float)(int16_t)(g & 0xFFFF), dy = (float)(g >> 16);
             const float gDL = dx * dL0 + dy * dL1;
             const float gDO = dx * dO0 + dy * dO1;
             if (gDL > 0) pgdL += gDL; else ngdL -= gDL;
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(64 * LBD_LINES_PER_WG) void lbd_describe_kernel(Lbd
 struct stvo_lbd {
     stvo_ctx* ctx = nullptr;
     stvo::LbdDev d{};
-    char* dev = nullptr;  // blur | dx | dy
+    char* dev = nullptr;  // blur | (dx, dy)
     char* io = nullptr;   // staging of the host-buffer entry point
     size_t io_bytes = 0;
 };
@@ -255,14 +255,14 @@ int stvo_lbd_create(stvo_ctx* ctx, int B, int cols, int rows, int max_keylines, 
     o->ctx = ctx;
     const size_t px = (size_t)B * rows * cols;
     auto al = [](size_t v) { return (v + 255) & ~size_t(255); };
-    const size_t o_dx = al(px), o_dy = o_dx + al(px * 2), total = o_dy + al(px * 2);
+    const size_t o_dxy = al(px), total = o_dxy + al(px * 4);
     if (!hip_ok(ctx, hipMalloc((void**)&o->dev, total), "hipMalloc lbd")) {
         delete o;
         return STVO_ERR_HIP;
     }
     stvo::LbdDev& d = o->d;
     d.B = B; d.cols = cols; d.rows = rows; d.M = max_keylines;
-    d.blur = (uint8_t*)o->dev; d.dx = (int16_t*)(o->dev + o_dx); d.dy = (int16_t*)(o->dev + o_dy);
+    d.blur = (uint8_t*)o->dev; d.dxy = (int32_t*)(o->dev + o_dxy);
     {   // getGaussianKernel(5, 1) in 8-bit fixed point (binary_descriptor_custom.cpp:358)
         double k[5], sum = 0.0;
         for (int i = 0; i < 5; ++i) {
