@@ -6,8 +6,9 @@
 // :1026-1340, binaryConversion :401-412, the weight tables of the constructor :217-258), restated in oracle/stvo_lbd_oracle.c,
 // against which these kernels are bit-exact (tests/test_gpu_lbd.py).  The LSD / FLD detectors that produce the key-lines are
 // not built.
-//   lbd_blur5_kernel     GaussianBlur(5 x 5, sigma 1) in OpenCV 3's 8-bit fixed point (weights x 2^8, one rounding shift by 16)
-//   lbd_sobel_kernel     Sobel 3 x 3 of the blurred image to int16 (dx, dy) in one word, BORDER_REFLECT_101
+//   launch_blur7_u8      GaussianBlur(5 x 5, sigma 1) in OpenCV 3's 8-bit fixed point (weights x 2^8, one rounding shift by 16): orb_kernels.hip's
+//                        register-resident 7-tap blur with zero outer weights
+//   lbd_sobel_kernel     Sobel 3 x 3 of the blurred image, BORDER_REFLECT_101, four pixels per thread: int16 (dx, dy) in one word per pixel
 //   lbd_describe_kernel  one wave per key-line: lane = row of the 63-row line support region.  The row sums are FLOAT sums in the
 //                        source's order (a sequential walk along the line per row — the rows are the parallelism), the 9 band
 //                        statistics are accumulated row by row in the source's order by the lane that owns the band, and the
@@ -47,40 +48,70 @@ __device__ __forceinline__ int reflect101(int p, int n) {
     return p;
 }
 
-// 5 x 5 separable blur, both passes in integers; one thread per output pixel (25 cached byte loads — the images are small and
-// this runs once per frame next to ~100 wave-sized descriptor problems)
-__global__ __launch_bounds__(256) void lbd_blur5_kernel(LbdDev o) {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
-    if (x >= o.cols) return;
-    const uint8_t* img = o.img + (size_t)b * o.rows * o.cols;
-    int xs[5];
-#pragma unroll
-    for (int i = 0; i < 5; ++i) xs[i] = reflect101(x + i - 2, o.cols);
-    int s = 0;
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        const uint8_t* row = img + (size_t)reflect101(y + j - 2, o.rows) * o.cols;
-        int h = 0;
-#pragma unroll
-        for (int i = 0; i < 5; ++i) h += o.k5[i] * (int)row[xs[i]];
-        s += o.k5[j] * h;
-    }
-    s = (s + (1 << 15)) >> 16;
-    o.blur[((size_t)b * o.rows + y) * o.cols + x] = (uint8_t)min(max(s, 0), 255);
-}
-
-__global__ __launch_bounds__(256) void lbd_sobel_kernel(LbdDev o) {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+// Sobel 3 x 3 (BORDER_REFLECT_101) of the blurred image: a thread produces FOUR adjacent pixels of SB_R consecutive rows.  Per input
+// row it loads the six bytes x - 1 .. x + 4 as two (unaligned) words — byte by byte with reflected columns only at the two image
+// borders —, forms the row's four differences p[i + 1] - p[i - 1] and four smoothed values p[i - 1] + 2 p[i] + p[i + 1], keeps three
+// rows of them in registers and emits one output row per input row: (dx, dy) as the int16 halves of one word per pixel.
+// (Round 6.  Until then one thread per pixel with eight cached byte loads, behind a 5 x 5 blur of the same kind: 14 ms per 4096
+// KITTI-size images; the blur is now orb_kernels.hip's register-resident 7-tap kernel with zero outer weights — the same 8-bit
+// fixed-point arithmetic —, together 2.x ms.)
+typedef uint32_t __attribute__((aligned(1))) lbd_u32_unaligned;
+typedef int32_t lbd_i32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+constexpr int SB_R = 16, SB_T = 64;
+__global__ __launch_bounds__(SB_T) void lbd_sobel_kernel(LbdDev o) {
+    const int b = blockIdx.z, x = (blockIdx.x * SB_T + threadIdx.x) * 4, y0 = blockIdx.y * SB_R;
     if (x >= o.cols) return;
     const uint8_t* img = o.blur + (size_t)b * o.rows * o.cols;
-    const uint8_t* r0 = img + (size_t)reflect101(y - 1, o.rows) * o.cols;
-    const uint8_t* r1 = img + (size_t)y * o.cols;
-    const uint8_t* r2 = img + (size_t)reflect101(y + 1, o.rows) * o.cols;
-    const int xm = reflect101(x - 1, o.cols), xp = reflect101(x + 1, o.cols);
-    const size_t k = ((size_t)b * o.rows + y) * o.cols + x;
-    const int gx = ((int)r0[xp] + 2 * (int)r1[xp] + (int)r2[xp]) - ((int)r0[xm] + 2 * (int)r1[xm] + (int)r2[xm]);
-    const int gy = ((int)r2[xm] + 2 * (int)r2[x] + (int)r2[xp]) - ((int)r0[xm] + 2 * (int)r0[x] + (int)r0[xp]);
-    o.dxy[k] = (int32_t)(((uint32_t)gx & 0xFFFFu) | ((uint32_t)gy << 16));  // (|g| <= 1020: int16 halves)
+    int32_t* out = o.dxy + (size_t)b * o.rows * o.cols;
+    const bool inner = x >= 1 && x + 5 <= o.cols;
+    int xr[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) xr[i] = reflect101(x - 1 + i, o.cols);
+    int hx[3][4], sx[3][4];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) hx[j][i] = sx[j][i] = 0;
+#pragma unroll
+    for (int r = 0; r < SB_R + 2; ++r) {
+        const int yo = y0 + r - 2;  // the output row completed by this input row
+        if (r >= 2 && yo >= o.rows) break;  // uniform over the workgroup
+        const uint8_t* row = img + (size_t)reflect101(y0 + r - 1, o.rows) * o.cols;
+        int p[6];
+        if (inner) {
+            const uint32_t wa = *reinterpret_cast<const lbd_u32_unaligned*>(row + x - 1), wb = *reinterpret_cast<const lbd_u32_unaligned*>(row + x + 1);
+            p[0] = (int)(wa & 0xFFu); p[1] = (int)((wa >> 8) & 0xFFu); p[2] = (int)((wa >> 16) & 0xFFu); p[3] = (int)(wa >> 24);
+            p[4] = (int)((wb >> 16) & 0xFFu); p[5] = (int)(wb >> 24);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) p[i] = (int)row[xr[i]];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            hx[0][i] = hx[1][i]; hx[1][i] = hx[2][i];
+            sx[0][i] = sx[1][i]; sx[1][i] = sx[2][i];
+            hx[2][i] = p[i + 2] - p[i];
+            sx[2][i] = p[i] + 2 * p[i + 1] + p[i + 2];
+        }
+        if (r >= 2) {
+            int32_t* dst = out + (size_t)yo * o.cols + x;
+            int32_t g[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int gx = hx[0][i] + 2 * hx[1][i] + hx[2][i], gy = sx[2][i] - sx[0][i];
+                g[i] = (int32_t)(((uint32_t)gx & 0xFFFFu) | ((uint32_t)gy << 16));  // (|g| <= 1020: int16 halves)
+            }
+            if (x + 4 <= o.cols) {  // one 16-byte store (word-aligned: the rows of an image of odd width are not 16-byte aligned)
+                lbd_i32x4_a4 v;
+                v.x = g[0]; v.y = g[1]; v.z = g[2]; v.w = g[3];
+                *reinterpret_cast<lbd_i32x4_a4*>(dst) = v;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (x + i < o.cols) dst[i] = g[i];
+            }
+        }
+    }
 }
 
 constexpr int LBD_LINES_PER_WG = 4;
@@ -309,9 +340,11 @@ int stvo_lbd_compute_dev(stvo_lbd* o, const uint8_t* images, const stvo_keyline*
     stvo::LbdDev d = o->d;
     d.img = images; d.lines = lines; d.n_lines = n_lines; d.desc = desc; d.desc_f = desc_float;
     hipStream_t s = ctx->stream;
-    const dim3 px((d.cols + 255) / 256, d.rows, d.B);
-    hipLaunchKernelGGL(stvo::lbd_blur5_kernel, px, dim3(256), 0, s, d);
-    hipLaunchKernelGGL(stvo::lbd_sobel_kernel, px, dim3(256), 0, s, d);
+    {   // GaussianBlur(5 x 5, sigma 1): the shared 7-tap blur with zero outer weights (the same fixed-point arithmetic: weights x 2^8 per pass, (s + 2^15) >> 16)
+        const int k7[7] = {0, d.k5[0], d.k5[1], d.k5[2], d.k5[3], d.k5[4], 0};
+        stvo::launch_blur7_u8(s, d.B, d.cols, d.rows, images, d.blur, k7);
+    }
+    hipLaunchKernelGGL(stvo::lbd_sobel_kernel, dim3((d.cols + 4 * stvo::SB_T - 1) / (4 * stvo::SB_T), (d.rows + stvo::SB_R - 1) / stvo::SB_R, d.B), dim3(stvo::SB_T), 0, s, d);
     hipLaunchKernelGGL(stvo::lbd_describe_kernel, dim3((d.M + stvo::LBD_LINES_PER_WG - 1) / stvo::LBD_LINES_PER_WG, d.B),
                        dim3(64 * stvo::LBD_LINES_PER_WG), 0, s, d);
     return check_launch(ctx);
