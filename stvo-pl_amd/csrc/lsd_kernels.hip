@@ -16,6 +16,8 @@
 //                        7 consecutive region points are fetched by 63 lanes at once (one memory round trip per 7 points) and
 //                        then resolved in order with ballots; the sums of region2rect are accumulated strictly in region
 //                        order (lane-parallel products, serial additions through v_readlane), so every rounding is the oracle's
+//   lsd_grow_xcd_kernel  the same search for batches of <= 128 images as an exact speculate / commit protocol over the CUs of one XCD per
+//                        image: a committing wave (LDS bitmap), a dispatcher, a feeder, speculating workgroups (9 ms instead of 63 per image)
 //   lsd_keylines_kernel  the wrapper: checkLineExtremes, length, min_length, KeyLine fields, top-N by response (stable)
 // Byte / integer work except where the source computes in floating point; no fused multiply-adds outside the two of the sine /
 // cosine reduction, which the oracle has too.
