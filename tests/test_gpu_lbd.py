@@ -25,7 +25,8 @@ def same_bits(a, b):
     return a.shape == b.shape and np.array_equal(a.view(np.uint8), b.view(np.uint8))
 
 
-@pytest.mark.parametrize("cols,rows,n", [(1241, 376, 100), (752, 480, 300), (320, 200, 512)])
+@pytest.mark.parametrize("cols,rows,n", [(1241, 376, 100), (752, 480, 300), (320, 200, 512),
+                                         (258, 67, 40), (259, 66, 40), (35, 21, 12), (24, 23, 16)])  # (widths of every residue mod 4, images a few words wide: the borders of the four-pixel blur / Sobel)
 def test_lbd_bit_exact(hip, oracle, cols, rows, n):
     from stvo_amd import capi
     B = 2
