@@ -48,6 +48,13 @@ inline bool hip_ok(stvo_ctx* ctx, hipError_t e, const char* what) {
         if (!hip_ok((ctx), (call), #call)) return STVO_ERR_HIP; \
     } while (0)
 
+// Zeroes freshly allocated device memory ON THE CONTEXT'S STREAM and waits.  hipMemset runs on the null stream, which the context's
+// non-blocking stream does not wait for, and it may return before the fill has run: a first call that followed at once had its
+// host-to-device copy land UNDER the fill (the first image of a new detector came out empty on some boxes of the pool).
+inline bool zero_device(stvo_ctx* ctx, void* p, size_t bytes, const char* what) {
+    return hip_ok(ctx, hipMemsetAsync(p, 0, bytes, ctx->stream), what) && hip_ok(ctx, hipStreamSynchronize(ctx->stream), what);
+}
+
 template <typename T>
 inline T* arena_alloc(stvo_ctx* ctx, size_t count) {
     size_t bytes = (count * sizeof(T) + 255) & ~size_t(255);

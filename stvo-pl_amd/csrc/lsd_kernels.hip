@@ -1780,7 +1780,7 @@ int stvo_lsd_create(stvo_ctx* ctx, int B, int cols, int rows, int max_keylines, 
                  o_order = c.take(nb * npx * 4), o_reg = c.take(nb * npx * 4), o_kmax = c.take(nb * 4), o_seg = c.take(nb * d.seg_cap * 16),
                  o_nseg = c.take(nb * 4), o_lines = c.take(nb * d.K * sizeof(stvo_keyline)),
                  o_resp = c.take(nb * d.K * 4), o_nl = c.take(nb * 4), o_np = c.take(nb * 4);
-    bool ok = hip_ok(ctx, hipMalloc((void**)&o->dev, c.off), "hipMalloc lsd") && hip_ok(ctx, hipMemset(o->dev, 0, c.off), "hipMemset lsd");
+    bool ok = hip_ok(ctx, hipMalloc((void**)&o->dev, c.off), "hipMalloc lsd") && zero_device(ctx, o->dev, c.off, "hipMemset lsd");
     if (ok) {
         char* D = o->dev;
         o->blur = (uint8_t*)(D + o_blur); o->scaled = (uint8_t*)(D + o_scaled); o->img = (uint8_t*)(D + o_img);
@@ -1870,7 +1870,7 @@ extern "C" int stvo_lsd_debug(stvo_lsd* o, int enable, double* out /* [seg_cap][
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (enable && !o->dbg) {
         HIP_TRY(ctx, hipMalloc((void**)&o->dbg, (size_t)o->d.B * o->d.seg_cap * 64));
-        HIP_TRY(ctx, hipMemset(o->dbg, 0, (size_t)o->d.B * o->d.seg_cap * 64));
+        if (!zero_device(ctx, o->dbg, (size_t)o->d.B * o->d.seg_cap * 64, "hipMemset lsd dbg")) return STVO_ERR_HIP;
     }
     o->d.dbg = enable ? o->dbg : nullptr;
     if (out && o->dbg) HIP_TRY(ctx, hipMemcpy(out, o->dbg, (size_t)o->d.seg_cap * 64, hipMemcpyDeviceToHost));

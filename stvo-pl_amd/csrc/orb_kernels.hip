@@ -906,7 +906,7 @@ int stvo_orb_create(stvo_ctx* ctx, int B, int cols, int rows, int max_keypoints,
         off_img[l] = total; if (l) total += al(px);
         off_out[l] = total; if (nlevels > 1) total += al(nk * 8) + 2 * al(nk * 4) + al(nk * 32) + 2 * al((size_t)B * 4);
     }
-    if (!hip_ok(ctx, hipMalloc((void**)&o->dev, total), "hipMalloc orb") || !hip_ok(ctx, hipMemset(o->dev, 0, total), "hipMemset orb")) {
+    if (!hip_ok(ctx, hipMalloc((void**)&o->dev, total), "hipMalloc orb") || !zero_device(ctx, o->dev, total, "hipMemset orb")) {
         if (o->dev) (void)hipFree(o->dev);
         delete o;
         return STVO_ERR_HIP;

@@ -859,7 +859,7 @@ int stvo_seq_create_multi(stvo_ctx* ctx, int B, int max_keypoints, int max_keyli
     }
     s->dev_bytes = c.off;
     bool ok = hip_ok(ctx, hipMalloc((void**)&s->dev, s->dev_bytes), "hipMalloc seq") &&
-              hip_ok(ctx, hipMemset(s->dev, 0, s->dev_bytes), "hipMemset seq") &&
+              zero_device(ctx, s->dev, s->dev_bytes, "hipMemset seq") &&
               hip_ok(ctx, hipHostMalloc((void**)&s->raw_host[0], s->raw_bytes, hipHostMallocDefault), "hipHostMalloc seq") &&
               hip_ok(ctx, hipHostMalloc((void**)&s->raw_host[1], s->raw_bytes, hipHostMallocDefault), "hipHostMalloc seq") &&
               hip_ok(ctx, hipHostMalloc((void**)&s->out_host, nb * (sizeof(stvo_pose_result) + 16), hipHostMallocDefault),
@@ -996,7 +996,7 @@ int stvo_seq_set_slots(stvo_seq* s, int n_slots) {
     s->raw_split.assign(2, 0);
     if (n_slots > 2) {
         HIP_TRY(ctx, hipMalloc((void**)&s->extra_raw, (size_t)(n_slots - 2) * s->raw_bytes));
-        HIP_TRY(ctx, hipMemset(s->extra_raw, 0, (size_t)(n_slots - 2) * s->raw_bytes));
+        if (!zero_device(ctx, s->extra_raw, (size_t)(n_slots - 2) * s->raw_bytes, "hipMemset seq raw")) return STVO_ERR_HIP;
         for (int k = 2; k < n_slots; ++k) {
             s->raw_dev.push_back(s->extra_raw + (size_t)(k - 2) * s->raw_bytes);
             s->raw_lines.push_back(0);

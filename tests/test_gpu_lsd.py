@@ -92,10 +92,28 @@ def test_lsd_many_waves_and_one_wave_per_image_are_the_same(hip, oracle, switche
         try:
             for _ in range(2):  # (the second call runs on the scratch the first one left)
                 segs, n = lsd.segments(imgs)
+                refs = [oracle.lsd_segments(imgs[b], oracle.lsd_opts(scale=scale)) for b in range(4)]
+                assert list(n) == [len(r) for r in refs], (scale, _)
                 for b in range(4):
-                    ref = oracle.lsd_segments(imgs[b], oracle.lsd_opts(scale=scale))
-                    assert n[b] == len(ref)
-                    assert np.array_equal(segs[b], ref)
+                    assert np.array_equal(segs[b], refs[b]), (scale, _, b)
+        finally:
+            lsd.close()
+
+
+def test_lsd_first_call_of_a_new_detector(hip, oracle):
+    """A detector's FIRST call right after its creation, many times over: the creation zeroes the detector's device memory, and that
+    fill has to be over before the first images arrive (it once ran on the null stream, which the context's non-blocking stream does
+    not wait for: on some boxes the first image of a new detector came back without a segment in about every second process)."""
+    from stvo_amd import capi
+    cols, rows, B = 640, 360, 20
+    rng = np.random.default_rng(57)
+    imgs = np.stack([rng.integers(0, 255, (rows, cols), dtype=np.uint8) if b % 5 == 0 else synth.make_image(680 + b, cols, rows) for b in range(B)])
+    refs = [len(oracle.lsd_segments(imgs[b], oracle.lsd_opts(scale=0.8))) for b in range(B)]
+    for rep in range(12):
+        lsd = capi.Lsd(hip, B, cols, rows, capi.lsd_params(min_length=4.0, nfeatures=0, scale=0.8), max_keylines=2048)
+        try:
+            _, n = lsd.segments(imgs)
+            assert list(n) == refs, rep
         finally:
             lsd.close()
 
