@@ -55,6 +55,11 @@ inline bool zero_device(stvo_ctx* ctx, void* p, size_t bytes, const char* what) 
     return hip_ok(ctx, hipMemsetAsync(p, 0, bytes, ctx->stream), what) && hip_ok(ctx, hipStreamSynchronize(ctx->stream), what);
 }
 
+// Set-up data to the device ON THE CONTEXT'S STREAM, complete on return (same reason: nothing of a context's set-up rides the null stream).
+inline bool upload_now(stvo_ctx* ctx, void* dst, const void* src, size_t bytes, const char* what) {
+    return hip_ok(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream), what) && hip_ok(ctx, hipStreamSynchronize(ctx->stream), what);
+}
+
 template <typename T>
 inline T* arena_alloc(stvo_ctx* ctx, size_t count) {
     size_t bytes = (count * sizeof(T) + 255) & ~size_t(255);

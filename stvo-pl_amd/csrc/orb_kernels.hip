@@ -931,7 +931,7 @@ int stvo_orb_create(stvo_ctx* ctx, int B, int cols, int rows, int max_keypoints,
         }
     }
     default_pattern(o->pattern);
-    if (!hip_ok(ctx, hipMemcpy(o->d_pattern, o->pattern, 1024, hipMemcpyHostToDevice), "hipMemcpy pattern")) {
+    if (!upload_now(ctx, o->d_pattern, o->pattern, 1024, "hipMemcpy pattern")) {
         (void)hipFree(o->dev);
         delete o;
         return STVO_ERR_HIP;
@@ -974,7 +974,7 @@ int stvo_orb_set_pattern(stvo_orb* o, const int8_t* pattern) {
     HIP_TRY(o->ctx, hipSetDevice(o->ctx->device));
     HIP_TRY(o->ctx, hipStreamSynchronize(o->ctx->stream));
     std::memcpy(o->pattern, pattern, 1024);
-    HIP_TRY(o->ctx, hipMemcpy(o->d_pattern, pattern, 1024, hipMemcpyHostToDevice));
+    if (!upload_now(o->ctx, o->d_pattern, o->pattern, 1024, "hipMemcpy pattern")) return STVO_ERR_HIP;
     return STVO_OK;
 }
 

@@ -914,9 +914,9 @@ int stvo_seq_create_multi(stvo_ctx* ctx, int B, int max_keypoints, int max_keyli
         }
         double qtab[stvo::STVO_POSE_QTAB];  // sqrt(sigma2) per pyramid level: the same operations as the kernels' own computation
         for (int l = 0; l < stvo::STVO_POSE_QTAB; ++l) qtab[l] = std::sqrt(pm::level_sigma2(l, s->mp.orb_scale_factor));
-        ok = hip_ok(ctx, hipMemcpy(s->d_qtab, qtab, sizeof(qtab), hipMemcpyHostToDevice), "hipMemcpy qtab") &&
-             hip_ok(ctx, hipMemcpy(s->d_cams, cams, nb * sizeof(stvo_cam), hipMemcpyHostToDevice), "hipMemcpy cams") &&
-             hip_ok(ctx, hipMemcpy(s->d_inv_wh, iw.data(), iw.size() * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy inv_wh");
+        ok = upload_now(ctx, s->d_qtab, qtab, sizeof(qtab), "hipMemcpy qtab") &&
+             upload_now(ctx, s->d_cams, cams, nb * sizeof(stvo_cam), "hipMemcpy cams") &&
+             upload_now(ctx, s->d_inv_wh, iw.data(), iw.size() * sizeof(double), "hipMemcpy inv_wh");
         if (!ok) {
             stvo_seq_destroy(s);
             return STVO_ERR_HIP;
@@ -1757,7 +1757,7 @@ int stvo_seq_set_motion_model(stvo_seq* s, int enable) {
         std::vector<double> I((size_t)s->B * 16, 0.0);
         for (int b = 0; b < s->B; ++b)
             for (int i = 0; i < 4; ++i) I[(size_t)b * 16 + i * 5] = 1.0;
-        HIP_TRY(ctx, hipMemcpy(s->d_motion_T, I.data(), I.size() * sizeof(double), hipMemcpyHostToDevice));
+        if (!upload_now(ctx, s->d_motion_T, I.data(), I.size() * sizeof(double), "hipMemcpy motion")) return STVO_ERR_HIP;
     }
     for (auto& g : s->graphs) (void)hipGraphExecDestroy(g.second);  // captured steps hold the old init_T pointer
     s->graphs.clear();

@@ -539,6 +539,7 @@ int stvo_time_stage_dev(stvo_ctx* ctx, const stvo_track_batch_dev* b, const stvo
         a.prof_out = dprof;
         stvo::launch_pose(ctx->stream, a);
         std::vector<long long> h((size_t)b->B * 16);
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // (the copy below rides the null stream, which does not wait for this one)
         HIP_TRY(ctx, hipMemcpy(h.data(), dprof, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
         double m[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         for (int f = 0; f < b->B; ++f)
