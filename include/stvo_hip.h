@@ -286,20 +286,22 @@ int stvo_lbd_compute_dev(stvo_lbd* lbd, const uint8_t* images, const stvo_keylin
 /* Replaces  lsd->detect(img, lines, Config::lsdScale(), 1, opts)  + the top-N cut by response of StereoFrame::detectLineFeatures
  * (src/stereoFrame.cpp:219-240; LSDDetectorC::detectImpl, 3rdparty/line_descriptor/src/LSDDetector_custom.cpp:227-325, one
  * octave) for B images of cols x rows bytes: cv::LineSegmentDetector — third-party code the reference does not hold — as restated
- * in oracle/stvo_lsd_oracle.c from the published algorithm (parity unpinned), lsd_refine = 0 only (what every shipped
- * configuration uses; other values: STVO_ERR_UNSUPPORTED), images up to 2^20 pixels after scaling.  Blur, resize, gradient /
+ * in oracle/stvo_lsd_oracle.c from the published algorithm (parity unpinned), lsd_refine = 0 (LSD_REFINE_NONE: what every
+ * shipped configuration uses) or 1 (LSD_REFINE_STD: a region too sparse for its rectangle is given back, grown again under a tolerance
+ * from the angles near its seed and cut back by radius — one wavefront per image for every batch size, since flags then also turn
+ * off); 2 (LSD_REFINE_ADV: rect_improve + the NFA test): STVO_ERR_UNSUPPORTED.  Images up to 2^20 pixels after scaling.  Blur, resize, gradient /
  * level-line angles and the pseudo-ordering are data-parallel kernels; region growing is inherently sequential per image (a
  * pixel joins a region depending on the running region angle and on what every earlier region took) and runs as ONE wavefront
  * per image, the images of the batch side by side. */
 typedef struct stvo_lsd_params {
-    int32_t refine;        /* Config::lsdRefine()      0 */
+    int32_t refine;        /* Config::lsdRefine()      0 (or 1) */
     int32_t n_bins;        /* Config::lsdNBins()       1024 (1 .. 2048; more: STVO_ERR_UNSUPPORTED) */
     double scale;          /* Config::lsdScale()       1.2 */
     double sigma_scale;    /* Config::lsdSigmaScale()  0.6 */
     double quant;          /* Config::lsdQuant()       2.0 */
     double ang_th;         /* Config::lsdAngTh()       22.5 */
-    double log_eps;        /* Config::lsdLogEps()      (unused with refine 0) */
-    double density_th;     /* Config::lsdDensityTh()   (unused with refine 0) */
+    double log_eps;        /* Config::lsdLogEps()      (unused: it belongs to refine 2) */
+    double density_th;     /* Config::lsdDensityTh()   0.6 (read with refine 1) */
     double min_length;     /* LSDOptions::min_length = min_line_length x min(cols, rows) (stereoFrame.cpp:78) */
     int32_t nfeatures;     /* Config::lsdNFeatures()   300, 0: keep all */
     int32_t reserved;

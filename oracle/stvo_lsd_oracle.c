@@ -215,10 +215,171 @@ static double angle_diff(double a, double b) {
     return fabs(diff);
 }
 
+static double angle_diff_signed(double a, double b) {
+    double diff = a - b;
+    while (diff <= -LSD_PI) diff += LSD_M_2_PI;
+    while (diff > LSD_PI) diff -= LSD_M_2_PI;
+    return diff;
+}
+
+/* what the search works on (one image) */
+typedef struct {
+    int w, h;
+    const double* angles;
+    const double* modgrad;
+    uint8_t* used;
+    int32_t* reg;       /* the current region: pixel indices in the order they joined */
+    double dbg[8];      /* region2rect's intermediates of the last rectangle (orc_lsd_set_debug) */
+} lsd_search;
+
+/* region_grow: the region of `seed` under the angle tolerance `prec`; returns its size, the list in c->reg, its angle in *reg_angle_out */
+static int region_grow(lsd_search* c, int32_t seed, double prec, double* reg_angle_out) {
+    const int w = c->w, h = c->h;
+    int32_t* reg = c->reg;
+    int n_reg = 0;
+    double reg_angle = c->angles[seed];
+    reg[n_reg++] = seed;
+    double sn, cs;
+    orc_sincos_det(reg_angle, &sn, &cs);
+    float sumdx = (float)cs, sumdy = (float)sn;
+    c->used[seed] = 1;
+    for (int i = 0; i < n_reg; ++i) {
+        const int px = reg[i] % w, py = reg[i] / w;
+        const int xx_min = px - 1 > 0 ? px - 1 : 0, xx_max = px + 1 < w - 1 ? px + 1 : w - 1;
+        const int yy_min = py - 1 > 0 ? py - 1 : 0, yy_max = py + 1 < h - 1 ? py + 1 : h - 1;
+        for (int yy = yy_min; yy <= yy_max; ++yy)
+            for (int xx = xx_min; xx <= xx_max; ++xx) {
+                const size_t q = (size_t)yy * w + xx;
+                if (!c->used[q] && is_aligned(c->angles, w, h, xx, yy, reg_angle, prec)) {
+                    const double angle = c->angles[q];
+                    c->used[q] = 1;
+                    reg[n_reg++] = (int32_t)q;
+                    orc_sincos_det((double)(float)angle, &sn, &cs); /* cos(float(angle)), sin(float(angle)) */
+                    sumdx += (float)cs;
+                    sumdy += (float)sn;
+                    reg_angle = orc_fast_atan2(sumdy, sumdx) * LSD_DEG_TO_RADS;
+                }
+            }
+    }
+    *reg_angle_out = reg_angle;
+    return n_reg;
+}
+
+/* region2rect: the rectangle of the region c->reg[0 .. n_reg) (coordinates of the scaled image, no offset yet) */
+static void region2rect(lsd_search* c, int n_reg, double reg_angle, double prec, lsd_rect* rec) {
+    const int w = c->w;
+    const int32_t* reg = c->reg;
+    double x = 0, y = 0, sum = 0;
+    for (int i = 0; i < n_reg; ++i) {
+        const double weight = c->modgrad[reg[i]];
+        x += (double)(reg[i] % w) * weight;
+        y += (double)(reg[i] / w) * weight;
+        sum += weight;
+    }
+    x /= sum;
+    y /= sum;
+    double Ixx = 0.0, Iyy = 0.0, Ixy = 0.0;
+    for (int i = 0; i < n_reg; ++i) {
+        const double weight = c->modgrad[reg[i]];
+        const double ddx = (double)(reg[i] % w) - x, ddy = (double)(reg[i] / w) - y;
+        Ixx += ddy * ddy * weight;
+        Iyy += ddx * ddx * weight;
+        Ixy -= ddx * ddy * weight;
+    }
+    const double lambda = 0.5 * (Ixx + Iyy - sqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
+    double theta = (fabs(Ixx) > fabs(Iyy)) ? (double)orc_fast_atan2((float)(lambda - Ixx), (float)Ixy)
+                                           : (double)orc_fast_atan2((float)Ixy, (float)(lambda - Iyy));
+    theta *= LSD_DEG_TO_RADS;
+    if (angle_diff(theta, reg_angle) > prec) theta += LSD_PI;
+    double dx, dy;
+    orc_sincos_det(theta, &dy, &dx);
+    double l_min = 0, l_max = 0, w_min = 0, w_max = 0;
+    for (int i = 0; i < n_reg; ++i) {
+        const double regdx = (double)(reg[i] % w) - x, regdy = (double)(reg[i] / w) - y;
+        const double l = regdx * dx + regdy * dy;
+        const double ww = -regdx * dy + regdy * dx;
+        if (l > l_max) l_max = l;
+        else if (l < l_min) l_min = l;
+        if (ww > w_max) w_max = ww;
+        else if (ww < w_min) w_min = ww;
+    }
+    rec->x1 = x + l_min * dx;
+    rec->y1 = y + l_min * dy;
+    rec->x2 = x + l_max * dx;
+    rec->y2 = y + l_max * dy;
+    rec->width = w_max - w_min;
+    if (rec->width < 1.0) rec->width = 1.0;
+    c->dbg[0] = x; c->dbg[1] = y; c->dbg[2] = Ixx; c->dbg[3] = Iyy; c->dbg[4] = Ixy; c->dbg[5] = theta; c->dbg[6] = l_min; c->dbg[7] = l_max;
+}
+
+static double lsd_dist(double x1, double y1, double x2, double y2) { return sqrt((x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1)); }
+static double lsd_dist_sq(double x1, double y1, double x2, double y2) { return (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1); }
+static double lsd_density(const lsd_rect* rec, int n_reg) { return (double)n_reg / (lsd_dist(rec->x1, rec->y1, rec->x2, rec->y2) * rec->width); }
+
+/* reduce_region_radius (lsd_refine >= 1): while the region is too sparse for its rectangle, drop the points farther than 75 % of
+ * the current radius from the seed (a dropped point is free again; the last point of the list takes its place), fit again.
+ * Returns the new size, 0 when fewer than two points are left (the region is given up). */
+static int reduce_region_radius(lsd_search* c, int n_reg, double reg_angle, double prec, lsd_rect* rec, double density, double density_th) {
+    const int w = c->w;
+    int32_t* reg = c->reg;
+    const double xc = (double)(reg[0] % w), yc = (double)(reg[0] / w);
+    const double r1 = lsd_dist_sq(xc, yc, rec->x1, rec->y1), r2 = lsd_dist_sq(xc, yc, rec->x2, rec->y2);
+    double rad_sq = r1 > r2 ? r1 : r2;
+    while (density < density_th) {
+        rad_sq *= 0.75 * 0.75;
+        for (int i = 0; i < n_reg; ++i)
+            if (lsd_dist_sq(xc, yc, (double)(reg[i] % w), (double)(reg[i] / w)) > rad_sq) {
+                c->used[reg[i]] = 0;
+                const int32_t t = reg[i];
+                reg[i] = reg[n_reg - 1];
+                reg[n_reg - 1] = t;
+                --n_reg;
+                --i; /* the point that took the place is looked at next */
+            }
+        if (n_reg < 2) return 0;
+        region2rect(c, n_reg, reg_angle, prec, rec);
+        density = lsd_density(rec, n_reg);
+    }
+    return n_reg;
+}
+
+/* refine (lsd_refine >= 1): a region dense enough for its rectangle stays; otherwise it is grown again from the same seed under a
+ * tolerance of twice the standard deviation of the angles near the seed, and, if still too sparse, cut back by radius.
+ * Returns the new size (*reg_angle_io updated), 0 when the region is given up. */
+static int refine_region(lsd_search* c, int n_reg, double* reg_angle_io, double prec, lsd_rect* rec, double density_th) {
+    const int w = c->w;
+    int32_t* reg = c->reg;
+    double density = lsd_density(rec, n_reg);
+    if (density >= density_th) return n_reg;
+    const double xc = (double)(reg[0] % w), yc = (double)(reg[0] / w);
+    const double ang_c = c->angles[reg[0]];
+    double sum = 0, s_sum = 0;
+    int n = 0;
+    for (int i = 0; i < n_reg; ++i) {
+        c->used[reg[i]] = 0;
+        if (lsd_dist(xc, yc, (double)(reg[i] % w), (double)(reg[i] / w)) < rec->width) {
+            const double ang_d = angle_diff_signed(c->angles[reg[i]], ang_c);
+            sum += ang_d;
+            s_sum += ang_d * ang_d;
+            ++n;
+        }
+    }
+    const double mean_angle = sum / (double)n; /* (the seed itself is always within the width: n >= 1) */
+    const double tau = 2.0 * sqrt((s_sum - 2.0 * mean_angle * sum) / (double)n + mean_angle * mean_angle);
+    n_reg = region_grow(c, reg[0], tau, reg_angle_io);
+    if (n_reg < 2) return 0;
+    region2rect(c, n_reg, *reg_angle_io, prec, rec);
+    density = lsd_density(rec, n_reg);
+    if (density < density_th) return reduce_region_radius(c, n_reg, *reg_angle_io, prec, rec, density, density_th);
+    return n_reg;
+}
+
 /* The detector core on an 8-bit image: segments (x1, y1, x2, y2) as cv::Vec4f in the coordinates of `img`, in detection order.
- * Returns the number found (all of them are counted, at most `cap` are stored), or < 0 on error. */
+ * Returns the number found (all of them are counted, at most `cap` are stored), or < 0 on error.
+ * lsd_refine: 0 (LSD_REFINE_NONE) and 1 (LSD_REFINE_STD: refine / reduce_region_radius above); 2 (LSD_REFINE_ADV: rect_improve + the
+ * NFA test) is not restated. */
 int orc_lsd_segments(const uint8_t* img, int cols, int rows, const orc_lsd_opts* o, float* seg /* [cap][4] */, int cap) {
-    if (o->refine != 0) return STVO_ERR_UNSUPPORTED;
+    if (o->refine != 0 && o->refine != 1) return STVO_ERR_UNSUPPORTED;
     const double prec = LSD_PI * o->ang_th / 180;
     const double rho = orc_lsd_rho(o->quant, o->ang_th);
     int w = cols, h = rows;
@@ -280,88 +441,27 @@ int orc_lsd_segments(const uint8_t* img, int cols, int rows, const orc_lsd_opts*
     free(bin_start);
     /* ---- the search ---- */
     const int min_reg_size = orc_lsd_min_reg_size(w, h, o->ang_th);
+    lsd_search c;
+    c.w = w; c.h = h; c.angles = angles; c.modgrad = modgrad; c.used = used; c.reg = reg;
     int n_seg = 0;
     for (size_t oi = 0; oi < n_order; ++oi) {
         const int32_t seed = order[oi];
         if (used[seed] || angles[seed] == LSD_NOTDEF) continue;
-        /* region_grow */
-        int n_reg = 0;
-        double reg_angle = angles[seed];
-        reg[n_reg++] = seed;
-        double sn, cs;
-        orc_sincos_det(reg_angle, &sn, &cs);
-        float sumdx = (float)cs, sumdy = (float)sn;
-        used[seed] = 1;
-        for (int i = 0; i < n_reg; ++i) {
-            const int px = reg[i] % w, py = reg[i] / w;
-            const int xx_min = px - 1 > 0 ? px - 1 : 0, xx_max = px + 1 < w - 1 ? px + 1 : w - 1;
-            const int yy_min = py - 1 > 0 ? py - 1 : 0, yy_max = py + 1 < h - 1 ? py + 1 : h - 1;
-            for (int yy = yy_min; yy <= yy_max; ++yy)
-                for (int xx = xx_min; xx <= xx_max; ++xx) {
-                    const size_t q = (size_t)yy * w + xx;
-                    if (!used[q] && is_aligned(angles, w, h, xx, yy, reg_angle, prec)) {
-                        const double angle = angles[q];
-                        used[q] = 1;
-                        reg[n_reg++] = (int32_t)q;
-                        orc_sincos_det((double)(float)angle, &sn, &cs); /* cos(float(angle)), sin(float(angle)) */
-                        sumdx += (float)cs;
-                        sumdy += (float)sn;
-                        reg_angle = orc_fast_atan2(sumdy, sumdx) * LSD_DEG_TO_RADS;
-                    }
-                }
-        }
+        double reg_angle;
+        int n_reg = region_grow(&c, seed, prec, &reg_angle);
         if (n_reg < min_reg_size) continue;
-        /* region2rect */
-        double x = 0, y = 0, sum = 0;
-        for (int i = 0; i < n_reg; ++i) {
-            const double weight = modgrad[reg[i]];
-            x += (double)(reg[i] % w) * weight;
-            y += (double)(reg[i] / w) * weight;
-            sum += weight;
-        }
-        x /= sum;
-        y /= sum;
-        double Ixx = 0.0, Iyy = 0.0, Ixy = 0.0;
-        for (int i = 0; i < n_reg; ++i) {
-            const double weight = modgrad[reg[i]];
-            const double ddx = (double)(reg[i] % w) - x, ddy = (double)(reg[i] / w) - y;
-            Ixx += ddy * ddy * weight;
-            Iyy += ddx * ddx * weight;
-            Ixy -= ddx * ddy * weight;
-        }
-        const double lambda = 0.5 * (Ixx + Iyy - sqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
-        double theta = (fabs(Ixx) > fabs(Iyy)) ? (double)orc_fast_atan2((float)(lambda - Ixx), (float)Ixy)
-                                               : (double)orc_fast_atan2((float)Ixy, (float)(lambda - Iyy));
-        theta *= LSD_DEG_TO_RADS;
-        if (angle_diff(theta, reg_angle) > prec) theta += LSD_PI;
-        double dx, dy;
-        orc_sincos_det(theta, &dy, &dx);
-        double l_min = 0, l_max = 0, w_min = 0, w_max = 0;
-        for (int i = 0; i < n_reg; ++i) {
-            const double regdx = (double)(reg[i] % w) - x, regdy = (double)(reg[i] / w) - y;
-            const double l = regdx * dx + regdy * dy;
-            const double ww = -regdx * dy + regdy * dx;
-            if (l > l_max) l_max = l;
-            else if (l < l_min) l_min = l;
-            if (ww > w_max) w_max = ww;
-            else if (ww < w_min) w_min = ww;
-        }
         lsd_rect rec;
-        rec.x1 = x + l_min * dx;
-        rec.y1 = y + l_min * dy;
-        rec.x2 = x + l_max * dx;
-        rec.y2 = y + l_max * dy;
-        rec.width = w_max - w_min;
-        if (rec.width < 1.0) rec.width = 1.0;
+        region2rect(&c, n_reg, reg_angle, prec, &rec);
+        if (o->refine >= 1) {
+            n_reg = refine_region(&c, n_reg, &reg_angle, prec, &rec, o->density_th);
+            if (n_reg == 0) continue;
+        }
         /* found: the offset, then back to the coordinates of the input image */
         rec.x1 += 0.5; rec.y1 += 0.5; rec.x2 += 0.5; rec.y2 += 0.5;
         if (o->scale != 1) {
             rec.x1 /= o->scale; rec.y1 /= o->scale; rec.x2 /= o->scale; rec.y2 /= o->scale;
         }
-        if (orc_lsd_debug_out && n_seg < cap) {
-            double* q = orc_lsd_debug_out + 8 * (size_t)n_seg;
-            q[0] = x; q[1] = y; q[2] = Ixx; q[3] = Iyy; q[4] = Ixy; q[5] = theta; q[6] = l_min; q[7] = l_max;
-        }
+        if (orc_lsd_debug_out && n_seg < cap) memcpy(orc_lsd_debug_out + 8 * (size_t)n_seg, c.dbg, sizeof(c.dbg));
         if (n_seg < cap) {
             seg[4 * n_seg + 0] = (float)rec.x1;
             seg[4 * n_seg + 1] = (float)rec.y1;

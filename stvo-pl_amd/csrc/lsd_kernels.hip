@@ -666,6 +666,307 @@ __global__ __launch_bounds__(64) void lsd_grow_kernel(LsdDev d) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
+// lsd_refine = 1 (LSD_REFINE_STD; oracle/stvo_lsd_oracle.c: refine_region / reduce_region_radius): a region too sparse for its rectangle
+// is given back (its pixels are FREE again), grown once more from the same seed under a tolerance of twice the standard deviation of
+// the angles near the seed and, if still too sparse, cut back to 75 % of its radius until it is dense enough or gone.  Flags that turn
+// OFF break what the other forms of the search rely on (a batch's seeds struck off for good, speculation against flags that only ever
+// turn on), so this mode has its own kernel: one wave per image, the direct statement of the oracle's loops (the plain form above)
+// with the growth and the rectangle as routines, for every batch size.  No shipped configuration uses the mode (config/*.yaml:
+// lsd_refine : 0); it is there so that a caller who sets it gets the detector it asked for rather than an error.
+struct LsdRect {
+    double x1, y1, x2, y2, width;
+};
+__global__ __launch_bounds__(64) void lsd_grow_refine_kernel(LsdDev d, const double density_th) {
+    __shared__ int s_ring[LSD_RING];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int w = d.w, h = d.h, npx = w * h;
+    const size_t base = (size_t)b * npx;
+    LsdPx* px = d.px + base;
+    const int32_t* __restrict__ k32 = d.k32 + base;
+    const uint32_t* __restrict__ order = d.order + base;
+    int32_t* reg = d.reg + base;
+    const double prec = d.prec;
+    int n_seg = 0;
+    int q_l = 0;
+    bool key_ok = false;
+    unsigned long long todo = 0ull;
+
+    // region_grow from `seed` (angle ang_deg) under the tolerance tol: the list in reg (and the ring), the size returned
+    auto grow = [&](const int seed, const float ang_deg, const double tol, double& reg_angle) -> int {
+        const int sx0 = seed % w, sy0 = seed / w;
+        reg_angle = (double)ang_deg * LSD_DEG2RAD;
+        double sn0, cs0;
+        sincos_det(reg_angle, sn0, cs0);
+        float sumdx = (float)cs0, sumdy = (float)sn0;
+        int n_reg = 1;
+        if (lane == 0) {
+            st_coherent(&px[seed].used, 1);
+            st_coherent(reg, sx0 | (sy0 << 16));
+            s_ring[0] = sx0 | (sy0 << 16);
+        }
+        for (int i = 0; i < n_reg;) {
+            wave_publish();
+            const int cnt = n_reg - i < 7 * LSD_GR ? n_reg - i : 7 * LSD_GR;  // uniform
+            const int slot0 = lane / 9, nb = lane - slot0 * 9;
+            int qq[LSD_GR], xy[LSD_GR];
+            float2 cs[LSD_GR];
+            double ad[LSD_GR];
+            bool cand[LSD_GR];
+#pragma unroll
+            for (int r = 0; r < LSD_GR; ++r) {
+                const int slot = 7 * r + slot0;
+                bool valid = lane < 63 && slot < cnt && nb != 4;  // (the centre is the region point itself)
+                int pxy = 0;
+                if (valid) pxy = (n_reg - (i + slot) <= LSD_RING) ? s_ring[(i + slot) & (LSD_RING - 1)] : ld_coherent(reg + i + slot);
+                const int xx = (pxy & 0xFFFF) + (nb % 3) - 1, yy = (pxy >> 16) + nb / 3 - 1;  // neighbours row by row
+                valid = valid && xx >= 0 && xx < w && yy >= 0 && yy < h;
+                qq[r] = valid ? yy * w + xx : 0;
+                xy[r] = xx | (yy << 16);
+                int u = 1;
+                float a = -1.f;
+                cs[r] = make_float2(0.f, 0.f);
+                if (valid) {
+                    const LsdPx t = px_ld(px + qq[r]);
+                    u = t.used;
+                    a = t.ang;
+                    cs[r] = make_float2(t.c, t.s);
+                }
+                cand[r] = valid && u == 0 && a >= 0.f;
+                ad[r] = (double)a * LSD_DEG2RAD;
+            }
+#pragma unroll
+            for (int r = 0; r < LSD_GR; ++r) {
+                if (7 * r >= cnt) break;  // uniform
+                int next = 0;  // lanes below `next` have had their turn
+                for (;;) {
+                    double n_theta = reg_angle - ad[r];  // isAligned
+                    if (n_theta < 0) n_theta = -n_theta;
+                    if (n_theta > LSD_3_2_PI) {
+                        n_theta -= LSD_2_PI;
+                        if (n_theta < 0) n_theta = -n_theta;
+                    }
+                    const unsigned long long m = __ballot(cand[r] && lane >= next && n_theta <= tol);
+                    if (!m || n_reg >= npx) break;
+                    const int L = __builtin_ctzll(m);
+                    const int qL = __builtin_amdgcn_readlane(qq[r], L), xyL = __builtin_amdgcn_readlane(xy[r], L);
+                    const float cL = readlane_f32(cs[r].x, L), sL = readlane_f32(cs[r].y, L);
+                    if (lane == 0) {
+                        st_coherent(&px[qL].used, 1);
+                        st_coherent(reg + n_reg, xyL);
+                        s_ring[n_reg & (LSD_RING - 1)] = xyL;
+                    }
+                    ++n_reg;
+#pragma unroll
+                    for (int r2 = 0; r2 < LSD_GR; ++r2) cand[r2] = cand[r2] && qq[r2] != qL;  // the same pixel seen from another point of the round
+                    todo &= ~__ballot(key_ok && q_l == qL);
+                    sumdx += cL;
+                    sumdy += sL;
+                    reg_angle = (double)fast_atan2_deg(sumdy, sumdx) * LSD_DEG2RAD;
+                    next = L + 1;
+                }
+            }
+            i += cnt;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // s_ring: lane 0's writes before the next round's reads
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        return n_reg;
+    };
+
+    // region2rect of reg[0 .. n_reg): every sum strictly in region order
+    auto rect = [&](const int n_reg, const double reg_angle) -> LsdRect {
+        wave_publish();
+        double X = 0.0, Y = 0.0, S = 0.0;
+        for (int c0 = 0; c0 < n_reg; c0 += 64) {
+            const int t = c0 + lane, cn = n_reg - c0 < 64 ? n_reg - c0 : 64;
+            int pxy = 0;
+            double wgt = 0.0;
+            if (t < n_reg) {
+                pxy = ld_coherent(reg + t);
+                wgt = sqrt((double)k32[(pxy >> 16) * w + (pxy & 0xFFFF)] / 4.0);
+            }
+            const double pxw = (double)(pxy & 0xFFFF) * wgt, pyw = (double)(pxy >> 16) * wgt;
+            for (int k = 0; k < cn; ++k) {
+                X += readlane_f64(pxw, k);
+                Y += readlane_f64(pyw, k);
+                S += readlane_f64(wgt, k);
+            }
+        }
+        const double cx = X / S, cy = Y / S;
+        double Ixx = 0.0, Iyy = 0.0, Ixy = 0.0;
+        for (int c0 = 0; c0 < n_reg; c0 += 64) {
+            const int t = c0 + lane, cn = n_reg - c0 < 64 ? n_reg - c0 : 64;
+            double t_xx = 0.0, t_yy = 0.0, t_xy = 0.0;
+            if (t < n_reg) {
+                const int pxy = ld_coherent(reg + t);
+                const double wgt = sqrt((double)k32[(pxy >> 16) * w + (pxy & 0xFFFF)] / 4.0);
+                const double ddx = (double)(pxy & 0xFFFF) - cx, ddy = (double)(pxy >> 16) - cy;
+                t_xx = ddy * ddy * wgt;
+                t_yy = ddx * ddx * wgt;
+                t_xy = ddx * ddy * wgt;
+            }
+            for (int k = 0; k < cn; ++k) {
+                Ixx += readlane_f64(t_xx, k);
+                Iyy += readlane_f64(t_yy, k);
+                Ixy -= readlane_f64(t_xy, k);
+            }
+        }
+        const double lambda = 0.5 * (Ixx + Iyy - sqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
+        double theta = (fabs(Ixx) > fabs(Iyy)) ? (double)fast_atan2_deg((float)(lambda - Ixx), (float)Ixy)
+                                               : (double)fast_atan2_deg((float)Ixy, (float)(lambda - Iyy));
+        theta *= LSD_DEG2RAD;
+        {
+            double diff = theta - reg_angle;  // angle_diff
+            while (diff <= -LSD_PI) diff += LSD_2_PI;
+            while (diff > LSD_PI) diff -= LSD_2_PI;
+            if (fabs(diff) > prec) theta += LSD_PI;
+        }
+        double dx, dy;
+        sincos_det(theta, dy, dx);
+        double l_min = 0.0, l_max = 0.0, w_min = 0.0, w_max = 0.0;
+        for (int t = lane; t < n_reg; t += 64) {
+            const int pxy = ld_coherent(reg + t);
+            const double rdx = (double)(pxy & 0xFFFF) - cx, rdy = (double)(pxy >> 16) - cy;
+            const double l = rdx * dx + rdy * dy, ww = -rdx * dy + rdy * dx;
+            l_max = l > l_max ? l : l_max;
+            l_min = l < l_min ? l : l_min;
+            w_max = ww > w_max ? ww : w_max;
+            w_min = ww < w_min ? ww : w_min;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {  // maxima / minima: any order
+            const double a0 = __shfl_xor(l_max, off, 64), a1 = __shfl_xor(l_min, off, 64), a2 = __shfl_xor(w_max, off, 64), a3 = __shfl_xor(w_min, off, 64);
+            l_max = a0 > l_max ? a0 : l_max;
+            l_min = a1 < l_min ? a1 : l_min;
+            w_max = a2 > w_max ? a2 : w_max;
+            w_min = a3 < w_min ? a3 : w_min;
+        }
+        LsdRect rc;
+        rc.x1 = cx + l_min * dx; rc.y1 = cy + l_min * dy; rc.x2 = cx + l_max * dx; rc.y2 = cy + l_max * dy;
+        rc.width = w_max - w_min;
+        if (rc.width < 1.0) rc.width = 1.0;
+        return rc;
+    };
+    auto dist_sq = [](double x1, double y1, double x2, double y2) { return (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1); };
+    auto density_of = [&](const LsdRect& rc, int n_reg) { return (double)n_reg / (sqrt(dist_sq(rc.x1, rc.y1, rc.x2, rc.y2)) * rc.width); };
+
+    for (int o0 = 0; o0 < npx; o0 += 64) {
+        const uint32_t key = o0 + lane < npx ? order[o0 + lane] : LSD_NOKEY;
+        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)key) == LSD_NOKEY) break;  // sorted: only undefined pixels from here on
+        q_l = (int)(key & ((1u << LSD_IDX_BITS) - 1u));
+        key_ok = key != LSD_NOKEY;
+        wave_publish();
+        const LsdPx seed_l = px_ld(px + (key_ok ? q_l : 0));
+        const float ang_l = key_ok ? seed_l.ang : -1.f;
+        todo = __ballot(key_ok && seed_l.used == 0);
+        while (todo) {
+            const int j = __builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            const int seed = __builtin_amdgcn_readlane(q_l, j);
+            const float seed_ang = readlane_f32(ang_l, j);
+            double reg_angle;
+            int n_reg = grow(seed, seed_ang, prec, reg_angle);
+            if (n_reg < d.min_reg_size) continue;
+            LsdRect rc = rect(n_reg, reg_angle);
+            double density = density_of(rc, n_reg);
+            if (!(density >= density_th)) {
+                // ---- refine: the angles near the seed (within the rectangle's width), every pixel of the region free again ----
+                const int xy0 = ld_coherent(reg);
+                const double xc = (double)(xy0 & 0xFFFF), yc = (double)(xy0 >> 16);
+                const double ang_c = (double)seed_ang * LSD_DEG2RAD;
+                double sum = 0.0, s_sum = 0.0;
+                int n = 0;
+                for (int c0 = 0; c0 < n_reg; c0 += 64) {
+                    const int t = c0 + lane, cn = n_reg - c0 < 64 ? n_reg - c0 : 64;
+                    bool in = false;
+                    double ang_d = 0.0;
+                    if (t < n_reg) {
+                        const int pxy = ld_coherent(reg + t);
+                        const int q = (pxy >> 16) * w + (pxy & 0xFFFF);
+                        const LsdPx tq = px_ld(px + q);
+                        st_coherent(&px[q].used, 0);
+                        in = sqrt(dist_sq(xc, yc, (double)(pxy & 0xFFFF), (double)(pxy >> 16))) < rc.width;
+                        double diff = (double)tq.ang * LSD_DEG2RAD - ang_c;  // angle_diff_signed
+                        while (diff <= -LSD_PI) diff += LSD_2_PI;
+                        while (diff > LSD_PI) diff -= LSD_2_PI;
+                        ang_d = diff;
+                    }
+                    const double sq = ang_d * ang_d;
+                    const unsigned long long in_m = __ballot(in);
+                    for (int k = 0; k < cn; ++k)
+                        if ((in_m >> k) & 1ull) {  // uniform
+                            sum += readlane_f64(ang_d, k);
+                            s_sum += readlane_f64(sq, k);
+                            ++n;
+                        }
+                }
+                const double mean_angle = sum / (double)n;
+                const double tau = 2.0 * sqrt((s_sum - 2.0 * mean_angle * sum) / (double)n + mean_angle * mean_angle);
+                n_reg = grow(seed, seed_ang, tau, reg_angle);
+                bool gone = n_reg < 2;
+                if (!gone) {
+                    rc = rect(n_reg, reg_angle);
+                    density = density_of(rc, n_reg);
+                    if (density < density_th) {
+                        // ---- reduce_region_radius: points farther than the (shrinking) radius from the seed leave, the LAST point of the
+                        // list takes a leaving point's place (and is looked at next) — one point after the other, as the oracle does
+                        const double r1 = dist_sq(xc, yc, rc.x1, rc.y1), r2 = dist_sq(xc, yc, rc.x2, rc.y2);
+                        double rad_sq = r1 > r2 ? r1 : r2;
+                        while (density < density_th) {
+                            rad_sq *= 0.75 * 0.75;
+                            wave_publish();
+                            for (int c0 = 0; c0 < n_reg; c0 += 64) {
+                                const int t = c0 + lane;
+                                const int pxy = t < n_reg ? ld_coherent(reg + t) : 0;
+                                const bool far = t < n_reg && dist_sq(xc, yc, (double)(pxy & 0xFFFF), (double)(pxy >> 16)) > rad_sq;
+                                unsigned long long far_m = __ballot(far);
+                                while (far_m) {
+                                    const int k = __builtin_ctzll(far_m);
+                                    far_m &= far_m - 1ull;
+                                    const int i = c0 + k;
+                                    if (i >= n_reg) break;  // (the list has shrunk below this position: its point left as a LAST point)
+                                    int out_xy = __builtin_amdgcn_readlane(pxy, k);
+                                    for (;;) {  // the point at position i leaves; the last point moves in and is tested in turn
+                                        if (lane == 0) st_coherent(&px[(out_xy >> 16) * w + (out_xy & 0xFFFF)].used, 0);
+                                        --n_reg;
+                                        if (i >= n_reg) break;  // (it was the last point itself)
+                                        const int last_xy = __builtin_amdgcn_readfirstlane(ld_coherent(reg + n_reg));
+                                        if (!(dist_sq(xc, yc, (double)(last_xy & 0xFFFF), (double)(last_xy >> 16)) > rad_sq)) {
+                                            if (lane == 0) st_coherent(reg + i, last_xy);
+                                            break;
+                                        }
+                                        out_xy = last_xy;  // the point that moved in is too far as well: it leaves from position i
+                                    }
+                                }
+                                wave_publish();  // (a later chunk may hold positions this one has just filled)
+                            }
+                            if (n_reg < 2) {
+                                gone = true;
+                                break;
+                            }
+                            rc = rect(n_reg, reg_angle);
+                            density = density_of(rc, n_reg);
+                        }
+                    }
+                }
+                // flags have been turned off: the batch's later seeds as they stand now
+                wave_publish();
+                const int u_now = key_ok ? ld_coherent(&px[q_l].used) : 1;
+                todo = __ballot(key_ok && lane > j && u_now == 0);
+                if (gone) continue;
+            }
+            double x1 = rc.x1 + 0.5, y1 = rc.y1 + 0.5, x2 = rc.x2 + 0.5, y2 = rc.y2 + 0.5;
+            if (d.scale != 1) {
+                x1 /= d.scale; y1 /= d.scale; x2 /= d.scale; y2 /= d.scale;
+            }
+            if (lane == 0 && n_seg < d.seg_cap) d.seg[(size_t)b * d.seg_cap + n_seg] = make_float4((float)x1, (float)y1, (float)x2, (float)y2);
+            ++n_seg;
+        }
+    }
+    if (lane == 0) d.n_seg[b] = n_seg;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
 // ONE image by many waves — an EXACT asynchronous form of the search, the default for batches of <= LSD_WAVES_MAX_B images
 // (STVO_LSD_WAVES=0: one wave per image there too).  The scheme is replayed on the CPU by tools/experiments/lsd_waves_sim.c.
 //   the COMMITTER walks the seeds in order.  A seed with a finished PENDING region takes it if every pixel of it is still free (the
@@ -1557,6 +1858,48 @@ __global__ __launch_bounds__(LSD_XW * 64) void lsd_grow_xcd_kernel(LsdDev d, Lsd
     }
 }
 
+// cv::LineIterator(img, Point2f(sx, sy), Point2f(ex, ey)).count (LSDDetector_custom.cpp:286-287): Point2f -> Point by cvRound, then
+// cv::clipLine on the image's rectangle (64-bit integers, the intersections through a double quotient truncated towards zero — the
+// statement of oracle/stvo_lsd_oracle.c: clip_line), then max(|dx|, |dy|) + 1 for the 8-connected raster; 0 when nothing is left.
+__device__ __forceinline__ int line_iterator_count(int cols, int rows, float sx, float sy, float ex, float ey) {
+    long long x1 = __float2int_rn(sx), y1 = __float2int_rn(sy), x2 = __float2int_rn(ex), y2 = __float2int_rn(ey);
+    const long long right = cols - 1, bottom = rows - 1;
+    int c1 = (x1 < 0) + (x1 > right) * 2 + (y1 < 0) * 4 + (y1 > bottom) * 8;
+    int c2 = (x2 < 0) + (x2 > right) * 2 + (y2 < 0) * 4 + (y2 > bottom) * 8;
+    if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+        long long a;
+        if (c1 & 12) {
+            a = c1 < 8 ? 0 : bottom;
+            x1 += (long long)((double)(a - y1) * (double)(x2 - x1) / (double)(y2 - y1));
+            y1 = a;
+            c1 = (x1 < 0) + (x1 > right) * 2;
+        }
+        if (c2 & 12) {
+            a = c2 < 8 ? 0 : bottom;
+            x2 += (long long)((double)(a - y2) * (double)(x2 - x1) / (double)(y2 - y1));
+            y2 = a;
+            c2 = (x2 < 0) + (x2 > right) * 2;
+        }
+        if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+            if (c1) {
+                a = c1 == 1 ? 0 : right;
+                y1 += (long long)((double)(a - x1) * (double)(y2 - y1) / (double)(x2 - x1));
+                x1 = a;
+                c1 = 0;
+            }
+            if (c2) {
+                a = c2 == 1 ? 0 : right;
+                y2 += (long long)((double)(a - x2) * (double)(y2 - y1) / (double)(x2 - x1));
+                x2 = a;
+                c2 = 0;
+            }
+        }
+    }
+    if ((c1 | c2) != 0) return 0;
+    const long long dx = x2 > x1 ? x2 - x1 : x1 - x2, dy = y2 > y1 ? y2 - y1 : y1 - y2;
+    return (int)((dx > dy ? dx : dy) + 1);
+}
+
 // LSDDetectorC::detectImpl's loop over the segments of the (single) octave (:254-303) and the cut of stereoFrame.cpp:231-240
 constexpr int KL_T = 256;
 __global__ __launch_bounds__(KL_T) void lsd_keylines_kernel(LsdDev d) {
@@ -1633,10 +1976,9 @@ __global__ __launch_bounds__(KL_T) void lsd_keylines_kernel(LsdDev d) {
         stvo_keyline kl;
         kl.sx = e.x; kl.sy = e.y; kl.ex = e.z; kl.ey = e.w;
         kl.angle = (float)atan2((double)(e.w - e.y), (double)(e.z - e.x));
-        // cv::LineIterator count: end points rounded to pixels (inside the image after checkLineExtremes), 8-connected raster
-        const int ix0 = __float2int_rn(e.x), iy0 = __float2int_rn(e.y), ix1 = __float2int_rn(e.z), iy1 = __float2int_rn(e.w);
-        const int adx = abs(ix1 - ix0), ady = abs(iy1 - iy0);
-        kl.num_pixels = (adx > ady ? adx : ady) + 1;
+        // cv::LineIterator count: end points rounded to pixels, the line CLIPPED to the image (checkLineExtremes leaves coordinates in
+        // [cols - 0.5, cols) / [rows - 0.5, rows) as they are, and those round to the first position outside), 8-connected raster
+        kl.num_pixels = line_iterator_count(d.cols, d.rows, e.x, e.y, e.z, e.w);
         d.lines[(size_t)b * d.K + rank] = kl;
         if (d.response) d.response[(size_t)b * d.K + rank] = s_resp[i];
     }
@@ -1699,7 +2041,9 @@ int lsd_enqueue(stvo_lsd* o, const uint8_t* images, stvo_keyline* lines, float* 
         hipLaunchKernelGGL(stvo::lsd_scan_kernel, dim3(d.B), dim3(1024), 0, s, d);
         hipLaunchKernelGGL(stvo::lsd_scatter_kernel, ug, dim3(256), lds_h, s, d);
     }
-    if (o->wdev) {  // small batches: a committing wave + speculating workgroups on the CUs of one XCD per image (lsd_grow_xcd_kernel)
+    if (o->prm.refine == 1) {  // LSD_REFINE_STD: regions may give their pixels back — its own one-wave kernel, for every batch size
+        hipLaunchKernelGGL(stvo::lsd_grow_refine_kernel, dim3(d.B), dim3(64), 0, s, d, o->prm.density_th);
+    } else if (o->wdev) {  // small batches: a committing wave + speculating workgroups on the CUs of one XCD per image (lsd_grow_xcd_kernel)
         HIP_TRY(ctx, hipMemsetAsync(o->xx.stamp, 0, o->stamp_bytes, s));
         HIP_TRY(ctx, hipMemsetAsync(o->xx.pend, 0, o->pend_bytes + (size_t)d.B * stvo::LSD_CTL * 4, s));  // (the control words lie behind the table)
         hipLaunchKernelGGL(stvo::lsd_grow_xcd_kernel, dim3(8 * ((d.B + 7) / 8) * (1 + o->xx.nsb)), dim3(stvo::LSD_XW * 64), o->xcd_lds, s, d, o->xx);
@@ -1719,7 +2063,8 @@ extern "C" {
 
 int stvo_lsd_create(stvo_ctx* ctx, int B, int cols, int rows, int max_keylines, const stvo_lsd_params* prm, stvo_lsd** out) {
     if (!ctx || !prm || !out || B < 1 || cols < 8 || rows < 8 || max_keylines < 1) return STVO_ERR_INVALID_ARG;
-    if (prm->refine != 0) return STVO_ERR_UNSUPPORTED;  // the refinement / NFA branches are not built (no shipped configuration uses them)
+    if (prm->refine != 0 && prm->refine != 1) return STVO_ERR_UNSUPPORTED;  // LSD_REFINE_ADV (rect_improve + the NFA test) is not built; no shipped configuration uses it
+    if (prm->refine == 1 && !(prm->density_th >= 0)) return STVO_ERR_INVALID_ARG;
     if (!(prm->scale > 0) || !(prm->ang_th > 0 && prm->ang_th < 180) || prm->n_bins < 1 || prm->n_bins > 4096 || prm->nfeatures < 0)
         return STVO_ERR_INVALID_ARG;
     // sort key = (n_bins - 1 - bin) << LSD_IDX_BITS | index, LSD_NOKEY = all ones: with 4096 bins the keys of bin 0 would share their
@@ -1795,7 +2140,7 @@ int stvo_lsd_create(stvo_ctx* ctx, int B, int cols, int rows, int max_keylines, 
     }
     if (ok && (size_t)d.seg_cap * 8 > 48 * 1024)
         ok = stvo::lds_opt_in(reinterpret_cast<const void*>(stvo::lsd_keylines_kernel), d.seg_cap * 8);
-    if (ok && stvo::dbg().lsd_waves != 0 && B <= stvo::LSD_WAVES_MAX_B && npx <= stvo::LSD_XCD_MAX_PX) {  // small batches (STVO_LSD_WAVES=0: one wave per image there too)
+    if (ok && prm->refine == 0 && stvo::dbg().lsd_waves != 0 && B <= stvo::LSD_WAVES_MAX_B && npx <= stvo::LSD_XCD_MAX_PX) {  // small batches (STVO_LSD_WAVES=0: one wave per image there too)
         // an XCD has 32 CUs and a CU holds one of the kernel's workgroups: images per XCD x (1 + speculating workgroups) <= 32
         const int per_xcd = (B + 7) / 8;
         int nsb = stvo::dbg().lsd_xcd_blocks == stvo::DBG_UNSET ? (32 / per_xcd - 1 < 16 ? 32 / per_xcd - 1 : 16) : stvo::dbg().lsd_xcd_blocks;  // STVO_LSD_XCD_BLOCKS

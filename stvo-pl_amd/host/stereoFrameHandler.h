@@ -23,8 +23,8 @@ public:
     // (include/stereoFrameHandler.h:44-45): the two rectified 8-bit images go through the ORB point front-end on the GPU
     // (stvo_orb_detect_levels with Config's orb_* values and the handler's adaptive orb_fast_th — what
     // StereoFrame::detectStereoPoints does with cv::ORB, src/stereoFrame.cpp:88-118) and continue as extracted features.
-    // Key-lines: with Config::hasLines() the images also go through detectStereoLines below (LSD with lsd_refine 0 + LBD on the GPU,
-    // StereoFrame::detectLineFeatures, src/stereoFrame.cpp:207-243); use_fld_lines and lsd_refine 1 / 2 are refused.
+    // Key-lines: with Config::hasLines() the images also go through detectStereoLines below (LSD with lsd_refine 0 or 1 + LBD on the GPU,
+    // StereoFrame::detectLineFeatures, src/stereoFrame.cpp:207-243); use_fld_lines and lsd_refine 2 are refused.
     void initialize(const GrayImage& img_l, const GrayImage& img_r, const int idx_);
     void insertStereoPair(const GrayImage& img_l, const GrayImage& img_r, const int idx_);
     void detectStereoLines(const uint8_t* pair, int cols, int rows, FrameFeatures& feat);

@@ -1,4 +1,4 @@
-"""A second, independent statement of the LSD detector core (cv::LineSegmentDetector with lsd_refine = 0) for SMALL images, written
+"""A second, independent statement of the LSD detector core (cv::LineSegmentDetector with lsd_refine = 0 or 1) for SMALL images, written
 from the published algorithm (von Gioi et al., IPOL 2012) in numpy + plain Python loops — the cross-check of oracle/stvo_lsd_oracle.c
 that a reference vector would otherwise provide (parity with OpenCV itself is unpinned: DESIGN.md §3).  It shares no code with the C
 oracle; where the two must agree to the last bit it follows the same published definitions:
@@ -63,8 +63,13 @@ def sincos_det(x):
     return ((sn, cs, -sn, -cs)[q], (cs, -sn, -cs, sn)[q])
 
 
-def segments(img, quant=2.0, ang_th=22.5, n_bins=1024):
-    """[n, 4] float32 (x1, y1, x2, y2) in detection order, for an 8-bit image at scale 1."""
+def segments(img, quant=2.0, ang_th=22.5, n_bins=1024, refine=0, density_th=0.6, stats=None):
+    """[n, 4] float32 (x1, y1, x2, y2) in detection order, for an 8-bit image at scale 1.  refine: 0 (LSD_REFINE_NONE) or 1
+    (LSD_REFINE_STD: a sparse region is given back, grown again under a tolerance from the angles near its seed, then cut back by
+    radius).  stats (a dict): how often the branches of the refinement ran."""
+    def count(key):
+        if stats is not None:
+            stats[key] = stats.get(key, 0) + 1
     img = np.asarray(img, np.int64)
     h, w = img.shape
     prec = math.pi * ang_th / 180
@@ -92,18 +97,16 @@ def segments(img, quant=2.0, ang_th=22.5, n_bins=1024):
     used = np.zeros((h, w), bool)
     out = []
 
-    def aligned(x, y, theta):
+    def aligned(x, y, theta, tol):
         a = ang[y, x]
         if a == -1024.0:
             return False
         d = abs(theta - a)
         if d > M_3_2_PI:
             d = abs(d - M_2_PI)
-        return d <= prec
+        return d <= tol
 
-    for sy, sx in zip(oy, ox):
-        if used[sy, sx] or not defined[sy, sx]:
-            continue
+    def grow(sx, sy, tol):
         reg = [(sx, sy)]
         reg_angle = ang[sy, sx]
         sn, cs = sincos_det(reg_angle)
@@ -114,7 +117,7 @@ def segments(img, quant=2.0, ang_th=22.5, n_bins=1024):
             px, py = reg[i]
             for yy in range(max(py - 1, 0), min(py + 1, h - 1) + 1):
                 for xx in range(max(px - 1, 0), min(px + 1, w - 1) + 1):
-                    if not used[yy, xx] and aligned(xx, yy, reg_angle):
+                    if not used[yy, xx] and aligned(xx, yy, reg_angle, tol):
                         used[yy, xx] = True
                         reg.append((xx, yy))
                         sn, cs = sincos_det(float(F32(ang[yy, xx])))
@@ -122,8 +125,9 @@ def segments(img, quant=2.0, ang_th=22.5, n_bins=1024):
                         sumdy = F32(sumdy + F32(sn))
                         reg_angle = float(fast_atan2_deg(sumdy, sumdx)) * DEG2RAD
             i += 1
-        if len(reg) < min_reg:
-            continue
+        return reg, reg_angle
+
+    def rect(reg, reg_angle):
         x = y = s = 0.0
         for px, py in reg:
             wgt = mod[py, px]
@@ -150,10 +154,84 @@ def segments(img, quant=2.0, ang_th=22.5, n_bins=1024):
         if abs(diff) > prec:
             theta += math.pi
         dy, dx = sincos_det(theta)
-        l_min = l_max = 0.0
+        l_min = l_max = w_min = w_max = 0.0
         for px, py in reg:
             l = (float(px) - x) * dx + (float(py) - y) * dy
+            ww = -(float(px) - x) * dy + (float(py) - y) * dx
             l_max = max(l_max, l)
             l_min = min(l_min, l)
-        out.append([F32(x + l_min * dx + 0.5), F32(y + l_min * dy + 0.5), F32(x + l_max * dx + 0.5), F32(y + l_max * dy + 0.5)])
+            w_max = max(w_max, ww)
+            w_min = min(w_min, ww)
+        return [x + l_min * dx, y + l_min * dy, x + l_max * dx, y + l_max * dy, max(w_max - w_min, 1.0)]
+
+    def dist_sq(x1, y1, x2, y2):
+        return (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1)
+
+    def density(rc, n):
+        return float(n) / (math.sqrt(dist_sq(rc[0], rc[1], rc[2], rc[3])) * rc[4])
+
+    def refine_region(reg, reg_angle, rc):
+        """-> (reg, reg_angle, rc) or None when the region is given up"""
+        if density(rc, len(reg)) >= density_th:
+            return reg, reg_angle, rc
+        count("regrown")
+        xc, yc = float(reg[0][0]), float(reg[0][1])
+        ang_c = ang[reg[0][1], reg[0][0]]
+        tot = sq = 0.0
+        n = 0
+        for px, py in reg:
+            used[py, px] = False
+            if math.sqrt(dist_sq(xc, yc, float(px), float(py))) < rc[4]:
+                d = ang[py, px] - ang_c
+                while d <= -math.pi:
+                    d += M_2_PI
+                while d > math.pi:
+                    d -= M_2_PI
+                tot += d
+                sq += d * d
+                n += 1
+        mean = tot / float(n)
+        arg = (sq - 2.0 * mean * tot) / float(n) + mean * mean
+        tau = 2.0 * math.sqrt(arg) if arg >= 0 else float("nan")
+        reg, reg_angle = grow(reg[0][0], reg[0][1], tau)
+        if len(reg) < 2:
+            count("gone_after_regrowing")
+            return None
+        rc = rect(reg, reg_angle)
+        dens = density(rc, len(reg))
+        if dens >= density_th:
+            return reg, reg_angle, rc
+        count("radius_reduced")
+        rad_sq = max(dist_sq(xc, yc, rc[0], rc[1]), dist_sq(xc, yc, rc[2], rc[3]))
+        while dens < density_th:
+            rad_sq *= 0.75 * 0.75
+            count("radius_steps")
+            i = 0
+            while i < len(reg):
+                if dist_sq(xc, yc, float(reg[i][0]), float(reg[i][1])) > rad_sq:
+                    used[reg[i][1], reg[i][0]] = False
+                    reg[i] = reg[-1]
+                    reg.pop()
+                else:
+                    i += 1
+            if len(reg) < 2:
+                count("gone_by_radius")
+                return None
+            rc = rect(reg, reg_angle)
+            dens = density(rc, len(reg))
+        return reg, reg_angle, rc
+
+    for sy, sx in zip(oy, ox):
+        if used[sy, sx] or not defined[sy, sx]:
+            continue
+        reg, reg_angle = grow(sx, sy, prec)
+        if len(reg) < min_reg:
+            continue
+        rc = rect(reg, reg_angle)
+        if refine >= 1:
+            res = refine_region(reg, reg_angle, rc)
+            if res is None:
+                continue
+            reg, reg_angle, rc = res
+        out.append([F32(rc[0] + 0.5), F32(rc[1] + 0.5), F32(rc[2] + 0.5), F32(rc[3] + 0.5)])
     return np.array(out, np.float32).reshape(-1, 4)

@@ -246,11 +246,77 @@ def test_lsd_keep_all_flat_and_unscaled(hip, oracle):
             lsd.close()
 
 
+@pytest.mark.parametrize("B", [4, 20])
+def test_lsd_refine_std_vs_oracle(hip, oracle, B):
+    """lsd_refine = 1 (LSD_REFINE_STD: a region too sparse for its rectangle gives its pixels back, is grown again under a tolerance
+    from the angles near its seed, then cut back by radius — oracle/stvo_lsd_oracle.c: refine_region / reduce_region_radius) runs on its
+    own one-wave kernel for every batch size (lsd_kernels.hip: lsd_grow_refine_kernel): segments in the oracle's order, bit for bit, the
+    wrapper's key-lines too; and the mode changes something (the refinement branches ran)."""
+    from stvo_amd import capi
+    cols, rows = 640, 360
+    rng = np.random.default_rng(71)
+    from scipy.ndimage import gaussian_filter
+
+    def blurred(seed, sigma):  # wide, sparse regions: the ones the refinement cuts back by radius (tests/test_oracle_lsd.py counts the branches)
+        return np.clip(np.rint(gaussian_filter(synth.make_image(seed, cols, rows).astype(float), sigma)), 0, 255).astype(np.uint8)
+    imgs = np.stack([synth.make_image(700 + b, cols, rows) if b % 5 == 0 else blurred(700 + b, 1.0 + 0.25 * (b % 4)) if b % 5 == 1 else
+                     clean_image(cols, rows, 700 + b) if b % 5 == 2 else rng.integers(0, 255, (rows, cols), dtype=np.uint8) if b % 5 == 3 else
+                     np.full((rows, cols), 50 + b, np.uint8) for b in range(B)])
+    changed = 0
+    for scale, dth in ((1.2, 0.6), (1.0, 0.6), (0.8, 0.6), (1.0, 0.85)):
+        prm = capi.lsd_params(min_length=4.0, nfeatures=0, scale=scale, refine=1)
+        prm.density_th = dth
+        opts = oracle.lsd_opts(min_length=4.0, nfeatures=0, scale=scale, refine=1)
+        opts.density_th = dth
+        lsd = capi.Lsd(hip, B, cols, rows, prm, max_keylines=2048)
+        try:
+            for _ in range(2):
+                segs, n = lsd.segments(imgs)
+                refs = [oracle.lsd_segments(imgs[b], opts) for b in range(B)]
+                assert list(n) == [len(r) for r in refs], (scale, dth, _)
+                for b in range(B):
+                    assert np.array_equal(segs[b], refs[b]), (scale, dth, _, b)
+            for b in (0, 1):
+                plain = oracle.lsd_segments(imgs[b], oracle.lsd_opts(scale=scale))
+                changed += plain.shape != refs[b].shape or not np.array_equal(plain, refs[b])
+            dets = lsd.detect(imgs)
+            for b in range(min(B, 5)):
+                check_keylines(dets[b], oracle.lsd_detect(imgs[b], opts), cols, rows)
+        finally:
+            lsd.close()
+    assert changed >= 6
+
+
+def test_lsd_keylines_whose_end_rounds_outside_the_image(hip, oracle):
+    """checkLineExtremes (LSDDetector_custom.cpp:75-100) leaves an end point in [cols - 0.5, cols) or [rows - 0.5, rows) as it is, cvRound
+    puts it on the first position OUTSIDE the image and cv::LineIterator clips the line: numOfPixels is one less than the rounded end
+    points say (found in round 6 by the refinement test's images; until then the device counted without clipping)."""
+    from scipy.ndimage import gaussian_filter
+    from stvo_amd import capi
+    cols, rows = 640, 360
+
+    def blurred(seed, sigma):
+        return np.clip(np.rint(gaussian_filter(synth.make_image(seed, cols, rows).astype(float), sigma)), 0, 255).astype(np.uint8)
+    imgs = np.stack([blurred(701, 1.25), synth.make_image(702, cols, rows), blurred(703, 1.75)])
+    outside = 0
+    for scale in (1.2, 1.0):
+        lsd = capi.Lsd(hip, 3, cols, rows, capi.lsd_params(min_length=4.0, nfeatures=0, scale=scale), max_keylines=2048)
+        try:
+            dets = lsd.detect(imgs)
+            for b in range(3):
+                kl = oracle.lsd_detect(imgs[b], oracle.lsd_opts(min_length=4.0, nfeatures=0, scale=scale))
+                check_keylines(dets[b], kl, cols, rows)
+                outside += int(np.sum((np.rint(kl["sx"]) >= cols) | (np.rint(kl["ex"]) >= cols) | (np.rint(kl["sy"]) >= rows) | (np.rint(kl["ey"]) >= rows)))
+        finally:
+            lsd.close()
+    assert outside >= 4
+
+
 def test_lsd_rejects_what_is_not_built(hip):
     from stvo_amd import capi
     from stvo_amd.capi import StvoError
     with pytest.raises(StvoError):
-        capi.Lsd(hip, 1, 320, 200, capi.lsd_params(refine=1))          # refinement / NFA: not built
+        capi.Lsd(hip, 1, 320, 200, capi.lsd_params(refine=2))          # LSD_REFINE_ADV (rect_improve + the NFA test): not built
     with pytest.raises(StvoError):
         capi.Lsd(hip, 1, 2000, 1000, capi.lsd_params())                # more than 2^20 pixels after scaling
 

@@ -102,7 +102,7 @@ def test_detector_core_against_the_numpy_restatement(oracle):
     bit for bit and in the same order, as oracle/stvo_lsd_oracle.c at scale 1 (small images: it runs plain Python loops)."""
     import np_lsd
     rng = np.random.default_rng(5)
-    total = 0
+    total = changed = 0
     for k in range(4):
         img = np.full((72, 104), 90.0)
         for _ in range(6):
@@ -118,7 +118,34 @@ def test_detector_core_against_the_numpy_restatement(oracle):
         got = np_lsd.segments(img)
         assert got.shape == ref.shape and np.array_equal(got, ref), k
         total += len(ref)
-    assert total > 30
+        # lsd_refine = 1 (refine_region / reduce_region_radius): the same agreement, and the mode is not a no-op on these images
+        ref1 = oracle.lsd_segments(img, oracle.lsd_opts(scale=1.0, refine=1))
+        got1 = np_lsd.segments(img, refine=1)
+        assert got1.shape == ref1.shape and np.array_equal(got1, ref1), k
+        changed += ref1.shape != ref.shape or not np.array_equal(ref1, ref)
+    assert total > 30 and changed >= 1
+
+
+def test_refine_std_branches_against_the_numpy_restatement(oracle):
+    """lsd_refine = 1 on images that make its branches run (a blurred scene: wide, sparse regions): regions grown again, regions cut
+    back by radius over several steps, regions given up — oracle and numpy restatement agree bit for bit, at both shipped density
+    thresholds and a strict one."""
+    import np_lsd
+    from scipy.ndimage import gaussian_filter
+    from stvo_amd import synth
+    base = synth.make_image(4711, 320, 200, n_rects=70, n_discs=15)[:120, :200]
+    seen = {}
+    for sigma, dth in ((0.0, 0.6), (1.0, 0.6), (2.0, 0.6), (2.0, 0.85)):
+        img = base if sigma == 0 else np.clip(np.rint(gaussian_filter(base.astype(float), sigma)), 0, 255).astype(np.uint8)
+        o = oracle.lsd_opts(scale=1.0, refine=1)
+        o.density_th = dth
+        ref = oracle.lsd_segments(img, o)
+        st = {}
+        got = np_lsd.segments(img, refine=1, density_th=dth, stats=st)
+        assert got.shape == ref.shape and np.array_equal(got, ref), (sigma, dth)
+        for k, v in st.items():
+            seen[k] = seen.get(k, 0) + v
+    assert seen.get("regrown", 0) >= 10 and seen.get("radius_steps", 0) >= 5 and seen.get("gone_after_regrowing", 0) + seen.get("gone_by_radius", 0) >= 1, seen
 
 
 def test_scaled_image_sample_positions_follow_the_scale_not_the_rounded_size(oracle):
