@@ -58,6 +58,8 @@ def main():
         case += 1
         rng = np.random.default_rng([args.seed, case])
         cols, rows = int(rng.integers(64, 900)), int(rng.integers(64, 500))
+        if rng.integers(0, 6) == 0:   # the sizes of the shipped configurations (and one beyond LSD's 2^20 pixels: ORB only)
+            cols, rows = [(1241, 376), (1226, 370), (752, 480), (1280, 720)][int(rng.integers(0, 4))]
         B = int(rng.integers(1, 6))
         imgs = np.stack([make_image(rng, cols, rows) for _ in range(B)])
         tag = f"seed {args.seed} case {case} {cols}x{rows} B {B}"
