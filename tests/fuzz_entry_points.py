@@ -2,7 +2,7 @@
 """Randomised parity of the per-stage entry points the handler mirror calls (stvo_match_nnr_mutual, stvo_match_grid_points,
 stvo_normal_eq, stvo_optimize_pose) against the oracle: sizes from empty to the capacity, low-entropy descriptors (ties), every window
 shape, optimizer modes and presets, outlier / noise levels that reach the failure paths.  Test infrastructure.  Run on a GPU box from
-the repo root:   python tools/fuzz_entry_points.py [--seconds 150] [--seed 1]"""
+the repo root:   python tests/fuzz_entry_points.py [--seconds 150] [--seed 1]"""
 import argparse, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "stvo-pl_amd", "python")); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -22,7 +22,7 @@ def rand_desc(rng, n, entropy_bits=256):
 
 
 def pose_sensitivity(orc, T0, cam, prm, rec, base, trials=8):
-    """The oracle's own move under a few roundings of its 3-D inputs (see tools/fuzz_pipeline.py); inf when its course changes."""
+    """The oracle's own move under a few roundings of its 3-D inputs (see tests/fuzz_pipeline.py); inf when its course changes."""
     cs = float(np.max(np.abs(base["cov"])))
     sT = serr = scov = 0.0
     for trial in range(trials):
@@ -43,17 +43,18 @@ def pose_sensitivity(orc, T0, cam, prm, rec, base, trials=8):
     return sT, serr, scov
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=150.0)
     ap.add_argument("--seed", type=int, default=1)
-    args = ap.parse_args()
+    ap.add_argument("--cases", type=int, default=0, help="stop after this many cases (0: run for --seconds)")
+    args = ap.parse_args(argv)
     orc = oracle_lib.load()
     ctx = capi.Context(device_id=0, max_rows=4096, max_batch=4)
     t_end = time.time() + args.seconds
     case = bad = 0
     counts = dict(match=0, grid=0, normal_eq=0, pose=0, pose_ill_posed=0)
-    while time.time() < t_end:
+    while time.time() < t_end and (args.cases == 0 or case < args.cases):
         case += 1
         rng = np.random.default_rng([args.seed, case])
         tag = f"seed {args.seed} case {case}"
@@ -130,8 +131,8 @@ def main():
                       f"{(ref['status'], ref['path'], ref['iters'])} dT {dT:.3g} derr {derr:.3g} dcov {dcov:.3g} | oracle's own sensitivity {sT:.3g} {serr:.3g} {scov:.3g}", flush=True)
     ctx.close()
     print(f"fuzz_entry_points: {case} cases ({counts}), {bad} findings, seed {args.seed}", flush=True)
-    sys.exit(1 if bad else 0)
+    return bad
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(1 if main() else 0)

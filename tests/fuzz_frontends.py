@@ -3,7 +3,7 @@
 C-ABI: random image sizes (every residue of the width, small and large), random content (scenes, blurred scenes, noise, ramps,
 checkerboards, saturated blocks, flat), random parameters.  Test infrastructure (round 6: a blurred scene found a one-off in
 numOfPixels that the fixed test images never met).  Run on a GPU box from the repo root:
-    python tools/fuzz_frontends.py [--seconds 120] [--seed 1]
+    python tests/fuzz_frontends.py [--seconds 120] [--seed 1]
 Prints one line per mismatch with everything needed to replay it; exit code 1 if any."""
 import argparse, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -44,17 +44,18 @@ def same_bits(a, b):
     return a.shape == b.shape and np.array_equal(np.ascontiguousarray(a).view(np.uint8), np.ascontiguousarray(b).view(np.uint8))
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120.0)
     ap.add_argument("--seed", type=int, default=1)
-    args = ap.parse_args()
+    ap.add_argument("--cases", type=int, default=0, help="stop after this many cases (0: run for --seconds)")
+    args = ap.parse_args(argv)
     orc = oracle_lib.load()
     ctx = capi.Context(device_id=0, max_rows=2048, max_batch=8)
     t_end = time.time() + args.seconds
     case, bad = 0, 0
     counts = {"orb": 0, "lsd": 0, "lbd": 0}
-    while time.time() < t_end:
+    while time.time() < t_end and (args.cases == 0 or case < args.cases):
         case += 1
         rng = np.random.default_rng([args.seed, case])
         cols, rows = int(rng.integers(64, 900)), int(rng.integers(64, 500))
@@ -129,8 +130,8 @@ def main():
                 lsd.close()
     ctx.close()
     print(f"fuzz_frontends: {case} cases ({counts}), {bad} mismatches, seed {args.seed}", flush=True)
-    sys.exit(1 if bad else 0)
+    return bad
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(1 if main() else 0)

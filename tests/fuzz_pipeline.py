@@ -3,7 +3,7 @@
 against the oracle-driven pipeline (tests/pipeline_ref.py), with the comparison of tests/test_gpu_seq.py::run_and_compare: random
 batch sizes (the latency pose kernel, the batch pose kernels, the many-sequences copy-back path), feature counts from empty to full,
 presets, optimizer modes, motion model, noise / outlier / distractor levels that reach the failure paths, clustered descriptors.
-Test infrastructure.  Run on a GPU box from the repo root:   python tools/fuzz_pipeline.py [--seconds 150] [--seed 1]"""
+Test infrastructure.  Run on a GPU box from the repo root:   python tests/fuzz_pipeline.py [--seconds 150] [--seed 1]"""
 import argparse, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "stvo-pl_amd", "python")); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -114,16 +114,17 @@ def run_and_compare(oracle, seqs, cam, preset, mode=0, has_lines=1, max_kp=2048,
     return worst
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=150.0)
     ap.add_argument("--seed", type=int, default=1)
-    args = ap.parse_args()
+    ap.add_argument("--cases", type=int, default=0, help="stop after this many cases (0: run for --seconds)")
+    args = ap.parse_args(argv)
     orc = oracle_lib.load()
     t_end = time.time() + args.seconds
     case = bad = 0
     worst = dict(dT=0.0, dcov=0.0, derr=0.0, cond=0.0)
-    while time.time() < t_end:
+    while time.time() < t_end and (args.cases == 0 or case < args.cases):
         case += 1
         rng = np.random.default_rng([args.seed, case])
         B = int(rng.choice([1, 1, 2, 3, 5, 8, 17, 40, 130]))
@@ -156,8 +157,8 @@ def main():
             bad += 1
             print("ERROR", tag, "|", repr(e)[:300], flush=True)
     print(f"fuzz_pipeline: {case} cases, {bad} findings, seed {args.seed}; worst deviations of the passing cases (incl. the pairs the oracle itself is unstable on): {worst}", flush=True)
-    sys.exit(1 if bad else 0)
+    return bad
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(1 if main() else 0)
