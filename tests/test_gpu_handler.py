@@ -177,8 +177,8 @@ def test_image_entry_points_of_the_handler(tmp_path, oracle, preset, nlevels):
     assert sum(r["ints"][1] == 0 for r in res) >= 2 and "FAST:" in p.stdout
 
 
-@pytest.mark.parametrize("preset,nlevels", [("kitti", 1), ("euroc", 4)])
-def test_image_entry_points_points_and_lines(tmp_path, oracle, preset, nlevels):
+@pytest.mark.parametrize("preset,nlevels,refine", [("kitti", 1, 0), ("euroc", 4, 0), ("kitti", 1, 1)])
+def test_image_entry_points_points_and_lines(tmp_path, oracle, preset, nlevels, refine):
     """The same with Config::hasLines(): insertStereoPair(img_l, img_r, idx) detects key-points (ORB) AND key-lines — the LSD detector
     with Config's lsd_* options and min_line_length x min(cols, rows), the top-N cut by response, LBD descriptors
     (src/stereoFrame.cpp:191-243) — on the GPU and runs points + lines through the usual path; against the CPU chain: ORB / LSD / LBD
@@ -187,7 +187,12 @@ def test_image_entry_points_points_and_lines(tmp_path, oracle, preset, nlevels):
     pairs = synth.make_stereo_image_sequence(91, 4, cam)
     seq = str(tmp_path / "img.bin"); res_path = str(tmp_path / "res.bin")
     synth.write_image_sequence(seq, pairs, cam)
-    p = subprocess.run([APP, seq, res_path, "--preset", preset], capture_output=True, text=True, timeout=300)
+    extra = ()
+    if refine:   # lsd_refine : 1 (src/config.cpp:105,198) travels through Config to the detector (LSD_REFINE_STD)
+        cfg = tmp_path / "cfg.yaml"
+        cfg.write_text(f"lsd_refine : {refine}\n")
+        extra = ("-c", str(cfg))
+    p = subprocess.run([APP, seq, res_path, "--preset", preset, *extra], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr + p.stdout
     res = synth.read_results(res_path)
     mp = match_params(preset); op = opt_params(preset, has_lines=1)
@@ -195,7 +200,7 @@ def test_image_entry_points_points_and_lines(tmp_path, oracle, preset, nlevels):
     fast = dict(adaptive=True, th0=20, mn=7, mx=30, inc=5, feat=50, err=0.5) if preset == "kitti" else \
         dict(adaptive=True, th0=20, mn=5, mx=50, inc=5, feat=50, err=0.5)
     pattern = oracle.orb_default_pattern()
-    lopts = oracle.lsd_opts(min_length=0.025 * min(cam["width"], cam["height"]), nfeatures=nlines)
+    lopts = oracle.lsd_opts(min_length=0.025 * min(cam["width"], cam["height"]), nfeatures=nlines, refine=refine)
 
     def lines_of(img):
         kl = oracle.lsd_detect(img, lopts)
@@ -217,3 +222,7 @@ def test_image_entry_points_points_and_lines(tmp_path, oracle, preset, nlevels):
             th = ref[-1]["fast"]
     compare(res, ref)
     assert any(r["ints"][7] > 0 for r in res[1:])  # matched key-lines took part
+    if refine:   # ... and the mode changes the key-lines of these images (the yaml key was not ignored on either side)
+        plain = oracle.lsd_detect(pairs[0][0], oracle.lsd_opts(min_length=0.025 * min(cam["width"], cam["height"]), nfeatures=nlines))
+        mine = oracle.lsd_detect(pairs[0][0], lopts)
+        assert not all(np.array_equal(plain[f], mine[f]) for f in ("sx", "sy", "ex", "ey"))
