@@ -91,6 +91,38 @@ def main(argv=None):
         if not np.array_equal(got, exp) or n != en:
             bad += 1
             print(f"MISMATCH grid {tag}: {g1} x {g2} entropy {gent} window {w} ratio {ratio} spread {spread} mutual {gm}: rows {np.nonzero(got != exp)[0][:8]}", flush=True)
+        # ---- StVO::matchGrid (lines): both end-point windows, the direction gate, the NaN direction of same-cell end points
+        if case % 4 == 0:   # (the oracle rasterises every right line: every fourth case)
+            l1, l2 = int(rng.integers(1, 513)), int(rng.integers(1, 513))
+            lent = int(rng.choice([8, 24, 256])); lth = float(rng.choice([0.3, 0.75, 0.95])); lratio = float(rng.choice([0.6, 0.75, 1.0]))
+            lw = tuple(int(x) for x in (rng.choice([0, 3, 10]), rng.choice([0, 2, 10]), rng.choice([0, 1, 5]), rng.choice([0, 1, 5])))
+
+            def make_lines(n):
+                a = np.stack([rng.uniform(0, 1241.0, n), rng.uniform(0, 376.0, n)], 1)
+                b = a + rng.uniform(-150, 150, (n, 2))
+                b[:, 0] = np.clip(b[:, 0], 0, 1240.0); b[:, 1] = np.clip(b[:, 1], 0, 375.0)
+                return a.astype(np.float32), b.astype(np.float32)
+            s1, t1 = make_lines(l1); s2, t2 = make_lines(l2)
+            k = int(rng.integers(0, min(l1, 10) + 1))
+            t1[:k] = s1[:k] + 1.0
+            cl1 = np.concatenate([(s1[:, 0:1] * iw).astype(np.int32), (s1[:, 1:2] * ih).astype(np.int32),
+                                  (t1[:, 0:1] * iw).astype(np.int32), (t1[:, 1:2] * ih).astype(np.int32)], 1)
+            ent_xy, owner = [], []
+            for j in range(l2):
+                cells = orc.line_coords(s2[j, 0] * iw, s2[j, 1] * ih, t2[j, 0] * iw, t2[j, 1] * ih)
+                ent_xy.append(cells); owner += [j] * len(cells)
+            lstart, litems = orc.grid_build(np.concatenate(ent_xy), np.array(owner, np.int32))
+            v = np.stack([(t2[:, 0] - s2[:, 0]).astype(np.float64) * iw, (t2[:, 1] - s2[:, 1]).astype(np.float64) * ih], 1)
+            with np.errstate(invalid="ignore", divide="ignore"):
+                dir2 = v / np.linalg.norm(v, axis=1, keepdims=True)
+            f1, f2 = rand_desc(rng, l1, lent), rand_desc(rng, l2, lent)
+            lm = int(rng.integers(0, 2))
+            got, n = ctx.match_grid_lines(cl1, f1, lstart, litems, f2, dir2, lw, lratio, lth, lm)
+            exp, en = orc.match_grid_lines(cl1, f1, lstart, litems, f2, dir2, lw, lratio, lth, lm)
+            counts["grid_lines"] = counts.get("grid_lines", 0) + 1
+            if not np.array_equal(got, exp) or n != en:
+                bad += 1
+                print(f"MISMATCH grid lines {tag}: {l1} x {l2} entropy {lent} window {lw} ratio {lratio} gate {lth} mutual {lm}: rows {np.nonzero(got != exp)[0][:8]}", flush=True)
         # ---- optimizeFunctions + optimizePose
         preset = str(rng.choice(["kitti", "euroc"])); mode = int(rng.choice([0, 0, 1, 2]))
         npts = int(rng.choice([0, 3, 12, 60, 300, 1200, 2048])); nl = int(rng.choice([0, 0, 5, 60, 300, 512]))
