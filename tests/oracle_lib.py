@@ -305,6 +305,12 @@ class Oracle:
     def lsd_opts(self, min_length=0.0, nfeatures=0, refine=0, scale=1.2, sigma_scale=0.6, quant=2.0, ang_th=22.5, n_bins=1024):
         return self.LsdOpts(refine, scale, sigma_scale, quant, ang_th, 1.0, 0.6, n_bins, min_length, nfeatures)  # src/config.cpp:104-112
 
+    def line_iterator_count(self, cols, rows, sx, sy, ex, ey):
+        """cv::LineIterator(img, Point2f(sx, sy), Point2f(ex, ey)).count as KeyLine::numOfPixels takes it (LSDDetector_custom.cpp:286-287)."""
+        self.lib.orc_line_iterator_count.argtypes = [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float]
+        self.lib.orc_line_iterator_count.restype = C.c_int
+        return int(self.lib.orc_line_iterator_count(cols, rows, sx, sy, ex, ey))
+
     def lsd_segments(self, img, opts, cap=65536):
         """cv::LineSegmentDetector::detect restated: [n, 4] float32 (x1, y1, x2, y2) in detection order."""
         self.lib.orc_lsd_segments.argtypes = [u8p, C.c_int, C.c_int, C.POINTER(self.LsdOpts), f32p, C.c_int]

@@ -126,6 +126,65 @@ def test_detector_core_against_the_numpy_restatement(oracle):
     assert total > 30 and changed >= 1
 
 
+def test_line_iterator_count_clips_like_cliprect(oracle):
+    """KeyLine::numOfPixels = cv::LineIterator(...).count: end points by cvRound, the line clipped to the image, 8-connected.  Against a
+    plain statement of the clipping (exact rational intersection of the ideal line with the image's borders, truncated towards zero as
+    cv::clipLine does with its double quotient) on random segments that start or end up to 40 pixels outside the image, on segments
+    whose end point rounds to the first column / row outside (the case checkLineExtremes leaves behind: x in [cols - 0.5, cols)), and on
+    segments entirely outside (count 0)."""
+    from fractions import Fraction
+
+    def count(cols, rows, sx, sy, ex, ey):
+        rnd = lambda v: int(np.rint(np.float32(v)))   # cvRound: half to even
+        x1, y1, x2, y2 = rnd(sx), rnd(sy), rnd(ex), rnd(ey)
+        right, bottom = cols - 1, rows - 1
+        code = lambda x, y: (x < 0) + (x > right) * 2 + (y < 0) * 4 + (y > bottom) * 8
+        trunc = lambda q: int(q) if q >= 0 else -int(-q)    # Fraction -> integer towards zero
+        c1, c2 = code(x1, y1), code(x2, y2)
+        if (c1 & c2) == 0 and (c1 | c2) != 0:
+            if c1 & 12:
+                a = 0 if c1 < 8 else bottom
+                x1 += trunc(Fraction((a - y1) * (x2 - x1), y2 - y1)); y1 = a
+                c1 = (x1 < 0) + (x1 > right) * 2
+            if c2 & 12:
+                a = 0 if c2 < 8 else bottom
+                x2 += trunc(Fraction((a - y2) * (x2 - x1), y2 - y1)); y2 = a
+                c2 = (x2 < 0) + (x2 > right) * 2
+            if (c1 & c2) == 0 and (c1 | c2) != 0:
+                if c1:
+                    a = 0 if c1 == 1 else right
+                    y1 += trunc(Fraction((a - x1) * (y2 - y1), x2 - x1)); x1 = a; c1 = 0
+                if c2:
+                    a = 0 if c2 == 1 else right
+                    y2 += trunc(Fraction((a - x2) * (y2 - y1), x2 - x1)); x2 = a; c2 = 0
+        if (c1 | c2) != 0:
+            return 0
+        assert 0 <= x1 <= right and 0 <= x2 <= right and 0 <= y1 <= bottom and 0 <= y2 <= bottom
+        return max(abs(x2 - x1), abs(y2 - y1)) + 1
+
+    rng = np.random.default_rng(12)
+    cols, rows = 640, 360
+    n_clipped = n_zero = 0
+    for trial in range(4000):
+        sx, sy = rng.uniform(-40, cols + 40), rng.uniform(-40, rows + 40)
+        ex, ey = rng.uniform(-40, cols + 40), rng.uniform(-40, rows + 40)
+        if trial % 5 == 0:     # what checkLineExtremes hands over: inside [0, cols) x [0, rows), an end within half a pixel of the far border
+            sx, sy = rng.uniform(0, cols - 1), rng.uniform(0, rows - 1)
+            ex, ey = (cols - rng.uniform(0.0, 0.5), rng.uniform(0, rows - 1)) if trial % 10 == 0 else (rng.uniform(0, cols - 1), rows - rng.uniform(0.0, 0.5))
+        if trial % 7 == 0:     # entirely outside, on one side
+            sx, ex = cols + rng.uniform(1, 30), cols + rng.uniform(1, 30)
+        got = oracle.line_iterator_count(cols, rows, sx, sy, ex, ey)
+        exp = count(cols, rows, sx, sy, ex, ey)
+        # (the double quotient of cv::clipLine and the exact one truncate alike unless the quotient is an integer to within 1e-12: not in this sample)
+        assert got == exp, (trial, sx, sy, ex, ey, got, exp)
+        inside = all(0 <= int(np.rint(np.float32(v))) <= lim for v, lim in ((sx, cols - 1), (ex, cols - 1), (sy, rows - 1), (ey, rows - 1)))
+        n_clipped += (not inside) and got > 0
+        n_zero += got == 0
+        if inside:
+            assert got == max(abs(int(np.rint(np.float32(ex))) - int(np.rint(np.float32(sx)))), abs(int(np.rint(np.float32(ey))) - int(np.rint(np.float32(sy))))) + 1
+    assert n_clipped > 500 and n_zero > 300
+
+
 def test_refine_std_branches_against_the_numpy_restatement(oracle):
     """lsd_refine = 1 on images that make its branches run (a blurred scene: wide, sparse regions): regions grown again, regions cut
     back by radius over several steps, regions given up — oracle and numpy restatement agree bit for bit, at both shipped density
