@@ -62,6 +62,9 @@ def main(argv=None):
         if rng.integers(0, 6) == 0:   # the sizes of the shipped configurations (and one beyond LSD's 2^20 pixels: ORB only)
             cols, rows = [(1241, 376), (1226, 370), (752, 480), (1280, 720)][int(rng.integers(0, 4))]
         B = int(rng.integers(1, 6))
+        if rng.integers(0, 8) == 0:   # the detector's other batch forms: several images per XCD (9 .. 128), one wave per image (beyond)
+            B = int(rng.choice([12, 40, 150]))
+            cols, rows = min(cols, 400), min(rows, 260)
         imgs = np.stack([make_image(rng, cols, rows) for _ in range(B)])
         tag = f"seed {args.seed} case {case} {cols}x{rows} B {B}"
         # ---- ORB
