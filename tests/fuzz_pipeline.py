@@ -54,7 +54,7 @@ def oracle_sensitivity(oracle, frames, cam, mp, op, motion_model, idx, trials=8)
     return sT, serr, scov
 
 
-def run_and_compare(oracle, seqs, cam, preset, mode=0, has_lines=1, max_kp=2048, max_kl=320, motion_model=False):
+def run_and_compare(oracle, seqs, cam, preset, mode=0, has_lines=1, max_kp=2048, max_kl=320, motion_model=False, slots=False):
     """tests/test_gpu_seq.py::run_and_compare with the numeric tolerances tied to the conditioning of the pair's normal equations:
     counts, status, path, iteration counts and inlier counts must be IDENTICAL; pose, error and covariance agree to 1e-8 / 1e-8 /
     1e-6 — or to 1e-13 x cond(cov) where a pair with a handful of features makes the 6 x 6 system that ill-conditioned (the device
@@ -70,10 +70,23 @@ def run_and_compare(oracle, seqs, cam, preset, mode=0, has_lines=1, max_kp=2048,
     try:
         if motion_model:
             dev.set_motion_model(True)
+        if slots:   # what bench.py does: every frame resident in its own slot (stvo_seq_set_slots / upload), then steps that ping-pong through them
+            S = nf
+            dev.set_slots(S)
+            for k in range(S):
+                dev.upload(k, [seqs[b][k] for b in range(B)])
+            visit = (list(range(S)) + list(range(S - 2, 0, -1))) * 2
+            visit = visit[:S + 3]
+            seqs = [[seqs[b][k] for k in visit] for b in range(B)]   # the frames in the order they are visited: the oracle's sequence
+            nf = len(visit)
         refs = [pipeline_ref.run_sequence(oracle, seqs[b], cams[b], mp, op, motion_model=motion_model) for b in range(B)]
         ref0 = [pipeline_ref.stereo_frame(oracle, seqs[b][0], cams[b], mp, True, bool(has_lines)) for b in range(B)]
         for k in range(nf):
-            res, counts = dev.push([seqs[b][k] for b in range(B)])
+            if slots:
+                dev.step_dev(visit[k])
+                res, counts = dev.read()
+            else:
+                res, counts = dev.push([seqs[b][k] for b in range(B)])
             for b in range(B):
                 if k == 0:
                     assert counts[b, 0] == len(ref0[b]["P"]) and counts[b, 1] == len(ref0[b]["sP"]), (b, k, "first frame counts")
@@ -145,9 +158,10 @@ def main(argv=None):
             c = cams[b] if isinstance(cams, list) else cams
             seqs.append(synth.make_stereo_sequence(int(rng.integers(1, 1 << 30)), n_frames=nf, n_pts=int(rng.integers(0, pts_hi + 1)),
                                                    n_lines=int(rng.integers(0, lines_hi + 1)), cam=c, **kw))
-        tag = f"seed {args.seed} case {case}: B {B} {preset} mode {mode} lines {has_lines} mm {mm} frames {nf} pts<={pts_hi} lines<={lines_hi} {kw}"
+        use_slots = bool(rng.integers(0, 3) == 0)
+        tag = f"seed {args.seed} case {case}: slots {use_slots} B {B} {preset} mode {mode} lines {has_lines} mm {mm} frames {nf} pts<={pts_hi} lines<={lines_hi} {kw}"
         try:
-            w = run_and_compare(orc, seqs, cams, preset, mode=mode, has_lines=has_lines, motion_model=mm)
+            w = run_and_compare(orc, seqs, cams, preset, mode=mode, has_lines=has_lines, motion_model=mm, slots=use_slots)
             for key, v in w.items():
                 worst[key] = worst.get(key, 0) + v if key.endswith("_pairs") else max(worst.get(key, 0.0), v)
         except AssertionError as e:
