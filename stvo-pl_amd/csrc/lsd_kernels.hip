@@ -18,7 +18,11 @@
 //                        order (lane-parallel products, serial additions through v_readlane), so every rounding is the oracle's
 //   lsd_grow_xcd_kernel  the same search for batches of <= 128 images as an exact speculate / commit protocol over the CUs of one XCD per
 //                        image: a committing wave (LDS bitmap), a dispatcher, a feeder, speculating workgroups (9 ms instead of 63 per image)
-//   lsd_keylines_kernel  the wrapper: checkLineExtremes, length, min_length, KeyLine fields, top-N by response (stable)
+//   lsd_grow_refine_kernel  lsd_refine = 1 (LSD_REFINE_STD): the plain search with refine / reduce_region_radius — a sparse region gives its
+//                        pixels back, is grown again under a tolerance from the angles near its seed, then cut back by radius; one wave per
+//                        image for every batch size (flags that turn off break the strike-off and the speculation of the other forms)
+//   lsd_keylines_kernel  the wrapper: checkLineExtremes, length, min_length, KeyLine fields (numOfPixels = the CLIPPED cv::LineIterator
+//                        count), top-N by response (stable)
 // Byte / integer work except where the source computes in floating point; no fused multiply-adds outside the two of the sine /
 // cosine reduction, which the oracle has too.
 #include <cmath>
