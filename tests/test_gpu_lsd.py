@@ -285,6 +285,17 @@ def test_lsd_refine_std_vs_oracle(hip, oracle, B):
         finally:
             lsd.close()
     assert changed >= 6
+    # density_th = 0: nothing is ever refined — the refinement kernel (one wave per image, plain form) must then give exactly what the
+    # default forms of the search give without refinement (many waves per image here): two different kernels, one answer
+    prm0 = capi.lsd_params(min_length=4.0, nfeatures=0, scale=1.2, refine=1)
+    prm0.density_th = 0.0
+    a = capi.Lsd(hip, B, cols, rows, prm0, max_keylines=2048)
+    b = capi.Lsd(hip, B, cols, rows, capi.lsd_params(min_length=4.0, nfeatures=0, scale=1.2), max_keylines=2048)
+    try:
+        (sa, na), (sb, nb) = a.segments(imgs), b.segments(imgs)
+        assert list(na) == list(nb) and all(np.array_equal(x, y) for x, y in zip(sa, sb)) and sum(na) > 1000
+    finally:
+        a.close(); b.close()
 
 
 def test_lsd_keylines_whose_end_rounds_outside_the_image(hip, oracle):

@@ -126,6 +126,18 @@ def test_detector_core_against_the_numpy_restatement(oracle):
     assert total > 30 and changed >= 1
 
 
+def test_refine_with_density_threshold_zero_is_no_refinement(oracle):
+    """lsd_refine = 1 with density_th = 0: every region is dense enough (density >= 0), so nothing is refined and the segments are those
+    of lsd_refine = 0, bit for bit — at every scale the detector supports."""
+    from stvo_amd import synth
+    img = synth.make_image(77, 640, 360)
+    for scale in (1.2, 1.0, 0.8):
+        o1 = oracle.lsd_opts(scale=scale, refine=1)
+        o1.density_th = 0.0
+        a, b = oracle.lsd_segments(img, oracle.lsd_opts(scale=scale)), oracle.lsd_segments(img, o1)
+        assert a.shape == b.shape and np.array_equal(a, b) and len(a) > 200
+
+
 def test_line_iterator_count_clips_like_cliprect(oracle):
     """KeyLine::numOfPixels = cv::LineIterator(...).count: end points by cvRound, the line clipped to the image, 8-connected.  Against a
     plain statement of the clipping (exact rational intersection of the ideal line with the image's borders, truncated towards zero as
