@@ -14,5 +14,6 @@ o = oracle_lib.load()
 img = synth.make_image(4711, 320, 200, n_rects=70, n_discs=15)
 seg = o.lsd_segments(img, o.lsd_opts())
 kl = o.lsd_detect(img, o.lsd_opts(min_length=0.025 * 200, nfeatures=50))
-np.savez_compressed(os.path.join(HERE, "lsd_oracle_320x200.npz"), img=img, segments=seg, keylines=kl)
-print(len(seg), "segments,", len(kl), "key-lines")
+seg1 = o.lsd_segments(img, o.lsd_opts(refine=1))   # lsd_refine = 1 (round 6)
+np.savez_compressed(os.path.join(HERE, "lsd_oracle_320x200.npz"), img=img, segments=seg, keylines=kl, segments_refine1=seg1)
+print(len(seg), "segments,", len(kl), "key-lines,", len(seg1), "segments with lsd_refine = 1")

@@ -95,6 +95,8 @@ def test_oracle_output_is_pinned(oracle):
     assert np.array_equal(seg, g["segments"])
     kl = oracle.lsd_detect(g["img"], oracle.lsd_opts(min_length=0.025 * 200, nfeatures=50))
     assert kl.tobytes() == g["keylines"].tobytes()
+    seg1 = oracle.lsd_segments(g["img"], oracle.lsd_opts(refine=1))
+    assert np.array_equal(seg1, g["segments_refine1"]) and not np.array_equal(seg1[:len(seg)], seg[:len(seg1)])
 
 
 def test_detector_core_against_the_numpy_restatement(oracle):
